@@ -1,0 +1,394 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz by running the REAL NTPoly
+reference (oracle/_ref/ref_driver, built by oracle/build_ref.py from /root/reference)
+on seeded inputs.  Run in the build container only (needs /root/reference, flang,
+MPICH); the .npz files it writes are committed and are all the GPU box needs.
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+Every .npz holds inputs and reference outputs as NTPoly triplets (1-based col,row,val
+sorted by column then row) plus scalars; `meta` is a JSON string with the parameters.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.trifile import from_scipy, read_tri, write_tri  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+DRV = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+ENV = dict(os.environ, OMP_NUM_THREADS="1", LD_LIBRARY_PATH="/opt/conda/lib")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def run(args, nranks=1):
+    cmd = [DRV] + [str(a) for a in args]
+    if nranks > 1:
+        cmd = [MPIEXEC, "-n", str(nranks)] + cmd
+    r = subprocess.run(cmd, env=ENV, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("ref_driver failed: %s\n%s\n%s" % (cmd, r.stdout, r.stderr))
+    return r.stdout
+
+
+def tri(m):
+    """scipy -> dict of triplet arrays"""
+    c, r, v = from_scipy(sp.csc_matrix(m))
+    return c, r, v
+
+
+def put(d, name, shape, t):
+    d[name + "_shape"] = np.array(shape, dtype=np.int32)
+    d[name + "_col"], d[name + "_row"], d[name + "_val"] = t
+
+
+def rnd(rng, rows, cols, density, complex_=False):
+    m = sp.random(rows, cols, density, random_state=rng, format="csc",
+                  data_rvs=lambda n: rng.uniform(-1, 1, n))
+    if complex_:
+        im = sp.random(rows, cols, density, random_state=rng, format="csc",
+                       data_rvs=lambda n: rng.uniform(-1, 1, n))
+        m = (m + 1j * im).tocsc()
+    m.sort_indices()
+    return m
+
+
+def banded(n, h, complex_=False):
+    """SURVEY 8(d) generator: H_ii = -1 + 2*((i*7919) mod 1000)/1000,
+    H_ij = -0.25*exp(-0.05|i-j|)/|i-j| (1-based i); complex: times exp(i*0.1*(i-j))."""
+    i = np.arange(1, n + 1)
+    diags, offs = [(-1.0 + 2.0 * ((i * 7919) % 1000) / 1000.0)], [0]
+    for d in range(1, h + 1):
+        v = np.full(n - d, -0.25 * np.exp(-0.05 * d) / d)
+        if complex_:
+            diags += [v * np.exp(-1j * 0.1 * d), v * np.exp(1j * 0.1 * d)]
+        else:
+            diags += [v, v]
+        offs += [d, -d]
+    m = sp.diags(diags, offs, shape=(n, n), format="csc", dtype=complex if complex_ else float)
+    m.sort_indices()
+    return m
+
+
+def save(name, d, meta):
+    d["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name, {k: v for k, v in meta.items() if k != "cases"})
+
+
+def local_gemm_case(tmp, A, B, Cin, tA, tB, alpha, beta, thr):
+    write_tri(tmp + "/A.tri", A.shape[0], A.shape[1], *tri(A))
+    write_tri(tmp + "/B.tri", B.shape[0], B.shape[1], *tri(B))
+    cin = "none"
+    if Cin is not None:
+        write_tri(tmp + "/Cin.tri", Cin.shape[0], Cin.shape[1], *tri(Cin))
+        cin = tmp + "/Cin.tri"
+    run(["lgemm", tmp + "/A.tri", tmp + "/B.tri", cin, int(tA), int(tB), repr(alpha), repr(beta),
+         repr(thr), tmp + "/C.tri"])
+    return read_tri(tmp + "/C.tri")
+
+
+def gen_local_gemm(tmp):
+    """test_matrix.py:224-362 (multiply nn/nt/tn/tt/zero) with seeded inputs, plus sparse-branch
+    cases (density < 10 %), alpha/beta/threshold, real + complex."""
+    rng = np.random.default_rng(20240601)
+    cases = []
+    d = {}
+    # the reference suite's own shapes (test_matrix.py:80-88): (rows, cols, density)
+    ref_shapes = [(2, 4, 0.0), (8, 8, 0.0), (2, 2, 1.0), (4, 4, 1.0), (19, 19, 1.0), (4, 2, 1.0),
+                  (2, 4, 1.0), (4, 4, 0.2), (8, 8, 1.0)]
+    specs = []
+    for (r, c, dens) in ref_shapes:
+        for (tA, tB) in [(0, 0), (0, 1), (1, 0), (1, 1)]:
+            specs.append(dict(m=r, k=c, n=r, da=dens, db=dens, tA=tA, tB=tB,
+                              alpha=float(rng.uniform(1, 2)), beta=None, thr=0.0))
+    # genuinely sparse x sparse: the branch the HIP kernel replaces
+    for (m, k, n, da, db) in [(120, 120, 120, 0.04, 0.04), (90, 140, 70, 0.05, 0.06),
+                              (48, 200, 48, 0.03, 0.08), (161, 161, 161, 0.015, 0.09)]:
+        for (tA, tB) in [(0, 0), (0, 1), (1, 0), (1, 1)]:
+            specs.append(dict(m=m, k=k, n=n, da=da, db=db, tA=tA, tB=tB,
+                              alpha=float(rng.uniform(-2, 2)), beta=None, thr=0.0))
+        specs.append(dict(m=m, k=k, n=n, da=da, db=db, tA=0, tB=0, alpha=1.0, beta=None, thr=1e-2))
+        specs.append(dict(m=m, k=k, n=n, da=da, db=db, tA=0, tB=0, alpha=-0.7, beta=0.5, thr=1e-3))
+        specs.append(dict(m=m, k=k, n=n, da=da, db=db, tA=1, tB=1, alpha=2.5, beta=-1.25, thr=0.0))
+    # one sparse operand, one dense (min sparsity decides the branch: GemmMatrix.f90:59)
+    specs.append(dict(m=40, k=40, n=40, da=0.05, db=0.9, tA=0, tB=0, alpha=1.0, beta=None, thr=1e-3))
+    specs.append(dict(m=40, k=40, n=40, da=0.5, db=0.5, tA=0, tB=0, alpha=3.0, beta=None, thr=0.3))
+    for is_c in (False, True):
+        for s in specs:
+            if is_c and (s["m"] > 150 or s["thr"] == 0.3):
+                continue
+            idx = len(cases)
+            sa = (s["k"], s["m"]) if s["tA"] else (s["m"], s["k"])
+            sb = (s["n"], s["k"]) if s["tB"] else (s["k"], s["n"])
+            A = rnd(rng, sa[0], sa[1], s["da"], is_c)
+            B = rnd(rng, sb[0], sb[1], s["db"], is_c)
+            Cin = rnd(rng, s["m"], s["n"], 0.05, is_c) if s["beta"] is not None else None
+            rows, cols, c, r, v = local_gemm_case(tmp, A, B, Cin, s["tA"], s["tB"], s["alpha"],
+                                                  0.0 if s["beta"] is None else s["beta"], s["thr"])
+            pre = "c%03d_" % idx
+            put(d, pre + "A", A.shape, tri(A))
+            put(d, pre + "B", B.shape, tri(B))
+            if Cin is not None:
+                put(d, pre + "Cin", Cin.shape, tri(Cin))
+            put(d, pre + "C", (rows, cols), (c, r, v))
+            cases.append(dict(s, complex=is_c, nnzA=int(A.nnz), nnzB=int(B.nnz), nnzC=int(len(c))))
+    save("local_gemm", d, dict(kind="local_gemm", cases=cases, ncases=len(cases)))
+
+
+def gen_local_increment(tmp):
+    rng = np.random.default_rng(7)
+    d, cases = {}, []
+    for is_c in (False, True):
+        for (m, n, da, db, alpha, thr) in [(50, 50, 0.1, 0.1, 1.0, 0.0), (50, 70, 0.2, 0.05, -2.0, 0.0),
+                                           (120, 120, 0.05, 0.3, 0.37, 0.25), (30, 30, 0.0, 0.2, 2.0, 0.1),
+                                           (30, 30, 0.2, 0.0, 2.0, 0.1), (64, 64, 1.0, 1.0, -1.0, 0.5)]:
+            A = rnd(rng, m, n, da, is_c)
+            B = rnd(rng, m, n, db, is_c)
+            if alpha == -1.0:  # force exact cancellations on the shared pattern
+                B = A.copy()
+            write_tri(tmp + "/A.tri", m, n, *tri(A))
+            write_tri(tmp + "/B.tri", m, n, *tri(B))
+            run(["lincr", tmp + "/A.tri", tmp + "/B.tri", repr(alpha), repr(thr), tmp + "/C.tri"])
+            rows, cols, c, r, v = read_tri(tmp + "/C.tri")
+            pre = "c%03d_" % len(cases)
+            put(d, pre + "A", A.shape, tri(A))
+            put(d, pre + "B", B.shape, tri(B))
+            put(d, pre + "C", (rows, cols), (c, r, v))
+            cases.append(dict(alpha=alpha, thr=thr, complex=is_c))
+    save("local_increment", d, dict(kind="local_increment", cases=cases))
+
+
+def gen_ps(tmp):
+    """test_psmatrixalgebra.py:193-218 (multiply, N=33, densities :103-107) on a 1x1x1 grid with
+    seeded inputs + banded/sparse cases with threshold, alpha, beta; plus increment and scalars."""
+    rng = np.random.default_rng(33)
+    d, cases = {}, []
+
+    def one(A, B, Cin, alpha, beta, thr, tag):
+        n = A.shape[0]
+        write_tri(tmp + "/A.tri", n, n, *tri(A))
+        write_tri(tmp + "/B.tri", n, n, *tri(B))
+        cin = "none"
+        if Cin is not None:
+            write_tri(tmp + "/Cin.tri", n, n, *tri(Cin))
+            cin = tmp + "/Cin.tri"
+        run(["pgemm", 1, 1, 1, tmp + "/A.tri", tmp + "/B.tri", cin, repr(alpha), repr(beta), repr(thr),
+             tmp + "/C.tri"])
+        rows, cols, c, r, v = read_tri(tmp + "/C.tri")
+        pre = "c%03d_" % len(cases)
+        put(d, pre + "A", A.shape, tri(A))
+        put(d, pre + "B", B.shape, tri(B))
+        if Cin is not None:
+            put(d, pre + "Cin", Cin.shape, tri(Cin))
+        put(d, pre + "C", (rows, cols), (c, r, v))
+        dens = min(A.nnz, B.nnz) / float(n * n)
+        cases.append(dict(tag=tag, alpha=alpha, beta=beta, thr=thr, n=n, dense_branch=bool(dens > 0.1),
+                          complexA=bool(np.iscomplexobj(A.data)), complexB=bool(np.iscomplexobj(B.data))))
+
+    for (da, db) in [(1.0, 1.0), (0.2, 0.2), (0.0, 0.0), (1.0, 0.0), (0.0, 1.0)]:
+        for (ca, cb) in [(False, False), (True, True), (True, False), (False, True)]:
+            one(rnd(rng, 33, 33, da, ca), rnd(rng, 33, 33, db, cb), None, 1.0, 0.0, 0.0, "ref_n33")
+    for (ca, cb) in [(False, False), (True, True), (True, False), (False, True)]:
+        A, B = rnd(rng, 129, 129, 0.04, ca), rnd(rng, 129, 129, 0.05, cb)
+        one(A, B, None, 1.0, 0.0, 0.0, "sparse_n129")
+        one(A, B, None, -1.5, 0.0, 1e-2, "sparse_n129_thr")
+        one(A, B, rnd(rng, 129, 129, 0.03, ca or cb), 0.75, -2.0, 1e-3, "sparse_n129_beta")
+    Hb = banded(512, 20)
+    one(Hb, Hb, None, 1.0, 0.0, 0.0, "banded_n512_h20")
+    one(Hb, Hb, None, 1.0, 0.0, 1e-8, "banded_n512_h20_thr1e-8")
+    one(Hb, Hb, None, 1.0, 0.0, 1e-4, "banded_n512_h20_thr1e-4")
+    Hc = banded(384, 12, True)
+    one(Hc, Hc, None, 1.0, 0.0, 1e-6, "cbanded_n384_h12")
+    perm = rng.permutation(512)
+    Hp = sp.csc_matrix(Hb[perm][:, perm])
+    one(Hp, Hp, None, 1.0, 0.0, 1e-8, "banded_n512_h20_permuted")
+    save("ps_gemm", d, dict(kind="ps_gemm", cases=cases))
+
+    # increment + scalars
+    d, cases = {}, []
+    for (ca, cb) in [(False, False), (True, True), (True, False), (False, True)]:
+        for (alpha, thr) in [(1.0, 0.0), (-2.5, 0.2)]:
+            A, B = rnd(rng, 65, 65, 0.2, ca), rnd(rng, 65, 65, 0.15, cb)
+            write_tri(tmp + "/A.tri", 65, 65, *tri(A))
+            write_tri(tmp + "/B.tri", 65, 65, *tri(B))
+            run(["pincr", 1, 1, 1, tmp + "/A.tri", tmp + "/B.tri", repr(alpha), repr(thr), tmp + "/C.tri"])
+            rows, cols, c, r, v = read_tri(tmp + "/C.tri")
+            pre = "c%03d_" % len(cases)
+            put(d, pre + "A", A.shape, tri(A))
+            put(d, pre + "B", B.shape, tri(B))
+            put(d, pre + "C", (rows, cols), (c, r, v))
+            cases.append(dict(alpha=alpha, thr=thr))
+    save("ps_increment", d, dict(kind="ps_increment", cases=cases))
+
+    d, cases = {}, []
+    mats = [(rnd(rng, 65, 65, 0.2), rnd(rng, 65, 65, 0.3)), (banded(512, 20), banded(512, 7)),
+            (rnd(rng, 48, 48, 0.3, True), rnd(rng, 48, 48, 0.3, True)),
+            (banded(200, 9, True), banded(200, 14, True))]
+    for (A, B) in mats:
+        n = A.shape[0]
+        write_tri(tmp + "/A.tri", n, n, *tri(A))
+        write_tri(tmp + "/B.tri", n, n, *tri(B))
+        run(["pscalars", 1, 1, 1, tmp + "/A.tri", tmp + "/B.tri", tmp + "/s.txt"])
+        sc = {k: float(v) for k, v in (ln.split() for ln in open(tmp + "/s.txt"))}
+        pre = "c%03d_" % len(cases)
+        put(d, pre + "A", A.shape, tri(A))
+        put(d, pre + "B", B.shape, tri(B))
+        cases.append(sc)
+    save("ps_scalars", d, dict(kind="ps_scalars", cases=cases))
+
+
+def parse_log(path):
+    """pull the per-iteration values out of the reference's YAML-ish log"""
+    conv, energy = [], []
+    total = None
+    for ln in open(path):
+        m = re.match(r"\s*- Convergence:\s*(\S+)", ln)
+        if m:
+            conv.append(float(m.group(1)))
+        m = re.match(r"\s*Energy Value:\s*(\S+)", ln)
+        if m:
+            energy.append(float(m.group(1)))
+        m = re.match(r"\s*Total Iterations:\s*(\S+)", ln)
+        if m:
+            total = int(m.group(1))
+    return conv, energy, total
+
+
+def spd_from(rng, n, density):
+    """symmetric, diagonally dominant (so Gershgorin-scaled iterations converge), sparse"""
+    m = rnd(rng, n, n, density)
+    m = (m + m.T) * 0.5
+    m = m + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0)
+    return sp.csc_matrix(m)
+
+
+def gen_solvers(tmp):
+    rng = np.random.default_rng(4242)
+    d, cases = {}, []
+
+    def solve(solver, H, ISQ, nel, thr, conv, maxit, monitor, tag):
+        n = H.shape[0]
+        write_tri(tmp + "/H.tri", n, n, *tri(H))
+        isq = "none"
+        if isinstance(ISQ, str):
+            isq = ISQ
+        elif ISQ is not None:
+            write_tri(tmp + "/ISQ.tri", n, n, *tri(ISQ))
+            isq = tmp + "/ISQ.tri"
+        run(["solve", 1, 1, 1, solver, tmp + "/H.tri", isq, repr(nel), repr(thr), repr(conv), maxit,
+             int(monitor), tmp + "/K.tri", tmp + "/log.yaml", tmp + "/s.txt"])
+        rows, cols, c, r, v = read_tri(tmp + "/K.tri")
+        sc = {k: float(x) for k, x in (ln.split() for ln in open(tmp + "/s.txt"))}
+        lc, le, total = parse_log(tmp + "/log.yaml")
+        pre = "c%03d_" % len(cases)
+        put(d, pre + "H", H.shape, tri(H))
+        if ISQ is not None and not isinstance(ISQ, str):
+            put(d, pre + "ISQ", ISQ.shape, tri(ISQ))
+        put(d, pre + "K", (rows, cols), (c, r, v))
+        d[pre + "log_convergence"] = np.array(lc)
+        d[pre + "log_energy"] = np.array(le)
+        cases.append(dict(tag=tag, solver=solver, nel=nel, thr=thr, conv=conv, maxit=maxit,
+                          monitor=bool(monitor), isq=("file" if pre + "ISQ_col" in d else isq),
+                          energy=sc["energy"], mu=sc["mu"], nnz=int(sc["nnz"]),
+                          total_iterations_logged=total))
+        return sp.csc_matrix((v, (r - 1, c - 1)), shape=(rows, cols))
+
+    # --- the reference's own shipped fixture: Examples/PremadeMatrix -------------
+    from scipy.io import mmread
+    ex = "/root/reference/Examples/PremadeMatrix/"
+    Hm, Sm = sp.csc_matrix(mmread(ex + "Hamiltonian.mtx")), sp.csc_matrix(mmread(ex + "Overlap.mtx"))
+    Dref = sp.csc_matrix(mmread(ex + "Density-Reference.mtx"))
+    ISQ = solve("isq", Sm, None, 0.0, 1e-6, 1e-3, 1000, 1, "premade_isq")
+    solve("trs2", Hm, ISQ, 5.0, 1e-6, 1e-5, 1000, 1, "premade_trs2_nel5")
+    put(d, "premade_density_reference", Dref.shape, tri(Dref))
+
+    # --- banded synthetic (BASELINE.md golden scalars use the same generator) ----------------
+    Hb = banded(512, 16)
+    solve("trs2", Hb, "identity", 256.0, 1e-8, 1e-30, 8, 0, "banded512_trs2_8it")
+    solve("trs2", Hb, "identity", 256.0, 1e-8, 1e-6, 1000, 1, "banded512_trs2_conv")
+    solve("trs2", banded(96, 6), "identity", 40.0, 0.0, 1e-8, 1000, 1, "banded96_trs2_thr0")
+    solve("trs4", Hb, "identity", 256.0, 1e-8, 1e-6, 1000, 1, "banded512_trs4_conv")
+    Hc = banded(256, 10, True)
+    solve("trs2", Hc, "identity", 128.0, 1e-8, 1e-6, 1000, 1, "cbanded256_trs2_conv")
+
+    # --- random symmetric, non-trivial overlap (test_chemistry.py:193-233 style) --------------
+    n = 64
+    Hr = rnd(rng, n, n, 0.08)
+    Hr = sp.csc_matrix((Hr + Hr.T) * 0.5 + sp.diags(np.linspace(-1, 1, n)))
+    Sr = spd_from(rng, n, 0.06)
+    ISQr = solve("isq", Sr, None, 0.0, 1e-9, 1e-8, 1000, 1, "rand64_isq")
+    solve("trs2", Hr, ISQr, 20.0, 1e-9, 1e-8, 1000, 1, "rand64_trs2")
+    solve("trs4", Hr, ISQr, 20.0, 1e-9, 1e-8, 1000, 1, "rand64_trs4")
+
+    # --- matrix functions (test_solvers.py:139-162,211-234,259-281,364-386 style) -------------
+    Sp = spd_from(rng, 96, 0.05)
+    solve("invert", Sp, None, 0.0, 1e-10, 1e-8, 1000, 1, "spd96_invert")
+    solve("isq", Sp, None, 0.0, 1e-10, 1e-8, 1000, 1, "spd96_isq")
+    solve("sqrt", Sp, None, 0.0, 1e-10, 1e-8, 1000, 1, "spd96_sqrt")
+    Sg = rnd(rng, 96, 96, 0.05)
+    Sg = sp.csc_matrix((Sg + Sg.T) * 0.5 + sp.diags(np.where(np.arange(96) % 2 == 0, 2.0, -2.0)))
+    solve("sign", Sg, None, 0.0, 1e-10, 1e-8, 1000, 1, "sym96_sign")
+    solve("sign", Sg, None, 0.0, 1e-10, 1e-8, 1000, 0, "sym96_sign_nomonitor")
+    Hs = sp.csc_matrix(banded(256, 10) + 2.0 * sp.identity(256))
+    solve("isq", Hs, None, 0.0, 1e-8, 1e-6, 1000, 1, "banded256_shift_isq")
+    solve("invert", Hs, None, 0.0, 1e-8, 1e-6, 1000, 1, "banded256_shift_invert")
+    Hcs = sp.csc_matrix(banded(128, 8, True) + 2.0 * sp.identity(128))
+    solve("isq", Hcs, None, 0.0, 1e-8, 1e-6, 1000, 1, "cbanded128_shift_isq")
+    solve("sign", sp.csc_matrix(banded(128, 8, True)), None, 0.0, 1e-8, 1e-6, 1000, 1,
+          "cbanded128_sign")
+    save("solvers", d, dict(kind="solvers", cases=cases))
+
+
+def gen_multirank(tmp):
+    """Same product on 1, 4 (2x2x1) and 8 (2x2x2) reference ranks: pins that values do not
+    depend on the grid when slices == 1 and records the slices>1 behaviour."""
+    d, cases = {}, []
+    Hb = banded(256, 12)
+    n = 256
+    write_tri(tmp + "/A.tri", n, n, *tri(Hb))
+    put(d, "A", Hb.shape, tri(Hb))
+    for (pr, pc, ps) in [(1, 1, 1), (2, 2, 1), (1, 4, 1), (2, 2, 2)]:
+        nr = pr * pc * ps
+        run(["pgemm", pr, pc, ps, tmp + "/A.tri", tmp + "/A.tri", "none", "1.0", "0.0", "1e-6",
+             tmp + "/C.tri"], nranks=nr)
+        parts = []
+        for rk in range(nr):
+            fn = tmp + "/C.tri" + ("" if nr == 1 else ".%d" % rk)
+            parts.append(read_tri(fn))
+        c = np.concatenate([p[2] for p in parts])
+        r = np.concatenate([p[3] for p in parts])
+        v = np.concatenate([p[4] for p in parts])
+        # slices replicate the matrix: keep unique (col,row)
+        key = c.astype(np.int64) * (n + 1) + r
+        _, first = np.unique(key, return_index=True)
+        c, r, v = c[first], r[first], v[first]
+        put(d, "C_%d%d%d" % (pr, pc, ps), (n, n), (c, r, v))
+        cases.append(dict(grid=[pr, pc, ps], nnz=int(len(c))))
+    save("ps_gemm_grids", d, dict(kind="ps_gemm_grids", thr=1e-6, cases=cases))
+
+
+def main():
+    if not os.path.exists(DRV):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import build_ref
+        if not build_ref.build():
+            raise SystemExit("reference not buildable here")
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_local_gemm(tmp)
+        gen_local_increment(tmp)
+        gen_ps(tmp)
+        gen_solvers(tmp)
+        gen_multirank(tmp)
+
+
+if __name__ == "__main__":
+    main()
