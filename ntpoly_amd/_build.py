@@ -1,0 +1,70 @@
+"""Build the engine's shared library (HIP kernels + C++ host + C ABI) for gfx950 with hipcc.
+
+    python -m ntpoly_amd._build        # -> ntpoly_amd/libntpoly_amd.so (in-tree, git-ignored)
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the numerical contract
+(DESIGN.md "Parity"): products and sums are rounded separately, as the reference does.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libntpoly_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["kernels.hip", "common.cpp", "comm.cpp", "psmatrix.cpp", "solvers.cpp", "io.cpp", "wrp.cpp"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in os.listdir(CSRC):
+        if os.path.getmtime(os.path.join(CSRC, f)) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        deps = headers + [src]
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(map(os.path.getmtime, deps)):
+            continue
+        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write("---- %s\n%s\n" % (s, out))
+            failed = True
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [
+        "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

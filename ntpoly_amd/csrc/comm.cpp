@@ -1,0 +1,167 @@
+// RCCL plumbing: one communicator over all ranks (one process per MI355X, xGMI links).
+// Replaces the reference's MPI communicators (ProcessGridModule.F90:186-262) for the calls on
+// the hot path.  The unique id is exchanged by the launcher
+// (bench.py / tests use torch.distributed for that) and handed in through comm_init().
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "engine.hpp"
+
+namespace ntp {
+
+#define NCCL_CHECK(expr)                                                                     \
+  do {                                                                                       \
+    ncclResult_t r_ = (expr);                                                                \
+    if (r_ != ncclSuccess)                                                                   \
+      ::ntp::fatal(__FILE__, __LINE__, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+  } while (0)
+
+Comm& world() {
+  static Comm c;
+  return c;
+}
+
+static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+
+void comm_get_unique_id(char out[128]) {
+  ncclUniqueId id;
+  NCCL_CHECK(ncclGetUniqueId(&id));
+  std::memcpy(out, &id, sizeof(id));
+}
+
+void comm_init(const char idbytes[128], int rank, int nranks) {
+  Comm& c = world();
+  if (c.nccl) comm_finalize();
+  c.rank = rank;
+  c.nranks = nranks;
+  if (nranks <= 1) {
+    c.rank = 0;
+    c.nranks = 1;
+    return;
+  }
+  ensure_init();
+  ncclUniqueId id;
+  std::memcpy(&id, idbytes, sizeof(id));
+  ncclComm_t comm;
+  NCCL_CHECK(ncclCommInitRank(&comm, nranks, id, rank));
+  c.nccl = comm;
+}
+
+void comm_finalize() {
+  Comm& c = world();
+  if (c.nccl) {
+    sync_stream();
+    (void)ncclCommDestroy(static_cast<ncclComm_t>(c.nccl));
+    c.nccl = nullptr;
+  }
+  c.rank = 0;
+  c.nranks = 1;
+}
+
+namespace {
+void allreduce_f64(double* host_vals, int n, ncclRedOp_t op) {
+  Comm& c = world();
+  if (!c.active() || n == 0) return;
+  DevBuf<double> d((size_t)n);
+  d.upload(host_vals, (size_t)n);
+  NCCL_CHECK(ncclAllReduce(d.p, d.p, (size_t)n, ncclDouble, op, static_cast<ncclComm_t>(c.nccl), stream()));
+  d.download(host_vals, (size_t)n);
+}
+}  // namespace
+
+void comm_allreduce_sum(double* v, int n) { allreduce_f64(v, n, ncclSum); }
+void comm_allreduce_min(double* v, int n) { allreduce_f64(v, n, ncclMin); }
+void comm_allreduce_max(double* v, int n) { allreduce_f64(v, n, ncclMax); }
+
+void comm_allreduce_sum_i64(int64_t* v, int n) {
+  Comm& c = world();
+  if (!c.active() || n == 0) return;
+  DevBuf<int64_t> d((size_t)n);
+  d.upload(v, (size_t)n);
+  NCCL_CHECK(ncclAllReduce(d.p, d.p, (size_t)n, ncclInt64, ncclSum, static_cast<ncclComm_t>(c.nccl), stream()));
+  d.download(v, (size_t)n);
+}
+
+void comm_bcast_i32(int32_t* v, int n, int root) {
+  Comm& c = world();
+  if (!c.active() || n == 0) return;
+  DevBuf<int32_t> d((size_t)n);
+  d.upload(v, (size_t)n);
+  NCCL_CHECK(ncclBroadcast(d.p, d.p, (size_t)n, ncclInt32, root, static_cast<ncclComm_t>(c.nccl), stream()));
+  d.download(v, (size_t)n);
+}
+
+void comm_barrier() {
+  double x = 0;
+  comm_allreduce_sum(&x, 1);
+}
+
+// Panel all-gather (the reference's ReduceAndComposeMatrix{Sizes,Data,Cleanup}: M1-M3 of SURVEY 2c):
+// every rank contributes its column panel; every rank receives all panels and concatenates them
+// into the full matrix.  RCCL has no variable-count all-gather, so after the fixed-size size
+// exchange each panel travels as a broadcast from its owner, all posted inside one group so the
+// point-to-point xGMI links are driven concurrently.
+DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths) {
+  Comm& c = world();
+  if (!c.active()) return loc.clone();
+  ncclComm_t comm = static_cast<ncclComm_t>(c.nccl);
+  const int P = c.nranks;
+  if ((int)widths.size() != P || widths[(size_t)c.rank] != loc.cols) NTP_FATAL("gather_panels: inconsistent panel widths");
+  // 1. sizes (M1)
+  DevBuf<int64_t> d_sizes((size_t)P);
+  int64_t mine = loc.nnz;
+  HIP_CHECK(hipMemcpyAsync(d_sizes.p + c.rank, &mine, sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+  NCCL_CHECK(ncclAllGather(d_sizes.p + c.rank, d_sizes.p, 1, ncclInt64, comm, stream()));
+  std::vector<int64_t> sizes((size_t)P);
+  d_sizes.download(sizes.data(), (size_t)P);
+  std::vector<int64_t> zoff((size_t)P + 1, 0), coff((size_t)P + 1, 0);
+  for (int r = 0; r < P; ++r) {
+    zoff[(size_t)r + 1] = zoff[(size_t)r] + sizes[(size_t)r];
+    coff[(size_t)r + 1] = coff[(size_t)r] + widths[(size_t)r];
+  }
+  if (coff[(size_t)P] > 2147483647LL) NTP_FATAL("gather_panels: too many columns");
+  // 2. data (M2, M3): column offsets go to a staging area (they need a per-panel shift), indices
+  //    and values land directly in their final place
+  DevMat full;
+  full.alloc(loc.rows, (int32_t)coff[(size_t)P], loc.cplx, zoff[(size_t)P]);
+  DevBuf<int64_t> stage((size_t)coff[(size_t)P] + (size_t)P);
+  const size_t w = loc.wval();
+  NCCL_CHECK(ncclGroupStart());
+  for (int r = 0; r < P; ++r) {
+    const size_t ncol = (size_t)widths[(size_t)r];
+    int64_t* st = stage.p + (size_t)coff[(size_t)r] + (size_t)r;
+    NCCL_CHECK(ncclBroadcast(loc.outer.p, st, ncol + 1, ncclInt64, r, comm, stream()));
+    if (sizes[(size_t)r] > 0) {
+      NCCL_CHECK(ncclBroadcast(loc.inner.p, full.inner.p + zoff[(size_t)r], (size_t)sizes[(size_t)r], ncclInt32, r,
+                               comm, stream()));
+      NCCL_CHECK(ncclBroadcast(loc.val.p, full.val.p + zoff[(size_t)r] * (int64_t)w, (size_t)sizes[(size_t)r] * w,
+                               ncclDouble, r, comm, stream()));
+    }
+  }
+  NCCL_CHECK(ncclGroupEnd());
+  // 3. cleanup: every panel's offsets are shifted by the number of entries before it
+  //    (ReduceAndComposeMatrixCleanup.f90:6-13); the last offset of panel r is the first of panel r+1
+  for (int r = 0; r < P; ++r) {
+    const int ncol = widths[(size_t)r];
+    if (ncol > 0)
+      copy_shift_i64(stage.p + (size_t)coff[(size_t)r] + (size_t)r, full.outer.p + coff[(size_t)r], ncol, zoff[(size_t)r]);
+  }
+  HIP_CHECK(hipMemcpyAsync(full.outer.p + coff[(size_t)P], &zoff[(size_t)P], sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+  sync_stream();
+  return full;
+}
+
+DevMat ps_gather_full(const PSMatrix& m) {
+  if (!world().active()) return m.loc.clone();
+  const int P = world().nranks;
+  std::vector<int32_t> widths((size_t)P);
+  for (int r = 0; r < P; ++r) {
+    int32_t a, b;
+    panel_range(m.dim, P, r, &a, &b);
+    widths[(size_t)r] = b - a;
+  }
+  return gather_panels(m.loc, widths);
+}
+
+}  // namespace ntp

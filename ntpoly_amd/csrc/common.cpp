@@ -1,0 +1,150 @@
+#include "common.hpp"
+
+#include <cstring>
+#include <mutex>
+
+namespace ntp {
+
+void fatal(const char* file, int line, const std::string& msg) {
+  std::fprintf(stderr, "[ntpoly_amd] FATAL %s:%d: %s\n", file, line, msg.c_str());
+  std::fflush(stderr);
+  std::abort();
+}
+
+Context& ctx() {
+  static Context c;
+  return c;
+}
+
+void ensure_init() {
+  Context& c = ctx();
+  if (c.initialised) return;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    NTP_FATAL("no HIP device visible: the ntpoly_amd engine has no CPU fallback");
+  int local_rank = 0;
+  if (const char* lr = std::getenv("LOCAL_RANK")) local_rank = std::atoi(lr);
+  c.device = local_rank % ndev;
+  HIP_CHECK(hipSetDevice(c.device));
+  HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, c.device));
+  c.num_cus = prop.multiProcessorCount;
+  c.initialised = true;
+}
+
+void sync_stream() { HIP_CHECK(hipStreamSynchronize(ctx().stream)); }
+
+// ---------------------------------------------------------------- caching allocator
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::map<size_t, std::vector<void*>> free_lists;
+  std::map<void*, size_t> live;
+  size_t in_use = 0, cached = 0;
+};
+Pool& pool() {
+  static Pool p;
+  return p;
+}
+size_t bucket(size_t bytes) {
+  if (bytes < 512) return 512;
+  const size_t big = (size_t)64 << 20;
+  if (bytes > big) return (bytes + big - 1) / big * big;
+  size_t b = 512;
+  while (b < bytes) b <<= 1;
+  return b;
+}
+}  // namespace
+
+void* dev_alloc(size_t bytes) {
+  ensure_init();
+  const size_t b = bucket(bytes);
+  Pool& P = pool();
+  std::lock_guard<std::mutex> g(P.mu);
+  auto it = P.free_lists.find(b);
+  void* p = nullptr;
+  if (it != P.free_lists.end() && !it->second.empty()) {
+    p = it->second.back();
+    it->second.pop_back();
+    P.cached -= b;
+  } else {
+    hipError_t e = hipMalloc(&p, b);
+    if (e != hipSuccess) {
+      // give cached blocks back to the driver and retry once
+      (void)hipGetLastError();
+      for (auto& kv : P.free_lists) {
+        for (void* q : kv.second) (void)hipFree(q);
+        kv.second.clear();
+      }
+      P.cached = 0;
+      HIP_CHECK(hipMalloc(&p, b));
+    }
+  }
+  P.live[p] = b;
+  P.in_use += b;
+  return p;
+}
+
+void dev_free(void* p) {
+  if (!p) return;
+  Pool& P = pool();
+  std::lock_guard<std::mutex> g(P.mu);
+  auto it = P.live.find(p);
+  if (it == P.live.end()) NTP_FATAL("dev_free of an unknown pointer");
+  const size_t b = it->second;
+  P.live.erase(it);
+  P.in_use -= b;
+  P.free_lists[b].push_back(p);
+  P.cached += b;
+}
+
+void dev_release_cache() {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> g(P.mu);
+  if (ctx().initialised) HIP_CHECK(hipStreamSynchronize(ctx().stream));
+  for (auto& kv : P.free_lists) {
+    for (void* q : kv.second) (void)hipFree(q);
+    kv.second.clear();
+  }
+  P.cached = 0;
+}
+size_t dev_bytes_in_use() { return pool().in_use; }
+size_t dev_bytes_cached() { return pool().cached; }
+
+// ---------------------------------------------------------------- DevMat
+void DevMat::reset_empty(int32_t r, int32_t c, bool z) {
+  rows = r;
+  cols = c;
+  cplx = z;
+  nnz = 0;
+  outer.alloc((size_t)c + 1);
+  outer.zero();
+  inner.alloc(0);
+  val.alloc(0);
+}
+
+void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
+  rows = r;
+  cols = c;
+  cplx = z;
+  nnz = nz;
+  outer.alloc((size_t)c + 1);
+  inner.alloc((size_t)nz);
+  val.alloc((size_t)nz * (z ? 2 : 1));
+}
+
+DevMat DevMat::clone() const {
+  DevMat R;
+  R.alloc(rows, cols, cplx, nnz);
+  HIP_CHECK(hipMemcpyAsync(R.outer.p, outer.p, sizeof(int64_t) * ((size_t)cols + 1), hipMemcpyDeviceToDevice, stream()));
+  if (nnz) {
+    HIP_CHECK(hipMemcpyAsync(R.inner.p, inner.p, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(R.val.p, val.p, sizeof(double) * (size_t)nnz * wval(), hipMemcpyDeviceToDevice, stream()));
+  }
+  return R;
+}
+
+}  // namespace ntp

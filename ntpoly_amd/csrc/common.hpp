@@ -1,0 +1,118 @@
+// Common host-side infrastructure of the MI355X engine: error handling, the HIP stream,
+// a stream-ordered caching device allocator and the device-resident local matrix type.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace ntp {
+
+// The reference has no status codes: fatal paths print and MPI_Abort
+// (ErrorModule.F90:193-205).  Same contract here.
+[[noreturn]] void fatal(const char* file, int line, const std::string& msg);
+#define NTP_FATAL(msg) ::ntp::fatal(__FILE__, __LINE__, (msg))
+#define HIP_CHECK(expr)                                                              \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess)                                                            \
+      ::ntp::fatal(__FILE__, __LINE__, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------
+// Engine context: one process drives one GPU (LOCAL_RANK), one compute stream and one
+// communication stream.
+struct Context {
+  int device = 0;
+  hipStream_t stream = nullptr;       // all kernels
+  hipStream_t comm_stream = nullptr;  // RCCL collectives (overlap with compute)
+  int num_cus = 256;
+  bool initialised = false;
+};
+Context& ctx();
+void ensure_init();  // fails loudly when no GPU is present
+inline hipStream_t stream() { return ctx().stream; }
+void sync_stream();
+
+// Caching allocator: sizes are rounded up to a small set of buckets and recycled.  All
+// device work of the engine is ordered on ctx().stream, so a block freed by the host can be
+// handed out again immediately (stream order protects it).
+void* dev_alloc(size_t bytes);
+void dev_free(void* p);
+void dev_release_cache();
+size_t dev_bytes_in_use();
+size_t dev_bytes_cached();
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  explicit DevBuf(size_t count) { alloc(count); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p; n = o.n; o.p = nullptr; o.n = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    p = static_cast<T*>(dev_alloc((count ? count : 1) * sizeof(T)));
+  }
+  void release() {
+    if (p) dev_free(p);
+    p = nullptr; n = 0;
+  }
+  void upload(const T* host, size_t count) {
+    if (count) HIP_CHECK(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, stream()));
+  }
+  void download(T* host, size_t count) const {
+    if (count) HIP_CHECK(hipMemcpyAsync(host, p, count * sizeof(T), hipMemcpyDeviceToHost, stream()));
+    sync_stream();
+  }
+  void zero() { if (n) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), stream())); }
+};
+
+// ---------------------------------------------------------------------------------
+// Local sparse matrix resident in HBM.  Same layout as the reference's Matrix_lsr /
+// Matrix_lsc (SMatrixModule.F90:15-30): column-compressed, `outer` = cols+1 offsets (0-based,
+// 64-bit here), `inner` = row ids ascending within a column (0-based here), `val` = nnz doubles
+// (real) or 2*nnz doubles (complex, interleaved re/im).
+struct DevMat {
+  int32_t rows = 0, cols = 0;
+  bool cplx = false;
+  int64_t nnz = 0;
+  DevBuf<int64_t> outer;
+  DevBuf<int32_t> inner;
+  DevBuf<double> val;
+
+  DevMat() = default;
+  DevMat(int32_t r, int32_t c, bool z) { reset_empty(r, c, z); }
+  DevMat(DevMat&&) noexcept = default;
+  DevMat& operator=(DevMat&&) noexcept = default;
+  void reset_empty(int32_t r, int32_t c, bool z);  // all-zero matrix of that shape
+  void alloc(int32_t r, int32_t c, bool z, int64_t nz);
+  DevMat clone() const;
+  size_t wval() const { return cplx ? 2 : 1; }
+};
+
+// host-side triplets, NTPoly convention: 1-based (index_column, index_row, value)
+struct HostTriplets {
+  std::vector<int32_t> col, row;
+  std::vector<double> val;  // nnz or 2*nnz
+  bool cplx = false;
+  size_t size() const { return col.size(); }
+};
+
+}  // namespace ntp

@@ -1,0 +1,166 @@
+// Host-side engine: process grid, distributed matrix (column panels, one per GPU),
+// distributed algebra, solver parameters, convergence monitor, logger and the solvers.
+// Mirrors the reference's module API (names cite the Fortran modules) in C++ because the
+// reference host is compiled code; the C ABI in wrp.cpp is the reference's own *_wrp surface.
+#pragma once
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace ntp {
+
+// ------------------------------------------------------------------ communication
+// One RCCL communicator over all ranks (one process per GPU).  nranks == 1 needs no RCCL.
+struct Comm {
+  int rank = 0, nranks = 1;
+  void* nccl = nullptr;  // ncclComm_t
+  bool active() const { return nranks > 1; }
+};
+Comm& world();
+void comm_get_unique_id(char out[128]);
+void comm_init(const char id[128], int rank, int nranks);
+void comm_finalize();
+void comm_allreduce_sum(double* host_vals, int n);
+void comm_allreduce_min(double* host_vals, int n);
+void comm_allreduce_max(double* host_vals, int n);
+void comm_allreduce_sum_i64(int64_t* host_vals, int n);
+void comm_bcast_i32(int32_t* host_vals, int n, int root);
+void comm_barrier();
+
+// ProcessGrid_t (ProcessGridModule.F90:15-56).  The reference's rows x columns x slices shape is
+// kept for the API (getters, consistency check); the data decomposition of this engine is always
+// 1-D column panels over the global rank (DESIGN.md "Multi-GPU").
+struct ProcessGrid {
+  int num_rows = 1, num_cols = 1, num_slices = 1;
+  int my_row = 0, my_col = 0, my_slice = 0;
+  int global_rank = 0, total = 1;
+  bool is_root() const { return global_rank == 0; }
+};
+ProcessGrid& global_grid();
+bool global_grid_constructed();
+void construct_grid(ProcessGrid& g, int rows, int cols, int slices);
+void construct_grid_default(ProcessGrid& g, int slices /* <=0: choose */);
+void write_grid_info(const ProcessGrid& g);
+
+// ------------------------------------------------------------------ distributed matrix
+// Matrix_ps (PSMatrixModule.F90:33-51): rank r owns the column panel [c0, c1) (all rows).
+struct PSMatrix {
+  const ProcessGrid* grid = nullptr;
+  int32_t dim = 0;  // actual == logical dimension (no padding needed for 1-D panels)
+  bool cplx = false;
+  int32_t c0 = 0, c1 = 0;
+  DevMat loc;       // dim x (c1-c0)
+  bool constructed() const { return grid != nullptr; }
+};
+void panel_range(int32_t dim, int nranks, int rank, int32_t* c0, int32_t* c1);
+void ps_construct_empty(PSMatrix& m, int32_t dim, const ProcessGrid* g, bool cplx);
+void ps_construct_like(PSMatrix& m, const PSMatrix& ref);
+void ps_copy(const PSMatrix& a, PSMatrix& b);
+void ps_fill_identity(PSMatrix& m);
+void ps_fill_permutation(PSMatrix& m, const std::vector<int32_t>& lookup /*1-based*/, bool rows);
+void ps_fill_from_triplets(PSMatrix& m, const HostTriplets& t);
+void ps_get_triplets(const PSMatrix& m, HostTriplets& t);
+int64_t ps_size(const PSMatrix& m);
+void ps_to_complex(const PSMatrix& a, PSMatrix& out);
+void ps_to_real(const PSMatrix& a, PSMatrix& out);
+DevMat ps_gather_full(const PSMatrix& m);  // every rank gets the whole matrix (dim x dim)
+// concatenate the column panels of all ranks (widths[r] = columns held by rank r, known to all)
+DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths);
+
+// PSMatrixAlgebraModule
+void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha, double beta, double threshold);
+void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold);
+void ps_scale(PSMatrix& A, double c);
+void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C);
+void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]);
+double ps_trace(const PSMatrix& A);
+double ps_norm(const PSMatrix& A);
+double ps_sigma(const PSMatrix& A);
+void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max);
+void ps_transpose(const PSMatrix& A, PSMatrix& AT);
+void ps_conjugate(PSMatrix& A);
+bool ps_is_identity(const PSMatrix& A);
+double ps_measure_asymmetry(const PSMatrix& A);
+void ps_symmetrize(PSMatrix& A);
+void ps_similarity(const PSMatrix& A, const PSMatrix& P, const PSMatrix& PInv, PSMatrix& Res, double threshold);
+// LoadBalancerModule
+struct Permutation {
+  std::vector<int32_t> index_lookup, reverse_index_lookup;  // 1-based values
+};
+void permutation_default(Permutation& p, int n);
+void permutation_reverse(Permutation& p, int n);
+void permutation_random(Permutation& p, int n);
+void ps_permute(const PSMatrix& in, PSMatrix& out, const Permutation& perm, bool undo);
+
+// ------------------------------------------------------------------ logger (LoggingModule.F90)
+struct Logger {
+  bool active = false;
+  int level = 0;
+  FILE* out = stdout;
+  bool owns_file = false;
+};
+Logger& logger();
+void log_activate(bool start_document, const char* file_name);
+void log_deactivate();
+void log_enter();
+void log_exit();
+void log_header(const char* h);
+void log_element(const char* key, double v);
+void log_element(const char* key, int v);
+void log_element(const char* key, const char* v);
+void log_element(const char* key, bool v);
+void log_list_element(const char* key, double v);
+void log_list_element(const char* key);
+
+// ------------------------------------------------------------------ solver parameters / monitor
+struct Monitor {  // ConvergenceMonitorModule.F90:14-27
+  double win_short[3] = {0, 0, 0}, win_long[6] = {0, 0, 0, 0, 0, 0};
+  int nval = 0;
+  double loose_cutoff = 1e-2, tight_cutoff = 1e-8;
+  bool automatic = true;
+};
+void monitor_construct(Monitor& m, bool automatic, double tight_cutoff);
+void monitor_append(Monitor& m, double v);
+bool monitor_converged(const Monitor& m, bool be_verbose);
+
+struct SolverParameters {  // SolverParametersModule.F90:14-33, defaults :48-50
+  double converge_diff = 1e-6;
+  int max_iterations = 1000;
+  double threshold = 0.0;
+  bool be_verbose = false;
+  bool do_load_balancing = false;
+  Permutation balance_permutation;
+  double step_thresh = 1e-2;
+  bool monitor_convergence = true;
+};
+void print_parameters(const SolverParameters& p);
+void print_matrix_information(const PSMatrix& m);
+
+// per-iteration record of the last solver call (tests/bench read it through the C ABI extension)
+struct SolverTrace {
+  std::vector<double> value, energy, sigma;
+  std::vector<int64_t> nnz;
+  int iterations = 0;
+  double setup_ms = 0, loop_ms = 0;
+};
+SolverTrace& last_trace();
+
+// ------------------------------------------------------------------ solvers
+void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy, double* mu,
+                 const SolverParameters& p);
+void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy, double* mu,
+                 const SolverParameters& p);
+void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy, double* mu,
+               const SolverParameters& p);
+void solver_hpcp(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy, double* mu,
+                 const SolverParameters& p);
+void solver_sign(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p);
+void solver_polar(const PSMatrix& A, PSMatrix& U, PSMatrix* Hm, const SolverParameters& p);
+void solver_invert(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p);
+void solver_pseudoinverse(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p);
+void solver_square_root(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p, bool inverse, int order);
+
+}  // namespace ntp

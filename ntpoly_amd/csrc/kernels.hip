@@ -1,0 +1,1551 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the NTPoly hot path.
+//
+// Numerical contract (DESIGN.md "Parity"): every C(i,j) of the SpGEMM is accumulated in
+// ascending-k order with an UNFUSED multiply and add (two roundings), exactly as the reference's
+// MultiplyBlock loop does on baseline x86-64 (sparse_includes/MultiplyBlock.f90:9-36), and is
+// pruned with PruneList's strict `|alpha*v| > threshold` (sparse_includes/PruneList.f90:22).
+// One wavefront owns one output column; lanes stride over the entries of one operand column at a
+// time, so no two lanes ever touch the same accumulator slot inside one step and no atomics are
+// needed.  The result is bit-identical to the reference's sparse branch and independent of the
+// GPU count.  This file must be compiled with -ffp-contract=off.
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <numeric>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace ntp {
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int NXCD = 8;
+
+// ------------------------------------------------------------------ scalar traits
+template <typename T>
+struct Sc;
+template <>
+struct Sc<double> {
+  static constexpr bool cplx = false;
+  __device__ static inline double zero() { return 0.0; }
+  __device__ static inline double mul(double a, double b) { return __dmul_rn(a, b); }
+  __device__ static inline double add(double a, double b) { return __dadd_rn(a, b); }
+  __device__ static inline double scale(double s, double v) { return __dmul_rn(s, v); }
+  __device__ static inline double mag(double v) { return fabs(v); }
+  __device__ static inline double conj(double v) { return v; }
+  __device__ static inline double re(double v) { return v; }
+  __device__ static inline bool is_zero(double v) { return v == 0.0; }
+};
+template <>
+struct Sc<double2> {
+  static constexpr bool cplx = true;
+  __device__ static inline double2 zero() { return make_double2(0.0, 0.0); }
+  // (a.x + i a.y)(b.x + i b.y), no contraction: matches gcc/flang on baseline x86-64
+  __device__ static inline double2 mul(double2 a, double2 b) {
+    return make_double2(__dsub_rn(__dmul_rn(a.x, b.x), __dmul_rn(a.y, b.y)),
+                        __dadd_rn(__dmul_rn(a.x, b.y), __dmul_rn(a.y, b.x)));
+  }
+  __device__ static inline double2 add(double2 a, double2 b) {
+    return make_double2(__dadd_rn(a.x, b.x), __dadd_rn(a.y, b.y));
+  }
+  __device__ static inline double2 scale(double s, double2 v) {
+    return make_double2(__dmul_rn(s, v.x), __dmul_rn(s, v.y));
+  }
+  __device__ static inline double mag(double2 v) { return hypot(v.x, v.y); }
+  __device__ static inline double2 conj(double2 v) { return make_double2(v.x, -v.y); }
+  __device__ static inline double re(double2 v) { return v.x; }
+  __device__ static inline bool is_zero(double2 v) { return v.x == 0.0 && v.y == 0.0; }
+};
+
+// ------------------------------------------------------------------ wave helpers
+__device__ inline int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ inline int readlane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ inline int64_t readlane_i64(int64_t v, int l) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+__device__ inline double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double readlane_T(double v, int l) { return readlane_f64(v, l); }
+__device__ inline double2 readlane_T(double2 v, int l) {
+  return make_double2(readlane_f64(v.x, l), readlane_f64(v.y, l));
+}
+__device__ inline int wave_min_i32(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+__device__ inline int wave_max_i32(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+__device__ inline int64_t wave_sum_i64(int64_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+// fixed-shape butterfly: deterministic for a given input
+__device__ inline double wave_sum_f64(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = __dadd_rn(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+__device__ inline unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// XCD-aware block index: hardware deals consecutive block ids round-robin over the 8 XCDs
+// (MI355X_MICROARCH.md, "Workgroup dispatch"), each XCD has its own 4 MiB L2.  Give every XCD a
+// contiguous range of columns so blocks that run together on one XCD read neighbouring operand
+// columns (banded operands re-use the same A columns across ~2h consecutive output columns).
+// grid must be launched with NXCD*ceil(nblocks/NXCD) blocks; returns -1 for padding blocks.
+__device__ inline int xcd_block(int nblocks) {
+  const int per = (nblocks + NXCD - 1) / NXCD;
+  const int b = (int)(blockIdx.x % NXCD) * per + (int)(blockIdx.x / NXCD);
+  return (b < nblocks && (int)(blockIdx.x / NXCD) < per) ? b : -1;
+}
+inline int xcd_grid(int nblocks) { return NXCD * ((nblocks + NXCD - 1) / NXCD); }
+
+struct Csc {
+  int32_t rows, cols;
+  const int64_t* outer;
+  const int32_t* inner;
+  const void* val;
+};
+inline Csc view(const DevMat& m) { return Csc{m.rows, m.cols, m.outer.p, m.inner.p, m.val.p}; }
+
+// ------------------------------------------------------------------ scans / reductions
+// single-workgroup exclusive scan of n int64 values (n <= a few million); out[n] = total
+__global__ __launch_bounds__(1024) void k_scan_excl_i64(const int64_t* __restrict__ in,
+                                                        int64_t* __restrict__ out, int64_t n) {
+  __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024;
+  const int64_t b = min(n, (int64_t)t * chunk), e = min(n, b + chunk);
+  int64_t s = 0;
+  for (int64_t i = b; i < e; ++i) s += in[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int64_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int64_t run = (t == 0) ? 0 : part[t - 1];
+  for (int64_t i = b; i < e; ++i) {
+    const int64_t v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  if (t == 1023) out[n] = part[1023];
+}
+
+// int32 counts -> int64 exclusive offsets (same structure)
+__global__ __launch_bounds__(1024) void k_scan_excl_i32(const int32_t* __restrict__ in,
+                                                        int64_t* __restrict__ out, int64_t n) {
+  __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024;
+  const int64_t b = min(n, (int64_t)t * chunk), e = min(n, b + chunk);
+  int64_t s = 0;
+  for (int64_t i = b; i < e; ++i) s += in[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int64_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int64_t run = (t == 0) ? 0 : part[t - 1];
+  for (int64_t i = b; i < e; ++i) {
+    const int64_t v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  if (t == 1023) out[n] = part[1023];
+}
+
+// deterministic final reduction of per-block partials (sum of pairs / min / max)
+__global__ __launch_bounds__(256) void k_reduce_sum2(const double* __restrict__ part, int n,
+                                                     double* __restrict__ out) {
+  __shared__ double sx[256], sy[256];
+  double x = 0, y = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    x = __dadd_rn(x, part[2 * i]);
+    y = __dadd_rn(y, part[2 * i + 1]);
+  }
+  sx[threadIdx.x] = x;
+  sy[threadIdx.x] = y;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sx[threadIdx.x] = __dadd_rn(sx[threadIdx.x], sx[threadIdx.x + o]);
+      sy[threadIdx.x] = __dadd_rn(sy[threadIdx.x], sy[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sx[0];
+    out[1] = sy[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_minmax(const double* __restrict__ vmin,
+                                                       const double* __restrict__ vmax, int64_t n,
+                                                       double* __restrict__ out) {
+  __shared__ double smin[256], smax[256];
+  double mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    if (vmin) mn = fmin(mn, vmin[i]);
+    if (vmax) mx = fmax(mx, vmax[i]);
+  }
+  smin[threadIdx.x] = mn;
+  smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + o]);
+      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = smin[0];
+    out[1] = smax[0];
+  }
+}
+
+// ------------------------------------------------------------------ SpGEMM: planning
+// first/last stored row and length of every column of A (compact arrays that stay L2-resident
+// while the plan kernel gathers them)
+__global__ void k_col_extent(Csc A, int32_t* __restrict__ cmin, int32_t* __restrict__ cmax,
+                             int32_t* __restrict__ clen) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= A.cols) return;
+  const int64_t s = A.outer[k], e = A.outer[k + 1];
+  clen[k] = (int32_t)(e - s);
+  cmin[k] = (e > s) ? A.inner[s] : INT_MAX;
+  cmax[k] = (e > s) ? A.inner[e - 1] : -1;
+}
+
+// bins: 0 empty | 1..4 LDS direct window of 512/1024/2048/4096 rows | 5 LDS hash | 6 HBM accumulator
+constexpr int BIN_EMPTY = 0, BIN_HASH = 5, BIN_HBM = 6;
+constexpr int HASH_SLOTS = 4096;      // per wave
+constexpr int HASH_MAX_FILL = 3072;   // leave the LDS hash for the HBM accumulator beyond this
+
+__host__ __device__ inline int window_bin(int span) {
+  return span <= 512 ? 1 : span <= 1024 ? 2 : span <= 2048 ? 3 : span <= 4096 ? 4 : BIN_HASH;
+}
+
+// one wave per output column j: row window [lo, lo+span) that column j of A*B can touch, the
+// number of intermediate products, an upper bound of its nnz and the kernel bin.
+// stats: [0..6] bin histogram, [7] total products
+__global__ __launch_bounds__(256) void k_spgemm_plan(Csc B, const int32_t* __restrict__ cmin,
+                                                     const int32_t* __restrict__ cmax,
+                                                     const int32_t* __restrict__ clen,
+                                                     int32_t* __restrict__ lo_arr,
+                                                     int32_t* __restrict__ span_arr,
+                                                     uint8_t* __restrict__ bin_arr,
+                                                     int64_t* __restrict__ ub_arr,
+                                                     int64_t* __restrict__ ip_arr,
+                                                     unsigned long long* __restrict__ stats,
+                                                     int force_bin) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= B.cols) return;
+  const int lane = lane_id();
+  int lo = INT_MAX, hi = -1;
+  int64_t ip = 0;
+  for (int64_t p = B.outer[j] + lane; p < B.outer[j + 1]; p += WAVE) {
+    const int k = B.inner[p];
+    const int len = clen[k];
+    if (len > 0) {
+      lo = min(lo, cmin[k]);
+      hi = max(hi, cmax[k]);
+      ip += len;
+    }
+  }
+  lo = wave_min_i32(lo);
+  hi = wave_max_i32(hi);
+  ip = wave_sum_i64(ip);
+  if (lane == 0) {
+    const int span = (hi >= lo) ? (hi - lo + 1) : 0;
+    int bin = span == 0 ? BIN_EMPTY : window_bin(span);
+    if (span > 0 && force_bin > 0) {
+      if (force_bin >= BIN_HASH) bin = force_bin;
+      else bin = max(bin, force_bin);  // a window can be forced larger, never smaller
+    }
+    int64_t ub = min((int64_t)span, ip);
+    if (bin == BIN_HASH) ub = min(ub, (int64_t)HASH_MAX_FILL);
+    lo_arr[j] = (span > 0) ? lo : 0;
+    span_arr[j] = span;
+    bin_arr[j] = (uint8_t)bin;
+    ub_arr[j] = ub;
+    ip_arr[j] = ip;
+    atomicAdd(&stats[bin], 1ull);
+    atomicAdd(&stats[7], (unsigned long long)ip);
+  }
+}
+
+// ------------------------------------------------------------------ SpGEMM: numeric, LDS window
+// Column j of C = alpha * A * B.  The wave walks column j of B in storage order (ascending k,
+// fetched 64 entries at a time and broadcast with v_readlane); for each (k, b) its lanes stride
+// over column k of A with coalesced index/value loads and update the direct-mapped LDS
+// accumulator acc[row - lo] (a collision-free hash: the bucket of row i is i - lo).  The
+// epilogue scans the window in row order, applies the prune rule and compacts the survivors with
+// ballot + popcount prefix, so the column comes out sorted with no sort.
+template <typename T, int W, int NW>
+__global__ __launch_bounds__(NW* WAVE) void k_spgemm_window(
+    Csc A, Csc B, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
+    const uint8_t* __restrict__ bin_arr, int my_bin, const int64_t* __restrict__ tmpoff,
+    int32_t* __restrict__ out_inner, T* __restrict__ out_val, int32_t* __restrict__ count,
+    double alpha, double threshold, int dense_rule, int nblocks) {
+  __shared__ T acc_all[NW * W];
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  const int j = b * NW + wave;
+  if (j >= B.cols) return;
+  if (bin_arr[j] != my_bin) return;
+  T* acc = acc_all + wave * W;
+  const int span = span_arr[j], lo = lo_arr[j];
+  for (int s = lane; s < span; s += WAVE) acc[s] = Sc<T>::zero();
+
+  const int32_t* __restrict__ Ai = A.inner;
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  const T* __restrict__ Bv = static_cast<const T*>(B.val);
+  const int64_t bs = B.outer[j], be = B.outer[j + 1];
+  for (int64_t p0 = bs; p0 < be; p0 += WAVE) {
+    const int np = (int)min((int64_t)WAVE, be - p0);
+    int k_l = 0;
+    T b_l = Sc<T>::zero();
+    int64_t as_l = 0;
+    int len_l = 0;
+    if (lane < np) {
+      k_l = B.inner[p0 + lane];
+      b_l = Bv[p0 + lane];
+      as_l = A.outer[k_l];
+      len_l = (int)(A.outer[k_l + 1] - as_l);
+    }
+    for (int t = 0; t < np; ++t) {
+      const int64_t as = readlane_i64(as_l, t);
+      const int len = readlane_i32(len_l, t);
+      const T bk = readlane_T(b_l, t);
+      for (int q = lane; q < len; q += 2 * WAVE) {
+        const int q1 = q + WAVE;
+        const bool v1 = q1 < len;
+        const int i0 = Ai[as + q];
+        const T a0 = Av[as + q];
+        const int i1 = v1 ? Ai[as + q1] : lo;
+        const T a1 = v1 ? Av[as + q1] : Sc<T>::zero();
+        const T p0v = Sc<T>::mul(a0, bk);
+        const T p1v = Sc<T>::mul(a1, bk);
+        acc[i0 - lo] = Sc<T>::add(acc[i0 - lo], p0v);
+        if (v1) acc[i1 - lo] = Sc<T>::add(acc[i1 - lo], p1v);
+      }
+      // the next k may hit the same rows: keep this wave's LDS traffic in program order
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  const int64_t base = tmpoff[j];
+  int cnt = 0;
+  for (int s0 = 0; s0 < span; s0 += WAVE) {
+    const int s = s0 + lane;
+    const T v = (s < span) ? acc[s] : Sc<T>::zero();
+    const T sv = Sc<T>::scale(alpha, v);
+    const bool keep = (s < span) && (dense_rule ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
+      out_inner[pos] = lo + s;
+      out_val[pos] = sv;
+    }
+    cnt += __popcll(m);
+  }
+  if (lane == 0) count[j] = cnt;
+}
+
+// ------------------------------------------------------------------ SpGEMM: numeric, LDS hash
+// For columns whose row window does not fit the direct map (e.g. after a load-balancing
+// permutation).  4096 LDS buckets per wave, multiplicative hash + linear probing; bucket claim by
+// LDS compare-and-swap, value update non-atomic (one lane per row inside a step).  Survivors are
+// packed as (row << 13 | slot), bitonic-sorted in LDS and written in row order.  A column that
+// fills more than HASH_MAX_FILL buckets is handed to the HBM accumulator kernel (bin 6).
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_spgemm_hash(
+    Csc A, Csc B, const int32_t* __restrict__ span_arr, uint8_t* __restrict__ bin_arr,
+    const int64_t* __restrict__ tmpoff, int32_t* __restrict__ out_inner, T* __restrict__ out_val,
+    int32_t* __restrict__ count, unsigned long long* __restrict__ stats, double alpha,
+    double threshold, int dense_rule, int nblocks) {
+  __shared__ int keys[HASH_SLOTS];
+  __shared__ T vals[HASH_SLOTS];
+  __shared__ unsigned long long sortbuf[HASH_SLOTS];
+  const int j = xcd_block(nblocks);
+  if (j < 0 || j >= B.cols) return;
+  if (bin_arr[j] != BIN_HASH) return;
+  const int lane = lane_id();
+  for (int s = lane; s < HASH_SLOTS; s += WAVE) {
+    keys[s] = -1;
+    vals[s] = Sc<T>::zero();
+  }
+  __syncthreads();
+  const int32_t* __restrict__ Ai = A.inner;
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  const T* __restrict__ Bv = static_cast<const T*>(B.val);
+  int filled = 0;
+  bool overflow = false;
+  for (int64_t p = B.outer[j]; p < B.outer[j + 1] && !overflow; ++p) {
+    const int k = B.inner[p];
+    const T bk = Bv[p];
+    const int64_t as = A.outer[k];
+    const int len = (int)(A.outer[k + 1] - as);
+    for (int q0 = 0; q0 < len; q0 += WAVE) {
+      const int q = q0 + lane;
+      const bool act = q < len;
+      int i = 0;
+      T a = Sc<T>::zero();
+      if (act) {
+        i = Ai[as + q];
+        a = Av[as + q];
+      }
+      bool fresh = false;
+      int h = 0;
+      if (act) {
+        h = (int)(((unsigned)i * 2654435761u) >> 20) & (HASH_SLOTS - 1);
+        for (;;) {
+          const int old = atomicCAS(&keys[h], -1, i);
+          if (old == -1) { fresh = true; break; }
+          if (old == i) break;
+          h = (h + 1) & (HASH_SLOTS - 1);
+        }
+        vals[h] = Sc<T>::add(vals[h], Sc<T>::mul(a, bk));
+      }
+      filled += __popcll(__ballot(fresh));
+      __builtin_amdgcn_wave_barrier();
+      if (filled > HASH_MAX_FILL) { overflow = true; break; }
+    }
+  }
+  if (overflow) {
+    if (lane == 0) {
+      bin_arr[j] = BIN_HBM;
+      count[j] = 0;
+      atomicAdd(&stats[8], 1ull);
+    }
+    return;
+  }
+  __syncthreads();
+  // pack the occupied buckets
+  int n = 0;
+  for (int s0 = 0; s0 < HASH_SLOTS; s0 += WAVE) {
+    const int s = s0 + lane;
+    const int key = keys[s];
+    const bool occ = key >= 0;
+    const unsigned long long m = __ballot(occ);
+    if (occ) sortbuf[n + __popcll(m & lanemask_lt())] = ((unsigned long long)(unsigned)key << 13) | (unsigned)s;
+    n += __popcll(m);
+  }
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (int s = n + lane; s < n2; s += WAVE) sortbuf[s] = ~0ull;
+  __syncthreads();
+  for (int kk = 2; kk <= n2; kk <<= 1) {
+    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+      for (int t = lane; t < n2; t += WAVE) {
+        const int ixj = t ^ jj;
+        if (ixj > t) {
+          const unsigned long long x = sortbuf[t], y = sortbuf[ixj];
+          const bool up = (t & kk) == 0;
+          if ((x > y) == up) {
+            sortbuf[t] = y;
+            sortbuf[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int64_t base = tmpoff[j];
+  int cnt = 0;
+  for (int s0 = 0; s0 < n; s0 += WAVE) {
+    const int s = s0 + lane;
+    const bool in = s < n;
+    const unsigned long long e = in ? sortbuf[s] : 0ull;
+    const int slot = (int)(e & 8191ull);
+    const int row = (int)(e >> 13);
+    const T v = in ? vals[slot] : Sc<T>::zero();
+    const T sv = Sc<T>::scale(alpha, v);
+    const bool keep = in && (dense_rule ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
+      out_inner[pos] = row;
+      out_val[pos] = sv;
+    }
+    cnt += __popcll(m);
+  }
+  if (lane == 0) count[j] = cnt;
+}
+
+// ------------------------------------------------------------------ SpGEMM: numeric, HBM accumulator
+// Last resort for very long columns: each persistent wave owns a dense accumulator of `rows`
+// entries in HBM (what the reference allocates for EVERY column).  Updates and the final scan
+// go through L2 (agent-scope atomics / sc1 loads) so that the wave always sees its own previous
+// step.  tmpoff2 gives the column's slot in the second temporary region.
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_spgemm_hbm(
+    Csc A, Csc B, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
+    const uint8_t* __restrict__ bin_arr, const int64_t* __restrict__ tmpoff2,
+    int32_t* __restrict__ out_inner, T* __restrict__ out_val, int32_t* __restrict__ count,
+    double* __restrict__ workspace, double alpha, double threshold, int dense_rule) {
+  constexpr int WV = Sc<T>::cplx ? 2 : 1;
+  double* acc = workspace + (size_t)blockIdx.x * (size_t)A.rows * WV;
+  const int lane = lane_id();
+  const int32_t* __restrict__ Ai = A.inner;
+  const double* __restrict__ Av = static_cast<const double*>(A.val);
+  const T* __restrict__ Bv = static_cast<const T*>(B.val);
+  for (int j = blockIdx.x; j < B.cols; j += gridDim.x) {
+    if (bin_arr[j] != BIN_HBM) continue;
+    const int lo = lo_arr[j], span = span_arr[j];
+    for (int64_t p = B.outer[j]; p < B.outer[j + 1]; ++p) {
+      const int k = B.inner[p];
+      const T bk = Bv[p];
+      const int64_t as = A.outer[k];
+      const int len = (int)(A.outer[k + 1] - as);
+      for (int q = lane; q < len; q += WAVE) {
+        const int i = Ai[as + q];
+        if constexpr (Sc<T>::cplx) {
+          const double2 a = make_double2(Av[2 * (as + q)], Av[2 * (as + q) + 1]);
+          const double2 pr = Sc<double2>::mul(a, bk);
+          double* slot = acc + 2 * (size_t)i;
+          const double ox = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double oy = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot, __dadd_rn(ox, pr.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot + 1, __dadd_rn(oy, pr.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          const double pr = __dmul_rn(Av[as + q], bk);
+          double* slot = acc + (size_t)i;
+          const double o = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot, __dadd_rn(o, pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // all of this step's stores must have reached L2 before the next step reads them
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_wave_barrier();
+    }
+    const int64_t base = tmpoff2[j];
+    int cnt = 0;
+    for (int s0 = 0; s0 < span; s0 += WAVE) {
+      const int s = s0 + lane;
+      const bool in = s < span;
+      T v = Sc<T>::zero();
+      if (in) {
+        double* slot = acc + (size_t)(lo + s) * WV;
+        if constexpr (Sc<T>::cplx) {
+          v = make_double2(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                           __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          __hip_atomic_store(slot, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot + 1, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      const T sv = Sc<T>::scale(alpha, v);
+      const bool keep = in && (dense_rule ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
+        out_inner[pos] = lo + s;
+        out_val[pos] = sv;
+      }
+      cnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) count[j] = cnt;
+  }
+}
+
+__global__ void k_hbm_ub(const uint8_t* __restrict__ bin_arr, const int32_t* __restrict__ span_arr,
+                         const int64_t* __restrict__ ip_arr, int64_t* __restrict__ ub2, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  ub2[j] = (bin_arr[j] == BIN_HBM) ? min((int64_t)span_arr[j], ip_arr[j]) : 0;
+}
+
+// copy the kept entries of every column from its temporary slot to its final place
+// (one wave per column, coalesced)
+template <typename T>
+__global__ __launch_bounds__(256) void k_compact(int ncols, const int64_t* __restrict__ srcoff,
+                                                 const int64_t* __restrict__ srcoff2,
+                                                 const uint8_t* __restrict__ sel2,
+                                                 const int64_t* __restrict__ dstoff,
+                                                 const int32_t* __restrict__ src_inner,
+                                                 const T* __restrict__ src_val,
+                                                 const int32_t* __restrict__ src2_inner,
+                                                 const T* __restrict__ src2_val,
+                                                 int32_t* __restrict__ dst_inner,
+                                                 T* __restrict__ dst_val, int nblocks) {
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int j = b * 4 + threadIdx.x / WAVE;
+  if (j >= ncols) return;
+  const int lane = lane_id();
+  const int64_t d0 = dstoff[j];
+  const int n = (int)(dstoff[j + 1] - d0);
+  const bool second = sel2 && sel2[j] == BIN_HBM;
+  const int64_t s0 = second ? srcoff2[j] : srcoff[j];
+  const int32_t* si = second ? src2_inner : src_inner;
+  const T* sv = second ? src2_val : src_val;
+  for (int t = lane; t < n; t += WAVE) {
+    dst_inner[d0 + t] = si[s0 + t];
+    dst_val[d0 + t] = sv[s0 + t];
+  }
+}
+
+// ------------------------------------------------------------------ increment (sparse AXPY)
+// B <- alpha*A + B, one wave per column, AddSparseVectors rules
+// (sparse_includes/AddSparseVectors.f90:24-68): in the region where both columns still have
+// entries an element is kept only if |value| > threshold; once one column is exhausted the rest
+// of the other is copied unfiltered.  "Exhausted" is a comparison with the other column's last
+// row, so a direct-mapped LDS window over the union row range decides every slot independently.
+__global__ void k_inc_plan(Csc A, Csc B, int32_t* __restrict__ lo_arr, int32_t* __restrict__ span_arr,
+                           uint8_t* __restrict__ bin_arr, unsigned long long* __restrict__ stats,
+                           int force_seq) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.cols) return;
+  const int64_t as = A.outer[j], ae = A.outer[j + 1], bs = B.outer[j], be = B.outer[j + 1];
+  int lo = INT_MAX, hi = -1;
+  if (ae > as) { lo = min(lo, A.inner[as]); hi = max(hi, A.inner[ae - 1]); }
+  if (be > bs) { lo = min(lo, B.inner[bs]); hi = max(hi, B.inner[be - 1]); }
+  const int span = hi >= lo ? hi - lo + 1 : 0;
+  int bin = span == 0 ? 0 : span <= 512 ? 1 : span <= 2048 ? 2 : 3;
+  if (span > 0 && force_seq) bin = 3;
+  lo_arr[j] = span > 0 ? lo : 0;
+  span_arr[j] = span;
+  bin_arr[j] = (uint8_t)bin;
+  atomicAdd(&stats[bin], 1ull);
+}
+
+template <typename T>
+__device__ inline bool inc_decide(bool ha, bool hb, T a, T b, int row, int amax, int bmax,
+                                  double alpha, double threshold, T* out) {
+  // a is the raw A value; wa = alpha*a as in AddSparseVectors.f90:28
+  if (ha && hb) {
+    const T s = Sc<T>::add(Sc<T>::scale(alpha, a), b);
+    *out = s;
+    return Sc<T>::mag(s) > threshold;
+  }
+  if (ha) {
+    const T wa = Sc<T>::scale(alpha, a);
+    *out = wa;
+    return (row > bmax) ? true : (Sc<T>::mag(wa) > threshold);  // tail of A copied unfiltered (:57-62)
+  }
+  *out = b;
+  return (row > amax) ? true : (Sc<T>::mag(b) > threshold);      // tail of B copied unfiltered (:63-68)
+}
+
+template <typename T, int W, int NW>
+__global__ __launch_bounds__(NW* WAVE) void k_inc_window(
+    Csc A, Csc B, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
+    const uint8_t* __restrict__ bin_arr, int my_bin, int32_t* __restrict__ out_inner,
+    T* __restrict__ out_val, int32_t* __restrict__ count, double alpha, double threshold,
+    int nblocks) {
+  __shared__ T wa_all[NW * W];
+  __shared__ T wb_all[NW * W];
+  __shared__ uint8_t fl_all[NW * W];
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  const int j = b * NW + wave;
+  if (j >= A.cols) return;
+  if (bin_arr[j] != my_bin) return;
+  T* wa = wa_all + wave * W;
+  T* wb = wb_all + wave * W;
+  uint8_t* fl = fl_all + wave * W;
+  const int span = span_arr[j], lo = lo_arr[j];
+  for (int s = lane; s < span; s += WAVE) fl[s] = 0;
+  __builtin_amdgcn_wave_barrier();
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  const T* __restrict__ Bv = static_cast<const T*>(B.val);
+  const int64_t as = A.outer[j], ae = A.outer[j + 1], bs = B.outer[j], be = B.outer[j + 1];
+  const int amax = ae > as ? A.inner[ae - 1] : -1;
+  const int bmax = be > bs ? B.inner[be - 1] : -1;
+  for (int64_t p = as + lane; p < ae; p += WAVE) {
+    const int s = A.inner[p] - lo;
+    wa[s] = Av[p];
+    fl[s] = 1;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int64_t p = bs + lane; p < be; p += WAVE) {
+    const int s = B.inner[p] - lo;
+    wb[s] = Bv[p];
+    fl[s] |= 2;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int64_t base = as + bs;  // upper-bound slot: every column may keep all of A and B
+  int cnt = 0;
+  for (int s0 = 0; s0 < span; s0 += WAVE) {
+    const int s = s0 + lane;
+    const int f = (s < span) ? fl[s] : 0;
+    T v = Sc<T>::zero();
+    bool keep = false;
+    if (f) keep = inc_decide<T>(f & 1, f & 2, (f & 1) ? wa[s] : Sc<T>::zero(), (f & 2) ? wb[s] : Sc<T>::zero(),
+                                lo + s, amax, bmax, alpha, threshold, &v);
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
+      out_inner[pos] = lo + s;
+      out_val[pos] = v;
+    }
+    cnt += __popcll(m);
+  }
+  if (lane == 0) count[j] = cnt;
+}
+
+// sequential two-pointer merge, one thread per column (columns wider than the LDS window)
+template <typename T>
+__global__ void k_inc_seq(Csc A, Csc B, const uint8_t* __restrict__ bin_arr, int my_bin,
+                          int32_t* __restrict__ out_inner, T* __restrict__ out_val,
+                          int32_t* __restrict__ count, double alpha, double threshold) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.cols) return;
+  if (bin_arr[j] != my_bin) return;
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  const T* __restrict__ Bv = static_cast<const T*>(B.val);
+  int64_t aa = A.outer[j], ea = A.outer[j + 1], bb = B.outer[j], eb = B.outer[j + 1];
+  int64_t cc = aa + bb;
+  const int64_t c0 = cc;
+  while (aa < ea && bb < eb) {
+    const int ia = A.inner[aa], ib = B.inner[bb];
+    if (ia == ib) {
+      const T s = Sc<T>::add(Sc<T>::scale(alpha, Av[aa]), Bv[bb]);
+      if (Sc<T>::mag(s) > threshold) { out_inner[cc] = ia; out_val[cc] = s; ++cc; }
+      ++aa; ++bb;
+    } else if (ia > ib) {
+      const T w = Bv[bb];
+      if (Sc<T>::mag(w) > threshold) { out_inner[cc] = ib; out_val[cc] = w; ++cc; }
+      ++bb;
+    } else {
+      const T w = Sc<T>::scale(alpha, Av[aa]);
+      if (Sc<T>::mag(w) > threshold) { out_inner[cc] = ia; out_val[cc] = w; ++cc; }
+      ++aa;
+    }
+  }
+  for (; aa < ea; ++aa) { out_inner[cc] = A.inner[aa]; out_val[cc] = Sc<T>::scale(alpha, Av[aa]); ++cc; }
+  for (; bb < eb; ++bb) { out_inner[cc] = B.inner[bb]; out_val[cc] = Bv[bb]; ++cc; }
+  count[j] = (int32_t)(cc - c0);
+}
+
+__global__ void k_sum_outer(const int64_t* __restrict__ a, const int64_t* __restrict__ b,
+                            int64_t* __restrict__ out, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j <= n) out[j] = a[j] + b[j];
+}
+
+// ------------------------------------------------------------------ dot / pairwise / trace / norms
+// sum_j sum_i conj(A_ij) B_ij.  One wave per column: lanes stride over A's column and find the
+// partner in B's column by binary search (B's column is hot in L1/L2: it is read log2 times by
+// neighbouring lanes).  Per-wave partials are reduced by k_reduce_sum2 in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ partial, int nblocks) {
+  __shared__ double sx[4], sy[4];
+  const int b = blockIdx.x;
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  const T* __restrict__ Bv = static_cast<const T*>(B.val);
+  double x = 0, y = 0;
+  for (int j = b * 4 + wave; j < A.cols; j += nblocks * 4) {
+    const int64_t bs = B.outer[j], be = B.outer[j + 1];
+    if (be == bs) continue;
+    for (int64_t p = A.outer[j] + lane; p < A.outer[j + 1]; p += WAVE) {
+      const int r = A.inner[p];
+      int64_t l = bs, h = be;
+      while (l < h) {
+        const int64_t mid = (l + h) >> 1;
+        if (B.inner[mid] < r) l = mid + 1; else h = mid;
+      }
+      if (l < be && B.inner[l] == r) {
+        if constexpr (Sc<T>::cplx) {
+          const double2 pr = Sc<double2>::mul(Sc<double2>::conj(Av[p]), Bv[l]);
+          x = __dadd_rn(x, pr.x);
+          y = __dadd_rn(y, pr.y);
+        } else {
+          x = __dadd_rn(x, __dmul_rn(Av[p], Bv[l]));
+        }
+      }
+    }
+  }
+  x = wave_sum_f64(x);
+  y = wave_sum_f64(y);
+  if (lane == 0) { sx[wave] = x; sy[wave] = y; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * b] = __dadd_rn(__dadd_rn(sx[0], sx[1]), __dadd_rn(sx[2], sx[3]));
+    partial[2 * b + 1] = __dadd_rn(__dadd_rn(sy[0], sy[1]), __dadd_rn(sy[2], sy[3]));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_grand_sum(const T* __restrict__ v, int64_t n,
+                                                   double* __restrict__ partial) {
+  __shared__ double sx[4], sy[4];
+  double x = 0, y = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if constexpr (Sc<T>::cplx) { x = __dadd_rn(x, v[i].x); y = __dadd_rn(y, v[i].y); }
+    else x = __dadd_rn(x, v[i]);
+  }
+  x = wave_sum_f64(x);
+  y = wave_sum_f64(y);
+  const int wave = threadIdx.x / WAVE;
+  if (lane_id() == 0) { sx[wave] = x; sy[wave] = y; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = __dadd_rn(__dadd_rn(sx[0], sx[1]), __dadd_rn(sx[2], sx[3]));
+    partial[2 * blockIdx.x + 1] = __dadd_rn(__dadd_rn(sy[0], sy[1]), __dadd_rn(sy[2], sy[3]));
+  }
+}
+
+// pairwise product, sequential per column; count pass (out_inner == nullptr) then fill pass
+template <typename T>
+__global__ void k_pairwise(Csc A, Csc B, const int64_t* __restrict__ couter, int32_t* __restrict__ out_inner,
+                           T* __restrict__ out_val, int32_t* __restrict__ count, int conj_a) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.cols) return;
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  const T* __restrict__ Bv = static_cast<const T*>(B.val);
+  int64_t aa = A.outer[j], ea = A.outer[j + 1], bb = B.outer[j], eb = B.outer[j + 1];
+  int64_t cc = couter ? couter[j] : 0;
+  int n = 0;
+  while (aa < ea && bb < eb) {
+    const int ia = A.inner[aa], ib = B.inner[bb];
+    if (ia == ib) {
+      if (out_inner) {
+        out_inner[cc] = ia;
+        out_val[cc] = Sc<T>::mul(conj_a ? Sc<T>::conj(Av[aa]) : Av[aa], Bv[bb]);
+        ++cc;
+      }
+      ++n; ++aa; ++bb;
+    } else if (ia > ib) ++bb;
+    else ++aa;
+  }
+  if (count) count[j] = n;
+}
+
+// diagonal sum: thread per column, binary search for row == j + col_offset
+template <typename T>
+__global__ __launch_bounds__(256) void k_trace(Csc A, int col_offset, double* __restrict__ partial) {
+  __shared__ double sx[4];
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  double x = 0;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < A.cols; j += gridDim.x * 256) {
+    const int r = j + col_offset;
+    int64_t l = A.outer[j], h = A.outer[j + 1];
+    const int64_t e = h;
+    while (l < h) {
+      const int64_t mid = (l + h) >> 1;
+      if (A.inner[mid] < r) l = mid + 1; else h = mid;
+    }
+    if (l < e && A.inner[l] == r) x = __dadd_rn(x, Sc<T>::re(Av[l]));
+  }
+  x = wave_sum_f64(x);
+  const int wave = threadIdx.x / WAVE;
+  if (lane_id() == 0) sx[wave] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = __dadd_rn(__dadd_rn(sx[0], sx[1]), __dadd_rn(sx[2], sx[3]));
+    partial[2 * blockIdx.x + 1] = 0.0;
+  }
+}
+
+// per column: sum |v| (mode 0) or Gershgorin disc ends d-r, d+r (mode 1); one wave per column
+template <typename T>
+__global__ __launch_bounds__(256) void k_colstat(Csc A, int col_offset, int mode,
+                                                 double* __restrict__ out0, double* __restrict__ out1) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= A.cols) return;
+  const int lane = lane_id();
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  double r = 0, d = 0;
+  for (int64_t p = A.outer[j] + lane; p < A.outer[j + 1]; p += WAVE) {
+    if (mode == 1 && A.inner[p] == j + col_offset) d = __dadd_rn(d, Sc<T>::re(Av[p]));
+    else r = __dadd_rn(r, Sc<T>::mag(Av[p]));
+  }
+  r = wave_sum_f64(r);
+  d = wave_sum_f64(d);
+  if (lane == 0) {
+    if (mode == 0) out0[j] = r;
+    else { out0[j] = d - r; out1[j] = d + r; }
+  }
+}
+
+__global__ void k_scale(double* __restrict__ v, int64_t n, double c) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    v[i] = __dmul_rn(c, v[i]);
+}
+__global__ void k_conj(double* __restrict__ v, int64_t nnz) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+    v[2 * i + 1] = -v[2 * i + 1];
+}
+__global__ void k_to_complex(const double* __restrict__ in, double* __restrict__ out, int64_t nnz) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+    out[2 * i] = in[i];
+    out[2 * i + 1] = 0.0;
+  }
+}
+__global__ void k_to_real(const double* __restrict__ in, double* __restrict__ out, int64_t nnz) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = in[2 * i];
+}
+__global__ void k_identity(int64_t* __restrict__ outer, int32_t* __restrict__ inner, double* __restrict__ val,
+                           int n, int col_offset, int cols, int cplx) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > cols) return;
+  // local column j is global column j + col_offset; it holds a one iff that is < n
+  const int ones_before = max(0, min(j, n - col_offset));
+  outer[j] = ones_before;
+  if (j < cols && j + col_offset < n) {
+    inner[ones_before] = j + col_offset;
+    if (cplx) { val[2 * ones_before] = 1.0; val[2 * ones_before + 1] = 0.0; }
+    else val[ones_before] = 1.0;
+  }
+}
+// flags[0] = off-diagonal or non-one entries, flags[1] = diagonal ones
+template <typename T>
+__global__ void k_identity_check(Csc A, int col_offset, unsigned long long* __restrict__ flags) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.cols) return;
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  for (int64_t p = A.outer[j]; p < A.outer[j + 1]; ++p) {
+    bool one;
+    if constexpr (Sc<T>::cplx) one = hypot(Av[p].x - 1.0, Av[p].y) <= 2.2250738585072014e-308;
+    else one = fabs(Av[p] - 1.0) <= 2.2250738585072014e-308;
+    if (A.inner[p] != j + col_offset || !one) atomicAdd(&flags[0], 1ull);
+    else atomicAdd(&flags[1], 1ull);
+  }
+}
+
+// ------------------------------------------------------------------ re-indexing (transpose / permutation)
+// key = new_col << 32 | new_row for every entry, payload = source position; radix sort (rocPRIM)
+// then gather.  Used by setup paths only (transpose of ISQ, load-balancing permutation).
+__global__ void k_expand_cols(const int64_t* __restrict__ outer, int cols, int32_t* __restrict__ colidx) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= cols) return;
+  for (int64_t p = outer[j] + lane_id(); p < outer[j + 1]; p += WAVE) colidx[p] = j;
+}
+template <typename T>
+__global__ void k_remap_keys(const int32_t* __restrict__ colidx, const int32_t* __restrict__ inner,
+                             const T* __restrict__ val, int64_t nnz, const int32_t* __restrict__ row_map,
+                             const int32_t* __restrict__ col_map, int transpose, int col_lo, int col_hi,
+                             int drop_zero, unsigned long long* __restrict__ keys,
+                             unsigned int* __restrict__ payload) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nnz) return;
+  int r = inner[p], c = colidx[p];
+  if (row_map) r = row_map[r];
+  if (col_map) c = col_map[c];
+  if (transpose) { const int t = r; r = c; c = t; }
+  const bool dropped = c < col_lo || c >= col_hi || (drop_zero && Sc<T>::is_zero(val[p]));
+  keys[p] = dropped ? ~0ull : (((unsigned long long)(unsigned)(c - col_lo) << 32) | (unsigned)r);
+  payload[p] = (unsigned int)p;
+}
+template <typename T>
+__global__ void k_remap_gather(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ payload,
+                               int64_t nkeep, const T* __restrict__ val, int32_t* __restrict__ inner_out,
+                               T* __restrict__ val_out, int32_t* __restrict__ colcount) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nkeep) return;
+  const unsigned long long k = keys[p];
+  inner_out[p] = (int32_t)(k & 0xffffffffull);
+  val_out[p] = val[payload[p]];
+  atomicAdd(&colcount[(int)(k >> 32)], 1);
+}
+__global__ void k_count_valid(const unsigned long long* __restrict__ keys, int64_t n,
+                              unsigned long long* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && keys[p] != ~0ull) atomicAdd(out, 1ull);
+}
+
+// column slicing / concatenation
+__global__ void k_shift_outer(const int64_t* __restrict__ in, int64_t* __restrict__ out, int n, int64_t shift) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j <= n) out[j] = in[j] + shift;
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+template <typename F>
+void dispatch_type(bool cplx, F&& f) {
+  if (cplx) f(double2{});
+  else f(double{});
+}
+
+}  // namespace
+
+// =====================================================================================
+EngineOptions& options() {
+  static EngineOptions o;
+  return o;
+}
+SpgemmStats& last_spgemm_stats() {
+  static SpgemmStats s;
+  return s;
+}
+SpgemmAccum& spgemm_accum() {
+  static SpgemmAccum a;
+  return a;
+}
+
+int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n) {
+  hipLaunchKernelGGL(k_scan_excl_i64, dim3(1), dim3(1024), 0, stream(), d_in, d_out, n);
+  int64_t total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, d_out + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  return total;
+}
+
+namespace {
+struct EventTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on;
+  explicit EventTimer(bool enable) : on(enable) {
+    if (on) {
+      HIP_CHECK(hipEventCreate(&a));
+      HIP_CHECK(hipEventCreate(&b));
+    }
+  }
+  void start() { if (on) HIP_CHECK(hipEventRecord(a, stream())); }
+  void stop() { if (on) HIP_CHECK(hipEventRecord(b, stream())); }
+  float ms() {
+    if (!on) return 0.f;
+    float t = 0.f;
+    HIP_CHECK(hipEventSynchronize(b));
+    HIP_CHECK(hipEventElapsedTime(&t, a, b));
+    return t;
+  }
+  ~EventTimer() {
+    if (on) {
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+    }
+  }
+};
+
+template <typename T, int W, int NW>
+void launch_window(int bin, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
+                   const uint8_t* binarr, const int64_t* tmpoff, int32_t* out_inner, T* out_val,
+                   int32_t* count, double alpha, double thr, int dense_rule) {
+  const int nblocks = cdiv(B.cols, NW);
+  hipLaunchKernelGGL((k_spgemm_window<T, W, NW>), dim3(xcd_grid(nblocks)), dim3(NW * WAVE), 0, stream(),
+                     view(A), view(B), lo, span, binarr, bin, tmpoff, out_inner, out_val, count, alpha, thr,
+                     dense_rule, nblocks);
+}
+}  // namespace
+
+void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {
+  if (A.cols != B.rows) NTP_FATAL("spgemm: inner dimensions differ");
+  if (A.cplx != B.cplx) NTP_FATAL("spgemm: mixed scalar types must be up-cast by the caller");
+  const int32_t m = A.rows, n = B.cols;
+  SpgemmStats st;
+  st.nnz_a = A.nnz;
+  st.nnz_b = B.nnz;
+  if (A.nnz == 0 || B.nnz == 0 || n == 0 || m == 0) {
+    C.reset_empty(m, n, A.cplx);
+    last_spgemm_stats() = st;
+    return;
+  }
+  const bool timing = options().time_kernels != 0;
+  EventTimer t_all(timing), t_num(timing);
+  t_all.start();
+  DevBuf<int32_t> cmin(A.cols), cmax(A.cols), clen(A.cols);
+  hipLaunchKernelGGL(k_col_extent, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), view(A), cmin.p, cmax.p, clen.p);
+  DevBuf<int32_t> lo(n), span(n), count(n);
+  DevBuf<uint8_t> bin(n);
+  DevBuf<int64_t> ub(n + 1), ip(n), tmpoff(n + 1);
+  DevBuf<unsigned long long> stats(16);
+  stats.zero();
+  count.zero();
+  hipLaunchKernelGGL(k_spgemm_plan, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(B), cmin.p,
+                     cmax.p, clen.p, lo.p, span.p, bin.p, ub.p, ip.p, stats.p, options().spgemm_force_bin);
+  hipLaunchKernelGGL(k_scan_excl_i64, dim3(1), dim3(1024), 0, stream(), ub.p, tmpoff.p, (int64_t)n);
+  unsigned long long hstats[16];
+  int64_t tmp_total = 0;
+  HIP_CHECK(hipMemcpyAsync(hstats, stats.p, sizeof(hstats), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipMemcpyAsync(&tmp_total, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  for (int i = 0; i < 6; ++i) st.bin_cols[i] = (int64_t)hstats[i];
+  st.bin_cols[5] += (int64_t)hstats[6];
+  st.products = (int64_t)hstats[7];
+  st.tmp_entries = tmp_total;
+
+  DevBuf<int32_t> tmp_inner((size_t)tmp_total);
+  DevBuf<double> tmp_val((size_t)tmp_total * A.wval());
+  DevBuf<int32_t> tmp2_inner;
+  DevBuf<double> tmp2_val;
+  DevBuf<int64_t> tmpoff2;
+  const int dr = dense_rule ? 1 : 0;
+  t_num.start();
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    T* tv = reinterpret_cast<T*>(tmp_val.p);
+    if (hstats[1]) launch_window<T, 512, 4>(1, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
+    if (hstats[2]) launch_window<T, 1024, 4>(2, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
+    if (hstats[3]) launch_window<T, 2048, 2>(3, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
+    if (hstats[4]) launch_window<T, 4096, 1>(4, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
+    if (hstats[5]) {
+      hipLaunchKernelGGL((k_spgemm_hash<T>), dim3(xcd_grid(n)), dim3(WAVE), 0, stream(), view(A), view(B), span.p,
+                         bin.p, tmpoff.p, tmp_inner.p, tv, count.p, stats.p, alpha, threshold, dr, n);
+    }
+  });
+  // columns that overflowed the LDS hash (or were forced) go through the HBM accumulator
+  unsigned long long overflow = hstats[6];
+  if (hstats[5]) {
+    unsigned long long ov = 0;
+    HIP_CHECK(hipMemcpyAsync(&ov, stats.p + 8, sizeof(ov), hipMemcpyDeviceToHost, stream()));
+    sync_stream();
+    overflow += ov;
+  }
+  st.overflow_cols = (int64_t)overflow;
+  if (overflow) {
+    DevBuf<int64_t> ub2(n + 1);
+    tmpoff2.alloc(n + 1);
+    hipLaunchKernelGGL(k_hbm_ub, dim3(cdiv(n, 256)), dim3(256), 0, stream(), bin.p, span.p, ip.p, ub2.p, n);
+    const int64_t total2 = exclusive_scan_i64(ub2.p, tmpoff2.p, n);
+    tmp2_inner.alloc((size_t)total2);
+    tmp2_val.alloc((size_t)total2 * A.wval());
+    const int nwaves = (int)std::min<int64_t>(overflow, 1024);
+    DevBuf<double> ws((size_t)nwaves * (size_t)m * A.wval());
+    ws.zero();
+    dispatch_type(A.cplx, [&](auto tag) {
+      using T = decltype(tag);
+      hipLaunchKernelGGL((k_spgemm_hbm<T>), dim3(nwaves), dim3(WAVE), 0, stream(), view(A), view(B), lo.p, span.p,
+                         bin.p, tmpoff2.p, tmp2_inner.p, reinterpret_cast<T*>(tmp2_val.p), count.p, ws.p, alpha,
+                         threshold, dr);
+    });
+    sync_stream();  // ws is released below
+  }
+  t_num.stop();
+
+  // exact column pointers, then move every column to its final place
+  C.rows = m;
+  C.cols = n;
+  C.cplx = A.cplx;
+  C.outer.alloc((size_t)n + 1);
+  hipLaunchKernelGGL(k_scan_excl_i32, dim3(1), dim3(1024), 0, stream(), count.p, C.outer.p, (int64_t)n);
+  int64_t nnz = 0;
+  HIP_CHECK(hipMemcpyAsync(&nnz, C.outer.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  C.nnz = nnz;
+  C.inner.alloc((size_t)nnz);
+  C.val.alloc((size_t)nnz * C.wval());
+  const int nblocks = cdiv(n, 4);
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_compact<T>), dim3(xcd_grid(nblocks)), dim3(256), 0, stream(), n, tmpoff.p,
+                       overflow ? tmpoff2.p : nullptr, overflow ? bin.p : nullptr, C.outer.p, tmp_inner.p,
+                       reinterpret_cast<const T*>(tmp_val.p), tmp2_inner.p, reinterpret_cast<const T*>(tmp2_val.p),
+                       C.inner.p, reinterpret_cast<T*>(C.val.p), nblocks);
+  });
+  t_all.stop();
+  st.nnz_c = nnz;
+  if (timing) {
+    st.ms_numeric = t_num.ms();
+    st.ms_total = t_all.ms();
+  }
+  last_spgemm_stats() = st;
+  SpgemmAccum& acc = spgemm_accum();
+  acc.calls += 1;
+  acc.products += st.products;
+  acc.nnz_c += nnz;
+  const double per = A.cplx ? 20.0 : 12.0;
+  acc.alg_bytes += per * (double)(A.nnz + B.nnz + nnz) + 4.0 * ((double)A.cols + B.cols + n + 3);
+  acc.ms_numeric += st.ms_numeric;
+  acc.ms_total += st.ms_total;
+  if (timing) sync_stream();
+}
+
+// -------------------------------------------------------------------------------------
+void increment(const DevMat& A, DevMat& B, double alpha, double threshold) {
+  if (A.rows != B.rows || A.cols != B.cols) NTP_FATAL("increment: shape mismatch");
+  if (A.cplx != B.cplx) NTP_FATAL("increment: mixed scalar types must be up-cast by the caller");
+  const int n = A.cols;
+  if (n == 0) return;
+  if (A.nnz == 0 && B.nnz == 0) return;
+  DevBuf<int32_t> lo(n), span(n), count(n);
+  DevBuf<uint8_t> bin(n);
+  DevBuf<unsigned long long> stats(8);
+  stats.zero();
+  count.zero();
+  hipLaunchKernelGGL(k_inc_plan, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(A), view(B), lo.p, span.p, bin.p,
+                     stats.p, options().increment_force_seq);
+  unsigned long long hs[8];
+  HIP_CHECK(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  const int64_t cap = A.nnz + B.nnz;
+  DevBuf<int32_t> tmp_inner((size_t)cap);
+  DevBuf<double> tmp_val((size_t)cap * A.wval());
+  DevBuf<int64_t> srcoff((size_t)n + 1);
+  hipLaunchKernelGGL(k_sum_outer, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), A.outer.p, B.outer.p, srcoff.p, n);
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    T* tv = reinterpret_cast<T*>(tmp_val.p);
+    if (hs[1]) {
+      const int nb = cdiv(n, 4);
+      hipLaunchKernelGGL((k_inc_window<T, 512, 4>), dim3(xcd_grid(nb)), dim3(256), 0, stream(), view(A), view(B), lo.p,
+                         span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, threshold, nb);
+    }
+    if (hs[2]) {
+      const int nb = n;
+      hipLaunchKernelGGL((k_inc_window<T, 2048, 1>), dim3(xcd_grid(nb)), dim3(WAVE), 0, stream(), view(A), view(B),
+                         lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, threshold, nb);
+    }
+    if (hs[3]) {
+      hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), view(A), view(B), bin.p, 3,
+                         tmp_inner.p, tv, count.p, alpha, threshold);
+    }
+  });
+  DevMat R;
+  R.rows = A.rows;
+  R.cols = n;
+  R.cplx = A.cplx;
+  R.outer.alloc((size_t)n + 1);
+  hipLaunchKernelGGL(k_scan_excl_i32, dim3(1), dim3(1024), 0, stream(), count.p, R.outer.p, (int64_t)n);
+  int64_t nnz = 0;
+  HIP_CHECK(hipMemcpyAsync(&nnz, R.outer.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  R.nnz = nnz;
+  R.inner.alloc((size_t)nnz);
+  R.val.alloc((size_t)nnz * R.wval());
+  const int nblocks = cdiv(n, 4);
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_compact<T>), dim3(xcd_grid(nblocks)), dim3(256), 0, stream(), n, srcoff.p, nullptr, nullptr,
+                       R.outer.p, tmp_inner.p, reinterpret_cast<const T*>(tmp_val.p), nullptr, nullptr, R.inner.p,
+                       reinterpret_cast<T*>(R.val.p), nblocks);
+  });
+  B = std::move(R);
+}
+
+void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a) {
+  if (A.rows != B.rows || A.cols != B.cols || A.cplx != B.cplx) NTP_FATAL("pairwise: operand mismatch");
+  const int n = A.cols;
+  DevMat R;
+  R.rows = A.rows;
+  R.cols = n;
+  R.cplx = A.cplx;
+  R.outer.alloc((size_t)n + 1);
+  DevBuf<int32_t> count((size_t)n);
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_pairwise<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), view(A), view(B), nullptr, nullptr,
+                       (T*)nullptr, count.p, 0);
+  });
+  hipLaunchKernelGGL(k_scan_excl_i32, dim3(1), dim3(1024), 0, stream(), count.p, R.outer.p, (int64_t)n);
+  int64_t nnz = 0;
+  HIP_CHECK(hipMemcpyAsync(&nnz, R.outer.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  R.nnz = nnz;
+  R.inner.alloc((size_t)nnz);
+  R.val.alloc((size_t)nnz * R.wval());
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_pairwise<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), view(A), view(B), R.outer.p,
+                       R.inner.p, reinterpret_cast<T*>(R.val.p), nullptr, conj_a ? 1 : 0);
+  });
+  C = std::move(R);
+}
+
+namespace {
+void finish_sum2(DevBuf<double>& partial, int nb, double out[2]) {
+  DevBuf<double> res(2);
+  hipLaunchKernelGGL(k_reduce_sum2, dim3(1), dim3(256), 0, stream(), partial.p, nb, res.p);
+  res.download(out, 2);
+}
+}  // namespace
+
+void dot(const DevMat& A, const DevMat& B, double out[2]) {
+  if (A.rows != B.rows || A.cols != B.cols || A.cplx != B.cplx) NTP_FATAL("dot: operand mismatch");
+  out[0] = out[1] = 0;
+  if (A.nnz == 0 || B.nnz == 0) return;
+  const int nb = std::min(cdiv(A.cols, 4), 4096);
+  DevBuf<double> partial((size_t)2 * nb);
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(256), 0, stream(), view(A), view(B), partial.p, nb);
+  });
+  finish_sum2(partial, nb, out);
+}
+
+void grand_sum(const DevMat& A, double out[2]) {
+  out[0] = out[1] = 0;
+  if (A.nnz == 0) return;
+  const int nb = std::min(cdiv(A.nnz, 256), 2048);
+  DevBuf<double> partial((size_t)2 * nb);
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_grand_sum<T>), dim3(nb), dim3(256), 0, stream(), reinterpret_cast<const T*>(A.val.p), A.nnz,
+                       partial.p);
+  });
+  finish_sum2(partial, nb, out);
+}
+
+double trace(const DevMat& A, int32_t col_offset) {
+  if (A.nnz == 0) return 0.0;
+  const int nb = std::min(cdiv(A.cols, 256), 1024);
+  DevBuf<double> partial((size_t)2 * nb);
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_trace<T>), dim3(nb), dim3(256), 0, stream(), view(A), col_offset, partial.p);
+  });
+  double out[2];
+  finish_sum2(partial, nb, out);
+  return out[0];
+}
+
+void column_abs_sums(const DevMat& A, DevBuf<double>& out) {
+  out.alloc((size_t)A.cols);
+  if (A.cols == 0) return;
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_colstat<T>), dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), 0, 0,
+                       out.p, (double*)nullptr);
+  });
+}
+
+double max_of(const DevBuf<double>& v, size_t n) {
+  if (n == 0) return 0.0;
+  DevBuf<double> res(2);
+  hipLaunchKernelGGL(k_reduce_minmax, dim3(1), dim3(256), 0, stream(), (const double*)nullptr, v.p, (int64_t)n, res.p);
+  double h[2];
+  res.download(h, 2);
+  return h[1];
+}
+
+void gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx) {
+  if (A.cols == 0) { *mn = INFINITY; *mx = -INFINITY; return; }
+  DevBuf<double> lo((size_t)A.cols), hi((size_t)A.cols), res(2);
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_colstat<T>), dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A),
+                       col_offset, 1, lo.p, hi.p);
+  });
+  hipLaunchKernelGGL(k_reduce_minmax, dim3(1), dim3(256), 0, stream(), lo.p, hi.p, (int64_t)A.cols, res.p);
+  double h[2];
+  res.download(h, 2);
+  *mn = h[0];
+  *mx = h[1];
+}
+
+void scale(DevMat& A, double c) {
+  const int64_t n = A.nnz * (int64_t)A.wval();
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_scale, dim3(std::min(cdiv(n, 256), 8192)), dim3(256), 0, stream(), A.val.p, n, c);
+}
+
+void conjugate(DevMat& A) {
+  if (!A.cplx || A.nnz == 0) return;
+  hipLaunchKernelGGL(k_conj, dim3(std::min(cdiv(A.nnz, 256), 8192)), dim3(256), 0, stream(), A.val.p, A.nnz);
+}
+
+DevMat to_complex(const DevMat& A) {
+  if (A.cplx) return A.clone();
+  DevMat R;
+  R.alloc(A.rows, A.cols, true, A.nnz);
+  HIP_CHECK(hipMemcpyAsync(R.outer.p, A.outer.p, sizeof(int64_t) * ((size_t)A.cols + 1), hipMemcpyDeviceToDevice, stream()));
+  if (A.nnz) {
+    HIP_CHECK(hipMemcpyAsync(R.inner.p, A.inner.p, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToDevice, stream()));
+    hipLaunchKernelGGL(k_to_complex, dim3(std::min(cdiv(A.nnz, 256), 8192)), dim3(256), 0, stream(), A.val.p, R.val.p, A.nnz);
+  }
+  return R;
+}
+
+DevMat to_real(const DevMat& A) {
+  if (!A.cplx) return A.clone();
+  DevMat R;
+  R.alloc(A.rows, A.cols, false, A.nnz);
+  HIP_CHECK(hipMemcpyAsync(R.outer.p, A.outer.p, sizeof(int64_t) * ((size_t)A.cols + 1), hipMemcpyDeviceToDevice, stream()));
+  if (A.nnz) {
+    HIP_CHECK(hipMemcpyAsync(R.inner.p, A.inner.p, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToDevice, stream()));
+    hipLaunchKernelGGL(k_to_real, dim3(std::min(cdiv(A.nnz, 256), 8192)), dim3(256), 0, stream(), A.val.p, R.val.p, A.nnz);
+  }
+  return R;
+}
+
+DevMat identity(int32_t n, int32_t col_offset, int32_t cols, bool cplx) {
+  const int64_t ones = std::max<int64_t>(0, std::min<int64_t>(cols, (int64_t)n - col_offset));
+  DevMat R;
+  R.alloc(n, cols, cplx, ones);
+  hipLaunchKernelGGL(k_identity, dim3(cdiv(cols + 1, 256)), dim3(256), 0, stream(), R.outer.p, R.inner.p, R.val.p, n,
+                     col_offset, cols, cplx ? 1 : 0);
+  return R;
+}
+
+int64_t identity_check(const DevMat& A, int32_t col_offset) {
+  if (A.cols == 0) return 0;
+  DevBuf<unsigned long long> flags(2);
+  flags.zero();
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_identity_check<T>), dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), view(A), col_offset, flags.p);
+  });
+  unsigned long long h[2];
+  flags.download(h, 2);
+  return h[0] ? -1 : (int64_t)h[1];
+}
+
+namespace {
+DevMat remap_impl(const DevMat& A, const int32_t* d_row_map, const int32_t* d_col_map, bool transpose_after,
+                  int32_t new_rows, int32_t col_lo, int32_t col_hi, bool drop_zero) {
+  const int32_t new_cols = col_hi - col_lo;
+  DevMat R;
+  if (A.nnz == 0) {
+    R.reset_empty(new_rows, new_cols, A.cplx);
+    return R;
+  }
+  const int64_t nnz = A.nnz;
+  DevBuf<int32_t> colidx((size_t)nnz);
+  hipLaunchKernelGGL(k_expand_cols, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.outer.p, A.cols, colidx.p);
+  DevBuf<unsigned long long> keys((size_t)nnz), keys2((size_t)nnz), nvalid(1);
+  DevBuf<unsigned int> pay((size_t)nnz), pay2((size_t)nnz);
+  nvalid.zero();
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_remap_keys<T>), dim3(cdiv(nnz, 256)), dim3(256), 0, stream(), colidx.p, A.inner.p,
+                       reinterpret_cast<const T*>(A.val.p), nnz, d_row_map, d_col_map, transpose_after ? 1 : 0, col_lo,
+                       col_hi, drop_zero ? 1 : 0, keys.p, pay.p);
+  });
+  hipLaunchKernelGGL(k_count_valid, dim3(cdiv(nnz, 256)), dim3(256), 0, stream(), keys.p, nnz, nvalid.p);
+  size_t tmp_bytes = 0;
+  HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.p, keys2.p, pay.p, pay2.p, (size_t)nnz, 0, 64, stream()));
+  DevBuf<char> tmp(tmp_bytes);
+  HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.p, keys2.p, pay.p, pay2.p, (size_t)nnz, 0, 64, stream()));
+  unsigned long long nkeep = 0;
+  nvalid.download(&nkeep, 1);
+  R.alloc(new_rows, new_cols, A.cplx, (int64_t)nkeep);
+  DevBuf<int32_t> colcount((size_t)new_cols + 1);
+  colcount.zero();
+  if (nkeep) {
+    dispatch_type(A.cplx, [&](auto tag) {
+      using T = decltype(tag);
+      hipLaunchKernelGGL((k_remap_gather<T>), dim3(cdiv((int64_t)nkeep, 256)), dim3(256), 0, stream(), keys2.p, pay2.p,
+                         (int64_t)nkeep, reinterpret_cast<const T*>(A.val.p), R.inner.p, reinterpret_cast<T*>(R.val.p),
+                         colcount.p);
+    });
+  }
+  hipLaunchKernelGGL(k_scan_excl_i32, dim3(1), dim3(1024), 0, stream(), colcount.p, R.outer.p, (int64_t)new_cols);
+  sync_stream();
+  return R;
+}
+}  // namespace
+
+DevMat transpose(const DevMat& A) { return remap_impl(A, nullptr, nullptr, true, A.cols, 0, A.rows, false); }
+
+DevMat remap_general(const DevMat& A, const int32_t* d_row_map, const int32_t* d_col_map, int32_t new_rows,
+                     int32_t col_lo, int32_t col_hi, bool drop_exact_zeros) {
+  return remap_impl(A, d_row_map, d_col_map, false, new_rows, col_lo, col_hi, drop_exact_zeros);
+}
+DevMat transpose_slice(const DevMat& A, int32_t col_lo, int32_t col_hi) {
+  return remap_impl(A, nullptr, nullptr, true, A.cols, col_lo, col_hi, false);
+}
+
+void copy_shift_i64(const int64_t* d_src, int64_t* d_dst, int64_t count, int64_t shift) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_shift_outer, dim3(cdiv(count, 256)), dim3(256), 0, stream(), d_src, d_dst, (int)(count - 1), shift);
+}
+
+DevMat column_slice(const DevMat& A, int32_t c0, int32_t c1) {
+  int64_t h[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(&h[0], A.outer.p + c0, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipMemcpyAsync(&h[1], A.outer.p + c1, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  DevMat R;
+  R.alloc(A.rows, c1 - c0, A.cplx, h[1] - h[0]);
+  hipLaunchKernelGGL(k_shift_outer, dim3(cdiv(c1 - c0 + 1, 256)), dim3(256), 0, stream(), A.outer.p + c0, R.outer.p, c1 - c0, -h[0]);
+  if (R.nnz) {
+    HIP_CHECK(hipMemcpyAsync(R.inner.p, A.inner.p + h[0], sizeof(int32_t) * (size_t)R.nnz, hipMemcpyDeviceToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(R.val.p, A.val.p + h[0] * (int64_t)A.wval(), sizeof(double) * (size_t)R.nnz * A.wval(), hipMemcpyDeviceToDevice, stream()));
+  }
+  return R;
+}
+
+DevMat concat_columns(const std::vector<const DevMat*>& parts) {
+  if (parts.empty()) NTP_FATAL("concat_columns: no parts");
+  int32_t cols = 0;
+  int64_t nnz = 0;
+  for (auto* p : parts) { cols += p->cols; nnz += p->nnz; }
+  DevMat R;
+  R.alloc(parts[0]->rows, cols, parts[0]->cplx, nnz);
+  int32_t c = 0;
+  int64_t z = 0;
+  for (auto* p : parts) {
+    hipLaunchKernelGGL(k_shift_outer, dim3(cdiv(p->cols + 1, 256)), dim3(256), 0, stream(), p->outer.p, R.outer.p + c, p->cols, z);
+    if (p->nnz) {
+      HIP_CHECK(hipMemcpyAsync(R.inner.p + z, p->inner.p, sizeof(int32_t) * (size_t)p->nnz, hipMemcpyDeviceToDevice, stream()));
+      HIP_CHECK(hipMemcpyAsync(R.val.p + z * (int64_t)R.wval(), p->val.p, sizeof(double) * (size_t)p->nnz * R.wval(), hipMemcpyDeviceToDevice, stream()));
+    }
+    c += p->cols;
+    z += p->nnz;
+  }
+  return R;
+}
+
+DevMat from_triplets(const HostTriplets& t, int32_t rows, int32_t cols, int32_t col_offset) {
+  // SortTripletList + ConstructMatrixFromTripletList (triplet_includes/SortTripletList.f90:20-67,
+  // sparse_includes/ConstructMatrixFromTripletList.f90:17-27); host-side: the caller hands over
+  // host memory (setup path)
+  const size_t n = t.size();
+  std::vector<size_t> order;
+  order.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t c = t.col[i] - 1 - col_offset;
+    if (c >= 0 && c < cols) order.push_back(i);
+  }
+  auto less = [&](size_t a, size_t b) {
+    if (t.col[a] != t.col[b]) return t.col[a] < t.col[b];
+    return t.row[a] < t.row[b];
+  };
+  if (!std::is_sorted(order.begin(), order.end(), less)) std::stable_sort(order.begin(), order.end(), less);
+  const size_t m = order.size();
+  const size_t w = t.cplx ? 2 : 1;
+  std::vector<int64_t> outer((size_t)cols + 1, 0);
+  std::vector<int32_t> inner(m);
+  std::vector<double> val(m * w);
+  for (size_t i = 0; i < m; ++i) {
+    const size_t s = order[i];
+    outer[(size_t)(t.col[s] - 1 - col_offset) + 1] += 1;
+    inner[i] = t.row[s] - 1;
+    for (size_t k = 0; k < w; ++k) val[i * w + k] = t.val[s * w + k];
+  }
+  for (int32_t j = 0; j < cols; ++j) outer[(size_t)j + 1] += outer[(size_t)j];
+  DevMat R;
+  R.alloc(rows, cols, t.cplx, (int64_t)m);
+  R.outer.upload(outer.data(), outer.size());
+  R.inner.upload(inner.data(), m);
+  R.val.upload(val.data(), m * w);
+  sync_stream();
+  return R;
+}
+
+void to_triplets(const DevMat& A, int32_t col_offset, HostTriplets& out) {
+  const size_t n = (size_t)A.nnz, w = A.wval();
+  std::vector<int64_t> outer((size_t)A.cols + 1);
+  out.cplx = A.cplx;
+  out.col.resize(n);
+  out.row.resize(n);
+  out.val.resize(n * w);
+  A.outer.download(outer.data(), outer.size());
+  if (n) {
+    A.inner.download(out.row.data(), n);
+    A.val.download(out.val.data(), n * w);
+  }
+  for (int32_t j = 0; j < A.cols; ++j)
+    for (int64_t p = outer[(size_t)j]; p < outer[(size_t)j + 1]; ++p) out.col[(size_t)p] = j + 1 + col_offset;
+  for (size_t i = 0; i < n; ++i) out.row[i] += 1;
+}
+
+}  // namespace ntp

@@ -1,0 +1,80 @@
+// Launchers of the hand-written gfx950 kernels (kernels.hip).  Everything operates on
+// device-resident column-compressed matrices (DevMat) on ctx().stream.
+#pragma once
+#include "common.hpp"
+
+namespace ntp {
+
+// Per-call statistics of the SpGEMM (for bench.py's roofline accounting).
+struct SpgemmStats {
+  int64_t nnz_a = 0, nnz_b = 0, nnz_c = 0;
+  int64_t products = 0;        // intermediate products IP = sum_j sum_{k in B(:,j)} nnz(A(:,k))
+  int64_t tmp_entries = 0;     // upper-bound entries reserved for the numeric pass
+  int64_t bin_cols[6] = {0, 0, 0, 0, 0, 0};
+  int64_t overflow_cols = 0;   // columns that left the LDS hash for the HBM accumulator
+  float ms_total = 0.f;        // filled only when timing is enabled
+  float ms_numeric = 0.f;
+};
+
+struct EngineOptions {
+  int spgemm_force_bin = -1;   // tests: force every non-empty column through one path (1..5), 6 = HBM fallback
+  int increment_force_seq = 0; // tests: force the sequential-merge fallback
+  int time_kernels = 0;        // record HIP-event timings in SpgemmStats
+};
+EngineOptions& options();
+SpgemmStats& last_spgemm_stats();
+// accumulated since reset: number of calls, products, algorithmic bytes, numeric-kernel ms
+struct SpgemmAccum { int64_t calls = 0, products = 0, nnz_c = 0; double alg_bytes = 0, ms_numeric = 0, ms_total = 0; };
+SpgemmAccum& spgemm_accum();
+
+// C = alpha * A * B with NTPoly's prune rule.  A: (m x k), B: (k x n), same scalar type.
+// dense_rule = the reference's dense-branch order (threshold before alpha, DenseBranch.f90:14-15).
+void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold,
+            bool dense_rule);
+
+// B <- alpha*A + B (AddSparseVectors semantics), same shape and scalar type.
+void increment(const DevMat& A, DevMat& B, double alpha, double threshold);
+// C = A .* B on the intersection of the patterns (conj_a: conjugate A first)
+void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a);
+// out = sum conj(A) .* B  (out[1] = imaginary part, 0 for real)
+void dot(const DevMat& A, const DevMat& B, double out[2]);
+void grand_sum(const DevMat& A, double out[2]);
+// sum of the real parts of entries with row == col + col_offset
+double trace(const DevMat& A, int32_t col_offset);
+// per-column sum |v| -> out[cols]
+void column_abs_sums(const DevMat& A, DevBuf<double>& out);
+double max_of(const DevBuf<double>& v, size_t n);
+// per-column Gershgorin discs -> min over columns of (d - r), max of (d + r)
+void gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx);
+void scale(DevMat& A, double c);
+void conjugate(DevMat& A);
+DevMat to_complex(const DevMat& A);
+DevMat to_real(const DevMat& A);
+// identity restricted to local columns [col_offset, col_offset+cols) of an n x n matrix
+DevMat identity(int32_t n, int32_t col_offset, int32_t cols, bool cplx);
+// is it exactly the (local part of the) identity?  returns number of diagonal ones or -1
+int64_t identity_check(const DevMat& A, int32_t col_offset);
+DevMat transpose(const DevMat& A);
+// general re-indexing: entry (i, j) -> (row_map[i], col_map[j]) (0-based device maps, may be null
+// = identity); entries whose mapped column falls outside [col_lo, col_hi) are dropped, columns are
+// stored relative to col_lo; the result is sorted.  drop_exact_zeros mimics a threshold-0 multiply
+// with a permutation matrix (LoadBalancerModule.F90:38-47), which prunes stored zeros.
+DevMat remap_general(const DevMat& A, const int32_t* d_row_map, const int32_t* d_col_map, int32_t new_rows,
+                     int32_t col_lo, int32_t col_hi, bool drop_exact_zeros);
+// columns [col_lo, col_hi) of A^T
+DevMat transpose_slice(const DevMat& A, int32_t col_lo, int32_t col_hi);
+// columns [c0, c1) of A as a new matrix
+DevMat column_slice(const DevMat& A, int32_t c0, int32_t c1);
+// concatenate column panels (all with the same rows / scalar type)
+DevMat concat_columns(const std::vector<const DevMat*>& parts);
+
+DevMat from_triplets(const HostTriplets& t, int32_t rows, int32_t cols, int32_t col_offset);
+void to_triplets(const DevMat& A, int32_t col_offset, HostTriplets& out);
+
+// dst[i] = src[i] + shift for i < count
+void copy_shift_i64(const int64_t* d_src, int64_t* d_dst, int64_t count, int64_t shift);
+
+// exclusive scan helper (device), out[n] = total; returns total (synchronises)
+int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n);
+
+}  // namespace ntp

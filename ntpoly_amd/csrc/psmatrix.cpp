@@ -1,0 +1,416 @@
+// Distributed matrix (Matrix_ps) and distributed algebra on column panels.
+// Reference: PSMatrixModule.F90, PSMatrixAlgebraModule.F90, ProcessGridModule.F90,
+// LoadBalancerModule.F90, PermutationModule.F90.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <random>
+
+#include "engine.hpp"
+
+namespace ntp {
+
+// ------------------------------------------------------------------ process grid
+namespace {
+ProcessGrid g_grid;
+bool g_grid_built = false;
+}  // namespace
+ProcessGrid& global_grid() { return g_grid; }
+bool global_grid_constructed() { return g_grid_built; }
+
+void construct_grid(ProcessGrid& g, int rows, int cols, int slices) {
+  const Comm& c = world();
+  // grid sanity check (ProcessGridModule.F90:162-176): fatal if the shape does not match
+  if (rows * cols * slices != c.nranks)
+    NTP_FATAL("process grid " + std::to_string(rows) + "x" + std::to_string(cols) + "x" + std::to_string(slices) +
+              " does not match " + std::to_string(c.nranks) + " processes");
+  g.num_rows = rows;
+  g.num_cols = cols;
+  g.num_slices = slices;
+  g.total = c.nranks;
+  g.global_rank = c.rank;
+  // rank -> (slice, row, column) as ProcessGridModule.F90:180-183
+  const int slice_size = rows * cols;
+  g.my_slice = c.rank / slice_size;
+  const int in_slice = c.rank - slice_size * g.my_slice;
+  g.my_row = in_slice / cols;
+  g.my_col = in_slice % cols;
+  if (&g == &g_grid) g_grid_built = true;
+}
+
+void construct_grid_default(ProcessGrid& g, int slices) {
+  // ComputeGridSize (ProcessGridModule.F90:576-601): most square rows x cols for the given slices
+  const int total = world().nranks;
+  if (slices <= 0) slices = 1;
+  while (total % slices != 0) --slices;
+  const int slice_size = total / slices;
+  int rows = 1, cols = slice_size;
+  for (int r = (int)std::floor(std::sqrt((double)slice_size)); r >= 1; --r) {
+    if (slice_size % r == 0) {
+      rows = r;
+      cols = slice_size / r;
+      break;
+    }
+  }
+  construct_grid(g, rows, cols, slices);
+}
+
+void write_grid_info(const ProcessGrid& g) {
+  log_header("Process Grid");
+  log_enter();
+  log_element("Process Rows", g.num_rows);
+  log_element("Process Columns", g.num_cols);
+  log_element("Process Slices", g.num_slices);
+  log_element("Column Panels (GPUs)", g.total);
+  log_exit();
+}
+
+// ------------------------------------------------------------------ construction / fill
+void panel_range(int32_t dim, int nranks, int rank, int32_t* c0, int32_t* c1) {
+  *c0 = (int32_t)(((int64_t)dim * rank) / nranks);
+  *c1 = (int32_t)(((int64_t)dim * (rank + 1)) / nranks);
+}
+
+void ps_construct_empty(PSMatrix& m, int32_t dim, const ProcessGrid* g, bool cplx) {
+  if (!g) NTP_FATAL("matrix constructed without a process grid (construct the global grid first)");
+  ensure_init();
+  m.grid = g;
+  m.dim = dim;
+  m.cplx = cplx;
+  panel_range(dim, world().nranks, world().rank, &m.c0, &m.c1);
+  m.loc.reset_empty(dim, m.c1 - m.c0, cplx);
+}
+
+void ps_construct_like(PSMatrix& m, const PSMatrix& ref) { ps_construct_empty(m, ref.dim, ref.grid, ref.cplx); }
+
+void ps_copy(const PSMatrix& a, PSMatrix& b) {
+  if (&a == &b) return;
+  DevMat t = a.loc.clone();
+  b.grid = a.grid;
+  b.dim = a.dim;
+  b.cplx = a.cplx;
+  b.c0 = a.c0;
+  b.c1 = a.c1;
+  b.loc = std::move(t);
+}
+
+void ps_fill_identity(PSMatrix& m) {  // FillMatrixIdentity (O(N) here, O(N^2/P) in the reference)
+  m.loc = identity(m.dim, m.c0, m.c1 - m.c0, m.cplx);
+}
+
+void ps_fill_permutation(PSMatrix& m, const std::vector<int32_t>& lookup, bool rows) {
+  // distributed_includes/FillMatrixPermutation.f90:1-35
+  HostTriplets t;
+  t.cplx = m.cplx;
+  const size_t w = m.cplx ? 2 : 1;
+  for (int32_t ii = 1; ii <= m.dim; ++ii) {
+    const int32_t col = rows ? lookup[(size_t)ii - 1] : ii;
+    const int32_t row = rows ? ii : lookup[(size_t)ii - 1];
+    if (col - 1 >= m.c0 && col - 1 < m.c1) {
+      t.col.push_back(col);
+      t.row.push_back(row);
+      t.val.push_back(1.0);
+      if (w == 2) t.val.push_back(0.0);
+    }
+  }
+  m.loc = from_triplets(t, m.dim, m.c1 - m.c0, m.c0);
+}
+
+void ps_fill_from_triplets(PSMatrix& m, const HostTriplets& t) {
+  // FillMatrixFromTripletList (distributed_includes/FillMatrixFromTripletList.f90:14-47): any rank
+  // may hold any triplet.  Ranks exchange what they hold (setup path, host triplets travel through
+  // device buffers because RCCL moves device memory) and keep their own columns.
+  if (t.cplx != m.cplx) {
+    HostTriplets conv;
+    conv.cplx = m.cplx;
+    conv.col = t.col;
+    conv.row = t.row;
+    if (m.cplx) {
+      conv.val.resize(t.size() * 2);
+      for (size_t i = 0; i < t.size(); ++i) {
+        conv.val[2 * i] = t.val[i];
+        conv.val[2 * i + 1] = 0.0;
+      }
+    } else {
+      conv.val.resize(t.size());
+      for (size_t i = 0; i < t.size(); ++i) conv.val[i] = t.val[2 * i];
+    }
+    ps_fill_from_triplets(m, conv);
+    return;
+  }
+  if (!world().active()) {
+    m.loc = from_triplets(t, m.dim, m.c1 - m.c0, m.c0);
+    return;
+  }
+  // multi-rank: every rank turns what it holds into a full-width matrix, all of them are gathered
+  // (one grouped broadcast per rank) and each rank sums the pieces that fall into its own panel.
+  // Contributions of different ranks are disjoint by contract.
+  const int P = world().nranks;
+  DevMat mine = from_triplets(t, m.dim, m.dim, 0);
+  std::vector<int32_t> widths((size_t)P, m.dim);
+  DevMat all = gather_panels(mine, widths);  // dim x (P*dim), rank r's matrix at columns [r*dim, (r+1)*dim)
+  DevMat acc;
+  acc.reset_empty(m.dim, m.c1 - m.c0, m.cplx);
+  for (int r = 0; r < P; ++r) {
+    DevMat part = column_slice(all, r * m.dim + m.c0, r * m.dim + m.c1);
+    if (part.nnz) increment(part, acc, 1.0, 0.0);
+  }
+  m.loc = std::move(acc);
+}
+
+void ps_get_triplets(const PSMatrix& m, HostTriplets& t) { to_triplets(m.loc, m.c0, t); }
+
+int64_t ps_size(const PSMatrix& m) {  // GetMatrixSize (PSMatrixModule.F90:1360-1389)
+  int64_t n = m.loc.nnz;
+  comm_allreduce_sum_i64(&n, 1);
+  return n;
+}
+
+void ps_to_complex(const PSMatrix& a, PSMatrix& out) {
+  DevMat t = to_complex(a.loc);
+  out.grid = a.grid; out.dim = a.dim; out.c0 = a.c0; out.c1 = a.c1;
+  out.cplx = true;
+  out.loc = std::move(t);
+}
+void ps_to_real(const PSMatrix& a, PSMatrix& out) {
+  DevMat t = to_real(a.loc);
+  out.grid = a.grid; out.dim = a.dim; out.c0 = a.c0; out.c1 = a.c1;
+  out.cplx = false;
+  out.loc = std::move(t);
+}
+
+// ------------------------------------------------------------------ algebra
+// MatrixMultiply_ps (PSMatrixAlgebraModule.F90:108-211).  Column j of C needs column j of B
+// (local) and the columns of A named by B's row indices: rank r gathers the panels of A
+// (M1-M3) and multiplies them with its own panel of B; C comes out in the same panel layout, so
+// there is no reduction step (slices == 1 semantics: working_threshold = threshold,
+// distributed_algebra_includes/MatrixMultiply.f90:25-29).
+void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha, double beta, double threshold) {
+  if (A.dim != B.dim) NTP_FATAL("MatrixMultiply: dimension mismatch");
+  // up-casting of mixed real/complex operands (PSMatrixAlgebraModule.F90:171-188)
+  if (A.cplx != B.cplx) {
+    PSMatrix Ac, Bc;
+    ps_to_complex(A, Ac);
+    ps_to_complex(B, Bc);
+    ps_multiply(Ac, Bc, C, alpha, beta, threshold);
+    return;
+  }
+  // dense-branch rule of the local multiply (GemmMatrix.f90:49-61): only the order of threshold and
+  // alpha differs here, the arithmetic is the same hash-free sparse kernel
+  int64_t nz[2] = {A.loc.nnz, B.loc.nnz};
+  comm_allreduce_sum_i64(nz, 2);
+  const double denom = (double)A.dim * (double)A.dim;
+  const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
+  DevMat AB;
+  if (world().active()) {
+    DevMat Afull = ps_gather_full(A);
+    spgemm(Afull, B.loc, AB, alpha, threshold, dense_rule);
+  } else {
+    spgemm(A.loc, B.loc, AB, alpha, threshold, dense_rule);
+  }
+  // beta handling (MatrixMultiply.f90:324-329)
+  if (std::fabs(beta) < 2.2250738585072014e-308 || !C.constructed() || C.dim != A.dim) {
+    C.grid = A.grid; C.dim = A.dim; C.c0 = B.c0; C.c1 = B.c1;
+    C.cplx = A.cplx;
+    C.loc = std::move(AB);
+  } else {
+    if (C.cplx != A.cplx) {
+      PSMatrix Cc;
+      ps_to_complex(C, Cc);
+      C.cplx = true;
+      C.loc = std::move(Cc.loc);
+      if (!A.cplx) AB = to_complex(AB);
+    }
+    scale(C.loc, beta);
+    increment(AB, C.loc, 1.0, 0.0);
+  }
+}
+
+// IncrementMatrix_ps (PSMatrixAlgebraModule.F90:414-460)
+void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold) {
+  if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
+  if (A.cplx && !B.cplx) {
+    DevMat bc = to_complex(B.loc);
+    increment(A.loc, bc, alpha, threshold);
+    B.cplx = true;
+    B.loc = std::move(bc);
+  } else if (!A.cplx && B.cplx) {
+    DevMat ac = to_complex(A.loc);
+    increment(ac, B.loc, alpha, threshold);
+  } else if (&A == &B) {
+    DevMat a2 = A.loc.clone();
+    increment(a2, B.loc, alpha, threshold);
+  } else {
+    increment(A.loc, B.loc, alpha, threshold);
+  }
+}
+
+void ps_scale(PSMatrix& A, double c) { scale(A.loc, c); }
+
+void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {
+  if (A.cplx != B.cplx) {
+    PSMatrix Ac, Bc;
+    ps_to_complex(A, Ac);
+    ps_to_complex(B, Bc);
+    ps_pairwise(Ac, Bc, C);
+    return;
+  }
+  DevMat R;
+  pairwise(A.loc, B.loc, R, false);
+  C.grid = A.grid; C.dim = A.dim; C.c0 = A.c0; C.c1 = A.c1;
+  C.cplx = A.cplx;
+  C.loc = std::move(R);
+}
+
+// DotMatrix_psr/psc (PSMatrixAlgebraModule.F90:387-410, distributed_algebra_includes/DotMatrix.f90):
+// sum conj(A).B; fused, no Hadamard temporary.
+void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
+  if (A.cplx != B.cplx) {
+    PSMatrix Ac, Bc;
+    ps_to_complex(A, Ac);
+    ps_to_complex(B, Bc);
+    dot(Ac.loc, Bc.loc, out);
+  } else {
+    dot(A.loc, B.loc, out);
+  }
+  comm_allreduce_sum(out, 2);
+}
+
+double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includes/MatrixTrace.f90)
+  double t = trace(A.loc, A.c0);
+  comm_allreduce_sum(&t, 1);
+  return t;
+}
+
+double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns are local
+  DevBuf<double> cs;
+  column_abs_sums(A.loc, cs);
+  double n = max_of(cs, (size_t)A.loc.cols);
+  comm_allreduce_max(&n, 1);
+  return n;
+}
+
+double ps_sigma(const PSMatrix& A) {  // MatrixSigma (distributed_algebra_includes/MatrixSigma.f90)
+  const double n = ps_norm(A);
+  return 1.0 / (n * n);
+}
+
+void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {  // GershgorinBounds.f90:1-41
+  double mn, mx;
+  gershgorin(A.loc, A.c0, &mn, &mx);
+  comm_allreduce_min(&mn, 1);
+  comm_allreduce_max(&mx, 1);
+  *e_min = mn;
+  *e_max = mx;
+}
+
+void ps_transpose(const PSMatrix& A, PSMatrix& AT) {  // TransposeMatrix_ps
+  DevMat R;
+  if (world().active()) {
+    DevMat full = ps_gather_full(A);
+    R = transpose_slice(full, A.c0, A.c1);
+  } else {
+    R = transpose(A.loc);
+  }
+  AT.grid = A.grid; AT.dim = A.dim; AT.c0 = A.c0; AT.c1 = A.c1;
+  AT.cplx = A.cplx;
+  AT.loc = std::move(R);
+}
+
+void ps_conjugate(PSMatrix& A) { conjugate(A.loc); }
+
+bool ps_is_identity(const PSMatrix& A) {  // distributed_includes/IsIdentity.f90:7-38
+  int64_t d = identity_check(A.loc, A.c0);
+  int64_t v[2] = {d < 0 ? 1 : 0, d < 0 ? 0 : d};
+  comm_allreduce_sum_i64(v, 2);
+  return v[0] == 0 && v[1] == A.dim;
+}
+
+double ps_measure_asymmetry(const PSMatrix& A) {  // MeasureAsymmetry: norm(A - A^H)
+  PSMatrix T;
+  ps_transpose(A, T);
+  ps_conjugate(T);
+  ps_increment(A, T, -1.0, 0.0);
+  return ps_norm(T);
+}
+
+void ps_symmetrize(PSMatrix& A) {  // SymmetrizeMatrix: A <- (A + A^H)/2
+  PSMatrix T;
+  ps_transpose(A, T);
+  ps_conjugate(T);
+  ps_increment(T, A, 1.0, 0.0);
+  ps_scale(A, 0.5);
+}
+
+void ps_similarity(const PSMatrix& A, const PSMatrix& P, const PSMatrix& PInv, PSMatrix& Res, double threshold) {
+  // SimilarityTransform (PSMatrixAlgebraModule.F90:603-654)
+  if (ps_is_identity(P)) {
+    ps_copy(A, Res);
+    return;
+  }
+  PSMatrix Temp, Out;
+  ps_multiply(P, A, Temp, 1.0, 0.0, threshold);
+  ps_multiply(Temp, PInv, Out, 1.0, 0.0, threshold);
+  Res = std::move(Out);
+}
+
+// ------------------------------------------------------------------ permutations
+void permutation_default(Permutation& p, int n) {
+  p.index_lookup.resize((size_t)n);
+  p.reverse_index_lookup.resize((size_t)n);
+  for (int i = 0; i < n; ++i) p.index_lookup[(size_t)i] = p.reverse_index_lookup[(size_t)i] = i + 1;
+}
+void permutation_reverse(Permutation& p, int n) {
+  p.index_lookup.resize((size_t)n);
+  p.reverse_index_lookup.resize((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    p.index_lookup[(size_t)i] = n - i;
+    p.reverse_index_lookup[(size_t)i] = i + 1;  // as PermutationModule.F90:66 (only index_lookup is used)
+  }
+}
+void permutation_random(Permutation& p, int n) {
+  // Fisher-Yates on the root, broadcast to everybody (PermutationModule.F90:92-107 shares the
+  // root's permutation the same way).  The reference draws from the Fortran RNG; any permutation
+  // gives the same result matrix up to the threshold.
+  permutation_default(p, n);
+  static std::mt19937_64 rng(42);
+  for (int i = n - 1; i > 0; --i) {
+    const int j = (int)(rng() % (uint64_t)(i + 1));
+    std::swap(p.index_lookup[(size_t)i], p.index_lookup[(size_t)j]);
+  }
+  comm_bcast_i32(p.index_lookup.data(), n, 0);
+  for (int i = 0; i < n; ++i) p.reverse_index_lookup[(size_t)p.index_lookup[(size_t)i] - 1] = i + 1;
+}
+
+// PermuteMatrix / UndoPermuteMatrix (LoadBalancerModule.F90:14-92).  The reference multiplies by two
+// permutation matrices; out(i,j) = in(perm(i), perm(j)) is computed here by re-indexing and a device
+// sort, with the same result (including the pruning of stored zeros by the threshold-0 products).
+void ps_permute(const PSMatrix& in, PSMatrix& out, const Permutation& perm, bool undo) {
+  const int n = in.dim;
+  if ((int)perm.index_lookup.size() != n) NTP_FATAL("permutation size does not match the matrix");
+  std::vector<int32_t> map((size_t)n);
+  if (!undo) {
+    // entry (r, c) moves to (inv[r], inv[c])
+    for (int i = 0; i < n; ++i) map[(size_t)perm.index_lookup[(size_t)i] - 1] = i;
+  } else {
+    for (int i = 0; i < n; ++i) map[(size_t)i] = perm.index_lookup[(size_t)i] - 1;
+  }
+  DevBuf<int32_t> dmap((size_t)n);
+  dmap.upload(map.data(), (size_t)n);
+  DevMat R;
+  if (world().active()) {
+    DevMat full = ps_gather_full(in);
+    R = remap_general(full, dmap.p, dmap.p, n, in.c0, in.c1, true);
+  } else {
+    R = remap_general(in.loc, dmap.p, dmap.p, n, 0, n, true);
+  }
+  sync_stream();
+  const ProcessGrid* g = in.grid;
+  const bool cplx = in.cplx;
+  const int32_t c0 = in.c0, c1 = in.c1;
+  out.grid = g; out.dim = n; out.cplx = cplx; out.c0 = c0; out.c1 = c1;
+  out.loc = std::move(R);
+}
+
+}  // namespace ntp

@@ -1,0 +1,640 @@
+// C ABI of the engine: the reference's own wrapper surface (Source/Wrapper/*_wrp.F90, declared in
+// Source/C/*_c.h) re-exported with identical names, argument order and calling convention
+// (every scalar by reference, handles = caller-owned int[SIZE_wrp] buffers, no status codes),
+// plus a few ntpoly_amd_* extension entry points (RCCL bootstrap, statistics, options).
+// See include/*.h for the declarations with the reference line each symbol replaces.
+#include <algorithm>
+#include <cstring>
+
+#include "engine.hpp"
+#include "io.hpp"
+
+using namespace ntp;
+
+namespace {
+constexpr int SIZE_wrp = 12;  // Source/C/Wrapper.h:4
+
+template <typename T>
+T* get(const int* ih) {
+  T* p;
+  std::memcpy(&p, ih, sizeof(p));
+  if (!p) NTP_FATAL("null handle passed to the C ABI");
+  return p;
+}
+template <typename T>
+void put(int* ih, T* p) {
+  std::memset(ih, 0, sizeof(int) * SIZE_wrp);
+  std::memcpy(ih, &p, sizeof(p));
+}
+
+struct Pool {  // MatrixMemoryPool_p / _lr / _lc: the engine keeps its own HBM workspace
+  int dummy = 0;
+};
+struct LocalMat {  // Matrix_lsr / Matrix_lsc
+  DevMat m;
+};
+
+const ProcessGrid* default_grid() {
+  if (!global_grid_constructed()) NTP_FATAL("the global process grid has not been constructed");
+  return &global_grid();
+}
+std::string fstring(const char* s, const int* n) { return std::string(s, (size_t)*n); }
+}  // namespace
+
+extern "C" {
+
+// ===================================================================== extensions
+// RCCL bootstrap: rank 0 calls ntpoly_amd_get_unique_id, the launcher broadcasts the 128 bytes,
+// every rank calls ntpoly_amd_init_comm before constructing a process grid.
+void ntpoly_amd_get_unique_id(char* out128) { comm_get_unique_id(out128); }
+void ntpoly_amd_init_comm(const char* id128, const int* rank, const int* nranks) { comm_init(id128, *rank, *nranks); }
+void ntpoly_amd_finalize_comm() { comm_finalize(); }
+int ntpoly_amd_comm_rank() { return world().rank; }
+int ntpoly_amd_comm_size() { return world().nranks; }
+void ntpoly_amd_barrier() { comm_barrier(); }
+void ntpoly_amd_synchronize() { ensure_init(); sync_stream(); }
+void ntpoly_amd_panel_range(const int* dim, const int* nranks, const int* rank, int* c0, int* c1) {
+  panel_range(*dim, *nranks, *rank, c0, c1);
+}
+void ntpoly_amd_set_option(const char* name, const int* value) {
+  const std::string n(name);
+  if (n == "spgemm_force_bin") options().spgemm_force_bin = *value;
+  else if (n == "increment_force_seq") options().increment_force_seq = *value;
+  else if (n == "time_kernels") options().time_kernels = *value;
+  else NTP_FATAL("unknown option " + n);
+}
+// statistics of the last SpGEMM: out[0..]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow
+void ntpoly_amd_last_spgemm_stats(long long* out, float* ms_numeric, float* ms_total) {
+  const SpgemmStats& s = last_spgemm_stats();
+  out[0] = s.nnz_a; out[1] = s.nnz_b; out[2] = s.nnz_c; out[3] = s.products; out[4] = s.tmp_entries;
+  for (int i = 0; i < 6; ++i) out[5 + i] = s.bin_cols[i];
+  out[11] = s.overflow_cols;
+  *ms_numeric = s.ms_numeric;
+  *ms_total = s.ms_total;
+}
+void ntpoly_amd_reset_spgemm_accum() { spgemm_accum() = SpgemmAccum(); }
+// out: calls, products, nnz_c ; dout: alg_bytes, ms_numeric, ms_total
+void ntpoly_amd_get_spgemm_accum(long long* out, double* dout) {
+  const SpgemmAccum& a = spgemm_accum();
+  out[0] = a.calls; out[1] = a.products; out[2] = a.nnz_c;
+  dout[0] = a.alg_bytes; dout[1] = a.ms_numeric; dout[2] = a.ms_total;
+}
+// per-iteration trace of the last solver call
+int ntpoly_amd_trace_iterations() { return last_trace().iterations; }
+void ntpoly_amd_trace_get(double* value, double* energy, double* sigma, long long* nnz) {
+  const SolverTrace& t = last_trace();
+  for (int i = 0; i < t.iterations; ++i) {
+    value[i] = t.value[(size_t)i];
+    energy[i] = t.energy[(size_t)i];
+    sigma[i] = t.sigma[(size_t)i];
+    nnz[i] = t.nnz[(size_t)i];
+  }
+}
+void ntpoly_amd_trace_times(double* setup_ms, double* loop_ms) {
+  *setup_ms = last_trace().setup_ms;
+  *loop_ms = last_trace().loop_ms;
+}
+void ntpoly_amd_memory(long long* in_use, long long* cached) {
+  *in_use = (long long)dev_bytes_in_use();
+  *cached = (long long)dev_bytes_cached();
+}
+void ntpoly_amd_release_cache() { dev_release_cache(); }
+// bulk triplet transfer (the reference ABI moves triplets one at a time)
+void ntpoly_amd_triplets_set_r(int* ih_list, const long long* n, const int* col, const int* row, const double* val) {
+  HostTriplets* t = get<HostTriplets>(ih_list);
+  t->cplx = false;
+  t->col.assign(col, col + *n);
+  t->row.assign(row, row + *n);
+  t->val.assign(val, val + *n);
+}
+void ntpoly_amd_triplets_set_c(int* ih_list, const long long* n, const int* col, const int* row, const double* val_ri) {
+  HostTriplets* t = get<HostTriplets>(ih_list);
+  t->cplx = true;
+  t->col.assign(col, col + *n);
+  t->row.assign(row, row + *n);
+  t->val.assign(val_ri, val_ri + 2 * *n);
+}
+void ntpoly_amd_triplets_get(const int* ih_list, int* col, int* row, double* val) {
+  const HostTriplets* t = get<HostTriplets>(ih_list);
+  std::copy(t->col.begin(), t->col.end(), col);
+  std::copy(t->row.begin(), t->row.end(), row);
+  std::copy(t->val.begin(), t->val.end(), val);
+}
+
+// ===================================================================== ProcessGrid_c.h
+void ConstructGlobalProcessGrid_wrp(const int* world_comm, const int* process_rows, const int* process_columns,
+                                    const int* process_slices) {
+  (void)world_comm;  // the MPI communicator of the reference; ranks come from ntpoly_amd_init_comm
+  construct_grid(global_grid(), *process_rows, *process_columns, *process_slices);
+}
+void ConstructGlobalProcessGrid_onlyslice_wrp(const int* world_comm, const int* process_slices) {
+  (void)world_comm;
+  construct_grid_default(global_grid(), *process_slices);
+}
+void ConstructGlobalProcessGrid_default_wrp(const int* world_comm) {
+  (void)world_comm;
+  construct_grid_default(global_grid(), 1);
+}
+void CopyProcessGrid_wrp(const int* ih_old_grid, int* ih_new_grid) {
+  put(ih_new_grid, new ProcessGrid(*get<ProcessGrid>(ih_old_grid)));
+}
+int GetGlobalMySlice_wrp() { return global_grid().my_slice; }
+int GetGlobalMyColumn_wrp() { return global_grid().my_col; }
+int GetGlobalMyRow_wrp() { return global_grid().my_row; }
+bool GetGlobalIsRoot_wrp() { return global_grid().is_root(); }
+int GetGlobalNumSlices_wrp() { return global_grid().num_slices; }
+int GetGlobalNumColumns_wrp() { return global_grid().num_cols; }
+int GetGlobalNumRows_wrp() { return global_grid().num_rows; }
+void WriteGlobalProcessGridInfo_wrp() { write_grid_info(global_grid()); }
+void DestructGlobalProcessGrid_wrp() {}
+void ConstructProcessGrid_wrp(int* ih_grid, const int* world_comm, const int* process_rows, const int* process_columns,
+                              const int* process_slices) {
+  (void)world_comm;
+  ProcessGrid* g = new ProcessGrid();
+  construct_grid(*g, *process_rows, *process_columns, *process_slices);
+  put(ih_grid, g);
+}
+void ConstructProcessGrid_onlyslice_wrp(int* ih_grid, const int* world_comm, const int* process_slices) {
+  (void)world_comm;
+  ProcessGrid* g = new ProcessGrid();
+  construct_grid_default(*g, *process_slices);
+  put(ih_grid, g);
+}
+void ConstructProcessGrid_default_wrp(int* ih_grid, const int* world_comm) {
+  (void)world_comm;
+  ProcessGrid* g = new ProcessGrid();
+  construct_grid_default(*g, 1);
+  put(ih_grid, g);
+}
+int GetMySlice_wrp(const int* ih_grid) { return get<ProcessGrid>(ih_grid)->my_slice; }
+int GetMyColumn_wrp(const int* ih_grid) { return get<ProcessGrid>(ih_grid)->my_col; }
+int GetMyRow_wrp(const int* ih_grid) { return get<ProcessGrid>(ih_grid)->my_row; }
+int GetNumSlices_wrp(const int* ih_grid) { return get<ProcessGrid>(ih_grid)->num_slices; }
+int GetNumColumns_wrp(const int* ih_grid) { return get<ProcessGrid>(ih_grid)->num_cols; }
+int GetNumRows_wrp(const int* ih_grid) { return get<ProcessGrid>(ih_grid)->num_rows; }
+void WriteProcessGridInfo_wrp(const int* ih_grid) { write_grid_info(*get<ProcessGrid>(ih_grid)); }
+void DestructProcessGrid_wrp(int* ih_grid) { delete get<ProcessGrid>(ih_grid); }
+
+// ===================================================================== TripletList_c.h
+void ConstructTripletList_r_wrp(int* ih_this, const int* size) {
+  HostTriplets* t = new HostTriplets();
+  t->cplx = false;
+  t->col.assign((size_t)*size, 0);
+  t->row.assign((size_t)*size, 0);
+  t->val.assign((size_t)*size, 0.0);
+  put(ih_this, t);
+}
+void ResizeTripletList_r_wrp(int* ih_this, const int* size) {
+  HostTriplets* t = get<HostTriplets>(ih_this);
+  t->col.resize((size_t)*size);
+  t->row.resize((size_t)*size);
+  t->val.resize((size_t)*size);
+}
+void AppendToTripletList_r_wrp(int* ih_this, const int* index_column, const int* index_row, const double* point_value) {
+  HostTriplets* t = get<HostTriplets>(ih_this);
+  t->col.push_back(*index_column);
+  t->row.push_back(*index_row);
+  t->val.push_back(*point_value);
+}
+void SetTripletAt_r_wrp(int* ih_this, const int* index, const int* index_column, const int* index_row,
+                        const double* point_value) {
+  HostTriplets* t = get<HostTriplets>(ih_this);
+  const size_t i = (size_t)*index - 1;  // 1-based (TripletList.cc:44-48 adds 1)
+  t->col[i] = *index_column;
+  t->row[i] = *index_row;
+  t->val[i] = *point_value;
+}
+void GetTripletAt_r_wrp(const int* ih_this, const int* index, int* index_column, int* index_row, double* point_value) {
+  const HostTriplets* t = get<HostTriplets>(ih_this);
+  const size_t i = (size_t)*index - 1;
+  *index_column = t->col[i];
+  *index_row = t->row[i];
+  *point_value = t->val[i];
+}
+void DestructTripletList_r_wrp(int* ih_this) { delete get<HostTriplets>(ih_this); }
+static void sort_triplets(const HostTriplets& in, HostTriplets& out) {
+  const size_t n = in.size(), w = in.cplx ? 2 : 1;
+  std::vector<size_t> order(n);
+  for (size_t i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+    if (in.col[a] != in.col[b]) return in.col[a] < in.col[b];
+    return in.row[a] < in.row[b];
+  });
+  out.cplx = in.cplx;
+  out.col.resize(n);
+  out.row.resize(n);
+  out.val.resize(n * w);
+  for (size_t i = 0; i < n; ++i) {
+    out.col[i] = in.col[order[i]];
+    out.row[i] = in.row[order[i]];
+    for (size_t k = 0; k < w; ++k) out.val[i * w + k] = in.val[order[i] * w + k];
+  }
+}
+void SortTripletList_r_wrp(const int* ih_this, const int* matrix_size, int* h_sorted) {
+  (void)matrix_size;
+  HostTriplets* s = new HostTriplets();
+  sort_triplets(*get<HostTriplets>(ih_this), *s);
+  put(h_sorted, s);
+}
+int GetTripletListSize_r_wrp(const int* ih_this) { return (int)get<HostTriplets>(ih_this)->size(); }
+
+void ConstructTripletList_c_wrp(int* ih_this, const int* size) {
+  HostTriplets* t = new HostTriplets();
+  t->cplx = true;
+  t->col.assign((size_t)*size, 0);
+  t->row.assign((size_t)*size, 0);
+  t->val.assign((size_t)*size * 2, 0.0);
+  put(ih_this, t);
+}
+void ResizeTripletList_c_wrp(int* ih_this, const int* size) {
+  HostTriplets* t = get<HostTriplets>(ih_this);
+  t->col.resize((size_t)*size);
+  t->row.resize((size_t)*size);
+  t->val.resize((size_t)*size * 2);
+}
+void AppendToTripletList_c_wrp(int* ih_this, const int* index_column, const int* index_row, const double* re,
+                               const double* im) {
+  HostTriplets* t = get<HostTriplets>(ih_this);
+  t->col.push_back(*index_column);
+  t->row.push_back(*index_row);
+  t->val.push_back(*re);
+  t->val.push_back(*im);
+}
+void SetTripletAt_c_wrp(int* ih_this, const int* index, const int* index_column, const int* index_row, const double* re,
+                        const double* im) {
+  HostTriplets* t = get<HostTriplets>(ih_this);
+  const size_t i = (size_t)*index - 1;
+  t->col[i] = *index_column;
+  t->row[i] = *index_row;
+  t->val[2 * i] = *re;
+  t->val[2 * i + 1] = *im;
+}
+// the reference declares the outputs `const double*` (TripletList_c.h:26-28) but writes them
+void GetTripletAt_c_wrp(const int* ih_this, const int* index, int* index_column, int* index_row, const double* re,
+                        const double* im) {
+  const HostTriplets* t = get<HostTriplets>(ih_this);
+  const size_t i = (size_t)*index - 1;
+  *index_column = t->col[i];
+  *index_row = t->row[i];
+  *const_cast<double*>(re) = t->val[2 * i];
+  *const_cast<double*>(im) = t->val[2 * i + 1];
+}
+void DestructTripletList_c_wrp(int* ih_this) { delete get<HostTriplets>(ih_this); }
+void SortTripletList_c_wrp(const int* ih_this, const int* matrix_size, int* h_sorted) {
+  (void)matrix_size;
+  HostTriplets* s = new HostTriplets();
+  sort_triplets(*get<HostTriplets>(ih_this), *s);
+  put(h_sorted, s);
+}
+int GetTripletListSize_c_wrp(const int* ih_this) { return (int)get<HostTriplets>(ih_this)->size(); }
+
+// ===================================================================== Permutation_c.h
+void ConstructDefaultPermutation_wrp(int* ih_this, const int* matrix_dimension) {
+  Permutation* p = new Permutation();
+  permutation_default(*p, *matrix_dimension);
+  put(ih_this, p);
+}
+void ConstructReversePermutation_wrp(int* ih_this, const int* matrix_dimension) {
+  Permutation* p = new Permutation();
+  permutation_reverse(*p, *matrix_dimension);
+  put(ih_this, p);
+}
+void ConstructRandomPermutation_wrp(int* ih_this, const int* matrix_dimension) {
+  Permutation* p = new Permutation();
+  permutation_random(*p, *matrix_dimension);
+  put(ih_this, p);
+}
+void DestructPermutation_wrp(int* ih_this) { delete get<Permutation>(ih_this); }
+// extension: explicit permutation (index_lookup, 1-based)
+void ntpoly_amd_permutation_set(int* ih_this, const int* n, const int* index_lookup) {
+  Permutation* p = get<Permutation>(ih_this);
+  permutation_default(*p, *n);
+  for (int i = 0; i < *n; ++i) p->index_lookup[(size_t)i] = index_lookup[i];
+  for (int i = 0; i < *n; ++i) p->reverse_index_lookup[(size_t)p->index_lookup[(size_t)i] - 1] = i + 1;
+}
+
+// ===================================================================== memory pools
+void ConstructMatrixMemoryPool_p_wrp(int* ih_this, const int* ih_matrix) {
+  (void)ih_matrix;
+  put(ih_this, new Pool());
+}
+void DestructMatrixMemoryPool_p_wrp(int* ih_this) { delete get<Pool>(ih_this); }
+void ConstructMatrixMemoryPool_lr_wrp(int* ih_this, const int* columns, const int* rows) {
+  (void)columns; (void)rows;
+  put(ih_this, new Pool());
+}
+void DestructMatrixMemoryPool_lr_wrp(int* ih_this) { delete get<Pool>(ih_this); }
+void ConstructMatrixMemoryPool_lc_wrp(int* ih_this, const int* columns, const int* rows) {
+  (void)columns; (void)rows;
+  put(ih_this, new Pool());
+}
+void DestructMatrixMemoryPool_lc_wrp(int* ih_this) { delete get<Pool>(ih_this); }
+
+// ===================================================================== SolverParameters_c.h
+void ConstructSolverParameters_wrp(int* ih_this) { put(ih_this, new SolverParameters()); }
+void SetParametersConvergeDiff_wrp(int* ih_this, const double* v) { get<SolverParameters>(ih_this)->converge_diff = *v; }
+void SetParametersMaxIterations_wrp(int* ih_this, const int* v) { get<SolverParameters>(ih_this)->max_iterations = *v; }
+void SetParametersBeVerbose_wrp(int* ih_this, const bool* v) { get<SolverParameters>(ih_this)->be_verbose = *v; }
+void SetParametersThreshold_wrp(int* ih_this, const double* v) { get<SolverParameters>(ih_this)->threshold = *v; }
+void SetParametersLoadBalance_wrp(int* ih_this, const int* ih_permutation) {
+  SolverParameters* p = get<SolverParameters>(ih_this);
+  p->do_load_balancing = true;  // SolverParametersModule.F90:160-167
+  p->balance_permutation = *get<Permutation>(ih_permutation);
+}
+void SetParametersStepThreshold_wrp(int* ih_this, const double* v) { get<SolverParameters>(ih_this)->step_thresh = *v; }
+void SetParametersMonitorConvergence_wrp(int* ih_this, const bool* v) {
+  get<SolverParameters>(ih_this)->monitor_convergence = *v;
+}
+void DestructSolverParameters_wrp(int* ih_this) { delete get<SolverParameters>(ih_this); }
+
+// ===================================================================== Logging_c.h
+void ActivateLogger_wrp(const bool* start_document) { log_activate(*start_document, nullptr); }
+void ActivateLoggerFile_wrp(const bool* start_document, const char* file_name, const int* name_size) {
+  log_activate(*start_document, fstring(file_name, name_size).c_str());
+}
+void DeactivateLogger_wrp() { log_deactivate(); }
+
+// ===================================================================== PSMatrix_c.h
+void ConstructEmptyMatrix_ps_wrp(int* ih_this, const int* matrix_dim) {
+  PSMatrix* m = new PSMatrix();
+  ps_construct_empty(*m, *matrix_dim, default_grid(), false);
+  put(ih_this, m);
+}
+void ConstructEmptyMatrixPG_ps_wrp(int* ih_this, const int* matrix_dim, const int* ih_grid) {
+  PSMatrix* m = new PSMatrix();
+  ps_construct_empty(*m, *matrix_dim, get<ProcessGrid>(ih_grid), false);
+  put(ih_this, m);
+}
+void CopyMatrix_ps_wrp(const int* ih_matA, int* ih_matB) { ps_copy(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB)); }
+void DestructMatrix_ps_wrp(int* ih_this) { delete get<PSMatrix>(ih_this); }
+void ConstructMatrixFromMatrixMarket_ps_wrp(int* ih_this, const char* file_name, const int* name_size) {
+  PSMatrix* m = new PSMatrix();
+  ps_read_matrix_market(*m, fstring(file_name, name_size), default_grid());
+  put(ih_this, m);
+}
+void ConstructMatrixFromBinary_ps_wrp(int* ih_this, const char* file_name, const int* name_size) {
+  PSMatrix* m = new PSMatrix();
+  ps_read_binary(*m, fstring(file_name, name_size), default_grid());
+  put(ih_this, m);
+}
+void ConstructMatrixFromMatrixMarketPG_ps_wrp(int* ih_this, const char* file_name, const int* name_size,
+                                              const int* ih_grid) {
+  PSMatrix* m = new PSMatrix();
+  ps_read_matrix_market(*m, fstring(file_name, name_size), get<ProcessGrid>(ih_grid));
+  put(ih_this, m);
+}
+void ConstructMatrixFromBinaryPG_ps_wrp(int* ih_this, const char* file_name, const int* name_size, const int* ih_grid) {
+  PSMatrix* m = new PSMatrix();
+  ps_read_binary(*m, fstring(file_name, name_size), get<ProcessGrid>(ih_grid));
+  put(ih_this, m);
+}
+void WriteMatrixToBinary_ps_wrp(const int* ih_this, const char* file_name, const int* name_size) {
+  ps_write_binary(*get<PSMatrix>(ih_this), fstring(file_name, name_size));
+}
+void WriteMatrixToMatrixMarket_ps_wrp(const int* ih_this, const char* file_name, const int* name_size) {
+  ps_write_matrix_market(*get<PSMatrix>(ih_this), fstring(file_name, name_size));
+}
+void FillMatrixFromTripletList_psr_wrp(const int* ih_this, const int* ih_triplet_list) {
+  PSMatrix* m = get<PSMatrix>(ih_this);
+  if (m->cplx) {  // a real fill of a (so far) complex-typed handle makes it real, as the Fortran generic does
+    m->cplx = false;
+    m->loc.reset_empty(m->dim, m->c1 - m->c0, false);
+  }
+  ps_fill_from_triplets(*m, *get<HostTriplets>(ih_triplet_list));
+}
+void FillMatrixFromTripletList_psc_wrp(const int* ih_this, const int* ih_triplet_list) {
+  PSMatrix* m = get<PSMatrix>(ih_this);
+  if (!m->cplx) {  // FillMatrixFromTripletList_psc converts the matrix to complex (PSMatrixModule.F90:846-850)
+    m->cplx = true;
+    m->loc.reset_empty(m->dim, m->c1 - m->c0, true);
+  }
+  ps_fill_from_triplets(*m, *get<HostTriplets>(ih_triplet_list));
+}
+// extension: the Fortran API's prepartitioned_in = .TRUE. (PSMatrixModule.F90:796-825): every rank
+// passes only entries of its own column panel, no exchange
+void ntpoly_amd_fill_prepartitioned(const int* ih_this, const int* ih_triplet_list) {
+  PSMatrix* m = get<PSMatrix>(ih_this);
+  const HostTriplets* t = get<HostTriplets>(ih_triplet_list);
+  if (m->cplx != t->cplx) {
+    m->cplx = t->cplx;
+  }
+  m->loc = from_triplets(*t, m->dim, m->c1 - m->c0, m->c0);
+}
+void FillMatrixPermutation_ps_wrp(int* ih_this, const int* ih_permutation, const bool* permuterows) {
+  ps_fill_permutation(*get<PSMatrix>(ih_this), get<Permutation>(ih_permutation)->index_lookup, *permuterows);
+}
+void FillMatrixIdentity_ps_wrp(int* ih_this) { ps_fill_identity(*get<PSMatrix>(ih_this)); }
+void GetMatrixActualDimension_ps_wrp(const int* ih_this, int* size) { *size = get<PSMatrix>(ih_this)->dim; }
+void GetMatrixLogicalDimension_ps_wrp(const int* ih_this, int* size) { *size = get<PSMatrix>(ih_this)->dim; }
+void GetMatrixSize_ps_wrp(const int* ih_this, long int* size) { *size = (long int)ps_size(*get<PSMatrix>(ih_this)); }
+void GetMatrixTripletList_psr_wrp(const int* ih_this, int* ih_triplet_list) {
+  const PSMatrix* m = get<PSMatrix>(ih_this);
+  HostTriplets* t = get<HostTriplets>(ih_triplet_list);
+  if (m->cplx) {  // ConvertMatrixToReal (PSMatrixModule.F90:1003-1004)
+    PSMatrix r;
+    ps_to_real(*m, r);
+    ps_get_triplets(r, *t);
+  } else {
+    ps_get_triplets(*m, *t);
+  }
+}
+void GetMatrixTripletList_psc_wrp(const int* ih_this, int* ih_triplet_list) {
+  const PSMatrix* m = get<PSMatrix>(ih_this);
+  HostTriplets* t = get<HostTriplets>(ih_triplet_list);
+  if (!m->cplx) {
+    PSMatrix c;
+    ps_to_complex(*m, c);
+    ps_get_triplets(c, *t);
+  } else {
+    ps_get_triplets(*m, *t);
+  }
+}
+void TransposeMatrix_ps_wrp(const int* ih_matA, int* ih_transmat) {
+  ps_transpose(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_transmat));
+}
+void ConjugateMatrix_ps_wrp(int* ih_matA) { ps_conjugate(*get<PSMatrix>(ih_matA)); }
+void GetMatrixProcessGrid_ps_wrp(const int* ih_this, int* ih_grid) {
+  put(ih_grid, const_cast<ProcessGrid*>(get<PSMatrix>(ih_this)->grid));
+}
+int ntpoly_amd_matrix_is_complex(const int* ih_this) { return get<PSMatrix>(ih_this)->cplx ? 1 : 0; }
+void ntpoly_amd_matrix_local_columns(const int* ih_this, int* c0, int* c1) {
+  *c0 = get<PSMatrix>(ih_this)->c0;
+  *c1 = get<PSMatrix>(ih_this)->c1;
+}
+
+void DotMatrix_psr_wrp(const int* ih_matA, const int* ih_matB, double* product) {
+  double out[2];
+  ps_dot(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), out);
+  *product = out[0];
+}
+void DotMatrix_psc_wrp(const int* ih_matA, const int* ih_matB, double* product_real, double* product_imag) {
+  double out[2];
+  ps_dot(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), out);
+  *product_real = out[0];
+  *product_imag = out[1];
+}
+void IncrementMatrix_ps_wrp(const int* ih_matA, int* ih_matB, const double* alpha_in, const double* threshold_in) {
+  ps_increment(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), *alpha_in, *threshold_in);
+}
+void MatrixPairwiseMultiply_ps_wrp(const int* ih_matA, const int* ih_matB, int* ih_matC) {
+  ps_pairwise(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), *get<PSMatrix>(ih_matC));
+}
+void MatrixMultiply_ps_wrp(const int* ih_matA, const int* ih_matB, int* ih_matC, const double* alpha_in,
+                           const double* beta_in, const double* threshold_in, int* ih_memory_pool_in) {
+  (void)ih_memory_pool_in;
+  ps_multiply(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), *get<PSMatrix>(ih_matC), *alpha_in, *beta_in,
+              *threshold_in);
+}
+void ScaleMatrix_ps_wrp(int* ih_this, const double* constant) { ps_scale(*get<PSMatrix>(ih_this), *constant); }
+double MatrixNorm_ps_wrp(const int* ih_this) { return ps_norm(*get<PSMatrix>(ih_this)); }
+double MeasureAsymmetry_ps_wrp(const int* ih_this) { return ps_measure_asymmetry(*get<PSMatrix>(ih_this)); }
+void MatrixTrace_ps_wrp(const int* ih_this, double* trace_val) { *trace_val = ps_trace(*get<PSMatrix>(ih_this)); }
+int IsIdentity_ps_wrp(const int* ih_this) { return ps_is_identity(*get<PSMatrix>(ih_this)) ? 1 : 0; }
+void SymmetrizeMatrix_ps_wrp(int* ih_this) { ps_symmetrize(*get<PSMatrix>(ih_this)); }
+
+// ===================================================================== LoadBalancer_c.h, EigenBounds_c.h
+void PermuteMatrix_wrp(const int* ih_mat_in, int* ih_mat_out, const int* ih_permutation, int* ih_memorypool) {
+  (void)ih_memorypool;
+  ps_permute(*get<PSMatrix>(ih_mat_in), *get<PSMatrix>(ih_mat_out), *get<Permutation>(ih_permutation), false);
+}
+void UndoPermuteMatrix_wrp(const int* ih_mat_in, int* ih_mat_out, const int* ih_permutation, int* ih_memorypool) {
+  (void)ih_memorypool;
+  ps_permute(*get<PSMatrix>(ih_mat_in), *get<PSMatrix>(ih_mat_out), *get<Permutation>(ih_permutation), true);
+}
+// EigenBounds_c.h:4-5 names the outputs (max_value, min_value) but the wrapper forwards them
+// positionally to GershgorinBounds(this, min_value, max_value) (EigenBoundsModule_wrp.F90): first = min
+void GershgorinBounds_wrp(const int* ih_Hamiltonian, double* max_value, double* min_value) {
+  ps_gershgorin(*get<PSMatrix>(ih_Hamiltonian), max_value, min_value);
+}
+
+// ===================================================================== solvers
+// outputs are declared `const double*` in DensityMatrixSolvers_c.h:4-23 but are written
+// (DensityMatrixSolversModule_wrp.F90:57-58)
+#define DENSITY_SOLVER(NAME, FN)                                                                              \
+  void NAME(const int* ih_Hamiltonian, const int* ih_InverseSquareRoot, const double* trace, int* ih_Density, \
+            const double* energy_value_out, const double* chemical_potential_out,                             \
+            const int* ih_solver_parameters) {                                                                \
+    FN(*get<PSMatrix>(ih_Hamiltonian), *get<PSMatrix>(ih_InverseSquareRoot), *trace, *get<PSMatrix>(ih_Density), \
+       const_cast<double*>(energy_value_out), const_cast<double*>(chemical_potential_out),                    \
+       *get<SolverParameters>(ih_solver_parameters));                                                         \
+  }
+DENSITY_SOLVER(PM_wrp, solver_pm)
+DENSITY_SOLVER(TRS2_wrp, solver_trs2)
+DENSITY_SOLVER(TRS4_wrp, solver_trs4)
+DENSITY_SOLVER(HPCP_wrp, solver_hpcp)
+
+void SignFunction_wrp(const int* ih_mat1, int* ih_signmat, const int* ih_solver_parameters) {
+  solver_sign(*get<PSMatrix>(ih_mat1), *get<PSMatrix>(ih_signmat), *get<SolverParameters>(ih_solver_parameters));
+}
+void PolarDecomposition_wrp(const int* ih_mat1, int* ih_umat, int* ih_hmat, const int* ih_solver_parameters) {
+  solver_polar(*get<PSMatrix>(ih_mat1), *get<PSMatrix>(ih_umat), get<PSMatrix>(ih_hmat),
+               *get<SolverParameters>(ih_solver_parameters));
+}
+void Invert_wrp(const int* ih_Hamiltonian, int* ih_Inverse, const int* ih_solver_parameters) {
+  solver_invert(*get<PSMatrix>(ih_Hamiltonian), *get<PSMatrix>(ih_Inverse), *get<SolverParameters>(ih_solver_parameters));
+}
+void PseudoInverse_wrp(const int* ih_Hamiltonian, int* ih_Inverse, const int* ih_solver_parameters) {
+  solver_pseudoinverse(*get<PSMatrix>(ih_Hamiltonian), *get<PSMatrix>(ih_Inverse),
+                       *get<SolverParameters>(ih_solver_parameters));
+}
+void SquareRoot_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  solver_square_root(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), *get<SolverParameters>(ih_solver_parameters),
+                     false, 5);
+}
+void InverseSquareRoot_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  solver_square_root(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), *get<SolverParameters>(ih_solver_parameters),
+                     true, 5);
+}
+// extension: the reference's optional order_in argument (SquareRootSolversModule.F90:30-61) is not
+// reachable through its C ABI; expose it for tests
+void ntpoly_amd_square_root_order(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters,
+                                  const int* inverse, const int* order) {
+  solver_square_root(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), *get<SolverParameters>(ih_solver_parameters),
+                     *inverse != 0, *order);
+}
+
+// ===================================================================== SMatrix_c.h (local matrices, config 2)
+#define LOCAL_API(SUF, CPLX)                                                                                     \
+  void ConstructMatrixFromTripletList_##SUF##_wrp(int* ih_this, const int* ih_triplet_list, const int* rows,     \
+                                                  const int* columns) {                                          \
+    ensure_init();                                                                                               \
+    LocalMat* m = new LocalMat();                                                                                \
+    m->m = from_triplets(*get<HostTriplets>(ih_triplet_list), *rows, *columns, 0);                               \
+    put(ih_this, m);                                                                                             \
+  }                                                                                                              \
+  void ConstructZeroMatrix_##SUF##_wrp(int* ih_this, const int* rows, const int* columns) {                      \
+    ensure_init();                                                                                               \
+    LocalMat* m = new LocalMat();                                                                                \
+    m->m.reset_empty(*rows, *columns, CPLX);                                                                     \
+    put(ih_this, m);                                                                                             \
+  }                                                                                                              \
+  void ConstructMatrixFromFile_##SUF##_wrp(int* ih_this, const char* file_name, const int* name_size) {          \
+    ensure_init();                                                                                               \
+    LocalMat* m = new LocalMat();                                                                                \
+    int rows = 0, cols = 0;                                                                                      \
+    HostTriplets t;                                                                                              \
+    read_matrix_market_file(fstring(file_name, name_size), t, &rows, &cols, CPLX);                               \
+    m->m = from_triplets(t, rows, cols, 0);                                                                      \
+    put(ih_this, m);                                                                                             \
+  }                                                                                                              \
+  void DestructMatrix_##SUF##_wrp(int* ih_this) { delete get<LocalMat>(ih_this); }                               \
+  void CopyMatrix_##SUF##_wrp(const int* ih_matA, int* ih_matB) {                                                \
+    get<LocalMat>(ih_matB)->m = get<LocalMat>(ih_matA)->m.clone();                                               \
+  }                                                                                                              \
+  void GetMatrixRows_##SUF##_wrp(const int* ih_this, int* rows) { *rows = get<LocalMat>(ih_this)->m.rows; }      \
+  void GetMatrixColumns_##SUF##_wrp(const int* ih_this, int* columns) { *columns = get<LocalMat>(ih_this)->m.cols; } \
+  void ScaleMatrix_##SUF##_wrp(int* ih_this, const double* constant) { scale(get<LocalMat>(ih_this)->m, *constant); } \
+  void IncrementMatrix_##SUF##_wrp(const int* ih_matA, int* ih_matB, const double* alpha_in,                     \
+                                   const double* threshold_in) {                                                 \
+    increment(get<LocalMat>(ih_matA)->m, get<LocalMat>(ih_matB)->m, *alpha_in, *threshold_in);                   \
+  }                                                                                                              \
+  void PairwiseMultiplyMatrix_##SUF##_wrp(const int* ih_matA, const int* ih_matB, int* ih_matC) {                \
+    pairwise(get<LocalMat>(ih_matA)->m, get<LocalMat>(ih_matB)->m, get<LocalMat>(ih_matC)->m, false);            \
+  }                                                                                                              \
+  void TransposeMatrix_##SUF##_wrp(const int* ih_matA, int* ih_matAT) {                                          \
+    get<LocalMat>(ih_matAT)->m = transpose(get<LocalMat>(ih_matA)->m);                                           \
+  }                                                                                                              \
+  void MatrixToTripletList_##SUF##_wrp(const int* ih_this, int* ih_triplet_list) {                               \
+    to_triplets(get<LocalMat>(ih_this)->m, 0, *get<HostTriplets>(ih_triplet_list));                              \
+  }                                                                                                              \
+  /* GemmMatrix (sparse_includes/GemmMatrix.f90:1-101) */                                                        \
+  void MatrixMultiply_##SUF##_wrp(const int* ih_matA, const int* ih_matB, int* ih_matC, const bool* IsATransposed, \
+                                  const bool* IsBTransposed, const double* alpha, const double* beta,            \
+                                  const double* threshold, int* ih_matrix_memory_pool) {                         \
+    (void)ih_matrix_memory_pool;                                                                                 \
+    const DevMat& A0 = get<LocalMat>(ih_matA)->m;                                                                \
+    const DevMat& B0 = get<LocalMat>(ih_matB)->m;                                                                \
+    DevMat& C = get<LocalMat>(ih_matC)->m;                                                                       \
+    const double sa = (double)A0.nnz / ((double)A0.rows * (double)A0.cols);                                      \
+    const double sb = (double)B0.nnz / ((double)B0.rows * (double)B0.cols);                                      \
+    const bool dense_rule = std::min(sa, sb) > 0.1;                                                              \
+    DevMat At, Bt;                                                                                               \
+    if (*IsATransposed) At = transpose(A0);                                                                      \
+    if (*IsBTransposed) Bt = transpose(B0);                                                                      \
+    DevMat AB;                                                                                                   \
+    spgemm(*IsATransposed ? At : A0, *IsBTransposed ? Bt : B0, AB, *alpha, *threshold, dense_rule);              \
+    if (std::fabs(*beta) > 0 && C.rows == AB.rows && C.cols == AB.cols) {                                        \
+      scale(C, *beta);                                                                                           \
+      increment(AB, C, 1.0, 0.0);                                                                                \
+    } else {                                                                                                     \
+      C = std::move(AB);                                                                                         \
+    }                                                                                                            \
+  }
+
+LOCAL_API(lsr, false)
+LOCAL_API(lsc, true)
+
+void DotMatrix_lsr_wrp(const int* ih_matA, const int* ih_matB, double* product) {
+  double out[2];
+  dot(get<LocalMat>(ih_matA)->m, get<LocalMat>(ih_matB)->m, out);
+  *product = out[0];
+}
+void DotMatrix_lsc_wrp(const int* ih_matA, const int* ih_matB, double* product_real, double* product_complex) {
+  double out[2];
+  dot(get<LocalMat>(ih_matA)->m, get<LocalMat>(ih_matB)->m, out);
+  *product_real = out[0];
+  *product_complex = out[1];
+}
+void ConjugateMatrix_lsc_wrp(int* ih_matA) { conjugate(get<LocalMat>(ih_matA)->m); }
+
+}  // extern "C"

@@ -1,0 +1,600 @@
+"""Python mirror of the reference's C++/SWIG classes (Source/CPlusPlus/*.h, the objects its own
+unit tests use: ProcessGrid, TripletList_r/_c, Matrix_ps, Matrix_lsr/_lsc, MatrixMemoryPool,
+Permutation, SolverParameters, DensityMatrixSolvers, SignSolvers, InverseSolvers,
+SquareRootSolvers, LoadBalancer, EigenBounds) on top of the C ABI of libntpoly_amd.so.
+
+Same method names and argument meaning as the reference so that the parity tests read like
+the reference's tests.  numpy arrays are only used at the boundary (triplets in / out); all
+matrix data lives in HBM.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import b, d, handle, i, lib, ll, s
+
+
+# ------------------------------------------------------------------ process grid
+def ConstructGlobalProcessGrid(process_rows=None, process_columns=None, process_slices=None, world_comm=0):
+    """ProcessGrid.cc:12-48 (ConstructGlobalProcessGrid overloads)."""
+    if process_rows is None and process_slices is None:
+        lib.ConstructGlobalProcessGrid_default_wrp(i(world_comm))
+    elif process_rows is None:
+        lib.ConstructGlobalProcessGrid_onlyslice_wrp(i(world_comm), i(process_slices))
+    else:
+        lib.ConstructGlobalProcessGrid_wrp(i(world_comm), i(process_rows), i(process_columns), i(process_slices))
+
+
+def DestructGlobalProcessGrid():
+    lib.DestructGlobalProcessGrid_wrp()
+
+
+def GetGlobalIsRoot():
+    return bool(lib.GetGlobalIsRoot_wrp())
+
+
+def init_comm(unique_id=None, rank=0, nranks=1):
+    """RCCL bootstrap (replaces MPI_Init + communicator handles of the reference)."""
+    if nranks <= 1:
+        lib.ntpoly_amd_init_comm(b"\0" * 128, i(0), i(1))
+    else:
+        lib.ntpoly_amd_init_comm(unique_id, i(rank), i(nranks))
+
+
+def get_unique_id():
+    buf = C.create_string_buffer(128)
+    lib.ntpoly_amd_get_unique_id(buf)
+    return buf.raw
+
+
+def init_comm_from_torch():
+    """One process per GPU under torch.distributed.run: broadcast the RCCL id with torch.distributed
+    (plumbing only) and build the engine's communicator.  Returns (rank, world_size)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world <= 1:
+        init_comm()
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if not dist.is_initialized():
+        dist.init_process_group("nccl")
+    box = [get_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    init_comm(box[0], rank, world)
+    return rank, world
+
+
+def set_option(name, value):
+    lib.ntpoly_amd_set_option(name.encode(), i(value))
+
+
+def synchronize():
+    lib.ntpoly_amd_synchronize()
+
+
+# ------------------------------------------------------------------ triplets
+class _TripletList:
+    _c = False
+
+    def __init__(self, size=0):
+        self.ih = handle()
+        getattr(lib, "ConstructTripletList_%s_wrp" % self._sfx)(self.ih, i(size))
+
+    def __del__(self):
+        if getattr(self, "ih", None) is not None and lib is not None:
+            getattr(lib, "DestructTripletList_%s_wrp" % self._sfx)(self.ih)
+            self.ih = None
+
+    def GetSize(self):
+        return int(getattr(lib, "GetTripletListSize_%s_wrp" % self._sfx)(self.ih))
+
+    def Append(self, index_column, index_row, point_value):
+        if self._c:
+            lib.AppendToTripletList_c_wrp(self.ih, i(index_column), i(index_row), d(point_value.real), d(point_value.imag))
+        else:
+            lib.AppendToTripletList_r_wrp(self.ih, i(index_column), i(index_row), d(point_value))
+
+    def GetTripletAt(self, index):
+        col, row = C.c_int(), C.c_int()
+        if self._c:
+            re, im = C.c_double(), C.c_double()
+            lib.GetTripletAt_c_wrp(self.ih, i(index + 1), C.byref(col), C.byref(row), C.byref(re), C.byref(im))
+            return col.value, row.value, complex(re.value, im.value)
+        val = C.c_double()
+        lib.GetTripletAt_r_wrp(self.ih, i(index + 1), C.byref(col), C.byref(row), C.byref(val))
+        return col.value, row.value, val.value
+
+    # bulk transfer (extension; the reference ABI moves one triplet per call)
+    def set_arrays(self, col, row, val):
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        row = np.ascontiguousarray(row, dtype=np.int32)
+        if self._c:
+            val = np.ascontiguousarray(val, dtype=np.complex128)
+            lib.ntpoly_amd_triplets_set_c(self.ih, ll(len(col)), col.ctypes.data_as(C.c_void_p),
+                                          row.ctypes.data_as(C.c_void_p), val.ctypes.data_as(C.c_void_p))
+        else:
+            val = np.ascontiguousarray(val, dtype=np.float64)
+            lib.ntpoly_amd_triplets_set_r(self.ih, ll(len(col)), col.ctypes.data_as(C.c_void_p),
+                                          row.ctypes.data_as(C.c_void_p), val.ctypes.data_as(C.c_void_p))
+
+    def arrays(self):
+        n = self.GetSize()
+        col = np.empty(n, dtype=np.int32)
+        row = np.empty(n, dtype=np.int32)
+        val = np.empty(n, dtype=np.complex128 if self._c else np.float64)
+        lib.ntpoly_amd_triplets_get(self.ih, col.ctypes.data_as(C.c_void_p), row.ctypes.data_as(C.c_void_p),
+                                    val.ctypes.data_as(C.c_void_p))
+        return col, row, val
+
+
+class TripletList_r(_TripletList):
+    _sfx, _c = "r", False
+
+
+class TripletList_c(_TripletList):
+    _sfx, _c = "c", True
+
+
+def _tlist_from(col, row, val):
+    t = TripletList_c() if np.iscomplexobj(val) else TripletList_r()
+    t.set_arrays(col, row, val)
+    return t
+
+
+# ------------------------------------------------------------------ permutation / parameters / pools
+class Permutation:
+    def __init__(self, matrix_dimension):
+        self.ih = handle()
+        self.dim = matrix_dimension
+        lib.ConstructDefaultPermutation_wrp(self.ih, i(matrix_dimension))
+
+    def __del__(self):
+        if getattr(self, "ih", None) is not None and lib is not None:
+            lib.DestructPermutation_wrp(self.ih)
+            self.ih = None
+
+    def _rebuild(self, fn):
+        lib.DestructPermutation_wrp(self.ih)
+        getattr(lib, fn)(self.ih, i(self.dim))
+
+    def SetDefaultPermutation(self):
+        self._rebuild("ConstructDefaultPermutation_wrp")
+
+    def SetReversePermutation(self):
+        self._rebuild("ConstructReversePermutation_wrp")
+
+    def SetRandomPermutation(self):
+        self._rebuild("ConstructRandomPermutation_wrp")
+
+    def set_lookup(self, index_lookup):
+        arr = np.ascontiguousarray(index_lookup, dtype=np.int32)
+        lib.ntpoly_amd_permutation_set(self.ih, i(len(arr)), arr.ctypes.data_as(C.c_void_p))
+
+
+class SolverParameters:
+    def __init__(self):
+        self.ih = handle()
+        lib.ConstructSolverParameters_wrp(self.ih)
+        self._perm = None
+
+    def __del__(self):
+        if getattr(self, "ih", None) is not None and lib is not None:
+            lib.DestructSolverParameters_wrp(self.ih)
+            self.ih = None
+
+    def SetConvergeDiff(self, v):
+        lib.SetParametersConvergeDiff_wrp(self.ih, d(v))
+
+    def SetMaxIterations(self, v):
+        lib.SetParametersMaxIterations_wrp(self.ih, i(v))
+
+    def SetVerbosity(self, v):
+        lib.SetParametersBeVerbose_wrp(self.ih, b(v))
+
+    def SetThreshold(self, v):
+        lib.SetParametersThreshold_wrp(self.ih, d(v))
+
+    def SetLoadBalance(self, permutation):
+        self._perm = permutation
+        lib.SetParametersLoadBalance_wrp(self.ih, permutation.ih)
+
+    def SetStepThreshold(self, v):
+        lib.SetParametersStepThreshold_wrp(self.ih, d(v))
+
+    def SetMonitorConvergence(self, v):
+        lib.SetParametersMonitorConvergence_wrp(self.ih, b(v))
+
+
+class PMatrixMemoryPool:
+    def __init__(self, matrix):
+        self.ih = handle()
+        lib.ConstructMatrixMemoryPool_p_wrp(self.ih, matrix.ih)
+
+    def __del__(self):
+        if getattr(self, "ih", None) is not None and lib is not None:
+            lib.DestructMatrixMemoryPool_p_wrp(self.ih)
+            self.ih = None
+
+
+class MatrixMemoryPool_r:
+    def __init__(self, columns, rows):
+        self.ih = handle()
+        lib.ConstructMatrixMemoryPool_lr_wrp(self.ih, i(columns), i(rows))
+
+    def __del__(self):
+        if getattr(self, "ih", None) is not None and lib is not None:
+            lib.DestructMatrixMemoryPool_lr_wrp(self.ih)
+            self.ih = None
+
+
+class MatrixMemoryPool_c(MatrixMemoryPool_r):
+    def __init__(self, columns, rows):
+        self.ih = handle()
+        lib.ConstructMatrixMemoryPool_lc_wrp(self.ih, i(columns), i(rows))
+
+    def __del__(self):
+        if getattr(self, "ih", None) is not None and lib is not None:
+            lib.DestructMatrixMemoryPool_lc_wrp(self.ih)
+            self.ih = None
+
+
+# ------------------------------------------------------------------ distributed matrix
+class Matrix_ps:
+    """PSMatrix.h:20-197."""
+
+    def __init__(self, arg=None):
+        self.ih = handle()
+        if isinstance(arg, Matrix_ps):
+            lib.ConstructEmptyMatrix_ps_wrp(self.ih, i(arg.GetActualDimension()))
+            lib.CopyMatrix_ps_wrp(arg.ih, self.ih)
+        elif isinstance(arg, str):
+            raw, n = s(arg)
+            if arg.endswith(".mtx"):
+                lib.ConstructMatrixFromMatrixMarket_ps_wrp(self.ih, raw, n)
+            else:
+                lib.ConstructMatrixFromBinary_ps_wrp(self.ih, raw, n)
+        else:
+            lib.ConstructEmptyMatrix_ps_wrp(self.ih, i(arg))
+
+    def __del__(self):
+        if getattr(self, "ih", None) is not None and lib is not None:
+            lib.DestructMatrix_ps_wrp(self.ih)
+            self.ih = None
+
+    # -- construction helpers used by the tests
+    @classmethod
+    def from_triplets(cls, dim, col, row, val):
+        m = cls(dim)
+        m.FillFromTripletList(_tlist_from(col, row, val))
+        return m
+
+    @classmethod
+    def from_scipy(cls, mat):
+        c = mat.tocsc()
+        c.sort_indices()
+        col = np.repeat(np.arange(c.shape[1], dtype=np.int32), np.diff(c.indptr)) + 1
+        return cls.from_triplets(c.shape[0], col, c.indices.astype(np.int32) + 1, c.data)
+
+    def triplets(self):
+        """local triplets (col,row,val), 1-based global indices, sorted by column then row"""
+        t = TripletList_c() if self.IsComplex() else TripletList_r()
+        self.GetTripletList(t)
+        return t.arrays()
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        col, row, val = self.triplets()
+        n = self.GetActualDimension()
+        return sp.csc_matrix((val, (row - 1, col - 1)), shape=(n, n))
+
+    # -- reference API
+    def WriteToBinary(self, path):
+        raw, n = s(path)
+        lib.WriteMatrixToBinary_ps_wrp(self.ih, raw, n)
+
+    def WriteToMatrixMarket(self, path):
+        raw, n = s(path)
+        lib.WriteMatrixToMatrixMarket_ps_wrp(self.ih, raw, n)
+
+    def FillFromTripletList(self, tlist, prepartitioned=False):
+        if prepartitioned:  # Fortran API: prepartitioned_in=.TRUE. (each rank passes its own columns)
+            lib.ntpoly_amd_fill_prepartitioned(self.ih, tlist.ih)
+        elif tlist._c:
+            lib.FillMatrixFromTripletList_psc_wrp(self.ih, tlist.ih)
+        else:
+            lib.FillMatrixFromTripletList_psr_wrp(self.ih, tlist.ih)
+
+    def FillPermutation(self, permutation, permuterows=True):
+        lib.FillMatrixPermutation_ps_wrp(self.ih, permutation.ih, b(permuterows))
+
+    def FillIdentity(self):
+        lib.FillMatrixIdentity_ps_wrp(self.ih)
+
+    def GetActualDimension(self):
+        v = C.c_int()
+        lib.GetMatrixActualDimension_ps_wrp(self.ih, C.byref(v))
+        return v.value
+
+    def GetLogicalDimension(self):
+        v = C.c_int()
+        lib.GetMatrixLogicalDimension_ps_wrp(self.ih, C.byref(v))
+        return v.value
+
+    def GetSize(self):
+        v = C.c_long()
+        lib.GetMatrixSize_ps_wrp(self.ih, C.byref(v))
+        return v.value
+
+    def IsComplex(self):
+        return bool(lib.ntpoly_amd_matrix_is_complex(self.ih))
+
+    def local_columns(self):
+        a, c = C.c_int(), C.c_int()
+        lib.ntpoly_amd_matrix_local_columns(self.ih, C.byref(a), C.byref(c))
+        return a.value, c.value
+
+    def GetTripletList(self, tlist):
+        if tlist._c:
+            lib.GetMatrixTripletList_psc_wrp(self.ih, tlist.ih)
+        else:
+            lib.GetMatrixTripletList_psr_wrp(self.ih, tlist.ih)
+
+    def Transpose(self, matA):
+        lib.TransposeMatrix_ps_wrp(matA.ih, self.ih)
+
+    def Conjugate(self):
+        lib.ConjugateMatrix_ps_wrp(self.ih)
+
+    def Dot(self, matB):
+        if self.IsComplex() or matB.IsComplex():
+            re, im = C.c_double(), C.c_double()
+            lib.DotMatrix_psc_wrp(self.ih, matB.ih, C.byref(re), C.byref(im))
+            return complex(re.value, im.value)
+        v = C.c_double()
+        lib.DotMatrix_psr_wrp(self.ih, matB.ih, C.byref(v))
+        return v.value
+
+    def Increment(self, matB, alpha=1.0, threshold=0.0):
+        """this <- alpha*matB + this (PSMatrix.cc Increment)"""
+        lib.IncrementMatrix_ps_wrp(matB.ih, self.ih, d(alpha), d(threshold))
+
+    def PairwiseMultiply(self, matA, matB):
+        lib.MatrixPairwiseMultiply_ps_wrp(matA.ih, matB.ih, self.ih)
+
+    def Gemm(self, matA, matB, memory_pool=None, alpha=1.0, beta=0.0, threshold=0.0):
+        """this = alpha*matA*matB + beta*this (PSMatrix.cc:208-213)"""
+        pool = memory_pool if memory_pool is not None else PMatrixMemoryPool(matA)
+        lib.MatrixMultiply_ps_wrp(matA.ih, matB.ih, self.ih, d(alpha), d(beta), d(threshold), pool.ih)
+
+    def Scale(self, constant):
+        lib.ScaleMatrix_ps_wrp(self.ih, d(constant))
+
+    def Norm(self):
+        return float(lib.MatrixNorm_ps_wrp(self.ih))
+
+    def MeasureAsymmetry(self):
+        return float(lib.MeasureAsymmetry_ps_wrp(self.ih))
+
+    def Trace(self):
+        v = C.c_double()
+        lib.MatrixTrace_ps_wrp(self.ih, C.byref(v))
+        return v.value
+
+    def IsIdentity(self):
+        return bool(lib.IsIdentity_ps_wrp(self.ih))
+
+    def Symmetrize(self):
+        lib.SymmetrizeMatrix_ps_wrp(self.ih)
+
+
+# ------------------------------------------------------------------ local matrices (config 2)
+class _Matrix_ls:
+    def __init__(self, rows=None, columns=None, tlist=None, path=None):
+        self.ih = handle()
+        sfx = self._sfx
+        if path is not None:
+            raw, n = s(path)
+            getattr(lib, "ConstructMatrixFromFile_%s_wrp" % sfx)(self.ih, raw, n)
+        elif tlist is not None:
+            getattr(lib, "ConstructMatrixFromTripletList_%s_wrp" % sfx)(self.ih, tlist.ih, i(rows), i(columns))
+        else:
+            getattr(lib, "ConstructZeroMatrix_%s_wrp" % sfx)(self.ih, i(rows), i(columns))
+
+    def __del__(self):
+        if getattr(self, "ih", None) is not None and lib is not None:
+            getattr(lib, "DestructMatrix_%s_wrp" % self._sfx)(self.ih)
+            self.ih = None
+
+    @classmethod
+    def from_triplets(cls, rows, cols, col, row, val):
+        return cls(rows, cols, tlist=_tlist_from(col, row, val))
+
+    def GetRows(self):
+        v = C.c_int()
+        getattr(lib, "GetMatrixRows_%s_wrp" % self._sfx)(self.ih, C.byref(v))
+        return v.value
+
+    def GetColumns(self):
+        v = C.c_int()
+        getattr(lib, "GetMatrixColumns_%s_wrp" % self._sfx)(self.ih, C.byref(v))
+        return v.value
+
+    def Scale(self, c):
+        getattr(lib, "ScaleMatrix_%s_wrp" % self._sfx)(self.ih, d(c))
+
+    def Increment(self, matB, alpha=1.0, threshold=0.0):
+        getattr(lib, "IncrementMatrix_%s_wrp" % self._sfx)(matB.ih, self.ih, d(alpha), d(threshold))
+
+    def PairwiseMultiply(self, matA, matB):
+        getattr(lib, "PairwiseMultiplyMatrix_%s_wrp" % self._sfx)(matA.ih, matB.ih, self.ih)
+
+    def Gemm(self, matA, matB, isATransposed=False, isBTransposed=False, alpha=1.0, beta=0.0, threshold=0.0,
+             memory_pool=None):
+        """this = alpha*op(matA)*op(matB) + beta*this (SMatrix.cc Gemm)"""
+        pool = memory_pool if memory_pool is not None else self._pool(matB.GetColumns(), matA.GetRows())
+        getattr(lib, "MatrixMultiply_%s_wrp" % self._sfx)(matA.ih, matB.ih, self.ih, b(isATransposed), b(isBTransposed),
+                                                          d(alpha), d(beta), d(threshold), pool.ih)
+
+    def Transpose(self, matA):
+        getattr(lib, "TransposeMatrix_%s_wrp" % self._sfx)(matA.ih, self.ih)
+
+    def triplets(self):
+        t = TripletList_c() if self._sfx == "lsc" else TripletList_r()
+        getattr(lib, "MatrixToTripletList_%s_wrp" % self._sfx)(self.ih, t.ih)
+        return t.arrays()
+
+
+class Matrix_lsr(_Matrix_ls):
+    _sfx, _pool = "lsr", MatrixMemoryPool_r
+
+    def Dot(self, matB):
+        v = C.c_double()
+        lib.DotMatrix_lsr_wrp(self.ih, matB.ih, C.byref(v))
+        return v.value
+
+
+class Matrix_lsc(_Matrix_ls):
+    _sfx, _pool = "lsc", MatrixMemoryPool_c
+
+    def Dot(self, matB):
+        re, im = C.c_double(), C.c_double()
+        lib.DotMatrix_lsc_wrp(self.ih, matB.ih, C.byref(re), C.byref(im))
+        return complex(re.value, im.value)
+
+    def Conjugate(self):
+        lib.ConjugateMatrix_lsc_wrp(self.ih)
+
+
+# ------------------------------------------------------------------ solvers (static-method classes as in Source/CPlusPlus)
+class DensityMatrixSolvers:
+    @staticmethod
+    def _run(fn, Hamiltonian, InverseSquareRoot, trace, Density, solver_parameters):
+        e, mu = C.c_double(), C.c_double()
+        fn(Hamiltonian.ih, InverseSquareRoot.ih, d(trace), Density.ih, C.byref(e), C.byref(mu), solver_parameters.ih)
+        return e.value, mu.value
+
+    @staticmethod
+    def PM(H, ISQ, trace, Density, solver_parameters):
+        return DensityMatrixSolvers._run(lib.PM_wrp, H, ISQ, trace, Density, solver_parameters)
+
+    @staticmethod
+    def TRS2(H, ISQ, trace, Density, solver_parameters):
+        return DensityMatrixSolvers._run(lib.TRS2_wrp, H, ISQ, trace, Density, solver_parameters)
+
+    @staticmethod
+    def TRS4(H, ISQ, trace, Density, solver_parameters):
+        return DensityMatrixSolvers._run(lib.TRS4_wrp, H, ISQ, trace, Density, solver_parameters)
+
+    @staticmethod
+    def HPCP(H, ISQ, trace, Density, solver_parameters):
+        return DensityMatrixSolvers._run(lib.HPCP_wrp, H, ISQ, trace, Density, solver_parameters)
+
+
+class SignSolvers:
+    @staticmethod
+    def ComputeSign(mat, signmat, solver_parameters):
+        lib.SignFunction_wrp(mat.ih, signmat.ih, solver_parameters.ih)
+
+    @staticmethod
+    def ComputePolarDecomposition(mat, umat, hmat, solver_parameters):
+        lib.PolarDecomposition_wrp(mat.ih, umat.ih, hmat.ih, solver_parameters.ih)
+
+
+class InverseSolvers:
+    @staticmethod
+    def Invert(mat, inverse, solver_parameters):
+        lib.Invert_wrp(mat.ih, inverse.ih, solver_parameters.ih)
+
+    @staticmethod
+    def PseudoInverse(mat, inverse, solver_parameters):
+        lib.PseudoInverse_wrp(mat.ih, inverse.ih, solver_parameters.ih)
+
+
+class SquareRootSolvers:
+    @staticmethod
+    def SquareRoot(mat, out, solver_parameters):
+        lib.SquareRoot_wrp(mat.ih, out.ih, solver_parameters.ih)
+
+    @staticmethod
+    def InverseSquareRoot(mat, out, solver_parameters):
+        lib.InverseSquareRoot_wrp(mat.ih, out.ih, solver_parameters.ih)
+
+    @staticmethod
+    def with_order(mat, out, solver_parameters, inverse, order):
+        lib.ntpoly_amd_square_root_order(mat.ih, out.ih, solver_parameters.ih, i(int(inverse)), i(order))
+
+
+class LoadBalancer:
+    @staticmethod
+    def PermuteMatrix(mat_in, mat_out, permutation, memorypool=None):
+        pool = memorypool if memorypool is not None else PMatrixMemoryPool(mat_in)
+        lib.PermuteMatrix_wrp(mat_in.ih, mat_out.ih, permutation.ih, pool.ih)
+
+    @staticmethod
+    def UndoPermuteMatrix(mat_in, mat_out, permutation, memorypool=None):
+        pool = memorypool if memorypool is not None else PMatrixMemoryPool(mat_in)
+        lib.UndoPermuteMatrix_wrp(mat_in.ih, mat_out.ih, permutation.ih, pool.ih)
+
+
+class EigenBounds:
+    @staticmethod
+    def GershgorinBounds(matrix):
+        mn, mx = C.c_double(), C.c_double()
+        lib.GershgorinBounds_wrp(matrix.ih, C.byref(mn), C.byref(mx))
+        return mn.value, mx.value
+
+
+def ActivateLogger(start_document=False, file_name=None):
+    if file_name:
+        raw, n = s(file_name)
+        lib.ActivateLoggerFile_wrp(b(start_document), raw, n)
+    else:
+        lib.ActivateLogger_wrp(b(start_document))
+
+
+def DeactivateLogger():
+    lib.DeactivateLogger_wrp()
+
+
+# ------------------------------------------------------------------ statistics (extensions)
+def last_spgemm_stats():
+    out = (C.c_longlong * 12)()
+    a, t = C.c_float(), C.c_float()
+    lib.ntpoly_amd_last_spgemm_stats(out, C.byref(a), C.byref(t))
+    return dict(nnz_a=out[0], nnz_b=out[1], nnz_c=out[2], products=out[3], tmp_entries=out[4],
+                bins=[out[5 + k] for k in range(6)], overflow=out[11], ms_numeric=a.value, ms_total=t.value)
+
+
+def reset_spgemm_accum():
+    lib.ntpoly_amd_reset_spgemm_accum()
+
+
+def spgemm_accum():
+    out = (C.c_longlong * 3)()
+    dd = (C.c_double * 3)()
+    lib.ntpoly_amd_get_spgemm_accum(out, dd)
+    return dict(calls=out[0], products=out[1], nnz_c=out[2], alg_bytes=dd[0], ms_numeric=dd[1], ms_total=dd[2])
+
+
+def solver_trace():
+    n = int(lib.ntpoly_amd_trace_iterations())
+    v = np.zeros(n)
+    e = np.zeros(n)
+    sg = np.zeros(n)
+    nz = np.zeros(n, dtype=np.int64)
+    if n:
+        lib.ntpoly_amd_trace_get(v.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                                 sg.ctypes.data_as(C.c_void_p), nz.ctypes.data_as(C.c_void_p))
+    a, c = C.c_double(), C.c_double()
+    lib.ntpoly_amd_trace_times(C.byref(a), C.byref(c))
+    return dict(iterations=n, value=v, energy=e, sigma=sg, nnz=nz, setup_ms=a.value, loop_ms=c.value)
+
+
+def memory():
+    a, c = C.c_longlong(), C.c_longlong()
+    lib.ntpoly_amd_memory(C.byref(a), C.byref(c))
+    return a.value, c.value

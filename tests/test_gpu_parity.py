@@ -1,0 +1,285 @@
+"""GPU parity tests: the HIP engine, called through its C ABI (ntpoly_amd.host is a thin ctypes
+mirror of the reference's class surface), against
+  (1) the golden vectors produced by the REAL reference (tests/golden/*.npz), and
+  (2) the C oracle (oracle/) on seeded inputs at sizes it finishes in seconds.
+Sparse-branch SpGEMM and increment must be BIT-EXACT (same ascending-k, unfused arithmetic);
+reductions (dot/trace/norm) are compared to 1e-13 relative (different summation tree);
+the reference's BLAS dense branch to 1e-13 relative."""
+import numpy as np
+import pytest
+
+from golden_util import Golden, same_pattern, to_dense
+from gen import banded_triplets
+
+pytestmark = pytest.mark.gpu
+DENSE_RTOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def nt():
+    import ntpoly_amd as nt
+    nt.init_comm()
+    nt.ConstructGlobalProcessGrid(1, 1, 1)
+    return nt
+
+
+def exact(got, want, what):
+    assert same_pattern((0, 0) + tuple(got), want), "%s: pattern differs (%d vs %d nnz)" % (what, len(got[0]), len(want[2]))
+    assert np.array_equal(got[2], want[4]), "%s: values differ, max |d| = %g" % (what, np.abs(got[2] - want[4]).max())
+
+
+def close(got, want, rtol, what):
+    g = to_dense((want[0], want[1]) + tuple(got))
+    w = to_dense(want)
+    assert np.abs(g - w).max() <= rtol * max(1.0, np.abs(w).max()), "%s: max |d| = %g" % (what, np.abs(g - w).max())
+
+
+def lmat(nt, t):
+    cls = nt.Matrix_lsc if np.iscomplexobj(t[4]) else nt.Matrix_lsr
+    return cls.from_triplets(t[0], t[1], t[2], t[3], t[4])
+
+
+def pmat(nt, t):
+    return nt.Matrix_ps.from_triplets(t[0], t[2], t[3], t[4])
+
+
+def test_local_gemm_golden(nt):
+    """test_matrix.py:224-362 through MatrixMultiply_ls{r,c}_wrp"""
+    g = Golden("local_gemm")
+    n_exact = 0
+    for i, c in enumerate(g.cases):
+        A, B = g.tri(i, "A"), g.tri(i, "B")
+        want = g.tri(i, "C")
+        is_c = c["complex"]
+        cls = nt.Matrix_lsc if is_c else nt.Matrix_lsr
+        mA = cls.from_triplets(A[0], A[1], A[2], A[3], A[4].astype(complex) if is_c else A[4])
+        mB = cls.from_triplets(B[0], B[1], B[2], B[3], B[4].astype(complex) if is_c else B[4])
+        if g.has(i, "Cin"):
+            Ci = g.tri(i, "Cin")
+            mC = cls.from_triplets(Ci[0], Ci[1], Ci[2], Ci[3], Ci[4].astype(complex) if is_c else Ci[4])
+        else:
+            mC = cls(want[0], want[1])
+        mC.Gemm(mA, mB, bool(c["tA"]), bool(c["tB"]), c["alpha"], 0.0 if c["beta"] is None else c["beta"], c["thr"])
+        got = mC.triplets()
+        sp_a = len(A[2]) / float(max(1, A[0] * A[1]))
+        sp_b = len(B[2]) / float(max(1, B[0] * B[1]))
+        if min(sp_a, sp_b) > 0.1:
+            if c["thr"] == 0.0:
+                close(got, want, DENSE_RTOL, "case %d (dense branch)" % i)
+        else:
+            exact(got, want, "case %d %s" % (i, c))
+            n_exact += 1
+    assert n_exact >= 40
+
+
+def test_local_increment_golden(nt):
+    g = Golden("local_increment")
+    for i, c in enumerate(g.cases):
+        mA, mB = lmat(nt, g.tri(i, "A")), lmat(nt, g.tri(i, "B"))
+        if c["complex"] and not np.iscomplexobj(g.tri(i, "A")[4]):
+            continue
+        mB.Increment(mA, c["alpha"], c["thr"])
+        exact(mB.triplets(), g.tri(i, "C"), "case %d %s" % (i, c))
+
+
+@pytest.mark.parametrize("force_bin", [-1, 4, 5, 6])
+def test_ps_gemm_golden(nt, force_bin):
+    """test_psmatrixalgebra.py:193-218 through MatrixMultiply_ps_wrp; every kernel path
+    (LDS window sizes, LDS hash, HBM accumulator) must give the same bits."""
+    nt.set_option("spgemm_force_bin", force_bin)
+    try:
+        g = Golden("ps_gemm")
+        n_exact = 0
+        for i, c in enumerate(g.cases):
+            mA, mB = pmat(nt, g.tri(i, "A")), pmat(nt, g.tri(i, "B"))
+            want = g.tri(i, "C")
+            mC = pmat(nt, g.tri(i, "Cin")) if g.has(i, "Cin") else nt.Matrix_ps(want[0])
+            mC.Gemm(mA, mB, None, c["alpha"], c["beta"], c["thr"])
+            got = mC.triplets()
+            if c["dense_branch"]:
+                close(got, want, DENSE_RTOL, "case %d %s" % (i, c["tag"]))
+            else:
+                exact(got, want, "case %d %s (force_bin %d)" % (i, c["tag"], force_bin))
+                n_exact += 1
+        assert n_exact >= 20
+    finally:
+        nt.set_option("spgemm_force_bin", -1)
+
+
+@pytest.mark.parametrize("force_seq", [0, 1])
+def test_ps_increment_golden(nt, force_seq):
+    nt.set_option("increment_force_seq", force_seq)
+    try:
+        g = Golden("ps_increment")
+        for i, c in enumerate(g.cases):
+            mA, mB = pmat(nt, g.tri(i, "A")), pmat(nt, g.tri(i, "B"))
+            mB.Increment(mA, c["alpha"], c["thr"])
+            exact(mB.triplets(), g.tri(i, "C"), "case %d" % i)
+    finally:
+        nt.set_option("increment_force_seq", 0)
+
+
+def test_ps_scalars_golden(nt):
+    g = Golden("ps_scalars")
+    for i, c in enumerate(g.cases):
+        A, B = pmat(nt, g.tri(i, "A")), pmat(nt, g.tri(i, "B"))
+        assert A.Trace() == pytest.approx(c["trace"], rel=1e-13, abs=1e-13)
+        assert A.Norm() == pytest.approx(c["norm"], rel=1e-13)
+        assert np.real(A.Dot(B)) == pytest.approx(c["dot_real"], rel=1e-12, abs=1e-12)
+        emin, emax = nt.EigenBounds.GershgorinBounds(A)
+        assert emin == pytest.approx(c["gersh_min"], rel=1e-13)
+        assert emax == pytest.approx(c["gersh_max"], rel=1e-13)
+        assert A.GetSize() == c["nnz"]
+
+
+def _params(nt, c):
+    p = nt.SolverParameters()
+    p.SetConvergeDiff(c["conv"])
+    p.SetMaxIterations(c["maxit"])
+    p.SetThreshold(c["thr"])
+    p.SetMonitorConvergence(c["monitor"])
+    return p
+
+
+def test_solvers_golden(nt):
+    """test_chemistry.py:193-233,266-276 and test_solvers.py:139-162,211-234,364-386 with seeded
+    inputs and the reference's own outputs / per-iteration log as the expected values."""
+    g = Golden("solvers")
+    for i, c in enumerate(g.cases):
+        H = pmat(nt, g.tri(i, "H"))
+        p = _params(nt, c)
+        want = g.tri(i, "K")
+        K = nt.Matrix_ps(want[0])
+        if c["solver"] in ("trs2", "trs4"):
+            if c["isq"] == "identity":
+                ISQ = nt.Matrix_ps(want[0])
+                ISQ.FillIdentity()
+                if H.IsComplex():
+                    pass
+            else:
+                ISQ = pmat(nt, g.tri(i, "ISQ"))
+            fn = nt.DensityMatrixSolvers.TRS2 if c["solver"] == "trs2" else nt.DensityMatrixSolvers.TRS4
+            energy, mu = fn(H, ISQ, c["nel"], K, p)
+            tr = nt.solver_trace()
+            log_e = g.arr(i, "log_energy")
+            n = len(log_e)
+            assert tr["iterations"] in (n, n + 1), (c["tag"], tr["iterations"], n)
+            assert np.allclose(tr["energy"][:n], log_e, rtol=1e-11, atol=1e-11), c["tag"]
+            assert energy == pytest.approx(c["energy"], rel=1e-11), c["tag"]
+            mu_tol = 1e-9 if c["solver"] == "trs2" else 1e-5
+            assert mu == pytest.approx(c["mu"], rel=mu_tol, abs=1e-11), c["tag"]
+        else:
+            fn = dict(sign=nt.SignSolvers.ComputeSign, invert=nt.InverseSolvers.Invert,
+                      isq=nt.SquareRootSolvers.InverseSquareRoot, sqrt=nt.SquareRootSolvers.SquareRoot)[c["solver"]]
+            fn(H, K, p)
+            tr = nt.solver_trace()
+            log_c = g.arr(i, "log_convergence")
+            if c["solver"] == "invert":
+                log_c = log_c[::2]
+            assert tr["iterations"] == len(log_c), (c["tag"], tr["iterations"], len(log_c))
+            assert np.allclose(tr["value"], log_c, rtol=1e-9, atol=1e-13), c["tag"]
+        got = K.triplets()
+        gd = to_dense((want[0], want[1]) + tuple(got))
+        wd = to_dense(want)
+        tol = max(10 * c["thr"], 1e-10) * max(1.0, np.abs(wd).max())
+        assert np.abs(gd - wd).max() <= tol, "%s: max |d| = %g" % (c["tag"], np.abs(gd - wd).max())
+        assert abs(K.GetSize() - c["nnz"]) <= max(2, 0.01 * c["nnz"]), (c["tag"], K.GetSize(), c["nnz"])
+
+
+def test_premade_fixture(nt):
+    """the reference's shipped Examples/PremadeMatrix output (nel = 5)"""
+    g = Golden("solvers")
+    idx = [i for i, c in enumerate(g.cases) if c["tag"] == "premade_trs2_nel5"][0]
+    c = g.cases[idx]
+    H, ISQ = pmat(nt, g.tri(idx, "H")), pmat(nt, g.tri(idx, "ISQ"))
+    K = nt.Matrix_ps(7)
+    energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, 5.0, K, _params(nt, c))
+    Dref = to_dense(g.tri(None, "premade_density_reference"))
+    assert np.linalg.norm(K.to_scipy().toarray() - Dref) <= 5e-5
+    assert energy == pytest.approx(-22.971963210096895, rel=1e-10)
+    assert mu == pytest.approx(0.1491684406929008, rel=1e-8)
+    assert nt.solver_trace()["iterations"] == 19
+
+
+def test_load_balanced_solver_matches(nt):
+    """test_chemistry.py:203-205: a random permutation must not change the result"""
+    g = Golden("solvers")
+    idx = [i for i, c in enumerate(g.cases) if c["tag"] == "banded512_trs2_conv"][0]
+    c = g.cases[idx]
+    H = pmat(nt, g.tri(idx, "H"))
+    ISQ = nt.Matrix_ps(512)
+    ISQ.FillIdentity()
+    p = _params(nt, c)
+    perm = nt.Permutation(512)
+    perm.SetRandomPermutation()
+    p.SetLoadBalance(perm)
+    K = nt.Matrix_ps(512)
+    energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, c["nel"], K, p)
+    assert energy == pytest.approx(c["energy"], rel=1e-10)
+    wd = to_dense(g.tri(idx, "K"))
+    assert np.abs(K.to_scipy().toarray() - wd).max() <= 10 * c["thr"]
+
+
+def test_spgemm_vs_oracle_banded_4096(nt):
+    """config-2 family at a size the oracle does in well under a second: bit-exact"""
+    from oracle import oracle_py as O
+    n, h = 4096, 50
+    col, row, val = banded_triplets(n, h)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    Co = O.ps_multiply(O.Mat.from_triplets(n, n, col, row, val), O.Mat.from_triplets(n, n, col, row, val), None, 1.0, 0.0, 1e-8)
+    C = nt.Matrix_ps(n)
+    C.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+    oc, orow, ov = Co.triplets()
+    exact(C.triplets(), (n, n, oc, orow, ov), "banded 4096")
+    st = nt.last_spgemm_stats()
+    assert st["nnz_c"] == len(ov) and st["products"] > 4e7
+
+
+def test_trs2_vs_oracle_banded_4096(nt):
+    """BASELINE.md golden scalars of the reference itself (N=4096, h=50, thr 1e-8, ISQ = I):
+    energy after 2 / 8 iterations, nnz(K) after 8."""
+    n, h = 4096, 50
+    col, row, val = banded_triplets(n, h)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    ISQ = nt.Matrix_ps(n)
+    ISQ.FillIdentity()
+    for iters, e_ref in ((2, -5.80031452295105E+02), (8, -1.06326987302440E+03)):
+        p = nt.SolverParameters()
+        p.SetConvergeDiff(1e-30)
+        p.SetThreshold(1e-8)
+        p.SetMaxIterations(iters)
+        p.SetMonitorConvergence(False)
+        K = nt.Matrix_ps(n)
+        energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, p)
+        assert energy == pytest.approx(e_ref, rel=1e-12)
+    assert K.GetSize() == 940848
+
+
+def test_full_size_properties_config2(nt):
+    """BASELINE config 2 (N=65536, 101 nnz/row): size-independent checks at full size --
+    symmetry of A*A for symmetric A, trace(A*A) == dot(A, A^T) and exact agreement of two kernel
+    paths (LDS window vs LDS hash) -- plus bit-exact agreement with the oracle."""
+    from oracle import oracle_py as O
+    n, h = 65536, 50
+    col, row, val = banded_triplets(n, h)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    C = nt.Matrix_ps(n)
+    C.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+    st = nt.last_spgemm_stats()
+    assert st["products"] == 668618200 or st["products"] > 6.6e8
+    AT = nt.Matrix_ps(n)
+    AT.Transpose(A)
+    assert C.Trace() == pytest.approx(A.Dot(AT), rel=1e-12)
+    assert C.MeasureAsymmetry() <= 1e-15
+    got = C.triplets()
+    nt.set_option("spgemm_force_bin", 5)
+    try:
+        C2 = nt.Matrix_ps(n)
+        C2.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+    finally:
+        nt.set_option("spgemm_force_bin", -1)
+    g2 = C2.triplets()
+    assert np.array_equal(got[0], g2[0]) and np.array_equal(got[1], g2[1]) and np.array_equal(got[2], g2[2])
+    Ao = O.Mat.from_triplets(n, n, col, row, val)
+    oc, orow, ov = O.ps_multiply(Ao, Ao, None, 1.0, 0.0, 1e-8).triplets()
+    exact(got, (n, n, oc, orow, ov), "config 2 vs oracle")
