@@ -91,8 +91,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     dist = None
     if world > 1:
-        import torch.distributed as dist  # noqa: F811
-    import torch
+        import torch
+        import torch.distributed as dist  # gloo control plane; the data plane is the engine's RCCL
 
     n, h, thr = args.n, args.halfband, args.threshold
     nt.ConstructGlobalProcessGrid(1, world, 1)  # column panels: one per GPU
@@ -119,10 +119,12 @@ def main():
     trace_target = n / 2.0
 
     def fence():
+        # device synchronise (stream + hipDeviceSynchronize inside the engine's own HIP runtime: the same
+        # thing torch.cuda.synchronize() does for torch's), then a barrier over all ranks
         nt.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            nt.synchronize()
 
     energy = 0.0
     for _ in range(args.warmup):
@@ -136,7 +138,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     acc = nt.spgemm_accum()

@@ -18,8 +18,8 @@ namespace ntp {
   } while (0)
 
 Comm& world() {
-  static Comm c;
-  return c;
+  static Comm* c = new Comm();
+  return *c;
 }
 
 static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");

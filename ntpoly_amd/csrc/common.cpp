@@ -11,9 +11,11 @@ void fatal(const char* file, int line, const std::string& msg) {
   std::abort();
 }
 
+// process-lifetime singletons are deliberately leaked: handles owned by the caller (e.g. Python
+// objects) may be destroyed after static destructors have run
 Context& ctx() {
-  static Context c;
-  return c;
+  static Context* c = new Context();
+  return *c;
 }
 
 void ensure_init() {
@@ -46,8 +48,8 @@ struct Pool {
   size_t in_use = 0, cached = 0;
 };
 Pool& pool() {
-  static Pool p;
-  return p;
+  static Pool* p = new Pool();
+  return *p;
 }
 size_t bucket(size_t bytes) {
   if (bytes < 512) return 512;

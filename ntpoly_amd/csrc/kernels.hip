@@ -287,9 +287,35 @@ __global__ __launch_bounds__(256) void k_spgemm_plan(Csc B, const int32_t* __res
     bin_arr[j] = (uint8_t)bin;
     ub_arr[j] = ub;
     ip_arr[j] = ip;
-    atomicAdd(&stats[bin], 1ull);
-    atomicAdd(&stats[7], (unsigned long long)ip);
   }
+}
+
+// histogram of the per-column bins (+ total of an optional int64 array) without hammering one
+// address per column: LDS partials per block, 8 atomics per block.
+// stats[0..6] += bin counts, stats[7] += sum(extra)
+__global__ __launch_bounds__(256) void k_bin_hist(const uint8_t* __restrict__ bin_arr, const int64_t* __restrict__ extra,
+                                                  int n, unsigned long long* __restrict__ stats) {
+  __shared__ unsigned long long h[8];
+  if (threadIdx.x < 8) h[threadIdx.x] = 0ull;
+  __syncthreads();
+  unsigned int local[7] = {0, 0, 0, 0, 0, 0, 0};
+  long long sum = 0;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int b = bin_arr[j];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) local[k] += (b == k) ? 1u : 0u;
+    if (extra) sum += extra[j];
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    unsigned int v = local[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    if (lane_id() == 0 && v) atomicAdd(&h[k], (unsigned long long)v);
+  }
+  sum = wave_sum_i64(sum);
+  if (lane_id() == 0 && sum) atomicAdd(&h[7], (unsigned long long)sum);
+  __syncthreads();
+  if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&stats[threadIdx.x], h[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ SpGEMM: numeric, LDS window
@@ -629,7 +655,6 @@ __global__ void k_inc_plan(Csc A, Csc B, int32_t* __restrict__ lo_arr, int32_t* 
   lo_arr[j] = span > 0 ? lo : 0;
   span_arr[j] = span;
   bin_arr[j] = (uint8_t)bin;
-  atomicAdd(&stats[bin], 1ull);
 }
 
 template <typename T>
@@ -989,16 +1014,16 @@ void dispatch_type(bool cplx, F&& f) {
 
 // =====================================================================================
 EngineOptions& options() {
-  static EngineOptions o;
-  return o;
+  static EngineOptions* o = new EngineOptions();
+  return *o;
 }
 SpgemmStats& last_spgemm_stats() {
-  static SpgemmStats s;
-  return s;
+  static SpgemmStats* s = new SpgemmStats();
+  return *s;
 }
 SpgemmAccum& spgemm_accum() {
-  static SpgemmAccum a;
-  return a;
+  static SpgemmAccum* a = new SpgemmAccum();
+  return *a;
 }
 
 int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n) {
@@ -1072,6 +1097,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   count.zero();
   hipLaunchKernelGGL(k_spgemm_plan, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(B), cmin.p,
                      cmax.p, clen.p, lo.p, span.p, bin.p, ub.p, ip.p, stats.p, options().spgemm_force_bin);
+  hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, ip.p, n, stats.p);
   hipLaunchKernelGGL(k_scan_excl_i64, dim3(1), dim3(1024), 0, stream(), ub.p, tmpoff.p, (int64_t)n);
   unsigned long long hstats[16];
   int64_t tmp_total = 0;
@@ -1183,6 +1209,8 @@ void increment(const DevMat& A, DevMat& B, double alpha, double threshold) {
   count.zero();
   hipLaunchKernelGGL(k_inc_plan, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(A), view(B), lo.p, span.p, bin.p,
                      stats.p, options().increment_force_seq);
+  hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, (const int64_t*)nullptr,
+                     n, stats.p);
   unsigned long long hs[8];
   HIP_CHECK(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, stream()));
   sync_stream();

@@ -15,8 +15,8 @@ namespace ntp {
 
 // ------------------------------------------------------------------ logger
 Logger& logger() {
-  static Logger l;
-  return l;
+  static Logger* l = new Logger();
+  return *l;
 }
 void log_activate(bool start_document, const char* file_name) {
   Logger& l = logger();
@@ -168,8 +168,8 @@ void print_matrix_information(const PSMatrix& m) {  // PSMatrixModule.F90:1248-1
 }
 
 SolverTrace& last_trace() {
-  static SolverTrace t;
-  return t;
+  static SolverTrace* t = new SolverTrace();
+  return *t;
 }
 
 namespace {

@@ -52,7 +52,17 @@ void ntpoly_amd_finalize_comm() { comm_finalize(); }
 int ntpoly_amd_comm_rank() { return world().rank; }
 int ntpoly_amd_comm_size() { return world().nranks; }
 void ntpoly_amd_barrier() { comm_barrier(); }
-void ntpoly_amd_synchronize() { ensure_init(); sync_stream(); }
+void ntpoly_amd_synchronize() {
+  ensure_init();
+  sync_stream();
+  HIP_CHECK(hipDeviceSynchronize());
+}
+// number of visible GPUs (0 without failing: used by test collection)
+int ntpoly_amd_device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
 void ntpoly_amd_panel_range(const int* dim, const int* nranks, const int* rank, int* c0, int* c1) {
   panel_range(*dim, *nranks, *rank, c0, c1);
 }

@@ -49,19 +49,20 @@ def get_unique_id():
 
 
 def init_comm_from_torch():
-    """One process per GPU under torch.distributed.run: broadcast the RCCL id with torch.distributed
-    (plumbing only) and build the engine's communicator.  Returns (rank, world_size)."""
+    """One process per GPU under torch.distributed.run: the 128-byte RCCL id is broadcast over a
+    torch.distributed *gloo* group (control plane only) and the engine builds its own RCCL
+    communicator (data plane, xGMI).  torch's GPU runtime is never initialised: the PyTorch wheel
+    bundles a second HIP/RCCL runtime and two initialised runtimes in one process corrupt the heap
+    at exit.  The engine picks its GPU from LOCAL_RANK.  Returns (rank, world_size)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world <= 1:
         init_comm()
         return 0, 1
-    import torch
     import torch.distributed as dist
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     if not dist.is_initialized():
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo")
     box = [get_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     init_comm(box[0], rank, world)

@@ -13,9 +13,11 @@ def pytest_configure(config):
 
 
 def _have_gpu():
+    # ask the engine's own HIP runtime (importing torch would load a second, bundled HIP runtime
+    # into the process)
     try:
-        import torch
-        return torch.cuda.is_available()
+        import ntpoly_amd
+        return int(ntpoly_amd.lib.ntpoly_amd_device_count()) > 0
     except Exception:
         return False
 
