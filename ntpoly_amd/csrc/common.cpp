@@ -124,8 +124,8 @@ void DevMat::reset_empty(int32_t r, int32_t c, bool z) {
   nnz = 0;
   outer.alloc((size_t)c + 1);
   outer.zero();
-  inner.alloc(0);
-  val.alloc(0);
+  inner.alloc(kIndexSlack);
+  val.alloc(kIndexSlack * (z ? 2 : 1));
 }
 
 void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
@@ -134,8 +134,8 @@ void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
   cplx = z;
   nnz = nz;
   outer.alloc((size_t)c + 1);
-  inner.alloc((size_t)nz);
-  val.alloc((size_t)nz * (z ? 2 : 1));
+  inner.alloc((size_t)nz + kIndexSlack);
+  val.alloc(((size_t)nz + kIndexSlack) * (z ? 2 : 1));
 }
 
 DevMat DevMat::clone() const {

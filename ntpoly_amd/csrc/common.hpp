@@ -89,6 +89,10 @@ struct DevBuf {
 // Matrix_lsc (SMatrixModule.F90:15-30): column-compressed, `outer` = cols+1 offsets (0-based,
 // 64-bit here), `inner` = row ids ascending within a column (0-based here), `val` = nnz doubles
 // (real) or 2*nnz doubles (complex, interleaved re/im).
+// entries reserved past nnz in `inner` and `val` so that the SpGEMM kernels may over-read the tail of
+// a column instead of clamping every lane (never dereferenced as data)
+constexpr size_t kIndexSlack = 1024;
+
 struct DevMat {
   int32_t rows = 0, cols = 0;
   bool cplx = false;

@@ -20,6 +20,8 @@ struct EngineOptions {
   int spgemm_force_bin = -1;   // tests: force every non-empty column through one path (1..5), 6 = HBM fallback
   int increment_force_seq = 0; // tests: force the sequential-merge fallback
   int time_kernels = 0;        // record HIP-event timings in SpgemmStats
+  int spgemm_variant = -1;     // numeric window kernel: -1 auto (column-pair v3 for real operands), 0 one column per
+                               // wave (first generation), other values: experimental generations kept for A/B (kernels.hip)
 };
 EngineOptions& options();
 SpgemmStats& last_spgemm_stats();

@@ -71,6 +71,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   if (n == "spgemm_force_bin") options().spgemm_force_bin = *value;
   else if (n == "increment_force_seq") options().increment_force_seq = *value;
   else if (n == "time_kernels") options().time_kernels = *value;
+  else if (n == "spgemm_variant") options().spgemm_variant = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow

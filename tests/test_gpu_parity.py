@@ -82,11 +82,13 @@ def test_local_increment_golden(nt):
         exact(mB.triplets(), g.tri(i, "C"), "case %d %s" % (i, c))
 
 
-@pytest.mark.parametrize("force_bin", [-1, 4, 5, 6])
-def test_ps_gemm_golden(nt, force_bin):
-    """test_psmatrixalgebra.py:193-218 through MatrixMultiply_ps_wrp; every kernel path
-    (LDS window sizes, LDS hash, HBM accumulator) must give the same bits."""
+@pytest.mark.parametrize("force_bin,variant", [(-1, -1), (-1, 0), (2, 321), (3, 361), (-1, 164), (-1, 2), (4, -1), (5, -1), (6, -1)])
+def test_ps_gemm_golden(nt, force_bin, variant):
+    """test_psmatrixalgebra.py:193-218 through MatrixMultiply_ps_wrp; every kernel path (column-pair
+    kernel, first-generation window kernel, other generations, LDS window sizes, LDS hash, HBM
+    accumulator) must give the same bits."""
     nt.set_option("spgemm_force_bin", force_bin)
+    nt.set_option("spgemm_variant", variant)
     try:
         g = Golden("ps_gemm")
         n_exact = 0
@@ -104,6 +106,7 @@ def test_ps_gemm_golden(nt, force_bin):
         assert n_exact >= 20
     finally:
         nt.set_option("spgemm_force_bin", -1)
+        nt.set_option("spgemm_variant", -1)
 
 
 @pytest.mark.parametrize("force_seq", [0, 1])
@@ -272,14 +275,17 @@ def test_full_size_properties_config2(nt):
     assert C.Trace() == pytest.approx(A.Dot(AT), rel=1e-12)
     assert C.MeasureAsymmetry() <= 1e-15
     got = C.triplets()
-    nt.set_option("spgemm_force_bin", 5)
-    try:
-        C2 = nt.Matrix_ps(n)
-        C2.Gemm(A, A, None, 1.0, 0.0, 1e-8)
-    finally:
-        nt.set_option("spgemm_force_bin", -1)
-    g2 = C2.triplets()
-    assert np.array_equal(got[0], g2[0]) and np.array_equal(got[1], g2[1]) and np.array_equal(got[2], g2[2])
+    for (fb, var) in ((5, -1), (-1, 0)):   # LDS hash path, first-generation window kernel
+        nt.set_option("spgemm_force_bin", fb)
+        nt.set_option("spgemm_variant", var)
+        try:
+            C2 = nt.Matrix_ps(n)
+            C2.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+        finally:
+            nt.set_option("spgemm_force_bin", -1)
+            nt.set_option("spgemm_variant", -1)
+        g2 = C2.triplets()
+        assert np.array_equal(got[0], g2[0]) and np.array_equal(got[1], g2[1]) and np.array_equal(got[2], g2[2])
     Ao = O.Mat.from_triplets(n, n, col, row, val)
     oc, orow, ov = O.ps_multiply(Ao, Ao, None, 1.0, 0.0, 1e-8).triplets()
     exact(got, (n, n, oc, orow, ov), "config 2 vs oracle")

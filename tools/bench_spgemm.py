@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""A/B timing of the SpGEMM numeric-kernel variants in ONE process on the same operand
+(cdna_hip_programming.md 5.4 rule 24): X after `--iters` TRS2 iterations at BASELINE configs[2]."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=262144)
+    ap.add_argument("--halfband", type=int, default=100)
+    ap.add_argument("--threshold", type=float, default=1e-8)
+    ap.add_argument("--iters", type=int, default=6)
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--variants", type=str, default="0,3,2,1")
+    args = ap.parse_args()
+    import ntpoly_amd as nt
+    from gen import banded_triplets
+    from bench import trs2_step
+    nt.init_comm()
+    nt.ConstructGlobalProcessGrid(1, 1, 1)
+    nt.set_option("time_kernels", 1)
+    n, h, thr = args.n, args.halfband, args.threshold
+    col, row, val = banded_triplets(n, h)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    del col, row, val
+    e_min, e_max = nt.EigenBounds.GershgorinBounds(H)
+    Ident = nt.Matrix_ps(n)
+    Ident.FillIdentity()
+    X = nt.Matrix_ps(H)
+    X.Scale(-1.0)
+    X.Increment(Ident, e_max, 0.0)
+    X.Scale(1.0 / (e_max - e_min))
+    X2 = nt.Matrix_ps(n)
+    pool = nt.PMatrixMemoryPool(H)
+    for _ in range(args.iters):
+        trs2_step(nt, X, X2, H, pool, n / 2.0, thr)
+    variants = [int(v) for v in args.variants.split(",")]
+    ref = None
+    res = {v: [] for v in variants}
+    for rep in range(args.reps):
+        for v in variants:
+            nt.set_option("spgemm_variant", v)
+            X2.Gemm(X, X, pool, 1.0, 0.0, thr)
+            st = nt.last_spgemm_stats()
+            sig = (st["nnz_c"], X2.Dot(H), X2.Trace())
+            if v in (0, 1, 2, 3, 30, 31, 32, 33) or (v >= 100 and v not in (291, 292, 293, 294, 295, 296)):  # ablation variants compute garbage on purpose
+                if ref is None:
+                    ref = sig
+                assert sig == ref, ("variant %d differs" % v, sig, ref)
+            res[v].append((st["ms_numeric"], st["ms_total"]))
+    st = nt.last_spgemm_stats()
+    print("max span per bin:", nt.last_spgemm_stats())
+    print("operand nnz %d, products %.3e, nnz_c %d, bins %s" % (st["nnz_a"], st["products"], st["nnz_c"], st["bins"]))
+    for v in variants:
+        a = np.array(res[v])
+        print("variant %d: numeric ms min %.3f med %.3f | total ms min %.3f med %.3f | %.3e products/s" % (
+            v, a[:, 0].min(), np.median(a[:, 0]), a[:, 1].min(), np.median(a[:, 1]), st["products"] / (a[:, 0].min() * 1e-3)))
+
+
+if __name__ == "__main__":
+    main()
