@@ -12,7 +12,7 @@ W warm-up iterations are followed by exactly K timed ones (barrier + device sync
 sides, max over ranks).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant kernel (SpGEMM numeric, k_spgemm_window): algorithmic bytes
+  roofline     -- the dominant kernel (SpGEMM numeric, k_spgemm_pair3): algorithmic bytes
                   12*(nnzA+nnzB+nnzC)+4*(cols...) per launch / its HIP-event time, vs 8 TB/s HBM
   cpu_baseline -- the oracle (C restatement, kind "port") timed on the host cores on a bounded
                   sample (N_s rows of the same generator), scaled linearly in N (cost is O(N) at
@@ -178,7 +178,7 @@ def main():
             "spgemm_ms_per_call": ms_spgemm / calls,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_spgemm_window (SpGEMM numeric phase)",
+                         "kernel": "k_spgemm_pair3 (SpGEMM numeric phase)",
                          "alg_bytes_per_launch": acc["alg_bytes"] / calls, "ms_per_launch": ms_numeric / calls,
                          "note": "rank-0 panel; algorithmic bytes = 12*(nnzA+nnzB+nnzC)+4*(colsA+colsB+colsC+3)"},
         }

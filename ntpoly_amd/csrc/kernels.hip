@@ -179,6 +179,52 @@ __global__ __launch_bounds__(1024) void k_scan_excl_i32(const int32_t* __restric
   if (t == 1023) out[n] = part[1023];
 }
 
+// three-kernel scan for long arrays: per-block sums, single-block scan of the sums, per-block rescan
+template <typename TIn>
+__global__ __launch_bounds__(256) void k_scan_block_sums(const TIn* __restrict__ in, int64_t n, int64_t* __restrict__ sums) {
+  __shared__ int64_t ws[4];
+  const int64_t base = (int64_t)blockIdx.x * 2048;
+  int64_t s = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int64_t i = base + u * 256 + threadIdx.x;
+    if (i < n) s += (int64_t)in[i];
+  }
+  s = wave_sum_i64(s);
+  if (lane_id() == 0) ws[threadIdx.x / WAVE] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+template <typename TIn>
+__global__ __launch_bounds__(256) void k_scan_block_apply(const TIn* __restrict__ in, int64_t n,
+                                                          const int64_t* __restrict__ block_off, int64_t* __restrict__ out) {
+  // each thread owns 8 consecutive elements; block-level exclusive scan of the per-thread sums
+  __shared__ int64_t part[256];
+  const int64_t base = (int64_t)blockIdx.x * 2048 + (int64_t)threadIdx.x * 8;
+  int64_t v[8];
+  int64_t s = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    v[u] = (base + u < n) ? (int64_t)in[base + u] : 0;
+    s += v[u];
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int64_t t = ((int)threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int64_t run = block_off[blockIdx.x] + (threadIdx.x ? part[threadIdx.x - 1] : 0);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (base + u < n) out[base + u] = run;
+    run += v[u];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = block_off[gridDim.x];
+}
+
 // deterministic final reduction of per-block partials (sum of pairs / min / max)
 __global__ __launch_bounds__(256) void k_reduce_sum2(const double* __restrict__ part, int n,
                                                      double* __restrict__ out) {
@@ -295,6 +341,19 @@ __global__ __launch_bounds__(256) void k_spgemm_plan(Csc B, const int32_t* __res
     bin_arr[j] = (uint8_t)bin;
     ub_arr[j] = ub;
     ip_arr[j] = ip;
+  }
+}
+
+// The column-pair kernel processes columns (2g, 2g+1) together: give both the larger window class so
+// that a pair is never split over two launches.
+__global__ void k_pair_bins(uint8_t* __restrict__ bin_arr, int n) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j0 = 2 * g, j1 = j0 + 1;
+  if (j1 >= n) return;
+  const int b0 = bin_arr[j0], b1 = bin_arr[j1];
+  if (b0 >= 1 && b0 <= 3 && b1 >= 1 && b1 <= 3 && (b0 == 3) != (b1 == 3)) {
+    bin_arr[j0] = 3;
+    bin_arr[j1] = 3;
   }
 }
 
@@ -1074,7 +1133,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_spgemm_pair2(
 template <int MAXCH, int NW>
 __global__ __launch_bounds__(NW* WAVE) void k_spgemm_pair3(
     Csc A, Csc B, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
-    const uint8_t* __restrict__ bin_arr, int my_bin, const int64_t* __restrict__ tmpoff,
+    const uint8_t* __restrict__ bin_arr, int bin_lo, int bin_hi, const int64_t* __restrict__ tmpoff,
     int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count,
     double alpha, double threshold, int dense_rule, int nblocks, int wrt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1092,8 +1151,9 @@ __global__ __launch_bounds__(NW* WAVE) void k_spgemm_pair3(
   const int64_t* __restrict__ Ao = A.outer;
 
   const int j0 = 2 * g, j1 = 2 * g + 1;
-  const bool act0 = uni_i32((j0 < B.cols && bin_arr[min(j0, B.cols - 1)] == my_bin) ? 1 : 0) != 0;
-  const bool act1 = uni_i32((j1 < B.cols && bin_arr[min(j1, B.cols - 1)] == my_bin) ? 1 : 0) != 0;
+  const int bb0 = bin_arr[min(j0, B.cols - 1)], bb1 = bin_arr[min(j1, B.cols - 1)];
+  const bool act0 = uni_i32((j0 < B.cols && bb0 >= bin_lo && bb0 <= bin_hi) ? 1 : 0) != 0;
+  const bool act1 = uni_i32((j1 < B.cols && bb1 >= bin_lo && bb1 <= bin_hi) ? 1 : 0) != 0;
   if (!act0 && !act1) return;
   const int lo0 = uni_i32(act0 ? lo_arr[j0] : 0), span0 = uni_i32(act0 ? span_arr[j0] : 0);
   const int lo1 = uni_i32(act1 ? lo_arr[j1] : 0), span1 = uni_i32(act1 ? span_arr[j1] : 0);
@@ -1856,8 +1916,25 @@ SpgemmAccum& spgemm_accum() {
   return *a;
 }
 
+namespace {
+// out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); asynchronous on the engine stream
+template <typename TIn>
+void scan_async(const TIn* d_in, int64_t* d_out, int64_t n) {
+  if (n <= 4096) {
+    if constexpr (sizeof(TIn) == 8) hipLaunchKernelGGL(k_scan_excl_i64, dim3(1), dim3(1024), 0, stream(), (const int64_t*)d_in, d_out, n);
+    else hipLaunchKernelGGL(k_scan_excl_i32, dim3(1), dim3(1024), 0, stream(), (const int32_t*)d_in, d_out, n);
+    return;
+  }
+  const int nb = (int)((n + 2047) / 2048);
+  DevBuf<int64_t> sums((size_t)nb), offs((size_t)nb + 1);
+  hipLaunchKernelGGL((k_scan_block_sums<TIn>), dim3(nb), dim3(256), 0, stream(), d_in, n, sums.p);
+  hipLaunchKernelGGL(k_scan_excl_i64, dim3(1), dim3(1024), 0, stream(), sums.p, offs.p, (int64_t)nb);
+  hipLaunchKernelGGL((k_scan_block_apply<TIn>), dim3(nb), dim3(256), 0, stream(), d_in, n, offs.p, d_out);
+}
+}  // namespace
+
 int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n) {
-  hipLaunchKernelGGL(k_scan_excl_i64, dim3(1), dim3(1024), 0, stream(), d_in, d_out, n);
+  scan_async<int64_t>(d_in, d_out, n);
   int64_t total = 0;
   HIP_CHECK(hipMemcpyAsync(&total, d_out + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
   sync_stream();
@@ -1924,14 +2001,14 @@ void launch_pair2(int bin, int wrt, const DevMat& A, const DevMat& B, const int3
 }
 
 template <int MAXCH, int NW>
-void launch_pair3(int bin, int wrt, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
+void launch_pair3(int bin_lo, int bin_hi, int wrt, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
                   const uint8_t* binarr, const int64_t* tmpoff, int32_t* out_inner, double* out_val, int32_t* count,
                   double alpha, double thr, int dense_rule) {
   const int ngroups = cdiv(B.cols, 2);
   const int nblocks = cdiv(ngroups, NW);
   const size_t lds = (size_t)NW * 2 * (size_t)wrt * sizeof(double);
   hipLaunchKernelGGL((k_spgemm_pair3<MAXCH, NW>), dim3(xcd_grid(nblocks)), dim3(NW * WAVE), lds, stream(), view(A), view(B),
-                     lo, span, binarr, bin, tmpoff, out_inner, out_val, count, alpha, thr, dense_rule, nblocks, wrt);
+                     lo, span, binarr, bin_lo, bin_hi, tmpoff, out_inner, out_val, count, alpha, thr, dense_rule, nblocks, wrt);
 }
 
 template <typename T, int W, int NW>
@@ -1970,8 +2047,10 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   count.zero();
   hipLaunchKernelGGL(k_spgemm_plan, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(B), cmin.p,
                      cmax.p, clen.p, lo.p, span.p, bin.p, ub.p, ip.p, stats.p, options().spgemm_force_bin);
+  if (!A.cplx && options().spgemm_force_bin <= 0)
+    hipLaunchKernelGGL(k_pair_bins, dim3(cdiv((n + 1) / 2, 256)), dim3(256), 0, stream(), bin.p, n);
   hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, ip.p, span.p, n, stats.p);
-  hipLaunchKernelGGL(k_scan_excl_i64, dim3(1), dim3(1024), 0, stream(), ub.p, tmpoff.p, (int64_t)n);
+  scan_async<int64_t>(ub.p, tmpoff.p, (int64_t)n);
   unsigned long long hstats[16];
   int64_t tmp_total = 0;
   HIP_CHECK(hipMemcpyAsync(hstats, stats.p, sizeof(hstats), hipMemcpyDeviceToHost, stream()));
@@ -1997,7 +2076,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       // default for real operands: column-pair kernel v3, register-set depth from the mean column length of A
       if (variant < 0 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {
         const double avg = (double)A.nnz / (double)std::max(1, A.cols);
-        const int need = (int)std::ceil(avg * 1.15 / 64.0);
+        const int need = (int)std::ceil(avg / 64.0);
         variant = 300 + 10 * std::min(6, std::max(2, need)) + 1;
       }
     }
@@ -2057,16 +2136,25 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
         }
       } else if (variant >= 300 && variant < 400 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {  // pair kernel v3
         const int maxch = (variant / 10) % 10, nw = variant % 10;  // variant = 3<MAXCH><NW>
-        bool launched = false;
-        for (int bsel = 1; bsel <= 3; ++bsel) {
-          if (!hstats[bsel]) continue;
-          const int w = wrt_of(bsel);
+        // window classes 1 and 2 (spans <= 1024) share one launch sized by the largest span present; class 3
+        // (<= 2048) gets its own so that a few wide columns do not cost everybody LDS occupancy
+        const int groups[2][2] = {{1, 2}, {3, 3}};
+        for (int gi = 0; gi < 2; ++gi) {
+          const int blo = groups[gi][0], bhi = groups[gi][1];
+          unsigned long long cols_here = 0;
+          int w = 64;
+          for (int bsel = blo; bsel <= bhi; ++bsel) {
+            cols_here += hstats[bsel];
+            if (hstats[bsel]) w = std::max(w, wrt_of(bsel));
+          }
+          if (!cols_here) continue;
+          bool launched = false;
 #define PAIR3_CASE(M, N) \
-  if (maxch == M && nw == N) { launch_pair3<M, N>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
+  if (maxch == M && nw == N) { launch_pair3<M, N>(blo, bhi, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
           PAIR3_CASE(2, 1) PAIR3_CASE(3, 1) PAIR3_CASE(4, 1) PAIR3_CASE(5, 1) PAIR3_CASE(6, 1) PAIR3_CASE(5, 2) PAIR3_CASE(5, 4)
 #undef PAIR3_CASE
           if (!launched) NTP_FATAL("unknown spgemm_variant");
-          hstats[bsel] = 0;
+          for (int bsel = blo; bsel <= bhi; ++bsel) hstats[bsel] = 0;
         }
       } else if (variant == 3) {  // 1 column per wave, pipelined + ds_add
         if (hstats[1]) launch_mc<T, 1, 4>(1, wrt_of(1), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
@@ -2118,7 +2206,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   C.cols = n;
   C.cplx = A.cplx;
   C.outer.alloc((size_t)n + 1);
-  hipLaunchKernelGGL(k_scan_excl_i32, dim3(1), dim3(1024), 0, stream(), count.p, C.outer.p, (int64_t)n);
+  scan_async<int32_t>(count.p, C.outer.p, (int64_t)n);
   int64_t nnz = 0;
   HIP_CHECK(hipMemcpyAsync(&nnz, C.outer.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
   sync_stream();
@@ -2198,7 +2286,7 @@ void increment(const DevMat& A, DevMat& B, double alpha, double threshold) {
   R.cols = n;
   R.cplx = A.cplx;
   R.outer.alloc((size_t)n + 1);
-  hipLaunchKernelGGL(k_scan_excl_i32, dim3(1), dim3(1024), 0, stream(), count.p, R.outer.p, (int64_t)n);
+  scan_async<int32_t>(count.p, R.outer.p, (int64_t)n);
   int64_t nnz = 0;
   HIP_CHECK(hipMemcpyAsync(&nnz, R.outer.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
   sync_stream();
@@ -2229,7 +2317,7 @@ void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a) {
     hipLaunchKernelGGL((k_pairwise<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), view(A), view(B), nullptr, nullptr,
                        (T*)nullptr, count.p, 0);
   });
-  hipLaunchKernelGGL(k_scan_excl_i32, dim3(1), dim3(1024), 0, stream(), count.p, R.outer.p, (int64_t)n);
+  scan_async<int32_t>(count.p, R.outer.p, (int64_t)n);
   int64_t nnz = 0;
   HIP_CHECK(hipMemcpyAsync(&nnz, R.outer.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
   sync_stream();
@@ -2421,7 +2509,7 @@ DevMat remap_impl(const DevMat& A, const int32_t* d_row_map, const int32_t* d_co
                          colcount.p);
     });
   }
-  hipLaunchKernelGGL(k_scan_excl_i32, dim3(1), dim3(1024), 0, stream(), colcount.p, R.outer.p, (int64_t)new_cols);
+  scan_async<int32_t>(colcount.p, R.outer.p, (int64_t)new_cols);
   sync_stream();
   return R;
 }
