@@ -4,6 +4,7 @@
 // (bench.py / tests use torch.distributed for that) and handed in through comm_init().
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "engine.hpp"
@@ -35,16 +36,23 @@ void comm_init(const char idbytes[128], int rank, int nranks) {
   if (c.nccl) comm_finalize();
   c.rank = rank;
   c.nranks = nranks;
-  if (nranks <= 1) {
+  const char* f = std::getenv("NTPOLY_AMD_FORCE_RCCL");
+  c.force = f && f[0] == '1';
+  if (nranks <= 1 && !c.force) {
     c.rank = 0;
     c.nranks = 1;
     return;
   }
+  if (nranks <= 1) {
+    c.rank = 0;
+    c.nranks = 1;
+  }
   ensure_init();
   ncclUniqueId id;
   std::memcpy(&id, idbytes, sizeof(id));
+  if (c.force && nranks <= 1) NCCL_CHECK(ncclGetUniqueId(&id));
   ncclComm_t comm;
-  NCCL_CHECK(ncclCommInitRank(&comm, nranks, id, rank));
+  NCCL_CHECK(ncclCommInitRank(&comm, c.nranks, id, c.rank));
   c.nccl = comm;
 }
 
