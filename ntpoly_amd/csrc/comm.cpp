@@ -4,6 +4,7 @@
 // (bench.py / tests use torch.distributed for that) and handed in through comm_init().
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -156,6 +157,125 @@ DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths) {
       copy_shift_i64(stage.p + (size_t)coff[(size_t)r] + (size_t)r, full.outer.p + coff[(size_t)r], ncol, zoff[(size_t)r]);
   }
   HIP_CHECK(hipMemcpyAsync(full.outer.p + coff[(size_t)P], &zoff[(size_t)P], sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+  sync_stream();
+  return full;
+}
+
+// Which columns of rank s's panel does a requester with row range [kmin, kmax] need?  Pure host
+// arithmetic, shared with the CPU tests through the C ABI (ntpoly_amd_halo_segment).
+void halo_segment(int32_t dim, int P, int s, int32_t kmin, int32_t kmax, int32_t* a, int32_t* b) {
+  int32_t c0, c1;
+  panel_range(dim, P, s, &c0, &c1);
+  const int32_t lo = std::max(c0, kmin), hi = std::min(c1, kmax + 1);
+  if (kmax < kmin || hi <= lo) {
+    *a = *b = c0;
+  } else {
+    *a = lo;
+    *b = hi;
+  }
+}
+
+// Range-restricted panel exchange ("halo"): rank q only needs the columns of A whose index appears
+// as a row of its B panel, i.e. the contiguous range [kmin_q, kmax_q].  For banded operands that is
+// its own panel plus a halo of one bandwidth on each side (KBs..MBs instead of the whole matrix);
+// for permuted operands it degenerates to the full gather.  Protocol (all on the engine stream):
+//   1. all-gather of the (kmin, kmax) pairs                                   [ncclAllGather, 2 ints]
+//   2. every owner reads the column offsets at its segment boundaries -> entry counts per requester
+//   3. all-gather of the P x P count matrix                                   [ncclAllGather, P int64]
+//   4. one group of ncclSend / ncclRecv per (owner, requester) pair with a non-empty segment:
+//      column offsets of the segment, row ids, values; the own segment is a device copy
+//   5. segments are re-based into one dim-wide matrix whose other columns are empty, so the SpGEMM
+//      kernels run unchanged.
+DevMat gather_needed(const PSMatrix& m, int32_t kmin, int32_t kmax) {
+  Comm& c = world();
+  const int32_t dim = m.dim;
+  if (!c.active()) NTP_FATAL("gather_needed without an active communicator");
+  ncclComm_t comm = static_cast<ncclComm_t>(c.nccl);
+  const int P = c.nranks, me = c.rank;
+  // 1. ranges
+  std::vector<int32_t> req((size_t)2 * P, 0);
+  {
+    DevBuf<int32_t> d((size_t)2 * P);
+    int32_t mine[2] = {kmin, kmax};
+    HIP_CHECK(hipMemcpyAsync(d.p + 2 * me, mine, sizeof(mine), hipMemcpyHostToDevice, stream()));
+    NCCL_CHECK(ncclAllGather(d.p + 2 * me, d.p, 2, ncclInt32, comm, stream()));
+    d.download(req.data(), (size_t)2 * P);
+  }
+  // 2. what I send to every requester
+  std::vector<int32_t> sa((size_t)P), sb((size_t)P);
+  std::vector<int64_t> bound((size_t)2 * P, 0);
+  for (int q = 0; q < P; ++q) {
+    halo_segment(dim, P, me, req[(size_t)2 * q], req[(size_t)2 * q + 1], &sa[(size_t)q], &sb[(size_t)q]);
+    HIP_CHECK(hipMemcpyAsync(&bound[(size_t)2 * q], m.loc.outer.p + (sa[(size_t)q] - m.c0), sizeof(int64_t),
+                             hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(&bound[(size_t)2 * q + 1], m.loc.outer.p + (sb[(size_t)q] - m.c0), sizeof(int64_t),
+                             hipMemcpyDeviceToHost, stream()));
+  }
+  sync_stream();
+  // 3. count matrix cnt[s*P + q] = entries rank s sends to rank q
+  std::vector<int64_t> cnt((size_t)P * P, 0);
+  {
+    DevBuf<int64_t> d((size_t)P * P);
+    std::vector<int64_t> row((size_t)P);
+    for (int q = 0; q < P; ++q) row[(size_t)q] = bound[(size_t)2 * q + 1] - bound[(size_t)2 * q];
+    HIP_CHECK(hipMemcpyAsync(d.p + (size_t)me * P, row.data(), sizeof(int64_t) * (size_t)P, hipMemcpyHostToDevice, stream()));
+    NCCL_CHECK(ncclAllGather(d.p + (size_t)me * P, d.p, (size_t)P, ncclInt64, comm, stream()));
+    d.download(cnt.data(), (size_t)P * P);
+  }
+  // 4. receive layout: sources in rank order (their segments tile [kmin, kmax] in ascending columns)
+  std::vector<int32_t> ra((size_t)P), rb((size_t)P);
+  std::vector<int64_t> zoff((size_t)P + 1, 0), soff((size_t)P + 1, 0);
+  for (int s = 0; s < P; ++s) {
+    halo_segment(dim, P, s, kmin, kmax, &ra[(size_t)s], &rb[(size_t)s]);
+    zoff[(size_t)s + 1] = zoff[(size_t)s] + cnt[(size_t)s * P + me];
+    soff[(size_t)s + 1] = soff[(size_t)s] + (rb[(size_t)s] - ra[(size_t)s] + 1);
+  }
+  const int64_t total = zoff[(size_t)P];
+  DevMat full;
+  full.alloc(dim, dim, m.cplx, total);
+  DevBuf<int64_t> stage((size_t)soff[(size_t)P]);
+  const size_t w = m.loc.wval();
+  NCCL_CHECK(ncclGroupStart());
+  for (int q = 0; q < P; ++q) {  // sends
+    const int64_t n = cnt[(size_t)me * P + q];
+    if (q == me || n == 0) continue;
+    const int64_t first = bound[(size_t)2 * q];
+    NCCL_CHECK(ncclSend(m.loc.outer.p + (sa[(size_t)q] - m.c0), (size_t)(sb[(size_t)q] - sa[(size_t)q] + 1), ncclInt64, q, comm, stream()));
+    NCCL_CHECK(ncclSend(m.loc.inner.p + first, (size_t)n, ncclInt32, q, comm, stream()));
+    NCCL_CHECK(ncclSend(m.loc.val.p + first * (int64_t)w, (size_t)n * w, ncclDouble, q, comm, stream()));
+  }
+  for (int s = 0; s < P; ++s) {  // receives
+    const int64_t n = cnt[(size_t)s * P + me];
+    if (s == me || n == 0) continue;
+    NCCL_CHECK(ncclRecv(stage.p + soff[(size_t)s], (size_t)(rb[(size_t)s] - ra[(size_t)s] + 1), ncclInt64, s, comm, stream()));
+    NCCL_CHECK(ncclRecv(full.inner.p + zoff[(size_t)s], (size_t)n, ncclInt32, s, comm, stream()));
+    NCCL_CHECK(ncclRecv(full.val.p + zoff[(size_t)s] * (int64_t)w, (size_t)n * w, ncclDouble, s, comm, stream()));
+  }
+  NCCL_CHECK(ncclGroupEnd());
+  {  // own segment
+    const int64_t n = cnt[(size_t)me * P + me];
+    if (n > 0) {
+      const int64_t first = bound[(size_t)2 * me];
+      HIP_CHECK(hipMemcpyAsync(stage.p + soff[(size_t)me], m.loc.outer.p + (sa[(size_t)me] - m.c0),
+                               sizeof(int64_t) * (size_t)(sb[(size_t)me] - sa[(size_t)me] + 1), hipMemcpyDeviceToDevice, stream()));
+      HIP_CHECK(hipMemcpyAsync(full.inner.p + zoff[(size_t)me], m.loc.inner.p + first, sizeof(int32_t) * (size_t)n,
+                               hipMemcpyDeviceToDevice, stream()));
+      HIP_CHECK(hipMemcpyAsync(full.val.p + zoff[(size_t)me] * (int64_t)w, m.loc.val.p + first * (int64_t)w,
+                               sizeof(double) * (size_t)n * w, hipMemcpyDeviceToDevice, stream()));
+    }
+  }
+  // 5. column offsets: 0 before the first needed column, re-based segments, `total` after the last
+  int32_t pos = 0;
+  for (int s = 0; s < P; ++s) {
+    const int32_t a = ra[(size_t)s], b = rb[(size_t)s];
+    const int64_t n = cnt[(size_t)s * P + me];
+    if (b <= a) continue;
+    if (a > pos) fill_i64(full.outer.p + pos, a - pos, zoff[(size_t)s]);
+    if (n > 0) rebase_i64(stage.p + soff[(size_t)s], full.outer.p + a, b - a, zoff[(size_t)s]);
+    else fill_i64(full.outer.p + a, b - a, zoff[(size_t)s]);
+    pos = b;
+  }
+  fill_i64(full.outer.p + pos, (int64_t)dim + 1 - pos, total);
   sync_stream();
   return full;
 }

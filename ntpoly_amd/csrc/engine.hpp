@@ -68,6 +68,9 @@ int64_t ps_size(const PSMatrix& m);
 void ps_to_complex(const PSMatrix& a, PSMatrix& out);
 void ps_to_real(const PSMatrix& a, PSMatrix& out);
 DevMat ps_gather_full(const PSMatrix& m);  // every rank gets the whole matrix (dim x dim)
+// range-restricted exchange: a dim x dim matrix holding only the columns [kmin, kmax] of the distributed matrix
+DevMat gather_needed(const PSMatrix& m, int32_t kmin, int32_t kmax);
+void halo_segment(int32_t dim, int P, int s, int32_t kmin, int32_t kmax, int32_t* a, int32_t* b);
 // concatenate the column panels of all ranks (widths[r] = columns held by rank r, known to all)
 DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths);
 

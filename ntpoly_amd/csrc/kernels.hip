@@ -1892,6 +1892,34 @@ __global__ void k_shift_outer(const int64_t* __restrict__ in, int64_t* __restric
   if (j <= n) out[j] = in[j] + shift;
 }
 
+// out[i] = in[i] - in[0] + add  (re-base a slice of column offsets)
+__global__ void k_rebase_i64(const int64_t* __restrict__ in, int64_t* __restrict__ out, int n, int64_t add) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] - in[0] + add;
+}
+__global__ void k_fill_i64(int64_t* __restrict__ out, int64_t n, int64_t v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+// smallest first row / largest last row over the non-empty columns: mm[0] = min, mm[1] = max
+__global__ void k_row_range(Csc A, int* __restrict__ mm) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int lo = INT_MAX, hi = -1;
+  if (j < A.cols) {
+    const int64_t s = A.outer[j], e = A.outer[j + 1];
+    if (e > s) {
+      lo = A.inner[s];
+      hi = A.inner[e - 1];
+    }
+  }
+  lo = wave_min_i32(lo);
+  hi = wave_max_i32(hi);
+  if (lane_id() == 0) {
+    if (lo != INT_MAX) atomicMin(&mm[0], lo);
+    if (hi >= 0) atomicMax(&mm[1], hi);
+  }
+}
+
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 template <typename F>
@@ -2528,6 +2556,28 @@ DevMat transpose_slice(const DevMat& A, int32_t col_lo, int32_t col_hi) {
 void copy_shift_i64(const int64_t* d_src, int64_t* d_dst, int64_t count, int64_t shift) {
   if (count <= 0) return;
   hipLaunchKernelGGL(k_shift_outer, dim3(cdiv(count, 256)), dim3(256), 0, stream(), d_src, d_dst, (int)(count - 1), shift);
+}
+
+void rebase_i64(const int64_t* d_src, int64_t* d_dst, int64_t count, int64_t add) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_rebase_i64, dim3(cdiv(count, 256)), dim3(256), 0, stream(), d_src, d_dst, (int)count, add);
+}
+void fill_i64(int64_t* d_dst, int64_t count, int64_t v) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_fill_i64, dim3(cdiv(count, 256)), dim3(256), 0, stream(), d_dst, count, v);
+}
+void row_range(const DevMat& A, int32_t* lo, int32_t* hi) {
+  *lo = INT_MAX;
+  *hi = -1;
+  if (A.nnz == 0 || A.cols == 0) return;
+  DevBuf<int> mm(2);
+  int init[2] = {INT_MAX, -1};
+  mm.upload(init, 2);
+  hipLaunchKernelGGL(k_row_range, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), view(A), mm.p);
+  int h[2];
+  mm.download(h, 2);
+  *lo = h[0];
+  *hi = h[1];
 }
 
 DevMat column_slice(const DevMat& A, int32_t c0, int32_t c1) {

@@ -76,6 +76,11 @@ void to_triplets(const DevMat& A, int32_t col_offset, HostTriplets& out);
 // dst[i] = src[i] + shift for i < count
 void copy_shift_i64(const int64_t* d_src, int64_t* d_dst, int64_t count, int64_t shift);
 
+// dst[i] = src[i] - src[0] + add ; dst[i] = v ; first/last stored row over all columns (INT_MAX / -1 if empty)
+void rebase_i64(const int64_t* d_src, int64_t* d_dst, int64_t count, int64_t add);
+void fill_i64(int64_t* d_dst, int64_t count, int64_t v);
+void row_range(const DevMat& A, int32_t* lo, int32_t* hi);
+
 // exclusive scan helper (device), out[n] = total; returns total (synchronises)
 int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n);
 

@@ -204,8 +204,12 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
   DevMat AB;
   if (world().active()) {
-    DevMat Afull = ps_gather_full(A);
-    spgemm(Afull, B.loc, AB, alpha, threshold, dense_rule);
+    // only the columns of A named by the rows of the local B panel travel (halo for banded operands)
+    int32_t kmin, kmax;
+    row_range(B.loc, &kmin, &kmax);
+    if (kmax < kmin) { kmin = 0; kmax = -1; }
+    DevMat Aneed = gather_needed(A, kmin, kmax);
+    spgemm(Aneed, B.loc, AB, alpha, threshold, dense_rule);
   } else {
     spgemm(A.loc, B.loc, AB, alpha, threshold, dense_rule);
   }

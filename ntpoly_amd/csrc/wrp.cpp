@@ -66,6 +66,11 @@ int ntpoly_amd_device_count() {
 void ntpoly_amd_panel_range(const int* dim, const int* nranks, const int* rank, int* c0, int* c1) {
   panel_range(*dim, *nranks, *rank, c0, c1);
 }
+// columns [a, b) of rank s's panel that a requester whose B panel has rows [kmin, kmax] receives
+void ntpoly_amd_halo_segment(const int* dim, const int* nranks, const int* s, const int* kmin, const int* kmax, int* a,
+                             int* b) {
+  halo_segment(*dim, *nranks, *s, *kmin, *kmax, a, b);
+}
 void ntpoly_amd_set_option(const char* name, const int* value) {
   const std::string n(name);
   if (n == "spgemm_force_bin") options().spgemm_force_bin = *value;

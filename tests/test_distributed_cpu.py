@@ -6,7 +6,8 @@ engine uses is *correct by construction*: panel ranges come from the engine's ow
 the right operand (computed here by the oracle, as the checker), panels are exchanged with the same
 three-array all-gather the engine performs (offsets, indices, values), and the concatenation must be
 bit-identical to the single-process product -- the property that makes the GPU-count-independent
-result of the engine possible (DESIGN.md "Multi-GPU")."""
+result of the engine possible (DESIGN.md "Multi-GPU").  The exchange is the range-restricted one:
+segment boundaries come from the engine's ntpoly_amd_halo_segment."""
 import os
 import sys
 
@@ -35,18 +36,27 @@ def _worker(rank, world, port, q):
         c0, c1 = a.value, b.value
         # my panel of A and of B (columns [c0, c1)), as the engine stores them
         m = (col - 1 >= c0) & (col - 1 < c1)
-        # --- all-gather of the A panels: sizes, then (outer offsets, row ids, values)
-        mine = [torch.from_numpy(np.ascontiguousarray(x[m])) for x in (col, row, val)]
-        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([int(m.sum())]))
-        parts = []
-        for arr in mine:
-            bufs = [torch.zeros(int(s.item()), dtype=arr.dtype) for s in sizes]
-            for r in range(world):  # broadcast-per-owner, like the engine's grouped ncclBroadcast
-                buf = arr.clone() if r == rank else bufs[r]
-                dist.broadcast(buf, src=r)
-                bufs[r] = buf
-            parts.append(torch.cat(bufs).numpy())
+        # --- range-restricted ("halo") exchange, as comm.cpp gather_needed does it: my B panel has rows
+        # [kmin, kmax]; from every owner s I receive exactly the columns ntpoly_amd_halo_segment names
+        kmin, kmax = int(row[m].min()) - 1, int(row[m].max()) - 1
+        ranges = [None] * world
+        dist.all_gather_object(ranges, (kmin, kmax))
+        outbox = []
+        for dst in range(world):  # what I owe rank dst
+            sa, sb = C.c_int(), C.c_int()
+            nt.lib.ntpoly_amd_halo_segment(nt.capi.i(n), nt.capi.i(world), nt.capi.i(rank), nt.capi.i(ranges[dst][0]),
+                                           nt.capi.i(ranges[dst][1]), C.byref(sa), C.byref(sb))
+            sel = (col - 1 >= sa.value) & (col - 1 < sb.value)
+            assert np.all((col[sel] - 1 >= c0) & (col[sel] - 1 < c1))  # only columns I own
+            outbox.append((col[sel], row[sel], val[sel]))
+        inbox = [None] * world
+        for src in range(world):  # all-to-all by scatter from every source
+            recv = [None]
+            dist.scatter_object_list(recv, outbox if rank == src else None, src=src)
+            inbox[src] = recv[0]
+        parts = [np.concatenate([inbox[s][k] for s in range(world)]) for k in range(3)]
+        assert parts[0].min() - 1 >= kmin and parts[0].max() - 1 <= kmax
+        assert len(parts[0]) < len(col)  # strictly less than the full gather for a banded operand
         A_full = O.Mat.from_triplets(n, n, parts[0], parts[1], parts[2])
         # B panel as an n x n matrix that is empty outside my columns: its product columns are my C panel
         B_mine = O.Mat.from_triplets(n, n, col[m], row[m], val[m])
