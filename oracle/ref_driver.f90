@@ -30,9 +30,9 @@ PROGRAM RefDriver
   USE SolverParametersModule, ONLY : SolverParameters_t, &
        & ConstructSolverParameters
   USE PermutationModule, ONLY : Permutation_t, ConstructDefaultPermutation
-  USE DensityMatrixSolversModule, ONLY : TRS2, TRS4
-  USE SignSolversModule, ONLY : SignFunction
-  USE InverseSolversModule, ONLY : Invert
+  USE DensityMatrixSolversModule, ONLY : TRS2, TRS4, PM, HPCP
+  USE SignSolversModule, ONLY : SignFunction, PolarDecomposition
+  USE InverseSolversModule, ONLY : Invert, PseudoInverse
   USE SquareRootSolversModule, ONLY : InverseSquareRoot, SquareRoot
   USE LoggingModule, ONLY : ActivateLogger, DeactivateLogger
   IMPLICIT NONE
@@ -379,7 +379,7 @@ CONTAINS
   END SUBROUTINE cmd_pscalars
 
   !! solve pr pc ps <solver> H ISQ|identity|none trace thr conv maxit monitor out log scal.txt
-  !!   solver in {trs2, trs4, sign, invert, isq, sqrt}
+  !!   solver in {trs2, trs4, pm, hpcp, sign, polar, invert, pinv, isq, sqrt}
   SUBROUTINE cmd_solve()
     TYPE(Matrix_ps) :: H, ISQ, K
     TYPE(SolverParameters_t) :: sp
@@ -408,6 +408,16 @@ CONTAINS
     CASE("trs4")
        CALL TRS4(H, ISQ, rarg(8), K, energy_value_out=energy, &
             & chemical_potential_out=mu, solver_parameters_in=sp)
+    CASE("pm")
+       CALL PM(H, ISQ, rarg(8), K, energy_value_out=energy, &
+            & chemical_potential_out=mu, solver_parameters_in=sp)
+    CASE("hpcp")
+       CALL HPCP(H, ISQ, rarg(8), K, energy_value_out=energy, &
+            & chemical_potential_out=mu, solver_parameters_in=sp)
+    CASE("pinv")
+       CALL PseudoInverse(H, K, sp)
+    CASE("polar")
+       CALL PolarDecomposition(H, K, solver_parameters_in=sp)
     CASE("sign")
        CALL SignFunction(H, K, sp)
     CASE("invert")

@@ -348,6 +348,41 @@ def gen_solvers(tmp):
     save("solvers", d, dict(kind="solvers", cases=cases))
 
 
+def gen_solvers_extra(tmp):
+    """PM / HPCP (test_chemistry.py:266-280), PseudoInverse, PolarDecomposition
+    (test_solvers.py:164-188,388-407 style) -- the cheap extras next to the four north-star solvers."""
+    rng = np.random.default_rng(777)
+    d, cases = {}, []
+
+    def solve(solver, H, ISQ, nel, thr, conv, maxit, monitor, tag):
+        n = H.shape[0]
+        write_tri(tmp + "/H.tri", n, n, *tri(H))
+        isq = ISQ if isinstance(ISQ, str) else "none"
+        run(["solve", 1, 1, 1, solver, tmp + "/H.tri", isq, repr(nel), repr(thr), repr(conv), maxit,
+             int(monitor), tmp + "/K.tri", tmp + "/log.yaml", tmp + "/s.txt"])
+        rows, cols, c, r, v = read_tri(tmp + "/K.tri")
+        sc = {k: float(x) for k, x in (ln.split() for ln in open(tmp + "/s.txt"))}
+        lc, le, total = parse_log(tmp + "/log.yaml")
+        pre = "c%03d_" % len(cases)
+        put(d, pre + "H", H.shape, tri(H))
+        put(d, pre + "K", (rows, cols), (c, r, v))
+        d[pre + "log_convergence"] = np.array(lc)
+        d[pre + "log_energy"] = np.array(le)
+        cases.append(dict(tag=tag, solver=solver, nel=nel, thr=thr, conv=conv, maxit=maxit, monitor=bool(monitor),
+                          isq=isq, energy=sc["energy"], mu=sc["mu"], nnz=int(sc["nnz"]), total_iterations_logged=total))
+
+    Hb = banded(256, 12)
+    solve("pm", Hb, "identity", 128.0, 1e-8, 1e-6, 1000, 1, "banded256_pm")
+    solve("hpcp", Hb, "identity", 128.0, 1e-8, 1e-6, 1000, 1, "banded256_hpcp")
+    solve("pm", banded(128, 6, True), "identity", 50.0, 1e-9, 1e-7, 1000, 1, "cbanded128_pm")
+    Sp = spd_from(rng, 80, 0.06)
+    solve("pinv", Sp, None, 0.0, 1e-10, 1e-8, 1000, 1, "spd80_pinv")
+    G = rnd(rng, 80, 80, 0.06)
+    G = sp.csc_matrix(G + sp.diags(np.full(80, 3.0)))
+    solve("polar", G, None, 0.0, 1e-10, 1e-8, 1000, 1, "gen80_polar")
+    save("solvers_extra", d, dict(kind="solvers_extra", cases=cases))
+
+
 def gen_multirank(tmp):
     """Same product on 1, 4 (2x2x1) and 8 (2x2x2) reference ranks: pins that values do not
     depend on the grid when slices == 1 and records the slices>1 behaviour."""
@@ -382,7 +417,13 @@ def main():
         import build_ref
         if not build_ref.build():
             raise SystemExit("reference not buildable here")
+    only = sys.argv[1:] 
     with tempfile.TemporaryDirectory() as tmp:
+        if only:
+            for name in only:
+                globals()["gen_" + name](tmp)
+            return
+        gen_solvers_extra(tmp)
         gen_local_gemm(tmp)
         gen_local_increment(tmp)
         gen_ps(tmp)

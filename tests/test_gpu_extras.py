@@ -1,0 +1,189 @@
+"""GPU: the rows next to the hot path -- PM / HPCP / PseudoInverse / PolarDecomposition against
+the reference's golden outputs, the on-disk formats (MatrixMarket, NTPoly binary), the remaining
+distributed-algebra entry points (pairwise, transpose, symmetrize, asymmetry, permutation,
+load balancer) against numpy, and the Taylor order-3 / Newton-Schulz order-2 square-root variants."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from golden_util import Golden, to_dense
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nt():
+    import ntpoly_amd as nt
+    nt.init_comm()
+    nt.ConstructGlobalProcessGrid(1, 1, 1)
+    return nt
+
+
+def pmat(nt, t):
+    return nt.Matrix_ps.from_triplets(t[0], t[2], t[3], t[4])
+
+
+def _params(nt, c):
+    p = nt.SolverParameters()
+    p.SetConvergeDiff(c["conv"])
+    p.SetMaxIterations(c["maxit"])
+    p.SetThreshold(c["thr"])
+    p.SetMonitorConvergence(c["monitor"])
+    return p
+
+
+def test_extra_solvers_golden(nt):
+    g = Golden("solvers_extra")
+    for i, c in enumerate(g.cases):
+        H = pmat(nt, g.tri(i, "H"))
+        want = g.tri(i, "K")
+        K = nt.Matrix_ps(want[0])
+        p = _params(nt, c)
+        if c["solver"] in ("pm", "hpcp"):
+            ISQ = nt.Matrix_ps(want[0])
+            ISQ.FillIdentity()
+            fn = nt.DensityMatrixSolvers.PM if c["solver"] == "pm" else nt.DensityMatrixSolvers.HPCP
+            energy, mu = fn(H, ISQ, c["nel"], K, p)
+            tr = nt.solver_trace()
+            log_e = g.arr(i, "log_energy")
+            n = len(log_e)
+            assert tr["iterations"] in (n, n + 1), (c["tag"], tr["iterations"], n)
+            assert np.allclose(tr["energy"][:n], log_e, rtol=1e-10, atol=1e-10), c["tag"]
+            assert energy == pytest.approx(c["energy"], rel=1e-10), c["tag"]
+            assert mu == pytest.approx(c["mu"], rel=1e-5, abs=1e-9), c["tag"]
+        elif c["solver"] == "pinv":
+            nt.InverseSolvers.PseudoInverse(H, K, p)
+            assert nt.solver_trace()["iterations"] == len(g.arr(i, "log_convergence")), c["tag"]
+        else:
+            Hm = nt.Matrix_ps(want[0])
+            nt.SignSolvers.ComputePolarDecomposition(H, K, Hm, p)
+            assert nt.solver_trace()["iterations"] == len(g.arr(i, "log_convergence")), c["tag"]
+            # U is unitary, U*Hm reproduces the input
+            U = K.to_scipy().toarray()
+            assert np.abs(U.conj().T @ U - np.eye(want[0])).max() < 1e-7
+            assert np.abs(U @ Hm.to_scipy().toarray() - H.to_scipy().toarray()).max() < 1e-7
+        gd = K.to_scipy().toarray()
+        wd = to_dense(want)
+        tol = max(10 * c["thr"], 1e-9) * max(1.0, np.abs(wd).max())
+        assert np.abs(gd - wd).max() <= tol, "%s: max |d| = %g" % (c["tag"], np.abs(gd - wd).max())
+
+
+def test_square_root_orders(nt):
+    """SquareRootSolversModule.F90:164-194: orders 2 (Newton-Schulz) and 3 (Taylor) next to the default 5"""
+    g = Golden("solvers")
+    idx = [i for i, c in enumerate(g.cases) if c["tag"] == "spd96_isq"][0]
+    A = pmat(nt, g.tri(idx, "H"))
+    Ad = A.to_scipy().toarray()
+    w, V = np.linalg.eigh(Ad)
+    ref = (V / np.sqrt(w)) @ V.T
+    p = _params(nt, g.cases[idx])
+    for order in (2, 3, 5):
+        out = nt.Matrix_ps(96)
+        nt.SquareRootSolvers.with_order(A, out, p, True, order)
+        assert np.abs(out.to_scipy().toarray() - ref).max() < 1e-6, order
+    out = nt.Matrix_ps(96)
+    nt.SquareRootSolvers.with_order(A, out, p, False, 2)
+    assert np.abs(out.to_scipy().toarray() @ out.to_scipy().toarray() - Ad).max() < 1e-6
+
+
+def test_matrix_market_and_binary_roundtrip(nt, tmp_path):
+    """PSMatrixModule.F90:351-745 formats: write -> read gives the same matrix bit for bit (%.17g text);
+    a symmetric file is expanded like SymmetrizeTripletList; the binary layout is the reference's."""
+    g = Golden("ps_gemm")
+    for idx in (0, 4):  # a real and a complex matrix
+        t = g.tri(idx, "A")
+        A = pmat(nt, t)
+        mm, bn = str(tmp_path / ("a%d.mtx" % idx)), str(tmp_path / ("a%d.bin" % idx))
+        A.WriteToMatrixMarket(mm)
+        A.WriteToBinary(bn)
+        for path in (mm, bn):
+            B = nt.Matrix_ps(path)
+            a, b = A.triplets(), B.triplets()
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), path
+        with open(bn, "rb") as f:  # header int32[3] {rows, cols, complex}, int64 nnz, then {col,row,val} records
+            rows, cols, cplx = struct.unpack("iii", f.read(12))
+            (total,) = struct.unpack("q", f.read(8))
+            assert (rows, cols, total) == (t[0], t[1], len(t[2])) and cplx == int(np.iscomplexobj(t[4]))
+            c0, r0 = struct.unpack("ii", f.read(8))
+            assert (c0, r0) == (int(t[2][0]), int(t[3][0]))
+    sym = tmp_path / "sym.mtx"
+    sym.write_text("%%MatrixMarket matrix coordinate real symmetric\n% comment\n3 3 4\n1 1 2.0\n2 1 -1.5\n3 2 0.25\n3 3 4.0\n")
+    S = nt.Matrix_ps(str(sym)).to_scipy().toarray()
+    assert np.array_equal(S, np.array([[2.0, -1.5, 0.0], [-1.5, 0.0, 0.25], [0.0, 0.25, 4.0]]))
+    # local matrix from file (ConstructMatrixFromFile_lsr_wrp)
+    L = nt.Matrix_lsr(path=str(sym))
+    assert (L.GetRows(), L.GetColumns()) == (3, 3)
+    assert len(L.triplets()[0]) == 6
+
+
+def test_remaining_algebra_vs_numpy(nt):
+    """test_psmatrixalgebra.py:165-191 (pairwise), :288-329 (asymmetry / symmetrize), transpose,
+    conjugate, permutation matrices and the load balancer (test_psmatrix.py style)"""
+    rng = np.random.default_rng(5)
+    n = 97
+    import scipy.sparse as sp
+    for is_c in (False, True):
+        def rnd(d):
+            m = sp.random(n, n, d, random_state=rng, format="csc", data_rvs=lambda k: rng.uniform(-1, 1, k))
+            if is_c:
+                m = m + 1j * sp.random(n, n, d, random_state=rng, format="csc", data_rvs=lambda k: rng.uniform(-1, 1, k))
+            return sp.csc_matrix(m)
+        a, b = rnd(0.1), rnd(0.15)
+        A, B = nt.Matrix_ps.from_scipy(a), nt.Matrix_ps.from_scipy(b)
+        C = nt.Matrix_ps(n)
+        C.PairwiseMultiply(A, B)
+        assert np.array_equal(C.to_scipy().toarray(), a.multiply(b).toarray())
+        T = nt.Matrix_ps(n)
+        T.Transpose(A)
+        assert np.array_equal(T.to_scipy().toarray(), a.T.toarray())
+        if is_c:
+            T.Conjugate()
+            assert np.array_equal(T.to_scipy().toarray(), a.conj().T.toarray())
+        asym = A.MeasureAsymmetry()
+        assert asym == pytest.approx(np.abs(a.toarray() - a.conj().T.toarray()).sum(axis=0).max(), rel=1e-13)
+        S = nt.Matrix_ps(A)
+        S.Symmetrize()
+        assert np.allclose(S.to_scipy().toarray(), 0.5 * (a.toarray() + a.conj().T.toarray()), atol=1e-16)
+        assert S.MeasureAsymmetry() < 1e-15
+        perm = nt.Permutation(n)
+        lookup = rng.permutation(n) + 1
+        perm.set_lookup(lookup)
+        P = nt.Matrix_ps(n)
+        nt.LoadBalancer.PermuteMatrix(A, P, perm)
+        pd = P.to_scipy().toarray()
+        ad = a.toarray()
+        assert np.array_equal(pd, ad[np.ix_(lookup - 1, lookup - 1)])  # out(i,j) = in(perm(i), perm(j))
+        U = nt.Matrix_ps(n)
+        nt.LoadBalancer.UndoPermuteMatrix(P, U, perm)
+        assert np.array_equal(U.to_scipy().toarray(), ad)
+        PR = nt.Matrix_ps(n)
+        PR.FillPermutation(perm, True)
+        prd = PR.to_scipy().toarray()
+        assert np.array_equal(prd @ ad, ad[lookup - 1, :])
+        assert not A.IsIdentity()
+    I = nt.Matrix_ps(n)
+    I.FillIdentity()
+    assert I.IsIdentity() and I.Trace() == n and I.Norm() == 1.0
+
+
+def test_local_matrix_api(nt):
+    """SMatrix_c.h entry points not covered by the multiply tests"""
+    g = Golden("local_increment")
+    t = g.tri(0, "A")
+    A = nt.Matrix_lsr.from_triplets(t[0], t[1], t[2], t[3], t[4])
+    B = nt.Matrix_lsr.from_triplets(*[g.tri(0, "B")[k] for k in range(5)])
+    ad, bd = to_dense(t), to_dense(g.tri(0, "B"))
+    assert A.Dot(B) == pytest.approx(float((ad * bd).sum()), rel=1e-13)
+    T = nt.Matrix_lsr(t[1], t[0])
+    T.Transpose(A)
+    c, r, v = T.triplets()
+    assert np.array_equal(to_dense((t[1], t[0], c, r, v)), ad.T)
+    C = nt.Matrix_lsr(t[0], t[1])
+    C.PairwiseMultiply(A, B)
+    c, r, v = C.triplets()
+    assert np.array_equal(to_dense((t[0], t[1], c, r, v)), ad * bd)
+    A.Scale(-2.0)
+    c, r, v = A.triplets()
+    assert np.array_equal(v, -2.0 * t[4])
