@@ -34,7 +34,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def trs2_step(nt, X, X2, WH, pool, trace_target, thr):
-    """one iteration of DensityMatrixSolversModule.F90:380-413; returns (sigma, energy)"""
+    """one iteration of DensityMatrixSolversModule.F90:380-413, exactly the body TRS2_wrp loops over
+    (ntpoly_amd_trs2_step = csrc/solvers.cpp trs2_step: trace -> sigma, X2 = X*X, fused update + energy);
+    returns (sigma, energy)"""
+    return nt.trs2_step(X, X2, WH, trace_target, thr)
+
+
+def trs2_step_unfused(nt, X, X2, WH, pool, trace_target, thr):
+    """the same iteration spelled with the reference's individual C-ABI calls (cross-check)"""
     tr = X.Trace()
     sigma = -1.0 if (trace_target - tr) < 0.0 else 1.0
     X2.Gemm(X, X, pool, 1.0, 0.0, thr)

@@ -78,6 +78,8 @@ DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths);
 void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha, double beta, double threshold);
 void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold);
 void ps_scale(PSMatrix& A, double c);
+// B <- alpha*A + beta*B with the increment rules and, fused, out = dot(B_new, D) (TRS2 update + energy)
+void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[2]);
 void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C);
 void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]);
 double ps_trace(const PSMatrix& A);
@@ -151,6 +153,8 @@ struct SolverTrace {
   double setup_ms = 0, loop_ms = 0;
 };
 SolverTrace& last_trace();
+// one TRS2 iteration (DensityMatrixSolversModule.F90:380-404): returns the energy, sets sigma
+double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_target, double threshold, double* sigma);
 
 // ------------------------------------------------------------------ solvers
 void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy, double* mu,

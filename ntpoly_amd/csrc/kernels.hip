@@ -1565,69 +1565,117 @@ __device__ inline bool inc_decide(bool ha, bool hb, T a, T b, int row, int amax,
   return (row > amax) ? true : (Sc<T>::mag(b) > threshold);      // tail of B copied unfiltered (:63-68)
 }
 
-template <typename T, int W, int NW>
+// DOT: additionally scatter column j of a third matrix D into the window and return
+// sum conj(result) * D per block (fused energy evaluation of the TRS2 update).
+// B's values are scaled by beta first (ScaleMatrix followed by IncrementMatrix in the reference).
+template <typename T, int W, int NW, bool DOT>
 __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
-    Csc A, Csc B, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
+    Csc A, Csc B, Csc D, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
     const uint8_t* __restrict__ bin_arr, int my_bin, int32_t* __restrict__ out_inner,
-    T* __restrict__ out_val, int32_t* __restrict__ count, double alpha, double threshold,
-    int nblocks) {
+    T* __restrict__ out_val, int32_t* __restrict__ count, double alpha, double beta, double threshold,
+    double* __restrict__ dot_partial, int nblocks) {
   __shared__ T wa_all[NW * W];
   __shared__ T wb_all[NW * W];
+  __shared__ T wd_all[DOT ? NW * W : 1];
   __shared__ uint8_t fl_all[NW * W];
+  __shared__ double red[2 * NW];
   const int b = xcd_block(nblocks);
   if (b < 0) return;
   const int wave = threadIdx.x / WAVE, lane = lane_id();
   const int j = b * NW + wave;
-  if (j >= A.cols) return;
-  if (bin_arr[j] != my_bin) return;
-  T* wa = wa_all + wave * W;
-  T* wb = wb_all + wave * W;
-  uint8_t* fl = fl_all + wave * W;
-  const int span = span_arr[j], lo = lo_arr[j];
-  for (int s = lane; s < span; s += WAVE) fl[s] = 0;
-  __builtin_amdgcn_wave_barrier();
-  const T* __restrict__ Av = static_cast<const T*>(A.val);
-  const T* __restrict__ Bv = static_cast<const T*>(B.val);
-  const int64_t as = A.outer[j], ae = A.outer[j + 1], bs = B.outer[j], be = B.outer[j + 1];
-  const int amax = ae > as ? A.inner[ae - 1] : -1;
-  const int bmax = be > bs ? B.inner[be - 1] : -1;
-  for (int64_t p = as + lane; p < ae; p += WAVE) {
-    const int s = A.inner[p] - lo;
-    wa[s] = Av[p];
-    fl[s] = 1;
-  }
-  __builtin_amdgcn_wave_barrier();
-  for (int64_t p = bs + lane; p < be; p += WAVE) {
-    const int s = B.inner[p] - lo;
-    wb[s] = Bv[p];
-    fl[s] |= 2;
-  }
-  __builtin_amdgcn_wave_barrier();
-  const int64_t base = as + bs;  // upper-bound slot: every column may keep all of A and B
-  int cnt = 0;
-  for (int s0 = 0; s0 < span; s0 += WAVE) {
-    const int s = s0 + lane;
-    const int f = (s < span) ? fl[s] : 0;
-    T v = Sc<T>::zero();
-    bool keep = false;
-    if (f) keep = inc_decide<T>(f & 1, f & 2, (f & 1) ? wa[s] : Sc<T>::zero(), (f & 2) ? wb[s] : Sc<T>::zero(),
-                                lo + s, amax, bmax, alpha, threshold, &v);
-    const unsigned long long m = __ballot(keep);
-    if (keep) {
-      const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
-      out_inner[pos] = lo + s;
-      out_val[pos] = v;
+  double dx = 0.0, dy = 0.0;
+  const bool mine = (j < A.cols) && (bin_arr[j < A.cols ? j : 0] == my_bin);
+  if (mine) {
+    T* wa = wa_all + wave * W;
+    T* wb = wb_all + wave * W;
+    T* wd = wd_all + (DOT ? wave * W : 0);
+    uint8_t* fl = fl_all + wave * W;
+    const int span = span_arr[j], lo = lo_arr[j];
+    for (int s = lane; s < span; s += WAVE) fl[s] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const T* __restrict__ Av = static_cast<const T*>(A.val);
+    const T* __restrict__ Bv = static_cast<const T*>(B.val);
+    const int64_t as = A.outer[j], ae = A.outer[j + 1], bs = B.outer[j], be = B.outer[j + 1];
+    const int amax = ae > as ? A.inner[ae - 1] : -1;
+    const int bmax = be > bs ? B.inner[be - 1] : -1;
+    for (int64_t p = as + lane; p < ae; p += WAVE) {
+      const int s = A.inner[p] - lo;
+      wa[s] = Av[p];
+      fl[s] = 1;
     }
-    cnt += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t p = bs + lane; p < be; p += WAVE) {
+      const int s = B.inner[p] - lo;
+      wb[s] = Sc<T>::scale(beta, Bv[p]);
+      fl[s] |= 2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (DOT) {
+      const T* __restrict__ Dv = static_cast<const T*>(D.val);
+      for (int64_t p = D.outer[j] + lane; p < D.outer[j + 1]; p += WAVE) {
+        const int s = D.inner[p] - lo;
+        if (s >= 0 && s < span) {
+          wd[s] = Dv[p];
+          fl[s] |= 4;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const int64_t base = as + bs;  // upper-bound slot: every column may keep all of A and B
+    int cnt = 0;
+    for (int s0 = 0; s0 < span; s0 += WAVE) {
+      const int s = s0 + lane;
+      const int f = (s < span) ? fl[s] : 0;
+      T v = Sc<T>::zero();
+      bool keep = false;
+      if (f & 3) keep = inc_decide<T>(f & 1, f & 2, (f & 1) ? wa[s] : Sc<T>::zero(), (f & 2) ? wb[s] : Sc<T>::zero(),
+                                      lo + s, amax, bmax, alpha, threshold, &v);
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
+        out_inner[pos] = lo + s;
+        out_val[pos] = v;
+        if constexpr (DOT) {
+          if (f & 4) {
+            if constexpr (Sc<T>::cplx) {
+              const double2 pr = Sc<double2>::mul(Sc<double2>::conj(v), wd[s]);
+              dx = __dadd_rn(dx, pr.x);
+              dy = __dadd_rn(dy, pr.y);
+            } else {
+              dx = __dadd_rn(dx, __dmul_rn(v, wd[s]));
+            }
+          }
+        }
+      }
+      cnt += __popcll(m);
+    }
+    if (lane == 0) count[j] = cnt;
   }
-  if (lane == 0) count[j] = cnt;
+  if constexpr (DOT) {
+    dx = wave_sum_f64(dx);
+    dy = wave_sum_f64(dy);
+    if (lane == 0) {
+      red[2 * wave] = dx;
+      red[2 * wave + 1] = dy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sx = 0.0, sy = 0.0;
+      for (int w = 0; w < NW; ++w) {
+        sx = __dadd_rn(sx, red[2 * w]);
+        sy = __dadd_rn(sy, red[2 * w + 1]);
+      }
+      dot_partial[2 * b] = sx;
+      dot_partial[2 * b + 1] = sy;
+    }
+  }
 }
 
 // sequential two-pointer merge, one thread per column (columns wider than the LDS window)
 template <typename T>
 __global__ void k_inc_seq(Csc A, Csc B, const uint8_t* __restrict__ bin_arr, int my_bin,
                           int32_t* __restrict__ out_inner, T* __restrict__ out_val,
-                          int32_t* __restrict__ count, double alpha, double threshold) {
+                          int32_t* __restrict__ count, double alpha, double beta, double threshold) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.cols) return;
   if (bin_arr[j] != my_bin) return;
@@ -1639,11 +1687,11 @@ __global__ void k_inc_seq(Csc A, Csc B, const uint8_t* __restrict__ bin_arr, int
   while (aa < ea && bb < eb) {
     const int ia = A.inner[aa], ib = B.inner[bb];
     if (ia == ib) {
-      const T s = Sc<T>::add(Sc<T>::scale(alpha, Av[aa]), Bv[bb]);
+      const T s = Sc<T>::add(Sc<T>::scale(alpha, Av[aa]), Sc<T>::scale(beta, Bv[bb]));
       if (Sc<T>::mag(s) > threshold) { out_inner[cc] = ia; out_val[cc] = s; ++cc; }
       ++aa; ++bb;
     } else if (ia > ib) {
-      const T w = Bv[bb];
+      const T w = Sc<T>::scale(beta, Bv[bb]);
       if (Sc<T>::mag(w) > threshold) { out_inner[cc] = ib; out_val[cc] = w; ++cc; }
       ++bb;
     } else {
@@ -1653,7 +1701,7 @@ __global__ void k_inc_seq(Csc A, Csc B, const uint8_t* __restrict__ bin_arr, int
     }
   }
   for (; aa < ea; ++aa) { out_inner[cc] = A.inner[aa]; out_val[cc] = Sc<T>::scale(alpha, Av[aa]); ++cc; }
-  for (; bb < eb; ++bb) { out_inner[cc] = B.inner[bb]; out_val[cc] = Bv[bb]; ++cc; }
+  for (; bb < eb; ++bb) { out_inner[cc] = B.inner[bb]; out_val[cc] = Sc<T>::scale(beta, Bv[bb]); ++cc; }
   count[j] = (int32_t)(cc - c0);
 }
 
@@ -2269,21 +2317,27 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
 
 // -------------------------------------------------------------------------------------
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold) {
+  axpby(A, B, alpha, 1.0, threshold, nullptr, nullptr);
+}
+
+void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out) {
   if (A.rows != B.rows || A.cols != B.cols) NTP_FATAL("increment: shape mismatch");
   if (A.cplx != B.cplx) NTP_FATAL("increment: mixed scalar types must be up-cast by the caller");
+  if (D && (D->rows != A.rows || D->cols != A.cols || D->cplx != A.cplx)) NTP_FATAL("increment: dot operand mismatch");
+  if (dot_out) dot_out[0] = dot_out[1] = 0.0;
   const int n = A.cols;
   if (n == 0) return;
   if (A.nnz == 0 && B.nnz == 0) return;
   DevBuf<int32_t> lo(n), span(n), count(n);
   DevBuf<uint8_t> bin(n);
-  DevBuf<unsigned long long> stats(8);
+  DevBuf<unsigned long long> stats(16);
   stats.zero();
   count.zero();
   hipLaunchKernelGGL(k_inc_plan, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(A), view(B), lo.p, span.p, bin.p,
                      stats.p, options().increment_force_seq);
   hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, (const int64_t*)nullptr,
                      (const int32_t*)nullptr, n, stats.p);
-  unsigned long long hs[8];
+  unsigned long long hs[16];
   HIP_CHECK(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, stream()));
   sync_stream();
   const int64_t cap = A.nnz + B.nnz;
@@ -2291,24 +2345,45 @@ void increment(const DevMat& A, DevMat& B, double alpha, double threshold) {
   DevBuf<double> tmp_val((size_t)cap * A.wval());
   DevBuf<int64_t> srcoff((size_t)n + 1);
   hipLaunchKernelGGL(k_sum_outer, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), A.outer.p, B.outer.p, srcoff.p, n);
+  const bool fuse_dot = D != nullptr && dot_out != nullptr && hs[3] == 0;
+  const int nb1 = cdiv(n, 4), nb2 = n;
+  DevBuf<double> part1, part2;
+  if (fuse_dot) {
+    if (hs[1]) { part1.alloc((size_t)2 * nb1); part1.zero(); }
+    if (hs[2]) { part2.alloc((size_t)2 * nb2); part2.zero(); }
+  }
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
     T* tv = reinterpret_cast<T*>(tmp_val.p);
+    const Csc dv = D ? view(*D) : view(A);
     if (hs[1]) {
-      const int nb = cdiv(n, 4);
-      hipLaunchKernelGGL((k_inc_window<T, 512, 4>), dim3(xcd_grid(nb)), dim3(256), 0, stream(), view(A), view(B), lo.p,
-                         span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, threshold, nb);
+      if (fuse_dot)
+        hipLaunchKernelGGL((k_inc_window<T, 512, 4, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), view(A), view(B), dv,
+                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, part1.p, nb1);
+      else
+        hipLaunchKernelGGL((k_inc_window<T, 512, 4, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), view(A), view(B), dv,
+                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1);
     }
     if (hs[2]) {
-      const int nb = n;
-      hipLaunchKernelGGL((k_inc_window<T, 2048, 1>), dim3(xcd_grid(nb)), dim3(WAVE), 0, stream(), view(A), view(B),
-                         lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, threshold, nb);
+      if (fuse_dot)
+        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, true>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), view(A), view(B), dv,
+                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, part2.p, nb2);
+      else
+        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, false>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), view(A), view(B), dv,
+                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb2);
     }
     if (hs[3]) {
       hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), view(A), view(B), bin.p, 3,
-                         tmp_inner.p, tv, count.p, alpha, threshold);
+                         tmp_inner.p, tv, count.p, alpha, beta, threshold);
     }
   });
+  DevBuf<double> dres;
+  if (fuse_dot) {
+    dres.alloc(4);
+    dres.zero();
+    if (hs[1]) hipLaunchKernelGGL(k_reduce_sum2, dim3(1), dim3(256), 0, stream(), part1.p, nb1, dres.p);
+    if (hs[2]) hipLaunchKernelGGL(k_reduce_sum2, dim3(1), dim3(256), 0, stream(), part2.p, nb2, dres.p + 2);
+  }
   DevMat R;
   R.rows = A.rows;
   R.cols = n;
@@ -2316,7 +2391,9 @@ void increment(const DevMat& A, DevMat& B, double alpha, double threshold) {
   R.outer.alloc((size_t)n + 1);
   scan_async<int32_t>(count.p, R.outer.p, (int64_t)n);
   int64_t nnz = 0;
+  double hd[4] = {0, 0, 0, 0};
   HIP_CHECK(hipMemcpyAsync(&nnz, R.outer.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+  if (fuse_dot) HIP_CHECK(hipMemcpyAsync(hd, dres.p, sizeof(hd), hipMemcpyDeviceToHost, stream()));
   sync_stream();
   R.nnz = nnz;
   R.inner.alloc((size_t)nnz + kIndexSlack);
@@ -2329,6 +2406,14 @@ void increment(const DevMat& A, DevMat& B, double alpha, double threshold) {
                        reinterpret_cast<T*>(R.val.p), nblocks);
   });
   B = std::move(R);
+  if (dot_out && D) {
+    if (fuse_dot) {
+      dot_out[0] = hd[0] + hd[2];
+      dot_out[1] = hd[1] + hd[3];
+    } else {
+      dot(B, *D, dot_out);
+    }
+  }
 }
 
 void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a) {

@@ -36,6 +36,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
 
 // B <- alpha*A + B (AddSparseVectors semantics), same shape and scalar type.
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold);
+// B <- alpha*A + beta*B (B scaled first, then the same rules); if D and dot_out are given, also
+// dot_out = sum conj(B_new) .* D, evaluated in the same pass
+void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out);
 // C = A .* B on the intersection of the patterns (conj_a: conjugate A first)
 void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a);
 // out = sum conj(A) .* B  (out[1] = imaginary part, 0 for real)

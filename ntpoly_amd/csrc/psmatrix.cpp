@@ -252,6 +252,17 @@ void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold
 
 void ps_scale(PSMatrix& A, double c) { scale(A.loc, c); }
 
+void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[2]) {
+  if (A.cplx != B.cplx || A.cplx != D.cplx || &A == &B) {  // mixed types: unfused sequence
+    ps_scale(B, beta);
+    ps_increment(A, B, alpha, threshold);
+    ps_dot(B, D, out);
+    return;
+  }
+  axpby(A.loc, B.loc, alpha, beta, threshold, &D.loc, out);
+  comm_allreduce_sum(out, 2);
+}
+
 void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {
   if (A.cplx != B.cplx) {
     PSMatrix Ac, Bc;

@@ -223,6 +223,23 @@ void density_finish(PSMatrix& X, const PSMatrix& ISQT, const PSMatrix& ISQ, PSMa
 }  // namespace
 
 // ------------------------------------------------------------------ TRS2
+// One iteration of the TRS2 loop (DensityMatrixSolversModule.F90:380-404).  The update
+// "ScaleMatrix(X,2); IncrementMatrix(X2,X,-1,threshold); DotMatrix(X,WH)" runs as ONE pass over X, X2
+// and WH (same arithmetic: 2*x is exact, then the AddSparseVectors rules, then the energy).
+double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_target, double threshold, double* sigma) {
+  const double trace_value = ps_trace(X);
+  *sigma = (trace_target - trace_value < 0.0) ? -1.0 : 1.0;
+  ps_multiply(X, X, X2, 1.0, 0.0, threshold);
+  double out[2];
+  if (*sigma > 0.0) {
+    ps_axpby_dot(X2, X, -1.0, 2.0, threshold, WH, out);
+  } else {
+    ps_copy(X2, X);
+    ps_dot(X, WH, out);
+  }
+  return out[0];
+}
+
 void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                  const SolverParameters& p) {
   trace_reset();
@@ -247,17 +264,8 @@ void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
   double energy_value = 0.0, energy_old;
   int II;
   for (II = 1; II <= p.max_iterations; ++II) {                     // :380-413
-    const double trace_value = ps_trace(X);
-    sigma_array[(size_t)II] = (trace - trace_value < 0.0) ? -1.0 : 1.0;
-    ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
-    if (sigma_array[(size_t)II] > 0.0) {
-      ps_scale(X, 2.0);
-      ps_increment(X2, X, -1.0, p.threshold);
-    } else {
-      ps_copy(X2, X);
-    }
     energy_old = energy_value;
-    energy_value = real_dot(X, WH);
+    energy_value = trs2_step(X, X2, WH, trace, p.threshold, &sigma_array[(size_t)II]);
     monitor_append(mon, energy_value - energy_old);
     trace_rec(energy_value - energy_old, energy_value, sigma_array[(size_t)II], X);
     if (monitor_converged(mon, p.be_verbose)) break;

@@ -561,6 +561,12 @@ void InverseSquareRoot_wrp(const int* ih_Input, int* ih_Output, const int* ih_so
   solver_square_root(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), *get<SolverParameters>(ih_solver_parameters),
                      true, 5);
 }
+// extension: one TRS2 iteration on caller-held matrices (what TRS2_wrp runs inside its loop); lets a
+// driver time exactly K iterations.  X and X2 must be constructed; returns energy and sigma.
+void ntpoly_amd_trs2_step(int* ih_X, int* ih_X2, const int* ih_WH, const double* trace, const double* threshold,
+                          double* energy_out, double* sigma_out) {
+  *energy_out = trs2_step(*get<PSMatrix>(ih_X), *get<PSMatrix>(ih_X2), *get<PSMatrix>(ih_WH), *trace, *threshold, sigma_out);
+}
 // extension: the reference's optional order_in argument (SquareRootSolversModule.F90:30-61) is not
 // reachable through its C ABI; expose it for tests
 void ntpoly_amd_square_root_order(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters,

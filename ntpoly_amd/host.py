@@ -495,6 +495,13 @@ class DensityMatrixSolvers:
         return DensityMatrixSolvers._run(lib.HPCP_wrp, H, ISQ, trace, Density, solver_parameters)
 
 
+def trs2_step(X, X2, WH, trace, threshold):
+    """one TRS2 iteration (what TRS2_wrp runs inside its loop) -> (sigma, energy)"""
+    e, sg = C.c_double(), C.c_double()
+    lib.ntpoly_amd_trs2_step(X.ih, X2.ih, WH.ih, d(trace), d(threshold), C.byref(e), C.byref(sg))
+    return sg.value, e.value
+
+
 class SignSolvers:
     @staticmethod
     def ComputeSign(mat, signmat, solver_parameters):

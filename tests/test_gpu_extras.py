@@ -187,3 +187,54 @@ def test_local_matrix_api(nt):
     A.Scale(-2.0)
     c, r, v = A.triplets()
     assert np.array_equal(v, -2.0 * t[4])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("force_seq", [0, 1])
+def test_fused_trs2_step_equals_call_sequence(nt, cplx, force_seq):
+    """ntpoly_amd_trs2_step (fused Scale+Increment+Dot pass) against the same iteration spelled with the
+    reference's individual entry points (DensityMatrixSolversModule.F90:380-404): X bit-identical,
+    energy to reduction tolerance.  force_seq routes the update through the two-pointer merge kernel,
+    where the energy falls back to the separate DotMatrix."""
+    from gen import banded_triplets
+    n, h, thr = 3000, 40, 1e-6
+    col, row, val = banded_triplets(n, h, complex_=cplx)
+    # a few far off-band couplings so that some columns need the wide (2048-row) window
+    far = np.arange(1, n + 1, 97)
+    col = np.concatenate([col, far, (far + 1500 - 1) % n + 1]).astype(np.int32)
+    row = np.concatenate([row, (far + 1500 - 1) % n + 1, far]).astype(np.int32)
+    val = np.concatenate([val, np.full(2 * len(far), 0.01, dtype=val.dtype)])
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    e_min, e_max = nt.EigenBounds.GershgorinBounds(H)
+    Ident = nt.Matrix_ps(n)
+    Ident.FillIdentity()
+
+    def start():
+        X = nt.Matrix_ps(H)
+        X.Scale(-1.0)
+        X.Increment(Ident, e_max, 0.0)
+        X.Scale(1.0 / (e_max - e_min))
+        return X, nt.Matrix_ps(n)
+
+    Xa, X2a = start()
+    Xb, X2b = start()
+    pool = nt.PMatrixMemoryPool(H)
+    nt.set_option("increment_force_seq", force_seq)
+    try:
+        for it in range(6):
+            sa, ea = nt.trs2_step(Xa, X2a, H, n / 2.0, thr)
+            tr = Xb.Trace()
+            sb = -1.0 if (n / 2.0 - tr) < 0.0 else 1.0
+            X2b.Gemm(Xb, Xb, pool, 1.0, 0.0, thr)
+            if sb > 0.0:
+                Xb.Scale(2.0)
+                Xb.Increment(X2b, -1.0, thr)
+            else:
+                nt.lib.CopyMatrix_ps_wrp(X2b.ih, Xb.ih)
+            eb = float(np.real(Xb.Dot(H)))
+            assert sa == sb
+            assert ea == pytest.approx(eb, rel=1e-12, abs=1e-12), it
+            ta, tb = Xa.triplets(), Xb.triplets()
+            assert all(np.array_equal(u, v) for u, v in zip(ta, tb)), it
+    finally:
+        nt.set_option("increment_force_seq", 0)
