@@ -288,6 +288,14 @@ __global__ void k_col_extent(Csc A, int32_t* __restrict__ cmin, int32_t* __restr
   cmax[k] = (e > s) ? A.inner[e - 1] : -1;
 }
 
+__global__ void k_span_of(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax, int32_t* __restrict__ span, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) span[k] = cmax[k] >= cmin[k] ? cmax[k] - cmin[k] + 1 : 0;
+}
+
+// register-slab kernel geometry: J output columns per workgroup, SL slabs of 64 rows per wave, NW waves
+constexpr int SLAB_J = 16, SLAB_SL = 3, SLAB_NW = 4;
+
 // bins: 0 empty | 1..4 LDS direct window of 512/1024/2048/4096 rows | 5 LDS hash | 6 HBM accumulator
 constexpr int BIN_EMPTY = 0, BIN_HASH = 5, BIN_HBM = 6;
 constexpr int HASH_SLOTS = 4096;      // per wave
@@ -1287,6 +1295,252 @@ __global__ __launch_bounds__(NW* WAVE) void k_spgemm_pair3(
   }
 }
 
+// ------------------------------------------------------------------ SpGEMM: numeric, register-slab kernel
+// For operands whose columns are (nearly) contiguous runs of rows -- banded Hamiltonians and the density
+// matrices purified from them -- the accumulator does not need LDS at all.  A workgroup owns a block of J
+// consecutive output columns and the row window [lo, lo+W) they can touch; the window is cut into slabs of 64
+// rows, slab m belongs to wave m % NW, and inside a slab lane l owns row lo + 64 m + l: the partial sums live
+// in REGISTERS, acc[slab][column].  Walking k = kmin..kmax in ascending order (the reference's accumulation
+// order, SMatrixAlgebraModule SparseBranch), a wave loads the 64 values A(rows of its slab, k) with one
+// coalesced load -- A is pre-expanded so that a column is a dense run over its span, holes = 0 -- and the J
+// multipliers B(k, j..j+J-1) arrive as wave-uniform SGPRs from a pre-expanded per-block tile, so every
+// product is v_mul_f64 v, s, v followed by v_add_f64: no atomics, no index loads, 16 B of L1 traffic per
+// 2 J flops.  Padding with zeros is exact: x + (+-0 * b) == x for every x that survives the prune
+// (|v| > threshold >= 0 drops the zeros themselves), so results stay bit-identical to the sparse walk.
+//
+// expanded A: aexp[aeoff[k] + (r - afirst[k])] = A(r, k) for afirst[k] <= r <= alast[k]
+__global__ __launch_bounds__(256) void k_slab_expand_a(Csc A, const int32_t* __restrict__ afirst,
+                                                       const int64_t* __restrict__ aeoff, double* __restrict__ aexp) {
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (k >= A.cols) return;
+  const int lane = lane_id();
+  const int64_t s = A.outer[k], e = A.outer[k + 1];
+  if (e <= s) return;
+  const double* __restrict__ Av = static_cast<const double*>(A.val);
+  double* __restrict__ dst = aexp + aeoff[k] - afirst[k];
+  for (int64_t p = s + lane; p < e; p += WAVE) {
+    const int r = A.inner[p];
+    const int prev = (p > s) ? A.inner[p - 1] : r - 1;
+    dst[r] = Av[p];
+    for (int h = prev + 1; h < r; ++h) dst[h] = 0.0;
+  }
+}
+
+// per block of J output columns: row window, k range and the sizes of its B tile / output slots
+// stats[16] = max window rows, stats[17] = max k range
+template <int J>
+__global__ void k_slab_plan(int ncols, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
+                            const int32_t* __restrict__ bfirst, const int32_t* __restrict__ blast,
+                            int32_t* __restrict__ blk_lo, int32_t* __restrict__ blk_w, int32_t* __restrict__ blk_kmin,
+                            int32_t* __restrict__ blk_kn, int64_t* __restrict__ bsz, int64_t* __restrict__ tsz,
+                            unsigned long long* __restrict__ stats, int nblocks) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  int lo = INT_MAX, hi = -1, kmin = INT_MAX, kmax = -1;
+  for (int jj = 0; jj < J; ++jj) {
+    const int j = b * J + jj;
+    if (j >= ncols) break;
+    if (span_arr[j] > 0) {
+      lo = min(lo, lo_arr[j]);
+      hi = max(hi, lo_arr[j] + span_arr[j]);
+    }
+    if (blast[j] >= 0) {
+      kmin = min(kmin, bfirst[j]);
+      kmax = max(kmax, blast[j]);
+    }
+  }
+  const int w = (hi > lo) ? hi - lo : 0;
+  const int kn = (w > 0 && kmax >= kmin) ? kmax - kmin + 1 : 0;
+  blk_lo[b] = w > 0 ? lo : 0;
+  blk_w[b] = w;
+  blk_kmin[b] = kn > 0 ? kmin : 0;
+  blk_kn[b] = kn;
+  bsz[b] = (int64_t)kn * J;
+  tsz[b] = (int64_t)w * J;
+  atomicMax(&stats[16], (unsigned long long)w);
+  atomicMax(&stats[17], (unsigned long long)kn);
+}
+
+// B tile of a block: bblk[boff + (k - kmin) * J + jj] = B(k, b*J + jj), zeros elsewhere.  Staged through LDS
+// (transposed, odd pitch) so that both the scatter and the write-out are conflict-free / coalesced.
+template <int J>
+__global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __restrict__ blk_kmin,
+                                                       const int32_t* __restrict__ blk_kn,
+                                                       const int64_t* __restrict__ blk_boff, double* __restrict__ bblk,
+                                                       int nblocks, int pitch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* tile = reinterpret_cast<double*>(smem);  // [J][pitch]
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int kn = blk_kn[b], kmin = blk_kmin[b];
+  if (kn == 0) return;
+  for (int jj = 0; jj < J; ++jj)
+    for (int i = threadIdx.x; i < kn; i += blockDim.x) tile[jj * pitch + i] = 0.0;
+  __syncthreads();
+  const double* __restrict__ Bv = static_cast<const double*>(B.val);
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  for (int jj = wave; jj < J; jj += 4) {
+    const int j = b * J + jj;
+    if (j >= B.cols) break;
+    for (int64_t p = B.outer[j] + lane; p < B.outer[j + 1]; p += WAVE) tile[jj * pitch + (B.inner[p] - kmin)] = Bv[p];
+  }
+  __syncthreads();
+  double* __restrict__ dst = bblk + blk_boff[b];
+  const int total = kn * J;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) dst[i] = tile[(i % J) * pitch + (i / J)];
+}
+
+// upper-bound output slot of every column: blk_toff[b] + jj * W_b
+template <int J>
+__global__ void k_slab_tmpoff(int ncols, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
+                              int64_t* __restrict__ tmpoff) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > ncols) return;
+  if (j == ncols) {
+    const int b = (ncols - 1) / J;
+    tmpoff[j] = blk_toff[b] + (int64_t)blk_w[b] * J;
+    return;
+  }
+  const int b = j / J;
+  tmpoff[j] = blk_toff[b] + (int64_t)(j % J) * blk_w[b];
+}
+
+// run descriptor of an expanded column of A: where it starts in aexp, its first row, its length in bytes
+struct ColRun {
+  int64_t eoff;
+  int32_t first;
+  int32_t nbytes;
+};
+
+__global__ void k_slab_runs(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax,
+                            const int64_t* __restrict__ aeoff, ColRun* __restrict__ runs, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const bool any = cmax[k] >= cmin[k];
+  runs[k] = ColRun{aeoff[k], any ? cmin[k] : 0, any ? (cmax[k] - cmin[k] + 1) * 8 : 0};
+}
+
+// Pipeline of one wave (steps = consecutive k): while step t is multiplied, the A slabs of step t+1 are in
+// flight (buffer loads: rows outside the run of column k read as 0.0 through the descriptor's bounds check, so
+// the loads are unconditional and the compiler can count them), and the scalar loads of B(k+1, :) and of the
+// run descriptor of step t+2 are in flight as well.
+template <int J, int SL, int NW>
+__global__ __launch_bounds__(NW* WAVE) void k_spgemm_slab(
+    const double* __restrict__ aexp, const ColRun* __restrict__ runs, int acols, const double* __restrict__ bblk,
+    const int64_t* __restrict__ blk_boff, const int32_t* __restrict__ blk_kmin, const int32_t* __restrict__ blk_kn,
+    const int32_t* __restrict__ blk_lo, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
+    int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count, double alpha,
+    double threshold, int dense_rule, int ncols, int nblocks) {
+  __shared__ int cnt_s[NW * SL][J];
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int wave = uni_i32(threadIdx.x / WAVE), lane = lane_id();
+  const int lo = blk_lo[b], kmin = blk_kmin[b], kn = blk_kn[b], w = blk_w[b];
+  if (kn == 0) return;
+  const double* __restrict__ bp = bblk + blk_boff[b];
+  const int rbase = lo + WAVE * wave;  // slab s of this wave starts at row rbase + 64*NW*s
+  const unsigned lane8 = (unsigned)lane * 8u;
+  double acc[SL][J];
+#pragma unroll
+  for (int s = 0; s < SL; ++s)
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) acc[s][jj] = 0.0;
+
+  // run descriptor of step kk (clamped past the end; such steps are made empty)
+  auto load_run = [&](int kk) -> ColRun {
+    const int k = min(kmin + min(kk, kn - 1), acols - 1);
+    return runs[k];
+  };
+  // issue the slab loads of step kk, return the bitmask of slabs the run touches
+  auto issue_a = [&](int kk, const ColRun& m, double (&a)[SL]) -> int {
+    const int nbytes = (kk < kn) ? m.nbytes : 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(aexp + m.eoff), 0, nbytes, 0x00020000);
+    const int last = m.first + (nbytes >> 3) - 1;
+    int act = 0;
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      const int r0 = rbase + WAVE * NW * s;
+      const unsigned voff = (unsigned)(r0 - m.first) * 8u + lane8;
+      a[s] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0));
+      if (m.first <= r0 + WAVE - 1 && last >= r0) act |= 1 << s;
+    }
+    return act;
+  };
+  auto load_b = [&](int kk, double (&bv)[J]) {
+    const double* __restrict__ row = bp + (int64_t)min(kk, kn - 1) * J;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) bv[jj] = row[jj];
+  };
+  auto compute = [&](int act, const double (&a)[SL], const double (&bv)[J]) {
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      if (act & (1 << s)) {
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) acc[s][jj] = __dadd_rn(acc[s][jj], __dmul_rn(a[s], bv[jj]));
+      }
+    }
+  };
+
+  double aA[SL], aB[SL], bA[J], bB[J];
+  ColRun mA = load_run(0), mB = load_run(1);
+  int actA = issue_a(0, mA, aA), actB = 0;
+  load_b(0, bA);
+  for (int kk = 0; kk < kn; kk += 2) {
+    // step kk on set A; prepare kk+1 on set B
+    actB = issue_a(kk + 1, mB, aB);
+    load_b(kk + 1, bB);
+    mA = load_run(kk + 2);
+    compute(actA, aA, bA);
+    // step kk+1 on set B; prepare kk+2 on set A
+    actA = issue_a(kk + 2, mA, aA);
+    load_b(kk + 2, bA);
+    mB = load_run(kk + 3);
+    compute(actB, aB, bB);
+  }
+
+  // ---- epilogue: prune, count per (slab, column), prefix over slabs, write in row order
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const double v = acc[s][jj];
+      const double sv = __dmul_rn(alpha, v);
+      const bool keep = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) cnt_s[wave + NW * s][jj] = __popcll(m);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < J) {
+    int run = 0;
+    for (int m = 0; m < NW * SL; ++m) {
+      const int c = cnt_s[m][threadIdx.x];
+      cnt_s[m][threadIdx.x] = run;
+      run += c;
+    }
+    const int j = b * J + threadIdx.x;
+    if (j < ncols) count[j] = run;
+  }
+  __syncthreads();
+  const int64_t tbase = blk_toff[b];
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    const int r = lo + WAVE * (wave + NW * s) + lane;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const double v = acc[s][jj];
+      const double sv = __dmul_rn(alpha, v);
+      const bool keep = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int64_t pos = tbase + (int64_t)jj * w + cnt_s[wave + NW * s][jj] + __popcll(m & lanemask_lt());
+        out_inner[pos] = r;
+        out_val[pos] = sv;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ SpGEMM: numeric, LDS hash
 // For columns whose row window does not fit the direct map (e.g. after a load-balancing
 // permutation).  4096 LDS buckets per wave, multiplicative hash + linear probing; bucket claim by
@@ -2118,7 +2372,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<int32_t> lo(n), span(n), count(n);
   DevBuf<uint8_t> bin(n);
   DevBuf<int64_t> ub(n + 1), ip(n), tmpoff(n + 1);
-  DevBuf<unsigned long long> stats(16);
+  DevBuf<unsigned long long> stats(24);
   stats.zero();
   count.zero();
   hipLaunchKernelGGL(k_spgemm_plan, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(B), cmin.p,
@@ -2127,11 +2381,58 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     hipLaunchKernelGGL(k_pair_bins, dim3(cdiv((n + 1) / 2, 256)), dim3(256), 0, stream(), bin.p, n);
   hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, ip.p, span.p, n, stats.p);
   scan_async<int64_t>(ub.p, tmpoff.p, (int64_t)n);
-  unsigned long long hstats[16];
+  // candidate for the register-slab kernel (real operands, run-like columns): plan it alongside
+  constexpr int SJ = SLAB_J;
+  const int sv_opt = options().spgemm_variant;
+  const bool slab_try = !A.cplx && options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4) &&
+                        A.nnz < 2000000000LL && B.nnz < 2000000000LL;
+  const int snb = cdiv(n, SJ);
+  DevBuf<int32_t> bfirst_own, blast_own, blen_own, aspan, blk_lo, blk_w, blk_kmin, blk_kn;
+  DevBuf<int64_t> aeoff, bsz, tsz, blk_boff, blk_toff;
+  DevBuf<char> runs;
+  int64_t slab_tot[3] = {0, 0, 0};
+  if (slab_try) {
+    const int32_t *bfirst = cmin.p, *blast = cmax.p;
+    if (&A != &B) {
+      bfirst_own.alloc(n); blast_own.alloc(n); blen_own.alloc(n);
+      hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(B), bfirst_own.p, blast_own.p, blen_own.p);
+      bfirst = bfirst_own.p; blast = blast_own.p;
+    }
+    aspan.alloc(A.cols); aeoff.alloc((size_t)A.cols + 1);
+    hipLaunchKernelGGL(k_span_of, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aspan.p, A.cols);
+    scan_async<int32_t>(aspan.p, aeoff.p, (int64_t)A.cols);
+    runs.alloc((size_t)A.cols * sizeof(ColRun));
+    hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aeoff.p,
+                       reinterpret_cast<ColRun*>(runs.p), A.cols);
+    blk_lo.alloc(snb); blk_w.alloc(snb); blk_kmin.alloc(snb); blk_kn.alloc(snb);
+    bsz.alloc(snb); tsz.alloc(snb); blk_boff.alloc((size_t)snb + 1); blk_toff.alloc((size_t)snb + 1);
+    hipLaunchKernelGGL((k_slab_plan<SJ>), dim3(cdiv(snb, 256)), dim3(256), 0, stream(), n, lo.p, span.p, bfirst, blast,
+                       blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, stats.p, snb);
+    scan_async<int64_t>(bsz.p, blk_boff.p, (int64_t)snb);
+    scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
+    HIP_CHECK(hipMemcpyAsync(&slab_tot[0], aeoff.p + A.cols, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(&slab_tot[1], blk_boff.p + snb, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(&slab_tot[2], blk_toff.p + snb, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+  }
+  unsigned long long hstats[24];
   int64_t tmp_total = 0;
   HIP_CHECK(hipMemcpyAsync(hstats, stats.p, sizeof(hstats), hipMemcpyDeviceToHost, stream()));
   HIP_CHECK(hipMemcpyAsync(&tmp_total, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
   sync_stream();
+  // use it when the window fits the register slabs and the zero padding stays small
+  bool use_slab = false;
+  if (slab_try) {
+    const int64_t max_w = (int64_t)hstats[16], max_kn = (int64_t)hstats[17];
+    const bool fits = max_w > 0 && max_w <= SLAB_NW * SLAB_SL * WAVE && (max_kn | 1) * SJ * 8 <= 64 * 1024;
+    const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
+                            (double)slab_tot[0] >= 48.0 * (double)A.cols;
+    use_slab = fits && (dense_runs || sv_opt / 100 == 4);
+  }
+  st.slab = use_slab ? 1 : 0;
+  if (use_slab) {
+    tmp_total = slab_tot[2];
+    hipLaunchKernelGGL((k_slab_tmpoff<SJ>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
+  }
   for (int i = 0; i < 6; ++i) st.bin_cols[i] = (int64_t)hstats[i];
   st.bin_cols[5] += (int64_t)hstats[6];
   st.products = (int64_t)hstats[7];
@@ -2143,11 +2444,28 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<double> tmp2_val;
   DevBuf<int64_t> tmpoff2;
   const int dr = dense_rule ? 1 : 0;
+  DevBuf<double> aexp, bblk;
+  if (use_slab) {
+    aexp.alloc((size_t)slab_tot[0] + 1);
+    bblk.alloc((size_t)slab_tot[1] + 2 * SJ);
+    hipLaunchKernelGGL(k_slab_expand_a, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), cmin.p,
+                       aeoff.p, aexp.p);
+    const int pitch = (int)hstats[17] | 1;
+    hipLaunchKernelGGL((k_slab_expand_b<SJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * 8, stream(), view(B),
+                       blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch);
+  }
   t_num.start();
+  if (use_slab) {
+    hipLaunchKernelGGL((k_spgemm_slab<SJ, SLAB_SL, SLAB_NW>), dim3(xcd_grid(snb)), dim3(SLAB_NW * WAVE), 0, stream(), aexp.p,
+                       reinterpret_cast<const ColRun*>(runs.p), A.cols, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p,
+                       tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
+    for (int i = 0; i < 7; ++i) hstats[i] = 0;
+  }
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
     T* tv = reinterpret_cast<T*>(tmp_val.p);
     int variant = options().spgemm_variant;
+    if (variant / 100 == 4) variant = -1;  // slab kernel requested but not applicable
     if constexpr (!Sc<T>::cplx) {
       // default for real operands: column-pair kernel v3, register-set depth from the mean column length of A
       if (variant < 0 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {

@@ -10,6 +10,7 @@ struct SpgemmStats {
   int64_t nnz_a = 0, nnz_b = 0, nnz_c = 0;
   int64_t products = 0;        // intermediate products IP = sum_j sum_{k in B(:,j)} nnz(A(:,k))
   int64_t tmp_entries = 0;     // upper-bound entries reserved for the numeric pass
+  int slab = 0;                // 1 when the register-slab kernel computed the product
   int64_t bin_cols[6] = {0, 0, 0, 0, 0, 0};
   int64_t overflow_cols = 0;   // columns that left the LDS hash for the HBM accumulator
   float ms_total = 0.f;        // filled only when timing is enabled

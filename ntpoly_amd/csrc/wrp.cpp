@@ -79,12 +79,13 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "spgemm_variant") options().spgemm_variant = *value;
   else NTP_FATAL("unknown option " + n);
 }
-// statistics of the last SpGEMM: out[0..]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow
+// statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used
 void ntpoly_amd_last_spgemm_stats(long long* out, float* ms_numeric, float* ms_total) {
   const SpgemmStats& s = last_spgemm_stats();
   out[0] = s.nnz_a; out[1] = s.nnz_b; out[2] = s.nnz_c; out[3] = s.products; out[4] = s.tmp_entries;
   for (int i = 0; i < 6; ++i) out[5 + i] = s.bin_cols[i];
   out[11] = s.overflow_cols;
+  out[12] = s.slab;
   *ms_numeric = s.ms_numeric;
   *ms_total = s.ms_total;
 }

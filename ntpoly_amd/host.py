@@ -570,11 +570,11 @@ def DeactivateLogger():
 
 # ------------------------------------------------------------------ statistics (extensions)
 def last_spgemm_stats():
-    out = (C.c_longlong * 12)()
+    out = (C.c_longlong * 13)()
     a, t = C.c_float(), C.c_float()
     lib.ntpoly_amd_last_spgemm_stats(out, C.byref(a), C.byref(t))
     return dict(nnz_a=out[0], nnz_b=out[1], nnz_c=out[2], products=out[3], tmp_entries=out[4],
-                bins=[out[5 + k] for k in range(6)], overflow=out[11], ms_numeric=a.value, ms_total=t.value)
+                bins=[out[5 + k] for k in range(6)], overflow=out[11], slab=out[12], ms_numeric=a.value, ms_total=t.value)
 
 
 def reset_spgemm_accum():

@@ -82,7 +82,7 @@ def test_local_increment_golden(nt):
         exact(mB.triplets(), g.tri(i, "C"), "case %d %s" % (i, c))
 
 
-@pytest.mark.parametrize("force_bin,variant", [(-1, -1), (-1, 0), (2, 321), (3, 361), (-1, 164), (-1, 2), (4, -1), (5, -1), (6, -1)])
+@pytest.mark.parametrize("force_bin,variant", [(-1, -1), (-1, 0), (2, 321), (3, 361), (-1, 164), (-1, 2), (4, -1), (5, -1), (6, -1), (-1, 400)])
 def test_ps_gemm_golden(nt, force_bin, variant):
     """test_psmatrixalgebra.py:193-218 through MatrixMultiply_ps_wrp; every kernel path (column-pair
     kernel, first-generation window kernel, other generations, LDS window sizes, LDS hash, HBM
@@ -275,7 +275,8 @@ def test_full_size_properties_config2(nt):
     assert C.Trace() == pytest.approx(A.Dot(AT), rel=1e-12)
     assert C.MeasureAsymmetry() <= 1e-15
     got = C.triplets()
-    for (fb, var) in ((5, -1), (-1, 0)):   # LDS hash path, first-generation window kernel
+    assert st["slab"] == 1   # run-like columns: the register-slab kernel is the default here
+    for (fb, var) in ((5, -1), (-1, 0), (-1, 351)):   # LDS hash path, first-generation window kernel, column-pair kernel
         nt.set_option("spgemm_force_bin", fb)
         nt.set_option("spgemm_variant", var)
         try:
@@ -289,3 +290,32 @@ def test_full_size_properties_config2(nt):
     Ao = O.Mat.from_triplets(n, n, col, row, val)
     oc, orow, ov = O.ps_multiply(Ao, Ao, None, 1.0, 0.0, 1e-8).triplets()
     exact(got, (n, n, oc, orow, ov), "config 2 vs oracle")
+
+
+@pytest.mark.parametrize("n,h,holes,thr", [(4096, 100, 0.0, 1e-8), (4096, 140, 0.2, 1e-6), (3000, 30, 0.5, 0.0),
+                                             (5000, 250, 0.05, 1e-7)])
+def test_slab_kernel_vs_oracle(nt, n, h, holes, thr):
+    """register-slab SpGEMM kernel (forced) on banded operands with random holes punched into the band,
+    A*B with A != B, against the oracle: bit-exact.  Holes exercise the zero padding of the expanded runs."""
+    from oracle import oracle_py as O
+    rng = np.random.default_rng(n + h)
+    mats = []
+    for t in range(2):
+        col, row, val = banded_triplets(n, h, shift=0.1 * t)
+        keep = (rng.random(len(val)) >= holes) | (col == row)
+        mats.append((col[keep], row[keep], val[keep] * (1.0 + 0.01 * t)))
+    A = nt.Matrix_ps.from_triplets(n, *mats[0])
+    B = nt.Matrix_ps.from_triplets(n, *mats[1])
+    nt.set_option("spgemm_variant", 400)
+    try:
+        C = nt.Matrix_ps(n)
+        C.Gemm(A, B, None, 0.5, 0.0, thr)
+        used = nt.last_spgemm_stats()["slab"]
+    finally:
+        nt.set_option("spgemm_variant", -1)
+    if 4 * h + 2 + 16 <= 768:
+        assert used == 1
+    Ao = O.Mat.from_triplets(n, n, *mats[0])
+    Bo = O.Mat.from_triplets(n, n, *mats[1])
+    oc, orow, ov = O.ps_multiply(Ao, Bo, None, 0.5, 0.0, thr).triplets()
+    exact(C.triplets(), (n, n, oc, orow, ov), "slab vs oracle n=%d h=%d holes=%g" % (n, h, holes))
