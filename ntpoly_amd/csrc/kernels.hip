@@ -1355,7 +1355,7 @@ __global__ void k_slab_plan(int ncols, const int32_t* __restrict__ lo_arr, const
   blk_w[b] = w;
   blk_kmin[b] = kn > 0 ? kmin : 0;
   blk_kn[b] = kn;
-  bsz[b] = (int64_t)kn * J;
+  bsz[b] = (int64_t)((kn + 1) & ~1) * J;  // an all-zero row pads odd k ranges (two steps per loop trip)
   tsz[b] = (int64_t)w * J;
   atomicMax(&stats[16], (unsigned long long)w);
   atomicMax(&stats[17], (unsigned long long)kn);
@@ -1374,8 +1374,9 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
   if (b < 0) return;
   const int kn = blk_kn[b], kmin = blk_kmin[b];
   if (kn == 0) return;
+  const int kne = (kn + 1) & ~1;
   for (int jj = 0; jj < J; ++jj)
-    for (int i = threadIdx.x; i < kn; i += blockDim.x) tile[jj * pitch + i] = 0.0;
+    for (int i = threadIdx.x; i < kne; i += blockDim.x) tile[jj * pitch + i] = 0.0;
   __syncthreads();
   const double* __restrict__ Bv = static_cast<const double*>(B.val);
   const int wave = threadIdx.x / WAVE, lane = lane_id();
@@ -1386,7 +1387,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
   }
   __syncthreads();
   double* __restrict__ dst = bblk + blk_boff[b];
-  const int total = kn * J;
+  const int total = kne * J;
   for (int i = threadIdx.x; i < total; i += blockDim.x) dst[i] = tile[(i % J) * pitch + (i / J)];
 }
 
@@ -1405,97 +1406,79 @@ __global__ void k_slab_tmpoff(int ncols, const int32_t* __restrict__ blk_w, cons
   tmpoff[j] = blk_toff[b] + (int64_t)(j % J) * blk_w[b];
 }
 
-// run descriptor of an expanded column of A: where it starts in aexp, its first row, its length in bytes
-struct ColRun {
-  int64_t eoff;
-  int32_t first;
-  int32_t nbytes;
+// Run record of an expanded column of A, 32 bytes, fetched by ONE s_load_dwordx8: words 0-3 are the buffer
+// descriptor of the run (base address, bytes, flags) used as-is by buffer_load; first8 = 8 * first row turns a
+// row offset into a run offset; (first, span62 = rows + 62) give the one-compare test "does the run touch
+// the slab that ends at row e": (unsigned)(e - first) <= span62.
+struct alignas(32) SlabRun {
+  uint32_t addr_lo, addr_hi, nbytes, flags;
+  int32_t first8, first, span62, pad;
 };
+constexpr uint32_t kBufferFlags = 0x00020000u;  // raw buffer, 32-bit data format (gfx9 family word 3)
 
+// n + 4 records: the tail is empty (pipelined prefetch past the last column)
 __global__ void k_slab_runs(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax,
-                            const int64_t* __restrict__ aeoff, ColRun* __restrict__ runs, int n) {
+                            const int64_t* __restrict__ aeoff, const double* __restrict__ aexp,
+                            SlabRun* __restrict__ runs, int n) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const bool any = cmax[k] >= cmin[k];
-  runs[k] = ColRun{aeoff[k], any ? cmin[k] : 0, any ? (cmax[k] - cmin[k] + 1) * 8 : 0};
+  if (k >= n + 4) return;
+  const bool any = k < n && cmax[k] >= cmin[k];
+  SlabRun r;
+  const uint64_t addr = reinterpret_cast<uint64_t>(aexp + (any ? aeoff[k] : 0));
+  r.addr_lo = (uint32_t)addr;
+  r.addr_hi = (uint32_t)(addr >> 32) & 0xffffu;
+  r.nbytes = any ? (uint32_t)(cmax[k] - cmin[k] + 1) * 8u : 0u;
+  r.flags = kBufferFlags;
+  r.first = any ? cmin[k] : (1 << 30);
+  r.first8 = any ? cmin[k] * 8 : 0;
+  r.span62 = any ? (cmax[k] - cmin[k] + 1) + 62 : 0;
+  r.pad = 0;
+  runs[k] = r;
 }
 
-// Pipeline of one wave (steps = consecutive k): while step t is multiplied, the A slabs of step t+1 are in
-// flight (buffer loads: rows outside the run of column k read as 0.0 through the descriptor's bounds check, so
-// the loads are unconditional and the compiler can count them), and the scalar loads of B(k+1, :) and of the
-// run descriptor of step t+2 are in flight as well.
+typedef double v8d __attribute__((ext_vector_type(8)));
+#include "slab_loop.inc"
+
+// Pipeline of one wave (steps = consecutive k, two register sets A/B): while step t is multiplied, the slab
+// loads of step t+1 are in flight (buffer loads: rows outside the run of column k read as 0.0 through the
+// descriptor's bounds check, so every step issues exactly SL loads and the waits are static), and so are the
+// scalar loads of B(k+1, :) and of the run record of step t+2.  Products are issued as four independent
+// multiply -> add chains (mul x4, add x4; unfused like the reference) so that no instruction waits on the one
+// before it.  The whole loop is ONE inline-asm block over fixed physical registers (slab_loop.inc, generated
+// by tools/gen_slab_asm.py, register map there): with separate asm statements the compiler is free to copy a
+// register between them -- including one whose asynchronous load has not landed yet.
 template <int J, int SL, int NW>
-__global__ __launch_bounds__(NW* WAVE) void k_spgemm_slab(
-    const double* __restrict__ aexp, const ColRun* __restrict__ runs, int acols, const double* __restrict__ bblk,
+__global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_spgemm_slab(
+    const SlabRun* __restrict__ runs, const double* __restrict__ bblk,
     const int64_t* __restrict__ blk_boff, const int32_t* __restrict__ blk_kmin, const int32_t* __restrict__ blk_kn,
     const int32_t* __restrict__ blk_lo, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
     int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count, double alpha,
     double threshold, int dense_rule, int ncols, int nblocks) {
+  static_assert(J == 16 && SL == 3, "register map of slab_loop.inc");
   __shared__ int cnt_s[NW * SL][J];
   const int b = xcd_block(nblocks);
   if (b < 0) return;
   const int wave = uni_i32(threadIdx.x / WAVE), lane = lane_id();
   const int lo = blk_lo[b], kmin = blk_kmin[b], kn = blk_kn[b], w = blk_w[b];
   if (kn == 0) return;
-  const double* __restrict__ bp = bblk + blk_boff[b];
   const int rbase = lo + WAVE * wave;  // slab s of this wave starts at row rbase + 64*NW*s
-  const unsigned lane8 = (unsigned)lane * 8u;
+  const SlabRun* rp = runs + kmin;        // record of step kk: rp[kk]
+  const double* bq = bblk + blk_boff[b];  // multipliers of step kk: bq[kk*J .. kk*J+J)
+  const unsigned r0 = (unsigned)(rbase + lane) * 8u, r1 = r0 + WAVE * NW * 8u, r2 = r1 + WAVE * NW * 8u;
+  const int e0 = rbase + WAVE - 1, e1 = e0 + WAVE * NW, e2 = e1 + WAVE * NW;
+  v8d accL0, accH0, accL1, accH1, accL2, accH2;
+  asm volatile(SLAB_LOOP_ASM
+               : "=&{v[2:17]}"(accL0), "=&{v[18:33]}"(accH0), "=&{v[34:49]}"(accL1), "=&{v[50:65]}"(accH1),
+                 "=&{v[66:81]}"(accL2), "=&{v[82:97]}"(accH2)
+               : [rp] "s"(rp), [bq] "s"(bq), [kn] "s"(kn), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [r0] "v"(r0),
+                 [r1] "v"(r1), [r2] "v"(r2)
+               : SLAB_LOOP_CLOBBERS);
   double acc[SL][J];
 #pragma unroll
-  for (int s = 0; s < SL; ++s)
-#pragma unroll
-    for (int jj = 0; jj < J; ++jj) acc[s][jj] = 0.0;
-
-  // run descriptor of step kk (clamped past the end; such steps are made empty)
-  auto load_run = [&](int kk) -> ColRun {
-    const int k = min(kmin + min(kk, kn - 1), acols - 1);
-    return runs[k];
-  };
-  // issue the slab loads of step kk, return the bitmask of slabs the run touches
-  auto issue_a = [&](int kk, const ColRun& m, double (&a)[SL]) -> int {
-    const int nbytes = (kk < kn) ? m.nbytes : 0;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(aexp + m.eoff), 0, nbytes, 0x00020000);
-    const int last = m.first + (nbytes >> 3) - 1;
-    int act = 0;
-#pragma unroll
-    for (int s = 0; s < SL; ++s) {
-      const int r0 = rbase + WAVE * NW * s;
-      const unsigned voff = (unsigned)(r0 - m.first) * 8u + lane8;
-      a[s] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0));
-      if (m.first <= r0 + WAVE - 1 && last >= r0) act |= 1 << s;
-    }
-    return act;
-  };
-  auto load_b = [&](int kk, double (&bv)[J]) {
-    const double* __restrict__ row = bp + (int64_t)min(kk, kn - 1) * J;
-#pragma unroll
-    for (int jj = 0; jj < J; ++jj) bv[jj] = row[jj];
-  };
-  auto compute = [&](int act, const double (&a)[SL], const double (&bv)[J]) {
-#pragma unroll
-    for (int s = 0; s < SL; ++s) {
-      if (act & (1 << s)) {
-#pragma unroll
-        for (int jj = 0; jj < J; ++jj) acc[s][jj] = __dadd_rn(acc[s][jj], __dmul_rn(a[s], bv[jj]));
-      }
-    }
-  };
-
-  double aA[SL], aB[SL], bA[J], bB[J];
-  ColRun mA = load_run(0), mB = load_run(1);
-  int actA = issue_a(0, mA, aA), actB = 0;
-  load_b(0, bA);
-  for (int kk = 0; kk < kn; kk += 2) {
-    // step kk on set A; prepare kk+1 on set B
-    actB = issue_a(kk + 1, mB, aB);
-    load_b(kk + 1, bB);
-    mA = load_run(kk + 2);
-    compute(actA, aA, bA);
-    // step kk+1 on set B; prepare kk+2 on set A
-    actA = issue_a(kk + 2, mA, aA);
-    load_b(kk + 2, bA);
-    mB = load_run(kk + 3);
-    compute(actB, aB, bB);
+  for (int jj = 0; jj < 8; ++jj) {
+    acc[0][jj] = accL0[jj]; acc[0][jj + 8] = accH0[jj];
+    acc[1][jj] = accL1[jj]; acc[1][jj + 8] = accH1[jj];
+    acc[2][jj] = accL2[jj]; acc[2][jj + 8] = accH2[jj];
   }
 
   // ---- epilogue: prune, count per (slab, column), prefix over slabs, write in row order
@@ -2401,9 +2384,6 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     aspan.alloc(A.cols); aeoff.alloc((size_t)A.cols + 1);
     hipLaunchKernelGGL(k_span_of, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aspan.p, A.cols);
     scan_async<int32_t>(aspan.p, aeoff.p, (int64_t)A.cols);
-    runs.alloc((size_t)A.cols * sizeof(ColRun));
-    hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aeoff.p,
-                       reinterpret_cast<ColRun*>(runs.p), A.cols);
     blk_lo.alloc(snb); blk_w.alloc(snb); blk_kmin.alloc(snb); blk_kn.alloc(snb);
     bsz.alloc(snb); tsz.alloc(snb); blk_boff.alloc((size_t)snb + 1); blk_toff.alloc((size_t)snb + 1);
     hipLaunchKernelGGL((k_slab_plan<SJ>), dim3(cdiv(snb, 256)), dim3(256), 0, stream(), n, lo.p, span.p, bfirst, blast,
@@ -2423,7 +2403,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   bool use_slab = false;
   if (slab_try) {
     const int64_t max_w = (int64_t)hstats[16], max_kn = (int64_t)hstats[17];
-    const bool fits = max_w > 0 && max_w <= SLAB_NW * SLAB_SL * WAVE && (max_kn | 1) * SJ * 8 <= 64 * 1024;
+    const bool fits = max_w > 0 && max_w <= SLAB_NW * SLAB_SL * WAVE && ((max_kn + 1) | 1) * SJ * 8 <= 64 * 1024;
     const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
                             (double)slab_tot[0] >= 48.0 * (double)A.cols;
     use_slab = fits && (dense_runs || sv_opt / 100 == 4);
@@ -2447,17 +2427,20 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<double> aexp, bblk;
   if (use_slab) {
     aexp.alloc((size_t)slab_tot[0] + 1);
-    bblk.alloc((size_t)slab_tot[1] + 2 * SJ);
+    bblk.alloc((size_t)slab_tot[1] + 4 * SJ);
     hipLaunchKernelGGL(k_slab_expand_a, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), cmin.p,
                        aeoff.p, aexp.p);
-    const int pitch = (int)hstats[17] | 1;
+    runs.alloc(((size_t)A.cols + 4) * sizeof(SlabRun));
+    hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aeoff.p, aexp.p,
+                       reinterpret_cast<SlabRun*>(runs.p), A.cols);
+    const int pitch = ((int)hstats[17] + 1) | 1;
     hipLaunchKernelGGL((k_slab_expand_b<SJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * 8, stream(), view(B),
                        blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch);
   }
   t_num.start();
   if (use_slab) {
-    hipLaunchKernelGGL((k_spgemm_slab<SJ, SLAB_SL, SLAB_NW>), dim3(xcd_grid(snb)), dim3(SLAB_NW * WAVE), 0, stream(), aexp.p,
-                       reinterpret_cast<const ColRun*>(runs.p), A.cols, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p,
+    hipLaunchKernelGGL((k_spgemm_slab<SJ, SLAB_SL, SLAB_NW>), dim3(xcd_grid(snb)), dim3(SLAB_NW * WAVE), 0, stream(),
+                       reinterpret_cast<const SlabRun*>(runs.p), bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p,
                        tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
     for (int i = 0; i < 7; ++i) hstats[i] = 0;
   }
