@@ -1828,28 +1828,68 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
     T* wd = wd_all + (DOT ? wave * W : 0);
     uint8_t* fl = fl_all + wave * W;
     const int span = span_arr[j], lo = lo_arr[j];
-    for (int s = lane; s < span; s += WAVE) fl[s] = 0;
-    __builtin_amdgcn_wave_barrier();
     const T* __restrict__ Av = static_cast<const T*>(A.val);
     const T* __restrict__ Bv = static_cast<const T*>(B.val);
+    const T* __restrict__ Dv = static_cast<const T*>(D.val);
     const int64_t as = A.outer[j], ae = A.outer[j + 1], bs = B.outer[j], be = B.outer[j + 1];
+    const int64_t ds = DOT ? D.outer[j] : 0, de = DOT ? D.outer[j + 1] : 0;
+    // All operand loads of the column are requested up front (CH chunks of 64 entries per operand, reading past
+    // the column end is harmless: DevMat keeps kIndexSlack entries of slack), so the column costs one memory
+    // round trip instead of one per operand; longer columns finish in the loops below.
+    constexpr int CH = 5;
+    int ai[CH], bi[CH], di[DOT ? CH : 1];
+    T av[CH], bv[CH], dv[DOT ? CH : 1];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      ai[c] = A.inner[as + c * WAVE + lane];
+      av[c] = Av[as + c * WAVE + lane];
+      bi[c] = B.inner[bs + c * WAVE + lane];
+      bv[c] = Bv[bs + c * WAVE + lane];
+      if constexpr (DOT) {
+        di[c] = D.inner[ds + c * WAVE + lane];
+        dv[c] = Dv[ds + c * WAVE + lane];
+      }
+    }
     const int amax = ae > as ? A.inner[ae - 1] : -1;
     const int bmax = be > bs ? B.inner[be - 1] : -1;
-    for (int64_t p = as + lane; p < ae; p += WAVE) {
+    for (int s = lane; s < span; s += WAVE) fl[s] = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (as + c * WAVE + lane < ae) {
+        wa[ai[c] - lo] = av[c];
+        fl[ai[c] - lo] = 1;
+      }
+    }
+    for (int64_t p = as + CH * WAVE + lane; p < ae; p += WAVE) {
       const int s = A.inner[p] - lo;
       wa[s] = Av[p];
       fl[s] = 1;
     }
     __builtin_amdgcn_wave_barrier();
-    for (int64_t p = bs + lane; p < be; p += WAVE) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (bs + c * WAVE + lane < be) {
+        wb[bi[c] - lo] = Sc<T>::scale(beta, bv[c]);
+        fl[bi[c] - lo] |= 2;
+      }
+    }
+    for (int64_t p = bs + CH * WAVE + lane; p < be; p += WAVE) {
       const int s = B.inner[p] - lo;
       wb[s] = Sc<T>::scale(beta, Bv[p]);
       fl[s] |= 2;
     }
     __builtin_amdgcn_wave_barrier();
     if constexpr (DOT) {
-      const T* __restrict__ Dv = static_cast<const T*>(D.val);
-      for (int64_t p = D.outer[j] + lane; p < D.outer[j + 1]; p += WAVE) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int s = di[c] - lo;
+        if (ds + c * WAVE + lane < de && s >= 0 && s < span) {
+          wd[s] = dv[c];
+          fl[s] |= 4;
+        }
+      }
+      for (int64_t p = ds + CH * WAVE + lane; p < de; p += WAVE) {
         const int s = D.inner[p] - lo;
         if (s >= 0 && s < span) {
           wd[s] = Dv[p];
@@ -1952,32 +1992,77 @@ __global__ void k_sum_outer(const int64_t* __restrict__ a, const int64_t* __rest
 // sum_j sum_i conj(A_ij) B_ij.  One wave per column: lanes stride over A's column and find the
 // partner in B's column by binary search (B's column is hot in L1/L2: it is read log2 times by
 // neighbouring lanes).  Per-wave partials are reduced by k_reduce_sum2 in a fixed order.
+// sum conj(A) .* B: column j of B is scattered into a direct-mapped LDS window over its row range (like the
+// SpGEMM / increment windows), column j of A probes it.  Columns of B wider than the window use a binary search.
 template <typename T>
 __global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ partial, int nblocks) {
+  constexpr int W = 1024, CH = 5;
+  __shared__ T win_all[4 * W];
+  __shared__ uint8_t fl_all[4 * W];
   __shared__ double sx[4], sy[4];
   const int b = blockIdx.x;
   const int wave = threadIdx.x / WAVE, lane = lane_id();
+  T* win = win_all + wave * W;
+  uint8_t* fl = fl_all + wave * W;
   const T* __restrict__ Av = static_cast<const T*>(A.val);
   const T* __restrict__ Bv = static_cast<const T*>(B.val);
   double x = 0, y = 0;
+  auto accum = [&](T a, T bval) {
+    if constexpr (Sc<T>::cplx) {
+      const double2 pr = Sc<double2>::mul(Sc<double2>::conj(a), bval);
+      x = __dadd_rn(x, pr.x);
+      y = __dadd_rn(y, pr.y);
+    } else {
+      x = __dadd_rn(x, __dmul_rn(a, bval));
+    }
+  };
   for (int j = b * 4 + wave; j < A.cols; j += nblocks * 4) {
-    const int64_t bs = B.outer[j], be = B.outer[j + 1];
-    if (be == bs) continue;
-    for (int64_t p = A.outer[j] + lane; p < A.outer[j + 1]; p += WAVE) {
-      const int r = A.inner[p];
-      int64_t l = bs, h = be;
-      while (l < h) {
-        const int64_t mid = (l + h) >> 1;
-        if (B.inner[mid] < r) l = mid + 1; else h = mid;
-      }
-      if (l < be && B.inner[l] == r) {
-        if constexpr (Sc<T>::cplx) {
-          const double2 pr = Sc<double2>::mul(Sc<double2>::conj(Av[p]), Bv[l]);
-          x = __dadd_rn(x, pr.x);
-          y = __dadd_rn(y, pr.y);
-        } else {
-          x = __dadd_rn(x, __dmul_rn(Av[p], Bv[l]));
+    const int64_t bs = B.outer[j], be = B.outer[j + 1], as = A.outer[j], ae = A.outer[j + 1];
+    if (be == bs || ae == as) continue;
+    int ai[CH], bi[CH];
+    T av[CH], bv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {  // over-read past the column end stays inside the DevMat slack
+      bi[c] = B.inner[bs + c * WAVE + lane];
+      bv[c] = Bv[bs + c * WAVE + lane];
+      ai[c] = A.inner[as + c * WAVE + lane];
+      av[c] = Av[as + c * WAVE + lane];
+    }
+    const int lo = B.inner[bs], span = B.inner[be - 1] - lo + 1;
+    if (span <= W) {
+      for (int s = lane; s < span; s += WAVE) fl[s] = 0;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (bs + c * WAVE + lane < be) {
+          win[bi[c] - lo] = bv[c];
+          fl[bi[c] - lo] = 1;
         }
+      }
+      for (int64_t p = bs + CH * WAVE + lane; p < be; p += WAVE) {
+        win[B.inner[p] - lo] = Bv[p];
+        fl[B.inner[p] - lo] = 1;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int s = ai[c] - lo;
+        if (as + c * WAVE + lane < ae && s >= 0 && s < span && fl[s]) accum(av[c], win[s]);
+      }
+      for (int64_t p = as + CH * WAVE + lane; p < ae; p += WAVE) {
+        const int s = A.inner[p] - lo;
+        if (s >= 0 && s < span && fl[s]) accum(Av[p], win[s]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      for (int64_t p = as + lane; p < ae; p += WAVE) {
+        const int r = A.inner[p];
+        int64_t l = bs, h = be;
+        while (l < h) {
+          const int64_t mid = (l + h) >> 1;
+          if (B.inner[mid] < r) l = mid + 1; else h = mid;
+        }
+        if (l < be && B.inner[l] == r) accum(Av[p], Bv[l]);
       }
     }
   }
@@ -2758,7 +2843,7 @@ void dot(const DevMat& A, const DevMat& B, double out[2]) {
   if (A.rows != B.rows || A.cols != B.cols || A.cplx != B.cplx) NTP_FATAL("dot: operand mismatch");
   out[0] = out[1] = 0;
   if (A.nnz == 0 || B.nnz == 0) return;
-  const int nb = std::min(cdiv(A.cols, 4), 4096);
+  const int nb = std::min(cdiv(A.cols, 4), 8192);
   DevBuf<double> partial((size_t)2 * nb);
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);

@@ -234,7 +234,7 @@ double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_tar
   if (*sigma > 0.0) {
     ps_axpby_dot(X2, X, -1.0, 2.0, threshold, WH, out);
   } else {
-    ps_copy(X2, X);
+    std::swap(X.loc, X2.loc);  // X <- X2; X2 is scratch (recomputed by the next multiply), so no copy
     ps_dot(X, WH, out);
   }
   return out[0];
