@@ -16,6 +16,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <numeric>
 #include <utility>
 
@@ -1362,33 +1363,82 @@ __global__ void k_slab_plan(int ncols, const int32_t* __restrict__ lo_arr, const
 }
 
 // B tile of a block: bblk[boff + (k - kmin) * J + jj] = B(k, b*J + jj), zeros elsewhere.  Staged through LDS
-// (transposed, odd pitch) so that both the scatter and the write-out are conflict-free / coalesced.
+// (transposed, odd pitch) so that both the scatter and the write-out are conflict-free / coalesced.  When A and
+// B are the same matrix (X*X in every purification step) the same pass also writes the expanded runs of A
+// (fuse_a), so the operand is read from HBM once.
 template <int J>
 __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __restrict__ blk_kmin,
                                                        const int32_t* __restrict__ blk_kn,
                                                        const int64_t* __restrict__ blk_boff, double* __restrict__ bblk,
-                                                       int nblocks, int pitch) {
+                                                       int nblocks, int pitch, int fuse_a,
+                                                       const int64_t* __restrict__ aeoff, double* __restrict__ aexp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* tile = reinterpret_cast<double*>(smem);  // [J][pitch]
   const int b = xcd_block(nblocks);
   if (b < 0) return;
   const int kn = blk_kn[b], kmin = blk_kmin[b];
-  if (kn == 0) return;
+  if (kn == 0 && !fuse_a) return;  // (fuse_a: the runs of these columns may still be needed as A columns)
+  const bool tiled = kn > 0;
+  const double* __restrict__ Bv = static_cast<const double*>(B.val);
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  constexpr int CH = 5, NCOL = J / 4;  // columns per wave
+  // request the first CH*64 entries of this wave's columns before anything else (over-read stays in the slack)
+  int idx[NCOL][CH];
+  double val[NCOL][CH];
+#pragma unroll
+  for (int q = 0; q < NCOL; ++q) {
+    const int j = min(b * J + wave + 4 * q, B.cols - 1);
+    const int64_t s = B.outer[j];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      idx[q][c] = B.inner[s + c * WAVE + lane];
+      val[q][c] = Bv[s + c * WAVE + lane];
+    }
+  }
   const int kne = (kn + 1) & ~1;
   for (int jj = 0; jj < J; ++jj)
     for (int i = threadIdx.x; i < kne; i += blockDim.x) tile[jj * pitch + i] = 0.0;
   __syncthreads();
-  const double* __restrict__ Bv = static_cast<const double*>(B.val);
-  const int wave = threadIdx.x / WAVE, lane = lane_id();
-  for (int jj = wave; jj < J; jj += 4) {
+#pragma unroll
+  for (int q = 0; q < NCOL; ++q) {
+    const int jj = wave + 4 * q;
     const int j = b * J + jj;
     if (j >= B.cols) break;
-    for (int64_t p = B.outer[j] + lane; p < B.outer[j + 1]; p += WAVE) tile[jj * pitch + (B.inner[p] - kmin)] = Bv[p];
+    const int64_t s = B.outer[j], e = B.outer[j + 1];
+    if (e <= s) continue;
+    const int first = readlane_i32(idx[q][0], 0);
+    double* __restrict__ dst = fuse_a ? aexp + aeoff[j] - first : nullptr;
+    int carry = first - 1;  // row of the entry before the current chunk
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int64_t p = s + c * WAVE + lane;
+      const int r = idx[q][c];
+      int prev = __shfl_up(r, 1, WAVE);
+      if (lane == 0) prev = carry;
+      if (p < e) {
+        if (tiled) tile[jj * pitch + (r - kmin)] = val[q][c];
+        if (fuse_a) {
+          dst[r] = val[q][c];
+          for (int h = prev + 1; h < r; ++h) dst[h] = 0.0;
+        }
+      }
+      carry = readlane_i32(r, WAVE - 1);
+    }
+    for (int64_t p = s + CH * WAVE + lane; p < e; p += WAVE) {
+      const int r = B.inner[p];
+      const double v = Bv[p];
+      if (tiled) tile[jj * pitch + (r - kmin)] = v;
+      if (fuse_a) {
+        const int prev = B.inner[p - 1];
+        dst[r] = v;
+        for (int h = prev + 1; h < r; ++h) dst[h] = 0.0;
+      }
+    }
   }
   __syncthreads();
-  double* __restrict__ dst = bblk + blk_boff[b];
+  double* __restrict__ out = bblk + blk_boff[b];
   const int total = kne * J;
-  for (int i = threadIdx.x; i < total; i += blockDim.x) dst[i] = tile[(i % J) * pitch + (i / J)];
+  for (int i = threadIdx.x; i < total; i += blockDim.x) out[i] = tile[(i % J) * pitch + (i / J)];
 }
 
 // upper-bound output slot of every column: blk_toff[b] + jj * W_b
@@ -1447,7 +1497,7 @@ typedef double v8d __attribute__((ext_vector_type(8)));
 // before it.  The whole loop is ONE inline-asm block over fixed physical registers (slab_loop.inc, generated
 // by tools/gen_slab_asm.py, register map there): with separate asm statements the compiler is free to copy a
 // register between them -- including one whose asynchronous load has not landed yet.
-template <int J, int SL, int NW>
+template <int J, int SL, int NW, int MODE>  // MODE 0 unfused, 1 fma, 2..4 ablations (timing experiments, wrong results)
 __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_spgemm_slab(
     const SlabRun* __restrict__ runs, const double* __restrict__ bblk,
     const int64_t* __restrict__ blk_boff, const int32_t* __restrict__ blk_kmin, const int32_t* __restrict__ blk_kn,
@@ -1463,16 +1513,28 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
   if (kn == 0) return;
   const int rbase = lo + WAVE * wave;  // slab s of this wave starts at row rbase + 64*NW*s
   const SlabRun* rp = runs + kmin;        // record of step kk: rp[kk]
-  const double* bq = bblk + blk_boff[b];  // multipliers of step kk: bq[kk*J .. kk*J+J)
-  const unsigned r0 = (unsigned)(rbase + lane) * 8u, r1 = r0 + WAVE * NW * 8u, r2 = r1 + WAVE * NW * 8u;
+  const double* bq = bblk + (MODE == 5 ? 0 : blk_boff[b]);  // multipliers of step kk: bq[kk*J .. kk*J+J)
+  const unsigned r0 = (unsigned)(rbase + lane) * 8u;
   const int e0 = rbase + WAVE - 1, e1 = e0 + WAVE * NW, e2 = e1 + WAVE * NW;
   v8d accL0, accH0, accL1, accH1, accL2, accH2;
-  asm volatile(SLAB_LOOP_ASM
-               : "=&{v[2:17]}"(accL0), "=&{v[18:33]}"(accH0), "=&{v[34:49]}"(accL1), "=&{v[50:65]}"(accH1),
-                 "=&{v[66:81]}"(accL2), "=&{v[82:97]}"(accH2)
-               : [rp] "s"(rp), [bq] "s"(bq), [kn] "s"(kn), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [r0] "v"(r0),
-                 [r1] "v"(r1), [r2] "v"(r2)
-               : SLAB_LOOP_CLOBBERS);
+#define SLAB_LOOP_OPERANDS                                                                                        \
+  : "=&{v[2:17]}"(accL0), "=&{v[18:33]}"(accH0), "=&{v[34:49]}"(accL1), "=&{v[50:65]}"(accH1),                   \
+    "=&{v[66:81]}"(accL2), "=&{v[82:97]}"(accH2)                                                                   \
+  : [rp] "s"(rp), [bq] "s"(bq), [kn] "s"(kn), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [r0] "v"(r0),            \
+    [c1] "n"(WAVE * NW * 8), [c2] "n"(2 * WAVE * NW * 8)                                                         \
+  : SLAB_LOOP_CLOBBERS
+  if constexpr (MODE == 1) {
+    asm volatile(SLAB_LOOP_ASM_FMA SLAB_LOOP_OPERANDS);  // option spgemm_fma: one rounding per product (v_fma_f64)
+  } else if constexpr (MODE == 2) {
+    asm volatile(SLAB_LOOP_ASM_ABL1 SLAB_LOOP_OPERANDS);  // no slab loads
+  } else if constexpr (MODE == 3) {
+    asm volatile(SLAB_LOOP_ASM_ABL2 SLAB_LOOP_OPERANDS);  // no multiplier loads
+  } else if constexpr (MODE == 4) {
+    asm volatile(SLAB_LOOP_ASM_ABL3 SLAB_LOOP_OPERANDS);  // no arithmetic
+  } else {
+    asm volatile(SLAB_LOOP_ASM SLAB_LOOP_OPERANDS);  // MODE 5 (experiment): every block reads the first tile (cache-hot multipliers)
+  }
+#undef SLAB_LOOP_OPERANDS
   double acc[SL][J];
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) {
@@ -2513,20 +2575,32 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   if (use_slab) {
     aexp.alloc((size_t)slab_tot[0] + 1);
     bblk.alloc((size_t)slab_tot[1] + 4 * SJ);
-    hipLaunchKernelGGL(k_slab_expand_a, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), cmin.p,
-                       aeoff.p, aexp.p);
+    const bool same = (&A == &B);
+    if (!same)
+      hipLaunchKernelGGL(k_slab_expand_a, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), cmin.p,
+                         aeoff.p, aexp.p);
     runs.alloc(((size_t)A.cols + 4) * sizeof(SlabRun));
     hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aeoff.p, aexp.p,
                        reinterpret_cast<SlabRun*>(runs.p), A.cols);
     const int pitch = ((int)hstats[17] + 1) | 1;
     hipLaunchKernelGGL((k_slab_expand_b<SJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * 8, stream(), view(B),
-                       blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch);
+                       blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p, aexp.p);
   }
   t_num.start();
   if (use_slab) {
-    hipLaunchKernelGGL((k_spgemm_slab<SJ, SLAB_SL, SLAB_NW>), dim3(xcd_grid(snb)), dim3(SLAB_NW * WAVE), 0, stream(),
-                       reinterpret_cast<const SlabRun*>(runs.p), bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p,
-                       tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
+    auto launch_slab = [&](auto fma_tag) {
+      hipLaunchKernelGGL((k_spgemm_slab<SJ, SLAB_SL, SLAB_NW, decltype(fma_tag)::value>), dim3(xcd_grid(snb)),
+                         dim3(SLAB_NW * WAVE), 0, stream(), reinterpret_cast<const SlabRun*>(runs.p), bblk.p, blk_boff.p,
+                         blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha,
+                         threshold, dr, n, snb);
+    };
+    const int abl = (sv_opt / 100 == 4) ? sv_opt % 100 : 0;  // 401..403: ablations for timing experiments
+    if (abl == 1) launch_slab(std::integral_constant<int, 2>{});
+    else if (abl == 2) launch_slab(std::integral_constant<int, 3>{});
+    else if (abl == 3) launch_slab(std::integral_constant<int, 4>{});
+    else if (abl == 4) launch_slab(std::integral_constant<int, 5>{});
+    else if (options().spgemm_fma) launch_slab(std::integral_constant<int, 1>{});
+    else launch_slab(std::integral_constant<int, 0>{});
     for (int i = 0; i < 7; ++i) hstats[i] = 0;
   }
   dispatch_type(A.cplx, [&](auto tag) {

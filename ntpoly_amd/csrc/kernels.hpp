@@ -21,6 +21,9 @@ struct EngineOptions {
   int spgemm_force_bin = -1;   // tests: force every non-empty column through one path (1..5), 6 = HBM fallback
   int increment_force_seq = 0; // tests: force the sequential-merge fallback
   int time_kernels = 0;        // record HIP-event timings in SpgemmStats
+  int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
+                               // reference built with FP contraction computes); 0: separate multiply and add (default, bit-
+                               // identical to the reference built without contraction)
   int spgemm_variant = -1;     // numeric window kernel: -1 auto (column-pair v3 for real operands), 0 one column per
                                // wave (first generation), other values: experimental generations kept for A/B (kernels.hip)
 };

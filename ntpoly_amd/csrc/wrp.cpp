@@ -75,6 +75,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   const std::string n(name);
   if (n == "spgemm_force_bin") options().spgemm_force_bin = *value;
   else if (n == "increment_force_seq") options().increment_force_seq = *value;
+  else if (n == "spgemm_fma") options().spgemm_fma = *value;
   else if (n == "time_kernels") options().time_kernels = *value;
   else if (n == "spgemm_variant") options().spgemm_variant = *value;
   else NTP_FATAL("unknown option " + n);

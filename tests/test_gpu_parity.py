@@ -319,3 +319,30 @@ def test_slab_kernel_vs_oracle(nt, n, h, holes, thr):
     Bo = O.Mat.from_triplets(n, n, *mats[1])
     oc, orow, ov = O.ps_multiply(Ao, Bo, None, 0.5, 0.0, thr).triplets()
     exact(C.triplets(), (n, n, oc, orow, ov), "slab vs oracle n=%d h=%d holes=%g" % (n, h, holes))
+
+
+def test_slab_kernel_fma_option(nt):
+    """option spgemm_fma = 1: products accumulated with v_fma_f64 (one rounding per product, what a reference
+    built with floating-point contraction computes).  Not bit-identical to the unfused reference build:
+    same sparsity pattern away from the threshold, values within 1e-13 relative of the oracle."""
+    from oracle import oracle_py as O
+    n, h, thr = 4096, 100, 1e-8
+    col, row, val = banded_triplets(n, h)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    nt.set_option("spgemm_fma", 1)
+    try:
+        C = nt.Matrix_ps(n)
+        C.Gemm(A, A, None, 1.0, 0.0, thr)
+        assert nt.last_spgemm_stats()["slab"] == 1
+    finally:
+        nt.set_option("spgemm_fma", 0)
+    Ao = O.Mat.from_triplets(n, n, col, row, val)
+    oc, orow, ov = O.ps_multiply(Ao, Ao, None, 1.0, 0.0, thr).triplets()
+    got = C.to_scipy()
+    import scipy.sparse as sp
+    want = sp.csc_matrix((ov, (orow - 1, oc - 1)), shape=(n, n))
+    d = abs(got - want)
+    scale = abs(want).max()
+    assert d.max() <= max(1e-13 * scale, 2 * thr * 1e-6) or d.max() <= 1.000001 * thr  # entries straddling the threshold
+    big = abs(want) > 10 * thr
+    assert abs((got - want).multiply(big)).max() <= 1e-13 * scale

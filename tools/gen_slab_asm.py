@@ -3,14 +3,21 @@
 block (gfx950).  Every register the loop touches is a fixed physical register, so nothing the compiler does
 can read an SGPR/VGPR whose asynchronous load has not landed.
 
+Pipeline (step t = column k = kmin + t of A):
+  top of step t : s_waitcnt lgkmcnt(0)      -> B(k, :) of step t and the run record of step t+2 have landed
+                  issue the SL slab loads of step t+2 (buffer_load, zero fill outside the run)
+                  issue s_load of B(k+1, :) and of the run record of step t+3
+                  s_waitcnt vmcnt(2*SL)     -> the slabs of step t have landed (t+1, t+2 still in flight)
+                  for every slab the run touches: 16 x (v_mul_f64, v_add_f64), 4 independent chains at a time
 Register map (J = 16 columns, SL = 3 slabs per wave):
-  s[14:15] run-record pointer     s[16:17] multiplier pointer      s18 step counter   s19 scratch
-  s20,s21  first / span62 of the step on set A      s22,s23  the same for set B
+  s[14:15] run-record pointer (advances 32 B per step)   s[16:17] multiplier pointer (128 B per step)
+  s18 step counter   s19 scratch   (first, span62) of the step on slab set 0/1/2: (s20,s21) (s22,s23) (s12,s13)
   s[24:31] run record: buffer descriptor s[24:27], first8 s28, first s29, span62 s30
+  s[36:67] multipliers B(k, 0..15) of set 0          s[68:99] of set 1
   (s32..s35 are left alone: s32 is the ABI stack pointer)
-  s[36:67] multipliers B(k, 0..15) of set A          s[68:99] of set B
   v[2:33], v[34:65], v[66:97]  accumulators of slab 0, 1, 2 (16 doubles each)
-  v[98:105] products in flight   v[106:108] load offsets   v[116:121] slabs of set A   v[122:127] of set B
+  v[98:105] products in flight   v[106:108] load offsets
+  slab values: set 0 v[116:121], set 1 v[122:127], set 2 v[110:115]
 """
 import os
 
@@ -18,9 +25,10 @@ SL, J = 3, 16
 ACC0 = 2          # first accumulator VGPR
 T0 = 98
 VOFF = 106
-A_SET = {"A": 116, "B": 122}
-B_SET = {"A": 36, "B": 68}
-FS = {"A": (20, 21), "B": (22, 23)}
+A_SET = [116, 122, 110]
+B_SET = [36, 68]
+FS = [(20, 21), (22, 23), (12, 13)]
+NA, NB = len(A_SET), len(B_SET)
 
 
 def vp(n):
@@ -31,88 +39,112 @@ def sp(n):
     return "s[%d:%d]" % (n, n + 1)
 
 
-def issue(which, lines):
+def issue(aset, lines, ablate=0):
     """copy first/span62 of the record that just landed, issue the SL slab loads of that step"""
-    f, s = FS[which]
+    f, s = FS[aset]
     lines.append("s_mov_b32 s%d, s29" % f)
     lines.append("s_mov_b32 s%d, s30" % s)
+    lines.append("v_sub_u32 v%d, %%[r0], s28" % VOFF)
+    for i in range(1, SL):
+        lines.append("v_add_u32 v%d, %%[c%d], v%d" % (VOFF + i, i, VOFF))
     for i in range(SL):
-        lines.append("v_sub_u32 v%d, %%[r%d], s28" % (VOFF + i, i))
-    for i in range(SL):
-        lines.append("buffer_load_dwordx2 %s, v%d, s[24:27], 0 offen" % (vp(A_SET[which] + 2 * i), VOFF + i))
+        if ablate == 1:
+            continue
+        lines.append("buffer_load_dwordx2 %s, v%d, s[24:27], 0 offen" % (vp(A_SET[aset] + 2 * i), VOFF + i))
 
 
-def compute(which, lines, label):
-    f, s = FS[which]
-    lines.append("s_waitcnt vmcnt(%d)" % SL)
+def load_b(bset, off, lines, ablate=0):
+    if ablate == 2:
+        return
+    lines.append("s_load_dwordx16 s[%d:%d], s[16:17], 0x%x" % (B_SET[bset], B_SET[bset] + 15, off))
+    lines.append("s_load_dwordx16 s[%d:%d], s[16:17], 0x%x" % (B_SET[bset] + 16, B_SET[bset] + 31, off + 0x40))
+
+
+def compute(aset, bset, lines, label, fused, ablate=0):
+    f, s = FS[aset]
     for i in range(SL):
         skip = "%d" % label[0]
         label[0] += 1
         lines.append("s_sub_i32 s19, %%[e%d], s%d" % (i, f))
         lines.append("s_cmp_gt_u32 s19, s%d" % s)
         lines.append("s_cbranch_scc1 %sf" % skip)
-        a = vp(A_SET[which] + 2 * i)
-        for g in range(J // 4):
+        a = vp(A_SET[aset] + 2 * i)
+        for g in range(J // 4 if ablate != 3 else 0):
+            if fused:
+                for q in range(4):
+                    acc = vp(ACC0 + 2 * J * i + 2 * (4 * g + q))
+                    lines.append("v_fma_f64 %s, %s, %s, %s" % (acc, a, sp(B_SET[bset] + 2 * (4 * g + q)), acc))
+                continue
             for q in range(4):
-                lines.append("v_mul_f64 %s, %s, %s" % (vp(T0 + 2 * q), a, sp(B_SET[which] + 2 * (4 * g + q))))
+                lines.append("v_mul_f64 %s, %s, %s" % (vp(T0 + 2 * q), a, sp(B_SET[bset] + 2 * (4 * g + q))))
             for q in range(4):
                 acc = vp(ACC0 + 2 * J * i + 2 * (4 * g + q))
                 lines.append("v_add_f64 %s, %s, %s" % (acc, acc, vp(T0 + 2 * q)))
         lines.append("%s:" % skip)
 
 
-def main():
+def build(fused, ablate=0):
     L = []
     label = [10]
     for i in range(SL * J):
         L.append("v_mov_b64 %s, 0" % vp(ACC0 + 2 * i))
     L.append("s_mov_b64 s[14:15], %[rp]")
     L.append("s_mov_b64 s[16:17], %[bq]")
+    # prologue: slabs of steps 0 and 1, multipliers of step 0, record of step 2
     L.append("s_load_dwordx8 s[24:31], s[14:15], 0x0")
     L.append("s_waitcnt lgkmcnt(0)")
-    issue("A", L)
-    L.append("s_load_dwordx16 s[36:51], s[16:17], 0x0")
-    L.append("s_load_dwordx16 s[52:67], s[16:17], 0x40")
+    issue(0, L, ablate)
     L.append("s_load_dwordx8 s[24:31], s[14:15], 0x20")
+    L.append("s_waitcnt lgkmcnt(0)")
+    issue(1, L, ablate)
+    load_b(0, 0, L, ablate)
+    L.append("s_load_dwordx8 s[24:31], s[14:15], 0x40")
     L.append("s_mov_b32 s18, 0")
     L.append("1:")
-    # step kk on set A; get step kk+1 going on set B
-    L.append("s_waitcnt lgkmcnt(0)")
-    issue("B", L)
-    L.append("s_load_dwordx16 s[68:83], s[16:17], 0x80")
-    L.append("s_load_dwordx16 s[84:99], s[16:17], 0xc0")
-    L.append("s_load_dwordx8 s[24:31], s[14:15], 0x40")
-    compute("A", L, label)
-    # step kk+1 on set B; get step kk+2 going on set A
-    L.append("s_waitcnt lgkmcnt(0)")
-    issue("A", L)
-    L.append("s_add_u32 s16, s16, 0x100")
-    L.append("s_addc_u32 s17, s17, 0")
-    L.append("s_add_u32 s14, s14, 0x40")
-    L.append("s_addc_u32 s15, s15, 0")
-    L.append("s_load_dwordx16 s[36:51], s[16:17], 0x0")
-    L.append("s_load_dwordx16 s[52:67], s[16:17], 0x40")
-    L.append("s_load_dwordx8 s[24:31], s[14:15], 0x20")
-    compute("B", L, label)
-    L.append("s_add_i32 s18, s18, 2")
-    L.append("s_cmp_lt_i32 s18, %[kn]")
-    L.append("s_cbranch_scc1 1b")
+    period = NA * NB
+    for t in range(period):
+        L.append("s_waitcnt lgkmcnt(0)")
+        issue((t + 2) % NA, L, ablate)
+        # pointers advance once per step: s[16:17] -> multipliers of step t+1, s[14:15] -> record of step t+1
+        L.append("s_add_u32 s16, s16, 0x80")
+        L.append("s_addc_u32 s17, s17, 0")
+        L.append("s_add_u32 s14, s14, 0x20")
+        L.append("s_addc_u32 s15, s15, 0")
+        load_b((t + 1) % NB, 0, L, ablate)
+        L.append("s_load_dwordx8 s[24:31], s[14:15], 0x40")   # record of step t+3
+        L.append("s_waitcnt vmcnt(%d)" % (2 * SL))
+        compute(t % NA, t % NB, L, label, fused, ablate)
+        L.append("s_add_i32 s18, s18, 1")
+        L.append("s_cmp_ge_i32 s18, %[kn]")
+        if t + 1 < period:
+            L.append("s_cbranch_scc1 2f")
+        else:
+            L.append("s_cbranch_scc0 1b")
+    L.append("2:")
     L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return L
 
-    sclob = ["s%d" % i for i in list(range(14, 32)) + list(range(36, 100))]
-    vclob = ["v%d" % i for i in list(range(T0, VOFF + SL)) + list(range(116, 128))]
+
+def main():
+    sclob = ["s%d" % i for i in [12, 13] + list(range(14, 32)) + list(range(36, 100))]
+    vclob = ["v%d" % i for i in list(range(T0, VOFF + SL)) + list(range(110, 128))]
     out = []
     out.append("// GENERATED by tools/gen_slab_asm.py -- do not edit.  Main loop of k_spgemm_slab<16,3,NW>.")
     out.append("// Operands: outputs accL0,accH0,accL1,accH1,accL2,accH2 (v8d, pinned to v[2:97]); inputs rp, bq (64-bit")
-    out.append("// uniform pointers), kn, e0..e2 (last row of the wave's slabs), r0..r2 (per-lane row offsets * 8).")
-    out.append("#define SLAB_LOOP_ASM \\")
-    for ln in L:
-        out.append('  "%s\\n\\t" \\' % ln)
-    out.append('  ""')
+    out.append("// uniform pointers), kn, e0..e2 (last row of the wave's slabs), r0 (per-lane row offset * 8 of slab 0), c1, c2")
+    out.append("// (immediates: byte distance of slabs 1 and 2 from slab 0).")
+    for name, fused, abl in (("SLAB_LOOP_ASM", False, 0), ("SLAB_LOOP_ASM_FMA", True, 0), ("SLAB_LOOP_ASM_ABL1", False, 1),
+                             ("SLAB_LOOP_ASM_ABL2", False, 2), ("SLAB_LOOP_ASM_ABL3", False, 3)):
+        L = build(fused, abl)
+        out.append("#define %s \\" % name)
+        for ln in L:
+            out.append('  "%s\\n\\t" \\' % ln)
+        out.append('  ""')
+        print(name, len(L), "instructions")
     out.append("#define SLAB_LOOP_CLOBBERS " + ", ".join('"%s"' % c for c in sclob + vclob) + ', "vcc", "scc", "memory"')
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ntpoly_amd", "csrc", "slab_loop.inc")
     open(path, "w").write("\n".join(out) + "\n")
-    print("wrote", path, len(L), "instructions")
+    print("wrote", path)
 
 
 if __name__ == "__main__":

@@ -7,6 +7,6 @@ i=0
 for ctrs in "$@"; do
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $ctrs -d gpurun_out/$out/p$i -o run --output-format csv -- \
-    python3 tools/bench_spgemm.py --iters 6 --reps 2 --variants $var > gpurun_out/$out.p$i.log 2>&1
+    python3 tools/bench_spgemm.py --iters 6 --reps 2 --variants $var $EXTRA > gpurun_out/$out.p$i.log 2>&1
   echo "pass $i ($ctrs): rc=$?"
 done
