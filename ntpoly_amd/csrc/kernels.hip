@@ -227,11 +227,13 @@ __global__ __launch_bounds__(256) void k_scan_block_apply(const TIn* __restrict_
 }
 
 // deterministic final reduction of per-block partials (sum of pairs / min / max)
+// block g reduces pairs [g*chunk, min(n, (g+1)*chunk)) in a fixed order -> out[2g], out[2g+1]
 __global__ __launch_bounds__(256) void k_reduce_sum2(const double* __restrict__ part, int n,
-                                                     double* __restrict__ out) {
+                                                     double* __restrict__ out, int chunk) {
   __shared__ double sx[256], sy[256];
   double x = 0, y = 0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  const int i0 = blockIdx.x * chunk, i1 = min(n, i0 + chunk);
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     x = __dadd_rn(x, part[2 * i]);
     y = __dadd_rn(y, part[2 * i + 1]);
   }
@@ -246,8 +248,8 @@ __global__ __launch_bounds__(256) void k_reduce_sum2(const double* __restrict__ 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    out[0] = sx[0];
-    out[1] = sy[0];
+    out[2 * blockIdx.x] = sx[0];
+    out[2 * blockIdx.x + 1] = sy[0];
   }
 }
 
@@ -2391,6 +2393,17 @@ void scan_async(const TIn* d_in, int64_t* d_out, int64_t n) {
   hipLaunchKernelGGL(k_scan_excl_i64, dim3(1), dim3(1024), 0, stream(), sums.p, offs.p, (int64_t)nb);
   hipLaunchKernelGGL((k_scan_block_apply<TIn>), dim3(nb), dim3(256), 0, stream(), d_in, n, offs.p, d_out);
 }
+// deterministic two-level sum of n (x, y) pairs into out_dev[0..1]
+void reduce_sum2_async(const double* part, int n, double* out_dev) {
+  if (n <= 8192) {
+    hipLaunchKernelGGL(k_reduce_sum2, dim3(1), dim3(256), 0, stream(), part, n, out_dev, n);
+    return;
+  }
+  const int chunk = 2048, g = (n + chunk - 1) / chunk;
+  DevBuf<double> lvl((size_t)2 * g);
+  hipLaunchKernelGGL(k_reduce_sum2, dim3(g), dim3(256), 0, stream(), part, n, lvl.p, chunk);
+  hipLaunchKernelGGL(k_reduce_sum2, dim3(1), dim3(256), 0, stream(), lvl.p, g, out_dev, g);
+}
 }  // namespace
 
 int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n) {
@@ -2841,8 +2854,8 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
   if (fuse_dot) {
     dres.alloc(4);
     dres.zero();
-    if (hs[1]) hipLaunchKernelGGL(k_reduce_sum2, dim3(1), dim3(256), 0, stream(), part1.p, nb1, dres.p);
-    if (hs[2]) hipLaunchKernelGGL(k_reduce_sum2, dim3(1), dim3(256), 0, stream(), part2.p, nb2, dres.p + 2);
+    if (hs[1]) reduce_sum2_async(part1.p, nb1, dres.p);
+    if (hs[2]) reduce_sum2_async(part2.p, nb2, dres.p + 2);
   }
   DevMat R;
   R.rows = A.rows;
@@ -2908,7 +2921,7 @@ void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a) {
 namespace {
 void finish_sum2(DevBuf<double>& partial, int nb, double out[2]) {
   DevBuf<double> res(2);
-  hipLaunchKernelGGL(k_reduce_sum2, dim3(1), dim3(256), 0, stream(), partial.p, nb, res.p);
+  reduce_sum2_async(partial.p, nb, res.p);
   res.download(out, 2);
 }
 }  // namespace
