@@ -12,7 +12,7 @@ W warm-up iterations are followed by exactly K timed ones (barrier + device sync
 sides, max over ranks).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant kernel (SpGEMM numeric, k_spgemm_pair3): algorithmic bytes
+  roofline     -- the dominant kernel (SpGEMM numeric, k_spgemm_slab): algorithmic bytes
                   12*(nnzA+nnzB+nnzC)+4*(cols...) per launch / its HIP-event time, vs 8 TB/s HBM
   cpu_baseline -- the oracle (C restatement, kind "port") timed on the host cores on a bounded
                   sample (N_s rows of the same generator), scaled linearly in N (cost is O(N) at
@@ -194,11 +194,16 @@ def main():
             "spgemm_ms_per_call": ms_spgemm / calls,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_spgemm_pair3 (SpGEMM numeric phase)",
+                         "kernel": "k_spgemm_slab (SpGEMM numeric phase)" if st.get("slab") else "k_spgemm_pair3 (SpGEMM numeric phase)",
                          "alg_bytes_per_launch": acc["alg_bytes"] / calls, "ms_per_launch": ms_numeric / calls,
                          "note": "rank-0 panel; algorithmic bytes = 12*(nnzA+nnzB+nnzC)+4*(colsA+colsB+colsC+3); traffic = bytes "
                                  "per launch from the committed PMC passes (profiles/r01_pmc_traffic.json)"},
         }
+        # the numeric kernel is FP64-ALU side bound: 2 flops per product against the vector peak for SEPARATE multiply and
+        # add instructions (78.6 TFLOP/s counts an FMA as 2 flops per instruction -> 39.3 for unfused mul + add)
+        tfl = 2.0 * acc["products"] / (ms_numeric * 1e-3) / 1e12
+        line["roofline_compute"] = {"bound": "fp64 vector ALU (unfused mul+add)", "achieved": tfl, "peak": 39.3,
+                                    "unit": "TFLOP/s", "frac": tfl / 39.3}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, h, thr, args.warmup, args.steps)
         print(json.dumps(line), flush=True)

@@ -291,9 +291,14 @@ __global__ void k_col_extent(Csc A, int32_t* __restrict__ cmin, int32_t* __restr
   cmax[k] = (e > s) ? A.inner[e - 1] : -1;
 }
 
-__global__ void k_span_of(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax, int32_t* __restrict__ span, int n) {
+// span of every column run; stats[18] += number of non-empty columns
+__global__ void k_span_of(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax, int32_t* __restrict__ span, int n,
+                          unsigned long long* __restrict__ stats) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) span[k] = cmax[k] >= cmin[k] ? cmax[k] - cmin[k] + 1 : 0;
+  const bool any = k < n && cmax[k] >= cmin[k];
+  if (k < n) span[k] = any ? cmax[k] - cmin[k] + 1 : 0;
+  const unsigned long long m = __ballot(any);
+  if (lane_id() == 0 && m) atomicAdd(&stats[18], (unsigned long long)__popcll(m));
 }
 
 // register-slab kernel geometry: J output columns per workgroup, SL slabs of 64 rows per wave, NW waves
@@ -2542,7 +2547,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       bfirst = bfirst_own.p; blast = blast_own.p;
     }
     aspan.alloc(A.cols); aeoff.alloc((size_t)A.cols + 1);
-    hipLaunchKernelGGL(k_span_of, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aspan.p, A.cols);
+    hipLaunchKernelGGL(k_span_of, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aspan.p, A.cols, stats.p);
     scan_async<int32_t>(aspan.p, aeoff.p, (int64_t)A.cols);
     blk_lo.alloc(snb); blk_w.alloc(snb); blk_kmin.alloc(snb); blk_kn.alloc(snb);
     bsz.alloc(snb); tsz.alloc(snb); blk_boff.alloc((size_t)snb + 1); blk_toff.alloc((size_t)snb + 1);
@@ -2565,7 +2570,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     const int64_t max_w = (int64_t)hstats[16], max_kn = (int64_t)hstats[17];
     const bool fits = max_w > 0 && max_w <= SLAB_NW * SLAB_SL * WAVE && ((max_kn + 1) | 1) * SJ * 8 <= 64 * 1024;
     const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
-                            (double)slab_tot[0] >= 48.0 * (double)A.cols;
+                            (double)slab_tot[0] >= 48.0 * (double)hstats[18];  // mean run of the non-empty columns >= 48 rows
     use_slab = fits && (dense_runs || sv_opt / 100 == 4);
   }
   st.slab = use_slab ? 1 : 0;
