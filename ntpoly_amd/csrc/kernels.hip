@@ -1511,7 +1511,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int32_t* __restrict__ blk_lo, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
     int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count, double alpha,
     double threshold, int dense_rule, int ncols, int nblocks) {
-  static_assert(J == 16 && SL == 3, "register map of slab_loop.inc");
+  static_assert(J == 16 && SL == 3 && NW == 4, "register map / wave rotation of slab_loop.inc");
   __shared__ int cnt_s[NW * SL][J];
   const int b = xcd_block(nblocks);
   if (b < 0) return;
@@ -1528,7 +1528,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
   : "=&{v[2:17]}"(accL0), "=&{v[18:33]}"(accH0), "=&{v[34:49]}"(accL1), "=&{v[50:65]}"(accH1),                   \
     "=&{v[66:81]}"(accL2), "=&{v[82:97]}"(accH2)                                                                   \
   : [rp] "s"(rp), [bq] "s"(bq), [kn] "s"(kn), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [r0] "v"(r0),            \
-    [c1] "n"(WAVE * NW * 8), [c2] "n"(2 * WAVE * NW * 8)                                                         \
+    [c1] "n"(WAVE * NW * 8), [c2] "n"(2 * WAVE * NW * 8), [wv] "s"(wave)                                         \
   : SLAB_LOOP_CLOBBERS
   if constexpr (MODE == 1) {
     asm volatile(SLAB_LOOP_ASM_FMA SLAB_LOOP_OPERANDS);  // option spgemm_fma: one rounding per product (v_fma_f64)
@@ -1538,6 +1538,8 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     asm volatile(SLAB_LOOP_ASM_ABL2 SLAB_LOOP_OPERANDS);  // no multiplier loads
   } else if constexpr (MODE == 4) {
     asm volatile(SLAB_LOOP_ASM_ABL3 SLAB_LOOP_OPERANDS);  // no arithmetic
+  } else if constexpr (MODE == 6) {
+    asm volatile(SLAB_LOOP_ASM_PF SLAB_LOOP_OPERANDS);  // unfused, with the rotating scalar-cache prefetch of the fused loop
   } else {
     asm volatile(SLAB_LOOP_ASM SLAB_LOOP_OPERANDS);  // MODE 5 (experiment): every block reads the first tile (cache-hot multipliers)
   }
@@ -2592,7 +2594,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<double> aexp, bblk;
   if (use_slab) {
     aexp.alloc((size_t)slab_tot[0] + 1);
-    bblk.alloc((size_t)slab_tot[1] + 4 * SJ);
+    bblk.alloc((size_t)slab_tot[1] + 16 * SJ);  // slack: the loop prefetches a few rows past the last tile
     const bool same = (&A == &B);
     if (!same)
       hipLaunchKernelGGL(k_slab_expand_a, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), cmin.p,
@@ -2617,6 +2619,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     else if (abl == 2) launch_slab(std::integral_constant<int, 3>{});
     else if (abl == 3) launch_slab(std::integral_constant<int, 4>{});
     else if (abl == 4) launch_slab(std::integral_constant<int, 5>{});
+    else if (abl == 5) launch_slab(std::integral_constant<int, 6>{});
     else if (options().spgemm_fma) launch_slab(std::integral_constant<int, 1>{});
     else launch_slab(std::integral_constant<int, 0>{});
     for (int i = 0; i < 7; ++i) hstats[i] = 0;

@@ -29,6 +29,7 @@ A_SET = [116, 122, 110]
 B_SET = [36, 68]
 FS = [(20, 21), (22, 23), (12, 13)]
 NA, NB = len(A_SET), len(B_SET)
+PF = 4           # scalar-cache prefetch distance of the multiplier rows, in steps (0 = off)
 
 
 def vp(n):
@@ -83,7 +84,7 @@ def compute(aset, bset, lines, label, fused, ablate=0):
         lines.append("%s:" % skip)
 
 
-def build(fused, ablate=0):
+def build(fused, ablate=0, pf=0):
     L = []
     label = [10]
     for i in range(SL * J):
@@ -112,6 +113,19 @@ def build(fused, ablate=0):
         L.append("s_addc_u32 s15, s15, 0")
         load_b((t + 1) % NB, 0, L, ablate)
         L.append("s_load_dwordx8 s[24:31], s[14:15], 0x40")   # record of step t+3
+        if pf:
+            # scalar-cache prefetch of the multiplier row PF steps further on, issued by ONE wave of the block per
+            # step (the wave whose index equals step mod 4): s_waitcnt lgkmcnt(0) makes the issuing wave sit out the
+            # full miss latency at its next step, so the four waves take turns and each stalls once in four steps
+            # while the other three find their rows in the cache.  s31 is the unused pad word of the record.
+            skip = "%d" % label[0]
+            label[0] += 1
+            L.append("s_and_b32 s19, s18, 3")
+            L.append("s_cmp_lg_u32 s19, %[wv]")
+            L.append("s_cbranch_scc1 %sf" % skip)
+            L.append("s_load_dword s31, s[16:17], 0x%x" % (pf * 0x80))
+            L.append("s_load_dword s31, s[16:17], 0x%x" % (pf * 0x80 + 0x40))
+            L.append("%s:" % skip)
         L.append("s_waitcnt vmcnt(%d)" % (2 * SL))
         compute(t % NA, t % NB, L, label, fused, ablate)
         L.append("s_add_i32 s18, s18, 1")
@@ -132,10 +146,13 @@ def main():
     out.append("// GENERATED by tools/gen_slab_asm.py -- do not edit.  Main loop of k_spgemm_slab<16,3,NW>.")
     out.append("// Operands: outputs accL0,accH0,accL1,accH1,accL2,accH2 (v8d, pinned to v[2:97]); inputs rp, bq (64-bit")
     out.append("// uniform pointers), kn, e0..e2 (last row of the wave's slabs), r0 (per-lane row offset * 8 of slab 0), c1, c2")
-    out.append("// (immediates: byte distance of slabs 1 and 2 from slab 0).")
-    for name, fused, abl in (("SLAB_LOOP_ASM", False, 0), ("SLAB_LOOP_ASM_FMA", True, 0), ("SLAB_LOOP_ASM_ABL1", False, 1),
-                             ("SLAB_LOOP_ASM_ABL2", False, 2), ("SLAB_LOOP_ASM_ABL3", False, 3)):
-        L = build(fused, abl)
+    out.append("// (immediates: byte distance of slabs 1 and 2 from slab 0), wv (index of the wave in its workgroup, 0..3).")
+    # the rotating prefetch pays off only when the loop is not ALU bound: measured 2.69 -> 2.30 ms with v_fma_f64,
+    # 2.81 -> 2.85 ms with separate multiply and add (kept selectable as variant 405)
+    for name, fused, abl, pf in (("SLAB_LOOP_ASM", False, 0, 0), ("SLAB_LOOP_ASM_FMA", True, 0, PF),
+                                 ("SLAB_LOOP_ASM_ABL1", False, 1, 0), ("SLAB_LOOP_ASM_ABL2", False, 2, 0),
+                                 ("SLAB_LOOP_ASM_ABL3", False, 3, 0), ("SLAB_LOOP_ASM_PF", False, 0, PF)):
+        L = build(fused, abl, pf)
         out.append("#define %s \\" % name)
         for ln in L:
             out.append('  "%s\\n\\t" \\' % ln)
