@@ -39,6 +39,20 @@ void ensure_init();  // fails loudly when no GPU is present
 inline hipStream_t stream() { return ctx().stream; }
 void sync_stream();
 
+// Batched read-back of small results: up to 8 device segments of 8-byte words are copied by ONE tiny kernel into
+// host-mapped pinned memory and the stream is synchronised once (a hipMemcpyAsync per scalar costs a copy
+// kernel and ~20 us of dispatch gap each).  fetch.add(dev_ptr, words, host_dst) ... fetch.run().
+struct ScalarFetch {
+  const void* src[8];
+  int words[8];
+  void* dst[8];
+  int n = 0;
+  void add(const void* dev, int words8, void* host_dst) {
+    src[n] = dev; words[n] = words8; dst[n] = host_dst; ++n;
+  }
+  void run();  // defined in kernels.hip; synchronises the stream
+};
+
 // Caching allocator: sizes are rounded up to a small set of buckets and recycled.  All
 // device work of the engine is ordered on ctx().stream, so a block freed by the host can be
 // handed out again immediately (stream order protects it).
@@ -78,7 +92,14 @@ struct DevBuf {
     if (count) HIP_CHECK(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, stream()));
   }
   void download(T* host, size_t count) const {
-    if (count) HIP_CHECK(hipMemcpyAsync(host, p, count * sizeof(T), hipMemcpyDeviceToHost, stream()));
+    const size_t bytes = count * sizeof(T);
+    if (bytes > 0 && bytes <= 1024 && bytes % 8 == 0) {
+      ScalarFetch f;
+      f.add(p, (int)(bytes / 8), host);
+      f.run();
+      return;
+    }
+    if (count) HIP_CHECK(hipMemcpyAsync(host, p, bytes, hipMemcpyDeviceToHost, stream()));
     sync_stream();
   }
   void zero() { if (n) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), stream())); }

@@ -291,14 +291,43 @@ __global__ void k_col_extent(Csc A, int32_t* __restrict__ cmin, int32_t* __restr
   cmax[k] = (e > s) ? A.inner[e - 1] : -1;
 }
 
-// span of every column run; stats[18] += number of non-empty columns
-__global__ void k_span_of(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax, int32_t* __restrict__ span, int n,
-                          unsigned long long* __restrict__ stats) {
+// span of every column run
+__global__ void k_span_of(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax, int32_t* __restrict__ span, int n) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool any = k < n && cmax[k] >= cmin[k];
-  if (k < n) span[k] = any ? cmax[k] - cmin[k] + 1 : 0;
-  const unsigned long long m = __ballot(any);
-  if (lane_id() == 0 && m) atomicAdd(&stats[18], (unsigned long long)__popcll(m));
+  if (k < n) span[k] = cmax[k] >= cmin[k] ? cmax[k] - cmin[k] + 1 : 0;
+}
+
+// one block: stats[16] = max window rows, stats[17] = max k range over the column blocks, stats[18] = number of
+// non-empty columns of A (same-address atomics from every block of the plan kernels cost more than this pass)
+__global__ __launch_bounds__(1024) void k_slab_reduce(const int32_t* __restrict__ blk_w, const int32_t* __restrict__ blk_kn,
+                                                      int nblocks, const int32_t* __restrict__ aspan, int acols,
+                                                      unsigned long long* __restrict__ stats) {
+  __shared__ int sw[16], sk[16], sn[16];
+  int w = 0, kn = 0, ne = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 1024) {
+    w = max(w, blk_w[i]);
+    kn = max(kn, blk_kn[i]);
+  }
+  for (int i = threadIdx.x; i < acols; i += 1024) ne += aspan[i] > 0 ? 1 : 0;
+  w = wave_max_i32(w);
+  kn = wave_max_i32(kn);
+  for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o, WAVE);
+  if (lane_id() == 0) {
+    sw[threadIdx.x / WAVE] = w;
+    sk[threadIdx.x / WAVE] = kn;
+    sn[threadIdx.x / WAVE] = ne;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) {
+      sw[0] = max(sw[0], sw[i]);
+      sk[0] = max(sk[0], sk[i]);
+      sn[0] += sn[i];
+    }
+    stats[16] = (unsigned long long)sw[0];
+    stats[17] = (unsigned long long)sk[0];
+    stats[18] = (unsigned long long)sn[0];
+  }
 }
 
 // register-slab kernel geometry: J output columns per workgroup, SL slabs of 64 rows per wave, NW waves
@@ -1334,39 +1363,41 @@ __global__ __launch_bounds__(256) void k_slab_expand_a(Csc A, const int32_t* __r
   }
 }
 
-// per block of J output columns: row window, k range and the sizes of its B tile / output slots
-// stats[16] = max window rows, stats[17] = max k range
+// per block of J output columns (one wave each): k range = union of the columns' row ranges in B, row window =
+// union of the runs of A(:, k) over that k range (a superset of the rows actually touched when B has holes --
+// harmless, the window only has to contain them), sizes of the B tile and of the output slots.
 template <int J>
-__global__ void k_slab_plan(int ncols, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
-                            const int32_t* __restrict__ bfirst, const int32_t* __restrict__ blast,
-                            int32_t* __restrict__ blk_lo, int32_t* __restrict__ blk_w, int32_t* __restrict__ blk_kmin,
-                            int32_t* __restrict__ blk_kn, int64_t* __restrict__ bsz, int64_t* __restrict__ tsz,
-                            unsigned long long* __restrict__ stats, int nblocks) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_slab_plan(int ncols, const int32_t* __restrict__ bfirst,
+                                                   const int32_t* __restrict__ blast, const int32_t* __restrict__ cmin,
+                                                   const int32_t* __restrict__ cmax, int32_t* __restrict__ blk_lo,
+                                                   int32_t* __restrict__ blk_w, int32_t* __restrict__ blk_kmin,
+                                                   int32_t* __restrict__ blk_kn, int64_t* __restrict__ bsz,
+                                                   int64_t* __restrict__ tsz, int nblocks) {
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   if (b >= nblocks) return;
-  int lo = INT_MAX, hi = -1, kmin = INT_MAX, kmax = -1;
-  for (int jj = 0; jj < J; ++jj) {
-    const int j = b * J + jj;
-    if (j >= ncols) break;
-    if (span_arr[j] > 0) {
-      lo = min(lo, lo_arr[j]);
-      hi = max(hi, lo_arr[j] + span_arr[j]);
-    }
-    if (blast[j] >= 0) {
-      kmin = min(kmin, bfirst[j]);
-      kmax = max(kmax, blast[j]);
+  const int lane = lane_id();
+  const int j = b * J + lane;
+  const bool has = lane < J && j < ncols && blast[min(j, ncols - 1)] >= 0;
+  const int kmin = wave_min_i32(has ? bfirst[j] : INT_MAX), kmax = wave_max_i32(has ? blast[j] : -1);
+  int lo = INT_MAX, hi = -1;
+  for (int k = kmin + lane; k <= kmax; k += WAVE) {
+    const int c0 = cmin[k], c1 = cmax[k];
+    if (c1 >= c0) {
+      lo = min(lo, c0);
+      hi = max(hi, c1 + 1);
     }
   }
+  lo = wave_min_i32(lo);
+  hi = wave_max_i32(hi);
+  if (lane != 0) return;
   const int w = (hi > lo) ? hi - lo : 0;
   const int kn = (w > 0 && kmax >= kmin) ? kmax - kmin + 1 : 0;
   blk_lo[b] = w > 0 ? lo : 0;
   blk_w[b] = w;
   blk_kmin[b] = kn > 0 ? kmin : 0;
   blk_kn[b] = kn;
-  bsz[b] = (int64_t)((kn + 1) & ~1) * J;  // an all-zero row pads odd k ranges (two steps per loop trip)
+  bsz[b] = (int64_t)((kn + 1) & ~1) * J;  // an all-zero row pads odd k ranges
   tsz[b] = (int64_t)w * J;
-  atomicMax(&stats[16], (unsigned long long)w);
-  atomicMax(&stats[17], (unsigned long long)kn);
 }
 
 // B tile of a block: bblk[boff + (k - kmin) * J + jj] = B(k, b*J + jj), zeros elsewhere.  Staged through LDS
@@ -1378,7 +1409,9 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
                                                        const int32_t* __restrict__ blk_kn,
                                                        const int64_t* __restrict__ blk_boff, double* __restrict__ bblk,
                                                        int nblocks, int pitch, int fuse_a,
-                                                       const int64_t* __restrict__ aeoff, double* __restrict__ aexp) {
+                                                       const int64_t* __restrict__ aeoff, double* __restrict__ aexp,
+                                                       const int32_t* __restrict__ clen,
+                                                       int64_t* __restrict__ blk_prod) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* tile = reinterpret_cast<double*>(smem);  // [J][pitch]
   const int b = xcd_block(nblocks);
@@ -1406,6 +1439,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
   for (int jj = 0; jj < J; ++jj)
     for (int i = threadIdx.x; i < kne; i += blockDim.x) tile[jj * pitch + i] = 0.0;
   __syncthreads();
+  long long nprod = 0;  // products of this wave's columns: sum over their entries of nnz(A(:, row))
 #pragma unroll
   for (int q = 0; q < NCOL; ++q) {
     const int jj = wave + 4 * q;
@@ -1423,6 +1457,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
       int prev = __shfl_up(r, 1, WAVE);
       if (lane == 0) prev = carry;
       if (p < e) {
+        nprod += clen[r];
         if (tiled) tile[jj * pitch + (r - kmin)] = val[q][c];
         if (fuse_a) {
           dst[r] = val[q][c];
@@ -1434,6 +1469,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
     for (int64_t p = s + CH * WAVE + lane; p < e; p += WAVE) {
       const int r = B.inner[p];
       const double v = Bv[p];
+      nprod += clen[r];
       if (tiled) tile[jj * pitch + (r - kmin)] = v;
       if (fuse_a) {
         const int prev = B.inner[p - 1];
@@ -1442,7 +1478,11 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
       }
     }
   }
+  nprod = wave_sum_i64(nprod);
+  __shared__ long long sprod[4];
+  if (lane == 0) sprod[wave] = nprod;
   __syncthreads();
+  if (threadIdx.x == 0) blk_prod[b] = sprod[0] + sprod[1] + sprod[2] + sprod[3];
   double* __restrict__ out = bblk + blk_boff[b];
   const int total = kne * J;
   for (int i = threadIdx.x; i < total; i += blockDim.x) out[i] = tile[(i % J) * pitch + (i / J)];
@@ -2413,6 +2453,49 @@ void reduce_sum2_async(const double* part, int n, double* out_dev) {
 }
 }  // namespace
 
+namespace {
+struct FetchArgs {
+  const unsigned long long* src[8];
+  int words[8];
+  int n;
+};
+__global__ __launch_bounds__(64) void k_fetch(FetchArgs a, unsigned long long* __restrict__ host_mapped) {
+  int off = 0;
+  for (int s = 0; s < a.n; ++s) {
+    for (int i = threadIdx.x; i < a.words[s]; i += 64) host_mapped[off + i] = a.src[s][i];
+    off += a.words[s];
+  }
+  __threadfence_system();
+}
+}  // namespace
+
+void ScalarFetch::run() {
+  static unsigned long long* host = nullptr;
+  static unsigned long long* dev = nullptr;
+  constexpr int kMaxWords = 512;
+  if (!host) {
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host), kMaxWords * 8, hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0));
+  }
+  FetchArgs a;
+  a.n = n;
+  int total = 0;
+  for (int s = 0; s < n; ++s) {
+    a.src[s] = static_cast<const unsigned long long*>(src[s]);
+    a.words[s] = words[s];
+    total += words[s];
+  }
+  if (total > kMaxWords) NTP_FATAL("ScalarFetch: too many words");
+  if (total) hipLaunchKernelGGL(k_fetch, dim3(1), dim3(64), 0, stream(), a, dev);
+  sync_stream();
+  int off = 0;
+  for (int s = 0; s < n; ++s) {
+    std::memcpy(dst[s], host + off, (size_t)words[s] * 8);
+    off += words[s];
+  }
+  n = 0;
+}
+
 int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n) {
   scan_async<int64_t>(d_in, d_out, n);
   int64_t total = 0;
@@ -2519,19 +2602,17 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   t_all.start();
   DevBuf<int32_t> cmin(A.cols), cmax(A.cols), clen(A.cols);
   hipLaunchKernelGGL(k_col_extent, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), view(A), cmin.p, cmax.p, clen.p);
-  DevBuf<int32_t> lo(n), span(n), count(n);
-  DevBuf<uint8_t> bin(n);
-  DevBuf<int64_t> ub(n + 1), ip(n), tmpoff(n + 1);
+  DevBuf<int32_t> lo, span, count(n);
+  DevBuf<uint8_t> bin;
+  DevBuf<int64_t> ub, ip, tmpoff(n + 1);
   DevBuf<unsigned long long> stats(24);
   stats.zero();
   count.zero();
-  hipLaunchKernelGGL(k_spgemm_plan, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(B), cmin.p,
-                     cmax.p, clen.p, lo.p, span.p, bin.p, ub.p, ip.p, stats.p, options().spgemm_force_bin);
-  if (!A.cplx && options().spgemm_force_bin <= 0)
-    hipLaunchKernelGGL(k_pair_bins, dim3(cdiv((n + 1) / 2, 256)), dim3(256), 0, stream(), bin.p, n);
-  hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, ip.p, span.p, n, stats.p);
-  scan_async<int64_t>(ub.p, tmpoff.p, (int64_t)n);
-  // candidate for the register-slab kernel (real operands, run-like columns): plan it alongside
+  unsigned long long hstats[24] = {0};
+  int64_t tmp_total = 0;
+
+  // ---- candidate for the register-slab kernel (real operands, run-like columns): its plan needs only the column
+  // extents, so the per-column walk over B (k_spgemm_plan) is skipped when the slab kernel is taken
   constexpr int SJ = SLAB_J;
   const int sv_opt = options().spgemm_variant;
   const bool slab_try = !A.cplx && options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4) &&
@@ -2541,6 +2622,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<int64_t> aeoff, bsz, tsz, blk_boff, blk_toff;
   DevBuf<char> runs;
   int64_t slab_tot[3] = {0, 0, 0};
+  bool use_slab = false;
   if (slab_try) {
     const int32_t *bfirst = cmin.p, *blast = cmax.p;
     if (&A != &B) {
@@ -2549,26 +2631,22 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       bfirst = bfirst_own.p; blast = blast_own.p;
     }
     aspan.alloc(A.cols); aeoff.alloc((size_t)A.cols + 1);
-    hipLaunchKernelGGL(k_span_of, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aspan.p, A.cols, stats.p);
+    hipLaunchKernelGGL(k_span_of, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aspan.p, A.cols);
     scan_async<int32_t>(aspan.p, aeoff.p, (int64_t)A.cols);
     blk_lo.alloc(snb); blk_w.alloc(snb); blk_kmin.alloc(snb); blk_kn.alloc(snb);
     bsz.alloc(snb); tsz.alloc(snb); blk_boff.alloc((size_t)snb + 1); blk_toff.alloc((size_t)snb + 1);
-    hipLaunchKernelGGL((k_slab_plan<SJ>), dim3(cdiv(snb, 256)), dim3(256), 0, stream(), n, lo.p, span.p, bfirst, blast,
-                       blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, stats.p, snb);
+    hipLaunchKernelGGL((k_slab_plan<SJ>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst, blast, cmin.p,
+                       cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(1), dim3(1024), 0, stream(), blk_w.p, blk_kn.p, snb, aspan.p, A.cols, stats.p);
     scan_async<int64_t>(bsz.p, blk_boff.p, (int64_t)snb);
     scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
-    HIP_CHECK(hipMemcpyAsync(&slab_tot[0], aeoff.p + A.cols, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
-    HIP_CHECK(hipMemcpyAsync(&slab_tot[1], blk_boff.p + snb, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
-    HIP_CHECK(hipMemcpyAsync(&slab_tot[2], blk_toff.p + snb, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
-  }
-  unsigned long long hstats[24];
-  int64_t tmp_total = 0;
-  HIP_CHECK(hipMemcpyAsync(hstats, stats.p, sizeof(hstats), hipMemcpyDeviceToHost, stream()));
-  HIP_CHECK(hipMemcpyAsync(&tmp_total, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
-  sync_stream();
-  // use it when the window fits the register slabs and the zero padding stays small
-  bool use_slab = false;
-  if (slab_try) {
+    ScalarFetch f;
+    f.add(aeoff.p + A.cols, 1, &slab_tot[0]);
+    f.add(blk_boff.p + snb, 1, &slab_tot[1]);
+    f.add(blk_toff.p + snb, 1, &slab_tot[2]);
+    f.add(stats.p, 24, hstats);
+    f.run();
+    // use it when the window fits the register slabs and the zero padding stays small
     const int64_t max_w = (int64_t)hstats[16], max_kn = (int64_t)hstats[17];
     const bool fits = max_w > 0 && max_w <= SLAB_NW * SLAB_SL * WAVE && ((max_kn + 1) | 1) * SJ * 8 <= 64 * 1024;
     const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
@@ -2579,10 +2657,23 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   if (use_slab) {
     tmp_total = slab_tot[2];
     hipLaunchKernelGGL((k_slab_tmpoff<SJ>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
+  } else {
+    // ---- general plan: per output column its row window, product count, upper bound and kernel bin
+    lo.alloc(n); span.alloc(n); bin.alloc(n); ub.alloc((size_t)n + 1); ip.alloc(n);
+    hipLaunchKernelGGL(k_spgemm_plan, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(B), cmin.p,
+                       cmax.p, clen.p, lo.p, span.p, bin.p, ub.p, ip.p, stats.p, options().spgemm_force_bin);
+    if (!A.cplx && options().spgemm_force_bin <= 0)
+      hipLaunchKernelGGL(k_pair_bins, dim3(cdiv((n + 1) / 2, 256)), dim3(256), 0, stream(), bin.p, n);
+    hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, ip.p, span.p, n, stats.p);
+    scan_async<int64_t>(ub.p, tmpoff.p, (int64_t)n);
+    ScalarFetch f;
+    f.add(stats.p, 24, hstats);
+    f.add(tmpoff.p + n, 1, &tmp_total);
+    f.run();
+    for (int i = 0; i < 6; ++i) st.bin_cols[i] = (int64_t)hstats[i];
+    st.bin_cols[5] += (int64_t)hstats[6];
+    st.products = (int64_t)hstats[7];
   }
-  for (int i = 0; i < 6; ++i) st.bin_cols[i] = (int64_t)hstats[i];
-  st.bin_cols[5] += (int64_t)hstats[6];
-  st.products = (int64_t)hstats[7];
   st.tmp_entries = tmp_total;
 
   DevBuf<int32_t> tmp_inner((size_t)tmp_total);
@@ -2592,7 +2683,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<int64_t> tmpoff2;
   const int dr = dense_rule ? 1 : 0;
   DevBuf<double> aexp, bblk;
+  DevBuf<int64_t> blk_prod, blk_prod_scan;
   if (use_slab) {
+    blk_prod.alloc(snb); blk_prod.zero(); blk_prod_scan.alloc((size_t)snb + 1);
     aexp.alloc((size_t)slab_tot[0] + 1);
     bblk.alloc((size_t)slab_tot[1] + 16 * SJ);  // slack: the loop prefetches a few rows past the last tile
     const bool same = (&A == &B);
@@ -2604,7 +2697,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                        reinterpret_cast<SlabRun*>(runs.p), A.cols);
     const int pitch = ((int)hstats[17] + 1) | 1;
     hipLaunchKernelGGL((k_slab_expand_b<SJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * 8, stream(), view(B),
-                       blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p, aexp.p);
+                       blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p, aexp.p, clen.p, blk_prod.p);
+    scan_async<int64_t>(blk_prod.p, blk_prod_scan.p, (int64_t)snb);  // total = products of this multiply
   }
   t_num.start();
   if (use_slab) {
@@ -2765,8 +2859,14 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   C.outer.alloc((size_t)n + 1);
   scan_async<int32_t>(count.p, C.outer.p, (int64_t)n);
   int64_t nnz = 0;
-  HIP_CHECK(hipMemcpyAsync(&nnz, C.outer.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
-  sync_stream();
+  unsigned long long slab_products = 0;
+  {
+    ScalarFetch f;
+    f.add(C.outer.p + n, 1, &nnz);
+    if (use_slab) f.add(blk_prod_scan.p + snb, 1, &slab_products);
+    f.run();
+  }
+  if (use_slab) st.products = (int64_t)slab_products;
   C.nnz = nnz;
   C.inner.alloc((size_t)nnz + kIndexSlack);
   C.val.alloc(((size_t)nnz + kIndexSlack) * C.wval());
@@ -2819,8 +2919,11 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
   hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, (const int64_t*)nullptr,
                      (const int32_t*)nullptr, n, stats.p);
   unsigned long long hs[16];
-  HIP_CHECK(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, stream()));
-  sync_stream();
+  {
+    ScalarFetch f;
+    f.add(stats.p, 16, hs);
+    f.run();
+  }
   const int64_t cap = A.nnz + B.nnz;
   DevBuf<int32_t> tmp_inner((size_t)cap);
   DevBuf<double> tmp_val((size_t)cap * A.wval());
@@ -2873,9 +2976,12 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
   scan_async<int32_t>(count.p, R.outer.p, (int64_t)n);
   int64_t nnz = 0;
   double hd[4] = {0, 0, 0, 0};
-  HIP_CHECK(hipMemcpyAsync(&nnz, R.outer.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
-  if (fuse_dot) HIP_CHECK(hipMemcpyAsync(hd, dres.p, sizeof(hd), hipMemcpyDeviceToHost, stream()));
-  sync_stream();
+  {
+    ScalarFetch f;
+    f.add(R.outer.p + n, 1, &nnz);
+    if (fuse_dot) f.add(dres.p, 4, hd);
+    f.run();
+  }
   R.nnz = nnz;
   R.inner.alloc((size_t)nnz + kIndexSlack);
   R.val.alloc(((size_t)nnz + kIndexSlack) * R.wval());
