@@ -33,11 +33,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def trs2_step(nt, X, X2, WH, pool, trace_target, thr):
+def trs2_step(nt, X, X2, WH, pool, trace_target, thr, trace_x=None):
     """one iteration of DensityMatrixSolversModule.F90:380-413, exactly the body TRS2_wrp loops over
-    (ntpoly_amd_trs2_step = csrc/solvers.cpp trs2_step: trace -> sigma, X2 = X*X, fused update + energy);
-    returns (sigma, energy)"""
-    return nt.trs2_step(X, X2, WH, trace_target, thr)
+    (ntpoly_amd_trs2_step = csrc/solvers.cpp trs2_step: trace -> sigma, X2 = X*X, fused update + energy + trace of the
+    new iterate, which the solver loop hands to the next iteration); returns (sigma, energy, trace of the new X)"""
+    return nt.trs2_step(X, X2, WH, trace_target, thr, trace_x)
 
 
 def trs2_step_unfused(nt, X, X2, WH, pool, trace_target, thr):
@@ -133,15 +133,15 @@ def main():
             dist.barrier()
             nt.synchronize()
 
-    energy = 0.0
+    energy, tr_x = 0.0, None
     for _ in range(args.warmup):
-        _, energy = trs2_step(nt, X, X2, H, pool, trace_target, thr)
+        _, energy, tr_x = trs2_step(nt, X, X2, H, pool, trace_target, thr, tr_x)
     nt.reset_spgemm_accum()
     fence()
     t0 = time.perf_counter()
     nnz_trace = []
     for _ in range(args.steps):
-        _, energy = trs2_step(nt, X, X2, H, pool, trace_target, thr)
+        _, energy, tr_x = trs2_step(nt, X, X2, H, pool, trace_target, thr, tr_x)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:

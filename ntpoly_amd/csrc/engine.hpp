@@ -79,7 +79,9 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
 void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold);
 void ps_scale(PSMatrix& A, double c);
 // B <- alpha*A + beta*B with the increment rules and, fused, out = dot(B_new, D) (TRS2 update + energy)
-void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[2]);
+void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[4],
+                  bool want_trace = false);  // out[2] = trace(B_new) on request
+void ps_dot_trace(const PSMatrix& A, const PSMatrix& B, double out[4], bool want_trace);
 void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C);
 void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]);
 double ps_trace(const PSMatrix& A);
@@ -154,7 +156,8 @@ struct SolverTrace {
 };
 SolverTrace& last_trace();
 // one TRS2 iteration (DensityMatrixSolversModule.F90:380-404): returns the energy, sets sigma
-double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_target, double threshold, double* sigma);
+double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_target, double threshold, double* sigma,
+                 double* trace_io = nullptr);
 
 // ------------------------------------------------------------------ solvers
 void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy, double* mu,

@@ -297,18 +297,20 @@ __global__ void k_span_of(const int32_t* __restrict__ cmin, const int32_t* __res
   if (k < n) span[k] = cmax[k] >= cmin[k] ? cmax[k] - cmin[k] + 1 : 0;
 }
 
-// one block: stats[16] = max window rows, stats[17] = max k range over the column blocks, stats[18] = number of
-// non-empty columns of A (same-address atomics from every block of the plan kernels cost more than this pass)
-__global__ __launch_bounds__(1024) void k_slab_reduce(const int32_t* __restrict__ blk_w, const int32_t* __restrict__ blk_kn,
-                                                      int nblocks, const int32_t* __restrict__ aspan, int acols,
-                                                      unsigned long long* __restrict__ stats) {
-  __shared__ int sw[16], sk[16], sn[16];
+// stats[16] = max window rows, stats[17] = max k range over the column blocks, stats[18] = number of non-empty
+// columns of A: a few blocks, one atomic per block and statistic (same-address atomics from every block of the
+// plan kernels would cost more than this pass)
+__global__ __launch_bounds__(256) void k_slab_reduce(const int32_t* __restrict__ blk_w, const int32_t* __restrict__ blk_kn,
+                                                     int nblocks, const int32_t* __restrict__ aspan, int acols,
+                                                     unsigned long long* __restrict__ stats) {
+  __shared__ int sw[4], sk[4], sn[4];
   int w = 0, kn = 0, ne = 0;
-  for (int i = threadIdx.x; i < nblocks; i += 1024) {
+  const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = t0; i < nblocks; i += stride) {
     w = max(w, blk_w[i]);
     kn = max(kn, blk_kn[i]);
   }
-  for (int i = threadIdx.x; i < acols; i += 1024) ne += aspan[i] > 0 ? 1 : 0;
+  for (int i = t0; i < acols; i += stride) ne += aspan[i] > 0 ? 1 : 0;
   w = wave_max_i32(w);
   kn = wave_max_i32(kn);
   for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o, WAVE);
@@ -319,14 +321,9 @@ __global__ __launch_bounds__(1024) void k_slab_reduce(const int32_t* __restrict_
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < 16; ++i) {
-      sw[0] = max(sw[0], sw[i]);
-      sk[0] = max(sk[0], sk[i]);
-      sn[0] += sn[i];
-    }
-    stats[16] = (unsigned long long)sw[0];
-    stats[17] = (unsigned long long)sk[0];
-    stats[18] = (unsigned long long)sn[0];
+    atomicMax(&stats[16], (unsigned long long)max(max(sw[0], sw[1]), max(sw[2], sw[3])));
+    atomicMax(&stats[17], (unsigned long long)max(max(sk[0], sk[1]), max(sk[2], sk[3])));
+    atomicAdd(&stats[18], (unsigned long long)(sn[0] + sn[1] + sn[2] + sn[3]));
   }
 }
 
@@ -1921,7 +1918,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
     Csc A, Csc B, Csc D, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
     const uint8_t* __restrict__ bin_arr, int my_bin, int32_t* __restrict__ out_inner,
     T* __restrict__ out_val, int32_t* __restrict__ count, double alpha, double beta, double threshold,
-    double* __restrict__ dot_partial, int nblocks) {
+    double* __restrict__ dot_partial, int nblocks, double* __restrict__ trace_partial, int col_offset) {
   __shared__ T wa_all[NW * W];
   __shared__ T wb_all[NW * W];
   __shared__ T wd_all[DOT ? NW * W : 1];
@@ -1931,7 +1928,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
   if (b < 0) return;
   const int wave = threadIdx.x / WAVE, lane = lane_id();
   const int j = b * NW + wave;
-  double dx = 0.0, dy = 0.0;
+  double dx = 0.0, dy = 0.0, dt = 0.0;
   const bool mine = (j < A.cols) && (bin_arr[j < A.cols ? j : 0] == my_bin);
   if (mine) {
     T* wa = wa_all + wave * W;
@@ -2024,6 +2021,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
         out_inner[pos] = lo + s;
         out_val[pos] = v;
         if constexpr (DOT) {
+          if (lo + s == col_offset + j) dt = Sc<T>::re(v);  // diagonal entry of the result (at most one per column)
           if (f & 4) {
             if constexpr (Sc<T>::cplx) {
               const double2 pr = Sc<double2>::mul(Sc<double2>::conj(v), wd[s]);
@@ -2055,6 +2053,18 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
       }
       dot_partial[2 * b] = sx;
       dot_partial[2 * b + 1] = sy;
+    }
+    if (trace_partial) {  // block-uniform
+      dt = wave_sum_f64(dt);
+      __syncthreads();
+      if (lane == 0) red[wave] = dt;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double st = 0.0;
+        for (int w = 0; w < NW; ++w) st = __dadd_rn(st, red[w]);
+        trace_partial[2 * b] = st;
+        trace_partial[2 * b + 1] = 0.0;
+      }
     }
   }
 }
@@ -2106,7 +2116,8 @@ __global__ void k_sum_outer(const int64_t* __restrict__ a, const int64_t* __rest
 // sum conj(A) .* B: column j of B is scattered into a direct-mapped LDS window over its row range (like the
 // SpGEMM / increment windows), column j of A probes it.  Columns of B wider than the window use a binary search.
 template <typename T>
-__global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ partial, int nblocks) {
+__global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ partial, int nblocks,
+                                             double* __restrict__ trace_partial, int col_offset) {
   constexpr int W = 1024, CH = 5;
   __shared__ T win_all[4 * W];
   __shared__ uint8_t fl_all[4 * W];
@@ -2117,7 +2128,7 @@ __global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ 
   uint8_t* fl = fl_all + wave * W;
   const T* __restrict__ Av = static_cast<const T*>(A.val);
   const T* __restrict__ Bv = static_cast<const T*>(B.val);
-  double x = 0, y = 0;
+  double x = 0, y = 0, tr = 0;  // tr: trace of A (diagonal = row col_offset + j of column j), on request
   auto accum = [&](T a, T bval) {
     if constexpr (Sc<T>::cplx) {
       const double2 pr = Sc<double2>::mul(Sc<double2>::conj(a), bval);
@@ -2129,7 +2140,7 @@ __global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ 
   };
   for (int j = b * 4 + wave; j < A.cols; j += nblocks * 4) {
     const int64_t bs = B.outer[j], be = B.outer[j + 1], as = A.outer[j], ae = A.outer[j + 1];
-    if (be == bs || ae == as) continue;
+    if (ae == as || (be == bs && !trace_partial)) continue;
     int ai[CH], bi[CH];
     T av[CH], bv[CH];
 #pragma unroll
@@ -2158,11 +2169,14 @@ __global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ 
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const int s = ai[c] - lo;
-        if (as + c * WAVE + lane < ae && s >= 0 && s < span && fl[s]) accum(av[c], win[s]);
+        const bool valid = as + c * WAVE + lane < ae;
+        if (valid && s >= 0 && s < span && fl[s]) accum(av[c], win[s]);
+        if (valid && ai[c] == col_offset + j) tr = __dadd_rn(tr, Sc<T>::re(av[c]));
       }
       for (int64_t p = as + CH * WAVE + lane; p < ae; p += WAVE) {
         const int s = A.inner[p] - lo;
         if (s >= 0 && s < span && fl[s]) accum(Av[p], win[s]);
+        if (A.inner[p] == col_offset + j) tr = __dadd_rn(tr, Sc<T>::re(Av[p]));
       }
       __builtin_amdgcn_wave_barrier();
     } else {
@@ -2174,16 +2188,27 @@ __global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ 
           if (B.inner[mid] < r) l = mid + 1; else h = mid;
         }
         if (l < be && B.inner[l] == r) accum(Av[p], Bv[l]);
+        if (r == col_offset + j) tr = __dadd_rn(tr, Sc<T>::re(Av[p]));
       }
     }
   }
   x = wave_sum_f64(x);
   y = wave_sum_f64(y);
+  tr = wave_sum_f64(tr);
   if (lane == 0) { sx[wave] = x; sy[wave] = y; }
   __syncthreads();
   if (threadIdx.x == 0) {
     partial[2 * b] = __dadd_rn(__dadd_rn(sx[0], sx[1]), __dadd_rn(sx[2], sx[3]));
     partial[2 * b + 1] = __dadd_rn(__dadd_rn(sy[0], sy[1]), __dadd_rn(sy[2], sy[3]));
+  }
+  if (trace_partial) {
+    __syncthreads();
+    if (lane == 0) sx[wave] = tr;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      trace_partial[2 * b] = __dadd_rn(__dadd_rn(sx[0], sx[1]), __dadd_rn(sx[2], sx[3]));
+      trace_partial[2 * b + 1] = 0.0;
+    }
   }
 }
 
@@ -2505,32 +2530,66 @@ int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n) {
 }
 
 namespace {
+// Kernel timing with HIP events on the engine's stream (option time_kernels).  The events of a multiply are only
+// recorded; they are resolved (hipEventElapsedTime) when the statistics are read, so timing adds no
+// synchronisation to the measured region.
+struct TimedCall {
+  hipEvent_t ev[4];  // total start/stop, numeric start/stop
+};
+std::vector<hipEvent_t>& event_pool() {
+  static auto* p = new std::vector<hipEvent_t>();
+  return *p;
+}
+std::vector<TimedCall>& pending_timings() {
+  static auto* p = new std::vector<TimedCall>();
+  return *p;
+}
+hipEvent_t get_event() {
+  auto& pool = event_pool();
+  if (!pool.empty()) {
+    hipEvent_t e = pool.back();
+    pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
 struct EventTimer {
   hipEvent_t a = nullptr, b = nullptr;
   bool on;
   explicit EventTimer(bool enable) : on(enable) {
     if (on) {
-      HIP_CHECK(hipEventCreate(&a));
-      HIP_CHECK(hipEventCreate(&b));
+      a = get_event();
+      b = get_event();
     }
   }
   void start() { if (on) HIP_CHECK(hipEventRecord(a, stream())); }
   void stop() { if (on) HIP_CHECK(hipEventRecord(b, stream())); }
-  float ms() {
-    if (!on) return 0.f;
-    float t = 0.f;
-    HIP_CHECK(hipEventSynchronize(b));
-    HIP_CHECK(hipEventElapsedTime(&t, a, b));
-    return t;
-  }
-  ~EventTimer() {
-    if (on) {
-      (void)hipEventDestroy(a);
-      (void)hipEventDestroy(b);
-    }
-  }
 };
+}  // namespace
 
+void flush_spgemm_timers() {
+  auto& pend = pending_timings();
+  if (pend.empty()) return;
+  SpgemmAccum& acc = spgemm_accum();
+  for (size_t i = 0; i < pend.size(); ++i) {
+    float t_all = 0.f, t_num = 0.f;
+    HIP_CHECK(hipEventSynchronize(pend[i].ev[1]));
+    HIP_CHECK(hipEventElapsedTime(&t_all, pend[i].ev[0], pend[i].ev[1]));
+    HIP_CHECK(hipEventElapsedTime(&t_num, pend[i].ev[2], pend[i].ev[3]));
+    acc.ms_total += t_all;
+    acc.ms_numeric += t_num;
+    if (i + 1 == pend.size()) {
+      last_spgemm_stats().ms_total = t_all;
+      last_spgemm_stats().ms_numeric = t_num;
+    }
+    for (int k = 0; k < 4; ++k) event_pool().push_back(pend[i].ev[k]);
+  }
+  pend.clear();
+}
+
+namespace {
 template <typename T, int R, int D, int ABL = 0>
 void launch_mc(int bin, int wrt, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
                const uint8_t* binarr, const int64_t* tmpoff, int32_t* out_inner, T* out_val, int32_t* count,
@@ -2637,7 +2696,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     bsz.alloc(snb); tsz.alloc(snb); blk_boff.alloc((size_t)snb + 1); blk_toff.alloc((size_t)snb + 1);
     hipLaunchKernelGGL((k_slab_plan<SJ>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst, blast, cmin.p,
                        cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
-    hipLaunchKernelGGL(k_slab_reduce, dim3(1), dim3(1024), 0, stream(), blk_w.p, blk_kn.p, snb, aspan.p, A.cols, stats.p);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, aspan.p, A.cols, stats.p);
     scan_async<int64_t>(bsz.p, blk_boff.p, (int64_t)snb);
     scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
     ScalarFetch f;
@@ -2881,8 +2940,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   t_all.stop();
   st.nnz_c = nnz;
   if (timing) {
-    st.ms_numeric = t_num.ms();
-    st.ms_total = t_all.ms();
+    if (pending_timings().size() >= 4096) flush_spgemm_timers();
+    pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
   }
   last_spgemm_stats() = st;
   SpgemmAccum& acc = spgemm_accum();
@@ -2891,17 +2950,15 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   acc.nnz_c += nnz;
   const double per = A.cplx ? 20.0 : 12.0;
   acc.alg_bytes += per * (double)(A.nnz + B.nnz + nnz) + 4.0 * ((double)A.cols + B.cols + n + 3);
-  acc.ms_numeric += st.ms_numeric;
-  acc.ms_total += st.ms_total;
-  if (timing) sync_stream();
 }
 
 // -------------------------------------------------------------------------------------
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold) {
-  axpby(A, B, alpha, 1.0, threshold, nullptr, nullptr);
+  axpby(A, B, alpha, 1.0, threshold, nullptr, nullptr, nullptr, 0);
 }
 
-void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out) {
+void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
+           double* trace_out, int32_t trace_col_offset) {
   if (A.rows != B.rows || A.cols != B.cols) NTP_FATAL("increment: shape mismatch");
   if (A.cplx != B.cplx) NTP_FATAL("increment: mixed scalar types must be up-cast by the caller");
   if (D && (D->rows != A.rows || D->cols != A.cols || D->cplx != A.cplx)) NTP_FATAL("increment: dot operand mismatch");
@@ -2931,10 +2988,15 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
   hipLaunchKernelGGL(k_sum_outer, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), A.outer.p, B.outer.p, srcoff.p, n);
   const bool fuse_dot = D != nullptr && dot_out != nullptr && hs[3] == 0;
   const int nb1 = cdiv(n, 4), nb2 = n;
-  DevBuf<double> part1, part2;
+  DevBuf<double> part1, part2, tpart1, tpart2;
+  const bool fuse_trace = fuse_dot && trace_out != nullptr;
   if (fuse_dot) {
     if (hs[1]) { part1.alloc((size_t)2 * nb1); part1.zero(); }
     if (hs[2]) { part2.alloc((size_t)2 * nb2); part2.zero(); }
+    if (fuse_trace) {
+      if (hs[1]) { tpart1.alloc((size_t)2 * nb1); tpart1.zero(); }
+      if (hs[2]) { tpart2.alloc((size_t)2 * nb2); tpart2.zero(); }
+    }
   }
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
@@ -2943,18 +3005,18 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
     if (hs[1]) {
       if (fuse_dot)
         hipLaunchKernelGGL((k_inc_window<T, 512, 4, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), view(A), view(B), dv,
-                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, part1.p, nb1);
+                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, part1.p, nb1, tpart1.p, trace_col_offset);
       else
         hipLaunchKernelGGL((k_inc_window<T, 512, 4, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), view(A), view(B), dv,
-                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1);
+                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1, (double*)nullptr, 0);
     }
     if (hs[2]) {
       if (fuse_dot)
         hipLaunchKernelGGL((k_inc_window<T, 2048, 1, true>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), view(A), view(B), dv,
-                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, part2.p, nb2);
+                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, part2.p, nb2, tpart2.p, trace_col_offset);
       else
         hipLaunchKernelGGL((k_inc_window<T, 2048, 1, false>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), view(A), view(B), dv,
-                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb2);
+                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb2, (double*)nullptr, 0);
     }
     if (hs[3]) {
       hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), view(A), view(B), bin.p, 3,
@@ -2963,10 +3025,12 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
   });
   DevBuf<double> dres;
   if (fuse_dot) {
-    dres.alloc(4);
+    dres.alloc(8);
     dres.zero();
     if (hs[1]) reduce_sum2_async(part1.p, nb1, dres.p);
     if (hs[2]) reduce_sum2_async(part2.p, nb2, dres.p + 2);
+    if (fuse_trace && hs[1]) reduce_sum2_async(tpart1.p, nb1, dres.p + 4);
+    if (fuse_trace && hs[2]) reduce_sum2_async(tpart2.p, nb2, dres.p + 6);
   }
   DevMat R;
   R.rows = A.rows;
@@ -2975,11 +3039,11 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
   R.outer.alloc((size_t)n + 1);
   scan_async<int32_t>(count.p, R.outer.p, (int64_t)n);
   int64_t nnz = 0;
-  double hd[4] = {0, 0, 0, 0};
+  double hd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   {
     ScalarFetch f;
     f.add(R.outer.p + n, 1, &nnz);
-    if (fuse_dot) f.add(dres.p, 4, hd);
+    if (fuse_dot) f.add(dres.p, 8, hd);
     f.run();
   }
   R.nnz = nnz;
@@ -3001,6 +3065,7 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
       dot(B, *D, dot_out);
     }
   }
+  if (trace_out) *trace_out = fuse_trace ? hd[4] + hd[6] : trace(B, trace_col_offset);
 }
 
 void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a) {
@@ -3040,17 +3105,35 @@ void finish_sum2(DevBuf<double>& partial, int nb, double out[2]) {
 }
 }  // namespace
 
-void dot(const DevMat& A, const DevMat& B, double out[2]) {
+void dot(const DevMat& A, const DevMat& B, double out[2]) { dot_trace(A, B, out, nullptr, 0); }
+
+void dot_trace(const DevMat& A, const DevMat& B, double out[2], double* trace_out, int32_t col_offset) {
   if (A.rows != B.rows || A.cols != B.cols || A.cplx != B.cplx) NTP_FATAL("dot: operand mismatch");
   out[0] = out[1] = 0;
-  if (A.nnz == 0 || B.nnz == 0) return;
+  if (trace_out) *trace_out = 0.0;
+  if (A.nnz == 0) return;
+  if (B.nnz == 0) {
+    if (trace_out) *trace_out = trace(A, col_offset);
+    return;
+  }
   const int nb = std::min(cdiv(A.cols, 4), 8192);
-  DevBuf<double> partial((size_t)2 * nb);
+  DevBuf<double> partial((size_t)2 * nb), tpartial;
+  if (trace_out) tpartial.alloc((size_t)2 * nb);
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(256), 0, stream(), view(A), view(B), partial.p, nb);
+    hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(256), 0, stream(), view(A), view(B), partial.p, nb,
+                       trace_out ? tpartial.p : (double*)nullptr, col_offset);
   });
-  finish_sum2(partial, nb, out);
+  DevBuf<double> res(4);
+  reduce_sum2_async(partial.p, nb, res.p);
+  if (trace_out) reduce_sum2_async(tpartial.p, nb, res.p + 2);
+  double h[4] = {0, 0, 0, 0};
+  ScalarFetch f;
+  f.add(res.p, trace_out ? 4 : 2, h);
+  f.run();
+  out[0] = h[0];
+  out[1] = h[1];
+  if (trace_out) *trace_out = h[2];
 }
 
 void grand_sum(const DevMat& A, double out[2]) {

@@ -32,6 +32,8 @@ SpgemmStats& last_spgemm_stats();
 // accumulated since reset: number of calls, products, algorithmic bytes, numeric-kernel ms
 struct SpgemmAccum { int64_t calls = 0, products = 0, nnz_c = 0; double alg_bytes = 0, ms_numeric = 0, ms_total = 0; };
 SpgemmAccum& spgemm_accum();
+// resolve the HIP events recorded by the timed multiplies since the last call (time_kernels option)
+void flush_spgemm_timers();
 
 // C = alpha * A * B with NTPoly's prune rule.  A: (m x k), B: (k x n), same scalar type.
 // dense_rule = the reference's dense-branch order (threshold before alpha, DenseBranch.f90:14-15).
@@ -42,11 +44,14 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold);
 // B <- alpha*A + beta*B (B scaled first, then the same rules); if D and dot_out are given, also
 // dot_out = sum conj(B_new) .* D, evaluated in the same pass
-void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out);
+void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
+           double* trace_out = nullptr, int32_t trace_col_offset = 0);  // trace_out: also trace(B_new), same pass
 // C = A .* B on the intersection of the patterns (conj_a: conjugate A first)
 void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a);
 // out = sum conj(A) .* B  (out[1] = imaginary part, 0 for real)
 void dot(const DevMat& A, const DevMat& B, double out[2]);
+// the same, plus trace(A) from the same pass (diagonal = row col_offset + j of local column j)
+void dot_trace(const DevMat& A, const DevMat& B, double out[2], double* trace_out, int32_t col_offset);
 void grand_sum(const DevMat& A, double out[2]);
 // sum of the real parts of entries with row == col + col_offset
 double trace(const DevMat& A, int32_t col_offset);

@@ -252,15 +252,30 @@ void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold
 
 void ps_scale(PSMatrix& A, double c) { scale(A.loc, c); }
 
-void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[2]) {
+void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[4],
+                  bool want_trace) {
+  out[2] = out[3] = 0.0;
   if (A.cplx != B.cplx || A.cplx != D.cplx || &A == &B) {  // mixed types: unfused sequence
     ps_scale(B, beta);
     ps_increment(A, B, alpha, threshold);
     ps_dot(B, D, out);
+    if (want_trace) out[2] = ps_trace(B);
     return;
   }
-  axpby(A.loc, B.loc, alpha, beta, threshold, &D.loc, out);
-  comm_allreduce_sum(out, 2);
+  axpby(A.loc, B.loc, alpha, beta, threshold, &D.loc, out, want_trace ? &out[2] : nullptr, B.c0);
+  comm_allreduce_sum(out, want_trace ? 3 : 2);
+}
+
+// dot(A, B) and trace(A) from one pass
+void ps_dot_trace(const PSMatrix& A, const PSMatrix& B, double out[4], bool want_trace) {
+  out[2] = out[3] = 0.0;
+  if (A.cplx != B.cplx) {
+    ps_dot(A, B, out);
+    if (want_trace) out[2] = ps_trace(A);
+    return;
+  }
+  dot_trace(A.loc, B.loc, out, want_trace ? &out[2] : nullptr, A.c0);
+  comm_allreduce_sum(out, want_trace ? 3 : 2);
 }
 
 void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {

@@ -226,17 +226,21 @@ void density_finish(PSMatrix& X, const PSMatrix& ISQT, const PSMatrix& ISQ, PSMa
 // One iteration of the TRS2 loop (DensityMatrixSolversModule.F90:380-404).  The update
 // "ScaleMatrix(X,2); IncrementMatrix(X2,X,-1,threshold); DotMatrix(X,WH)" runs as ONE pass over X, X2
 // and WH (same arithmetic: 2*x is exact, then the AddSparseVectors rules, then the energy).
-double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_target, double threshold, double* sigma) {
-  const double trace_value = ps_trace(X);
+double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_target, double threshold, double* sigma,
+                 double* trace_io) {
+  // trace_io (optional): in = trace(X) if the caller already has it (NaN: compute it), out = trace of the new X,
+  // accumulated in the pass that produces the energy -> one reduction + read-back less per iteration
+  const double trace_value = (trace_io && *trace_io == *trace_io) ? *trace_io : ps_trace(X);
   *sigma = (trace_target - trace_value < 0.0) ? -1.0 : 1.0;
   ps_multiply(X, X, X2, 1.0, 0.0, threshold);
-  double out[2];
+  double out[4] = {0, 0, 0, 0};
   if (*sigma > 0.0) {
-    ps_axpby_dot(X2, X, -1.0, 2.0, threshold, WH, out);
+    ps_axpby_dot(X2, X, -1.0, 2.0, threshold, WH, out, trace_io != nullptr);
   } else {
     std::swap(X.loc, X2.loc);  // X <- X2; X2 is scratch (recomputed by the next multiply), so no copy
-    ps_dot(X, WH, out);
+    ps_dot_trace(X, WH, out, trace_io != nullptr);
   }
+  if (trace_io) *trace_io = out[2];
   return out[0];
 }
 
@@ -262,10 +266,11 @@ void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
   last_trace().setup_ms = ms_since(t0);
   auto t1 = Clock::now();
   double energy_value = 0.0, energy_old;
+  double trace_x = std::nan("");  // trace of the current iterate, handed from step to step
   int II;
   for (II = 1; II <= p.max_iterations; ++II) {                     // :380-413
     energy_old = energy_value;
-    energy_value = trs2_step(X, X2, WH, trace, p.threshold, &sigma_array[(size_t)II]);
+    energy_value = trs2_step(X, X2, WH, trace, p.threshold, &sigma_array[(size_t)II], &trace_x);
     monitor_append(mon, energy_value - energy_old);
     trace_rec(energy_value - energy_old, energy_value, sigma_array[(size_t)II], X);
     if (monitor_converged(mon, p.be_verbose)) break;

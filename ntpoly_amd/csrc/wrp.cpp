@@ -82,6 +82,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used
 void ntpoly_amd_last_spgemm_stats(long long* out, float* ms_numeric, float* ms_total) {
+  flush_spgemm_timers();
   const SpgemmStats& s = last_spgemm_stats();
   out[0] = s.nnz_a; out[1] = s.nnz_b; out[2] = s.nnz_c; out[3] = s.products; out[4] = s.tmp_entries;
   for (int i = 0; i < 6; ++i) out[5 + i] = s.bin_cols[i];
@@ -90,9 +91,13 @@ void ntpoly_amd_last_spgemm_stats(long long* out, float* ms_numeric, float* ms_t
   *ms_numeric = s.ms_numeric;
   *ms_total = s.ms_total;
 }
-void ntpoly_amd_reset_spgemm_accum() { spgemm_accum() = SpgemmAccum(); }
+void ntpoly_amd_reset_spgemm_accum() {
+  flush_spgemm_timers();
+  spgemm_accum() = SpgemmAccum();
+}
 // out: calls, products, nnz_c ; dout: alg_bytes, ms_numeric, ms_total
 void ntpoly_amd_get_spgemm_accum(long long* out, double* dout) {
+  flush_spgemm_timers();
   const SpgemmAccum& a = spgemm_accum();
   out[0] = a.calls; out[1] = a.products; out[2] = a.nnz_c;
   dout[0] = a.alg_bytes; dout[1] = a.ms_numeric; dout[2] = a.ms_total;
@@ -565,9 +570,12 @@ void InverseSquareRoot_wrp(const int* ih_Input, int* ih_Output, const int* ih_so
 }
 // extension: one TRS2 iteration on caller-held matrices (what TRS2_wrp runs inside its loop); lets a
 // driver time exactly K iterations.  X and X2 must be constructed; returns energy and sigma.
+// trace_io: in = trace(X) when the caller has it from the previous step (NaN: computed here), out = trace of the new X
+// (accumulated in the pass that evaluates the energy), exactly what the solver loop hands from iteration to iteration.
 void ntpoly_amd_trs2_step(int* ih_X, int* ih_X2, const int* ih_WH, const double* trace, const double* threshold,
-                          double* energy_out, double* sigma_out) {
-  *energy_out = trs2_step(*get<PSMatrix>(ih_X), *get<PSMatrix>(ih_X2), *get<PSMatrix>(ih_WH), *trace, *threshold, sigma_out);
+                          double* energy_out, double* sigma_out, double* trace_io) {
+  *energy_out = trs2_step(*get<PSMatrix>(ih_X), *get<PSMatrix>(ih_X2), *get<PSMatrix>(ih_WH), *trace, *threshold, sigma_out,
+                          trace_io);
 }
 // extension: the reference's optional order_in argument (SquareRootSolversModule.F90:30-61) is not
 // reachable through its C ABI; expose it for tests

@@ -495,11 +495,13 @@ class DensityMatrixSolvers:
         return DensityMatrixSolvers._run(lib.HPCP_wrp, H, ISQ, trace, Density, solver_parameters)
 
 
-def trs2_step(X, X2, WH, trace, threshold):
-    """one TRS2 iteration (what TRS2_wrp runs inside its loop) -> (sigma, energy)"""
+def trs2_step(X, X2, WH, trace, threshold, trace_x=None):
+    """one TRS2 iteration (what TRS2_wrp runs inside its loop) -> (sigma, energy, trace of the new X);
+    trace_x = trace of X from the previous step's return value (None: computed)"""
     e, sg = C.c_double(), C.c_double()
-    lib.ntpoly_amd_trs2_step(X.ih, X2.ih, WH.ih, d(trace), d(threshold), C.byref(e), C.byref(sg))
-    return sg.value, e.value
+    tr = C.c_double(float("nan") if trace_x is None else trace_x)
+    lib.ntpoly_amd_trs2_step(X.ih, X2.ih, WH.ih, d(trace), d(threshold), C.byref(e), C.byref(sg), C.byref(tr))
+    return sg.value, e.value, tr.value
 
 
 class SignSolvers:

@@ -221,8 +221,9 @@ def test_fused_trs2_step_equals_call_sequence(nt, cplx, force_seq):
     pool = nt.PMatrixMemoryPool(H)
     nt.set_option("increment_force_seq", force_seq)
     try:
+        tra = None
         for it in range(6):
-            sa, ea = nt.trs2_step(Xa, X2a, H, n / 2.0, thr)
+            sa, ea, tra = nt.trs2_step(Xa, X2a, H, n / 2.0, thr, tra if it % 2 else None)  # handed over / recomputed
             tr = Xb.Trace()
             sb = -1.0 if (n / 2.0 - tr) < 0.0 else 1.0
             X2b.Gemm(Xb, Xb, pool, 1.0, 0.0, thr)
@@ -234,6 +235,7 @@ def test_fused_trs2_step_equals_call_sequence(nt, cplx, force_seq):
             eb = float(np.real(Xb.Dot(H)))
             assert sa == sb
             assert ea == pytest.approx(eb, rel=1e-12, abs=1e-12), it
+            assert tra == pytest.approx(Xb.Trace(), rel=1e-12, abs=1e-12), it
             ta, tb = Xa.triplets(), Xb.triplets()
             assert all(np.array_equal(u, v) for u, v in zip(ta, tb)), it
     finally:
