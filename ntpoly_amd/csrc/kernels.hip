@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
       int prev = __shfl_up(r, 1, WAVE);
       if (lane == 0) prev = carry;
       if (p < e) {
-        nprod += clen[r];
+        if (clen) nprod += clen[r];
         if (tiled) tile[jj * pitch + (r - kmin)] = val[q][c];
         if (fuse_a) {
           dst[r] = val[q][c];
@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
     for (int64_t p = s + CH * WAVE + lane; p < e; p += WAVE) {
       const int r = B.inner[p];
       const double v = Bv[p];
-      nprod += clen[r];
+      if (clen) nprod += clen[r];
       if (tiled) tile[jj * pitch + (r - kmin)] = v;
       if (fuse_a) {
         const int prev = B.inner[p - 1];
@@ -2756,7 +2756,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                        reinterpret_cast<SlabRun*>(runs.p), A.cols);
     const int pitch = ((int)hstats[17] + 1) | 1;
     hipLaunchKernelGGL((k_slab_expand_b<SJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * 8, stream(), view(B),
-                       blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p, aexp.p, clen.p, blk_prod.p);
+                       blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p, aexp.p,
+                       timing ? clen.p : (const int32_t*)nullptr, blk_prod.p);  // product count: statistics only
     scan_async<int64_t>(blk_prod.p, blk_prod_scan.p, (int64_t)snb);  // total = products of this multiply
   }
   t_num.start();

@@ -8,7 +8,8 @@ namespace ntp {
 // Per-call statistics of the SpGEMM (for bench.py's roofline accounting).
 struct SpgemmStats {
   int64_t nnz_a = 0, nnz_b = 0, nnz_c = 0;
-  int64_t products = 0;        // intermediate products IP = sum_j sum_{k in B(:,j)} nnz(A(:,k))
+  int64_t products = 0;        // intermediate products IP = sum_j sum_{k in B(:,j)} nnz(A(:,k)); on the register-slab path
+                               // only counted when the time_kernels option is on (it costs a gather per entry of B)
   int64_t tmp_entries = 0;     // upper-bound entries reserved for the numeric pass
   int slab = 0;                // 1 when the register-slab kernel computed the product
   int64_t bin_cols[6] = {0, 0, 0, 0, 0, 0};
