@@ -354,3 +354,72 @@ def test_slab_kernel_fma_option(nt):
     assert d.max() <= max(1e-13 * scale, 2 * thr * 1e-6) or d.max() <= 1.000001 * thr  # entries straddling the threshold
     big = abs(want) > 10 * thr
     assert abs((got - want).multiply(big)).max() <= 1e-13 * scale
+
+
+def test_full_size_properties_config3_panel(nt):
+    """BASELINE configs[3] operand (N = 1 048 576, 201 nnz/row; the 8-GPU config) as ONE A*A on one GPU:
+    size-independent checks at full size -- exact symmetry of A*A for symmetric A, trace(A*A) == dot(A, A^T),
+    bit-exact agreement of the register-slab kernel with the column-pair kernel, and the analytic product
+    count of a band."""
+    n, h = 1048576, 100
+    col, row, val = banded_triplets(n, h)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    nnz_a = len(val)
+    del col, row, val
+    C = nt.Matrix_ps(n)
+    nt.set_option("time_kernels", 1)
+    try:
+        C.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+        st = nt.last_spgemm_stats()
+    finally:
+        nt.set_option("time_kernels", 0)
+    assert st["slab"] == 1 and st["nnz_a"] == nnz_a
+    w = 2 * h + 1
+    ip_interior = n * w * w   # minus the band truncation at the two ends
+    assert 0.999 * ip_interior < st["products"] <= ip_interior
+    assert C.MeasureAsymmetry() == 0.0
+    AT = nt.Matrix_ps(n)
+    AT.Transpose(A)
+    assert C.Trace() == pytest.approx(A.Dot(AT), rel=1e-12)
+    got = C.triplets()
+    nt.set_option("spgemm_variant", 351)
+    try:
+        C2 = nt.Matrix_ps(n)
+        C2.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+    finally:
+        nt.set_option("spgemm_variant", -1)
+    g2 = C2.triplets()
+    assert all(np.array_equal(u, v) for u, v in zip(got, g2))
+
+
+def test_full_size_properties_config4_complex(nt):
+    """BASELINE configs[4] (Hermitian complex N = 131 072, 101 nnz/row, H + 2I): SignFunction and
+    InverseSquareRoot at full size, checked through what they must satisfy: sign(H)^2 = I and
+    Z H Z = I up to the solver threshold, Hermitian results."""
+    n, h, thr = 131072, 50, 1e-8
+    col, row, val = banded_triplets(n, h, complex_=True, shift=2.0)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    del col, row, val
+    p = nt.SolverParameters()
+    p.SetThreshold(thr)
+    p.SetConvergeDiff(1e-10)
+    Ident = nt.Matrix_ps(n)
+    Ident.FillIdentity()
+
+    S = nt.Matrix_ps(n)
+    nt.SignSolvers.ComputeSign(H, S, p)
+    S2 = nt.Matrix_ps(n)
+    S2.Gemm(S, S, None, 1.0, 0.0, thr)
+    S2.Increment(Ident, -1.0, 0.0)
+    assert S2.Norm() <= 1e-5
+    assert S.MeasureAsymmetry() <= 1e-5
+
+    Z = nt.Matrix_ps(n)
+    nt.SquareRootSolvers.InverseSquareRoot(H, Z, p)
+    T = nt.Matrix_ps(n)
+    T.Gemm(Z, H, None, 1.0, 0.0, thr)
+    R = nt.Matrix_ps(n)
+    R.Gemm(T, Z, None, 1.0, 0.0, thr)
+    R.Increment(Ident, -1.0, 0.0)
+    assert R.Norm() <= 1e-5
+    assert Z.MeasureAsymmetry() <= 1e-5   # Newton-Schulz with threshold 1e-8 is Hermitian to the pruning error only
