@@ -4,9 +4,16 @@
 // (bench.py / tests use torch.distributed for that) and handed in through comm_init().
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "engine.hpp"
 
@@ -26,7 +33,158 @@ Comm& world() {
 
 static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
 
+// ------------------------------------------------------------------ transport 1: RCCL (the product)
+namespace {
+struct RcclTransport : Transport {
+  ncclComm_t comm = nullptr;
+  ~RcclTransport() override {
+    if (comm) (void)ncclCommDestroy(comm);
+  }
+  void allgather(const void* send, void* recv, size_t bytes) override {
+    NCCL_CHECK(ncclAllGather(send, recv, bytes, ncclInt8, comm, stream()));
+  }
+  void allreduce(void* buf, size_t count, bool is_f64, int op) override {
+    const ncclRedOp_t o = op == 0 ? ncclSum : op == 1 ? ncclMin : ncclMax;
+    NCCL_CHECK(ncclAllReduce(buf, buf, count, is_f64 ? ncclDouble : ncclInt64, o, comm, stream()));
+  }
+  void bcast(const void* send, void* recv, size_t bytes, int root) override {
+    NCCL_CHECK(ncclBroadcast(send, recv, bytes, ncclInt8, root, comm, stream()));
+  }
+  void group_begin() override { NCCL_CHECK(ncclGroupStart()); }
+  void send(const void* p, size_t bytes, int peer) override { NCCL_CHECK(ncclSend(p, bytes, ncclInt8, peer, comm, stream())); }
+  void recv(void* p, size_t bytes, int peer) override { NCCL_CHECK(ncclRecv(p, bytes, ncclInt8, peer, comm, stream())); }
+  void group_end() override { NCCL_CHECK(ncclGroupEnd()); }
+};
+
+// ------------------------------------------------------------------ transport 2: shared memory (tests only)
+// Layout of the segment: a header with a sense-reversing barrier, then P*P mailboxes of `box` bytes
+// (mailbox s*P + q carries rank s -> rank q).  Every operation synchronises the engine stream, stages through the
+// host and uses two barriers; it is a correctness vehicle, not a fast path.
+struct ShmHeader {
+  volatile int count;
+  volatile int sense;
+  int nranks;
+  int pad;
+};
+struct ShmTransport : Transport {
+  int rank = 0, P = 1;
+  size_t box = 0;
+  char* base = nullptr;
+  size_t total = 0;
+  int local_sense = 0;
+  struct Pending { const void* s; void* r; size_t bytes; int peer; };
+  std::vector<Pending> sends, recvs;
+  std::vector<char> host;
+
+  ShmHeader* hdr() { return reinterpret_cast<ShmHeader*>(base); }
+  char* mailbox(int s, int q) { return base + 4096 + ((size_t)s * P + q) * box; }
+  void barrier() {
+    local_sense = 1 - local_sense;
+    if (__sync_add_and_fetch(&hdr()->count, 1) == P) {
+      hdr()->count = 0;
+      __sync_synchronize();
+      hdr()->sense = local_sense;
+    } else {
+      while (hdr()->sense != local_sense) sched_yield();
+    }
+    __sync_synchronize();
+  }
+  void d2h(void* h, const void* d, size_t n) { if (n) HIP_CHECK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); }
+  void h2d(void* d, const void* h, size_t n) { if (n) HIP_CHECK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); }
+  void check(size_t bytes) { if (bytes > box) NTP_FATAL("shm transport: message larger than the mailbox (NTPOLY_AMD_SHM_MB)"); }
+
+  void allgather(const void* send, void* recv, size_t bytes) override {
+    check(bytes);
+    sync_stream();
+    d2h(mailbox(rank, rank), send, bytes);
+    barrier();
+    for (int s = 0; s < P; ++s) h2d(static_cast<char*>(recv) + (size_t)s * bytes, mailbox(s, s), bytes);
+    barrier();
+  }
+  void allreduce(void* buf, size_t count, bool is_f64, int op) override {
+    const size_t bytes = count * 8;
+    check(bytes);
+    sync_stream();
+    d2h(mailbox(rank, rank), buf, bytes);
+    barrier();
+    host.resize(bytes);
+    std::memcpy(host.data(), mailbox(0, 0), bytes);
+    for (int s = 1; s < P; ++s) {  // rank order: the same result on every rank
+      for (size_t i = 0; i < count; ++i) {
+        if (is_f64) {
+          double& a = reinterpret_cast<double*>(host.data())[i];
+          const double b = reinterpret_cast<const double*>(mailbox(s, s))[i];
+          a = op == 0 ? a + b : op == 1 ? std::min(a, b) : std::max(a, b);
+        } else {
+          int64_t& a = reinterpret_cast<int64_t*>(host.data())[i];
+          const int64_t b = reinterpret_cast<const int64_t*>(mailbox(s, s))[i];
+          a = op == 0 ? a + b : op == 1 ? std::min(a, b) : std::max(a, b);
+        }
+      }
+    }
+    h2d(buf, host.data(), bytes);
+    barrier();
+  }
+  void bcast(const void* send, void* recv, size_t bytes, int root) override {
+    check(bytes);
+    sync_stream();
+    if (rank == root) d2h(mailbox(root, root), send, bytes);
+    barrier();
+    h2d(recv, mailbox(root, root), bytes);
+    barrier();
+  }
+  void group_begin() override { sends.clear(); recvs.clear(); }
+  void send(const void* p, size_t bytes, int peer) override { sends.push_back({p, nullptr, bytes, peer}); }
+  void recv(void* p, size_t bytes, int peer) override { recvs.push_back({nullptr, p, bytes, peer}); }
+  void group_end() override {
+    sync_stream();
+    std::vector<size_t> off((size_t)P, 0);
+    for (const Pending& m : sends) {  // messages to one peer are appended in posting order
+      if (off[(size_t)m.peer] + m.bytes > box) NTP_FATAL("shm transport: mailbox overflow (NTPOLY_AMD_SHM_MB)");
+      d2h(mailbox(rank, m.peer) + off[(size_t)m.peer], m.s, m.bytes);
+      off[(size_t)m.peer] += (m.bytes + 15) & ~(size_t)15;
+    }
+    barrier();
+    std::fill(off.begin(), off.end(), 0);
+    for (const Pending& m : recvs) {
+      h2d(m.r, mailbox(m.peer, rank) + off[(size_t)m.peer], m.bytes);
+      off[(size_t)m.peer] += (m.bytes + 15) & ~(size_t)15;
+    }
+    barrier();
+    sends.clear();
+    recvs.clear();
+  }
+  ~ShmTransport() override {
+    if (base) munmap(base, total);
+  }
+};
+
+Transport* open_shm(const std::string& name, int rank, int nranks) {
+  auto* t = new ShmTransport();
+  t->rank = rank;
+  t->P = nranks;
+  const char* mb = std::getenv("NTPOLY_AMD_SHM_MB");
+  t->box = (size_t)(mb ? std::atoi(mb) : 16) << 20;
+  t->total = 4096 + (size_t)nranks * nranks * t->box;
+  const std::string path = "/ntpoly_amd_" + name;
+  int fd = shm_open(path.c_str(), O_CREAT | O_RDWR, 0600);
+  if (fd < 0) NTP_FATAL("shm_open failed");
+  if (ftruncate(fd, (off_t)t->total) != 0) NTP_FATAL("ftruncate failed");
+  void* p = mmap(nullptr, t->total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) NTP_FATAL("mmap failed");
+  t->base = static_cast<char*>(p);
+  // the segment is created zero-filled by the launcher-unique name: count = 0, sense = 0
+  return t;
+}
+}  // namespace
+
 void comm_get_unique_id(char out[128]) {
+  const char* mode = std::getenv("NTPOLY_AMD_COMM");
+  if (mode && std::strncmp(mode, "shm:", 4) == 0) {  // nothing to exchange: the segment name is in the environment
+    std::memset(out, 0, 128);
+    return;
+  }
   ncclUniqueId id;
   NCCL_CHECK(ncclGetUniqueId(&id));
   std::memcpy(out, &id, sizeof(id));
@@ -34,7 +192,7 @@ void comm_get_unique_id(char out[128]) {
 
 void comm_init(const char idbytes[128], int rank, int nranks) {
   Comm& c = world();
-  if (c.nccl) comm_finalize();
+  if (c.tr) comm_finalize();
   c.rank = rank;
   c.nranks = nranks;
   const char* f = std::getenv("NTPOLY_AMD_FORCE_RCCL");
@@ -49,56 +207,54 @@ void comm_init(const char idbytes[128], int rank, int nranks) {
     c.nranks = 1;
   }
   ensure_init();
+  const char* mode = std::getenv("NTPOLY_AMD_COMM");
+  if (mode && std::strncmp(mode, "shm:", 4) == 0) {
+    c.tr = open_shm(mode + 4, c.rank, c.nranks);
+    return;
+  }
   ncclUniqueId id;
   std::memcpy(&id, idbytes, sizeof(id));
   if (c.force && nranks <= 1) NCCL_CHECK(ncclGetUniqueId(&id));
-  ncclComm_t comm;
-  NCCL_CHECK(ncclCommInitRank(&comm, c.nranks, id, c.rank));
-  c.nccl = comm;
+  auto* t = new RcclTransport();
+  NCCL_CHECK(ncclCommInitRank(&t->comm, c.nranks, id, c.rank));
+  c.tr = t;
 }
 
 void comm_finalize() {
   Comm& c = world();
-  if (c.nccl) {
+  if (c.tr) {
     sync_stream();
-    (void)ncclCommDestroy(static_cast<ncclComm_t>(c.nccl));
-    c.nccl = nullptr;
+    delete c.tr;
+    c.tr = nullptr;
   }
   c.rank = 0;
   c.nranks = 1;
 }
 
 namespace {
-void allreduce_f64(double* host_vals, int n, ncclRedOp_t op) {
+void allreduce_host(void* host_vals, int n, bool is_f64, int op) {
   Comm& c = world();
   if (!c.active() || n == 0) return;
   DevBuf<double> d((size_t)n);
-  d.upload(host_vals, (size_t)n);
-  NCCL_CHECK(ncclAllReduce(d.p, d.p, (size_t)n, ncclDouble, op, static_cast<ncclComm_t>(c.nccl), stream()));
-  d.download(host_vals, (size_t)n);
+  HIP_CHECK(hipMemcpyAsync(d.p, host_vals, (size_t)n * 8, hipMemcpyHostToDevice, stream()));
+  c.tr->allreduce(d.p, (size_t)n, is_f64, op);
+  d.download(static_cast<double*>(host_vals), (size_t)n);
 }
 }  // namespace
 
-void comm_allreduce_sum(double* v, int n) { allreduce_f64(v, n, ncclSum); }
-void comm_allreduce_min(double* v, int n) { allreduce_f64(v, n, ncclMin); }
-void comm_allreduce_max(double* v, int n) { allreduce_f64(v, n, ncclMax); }
-
-void comm_allreduce_sum_i64(int64_t* v, int n) {
-  Comm& c = world();
-  if (!c.active() || n == 0) return;
-  DevBuf<int64_t> d((size_t)n);
-  d.upload(v, (size_t)n);
-  NCCL_CHECK(ncclAllReduce(d.p, d.p, (size_t)n, ncclInt64, ncclSum, static_cast<ncclComm_t>(c.nccl), stream()));
-  d.download(v, (size_t)n);
-}
+void comm_allreduce_sum(double* v, int n) { allreduce_host(v, n, true, 0); }
+void comm_allreduce_min(double* v, int n) { allreduce_host(v, n, true, 1); }
+void comm_allreduce_max(double* v, int n) { allreduce_host(v, n, true, 2); }
+void comm_allreduce_sum_i64(int64_t* v, int n) { allreduce_host(v, n, false, 0); }
 
 void comm_bcast_i32(int32_t* v, int n, int root) {
   Comm& c = world();
   if (!c.active() || n == 0) return;
   DevBuf<int32_t> d((size_t)n);
   d.upload(v, (size_t)n);
-  NCCL_CHECK(ncclBroadcast(d.p, d.p, (size_t)n, ncclInt32, root, static_cast<ncclComm_t>(c.nccl), stream()));
-  d.download(v, (size_t)n);
+  c.tr->bcast(d.p, d.p, (size_t)n * 4, root);
+  HIP_CHECK(hipMemcpyAsync(v, d.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream()));
+  sync_stream();
 }
 
 void comm_barrier() {
@@ -114,14 +270,14 @@ void comm_barrier() {
 DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths) {
   Comm& c = world();
   if (!c.active()) return loc.clone();
-  ncclComm_t comm = static_cast<ncclComm_t>(c.nccl);
+  Transport& tr = *c.tr;
   const int P = c.nranks;
   if ((int)widths.size() != P || widths[(size_t)c.rank] != loc.cols) NTP_FATAL("gather_panels: inconsistent panel widths");
   // 1. sizes (M1)
   DevBuf<int64_t> d_sizes((size_t)P);
   int64_t mine = loc.nnz;
   HIP_CHECK(hipMemcpyAsync(d_sizes.p + c.rank, &mine, sizeof(int64_t), hipMemcpyHostToDevice, stream()));
-  NCCL_CHECK(ncclAllGather(d_sizes.p + c.rank, d_sizes.p, 1, ncclInt64, comm, stream()));
+  tr.allgather(d_sizes.p + c.rank, d_sizes.p, sizeof(int64_t));
   std::vector<int64_t> sizes((size_t)P);
   d_sizes.download(sizes.data(), (size_t)P);
   std::vector<int64_t> zoff((size_t)P + 1, 0), coff((size_t)P + 1, 0);
@@ -136,19 +292,17 @@ DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths) {
   full.alloc(loc.rows, (int32_t)coff[(size_t)P], loc.cplx, zoff[(size_t)P]);
   DevBuf<int64_t> stage((size_t)coff[(size_t)P] + (size_t)P);
   const size_t w = loc.wval();
-  NCCL_CHECK(ncclGroupStart());
+  tr.group_begin();  // the owners' broadcasts travel concurrently over the point-to-point links
   for (int r = 0; r < P; ++r) {
     const size_t ncol = (size_t)widths[(size_t)r];
     int64_t* st = stage.p + (size_t)coff[(size_t)r] + (size_t)r;
-    NCCL_CHECK(ncclBroadcast(loc.outer.p, st, ncol + 1, ncclInt64, r, comm, stream()));
+    tr.bcast(loc.outer.p, st, (ncol + 1) * sizeof(int64_t), r);
     if (sizes[(size_t)r] > 0) {
-      NCCL_CHECK(ncclBroadcast(loc.inner.p, full.inner.p + zoff[(size_t)r], (size_t)sizes[(size_t)r], ncclInt32, r,
-                               comm, stream()));
-      NCCL_CHECK(ncclBroadcast(loc.val.p, full.val.p + zoff[(size_t)r] * (int64_t)w, (size_t)sizes[(size_t)r] * w,
-                               ncclDouble, r, comm, stream()));
+      tr.bcast(loc.inner.p, full.inner.p + zoff[(size_t)r], (size_t)sizes[(size_t)r] * sizeof(int32_t), r);
+      tr.bcast(loc.val.p, full.val.p + zoff[(size_t)r] * (int64_t)w, (size_t)sizes[(size_t)r] * w * sizeof(double), r);
     }
   }
-  NCCL_CHECK(ncclGroupEnd());
+  tr.group_end();
   // 3. cleanup: every panel's offsets are shifted by the number of entries before it
   //    (ReduceAndComposeMatrixCleanup.f90:6-13); the last offset of panel r is the first of panel r+1
   for (int r = 0; r < P; ++r) {
@@ -178,51 +332,61 @@ void halo_segment(int32_t dim, int P, int s, int32_t kmin, int32_t kmax, int32_t
 // Range-restricted panel exchange ("halo"): rank q only needs the columns of A whose index appears
 // as a row of its B panel, i.e. the contiguous range [kmin_q, kmax_q].  For banded operands that is
 // its own panel plus a halo of one bandwidth on each side (KBs..MBs instead of the whole matrix);
-// for permuted operands it degenerates to the full gather.  Protocol (all on the engine stream):
-//   1. all-gather of the (kmin, kmax) pairs                                   [ncclAllGather, 2 ints]
-//   2. every owner reads the column offsets at its segment boundaries -> entry counts per requester
-//   3. all-gather of the P x P count matrix                                   [ncclAllGather, P int64]
-//   4. one group of ncclSend / ncclRecv per (owner, requester) pair with a non-empty segment:
-//      column offsets of the segment, row ids, values; the own segment is a device copy
-//   5. segments are re-based into one dim-wide matrix whose other columns are empty, so the SpGEMM
-//      kernels run unchanged.
-DevMat gather_needed(const PSMatrix& m, int32_t kmin, int32_t kmax) {
+// for permuted operands it degenerates to the full gather.  Protocol (all on the engine stream, TWO host
+// synchronisations):
+//   1. every rank computes (kmin, kmax, nnz(A_loc), nnz(B_loc)) on the device; one all-gather of these records;
+//      read-back #1 (also yields the global nnz the caller needs for the dense-branch rule)
+//   2. every owner looks up, on the device, the entry offsets at the boundaries of the segment each requester
+//      needs -> one row of the P x P count matrix; one all-gather of the rows; read-back #2
+//   3. one group of send / recv per (owner, requester) pair with a non-empty segment: column offsets of the
+//      segment, row ids, values; the own segment is a device copy
+//   4. segments are re-based into one dim-wide matrix whose other columns are empty, so the SpGEMM
+//      kernels run unchanged.  No synchronisation at the end: everything downstream is stream ordered.
+DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2]) {
   Comm& c = world();
   const int32_t dim = m.dim;
   if (!c.active()) NTP_FATAL("gather_needed without an active communicator");
-  ncclComm_t comm = static_cast<ncclComm_t>(c.nccl);
+  Transport& tr = *c.tr;
   const int P = c.nranks, me = c.rank;
-  // 1. ranges
-  std::vector<int32_t> req((size_t)2 * P, 0);
+  // 1. requests
+  std::vector<int64_t> req((size_t)4 * P, 0);
   {
-    DevBuf<int32_t> d((size_t)2 * P);
-    int32_t mine[2] = {kmin, kmax};
-    HIP_CHECK(hipMemcpyAsync(d.p + 2 * me, mine, sizeof(mine), hipMemcpyHostToDevice, stream()));
-    NCCL_CHECK(ncclAllGather(d.p + 2 * me, d.p, 2, ncclInt32, comm, stream()));
-    d.download(req.data(), (size_t)2 * P);
+    DevBuf<int64_t> d((size_t)4 * P);
+    halo_request_async(Bloc, m.loc.nnz, d.p + 4 * me);
+    tr.allgather(d.p + 4 * me, d.p, 4 * sizeof(int64_t));
+    d.download(req.data(), (size_t)4 * P);
   }
-  // 2. what I send to every requester
-  std::vector<int32_t> sa((size_t)P), sb((size_t)P);
-  std::vector<int64_t> bound((size_t)2 * P, 0);
+  nnz_global[0] = nnz_global[1] = 0;
   for (int q = 0; q < P; ++q) {
-    halo_segment(dim, P, me, req[(size_t)2 * q], req[(size_t)2 * q + 1], &sa[(size_t)q], &sb[(size_t)q]);
-    HIP_CHECK(hipMemcpyAsync(&bound[(size_t)2 * q], m.loc.outer.p + (sa[(size_t)q] - m.c0), sizeof(int64_t),
-                             hipMemcpyDeviceToHost, stream()));
-    HIP_CHECK(hipMemcpyAsync(&bound[(size_t)2 * q + 1], m.loc.outer.p + (sb[(size_t)q] - m.c0), sizeof(int64_t),
-                             hipMemcpyDeviceToHost, stream()));
+    nnz_global[0] += req[(size_t)4 * q + 2];
+    nnz_global[1] += req[(size_t)4 * q + 3];
   }
-  sync_stream();
-  // 3. count matrix cnt[s*P + q] = entries rank s sends to rank q
-  std::vector<int64_t> cnt((size_t)P * P, 0);
+  auto kmin_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? 0 : (int32_t)lo; };
+  auto kmax_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? -1 : (int32_t)hi; };
+  const int32_t kmin = kmin_of(me), kmax = kmax_of(me);
+  // 2. what I send to every requester: segment boundaries (host arithmetic), entry offsets and counts (device)
+  std::vector<int32_t> sab((size_t)2 * P);
+  for (int q = 0; q < P; ++q) halo_segment(dim, P, me, kmin_of(q), kmax_of(q), &sab[(size_t)q], &sab[(size_t)P + q]);
+  const int32_t* sa = sab.data();
+  const int32_t* sb = sab.data() + P;
+  std::vector<int64_t> bound((size_t)2 * P, 0), cnt((size_t)P * P, 0);
   {
-    DevBuf<int64_t> d((size_t)P * P);
-    std::vector<int64_t> row((size_t)P);
-    for (int q = 0; q < P; ++q) row[(size_t)q] = bound[(size_t)2 * q + 1] - bound[(size_t)2 * q];
-    HIP_CHECK(hipMemcpyAsync(d.p + (size_t)me * P, row.data(), sizeof(int64_t) * (size_t)P, hipMemcpyHostToDevice, stream()));
-    NCCL_CHECK(ncclAllGather(d.p + (size_t)me * P, d.p, (size_t)P, ncclInt64, comm, stream()));
-    d.download(cnt.data(), (size_t)P * P);
+    DevBuf<int32_t> d_sab((size_t)2 * P);
+    d_sab.upload(sab.data(), (size_t)2 * P);
+    DevBuf<int64_t> d_bound((size_t)2 * P), d_cnt((size_t)P * P);
+    halo_bounds_async(m.loc, m.c0, d_sab.p, d_sab.p + P, P, d_bound.p, d_cnt.p + (size_t)me * P);
+    tr.allgather(d_cnt.p + (size_t)me * P, d_cnt.p, (size_t)P * sizeof(int64_t));
+    ScalarFetch f;
+    if ((size_t)P * P + 2 * P <= 500) {
+      f.add(d_bound.p, 2 * P, bound.data());
+      f.add(d_cnt.p, P * P, cnt.data());
+      f.run();
+    } else {
+      d_bound.download(bound.data(), (size_t)2 * P);
+      d_cnt.download(cnt.data(), (size_t)P * P);
+    }
   }
-  // 4. receive layout: sources in rank order (their segments tile [kmin, kmax] in ascending columns)
+  // 3. receive layout: sources in rank order (their segments tile [kmin, kmax] in ascending columns)
   std::vector<int32_t> ra((size_t)P), rb((size_t)P);
   std::vector<int64_t> zoff((size_t)P + 1, 0), soff((size_t)P + 1, 0);
   for (int s = 0; s < P; ++s) {
@@ -235,36 +399,36 @@ DevMat gather_needed(const PSMatrix& m, int32_t kmin, int32_t kmax) {
   full.alloc(dim, dim, m.cplx, total);
   DevBuf<int64_t> stage((size_t)soff[(size_t)P]);
   const size_t w = m.loc.wval();
-  NCCL_CHECK(ncclGroupStart());
+  tr.group_begin();
   for (int q = 0; q < P; ++q) {  // sends
     const int64_t n = cnt[(size_t)me * P + q];
     if (q == me || n == 0) continue;
     const int64_t first = bound[(size_t)2 * q];
-    NCCL_CHECK(ncclSend(m.loc.outer.p + (sa[(size_t)q] - m.c0), (size_t)(sb[(size_t)q] - sa[(size_t)q] + 1), ncclInt64, q, comm, stream()));
-    NCCL_CHECK(ncclSend(m.loc.inner.p + first, (size_t)n, ncclInt32, q, comm, stream()));
-    NCCL_CHECK(ncclSend(m.loc.val.p + first * (int64_t)w, (size_t)n * w, ncclDouble, q, comm, stream()));
+    tr.send(m.loc.outer.p + (sa[q] - m.c0), (size_t)(sb[q] - sa[q] + 1) * sizeof(int64_t), q);
+    tr.send(m.loc.inner.p + first, (size_t)n * sizeof(int32_t), q);
+    tr.send(m.loc.val.p + first * (int64_t)w, (size_t)n * w * sizeof(double), q);
   }
   for (int s = 0; s < P; ++s) {  // receives
     const int64_t n = cnt[(size_t)s * P + me];
     if (s == me || n == 0) continue;
-    NCCL_CHECK(ncclRecv(stage.p + soff[(size_t)s], (size_t)(rb[(size_t)s] - ra[(size_t)s] + 1), ncclInt64, s, comm, stream()));
-    NCCL_CHECK(ncclRecv(full.inner.p + zoff[(size_t)s], (size_t)n, ncclInt32, s, comm, stream()));
-    NCCL_CHECK(ncclRecv(full.val.p + zoff[(size_t)s] * (int64_t)w, (size_t)n * w, ncclDouble, s, comm, stream()));
+    tr.recv(stage.p + soff[(size_t)s], (size_t)(rb[(size_t)s] - ra[(size_t)s] + 1) * sizeof(int64_t), s);
+    tr.recv(full.inner.p + zoff[(size_t)s], (size_t)n * sizeof(int32_t), s);
+    tr.recv(full.val.p + zoff[(size_t)s] * (int64_t)w, (size_t)n * w * sizeof(double), s);
   }
-  NCCL_CHECK(ncclGroupEnd());
+  tr.group_end();
   {  // own segment
     const int64_t n = cnt[(size_t)me * P + me];
     if (n > 0) {
       const int64_t first = bound[(size_t)2 * me];
-      HIP_CHECK(hipMemcpyAsync(stage.p + soff[(size_t)me], m.loc.outer.p + (sa[(size_t)me] - m.c0),
-                               sizeof(int64_t) * (size_t)(sb[(size_t)me] - sa[(size_t)me] + 1), hipMemcpyDeviceToDevice, stream()));
+      HIP_CHECK(hipMemcpyAsync(stage.p + soff[(size_t)me], m.loc.outer.p + (sa[me] - m.c0),
+                               sizeof(int64_t) * (size_t)(sb[me] - sa[me] + 1), hipMemcpyDeviceToDevice, stream()));
       HIP_CHECK(hipMemcpyAsync(full.inner.p + zoff[(size_t)me], m.loc.inner.p + first, sizeof(int32_t) * (size_t)n,
                                hipMemcpyDeviceToDevice, stream()));
       HIP_CHECK(hipMemcpyAsync(full.val.p + zoff[(size_t)me] * (int64_t)w, m.loc.val.p + first * (int64_t)w,
                                sizeof(double) * (size_t)n * w, hipMemcpyDeviceToDevice, stream()));
     }
   }
-  // 5. column offsets: 0 before the first needed column, re-based segments, `total` after the last
+  // 4. column offsets: 0 before the first needed column, re-based segments, `total` after the last
   int32_t pos = 0;
   for (int s = 0; s < P; ++s) {
     const int32_t a = ra[(size_t)s], b = rb[(size_t)s];
@@ -276,7 +440,7 @@ DevMat gather_needed(const PSMatrix& m, int32_t kmin, int32_t kmax) {
     pos = b;
   }
   fill_i64(full.outer.p + pos, (int64_t)dim + 1 - pos, total);
-  sync_stream();
+  // `stage` is released on return: the allocator is stream ordered, later kernels run after the re-base kernels
   return full;
 }
 

@@ -13,12 +13,26 @@
 namespace ntp {
 
 // ------------------------------------------------------------------ communication
-// One RCCL communicator over all ranks (one process per GPU).  nranks == 1 needs no RCCL.
+// One communicator over all ranks (one process per GPU).  nranks == 1 needs no transport.
+// The data plane is RCCL over xGMI.  A second transport exists for TESTS only (NTPOLY_AMD_COMM=shm:<name>): the
+// ranks are processes sharing ONE GPU and exchange through a POSIX shared-memory segment, which lets the multi-rank
+// code paths (halo exchange, panel gathers, distributed solvers) run on a single-GPU box.
+struct Transport {
+  virtual ~Transport() {}
+  // all pointers are device pointers; sizes in bytes; operations are ordered on the engine stream
+  virtual void allgather(const void* send, void* recv, size_t bytes_per_rank) = 0;
+  virtual void allreduce(void* buf, size_t count, bool is_f64, int op /*0 sum, 1 min, 2 max*/) = 0;
+  virtual void bcast(const void* send, void* recv, size_t bytes, int root) = 0;
+  virtual void group_begin() = 0;
+  virtual void send(const void* p, size_t bytes, int peer) = 0;
+  virtual void recv(void* p, size_t bytes, int peer) = 0;
+  virtual void group_end() = 0;
+};
 struct Comm {
   int rank = 0, nranks = 1;
-  void* nccl = nullptr;  // ncclComm_t
-  bool force = false;    // tests: run the RCCL code paths even with a single rank
-  bool active() const { return nccl != nullptr && (nranks > 1 || force); }
+  Transport* tr = nullptr;
+  bool force = false;    // tests: run the multi-rank code paths even with a single rank
+  bool active() const { return tr != nullptr && (nranks > 1 || force); }
 };
 Comm& world();
 void comm_get_unique_id(char out[128]);
@@ -69,7 +83,9 @@ void ps_to_complex(const PSMatrix& a, PSMatrix& out);
 void ps_to_real(const PSMatrix& a, PSMatrix& out);
 DevMat ps_gather_full(const PSMatrix& m);  // every rank gets the whole matrix (dim x dim)
 // range-restricted exchange: a dim x dim matrix holding only the columns [kmin, kmax] of the distributed matrix
-DevMat gather_needed(const PSMatrix& m, int32_t kmin, int32_t kmax);
+// halo exchange for C = A*B: the columns of A named by the rows of the local B panel; also returns the global
+// nnz of A and B (collected in the same exchange)
+DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2]);
 void halo_segment(int32_t dim, int P, int s, int32_t kmin, int32_t kmax, int32_t* a, int32_t* b);
 // concatenate the column panels of all ranks (widths[r] = columns held by rank r, known to all)
 DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths);

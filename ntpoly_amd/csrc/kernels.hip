@@ -3322,6 +3322,58 @@ void fill_i64(int64_t* d_dst, int64_t count, int64_t v) {
   if (count <= 0) return;
   hipLaunchKernelGGL(k_fill_i64, dim3(cdiv(count, 256)), dim3(256), 0, stream(), d_dst, count, v);
 }
+namespace {
+// request record of one rank for the halo exchange: (first row, last row of the local B panel, nnz(A_loc), nnz(B_loc))
+__global__ void k_halo_request(Csc B, long long nnz_a, long long nnz_b, long long* __restrict__ out4) {
+  // out4[0], out4[1] were preset to (INT_MAX, -1); one block per 256 columns reduces with atomics (few blocks)
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int lo = INT_MAX, hi = -1;
+  if (j < B.cols) {
+    const int64_t s = B.outer[j], e = B.outer[j + 1];
+    if (e > s) {
+      lo = B.inner[s];
+      hi = B.inner[e - 1];
+    }
+  }
+  lo = wave_min_i32(lo);
+  hi = wave_max_i32(hi);
+  if (lane_id() == 0) {
+    if (lo != INT_MAX) atomicMin(&out4[0], (long long)lo);
+    if (hi >= 0) atomicMax(&out4[1], (long long)hi);
+  }
+  if (j == 0) {
+    out4[2] = nnz_a;
+    out4[3] = nnz_b;
+  }
+}
+// per requester q: entry offsets of my panel at the boundaries of the segment [sa[q], sb[q]) it needs, and the
+// number of entries in between (one row of the P x P count matrix)
+__global__ void k_halo_bounds(const int64_t* __restrict__ outer, int c0, const int32_t* __restrict__ sa,
+                              const int32_t* __restrict__ sb, int P, long long* __restrict__ bound,
+                              long long* __restrict__ cnt_row) {
+  const int q = threadIdx.x;
+  if (q >= P) return;
+  const long long a = outer[sa[q] - c0], b = outer[sb[q] - c0];
+  bound[2 * q] = a;
+  bound[2 * q + 1] = b;
+  cnt_row[q] = b - a;
+}
+}  // namespace
+
+void halo_request_async(const DevMat& B, int64_t nnz_a, int64_t* d_out4) {
+  const long long init[2] = {INT_MAX, -1};
+  HIP_CHECK(hipMemcpyAsync(d_out4, init, sizeof(init), hipMemcpyHostToDevice, stream()));
+  hipLaunchKernelGGL(k_halo_request, dim3(std::max(1, cdiv(B.cols, 256))), dim3(256), 0, stream(), view(B), (long long)nnz_a,
+                     (long long)B.nnz, reinterpret_cast<long long*>(d_out4));
+}
+
+void halo_bounds_async(const DevMat& A, int32_t c0, const int32_t* d_sa, const int32_t* d_sb, int P, int64_t* d_bound,
+                       int64_t* d_cnt_row) {
+  if (P > 1024) NTP_FATAL("halo_bounds: too many ranks");
+  hipLaunchKernelGGL(k_halo_bounds, dim3(1), dim3(1024), 0, stream(), A.outer.p, c0, d_sa, d_sb, P,
+                     reinterpret_cast<long long*>(d_bound), reinterpret_cast<long long*>(d_cnt_row));
+}
+
 void row_range(const DevMat& A, int32_t* lo, int32_t* hi) {
   *lo = INT_MAX;
   *hi = -1;

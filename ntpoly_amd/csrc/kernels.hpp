@@ -93,6 +93,10 @@ void copy_shift_i64(const int64_t* d_src, int64_t* d_dst, int64_t count, int64_t
 void rebase_i64(const int64_t* d_src, int64_t* d_dst, int64_t count, int64_t add);
 void fill_i64(int64_t* d_dst, int64_t count, int64_t v);
 void row_range(const DevMat& A, int32_t* lo, int32_t* hi);
+// device-side pieces of the halo-exchange plan (comm.cpp gather_needed): no host round trip of their own
+void halo_request_async(const DevMat& B, int64_t nnz_a, int64_t* d_out4);
+void halo_bounds_async(const DevMat& A, int32_t c0, const int32_t* d_sa, const int32_t* d_sb, int P, int64_t* d_bound,
+                       int64_t* d_cnt_row);
 
 // exclusive scan helper (device), out[n] = total; returns total (synchronises)
 int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n);

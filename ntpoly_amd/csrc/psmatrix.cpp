@@ -199,18 +199,16 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   // dense-branch rule of the local multiply (GemmMatrix.f90:49-61): only the order of threshold and
   // alpha differs here, the arithmetic is the same hash-free sparse kernel
   int64_t nz[2] = {A.loc.nnz, B.loc.nnz};
-  comm_allreduce_sum_i64(nz, 2);
   const double denom = (double)A.dim * (double)A.dim;
-  const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
   DevMat AB;
   if (world().active()) {
-    // only the columns of A named by the rows of the local B panel travel (halo for banded operands)
-    int32_t kmin, kmax;
-    row_range(B.loc, &kmin, &kmax);
-    if (kmax < kmin) { kmin = 0; kmax = -1; }
-    DevMat Aneed = gather_needed(A, kmin, kmax);
+    // only the columns of A named by the rows of the local B panel travel (halo for banded operands); the same
+    // exchange returns the global nnz for the dense-branch rule
+    DevMat Aneed = gather_needed(A, B.loc, nz);
+    const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
     spgemm(Aneed, B.loc, AB, alpha, threshold, dense_rule);
   } else {
+    const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
     spgemm(A.loc, B.loc, AB, alpha, threshold, dense_rule);
   }
   // beta handling (MatrixMultiply.f90:324-329)

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""One rank of the multi-process engine test (tests/test_gpu_multirank.py): RANK / WORLD_SIZE / NTPOLY_AMD_COMM
+come from the environment, the ranks are processes sharing ONE GPU and exchange through the shared-memory test
+transport (csrc/comm.cpp).  Writes this rank's results to <out>.<rank>.npz.
+
+    python tests/multirank_worker.py <out-prefix>
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    out = sys.argv[1]
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    import ntpoly_amd as nt
+    from gen import banded_triplets
+    nt.init_comm(nt.get_unique_id(), rank, world)
+    nt.ConstructGlobalProcessGrid(1, world, 1)
+    res = {}
+
+    def keep(tag, M):
+        c, r, v = M.triplets()
+        res[tag + "_col"], res[tag + "_row"], res[tag + "_val"] = c, r, v
+
+    # ---- banded operands (halo exchange): A*B with A != B, then the same product with a threshold
+    n, h = 2500, 30
+    A = nt.Matrix_ps(n)
+    c0, c1 = A.local_columns()
+    res["c0"], res["c1"] = c0, c1
+    t = nt.TripletList_r()
+    t.set_arrays(*banded_triplets(n, h, c0=c0, c1=c1))
+    A.FillFromTripletList(t, prepartitioned=True)
+    B = nt.Matrix_ps(n)
+    t2 = nt.TripletList_r()
+    col, row, val = banded_triplets(n, h + 7, shift=0.3, c0=c0, c1=c1)
+    t2.set_arrays(col, row, val * 1.01)
+    B.FillFromTripletList(t2, prepartitioned=True)
+    C = nt.Matrix_ps(n)
+    C.Gemm(A, B, None, 0.5, 0.0, 1e-7)
+    keep("AB", C)
+    res["AB_trace"], res["AB_norm"], res["AB_dot"] = C.Trace(), C.Norm(), float(np.real(C.Dot(A)))
+    AT = nt.Matrix_ps(n)
+    AT.Transpose(C)
+    keep("ABT", AT)
+
+    # ---- TRS2 on the banded Hamiltonian (ISQ = I): energies per iteration, chemical potential, density
+    Ident = nt.Matrix_ps(n)
+    Ident.FillIdentity()
+    p = nt.SolverParameters()
+    p.SetThreshold(1e-7)
+    p.SetConvergeDiff(1e-9)
+    K = nt.Matrix_ps(n)
+    energy, mu = nt.DensityMatrixSolvers.TRS2(A, Ident, n / 2.0, K, p)
+    tr = nt.solver_trace()
+    res["trs2_energy"], res["trs2_mu"], res["trs2_iters"] = energy, mu, tr["iterations"]
+    res["trs2_log"] = np.array(tr["energy"])
+    keep("K", K)
+
+    # ---- operands without band structure (the halo degenerates to a full gather; general SpGEMM path)
+    rng = np.random.default_rng(1234)   # same seed on every rank: every rank generates the whole matrix ...
+    m = 900
+    dense = rng.random((m, m))
+    mask = rng.random((m, m)) < 0.02
+    R = np.where(mask, dense - 0.5, 0.0)
+    rr, cc = np.nonzero(R.T)            # column-major triplets
+    colg, rowg, valg = rr + 1, cc + 1, R.T[rr, cc]
+    G = nt.Matrix_ps(m)
+    g0, g1 = G.local_columns()
+    sel = (colg > g0) & (colg <= g1)    # ... and passes its own columns
+    tg = nt.TripletList_r()
+    tg.set_arrays(colg[sel].astype(np.int32), rowg[sel].astype(np.int32), valg[sel])
+    G.FillFromTripletList(tg, prepartitioned=True)
+    GG = nt.Matrix_ps(m)
+    GG.Gemm(G, G, None, 1.0, 0.0, 1e-4)
+    keep("GG", GG)
+    res["g0"], res["g1"] = g0, g1
+
+    np.savez(out + ".%d.npz" % rank, **res)
+    nt.DestructGlobalProcessGrid()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""GPU: the multi-rank code paths of the engine (halo exchange of the distributed multiply, panel gathers of the
+transposes, all-reduced scalars, a whole TRS2 solve) with 2, 3 and 4 ranks.  The GPU box has ONE MI355X, and RCCL
+needs one GPU per rank, so here the ranks are processes sharing the GPU and exchanging through the engine's
+shared-memory TEST transport (NTPOLY_AMD_COMM=shm:<name>, csrc/comm.cpp) -- every line of the distributed
+algorithm except the RCCL calls themselves runs as in production.  Results must match the one-rank run: products
+bit for bit (a column's arithmetic does not depend on who owns it), reductions to 1e-12."""
+import os
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_world(world, tmp_path):
+    out = str(tmp_path / ("w%d" % world))
+    name = "t%s" % uuid.uuid4().hex[:12]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", NTPOLY_AMD_COMM="shm:" + name,
+                   NTPOLY_AMD_SHM_MB="8")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=600)
+            logs.append(o)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        try:
+            os.unlink("/dev/shm/ntpoly_amd_" + name)
+        except OSError:
+            pass
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d of %d failed:\n%s" % (r, world, logs[r][-3000:])
+    return [dict(np.load(out + ".%d.npz" % r)) for r in range(world)]
+
+
+def cat(parts, tag):
+    return tuple(np.concatenate([p[tag + s] for p in parts]) for s in ("_col", "_row", "_val"))
+
+
+@pytest.fixture(scope="module")
+def reference(tmp_path_factory):
+    return run_world(1, tmp_path_factory.mktemp("ref"))[0]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_multirank_equals_single_rank(world, reference, tmp_path):
+    parts = run_world(world, tmp_path)
+    # panels tile the columns in rank order
+    assert parts[0]["c0"] == 0 and all(parts[r]["c1"] == parts[r + 1]["c0"] for r in range(world - 1))
+    for tag in ("AB", "ABT", "GG", "K"):
+        got = cat(parts, tag)
+        want = tuple(reference[tag + s] for s in ("_col", "_row", "_val"))
+        if tag == "K":   # solver result: same iterations, entries equal up to reduction-order effects on sigma
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+            assert np.allclose(got[2], want[2], rtol=0, atol=1e-10)
+        else:
+            assert all(np.array_equal(g, w) for g, w in zip(got, want)), tag
+    for r in range(world):
+        for s in ("AB_trace", "AB_norm", "AB_dot", "trs2_energy", "trs2_mu"):
+            assert parts[r][s] == pytest.approx(float(reference[s]), rel=1e-12, abs=1e-12), (s, r)
+        assert parts[r]["trs2_iters"] == reference["trs2_iters"]
+        assert np.allclose(parts[r]["trs2_log"], reference["trs2_log"], rtol=1e-12, atol=1e-12)
