@@ -93,13 +93,12 @@ def main():
 
     import ntpoly_amd as nt
     from gen import banded_triplets
-    rank, world = nt.init_comm_from_torch()
+    # one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from the launcher); the engine owns its RCCL
+    # communicator and torch is not imported: its wheel bundles a second HIP runtime, and two runtimes in one process
+    # corrupt the heap at exit
+    rank, world = nt.init_comm_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist  # gloo control plane; the data plane is the engine's RCCL
 
     n, h, thr = args.n, args.halfband, args.threshold
     nt.ConstructGlobalProcessGrid(1, world, 1)  # column panels: one per GPU
@@ -129,8 +128,8 @@ def main():
         # device synchronise (stream + hipDeviceSynchronize inside the engine's own HIP runtime: the same
         # thing torch.cuda.synchronize() does for torch's), then a barrier over all ranks
         nt.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if world > 1:
+            nt.barrier()
             nt.synchronize()
 
     energy, tr_x = 0.0, None
@@ -144,10 +143,8 @@ def main():
         _, energy, tr_x = trs2_step(nt, X, X2, H, pool, trace_target, thr, tr_x)
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if world > 1:
+        elapsed = nt.allreduce_max(elapsed)
     acc = nt.spgemm_accum()
     st = nt.last_spgemm_stats()
     nnz_x = X.GetSize()
@@ -207,9 +204,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, h, thr, args.warmup, args.steps)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if world > 1:
+        nt.barrier()
 
 
 if __name__ == "__main__":

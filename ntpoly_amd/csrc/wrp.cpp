@@ -52,6 +52,8 @@ void ntpoly_amd_finalize_comm() { comm_finalize(); }
 int ntpoly_amd_comm_rank() { return world().rank; }
 int ntpoly_amd_comm_size() { return world().nranks; }
 void ntpoly_amd_barrier() { comm_barrier(); }
+// max over all ranks of n host doubles, in place (timing of a distributed region: the slowest rank counts)
+void ntpoly_amd_allreduce_max(double* values, const int* n) { comm_allreduce_max(values, *n); }
 void ntpoly_amd_synchronize() {
   ensure_init();
   sync_stream();

@@ -69,6 +69,50 @@ def init_comm_from_torch():
     return rank, world
 
 
+def init_comm_from_env(timeout=300.0):
+    """One process per GPU under `python -m torch.distributed.run` (or any launcher that sets RANK, WORLD_SIZE,
+    LOCAL_RANK, MASTER_PORT) on ONE node, without importing torch: rank 0 creates the 128-byte RCCL id and hands
+    it to the other ranks through a file in /tmp named after the launcher's pid (all ranks are children of the
+    same launcher) and the master port; the engine then builds its own RCCL communicator and picks its GPU from
+    LOCAL_RANK.  Returns (rank, world_size)."""
+    import os
+    import time
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world <= 1:
+        init_comm()
+        return 0, 1
+    path = "/tmp/ntpoly_amd_rdv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    if rank == 0:
+        uid = get_unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(path + ".tmp", path)
+    else:
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                raise RuntimeError("rendezvous file %s did not appear" % path)
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            uid = f.read()
+    init_comm(uid, rank, world)
+    barrier()
+    if rank == 0:
+        os.unlink(path)
+    return rank, world
+
+
+def barrier():
+    lib.ntpoly_amd_barrier()
+
+
+def allreduce_max(x):
+    v = C.c_double(float(x))
+    lib.ntpoly_amd_allreduce_max(C.byref(v), i(1))
+    return v.value
+
+
 def set_option(name, value):
     lib.ntpoly_amd_set_option(name.encode(), i(value))
 
