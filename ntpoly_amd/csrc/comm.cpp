@@ -257,6 +257,19 @@ void comm_bcast_i32(int32_t* v, int n, int root) {
   sync_stream();
 }
 
+void comm_allgather_i64(const int64_t* mine, int n, int64_t* all) {
+  Comm& c = world();
+  if (!c.active()) {
+    std::memcpy(all, mine, sizeof(int64_t) * (size_t)n);
+    return;
+  }
+  DevBuf<int64_t> d((size_t)n * c.nranks);
+  HIP_CHECK(hipMemcpyAsync(d.p + (size_t)n * c.rank, mine, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, stream()));
+  c.tr->allgather(d.p + (size_t)n * c.rank, d.p, sizeof(int64_t) * (size_t)n);
+  HIP_CHECK(hipMemcpyAsync(all, d.p, sizeof(int64_t) * (size_t)n * c.nranks, hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+}
+
 void comm_barrier() {
   double x = 0;
   comm_allreduce_sum(&x, 1);

@@ -43,6 +43,7 @@ void comm_allreduce_min(double* host_vals, int n);
 void comm_allreduce_max(double* host_vals, int n);
 void comm_allreduce_sum_i64(int64_t* host_vals, int n);
 void comm_bcast_i32(int32_t* host_vals, int n, int root);
+void comm_allgather_i64(const int64_t* mine, int n, int64_t* all /* n * nranks */);
 void comm_barrier();
 
 // ProcessGrid_t (ProcessGridModule.F90:15-56).  The reference's rows x columns x slices shape is
@@ -79,6 +80,12 @@ void ps_fill_permutation(PSMatrix& m, const std::vector<int32_t>& lookup /*1-bas
 void ps_fill_from_triplets(PSMatrix& m, const HostTriplets& t);
 void ps_get_triplets(const PSMatrix& m, HostTriplets& t);
 int64_t ps_size(const PSMatrix& m);
+// PSMatrixModule utilities on the caller side of the path (triplet based, as in the reference)
+void ps_fill_dense(PSMatrix& m);                                          // FillMatrixDense: every element 1
+void ps_diagonal_scale(PSMatrix& m, const HostTriplets& t);               // MatrixDiagonalScale: column col *= value
+void ps_get_block(const PSMatrix& m, int sr, int er, int sc, int ec, HostTriplets& out);  // [sr,er) x [sc,ec), 1-based
+void ps_get_slice(const PSMatrix& m, PSMatrix& sub, int sr, int er, int sc, int ec);      // inclusive bounds, 1-based
+void ps_resize(PSMatrix& m, int new_size);
 void ps_to_complex(const PSMatrix& a, PSMatrix& out);
 void ps_to_real(const PSMatrix& a, PSMatrix& out);
 DevMat ps_gather_full(const PSMatrix& m);  // every rank gets the whole matrix (dim x dim)
@@ -172,6 +179,11 @@ struct SolverTrace {
 };
 SolverTrace& last_trace();
 // one TRS2 iteration (DensityMatrixSolversModule.F90:380-404): returns the energy, sets sigma
+// DensityMatrixSolversModule.F90:953-1117, :1165-1187, :1190-1231
+void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double homo, double lumo,
+                           double* energy_out, const SolverParameters& p);
+void energy_density_matrix(const PSMatrix& H, const PSMatrix& D, PSMatrix& ED, double threshold);
+void mcweeny_step(const PSMatrix& D, PSMatrix& DOut, const PSMatrix* S, double threshold);
 double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_target, double threshold, double* sigma,
                  double* trace_io = nullptr);
 

@@ -3203,6 +3203,27 @@ void scale(DevMat& A, double c) {
   hipLaunchKernelGGL(k_scale, dim3(std::min(cdiv(n, 256), 8192)), dim3(256), 0, stream(), A.val.p, n, c);
 }
 
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_columns(const int64_t* __restrict__ outer, T* __restrict__ val,
+                                                       const T* __restrict__ factor, int cols) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= cols) return;
+  const T f = factor[j];
+  for (int64_t p = outer[j] + lane_id(); p < outer[j + 1]; p += WAVE) val[p] = Sc<T>::mul(f, val[p]);
+}
+}  // namespace
+
+// values of column j *= factor[j] (factor: cols scalars of the matrix' type, device memory)
+void scale_columns(DevMat& A, const double* d_factor) {
+  if (A.nnz == 0) return;
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_scale_columns<T>), dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.outer.p,
+                       reinterpret_cast<T*>(A.val.p), reinterpret_cast<const T*>(d_factor), A.cols);
+  });
+}
+
 void conjugate(DevMat& A) {
   if (!A.cplx || A.nnz == 0) return;
   hipLaunchKernelGGL(k_conj, dim3(std::min(cdiv(A.nnz, 256), 8192)), dim3(256), 0, stream(), A.val.p, A.nnz);

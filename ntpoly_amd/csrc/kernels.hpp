@@ -63,6 +63,8 @@ double max_of(const DevBuf<double>& v, size_t n);
 void gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx);
 void scale(DevMat& A, double c);
 void conjugate(DevMat& A);
+// values of column j *= factor[j] (cols scalars of the matrix' scalar type in device memory)
+void scale_columns(DevMat& A, const double* d_factor);
 DevMat to_complex(const DevMat& A);
 DevMat to_real(const DevMat& A);
 // identity restricted to local columns [col_offset, col_offset+cols) of an n x n matrix

@@ -161,6 +161,123 @@ void ps_fill_from_triplets(PSMatrix& m, const HostTriplets& t) {
 
 void ps_get_triplets(const PSMatrix& m, HostTriplets& t) { to_triplets(m.loc, m.c0, t); }
 
+// FillMatrixDense (PSMatrixModule.F90:958-990, distributed_includes/FillMatrixDense.f90): every element of the
+// local panel is 1; dense by definition, so the O(dim * width) host triplets are what the caller asked for
+void ps_fill_dense(PSMatrix& m) {
+  HostTriplets t;
+  t.cplx = m.cplx;
+  const size_t w = m.cplx ? 2 : 1;
+  const size_t n = (size_t)m.dim * (size_t)(m.c1 - m.c0);
+  t.col.reserve(n); t.row.reserve(n); t.val.reserve(n * w);
+  for (int32_t c = m.c0; c < m.c1; ++c)
+    for (int32_t r = 0; r < m.dim; ++r) {
+      t.col.push_back(c + 1);
+      t.row.push_back(r + 1);
+      t.val.push_back(1.0);
+      if (m.cplx) t.val.push_back(0.0);
+    }
+  m.loc = from_triplets(t, m.dim, m.c1 - m.c0, m.c0);
+}
+
+// MatrixDiagonalScale (PSMatrixAlgebraModule.F90:507-532, ScaleDiagonal.f90, sparse_includes/DiagonalScale.f90):
+// for every triplet whose column is stored here, the values of that column are multiplied by its value
+void ps_diagonal_scale(PSMatrix& m, const HostTriplets& t) {
+  const int32_t width = m.c1 - m.c0;
+  if (width == 0) return;
+  const size_t w = m.cplx ? 2 : 1;
+  std::vector<double> f((size_t)width * w, 0.0);
+  for (int32_t j = 0; j < width; ++j) f[(size_t)j * w] = 1.0;
+  for (size_t i = 0; i < t.size(); ++i) {
+    const int32_t col = t.col[i] - 1;
+    if (col < m.c0 || col >= m.c1) continue;
+    double re, im = 0.0;
+    if (t.cplx) { re = t.val[2 * i]; im = t.val[2 * i + 1]; } else { re = t.val[i]; }
+    // several triplets naming the same column multiply one after the other, as the reference loop does
+    double& fr = f[(size_t)(col - m.c0) * w];
+    if (m.cplx) {
+      double& fi = f[(size_t)(col - m.c0) * w + 1];
+      const double nr = fr * re - fi * im, ni = fr * im + fi * re;
+      fr = nr; fi = ni;
+    } else {
+      fr *= re;
+    }
+  }
+  DevBuf<double> d(f.size());
+  d.upload(f.data(), f.size());
+  scale_columns(m.loc, d.p);
+  sync_stream();  // f / d go out of scope
+}
+
+// GetMatrixBlock (PSMatrixModule.F90:1036-1150, distributed_includes/GetMatrixBlock.f90): every rank names a block
+// [start_row, end_row) x [start_column, end_column) (1-based) and receives its entries with absolute coordinates;
+// an entry goes to the FIRST rank whose block contains it (the EXIT in the reference's routing loop)
+void ps_get_block(const PSMatrix& m, int sr, int er, int sc, int ec, HostTriplets& out) {
+  const int P = world().active() ? world().nranks : 1, me = world().active() ? world().rank : 0;
+  std::vector<int64_t> box((size_t)4 * P);
+  const int64_t mine[4] = {sr, er, sc, ec};
+  comm_allgather_i64(mine, 4, box.data());
+  DevMat full = ps_gather_full(m);
+  HostTriplets all;
+  to_triplets(full, 0, all);
+  out = HostTriplets();
+  out.cplx = m.cplx;
+  const size_t w = m.cplx ? 2 : 1;
+  for (size_t i = 0; i < all.size(); ++i) {
+    const int r = all.row[i], c = all.col[i];
+    for (int p = 0; p < P; ++p) {
+      if (r >= box[(size_t)4 * p] && r < box[(size_t)4 * p + 1] && c >= box[(size_t)4 * p + 2] && c < box[(size_t)4 * p + 3]) {
+        if (p == me) {
+          out.col.push_back(c);
+          out.row.push_back(r);
+          for (size_t k = 0; k < w; ++k) out.val.push_back(all.val[i * w + k]);
+        }
+        break;
+      }
+    }
+  }
+}
+
+// GetMatrixSlice (PSMatrixModule.F90:1153-1225, distributed_includes/SliceMatrix.f90): inclusive bounds, result of
+// dimension max(rows, columns) of the slice on the same grid
+void ps_get_slice(const PSMatrix& m, PSMatrix& sub, int sr, int er, int sc, int ec) {
+  HostTriplets t, s;
+  ps_get_triplets(m, t);
+  s.cplx = m.cplx;
+  const size_t w = m.cplx ? 2 : 1;
+  for (size_t i = 0; i < t.size(); ++i) {
+    if (t.row[i] >= sr && t.row[i] <= er && t.col[i] >= sc && t.col[i] <= ec) {
+      s.row.push_back(t.row[i] - sr + 1);
+      s.col.push_back(t.col[i] - sc + 1);
+      for (size_t k = 0; k < w; ++k) s.val.push_back(t.val[i * w + k]);
+    }
+  }
+  const int new_dim = std::max(er - sr + 1, ec - sc + 1);
+  const ProcessGrid* g = m.grid;
+  const bool cplx = m.cplx;
+  ps_construct_empty(sub, new_dim, g, cplx);
+  ps_fill_from_triplets(sub, s);
+}
+
+// ResizeMatrix (PSMatrixModule.F90:1704-1741, distributed_includes/ResizeMatrix.f90): entries beyond the new size
+// are dropped
+void ps_resize(PSMatrix& m, int new_size) {
+  HostTriplets t, s;
+  ps_get_triplets(m, t);
+  s.cplx = m.cplx;
+  const size_t w = m.cplx ? 2 : 1;
+  for (size_t i = 0; i < t.size(); ++i) {
+    if (t.row[i] <= new_size && t.col[i] <= new_size) {
+      s.row.push_back(t.row[i]);
+      s.col.push_back(t.col[i]);
+      for (size_t k = 0; k < w; ++k) s.val.push_back(t.val[i * w + k]);
+    }
+  }
+  const ProcessGrid* g = m.grid;
+  const bool cplx = m.cplx;
+  ps_construct_empty(m, new_size, g, cplx);
+  ps_fill_from_triplets(m, s);
+}
+
 int64_t ps_size(const PSMatrix& m) {  // GetMatrixSize (PSMatrixModule.F90:1360-1389)
   int64_t n = m.loc.nnz;
   comm_allreduce_sum_i64(&n, 1);

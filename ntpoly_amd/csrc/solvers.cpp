@@ -308,6 +308,92 @@ void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
 }
 
 // ------------------------------------------------------------------ TRS4
+// ------------------------------------------------------------------ ScaleAndFold
+// DensityMatrixSolversModule.F90:953-1117 (rubensson2011nonmonotonic): like TRS2 with the polynomials scaled by the
+// running estimates Beta / BetaBar of where lumo and homo have moved to
+void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double homo, double lumo,
+                           double* energy_out, const SolverParameters& p) {
+  trace_reset();
+  auto t0 = Clock::now();
+  Monitor mon;
+  monitor_construct(mon, p.monitor_convergence, p.converge_diff);
+  density_header("Scale and Fold", "rubensson2011nonmonotonic", p);
+  PSMatrix WH, IMat, ISQT, X, X2;
+  double e_min, e_max;
+  density_setup(H, ISQ, p, IMat, ISQT, WH, &e_min, &e_max);       // :1022-1034
+  ps_copy(WH, X);                                                  // :1036-1039
+  ps_scale(X, -1.0);
+  ps_increment(IMat, X, e_max, 0.0);
+  ps_scale(X, 1.0 / (e_max - e_min));
+  double Beta = (e_max - lumo) / (e_max - e_min);
+  double BetaBar = (e_max - homo) / (e_max - e_min);
+  if (p.be_verbose) {
+    log_header("Iterations");
+    log_enter();
+  }
+  last_trace().setup_ms = ms_since(t0);
+  auto t1 = Clock::now();
+  double energy_value = 0.0, energy_old;
+  int II;
+  for (II = 1; II <= p.max_iterations; ++II) {                     // :1049-1081
+    const double trace_value = ps_trace(X);
+    double alpha;
+    if (trace_value > trace) {
+      alpha = 2.0 / (2.0 - Beta);
+      ps_scale(X, alpha);
+      ps_increment(IMat, X, 1.0 - alpha, 0.0);
+      ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
+      std::swap(X.loc, X2.loc);  // CopyMatrix(X_k2, X_k); X2 is scratch
+      Beta = (alpha * Beta + 1 - alpha) * (alpha * Beta + 1 - alpha);
+      BetaBar = (alpha * BetaBar + 1 - alpha) * (alpha * BetaBar + 1 - alpha);
+    } else {
+      alpha = 2.0 / (1.0 + BetaBar);
+      ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
+      ps_scale(X, 2 * alpha);
+      ps_increment(X2, X, -1.0 * alpha * alpha, 0.0);
+      Beta = 2.0 * alpha * Beta - alpha * alpha * Beta * Beta;
+      BetaBar = 2.0 * alpha * BetaBar - alpha * alpha * BetaBar * BetaBar;
+    }
+    energy_old = energy_value;
+    energy_value = 2.0 * real_dot(X, WH);
+    monitor_append(mon, energy_value - energy_old);
+    trace_rec(energy_value - energy_old, energy_value, trace_value > trace ? -1.0 : 1.0, X);
+    if (monitor_converged(mon, p.be_verbose)) break;
+    if (p.be_verbose) {
+      log_enter();
+      log_element("Energy Value", energy_value);
+      log_exit();
+    }
+  }
+  last_trace().loop_ms = ms_since(t1);
+  if (p.be_verbose) {
+    log_exit();
+    log_element("Total Iterations", II);
+    print_matrix_information(X);
+  }
+  if (energy_out) *energy_out = energy_value;
+  density_finish(X, ISQT, ISQ, K, p);                              // :1095-1101
+  if (p.be_verbose) log_exit();
+}
+
+// EnergyDensityMatrix (:1165-1187): ED = D H D
+void energy_density_matrix(const PSMatrix& H, const PSMatrix& D, PSMatrix& ED, double threshold) {
+  ps_similarity(H, D, D, ED, threshold);
+}
+
+// McWeenyStep (:1190-1231): DOut = 3 DSD - 2 DSDSD
+void mcweeny_step(const PSMatrix& D, PSMatrix& DOut, const PSMatrix* S, double threshold) {
+  PSMatrix DS, DSD;
+  if (S) ps_multiply(D, *S, DS, 1.0, 0.0, threshold);
+  else ps_copy(D, DS);
+  ps_multiply(DS, D, DSD, 1.0, 0.0, threshold);
+  PSMatrix Out;
+  ps_multiply(DS, DSD, Out, -2.0, 0.0, threshold);
+  ps_increment(DSD, Out, 3.0, 0.0);
+  DOut.grid = Out.grid; DOut.dim = Out.dim; DOut.cplx = Out.cplx; DOut.c0 = Out.c0; DOut.c1 = Out.c1;
+  DOut.loc = std::move(Out.loc);
+}
+
 void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                  const SolverParameters& p) {
   trace_reset();

@@ -452,6 +452,53 @@ void FillMatrixIdentity_ps_wrp(int* ih_this) { ps_fill_identity(*get<PSMatrix>(i
 void GetMatrixActualDimension_ps_wrp(const int* ih_this, int* size) { *size = get<PSMatrix>(ih_this)->dim; }
 void GetMatrixLogicalDimension_ps_wrp(const int* ih_this, int* size) { *size = get<PSMatrix>(ih_this)->dim; }
 void GetMatrixSize_ps_wrp(const int* ih_this, long int* size) { *size = (long int)ps_size(*get<PSMatrix>(ih_this)); }
+// PSMatrix_c.h:31 (wrapper PSMatrixModule_wrp.F90:259-266)
+void FillMatrixDense_ps_wrp(int* ih_this) { ps_fill_dense(*get<PSMatrix>(ih_this)); }
+// PSMatrix_c.h:37-44 (wrapper :344-391): blocks are [start, end) with 1-based indices, slices are inclusive
+void GetMatrixBlock_psr_wrp(const int* ih_this, int* ih_triplet_list, int* start_row, int* end_row, int* start_column,
+                            int* end_column) {
+  const PSMatrix* m = get<PSMatrix>(ih_this);
+  HostTriplets* t = get<HostTriplets>(ih_triplet_list);
+  if (m->cplx) {
+    PSMatrix r;
+    ps_to_real(*m, r);
+    ps_get_block(r, *start_row, *end_row, *start_column, *end_column, *t);
+  } else {
+    ps_get_block(*m, *start_row, *end_row, *start_column, *end_column, *t);
+  }
+}
+void GetMatrixBlock_psc_wrp(const int* ih_this, int* ih_triplet_list, int* start_row, int* end_row, int* start_column,
+                            int* end_column) {
+  const PSMatrix* m = get<PSMatrix>(ih_this);
+  HostTriplets* t = get<HostTriplets>(ih_triplet_list);
+  if (!m->cplx) {
+    PSMatrix c;
+    ps_to_complex(*m, c);
+    ps_get_block(c, *start_row, *end_row, *start_column, *end_column, *t);
+  } else {
+    ps_get_block(*m, *start_row, *end_row, *start_column, *end_column, *t);
+  }
+}
+void GetMatrixSlice_wrp(const int* ih_this, int* ih_submatrix, int* start_row, int* end_row, int* start_column,
+                        int* end_column) {
+  ps_get_slice(*get<PSMatrix>(ih_this), *get<PSMatrix>(ih_submatrix), *start_row, *end_row, *start_column, *end_column);
+}
+// PSMatrix_c.h:48 (wrapper :417-425)
+void ResizeMatrix_ps_wrp(int* ih_this, const int* new_size) { ps_resize(*get<PSMatrix>(ih_this), *new_size); }
+// PSMatrix_c.h:67-68 (wrapper PSMatrixAlgebraModule_wrp.F90)
+void MatrixDiagonalScale_psr_wrp(int* ih_mat, const int* ih_tlist) {
+  ps_diagonal_scale(*get<PSMatrix>(ih_mat), *get<HostTriplets>(ih_tlist));
+}
+void MatrixDiagonalScale_psc_wrp(int* ih_mat, const int* ih_tlist) {
+  PSMatrix* m = get<PSMatrix>(ih_mat);
+  if (!m->cplx) {  // a complex diagonal turns the matrix complex, as ScaleMatrix_psc does (PSMatrixAlgebraModule.F90:486-504)
+    PSMatrix c;
+    ps_to_complex(*m, c);
+    m->cplx = true;
+    m->loc = std::move(c.loc);
+  }
+  ps_diagonal_scale(*m, *get<HostTriplets>(ih_tlist));
+}
 void GetMatrixTripletList_psr_wrp(const int* ih_this, int* ih_triplet_list) {
   const PSMatrix* m = get<PSMatrix>(ih_this);
   HostTriplets* t = get<HostTriplets>(ih_triplet_list);
@@ -547,6 +594,37 @@ DENSITY_SOLVER(PM_wrp, solver_pm)
 DENSITY_SOLVER(TRS2_wrp, solver_trs2)
 DENSITY_SOLVER(TRS4_wrp, solver_trs4)
 DENSITY_SOLVER(HPCP_wrp, solver_hpcp)
+// DensityMatrixSolvers_c.h:24-28 (wrapper DensityMatrixSolversModule_wrp.F90:129-153)
+void ScaleAndFold_wrp(const int* ih_Hamiltonian, const int* ih_InverseSquareRoot, const double* trace, int* ih_Density,
+                      const double* homo, const double* lumo, const double* energy_value_out,
+                      const int* ih_solver_parameters) {
+  solver_scale_and_fold(*get<PSMatrix>(ih_Hamiltonian), *get<PSMatrix>(ih_InverseSquareRoot), *trace,
+                        *get<PSMatrix>(ih_Density), *homo, *lumo, const_cast<double*>(energy_value_out),
+                        *get<SolverParameters>(ih_solver_parameters));
+}
+// DensityMatrixSolvers_c.h:34-38 (wrapper :183-231)
+void EnergyDensityMatrix_wrp(const int* ih_Hamiltonian, const int* ih_Density, int* ih_EnergyDensity, const double* threshold) {
+  energy_density_matrix(*get<PSMatrix>(ih_Hamiltonian), *get<PSMatrix>(ih_Density), *get<PSMatrix>(ih_EnergyDensity), *threshold);
+}
+void McWeenyStep_wrp(const int* ih_D, int* ih_DOut, const double* threshold) {
+  mcweeny_step(*get<PSMatrix>(ih_D), *get<PSMatrix>(ih_DOut), nullptr, *threshold);
+}
+void McWeenyStepS_wrp(const int* ih_D, int* ih_DOut, const int* ih_S, const double* threshold) {
+  mcweeny_step(*get<PSMatrix>(ih_D), *get<PSMatrix>(ih_DOut), get<PSMatrix>(ih_S), *threshold);
+}
+// The dense eigensolver paths of the reference (DenseDensity, DenseSquareRoot, DenseInverseSquareRoot: gather to a
+// dense matrix + LAPACK/EigenExa, EigenSolversModule) are outside this engine's scope.  The
+// symbols exist so that the reference's C++ layer links unchanged; calling them ends the run like the reference's
+// own fatal paths (ErrorModule.F90:193-205) -- there is no silent CPU fallback.
+void DenseDensity_wrp(const int*, const int*, const double*, int*, const double*, const double*, const int*) {
+  NTP_FATAL("DenseDensity: the dense eigensolver path is not part of the MI355X engine; use TRS2/TRS4/PM/HPCP/ScaleAndFold");
+}
+void DenseSquareRoot_wrp(const int*, int*, const int*) {
+  NTP_FATAL("DenseSquareRoot: the dense eigensolver path is not part of the MI355X engine; use SquareRoot");
+}
+void DenseInverseSquareRoot_wrp(const int*, int*, const int*) {
+  NTP_FATAL("DenseInverseSquareRoot: the dense eigensolver path is not part of the MI355X engine; use InverseSquareRoot");
+}
 
 void SignFunction_wrp(const int* ih_mat1, int* ih_signmat, const int* ih_solver_parameters) {
   solver_sign(*get<PSMatrix>(ih_mat1), *get<PSMatrix>(ih_signmat), *get<SolverParameters>(ih_solver_parameters));

@@ -30,7 +30,7 @@ PROGRAM RefDriver
   USE SolverParametersModule, ONLY : SolverParameters_t, &
        & ConstructSolverParameters
   USE PermutationModule, ONLY : Permutation_t, ConstructDefaultPermutation
-  USE DensityMatrixSolversModule, ONLY : TRS2, TRS4, PM, HPCP
+  USE DensityMatrixSolversModule, ONLY : TRS2, TRS4, PM, HPCP, ScaleAndFold
   USE SignSolversModule, ONLY : SignFunction, PolarDecomposition
   USE InverseSolversModule, ONLY : Invert, PseudoInverse
   USE SquareRootSolversModule, ONLY : InverseSquareRoot, SquareRoot
@@ -378,8 +378,18 @@ CONTAINS
     CALL DestructProcessGrid
   END SUBROUTINE cmd_pscalars
 
+  FUNCTION env_real(name) RESULT(v)
+    CHARACTER(len=*), INTENT(IN) :: name
+    REAL(NTREAL) :: v
+    CHARACTER(len=64) :: buf
+    INTEGER :: stat
+    CALL GET_ENVIRONMENT_VARIABLE(name, buf, STATUS=stat)
+    v = 0
+    IF (stat .EQ. 0) READ(buf, *) v
+  END FUNCTION env_real
+
   !! solve pr pc ps <solver> H ISQ|identity|none trace thr conv maxit monitor out log scal.txt
-  !!   solver in {trs2, trs4, pm, hpcp, sign, polar, invert, pinv, isq, sqrt}
+  !!   solver in {trs2, trs4, pm, hpcp, scalefold, sign, polar, invert, pinv, isq, sqrt}
   SUBROUTINE cmd_solve()
     TYPE(Matrix_ps) :: H, ISQ, K
     TYPE(SolverParameters_t) :: sp
@@ -414,6 +424,9 @@ CONTAINS
     CASE("hpcp")
        CALL HPCP(H, ISQ, rarg(8), K, energy_value_out=energy, &
             & chemical_potential_out=mu, solver_parameters_in=sp)
+    CASE("scalefold")   ! homo / lumo estimates come through the environment (REF_HOMO, REF_LUMO)
+       CALL ScaleAndFold(H, ISQ, rarg(8), K, env_real("REF_HOMO"), env_real("REF_LUMO"), &
+            & energy_value_out=energy, solver_parameters_in=sp)
     CASE("pinv")
        CALL PseudoInverse(H, K, sp)
     CASE("polar")

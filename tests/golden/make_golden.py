@@ -383,6 +383,34 @@ def gen_solvers_extra(tmp):
     save("solvers_extra", d, dict(kind="solvers_extra", cases=cases))
 
 
+def gen_scalefold(tmp):
+    """ScaleAndFold (DensityMatrixSolversModule.F90:953-1117): needs estimates of homo and lumo; taken from the
+    dense spectrum with a margin inside the gap, handed to the driver through the environment."""
+    d, cases = {}, []
+    for (n, h, nel, thr, tag) in ((256, 12, 128.0, 1e-8, "banded256_scalefold"), (192, 8, 60.0, 0.0, "banded192_scalefold_thr0")):
+        H = banded(n, h)
+        ev = np.linalg.eigvalsh(H.toarray())
+        k = int(nel)
+        gap = ev[k] - ev[k - 1]
+        homo, lumo = ev[k - 1] + 0.05 * gap, ev[k] - 0.05 * gap
+        write_tri(tmp + "/H.tri", n, n, *tri(H))
+        ENV["REF_HOMO"], ENV["REF_LUMO"] = repr(float(homo)), repr(float(lumo))
+        run(["solve", 1, 1, 1, "scalefold", tmp + "/H.tri", "identity", repr(nel), repr(thr), repr(1e-6), 1000, 1,
+             tmp + "/K.tri", tmp + "/log.yaml", tmp + "/s.txt"])
+        rows, cols, c, r, v = read_tri(tmp + "/K.tri")
+        sc = {kk: float(x) for kk, x in (ln.split() for ln in open(tmp + "/s.txt"))}
+        lc, le, total = parse_log(tmp + "/log.yaml")
+        pre = "c%03d_" % len(cases)
+        put(d, pre + "H", H.shape, tri(H))
+        put(d, pre + "K", (rows, cols), (c, r, v))
+        d[pre + "log_convergence"] = np.array(lc)
+        d[pre + "log_energy"] = np.array(le)
+        cases.append(dict(tag=tag, solver="scalefold", nel=nel, thr=thr, conv=1e-6, maxit=1000, monitor=True,
+                          isq="identity", homo=float(homo), lumo=float(lumo), energy=sc["energy"], nnz=int(sc["nnz"]),
+                          total_iterations_logged=total))
+    save("solvers_scalefold", d, dict(kind="solvers_scalefold", cases=cases))
+
+
 def gen_multirank(tmp):
     """Same product on 1, 4 (2x2x1) and 8 (2x2x2) reference ranks: pins that values do not
     depend on the grid when slices == 1 and records the slices>1 behaviour."""
@@ -424,6 +452,7 @@ def main():
                 globals()["gen_" + name](tmp)
             return
         gen_solvers_extra(tmp)
+        gen_scalefold(tmp)
         gen_local_gemm(tmp)
         gen_local_increment(tmp)
         gen_ps(tmp)

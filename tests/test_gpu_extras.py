@@ -240,3 +240,125 @@ def test_fused_trs2_step_equals_call_sequence(nt, cplx, force_seq):
             assert all(np.array_equal(u, v) for u, v in zip(ta, tb)), it
     finally:
         nt.set_option("increment_force_seq", 0)
+
+
+def test_reference_cxx_example_links_and_runs(tmp_path):
+    """Drop-in at the reference's own C++ layer: oracle/_ref/premade_cxx is the reference's UNCHANGED
+    Source/CPlusPlus classes + Examples/PremadeMatrix/main.cc, compiled where they lie and linked against
+    libntpoly_amd.so (oracle/build_cxx_example.py; built only where /root/reference exists, travels as a built
+    file).  Run here as the reference's ReadMe runs it, on the reference's Hamiltonian / Overlap, it must reproduce
+    the reference's shipped density (nel = 5)."""
+    import subprocess
+    import scipy.io
+    import scipy.sparse as sp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "premade_cxx")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/premade_cxx was not built (needs /root/reference at build time)")
+    g = Golden("solvers")
+    i_h = [i for i, c in enumerate(g.cases) if c["tag"] == "premade_trs2_nel5"][0]
+    i_s = [i for i, c in enumerate(g.cases) if c["tag"] == "premade_isq"][0]
+    for name, t in (("Hamiltonian.mtx", g.tri(i_h, "H")), ("Overlap.mtx", g.tri(i_s, "H"))):
+        m = sp.coo_matrix((t[4], (t[3] - 1, t[2] - 1)), shape=(t[0], t[1]))
+        scipy.io.mmwrite(str(tmp_path / name), m)
+    out = tmp_path / "Density.mtx"
+    r = subprocess.run([exe, "--process_rows", "1", "--process_columns", "1", "--process_slices", "1",
+                        "--hamiltonian", str(tmp_path / "Hamiltonian.mtx"), "--overlap", str(tmp_path / "Overlap.mtx"),
+                        "--number_of_electrons", "5", "--threshold", "1e-6", "--converge_overlap", "1e-3",
+                        "--converge_density", "1e-5", "--density", str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "Density Matrix Solver" in r.stdout and "TRS2" in r.stdout     # the reference's log format, from our logger
+    D = scipy.io.mmread(str(out)).toarray()
+    Dref = to_dense(g.tri(None, "premade_density_reference"))
+    assert np.linalg.norm(D - Dref) <= 5e-5
+
+
+def test_utilities_for_the_cxx_layer(nt):
+    """FillMatrixDense, MatrixDiagonalScale, GetMatrixBlock, GetMatrixSlice, ResizeMatrix, McWeenyStep(S),
+    EnergyDensityMatrix against numpy on a small banded matrix (semantics: PSMatrixModule.F90:958-990, 1036-1225,
+    1704-1741, PSMatrixAlgebraModule.F90:507-532, DensityMatrixSolversModule.F90:1165-1231)."""
+    import ctypes as C
+    from gen import banded_triplets
+    from ntpoly_amd.capi import i, d
+    n, h = 60, 4
+    col, row, val = banded_triplets(n, h)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    Ad = A.to_scipy().toarray()
+    # dense fill
+    F = nt.Matrix_ps(9)
+    nt.lib.FillMatrixDense_ps_wrp(F.ih)
+    assert np.array_equal(F.to_scipy().toarray(), np.ones((9, 9)))
+    # diagonal scale: column c *= value
+    B = nt.Matrix_ps(A)
+    t = nt.TripletList_r()
+    t.set_arrays(np.array([3, 10, 60], dtype=np.int32), np.array([3, 10, 60], dtype=np.int32), np.array([2.0, -0.5, 3.0]))
+    nt.lib.MatrixDiagonalScale_psr_wrp(B.ih, t.ih)
+    want = Ad.copy()
+    want[:, 2] *= 2.0
+    want[:, 9] *= -0.5
+    want[:, 59] *= 3.0
+    assert np.array_equal(B.to_scipy().toarray(), want)
+    # block [5, 20) x [8, 30), absolute coordinates
+    tb = nt.TripletList_r()
+    nt.lib.GetMatrixBlock_psr_wrp(A.ih, tb.ih, i(5), i(20), i(8), i(30))
+    c, r, v = tb.arrays()
+    blk = np.zeros((n, n))
+    blk[r - 1, c - 1] = v
+    ref = np.zeros((n, n))
+    ref[4:19, 7:29] = Ad[4:19, 7:29]
+    assert np.array_equal(blk, ref)
+    # slice rows 5..20, columns 8..30 (inclusive) -> dimension max(16, 23)
+    S = nt.Matrix_ps(1)
+    nt.lib.GetMatrixSlice_wrp(A.ih, S.ih, i(5), i(20), i(8), i(30))
+    assert S.GetActualDimension() == 23
+    sd = S.to_scipy().toarray()
+    assert np.array_equal(sd[:16, :23], Ad[4:20, 7:30]) and not sd[16:, :].any()
+    # resize down
+    R = nt.Matrix_ps(A)
+    nt.lib.ResizeMatrix_ps_wrp(R.ih, i(25))
+    assert R.GetActualDimension() == 25 and np.array_equal(R.to_scipy().toarray(), Ad[:25, :25])
+    # McWeeny step and energy-weighted density (threshold 0: plain products)
+    Dm = nt.Matrix_ps(A)
+    Dm.Scale(0.3)
+    Out = nt.Matrix_ps(n)
+    nt.lib.McWeenyStep_wrp(Dm.ih, Out.ih, d(0.0))
+    Dd = 0.3 * Ad
+    assert np.allclose(Out.to_scipy().toarray(), 3 * Dd @ Dd - 2 * Dd @ Dd @ Dd, rtol=1e-13, atol=1e-15)
+    Sm = nt.Matrix_ps(n)
+    Sm.FillIdentity()
+    Sm.Scale(1.5)
+    nt.lib.McWeenyStepS_wrp(Dm.ih, Out.ih, Sm.ih, d(0.0))
+    DS = Dd * 1.5
+    assert np.allclose(Out.to_scipy().toarray(), 3 * DS @ Dd - 2 * DS @ DS @ Dd, rtol=1e-13, atol=1e-15)
+    ED = nt.Matrix_ps(n)
+    nt.lib.EnergyDensityMatrix_wrp(A.ih, Dm.ih, ED.ih, d(0.0))
+    assert np.allclose(ED.to_scipy().toarray(), Dd @ Ad @ Dd, rtol=1e-13, atol=1e-15)
+
+
+def test_scale_and_fold_golden(nt):
+    """ScaleAndFold_wrp against the reference's own run (tests/golden/solvers_scalefold.npz, made by
+    make_golden.py scalefold from oracle/_ref): same iteration count, per-iteration energies, energy, density."""
+    import ctypes as C
+    from ntpoly_amd.capi import d
+    g = Golden("solvers_scalefold")
+    for i, c in enumerate(g.cases):
+        H = pmat(nt, g.tri(i, "H"))
+        n = g.tri(i, "H")[0]
+        ISQ = nt.Matrix_ps(n)
+        ISQ.FillIdentity()
+        K = nt.Matrix_ps(n)
+        p = _params(nt, c)
+        e = C.c_double()
+        nt.lib.ScaleAndFold_wrp(H.ih, ISQ.ih, d(c["nel"]), K.ih, d(c["homo"]), d(c["lumo"]), C.byref(e), p.ih)
+        tr = nt.solver_trace()
+        log_e = g.arr(i, "log_energy")
+        assert tr["iterations"] in (len(log_e), len(log_e) + 1), (c["tag"], tr["iterations"], len(log_e))
+        assert np.allclose(tr["energy"][:len(log_e)], log_e, rtol=1e-11, atol=1e-11), c["tag"]
+        assert e.value == pytest.approx(c["energy"], rel=1e-11), c["tag"]
+        want = g.tri(i, "K")
+        got = K.triplets()
+        gd = to_dense((want[0], want[1]) + tuple(got))
+        wd = to_dense(want)
+        tol = max(10 * c["thr"], 1e-10) * max(1.0, np.abs(wd).max())
+        assert np.abs(gd - wd).max() <= tol, c["tag"]
