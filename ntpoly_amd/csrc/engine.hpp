@@ -179,6 +179,12 @@ struct SolverTrace {
 };
 SolverTrace& last_trace();
 // one TRS2 iteration (DensityMatrixSolversModule.F90:380-404): returns the energy, sets sigma
+// matrix polynomials (solvers_poly.cpp): coefficient i of the vector multiplies x^i / T_i(x) / H_i(x)
+void polynomial_horner(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p);
+void polynomial_paterson_stockmeyer(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p);
+void chebyshev_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p);
+void chebyshev_factorized(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p);
+void hermite_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p);
 // DensityMatrixSolversModule.F90:953-1117, :1165-1187, :1190-1231
 void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double homo, double lumo,
                            double* energy_out, const SolverParameters& p);

@@ -626,6 +626,43 @@ void DenseInverseSquareRoot_wrp(const int*, int*, const int*) {
   NTP_FATAL("DenseInverseSquareRoot: the dense eigensolver path is not part of the MI355X engine; use InverseSquareRoot");
 }
 
+// ---- matrix polynomials: Polynomial_c.h:4-13, ChebyshevSolvers_c.h:4-15, HermiteSolvers_c.h:4-11
+// (wrappers PolynomialSolversModule_wrp.F90:27-90, ChebyshevSolversModule_wrp.F90, HermiteSolversModule_wrp.F90).
+// A polynomial handle holds `degree` coefficients; SetCoefficient takes a 1-based position (the C++ layer adds 1).
+struct PolyHandle {
+  std::vector<double> c;
+};
+#define POLY_FAMILY(CONSTRUCT, DESTRUCT, SETCOEF)                                              \
+  void CONSTRUCT(int* ih_polynomial, const int* degree) {                                      \
+    auto* h = new PolyHandle();                                                                \
+    h->c.assign((size_t)std::max(0, *degree), 0.0);                                            \
+    put(ih_polynomial, h);                                                                     \
+  }                                                                                            \
+  void DESTRUCT(int* ih_polynomial) {                                                          \
+    delete get<PolyHandle>(ih_polynomial);                                                     \
+    std::memset(ih_polynomial, 0, sizeof(int) * SIZE_wrp);                                     \
+  }                                                                                            \
+  void SETCOEF(int* ih_polynomial, const int* degree, const double* coefficient) {             \
+    PolyHandle* h = get<PolyHandle>(ih_polynomial);                                            \
+    if (*degree < 1 || *degree > (int)h->c.size()) NTP_FATAL("SetCoefficient: degree out of range"); \
+    h->c[(size_t)*degree - 1] = *coefficient;                                                  \
+  }
+POLY_FAMILY(ConstructPolynomial_wrp, DestructPolynomial_wrp, SetCoefficient_wrp)
+POLY_FAMILY(ConstructChebyshevPolynomial_wrp, DestructChebyshevPolynomial_wrp, SetChebyshevCoefficient_wrp)
+POLY_FAMILY(ConstructHermitePolynomial_wrp, DestructHermitePolynomial_wrp, SetHermiteCoefficient_wrp)
+#undef POLY_FAMILY
+#define POLY_COMPUTE(NAME, FN)                                                                                   \
+  void NAME(const int* ih_InputMat, int* ih_OutputMat, const int* ih_polynomial, const int* ih_solver_parameters) { \
+    FN(*get<PSMatrix>(ih_InputMat), *get<PSMatrix>(ih_OutputMat), get<PolyHandle>(ih_polynomial)->c,             \
+       *get<SolverParameters>(ih_solver_parameters));                                                            \
+  }
+POLY_COMPUTE(HornerCompute_wrp, polynomial_horner)
+POLY_COMPUTE(PatersonStockmeyerCompute_wrp, polynomial_paterson_stockmeyer)
+POLY_COMPUTE(ChebyshevCompute_wrp, chebyshev_compute)
+POLY_COMPUTE(FactorizedChebyshevCompute_wrp, chebyshev_factorized)
+POLY_COMPUTE(HermiteCompute_wrp, hermite_compute)
+#undef POLY_COMPUTE
+
 void SignFunction_wrp(const int* ih_mat1, int* ih_signmat, const int* ih_solver_parameters) {
   solver_sign(*get<PSMatrix>(ih_mat1), *get<PSMatrix>(ih_signmat), *get<SolverParameters>(ih_solver_parameters));
 }

@@ -582,6 +582,54 @@ class SquareRootSolvers:
         lib.ntpoly_amd_square_root_order(mat.ih, out.ih, solver_parameters.ih, i(int(inverse)), i(order))
 
 
+class _Poly:
+    """Polynomial.h / ChebyshevSolvers.h / HermiteSolvers.h: coefficient `degree` (0-based) multiplies
+    x^degree, T_degree(x) or H_degree(x)"""
+    _construct = _destruct = _set = None
+
+    def __init__(self, degree):
+        self.ih = handle()
+        getattr(lib, self._construct)(self.ih, i(degree))
+
+    def __del__(self):
+        try:
+            getattr(lib, self._destruct)(self.ih)
+        except Exception:
+            pass
+
+    def SetCoefficient(self, degree, coefficient):
+        getattr(lib, self._set)(self.ih, i(degree + 1), d(coefficient))
+
+
+class Polynomial(_Poly):
+    _construct, _destruct, _set = "ConstructPolynomial_wrp", "DestructPolynomial_wrp", "SetCoefficient_wrp"
+
+    def HornerCompute(self, InputMat, OutputMat, solver_parameters):
+        lib.HornerCompute_wrp(InputMat.ih, OutputMat.ih, self.ih, solver_parameters.ih)
+
+    def PatersonStockmeyerCompute(self, InputMat, OutputMat, solver_parameters):
+        lib.PatersonStockmeyerCompute_wrp(InputMat.ih, OutputMat.ih, self.ih, solver_parameters.ih)
+
+
+class ChebyshevPolynomial(_Poly):
+    _construct, _destruct, _set = ("ConstructChebyshevPolynomial_wrp", "DestructChebyshevPolynomial_wrp",
+                                   "SetChebyshevCoefficient_wrp")
+
+    def Compute(self, InputMat, OutputMat, solver_parameters):
+        lib.ChebyshevCompute_wrp(InputMat.ih, OutputMat.ih, self.ih, solver_parameters.ih)
+
+    def ComputeFactorized(self, InputMat, OutputMat, solver_parameters):
+        lib.FactorizedChebyshevCompute_wrp(InputMat.ih, OutputMat.ih, self.ih, solver_parameters.ih)
+
+
+class HermitePolynomial(_Poly):
+    _construct, _destruct, _set = ("ConstructHermitePolynomial_wrp", "DestructHermitePolynomial_wrp",
+                                   "SetHermiteCoefficient_wrp")
+
+    def Compute(self, InputMat, OutputMat, solver_parameters):
+        lib.HermiteCompute_wrp(InputMat.ih, OutputMat.ih, self.ih, solver_parameters.ih)
+
+
 class LoadBalancer:
     @staticmethod
     def PermuteMatrix(mat_in, mat_out, permutation, memorypool=None):

@@ -35,6 +35,15 @@ PROGRAM RefDriver
   USE InverseSolversModule, ONLY : Invert, PseudoInverse
   USE SquareRootSolversModule, ONLY : InverseSquareRoot, SquareRoot
   USE LoggingModule, ONLY : ActivateLogger, DeactivateLogger
+  USE PolynomialSolversModule, ONLY : Polynomial_t, ConstructPolynomial, &
+       & SetCoefficient, HornerCompute => Compute, &
+       & PatersonStockmeyerCompute => FactorizedCompute
+  USE ChebyshevSolversModule, ONLY : ChebyshevPolynomial_t, &
+       & ChebConstruct => ConstructPolynomial, ChebSet => SetCoefficient, &
+       & ChebCompute => Compute, ChebFactorized => FactorizedCompute
+  USE HermiteSolversModule, ONLY : HermitePolynomial_t, &
+       & HermConstruct => ConstructPolynomial, HermSet => SetCoefficient, &
+       & HermCompute => Compute
   IMPLICIT NONE
   INCLUDE "mpif.h"
   CHARACTER(len=32) :: cmd
@@ -55,6 +64,8 @@ PROGRAM RefDriver
      CALL cmd_pscalars()
   CASE("solve")
      CALL cmd_solve()
+  CASE("poly")
+     CALL cmd_poly()
   CASE DEFAULT
      WRITE(*,*) "unknown command ", cmd
   END SELECT
@@ -377,6 +388,53 @@ CONTAINS
     END IF
     CALL DestructProcessGrid
   END SUBROUTINE cmd_pscalars
+
+  !! poly pr pc ps <kind> A thr out ncoef c_1 ... c_ncoef
+  !!   kind in {horner, ps, cheby, chebyfact, hermite}; coefficient i multiplies x^(i-1) / T_(i-1) / H_(i-1)
+  SUBROUTINE cmd_poly()
+    TYPE(Matrix_ps) :: A, K
+    TYPE(SolverParameters_t) :: sp
+    TYPE(Polynomial_t) :: p1
+    TYPE(ChebyshevPolynomial_t) :: p2
+    TYPE(HermitePolynomial_t) :: p3
+    CHARACTER(len=32) :: kind
+    INTEGER :: n, II
+    CALL make_grid(2)
+    kind = sarg(5)
+    CALL load_ps(sarg(6), A)
+    CALL ConstructSolverParameters(sp, threshold_in=rarg(7))
+    n = iarg(9)
+    SELECT CASE(TRIM(kind))
+    CASE("horner", "ps")
+       CALL ConstructPolynomial(p1, n)
+       DO II = 1, n
+          CALL SetCoefficient(p1, II, rarg(9 + II))
+       END DO
+       IF (TRIM(kind) .EQ. "horner") THEN
+          CALL HornerCompute(A, K, p1, sp)
+       ELSE
+          CALL PatersonStockmeyerCompute(A, K, p1, sp)
+       END IF
+    CASE("cheby", "chebyfact")
+       CALL ChebConstruct(p2, n)
+       DO II = 1, n
+          CALL ChebSet(p2, II, rarg(9 + II))
+       END DO
+       IF (TRIM(kind) .EQ. "cheby") THEN
+          CALL ChebCompute(A, K, p2, sp)
+       ELSE
+          CALL ChebFactorized(A, K, p2, sp)
+       END IF
+    CASE("hermite")
+       CALL HermConstruct(p3, n)
+       DO II = 1, n
+          CALL HermSet(p3, II, rarg(9 + II))
+       END DO
+       CALL HermCompute(A, K, p3, sp)
+    END SELECT
+    CALL store_ps(sarg(8), K)
+    CALL DestructProcessGrid
+  END SUBROUTINE cmd_poly
 
   FUNCTION env_real(name) RESULT(v)
     CHARACTER(len=*), INTENT(IN) :: name

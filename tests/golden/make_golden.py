@@ -411,6 +411,29 @@ def gen_scalefold(tmp):
     save("solvers_scalefold", d, dict(kind="solvers_scalefold", cases=cases))
 
 
+def gen_polynomials(tmp):
+    """Horner / Paterson-Stockmeyer / Chebyshev (standard + recursive) / Hermite matrix polynomials
+    (test_solvers.py:409-560 style) on a banded symmetric matrix scaled into [-1, 1], real and complex."""
+    d, cases = {}, []
+    rng = np.random.default_rng(4242)
+    for cplx in (False, True):
+        H = banded(160, 6, cplx)
+        H = sp.csc_matrix(H * (1.0 / (1.05 * abs(H).sum(axis=0).max())))
+        write_tri(tmp + "/A.tri", 160, 160, *tri(H))
+        put(d, "A%d" % int(cplx), H.shape, tri(H))
+        for kind, ncoef, thr in (("horner", 1, 0.0), ("horner", 2, 0.0), ("horner", 7, 1e-9), ("ps", 2, 0.0), ("ps", 6, 0.0),
+                                 ("ps", 11, 1e-9), ("cheby", 1, 0.0), ("cheby", 2, 0.0), ("cheby", 3, 0.0), ("cheby", 9, 1e-9),
+                                 ("chebyfact", 1, 0.0), ("chebyfact", 2, 0.0), ("chebyfact", 5, 0.0), ("chebyfact", 9, 1e-9),
+                                 ("chebyfact", 16, 1e-9), ("hermite", 1, 0.0), ("hermite", 2, 0.0), ("hermite", 6, 1e-9)):
+            coef = [float(x) for x in np.round(rng.uniform(-1.0, 1.0, ncoef), 6)]
+            run(["poly", 1, 1, 1, kind, tmp + "/A.tri", repr(thr), tmp + "/K.tri", ncoef] + [repr(c) for c in coef])
+            rows, cols, c, r, v = read_tri(tmp + "/K.tri")
+            pre = "c%03d_" % len(cases)
+            put(d, pre + "K", (rows, cols), (c, r, v))
+            cases.append(dict(kind=kind, complex=cplx, coef=coef, thr=thr, nnz=int(len(c))))
+    save("polynomials", d, dict(kind="polynomials", cases=cases))
+
+
 def gen_multirank(tmp):
     """Same product on 1, 4 (2x2x1) and 8 (2x2x2) reference ranks: pins that values do not
     depend on the grid when slices == 1 and records the slices>1 behaviour."""
@@ -453,6 +476,7 @@ def main():
             return
         gen_solvers_extra(tmp)
         gen_scalefold(tmp)
+        gen_polynomials(tmp)
         gen_local_gemm(tmp)
         gen_local_increment(tmp)
         gen_ps(tmp)

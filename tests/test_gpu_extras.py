@@ -362,3 +362,39 @@ def test_scale_and_fold_golden(nt):
         wd = to_dense(want)
         tol = max(10 * c["thr"], 1e-10) * max(1.0, np.abs(wd).max())
         assert np.abs(gd - wd).max() <= tol, c["tag"]
+
+
+def test_polynomial_solvers_golden(nt):
+    """Horner, Paterson-Stockmeyer, Chebyshev (standard and recursive), Hermite matrix polynomials against the
+    reference's own results (tests/golden/polynomials.npz from make_golden.py polynomials), real and complex,
+    degrees 0..15, with and without threshold; plus a load-balanced run that must give the same matrix."""
+    g = Golden("polynomials")
+    mats = {False: pmat(nt, g.tri(None, "A0")), True: pmat(nt, g.tri(None, "A1"))}
+    for i, c in enumerate(g.cases):
+        A = mats[bool(c["complex"])]
+        n = A.GetActualDimension()
+        p = nt.SolverParameters()
+        p.SetThreshold(c["thr"])
+        cls, fn = {"horner": (nt.Polynomial, "HornerCompute"), "ps": (nt.Polynomial, "PatersonStockmeyerCompute"),
+                   "cheby": (nt.ChebyshevPolynomial, "Compute"), "chebyfact": (nt.ChebyshevPolynomial, "ComputeFactorized"),
+                   "hermite": (nt.HermitePolynomial, "Compute")}[c["kind"]]
+        poly = cls(len(c["coef"]))
+        for k, v in enumerate(c["coef"]):
+            poly.SetCoefficient(k, v)
+        Out = nt.Matrix_ps(n)
+        getattr(poly, fn)(A, Out, p)
+        want = g.tri(i, "K")
+        got = Out.triplets()
+        gd = to_dense((want[0], want[1]) + tuple(got))
+        wd = to_dense(want)
+        tol = max(100 * c["thr"], 1e-12) * max(1.0, np.abs(wd).max())
+        assert np.abs(gd - wd).max() <= tol, (i, c["kind"], len(c["coef"]), np.abs(gd - wd).max())
+        if c["thr"] == 0.0:
+            assert abs(Out.GetSize() - c["nnz"]) <= 0.002 * c["nnz"] + 2, (i, c["kind"], Out.GetSize(), c["nnz"])
+        if c["kind"] in ("horner", "cheby") and len(c["coef"]) > 3 and not c["complex"]:
+            perm = nt.Permutation(n)
+            perm.SetRandomPermutation()
+            p.SetLoadBalance(perm)
+            Out2 = nt.Matrix_ps(n)
+            getattr(poly, fn)(A, Out2, p)
+            assert np.abs(Out2.to_scipy().toarray() - gd).max() <= tol
