@@ -185,6 +185,14 @@ void polynomial_paterson_stockmeyer(const PSMatrix& In, PSMatrix& Out, const std
 void chebyshev_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p);
 void chebyshev_factorized(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p);
 void hermite_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p);
+// matrix functions (solvers_func.cpp)
+void power_bounds(const PSMatrix& A, double* max_value, const SolverParameters& p, bool defaults);
+void compute_exponential(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p);
+void compute_logarithm(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p);
+void compute_sine(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p);
+void compute_cosine(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p);
+void compute_root(const PSMatrix& In, PSMatrix& Out, int root, const SolverParameters& p);
+void compute_inverse_root(const PSMatrix& In, PSMatrix& Out, int root, const SolverParameters& p);
 // DensityMatrixSolversModule.F90:953-1117, :1165-1187, :1190-1231
 void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double homo, double lumo,
                            double* energy_out, const SolverParameters& p);

@@ -632,36 +632,107 @@ void DenseInverseSquareRoot_wrp(const int*, int*, const int*) {
 struct PolyHandle {
   std::vector<double> c;
 };
-#define POLY_FAMILY(CONSTRUCT, DESTRUCT, SETCOEF)                                              \
-  void CONSTRUCT(int* ih_polynomial, const int* degree) {                                      \
-    auto* h = new PolyHandle();                                                                \
-    h->c.assign((size_t)std::max(0, *degree), 0.0);                                            \
-    put(ih_polynomial, h);                                                                     \
-  }                                                                                            \
-  void DESTRUCT(int* ih_polynomial) {                                                          \
-    delete get<PolyHandle>(ih_polynomial);                                                     \
-    std::memset(ih_polynomial, 0, sizeof(int) * SIZE_wrp);                                     \
-  }                                                                                            \
-  void SETCOEF(int* ih_polynomial, const int* degree, const double* coefficient) {             \
-    PolyHandle* h = get<PolyHandle>(ih_polynomial);                                            \
-    if (*degree < 1 || *degree > (int)h->c.size()) NTP_FATAL("SetCoefficient: degree out of range"); \
-    h->c[(size_t)*degree - 1] = *coefficient;                                                  \
-  }
-POLY_FAMILY(ConstructPolynomial_wrp, DestructPolynomial_wrp, SetCoefficient_wrp)
-POLY_FAMILY(ConstructChebyshevPolynomial_wrp, DestructChebyshevPolynomial_wrp, SetChebyshevCoefficient_wrp)
-POLY_FAMILY(ConstructHermitePolynomial_wrp, DestructHermitePolynomial_wrp, SetHermiteCoefficient_wrp)
-#undef POLY_FAMILY
-#define POLY_COMPUTE(NAME, FN)                                                                                   \
-  void NAME(const int* ih_InputMat, int* ih_OutputMat, const int* ih_polynomial, const int* ih_solver_parameters) { \
-    FN(*get<PSMatrix>(ih_InputMat), *get<PSMatrix>(ih_OutputMat), get<PolyHandle>(ih_polynomial)->c,             \
-       *get<SolverParameters>(ih_solver_parameters));                                                            \
-  }
-POLY_COMPUTE(HornerCompute_wrp, polynomial_horner)
-POLY_COMPUTE(PatersonStockmeyerCompute_wrp, polynomial_paterson_stockmeyer)
-POLY_COMPUTE(ChebyshevCompute_wrp, chebyshev_compute)
-POLY_COMPUTE(FactorizedChebyshevCompute_wrp, chebyshev_factorized)
-POLY_COMPUTE(HermiteCompute_wrp, hermite_compute)
-#undef POLY_COMPUTE
+static void poly_construct(int* ih_polynomial, int degree) {
+  auto* h = new PolyHandle();
+  h->c.assign((size_t)std::max(0, degree), 0.0);
+  put(ih_polynomial, h);
+}
+static void poly_destruct(int* ih_polynomial) {
+  delete get<PolyHandle>(ih_polynomial);
+  std::memset(ih_polynomial, 0, sizeof(int) * SIZE_wrp);
+}
+static void poly_set(int* ih_polynomial, int degree, double coefficient) {
+  PolyHandle* h = get<PolyHandle>(ih_polynomial);
+  if (degree < 1 || degree > (int)h->c.size()) NTP_FATAL("SetCoefficient: degree out of range");
+  h->c[(size_t)degree - 1] = coefficient;
+}
+void ConstructPolynomial_wrp(int* ih_polynomial, const int* degree) { poly_construct(ih_polynomial, *degree); }
+void DestructPolynomial_wrp(int* ih_polynomial) { poly_destruct(ih_polynomial); }
+void SetCoefficient_wrp(int* ih_polynomial, const int* degree, const double* coefficient) {
+  poly_set(ih_polynomial, *degree, *coefficient);
+}
+void ConstructChebyshevPolynomial_wrp(int* ih_polynomial, const int* degree) { poly_construct(ih_polynomial, *degree); }
+void DestructChebyshevPolynomial_wrp(int* ih_polynomial) { poly_destruct(ih_polynomial); }
+void SetChebyshevCoefficient_wrp(int* ih_polynomial, const int* degree, const double* coefficient) {
+  poly_set(ih_polynomial, *degree, *coefficient);
+}
+void ConstructHermitePolynomial_wrp(int* ih_polynomial, const int* degree) { poly_construct(ih_polynomial, *degree); }
+void DestructHermitePolynomial_wrp(int* ih_polynomial) { poly_destruct(ih_polynomial); }
+void SetHermiteCoefficient_wrp(int* ih_polynomial, const int* degree, const double* coefficient) {
+  poly_set(ih_polynomial, *degree, *coefficient);
+}
+void HornerCompute_wrp(const int* ih_InputMat, int* ih_OutputMat, const int* ih_polynomial, const int* ih_solver_parameters) {
+  polynomial_horner(*get<PSMatrix>(ih_InputMat), *get<PSMatrix>(ih_OutputMat), get<PolyHandle>(ih_polynomial)->c,
+     *get<SolverParameters>(ih_solver_parameters));
+}
+void PatersonStockmeyerCompute_wrp(const int* ih_InputMat, int* ih_OutputMat, const int* ih_polynomial, const int* ih_solver_parameters) {
+  polynomial_paterson_stockmeyer(*get<PSMatrix>(ih_InputMat), *get<PSMatrix>(ih_OutputMat), get<PolyHandle>(ih_polynomial)->c,
+     *get<SolverParameters>(ih_solver_parameters));
+}
+void ChebyshevCompute_wrp(const int* ih_InputMat, int* ih_OutputMat, const int* ih_polynomial, const int* ih_solver_parameters) {
+  chebyshev_compute(*get<PSMatrix>(ih_InputMat), *get<PSMatrix>(ih_OutputMat), get<PolyHandle>(ih_polynomial)->c,
+     *get<SolverParameters>(ih_solver_parameters));
+}
+void FactorizedChebyshevCompute_wrp(const int* ih_InputMat, int* ih_OutputMat, const int* ih_polynomial, const int* ih_solver_parameters) {
+  chebyshev_factorized(*get<PSMatrix>(ih_InputMat), *get<PSMatrix>(ih_OutputMat), get<PolyHandle>(ih_polynomial)->c,
+     *get<SolverParameters>(ih_solver_parameters));
+}
+void HermiteCompute_wrp(const int* ih_InputMat, int* ih_OutputMat, const int* ih_polynomial, const int* ih_solver_parameters) {
+  hermite_compute(*get<PSMatrix>(ih_InputMat), *get<PSMatrix>(ih_OutputMat), get<PolyHandle>(ih_polynomial)->c,
+     *get<SolverParameters>(ih_solver_parameters));
+}
+
+// ---- matrix functions: ExponentialSolvers_c.h, TrigonometrySolvers_c.h, RootSolvers_c.h, EigenBounds_c.h
+void ComputeExponential_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  compute_exponential(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), *get<SolverParameters>(ih_solver_parameters));
+}
+void ComputeLogarithm_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  compute_logarithm(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), *get<SolverParameters>(ih_solver_parameters));
+}
+void Sine_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  compute_sine(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), *get<SolverParameters>(ih_solver_parameters));
+}
+void Cosine_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  compute_cosine(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), *get<SolverParameters>(ih_solver_parameters));
+}
+void ComputeRoot_wrp(const int* ih_inputmat, int* ih_outputmat, const int* root, const int* ih_solver_parameters) {
+  compute_root(*get<PSMatrix>(ih_inputmat), *get<PSMatrix>(ih_outputmat), *root, *get<SolverParameters>(ih_solver_parameters));
+}
+void ComputeInverseRoot_wrp(const int* ih_inputmat, int* ih_outputmat, const int* root, const int* ih_solver_parameters) {
+  compute_inverse_root(*get<PSMatrix>(ih_inputmat), *get<PSMatrix>(ih_outputmat), *root,
+                       *get<SolverParameters>(ih_solver_parameters));
+}
+void PowerBounds_wrp(const int* ih_Hamiltonian, double* max_value, const int* ih_solver_parameters) {
+  power_bounds(*get<PSMatrix>(ih_Hamiltonian), max_value, *get<SolverParameters>(ih_solver_parameters), false);
+}
+// dense (eigendecomposition) variants: link compatibility only, see DenseDensity_wrp above
+static void dense_stub(const char* name) {
+  NTP_FATAL(std::string(name) + ": the dense eigensolver path is not part of the MI355X engine; use the sparse solver of the same name");
+}
+void ComputeDenseExponential_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
+  dense_stub("ComputeDenseExponential_wrp");
+}
+void ComputeDenseLogarithm_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
+  dense_stub("ComputeDenseLogarithm_wrp");
+}
+void DenseSine_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
+  dense_stub("DenseSine_wrp");
+}
+void DenseCosine_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
+  dense_stub("DenseCosine_wrp");
+}
+void DenseInvert_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
+  dense_stub("DenseInvert_wrp");
+}
+void DenseSignFunction_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
+  dense_stub("DenseSignFunction_wrp");
+}
 
 void SignFunction_wrp(const int* ih_mat1, int* ih_signmat, const int* ih_solver_parameters) {
   solver_sign(*get<PSMatrix>(ih_mat1), *get<PSMatrix>(ih_signmat), *get<SolverParameters>(ih_solver_parameters));

@@ -630,6 +630,36 @@ class HermitePolynomial(_Poly):
         lib.HermiteCompute_wrp(InputMat.ih, OutputMat.ih, self.ih, solver_parameters.ih)
 
 
+class ExponentialSolvers:
+    @staticmethod
+    def ComputeExponential(InputMat, OutputMat, solver_parameters):
+        lib.ComputeExponential_wrp(InputMat.ih, OutputMat.ih, solver_parameters.ih)
+
+    @staticmethod
+    def ComputeLogarithm(InputMat, OutputMat, solver_parameters):
+        lib.ComputeLogarithm_wrp(InputMat.ih, OutputMat.ih, solver_parameters.ih)
+
+
+class TrigonometrySolvers:
+    @staticmethod
+    def Sine(InputMat, OutputMat, solver_parameters):
+        lib.Sine_wrp(InputMat.ih, OutputMat.ih, solver_parameters.ih)
+
+    @staticmethod
+    def Cosine(InputMat, OutputMat, solver_parameters):
+        lib.Cosine_wrp(InputMat.ih, OutputMat.ih, solver_parameters.ih)
+
+
+class RootSolvers:
+    @staticmethod
+    def ComputeRoot(InputMat, OutputMat, root, solver_parameters):
+        lib.ComputeRoot_wrp(InputMat.ih, OutputMat.ih, i(root), solver_parameters.ih)
+
+    @staticmethod
+    def ComputeInverseRoot(InputMat, OutputMat, root, solver_parameters):
+        lib.ComputeInverseRoot_wrp(InputMat.ih, OutputMat.ih, i(root), solver_parameters.ih)
+
+
 class LoadBalancer:
     @staticmethod
     def PermuteMatrix(mat_in, mat_out, permutation, memorypool=None):
@@ -643,6 +673,12 @@ class LoadBalancer:
 
 
 class EigenBounds:
+    @staticmethod
+    def PowerBounds(matrix, solver_parameters):
+        v = C.c_double()
+        lib.PowerBounds_wrp(matrix.ih, C.byref(v), solver_parameters.ih)
+        return v.value
+
     @staticmethod
     def GershgorinBounds(matrix):
         mn, mx = C.c_double(), C.c_double()

@@ -41,6 +41,10 @@ PROGRAM RefDriver
   USE ChebyshevSolversModule, ONLY : ChebyshevPolynomial_t, &
        & ChebConstruct => ConstructPolynomial, ChebSet => SetCoefficient, &
        & ChebCompute => Compute, ChebFactorized => FactorizedCompute
+  USE ExponentialSolversModule, ONLY : ComputeExponential, ComputeLogarithm
+  USE TrigonometrySolversModule, ONLY : Sine, Cosine
+  USE RootSolversModule, ONLY : ComputeRoot, ComputeInverseRoot
+  USE EigenBoundsModule, ONLY : PowerBounds
   USE HermiteSolversModule, ONLY : HermitePolynomial_t, &
        & HermConstruct => ConstructPolynomial, HermSet => SetCoefficient, &
        & HermCompute => Compute
@@ -66,6 +70,8 @@ PROGRAM RefDriver
      CALL cmd_solve()
   CASE("poly")
      CALL cmd_poly()
+  CASE("func")
+     CALL cmd_func()
   CASE DEFAULT
      WRITE(*,*) "unknown command ", cmd
   END SELECT
@@ -435,6 +441,49 @@ CONTAINS
     CALL store_ps(sarg(8), K)
     CALL DestructProcessGrid
   END SUBROUTINE cmd_poly
+
+  !! func pr pc ps <kind> A thr conv out scal.txt [root]
+  !!   kind in {exp, log, sin, cos, root, invroot, power}
+  SUBROUTINE cmd_func()
+    TYPE(Matrix_ps) :: A, K
+    TYPE(SolverParameters_t) :: sp
+    CHARACTER(len=32) :: kind
+    REAL(NTREAL) :: bound
+    INTEGER :: u
+    CALL make_grid(2)
+    kind = sarg(5)
+    CALL load_ps(sarg(6), A)
+    IF (IsRoot()) CALL ActivateLogger(start_document_in=.TRUE., &
+         & file_name_in=TRIM(sarg(9))//".log")
+    CALL ConstructSolverParameters(sp, threshold_in=rarg(7), converge_diff_in=rarg(8), &
+         & be_verbose_in=.TRUE.)
+    bound = 0
+    SELECT CASE(TRIM(kind))
+    CASE("exp")
+       CALL ComputeExponential(A, K, sp)
+    CASE("log")
+       CALL ComputeLogarithm(A, K, sp)
+    CASE("sin")
+       CALL Sine(A, K, sp)
+    CASE("cos")
+       CALL Cosine(A, K, sp)
+    CASE("root")
+       CALL ComputeRoot(A, K, iarg(11), sp)
+    CASE("invroot")
+       CALL ComputeInverseRoot(A, K, iarg(11), sp)
+    CASE("power")
+       CALL PowerBounds(A, bound, sp)
+       CALL CopyMatrix(A, K)
+    END SELECT
+    IF (IsRoot()) CALL DeactivateLogger
+    CALL store_ps(sarg(9), K)
+    IF (IsRoot()) THEN
+       OPEN(NEWUNIT=u, FILE=TRIM(sarg(10)), STATUS="REPLACE")
+       WRITE(u, '(A,ES26.17E3)') "bound ", bound
+       CLOSE(u)
+    END IF
+    CALL DestructProcessGrid
+  END SUBROUTINE cmd_func
 
   FUNCTION env_real(name) RESULT(v)
     CHARACTER(len=*), INTENT(IN) :: name

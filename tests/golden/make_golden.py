@@ -434,6 +434,34 @@ def gen_polynomials(tmp):
     save("polynomials", d, dict(kind="polynomials", cases=cases))
 
 
+def gen_functions(tmp):
+    """exp / log / sin / cos / roots / inverse roots / PowerBounds (test_solvers.py:586-800 style) on small banded
+    matrices: symmetric indefinite for exp/sin/cos, shifted positive definite for log and the roots."""
+    d, cases = {}, []
+    Hs = banded(128, 5)
+    Hp = sp.csc_matrix(banded(128, 5) + 2.5 * sp.identity(128))
+    Hc = sp.csc_matrix(banded(96, 4, True))
+    for name, M in (("sym", Hs), ("spd", Hp), ("csym", Hc)):
+        put(d, "M_" + name, M.shape, tri(M))
+    jobs = [("exp", "sym", 1e-9, 0), ("exp", "csym", 1e-9, 0), ("sin", "sym", 1e-9, 0), ("cos", "sym", 1e-9, 0),
+            ("cos", "csym", 1e-9, 0), ("log", "spd", 1e-10, 0), ("power", "spd", 0.0, 0), ("power", "sym", 0.0, 0)]
+    for r in (1, 2, 3, 4, 5, 6, 7, 8):
+        jobs.append(("root", "spd", 1e-10, r))
+        jobs.append(("invroot", "spd", 1e-10, r))
+    for kind, name, thr, root in jobs:
+        M = dict(sym=Hs, spd=Hp, csym=Hc)[name]
+        n = M.shape[0]
+        write_tri(tmp + "/A.tri", n, n, *tri(M))
+        run(["func", 1, 1, 1, kind, tmp + "/A.tri", repr(thr), repr(1e-8), tmp + "/K.tri", tmp + "/s.txt", root])
+        rows, cols, c, r, v = read_tri(tmp + "/K.tri")
+        sc = {kk: float(x) for kk, x in (ln.split() for ln in open(tmp + "/s.txt"))}
+        pre = "c%03d_" % len(cases)
+        if kind != "power":
+            put(d, pre + "K", (rows, cols), (c, r, v))
+        cases.append(dict(kind=kind, matrix=name, thr=thr, conv=1e-8, root=root, bound=sc["bound"], nnz=int(len(c))))
+    save("functions", d, dict(kind="functions", cases=cases))
+
+
 def gen_multirank(tmp):
     """Same product on 1, 4 (2x2x1) and 8 (2x2x2) reference ranks: pins that values do not
     depend on the grid when slices == 1 and records the slices>1 behaviour."""
@@ -477,6 +505,7 @@ def main():
         gen_solvers_extra(tmp)
         gen_scalefold(tmp)
         gen_polynomials(tmp)
+        gen_functions(tmp)
         gen_local_gemm(tmp)
         gen_local_increment(tmp)
         gen_ps(tmp)

@@ -75,6 +75,12 @@ GROUPS = [
     ("ntpoly_amd_load_balancer.h", "LoadBalancer_c.h", "load balancer (LoadBalancerModule.F90)"),
     ("ntpoly_amd_eigen_bounds.h", "EigenBounds_c.h", "eigenvalue bounds (EigenBoundsModule.F90:29-56)"),
     ("ntpoly_amd_logging.h", "Logging_c.h", "logger (LoggingModule.F90)"),
+    ("ntpoly_amd_polynomial_solvers.h", "Polynomial_c.h", "matrix polynomials, Horner / Paterson-Stockmeyer (PolynomialSolversModule.F90)"),
+    ("ntpoly_amd_polynomial_solvers.h", "ChebyshevSolvers_c.h", "Chebyshev polynomials (ChebyshevSolversModule.F90)"),
+    ("ntpoly_amd_polynomial_solvers.h", "HermiteSolvers_c.h", "Hermite polynomials (HermiteSolversModule.F90)"),
+    ("ntpoly_amd_function_solvers.h", "ExponentialSolvers_c.h", "exponential / logarithm (ExponentialSolversModule.F90)"),
+    ("ntpoly_amd_function_solvers.h", "TrigonometrySolvers_c.h", "sine / cosine (TrigonometrySolversModule.F90)"),
+    ("ntpoly_amd_function_solvers.h", "RootSolvers_c.h", "roots / inverse roots (RootSolversModule.F90)"),
 ]
 
 
