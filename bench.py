@@ -136,6 +136,7 @@ def main():
     for _ in range(args.warmup):
         _, energy, tr_x = trs2_step(nt, X, X2, H, pool, trace_target, thr, tr_x)
     nt.reset_spgemm_accum()
+    m0 = nt.malloc_stats()
     fence()
     t0 = time.perf_counter()
     nnz_trace = []
@@ -145,6 +146,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = nt.allreduce_max(elapsed)
+    m1 = nt.malloc_stats()
     acc = nt.spgemm_accum()
     st = nt.last_spgemm_stats()
     nnz_x = X.GetSize()
@@ -185,7 +187,8 @@ def main():
                                        n, h, 2 * h + 1, thr, args.warmup + 1, args.warmup + args.steps),
                        "n": n, "halfband": h, "threshold": thr, "nnz_H": int(nnz_h), "nnz_X_end": int(nnz_x),
                        "nnz_X2_end": int(nnz_x2), "energy_end": energy,
-                       "decomposition": "1-D column panels, %d GPU(s)" % world},
+                       "decomposition": "1-D column panels, %d GPU(s)" % world,
+                       "hipMalloc_in_timed_region": {"calls": m1[0] - m0[0], "ms": m1[1] - m0[1]}},
             "spgemm_nnz_out_per_s": world * acc["nnz_c"] / (ms_spgemm * 1e-3),
             "spgemm_products_per_s": world * acc["products"] / (ms_numeric * 1e-3),
             "spgemm_ms_per_call": ms_spgemm / calls,

@@ -61,6 +61,7 @@ void dev_free(void* p);
 void dev_release_cache();
 size_t dev_bytes_in_use();
 size_t dev_bytes_cached();
+void dev_malloc_stats(long long* calls, double* ms);  // hipMalloc calls behind the cache and the host time they took
 
 template <typename T>
 struct DevBuf {

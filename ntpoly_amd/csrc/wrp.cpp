@@ -124,6 +124,8 @@ void ntpoly_amd_memory(long long* in_use, long long* cached) {
   *cached = (long long)dev_bytes_cached();
 }
 void ntpoly_amd_release_cache() { dev_release_cache(); }
+// hipMalloc calls the caching allocator had to make so far, and the host milliseconds they took
+void ntpoly_amd_malloc_stats(long long* calls, double* ms) { dev_malloc_stats(calls, ms); }
 // bulk triplet transfer (the reference ABI moves triplets one at a time)
 void ntpoly_amd_triplets_set_r(int* ih_list, const long long* n, const int* col, const int* row, const double* val) {
   HostTriplets* t = get<HostTriplets>(ih_list);

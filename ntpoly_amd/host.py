@@ -732,6 +732,12 @@ def solver_trace():
     return dict(iterations=n, value=v, energy=e, sigma=sg, nnz=nz, setup_ms=a.value, loop_ms=c.value)
 
 
+def malloc_stats():
+    n, ms = C.c_longlong(), C.c_double()
+    lib.ntpoly_amd_malloc_stats(C.byref(n), C.byref(ms))
+    return n.value, ms.value
+
+
 def memory():
     a, c = C.c_longlong(), C.c_longlong()
     lib.ntpoly_amd_memory(C.byref(a), C.byref(c))
