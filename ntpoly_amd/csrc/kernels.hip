@@ -124,8 +124,11 @@ struct Csc {
   const int64_t* outer;
   const int32_t* inner;
   const void* val;
+  const int32_t* cnt = nullptr;  // "loose" columns (a product left in its upper-bound slots): column j holds the
+                                 // entries outer[j] .. outer[j] + cnt[j]; nullptr = packed (ends at outer[j + 1])
 };
 inline Csc view(const DevMat& m) { return Csc{m.rows, m.cols, m.outer.p, m.inner.p, m.val.p}; }
+__device__ inline int64_t col_end(const Csc& M, int j) { return M.cnt ? M.outer[j] + M.cnt[j] : M.outer[j + 1]; }
 
 // ------------------------------------------------------------------ scans / reductions
 // single-workgroup exclusive scan of n int64 values (n <= a few million); out[n] = total
@@ -1880,7 +1883,7 @@ __global__ void k_inc_plan(Csc A, Csc B, int32_t* __restrict__ lo_arr, int32_t* 
                            int force_seq) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.cols) return;
-  const int64_t as = A.outer[j], ae = A.outer[j + 1], bs = B.outer[j], be = B.outer[j + 1];
+  const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = B.outer[j + 1];
   int lo = INT_MAX, hi = -1;
   if (ae > as) { lo = min(lo, A.inner[as]); hi = max(hi, A.inner[ae - 1]); }
   if (be > bs) { lo = min(lo, B.inner[bs]); hi = max(hi, B.inner[be - 1]); }
@@ -1939,7 +1942,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
     const T* __restrict__ Av = static_cast<const T*>(A.val);
     const T* __restrict__ Bv = static_cast<const T*>(B.val);
     const T* __restrict__ Dv = static_cast<const T*>(D.val);
-    const int64_t as = A.outer[j], ae = A.outer[j + 1], bs = B.outer[j], be = B.outer[j + 1];
+    const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = B.outer[j + 1];
     const int64_t ds = DOT ? D.outer[j] : 0, de = DOT ? D.outer[j + 1] : 0;
     // All operand loads of the column are requested up front (CH chunks of 64 entries per operand, reading past
     // the column end is harmless: DevMat keeps kIndexSlack entries of slack), so the column costs one memory
@@ -2079,7 +2082,7 @@ __global__ void k_inc_seq(Csc A, Csc B, const uint8_t* __restrict__ bin_arr, int
   if (bin_arr[j] != my_bin) return;
   const T* __restrict__ Av = static_cast<const T*>(A.val);
   const T* __restrict__ Bv = static_cast<const T*>(B.val);
-  int64_t aa = A.outer[j], ea = A.outer[j + 1], bb = B.outer[j], eb = B.outer[j + 1];
+  int64_t aa = A.outer[j], ea = col_end(A, j), bb = B.outer[j], eb = B.outer[j + 1];
   int64_t cc = aa + bb;
   const int64_t c0 = cc;
   while (aa < ea && bb < eb) {
@@ -2644,7 +2647,9 @@ void launch_window(int bin, const DevMat& A, const DevMat& B, const int32_t* lo,
 }
 }  // namespace
 
-void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {
+void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule,
+            LooseProduct* loose) {
+  if (loose) loose->valid = false;
   if (A.cols != B.rows) NTP_FATAL("spgemm: inner dimensions differ");
   if (A.cplx != B.cplx) NTP_FATAL("spgemm: mixed scalar types must be up-cast by the caller");
   const int32_t m = A.rows, n = B.cols;
@@ -2735,8 +2740,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   }
   st.tmp_entries = tmp_total;
 
-  DevBuf<int32_t> tmp_inner((size_t)tmp_total);
-  DevBuf<double> tmp_val((size_t)tmp_total * A.wval());
+  // + slack: a loose product is read by kernels that fetch whole 64-entry chunks past a column's end
+  DevBuf<int32_t> tmp_inner((size_t)tmp_total + kIndexSlack);
+  DevBuf<double> tmp_val(((size_t)tmp_total + kIndexSlack) * A.wval());
   DevBuf<int32_t> tmp2_inner;
   DevBuf<double> tmp2_val;
   DevBuf<int64_t> tmpoff2;
@@ -2912,6 +2918,35 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   }
   t_num.stop();
 
+  if (loose && use_slab) {
+    // hand the slots over as they are: the consumer (axpby) reads the columns in place and reports the exact nnz
+    loose->valid = true;
+    loose->rows = m;
+    loose->cols = n;
+    loose->slots = tmp_total;
+    loose->start = std::move(tmpoff);
+    loose->count = std::move(count);
+    loose->inner = std::move(tmp_inner);
+    loose->val = std::move(tmp_val);
+    t_all.stop();
+    if (timing) {
+      if (pending_timings().size() >= 4096) flush_spgemm_timers();
+      pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+    }
+    loose->prod_index = -1;
+    if (timing) {  // the product count of the slab path comes from the expansion pass; read together with the nnz later
+      loose->prod_scan = std::move(blk_prod_scan);
+      loose->prod_index = snb;
+    }
+    st.nnz_c = -1;  // not known yet
+    last_spgemm_stats() = st;
+    SpgemmAccum& acc = spgemm_accum();
+    acc.calls += 1;
+    acc.products += st.products;
+    acc.alg_bytes += 12.0 * (double)(A.nnz + B.nnz) + 4.0 * ((double)A.cols + B.cols + n + 3);  // + 12 * nnzC: axpby
+    return;
+  }
+
   // exact column pointers, then move every column to its final place
   C.rows = m;
   C.cols = n;
@@ -2958,21 +2993,32 @@ void increment(const DevMat& A, DevMat& B, double alpha, double threshold) {
   axpby(A, B, alpha, 1.0, threshold, nullptr, nullptr, nullptr, 0);
 }
 
-void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
-           double* trace_out, int32_t trace_col_offset) {
+namespace {
+// first operand of the merge: a packed matrix or a loose product (columns in upper-bound slots)
+struct MergeOperand {
+  Csc v;
+  int32_t rows, cols;
+  bool cplx;
+  int64_t slots;  // entries addressable through v.outer (nnz for a packed operand)
+  bool loose;
+};
+void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D,
+                double* dot_out, double* trace_out, int32_t trace_col_offset, int64_t* a_nnz_out,
+                const int64_t* d_extra = nullptr, int64_t* extra_out = nullptr) {
   if (A.rows != B.rows || A.cols != B.cols) NTP_FATAL("increment: shape mismatch");
   if (A.cplx != B.cplx) NTP_FATAL("increment: mixed scalar types must be up-cast by the caller");
   if (D && (D->rows != A.rows || D->cols != A.cols || D->cplx != A.cplx)) NTP_FATAL("increment: dot operand mismatch");
   if (dot_out) dot_out[0] = dot_out[1] = 0.0;
+  if (a_nnz_out) *a_nnz_out = A.loose ? 0 : A.slots;
   const int n = A.cols;
   if (n == 0) return;
-  if (A.nnz == 0 && B.nnz == 0) return;
+  if (!A.loose && A.slots == 0 && B.nnz == 0) return;
   DevBuf<int32_t> lo(n), span(n), count(n);
   DevBuf<uint8_t> bin(n);
   DevBuf<unsigned long long> stats(16);
   stats.zero();
   count.zero();
-  hipLaunchKernelGGL(k_inc_plan, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(A), view(B), lo.p, span.p, bin.p,
+  hipLaunchKernelGGL(k_inc_plan, dim3(cdiv(n, 256)), dim3(256), 0, stream(), A.v, view(B), lo.p, span.p, bin.p,
                      stats.p, options().increment_force_seq);
   hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, (const int64_t*)nullptr,
                      (const int32_t*)nullptr, n, stats.p);
@@ -2982,11 +3028,19 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
     f.add(stats.p, 16, hs);
     f.run();
   }
-  const int64_t cap = A.nnz + B.nnz;
+  // output slot of column j = A.outer[j] + B.outer[j] (room for all of both columns; for a loose A the slots are
+  // simply further apart)
+  const int64_t cap = A.slots + B.nnz;
+  const size_t wv = A.cplx ? 2 : 1;
   DevBuf<int32_t> tmp_inner((size_t)cap);
-  DevBuf<double> tmp_val((size_t)cap * A.wval());
+  DevBuf<double> tmp_val((size_t)cap * wv);
   DevBuf<int64_t> srcoff((size_t)n + 1);
-  hipLaunchKernelGGL(k_sum_outer, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), A.outer.p, B.outer.p, srcoff.p, n);
+  hipLaunchKernelGGL(k_sum_outer, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), A.v.outer, B.outer.p, srcoff.p, n);
+  DevBuf<int64_t> a_total;  // exact nnz of a loose first operand
+  if (A.loose) {
+    a_total.alloc((size_t)n + 1);
+    scan_async<int32_t>(A.v.cnt, a_total.p, (int64_t)n);
+  }
   const bool fuse_dot = D != nullptr && dot_out != nullptr && hs[3] == 0;
   const int nb1 = cdiv(n, 4), nb2 = n;
   DevBuf<double> part1, part2, tpart1, tpart2;
@@ -3002,25 +3056,25 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
     T* tv = reinterpret_cast<T*>(tmp_val.p);
-    const Csc dv = D ? view(*D) : view(A);
+    const Csc dv = D ? view(*D) : A.v;
     if (hs[1]) {
       if (fuse_dot)
-        hipLaunchKernelGGL((k_inc_window<T, 512, 4, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), view(A), view(B), dv,
+        hipLaunchKernelGGL((k_inc_window<T, 512, 4, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv,
                            lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, part1.p, nb1, tpart1.p, trace_col_offset);
       else
-        hipLaunchKernelGGL((k_inc_window<T, 512, 4, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), view(A), view(B), dv,
+        hipLaunchKernelGGL((k_inc_window<T, 512, 4, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv,
                            lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1, (double*)nullptr, 0);
     }
     if (hs[2]) {
       if (fuse_dot)
-        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, true>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), view(A), view(B), dv,
+        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, true>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), A.v, view(B), dv,
                            lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, part2.p, nb2, tpart2.p, trace_col_offset);
       else
-        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, false>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), view(A), view(B), dv,
+        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, false>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), A.v, view(B), dv,
                            lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb2, (double*)nullptr, 0);
     }
     if (hs[3]) {
-      hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), view(A), view(B), bin.p, 3,
+      hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), A.v, view(B), bin.p, 3,
                          tmp_inner.p, tv, count.p, alpha, beta, threshold);
     }
   });
@@ -3045,7 +3099,11 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
     ScalarFetch f;
     f.add(R.outer.p + n, 1, &nnz);
     if (fuse_dot) f.add(dres.p, 8, hd);
+    int64_t a_nnz = 0;
+    if (A.loose) f.add(a_total.p + n, 1, &a_nnz);
+    if (d_extra && extra_out) f.add(d_extra, 1, extra_out);
     f.run();
+    if (A.loose && a_nnz_out) *a_nnz_out = a_nnz;
   }
   R.nnz = nnz;
   R.inner.alloc((size_t)nnz + kIndexSlack);
@@ -3067,6 +3125,32 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
     }
   }
   if (trace_out) *trace_out = fuse_trace ? hd[4] + hd[6] : trace(B, trace_col_offset);
+}
+}  // namespace
+
+void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
+           double* trace_out, int32_t trace_col_offset) {
+  const MergeOperand a{view(A), A.rows, A.cols, A.cplx, A.nnz, false};
+  axpby_impl(a, B, alpha, beta, threshold, D, dot_out, trace_out, trace_col_offset, nullptr);
+}
+
+void axpby(const LooseProduct& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
+           double* trace_out, int32_t trace_col_offset, int64_t* a_nnz_out) {
+  if (!A.valid) NTP_FATAL("axpby: invalid loose product");
+  Csc v{A.rows, A.cols, A.start.p, A.inner.p, A.val.p};
+  v.cnt = A.count.p;
+  const MergeOperand a{v, A.rows, A.cols, false, A.slots, true};
+  int64_t a_nnz = 0, products = 0;
+  axpby_impl(a, B, alpha, beta, threshold, D, dot_out, trace_out, trace_col_offset, &a_nnz,
+             A.prod_index >= 0 ? A.prod_scan.p + A.prod_index : nullptr, &products);
+  if (a_nnz_out) *a_nnz_out = a_nnz;
+  // the multiply that produced A could not account for its output: do it now
+  SpgemmAccum& acc = spgemm_accum();
+  acc.nnz_c += a_nnz;
+  acc.alg_bytes += 12.0 * (double)a_nnz;
+  acc.products += products;
+  last_spgemm_stats().nnz_c = a_nnz;
+  last_spgemm_stats().products = products;
 }
 
 void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a) {

@@ -36,10 +36,27 @@ SpgemmAccum& spgemm_accum();
 // resolve the HIP events recorded by the timed multiplies since the last call (time_kernels option)
 void flush_spgemm_timers();
 
+// A product left "loose": every column sits in the upper-bound slot the numeric kernel wrote it to (entries
+// start[j] .. start[j] + count[j]), the compaction pass has not run.  Produced by spgemm(..., &loose) on the
+// register-slab path and consumed by axpby(loose, ...): the TRS2 update reads X*X straight from the slots.
+struct LooseProduct {
+  bool valid = false;
+  int32_t rows = 0, cols = 0;
+  int64_t slots = 0;            // capacity of inner / val (= start[cols])
+  DevBuf<int64_t> start;        // cols + 1
+  DevBuf<int32_t> count;        // cols
+  DevBuf<int32_t> inner;
+  DevBuf<double> val;           // real only
+  DevBuf<int64_t> prod_scan;    // statistics: [prod_index] = product count of the multiply (when counted)
+  int64_t prod_index = -1;
+};
+
 // C = alpha * A * B with NTPoly's prune rule.  A: (m x k), B: (k x n), same scalar type.
 // dense_rule = the reference's dense-branch order (threshold before alpha, DenseBranch.f90:14-15).
+// loose != nullptr: if the register-slab kernel computes the product, leave it uncompacted in *loose (loose->valid,
+// C untouched); otherwise C is produced as usual and loose->valid stays false.
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold,
-            bool dense_rule);
+            bool dense_rule, LooseProduct* loose = nullptr);
 
 // B <- alpha*A + B (AddSparseVectors semantics), same shape and scalar type.
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold);
@@ -47,6 +64,9 @@ void increment(const DevMat& A, DevMat& B, double alpha, double threshold);
 // dot_out = sum conj(B_new) .* D, evaluated in the same pass
 void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
            double* trace_out = nullptr, int32_t trace_col_offset = 0);  // trace_out: also trace(B_new), same pass
+// the same with the first operand taken from a loose product (its exact nnz is learned on the way and returned)
+void axpby(const LooseProduct& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
+           double* trace_out, int32_t trace_col_offset, int64_t* a_nnz_out);
 // C = A .* B on the intersection of the patterns (conj_a: conjugate A first)
 void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a);
 // out = sum conj(A) .* B  (out[1] = imaginary part, 0 for real)

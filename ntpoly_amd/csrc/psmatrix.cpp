@@ -381,6 +381,37 @@ void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, dou
   comm_allreduce_sum(out, want_trace ? 3 : 2);
 }
 
+// TRS2, sigma > 0 (DensityMatrixSolversModule.F90:388-396): X2 = X*X; X = 2X - X2; energy = dot(X, D).  When the
+// register-slab kernel computes X*X the product is never compacted: the merge kernel reads it from its slots.
+void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
+  out[2] = out[3] = 0.0;
+  if (B.cplx || D.cplx != B.cplx) {
+    ps_multiply(B, B, scratch, 1.0, 0.0, threshold);
+    ps_axpby_dot(scratch, B, -1.0, 2.0, threshold, D, out, want_trace);
+    return;
+  }
+  const double denom = (double)B.dim * (double)B.dim;
+  int64_t nz[2] = {B.loc.nnz, B.loc.nnz};
+  LooseProduct L;
+  DevMat AB;
+  if (world().active()) {
+    DevMat Aneed = gather_needed(B, B.loc, nz);
+    const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
+    spgemm(Aneed, B.loc, AB, 1.0, threshold, dense_rule, &L);
+  } else {
+    const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
+    spgemm(B.loc, B.loc, AB, 1.0, threshold, dense_rule, &L);
+  }
+  if (L.valid) {
+    axpby(L, B.loc, -1.0, 2.0, threshold, &D.loc, out, want_trace ? &out[2] : nullptr, B.c0, nullptr);
+  } else {
+    scratch.grid = B.grid; scratch.dim = B.dim; scratch.c0 = B.c0; scratch.c1 = B.c1; scratch.cplx = B.cplx;
+    scratch.loc = std::move(AB);
+    axpby(scratch.loc, B.loc, -1.0, 2.0, threshold, &D.loc, out, want_trace ? &out[2] : nullptr, B.c0);
+  }
+  comm_allreduce_sum(out, want_trace ? 3 : 2);
+}
+
 // dot(A, B) and trace(A) from one pass
 void ps_dot_trace(const PSMatrix& A, const PSMatrix& B, double out[4], bool want_trace) {
   out[2] = out[3] = 0.0;

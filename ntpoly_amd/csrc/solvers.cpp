@@ -232,11 +232,11 @@ double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_tar
   // accumulated in the pass that produces the energy -> one reduction + read-back less per iteration
   const double trace_value = (trace_io && *trace_io == *trace_io) ? *trace_io : ps_trace(X);
   *sigma = (trace_target - trace_value < 0.0) ? -1.0 : 1.0;
-  ps_multiply(X, X, X2, 1.0, 0.0, threshold);
   double out[4] = {0, 0, 0, 0};
   if (*sigma > 0.0) {
-    ps_axpby_dot(X2, X, -1.0, 2.0, threshold, WH, out, trace_io != nullptr);
+    ps_square_update_dot(X, X2, threshold, WH, out, trace_io != nullptr);  // X2 = X*X; X = 2X - X2; energy; trace
   } else {
+    ps_multiply(X, X, X2, 1.0, 0.0, threshold);
     std::swap(X.loc, X2.loc);  // X <- X2; X2 is scratch (recomputed by the next multiply), so no copy
     ps_dot_trace(X, WH, out, trace_io != nullptr);
   }
