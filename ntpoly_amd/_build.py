@@ -66,5 +66,34 @@ def build(force=False, verbose=False):
     return LIB
 
 
+FLANG = os.environ.get("FLANG", "/opt/rocm/lib/llvm/bin/flang")
+FORTRAN_SRC = os.path.join(os.path.dirname(HERE), "fortran", "ntpoly_amd_modules.f90")
+FORTRAN_LIB = os.path.join(HERE, "libntpoly_amd_fortran.a")
+FORTRAN_MOD = os.path.join(HERE, "fortran_mod")
+
+
+def build_fortran(force=False):
+    """The Fortran module layer (NTPoly's module / type / procedure names over the C ABI): flang ->
+    ntpoly_amd/libntpoly_amd_fortran.a + ntpoly_amd/fortran_mod/*.mod.  A Fortran program written against NTPoly
+    compiles with `-I ntpoly_amd/fortran_mod` and links `libntpoly_amd_fortran.a -lntpoly_amd`."""
+    if not os.path.exists(FLANG):
+        return None
+    if not force and os.path.exists(FORTRAN_LIB) and os.path.getmtime(FORTRAN_LIB) > os.path.getmtime(FORTRAN_SRC):
+        return FORTRAN_LIB
+    os.makedirs(FORTRAN_MOD, exist_ok=True)
+    obj = os.path.join(HERE, "build", "ntpoly_amd_modules.o")
+    os.makedirs(os.path.dirname(obj), exist_ok=True)
+    r = subprocess.run([FLANG, "-O2", "-fPIC", "-c", FORTRAN_SRC, "-o", obj, "-J", FORTRAN_MOD], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("flang failed")
+    if os.path.exists(FORTRAN_LIB):
+        os.unlink(FORTRAN_LIB)
+    subprocess.run(["ar", "rcs", FORTRAN_LIB, obj], check=True)
+    return FORTRAN_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_fortran(force="--force" in sys.argv))

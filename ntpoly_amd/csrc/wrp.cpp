@@ -380,6 +380,18 @@ void ActivateLoggerFile_wrp(const bool* start_document, const char* file_name, c
   log_activate(*start_document, fstring(file_name, name_size).c_str());
 }
 void DeactivateLogger_wrp() { log_deactivate(); }
+// extension: the writing half of LoggingModule.F90 (WriteHeader / WriteElement / WriteListElement / Enter / ExitSubLog),
+// which the reference exposes to Fortran callers only; used by the Fortran module layer (fortran/ntpoly_amd_modules.f90)
+void ntpoly_amd_log_header(const char* text, const int* n) { log_header(fstring(text, n).c_str()); }
+void ntpoly_amd_log_enter() { log_enter(); }
+void ntpoly_amd_log_exit() { log_exit(); }
+void ntpoly_amd_log_element_string(const char* key, const int* nk, const char* v, const int* nv) {
+  log_element(fstring(key, nk).c_str(), fstring(v, nv).c_str());
+}
+void ntpoly_amd_log_element_int(const char* key, const int* nk, const int* v) { log_element(fstring(key, nk).c_str(), *v); }
+void ntpoly_amd_log_element_real(const char* key, const int* nk, const double* v) { log_element(fstring(key, nk).c_str(), *v); }
+void ntpoly_amd_log_element_bool(const char* key, const int* nk, const bool* v) { log_element(fstring(key, nk).c_str(), *v); }
+void ntpoly_amd_log_list_element(const char* key, const int* nk) { log_list_element(fstring(key, nk).c_str()); }
 
 // ===================================================================== PSMatrix_c.h
 void ConstructEmptyMatrix_ps_wrp(int* ih_this, const int* matrix_dim) {

@@ -102,3 +102,19 @@ def test_product_never_touches_the_oracle():
                 assert "oracle" not in text.lower() or f == "capi.py", (f, "mentions the oracle")
     out = subprocess.run(["ldd", os.path.join(pkg, "libntpoly_amd.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_fortran_module_layer_builds():
+    """fortran/ntpoly_amd_modules.f90 (NTPoly's Fortran module names over the C ABI) compiles with flang and every
+    BIND(C) name it declares is exported by the library."""
+    import re
+    import subprocess
+    from ntpoly_amd import _build
+    if not os.path.exists(_build.FLANG):
+        pytest.skip("no flang in this image")
+    assert _build.build_fortran() and os.path.exists(os.path.join(_build.FORTRAN_MOD, "psmatrixmodule.mod"))
+    src = open(_build.FORTRAN_SRC).read()
+    names = set(re.findall(r'BIND\(C, name="(\w+)"\)', src))
+    syms = subprocess.run(["nm", "-D", "--defined-only", _build.LIB], capture_output=True, text=True).stdout
+    have = set(ln.split()[-1] for ln in syms.splitlines() if ln.strip())
+    assert len(names) > 70 and not sorted(names - have)

@@ -242,19 +242,23 @@ def test_fused_trs2_step_equals_call_sequence(nt, cplx, force_seq):
         nt.set_option("increment_force_seq", 0)
 
 
-def test_reference_cxx_example_links_and_runs(tmp_path):
-    """Drop-in at the reference's own C++ layer: oracle/_ref/premade_cxx is the reference's UNCHANGED
-    Source/CPlusPlus classes + Examples/PremadeMatrix/main.cc, compiled where they lie and linked against
-    libntpoly_amd.so (oracle/build_cxx_example.py; built only where /root/reference exists, travels as a built
-    file).  Run here as the reference's ReadMe runs it, on the reference's Hamiltonian / Overlap, it must reproduce
-    the reference's shipped density (nel = 5)."""
+@pytest.mark.parametrize("binary", ["premade_cxx", "premade_f90"])
+def test_reference_examples_link_and_run(tmp_path, binary):
+    """Drop-in at the reference's own language layers.
+    premade_cxx: the reference's UNCHANGED Source/CPlusPlus classes + Examples/PremadeMatrix/main.cc, compiled where
+    they lie and linked against libntpoly_amd.so (oracle/build_cxx_example.py).
+    premade_f90: the reference's UNCHANGED Examples/PremadeMatrix/main.f90 compiled against the product's Fortran
+    module layer fortran/ntpoly_amd_modules.f90 (ISO_C_BINDING over the same C ABI; oracle/build_fortran_example.py).
+    Both are built only where /root/reference exists and travel as built files.  Run here as the reference's ReadMe
+    runs them, on the reference's Hamiltonian / Overlap, they must reproduce the reference's shipped density
+    (nel = 5)."""
     import subprocess
     import scipy.io
     import scipy.sparse as sp
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "oracle", "_ref", "premade_cxx")
+    exe = os.path.join(root, "oracle", "_ref", binary)
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/premade_cxx was not built (needs /root/reference at build time)")
+        pytest.skip("oracle/_ref/%s was not built (needs /root/reference at build time)" % binary)
     g = Golden("solvers")
     i_h = [i for i, c in enumerate(g.cases) if c["tag"] == "premade_trs2_nel5"][0]
     i_s = [i for i, c in enumerate(g.cases) if c["tag"] == "premade_isq"][0]
@@ -269,6 +273,8 @@ def test_reference_cxx_example_links_and_runs(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "Density Matrix Solver" in r.stdout and "TRS2" in r.stdout     # the reference's log format, from our logger
+    if binary == "premade_f90":
+        assert "Command Line Parameters" in r.stdout and "number_of_electrons" in r.stdout   # LoggingModule wrappers
     D = scipy.io.mmread(str(out)).toarray()
     Dref = to_dense(g.tri(None, "premade_density_reference"))
     assert np.linalg.norm(D - Dref) <= 5e-5
