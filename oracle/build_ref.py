@@ -80,10 +80,25 @@ def run(cmd, **kw):
     return r.stdout
 
 
-def build(force=False):
+def build(force=False, fma=False):
+    """fma=True: a second build under oracle/_ref/fma with floating-point contraction on (-ffp-contract=fast
+    -march=haswell: `acc = acc + a*b` becomes one FMA), i.e. what the reference computes on targets where FMA is
+    baseline (its Fugaku/aarch64 target) or with -march=native; pins the engine's spgemm_fma option."""
+    global OUT, FFLAGS
     if not available():
         print("reference toolchain/sources not present: skipping oracle/_ref build")
         return False
+    out0, flags0 = OUT, FFLAGS
+    if fma:
+        OUT = os.path.join(out0, "fma")
+        FFLAGS = flags0 + ["-ffp-contract=fast", "-march=haswell"]
+    try:
+        return _build(force)
+    finally:
+        OUT, FFLAGS = out0, flags0
+
+
+def _build(force):
     os.makedirs(os.path.join(OUT, "obj"), exist_ok=True)
     os.makedirs(os.path.join(OUT, "mod"), exist_ok=True)
     lib = os.path.join(OUT, "libNTPoly_ref.a")
@@ -109,5 +124,5 @@ def build(force=False):
 
 
 if __name__ == "__main__":
-    ok = build(force="--force" in sys.argv)
+    ok = build(force="--force" in sys.argv, fma="--fma" in sys.argv)
     sys.exit(0 if ok else 2)

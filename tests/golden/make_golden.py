@@ -462,6 +462,36 @@ def gen_functions(tmp):
     save("functions", d, dict(kind="functions", cases=cases))
 
 
+def gen_ps_gemm_fma(tmp):
+    """Distributed multiply computed by the reference built WITH floating-point contraction (oracle/build_ref.py
+    --fma: -ffp-contract=fast -march=haswell, `acc + a*b` is one FMA) -- what the reference produces on targets
+    with baseline FMA.  Pins the engine's spgemm_fma option (v_fma_f64 in the register-slab kernel)."""
+    global DRV
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import build_ref
+    if not build_ref.build(fma=True):
+        raise SystemExit("reference not buildable here")
+    drv0, DRV = DRV, os.path.join(ROOT, "oracle", "_ref", "fma", "ref_driver")
+    try:
+        d, cases = {}, []
+        for (n, h, h2, alpha, thr, tag) in ((512, 16, 16, 1.0, 0.0, "b512_sq_thr0"), (1024, 40, 40, 1.0, 1e-8, "b1024_sq"),
+                                            (1500, 70, 90, 0.5, 1e-7, "b1500_ab"), (1800, 80, 80, 1.0, 1e-9, "b1800_wide")):   # all < 10 % dense: sparse branch
+            A = banded(n, h)
+            B = A if h2 == h and alpha == 1.0 else sp.csc_matrix(banded(n, h2) * 1.01)
+            write_tri(tmp + "/A.tri", n, n, *tri(A))
+            write_tri(tmp + "/B.tri", n, n, *tri(B))
+            run(["pgemm", 1, 1, 1, tmp + "/A.tri", tmp + "/B.tri", "none", repr(alpha), "0.0", repr(thr), tmp + "/C.tri"])
+            rows, cols, c, r, v = read_tri(tmp + "/C.tri")
+            pre = "c%03d_" % len(cases)
+            put(d, pre + "A", A.shape, tri(A))
+            put(d, pre + "B", B.shape, tri(B))
+            put(d, pre + "C", (rows, cols), (c, r, v))
+            cases.append(dict(tag=tag, alpha=alpha, thr=thr, n=n, same=bool(B is A)))
+        save("ps_gemm_fma", d, dict(kind="ps_gemm_fma", cases=cases))
+    finally:
+        DRV = drv0
+
+
 def gen_multirank(tmp):
     """Same product on 1, 4 (2x2x1) and 8 (2x2x2) reference ranks: pins that values do not
     depend on the grid when slices == 1 and records the slices>1 behaviour."""

@@ -423,3 +423,31 @@ def test_full_size_properties_config4_complex(nt):
     R.Increment(Ident, -1.0, 0.0)
     assert R.Norm() <= 1e-5
     assert Z.MeasureAsymmetry() <= 1e-5   # Newton-Schulz with threshold 1e-8 is Hermitian to the pruning error only
+
+
+def test_fma_option_matches_contracted_reference_build(nt):
+    """spgemm_fma = 1 against the reference compiled WITH floating-point contraction (tests/golden/ps_gemm_fma.npz,
+    make_golden.py ps_gemm_fma; oracle/build_ref.py --fma): bit-identical.  So each arithmetic mode of the engine
+    equals a build of the reference: the default its Linux/x86-64 build (no FMA), the option its FMA builds."""
+    g = Golden("ps_gemm_fma")
+    nt.set_option("spgemm_fma", 1)
+    nt.set_option("spgemm_variant", 400)   # the option lives in the register-slab kernel: take it whenever it fits
+    try:
+        for i, c in enumerate(g.cases):
+            A = pmat(nt, g.tri(i, "A"))
+            B = A if c["same"] else pmat(nt, g.tri(i, "B"))
+            want = g.tri(i, "C")
+            C = nt.Matrix_ps(want[0])
+            C.Gemm(A, B, None, c["alpha"], 0.0, c["thr"])
+            assert nt.last_spgemm_stats()["slab"] == 1, c["tag"]
+            exact(C.triplets(), want, "fma " + c["tag"])
+    finally:
+        nt.set_option("spgemm_fma", 0)
+        nt.set_option("spgemm_variant", -1)
+    # and the default mode must NOT equal it (the two builds of the reference differ in the last bits)
+    i = 1
+    A = pmat(nt, g.tri(i, "A"))
+    C = nt.Matrix_ps(g.tri(i, "C")[0])
+    C.Gemm(A, A, None, 1.0, 0.0, g.cases[i]["thr"])
+    got, want = C.triplets(), g.tri(i, "C")
+    assert not (len(got[2]) == len(want[4]) and np.array_equal(got[2], want[4]))
