@@ -451,3 +451,44 @@ def test_fma_option_matches_contracted_reference_build(nt):
     C.Gemm(A, A, None, 1.0, 0.0, g.cases[i]["thr"])
     got, want = C.triplets(), g.tri(i, "C")
     assert not (len(got[2]) == len(want[4]) and np.array_equal(got[2], want[4]))
+
+
+def test_full_size_properties_config2_trs2(nt):
+    """BASELINE configs[2] (the bench workload: N = 262 144, 201 nnz/row, threshold 1e-8, ISQ = I, trace = N/2) as a
+    whole converged TRS2 solve, checked through what does not depend on the size: the density is symmetric,
+    idempotent up to the threshold, has the requested trace, energy = dot(K, H); and two independent kernel
+    implementations (register-slab with the product handed uncompacted to the update, vs the LDS column-pair kernel
+    with the unfused call sequence) give the same energies at every iteration and the same density, bit for bit."""
+    n, h, thr = 262144, 100, 1e-8
+    col, row, val = banded_triplets(n, h)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    del col, row, val
+    ISQ = nt.Matrix_ps(n)
+    ISQ.FillIdentity()
+    p = nt.SolverParameters()
+    p.SetThreshold(thr)
+    p.SetConvergeDiff(1e-6)
+    K = nt.Matrix_ps(n)
+    energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, p)
+    tr = nt.solver_trace()
+    assert 10 <= tr["iterations"] <= 60
+    assert K.Trace() == pytest.approx(n / 2.0, abs=5e-2)
+    assert K.MeasureAsymmetry() <= 1e-12
+    assert energy == pytest.approx(float(np.real(K.Dot(H))), rel=1e-12)
+    K2 = nt.Matrix_ps(n)
+    K2.Gemm(K, K, None, 1.0, 0.0, thr)
+    K2.Increment(K, -1.0, 0.0)
+    assert K2.Norm() <= 1e-4            # idempotent to the purification's own convergence
+    nt.set_option("spgemm_variant", 351)
+    try:
+        Kb = nt.Matrix_ps(n)
+        energy_b, mu_b = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, Kb, p)
+        tr_b = nt.solver_trace()
+    finally:
+        nt.set_option("spgemm_variant", -1)
+    assert tr_b["iterations"] == tr["iterations"]
+    assert np.array_equal(tr_b["sigma"], tr["sigma"])
+    assert np.allclose(tr_b["energy"], tr["energy"], rtol=1e-13, atol=0)
+    assert energy_b == pytest.approx(energy, rel=1e-13) and mu_b == pytest.approx(mu, rel=1e-12)
+    ka, kb = K.triplets(), Kb.triplets()
+    assert all(np.array_equal(u, v) for u, v in zip(ka, kb))
