@@ -517,446 +517,12 @@ __global__ __launch_bounds__(NW* WAVE) void k_spgemm_window(
   if (lane == 0) count[j] = cnt;
 }
 
-// ------------------------------------------------------------------ SpGEMM: numeric, multi-column LDS window
-// Second-generation window kernel.  One wave owns R CONSECUTIVE output columns and walks the UNION
-// of their B rows in ascending k (a scalar R-way merge over 64-entry batches held in VGPRs and read
-// with v_readlane).  Every 64-entry chunk of A(:,k) is fetched ONCE into registers and applied to
-// each of the R columns that has a B(k, j_r) entry: operand traffic through L1/L2 per product drops
-// by ~R for banded operands (neighbouring columns share almost all k).  The accumulators are R
-// direct-mapped LDS windows updated with ds_add_f64 (fire-and-forget, no read-modify-write round
-// trip; one lane per row inside an instruction, instructions of a wave execute in order => the
-// ascending-k, unfused arithmetic of the contract is preserved bit for bit).  Chunk loads run D
-// slots ahead of their use (software pipeline in registers) to cover L2/HBM latency at the low wave
-// count the LDS budget allows.  Window length is a launch parameter (max span of the bin), LDS is
-// dynamic.
-// Chunk loads are issued with inline asm so that hipcc's own s_waitcnt bookkeeping (which falls back
-// to vmcnt(0) across the data-dependent control flow of the merge and would drain the pipeline at
-// every use) does not see them; the waits are counted by hand.  Invariant: EVERY produce() issues
-// exactly MC_LOADS<T> vector-memory loads (a dummy re-read of a valid address when the stream has
-// ended), so at consume(s) exactly MC_LOADS*(D-1) younger loads are outstanding and
-// `s_waitcnt vmcnt(MC_LOADS*(D-1))` retires slot s (vmcnt is in issue order).  Loads the compiler
-// emits itself (batch refills) are waited for by the compiler before their first use, which can only
-// make the hand-counted wait conservative.  (cdna_hip_programming.md 5.7)
-__device__ inline void gload_i32(int& dst, const int* p) {
-  asm volatile("global_load_dword %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
-}
-__device__ inline void gload_f64(double& dst, const double* p) {
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
-}
-template <int N>
-__device__ inline void wait_vm(int& a, double& b) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
-}
-template <int N>
-__device__ inline void wait_vm(int& a, double2& b) {
-  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b.x), "+v"(b.y) : "n"(N) : "memory");
-}
-__device__ inline void gload_T(double& dst, const double* p) { gload_f64(dst, p); }
-__device__ inline void gload_T(double2& dst, const double2* p) {
-  gload_f64(dst.x, reinterpret_cast<const double*>(p));
-  gload_f64(dst.y, reinterpret_cast<const double*>(p) + 1);
-}
-template <typename T>
-struct McLoads { static constexpr int n = 2; };
-template <>
-struct McLoads<double2> { static constexpr int n = 3; };
-
-template <typename T, int R>
-struct McBatch {
-  int kv[R];        // row index k of B(:, j_r) entries (lane-parallel, 64 per batch)
-  T bv[R];          // their values
-  int64_t asv[R];   // A.outer[k]
-  int lenv[R];      // nnz(A(:,k))
-};
-
-template <typename T, int R, int D, int ABL = 0>
-__global__ __launch_bounds__(WAVE) void k_spgemm_mc(
-    Csc A, Csc B, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
-    const uint8_t* __restrict__ bin_arr, int my_bin, const int64_t* __restrict__ tmpoff,
-    int32_t* __restrict__ out_inner, T* __restrict__ out_val, int32_t* __restrict__ count,
-    double alpha, double threshold, int dense_rule, int ngroups, int wrt) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* acc_all = reinterpret_cast<T*>(smem);
-  const int g = xcd_block(ngroups);
-  if (g < 0) return;
-  const int lane = lane_id();
-  const int32_t* __restrict__ Ai = A.inner;
-  const T* __restrict__ Av = static_cast<const T*>(A.val);
-  const T* __restrict__ Bv = static_cast<const T*>(B.val);
-
-  int lo[R], span[R];
-  bool act[R];
-  int64_t pb[R];
-  int rem[R];       // B entries of column r not yet fetched into a batch
-  int cnt[R], cur[R];
-  McBatch<T, R> bt;
-  bool any = false;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int j = g * R + r;
-    // wave-uniform by construction; readfirstlane pins them to SGPRs so the merge below is scalar code
-    act[r] = uni_i32(((j < B.cols) && (bin_arr[min(j, B.cols - 1)] == my_bin)) ? 1 : 0) != 0;
-    lo[r] = uni_i32(act[r] ? lo_arr[j] : 0);
-    span[r] = uni_i32(act[r] ? span_arr[j] : 0);
-    pb[r] = uni_i64(act[r] ? B.outer[j] : 0);
-    rem[r] = uni_i32(act[r] ? (int)(B.outer[j + 1] - B.outer[j]) : 0);
-    cnt[r] = 0;
-    cur[r] = 0;
-    any = any || act[r];
-  }
-  if (!any) return;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    T* acc = acc_all + r * wrt;
-    for (int s = lane; s < span[r]; s += WAVE) acc[s] = Sc<T>::zero();
-  }
-
-  // ---- stream state: the current union row k and its A column
-  int64_t as_cur = 0;
-  int len_cur = 0, q_cur = 0;
-  T bcur[R];
-  unsigned fl_cur = 0;
-  bool done = false;
-
-  auto refill = [&](int r) {
-    const int n = min(WAVE, rem[r]);
-    int k = 0;
-    T b = Sc<T>::zero();
-    int64_t as = 0;
-    int len = 0;
-    if (lane < n) {
-      k = B.inner[pb[r] + lane];
-      b = Bv[pb[r] + lane];
-      as = A.outer[k];
-      len = (int)(A.outer[k + 1] - as);
-    }
-    bt.kv[r] = k;
-    bt.bv[r] = b;
-    bt.asv[r] = as;
-    bt.lenv[r] = len;
-    cnt[r] = n;
-    cur[r] = 0;
-    pb[r] += n;
-    rem[r] -= n;
-  };
-
-  auto advance_k = [&]() {
-    int kmin = INT_MAX;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (cur[r] == cnt[r] && rem[r] > 0) refill(r);
-      if (cur[r] < cnt[r]) kmin = min(kmin, readlane_i32(bt.kv[r], cur[r]));
-    }
-    if (kmin == INT_MAX) {
-      done = true;
-      len_cur = 0;
-      q_cur = 0;
-      fl_cur = 0;
-      return;
-    }
-    fl_cur = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      bcur[r] = Sc<T>::zero();
-      if (cur[r] < cnt[r] && readlane_i32(bt.kv[r], cur[r]) == kmin) {
-        fl_cur |= (1u << r);
-        bcur[r] = readlane_T(bt.bv[r], cur[r]);
-        as_cur = readlane_i64(bt.asv[r], cur[r]);
-        len_cur = readlane_i32(bt.lenv[r], cur[r]);
-        cur[r] += 1;
-      }
-    }
-    q_cur = 0;
-  };
-
-  // ---- register pipeline of D chunk slots
-  int s_idx[D];
-  T s_val[D];
-  int s_n[D];
-  unsigned s_fl[D];
-  T s_b[D][R];
-
-  auto produce = [&](int s) {
-    while (!done && q_cur >= len_cur) advance_k();  // also skips empty A columns
-    int64_t at = 0;  // dummy (valid) address when the stream has ended: keeps the load count static
-    if (done) {
-      s_n[s] = 0;
-      s_fl[s] = 0;
-    } else {
-      const int n = min(WAVE, len_cur - q_cur);
-      s_n[s] = n;
-      s_fl[s] = fl_cur;
-#pragma unroll
-      for (int r = 0; r < R; ++r) s_b[s][r] = bcur[r];
-      at = as_cur + q_cur + min(lane, n - 1);  // clamp instead of predicating: every lane loads
-      q_cur += WAVE;
-    }
-    if constexpr (ABL & 2) {  // ablation: no operand loads
-      s_idx[s] = lo[0] + (lane & 255);
-      s_val[s] = Sc<T>::zero();
-      asm volatile("" :: "v"(at));
-    } else {
-      gload_i32(s_idx[s], Ai + at);
-      gload_T(s_val[s], Av + at);
-    }
-  };
-
-  auto consume = [&](int s) {
-    if constexpr (!(ABL & 2)) wait_vm<McLoads<T>::n*(D - 1)>(s_idx[s], s_val[s]);
-    if (lane < s_n[s]) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (s_fl[s] & (1u << r)) {
-          const T pr = Sc<T>::mul(s_val[s], s_b[s][r]);
-          T* slot = acc_all + r * wrt + (s_idx[s] - lo[r]);
-          if constexpr (ABL & 1) {  // ablation: no LDS accumulate (keep the operands live)
-            if constexpr (Sc<T>::cplx) asm volatile("" :: "v"(pr.x), "v"(pr.y), "v"(slot));
-            else asm volatile("" :: "v"(pr), "v"(slot));
-          } else if constexpr (Sc<T>::cplx) {
-            atomicAdd(&slot->x, pr.x);
-            atomicAdd(&slot->y, pr.y);
-          } else {
-            atomicAdd(slot, pr);
-          }
-        }
-      }
-    }
-  };
-
-#pragma unroll
-  for (int s = 0; s < D; ++s) produce(s);
-  for (;;) {
-    bool live = false;
-#pragma unroll
-    for (int s = 0; s < D; ++s) live = live || (s_n[s] > 0);
-    if (!live) break;
-#pragma unroll
-    for (int s = 0; s < D; ++s) {
-      consume(s);
-      produce(s);
-    }
-  }
-  // drain the dummy loads of the last round before the registers are reused
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-
-  // ---- epilogue: prune + compact every window in row order
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (!act[r]) continue;
-    const int j = g * R + r;
-    const T* acc = acc_all + r * wrt;
-    const int64_t base = tmpoff[j];
-    int c = 0;
-    for (int s0 = 0; s0 < span[r]; s0 += WAVE) {
-      const int s = s0 + lane;
-      const T v = (s < span[r]) ? acc[s] : Sc<T>::zero();
-      const T sv = Sc<T>::scale(alpha, v);
-      const bool keep = (s < span[r]) && (dense_rule ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
-      const unsigned long long m = __ballot(keep);
-      if (keep) {
-        const int64_t pos = base + c + __popcll(m & lanemask_lt());
-        out_inner[pos] = lo[r] + s;
-        out_val[pos] = sv;
-      }
-      c += __popcll(m);
-    }
-    if (lane == 0) count[j] = c;
-  }
-}
-
-// ------------------------------------------------------------------ SpGEMM: numeric, lean column-pair kernel
-// Third-generation window kernel, built from the measurements in profiles/README.md (ablation: the
-// generic multi-column kernel above is bound by its own scalar bookkeeping, not by loads or LDS).
-// One wave owns TWO adjacent output columns.  Their B rows are merged by a 3-way scalar compare
-// (k0 < k1, k0 == k1, k0 > k1) over 64-entry batches kept in VGPRs; the A column of the current
-// union row is held in one of two register sets of MAXCH chunks (64 entries each) while the OTHER
-// set is being loaded for the next union row (double buffering at column granularity, hand-counted
-// vmcnt: every issue() posts exactly 2*MAXCH loads, clamped to valid addresses).  Each loaded entry
-// feeds up to two ds_add_f64 (one per output column).  Columns of A longer than 64*MAXCH finish in a
-// plain loop.  Arithmetic and order are those of k_spgemm_window (bit-identical results).
-template <int MAXCH>
-struct PairSet {
-  int idx[MAXCH];
-  double val[MAXCH];
-};
-
-template <int MAXCH, int NW>
-__global__ __launch_bounds__(NW* WAVE) void k_spgemm_pair(
-    Csc A, Csc B, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
-    const uint8_t* __restrict__ bin_arr, int my_bin, const int64_t* __restrict__ tmpoff,
-    int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count,
-    double alpha, double threshold, int dense_rule, int nblocks, int wrt) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = xcd_block(nblocks);
-  if (b < 0) return;
-  const int wave = uni_i32(threadIdx.x / WAVE), lane = lane_id();
-  const int g = b * NW + wave;
-  double* acc0 = reinterpret_cast<double*>(smem) + (size_t)(wave * 2) * wrt;
-  double* acc1 = acc0 + wrt;
-  const int32_t* __restrict__ Ai = A.inner;
-  const double* __restrict__ Av = static_cast<const double*>(A.val);
-  const double* __restrict__ Bv = static_cast<const double*>(B.val);
-  const int last = (int)A.outer[A.cols] - 1;  // clamp target for padded lanes (host guarantees nnz(A) > 0)
-
-  const int j0 = 2 * g, j1 = 2 * g + 1;
-  const bool act0 = uni_i32((j0 < B.cols && bin_arr[min(j0, B.cols - 1)] == my_bin) ? 1 : 0) != 0;
-  const bool act1 = uni_i32((j1 < B.cols && bin_arr[min(j1, B.cols - 1)] == my_bin) ? 1 : 0) != 0;
-  if (!act0 && !act1) return;
-  const int lo0 = uni_i32(act0 ? lo_arr[j0] : 0), span0 = uni_i32(act0 ? span_arr[j0] : 0);
-  const int lo1 = uni_i32(act1 ? lo_arr[j1] : 0), span1 = uni_i32(act1 ? span_arr[j1] : 0);
-  int pb0 = uni_i32(act0 ? (int)B.outer[j0] : 0), rem0 = uni_i32(act0 ? (int)(B.outer[j0 + 1] - B.outer[j0]) : 0);
-  int pb1 = uni_i32(act1 ? (int)B.outer[j1] : 0), rem1 = uni_i32(act1 ? (int)(B.outer[j1 + 1] - B.outer[j1]) : 0);
-  for (int s = lane; s < span0; s += WAVE) acc0[s] = 0.0;
-  for (int s = lane; s < span1; s += WAVE) acc1[s] = 0.0;
-
-  // 64-entry batches of the two B columns: row k, value, start and length of A(:,k)
-  int kv0 = 0, av0 = 0, lv0 = 0, n0 = 0, c0 = 0;
-  int kv1 = 0, av1 = 0, lv1 = 0, n1 = 0, c1 = 0;
-  double bv0 = 0.0, bv1 = 0.0;
-  auto refill0 = [&]() {
-    n0 = min(WAVE, rem0);
-    c0 = 0;
-    if (lane < n0) {
-      kv0 = B.inner[pb0 + lane];
-      bv0 = Bv[pb0 + lane];
-      const int64_t as = A.outer[kv0];
-      av0 = (int)as;
-      lv0 = (int)(A.outer[kv0 + 1] - as);
-    }
-    pb0 += n0;
-    rem0 -= n0;
-  };
-  auto refill1 = [&]() {
-    n1 = min(WAVE, rem1);
-    c1 = 0;
-    if (lane < n1) {
-      kv1 = B.inner[pb1 + lane];
-      bv1 = Bv[pb1 + lane];
-      const int64_t as = A.outer[kv1];
-      av1 = (int)as;
-      lv1 = (int)(A.outer[kv1 + 1] - as);
-    }
-    pb1 += n1;
-    rem1 -= n1;
-  };
-  // next union row: returns false at the end; fl bit0 / bit1 = column 0 / 1 has an entry in this row
-  auto next_desc = [&](int& as, int& len, int& fl, double& b0, double& b1) -> bool {
-    if (c0 == n0 && rem0 > 0) refill0();
-    if (c1 == n1 && rem1 > 0) refill1();
-    const int k0 = (c0 < n0) ? readlane_i32(kv0, c0) : INT_MAX;
-    const int k1 = (c1 < n1) ? readlane_i32(kv1, c1) : INT_MAX;
-    if (k0 == INT_MAX && k1 == INT_MAX) return false;
-    if (k0 <= k1) {
-      as = readlane_i32(av0, c0);
-      len = readlane_i32(lv0, c0);
-      b0 = readlane_f64(bv0, c0);
-      fl = 1;
-      if (k0 == k1) {
-        b1 = readlane_f64(bv1, c1);
-        fl = 3;
-        c1 += 1;
-      }
-      c0 += 1;
-    } else {
-      as = readlane_i32(av1, c1);
-      len = readlane_i32(lv1, c1);
-      b1 = readlane_f64(bv1, c1);
-      fl = 2;
-      c1 += 1;
-    }
-    return true;
-  };
-  auto issue = [&](PairSet<MAXCH>& st, int as, int len) {
-#pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
-      const int off = min(as + min(c * WAVE + lane, len - 1), last);
-      gload_i32(st.idx[c], Ai + max(off, 0));
-      gload_f64(st.val[c], Av + max(off, 0));
-    }
-  };
-  auto process = [&](PairSet<MAXCH>& st, int as, int len, int fl, double b0, double b1) {
-    // this set has landed once only the 2*MAXCH loads of the other set (issued after it) are pending;
-    // the empty asm statements tie every later use of the registers to the wait (volatile asm keeps order)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MAXCH) : "memory");
-#pragma unroll
-    for (int c = 0; c < MAXCH; ++c) asm volatile("" : "+v"(st.idx[c]), "+v"(st.val[c]));
-#pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
-      if (c * WAVE < len) {
-        if (c * WAVE + lane < len) {
-          if (fl & 1) atomicAdd(acc0 + (st.idx[c] - lo0), __dmul_rn(st.val[c], b0));
-          if (fl & 2) atomicAdd(acc1 + (st.idx[c] - lo1), __dmul_rn(st.val[c], b1));
-        }
-      }
-    }
-    for (int q = MAXCH * WAVE; q < len; q += WAVE) {  // rare: column longer than the register set
-      if (q + lane < len) {
-        const int i = Ai[as + q + lane];
-        const double v = Av[as + q + lane];
-        if (fl & 1) atomicAdd(acc0 + (i - lo0), __dmul_rn(v, b0));
-        if (fl & 2) atomicAdd(acc1 + (i - lo1), __dmul_rn(v, b1));
-      }
-    }
-  };
-
-  PairSet<MAXCH> sa, sb;
-  int as_a = 0, len_a = 0, fl_a = 0, as_b = 0, len_b = 0, fl_b = 0;
-  double b0_a = 0, b1_a = 0, b0_b = 0, b1_b = 0;
-  bool have = next_desc(as_a, len_a, fl_a, b0_a, b1_a);
-  if (have) {
-    issue(sa, as_a, len_a);
-    for (;;) {
-      const bool hb = next_desc(as_b, len_b, fl_b, b0_b, b1_b);
-      issue(sb, hb ? as_b : 0, hb ? len_b : 1);  // dummy loads keep the outstanding count static
-      process(sa, as_a, len_a, fl_a, b0_a, b1_a);
-      if (!hb) break;
-      const bool ha = next_desc(as_a, len_a, fl_a, b0_a, b1_a);
-      issue(sa, ha ? as_a : 0, ha ? len_a : 1);
-      process(sb, as_b, len_b, fl_b, b0_b, b1_b);
-      if (!ha) break;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const bool act = r == 0 ? act0 : act1;
-    if (!act) continue;
-    const int j = r == 0 ? j0 : j1;
-    const int lo = r == 0 ? lo0 : lo1, span = r == 0 ? span0 : span1;
-    const double* acc = r == 0 ? acc0 : acc1;
-    const int64_t base = tmpoff[j];
-    int cnt = 0;
-    for (int s0 = 0; s0 < span; s0 += WAVE) {
-      const int s = s0 + lane;
-      const double v = (s < span) ? acc[s] : 0.0;
-      const double sv = __dmul_rn(alpha, v);
-      const bool keep = (s < span) && (dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold));
-      const unsigned long long m = __ballot(keep);
-      if (keep) {
-        const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
-        out_inner[pos] = lo + s;
-        out_val[pos] = sv;
-      }
-      cnt += __popcll(m);
-    }
-    if (lane == 0) count[j] = cnt;
-  }
-}
-
-// ------------------------------------------------------------------ SpGEMM: numeric, column-pair kernel v2
-// Same algorithm as k_spgemm_pair, rebuilt around the profile (profiles/README.md): the v1 build spent
-// ~70 % of every SIMD's cycles in VALU address arithmetic and lane predication that the compiler
-// generated around the loads.  Here
-//   * operand loads use the SGPR-base + 32-bit VGPR offset form with the chunk stride as an immediate
-//     (2 VALU per union row instead of ~10 per chunk); lanes past the end of a column over-read into
-//     the array slack (DevMat reserves kIndexSlack entries) instead of being clamped,
-//   * row descriptor, flags and multipliers are pinned to SGPRs (readfirstlane), the three merge cases
-//     (column 0 only / column 1 only / both) are separate straight-line bodies, and only the last,
-//     partial chunk of a column pays for a lane predicate,
-//   * the LDS address of a product is one v_lshl_add_u32: (row << 3) + (window base - lo*8).
+// ------------------------------------------------------------------ SpGEMM: numeric, column-pair kernel (LDS accumulators)
+// General fallback of the register-slab kernel (operands whose columns are not run-like).  Design notes from its
+// profiles (profiles/README.md items 2-5): operand loads use the SGPR-base + 32-bit VGPR offset form with the chunk
+// stride as an immediate (lanes past the end of a column over-read into the DevMat slack instead of being clamped),
+// multipliers and row descriptors are pinned to SGPRs, the LDS address of a product is one v_lshl_add_u32:
+// (row << 3) + (window base - lo*8), and the accumulate is one ds_add_f64 per product.
 template <int MAXCH>
 struct PairRegs {
   int idx[MAXCH];
@@ -997,179 +563,8 @@ __device__ inline void pair_process(PairRegs<MAXCH>& st, int len, double b0, dou
   }
 }
 
-template <int MAXCH, int NW, int ABL = 0>
-__global__ __launch_bounds__(NW* WAVE) void k_spgemm_pair2(
-    Csc A, Csc B, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
-    const uint8_t* __restrict__ bin_arr, int my_bin, const int64_t* __restrict__ tmpoff,
-    int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count,
-    double alpha, double threshold, int dense_rule, int nblocks, int wrt) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = xcd_block(nblocks);
-  if (b < 0) return;
-  const int wave = uni_i32(threadIdx.x / WAVE), lane = lane_id();
-  const int g = b * NW + wave;
-  const int base0 = (wave * 2) * wrt * 8, base1 = base0 + wrt * 8;  // byte offsets of the two windows
-  double* acc0 = reinterpret_cast<double*>(smem + base0);
-  double* acc1 = reinterpret_cast<double*>(smem + base1);
-  const int32_t* __restrict__ Ai = A.inner;
-  const double* __restrict__ Av = static_cast<const double*>(A.val);
-  const double* __restrict__ Bv = static_cast<const double*>(B.val);
-
-  const int j0 = 2 * g, j1 = 2 * g + 1;
-  const bool act0 = uni_i32((j0 < B.cols && bin_arr[min(j0, B.cols - 1)] == my_bin) ? 1 : 0) != 0;
-  const bool act1 = uni_i32((j1 < B.cols && bin_arr[min(j1, B.cols - 1)] == my_bin) ? 1 : 0) != 0;
-  if (!act0 && !act1) return;
-  const int lo0 = uni_i32(act0 ? lo_arr[j0] : 0), span0 = uni_i32(act0 ? span_arr[j0] : 0);
-  const int lo1 = uni_i32(act1 ? lo_arr[j1] : 0), span1 = uni_i32(act1 ? span_arr[j1] : 0);
-  const int cb0 = base0 - lo0 * 8, cb1 = base1 - lo1 * 8;
-  int pb0 = uni_i32(act0 ? (int)B.outer[j0] : 0), rem0 = uni_i32(act0 ? (int)(B.outer[j0 + 1] - B.outer[j0]) : 0);
-  int pb1 = uni_i32(act1 ? (int)B.outer[j1] : 0), rem1 = uni_i32(act1 ? (int)(B.outer[j1 + 1] - B.outer[j1]) : 0);
-  for (int s = lane; s < span0; s += WAVE) acc0[s] = 0.0;
-  for (int s = lane; s < span1; s += WAVE) acc1[s] = 0.0;
-  const unsigned lane4 = (unsigned)lane * 4u, lane8 = (unsigned)lane * 8u;
-
-  int kv0 = 0, av0 = 0, lv0 = 0, n0 = 0, c0 = 0;
-  int kv1 = 0, av1 = 0, lv1 = 0, n1 = 0, c1 = 0;
-  double bv0 = 0.0, bv1 = 0.0;
-  auto refill0 = [&]() {
-    n0 = min(WAVE, rem0);
-    c0 = 0;
-    if (lane < n0) {
-      kv0 = B.inner[pb0 + lane];
-      bv0 = Bv[pb0 + lane];
-      const int64_t as = A.outer[kv0];
-      av0 = (int)as;
-      lv0 = (int)(A.outer[kv0 + 1] - as);
-    }
-    pb0 += n0;
-    rem0 -= n0;
-  };
-  auto refill1 = [&]() {
-    n1 = min(WAVE, rem1);
-    c1 = 0;
-    if (lane < n1) {
-      kv1 = B.inner[pb1 + lane];
-      bv1 = Bv[pb1 + lane];
-      const int64_t as = A.outer[kv1];
-      av1 = (int)as;
-      lv1 = (int)(A.outer[kv1 + 1] - as);
-    }
-    pb1 += n1;
-    rem1 -= n1;
-  };
-  auto next_desc = [&](int& as, int& len, int& fl, double& b0, double& b1) -> bool {
-    if (c0 == n0 && rem0 > 0) refill0();
-    if (c1 == n1 && rem1 > 0) refill1();
-    const int k0 = (c0 < n0) ? readlane_i32(kv0, c0) : INT_MAX;
-    const int k1 = (c1 < n1) ? readlane_i32(kv1, c1) : INT_MAX;
-    if (k0 == INT_MAX && k1 == INT_MAX) return false;
-    if (k0 <= k1) {
-      as = readlane_i32(av0, c0);
-      len = readlane_i32(lv0, c0);
-      b0 = readlane_f64(bv0, c0);
-      fl = 1;
-      if (k0 == k1) {
-        b1 = readlane_f64(bv1, c1);
-        fl = 3;
-        c1 += 1;
-      }
-      c0 += 1;
-    } else {
-      as = readlane_i32(av1, c1);
-      len = readlane_i32(lv1, c1);
-      b1 = readlane_f64(bv1, c1);
-      fl = 2;
-      c1 += 1;
-    }
-    return true;
-  };
-  auto issue = [&](PairRegs<MAXCH>& st, int as) {
-    const unsigned a = (unsigned)uni_i32(as);
-    if constexpr (ABL & 2) {  // ablation: no operand loads
-#pragma unroll
-      for (int c = 0; c < MAXCH; ++c) { st.idx[c] = lo0 + ((lane + c * 64) & 255); st.val[c] = 1.0; }
-      asm volatile("" :: "v"(a));
-    } else {
-      pair_issue<MAXCH>(st, (a << 2) + lane4, (a << 3) + lane8, Ai, Av, std::make_integer_sequence<int, MAXCH>{});
-    }
-  };
-  auto process = [&](PairRegs<MAXCH>& st, int as_x, int len_x, int fl_x, double b0_x, double b1_x) {
-    // only the 2*MAXCH loads of the other register set (issued after this one) may still be pending
-    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MAXCH) : "memory");
-#pragma unroll
-    for (int c = 0; c < MAXCH; ++c) asm volatile("" : "+v"(st.idx[c]), "+v"(st.val[c]));
-    if constexpr (ABL & 4) {  // ablation: merge/refill only
-      asm volatile("" :: "s"(len_x), "s"(fl_x), "v"(b0_x), "v"(b1_x), "s"(as_x));
-      return;
-    }
-    const int len = uni_i32(len_x), fl = uni_i32(fl_x);
-    const double b0 = readlane_f64(b0_x, 0), b1 = readlane_f64(b1_x, 0);
-    if (fl == 3) pair_process<3, MAXCH, ABL>(st, len, b0, b1, cb0, cb1, smem, lane);
-    else if (fl == 1) pair_process<1, MAXCH, ABL>(st, len, b0, b1, cb0, cb1, smem, lane);
-    else pair_process<2, MAXCH, ABL>(st, len, b0, b1, cb0, cb1, smem, lane);
-    if (len > MAXCH * WAVE) {  // rare: column longer than the register set
-      const int as = uni_i32(as_x);
-      for (int q = MAXCH * WAVE; q < len; q += WAVE) {
-        if (q + lane < len) {
-          const int i = Ai[as + q + lane];
-          const double v = Av[as + q + lane];
-          if (fl & 1) atomicAdd(acc0 + (i - lo0), __dmul_rn(v, b0));
-          if (fl & 2) atomicAdd(acc1 + (i - lo1), __dmul_rn(v, b1));
-        }
-      }
-    }
-  };
-
-  PairRegs<MAXCH> sa, sb;
-  int as_a = 0, len_a = 0, fl_a = 0, as_b = 0, len_b = 0, fl_b = 0;
-  double b0_a = 0, b1_a = 0, b0_b = 0, b1_b = 0;
-  bool have = next_desc(as_a, len_a, fl_a, b0_a, b1_a);
-  if (have) {
-    issue(sa, as_a);
-    for (;;) {
-      const bool hb = next_desc(as_b, len_b, fl_b, b0_b, b1_b);
-      issue(sb, hb ? as_b : 0);  // a dummy issue keeps the outstanding-load count static
-      process(sa, as_a, len_a, fl_a, b0_a, b1_a);
-      if (!hb) break;
-      const bool ha = next_desc(as_a, len_a, fl_a, b0_a, b1_a);
-      issue(sa, ha ? as_a : 0);
-      process(sb, as_b, len_b, fl_b, b0_b, b1_b);
-      if (!ha) break;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-
-  if constexpr (ABL & 8) return;  // ablation: no epilogue
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const bool act = r == 0 ? act0 : act1;
-    if (!act) continue;
-    const int j = r == 0 ? j0 : j1;
-    const int lo = r == 0 ? lo0 : lo1, span = r == 0 ? span0 : span1;
-    const double* acc = r == 0 ? acc0 : acc1;
-    const int64_t base = tmpoff[j];
-    int cnt = 0;
-    for (int s0 = 0; s0 < span; s0 += WAVE) {
-      const int s = s0 + lane;
-      const double v = (s < span) ? acc[s] : 0.0;
-      const double sv = __dmul_rn(alpha, v);
-      const bool keep = (s < span) && (dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold));
-      const unsigned long long m = __ballot(keep);
-      if (keep) {
-        const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
-        out_inner[pos] = lo + s;
-        out_val[pos] = sv;
-      }
-      cnt += __popcll(m);
-    }
-    if (lane == 0) count[j] = cnt;
-  }
-}
-
-// ------------------------------------------------------------------ SpGEMM: numeric, column-pair kernel v3
-// Ablation of v2 (profiles/README.md): 7.5 of 13.3 ms were the serial scalar merge of the two B
-// columns plus their synchronous batch refills.  v3 removes the merge: the union of the two columns
+// One wave owns two adjacent output columns.  An earlier generation merged the two B columns with a serial scalar
+// merge (7.5 of its 13.3 ms, profiles/README.md item 4); here the union of the two columns
 // is walked in ROW WINDOWS of 64 consecutive k.  Inside a window the slot of a row is simply
 // k - kw, i.e. a LANE: each column scatters its multipliers to the slot lanes with one ds_permute
 // (cross-lane, no LDS memory), A's column pointers for the 64 slots are one coalesced load of
@@ -2593,38 +1988,6 @@ void flush_spgemm_timers() {
 }
 
 namespace {
-template <typename T, int R, int D, int ABL = 0>
-void launch_mc(int bin, int wrt, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
-               const uint8_t* binarr, const int64_t* tmpoff, int32_t* out_inner, T* out_val, int32_t* count,
-               double alpha, double thr, int dense_rule) {
-  const int ngroups = cdiv(B.cols, R);
-  const size_t lds = (size_t)R * (size_t)wrt * sizeof(T);
-  hipLaunchKernelGGL((k_spgemm_mc<T, R, D, ABL>), dim3(xcd_grid(ngroups)), dim3(WAVE), lds, stream(), view(A), view(B), lo,
-                     span, binarr, bin, tmpoff, out_inner, out_val, count, alpha, thr, dense_rule, ngroups, wrt);
-}
-
-template <int MAXCH, int NW>
-void launch_pair(int bin, int wrt, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
-                 const uint8_t* binarr, const int64_t* tmpoff, int32_t* out_inner, double* out_val, int32_t* count,
-                 double alpha, double thr, int dense_rule) {
-  const int ngroups = cdiv(B.cols, 2);
-  const int nblocks = cdiv(ngroups, NW);
-  const size_t lds = (size_t)NW * 2 * (size_t)wrt * sizeof(double);
-  hipLaunchKernelGGL((k_spgemm_pair<MAXCH, NW>), dim3(xcd_grid(nblocks)), dim3(NW * WAVE), lds, stream(), view(A), view(B),
-                     lo, span, binarr, bin, tmpoff, out_inner, out_val, count, alpha, thr, dense_rule, nblocks, wrt);
-}
-
-template <int MAXCH, int NW, int ABL = 0>
-void launch_pair2(int bin, int wrt, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
-                  const uint8_t* binarr, const int64_t* tmpoff, int32_t* out_inner, double* out_val, int32_t* count,
-                  double alpha, double thr, int dense_rule) {
-  const int ngroups = cdiv(B.cols, 2);
-  const int nblocks = cdiv(ngroups, NW);
-  const size_t lds = (size_t)NW * 2 * (size_t)wrt * sizeof(double);
-  hipLaunchKernelGGL((k_spgemm_pair2<MAXCH, NW, ABL>), dim3(xcd_grid(nblocks)), dim3(NW * WAVE), lds, stream(), view(A), view(B),
-                     lo, span, binarr, bin, tmpoff, out_inner, out_val, count, alpha, thr, dense_rule, nblocks, wrt);
-}
-
 template <int MAXCH, int NW>
 void launch_pair3(int bin_lo, int bin_hi, int wrt, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
                   const uint8_t* binarr, const int64_t* tmpoff, int32_t* out_inner, double* out_val, int32_t* count,
@@ -2790,7 +2153,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     int variant = options().spgemm_variant;
     if (variant / 100 == 4) variant = -1;  // slab kernel requested but not applicable
     if constexpr (!Sc<T>::cplx) {
-      // default for real operands: column-pair kernel v3, register-set depth from the mean column length of A
+      // real operands that are not run-like: column-pair kernel, register-set depth from the mean column length of A
       if (variant < 0 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {
         const double avg = (double)A.nnz / (double)std::max(1, A.cols);
         const int need = (int)std::ceil(avg / 64.0);
@@ -2799,59 +2162,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     }
     auto wrt_of = [&](int b) { return (int)((hstats[9 + b] + 63) / 64 * 64); };
     if constexpr (!Sc<T>::cplx) {
-      if (variant == 1) {  // multi-column pipelined kernel, 4 columns per wave
-        if (hstats[1]) launch_mc<T, 4, 4>(1, wrt_of(1), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        if (hstats[2]) launch_mc<T, 4, 4>(2, wrt_of(2), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        if (hstats[3]) launch_mc<T, 2, 4>(3, wrt_of(3), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        hstats[1] = hstats[2] = hstats[3] = 0;
-      } else if (variant == 2) {  // 2 columns per wave
-        if (hstats[1]) launch_mc<T, 2, 4>(1, wrt_of(1), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        if (hstats[2]) launch_mc<T, 2, 4>(2, wrt_of(2), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        if (hstats[3]) launch_mc<T, 2, 4>(3, wrt_of(3), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        hstats[1] = hstats[2] = hstats[3] = 0;
-      } else if (variant >= 10 && variant < 100) {  // ablations / depth experiments on the dominant bin only
-        const int bsel = hstats[2] >= hstats[1] ? 2 : 1;
-        const int w = wrt_of(bsel);
-#define MC_CASE(V, RR, DD, AB) \
-  if (variant == V) launch_mc<T, RR, DD, AB>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        MC_CASE(10, 2, 4, 1) MC_CASE(11, 2, 4, 2) MC_CASE(12, 2, 4, 3)
-        MC_CASE(20, 4, 4, 1) MC_CASE(21, 4, 4, 2) MC_CASE(22, 4, 4, 3)
-        MC_CASE(30, 2, 8, 0) MC_CASE(31, 4, 8, 0) MC_CASE(32, 2, 2, 0) MC_CASE(33, 1, 8, 0)
-#undef MC_CASE
-        hstats[bsel] = 0;
-      } else if (variant >= 100 && variant < 200 && A.nnz < 2000000000LL && B.nnz < 2000000000LL) {  // lean pair kernel
-        const int maxch = (variant / 10) % 10, nw = variant % 10;  // variant = 1<MAXCH><NW>
-        bool launched = false;
-        for (int bsel = 1; bsel <= 3; ++bsel) {
-          if (!hstats[bsel]) continue;
-          const int w = wrt_of(bsel);
-#define PAIR_CASE(M, N) \
-  if (maxch == M && nw == N) { launch_pair<M, N>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
-          PAIR_CASE(4, 1) PAIR_CASE(6, 1) PAIR_CASE(8, 1) PAIR_CASE(4, 2) PAIR_CASE(6, 2) PAIR_CASE(4, 4) PAIR_CASE(6, 4) PAIR_CASE(2, 4)
-#undef PAIR_CASE
-          if (!launched) NTP_FATAL("unknown spgemm_variant");
-          hstats[bsel] = 0;
-        }
-      } else if (variant >= 200 && variant < 300 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {  // pair kernel v2
-        const int maxch = (variant / 10) % 10, nw = variant % 10;  // variant = 2<MAXCH><NW>
-        bool launched = false;
-        for (int bsel = 1; bsel <= 3; ++bsel) {
-          if (!hstats[bsel]) continue;
-          const int w = wrt_of(bsel);
-#define PAIR2_CASE(M, N) \
-  if (maxch == M && nw == N) { launch_pair2<M, N>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
-          if (variant == 291) { launch_pair2<5, 4, 1>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
-          if (variant == 292) { launch_pair2<5, 4, 2>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
-          if (variant == 294) { launch_pair2<5, 4, 7>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
-          if (variant == 295) { launch_pair2<5, 4, 15>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
-          if (variant == 296) { launch_pair2<5, 4, 8>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
-          if (variant == 293) { launch_pair2<5, 4, 3>(bsel, w, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr); launched = true; }
-          PAIR2_CASE(4, 1) PAIR2_CASE(6, 1) PAIR2_CASE(4, 2) PAIR2_CASE(6, 2) PAIR2_CASE(4, 4) PAIR2_CASE(6, 4) PAIR2_CASE(2, 4) PAIR2_CASE(7, 4) PAIR2_CASE(5, 4)
-#undef PAIR2_CASE
-          if (!launched) NTP_FATAL("unknown spgemm_variant");
-          hstats[bsel] = 0;
-        }
-      } else if (variant >= 300 && variant < 400 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {  // pair kernel v3
+      if (variant >= 300 && variant < 400 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {  // column-pair kernel
         const int maxch = (variant / 10) % 10, nw = variant % 10;  // variant = 3<MAXCH><NW>
         // window classes 1 and 2 (spans <= 1024) share one launch sized by the largest span present; class 3
         // (<= 2048) gets its own so that a few wide columns do not cost everybody LDS occupancy
@@ -2873,11 +2184,6 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
           if (!launched) NTP_FATAL("unknown spgemm_variant");
           for (int bsel = blo; bsel <= bhi; ++bsel) hstats[bsel] = 0;
         }
-      } else if (variant == 3) {  // 1 column per wave, pipelined + ds_add
-        if (hstats[1]) launch_mc<T, 1, 4>(1, wrt_of(1), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        if (hstats[2]) launch_mc<T, 1, 4>(2, wrt_of(2), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        if (hstats[3]) launch_mc<T, 1, 4>(3, wrt_of(3), A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
-        hstats[1] = hstats[2] = hstats[3] = 0;
       }
     }
     if (hstats[1]) launch_window<T, 512, 4>(1, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);

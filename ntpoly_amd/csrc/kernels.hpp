@@ -25,8 +25,10 @@ struct EngineOptions {
   int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
                                // reference built with FP contraction computes); 0: separate multiply and add (default, bit-
                                // identical to the reference built without contraction)
-  int spgemm_variant = -1;     // numeric window kernel: -1 auto (column-pair v3 for real operands), 0 one column per
-                               // wave (first generation), other values: experimental generations kept for A/B (kernels.hip)
+  int spgemm_variant = -1;     // numeric kernel: -1 automatic (register-slab kernel for run-like real operands, else the
+                               // column-pair kernel; complex operands: one column per wave); 0 one column per wave for
+                               // everything (first generation); 3<MAXCH><NW> column-pair kernel with that geometry;
+                               // 400 register-slab kernel whenever it fits, 401..405 its timing ablations (wrong results)
 };
 EngineOptions& options();
 SpgemmStats& last_spgemm_stats();

@@ -82,7 +82,7 @@ def test_local_increment_golden(nt):
         exact(mB.triplets(), g.tri(i, "C"), "case %d %s" % (i, c))
 
 
-@pytest.mark.parametrize("force_bin,variant", [(-1, -1), (-1, 0), (2, 321), (3, 361), (-1, 164), (-1, 2), (4, -1), (5, -1), (6, -1), (-1, 400)])
+@pytest.mark.parametrize("force_bin,variant", [(-1, -1), (-1, 0), (2, 321), (3, 361), (-1, 351), (4, -1), (5, -1), (6, -1), (-1, 400)])
 def test_ps_gemm_golden(nt, force_bin, variant):
     """test_psmatrixalgebra.py:193-218 through MatrixMultiply_ps_wrp; every kernel path (column-pair
     kernel, first-generation window kernel, other generations, LDS window sizes, LDS hash, HBM

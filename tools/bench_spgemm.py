@@ -53,7 +53,7 @@ def main():
             X2.Gemm(X, X, pool, 1.0, 0.0, thr)
             st = nt.last_spgemm_stats()
             sig = (st["nnz_c"], X2.Dot(H), X2.Trace())
-            if v in (0, 1, 2, 3, 30, 31, 32, 33) or (v >= 100 and v not in (291, 292, 293, 294, 295, 296, 401, 402, 403, 404)):  # ablation variants compute garbage on purpose
+            if v not in (401, 402, 403, 404):  # ablation variants compute garbage on purpose
                 if ref is None:
                     ref = sig
                 assert sig == ref or args.fma, ("variant %d differs" % v, sig, ref)
