@@ -1275,9 +1275,11 @@ __global__ __launch_bounds__(256) void k_compact(int ncols, const int64_t* __res
 // row, so a direct-mapped LDS window over the union row range decides every slot independently.
 __global__ void k_inc_plan(Csc A, Csc B, int32_t* __restrict__ lo_arr, int32_t* __restrict__ span_arr,
                            uint8_t* __restrict__ bin_arr, unsigned long long* __restrict__ stats,
-                           int force_seq) {
+                           int32_t* __restrict__ count, int force_seq) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 16) stats[threadIdx.x] = 0ull;  // the histogram kernel that follows adds into it
   if (j >= A.cols) return;
+  count[j] = 0;  // columns of the empty bin are never visited by a merge kernel
   const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = B.outer[j + 1];
   int lo = INT_MAX, hi = -1;
   if (ae > as) { lo = min(lo, A.inner[as]); hi = max(hi, A.inner[ae - 1]); }
@@ -2322,10 +2324,8 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
   DevBuf<int32_t> lo(n), span(n), count(n);
   DevBuf<uint8_t> bin(n);
   DevBuf<unsigned long long> stats(16);
-  stats.zero();
-  count.zero();
   hipLaunchKernelGGL(k_inc_plan, dim3(cdiv(n, 256)), dim3(256), 0, stream(), A.v, view(B), lo.p, span.p, bin.p,
-                     stats.p, options().increment_force_seq);
+                     stats.p, count.p, options().increment_force_seq);
   hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, (const int64_t*)nullptr,
                      (const int32_t*)nullptr, n, stats.p);
   unsigned long long hs[16];
@@ -2351,12 +2351,12 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
   const int nb1 = cdiv(n, 4), nb2 = n;
   DevBuf<double> part1, part2, tpart1, tpart2;
   const bool fuse_trace = fuse_dot && trace_out != nullptr;
-  if (fuse_dot) {
-    if (hs[1]) { part1.alloc((size_t)2 * nb1); part1.zero(); }
-    if (hs[2]) { part2.alloc((size_t)2 * nb2); part2.zero(); }
+  if (fuse_dot) {  // every (non-padding) block of the merge kernels writes its slot: no zero fill needed
+    if (hs[1]) part1.alloc((size_t)2 * nb1);
+    if (hs[2]) part2.alloc((size_t)2 * nb2);
     if (fuse_trace) {
-      if (hs[1]) { tpart1.alloc((size_t)2 * nb1); tpart1.zero(); }
-      if (hs[2]) { tpart2.alloc((size_t)2 * nb2); tpart2.zero(); }
+      if (hs[1]) tpart1.alloc((size_t)2 * nb1);
+      if (hs[2]) tpart2.alloc((size_t)2 * nb2);
     }
   }
   dispatch_type(A.cplx, [&](auto tag) {
@@ -2386,8 +2386,7 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
   });
   DevBuf<double> dres;
   if (fuse_dot) {
-    dres.alloc(8);
-    dres.zero();
+    dres.alloc(8);  // pairs that are not produced are not read either (see the sums below)
     if (hs[1]) reduce_sum2_async(part1.p, nb1, dres.p);
     if (hs[2]) reduce_sum2_async(part2.p, nb2, dres.p + 2);
     if (fuse_trace && hs[1]) reduce_sum2_async(tpart1.p, nb1, dres.p + 4);
@@ -2424,13 +2423,13 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
   B = std::move(R);
   if (dot_out && D) {
     if (fuse_dot) {
-      dot_out[0] = hd[0] + hd[2];
-      dot_out[1] = hd[1] + hd[3];
+      dot_out[0] = (hs[1] ? hd[0] : 0.0) + (hs[2] ? hd[2] : 0.0);
+      dot_out[1] = (hs[1] ? hd[1] : 0.0) + (hs[2] ? hd[3] : 0.0);
     } else {
       dot(B, *D, dot_out);
     }
   }
-  if (trace_out) *trace_out = fuse_trace ? hd[4] + hd[6] : trace(B, trace_col_offset);
+  if (trace_out) *trace_out = fuse_trace ? (hs[1] ? hd[4] : 0.0) + (hs[2] ? hd[6] : 0.0) : trace(B, trace_col_offset);
 }
 }  // namespace
 
