@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const int32_t* __restrict__
 
 // register-slab kernel geometry: J output columns per workgroup, SL slabs of 64 rows per wave, NW waves
 constexpr int SLAB_J = 16, SLAB_SL = 3, SLAB_NW = 4;
+constexpr int SLAB_CJ = 8, SLAB_CSL = 2, SLAB_CNW = 6;  // complex operands
 
 // bins: 0 empty | 1..4 LDS direct window of 512/1024/2048/4096 rows | 5 LDS hash | 6 HBM accumulator
 constexpr int BIN_EMPTY = 0, BIN_HASH = 5, BIN_HBM = 6;
@@ -741,20 +742,21 @@ __global__ __launch_bounds__(NW* WAVE) void k_spgemm_pair3(
 // (|v| > threshold >= 0 drops the zeros themselves), so results stay bit-identical to the sparse walk.
 //
 // expanded A: aexp[aeoff[k] + (r - afirst[k])] = A(r, k) for afirst[k] <= r <= alast[k]
+template <typename T>
 __global__ __launch_bounds__(256) void k_slab_expand_a(Csc A, const int32_t* __restrict__ afirst,
-                                                       const int64_t* __restrict__ aeoff, double* __restrict__ aexp) {
+                                                       const int64_t* __restrict__ aeoff, T* __restrict__ aexp) {
   const int k = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   if (k >= A.cols) return;
   const int lane = lane_id();
   const int64_t s = A.outer[k], e = A.outer[k + 1];
   if (e <= s) return;
-  const double* __restrict__ Av = static_cast<const double*>(A.val);
-  double* __restrict__ dst = aexp + aeoff[k] - afirst[k];
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  T* __restrict__ dst = aexp + aeoff[k] - afirst[k];
   for (int64_t p = s + lane; p < e; p += WAVE) {
     const int r = A.inner[p];
     const int prev = (p > s) ? A.inner[p - 1] : r - 1;
     dst[r] = Av[p];
-    for (int h = prev + 1; h < r; ++h) dst[h] = 0.0;
+    for (int h = prev + 1; h < r; ++h) dst[h] = Sc<T>::zero();
   }
 }
 
@@ -799,27 +801,27 @@ __global__ __launch_bounds__(256) void k_slab_plan(int ncols, const int32_t* __r
 // (transposed, odd pitch) so that both the scatter and the write-out are conflict-free / coalesced.  When A and
 // B are the same matrix (X*X in every purification step) the same pass also writes the expanded runs of A
 // (fuse_a), so the operand is read from HBM once.
-template <int J>
+template <typename T, int J>
 __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __restrict__ blk_kmin,
                                                        const int32_t* __restrict__ blk_kn,
-                                                       const int64_t* __restrict__ blk_boff, double* __restrict__ bblk,
+                                                       const int64_t* __restrict__ blk_boff, T* __restrict__ bblk,
                                                        int nblocks, int pitch, int fuse_a,
-                                                       const int64_t* __restrict__ aeoff, double* __restrict__ aexp,
+                                                       const int64_t* __restrict__ aeoff, T* __restrict__ aexp,
                                                        const int32_t* __restrict__ clen,
                                                        int64_t* __restrict__ blk_prod) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* tile = reinterpret_cast<double*>(smem);  // [J][pitch]
+  T* tile = reinterpret_cast<T*>(smem);  // [J][pitch]
   const int b = xcd_block(nblocks);
   if (b < 0) return;
   const int kn = blk_kn[b], kmin = blk_kmin[b];
   if (kn == 0 && !fuse_a) return;  // (fuse_a: the runs of these columns may still be needed as A columns)
   const bool tiled = kn > 0;
-  const double* __restrict__ Bv = static_cast<const double*>(B.val);
+  const T* __restrict__ Bv = static_cast<const T*>(B.val);
   const int wave = threadIdx.x / WAVE, lane = lane_id();
   constexpr int CH = 5, NCOL = J / 4;  // columns per wave
   // request the first CH*64 entries of this wave's columns before anything else (over-read stays in the slack)
   int idx[NCOL][CH];
-  double val[NCOL][CH];
+  T val[NCOL][CH];
 #pragma unroll
   for (int q = 0; q < NCOL; ++q) {
     const int j = min(b * J + wave + 4 * q, B.cols - 1);
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
   }
   const int kne = (kn + 1) & ~1;
   for (int jj = 0; jj < J; ++jj)
-    for (int i = threadIdx.x; i < kne; i += blockDim.x) tile[jj * pitch + i] = 0.0;
+    for (int i = threadIdx.x; i < kne; i += blockDim.x) tile[jj * pitch + i] = Sc<T>::zero();
   __syncthreads();
   long long nprod = 0;  // products of this wave's columns: sum over their entries of nnz(A(:, row))
 #pragma unroll
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
     const int64_t s = B.outer[j], e = B.outer[j + 1];
     if (e <= s) continue;
     const int first = readlane_i32(idx[q][0], 0);
-    double* __restrict__ dst = fuse_a ? aexp + aeoff[j] - first : nullptr;
+    T* __restrict__ dst = fuse_a ? aexp + aeoff[j] - first : nullptr;
     int carry = first - 1;  // row of the entry before the current chunk
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -856,20 +858,20 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
         if (tiled) tile[jj * pitch + (r - kmin)] = val[q][c];
         if (fuse_a) {
           dst[r] = val[q][c];
-          for (int h = prev + 1; h < r; ++h) dst[h] = 0.0;
+          for (int h = prev + 1; h < r; ++h) dst[h] = Sc<T>::zero();
         }
       }
       carry = readlane_i32(r, WAVE - 1);
     }
     for (int64_t p = s + CH * WAVE + lane; p < e; p += WAVE) {
       const int r = B.inner[p];
-      const double v = Bv[p];
+      const T v = Bv[p];
       if (clen) nprod += clen[r];
       if (tiled) tile[jj * pitch + (r - kmin)] = v;
       if (fuse_a) {
         const int prev = B.inner[p - 1];
         dst[r] = v;
-        for (int h = prev + 1; h < r; ++h) dst[h] = 0.0;
+        for (int h = prev + 1; h < r; ++h) dst[h] = Sc<T>::zero();
       }
     }
   }
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
   if (lane == 0) sprod[wave] = nprod;
   __syncthreads();
   if (threadIdx.x == 0) blk_prod[b] = sprod[0] + sprod[1] + sprod[2] + sprod[3];
-  double* __restrict__ out = bblk + blk_boff[b];
+  T* __restrict__ out = bblk + blk_boff[b];
   const int total = kne * J;
   for (int i = threadIdx.x; i < total; i += blockDim.x) out[i] = tile[(i % J) * pitch + (i / J)];
 }
@@ -910,19 +912,19 @@ constexpr uint32_t kBufferFlags = 0x00020000u;  // raw buffer, 32-bit data forma
 
 // n + 4 records: the tail is empty (pipelined prefetch past the last column)
 __global__ void k_slab_runs(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax,
-                            const int64_t* __restrict__ aeoff, const double* __restrict__ aexp,
+                            const int64_t* __restrict__ aeoff, const char* __restrict__ aexp, int elem_bytes,
                             SlabRun* __restrict__ runs, int n) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n + 4) return;
   const bool any = k < n && cmax[k] >= cmin[k];
   SlabRun r;
-  const uint64_t addr = reinterpret_cast<uint64_t>(aexp + (any ? aeoff[k] : 0));
+  const uint64_t addr = reinterpret_cast<uint64_t>(aexp + (any ? aeoff[k] * elem_bytes : 0));
   r.addr_lo = (uint32_t)addr;
   r.addr_hi = (uint32_t)(addr >> 32) & 0xffffu;
-  r.nbytes = any ? (uint32_t)(cmax[k] - cmin[k] + 1) * 8u : 0u;
+  r.nbytes = any ? (uint32_t)(cmax[k] - cmin[k] + 1) * (uint32_t)elem_bytes : 0u;
   r.flags = kBufferFlags;
   r.first = any ? cmin[k] : (1 << 30);
-  r.first8 = any ? cmin[k] * 8 : 0;
+  r.first8 = any ? cmin[k] * elem_bytes : 0;  // first row * element size
   r.span62 = any ? (cmax[k] - cmin[k] + 1) + 62 : 0;
   r.pad = 0;
   runs[k] = r;
@@ -1025,6 +1027,86 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int64_t pos = tbase + (int64_t)jj * w + cnt_s[wave + NW * s][jj] + __popcll(m & lanemask_lt());
         out_inner[pos] = r;
         out_val[pos] = sv;
+      }
+    }
+  }
+}
+
+// Complex operands: the same design with 8 complex columns per workgroup (a multiplier set is again 32 SGPRs), two
+// slabs per wave and six waves (12 slabs = the same 768-row window), one buffer_load_dwordx4 per slab and step.
+// (ar + i ai)(br + i bi) is four products, one subtraction, one addition and the two accumulates, each rounded on
+// its own -- the arithmetic of the reference's complex multiply-add (and of Sc<double2>::mul / add here).
+template <int NW>
+__global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_spgemm_slab_c(
+    const SlabRun* __restrict__ runs, const double2* __restrict__ bblk,
+    const int64_t* __restrict__ blk_boff, const int32_t* __restrict__ blk_kmin, const int32_t* __restrict__ blk_kn,
+    const int32_t* __restrict__ blk_lo, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
+    int32_t* __restrict__ out_inner, double2* __restrict__ out_val, int32_t* __restrict__ count, double alpha,
+    double threshold, int dense_rule, int ncols, int nblocks) {
+  constexpr int J = 8, SL = 2;
+  static_assert(NW == 6, "register map of slab_loop.inc (complex loop)");
+  __shared__ int cnt_s[NW * SL][J];
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int wave = uni_i32(threadIdx.x / WAVE), lane = lane_id();
+  const int lo = blk_lo[b], kmin = blk_kmin[b], kn = blk_kn[b], w = blk_w[b];
+  if (kn == 0) return;
+  const int rbase = lo + WAVE * wave;
+  const SlabRun* rp = runs + kmin;
+  const double2* bq = bblk + blk_boff[b];
+  const unsigned r0 = (unsigned)(rbase + lane) * 16u;
+  const int e0 = rbase + WAVE - 1, e1 = e0 + WAVE * NW;
+  v8d accA, accB, accC, accD;  // slab 0: columns 0..3, 4..7 (re, im pairs); slab 1: the same
+  asm volatile(SLAB_LOOP_ASM_CPLX
+               : "=&{v[2:17]}"(accA), "=&{v[18:33]}"(accB), "=&{v[34:49]}"(accC), "=&{v[50:65]}"(accD)
+               : [rp] "s"(rp), [bq] "s"(bq), [kn] "s"(kn), [e0] "s"(e0), [e1] "s"(e1), [r0] "v"(r0),
+                 [c1] "n"(WAVE * NW * 16)
+               : SLAB_LOOP_CPLX_CLOBBERS);
+  double2 acc[SL][J];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    acc[0][c] = make_double2(accA[2 * c], accA[2 * c + 1]);
+    acc[0][c + 4] = make_double2(accB[2 * c], accB[2 * c + 1]);
+    acc[1][c] = make_double2(accC[2 * c], accC[2 * c + 1]);
+    acc[1][c + 4] = make_double2(accD[2 * c], accD[2 * c + 1]);
+  }
+  using T = double2;
+  unsigned keepbits = 0;  // bit s*J + jj: the magnitude test (a hypot) is evaluated once per value
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const T v = acc[s][jj];
+      const bool keep = Sc<T>::mag(dense_rule ? v : Sc<T>::scale(alpha, v)) > threshold;
+      const unsigned long long m = __ballot(keep);
+      keepbits |= keep ? (1u << (s * J + jj)) : 0u;
+      if (lane == 0) cnt_s[wave + NW * s][jj] = __popcll(m);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < J) {
+    int run = 0;
+    for (int m = 0; m < NW * SL; ++m) {
+      const int c = cnt_s[m][threadIdx.x];
+      cnt_s[m][threadIdx.x] = run;
+      run += c;
+    }
+    const int j = b * J + threadIdx.x;
+    if (j < ncols) count[j] = run;
+  }
+  __syncthreads();
+  const int64_t tbase = blk_toff[b];
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    const int r = lo + WAVE * (wave + NW * s) + lane;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const bool keep = (keepbits >> (s * J + jj)) & 1u;
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int64_t pos = tbase + (int64_t)jj * w + cnt_s[wave + NW * s][jj] + __popcll(m & lanemask_lt());
+        out_inner[pos] = r;
+        out_val[pos] = Sc<T>::scale(alpha, acc[s][jj]);
       }
     }
   }
@@ -2042,10 +2124,14 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
 
   // ---- candidate for the register-slab kernel (real operands, run-like columns): its plan needs only the column
   // extents, so the per-column walk over B (k_spgemm_plan) is skipped when the slab kernel is taken
-  constexpr int SJ = SLAB_J;
+  // (complex operands: 8 columns per workgroup, two slabs per wave, six waves -- the same 768-row window and the
+  // same 128-byte multiplier row)
+  const int SJ = A.cplx ? SLAB_CJ : SLAB_J;
+  const int slab_rows = A.cplx ? SLAB_CNW * SLAB_CSL * WAVE : SLAB_NW * SLAB_SL * WAVE;
+  const size_t esz = A.cplx ? 16 : 8;
   const int sv_opt = options().spgemm_variant;
-  const bool slab_try = !A.cplx && options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4) &&
-                        A.nnz < 2000000000LL && B.nnz < 2000000000LL;
+  const bool slab_try = options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4) &&
+                        A.nnz < 1000000000LL && B.nnz < 1000000000LL;
   const int snb = cdiv(n, SJ);
   DevBuf<int32_t> bfirst_own, blast_own, blen_own, aspan, blk_lo, blk_w, blk_kmin, blk_kn;
   DevBuf<int64_t> aeoff, bsz, tsz, blk_boff, blk_toff;
@@ -2064,8 +2150,12 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     scan_async<int32_t>(aspan.p, aeoff.p, (int64_t)A.cols);
     blk_lo.alloc(snb); blk_w.alloc(snb); blk_kmin.alloc(snb); blk_kn.alloc(snb);
     bsz.alloc(snb); tsz.alloc(snb); blk_boff.alloc((size_t)snb + 1); blk_toff.alloc((size_t)snb + 1);
-    hipLaunchKernelGGL((k_slab_plan<SJ>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst, blast, cmin.p,
-                       cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
+    if (A.cplx)
+      hipLaunchKernelGGL((k_slab_plan<SLAB_CJ>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst,
+                         blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
+    else
+      hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst,
+                         blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
     hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, aspan.p, A.cols, stats.p);
     scan_async<int64_t>(bsz.p, blk_boff.p, (int64_t)snb);
     scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
@@ -2077,7 +2167,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     f.run();
     // use it when the window fits the register slabs and the zero padding stays small
     const int64_t max_w = (int64_t)hstats[16], max_kn = (int64_t)hstats[17];
-    const bool fits = max_w > 0 && max_w <= SLAB_NW * SLAB_SL * WAVE && ((max_kn + 1) | 1) * SJ * 8 <= 64 * 1024;
+    const bool fits = max_w > 0 && max_w <= slab_rows && ((max_kn + 1) | 1) * SJ * (int64_t)esz <= 64 * 1024;
     const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
                             (double)slab_tot[0] >= 48.0 * (double)hstats[18];  // mean run of the non-empty columns >= 48 rows
     use_slab = fits && (dense_runs || sv_opt / 100 == 4);
@@ -2085,7 +2175,10 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   st.slab = use_slab ? 1 : 0;
   if (use_slab) {
     tmp_total = slab_tot[2];
-    hipLaunchKernelGGL((k_slab_tmpoff<SJ>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
+    if (A.cplx)
+      hipLaunchKernelGGL((k_slab_tmpoff<SLAB_CJ>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
+    else
+      hipLaunchKernelGGL((k_slab_tmpoff<SLAB_J>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
   } else {
     // ---- general plan: per output column its row window, product count, upper bound and kernel bin
     lo.alloc(n); span.alloc(n); bin.alloc(n); ub.alloc((size_t)n + 1); ip.alloc(n);
@@ -2116,25 +2209,42 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<int64_t> blk_prod, blk_prod_scan;
   if (use_slab) {
     blk_prod.alloc(snb); blk_prod.zero(); blk_prod_scan.alloc((size_t)snb + 1);
-    aexp.alloc((size_t)slab_tot[0] + 1);
-    bblk.alloc((size_t)slab_tot[1] + 16 * SJ);  // slack: the loop prefetches a few rows past the last tile
+    aexp.alloc(((size_t)slab_tot[0] + 1) * A.wval());
+    bblk.alloc(((size_t)slab_tot[1] + 16 * SJ) * A.wval());  // slack: the loop prefetches a few rows past the last tile
     const bool same = (&A == &B);
-    if (!same)
-      hipLaunchKernelGGL(k_slab_expand_a, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), cmin.p,
-                         aeoff.p, aexp.p);
     runs.alloc(((size_t)A.cols + 4) * sizeof(SlabRun));
-    hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aeoff.p, aexp.p,
-                       reinterpret_cast<SlabRun*>(runs.p), A.cols);
+    hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aeoff.p,
+                       reinterpret_cast<const char*>(aexp.p), (int)esz, reinterpret_cast<SlabRun*>(runs.p), A.cols);
     const int pitch = ((int)hstats[17] + 1) | 1;
-    hipLaunchKernelGGL((k_slab_expand_b<SJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * 8, stream(), view(B),
-                       blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p, aexp.p,
-                       timing ? clen.p : (const int32_t*)nullptr, blk_prod.p);  // product count: statistics only
+    const int32_t* clen_opt = timing ? clen.p : (const int32_t*)nullptr;  // product count: statistics only
+    if (A.cplx) {
+      double2* ae = reinterpret_cast<double2*>(aexp.p);
+      if (!same)
+        hipLaunchKernelGGL(k_slab_expand_a<double2>, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(),
+                           view(A), cmin.p, aeoff.p, ae);
+      hipLaunchKernelGGL((k_slab_expand_b<double2, SLAB_CJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * esz,
+                         stream(), view(B), blk_kmin.p, blk_kn.p, blk_boff.p, reinterpret_cast<double2*>(bblk.p), snb, pitch,
+                         same ? 1 : 0, aeoff.p, ae, clen_opt, blk_prod.p);
+    } else {
+      if (!same)
+        hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(),
+                           view(A), cmin.p, aeoff.p, aexp.p);
+      hipLaunchKernelGGL((k_slab_expand_b<double, SLAB_J>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * esz,
+                         stream(), view(B), blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p,
+                         aexp.p, clen_opt, blk_prod.p);
+    }
     scan_async<int64_t>(blk_prod.p, blk_prod_scan.p, (int64_t)snb);  // total = products of this multiply
   }
   t_num.start();
-  if (use_slab) {
+  if (use_slab && A.cplx) {
+    hipLaunchKernelGGL((k_spgemm_slab_c<SLAB_CNW>), dim3(xcd_grid(snb)), dim3(SLAB_CNW * WAVE), 0, stream(),
+                       reinterpret_cast<const SlabRun*>(runs.p), reinterpret_cast<const double2*>(bblk.p), blk_boff.p,
+                       blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p,
+                       reinterpret_cast<double2*>(tmp_val.p), count.p, alpha, threshold, dr, n, snb);
+    for (int i = 0; i < 7; ++i) hstats[i] = 0;
+  } else if (use_slab) {
     auto launch_slab = [&](auto fma_tag) {
-      hipLaunchKernelGGL((k_spgemm_slab<SJ, SLAB_SL, SLAB_NW, decltype(fma_tag)::value>), dim3(xcd_grid(snb)),
+      hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, SLAB_NW, decltype(fma_tag)::value>), dim3(xcd_grid(snb)),
                          dim3(SLAB_NW * WAVE), 0, stream(), reinterpret_cast<const SlabRun*>(runs.p), bblk.p, blk_boff.p,
                          blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha,
                          threshold, dr, n, snb);
@@ -2251,7 +2361,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     SpgemmAccum& acc = spgemm_accum();
     acc.calls += 1;
     acc.products += st.products;
-    acc.alg_bytes += 12.0 * (double)(A.nnz + B.nnz) + 4.0 * ((double)A.cols + B.cols + n + 3);  // + 12 * nnzC: axpby
+    acc.alg_bytes += (4.0 + (double)esz) * (double)(A.nnz + B.nnz) + 4.0 * ((double)A.cols + B.cols + n + 3);  // + 12 * nnzC: axpby
     return;
   }
 

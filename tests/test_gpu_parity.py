@@ -300,16 +300,18 @@ def test_full_size_properties_config2(nt):
     exact(got, (n, n, oc, orow, ov), "config 2 vs oracle")
 
 
-@pytest.mark.parametrize("n,h,holes,thr", [(4096, 100, 0.0, 1e-8), (4096, 140, 0.2, 1e-6), (3000, 30, 0.5, 0.0),
-                                             (5000, 250, 0.05, 1e-7)])
-def test_slab_kernel_vs_oracle(nt, n, h, holes, thr):
-    """register-slab SpGEMM kernel (forced) on banded operands with random holes punched into the band,
-    A*B with A != B, against the oracle: bit-exact.  Holes exercise the zero padding of the expanded runs."""
+@pytest.mark.parametrize("n,h,holes,thr,cplx", [(4096, 100, 0.0, 1e-8, False), (4096, 140, 0.2, 1e-6, False),
+                                                  (3000, 30, 0.5, 0.0, False), (5000, 250, 0.05, 1e-7, False),
+                                                  (4096, 100, 0.0, 1e-8, True), (3001, 37, 0.4, 0.0, True),
+                                                  (5000, 180, 0.05, 1e-7, True), (777, 3, 0.3, 1e-3, True)])
+def test_slab_kernel_vs_oracle(nt, n, h, holes, thr, cplx):
+    """register-slab SpGEMM kernels (forced; real and complex) on banded operands with random holes punched into
+    the band, A*B with A != B, against the oracle: bit-exact.  Holes exercise the zero padding of the expanded runs."""
     from oracle import oracle_py as O
     rng = np.random.default_rng(n + h)
     mats = []
     for t in range(2):
-        col, row, val = banded_triplets(n, h, shift=0.1 * t)
+        col, row, val = banded_triplets(n, h, shift=0.1 * t, complex_=cplx)
         keep = (rng.random(len(val)) >= holes) | (col == row)
         mats.append((col[keep], row[keep], val[keep] * (1.0 + 0.01 * t)))
     A = nt.Matrix_ps.from_triplets(n, *mats[0])
@@ -326,7 +328,7 @@ def test_slab_kernel_vs_oracle(nt, n, h, holes, thr):
     Ao = O.Mat.from_triplets(n, n, *mats[0])
     Bo = O.Mat.from_triplets(n, n, *mats[1])
     oc, orow, ov = O.ps_multiply(Ao, Bo, None, 0.5, 0.0, thr).triplets()
-    exact(C.triplets(), (n, n, oc, orow, ov), "slab vs oracle n=%d h=%d holes=%g" % (n, h, holes))
+    exact(C.triplets(), (n, n, oc, orow, ov), "slab vs oracle n=%d h=%d holes=%g cplx=%d" % (n, h, holes, cplx))
 
 
 def test_slab_kernel_fma_option(nt):

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--variants", type=str, default="400,351")
     ap.add_argument("--fma", type=int, default=0)
+    ap.add_argument("--complex", type=int, default=0, help="Hermitian complex operand (BASELINE configs[4] family)")
     args = ap.parse_args()
     import ntpoly_amd as nt
     from gen import banded_triplets
@@ -30,7 +31,7 @@ def main():
     nt.set_option("time_kernels", 1)
     nt.set_option("spgemm_fma", args.fma)
     n, h, thr = args.n, args.halfband, args.threshold
-    col, row, val = banded_triplets(n, h)
+    col, row, val = banded_triplets(n, h, complex_=bool(args.complex))
     H = nt.Matrix_ps.from_triplets(n, col, row, val)
     del col, row, val
     e_min, e_max = nt.EigenBounds.GershgorinBounds(H)
@@ -43,7 +44,15 @@ def main():
     X2 = nt.Matrix_ps(n)
     pool = nt.PMatrixMemoryPool(H)
     for _ in range(args.iters):
-        trs2_step(nt, X, X2, H, pool, n / 2.0, thr)
+        if args.complex:   # the same recurrence through the public calls (the fused step is a real-arithmetic entry)
+            X2.Gemm(X, X, pool, 1.0, 0.0, thr)
+            if np.real(X.Trace()) > n / 2.0:
+                X, X2 = X2, X
+            else:
+                X.Scale(2.0)
+                X.Increment(X2, -1.0, thr)
+        else:
+            trs2_step(nt, X, X2, H, pool, n / 2.0, thr)
     variants = [int(v) for v in args.variants.split(",")]
     ref = None
     res = {v: [] for v in variants}

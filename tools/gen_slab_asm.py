@@ -139,6 +139,95 @@ def build(fused, ablate=0, pf=0):
     return L
 
 
+# ------------------------------------------------------------------------------------------------- complex operands
+# Register map of the complex loop (J = 8 complex columns, SL = 2 slabs per wave, NW = 6 waves):
+#   SGPRs as above; a multiplier set holds 8 complex numbers (re, im pairs): B(k, c) = s[base+4c : base+4c+3]
+#   v[2:33], v[34:65]  accumulators of slab 0, 1: column c -> (re, im) = v[.. + 4c : .. + 4c + 3]
+#   v[66:81] eight temporaries   v[82:83] load offsets   slab values (re, im per lane): set 0 v[84:91], set 1 v[92:99]
+C_SL, C_J = 2, 8
+C_ACC0, C_T0, C_VOFF = 2, 66, 82
+C_A_SET = [84, 92]
+
+
+def c_issue(aset, lines):
+    f, s = FS[aset]
+    lines.append("s_mov_b32 s%d, s29" % f)
+    lines.append("s_mov_b32 s%d, s30" % s)
+    lines.append("v_sub_u32 v%d, %%[r0], s28" % C_VOFF)
+    lines.append("v_add_u32 v%d, %%[c1], v%d" % (C_VOFF + 1, C_VOFF))
+    for i in range(C_SL):
+        a = C_A_SET[aset] + 4 * i
+        lines.append("buffer_load_dwordx4 v[%d:%d], v%d, s[24:27], 0 offen" % (a, a + 3, C_VOFF + i))
+
+
+def c_compute(aset, bset, lines, label):
+    """(ar + i ai)(br + i bi): four products, one subtraction, one addition, then the two accumulates -- every operation
+    rounded on its own, as the reference's complex multiply-add; two columns interleaved so nothing waits on its
+    predecessor"""
+    f, s = FS[aset]
+    for i in range(C_SL):
+        skip = "%d" % label[0]
+        label[0] += 1
+        lines.append("s_sub_i32 s19, %%[e%d], s%d" % (i, f))
+        lines.append("s_cmp_gt_u32 s19, s%d" % s)
+        lines.append("s_cbranch_scc1 %sf" % skip)
+        ar, ai = vp(C_A_SET[aset] + 4 * i), vp(C_A_SET[aset] + 4 * i + 2)
+        for c0 in range(0, C_J, 2):
+            t = [vp(C_T0 + 2 * q) for q in range(8)]
+            for q, c in enumerate((c0, c0 + 1)):
+                br, bi = sp(B_SET[bset] + 4 * c), sp(B_SET[bset] + 4 * c + 2)
+                lines.append("v_mul_f64 %s, %s, %s" % (t[4 * q + 0], ar, br))
+                lines.append("v_mul_f64 %s, %s, %s" % (t[4 * q + 1], ai, bi))
+                lines.append("v_mul_f64 %s, %s, %s" % (t[4 * q + 2], ar, bi))
+                lines.append("v_mul_f64 %s, %s, %s" % (t[4 * q + 3], ai, br))
+            for q in range(2):
+                lines.append("v_add_f64 %s, %s, -%s" % (t[4 * q + 0], t[4 * q + 0], t[4 * q + 1]))
+                lines.append("v_add_f64 %s, %s, %s" % (t[4 * q + 2], t[4 * q + 2], t[4 * q + 3]))
+            for q, c in enumerate((c0, c0 + 1)):
+                accr = vp(C_ACC0 + 4 * C_J * i + 4 * c)
+                acci = vp(C_ACC0 + 4 * C_J * i + 4 * c + 2)
+                lines.append("v_add_f64 %s, %s, %s" % (accr, accr, t[4 * q + 0]))
+                lines.append("v_add_f64 %s, %s, %s" % (acci, acci, t[4 * q + 2]))
+        lines.append("%s:" % skip)
+
+
+def build_complex():
+    L = []
+    label = [10]
+    for i in range(C_SL * C_J * 2):
+        L.append("v_mov_b64 %s, 0" % vp(C_ACC0 + 2 * i))
+    L.append("s_mov_b64 s[14:15], %[rp]")
+    L.append("s_mov_b64 s[16:17], %[bq]")
+    # prologue: slabs of step 0, multipliers of step 0, record of step 1
+    L.append("s_load_dwordx8 s[24:31], s[14:15], 0x0")
+    L.append("s_waitcnt lgkmcnt(0)")
+    c_issue(0, L)
+    load_b(0, 0, L)
+    L.append("s_load_dwordx8 s[24:31], s[14:15], 0x20")
+    L.append("s_mov_b32 s18, 0")
+    L.append("1:")
+    for t in range(2):
+        L.append("s_waitcnt lgkmcnt(0)")       # B(k, :) of step t and the record of step t+1
+        c_issue((t + 1) % 2, L)
+        L.append("s_add_u32 s16, s16, 0x80")
+        L.append("s_addc_u32 s17, s17, 0")
+        L.append("s_add_u32 s14, s14, 0x20")
+        L.append("s_addc_u32 s15, s15, 0")
+        load_b((t + 1) % 2, 0, L)
+        L.append("s_load_dwordx8 s[24:31], s[14:15], 0x20")   # record of step t+2
+        L.append("s_waitcnt vmcnt(%d)" % C_SL)
+        c_compute(t % 2, t % 2, L, label)
+        L.append("s_add_i32 s18, s18, 1")
+        L.append("s_cmp_ge_i32 s18, %[kn]")
+        if t == 0:
+            L.append("s_cbranch_scc1 2f")
+        else:
+            L.append("s_cbranch_scc0 1b")
+    L.append("2:")
+    L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return L
+
+
 def main():
     sclob = ["s%d" % i for i in [12, 13] + list(range(14, 32)) + list(range(36, 100))]
     vclob = ["v%d" % i for i in list(range(T0, VOFF + SL)) + list(range(110, 128))]
@@ -159,6 +248,16 @@ def main():
         out.append('  ""')
         print(name, len(L), "instructions")
     out.append("#define SLAB_LOOP_CLOBBERS " + ", ".join('"%s"' % c for c in sclob + vclob) + ', "vcc", "scc", "memory"')
+    # complex loop: outputs accA..accD (v8d, v[2:65]); inputs rp, bq, kn, e0, e1, r0 (row offset * 16), c1 (immediate)
+    L = build_complex()
+    out.append("#define SLAB_LOOP_ASM_CPLX \\")
+    for ln in L:
+        out.append('  "%s\\n\\t" \\' % ln)
+    out.append('  ""')
+    print("SLAB_LOOP_ASM_CPLX", len(L), "instructions")
+    cs = ["s%d" % i for i in [12, 13] + list(range(14, 32)) + list(range(36, 100))]
+    cv = ["v%d" % i for i in range(C_T0, 100)]
+    out.append("#define SLAB_LOOP_CPLX_CLOBBERS " + ", ".join('"%s"' % c for c in cs + cv) + ', "vcc", "scc", "memory"')
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ntpoly_amd", "csrc", "slab_loop.inc")
     open(path, "w").write("\n".join(out) + "\n")
     print("wrote", path)
