@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdio>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "common.hpp"
@@ -218,5 +219,29 @@ void solver_polar(const PSMatrix& A, PSMatrix& U, PSMatrix* Hm, const SolverPara
 void solver_invert(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p);
 void solver_pseudoinverse(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p);
 void solver_square_root(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p, bool inverse, int order);
+
+// solvers_extra.cpp: linear solvers, Pade exponential, geometry extrapolation, the dense (eigendecomposition) family,
+// Fermi-operator solvers, Cholesky factorisations
+void ps_filter(PSMatrix& m, double threshold);
+void ps_gather_triplets(const PSMatrix& m, HostTriplets& t);
+void solver_cg(const PSMatrix& A, PSMatrix& X, const PSMatrix& B, const SolverParameters& p);
+void compute_exponential_pade(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p);
+void purification_extrapolate(const PSMatrix& PreviousDensity, const PSMatrix& Overlap, double trace, PSMatrix& NewDensity,
+                              const SolverParameters& p);
+void lowdin_extrapolate(const PSMatrix& PreviousDensity, const PSMatrix& OldOverlap, const PSMatrix& NewOverlap,
+                        PSMatrix& NewDensity, const SolverParameters& p);
+void snap_to_sparsity_pattern(PSMatrix& mat, const PSMatrix& pattern);
+void ps_eigendecomposition(const PSMatrix& A, PSMatrix& eigenvalues, PSMatrix* eigenvectors, int nvals,
+                           const SolverParameters& p);
+void dense_matrix_function(const PSMatrix& A, PSMatrix& Result, const std::function<double(double)>& func,
+                           const SolverParameters& p);
+void ps_svd(const PSMatrix& A, PSMatrix& left, PSMatrix& right, PSMatrix& singular, const SolverParameters& p);
+void estimate_gap(const PSMatrix& H, const PSMatrix& K, double chemical_potential, double* gap, const SolverParameters& p);
+void compute_dense_foe(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, const double* inv_temp_in,
+                       double* energy_out, double* mu_out, const SolverParameters& p);
+void solver_wom(const PSMatrix& H, const PSMatrix& ISQ, PSMatrix& K, double inv_temp, const double* trace_in,
+                const double* mu_in, double* energy_out, const SolverParameters& p);
+void ps_cholesky(const PSMatrix& A, PSMatrix& L, int rank, const SolverParameters& p);
+void reduce_dimension(const PSMatrix& A, int dim, PSMatrix& Reduced, const SolverParameters& p);
 
 }  // namespace ntp

@@ -777,7 +777,8 @@ __global__ __launch_bounds__(256) void k_slab_plan(int ncols, const int32_t* __r
   const bool has = lane < J && j < ncols && blast[min(j, ncols - 1)] >= 0;
   const int kmin = wave_min_i32(has ? bfirst[j] : INT_MAX), kmax = wave_max_i32(has ? blast[j] : -1);
   int lo = INT_MAX, hi = -1;
-  for (int k = kmin + lane; k <= kmax; k += WAVE) {
+  // (a block whose columns are all empty has kmin = INT_MAX: kmin + lane must not be formed)
+  for (int k = (kmax >= kmin) ? kmin + lane : 0; k <= kmax; k += WAVE) {
     const int c0 = cmin[k], c1 = cmax[k];
     if (c1 >= c0) {
       lo = min(lo, c0);

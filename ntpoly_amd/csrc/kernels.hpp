@@ -123,6 +123,14 @@ void halo_bounds_async(const DevMat& A, int32_t c0, const int32_t* d_sa, const i
                        int64_t* d_cnt_row);
 
 // exclusive scan helper (device), out[n] = total; returns total (synchronises)
+// dense side (dense.hip): entry filter, sparse <-> dense (column major), Hermitian eigendecomposition (parallel
+// two-sided Jacobi), (pivoted) Cholesky on a dense copy
+DevMat filter(const DevMat& A, double threshold);  // entries with |v| > threshold
+void to_dense(const DevMat& A, double* d_dense, int64_t ld);
+DevMat from_dense(const double* d_dense, int64_t ld, int32_t rows, int32_t c0, int32_t cols, bool cplx, double threshold);
+void dense_zero_columns(double* d_dense, int64_t ld, int32_t rows, int32_t c_first, int32_t c_end, bool cplx);
+void dense_eigh(double* d_A, int32_t n, bool cplx, double* d_W);
+void dense_cholesky(const double* d_A, double* d_L, int32_t n, double threshold, int32_t rank);
 int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n);
 
 }  // namespace ntp

@@ -4,6 +4,7 @@
 // plus a few ntpoly_amd_* extension entry points (RCCL bootstrap, statistics, options).
 // See include/*.h for the declarations with the reference line each symbol replaces.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "engine.hpp"
@@ -39,6 +40,48 @@ const ProcessGrid* default_grid() {
   return &global_grid();
 }
 std::string fstring(const char* s, const int* n) { return std::string(s, (size_t)*n); }
+
+// MatrixDiagonalScale of a local matrix (sparse_includes/MatrixDiagonalScale.f90): values of column `index_column`
+// are multiplied by the triplet's value, triplet after triplet
+void local_diagonal_scale(DevMat& m, const HostTriplets& t) {
+  if (m.cols == 0) return;
+  const size_t w = m.wval();
+  std::vector<double> f((size_t)m.cols * w, 0.0);
+  for (int32_t j = 0; j < m.cols; ++j) f[(size_t)j * w] = 1.0;
+  for (size_t i = 0; i < t.size(); ++i) {
+    const int32_t col = t.col[i] - 1;
+    if (col < 0 || col >= m.cols) continue;
+    const double re = t.cplx ? t.val[2 * i] : t.val[i], im = t.cplx ? t.val[2 * i + 1] : 0.0;
+    double& fr = f[(size_t)col * w];
+    if (m.cplx) {
+      double& fi = f[(size_t)col * w + 1];
+      const double nr = fr * re - fi * im, ni = fr * im + fi * re;
+      fr = nr;
+      fi = ni;
+    } else {
+      fr *= re;
+    }
+  }
+  DevBuf<double> d(f.size());
+  d.upload(f.data(), f.size());
+  scale_columns(m, d.p);
+  sync_stream();
+}
+// PrintMatrix (sparse_includes/PrintMatrix.f90): MatrixMarket coordinate text, entries in column order
+void local_print(const DevMat& m, const char* path) {
+  HostTriplets t;
+  to_triplets(m, 0, t);
+  FILE* f = path ? std::fopen(path, "w") : stdout;
+  if (!f) NTP_FATAL(std::string("cannot open ") + path + " for writing");
+  std::fprintf(f, "%%%%MatrixMarket matrix coordinate %s general\n%%\n", m.cplx ? "complex" : "real");
+  std::fprintf(f, "%d %d %lld\n", m.rows, m.cols, (long long)m.nnz);
+  for (size_t i = 0; i < t.size(); ++i) {
+    if (m.cplx) std::fprintf(f, "%d %d %.17g %.17g\n", t.row[i], t.col[i], t.val[2 * i], t.val[2 * i + 1]);
+    else std::fprintf(f, "%d %d %.17g\n", t.row[i], t.col[i], t.val[i]);
+  }
+  if (path) std::fclose(f);
+  else std::fflush(f);
+}
 }  // namespace
 
 extern "C" {
@@ -626,18 +669,97 @@ void McWeenyStep_wrp(const int* ih_D, int* ih_DOut, const double* threshold) {
 void McWeenyStepS_wrp(const int* ih_D, int* ih_DOut, const int* ih_S, const double* threshold) {
   mcweeny_step(*get<PSMatrix>(ih_D), *get<PSMatrix>(ih_DOut), get<PSMatrix>(ih_S), *threshold);
 }
-// The dense eigensolver paths of the reference (DenseDensity, DenseSquareRoot, DenseInverseSquareRoot: gather to a
-// dense matrix + LAPACK/EigenExa, EigenSolversModule) are outside this engine's scope.  The
-// symbols exist so that the reference's C++ layer links unchanged; calling them ends the run like the reference's
-// own fatal paths (ErrorModule.F90:193-205) -- there is no silent CPU fallback.
-void DenseDensity_wrp(const int*, const int*, const double*, int*, const double*, const double*, const int*) {
-  NTP_FATAL("DenseDensity: the dense eigensolver path is not part of the MI355X engine; use TRS2/TRS4/PM/HPCP/ScaleAndFold");
+// The dense family of the reference (gather + LAPACK eigensolver, EigenSolversModule.F90:74-131): here the
+// eigendecomposition runs on the GPU (two-sided Jacobi, solvers_extra.cpp, dense.hip); f(A) = V f(L) V^H.
+void DenseDensity_wrp(const int* ih_Hamiltonian, const int* ih_InverseSquareRoot, const double* trace, int* ih_Density,
+                      const double* energy_value_out, const double* chemical_potential_out, const int* ih_solver_parameters) {
+  // DensityMatrixSolversModule.F90:1120-1160: the step-function occupation (no smearing)
+  compute_dense_foe(*get<PSMatrix>(ih_Hamiltonian), *get<PSMatrix>(ih_InverseSquareRoot), *trace, *get<PSMatrix>(ih_Density),
+                    nullptr, const_cast<double*>(energy_value_out), const_cast<double*>(chemical_potential_out),
+                    *get<SolverParameters>(ih_solver_parameters));
 }
-void DenseSquareRoot_wrp(const int*, int*, const int*) {
-  NTP_FATAL("DenseSquareRoot: the dense eigensolver path is not part of the MI355X engine; use SquareRoot");
+static void dense_function(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters, const char* header,
+                           double (*f)(double)) {
+  const SolverParameters& p = *get<SolverParameters>(ih_solver_parameters);
+  if (p.be_verbose && header) {
+    log_header(header);
+    log_enter();
+  }
+  dense_matrix_function(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), f, p);
+  if (p.be_verbose && header) log_exit();
 }
-void DenseInverseSquareRoot_wrp(const int*, int*, const int*) {
-  NTP_FATAL("DenseInverseSquareRoot: the dense eigensolver path is not part of the MI355X engine; use InverseSquareRoot");
+void DenseSquareRoot_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  dense_function(ih_Input, ih_Output, ih_solver_parameters, "Square Root Solver", [](double v) { return std::sqrt(v); });
+}
+void DenseInverseSquareRoot_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  dense_function(ih_Input, ih_Output, ih_solver_parameters, "Inverse Square Root Solver",
+                 [](double v) { return 1.0 / std::sqrt(v); });
+}
+// FermiOperator_c.h:4-16 (FermiOperatorModule_wrp.F90): the wrapper always passes the inverse temperature
+void ComputeDenseFOE_wrp(const int* ih_Hamiltonian, const int* ih_InverseSquareRoot, const double* trace, int* ih_Density,
+                         const double* inv_temp_in, const double* energy_value_out, const double* chemical_potential_out,
+                         const int* ih_solver_parameters) {
+  compute_dense_foe(*get<PSMatrix>(ih_Hamiltonian), *get<PSMatrix>(ih_InverseSquareRoot), *trace, *get<PSMatrix>(ih_Density),
+                    inv_temp_in, const_cast<double*>(energy_value_out), const_cast<double*>(chemical_potential_out),
+                    *get<SolverParameters>(ih_solver_parameters));
+}
+void WOM_GC_wrp(const int* ih_Hamiltonian, const int* ih_InverseSquareRoot, int* ih_Density, const double* chemical_potential,
+                const double* inv_temp, const double* energy_value_out, const int* ih_solver_parameters) {
+  solver_wom(*get<PSMatrix>(ih_Hamiltonian), *get<PSMatrix>(ih_InverseSquareRoot), *get<PSMatrix>(ih_Density), *inv_temp,
+             nullptr, chemical_potential, const_cast<double*>(energy_value_out), *get<SolverParameters>(ih_solver_parameters));
+}
+void WOM_C_wrp(const int* ih_Hamiltonian, const int* ih_InverseSquareRoot, int* ih_Density, const double* trace,
+               const double* inv_temp, const double* energy_value_out, const int* ih_solver_parameters) {
+  solver_wom(*get<PSMatrix>(ih_Hamiltonian), *get<PSMatrix>(ih_InverseSquareRoot), *get<PSMatrix>(ih_Density), *inv_temp,
+             trace, nullptr, const_cast<double*>(energy_value_out), *get<SolverParameters>(ih_solver_parameters));
+}
+// EigenSolvers_c.h:4-15 -- positions as the Fortran wrapper binds them (EigenSolversModule_wrp.F90:19-62: matrix,
+// eigenvalues, nvals, eigenvectors), which is how the C++ layer calls them (EigenSolvers.cc:12-21); the parameter
+// NAMES in the C header are swapped
+void EigenDecomposition_wrp(const int* ih_this, int* ih_eigenvalues, const int* nvals, int* ih_eigenvectors,
+                            const int* ih_solver_parameters) {
+  ps_eigendecomposition(*get<PSMatrix>(ih_this), *get<PSMatrix>(ih_eigenvalues), get<PSMatrix>(ih_eigenvectors), *nvals,
+                        *get<SolverParameters>(ih_solver_parameters));
+}
+void EigenDecomposition_novec_wrp(const int* ih_this, int* ih_eigenvalues, const int* nvals, const int* ih_solver_parameters) {
+  ps_eigendecomposition(*get<PSMatrix>(ih_this), *get<PSMatrix>(ih_eigenvalues), nullptr, *nvals,
+                        *get<SolverParameters>(ih_solver_parameters));
+}
+void SingularValueDecompostion_wrp(const int* ih_this, int* ih_leftvectors, int* ih_rightvectors, int* ih_singularvalues,
+                                   const int* ih_solver_parameters) {
+  ps_svd(*get<PSMatrix>(ih_this), *get<PSMatrix>(ih_leftvectors), *get<PSMatrix>(ih_rightvectors),
+         *get<PSMatrix>(ih_singularvalues), *get<SolverParameters>(ih_solver_parameters));
+}
+void EstimateGap_wrp(const int* ih_H, const int* ih_K, const double* chemical_potential, double* gap,
+                     const int* ih_solver_parameters) {
+  estimate_gap(*get<PSMatrix>(ih_H), *get<PSMatrix>(ih_K), *chemical_potential, gap, *get<SolverParameters>(ih_solver_parameters));
+}
+// LinearSolvers_c.h:4-7, Analysis_c.h:4-8
+void CGSolver_wrp(const int* ih_MatA, int* ih_MatX, const int* ih_matB, const int* ih_solver_parameters) {
+  solver_cg(*get<PSMatrix>(ih_MatA), *get<PSMatrix>(ih_MatX), *get<PSMatrix>(ih_matB), *get<SolverParameters>(ih_solver_parameters));
+}
+void CholeskyDecomposition_wrp(const int* ih_MatA, int* ih_MatL, const int* ih_solver_parameters) {
+  ps_cholesky(*get<PSMatrix>(ih_MatA), *get<PSMatrix>(ih_MatL), -1, *get<SolverParameters>(ih_solver_parameters));
+}
+void PivotedCholeskyDecomposition_wrp(const int* ih_MatA, int* ih_MatL, const int* rank_in, const int* ih_solver_parameters) {
+  ps_cholesky(*get<PSMatrix>(ih_MatA), *get<PSMatrix>(ih_MatL), *rank_in, *get<SolverParameters>(ih_solver_parameters));
+}
+void ReduceDimension_wrp(const int* ih_this, const int* dim, int* ih_reduced, const int* ih_solver_parameters) {
+  reduce_dimension(*get<PSMatrix>(ih_this), *dim, *get<PSMatrix>(ih_reduced), *get<SolverParameters>(ih_solver_parameters));
+}
+// GeometryOptimization_c.h:4-10, MatrixConversion_c.h:4
+void PurificationExtrapolate_wrp(const int* ih_PreviousDensity, const int* Overlap, const double* trace, int* ih_NewDensity,
+                                 const int* ih_solver_parameters) {
+  purification_extrapolate(*get<PSMatrix>(ih_PreviousDensity), *get<PSMatrix>(Overlap), *trace, *get<PSMatrix>(ih_NewDensity),
+                           *get<SolverParameters>(ih_solver_parameters));
+}
+void LowdinExtrapolate_wrp(const int* ih_PreviousDensity, const int* OldOverlap, const int* NewOverlap, int* ih_NewDensity,
+                           const int* ih_solver_parameters) {
+  lowdin_extrapolate(*get<PSMatrix>(ih_PreviousDensity), *get<PSMatrix>(OldOverlap), *get<PSMatrix>(NewOverlap),
+                     *get<PSMatrix>(ih_NewDensity), *get<SolverParameters>(ih_solver_parameters));
+}
+void SnapMatrixToSparsityPattern_wrp(int* ih_matA, const int* ih_matB) {
+  snap_to_sparsity_pattern(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB));
 }
 
 // ---- matrix polynomials: Polynomial_c.h:4-13, ChebyshevSolvers_c.h:4-15, HermiteSolvers_c.h:4-11
@@ -719,33 +841,28 @@ void ComputeInverseRoot_wrp(const int* ih_inputmat, int* ih_outputmat, const int
 void PowerBounds_wrp(const int* ih_Hamiltonian, double* max_value, const int* ih_solver_parameters) {
   power_bounds(*get<PSMatrix>(ih_Hamiltonian), max_value, *get<SolverParameters>(ih_solver_parameters), false);
 }
-// dense (eigendecomposition) variants: link compatibility only, see DenseDensity_wrp above
-static void dense_stub(const char* name) {
-  NTP_FATAL(std::string(name) + ": the dense eigensolver path is not part of the MI355X engine; use the sparse solver of the same name");
+// dense (eigendecomposition) variants: ExponentialSolversModule.F90:372-404,637-669, TrigonometrySolversModule.F90:66-150,
+// InverseSolversModule.F90:152-181, SignSolversModule.F90:67-96
+void ComputeExponentialPade_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
+  compute_exponential_pade(*get<PSMatrix>(ih_Input), *get<PSMatrix>(ih_Output), *get<SolverParameters>(ih_solver_parameters));
 }
 void ComputeDenseExponential_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
-  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
-  dense_stub("ComputeDenseExponential_wrp");
+  dense_function(ih_Input, ih_Output, ih_solver_parameters, "Exponential Solver", [](double v) { return std::exp(v); });
 }
 void ComputeDenseLogarithm_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
-  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
-  dense_stub("ComputeDenseLogarithm_wrp");
+  dense_function(ih_Input, ih_Output, ih_solver_parameters, "Logarithm Solver", [](double v) { return std::log(v); });
 }
 void DenseSine_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
-  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
-  dense_stub("DenseSine_wrp");
+  dense_function(ih_Input, ih_Output, ih_solver_parameters, "Trigonometry Solver", [](double v) { return std::sin(v); });
 }
 void DenseCosine_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
-  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
-  dense_stub("DenseCosine_wrp");
+  dense_function(ih_Input, ih_Output, ih_solver_parameters, "Trigonometry Solver", [](double v) { return std::cos(v); });
 }
 void DenseInvert_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
-  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
-  dense_stub("DenseInvert_wrp");
+  dense_function(ih_Input, ih_Output, ih_solver_parameters, "Inverse Solver", [](double v) { return 1.0 / v; });
 }
 void DenseSignFunction_wrp(const int* ih_Input, int* ih_Output, const int* ih_solver_parameters) {
-  (void)ih_Input; (void)ih_Output; (void)ih_solver_parameters;
-  dense_stub("DenseSignFunction_wrp");
+  dense_function(ih_Input, ih_Output, ih_solver_parameters, "Sign Function Solver", [](double v) { return v < 0.0 ? -1.0 : 1.0; });
 }
 
 void SignFunction_wrp(const int* ih_mat1, int* ih_signmat, const int* ih_solver_parameters) {
@@ -830,6 +947,24 @@ void ntpoly_amd_square_root_order(const int* ih_Input, int* ih_Output, const int
   }                                                                                                              \
   void MatrixToTripletList_##SUF##_wrp(const int* ih_this, int* ih_triplet_list) {                               \
     to_triplets(get<LocalMat>(ih_this)->m, 0, *get<HostTriplets>(ih_triplet_list));                              \
+  }                                                                                                              \
+  /* ExtractMatrixRow.f90 / ExtractMatrixColumn.f90 (1-based number), MatrixDiagonalScale (column col *= value), */ \
+  /* PrintMatrix.f90 (MatrixMarket text to stdout or a file) */                                                  \
+  void ExtractMatrixColumn_##SUF##_wrp(const int* ih_this, int* column_number, int* ih_column_out) {             \
+    get<LocalMat>(ih_column_out)->m = column_slice(get<LocalMat>(ih_this)->m, *column_number - 1, *column_number); \
+  }                                                                                                              \
+  void ExtractMatrixRow_##SUF##_wrp(const int* ih_this, int* row_number, int* ih_row_out) {                      \
+    DevMat t = transpose(get<LocalMat>(ih_this)->m);                                                             \
+    DevMat c = column_slice(t, *row_number - 1, *row_number);                                                    \
+    get<LocalMat>(ih_row_out)->m = transpose(c);                                                                 \
+  }                                                                                                              \
+  void MatrixDiagonalScale_##SUF##_wrp(int* ih_mat, const int* ih_tlist) {                                       \
+    local_diagonal_scale(get<LocalMat>(ih_mat)->m, *get<HostTriplets>(ih_tlist));                                \
+  }                                                                                                              \
+  void PrintMatrix_##SUF##_wrp(const int* ih_this) { local_print(get<LocalMat>(ih_this)->m, nullptr); }          \
+  void PrintMatrixF_##SUF##_wrp(const int* ih_this, const char* file_name, const int* name_size) {                \
+    const std::string path = fstring(file_name, name_size);                                                      \
+    local_print(get<LocalMat>(ih_this)->m, path.c_str());                                                        \
   }                                                                                                              \
   /* GemmMatrix (sparse_includes/GemmMatrix.f90:1-101) */                                                        \
   void MatrixMultiply_##SUF##_wrp(const int* ih_matA, const int* ih_matB, int* ih_matC, const bool* IsATransposed, \

@@ -639,6 +639,10 @@ class ExponentialSolvers:
     def ComputeLogarithm(InputMat, OutputMat, solver_parameters):
         lib.ComputeLogarithm_wrp(InputMat.ih, OutputMat.ih, solver_parameters.ih)
 
+    @staticmethod
+    def ComputeExponentialPade(InputMat, OutputMat, solver_parameters):
+        lib.ComputeExponentialPade_wrp(InputMat.ih, OutputMat.ih, solver_parameters.ih)
+
 
 class TrigonometrySolvers:
     @staticmethod
@@ -658,6 +662,109 @@ class RootSolvers:
     @staticmethod
     def ComputeInverseRoot(InputMat, OutputMat, root, solver_parameters):
         lib.ComputeInverseRoot_wrp(InputMat.ih, OutputMat.ih, i(root), solver_parameters.ih)
+
+
+class LinearSolvers:
+    """Source/CPlusPlus/LinearSolvers.h"""
+    @staticmethod
+    def CGSolver(AMat, XMat, BMat, solver_parameters):
+        lib.CGSolver_wrp(AMat.ih, XMat.ih, BMat.ih, solver_parameters.ih)
+
+    @staticmethod
+    def CholeskyDecomposition(AMat, LMat, solver_parameters):
+        lib.CholeskyDecomposition_wrp(AMat.ih, LMat.ih, solver_parameters.ih)
+
+
+class Analysis:
+    """Source/CPlusPlus/Analysis.h"""
+    @staticmethod
+    def PivotedCholeskyDecomposition(AMat, LMat, rank, solver_parameters):
+        lib.PivotedCholeskyDecomposition_wrp(AMat.ih, LMat.ih, i(rank), solver_parameters.ih)
+
+    @staticmethod
+    def ReduceDimension(AMat, dim, RMat, solver_parameters):
+        lib.ReduceDimension_wrp(AMat.ih, i(dim), RMat.ih, solver_parameters.ih)
+
+
+class GeometryOptimization:
+    """Source/CPlusPlus/GeometryOptimization.h"""
+    @staticmethod
+    def PurificationExtrapolate(PreviousDensity, Overlap, trace, NewDensity, solver_parameters):
+        lib.PurificationExtrapolate_wrp(PreviousDensity.ih, Overlap.ih, d(trace), NewDensity.ih, solver_parameters.ih)
+
+    @staticmethod
+    def LowdinExtrapolate(PreviousDensity, OldOverlap, NewOverlap, NewDensity, solver_parameters):
+        lib.LowdinExtrapolate_wrp(PreviousDensity.ih, OldOverlap.ih, NewOverlap.ih, NewDensity.ih, solver_parameters.ih)
+
+
+class MatrixConversion:
+    """Source/CPlusPlus/MatrixConversion.h"""
+    @staticmethod
+    def SnapMatrixToSparsityPattern(mat, pattern):
+        lib.SnapMatrixToSparsityPattern_wrp(mat.ih, pattern.ih)
+
+
+class EigenSolvers:
+    """Source/CPlusPlus/EigenSolvers.h (the dense eigensolver is the engine's own Jacobi method on the GPU)"""
+    @staticmethod
+    def EigenDecomposition(matrix, eigenvalues, nvals, eigenvectors, solver_parameters):
+        lib.EigenDecomposition_wrp(matrix.ih, eigenvalues.ih, i(nvals), eigenvectors.ih, solver_parameters.ih)
+
+    @staticmethod
+    def EigenValues(matrix, eigenvalues, nvals, solver_parameters):
+        lib.EigenDecomposition_novec_wrp(matrix.ih, eigenvalues.ih, i(nvals), solver_parameters.ih)
+
+    @staticmethod
+    def SingularValueDecomposition(matrix, leftvectors, rightvectors, singularvalues, solver_parameters):
+        lib.SingularValueDecompostion_wrp(matrix.ih, leftvectors.ih, rightvectors.ih, singularvalues.ih,
+                                          solver_parameters.ih)
+
+    @staticmethod
+    def EstimateGap(H, K, chemical_potential, solver_parameters):
+        gap = C.c_double()
+        lib.EstimateGap_wrp(H.ih, K.ih, d(chemical_potential), C.byref(gap), solver_parameters.ih)
+        return gap.value
+
+
+class FermiOperator:
+    """Source/CPlusPlus/FermiOperator.h; each returns (energy, chemical potential or None)"""
+    @staticmethod
+    def ComputeDenseFOE(H, ISQ, trace, Density, inv_temp, solver_parameters):
+        e, mu = C.c_double(), C.c_double()
+        lib.ComputeDenseFOE_wrp(H.ih, ISQ.ih, d(trace), Density.ih, d(inv_temp), C.byref(e), C.byref(mu), solver_parameters.ih)
+        return e.value, mu.value
+
+    @staticmethod
+    def WOM_GC(H, ISQ, Density, chemical_potential, inv_temp, solver_parameters):
+        e = C.c_double()
+        lib.WOM_GC_wrp(H.ih, ISQ.ih, Density.ih, d(chemical_potential), d(inv_temp), C.byref(e), solver_parameters.ih)
+        return e.value
+
+    @staticmethod
+    def WOM_C(H, ISQ, Density, trace, inv_temp, solver_parameters):
+        e = C.c_double()
+        lib.WOM_C_wrp(H.ih, ISQ.ih, Density.ih, d(trace), d(inv_temp), C.byref(e), solver_parameters.ih)
+        return e.value
+
+
+class DenseSolvers:
+    """the reference's Dense* entry points (f(A) = V f(L) V^H through the eigendecomposition)"""
+    @staticmethod
+    def DenseDensity(H, ISQ, trace, Density, solver_parameters):
+        return DensityMatrixSolvers._run(lib.DenseDensity_wrp, H, ISQ, trace, Density, solver_parameters)
+
+    @staticmethod
+    def _f(name, In, Out, solver_parameters):
+        getattr(lib, name)(In.ih, Out.ih, solver_parameters.ih)
+
+    SquareRoot = staticmethod(lambda a, o, p: DenseSolvers._f("DenseSquareRoot_wrp", a, o, p))
+    InverseSquareRoot = staticmethod(lambda a, o, p: DenseSolvers._f("DenseInverseSquareRoot_wrp", a, o, p))
+    Exponential = staticmethod(lambda a, o, p: DenseSolvers._f("ComputeDenseExponential_wrp", a, o, p))
+    Logarithm = staticmethod(lambda a, o, p: DenseSolvers._f("ComputeDenseLogarithm_wrp", a, o, p))
+    Sine = staticmethod(lambda a, o, p: DenseSolvers._f("DenseSine_wrp", a, o, p))
+    Cosine = staticmethod(lambda a, o, p: DenseSolvers._f("DenseCosine_wrp", a, o, p))
+    Invert = staticmethod(lambda a, o, p: DenseSolvers._f("DenseInvert_wrp", a, o, p))
+    SignFunction = staticmethod(lambda a, o, p: DenseSolvers._f("DenseSignFunction_wrp", a, o, p))
 
 
 class LoadBalancer:

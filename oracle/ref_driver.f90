@@ -45,6 +45,21 @@ PROGRAM RefDriver
   USE TrigonometrySolversModule, ONLY : Sine, Cosine
   USE RootSolversModule, ONLY : ComputeRoot, ComputeInverseRoot
   USE EigenBoundsModule, ONLY : PowerBounds
+  USE LinearSolversModule, ONLY : CGSolver, CholeskyDecomposition
+  USE AnalysisModule, ONLY : PivotedCholeskyDecomposition, ReduceDimension
+  USE ExponentialSolversModule, ONLY : ComputeExponentialPade, &
+       & ComputeDenseExponential, ComputeDenseLogarithm
+  USE GeometryOptimizationModule, ONLY : PurificationExtrapolate, &
+       & LowdinExtrapolate
+  USE MatrixConversionModule, ONLY : SnapMatrixToSparsityPattern
+  USE EigenSolversModule, ONLY : EigenDecomposition, EstimateGap
+  USE SingularValueSolversModule, ONLY : SingularValueDecomposition
+  USE FermiOperatorModule, ONLY : ComputeDenseFOE, WOM_GC, WOM_C
+  USE DensityMatrixSolversModule, ONLY : DenseDensity
+  USE SquareRootSolversModule, ONLY : DenseSquareRoot, DenseInverseSquareRoot
+  USE TrigonometrySolversModule, ONLY : DenseSine, DenseCosine
+  USE InverseSolversModule, ONLY : DenseInvert
+  USE SignSolversModule, ONLY : DenseSignFunction
   USE HermiteSolversModule, ONLY : HermitePolynomial_t, &
        & HermConstruct => ConstructPolynomial, HermSet => SetCoefficient, &
        & HermCompute => Compute
@@ -72,6 +87,8 @@ PROGRAM RefDriver
      CALL cmd_poly()
   CASE("func")
      CALL cmd_func()
+  CASE("extra")
+     CALL cmd_extra()
   CASE DEFAULT
      WRITE(*,*) "unknown command ", cmd
   END SELECT
@@ -484,6 +501,98 @@ CONTAINS
     END IF
     CALL DestructProcessGrid
   END SUBROUTINE cmd_func
+
+  !! extra pr pc ps <kind> A B C thr conv out scal.txt p1 p2    (B, C may be "none"; second output: out.2)
+  !!   kind in {cg, pade, purify, lowdin, snap, eig, svd, gap, foe, density, womgc, womc, chol, pchol, reduce,
+  !!            dsqrt, disqrt, dexp, dlog, dsin, dcos, dinv, dsign}
+  SUBROUTINE cmd_extra()
+    TYPE(Matrix_ps) :: A, B, C, K, K2, K3
+    TYPE(SolverParameters_t) :: sp
+    CHARACTER(len=32) :: kind
+    REAL(NTREAL) :: s1, s2, p1, p2
+    INTEGER :: u
+    LOGICAL :: have2
+    CALL make_grid(2)
+    kind = sarg(5)
+    CALL load_ps(sarg(6), A)
+    IF (TRIM(sarg(7)) .NE. "none") CALL load_ps(sarg(7), B)
+    IF (TRIM(sarg(8)) .NE. "none") CALL load_ps(sarg(8), C)
+    p1 = rarg(13)
+    p2 = rarg(14)
+    !! (EstimateGap writes a key without a value, which the flang runtime rejects: it runs with the logger off)
+    IF (IsRoot() .AND. TRIM(kind) .NE. "gap") CALL ActivateLogger(start_document_in=.TRUE., &
+         & file_name_in=TRIM(sarg(11))//".log")
+    CALL ConstructSolverParameters(sp, threshold_in=rarg(9), converge_diff_in=rarg(10), &
+         & be_verbose_in=(TRIM(kind) .NE. "gap"))
+    s1 = 0; s2 = 0
+    have2 = .FALSE.
+    SELECT CASE(TRIM(kind))
+    CASE("cg")
+       CALL CGSolver(A, K, B, sp)
+    CASE("pade")
+       CALL ComputeExponentialPade(A, K, sp)
+    CASE("purify")
+       CALL PurificationExtrapolate(A, B, p1, K, sp)
+    CASE("lowdin")
+       CALL LowdinExtrapolate(A, B, C, K, sp)
+    CASE("snap")
+       CALL CopyMatrix(A, K)
+       CALL SnapMatrixToSparsityPattern(K, B)
+    CASE("eig")
+       CALL EigenDecomposition(A, K, eigenvectors_in=K2, nvals_in=INT(p1), &
+            & solver_parameters_in=sp)
+       have2 = .TRUE.
+    CASE("svd")
+       CALL SingularValueDecomposition(A, K2, K3, K, sp)
+       have2 = .TRUE.
+    CASE("gap")
+       CALL EstimateGap(A, B, p1, s1, sp)
+       CALL CopyMatrix(A, K)
+    CASE("foe")
+       CALL ComputeDenseFOE(A, B, p1, K, inv_temp_in=p2, energy_value_out=s1, &
+            & chemical_potential_out=s2, solver_parameters_in=sp)
+    CASE("density")
+       CALL DenseDensity(A, B, p1, K, energy_value_out=s1, &
+            & chemical_potential_out=s2, solver_parameters_in=sp)
+    CASE("womgc")
+       CALL WOM_GC(A, B, K, p1, p2, energy_value_out=s1, solver_parameters_in=sp)
+    CASE("womc")
+       CALL WOM_C(A, B, K, p1, p2, energy_value_out=s1, solver_parameters_in=sp)
+    CASE("chol")
+       CALL CholeskyDecomposition(A, K, sp)
+    CASE("pchol")
+       CALL PivotedCholeskyDecomposition(A, K, INT(p1), sp)
+    CASE("reduce")
+       CALL ReduceDimension(A, INT(p1), K, sp)
+    CASE("dsqrt")
+       CALL DenseSquareRoot(A, K, sp)
+    CASE("disqrt")
+       CALL DenseInverseSquareRoot(A, K, sp)
+    CASE("dexp")
+       CALL ComputeDenseExponential(A, K, sp)
+    CASE("dlog")
+       CALL ComputeDenseLogarithm(A, K, sp)
+    CASE("dsin")
+       CALL DenseSine(A, K, sp)
+    CASE("dcos")
+       CALL DenseCosine(A, K, sp)
+    CASE("dinv")
+       CALL DenseInvert(A, K, sp)
+    CASE("dsign")
+       CALL DenseSignFunction(A, K, sp)
+    END SELECT
+    IF (IsRoot() .AND. TRIM(kind) .NE. "gap") CALL DeactivateLogger
+    CALL store_ps(sarg(11), K)
+    IF (have2) CALL store_ps(TRIM(sarg(11))//".2", K2)
+    IF (IsRoot()) THEN
+       OPEN(NEWUNIT=u, FILE=TRIM(sarg(12)), STATUS="REPLACE")
+       WRITE(u, '(A,ES26.17E3)') "s1 ", s1
+       WRITE(u, '(A,ES26.17E3)') "s2 ", s2
+       WRITE(u, '(A,I0)') "nnz ", GetMatrixSize(K)
+       CLOSE(u)
+    END IF
+    CALL DestructProcessGrid
+  END SUBROUTINE cmd_extra
 
   FUNCTION env_real(name) RESULT(v)
     CHARACTER(len=*), INTENT(IN) :: name

@@ -462,6 +462,96 @@ def gen_functions(tmp):
     save("functions", d, dict(kind="functions", cases=cases))
 
 
+def gen_extras(tmp):
+    """The remaining solver families run by the real reference (ref_driver extra ...): CG, Pade exponential, geometry
+    extrapolation, sparsity-pattern snap, dense eigendecomposition / SVD / matrix functions, gap estimate, Fermi
+    operator (dense FOE, dense step function, WOM_GC, WOM_C), Cholesky, pivoted Cholesky, ReduceDimension."""
+    rng = np.random.default_rng(77)
+    d, cases = {}, []
+    n, nel = 96, 30
+    Hs = banded(n, 5)
+    Hp = sp.csc_matrix(Hs + 2.5 * sp.identity(n))
+    Hc = sp.csc_matrix(banded(64, 4, True))
+    Hcp = sp.csc_matrix(Hc + 2.5 * sp.identity(64))
+    B1 = banded(n, 3)
+    S_old = sp.csc_matrix(sp.identity(n) + 0.05 * B1)
+    S_new = sp.csc_matrix(sp.identity(n) + 0.06 * B1)
+    w, v = np.linalg.eigh(Hs.toarray())
+    Dd = v[:, :nel] @ v[:, :nel].T
+    Dd[np.abs(Dd) < 1e-12] = 0.0
+    D = sp.csc_matrix(Dd)
+    mu_mid = 0.5 * (w[nel - 1] + w[nel])
+    ws, vs = np.linalg.eigh(S_old.toarray())
+    ISQ = sp.csc_matrix((vs / np.sqrt(ws)) @ vs.T)
+    Ident = sp.identity(n, format="csc")
+    R = sp.csc_matrix(rnd(rng, n, n, 0.08) + 2.0 * sp.identity(n))
+    Ra, Rb = rnd(rng, n, n, 0.10), rnd(rng, n, n, 0.12)
+    Rc = rnd(rng, n, n, 0.10, True)
+    mats = dict(Hs=Hs, Hp=Hp, Hc=Hc, Hcp=Hcp, S_old=S_old, S_new=S_new, D=D, ISQ=ISQ, I=Ident, R=R, Ra=Ra, Rb=Rb, Rc=Rc)
+    for name, M in mats.items():
+        M = sp.csc_matrix(M)
+        M.sort_indices()
+        mats[name] = M
+        put(d, "M_" + name, M.shape, tri(M))
+    jobs = [  # kind, A, B, C, thr, conv, p1, p2
+        ("cg", "Hp", "Hs", None, 0.0, 1e-9, 0, 0),      # (with a threshold the residual becomes exactly zero and the
+        ("cg", "Hcp", "Hc", None, 0.0, 1e-9, 0, 0),     #  reference's loop divides 0 / 0 before its monitor stops it)
+        ("pade", "Hs", None, None, 1e-9, 1e-8, 0, 0),
+        ("purify", "D", "S_old", None, 1e-9, 1e-8, nel, 0),
+        ("lowdin", "D", "S_old", "S_new", 1e-9, 1e-8, 0, 0),
+        ("snap", "Ra", "Rb", None, 0.0, 1e-8, 0, 0),
+        ("snap", "Rc", "Rb", None, 0.0, 1e-8, 0, 0),
+        ("eig", "Hs", None, None, 1e-12, 1e-8, n, 0),
+        ("eig", "Hs", None, None, 1e-12, 1e-8, 10, 0),
+        ("eig", "Hc", None, None, 1e-12, 1e-8, 64, 0),
+        ("svd", "R", None, None, 1e-12, 1e-10, 0, 0),
+        ("gap", "Hs", "D", None, 1e-10, 1e-8, mu_mid, 0),
+        ("foe", "Hs", "I", None, 1e-10, 1e-8, nel, 20.0),
+        ("foe", "Hs", "ISQ", None, 1e-10, 1e-8, nel, 50.0),
+        ("foe", "Hc", "none_identity", None, 1e-10, 1e-8, 20, 30.0),
+        ("density", "Hs", "I", None, 1e-10, 1e-8, nel, 0),
+        ("density", "Hs", "ISQ", None, 1e-10, 1e-8, nel + 0.5, 0),
+        ("womgc", "Hs", "I", None, 1e-8, 1e-8, mu_mid, 4.0),
+        ("womc", "Hs", "ISQ", None, 1e-8, 1e-8, nel, 4.0),
+        ("chol", "Hp", None, None, 0.0, 1e-8, 0, 0),
+        ("chol", "Hp", None, None, 1e-6, 1e-8, 0, 0),
+        ("pchol", "D", None, None, 1e-10, 1e-8, nel, 0),
+        ("pchol", "Hp", None, None, 1e-8, 1e-8, 40, 0),
+        ("reduce", "Hs", None, None, 1e-9, 1e-8, nel, 0),
+        ("dsqrt", "Hp", None, None, 1e-10, 1e-8, 0, 0),
+        ("dsqrt", "Hcp", None, None, 1e-10, 1e-8, 0, 0),
+        ("disqrt", "Hp", None, None, 1e-10, 1e-8, 0, 0),
+        ("dexp", "Hs", None, None, 1e-10, 1e-8, 0, 0),
+        ("dlog", "Hp", None, None, 1e-10, 1e-8, 0, 0),
+        ("dsin", "Hs", None, None, 1e-10, 1e-8, 0, 0),
+        ("dcos", "Hc", None, None, 1e-10, 1e-8, 0, 0),
+        ("dinv", "Hp", None, None, 1e-10, 1e-8, 0, 0),
+        ("dsign", "Hs", None, None, 1e-10, 1e-8, 0, 0),
+    ]
+    IdentC = sp.identity(64, format="csc")
+    for kind, a, b, c, thr, conv, p1, p2 in jobs:
+        files = []
+        for tag, nm in (("A", a), ("B", b), ("C", c)):
+            if nm is None:
+                files.append("none")
+                continue
+            M = IdentC if nm == "none_identity" else mats[nm]
+            write_tri("%s/%s.tri" % (tmp, tag), M.shape[0], M.shape[1], *tri(M))
+            files.append("%s/%s.tri" % (tmp, tag))
+        run(["extra", 1, 1, 1, kind] + files + [repr(thr), repr(conv), tmp + "/K.tri", tmp + "/s.txt", repr(float(p1)), repr(float(p2))])
+        rows, cols, cc, rr, vv = read_tri(tmp + "/K.tri")
+        sc = {kk: float(x) for kk, x in (ln.split() for ln in open(tmp + "/s.txt"))}
+        pre = "c%03d_" % len(cases)
+        put(d, pre + "K", (rows, cols), (cc, rr, vv))
+        if kind in ("eig", "svd"):
+            rows2, cols2, c2, r2, v2 = read_tri(tmp + "/K.tri.2")
+            put(d, pre + "K2", (rows2, cols2), (c2, r2, v2))
+        cases.append(dict(kind=kind, A=a, B=b, C=c, thr=thr, conv=conv, p1=float(p1), p2=float(p2), s1=sc["s1"], s2=sc["s2"],
+                          nnz=int(len(cc))))
+        print("  ", kind, a, b, "nnz", len(cc), "s1", sc["s1"], "s2", sc["s2"])
+    save("extras", d, dict(kind="extras", cases=cases))
+
+
 def gen_ps_gemm_fma(tmp):
     """Distributed multiply computed by the reference built WITH floating-point contraction (oracle/build_ref.py
     --fma: -ffp-contract=fast -march=haswell, `acc + a*b` is one FMA) -- what the reference produces on targets

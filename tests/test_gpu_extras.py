@@ -448,3 +448,134 @@ def test_matrix_functions_golden(nt):
         tol = max(1000 * c["thr"], 1e-11) * max(1.0, np.abs(wd).max())
         assert np.abs(gd - wd).max() <= tol, (i, c["kind"], c["matrix"], c["root"], np.abs(gd - wd).max())
     assert n_diverged <= 4
+
+
+def test_remaining_solver_families_golden(nt):
+    """CG, Pade exponential, geometry extrapolation, sparsity snap, dense eigendecomposition / SVD / matrix functions
+    (own Jacobi eigensolver on the GPU), gap estimate, dense FOE / step function, WOM_GC / WOM_C, Cholesky, pivoted Cholesky and
+    ReduceDimension against what the REAL reference computed (tests/golden/extras.npz, make_golden.py extras)."""
+    g = Golden("extras")
+    names = ("Hs", "Hp", "Hc", "Hcp", "S_old", "S_new", "D", "ISQ", "I", "R", "Ra", "Rb", "Rc")
+    mats = {k: pmat(nt, g.tri(None, "M_" + k)) for k in names}
+    I64 = nt.Matrix_ps(64)
+    I64.FillIdentity()
+    mats["none_identity"] = I64
+    dense_fn = dict(dsqrt="SquareRoot", disqrt="InverseSquareRoot", dexp="Exponential", dlog="Logarithm", dsin="Sine",
+                    dcos="Cosine", dinv="Invert", dsign="SignFunction")
+    seen = set()
+    for i, c in enumerate(g.cases):
+        kind = c["kind"]
+        seen.add(kind)
+        A = mats[c["A"]]
+        B = mats.get(c["B"])
+        n = A.GetActualDimension()
+        p = nt.SolverParameters()
+        p.SetThreshold(c["thr"])
+        p.SetConvergeDiff(c["conv"])
+        Out, Out2, Out3 = nt.Matrix_ps(n), nt.Matrix_ps(n), nt.Matrix_ps(n)
+        s1 = s2 = None
+        if kind == "cg":
+            nt.LinearSolvers.CGSolver(A, Out, B, p)
+        elif kind == "pade":
+            nt.ExponentialSolvers.ComputeExponentialPade(A, Out, p)
+        elif kind == "purify":
+            nt.GeometryOptimization.PurificationExtrapolate(A, B, c["p1"], Out, p)
+        elif kind == "lowdin":
+            nt.GeometryOptimization.LowdinExtrapolate(A, B, mats[c["C"]], Out, p)
+        elif kind == "snap":
+            Out = nt.Matrix_ps(A)
+            nt.MatrixConversion.SnapMatrixToSparsityPattern(Out, B)
+        elif kind == "eig":
+            nt.EigenSolvers.EigenDecomposition(A, Out, int(c["p1"]), Out2, p)
+        elif kind == "svd":
+            nt.EigenSolvers.SingularValueDecomposition(A, Out2, Out3, Out, p)
+        elif kind == "gap":
+            s1 = nt.EigenSolvers.EstimateGap(A, B, c["p1"], p)
+        elif kind == "foe":
+            s1, s2 = nt.FermiOperator.ComputeDenseFOE(A, B, c["p1"], Out, c["p2"], p)
+        elif kind == "density":
+            s1, s2 = nt.DenseSolvers.DenseDensity(A, B, c["p1"], Out, p)
+        elif kind == "womgc":
+            s1 = nt.FermiOperator.WOM_GC(A, B, Out, c["p1"], c["p2"], p)
+        elif kind == "womc":
+            s1 = nt.FermiOperator.WOM_C(A, B, Out, c["p1"], c["p2"], p)
+        elif kind == "chol":
+            nt.LinearSolvers.CholeskyDecomposition(A, Out, p)
+        elif kind == "pchol":
+            nt.Analysis.PivotedCholeskyDecomposition(A, Out, int(c["p1"]), p)
+        elif kind == "reduce":
+            Out = nt.Matrix_ps(int(c["p1"]))
+            nt.Analysis.ReduceDimension(A, int(c["p1"]), Out, p)
+        else:
+            getattr(nt.DenseSolvers, dense_fn[kind])(A, Out, p)
+        tag = (i, kind, c["A"], c["B"])
+        if s1 is not None:
+            rel = 1e-6 if kind == "gap" else 1e-9   # gap: two power iterations, stopping step sensitive (see PowerBounds)
+            if kind in ("womgc", "womc"):
+                rel = 1e-6                           # adaptive step control compares norms against step_thresh
+            assert s1 == pytest.approx(c["s1"], rel=rel, abs=1e-9), tag
+        if s2 is not None:
+            assert s2 == pytest.approx(c["s2"], rel=1e-9, abs=1e-9), tag
+        if kind == "gap":
+            continue
+        want = g.tri(i, "K")
+        wd = to_dense(want)
+        got = Out.triplets()
+        gd = to_dense((want[0], want[1]) + tuple(got))
+        scale = max(1.0, np.abs(wd).max())
+        if kind == "snap":
+            assert np.array_equal(got[0], want[2]) and np.array_equal(got[1], want[3]) and np.array_equal(got[2], want[4]), tag
+            continue
+        if kind == "reduce":
+            # the pivot order of a projector's (degenerate) diagonal is decided by its last bits: compare the spectrum
+            ew, eg = np.linalg.eigvalsh(wd), np.linalg.eigvalsh(gd)
+            assert np.abs(ew - eg).max() <= 1e-6 * scale, tag
+            continue
+        tol = {"womgc": 1e-5, "womc": 1e-5, "pade": 1e-7, "cg": 1e-8}.get(kind, max(100 * c["thr"], 1e-9)) * scale
+        if kind in ("eig", "svd"):
+            assert np.abs(np.diag(gd) - np.diag(wd)).max() <= 1e-10 * scale, tag
+            if kind == "eig":
+                # eigenvectors: defined up to a phase per column (spectrum is non-degenerate here)
+                v_w = to_dense(g.tri(i, "K2"))
+                got2 = Out2.triplets()
+                v_g = to_dense((v_w.shape[0], v_w.shape[1]) + tuple(got2))
+                assert np.abs(np.abs(v_g) - np.abs(v_w)).max() <= 1e-8, tag
+                a = A.to_scipy().toarray()
+                k = int(c["p1"])
+                assert np.abs(a @ v_g[:, :k] - v_g[:, :k] * np.diag(gd)[:k]).max() <= 1e-9 * scale, tag
+            continue
+        if kind == "pchol" and c["A"] == "D":
+            # rank-nel projector: ties in the pivot search (equal diagonal up to roundoff) may be taken in another
+            # order; what is pinned is the product L L^T
+            assert np.abs(gd @ gd.T - wd @ wd.T).max() <= 1e-8, tag
+            continue
+        assert np.abs(gd - wd).max() <= tol, tag + (np.abs(gd - wd).max(),)
+    assert len(seen) == 23
+
+
+@pytest.mark.parametrize("n,cplx", [(257, False), (600, False), (301, True)])
+def test_jacobi_eigensolver_vs_numpy(nt, n, cplx):
+    """the engine's dense Hermitian eigensolver (two-sided Jacobi, dense.hip) on full random matrices of odd and even
+    order, with a degenerate cluster and a zero eigenvalue: eigenvalues against numpy.linalg.eigvalsh (1e-12 relative to
+    the norm), A V = V W and V^H V = I to 1e-11."""
+    rng = np.random.default_rng(n)
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0))
+    w = rng.uniform(-3, 3, n)
+    w[:4] = 1.25          # degenerate cluster
+    w[4] = 0.0            # zero eigenvalue
+    a = (q * w) @ q.conj().T
+    a = 0.5 * (a + a.conj().T)
+    import scipy.sparse as sp
+    A = nt.Matrix_ps.from_scipy(sp.csc_matrix(a))
+    W, V = nt.Matrix_ps(n), nt.Matrix_ps(n)
+    p = nt.SolverParameters()
+    p.SetThreshold(0.0)
+    nt.EigenSolvers.EigenDecomposition(A, W, n, V, p)
+    wd = np.real(W.to_scipy().toarray().diagonal())
+    vd = V.to_scipy().toarray()
+    ref = np.linalg.eigvalsh(a)
+    scale = np.abs(ref).max()
+    assert np.all(np.diff(wd) >= -1e-13)
+    assert np.abs(wd - ref).max() <= 1e-12 * scale
+    assert np.abs(a @ vd - vd * wd).max() <= 1e-11 * scale
+    assert np.abs(vd.conj().T @ vd - np.eye(n)).max() <= 1e-11

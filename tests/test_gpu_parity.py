@@ -494,3 +494,24 @@ def test_full_size_properties_config2_trs2(nt):
     assert energy_b == pytest.approx(energy, rel=1e-13) and mu_b == pytest.approx(mu, rel=1e-12)
     ka, kb = K.triplets(), Kb.triplets()
     assert all(np.array_equal(u, v) for u, v in zip(ka, kb))
+
+
+def test_spgemm_blocks_of_empty_columns(nt):
+    """B with whole 16-column blocks empty (a rank-30 factor stored in an N x N matrix, as the pivoted Cholesky
+    returns it): the slab planner must not walk a k range for such a block.  Bit-exact against the oracle."""
+    from oracle import oracle_py as O
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    n = 200
+    A = sp.random(n, n, 0.2, random_state=rng, format="csc")
+    B = sp.random(n, n, 0.3, random_state=rng, format="csc").tolil()
+    B[:, 30:170] = 0
+    B = sp.csc_matrix(B)
+    B.eliminate_zeros()
+    for X, Y in ((A, B), (B, A), (B, B)):
+        mA, mB = nt.Matrix_ps.from_scipy(X), nt.Matrix_ps.from_scipy(Y)
+        C = nt.Matrix_ps(n)
+        C.Gemm(mA, mB, None, 1.0, 0.0, 1e-9)
+        tx, ty = mA.triplets(), mB.triplets()
+        oc, orow, ov = O.ps_multiply(O.Mat.from_triplets(n, n, *tx), O.Mat.from_triplets(n, n, *ty), None, 1.0, 0.0, 1e-9).triplets()
+        exact(C.triplets(), (n, n, oc, orow, ov), "empty column blocks")

@@ -81,6 +81,12 @@ GROUPS = [
     ("ntpoly_amd_function_solvers.h", "ExponentialSolvers_c.h", "exponential / logarithm (ExponentialSolversModule.F90)"),
     ("ntpoly_amd_function_solvers.h", "TrigonometrySolvers_c.h", "sine / cosine (TrigonometrySolversModule.F90)"),
     ("ntpoly_amd_function_solvers.h", "RootSolvers_c.h", "roots / inverse roots (RootSolversModule.F90)"),
+    ("ntpoly_amd_linear_solvers.h", "LinearSolvers_c.h", "CG, Cholesky (LinearSolversModule.F90)"),
+    ("ntpoly_amd_linear_solvers.h", "Analysis_c.h", "pivoted Cholesky, ReduceDimension (AnalysisModule.F90)"),
+    ("ntpoly_amd_eigen_solvers.h", "EigenSolvers_c.h", "eigendecomposition, SVD, gap estimate (EigenSolversModule.F90, SingularValueSolversModule.F90)"),
+    ("ntpoly_amd_eigen_solvers.h", "FermiOperator_c.h", "dense FOE, wave-operator minimisation (FermiOperatorModule.F90)"),
+    ("ntpoly_amd_geometry.h", "GeometryOptimization_c.h", "density matrix extrapolation (GeometryOptimizationModule.F90)"),
+    ("ntpoly_amd_geometry.h", "MatrixConversion_c.h", "sparsity-pattern snap (MatrixConversionModule.F90)"),
 ]
 
 
