@@ -81,6 +81,46 @@ def main():
     keep("GG", GG)
     res["g0"], res["g1"] = g0, g1
 
+    # ---- the gather-based solver families: eigendecomposition (every rank factors the gathered matrix and keeps its
+    # panel), dense matrix function, Cholesky, pivoted Cholesky, CG, dense FOE, pattern snap
+    ms = 160
+    S = nt.Matrix_ps(ms)
+    s0, s1 = S.local_columns()
+    ts = nt.TripletList_r()
+    ts.set_arrays(*banded_triplets(ms, 6, shift=2.5, c0=s0, c1=s1))
+    S.FillFromTripletList(ts, prepartitioned=True)
+    res["s0"], res["s1"] = s0, s1
+    q = nt.SolverParameters()
+    q.SetThreshold(1e-10)
+    q.SetConvergeDiff(1e-9)
+    W, V = nt.Matrix_ps(ms), nt.Matrix_ps(ms)
+    nt.EigenSolvers.EigenDecomposition(S, W, ms, V, q)
+    keep("eigW", W)
+    keep("eigV", V)
+    F = nt.Matrix_ps(ms)
+    nt.DenseSolvers.InverseSquareRoot(S, F, q)
+    keep("disq", F)
+    L = nt.Matrix_ps(ms)
+    nt.LinearSolvers.CholeskyDecomposition(S, L, q)
+    keep("chol", L)
+    L2 = nt.Matrix_ps(ms)
+    nt.Analysis.PivotedCholeskyDecomposition(S, L2, 40, q)
+    keep("pchol", L2)
+    q0 = nt.SolverParameters()
+    q0.SetThreshold(0.0)
+    q0.SetConvergeDiff(1e-9)
+    X = nt.Matrix_ps(ms)
+    nt.LinearSolvers.CGSolver(S, X, L, q0)
+    keep("cg", X)
+    Is = nt.Matrix_ps(ms)
+    Is.FillIdentity()
+    Kf = nt.Matrix_ps(ms)
+    res["foe_energy"], res["foe_mu"] = nt.FermiOperator.ComputeDenseFOE(S, Is, 50.0, Kf, 25.0, q)
+    keep("foe", Kf)
+    Sn = nt.Matrix_ps(F)
+    nt.MatrixConversion.SnapMatrixToSparsityPattern(Sn, S)
+    keep("snap", Sn)
+
     np.savez(out + ".%d.npz" % rank, **res)
     nt.DestructGlobalProcessGrid()
 

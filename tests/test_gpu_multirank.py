@@ -65,6 +65,18 @@ def test_multirank_equals_single_rank(world, reference, tmp_path):
             assert np.allclose(got[2], want[2], rtol=0, atol=1e-10)
         else:
             assert all(np.array_equal(g, w) for g, w in zip(got, want)), tag
+    # gather-based families: every rank computes from the same gathered matrix -> identical panels
+    for tag in ("eigW", "eigV", "disq", "chol", "pchol", "foe", "snap"):
+        got = cat(parts, tag)
+        want = tuple(reference[tag + s] for s in ("_col", "_row", "_val"))
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), tag
+        assert np.allclose(got[2], want[2], rtol=0, atol=1e-11), tag
+    got, want = cat(parts, "cg"), tuple(reference["cg" + s] for s in ("_col", "_row", "_val"))
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.allclose(got[2], want[2], rtol=0, atol=1e-9)
+    for r in range(world):
+        assert parts[r]["foe_energy"] == pytest.approx(float(reference["foe_energy"]), rel=1e-12)
+        assert parts[r]["foe_mu"] == pytest.approx(float(reference["foe_mu"]), rel=1e-12)
     for r in range(world):
         for s in ("AB_trace", "AB_norm", "AB_dot", "trs2_energy", "trs2_mu"):
             assert parts[r][s] == pytest.approx(float(reference[s]), rel=1e-12, abs=1e-12), (s, r)

@@ -1,4 +1,2 @@
-timeout -s KILL 2400 python -m pytest tests/ -m gpu -x -q --durations=8 > gpurun_out/run6.log 2>&1
-tail -25 gpurun_out/run6.log
-timeout -s KILL 600 python bench.py > gpurun_out/bench_now.json 2> gpurun_out/bench_now.err
-tail -c 600 gpurun_out/bench_now.json
+timeout -s KILL 1200 python -m pytest tests/test_gpu_multirank.py -m gpu -x -q > gpurun_out/run6.log 2>&1
+tail -30 gpurun_out/run6.log
