@@ -37,6 +37,9 @@ static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 b
 namespace {
 struct RcclTransport : Transport {
   ncclComm_t comm = nullptr;
+  hipStream_t p2p = nullptr;  // stream of the next send / recv group (nullptr: the engine stream)
+  hipStream_t p2p_stream() const { return p2p ? p2p : stream(); }
+  void set_stream(hipStream_t st) override { p2p = st; }
   ~RcclTransport() override {
     if (comm) (void)ncclCommDestroy(comm);
   }
@@ -51,8 +54,8 @@ struct RcclTransport : Transport {
     NCCL_CHECK(ncclBroadcast(send, recv, bytes, ncclInt8, root, comm, stream()));
   }
   void group_begin() override { NCCL_CHECK(ncclGroupStart()); }
-  void send(const void* p, size_t bytes, int peer) override { NCCL_CHECK(ncclSend(p, bytes, ncclInt8, peer, comm, stream())); }
-  void recv(void* p, size_t bytes, int peer) override { NCCL_CHECK(ncclRecv(p, bytes, ncclInt8, peer, comm, stream())); }
+  void send(const void* p, size_t bytes, int peer) override { NCCL_CHECK(ncclSend(p, bytes, ncclInt8, peer, comm, p2p_stream())); }
+  void recv(void* p, size_t bytes, int peer) override { NCCL_CHECK(ncclRecv(p, bytes, ncclInt8, peer, comm, p2p_stream())); }
   void group_end() override { NCCL_CHECK(ncclGroupEnd()); }
 };
 
@@ -355,19 +358,33 @@ void halo_segment(int32_t dim, int P, int s, int32_t kmin, int32_t kmax, int32_t
 //      segment, row ids, values; the own segment is a device copy
 //   4. segments are re-based into one dim-wide matrix whose other columns are empty, so the SpGEMM
 //      kernels run unchanged.  No synchronisation at the end: everything downstream is stream ordered.
-DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2]) {
+namespace {
+// events ordering the communication stream against the engine stream (overlapped halo exchange)
+hipEvent_t halo_event(int which) {
+  static hipEvent_t ev[2] = {nullptr, nullptr};
+  if (!ev[which]) HIP_CHECK(hipEventCreateWithFlags(&ev[which], hipEventDisableTiming));
+  return ev[which];
+}
+}  // namespace
+
+void gather_needed_begin(HaloExchange& hx, const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2], bool may_overlap) {
   Comm& c = world();
   const int32_t dim = m.dim;
   if (!c.active()) NTP_FATAL("gather_needed without an active communicator");
   Transport& tr = *c.tr;
   const int P = c.nranks, me = c.rank;
-  // 1. requests
-  std::vector<int64_t> req((size_t)4 * P, 0);
+  hx.dim = dim;
+  hx.P = P;
+  const int ov_opt = options().halo_overlap;
+  const bool probe = may_overlap && ov_opt > 0;
+  // 1. requests (+ the interior column range of my B panel when the caller can split its multiply)
+  std::vector<int64_t> req((size_t)4 * P + 8, 0);
   {
-    DevBuf<int64_t> d((size_t)4 * P);
+    DevBuf<int64_t> d((size_t)4 * P + 8);
     halo_request_async(Bloc, m.loc.nnz, d.p + 4 * me);
+    if (probe) halo_interior_async(Bloc, m.c0, m.c1, d.p + 4 * P);
     tr.allgather(d.p + 4 * me, d.p, 4 * sizeof(int64_t));
-    d.download(req.data(), (size_t)4 * P);
+    d.download(req.data(), (size_t)4 * P + (probe ? 8 : 0));
   }
   nnz_global[0] = nnz_global[1] = 0;
   for (int q = 0; q < P; ++q) {
@@ -400,18 +417,44 @@ DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2
     }
   }
   // 3. receive layout: sources in rank order (their segments tile [kmin, kmax] in ascending columns)
-  std::vector<int32_t> ra((size_t)P), rb((size_t)P);
-  std::vector<int64_t> zoff((size_t)P + 1, 0), soff((size_t)P + 1, 0);
+  hx.ra.assign((size_t)P, 0);
+  hx.rb.assign((size_t)P, 0);
+  hx.zoff.assign((size_t)P + 1, 0);
+  hx.soff.assign((size_t)P + 1, 0);
+  hx.cnt_from.assign((size_t)P, 0);
+  int64_t remote = 0;
   for (int s = 0; s < P; ++s) {
-    halo_segment(dim, P, s, kmin, kmax, &ra[(size_t)s], &rb[(size_t)s]);
-    zoff[(size_t)s + 1] = zoff[(size_t)s] + cnt[(size_t)s * P + me];
-    soff[(size_t)s + 1] = soff[(size_t)s] + (rb[(size_t)s] - ra[(size_t)s] + 1);
+    halo_segment(dim, P, s, kmin, kmax, &hx.ra[(size_t)s], &hx.rb[(size_t)s]);
+    hx.cnt_from[(size_t)s] = cnt[(size_t)s * P + me];
+    hx.zoff[(size_t)s + 1] = hx.zoff[(size_t)s] + hx.cnt_from[(size_t)s];
+    hx.soff[(size_t)s + 1] = hx.soff[(size_t)s] + (hx.rb[(size_t)s] - hx.ra[(size_t)s] + 1);
+    if (s != me) remote += hx.cnt_from[(size_t)s];
   }
-  const int64_t total = zoff[(size_t)P];
-  DevMat full;
-  full.alloc(dim, dim, m.cplx, total);
-  DevBuf<int64_t> stage((size_t)soff[(size_t)P]);
+  const int64_t total = hx.zoff[(size_t)P];
+  hx.full.alloc(dim, dim, m.cplx, total);
+  hx.stage.alloc((size_t)hx.soff[(size_t)P]);
+  // overlap decision: the panel must have a clean interior (one contiguous run of interior columns with boundary
+  // columns only on its two sides) and -- unless forced -- the halo must be worth hiding.  Every rank decides for
+  // itself: the stream a rank enqueues its group on is invisible to its peers.
+  hx.overlapped = false;
+  if (probe) {
+    const int64_t jl = req[(size_t)4 * P], jlast = req[(size_t)4 * P + 1], ncount = req[(size_t)4 * P + 2];
+    const bool clean = jlast >= jl && ncount == jlast - jl + 1;
+    const bool worth = ov_opt >= 2 || (remote * 4 >= m.loc.nnz && ncount * 2 >= Bloc.cols);
+    if (clean && worth && (remote > 0 || ov_opt >= 3)) {  // (3: tests, also with nothing to receive)
+      hx.overlapped = true;
+      hx.jl = (int32_t)jl;
+      hx.jr = (int32_t)jlast + 1;
+      hx.off_l = req[(size_t)4 * P + 3];
+      hx.off_r = req[(size_t)4 * P + 4];
+    }
+  }
   const size_t w = m.loc.wval();
+  if (hx.overlapped) {  // the group goes to the communication stream, behind everything enqueued so far
+    HIP_CHECK(hipEventRecord(halo_event(0), stream()));
+    HIP_CHECK(hipStreamWaitEvent(ctx().comm_stream, halo_event(0), 0));
+    tr.set_stream(ctx().comm_stream);
+  }
   tr.group_begin();
   for (int q = 0; q < P; ++q) {  // sends
     const int64_t n = cnt[(size_t)me * P + q];
@@ -422,30 +465,39 @@ DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2
     tr.send(m.loc.val.p + first * (int64_t)w, (size_t)n * w * sizeof(double), q);
   }
   for (int s = 0; s < P; ++s) {  // receives
-    const int64_t n = cnt[(size_t)s * P + me];
+    const int64_t n = hx.cnt_from[(size_t)s];
     if (s == me || n == 0) continue;
-    tr.recv(stage.p + soff[(size_t)s], (size_t)(rb[(size_t)s] - ra[(size_t)s] + 1) * sizeof(int64_t), s);
-    tr.recv(full.inner.p + zoff[(size_t)s], (size_t)n * sizeof(int32_t), s);
-    tr.recv(full.val.p + zoff[(size_t)s] * (int64_t)w, (size_t)n * w * sizeof(double), s);
+    tr.recv(hx.stage.p + hx.soff[(size_t)s], (size_t)(hx.rb[(size_t)s] - hx.ra[(size_t)s] + 1) * sizeof(int64_t), s);
+    tr.recv(hx.full.inner.p + hx.zoff[(size_t)s], (size_t)n * sizeof(int32_t), s);
+    tr.recv(hx.full.val.p + hx.zoff[(size_t)s] * (int64_t)w, (size_t)n * w * sizeof(double), s);
   }
   tr.group_end();
-  {  // own segment
-    const int64_t n = cnt[(size_t)me * P + me];
+  if (hx.overlapped) {
+    tr.set_stream(nullptr);
+    HIP_CHECK(hipEventRecord(halo_event(1), ctx().comm_stream));
+  }
+  {  // own segment (engine stream; disjoint from the receive targets)
+    const int64_t n = hx.cnt_from[(size_t)me];
     if (n > 0) {
       const int64_t first = bound[(size_t)2 * me];
-      HIP_CHECK(hipMemcpyAsync(stage.p + soff[(size_t)me], m.loc.outer.p + (sa[me] - m.c0),
+      HIP_CHECK(hipMemcpyAsync(hx.stage.p + hx.soff[(size_t)me], m.loc.outer.p + (sa[me] - m.c0),
                                sizeof(int64_t) * (size_t)(sb[me] - sa[me] + 1), hipMemcpyDeviceToDevice, stream()));
-      HIP_CHECK(hipMemcpyAsync(full.inner.p + zoff[(size_t)me], m.loc.inner.p + first, sizeof(int32_t) * (size_t)n,
+      HIP_CHECK(hipMemcpyAsync(hx.full.inner.p + hx.zoff[(size_t)me], m.loc.inner.p + first, sizeof(int32_t) * (size_t)n,
                                hipMemcpyDeviceToDevice, stream()));
-      HIP_CHECK(hipMemcpyAsync(full.val.p + zoff[(size_t)me] * (int64_t)w, m.loc.val.p + first * (int64_t)w,
+      HIP_CHECK(hipMemcpyAsync(hx.full.val.p + hx.zoff[(size_t)me] * (int64_t)w, m.loc.val.p + first * (int64_t)w,
                                sizeof(double) * (size_t)n * w, hipMemcpyDeviceToDevice, stream()));
     }
   }
-  // 4. column offsets: 0 before the first needed column, re-based segments, `total` after the last
+}
+
+// 4. column offsets: 0 before the first needed column, re-based segments, `total` after the last
+void HaloExchange::finish() {
+  if (overlapped) HIP_CHECK(hipStreamWaitEvent(stream(), halo_event(1), 0));
+  const int64_t total = zoff[(size_t)P];
   int32_t pos = 0;
   for (int s = 0; s < P; ++s) {
     const int32_t a = ra[(size_t)s], b = rb[(size_t)s];
-    const int64_t n = cnt[(size_t)s * P + me];
+    const int64_t n = cnt_from[(size_t)s];
     if (b <= a) continue;
     if (a > pos) fill_i64(full.outer.p + pos, a - pos, zoff[(size_t)s]);
     if (n > 0) rebase_i64(stage.p + soff[(size_t)s], full.outer.p + a, b - a, zoff[(size_t)s]);
@@ -453,8 +505,15 @@ DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2
     pos = b;
   }
   fill_i64(full.outer.p + pos, (int64_t)dim + 1 - pos, total);
-  // `stage` is released on return: the allocator is stream ordered, later kernels run after the re-base kernels
-  return full;
+  // `stage` is released by the caller afterwards: the allocator is stream ordered, later kernels run after the
+  // re-base kernels above
+}
+
+DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2]) {
+  HaloExchange hx;
+  gather_needed_begin(hx, m, Bloc, nnz_global, false);
+  hx.finish();
+  return std::move(hx.full);
 }
 
 DevMat ps_gather_full(const PSMatrix& m) {

@@ -28,6 +28,8 @@ struct Transport {
   virtual void send(const void* p, size_t bytes, int peer) = 0;
   virtual void recv(void* p, size_t bytes, int peer) = 0;
   virtual void group_end() = 0;
+  // stream the following point-to-point group is enqueued on (RCCL); the shared-memory test transport is synchronous
+  virtual void set_stream(hipStream_t) {}
 };
 struct Comm {
   int rank = 0, nranks = 1;
@@ -94,6 +96,24 @@ DevMat ps_gather_full(const PSMatrix& m);  // every rank gets the whole matrix (
 // halo exchange for C = A*B: the columns of A named by the rows of the local B panel; also returns the global
 // nnz of A and B (collected in the same exchange)
 DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2]);
+// The same exchange in two steps, so that the caller can multiply the INTERIOR columns of its B panel (those that
+// name only local columns of A) while the halo travels on the communication stream: begin() does the two size
+// round trips and posts the send / recv group -- on comm_stream when `overlapped` comes back true --, finish() makes
+// the engine stream wait for it and builds the column offsets of `full`.
+struct HaloExchange {
+  DevMat full;                    // dim x dim, columns outside the needed range empty; valid after finish()
+  bool overlapped = false;
+  int32_t jl = 0, jr = 0;         // interior columns [jl, jr) of the local B panel (overlapped mode)
+  int64_t off_l = 0, off_r = 0;   // their entry offsets in the panel
+  // state between begin and finish
+  DevBuf<int64_t> stage;
+  std::vector<int32_t> ra, rb;
+  std::vector<int64_t> zoff, soff, cnt_from;
+  int32_t dim = 0;
+  int P = 1;
+  void finish();
+};
+void gather_needed_begin(HaloExchange& hx, const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2], bool may_overlap);
 void halo_segment(int32_t dim, int P, int s, int32_t kmin, int32_t kmax, int32_t* a, int32_t* b);
 // concatenate the column panels of all ranks (widths[r] = columns held by rank r, known to all)
 DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -1921,7 +1922,11 @@ void dispatch_type(bool cplx, F&& f) {
 
 // =====================================================================================
 EngineOptions& options() {
-  static EngineOptions* o = new EngineOptions();
+  static EngineOptions* o = [] {
+    auto* e = new EngineOptions();
+    if (const char* v = std::getenv("NTPOLY_AMD_HALO_OVERLAP")) e->halo_overlap = std::atoi(v);  // see kernels.hpp
+    return e;
+  }();
   return *o;
 }
 SpgemmStats& last_spgemm_stats() {
@@ -2880,6 +2885,41 @@ __global__ void k_halo_bounds(const int64_t* __restrict__ outer, int c0, const i
   cnt_row[q] = b - a;
 }
 }  // namespace
+
+namespace {
+__global__ void k_halo_interior(Csc B, int c0, int c1, long long* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  bool interior = false;
+  if (j < B.cols) {
+    const int64_t s = B.outer[j], e = B.outer[j + 1];
+    interior = (e <= s) || (B.inner[s] >= c0 && B.inner[e - 1] < c1);
+  }
+  const int lo = wave_min_i32(interior ? j : INT_MAX), hi = wave_max_i32(interior ? j : -1);
+  const unsigned long long m = __ballot(interior);
+  if (lane_id() == 0 && m) {
+    atomicMin(&out[0], (long long)lo);
+    atomicMax(&out[1], (long long)hi);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&out[2]), (unsigned long long)__popcll(m));
+  }
+}
+__global__ void k_halo_interior_offsets(const int64_t* __restrict__ outer, long long* __restrict__ out) {
+  if (out[1] >= out[0]) {
+    out[3] = outer[out[0]];
+    out[4] = outer[out[1] + 1];
+  } else {
+    out[3] = out[4] = 0;
+  }
+}
+}  // namespace
+
+void halo_interior_async(const DevMat& B, int32_t c0, int32_t c1, int64_t* d_out5) {
+  const long long init[5] = {INT_MAX, -1, 0, 0, 0};
+  HIP_CHECK(hipMemcpyAsync(d_out5, init, sizeof(init), hipMemcpyHostToDevice, stream()));
+  if (B.cols == 0) return;
+  hipLaunchKernelGGL(k_halo_interior, dim3(cdiv(B.cols, 256)), dim3(256), 0, stream(), view(B), c0, c1,
+                     reinterpret_cast<long long*>(d_out5));
+  hipLaunchKernelGGL(k_halo_interior_offsets, dim3(1), dim3(1), 0, stream(), B.outer.p, reinterpret_cast<long long*>(d_out5));
+}
 
 void halo_request_async(const DevMat& B, int64_t nnz_a, int64_t* d_out4) {
   const long long init[2] = {INT_MAX, -1};

@@ -25,6 +25,9 @@ struct EngineOptions {
   int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
                                // reference built with FP contraction computes); 0: separate multiply and add (default, bit-
                                // identical to the reference built without contraction)
+  int halo_overlap = 1;        // distributed multiply: 0 exchange then multiply, 1 overlap the exchange with the interior
+                               // columns when the halo is a sizeable part of the panel, 2 always split, 3 split even
+                               // with an empty halo (tests; also NTPOLY_AMD_HALO_OVERLAP in the environment)
   int spgemm_variant = -1;     // numeric kernel: -1 automatic (register-slab kernel for run-like real operands, else the
                                // column-pair kernel; complex operands: one column per wave); 0 one column per wave for
                                // everything (first generation); 3<MAXCH><NW> column-pair kernel with that geometry;
@@ -119,6 +122,9 @@ void fill_i64(int64_t* d_dst, int64_t count, int64_t v);
 void row_range(const DevMat& A, int32_t* lo, int32_t* hi);
 // device-side pieces of the halo-exchange plan (comm.cpp gather_needed): no host round trip of their own
 void halo_request_async(const DevMat& B, int64_t nnz_a, int64_t* d_out4);
+// interior columns of a B panel (empty, or every row in [c0, c1)): d_out5 = {first interior column, last interior
+// column, number of interior columns, entry offset of the first, entry offset one past the last}
+void halo_interior_async(const DevMat& B, int32_t c0, int32_t c1, int64_t* d_out5);
 void halo_bounds_async(const DevMat& A, int32_t c0, const int32_t* d_sa, const int32_t* d_sb, int P, int64_t* d_bound,
                        int64_t* d_cnt_row);
 

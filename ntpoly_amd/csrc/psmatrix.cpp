@@ -11,6 +11,24 @@
 
 namespace ntp {
 
+namespace {
+// non-owning window on the arrays of another DevMat: a column range of it, or the same entries under another
+// column-offset array.  The kernels only ever index inner / val through the (absolute) offsets in `outer`.
+struct MatView {
+  DevMat m;
+  void alias(const DevMat& src, int64_t* outer, int32_t cols, int64_t nnz) {
+    m.rows = src.rows;
+    m.cols = cols;
+    m.cplx = src.cplx;
+    m.nnz = nnz;
+    m.outer.p = outer;
+    m.inner.p = src.inner.p;
+    m.val.p = src.val.p;
+  }
+  ~MatView() { m.outer.p = nullptr; m.inner.p = nullptr; m.val.p = nullptr; }
+};
+}  // namespace
+
 // ------------------------------------------------------------------ process grid
 namespace {
 ProcessGrid g_grid;
@@ -321,9 +339,49 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   if (world().active()) {
     // only the columns of A named by the rows of the local B panel travel (halo for banded operands); the same
     // exchange returns the global nnz for the dense-branch rule
-    DevMat Aneed = gather_needed(A, B.loc, nz);
+    HaloExchange hx;
+    gather_needed_begin(hx, A, B.loc, nz, true);
     const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
-    spgemm(Aneed, B.loc, AB, alpha, threshold, dense_rule);
+    if (!hx.overlapped) {
+      hx.finish();
+      spgemm(hx.full, B.loc, AB, alpha, threshold, dense_rule);
+    } else {
+      // the halo is travelling on the communication stream: multiply the interior columns of the B panel (they
+      // name local columns of A only) meanwhile, then the boundary columns against the gathered operand.  A
+      // column's arithmetic does not depend on which call computes it, so the result is bit-identical.
+      const int32_t width = B.c1 - B.c0;
+      DevMat Cint, Cleft, Cright;
+      {
+        MatView Apad, Bint;
+        DevBuf<int64_t> pad_outer((size_t)A.dim + 1);
+        fill_i64(pad_outer.p, A.c0, 0);
+        copy_shift_i64(A.loc.outer.p, pad_outer.p + A.c0, (int64_t)(A.c1 - A.c0) + 1, 0);
+        fill_i64(pad_outer.p + A.c1 + 1, (int64_t)A.dim - A.c1, A.loc.nnz);
+        Apad.alias(A.loc, pad_outer.p, A.dim, A.loc.nnz);
+        Bint.alias(B.loc, B.loc.outer.p + hx.jl, hx.jr - hx.jl, hx.off_r - hx.off_l);
+        spgemm(Apad.m, Bint.m, Cint, alpha, threshold, dense_rule);
+      }
+      hx.finish();
+      if (hx.jl > 0) {
+        MatView Bl;
+        Bl.alias(B.loc, B.loc.outer.p, hx.jl, hx.off_l);
+        spgemm(hx.full, Bl.m, Cleft, alpha, threshold, dense_rule);
+      } else {
+        Cleft.reset_empty(A.dim, 0, A.cplx);
+      }
+      if (hx.jr < width) {
+        MatView Br;
+        Br.alias(B.loc, B.loc.outer.p + hx.jr, width - hx.jr, B.loc.nnz - hx.off_r);
+        spgemm(hx.full, Br.m, Cright, alpha, threshold, dense_rule);
+      } else {
+        Cright.reset_empty(A.dim, 0, A.cplx);
+      }
+      std::vector<const DevMat*> parts;
+      if (Cleft.cols) parts.push_back(&Cleft);
+      parts.push_back(&Cint);
+      if (Cright.cols) parts.push_back(&Cright);
+      AB = parts.size() == 1 ? std::move(Cint) : concat_columns(parts);
+    }
   } else {
     const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
     spgemm(A.loc, B.loc, AB, alpha, threshold, dense_rule);

@@ -123,6 +123,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "spgemm_fma") options().spgemm_fma = *value;
   else if (n == "time_kernels") options().time_kernels = *value;
   else if (n == "spgemm_variant") options().spgemm_variant = *value;
+  else if (n == "halo_overlap") options().halo_overlap = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used

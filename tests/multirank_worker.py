@@ -48,6 +48,20 @@ def main():
     AT = nt.Matrix_ps(n)
     AT.Transpose(C)
     keep("ABT", AT)
+    # the same product with the halo exchange overlapped: interior columns multiplied while the halo travels on the
+    # communication stream, boundary columns afterwards (forced; by default only when the halo is large)
+    nt.set_option("halo_overlap", 2)
+    C2 = nt.Matrix_ps(n)
+    C2.Gemm(A, B, None, 0.5, 0.0, 1e-7)
+    keep("AB_ov", C2)
+    C3 = nt.Matrix_ps(n)
+    C3.Gemm(A, A, None, 1.0, 0.0, 0.0)
+    nt.set_option("halo_overlap", 0)
+    C4 = nt.Matrix_ps(n)
+    C4.Gemm(A, A, None, 1.0, 0.0, 0.0)
+    nt.set_option("halo_overlap", 1)
+    keep("AA_ov", C3)
+    keep("AA", C4)
 
     # ---- TRS2 on the banded Hamiltonian (ISQ = I): energies per iteration, chemical potential, density
     Ident = nt.Matrix_ps(n)

@@ -65,6 +65,11 @@ def test_multirank_equals_single_rank(world, reference, tmp_path):
             assert np.allclose(got[2], want[2], rtol=0, atol=1e-10)
         else:
             assert all(np.array_equal(g, w) for g, w in zip(got, want)), tag
+    # overlapped halo exchange (interior / boundary split): bit-identical to the plain product and to one rank
+    for tag, base in (("AB_ov", "AB"), ("AA_ov", "AA")):
+        got = cat(parts, tag)
+        assert all(np.array_equal(g, w) for g, w in zip(got, cat(parts, base))), tag
+        assert all(np.array_equal(g, reference[base + s]) for g, s in zip(got, ("_col", "_row", "_val"))), tag
     # gather-based families: every rank computes from the same gathered matrix -> identical panels
     for tag in ("eigW", "eigV", "disq", "chol", "pchol", "foe", "snap"):
         got = cat(parts, tag)

@@ -21,3 +21,15 @@ def test_forced_rccl_paths_match_golden():
                         "-m", "gpu", "-k", sel], env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+def test_forced_rccl_overlapped_halo_matches_golden():
+    """the same with every distributed multiply split into interior / boundary columns and its send / recv group
+    enqueued on the communication stream (NTPOLY_AMD_HALO_OVERLAP=3): event ordering between the two streams and the
+    RCCL group on a second stream run for real, results still bit-identical to the reference's."""
+    env = dict(os.environ, NTPOLY_AMD_FORCE_RCCL="1", NTPOLY_AMD_HALO_OVERLAP="3")
+    sel = "test_ps_gemm_golden and -1--1 or test_solvers_golden or test_premade_fixture"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q",
+                        "-m", "gpu", "-k", sel], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
