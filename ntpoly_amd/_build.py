@@ -68,6 +68,7 @@ def build(force=False, verbose=False):
 
 FLANG = os.environ.get("FLANG", "/opt/rocm/lib/llvm/bin/flang")
 FORTRAN_SRC = os.path.join(os.path.dirname(HERE), "fortran", "ntpoly_amd_modules.f90")
+FORTRAN_SRC2 = os.path.join(os.path.dirname(HERE), "fortran", "ntpoly_amd_modules_more.f90")  # tools/gen_fortran_more.py
 FORTRAN_LIB = os.path.join(HERE, "libntpoly_amd_fortran.a")
 FORTRAN_MOD = os.path.join(HERE, "fortran_mod")
 
@@ -78,19 +79,23 @@ def build_fortran(force=False):
     compiles with `-I ntpoly_amd/fortran_mod` and links `libntpoly_amd_fortran.a -lntpoly_amd`."""
     if not os.path.exists(FLANG):
         return None
-    if not force and os.path.exists(FORTRAN_LIB) and os.path.getmtime(FORTRAN_LIB) > os.path.getmtime(FORTRAN_SRC):
+    srcs = [FORTRAN_SRC, FORTRAN_SRC2]
+    if not force and os.path.exists(FORTRAN_LIB) and os.path.getmtime(FORTRAN_LIB) > max(map(os.path.getmtime, srcs)):
         return FORTRAN_LIB
     os.makedirs(FORTRAN_MOD, exist_ok=True)
-    obj = os.path.join(HERE, "build", "ntpoly_amd_modules.o")
-    os.makedirs(os.path.dirname(obj), exist_ok=True)
-    r = subprocess.run([FLANG, "-O2", "-fPIC", "-c", FORTRAN_SRC, "-o", obj, "-J", FORTRAN_MOD], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout)
-        raise RuntimeError("flang failed")
+    objs = []
+    for src in srcs:   # in order: part 2 uses the modules of part 1
+        obj = os.path.join(HERE, "build", os.path.basename(src)[:-4] + ".o")
+        os.makedirs(os.path.dirname(obj), exist_ok=True)
+        r = subprocess.run([FLANG, "-O2", "-fPIC", "-c", src, "-o", obj, "-J", FORTRAN_MOD, "-I", FORTRAN_MOD],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout)
+            raise RuntimeError("flang failed")
+        objs.append(obj)
     if os.path.exists(FORTRAN_LIB):
         os.unlink(FORTRAN_LIB)
-    subprocess.run(["ar", "rcs", FORTRAN_LIB, obj], check=True)
+    subprocess.run(["ar", "rcs", FORTRAN_LIB] + objs, check=True)
     return FORTRAN_LIB
 
 
