@@ -977,6 +977,8 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     asm volatile(SLAB_LOOP_ASM_ABL2 SLAB_LOOP_OPERANDS);  // no multiplier loads
   } else if constexpr (MODE == 4) {
     asm volatile(SLAB_LOOP_ASM_ABL3 SLAB_LOOP_OPERANDS);  // no arithmetic
+  } else if constexpr (MODE == 7) {
+    asm volatile(SLAB_LOOP_ASM_LEAN SLAB_LOOP_OPERANDS);  // whole periods without pointer arithmetic / exit tests, then the plain loop
   } else if constexpr (MODE == 6) {
     asm volatile(SLAB_LOOP_ASM_PF SLAB_LOOP_OPERANDS);  // unfused, with the rotating scalar-cache prefetch of the fused loop
   } else {
@@ -2249,9 +2251,11 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                        reinterpret_cast<double2*>(tmp_val.p), count.p, alpha, threshold, dr, n, snb);
     for (int i = 0; i < 7; ++i) hstats[i] = 0;
   } else if (use_slab) {
+    // occupancy experiments (408 / 409): unused dynamic LDS limits the workgroups per CU to 2 / 3 instead of 4
+    const size_t occ_lds = sv_opt == 408 ? 60 * 1024 : sv_opt == 409 ? 50 * 1024 : 0;
     auto launch_slab = [&](auto fma_tag) {
       hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, SLAB_NW, decltype(fma_tag)::value>), dim3(xcd_grid(snb)),
-                         dim3(SLAB_NW * WAVE), 0, stream(), reinterpret_cast<const SlabRun*>(runs.p), bblk.p, blk_boff.p,
+                         dim3(SLAB_NW * WAVE), occ_lds, stream(), reinterpret_cast<const SlabRun*>(runs.p), bblk.p, blk_boff.p,
                          blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha,
                          threshold, dr, n, snb);
     };
@@ -2261,6 +2265,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     else if (abl == 3) launch_slab(std::integral_constant<int, 4>{});
     else if (abl == 4) launch_slab(std::integral_constant<int, 5>{});
     else if (abl == 5) launch_slab(std::integral_constant<int, 6>{});
+    else if (abl == 6) launch_slab(std::integral_constant<int, 7>{});
     else if (options().spgemm_fma) launch_slab(std::integral_constant<int, 1>{});
     else launch_slab(std::integral_constant<int, 0>{});
     for (int i = 0; i < 7; ++i) hstats[i] = 0;

@@ -84,7 +84,40 @@ def compute(aset, bset, lines, label, fused, ablate=0):
         lines.append("%s:" % skip)
 
 
-def build(fused, ablate=0, pf=0):
+def step(L, label, t, fused, ablate, pf, lean):
+    """one k step at position t of the period.  lean: the pointers stay at the period start (immediate offsets carry
+    the step) and there is no exit test -- the caller guarantees a whole period"""
+    L.append("s_waitcnt lgkmcnt(0)")
+    issue((t + 2) % NA, L, ablate)
+    if lean:
+        boff, roff = 0x80 * (t + 1), 0x20 * (t + 3)
+    else:
+        # pointers advance once per step: s[16:17] -> multipliers of step t+1, s[14:15] -> record of step t+1
+        L.append("s_add_u32 s16, s16, 0x80")
+        L.append("s_addc_u32 s17, s17, 0")
+        L.append("s_add_u32 s14, s14, 0x20")
+        L.append("s_addc_u32 s15, s15, 0")
+        boff, roff = 0, 0x40
+    load_b((t + 1) % NB, boff, L, ablate)
+    L.append("s_load_dwordx8 s[24:31], s[14:15], 0x%x" % roff)   # record of step t+3
+    if pf:
+        # scalar-cache prefetch of the multiplier row PF steps further on, issued by ONE wave of the block per
+        # step (the wave whose index equals step mod 4): s_waitcnt lgkmcnt(0) makes the issuing wave sit out the
+        # full miss latency at its next step, so the four waves take turns and each stalls once in four steps
+        # while the other three find their rows in the cache.  s31 is the unused pad word of the record.
+        skip = "%d" % label[0]
+        label[0] += 1
+        L.append("s_and_b32 s19, s18, 3")
+        L.append("s_cmp_lg_u32 s19, %[wv]")
+        L.append("s_cbranch_scc1 %sf" % skip)
+        L.append("s_load_dword s31, s[16:17], 0x%x" % (pf * 0x80))
+        L.append("s_load_dword s31, s[16:17], 0x%x" % (pf * 0x80 + 0x40))
+        L.append("%s:" % skip)
+    L.append("s_waitcnt vmcnt(%d)" % (2 * SL))
+    compute(t % NA, t % NB, L, label, fused, ablate)
+
+
+def build(fused, ablate=0, pf=0, lean=False):
     L = []
     label = [10]
     for i in range(SL * J):
@@ -101,33 +134,27 @@ def build(fused, ablate=0, pf=0):
     load_b(0, 0, L, ablate)
     L.append("s_load_dwordx8 s[24:31], s[14:15], 0x40")
     L.append("s_mov_b32 s18, 0")
-    L.append("1:")
     period = NA * NB
-    for t in range(period):
-        L.append("s_waitcnt lgkmcnt(0)")
-        issue((t + 2) % NA, L, ablate)
-        # pointers advance once per step: s[16:17] -> multipliers of step t+1, s[14:15] -> record of step t+1
-        L.append("s_add_u32 s16, s16, 0x80")
+    if lean:
+        # whole periods first: no pointer arithmetic and no exit test inside (7 scalar instructions less per step)
+        L.append("3:")
+        L.append("s_sub_i32 s19, %[kn], s18")
+        L.append("s_cmp_lt_i32 s19, %d" % period)
+        L.append("s_cbranch_scc1 4f")
+        for t in range(period):
+            step(L, label, t, fused, ablate, 0, True)
+        L.append("s_add_u32 s16, s16, 0x%x" % (0x80 * period))
         L.append("s_addc_u32 s17, s17, 0")
-        L.append("s_add_u32 s14, s14, 0x20")
+        L.append("s_add_u32 s14, s14, 0x%x" % (0x20 * period))
         L.append("s_addc_u32 s15, s15, 0")
-        load_b((t + 1) % NB, 0, L, ablate)
-        L.append("s_load_dwordx8 s[24:31], s[14:15], 0x40")   # record of step t+3
-        if pf:
-            # scalar-cache prefetch of the multiplier row PF steps further on, issued by ONE wave of the block per
-            # step (the wave whose index equals step mod 4): s_waitcnt lgkmcnt(0) makes the issuing wave sit out the
-            # full miss latency at its next step, so the four waves take turns and each stalls once in four steps
-            # while the other three find their rows in the cache.  s31 is the unused pad word of the record.
-            skip = "%d" % label[0]
-            label[0] += 1
-            L.append("s_and_b32 s19, s18, 3")
-            L.append("s_cmp_lg_u32 s19, %[wv]")
-            L.append("s_cbranch_scc1 %sf" % skip)
-            L.append("s_load_dword s31, s[16:17], 0x%x" % (pf * 0x80))
-            L.append("s_load_dword s31, s[16:17], 0x%x" % (pf * 0x80 + 0x40))
-            L.append("%s:" % skip)
-        L.append("s_waitcnt vmcnt(%d)" % (2 * SL))
-        compute(t % NA, t % NB, L, label, fused, ablate)
+        L.append("s_add_i32 s18, s18, %d" % period)
+        L.append("s_branch 3b")
+        L.append("4:")
+        L.append("s_cmp_ge_i32 s18, %[kn]")
+        L.append("s_cbranch_scc1 2f")
+    L.append("1:")
+    for t in range(period):
+        step(L, label, t, fused, ablate, pf, False)
         L.append("s_add_i32 s18, s18, 1")
         L.append("s_cmp_ge_i32 s18, %[kn]")
         if t + 1 < period:
@@ -238,10 +265,11 @@ def main():
     out.append("// (immediates: byte distance of slabs 1 and 2 from slab 0), wv (index of the wave in its workgroup, 0..3).")
     # the rotating prefetch pays off only when the loop is not ALU bound: measured 2.69 -> 2.30 ms with v_fma_f64,
     # 2.81 -> 2.85 ms with separate multiply and add (kept selectable as variant 405)
-    for name, fused, abl, pf in (("SLAB_LOOP_ASM", False, 0, 0), ("SLAB_LOOP_ASM_FMA", True, 0, PF),
-                                 ("SLAB_LOOP_ASM_ABL1", False, 1, 0), ("SLAB_LOOP_ASM_ABL2", False, 2, 0),
-                                 ("SLAB_LOOP_ASM_ABL3", False, 3, 0), ("SLAB_LOOP_ASM_PF", False, 0, PF)):
-        L = build(fused, abl, pf)
+    for name, fused, abl, pf, lean in (("SLAB_LOOP_ASM", False, 0, 0, False), ("SLAB_LOOP_ASM_FMA", True, 0, PF, False),
+                                       ("SLAB_LOOP_ASM_ABL1", False, 1, 0, False), ("SLAB_LOOP_ASM_ABL2", False, 2, 0, False),
+                                       ("SLAB_LOOP_ASM_ABL3", False, 3, 0, False), ("SLAB_LOOP_ASM_PF", False, 0, PF, False),
+                                       ("SLAB_LOOP_ASM_LEAN", False, 0, 0, True)):
+        L = build(fused, abl, pf, lean)
         out.append("#define %s \\" % name)
         for ln in L:
             out.append('  "%s\\n\\t" \\' % ln)
