@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of one kernel from the two PMC passes of tools/collect_profiles.sh:
+   python tools/pmc_traffic_json.py gpurun_out/<tag> k_spgemm_slab [out.json]
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE under-counts 64-byte reads by 2x (MI355X_MICROARCH.md, HBM
+section; calibrated on k_scale, which reads and writes the same number of bytes)."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"(k_[a-z0-9_]+|__amd_rocclr_\w+)", r["Kernel_Name"])
+        acc[m.group(1) if m else r["Kernel_Name"][:40]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    root, pat = sys.argv[1], sys.argv[2]
+    f = per_kernel(root + "/pmc_FETCH_SIZE/run_counter_collection.csv")
+    w = per_kernel(root + "/pmc_WRITE_SIZE/run_counter_collection.csv")
+    fk = [k for k in f if pat in k][0]
+    fetch, write = f[fk][1:] or f[fk], w[fk][1:] or w[fk]   # drop the first (cold) launch
+    fa, wa = sum(fetch) / len(fetch), sum(write) / len(write)
+    cal = None
+    if "k_scale" in f and "k_scale" in w:
+        cal = (sum(w["k_scale"]) / len(w["k_scale"])) / (sum(f["k_scale"]) / len(f["k_scale"]))
+    out = {"kernel": fk, "launches": len(fetch), "fetch_size_KB_avg": fa, "write_size_KB_avg": wa, "fetch_correction": 2.0,
+           "k_scale_write_over_fetch": cal, "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
+    s = json.dumps(out, indent=1)
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write(s + "\n")
+    print(s)
+
+
+if __name__ == "__main__":
+    main()
