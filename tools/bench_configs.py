@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE configs on one MI355X (documentation numbers for DESIGN.md section 7; the driver's
+bench.py measures configs[2]).  Prints one JSON object.
+
+  configs[1]  local A*A, banded N = 65 536, h = 50 (101 nnz/row), threshold 0 and 1e-8
+  configs[3]  the N = 1 048 576, h = 100 operand as ONE A*A on one GPU (the 8-GPU config's whole problem)
+  configs[4]  Hermitian complex N = 131 072, h = 50, H + 2I: SignFunction and InverseSquareRoot
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import ntpoly_amd as nt
+    from gen import banded_triplets
+    nt.init_comm()
+    nt.ConstructGlobalProcessGrid(1, 1, 1)
+    nt.set_option("time_kernels", 1)
+    out = {}
+
+    def product(n, h, thr, reps=5, complex_=False):
+        col, row, val = banded_triplets(n, h, complex_=complex_)
+        A = nt.Matrix_ps.from_triplets(n, col, row, val)
+        del col, row, val
+        C = nt.Matrix_ps(n)
+        C.Gemm(A, A, None, 1.0, 0.0, thr)   # warm-up (allocator, first-touch)
+        best = None
+        for _ in range(reps):
+            nt.synchronize()
+            t0 = time.perf_counter()
+            C.Gemm(A, A, None, 1.0, 0.0, thr)
+            nt.synchronize()
+            dt = time.perf_counter() - t0
+            st = nt.last_spgemm_stats()
+            if best is None or dt < best[0]:
+                best = (dt, st)
+        dt, st = best
+        per = 20 if complex_ else 12
+        alg = per * (st["nnz_a"] + st["nnz_b"] + st["nnz_c"]) + 4 * (3 * n + 3)
+        return dict(n=n, halfband=h, threshold=thr, wall_ms=1e3 * dt, kernel_ms=st["ms_numeric"], nnz_out=st["nnz_c"],
+                    products=st["products"], nnz_out_per_s=st["nnz_c"] / dt, products_per_s=st["products"] / (st["ms_numeric"] * 1e-3),
+                    alg_GBps_kernel=alg / (st["ms_numeric"] * 1e-3) / 1e9, slab=st["slab"])
+
+    out["config1_thr0"] = product(65536, 50, 0.0)
+    out["config1_thr1e-8"] = product(65536, 50, 1e-8)
+    out["config3_one_product_1gpu"] = product(1048576, 100, 1e-8, reps=3)
+
+    n, h, thr = 131072, 50, 1e-8
+    col, row, val = banded_triplets(n, h, complex_=True, shift=2.0)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    del col, row, val
+    p = nt.SolverParameters()
+    p.SetThreshold(thr)
+    p.SetConvergeDiff(1e-10)
+    for name, fn in (("sign", lambda o: nt.SignSolvers.ComputeSign(H, o, p)),
+                     ("inverse_square_root", lambda o: nt.SquareRootSolvers.InverseSquareRoot(H, o, p))):
+        O = nt.Matrix_ps(n)
+        fn(O)   # warm-up
+        nt.synchronize()
+        t0 = time.perf_counter()
+        fn(O)
+        nt.synchronize()
+        dt = time.perf_counter() - t0
+        tr = nt.solver_trace()
+        out["config4_" + name] = dict(n=n, halfband=h, threshold=thr, wall_s=dt, iterations=tr["iterations"],
+                                      s_per_iteration=dt / max(1, tr["iterations"]), nnz_result=O.GetSize())
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
