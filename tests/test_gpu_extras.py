@@ -602,3 +602,35 @@ def test_jacobi_eigensolver_vs_numpy(nt, n, cplx):
     assert np.abs(wd - ref).max() <= 1e-12 * scale
     assert np.abs(a @ vd - vd * wd).max() <= 1e-11 * scale
     assert np.abs(vd.conj().T @ vd - np.eye(n)).max() <= 1e-11
+
+
+def test_reference_data_fixtures(nt, tmp_path):
+    """The data files the reference's own tests hold (tests/golden/reference_data = its UnitTests/Data), checked the way
+    its tests check them: geometry extrapolation F1/S1/S2 -> D2 at its tolerance 1e-1 (test_chemistry.py:509-563,
+    load-balancing permutation on), the symmetric MatrixMarket file realio.mtx read and written back
+    (test_chemistry.py:490-507)."""
+    import scipy.io
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_data")
+    f1, o1, o2 = (nt.Matrix_ps(os.path.join(data, n + ".mtx")) for n in ("F1", "S1", "S2"))
+    d2 = scipy.io.mmread(os.path.join(data, "D2.mtx")).toarray()
+    n = f1.GetActualDimension()
+    p = nt.SolverParameters()
+    perm = nt.Permutation(f1.GetLogicalDimension())
+    perm.SetRandomPermutation()
+    p.SetLoadBalance(perm)
+    isq, d1 = nt.Matrix_ps(n), nt.Matrix_ps(n)
+    nt.SquareRootSolvers.InverseSquareRoot(o1, isq, p)
+    nt.DensityMatrixSolvers.TRS2(f1, isq, 5.0, d1, p)
+    for which in ("purification", "lowdin"):
+        ex = nt.Matrix_ps(n)
+        if which == "purification":
+            nt.GeometryOptimization.PurificationExtrapolate(d1, o2, 5.0, ex, p)
+        else:
+            nt.GeometryOptimization.LowdinExtrapolate(d1, o1, o2, ex, p)
+        assert np.linalg.norm(2.0 * ex.to_scipy().toarray() - d2) <= 1e-1, which
+    # symmetric MatrixMarket round trip
+    rio = nt.Matrix_ps(os.path.join(data, "realio.mtx"))
+    out = str(tmp_path / "realio_out.mtx")
+    rio.WriteToMatrixMarket(out)
+    want = scipy.io.mmread(os.path.join(data, "realio.mtx")).toarray()
+    assert np.abs(scipy.io.mmread(out).toarray() - want).max() <= 1e-14 * np.abs(want).max()
