@@ -394,6 +394,8 @@ void gather_needed_begin(HaloExchange& hx, const PSMatrix& m, const DevMat& Bloc
   auto kmin_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? 0 : (int32_t)lo; };
   auto kmax_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? -1 : (int32_t)hi; };
   const int32_t kmin = kmin_of(me), kmax = kmax_of(me);
+  hx.kmin = kmin;
+  hx.kmax = kmax;
   // 2. what I send to every requester: segment boundaries (host arithmetic), entry offsets and counts (device)
   std::vector<int32_t> sab((size_t)2 * P);
   for (int q = 0; q < P; ++q) halo_segment(dim, P, me, kmin_of(q), kmax_of(q), &sab[(size_t)q], &sab[(size_t)P + q]);

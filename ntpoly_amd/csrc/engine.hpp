@@ -103,6 +103,7 @@ DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2
 struct HaloExchange {
   DevMat full;                    // dim x dim, columns outside the needed range empty; valid after finish()
   bool overlapped = false;
+  int32_t kmin = 0, kmax = -1;    // columns of the distributed matrix present in `full` (the requested range)
   int32_t jl = 0, jr = 0;         // interior columns [jl, jr) of the local B panel (overlapped mode)
   int64_t off_l = 0, off_r = 0;   // their entry offsets in the panel
   // state between begin and finish

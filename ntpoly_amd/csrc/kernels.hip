@@ -2103,7 +2103,7 @@ void launch_window(int bin, const DevMat& A, const DevMat& B, const int32_t* lo,
 }  // namespace
 
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule,
-            LooseProduct* loose) {
+            LooseProduct* loose, const ColRange* arange) {
   if (loose) loose->valid = false;
   if (A.cols != B.rows) NTP_FATAL("spgemm: inner dimensions differ");
   if (A.cplx != B.cplx) NTP_FATAL("spgemm: mixed scalar types must be up-cast by the caller");
@@ -2119,8 +2119,18 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   const bool timing = options().time_kernels != 0;
   EventTimer t_all(timing), t_num(timing);
   t_all.start();
-  DevBuf<int32_t> cmin(A.cols), cmax(A.cols), clen(A.cols);
-  hipLaunchKernelGGL(k_col_extent, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), view(A), cmin.p, cmax.p, clen.p);
+  // columns of A that the rows of B can name: all of them, or the range the caller knows (a gathered operand is
+  // dim wide but populated only over the halo range: the per-column work arrays then cover that range only and are
+  // addressed with absolute column ids through pointers biased by -ka)
+  const int32_t ka = arange ? arange->a : 0, kb = arange ? arange->b : A.cols;
+  const int32_t nka = std::max(0, kb - ka);
+  DevBuf<int32_t> cmin_own((size_t)nka), cmax_own((size_t)nka), clen_own((size_t)nka);
+  struct Biased { int32_t* p; };
+  const Biased cmin{cmin_own.p - ka}, cmax{cmax_own.p - ka}, clen{clen_own.p - ka};
+  Csc Ar = view(A);
+  Ar.outer += ka;
+  Ar.cols = nka;
+  if (nka) hipLaunchKernelGGL(k_col_extent, dim3(cdiv(nka, 256)), dim3(256), 0, stream(), Ar, cmin_own.p, cmax_own.p, clen_own.p);
   DevBuf<int32_t> lo, span, count(n);
   DevBuf<uint8_t> bin;
   DevBuf<int64_t> ub, ip, tmpoff(n + 1);
@@ -2153,9 +2163,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(B), bfirst_own.p, blast_own.p, blen_own.p);
       bfirst = bfirst_own.p; blast = blast_own.p;
     }
-    aspan.alloc(A.cols); aeoff.alloc((size_t)A.cols + 1);
-    hipLaunchKernelGGL(k_span_of, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aspan.p, A.cols);
-    scan_async<int32_t>(aspan.p, aeoff.p, (int64_t)A.cols);
+    aspan.alloc((size_t)nka); aeoff.alloc((size_t)nka + 1);   // local ids 0 .. nka (column ka + id)
+    hipLaunchKernelGGL(k_span_of, dim3(cdiv(nka, 256)), dim3(256), 0, stream(), cmin_own.p, cmax_own.p, aspan.p, nka);
+    scan_async<int32_t>(aspan.p, aeoff.p, (int64_t)nka);
     blk_lo.alloc(snb); blk_w.alloc(snb); blk_kmin.alloc(snb); blk_kn.alloc(snb);
     bsz.alloc(snb); tsz.alloc(snb); blk_boff.alloc((size_t)snb + 1); blk_toff.alloc((size_t)snb + 1);
     if (A.cplx)
@@ -2164,11 +2174,11 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     else
       hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst,
                          blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
-    hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, aspan.p, A.cols, stats.p);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, aspan.p, nka, stats.p);
     scan_async<int64_t>(bsz.p, blk_boff.p, (int64_t)snb);
     scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
     ScalarFetch f;
-    f.add(aeoff.p + A.cols, 1, &slab_tot[0]);
+    f.add(aeoff.p + nka, 1, &slab_tot[0]);
     f.add(blk_boff.p + snb, 1, &slab_tot[1]);
     f.add(blk_toff.p + snb, 1, &slab_tot[2]);
     f.add(stats.p, 24, hstats);
@@ -2220,23 +2230,23 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     aexp.alloc(((size_t)slab_tot[0] + 1) * A.wval());
     bblk.alloc(((size_t)slab_tot[1] + 16 * SJ) * A.wval());  // slack: the loop prefetches a few rows past the last tile
     const bool same = (&A == &B);
-    runs.alloc(((size_t)A.cols + 4) * sizeof(SlabRun));
-    hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), cmin.p, cmax.p, aeoff.p,
-                       reinterpret_cast<const char*>(aexp.p), (int)esz, reinterpret_cast<SlabRun*>(runs.p), A.cols);
+    runs.alloc(((size_t)nka + 4) * sizeof(SlabRun));
+    hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(nka + 4, 256)), dim3(256), 0, stream(), cmin_own.p, cmax_own.p, aeoff.p,
+                       reinterpret_cast<const char*>(aexp.p), (int)esz, reinterpret_cast<SlabRun*>(runs.p), nka);
     const int pitch = ((int)hstats[17] + 1) | 1;
     const int32_t* clen_opt = timing ? clen.p : (const int32_t*)nullptr;  // product count: statistics only
     if (A.cplx) {
       double2* ae = reinterpret_cast<double2*>(aexp.p);
       if (!same)
-        hipLaunchKernelGGL(k_slab_expand_a<double2>, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(),
-                           view(A), cmin.p, aeoff.p, ae);
+        hipLaunchKernelGGL(k_slab_expand_a<double2>, dim3(cdiv((int64_t)nka * WAVE, 256)), dim3(256), 0, stream(),
+                           Ar, cmin_own.p, aeoff.p, ae);
       hipLaunchKernelGGL((k_slab_expand_b<double2, SLAB_CJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * esz,
                          stream(), view(B), blk_kmin.p, blk_kn.p, blk_boff.p, reinterpret_cast<double2*>(bblk.p), snb, pitch,
                          same ? 1 : 0, aeoff.p, ae, clen_opt, blk_prod.p);
     } else {
       if (!same)
-        hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(),
-                           view(A), cmin.p, aeoff.p, aexp.p);
+        hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)nka * WAVE, 256)), dim3(256), 0, stream(),
+                           Ar, cmin_own.p, aeoff.p, aexp.p);
       hipLaunchKernelGGL((k_slab_expand_b<double, SLAB_J>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * esz,
                          stream(), view(B), blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p,
                          aexp.p, clen_opt, blk_prod.p);
@@ -2246,7 +2256,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   t_num.start();
   if (use_slab && A.cplx) {
     hipLaunchKernelGGL((k_spgemm_slab_c<SLAB_CNW>), dim3(xcd_grid(snb)), dim3(SLAB_CNW * WAVE), 0, stream(),
-                       reinterpret_cast<const SlabRun*>(runs.p), reinterpret_cast<const double2*>(bblk.p), blk_boff.p,
+                       reinterpret_cast<const SlabRun*>(runs.p) - ka, reinterpret_cast<const double2*>(bblk.p), blk_boff.p,
                        blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p,
                        reinterpret_cast<double2*>(tmp_val.p), count.p, alpha, threshold, dr, n, snb);
     for (int i = 0; i < 7; ++i) hstats[i] = 0;
@@ -2255,7 +2265,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     const size_t occ_lds = sv_opt == 408 ? 60 * 1024 : sv_opt == 409 ? 50 * 1024 : 0;
     auto launch_slab = [&](auto fma_tag) {
       hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, SLAB_NW, decltype(fma_tag)::value>), dim3(xcd_grid(snb)),
-                         dim3(SLAB_NW * WAVE), occ_lds, stream(), reinterpret_cast<const SlabRun*>(runs.p), bblk.p, blk_boff.p,
+                         dim3(SLAB_NW * WAVE), occ_lds, stream(), reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p,
                          blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha,
                          threshold, dr, n, snb);
     };
@@ -2278,7 +2288,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     if constexpr (!Sc<T>::cplx) {
       // real operands that are not run-like: column-pair kernel, register-set depth from the mean column length of A
       if (variant < 0 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {
-        const double avg = (double)A.nnz / (double)std::max(1, A.cols);
+        const double avg = (double)A.nnz / (double)std::max(1, nka);
         const int need = (int)std::ceil(avg / 64.0);
         variant = 300 + 10 * std::min(6, std::max(2, need)) + 1;
       }

@@ -60,8 +60,11 @@ struct LooseProduct {
 // dense_rule = the reference's dense-branch order (threshold before alpha, DenseBranch.f90:14-15).
 // loose != nullptr: if the register-slab kernel computes the product, leave it uncompacted in *loose (loose->valid,
 // C untouched); otherwise C is produced as usual and loose->valid stays false.
+// arange: the columns [a, b) of A that the rows of B can name, when the caller knows them (gathered operands are
+// dim wide but populated over the halo range only): the per-column planning work then covers that range only
+struct ColRange { int32_t a, b; };
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold,
-            bool dense_rule, LooseProduct* loose = nullptr);
+            bool dense_rule, LooseProduct* loose = nullptr, const ColRange* arange = nullptr);
 
 // B <- alpha*A + B (AddSparseVectors semantics), same shape and scalar type.
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold);

@@ -342,9 +342,10 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     HaloExchange hx;
     gather_needed_begin(hx, A, B.loc, nz, true);
     const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
+    const ColRange need{hx.kmin, hx.kmax + 1};   // the rows of the B panel name these columns only
     if (!hx.overlapped) {
       hx.finish();
-      spgemm(hx.full, B.loc, AB, alpha, threshold, dense_rule);
+      spgemm(hx.full, B.loc, AB, alpha, threshold, dense_rule, nullptr, &need);
     } else {
       // the halo is travelling on the communication stream: multiply the interior columns of the B panel (they
       // name local columns of A only) meanwhile, then the boundary columns against the gathered operand.  A
@@ -365,14 +366,14 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
       if (hx.jl > 0) {
         MatView Bl;
         Bl.alias(B.loc, B.loc.outer.p, hx.jl, hx.off_l);
-        spgemm(hx.full, Bl.m, Cleft, alpha, threshold, dense_rule);
+        spgemm(hx.full, Bl.m, Cleft, alpha, threshold, dense_rule, nullptr, &need);
       } else {
         Cleft.reset_empty(A.dim, 0, A.cplx);
       }
       if (hx.jr < width) {
         MatView Br;
         Br.alias(B.loc, B.loc.outer.p + hx.jr, width - hx.jr, B.loc.nnz - hx.off_r);
-        spgemm(hx.full, Br.m, Cright, alpha, threshold, dense_rule);
+        spgemm(hx.full, Br.m, Cright, alpha, threshold, dense_rule, nullptr, &need);
       } else {
         Cright.reset_empty(A.dim, 0, A.cplx);
       }
@@ -453,9 +454,12 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
   LooseProduct L;
   DevMat AB;
   if (world().active()) {
-    DevMat Aneed = gather_needed(B, B.loc, nz);
+    HaloExchange hx;
+    gather_needed_begin(hx, B, B.loc, nz, false);
+    hx.finish();
     const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
-    spgemm(Aneed, B.loc, AB, 1.0, threshold, dense_rule, &L);
+    const ColRange need{hx.kmin, hx.kmax + 1};
+    spgemm(hx.full, B.loc, AB, 1.0, threshold, dense_rule, &L, &need);
   } else {
     const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
     spgemm(B.loc, B.loc, AB, 1.0, threshold, dense_rule, &L);
