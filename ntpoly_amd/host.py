@@ -82,7 +82,13 @@ def init_comm_from_env(timeout=300.0):
     if world <= 1:
         init_comm()
         return 0, 1
-    path = "/tmp/ntpoly_amd_rdv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    if os.environ.get("NTPOLY_AMD_COMM", "").startswith("shm:"):
+        # shared-memory test transport: the segment name is in the environment, there is no id to hand over
+        init_comm(get_unique_id(), rank, world)
+        barrier()
+        return rank, world
+    # NTPOLY_AMD_RDV names the file explicitly (launchers whose ranks are not children of one process)
+    path = os.environ.get("NTPOLY_AMD_RDV") or "/tmp/ntpoly_amd_rdv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
     if rank == 0:
         uid = get_unique_id()
         with open(path + ".tmp", "wb") as f:
