@@ -336,9 +336,8 @@ constexpr int SLAB_J = 16, SLAB_SL = 3, SLAB_NW = 4;
 constexpr int SLAB_CJ = 8, SLAB_CSL = 2, SLAB_CNW = 6;  // complex operands
 
 // bins: 0 empty | 1..4 LDS direct window of 512/1024/2048/4096 rows | 5 LDS hash | 6 HBM accumulator
-constexpr int BIN_EMPTY = 0, BIN_HASH = 5, BIN_HBM = 6;
-constexpr int HASH_SLOTS = 4096;      // per wave
-constexpr int HASH_MAX_FILL = 3072;   // leave the LDS hash for the HBM accumulator beyond this
+constexpr int BIN_EMPTY = 0, BIN_HASH = 5, BIN_HBM = 6, BIN_HASH_BIG = 7;  // 7: overflowed the small table
+constexpr int HASH_MAX_FILL = 3072;   // distinct rows per column the LDS hash takes (3/4 of its large table); beyond: HBM accumulator
 
 __host__ __device__ inline int window_bin(int span) {
   return span <= 512 ? 1 : span <= 1024 ? 2 : span <= 2048 ? 3 : span <= 4096 ? 4 : BIN_HASH;
@@ -1122,20 +1121,27 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 5))
 // LDS compare-and-swap, value update non-atomic (one lane per row inside a step).  Survivors are
 // packed as (row << 13 | slot), bitonic-sorted in LDS and written in row order.  A column that
 // fills more than HASH_MAX_FILL buckets is handed to the HBM accumulator kernel (bin 6).
-template <typename T>
+template <typename T, int SLOTS>
 __global__ __launch_bounds__(WAVE) void k_spgemm_hash(
     Csc A, Csc B, const int32_t* __restrict__ span_arr, uint8_t* __restrict__ bin_arr,
     const int64_t* __restrict__ tmpoff, int32_t* __restrict__ out_inner, T* __restrict__ out_val,
     int32_t* __restrict__ count, unsigned long long* __restrict__ stats, double alpha,
     double threshold, int dense_rule, int nblocks) {
-  __shared__ int keys[HASH_SLOTS];
-  __shared__ T vals[HASH_SLOTS];
-  __shared__ unsigned long long sortbuf[HASH_SLOTS];
+  // One wave per output column, k ascending (the accumulation order of the reference).  The table is sized for
+  // occupancy, not for the worst case: SLOTS = 1024 (12 KB for real values: a dozen waves per CU) takes every column
+  // first, a column that fills more than 3/4 of it is handed to the 4096-slot pass, and from there to the HBM
+  // accumulator.  Keys and values are compacted and sorted in place (bitonic on pairs), so the table is all the
+  // LDS a wave needs.
+  constexpr int MAX_FILL = SLOTS * 3 / 4;
+  constexpr int SHIFT = SLOTS == 1024 ? 22 : 20;
+  static_assert(SLOTS == 1024 || SLOTS == 4096, "table classes");
+  __shared__ int keys[SLOTS];
+  __shared__ T vals[SLOTS];
   const int j = xcd_block(nblocks);
   if (j < 0 || j >= B.cols) return;
-  if (bin_arr[j] != BIN_HASH) return;
+  if (bin_arr[j] != (SLOTS == 1024 ? BIN_HASH : BIN_HASH_BIG)) return;
   const int lane = lane_id();
-  for (int s = lane; s < HASH_SLOTS; s += WAVE) {
+  for (int s = lane; s < SLOTS; s += WAVE) {
     keys[s] = -1;
     vals[s] = Sc<T>::zero();
   }
@@ -1145,70 +1151,90 @@ __global__ __launch_bounds__(WAVE) void k_spgemm_hash(
   const T* __restrict__ Bv = static_cast<const T*>(B.val);
   int filled = 0;
   bool overflow = false;
-  for (int64_t p = B.outer[j]; p < B.outer[j + 1] && !overflow; ++p) {
-    const int k = B.inner[p];
-    const T bk = Bv[p];
-    const int64_t as = A.outer[k];
-    const int len = (int)(A.outer[k + 1] - as);
-    for (int q0 = 0; q0 < len; q0 += WAVE) {
-      const int q = q0 + lane;
-      const bool act = q < len;
-      int i = 0;
-      T a = Sc<T>::zero();
-      if (act) {
-        i = Ai[as + q];
-        a = Av[as + q];
-      }
-      bool fresh = false;
-      int h = 0;
-      if (act) {
-        h = (int)(((unsigned)i * 2654435761u) >> 20) & (HASH_SLOTS - 1);
-        for (;;) {
-          const int old = atomicCAS(&keys[h], -1, i);
-          if (old == -1) { fresh = true; break; }
-          if (old == i) break;
-          h = (h + 1) & (HASH_SLOTS - 1);
+  const int64_t bs = B.outer[j], be = B.outer[j + 1];
+  for (int64_t p0 = bs; p0 < be && !overflow; p0 += WAVE) {
+    // 64 entries of the B column at once: row id, value and the extent of the A column it names
+    const bool have = p0 + lane < be;
+    const int kk = have ? B.inner[p0 + lane] : 0;
+    const T bvv = have ? Bv[p0 + lane] : Sc<T>::zero();
+    const int64_t a0 = have ? A.outer[kk] : 0;
+    const int alen = have ? (int)(A.outer[kk + 1] - a0) : 0;
+    const int m = (int)min((int64_t)WAVE, be - p0);
+    for (int t = 0; t < m && !overflow; ++t) {
+      const int64_t as = readlane_i64(a0, t);
+      const int len = readlane_i32(alen, t);
+      const T bk = readlane_T(bvv, t);
+      for (int q0 = 0; q0 < len; q0 += WAVE) {
+        const int q = q0 + lane;
+        const bool act = q < len;
+        bool fresh = false;
+        if (act) {
+          const int i = Ai[as + q];
+          const T a = Av[as + q];
+          int h = (int)(((unsigned)i * 2654435761u) >> SHIFT) & (SLOTS - 1);
+          for (;;) {
+            const int old = atomicCAS(&keys[h], -1, i);
+            if (old == -1) { fresh = true; break; }
+            if (old == i) break;
+            h = (h + 1) & (SLOTS - 1);
+          }
+          vals[h] = Sc<T>::add(vals[h], Sc<T>::mul(a, bk));
         }
-        vals[h] = Sc<T>::add(vals[h], Sc<T>::mul(a, bk));
+        filled += __popcll(__ballot(fresh));
+        __builtin_amdgcn_wave_barrier();
+        if (filled > MAX_FILL) { overflow = true; break; }
       }
-      filled += __popcll(__ballot(fresh));
-      __builtin_amdgcn_wave_barrier();
-      if (filled > HASH_MAX_FILL) { overflow = true; break; }
     }
   }
   if (overflow) {
     if (lane == 0) {
-      bin_arr[j] = BIN_HBM;
+      if (SLOTS == 1024) {
+        bin_arr[j] = BIN_HASH_BIG;
+        atomicAdd(&stats[19], 1ull);
+      } else {
+        bin_arr[j] = BIN_HBM;
+        atomicAdd(&stats[8], 1ull);
+      }
       count[j] = 0;
-      atomicAdd(&stats[8], 1ull);
     }
     return;
   }
   __syncthreads();
-  // pack the occupied buckets
+  // occupied buckets to the front, in place (a chunk is read into registers before anything of it is overwritten,
+  // and the write position never passes the read position)
   int n = 0;
-  for (int s0 = 0; s0 < HASH_SLOTS; s0 += WAVE) {
+  for (int s0 = 0; s0 < SLOTS; s0 += WAVE) {
     const int s = s0 + lane;
     const int key = keys[s];
+    const T v = vals[s];
     const bool occ = key >= 0;
-    const unsigned long long m = __ballot(occ);
-    if (occ) sortbuf[n + __popcll(m & lanemask_lt())] = ((unsigned long long)(unsigned)key << 13) | (unsigned)s;
-    n += __popcll(m);
+    const unsigned long long mk = __ballot(occ);
+    __syncthreads();
+    if (occ) {
+      const int d = n + __popcll(mk & lanemask_lt());
+      keys[d] = key;
+      vals[d] = v;
+    }
+    n += __popcll(mk);
+    __syncthreads();
   }
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
-  for (int s = n + lane; s < n2; s += WAVE) sortbuf[s] = ~0ull;
+  for (int s = n + lane; s < n2; s += WAVE) keys[s] = INT_MAX;
   __syncthreads();
-  for (int kk = 2; kk <= n2; kk <<= 1) {
-    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+  for (int kk2 = 2; kk2 <= n2; kk2 <<= 1) {
+    for (int jj = kk2 >> 1; jj > 0; jj >>= 1) {
       for (int t = lane; t < n2; t += WAVE) {
         const int ixj = t ^ jj;
         if (ixj > t) {
-          const unsigned long long x = sortbuf[t], y = sortbuf[ixj];
-          const bool up = (t & kk) == 0;
+          const int x = keys[t], y = keys[ixj];
+          const bool up = (t & kk2) == 0;
           if ((x > y) == up) {
-            sortbuf[t] = y;
-            sortbuf[ixj] = x;
+            keys[t] = y;
+            keys[ixj] = x;
+            const T vx = vals[t];
+            vals[t] = vals[ixj];
+            vals[ixj] = vx;
           }
         }
       }
@@ -1220,19 +1246,17 @@ __global__ __launch_bounds__(WAVE) void k_spgemm_hash(
   for (int s0 = 0; s0 < n; s0 += WAVE) {
     const int s = s0 + lane;
     const bool in = s < n;
-    const unsigned long long e = in ? sortbuf[s] : 0ull;
-    const int slot = (int)(e & 8191ull);
-    const int row = (int)(e >> 13);
-    const T v = in ? vals[slot] : Sc<T>::zero();
+    const int row = in ? keys[s] : 0;
+    const T v = in ? vals[s] : Sc<T>::zero();
     const T sv = Sc<T>::scale(alpha, v);
     const bool keep = in && (dense_rule ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
-    const unsigned long long m = __ballot(keep);
+    const unsigned long long mk = __ballot(keep);
     if (keep) {
-      const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
+      const int64_t pos = base + cnt + __popcll(mk & lanemask_lt());
       out_inner[pos] = row;
       out_val[pos] = sv;
     }
-    cnt += __popcll(m);
+    cnt += __popcll(mk);
   }
   if (lane == 0) count[j] = cnt;
 }
@@ -2280,6 +2304,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     else launch_slab(std::integral_constant<int, 0>{});
     for (int i = 0; i < 7; ++i) hstats[i] = 0;
   }
+  unsigned long long hash_big = 0;  // columns that outgrew the small hash table
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
     T* tv = reinterpret_cast<T*>(tmp_val.p);
@@ -2324,16 +2349,28 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     if (hstats[3]) launch_window<T, 2048, 2>(3, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
     if (hstats[4]) launch_window<T, 4096, 1>(4, A, B, lo.p, span.p, bin.p, tmpoff.p, tmp_inner.p, tv, count.p, alpha, threshold, dr);
     if (hstats[5]) {
-      hipLaunchKernelGGL((k_spgemm_hash<T>), dim3(xcd_grid(n)), dim3(WAVE), 0, stream(), view(A), view(B), span.p,
+      // small tables first (occupancy); the columns that outgrow them go through the large-table pass
+      hipLaunchKernelGGL((k_spgemm_hash<T, 1024>), dim3(xcd_grid(n)), dim3(WAVE), 0, stream(), view(A), view(B), span.p,
                          bin.p, tmpoff.p, tmp_inner.p, tv, count.p, stats.p, alpha, threshold, dr, n);
+      unsigned long long big = 0;
+      {
+        ScalarFetch f;
+        f.add(stats.p + 19, 1, &big);
+        f.run();
+      }
+      if (big)
+        hipLaunchKernelGGL((k_spgemm_hash<T, 4096>), dim3(xcd_grid(n)), dim3(WAVE), 0, stream(), view(A), view(B), span.p,
+                           bin.p, tmpoff.p, tmp_inner.p, tv, count.p, stats.p, alpha, threshold, dr, n);
+      hash_big = big;
     }
   });
   // columns that overflowed the LDS hash (or were forced) go through the HBM accumulator
   unsigned long long overflow = hstats[6];
-  if (hstats[5]) {
+  if (hstats[5] && hash_big) {
     unsigned long long ov = 0;
-    HIP_CHECK(hipMemcpyAsync(&ov, stats.p + 8, sizeof(ov), hipMemcpyDeviceToHost, stream()));
-    sync_stream();
+    ScalarFetch f;
+    f.add(stats.p + 8, 1, &ov);
+    f.run();
     overflow += ov;
   }
   st.overflow_cols = (int64_t)overflow;
