@@ -25,6 +25,10 @@ struct EngineOptions {
   int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
                                // reference built with FP contraction computes); 0: separate multiply and add (default, bit-
                                // identical to the reference built without contraction)
+  int load_balance = 1;        // 1: solvers permute with the caller's load-balancing permutation as the reference does;
+                               // 0: SetParametersLoadBalance is ignored -- the same results up to summation order (a
+                               // symmetric permutation only relabels entries), but banded operands stay on the run-based
+                               // kernels (a random permutation costs ~25x in SpGEMM time and turns the halo into a full gather)
   int halo_overlap = 1;        // distributed multiply: 0 exchange then multiply, 1 overlap the exchange with the interior
                                // columns when the halo is a sizeable part of the panel, 2 always split, 3 split even
                                // with an empty halo (tests; also NTPOLY_AMD_HALO_OVERLAP in the environment)

@@ -124,6 +124,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "time_kernels") options().time_kernels = *value;
   else if (n == "spgemm_variant") options().spgemm_variant = *value;
   else if (n == "halo_overlap") options().halo_overlap = *value;
+  else if (n == "load_balance") options().load_balance = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used
@@ -409,6 +410,7 @@ void SetParametersBeVerbose_wrp(int* ih_this, const bool* v) { get<SolverParamet
 void SetParametersThreshold_wrp(int* ih_this, const double* v) { get<SolverParameters>(ih_this)->threshold = *v; }
 void SetParametersLoadBalance_wrp(int* ih_this, const int* ih_permutation) {
   SolverParameters* p = get<SolverParameters>(ih_this);
+  if (options().load_balance == 0) return;  // engine option: keep the caller's ordering (kernels.hpp)
   p->do_load_balancing = true;  // SolverParametersModule.F90:160-167
   p->balance_permutation = *get<Permutation>(ih_permutation);
 }

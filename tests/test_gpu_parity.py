@@ -221,6 +221,18 @@ def test_load_balanced_solver_matches(nt):
     assert energy == pytest.approx(c["energy"], rel=1e-10)
     wd = to_dense(g.tri(idx, "K"))
     assert np.abs(K.to_scipy().toarray() - wd).max() <= 10 * c["thr"]
+    # engine option load_balance = 0: the permutation is not applied (the solve stays in the caller's ordering and on
+    # the run-based kernels); the result is the same up to summation order
+    nt.set_option("load_balance", 0)
+    try:
+        p2 = _params(nt, c)
+        p2.SetLoadBalance(perm)
+        K2 = nt.Matrix_ps(512)
+        e2, mu2 = nt.DensityMatrixSolvers.TRS2(H, ISQ, c["nel"], K2, p2)
+    finally:
+        nt.set_option("load_balance", 1)
+    assert e2 == pytest.approx(c["energy"], rel=1e-10)
+    assert np.abs(K2.to_scipy().toarray() - wd).max() <= 10 * c["thr"]
 
 
 def test_spgemm_vs_oracle_banded_4096(nt):
