@@ -527,3 +527,106 @@ def test_spgemm_blocks_of_empty_columns(nt):
         tx, ty = mA.triplets(), mB.triplets()
         oc, orow, ov = O.ps_multiply(O.Mat.from_triplets(n, n, *tx), O.Mat.from_triplets(n, n, *ty), None, 1.0, 0.0, 1e-9).triplets()
         exact(C.triplets(), (n, n, oc, orow, ov), "empty column blocks")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_spgemm_vs_oracle(nt, seed):
+    """seeded random operands (sizes 1..400, densities 0..40 %, empty rows / columns, real and complex, alpha, beta with
+    an existing C, thresholds), every kernel family forced in turn: the product must equal the oracle's bit for bit on
+    the sparse branch and to 1e-13 where the reference would take its dense branch."""
+    from oracle import oracle_py as O
+    import scipy.sparse as sp
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(8):
+        n = int(rng.choice([1, 2, 7, 33, 64, 65, 130, 257, 400]))
+        dens_a, dens_b = float(rng.choice([0.0, 0.02, 0.08, 0.4])), float(rng.choice([0.01, 0.05, 0.3]))
+        cplx = bool(rng.integers(0, 2))
+        thr = float(rng.choice([0.0, 1e-9, 1e-3]))
+        alpha = float(rng.choice([1.0, -0.5, 2.0]))
+        beta = float(rng.choice([0.0, 0.0, 0.7]))
+
+        def rnd(d):
+            m = sp.random(n, n, d, random_state=rng, format="csc", data_rvs=lambda k: rng.uniform(-1, 1, k))
+            if cplx:
+                m = m + 1j * sp.random(n, n, d, random_state=rng, format="csc", data_rvs=lambda k: rng.uniform(-1, 1, k))
+            m = sp.csc_matrix(m)
+            if n > 4:   # a few empty columns and rows
+                m = m.tolil()
+                m[:, n // 3] = 0
+                m[n // 2, :] = 0
+                m = sp.csc_matrix(m)
+            m.eliminate_zeros()
+            m.sort_indices()
+            return m
+
+        A, B, C0 = rnd(dens_a), rnd(dens_b), rnd(0.05)
+        dense_branch = min(A.nnz, B.nnz) / float(n * n) > 0.1
+        Ao, Bo, Co = (O.Mat.from_triplets(n, n, *nt.Matrix_ps.from_scipy(M).triplets()) for M in (A, B, C0))
+        want = O.ps_multiply(Ao, Bo, Co if beta != 0.0 else None, alpha, beta, thr).triplets()
+        for fb, var in ((-1, -1), (5, -1), (6, -1), (-1, 0), (-1, 400)):
+            nt.set_option("spgemm_force_bin", fb)
+            nt.set_option("spgemm_variant", var)
+            try:
+                mA, mB = nt.Matrix_ps.from_scipy(A), nt.Matrix_ps.from_scipy(B)
+                mC = nt.Matrix_ps.from_scipy(C0) if beta != 0.0 else nt.Matrix_ps(n)
+                mC.Gemm(mA, mB, None, alpha, beta, thr)
+                got = mC.triplets()
+            finally:
+                nt.set_option("spgemm_force_bin", -1)
+                nt.set_option("spgemm_variant", -1)
+            tag = "seed %d case %d n=%d cplx=%d fb=%d var=%d" % (seed, case, n, cplx, fb, var)
+            if dense_branch or beta != 0.0:
+                gd = to_dense((n, n) + tuple(got))
+                wd = to_dense((n, n) + tuple(want))
+                assert np.abs(gd - wd).max() <= 1e-13 * max(1.0, np.abs(wd).max()) + 2 * thr * (1 if dense_branch else 0), tag
+            else:
+                exact(got, (n, n) + tuple(want), tag)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_elementwise_vs_oracle(nt, seed):
+    """seeded random operands through the element-wise entry points against the oracle: Increment (AddSparseVectors
+    rules incl. threshold and the unfiltered tails; both merge kernels) and PairwiseMultiply bit for bit; Dot, Trace,
+    Norm and the Gershgorin bounds to 1e-13."""
+    from oracle import oracle_py as O
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2000 + seed)
+    for case in range(10):
+        n = int(rng.choice([1, 3, 40, 64, 129, 300, 700]))
+        cplx = bool(rng.integers(0, 2))
+        thr = float(rng.choice([0.0, 1e-6, 0.3]))
+        alpha = float(rng.choice([1.0, -1.0, 0.37]))
+
+        def rnd(d):
+            m = sp.random(n, n, d, random_state=rng, format="csc", data_rvs=lambda k: rng.uniform(-1, 1, k))
+            if cplx:
+                m = m + 1j * sp.random(n, n, d, random_state=rng, format="csc", data_rvs=lambda k: rng.uniform(-1, 1, k))
+            m = sp.csc_matrix(m)
+            m.eliminate_zeros()
+            m.sort_indices()
+            return m
+
+        A, B = rnd(float(rng.choice([0.0, 0.05, 0.5]))), rnd(float(rng.choice([0.02, 0.3])))
+        mA, mB = nt.Matrix_ps.from_scipy(A), nt.Matrix_ps.from_scipy(B)
+        Ao, Bo = O.Mat.from_triplets(n, n, *mA.triplets()), O.Mat.from_triplets(n, n, *mB.triplets())
+        tag = "seed %d case %d n=%d cplx=%d thr=%g" % (seed, case, n, cplx, thr)
+        want = O.increment(Ao, Bo, alpha, thr).triplets()
+        for force_seq in (0, 1):
+            nt.set_option("increment_force_seq", force_seq)
+            try:
+                R = nt.Matrix_ps(mB)
+                R.Increment(mA, alpha, thr)
+            finally:
+                nt.set_option("increment_force_seq", 0)
+            exact(R.triplets(), (n, n) + tuple(want), tag + " increment seq=%d" % force_seq)
+        Pm = nt.Matrix_ps(n)
+        Pm.PairwiseMultiply(mA, mB)
+        exact(Pm.triplets(), (n, n) + tuple(O.pairwise(Ao, Bo).triplets()), tag + " pairwise")
+        d_want = O.dot(Ao, Bo)
+        assert abs(mA.Dot(mB) - d_want) <= 1e-13 * max(1.0, abs(d_want)), tag + " dot"
+        assert mB.Trace() == pytest.approx(O.trace(Bo), rel=1e-13, abs=1e-13), tag + " trace"
+        assert mB.Norm() == pytest.approx(O.norm(Bo), rel=1e-13, abs=1e-13), tag + " norm"
+        if not cplx:
+            lo, hi = nt.EigenBounds.GershgorinBounds(mB)
+            wlo, whi = O.gershgorin(Bo)
+            assert lo == pytest.approx(wlo, rel=1e-13, abs=1e-13) and hi == pytest.approx(whi, rel=1e-13, abs=1e-13), tag
