@@ -1035,6 +1035,102 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
   }
 }
 
+// Narrow row windows (<= 256 / 512 rows): the same loop with ONE / TWO slabs per wave.  A third / two thirds of the
+// partial-sum registers means 6 / 5 resident waves per SIMD instead of 4, and the loop is latency bound (time ~ 1 /
+// occupancy, profiles/README.md item 14).  Register maps: tools/gen_slab_asm.py geometry().
+template <int SL>
+struct SlabOcc;
+template <>
+struct SlabOcc<1> { static constexpr int waves = 6; };  // (7+ waves per SIMD would leave a wave fewer SGPRs than the loop uses)
+template <>
+struct SlabOcc<2> { static constexpr int waves = 5; };
+
+template <int SL>
+__global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(SlabOcc<SL>::waves, SlabOcc<SL>::waves)))
+void k_spgemm_slab_n(const SlabRun* __restrict__ runs, const double* __restrict__ bblk,
+                     const int64_t* __restrict__ blk_boff, const int32_t* __restrict__ blk_kmin,
+                     const int32_t* __restrict__ blk_kn, const int32_t* __restrict__ blk_lo,
+                     const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
+                     int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count,
+                     double alpha, double threshold, int dense_rule, int ncols, int nblocks) {
+  constexpr int J = 16, NW = 4;
+  static_assert(SL == 1 || SL == 2, "register maps of slab_loop.inc");
+  __shared__ int cnt_s[NW * SL][J];
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int wave = uni_i32(threadIdx.x / WAVE), lane = lane_id();
+  const int lo = blk_lo[b], kmin = blk_kmin[b], kn = blk_kn[b], w = blk_w[b];
+  if (kn == 0) return;
+  const int rbase = lo + WAVE * wave;
+  const SlabRun* rp = runs + kmin;
+  const double* bq = bblk + blk_boff[b];
+  const unsigned r0 = (unsigned)(rbase + lane) * 8u;
+  const int e0 = rbase + WAVE - 1, e1 = e0 + WAVE * NW;
+  double acc[SL][J];
+  if constexpr (SL == 1) {
+    v8d aL0, aH0;
+    asm volatile(SLAB_LOOP_ASM_SL1
+                 : "=&{v[2:17]}"(aL0), "=&{v[18:33]}"(aH0)
+                 : [rp] "s"(rp), [bq] "s"(bq), [kn] "s"(kn), [e0] "s"(e0), [r0] "v"(r0)
+                 : SLAB_LOOP_SL1_CLOBBERS);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) { acc[0][jj] = aL0[jj]; acc[0][jj + 8] = aH0[jj]; }
+  } else {
+    v8d aL0, aH0, aL1, aH1;
+    asm volatile(SLAB_LOOP_ASM_SL2
+                 : "=&{v[2:17]}"(aL0), "=&{v[18:33]}"(aH0), "=&{v[34:49]}"(aL1), "=&{v[50:65]}"(aH1)
+                 : [rp] "s"(rp), [bq] "s"(bq), [kn] "s"(kn), [e0] "s"(e0), [e1] "s"(e1), [r0] "v"(r0),
+                   [c1] "n"(WAVE * NW * 8)
+                 : SLAB_LOOP_SL2_CLOBBERS);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      acc[0][jj] = aL0[jj]; acc[0][jj + 8] = aH0[jj];
+      acc[SL - 1][jj] = aL1[jj]; acc[SL - 1][jj + 8] = aH1[jj];
+    }
+  }
+  // ---- epilogue as in k_spgemm_slab: prune, count per (slab, column), prefix over slabs, write in row order
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const double v = acc[s][jj];
+      const double sv = __dmul_rn(alpha, v);
+      const bool keep = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) cnt_s[wave + NW * s][jj] = __popcll(m);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < J) {
+    int run = 0;
+    for (int m = 0; m < NW * SL; ++m) {
+      const int c = cnt_s[m][threadIdx.x];
+      cnt_s[m][threadIdx.x] = run;
+      run += c;
+    }
+    const int j = b * J + threadIdx.x;
+    if (j < ncols) count[j] = run;
+  }
+  __syncthreads();
+  const int64_t tbase = blk_toff[b];
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    const int r = lo + WAVE * (wave + NW * s) + lane;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const double v = acc[s][jj];
+      const double sv = __dmul_rn(alpha, v);
+      const bool keep = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int64_t pos = tbase + (int64_t)jj * w + cnt_s[wave + NW * s][jj] + __popcll(m & lanemask_lt());
+        out_inner[pos] = r;
+        out_val[pos] = sv;
+      }
+    }
+  }
+}
+
 // Complex operands: the same design with 8 complex columns per workgroup (a multiplier set is again 32 SGPRs), two
 // slabs per wave and six waves (12 slabs = the same 768-row window), one buffer_load_dwordx4 per slab and step.
 // (ar + i ai)(br + i bi) is four products, one subtraction, one addition and the two accumulates, each rounded on
@@ -2310,7 +2406,17 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                          threshold, dr, n, snb);
     };
     const int abl = (sv_opt / 100 == 4) ? sv_opt % 100 : 0;  // 401..403: ablations for timing experiments
-    if (abl == 1) launch_slab(std::integral_constant<int, 2>{});
+    // narrow windows: one / two slabs per wave (more resident waves); 410 keeps three slabs for comparison
+    const int64_t max_w_now = (int64_t)hstats[16];
+    auto launch_narrow = [&](auto sl_tag) {
+      constexpr int SLN = decltype(sl_tag)::value;
+      hipLaunchKernelGGL((k_spgemm_slab_n<SLN>), dim3(xcd_grid(snb)), dim3(SLAB_NW * WAVE), 0, stream(),
+                         reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
+                         blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
+    };
+    if (abl == 0 && !options().spgemm_fma && sv_opt != 410 && max_w_now <= SLAB_NW * WAVE) launch_narrow(std::integral_constant<int, 1>{});
+    else if (abl == 0 && !options().spgemm_fma && sv_opt != 410 && max_w_now <= 2 * SLAB_NW * WAVE) launch_narrow(std::integral_constant<int, 2>{});
+    else if (abl == 1) launch_slab(std::integral_constant<int, 2>{});
     else if (abl == 2) launch_slab(std::integral_constant<int, 3>{});
     else if (abl == 3) launch_slab(std::integral_constant<int, 4>{});
     else if (abl == 4) launch_slab(std::integral_constant<int, 5>{});

@@ -255,6 +255,21 @@ def build_complex():
     return L
 
 
+def geometry(sl):
+    """register map for SL slabs per wave (the accumulators start at v2; everything else follows them):
+    SL = 3: the map in the header (128 VGPRs, 4 waves per SIMD); SL = 2: 88 VGPRs (5 waves); SL = 1: 50 VGPRs (8 waves)"""
+    global SL, T0, VOFF, A_SET
+    SL = sl
+    if sl == 3:
+        T0, VOFF, A_SET = 98, 106, [116, 122, 110]
+    else:
+        T0 = ACC0 + 2 * J * sl
+        VOFF = T0 + 8
+        a0 = VOFF + sl + (VOFF + sl) % 2          # slab values sit on even registers
+        A_SET = [a0, a0 + 2 * sl, a0 + 4 * sl]
+    return T0, VOFF, A_SET
+
+
 def main():
     sclob = ["s%d" % i for i in [12, 13] + list(range(14, 32)) + list(range(36, 100))]
     vclob = ["v%d" % i for i in list(range(T0, VOFF + SL)) + list(range(110, 128))]
@@ -276,6 +291,19 @@ def main():
         out.append('  ""')
         print(name, len(L), "instructions")
     out.append("#define SLAB_LOOP_CLOBBERS " + ", ".join('"%s"' % c for c in sclob + vclob) + ', "vcc", "scc", "memory"')
+    # narrower row windows: fewer slabs per wave = fewer accumulator registers = more waves per SIMD (the loop is
+    # latency bound: time ~ 1 / occupancy, profiles/README.md item 14)
+    for sl in (1, 2):
+        t0, voff, a_set = geometry(sl)
+        L = build(False)
+        out.append("#define SLAB_LOOP_ASM_SL%d \\" % sl)
+        for ln in L:
+            out.append('  "%s\\n\\t" \\' % ln)
+        out.append('  ""')
+        vc = ["v%d" % i for i in range(t0, a_set[2] + 2 * sl)]
+        out.append("#define SLAB_LOOP_SL%d_CLOBBERS " % sl + ", ".join('"%s"' % c for c in sclob + vc) + ', "vcc", "scc", "memory"')
+        print("SLAB_LOOP_ASM_SL%d" % sl, len(L), "instructions; VGPRs up to v%d" % (a_set[2] + 2 * sl - 1))
+    geometry(3)
     # complex loop: outputs accA..accD (v8d, v[2:65]); inputs rp, bq, kn, e0, e1, r0 (row offset * 16), c1 (immediate)
     L = build_complex()
     out.append("#define SLAB_LOOP_ASM_CPLX \\")
