@@ -949,7 +949,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int32_t* __restrict__ blk_lo, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
     int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count, double alpha,
     double threshold, int dense_rule, int ncols, int nblocks) {
-  static_assert(J == 16 && SL == 3 && NW == 4, "register map / wave rotation of slab_loop.inc");
+  static_assert(J == 16 && SL == 3 && (NW == 4 || (NW == 6 && MODE == 0)), "register map / wave rotation of slab_loop.inc");
   __shared__ int cnt_s[NW * SL][J];
   const int b = xcd_block(nblocks);
   if (b < 0) return;
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 5))
     int32_t* __restrict__ out_inner, double2* __restrict__ out_val, int32_t* __restrict__ count, double alpha,
     double threshold, int dense_rule, int ncols, int nblocks) {
   constexpr int J = 8, SL = 2;
-  static_assert(NW == 6, "register map of slab_loop.inc (complex loop)");
+  static_assert(NW == 6 || NW == 8, "row window of 768 / 1024 rows (the register map does not depend on NW)");
   __shared__ int cnt_s[NW * SL][J];
   const int b = xcd_block(nblocks);
   if (b < 0) return;
@@ -2281,7 +2281,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   // (complex operands: 8 columns per workgroup, two slabs per wave, six waves -- the same 768-row window and the
   // same 128-byte multiplier row)
   const int SJ = A.cplx ? SLAB_CJ : SLAB_J;
-  const int slab_rows = A.cplx ? SLAB_CNW * SLAB_CSL * WAVE : SLAB_NW * SLAB_SL * WAVE;
+  // widest row window the slab kernels take: real 6 waves x 3 slabs = 1152 rows, complex 8 waves x 2 slabs = 1024
+  // (the usual geometries are 4 x 3 and 6 x 2 = 768 rows; the wider workgroups serve operands with longer runs)
+  const int slab_rows = A.cplx ? 8 * SLAB_CSL * WAVE : (options().spgemm_fma ? SLAB_NW : 6) * SLAB_SL * WAVE;  // (the fused loop exists for 4 waves)
   const size_t esz = A.cplx ? 16 : 8;
   const int sv_opt = options().spgemm_variant;
   const bool slab_try = options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4) &&
@@ -2391,10 +2393,16 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   }
   t_num.start();
   if (use_slab && A.cplx) {
-    hipLaunchKernelGGL((k_spgemm_slab_c<SLAB_CNW>), dim3(xcd_grid(snb)), dim3(SLAB_CNW * WAVE), 0, stream(),
-                       reinterpret_cast<const SlabRun*>(runs.p) - ka, reinterpret_cast<const double2*>(bblk.p), blk_boff.p,
-                       blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p,
-                       reinterpret_cast<double2*>(tmp_val.p), count.p, alpha, threshold, dr, n, snb);
+    if ((int64_t)hstats[16] <= SLAB_CNW * SLAB_CSL * WAVE)
+      hipLaunchKernelGGL((k_spgemm_slab_c<SLAB_CNW>), dim3(xcd_grid(snb)), dim3(SLAB_CNW * WAVE), 0, stream(),
+                         reinterpret_cast<const SlabRun*>(runs.p) - ka, reinterpret_cast<const double2*>(bblk.p), blk_boff.p,
+                         blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p,
+                         reinterpret_cast<double2*>(tmp_val.p), count.p, alpha, threshold, dr, n, snb);
+    else
+      hipLaunchKernelGGL((k_spgemm_slab_c<8>), dim3(xcd_grid(snb)), dim3(8 * WAVE), 0, stream(),
+                         reinterpret_cast<const SlabRun*>(runs.p) - ka, reinterpret_cast<const double2*>(bblk.p), blk_boff.p,
+                         blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p,
+                         reinterpret_cast<double2*>(tmp_val.p), count.p, alpha, threshold, dr, n, snb);
     for (int i = 0; i < 7; ++i) hstats[i] = 0;
   } else if (use_slab) {
     // occupancy experiments (408 / 409): unused dynamic LDS limits the workgroups per CU to 2 / 3 instead of 4
@@ -2414,7 +2422,11 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                          reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
                          blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
     };
-    if (abl == 0 && !options().spgemm_fma && sv_opt != 410 && max_w_now <= SLAB_NW * WAVE) launch_narrow(std::integral_constant<int, 1>{});
+    if (max_w_now > SLAB_NW * SLAB_SL * WAVE)   // 769 .. 1152 rows: six waves per workgroup
+      hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, 6, 0>), dim3(xcd_grid(snb)), dim3(6 * WAVE), 0, stream(),
+                         reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
+                         blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
+    else if (abl == 0 && !options().spgemm_fma && sv_opt != 410 && max_w_now <= SLAB_NW * WAVE) launch_narrow(std::integral_constant<int, 1>{});
     else if (abl == 0 && !options().spgemm_fma && sv_opt != 410 && max_w_now <= 2 * SLAB_NW * WAVE) launch_narrow(std::integral_constant<int, 2>{});
     else if (abl == 1) launch_slab(std::integral_constant<int, 2>{});
     else if (abl == 2) launch_slab(std::integral_constant<int, 3>{});
