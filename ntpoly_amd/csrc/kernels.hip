@@ -1136,7 +1136,7 @@ void k_spgemm_slab_n(const SlabRun* __restrict__ runs, const double* __restrict_
 // (ar + i ai)(br + i bi) is four products, one subtraction, one addition and the two accumulates, each rounded on
 // its own -- the arithmetic of the reference's complex multiply-add (and of Sc<double2>::mul / add here).
 template <int NW>
-__global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_spgemm_slab_c(
+__global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_spgemm_slab_c(
     const SlabRun* __restrict__ runs, const double2* __restrict__ bblk,
     const int64_t* __restrict__ blk_boff, const int32_t* __restrict__ blk_kmin, const int32_t* __restrict__ blk_kn,
     const int32_t* __restrict__ blk_lo, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,

@@ -170,10 +170,10 @@ def build(fused, ablate=0, pf=0, lean=False):
 # Register map of the complex loop (J = 8 complex columns, SL = 2 slabs per wave, NW = 6 waves):
 #   SGPRs as above; a multiplier set holds 8 complex numbers (re, im pairs): B(k, c) = s[base+4c : base+4c+3]
 #   v[2:33], v[34:65]  accumulators of slab 0, 1: column c -> (re, im) = v[.. + 4c : .. + 4c + 3]
-#   v[66:81] eight temporaries   v[82:83] load offsets   slab values (re, im per lane): set 0 v[84:91], set 1 v[92:99]
+#   v[66:73] four temporaries   v[74:75] load offsets   slab values (re, im per lane): set 0 v[76:83], set 1 v[84:91]
 C_SL, C_J = 2, 8
-C_ACC0, C_T0, C_VOFF = 2, 66, 82
-C_A_SET = [84, 92]
+C_ACC0, C_T0, C_VOFF = 2, 66, 74
+C_A_SET = [76, 84]
 
 
 def c_issue(aset, lines):
@@ -189,8 +189,8 @@ def c_issue(aset, lines):
 
 def c_compute(aset, bset, lines, label):
     """(ar + i ai)(br + i bi): four products, one subtraction, one addition, then the two accumulates -- every operation
-    rounded on its own, as the reference's complex multiply-add; two columns interleaved so nothing waits on its
-    predecessor"""
+    rounded on its own, as the reference's complex multiply-add.  One column at a time on four temporaries: with 92
+    VGPRs five waves fit a SIMD (the loop is latency bound, so residency beats interleaving two columns on sixteen)."""
     f, s = FS[aset]
     for i in range(C_SL):
         skip = "%d" % label[0]
@@ -199,22 +199,19 @@ def c_compute(aset, bset, lines, label):
         lines.append("s_cmp_gt_u32 s19, s%d" % s)
         lines.append("s_cbranch_scc1 %sf" % skip)
         ar, ai = vp(C_A_SET[aset] + 4 * i), vp(C_A_SET[aset] + 4 * i + 2)
-        for c0 in range(0, C_J, 2):
-            t = [vp(C_T0 + 2 * q) for q in range(8)]
-            for q, c in enumerate((c0, c0 + 1)):
-                br, bi = sp(B_SET[bset] + 4 * c), sp(B_SET[bset] + 4 * c + 2)
-                lines.append("v_mul_f64 %s, %s, %s" % (t[4 * q + 0], ar, br))
-                lines.append("v_mul_f64 %s, %s, %s" % (t[4 * q + 1], ai, bi))
-                lines.append("v_mul_f64 %s, %s, %s" % (t[4 * q + 2], ar, bi))
-                lines.append("v_mul_f64 %s, %s, %s" % (t[4 * q + 3], ai, br))
-            for q in range(2):
-                lines.append("v_add_f64 %s, %s, -%s" % (t[4 * q + 0], t[4 * q + 0], t[4 * q + 1]))
-                lines.append("v_add_f64 %s, %s, %s" % (t[4 * q + 2], t[4 * q + 2], t[4 * q + 3]))
-            for q, c in enumerate((c0, c0 + 1)):
-                accr = vp(C_ACC0 + 4 * C_J * i + 4 * c)
-                acci = vp(C_ACC0 + 4 * C_J * i + 4 * c + 2)
-                lines.append("v_add_f64 %s, %s, %s" % (accr, accr, t[4 * q + 0]))
-                lines.append("v_add_f64 %s, %s, %s" % (acci, acci, t[4 * q + 2]))
+        t = [vp(C_T0 + 2 * q) for q in range(4)]
+        for c in range(C_J):
+            br, bi = sp(B_SET[bset] + 4 * c), sp(B_SET[bset] + 4 * c + 2)
+            lines.append("v_mul_f64 %s, %s, %s" % (t[0], ar, br))
+            lines.append("v_mul_f64 %s, %s, %s" % (t[1], ai, bi))
+            lines.append("v_mul_f64 %s, %s, %s" % (t[2], ar, bi))
+            lines.append("v_mul_f64 %s, %s, %s" % (t[3], ai, br))
+            lines.append("v_add_f64 %s, %s, -%s" % (t[0], t[0], t[1]))
+            lines.append("v_add_f64 %s, %s, %s" % (t[2], t[2], t[3]))
+            accr = vp(C_ACC0 + 4 * C_J * i + 4 * c)
+            acci = vp(C_ACC0 + 4 * C_J * i + 4 * c + 2)
+            lines.append("v_add_f64 %s, %s, %s" % (accr, accr, t[0]))
+            lines.append("v_add_f64 %s, %s, %s" % (acci, acci, t[2]))
         lines.append("%s:" % skip)
 
 
@@ -312,7 +309,7 @@ def main():
     out.append('  ""')
     print("SLAB_LOOP_ASM_CPLX", len(L), "instructions")
     cs = ["s%d" % i for i in [12, 13] + list(range(14, 32)) + list(range(36, 100))]
-    cv = ["v%d" % i for i in range(C_T0, 100)]
+    cv = ["v%d" % i for i in range(C_T0, C_A_SET[1] + 4 * C_SL)]
     out.append("#define SLAB_LOOP_CPLX_CLOBBERS " + ", ".join('"%s"' % c for c in cs + cv) + ', "vcc", "scc", "memory"')
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ntpoly_amd", "csrc", "slab_loop.inc")
     open(path, "w").write("\n".join(out) + "\n")
