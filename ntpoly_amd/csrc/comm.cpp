@@ -1,7 +1,7 @@
 // RCCL plumbing: one communicator over all ranks (one process per MI355X, xGMI links).
 // Replaces the reference's MPI communicators (ProcessGridModule.F90:186-262) for the calls on
 // the hot path.  The unique id is exchanged by the launcher
-// (bench.py / tests use torch.distributed for that) and handed in through comm_init().
+// (ntpoly_amd.host.init_comm_from_env: a file in /tmp, no torch) and handed in through comm_init().
 #include <rccl/rccl.h>
 
 #include <fcntl.h>
