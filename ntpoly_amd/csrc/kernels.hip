@@ -976,6 +976,8 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     asm volatile(SLAB_LOOP_ASM_ABL2 SLAB_LOOP_OPERANDS);  // no multiplier loads
   } else if constexpr (MODE == 4) {
     asm volatile(SLAB_LOOP_ASM_ABL3 SLAB_LOOP_OPERANDS);  // no arithmetic
+  } else if constexpr (MODE == 8) {
+    asm volatile(SLAB_LOOP_ASM_LEANPF SLAB_LOOP_OPERANDS);  // lean periods + rotating scalar-cache prefetch
   } else if constexpr (MODE == 7) {
     asm volatile(SLAB_LOOP_ASM_LEAN SLAB_LOOP_OPERANDS);  // whole periods without pointer arithmetic / exit tests, then the plain loop
   } else if constexpr (MODE == 6) {
@@ -2434,8 +2436,10 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     else if (abl == 4) launch_slab(std::integral_constant<int, 5>{});
     else if (abl == 5) launch_slab(std::integral_constant<int, 6>{});
     else if (abl == 6) launch_slab(std::integral_constant<int, 7>{});
+    else if (abl == 7) launch_slab(std::integral_constant<int, 8>{});
     else if (options().spgemm_fma) launch_slab(std::integral_constant<int, 1>{});
-    else launch_slab(std::integral_constant<int, 0>{});
+    else if (sv_opt == 410) launch_slab(std::integral_constant<int, 0>{});  // the plain loop (comparison)
+    else launch_slab(std::integral_constant<int, 8>{});  // whole periods without pointer arithmetic + rotating prefetch
     for (int i = 0; i < 7; ++i) hstats[i] = 0;
   }
   unsigned long long hash_big = 0;  // columns that outgrew the small hash table

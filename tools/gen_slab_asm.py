@@ -107,11 +107,17 @@ def step(L, label, t, fused, ablate, pf, lean):
         # while the other three find their rows in the cache.  s31 is the unused pad word of the record.
         skip = "%d" % label[0]
         label[0] += 1
-        L.append("s_and_b32 s19, s18, 3")
+        if lean:   # s18 counts whole periods here: the step within the period is known at generation time
+            L.append("s_add_i32 s19, s18, %d" % t)
+            L.append("s_and_b32 s19, s19, 3")
+            poff = 0x80 * (t + pf)
+        else:
+            L.append("s_and_b32 s19, s18, 3")
+            poff = pf * 0x80
         L.append("s_cmp_lg_u32 s19, %[wv]")
         L.append("s_cbranch_scc1 %sf" % skip)
-        L.append("s_load_dword s31, s[16:17], 0x%x" % (pf * 0x80))
-        L.append("s_load_dword s31, s[16:17], 0x%x" % (pf * 0x80 + 0x40))
+        L.append("s_load_dword s31, s[16:17], 0x%x" % poff)
+        L.append("s_load_dword s31, s[16:17], 0x%x" % (poff + 0x40))
         L.append("%s:" % skip)
     L.append("s_waitcnt vmcnt(%d)" % (2 * SL))
     compute(t % NA, t % NB, L, label, fused, ablate)
@@ -142,7 +148,7 @@ def build(fused, ablate=0, pf=0, lean=False):
         L.append("s_cmp_lt_i32 s19, %d" % period)
         L.append("s_cbranch_scc1 4f")
         for t in range(period):
-            step(L, label, t, fused, ablate, 0, True)
+            step(L, label, t, fused, ablate, pf, True)
         L.append("s_add_u32 s16, s16, 0x%x" % (0x80 * period))
         L.append("s_addc_u32 s17, s17, 0")
         L.append("s_add_u32 s14, s14, 0x%x" % (0x20 * period))
@@ -280,7 +286,7 @@ def main():
     for name, fused, abl, pf, lean in (("SLAB_LOOP_ASM", False, 0, 0, False), ("SLAB_LOOP_ASM_FMA", True, 0, PF, False),
                                        ("SLAB_LOOP_ASM_ABL1", False, 1, 0, False), ("SLAB_LOOP_ASM_ABL2", False, 2, 0, False),
                                        ("SLAB_LOOP_ASM_ABL3", False, 3, 0, False), ("SLAB_LOOP_ASM_PF", False, 0, PF, False),
-                                       ("SLAB_LOOP_ASM_LEAN", False, 0, 0, True)):
+                                       ("SLAB_LOOP_ASM_LEAN", False, 0, 0, True), ("SLAB_LOOP_ASM_LEANPF", False, 0, PF, True)):
         L = build(fused, abl, pf, lean)
         out.append("#define %s \\" % name)
         for ln in L:
