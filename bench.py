@@ -155,11 +155,11 @@ def main():
     if rank == 0:
         # HBM traffic of the dominant kernel comes from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
         # runs of this same command; they cannot be collected from inside the process): the committed summary
-        # profiles/r01_v10_pmc_traffic.json (tools/collect_profiles.sh + tools/pmc_traffic_json.py) holds the corrected
+        # profiles/r01_v11_pmc_traffic.json (tools/collect_profiles.sh + tools/pmc_traffic_json.py) holds the corrected
         # bytes per launch
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_v10_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_v11_pmc_traffic.json")) as f:
                 traffic = float(json.load(f)["hbm_bytes_per_launch"]) if (n, h, thr, world) == (262144, 100, 1e-8, 1) else None
         except Exception:
             traffic = None
@@ -198,7 +198,7 @@ def main():
                          "kernel": "k_spgemm_slab (SpGEMM numeric phase)" if st.get("slab") else "k_spgemm_pair3 (SpGEMM numeric phase)",
                          "alg_bytes_per_launch": acc["alg_bytes"] / calls, "ms_per_launch": ms_numeric / calls,
                          "note": "rank-0 panel; algorithmic bytes = 12*(nnzA+nnzB+nnzC)+4*(colsA+colsB+colsC+3); traffic = bytes "
-                                 "per launch from the committed PMC passes (profiles/r01_v10_pmc_traffic.json)"},
+                                 "per launch from the committed PMC passes (profiles/r01_v11_pmc_traffic.json)"},
         }
         # the numeric kernel is FP64-ALU side bound: 2 flops per product against the vector peak for SEPARATE multiply and
         # add instructions (78.6 TFLOP/s counts an FMA as 2 flops per instruction -> 39.3 for unfused mul + add)

@@ -22,7 +22,7 @@ def main():
     root, pat = sys.argv[1], sys.argv[2]
     f = per_kernel(root + "/pmc_FETCH_SIZE/run_counter_collection.csv")
     w = per_kernel(root + "/pmc_WRITE_SIZE/run_counter_collection.csv")
-    fk = [k for k in f if pat in k][0]
+    fk = pat if pat in f else [k for k in f if pat in k][0]   # exact kernel name first
     fetch, write = f[fk][1:] or f[fk], w[fk][1:] or w[fk]   # drop the first (cold) launch
     fa, wa = sum(fetch) / len(fetch), sum(write) / len(write)
     cal = None
