@@ -632,3 +632,28 @@ def test_fuzz_elementwise_vs_oracle(nt, seed):
             lo, hi = nt.EigenBounds.GershgorinBounds(mB)
             wlo, whi = O.gershgorin(Bo)
             assert lo == pytest.approx(wlo, rel=1e-13, abs=1e-13) and hi == pytest.approx(whi, rel=1e-13, abs=1e-13), tag
+
+
+@pytest.mark.parametrize("density,expect_overflow", [(0.006, False), (0.02, True)])
+def test_hash_table_classes_vs_oracle(nt, density, expect_overflow):
+    """unstructured operand whose output columns outgrow the small hash table: N = 6000, ~36 / ~120 entries per column,
+    so a column of A*A has ~1200 distinct rows (1024-bucket table -> 4096-bucket pass) or ~5400 (-> HBM accumulator
+    as well).  Bit-exact against the oracle; the statistics show which passes ran."""
+    from oracle import oracle_py as O
+    import scipy.sparse as sp
+    rng = np.random.default_rng(7)
+    n = 6000
+    A = sp.random(n, n, density, random_state=rng, format="csc", data_rvs=lambda k: rng.uniform(-1, 1, k))
+    A.sort_indices()
+    mA = nt.Matrix_ps.from_scipy(A)
+    C = nt.Matrix_ps(n)
+    C.Gemm(mA, mA, None, 1.0, 0.0, 1e-6)
+    st = nt.last_spgemm_stats()
+    assert st["bins"][5] == n and st["slab"] == 0          # every column went to the hash bin
+    assert (st["overflow"] > 0) == expect_overflow          # columns handed on to the HBM accumulator
+    t = mA.triplets()
+    Ao = O.Mat.from_triplets(n, n, *t)
+    oc, orow, ov = O.ps_multiply(Ao, Ao, None, 1.0, 0.0, 1e-6).triplets()
+    dense_branch = A.nnz / float(n * n) > 0.1
+    assert not dense_branch
+    exact(C.triplets(), (n, n, oc, orow, ov), "hash classes density %g" % density)
