@@ -949,7 +949,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int32_t* __restrict__ blk_lo, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
     int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count, double alpha,
     double threshold, int dense_rule, int ncols, int nblocks) {
-  static_assert(J == 16 && SL == 3 && (NW == 4 || (NW == 6 && MODE == 0)), "register map / wave rotation of slab_loop.inc");
+  static_assert(J == 16 && SL == 3 && (NW == 4 || ((NW == 6 || NW == 8) && MODE == 0)), "register map / wave rotation of slab_loop.inc");
   __shared__ int cnt_s[NW * SL][J];
   const int b = xcd_block(nblocks);
   if (b < 0) return;
@@ -2285,7 +2285,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   const int SJ = A.cplx ? SLAB_CJ : SLAB_J;
   // widest row window the slab kernels take: real 6 waves x 3 slabs = 1152 rows, complex 8 waves x 2 slabs = 1024
   // (the usual geometries are 4 x 3 and 6 x 2 = 768 rows; the wider workgroups serve operands with longer runs)
-  const int slab_rows = A.cplx ? 8 * SLAB_CSL * WAVE : (options().spgemm_fma ? SLAB_NW : 6) * SLAB_SL * WAVE;  // (the fused loop exists for 4 waves)
+  const int slab_rows = A.cplx ? 8 * SLAB_CSL * WAVE : (options().spgemm_fma ? SLAB_NW : 8) * SLAB_SL * WAVE;  // (the fused loop exists for 4 waves)
   const size_t esz = A.cplx ? 16 : 8;
   const int sv_opt = options().spgemm_variant;
   const bool slab_try = options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4) &&
@@ -2325,7 +2325,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     f.run();
     // use it when the window fits the register slabs and the zero padding stays small
     const int64_t max_w = (int64_t)hstats[16], max_kn = (int64_t)hstats[17];
-    const bool fits = max_w > 0 && max_w <= slab_rows && ((max_kn + 1) | 1) * SJ * (int64_t)esz <= 64 * 1024;
+    // (the multiplier tile of a block is staged in LDS by the expansion kernel: up to 128 KB, requested explicitly)
+    const bool fits = max_w > 0 && max_w <= slab_rows && ((max_kn + 1) | 1) * SJ * (int64_t)esz <= 128 * 1024;
     const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
                             (double)slab_tot[0] >= 48.0 * (double)hstats[18];  // mean run of the non-empty columns >= 48 rows
     use_slab = fits && (dense_runs || sv_opt / 100 == 4);
@@ -2374,6 +2375,16 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(nka + 4, 256)), dim3(256), 0, stream(), cmin_own.p, cmax_own.p, aeoff.p,
                        reinterpret_cast<const char*>(aexp.p), (int)esz, reinterpret_cast<SlabRun*>(runs.p), nka);
     const int pitch = ((int)hstats[17] + 1) | 1;
+    if ((size_t)pitch * SJ * esz > 64 * 1024) {   // tiles beyond the default dynamic-LDS limit
+      static bool raised = false;
+      if (!raised) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_expand_b<double, SLAB_J>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_expand_b<double2, SLAB_CJ>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        raised = true;
+      }
+    }
     const int32_t* clen_opt = timing ? clen.p : (const int32_t*)nullptr;  // product count: statistics only
     if (A.cplx) {
       double2* ae = reinterpret_cast<double2*>(aexp.p);
@@ -2424,7 +2435,11 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                          reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
                          blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
     };
-    if (max_w_now > SLAB_NW * SLAB_SL * WAVE)   // 769 .. 1152 rows: six waves per workgroup
+    if (max_w_now > 6 * SLAB_SL * WAVE)         // 1153 .. 1536 rows: eight waves per workgroup
+      hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, 8, 0>), dim3(xcd_grid(snb)), dim3(8 * WAVE), 0, stream(),
+                         reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
+                         blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
+    else if (max_w_now > SLAB_NW * SLAB_SL * WAVE)   // 769 .. 1152 rows: six waves per workgroup
       hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, 6, 0>), dim3(xcd_grid(snb)), dim3(6 * WAVE), 0, stream(),
                          reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
                          blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
