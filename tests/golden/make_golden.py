@@ -552,6 +552,28 @@ def gen_extras(tmp):
     save("extras", d, dict(kind="extras", cases=cases))
 
 
+def gen_example_complexmatrix(tmp):
+    """Examples/ComplexMatrix: the Hermitian "Guo" matrix built from the reference's input graph (tests/golden/
+    reference_data/complexmatrix_input.mtx, the example's own construction restated in numpy) and the reference's
+    ComputeExponential of it at the ReadMe's threshold 1e-6.  (With eigenvalues up to 25.8 the reference's Chebyshev
+    scheme is far from scipy's expm here; what is pinned is what the reference computes.)"""
+    import scipy.io
+    A = scipy.io.mmread(os.path.join(OUT, "reference_data", "complexmatrix_input.mtx")).toarray()
+    n = len(A)
+    S = A + A.T - np.diag(np.diag(A))
+    S = np.where((A != 0) & (A.T != 0) & ~np.eye(n, dtype=bool), A + A.T, S)
+    Cm = np.where((S - A) != 0, 1j, 0.0)
+    G = sp.csc_matrix(0.5 * (Cm.conj().T + Cm + S))
+    G.sort_indices()
+    write_tri(tmp + "/A.tri", n, n, *tri(G))
+    run(["func", 1, 1, 1, "exp", tmp + "/A.tri", repr(1e-6), repr(1e-6), tmp + "/K.tri", tmp + "/s.txt", 0])
+    rows, cols, c, r, v = read_tri(tmp + "/K.tri")
+    d = {}
+    put(d, "G", (n, n), tri(G))
+    put(d, "K", (rows, cols), (c, r, v))
+    save("example_complexmatrix", d, dict(kind="example_complexmatrix", thr=1e-6, cases=[]))
+
+
 def gen_ps_gemm_fma(tmp):
     """Distributed multiply computed by the reference built WITH floating-point contraction (oracle/build_ref.py
     --fma: -ffp-contract=fast -march=haswell, `acc + a*b` is one FMA) -- what the reference produces on targets

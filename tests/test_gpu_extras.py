@@ -634,3 +634,103 @@ def test_reference_data_fixtures(nt, tmp_path):
     rio.WriteToMatrixMarket(out)
     want = scipy.io.mmread(os.path.join(data, "realio.mtx")).toarray()
     assert np.abs(scipy.io.mmread(out).toarray() - want).max() <= 1e-14 * np.abs(want).max()
+
+
+def test_reference_cxx_examples_run(nt, tmp_path):
+    """The reference's other C++ example programs -- UNCHANGED sources (Examples/{HydrogenAtom,GraphTheory,ComplexMatrix,
+    MatrixMaps}/main.cc) over its UNCHANGED C++ class layer (all of Source/CPlusPlus), linked against libntpoly_amd.so
+    by oracle/build_cxx_example.py -- run as their ReadMe files run them; results checked against numpy / scipy."""
+    import ctypes
+    import subprocess
+    import scipy.io
+    import scipy.linalg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = os.path.join(root, "oracle", "_ref")
+    data = os.path.join(root, "tests", "golden", "reference_data")
+    if not all(os.path.exists(os.path.join(ref, e)) for e in ("hydrogen_cxx", "graph_cxx", "complex_cxx", "maps_cxx")):
+        pytest.skip("oracle/_ref/*_cxx were not built (needs /root/reference at build time)")
+    grid = ["--process_rows", "1", "--process_columns", "1", "--process_slices", "1"]
+
+    def run(exe, args):
+        r = subprocess.run([os.path.join(ref, exe)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=600, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout[-3000:]
+        return r.stdout
+
+    # HydrogenAtom: one electron in -1/2 d2/dr2 - 1/r on 100 grid points -> a rank-one projector
+    out = str(tmp_path / "Density.mtx")
+    run("hydrogen_cxx", grid + ["--threshold", "1e-6", "--convergence_threshold", "1e-5", "--grid_points", "100", "--density", out])
+    D = scipy.io.mmread(out).toarray()
+    assert abs(np.trace(D) - 1.0) <= 1e-4 and np.abs(D - D.T).max() <= 1e-6 and np.abs(D @ D - D).max() <= 1e-3
+
+    # GraphTheory: (I - 0.7 M)^-1 of a ring with extra connections drawn with libc rand() (unseeded -> reproducible)
+    out = str(tmp_path / "Output.mtx")
+    n, extra, att = 512, 32, 0.7
+    run("graph_cxx", grid + ["--threshold", "1e-6", "--convergence_threshold", "1e-4", "--number_of_nodes", str(n),
+                             "--extra_connections", str(extra), "--attenuation", str(att), "--output_file", out])
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)   # the state a fresh process starts from
+    M = np.zeros((n, n))
+    for i in range(n):
+        M[i, i] = 1.0
+        if i > 0:
+            M[i, i - 1] = 0.1
+        if i < n - 1:
+            M[i, i + 1] = 0.1
+    used = np.zeros(n, dtype=bool)
+    count = 0
+    while count < extra:
+        s_, d_ = libc.rand() % n, libc.rand() % n
+        if not used[s_] and not used[d_] and s_ != d_ and s_ != d_ - 1 and s_ != d_ + 1:
+            count += 1
+            used[s_] = used[d_] = True
+            M[s_, d_] = 0.1   # one rank owns every node: the source-node branch is always taken
+    want = np.linalg.inv(np.eye(n) - att * M)
+    got = scipy.io.mmread(out).toarray()
+    assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
+
+    # ComplexMatrix: exp of the Hermitian "Guo" matrix built from the reference's input graph
+    out = str(tmp_path / "exp-nt.mtx")
+    inp = os.path.join(data, "complexmatrix_input.mtx")
+    run("complex_cxx", grid + ["--threshold", "1e-6", "--input_file", inp, "--exponential_file", out])
+    # the same construction through the Python surface (ConstructGuoMatrix of the example, step by step) must give the
+    # matrix the golden was made from; the exponential is compared with what the REFERENCE computes for it
+    # (tests/golden/example_complexmatrix.npz).  With eigenvalues up to 25.8 the reference's Chebyshev scheme is far
+    # from scipy's expm on this input -- parity means reproducing the reference, and the engine does to 1e-9.
+    In = nt.Matrix_ps(inp)
+    nn = In.GetActualDimension()
+    tl = nt.TripletList_r()
+    In.GetTripletList(tl)
+    c, r, v = tl.arrays()
+    off = c != r
+    st = nt.TripletList_r()
+    st.set_arrays(np.concatenate([c, r[off]]), np.concatenate([r, c[off]]), np.concatenate([v, v[off]]))
+    SMat = nt.Matrix_ps(nn)
+    SMat.FillFromTripletList(st)
+    Guide = nt.Matrix_ps(SMat)
+    Guide.Increment(In, -1.0)
+    tg = nt.TripletList_r()
+    Guide.GetTripletList(tg)
+    gc, gr, gv = tg.arrays()
+    cl = nt.TripletList_c()
+    cl.set_arrays(gc, gr, np.full(len(gc), 1j))
+    CM = nt.Matrix_ps(nn)
+    CM.FillFromTripletList(cl)
+    G = nt.Matrix_ps(nn)
+    G.Transpose(CM)
+    G.Conjugate()
+    G.Increment(CM)
+    G.Increment(SMat)
+    G.Scale(0.5)
+    gx = Golden("example_complexmatrix")
+    assert np.abs(G.to_scipy().toarray() - to_dense(gx.tri(None, "G"))).max() == 0.0
+    want = to_dense(gx.tri(None, "K"))
+    got = scipy.io.mmread(out).toarray()
+    assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+
+    # MatrixMaps: entries on or below the diagonal doubled, the rest dropped
+    out = str(tmp_path / "output.mtx")
+    inp = os.path.join(data, "matrixmaps_input.mtx")
+    run("maps_cxx", ["--process_slices", "1", "--input_matrix", inp, "--output_matrix", out])
+    A = scipy.io.mmread(inp).toarray()
+    assert np.abs(scipy.io.mmread(out).toarray() - 2.0 * np.tril(A)).max() <= 1e-14 * np.abs(A).max()
