@@ -117,6 +117,9 @@ MODULE NTPolyAMDBindings
      SUBROUTINE AppendToTripletList_r_wrp(ih, c, r, v) BIND(C, name="AppendToTripletList_r_wrp")
        IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*); INTEGER(c_int), INTENT(IN) :: c, r; REAL(c_double), INTENT(IN) :: v
      END SUBROUTINE
+     SUBROUTINE SetTripletAt_r_wrp(ih, idx, c, r, v) BIND(C, name="SetTripletAt_r_wrp")
+       IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*); INTEGER(c_int), INTENT(IN) :: idx, c, r; REAL(c_double), INTENT(IN) :: v
+     END SUBROUTINE
      SUBROUTINE GetTripletAt_r_wrp(ih, idx, c, r, v) BIND(C, name="GetTripletAt_r_wrp")
        IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*), idx; INTEGER(c_int), INTENT(OUT) :: c, r; REAL(c_double), INTENT(OUT) :: v
      END SUBROUTINE
@@ -382,8 +385,7 @@ CONTAINS
   END SUBROUTINE DestructPermutation
 END MODULE PermutationModule
 
-MODULE TripletListModule   !< TripletListModule.F90 (real lists)
-  USE NTPolyAMDBindings
+MODULE TripletModule   !< TripletModule.F90: the (column, row, value) record
   USE DataTypesModule, ONLY : NTREAL
   IMPLICIT NONE
   PRIVATE
@@ -391,11 +393,28 @@ MODULE TripletListModule   !< TripletListModule.F90 (real lists)
      INTEGER :: index_column = 0, index_row = 0
      REAL(NTREAL) :: point_value = 0
   END TYPE Triplet_r
+END MODULE TripletModule
+
+MODULE TripletListModule   !< TripletListModule.F90 (real lists)
+  USE NTPolyAMDBindings
+  USE DataTypesModule, ONLY : NTREAL
+  USE TripletModule, ONLY : Triplet_r
+  IMPLICIT NONE
+  PRIVATE
+  PUBLIC :: Triplet_r
   TYPE, PUBLIC :: TripletList_r
      INTEGER(c_int) :: ih(SIZE_wrp) = 0
   END TYPE TripletList_r
-  PUBLIC :: ConstructTripletList, DestructTripletList, AppendToTripletList, GetTripletAt, GetTripletListSize
+  PUBLIC :: ConstructTripletList, DestructTripletList, AppendToTripletList, GetTripletAt, GetTripletListSize, &
+       & SetTripletAt
 CONTAINS
+  SUBROUTINE SetTripletAt(this, index, triplet)
+    TYPE(TripletList_r), INTENT(INOUT) :: this
+    INTEGER, INTENT(IN) :: index
+    TYPE(Triplet_r), INTENT(IN) :: triplet
+    CALL SetTripletAt_r_wrp(this%ih, INT(index, c_int), INT(triplet%index_column, c_int), &
+         & INT(triplet%index_row, c_int), triplet%point_value)
+  END SUBROUTINE SetTripletAt
   SUBROUTINE ConstructTripletList(this, size_in)
     TYPE(TripletList_r), INTENT(INOUT) :: this
     INTEGER, INTENT(IN), OPTIONAL :: size_in

@@ -18,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "oracle", "_ref")
 FLANG = "/opt/rocm/lib/llvm/bin/flang"
+# executable name -> the reference's unchanged Fortran example driver
+EXAMPLES = {"premade_f90": "PremadeMatrix", "hydrogen_f90": "HydrogenAtom", "graph_f90": "GraphTheory"}
 
 
 def build():
@@ -29,12 +31,12 @@ def build():
     shim = os.path.join(work, "mpi_shim.f90")
     with open(shim, "w") as f:
         f.write("MODULE MPI\n  INCLUDE \"mpif.h\"\nEND MODULE MPI\n")
-    objs = []
-    for name, src in (("mods", os.path.join(ROOT, "fortran", "ntpoly_amd_modules.f90")), ("mpi_shim", shim),
-                      ("premade_main", REF + "/Examples/PremadeMatrix/main.f90")):
+    common = []
+    for name, src in (("mods", os.path.join(ROOT, "fortran", "ntpoly_amd_modules.f90")),
+                      ("mods_more", os.path.join(ROOT, "fortran", "ntpoly_amd_modules_more.f90")), ("mpi_shim", shim)):
         obj = os.path.join(work, name + ".o")
         subprocess.run([FLANG, "-O1", "-cpp", "-c", src, "-o", obj, "-J", work, "-I", work, "-I/opt/conda/include"], check=True)
-        objs.append(obj)
+        common.append(obj)
     mpidir = os.path.join(OUT, "mpilib")
     os.makedirs(mpidir, exist_ok=True)
     for lib in ("libmpi.so.12", "libmpifort.so.12", "libgfortran.so.4", "libquadmath.so.0", "libgomp.so.1"):
@@ -42,12 +44,18 @@ def build():
         if os.path.lexists(dst):
             os.unlink(dst)
         os.symlink(os.path.join("/opt/conda/lib", lib), dst)
-    exe = os.path.join(OUT, "premade_f90")
-    subprocess.run([FLANG, "-o", exe] + objs + ["-L" + os.path.join(ROOT, "ntpoly_amd"), "-lntpoly_amd",
-                                                "/opt/conda/lib/libmpifort.so", "/opt/conda/lib/libmpi.so",
-                                                "-Wl,-rpath,$ORIGIN/../../ntpoly_amd", "-Wl,-rpath,$ORIGIN/mpilib",
-                                                "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"], check=True)
-    print("built", exe)
+    exe = None
+    for name, example in EXAMPLES.items():
+        obj = os.path.join(work, name + "_main.o")
+        subprocess.run([FLANG, "-O1", "-cpp", "-c", "%s/Examples/%s/main.f90" % (REF, example), "-o", obj, "-J", work,
+                        "-I", work, "-I/opt/conda/include"], check=True)
+        exe = os.path.join(OUT, name)
+        subprocess.run([FLANG, "-o", exe, obj] + common + ["-L" + os.path.join(ROOT, "ntpoly_amd"), "-lntpoly_amd",
+                                                            "/opt/conda/lib/libmpifort.so", "/opt/conda/lib/libmpi.so",
+                                                            "-Wl,-rpath,$ORIGIN/../../ntpoly_amd", "-Wl,-rpath,$ORIGIN/mpilib",
+                                                            "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"],
+                       check=True)
+        print("built", exe)
     return exe
 
 

@@ -728,6 +728,21 @@ def test_reference_cxx_examples_run(nt, tmp_path):
     got = scipy.io.mmread(out).toarray()
     assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
 
+    # the Fortran versions of two of them (Examples/{HydrogenAtom,GraphTheory}/main.f90, unchanged, over the product's
+    # Fortran module layer; oracle/build_fortran_example.py).  The Fortran graph example draws its extra connections
+    # with RANDOM_NUMBER, so it runs without them (a plain chain), which numpy can restate.
+    if all(os.path.exists(os.path.join(ref, e)) for e in ("hydrogen_f90", "graph_f90")):
+        out = str(tmp_path / "DensityF.mtx")
+        run("hydrogen_f90", grid + ["--threshold", "1e-6", "--convergence_threshold", "1e-5", "--grid_points", "100", "--density", out])
+        D = scipy.io.mmread(out).toarray()
+        assert abs(np.trace(D) - 1.0) <= 1e-4 and np.abs(D - D.T).max() <= 1e-6 and np.abs(D @ D - D).max() <= 1e-3
+        out = str(tmp_path / "OutputF.mtx")
+        run("graph_f90", grid + ["--threshold", "1e-6", "--convergence_threshold", "1e-4", "--number_of_nodes", "400",
+                                 "--extra_connections", "0", "--attenuation", "0.7", "--output_file", out])
+        Mc = np.eye(400) + 0.1 * (np.eye(400, k=1) + np.eye(400, k=-1))
+        want = np.linalg.inv(np.eye(400) - 0.7 * Mc)
+        assert np.abs(scipy.io.mmread(out).toarray() - want).max() <= 1e-3 * np.abs(want).max()
+
     # MatrixMaps: entries on or below the diagonal doubled, the rest dropped
     out = str(tmp_path / "output.mtx")
     inp = os.path.join(data, "matrixmaps_input.mtx")
