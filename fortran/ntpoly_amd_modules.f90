@@ -25,10 +25,34 @@ MODULE NTPolyAMDBindings
      SUBROUTINE ConstructGlobalProcessGrid_wrp(comm, r, c, s) BIND(C, name="ConstructGlobalProcessGrid_wrp")
        IMPORT; INTEGER(c_int), INTENT(IN) :: comm, r, c, s
      END SUBROUTINE
+     SUBROUTINE ConstructGlobalProcessGrid_onlyslice_wrp(comm, s) BIND(C, name="ConstructGlobalProcessGrid_onlyslice_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: comm, s
+     END SUBROUTINE
+     SUBROUTINE ConstructGlobalProcessGrid_default_wrp(comm) BIND(C, name="ConstructGlobalProcessGrid_default_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: comm
+     END SUBROUTINE
      SUBROUTINE DestructGlobalProcessGrid_wrp() BIND(C, name="DestructGlobalProcessGrid_wrp")
      END SUBROUTINE
      FUNCTION GetGlobalIsRoot_wrp() BIND(C, name="GetGlobalIsRoot_wrp") RESULT(v)
        IMPORT; LOGICAL(c_bool) :: v
+     END FUNCTION
+     FUNCTION GetGlobalNumRows_wrp() BIND(C, name="GetGlobalNumRows_wrp") RESULT(v)
+       IMPORT; INTEGER(c_int) :: v
+     END FUNCTION
+     FUNCTION GetGlobalNumColumns_wrp() BIND(C, name="GetGlobalNumColumns_wrp") RESULT(v)
+       IMPORT; INTEGER(c_int) :: v
+     END FUNCTION
+     FUNCTION GetGlobalNumSlices_wrp() BIND(C, name="GetGlobalNumSlices_wrp") RESULT(v)
+       IMPORT; INTEGER(c_int) :: v
+     END FUNCTION
+     FUNCTION GetGlobalMyRow_wrp() BIND(C, name="GetGlobalMyRow_wrp") RESULT(v)
+       IMPORT; INTEGER(c_int) :: v
+     END FUNCTION
+     FUNCTION GetGlobalMyColumn_wrp() BIND(C, name="GetGlobalMyColumn_wrp") RESULT(v)
+       IMPORT; INTEGER(c_int) :: v
+     END FUNCTION
+     FUNCTION GetGlobalMySlice_wrp() BIND(C, name="GetGlobalMySlice_wrp") RESULT(v)
+       IMPORT; INTEGER(c_int) :: v
      END FUNCTION
      SUBROUTINE WriteGlobalProcessGridInfo_wrp() BIND(C, name="WriteGlobalProcessGridInfo_wrp")
      END SUBROUTINE
@@ -263,18 +287,44 @@ MODULE ProcessGridModule   !< ProcessGridModule.F90:15-56, 130-264 (global grid 
   USE NTPolyAMDBindings
   IMPLICIT NONE
   PRIVATE
-  TYPE, PUBLIC :: ProcessGrid_t
-     INTEGER :: dummy = 0   !< the engine keeps one global grid; per-matrix grids are not mirrored
+  TYPE, PUBLIC :: ProcessGrid_t   !< the members user code reads (ProcessGridModule.F90:15-56); the engine keeps ONE grid
+     INTEGER :: num_process_rows = 1, num_process_columns = 1, num_process_slices = 1
+     INTEGER :: my_row = 0, my_column = 0, my_slice = 0
   END TYPE ProcessGrid_t
+  TYPE(ProcessGrid_t), PUBLIC, SAVE :: global_grid
   PUBLIC :: ConstructProcessGrid, DestructProcessGrid, IsRoot, WriteProcessGridInfo
+  INTERFACE ConstructProcessGrid   !< ProcessGridModule.F90: full grid, or only the number of slices (rest chosen)
+     MODULE PROCEDURE ConstructProcessGrid_full
+     MODULE PROCEDURE ConstructProcessGrid_onlyslice
+  END INTERFACE ConstructProcessGrid
 CONTAINS
-  SUBROUTINE ConstructProcessGrid(world_comm, process_rows, process_columns, process_slices, be_verbose_in)
+  SUBROUTINE RefreshGlobalGrid()
+    global_grid%num_process_rows = GetGlobalNumRows_wrp()
+    global_grid%num_process_columns = GetGlobalNumColumns_wrp()
+    global_grid%num_process_slices = GetGlobalNumSlices_wrp()
+    global_grid%my_row = GetGlobalMyRow_wrp()
+    global_grid%my_column = GetGlobalMyColumn_wrp()
+    global_grid%my_slice = GetGlobalMySlice_wrp()
+  END SUBROUTINE RefreshGlobalGrid
+  SUBROUTINE ConstructProcessGrid_onlyslice(world_comm, process_slices_in, be_verbose_in)
+    INTEGER, INTENT(IN) :: world_comm
+    INTEGER, INTENT(IN), OPTIONAL :: process_slices_in
+    LOGICAL, INTENT(IN), OPTIONAL :: be_verbose_in
+    IF (PRESENT(process_slices_in)) THEN
+       CALL ConstructGlobalProcessGrid_onlyslice_wrp(INT(world_comm, c_int), INT(process_slices_in, c_int))
+    ELSE
+       CALL ConstructGlobalProcessGrid_default_wrp(INT(world_comm, c_int))
+    END IF
+    CALL RefreshGlobalGrid
+  END SUBROUTINE ConstructProcessGrid_onlyslice
+  SUBROUTINE ConstructProcessGrid_full(world_comm, process_rows, process_columns, process_slices, be_verbose_in)
     INTEGER, INTENT(IN) :: world_comm
     INTEGER, INTENT(IN) :: process_rows, process_columns, process_slices
     LOGICAL, INTENT(IN), OPTIONAL :: be_verbose_in
     CALL ConstructGlobalProcessGrid_wrp(INT(world_comm, c_int), INT(process_rows, c_int), &
          & INT(process_columns, c_int), INT(process_slices, c_int))
-  END SUBROUTINE ConstructProcessGrid
+    CALL RefreshGlobalGrid
+  END SUBROUTINE ConstructProcessGrid_full
   SUBROUTINE DestructProcessGrid()
     CALL DestructGlobalProcessGrid_wrp
   END SUBROUTINE DestructProcessGrid

@@ -731,7 +731,7 @@ def test_reference_cxx_examples_run(nt, tmp_path):
     # the Fortran versions of two of them (Examples/{HydrogenAtom,GraphTheory}/main.f90, unchanged, over the product's
     # Fortran module layer; oracle/build_fortran_example.py).  The Fortran graph example draws its extra connections
     # with RANDOM_NUMBER, so it runs without them (a plain chain), which numpy can restate.
-    if all(os.path.exists(os.path.join(ref, e)) for e in ("hydrogen_f90", "graph_f90")):
+    if all(os.path.exists(os.path.join(ref, e)) for e in ("hydrogen_f90", "graph_f90")):  # (built where flang is)
         out = str(tmp_path / "DensityF.mtx")
         run("hydrogen_f90", grid + ["--threshold", "1e-6", "--convergence_threshold", "1e-5", "--grid_points", "100", "--density", out])
         D = scipy.io.mmread(out).toarray()
@@ -742,6 +742,23 @@ def test_reference_cxx_examples_run(nt, tmp_path):
         Mc = np.eye(400) + 0.1 * (np.eye(400, k=1) + np.eye(400, k=-1))
         want = np.linalg.inv(np.eye(400) - 0.7 * Mc)
         assert np.abs(scipy.io.mmread(out).toarray() - want).max() <= 1e-3 * np.abs(want).max()
+
+    # Fortran MatrixMaps (MapMatrix_psr with the example's own procedure) and OverlapMatrix (TimerModule, global_grid,
+    # a load-balanced InverseSquareRoot of S_ij = 1 / (|i - j| + 1); the example writes no file, its log must show
+    # the timers and a converged solver)
+    if all(os.path.exists(os.path.join(ref, e)) for e in ("maps_f90", "overlap_f90")):
+        import shutil
+        shutil.copy(os.path.join(data, "matrixmaps_input.mtx"), str(tmp_path / "mapsin.mtx"))   # (the example reads
+        run("maps_f90", ["--process_slices", "1", "--input_matrix", "mapsin.mtx", "--output_matrix", "mapsout.mtx"])  # 80-char names)
+        Am = scipy.io.mmread(str(tmp_path / "mapsin.mtx")).toarray()
+        assert np.abs(scipy.io.mmread(str(tmp_path / "mapsout.mtx")).toarray() - 2.0 * np.tril(Am)).max() <= 1e-14 * np.abs(Am).max()
+        log = run("overlap_f90", grid + ["--threshold", "1e-6", "--convergence_threshold", "1e-5", "--basis_functions", "100"])
+        assert "Timers" in log and "Construct Triplet List" in log and "Solve" in log and "Total Iterations" in log
+        Sm = scipy.io.mmread(str(tmp_path / "input.mtx")).toarray()       # the example writes both matrices
+        Zm = scipy.io.mmread(str(tmp_path / "output.mtx")).toarray()
+        ii = np.arange(100)
+        assert np.abs(Sm - 1.0 / (np.abs(ii[:, None] - ii[None, :]) + 1.0)).max() <= 1e-6    # entries <= threshold dropped
+        assert np.abs(Zm @ Sm @ Zm - np.eye(100)).max() <= 1e-3
 
     # MatrixMaps: entries on or below the diagonal doubled, the rest dropped
     out = str(tmp_path / "output.mtx")
