@@ -132,6 +132,30 @@ MODULE NTPolyAMDBindings
      SUBROUTINE GershgorinBounds_wrp(a, mn, mx) BIND(C, name="GershgorinBounds_wrp")
        IMPORT; INTEGER(c_int), INTENT(IN) :: a(*); REAL(c_double), INTENT(OUT) :: mn, mx
      END SUBROUTINE
+     SUBROUTINE ConstructTripletList_c_wrp(ih, n) BIND(C, name="ConstructTripletList_c_wrp")
+       IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*); INTEGER(c_int), INTENT(IN) :: n
+     END SUBROUTINE
+     SUBROUTINE DestructTripletList_c_wrp(ih) BIND(C, name="DestructTripletList_c_wrp")
+       IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*)
+     END SUBROUTINE
+     SUBROUTINE AppendToTripletList_c_wrp(ih, c, r, re, im) BIND(C, name="AppendToTripletList_c_wrp")
+       IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*); INTEGER(c_int), INTENT(IN) :: c, r; REAL(c_double), INTENT(IN) :: re, im
+     END SUBROUTINE
+     SUBROUTINE SetTripletAt_c_wrp(ih, idx, c, r, re, im) BIND(C, name="SetTripletAt_c_wrp")
+       IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*); INTEGER(c_int), INTENT(IN) :: idx, c, r; REAL(c_double), INTENT(IN) :: re, im
+     END SUBROUTINE
+     SUBROUTINE GetTripletAt_c_wrp(ih, idx, c, r, re, im) BIND(C, name="GetTripletAt_c_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*), idx; INTEGER(c_int), INTENT(OUT) :: c, r; REAL(c_double), INTENT(OUT) :: re, im
+     END SUBROUTINE
+     FUNCTION GetTripletListSize_c_wrp(ih) BIND(C, name="GetTripletListSize_c_wrp") RESULT(n)
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*); INTEGER(c_int) :: n
+     END FUNCTION
+     SUBROUTINE FillMatrixFromTripletList_psc_wrp(ih, tl) BIND(C, name="FillMatrixFromTripletList_psc_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*), tl(*)
+     END SUBROUTINE
+     SUBROUTINE GetMatrixTripletList_psc_wrp(ih, tl) BIND(C, name="GetMatrixTripletList_psc_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*); INTEGER(c_int), INTENT(INOUT) :: tl(*)
+     END SUBROUTINE
      SUBROUTINE ConstructTripletList_r_wrp(ih, n) BIND(C, name="ConstructTripletList_r_wrp")
        IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*); INTEGER(c_int), INTENT(IN) :: n
      END SUBROUTINE
@@ -436,56 +460,135 @@ CONTAINS
 END MODULE PermutationModule
 
 MODULE TripletModule   !< TripletModule.F90: the (column, row, value) record
-  USE DataTypesModule, ONLY : NTREAL
+  USE DataTypesModule, ONLY : NTREAL, NTCOMPLEX
   IMPLICIT NONE
   PRIVATE
   TYPE, PUBLIC :: Triplet_r
      INTEGER :: index_column = 0, index_row = 0
      REAL(NTREAL) :: point_value = 0
   END TYPE Triplet_r
+  TYPE, PUBLIC :: Triplet_c
+     INTEGER :: index_column = 0, index_row = 0
+     COMPLEX(NTCOMPLEX) :: point_value = 0
+  END TYPE Triplet_c
 END MODULE TripletModule
 
-MODULE TripletListModule   !< TripletListModule.F90 (real lists)
+MODULE MatrixMarketModule   !< MatrixMarketModule.F90:19-28: the symmetry kinds of the file format
+  IMPLICIT NONE
+  PUBLIC
+  ENUM, BIND(c)
+     ENUMERATOR :: MM_GENERAL = 1
+     ENUMERATOR :: MM_SYMMETRIC = 2
+     ENUMERATOR :: MM_SKEW_SYMMETRIC = 3
+     ENUMERATOR :: MM_HERMITIAN = 4
+  END ENUM
+END MODULE MatrixMarketModule
+
+MODULE TripletListModule   !< TripletListModule.F90: lists live in the engine; CurrentSize is mirrored for user code
   USE NTPolyAMDBindings
-  USE DataTypesModule, ONLY : NTREAL
-  USE TripletModule, ONLY : Triplet_r
+  USE DataTypesModule, ONLY : NTREAL, NTCOMPLEX
+  USE TripletModule, ONLY : Triplet_r, Triplet_c
+  USE MatrixMarketModule, ONLY : MM_SYMMETRIC, MM_SKEW_SYMMETRIC, MM_HERMITIAN
   IMPLICIT NONE
   PRIVATE
-  PUBLIC :: Triplet_r
+  PUBLIC :: Triplet_r, Triplet_c
   TYPE, PUBLIC :: TripletList_r
      INTEGER(c_int) :: ih(SIZE_wrp) = 0
+     INTEGER :: CurrentSize = 0
   END TYPE TripletList_r
+  TYPE, PUBLIC :: TripletList_c
+     INTEGER(c_int) :: ih(SIZE_wrp) = 0
+     INTEGER :: CurrentSize = 0
+  END TYPE TripletList_c
   PUBLIC :: ConstructTripletList, DestructTripletList, AppendToTripletList, GetTripletAt, GetTripletListSize, &
-       & SetTripletAt
+       & SetTripletAt, SymmetrizeTripletList, SyncTripletListSize
+  INTERFACE ConstructTripletList
+     MODULE PROCEDURE ConstructTripletList_r, ConstructTripletList_c
+  END INTERFACE ConstructTripletList
+  INTERFACE DestructTripletList
+     MODULE PROCEDURE DestructTripletList_r, DestructTripletList_c
+  END INTERFACE DestructTripletList
+  INTERFACE AppendToTripletList
+     MODULE PROCEDURE AppendToTripletList_r, AppendToTripletList_c
+  END INTERFACE AppendToTripletList
+  INTERFACE GetTripletAt
+     MODULE PROCEDURE GetTripletAt_r, GetTripletAt_c
+  END INTERFACE GetTripletAt
+  INTERFACE SetTripletAt
+     MODULE PROCEDURE SetTripletAt_r, SetTripletAt_c
+  END INTERFACE SetTripletAt
+  INTERFACE GetTripletListSize
+     MODULE PROCEDURE GetTripletListSize_r, GetTripletListSize_c
+  END INTERFACE GetTripletListSize
+  INTERFACE SymmetrizeTripletList
+     MODULE PROCEDURE SymmetrizeTripletList_r, SymmetrizeTripletList_c
+  END INTERFACE SymmetrizeTripletList
+  INTERFACE SyncTripletListSize   !< after the engine filled a list (GetMatrixTripletList)
+     MODULE PROCEDURE SyncTripletListSize_r, SyncTripletListSize_c
+  END INTERFACE SyncTripletListSize
 CONTAINS
-  SUBROUTINE SetTripletAt(this, index, triplet)
+  SUBROUTINE ConstructTripletList_r(this, size_in)
+    TYPE(TripletList_r), INTENT(INOUT) :: this
+    INTEGER, INTENT(IN), OPTIONAL :: size_in
+    INTEGER(c_int) :: n
+    CALL DestructTripletList_r(this)
+    n = 0
+    IF (PRESENT(size_in)) n = size_in
+    CALL ConstructTripletList_r_wrp(this%ih, n)
+    this%CurrentSize = n
+  END SUBROUTINE ConstructTripletList_r
+  SUBROUTINE ConstructTripletList_c(this, size_in)
+    TYPE(TripletList_c), INTENT(INOUT) :: this
+    INTEGER, INTENT(IN), OPTIONAL :: size_in
+    INTEGER(c_int) :: n
+    CALL DestructTripletList_c(this)
+    n = 0
+    IF (PRESENT(size_in)) n = size_in
+    CALL ConstructTripletList_c_wrp(this%ih, n)
+    this%CurrentSize = n
+  END SUBROUTINE ConstructTripletList_c
+  SUBROUTINE DestructTripletList_r(this)
+    TYPE(TripletList_r), INTENT(INOUT) :: this
+    IF (ANY(this%ih .NE. 0)) CALL DestructTripletList_r_wrp(this%ih)
+    this%ih = 0
+    this%CurrentSize = 0
+  END SUBROUTINE DestructTripletList_r
+  SUBROUTINE DestructTripletList_c(this)
+    TYPE(TripletList_c), INTENT(INOUT) :: this
+    IF (ANY(this%ih .NE. 0)) CALL DestructTripletList_c_wrp(this%ih)
+    this%ih = 0
+    this%CurrentSize = 0
+  END SUBROUTINE DestructTripletList_c
+  SUBROUTINE AppendToTripletList_r(this, triplet)
+    TYPE(TripletList_r), INTENT(INOUT) :: this
+    TYPE(Triplet_r), INTENT(IN) :: triplet
+    IF (ALL(this%ih .EQ. 0)) CALL ConstructTripletList_r_wrp(this%ih, 0_c_int)
+    CALL AppendToTripletList_r_wrp(this%ih, INT(triplet%index_column, c_int), INT(triplet%index_row, c_int), triplet%point_value)
+    this%CurrentSize = this%CurrentSize + 1
+  END SUBROUTINE AppendToTripletList_r
+  SUBROUTINE AppendToTripletList_c(this, triplet)
+    TYPE(TripletList_c), INTENT(INOUT) :: this
+    TYPE(Triplet_c), INTENT(IN) :: triplet
+    IF (ALL(this%ih .EQ. 0)) CALL ConstructTripletList_c_wrp(this%ih, 0_c_int)
+    CALL AppendToTripletList_c_wrp(this%ih, INT(triplet%index_column, c_int), INT(triplet%index_row, c_int), &
+         & REAL(triplet%point_value, c_double), REAL(AIMAG(triplet%point_value), c_double))
+    this%CurrentSize = this%CurrentSize + 1
+  END SUBROUTINE AppendToTripletList_c
+  SUBROUTINE SetTripletAt_r(this, index, triplet)
     TYPE(TripletList_r), INTENT(INOUT) :: this
     INTEGER, INTENT(IN) :: index
     TYPE(Triplet_r), INTENT(IN) :: triplet
     CALL SetTripletAt_r_wrp(this%ih, INT(index, c_int), INT(triplet%index_column, c_int), &
          & INT(triplet%index_row, c_int), triplet%point_value)
-  END SUBROUTINE SetTripletAt
-  SUBROUTINE ConstructTripletList(this, size_in)
-    TYPE(TripletList_r), INTENT(INOUT) :: this
-    INTEGER, INTENT(IN), OPTIONAL :: size_in
-    INTEGER(c_int) :: n
-    CALL DestructTripletList(this)
-    n = 0
-    IF (PRESENT(size_in)) n = size_in
-    CALL ConstructTripletList_r_wrp(this%ih, n)
-  END SUBROUTINE ConstructTripletList
-  SUBROUTINE DestructTripletList(this)
-    TYPE(TripletList_r), INTENT(INOUT) :: this
-    IF (ANY(this%ih .NE. 0)) CALL DestructTripletList_r_wrp(this%ih)
-    this%ih = 0
-  END SUBROUTINE DestructTripletList
-  SUBROUTINE AppendToTripletList(this, triplet)
-    TYPE(TripletList_r), INTENT(INOUT) :: this
-    TYPE(Triplet_r), INTENT(IN) :: triplet
-    IF (ALL(this%ih .EQ. 0)) CALL ConstructTripletList_r_wrp(this%ih, 0_c_int)
-    CALL AppendToTripletList_r_wrp(this%ih, INT(triplet%index_column, c_int), INT(triplet%index_row, c_int), triplet%point_value)
-  END SUBROUTINE AppendToTripletList
-  SUBROUTINE GetTripletAt(this, index, triplet)
+  END SUBROUTINE SetTripletAt_r
+  SUBROUTINE SetTripletAt_c(this, index, triplet)
+    TYPE(TripletList_c), INTENT(INOUT) :: this
+    INTEGER, INTENT(IN) :: index
+    TYPE(Triplet_c), INTENT(IN) :: triplet
+    CALL SetTripletAt_c_wrp(this%ih, INT(index, c_int), INT(triplet%index_column, c_int), &
+         & INT(triplet%index_row, c_int), REAL(triplet%point_value, c_double), REAL(AIMAG(triplet%point_value), c_double))
+  END SUBROUTINE SetTripletAt_c
+  SUBROUTINE GetTripletAt_r(this, index, triplet)
     TYPE(TripletList_r), INTENT(IN) :: this
     INTEGER, INTENT(IN) :: index
     TYPE(Triplet_r), INTENT(OUT) :: triplet
@@ -493,18 +596,80 @@ CONTAINS
     CALL GetTripletAt_r_wrp(this%ih, INT(index, c_int), c, r, triplet%point_value)
     triplet%index_column = c
     triplet%index_row = r
-  END SUBROUTINE GetTripletAt
-  FUNCTION GetTripletListSize(this) RESULT(n)
+  END SUBROUTINE GetTripletAt_r
+  SUBROUTINE GetTripletAt_c(this, index, triplet)
+    TYPE(TripletList_c), INTENT(IN) :: this
+    INTEGER, INTENT(IN) :: index
+    TYPE(Triplet_c), INTENT(OUT) :: triplet
+    INTEGER(c_int) :: c, r
+    REAL(c_double) :: re, im
+    CALL GetTripletAt_c_wrp(this%ih, INT(index, c_int), c, r, re, im)
+    triplet%index_column = c
+    triplet%index_row = r
+    triplet%point_value = CMPLX(re, im, KIND=NTCOMPLEX)
+  END SUBROUTINE GetTripletAt_c
+  FUNCTION GetTripletListSize_r(this) RESULT(n)
     TYPE(TripletList_r), INTENT(IN) :: this
     INTEGER :: n
     n = GetTripletListSize_r_wrp(this%ih)
-  END FUNCTION GetTripletListSize
+  END FUNCTION GetTripletListSize_r
+  FUNCTION GetTripletListSize_c(this) RESULT(n)
+    TYPE(TripletList_c), INTENT(IN) :: this
+    INTEGER :: n
+    n = GetTripletListSize_c_wrp(this%ih)
+  END FUNCTION GetTripletListSize_c
+  SUBROUTINE SyncTripletListSize_r(this)
+    TYPE(TripletList_r), INTENT(INOUT) :: this
+    this%CurrentSize = GetTripletListSize_r_wrp(this%ih)
+  END SUBROUTINE SyncTripletListSize_r
+  SUBROUTINE SyncTripletListSize_c(this)
+    TYPE(TripletList_c), INTENT(INOUT) :: this
+    this%CurrentSize = GetTripletListSize_c_wrp(this%ih)
+  END SUBROUTINE SyncTripletListSize_c
+  !> TripletListModule.F90:509-575: append the mirrored off-diagonal entries
+  SUBROUTINE SymmetrizeTripletList_r(triplet_list, pattern_type)
+    TYPE(TripletList_r), INTENT(INOUT) :: triplet_list
+    INTEGER, INTENT(IN) :: pattern_type
+    TYPE(Triplet_r) :: trip, trip_t
+    INTEGER :: II, initial_size
+    initial_size = triplet_list%CurrentSize
+    IF (pattern_type .NE. MM_SYMMETRIC .AND. pattern_type .NE. MM_SKEW_SYMMETRIC) RETURN
+    DO II = 1, initial_size
+       CALL GetTripletAt_r(triplet_list, II, trip)
+       IF (trip%index_column .NE. trip%index_row) THEN
+          trip_t%index_row = trip%index_column
+          trip_t%index_column = trip%index_row
+          trip_t%point_value = trip%point_value
+          IF (pattern_type .EQ. MM_SKEW_SYMMETRIC) trip_t%point_value = -1.0 * trip%point_value
+          CALL AppendToTripletList_r(triplet_list, trip_t)
+       END IF
+    END DO
+  END SUBROUTINE SymmetrizeTripletList_r
+  SUBROUTINE SymmetrizeTripletList_c(triplet_list, pattern_type)
+    TYPE(TripletList_c), INTENT(INOUT) :: triplet_list
+    INTEGER, INTENT(IN) :: pattern_type
+    TYPE(Triplet_c) :: trip, trip_t
+    INTEGER :: II, initial_size
+    initial_size = triplet_list%CurrentSize
+    IF (pattern_type .NE. MM_SYMMETRIC .AND. pattern_type .NE. MM_SKEW_SYMMETRIC .AND. pattern_type .NE. MM_HERMITIAN) RETURN
+    DO II = 1, initial_size
+       CALL GetTripletAt_c(triplet_list, II, trip)
+       IF (trip%index_column .NE. trip%index_row) THEN
+          trip_t%index_row = trip%index_column
+          trip_t%index_column = trip%index_row
+          trip_t%point_value = trip%point_value
+          IF (pattern_type .EQ. MM_SKEW_SYMMETRIC) trip_t%point_value = -1.0 * trip%point_value
+          IF (pattern_type .EQ. MM_HERMITIAN) trip_t%point_value = CONJG(trip%point_value)
+          CALL AppendToTripletList_c(triplet_list, trip_t)
+       END IF
+    END DO
+  END SUBROUTINE SymmetrizeTripletList_c
 END MODULE TripletListModule
 
 MODULE PSMatrixModule   !< PSMatrixModule.F90:33-51 and the routines user code calls
   USE NTPolyAMDBindings
   USE DataTypesModule, ONLY : NTREAL, NTLONG
-  USE TripletListModule, ONLY : TripletList_r
+  USE TripletListModule, ONLY : TripletList_r, TripletList_c, SyncTripletListSize
   IMPLICIT NONE
   PRIVATE
   TYPE, PUBLIC :: Matrix_ps
@@ -516,7 +681,13 @@ MODULE PSMatrixModule   !< PSMatrixModule.F90:33-51 and the routines user code c
   PUBLIC :: ConstructEmptyMatrix, ConstructMatrixFromMatrixMarket, ConstructMatrixFromBinary, &
        & WriteMatrixToMatrixMarket, WriteMatrixToBinary, DestructMatrix, CopyMatrix, FillMatrixIdentity, &
        & FillMatrixFromTripletList, GetMatrixTripletList, GetMatrixSize, GetMatrixActualDimension, &
-       & GetMatrixLogicalDimension, TransposeMatrix, ConjugateMatrix, PrepareOutput, RefreshMatrix
+       & GetMatrixLogicalDimension, TransposeMatrix, ConjugateMatrix, PrepareOutput, RefreshMatrix, PrintMatrix
+  INTERFACE FillMatrixFromTripletList
+     MODULE PROCEDURE FillMatrixFromTripletList_r, FillMatrixFromTripletList_c
+  END INTERFACE FillMatrixFromTripletList
+  INTERFACE GetMatrixTripletList
+     MODULE PROCEDURE GetMatrixTripletList_r, GetMatrixTripletList_c
+  END INTERFACE GetMatrixTripletList
   INTERFACE ConstructEmptyMatrix
      MODULE PROCEDURE ConstructEmptyMatrix_dim, ConstructEmptyMatrix_like
   END INTERFACE ConstructEmptyMatrix
@@ -598,19 +769,44 @@ CONTAINS
     TYPE(Matrix_ps), INTENT(INOUT) :: this
     CALL FillMatrixIdentity_ps_wrp(this%ih)
   END SUBROUTINE FillMatrixIdentity
-  SUBROUTINE FillMatrixFromTripletList(this, triplet_list, preduplicated_in, prepartitioned_in)
+  SUBROUTINE FillMatrixFromTripletList_r(this, triplet_list, preduplicated_in, prepartitioned_in)
     TYPE(Matrix_ps), INTENT(INOUT) :: this
     TYPE(TripletList_r), INTENT(IN) :: triplet_list
     LOGICAL, INTENT(IN), OPTIONAL :: preduplicated_in, prepartitioned_in
     CALL FillMatrixFromTripletList_psr_wrp(this%ih, triplet_list%ih)
     CALL RefreshMatrix(this)
-  END SUBROUTINE FillMatrixFromTripletList
-  SUBROUTINE GetMatrixTripletList(this, triplet_list)
+  END SUBROUTINE FillMatrixFromTripletList_r
+  SUBROUTINE FillMatrixFromTripletList_c(this, triplet_list, preduplicated_in, prepartitioned_in)
+    TYPE(Matrix_ps), INTENT(INOUT) :: this
+    TYPE(TripletList_c), INTENT(IN) :: triplet_list
+    LOGICAL, INTENT(IN), OPTIONAL :: preduplicated_in, prepartitioned_in
+    CALL FillMatrixFromTripletList_psc_wrp(this%ih, triplet_list%ih)
+    CALL RefreshMatrix(this)
+  END SUBROUTINE FillMatrixFromTripletList_c
+  SUBROUTINE GetMatrixTripletList_r(this, triplet_list)
     TYPE(Matrix_ps), INTENT(IN) :: this
     TYPE(TripletList_r), INTENT(INOUT) :: triplet_list
     IF (ALL(triplet_list%ih .EQ. 0)) CALL ConstructTripletList_r_wrp(triplet_list%ih, 0_c_int)
     CALL GetMatrixTripletList_psr_wrp(this%ih, triplet_list%ih)
-  END SUBROUTINE GetMatrixTripletList
+    CALL SyncTripletListSize(triplet_list)
+  END SUBROUTINE GetMatrixTripletList_r
+  SUBROUTINE GetMatrixTripletList_c(this, triplet_list)
+    TYPE(Matrix_ps), INTENT(IN) :: this
+    TYPE(TripletList_c), INTENT(INOUT) :: triplet_list
+    IF (ALL(triplet_list%ih .EQ. 0)) CALL ConstructTripletList_c_wrp(triplet_list%ih, 0_c_int)
+    CALL GetMatrixTripletList_psc_wrp(this%ih, triplet_list%ih)
+    CALL SyncTripletListSize(triplet_list)
+  END SUBROUTINE GetMatrixTripletList_c
+  !> PrintMatrix (PSMatrixModule.F90:1271-1290): MatrixMarket text to the console, or to a file
+  SUBROUTINE PrintMatrix(this, file_name_in)
+    TYPE(Matrix_ps) :: this
+    CHARACTER(len=*), OPTIONAL, INTENT(IN) :: file_name_in
+    IF (PRESENT(file_name_in)) THEN
+       CALL WriteMatrixToMatrixMarket_ps_wrp(this%ih, cstr(file_name_in), INT(LEN_TRIM(file_name_in), c_int))
+    ELSE
+       CALL WriteMatrixToMatrixMarket_ps_wrp(this%ih, cstr("/dev/stdout"), INT(11, c_int))
+    END IF
+  END SUBROUTINE PrintMatrix
   FUNCTION GetMatrixSize(this) RESULT(total_size)
     TYPE(Matrix_ps), INTENT(IN) :: this
     INTEGER(NTLONG) :: total_size

@@ -20,7 +20,7 @@ OUT = os.path.join(ROOT, "oracle", "_ref")
 FLANG = "/opt/rocm/lib/llvm/bin/flang"
 # executable name -> the reference's unchanged Fortran example driver
 EXAMPLES = {"premade_f90": "PremadeMatrix", "hydrogen_f90": "HydrogenAtom", "graph_f90": "GraphTheory",
-            "maps_f90": "MatrixMaps", "overlap_f90": "OverlapMatrix"}
+            "maps_f90": "MatrixMaps", "overlap_f90": "OverlapMatrix", "complex_f90": "ComplexMatrix"}
 
 
 def build():

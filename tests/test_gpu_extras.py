@@ -760,6 +760,16 @@ def test_reference_cxx_examples_run(nt, tmp_path):
         assert np.abs(Sm - 1.0 / (np.abs(ii[:, None] - ii[None, :]) + 1.0)).max() <= 1e-6    # entries <= threshold dropped
         assert np.abs(Zm @ Sm @ Zm - np.eye(100)).max() <= 1e-3
 
+    # Fortran ComplexMatrix (complex triplet lists, SymmetrizeTripletList, the list's CurrentSize member): the same
+    # exponential as the C++ version, i.e. what the reference computes
+    if os.path.exists(os.path.join(ref, "complex_f90")):
+        import shutil
+        shutil.copy(os.path.join(data, "complexmatrix_input.mtx"), str(tmp_path / "cin.mtx"))
+        run("complex_f90", grid + ["--threshold", "1e-6", "--input_file", "cin.mtx", "--exponential_file", "cexp.mtx"])
+        gotf = scipy.io.mmread(str(tmp_path / "cexp.mtx")).toarray()
+        wantc = to_dense(gx.tri(None, "K"))
+        assert np.abs(gotf - wantc).max() <= 1e-9 * np.abs(wantc).max()
+
     # MatrixMaps: entries on or below the diagonal doubled, the rest dropped
     out = str(tmp_path / "output.mtx")
     inp = os.path.join(data, "matrixmaps_input.mtx")
