@@ -26,6 +26,10 @@ def ConstructGlobalProcessGrid(process_rows=None, process_columns=None, process_
         lib.ConstructGlobalProcessGrid_wrp(i(world_comm), i(process_rows), i(process_columns), i(process_slices))
 
 
+def WriteGridInfo():
+    lib.WriteGlobalProcessGridInfo_wrp()
+
+
 def DestructGlobalProcessGrid():
     lib.DestructGlobalProcessGrid_wrp()
 
@@ -128,6 +132,19 @@ def synchronize():
 
 
 # ------------------------------------------------------------------ triplets
+class Triplet_r:
+    """Triplet.h: (index_column, index_row, point_value), 1-based indices"""
+    def __init__(self, index_column=0, index_row=0, point_value=0.0):
+        self.index_column, self.index_row, self.point_value = index_column, index_row, point_value
+
+    def __iter__(self):
+        return iter((self.index_column, self.index_row, self.point_value))
+
+
+class Triplet_c(Triplet_r):
+    pass
+
+
 class _TripletList:
     _c = False
 
@@ -143,21 +160,28 @@ class _TripletList:
     def GetSize(self):
         return int(getattr(lib, "GetTripletListSize_%s_wrp" % self._sfx)(self.ih))
 
-    def Append(self, index_column, index_row, point_value):
+    def Append(self, index_column, index_row=None, point_value=None):
+        """Append(triplet) as the reference's SWIG classes take it (a Triplet_r / Triplet_c object), or the three
+        fields directly"""
+        if index_row is None:
+            t = index_column
+            index_column, index_row, point_value = t.index_column, t.index_row, t.point_value
         if self._c:
             lib.AppendToTripletList_c_wrp(self.ih, i(index_column), i(index_row), d(point_value.real), d(point_value.imag))
         else:
             lib.AppendToTripletList_r_wrp(self.ih, i(index_column), i(index_row), d(point_value))
 
     def GetTripletAt(self, index):
+        """0-based index, as the reference's C++ / SWIG layer; returns a Triplet object that also unpacks as
+        (index_column, index_row, point_value)"""
         col, row = C.c_int(), C.c_int()
         if self._c:
             re, im = C.c_double(), C.c_double()
             lib.GetTripletAt_c_wrp(self.ih, i(index + 1), C.byref(col), C.byref(row), C.byref(re), C.byref(im))
-            return col.value, row.value, complex(re.value, im.value)
+            return Triplet_c(col.value, row.value, complex(re.value, im.value))
         val = C.c_double()
         lib.GetTripletAt_r_wrp(self.ih, i(index + 1), C.byref(col), C.byref(row), C.byref(val))
-        return col.value, row.value, val.value
+        return Triplet_r(col.value, row.value, val.value)
 
     # bulk transfer (extension; the reference ABI moves one triplet per call)
     def set_arrays(self, col, row, val):

@@ -51,8 +51,8 @@ def test_triplet_list_semantics(nt):
     t.Append(3, 1, 2.5)
     t.Append(1, 2, -1.0)
     assert t.GetSize() == 2
-    assert t.GetTripletAt(0) == (3, 1, 2.5)
-    assert t.GetTripletAt(1) == (1, 2, -1.0)
+    assert tuple(t.GetTripletAt(0)) == (3, 1, 2.5)
+    assert tuple(t.GetTripletAt(1)) == (1, 2, -1.0)
     srt = nt.capi.handle()
     nt.lib.SortTripletList_r_wrp(t.ih, nt.capi.i(3), srt)
     col, row, val = C.c_int(), C.c_int(), C.c_double()
@@ -62,7 +62,13 @@ def test_triplet_list_semantics(nt):
     c = nt.TripletList_c(2)
     assert c.GetSize() == 2
     c.set_arrays([1, 2], [2, 1], np.array([1 + 2j, 3 - 4j]))
-    assert c.GetTripletAt(1) == (2, 1, 3 - 4j)
+    assert tuple(c.GetTripletAt(1)) == (2, 1, 3 - 4j)
+    # the SWIG classes' way: a triplet object in, a triplet object out
+    tr = nt.Triplet_r()
+    tr.index_column, tr.index_row, tr.point_value = 4, 5, 0.25
+    t.Append(tr)
+    back = t.GetTripletAt(2)
+    assert (back.index_column, back.index_row, back.point_value) == (4, 5, 0.25)
 
 
 def test_panel_ranges_cover_the_matrix(nt):
