@@ -3,6 +3,7 @@ the reference's golden outputs, the on-disk formats (MatrixMarket, NTPoly binary
 distributed-algebra entry points (pairwise, transpose, symmetrize, asymmetry, permutation,
 load balancer) against numpy, and the Taylor order-3 / Newton-Schulz order-2 square-root variants."""
 import os
+import sys
 import struct
 
 import numpy as np
@@ -776,3 +777,58 @@ def test_reference_cxx_examples_run(nt, tmp_path):
     run("maps_cxx", ["--process_slices", "1", "--input_matrix", inp, "--output_matrix", out])
     A = scipy.io.mmread(inp).toarray()
     assert np.abs(scipy.io.mmread(out).toarray() - 2.0 * np.tril(A)).max() <= 1e-14 * np.abs(A).max()
+
+
+def test_swig_style_python_program(tmp_path):
+    """`import NTPolySwig as nt` (ntpoly_amd/compat on the path): a program in the style of the reference's Python
+    examples -- triplet objects appended one by one, Matrix_ps from a dimension / from another matrix, solver parameters,
+    TRS2 returning (energy, chemical potential) -- run as its own process, result checked against numpy."""
+    import subprocess
+    import scipy.io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = tmp_path / "prog.py"
+    prog.write_text('''
+import sys
+import NTPolySwig as nt
+n = 60
+nt.ConstructGlobalProcessGrid(1, 1, 1)
+if nt.GetGlobalIsRoot():
+    nt.ActivateLogger()
+nt.WriteGridInfo()
+tl = nt.TripletList_r()
+t = nt.Triplet_r()
+for j in range(1, n + 1):
+    for i in range(max(1, j - 2), min(n, j + 2) + 1):
+        t.index_column, t.index_row = j, i
+        t.point_value = (-2.0 + 0.01 * j) if i == j else 0.5 / abs(i - j)
+        tl.Append(t)
+H = nt.Matrix_ps(n)
+H.FillFromTripletList(tl)
+I = nt.Matrix_ps(n)
+I.FillIdentity()
+D = nt.Matrix_ps(H.GetActualDimension())
+p = nt.SolverParameters()
+p.SetConvergeDiff(1e-8)
+p.SetThreshold(1e-10)
+p.SetVerbosity(True)
+energy, mu = nt.DensityMatrixSolvers.TRS2(H, I, 7.0, D, p)
+H.WriteToMatrixMarket(sys.argv[1])
+D.WriteToMatrixMarket(sys.argv[2])
+print("ENERGY %.12f MU %.12f" % (energy, mu))
+if nt.GetGlobalIsRoot():
+    nt.DeactivateLogger()
+nt.DestructGlobalProcessGrid()
+''')
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "ntpoly_amd", "compat"),
+                                                        os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, str(prog), str(tmp_path / "H.mtx"), str(tmp_path / "D.mtx")], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "Density Matrix Solver" in r.stdout and "TRS2" in r.stdout
+    H = scipy.io.mmread(str(tmp_path / "H.mtx")).toarray()
+    D = scipy.io.mmread(str(tmp_path / "D.mtx")).toarray()
+    w, v = np.linalg.eigh(H)
+    want = v[:, :7] @ v[:, :7].T
+    assert np.abs(D - want).max() <= 1e-6
+    energy = float(r.stdout.split("ENERGY")[1].split()[0])
+    assert energy == pytest.approx(w[:7].sum(), rel=1e-8)
