@@ -28,6 +28,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL between processes needs dmabuf IPC on this driver stack (already exported on the GPU boxes; kept for other launchers)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
