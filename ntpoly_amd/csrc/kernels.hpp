@@ -32,10 +32,15 @@ struct EngineOptions {
   int halo_overlap = 1;        // distributed multiply: 0 exchange then multiply, 1 overlap the exchange with the interior
                                // columns when the halo is a sizeable part of the panel, 2 always split, 3 split even
                                // with an empty halo (tests; also NTPOLY_AMD_HALO_OVERLAP in the environment)
-  int spgemm_variant = -1;     // numeric kernel: -1 automatic (register-slab kernel for run-like real operands, else the
-                               // column-pair kernel; complex operands: one column per wave); 0 one column per wave for
-                               // everything (first generation); 3<MAXCH><NW> column-pair kernel with that geometry;
-                               // 400 register-slab kernel whenever it fits, 401..405 its timing ablations (wrong results)
+  int spgemm_variant = -1;     // numeric kernel: -1 automatic (register-slab kernels for run-like operands, real and complex,
+                               // geometry by the widest row window; else the column-pair kernel for real operands, one
+                               // column per wave for complex ones; LDS hash beyond 4096-row windows); 0 one column per wave
+                               // for everything (first generation); 3<MAXCH><NW> column-pair kernel with that geometry;
+                               // 400 register-slab kernel whenever it fits (also when its run-density test says no);
+                               // timing experiments on the three-slab real kernel: 401..404 ablations (WRONG results:
+                               // no slab loads / no multiplier loads / no arithmetic / cache-hot multipliers), 405 plain
+                               // loop + rotating prefetch, 406 lean periods, 407 both (= the default loop), 408 / 409
+                               // two / three workgroups per CU, 410 plain loop and three slabs also for narrow windows
 };
 EngineOptions& options();
 SpgemmStats& last_spgemm_stats();
