@@ -91,10 +91,13 @@ def main():
     ap.add_argument("--halfband", type=int, default=100)
     ap.add_argument("--threshold", type=float, default=1e-8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--permute", type=int, default=None, metavar="SEED",
+                    help="run on P^T H P under a seeded random relabelling (SURVEY 8(d): the load-balanced / "
+                         "unstructured operand; the SpGEMM leaves the run-based kernels for the LDS hash path)")
     args = ap.parse_args()
 
     import ntpoly_amd as nt
-    from gen import banded_triplets
+    from gen import banded_triplets, permuted_banded_triplets
     # one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from the launcher); the engine owns its RCCL
     # communicator and torch is not imported: its wheel bundles a second HIP runtime, and two runtimes in one process
     # corrupt the heap at exit
@@ -109,7 +112,10 @@ def main():
     # ---- setup (untimed): Hamiltonian panel, X0 = (e_max*I - H)/(e_max - e_min)  (:344-371)
     H = nt.Matrix_ps(n)
     c0, c1 = H.local_columns()
-    col, row, val = banded_triplets(n, h, c0=c0, c1=c1)
+    if args.permute is None:
+        col, row, val = banded_triplets(n, h, c0=c0, c1=c1)
+    else:
+        col, row, val = permuted_banded_triplets(n, h, args.permute, c0=c0, c1=c1)
     tl = nt.TripletList_r()
     tl.set_arrays(col, row, val)
     H.FillFromTripletList(tl, prepartitioned=True)

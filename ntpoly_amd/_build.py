@@ -28,6 +28,31 @@ def _stale():
     return False
 
 
+def _depfile_deps(depfile):
+    """prerequisites listed in a -MMD dependency file (own sources only: system headers are not listed)"""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    if ":" not in text:
+        return None
+    return [t for t in text.split(":", 1)[1].split() if t]
+
+
+def object_is_stale(obj, src):
+    """True when `obj` must be recompiled: it is missing, or older than its source or than ANY file the source
+    includes -- the compiler's own list (-MMD, kept beside the object) when there is one, otherwise every
+    non-source file in csrc (*.hpp and the generated *.inc loops)."""
+    if not os.path.exists(obj):
+        return True
+    deps = _depfile_deps(obj[:-2] + ".d")
+    if deps is None or any(not os.path.exists(d) for d in deps):
+        deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith((".cpp", ".hip"))]
+    deps = list(deps) + [src]
+    return os.path.getmtime(obj) <= max(map(os.path.getmtime, deps))
+
+
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
@@ -35,15 +60,13 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        deps = headers + [src]
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(map(os.path.getmtime, deps)):
+        if not force and not object_is_stale(obj, src):
             continue
-        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + ["-MMD", "-MF", obj[:-2] + ".d", "-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

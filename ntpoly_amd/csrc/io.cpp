@@ -12,7 +12,7 @@
 
 namespace ntp {
 
-void read_matrix_market_file(const std::string& path, HostTriplets& t, int* rows, int* cols, int want_complex) {
+void read_matrix_market_file(const std::string& path, HostTriplets& t, int* rows, int* cols, int want_complex, bool header_only) {
   std::ifstream f(path);
   if (!f) NTP_FATAL("cannot open matrix market file " + path);  // PSMatrixModule.F90:405-415
   std::string line;
@@ -37,6 +37,8 @@ void read_matrix_market_file(const std::string& path, HostTriplets& t, int* rows
   const bool out_complex = want_complex < 0 ? file_complex : (want_complex != 0);
   t = HostTriplets();
   t.cplx = out_complex;
+  if (r < 1 || c < 1 || nnz < 0) NTP_FATAL("bad size line in matrix market file " + path);
+  if (header_only) return;
   t.col.reserve((size_t)nnz * 2);
   t.row.reserve((size_t)nnz * 2);
   auto push = [&](int row, int col, double re, double im) {
@@ -52,6 +54,9 @@ void read_matrix_market_file(const std::string& path, HostTriplets& t, int* rows
     if (!pattern) f >> re;
     if (file_complex) f >> im;
     if (!f) NTP_FATAL("truncated matrix market file " + path);
+    if (row < 1 || row > r || col < 1 || col > c)
+      NTP_FATAL("entry " + std::to_string(i + 1) + " (" + std::to_string(row) + ", " + std::to_string(col) + ") of " + path +
+                " lies outside the " + std::to_string(r) + " x " + std::to_string(c) + " matrix of its header");
     push(row, col, re, im);
     if (row != col) {
       if (symmetry == "symmetric") push(col, row, re, im);
@@ -64,14 +69,9 @@ void read_matrix_market_file(const std::string& path, HostTriplets& t, int* rows
 void ps_read_matrix_market(PSMatrix& m, const std::string& path, const ProcessGrid* g) {
   int rows = 0, cols = 0;
   HostTriplets t;
-  // every rank parses the header (cheap), only the root contributes entries
-  read_matrix_market_file(path, t, &rows, &cols, -1);
+  // every rank parses the header (cheap), only the root reads and contributes the entries
+  read_matrix_market_file(path, t, &rows, &cols, -1, world().rank != 0);
   ps_construct_empty(m, rows, g, t.cplx);
-  if (world().rank != 0) {
-    const bool z = t.cplx;
-    t = HostTriplets();
-    t.cplx = z;
-  }
   ps_fill_from_triplets(m, t);
 }
 
@@ -146,6 +146,8 @@ void ps_read_binary(PSMatrix& m, const std::string& path, const ProcessGrid* g) 
       if (std::fread(&t.col[(size_t)i], sizeof(int32_t), 1, f) != 1 || std::fread(&t.row[(size_t)i], sizeof(int32_t), 1, f) != 1 ||
           std::fread(&t.val[(size_t)i * w], sizeof(double), w, f) != w)
         NTP_FATAL("truncated binary matrix file " + path);
+      if (t.col[(size_t)i] < 1 || t.col[(size_t)i] > header[1] || t.row[(size_t)i] < 1 || t.row[(size_t)i] > header[0])
+        NTP_FATAL("entry " + std::to_string(i + 1) + " of " + path + " lies outside the matrix of its header");
     }
   }
   std::fclose(f);

@@ -3198,6 +3198,10 @@ DevMat from_triplets(const HostTriplets& t, int32_t rows, int32_t cols, int32_t 
   std::vector<size_t> order;
   order.reserve(n);
   for (size_t i = 0; i < n; ++i) {
+    // a row outside the matrix would become an out-of-range LDS / register index in the kernels: refuse it here
+    if (t.row[i] < 1 || t.row[i] > rows || t.col[i] < 1)
+      NTP_FATAL("triplet " + std::to_string(i) + " (column " + std::to_string(t.col[i]) + ", row " + std::to_string(t.row[i]) +
+                ") lies outside the " + std::to_string(rows) + "-row matrix");
     const int32_t c = t.col[i] - 1 - col_offset;
     if (c >= 0 && c < cols) order.push_back(i);
   }

@@ -157,6 +157,10 @@ void ps_fill_from_triplets(PSMatrix& m, const HostTriplets& t) {
     ps_fill_from_triplets(m, conv);
     return;
   }
+  for (size_t i = 0; i < t.size(); ++i)
+    if (t.col[i] < 1 || t.col[i] > m.dim)
+      NTP_FATAL("triplet " + std::to_string(i) + " names column " + std::to_string(t.col[i]) + " of a matrix of dimension " +
+                std::to_string(m.dim));
   if (!world().active()) {
     m.loc = from_triplets(t, m.dim, m.c1 - m.c0, m.c0);
     return;

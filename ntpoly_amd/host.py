@@ -93,19 +93,37 @@ def init_comm_from_env(timeout=300.0):
         return rank, world
     # NTPOLY_AMD_RDV names the file explicitly (launchers whose ranks are not children of one process)
     path = os.environ.get("NTPOLY_AMD_RDV") or "/tmp/ntpoly_amd_rdv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    # a per-launch nonce keeps a stale file of an earlier (crashed) launch from being taken for this one's id
+    # (an explicitly named file may be shared by ranks of different parents: NTPOLY_AMD_RDV_NONCE stands in for the pid)
+    who = os.environ.get("NTPOLY_AMD_RDV_NONCE", "") if os.environ.get("NTPOLY_AMD_RDV") else str(os.getppid())
+    nonce = (os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("MASTER_PORT", "0") + ":" +
+             who).encode()[:64].ljust(64, b"\0")
     if rank == 0:
         uid = get_unique_id()
-        with open(path + ".tmp", "wb") as f:
-            f.write(uid)
-        os.rename(path + ".tmp", path)
+        try:
+            os.unlink(path)          # left behind by a launch that died between writing and joining
+        except FileNotFoundError:
+            pass
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(nonce + uid)
+        os.rename(tmp, path)
     else:
         t0 = time.time()
-        while not os.path.exists(path):
-            if time.time() - t0 > timeout:
-                raise RuntimeError("rendezvous file %s did not appear" % path)
-            time.sleep(0.01)
-        with open(path, "rb") as f:
-            uid = f.read()
+        uid = None
+        while uid is None:
+            try:
+                with open(path, "rb") as f:
+                    blob = f.read()
+                if len(blob) == 64 + 128 and blob[:64] == nonce:
+                    uid = blob[64:]
+            except FileNotFoundError:
+                pass
+            if uid is None:
+                if time.time() - t0 > timeout:
+                    raise RuntimeError("rendezvous file %s did not appear (or belongs to another launch)" % path)
+                time.sleep(0.01)
     init_comm(uid, rank, world)
     barrier()
     if rank == 0:

@@ -23,3 +23,44 @@ def banded_triplets(n, h, complex_=False, shift=0.0, c0=0, c1=None):
         val = val * np.exp(1j * 0.1 * (row - col))
         val = np.where(dist == 0, diag[col - 1] + 0j, val)
     return col.astype(np.int32), row.astype(np.int32), val
+
+
+def random_permutation(n, seed):
+    """Seeded random relabelling perm[old 0-based] = new 0-based (the load-balancing permutation of
+    LoadBalancerModule.F90:14-52 / PermutationModule.F90:92-107; the reference draws from the Fortran RNG, any
+    permutation serves)."""
+    return np.random.default_rng(seed).permutation(n).astype(np.int64)
+
+
+def permuted_banded_triplets(n, h, seed, c0=0, c1=None, shift=0.0, complex_=False):
+    """P^T H P of banded_triplets(n, h) under random_permutation(n, seed): entry (r, c) of H moves to
+    (perm[r], perm[c]).  Only the NEW columns [c0, c1) (0-based) if given; sorted by column then row."""
+    c1 = n if c1 is None else c1
+    perm = random_permutation(n, seed)
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n, dtype=np.int64)
+    cols, rows, vals = [], [], []
+    step = 1 << 16
+    offs = np.arange(-h, h + 1, dtype=np.int64)
+    for b0 in range(c0, c1, step):
+        b1 = min(c1, b0 + step)
+        jo = inv[b0:b1]                                   # original (0-based) column of every new column
+        ro = jo[:, None] + offs[None, :]                  # original rows
+        ok = (ro >= 0) & (ro < n)
+        rn = np.where(ok, perm[np.clip(ro, 0, n - 1)], n)  # new rows, invalid -> n (sorts last)
+        dist = np.abs(ro - jo[:, None])
+        i1 = jo + 1
+        diag = -1.0 + 2.0 * ((i1 * 7919) % 1000) / 1000.0 + shift
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v = np.where(dist == 0, diag[:, None], -0.25 * np.exp(-0.05 * dist) / np.maximum(dist, 1))
+        if complex_:
+            v = np.where(dist == 0, diag[:, None] + 0j, v * np.exp(1j * 0.1 * (ro - jo[:, None])))
+        order = np.argsort(rn, axis=1, kind="stable")
+        rn = np.take_along_axis(rn, order, axis=1)
+        v = np.take_along_axis(v, order, axis=1)
+        keep = rn < n
+        cn = np.broadcast_to(np.arange(b0, b1, dtype=np.int64)[:, None], rn.shape)
+        cols.append((cn[keep] + 1).astype(np.int32))
+        rows.append((rn[keep] + 1).astype(np.int32))
+        vals.append(v[keep])
+    return np.concatenate(cols), np.concatenate(rows), np.concatenate(vals)

@@ -632,6 +632,42 @@ def gen_multirank(tmp):
     save("ps_gemm_grids", d, dict(kind="ps_gemm_grids", thr=1e-6, cases=cases))
 
 
+def gen_scale_logs(tmp):
+    """Parity at scale: the REAL reference on 8 ranks (grid 8x1x1) at sizes well beyond the small
+    goldens -- TRS2 and TRS4 at N = 16 384, h = 100 (the headline band), complex InverseSquareRoot (H + 2I) and
+    SignFunction (the indefinite H itself) at N = 8 192, h = 50.  Only the per-iteration logs and a few scalars of the
+    result are kept (the inputs are the closed-form generator; the results have millions of entries)."""
+    d, cases = {}, []
+
+    def solve(solver, n, h, cplx, shift, nel, thr, conv, maxit, monitor, tag, nranks=8):
+        H = banded(n, h, cplx)
+        if shift:
+            H = sp.csc_matrix(H + shift * sp.identity(n))
+        write_tri(tmp + "/H.tri", n, n, *tri(H))
+        isq = "identity" if solver in ("trs2", "trs4") else "none"
+        run(["solve", nranks, 1, 1, solver, tmp + "/H.tri", isq, repr(nel), repr(thr), repr(conv), maxit,
+             int(monitor), tmp + "/K.tri", tmp + "/log.yaml", tmp + "/s.txt"], nranks=nranks)
+        rows, cols, c, r, v = read_tri(tmp + "/K.tri")
+        sc = {k: float(x) for k, x in (ln.split() for ln in open(tmp + "/s.txt"))}
+        lc, le, total = parse_log(tmp + "/log.yaml")
+        pre = "c%03d_" % len(cases)
+        d[pre + "log_convergence"] = np.array(lc)
+        d[pre + "log_energy"] = np.array(le)
+        diag = v[c == r]
+        cases.append(dict(tag=tag, solver=solver, n=n, h=h, cplx=bool(cplx), shift=shift, nel=nel, thr=thr, conv=conv,
+                          maxit=maxit, monitor=bool(monitor), energy=sc["energy"], mu=sc["mu"], nnz=int(sc["nnz"]),
+                          total_iterations_logged=total, grid=[nranks, 1, 1],
+                          trace_re=float(np.real(diag).sum()), frob2=float((np.abs(v) ** 2).sum()),
+                          sum_re=float(np.real(v).sum()), sum_im=float(np.imag(v).sum())))
+        print(tag, "iterations", total, "nnz", int(sc["nnz"]), flush=True)
+
+    solve("trs2", 16384, 100, False, 0.0, 8192.0, 1e-8, 1e-6, 1000, 1, "banded16384_h100_trs2_conv")
+    solve("trs4", 16384, 100, False, 0.0, 8192.0, 1e-8, 1e-6, 1000, 1, "banded16384_h100_trs4_conv")
+    solve("isq", 8192, 50, True, 2.0, 0.0, 1e-8, 1e-6, 1000, 1, "cbanded8192_shift_isq")
+    solve("sign", 8192, 50, True, 0.0, 0.0, 1e-8, 1e-6, 1000, 1, "cbanded8192_sign")
+    save("scale_logs", d, dict(kind="scale_logs", cases=cases))
+
+
 def main():
     if not os.path.exists(DRV):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

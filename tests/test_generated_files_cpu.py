@@ -46,3 +46,35 @@ def test_headers_are_generated(tmp_path):
     inc = os.path.join(ROOT, "include")
     outputs = [os.path.join("include", f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
     _regenerates_identically("gen_headers.py", outputs, tmp_path)
+
+
+def test_incremental_build_sees_included_files(tmp_path):
+    """an object must be rebuilt when a file its source #includes changes -- in particular the generated
+    slab loops (csrc/slab_loop.inc, included by kernels.hip), which are neither a source nor a header."""
+    import time
+    from ntpoly_amd import _build
+    src = tmp_path / "k.hip"
+    inc = tmp_path / "loop.inc"
+    obj = tmp_path / "k.o"
+    dep = tmp_path / "k.d"
+    for f in (src, inc):
+        f.write_text("// x\n")
+    obj.write_text("o")
+    dep.write_text("%s: %s \\\n  %s\n" % (obj, src, inc))
+    now = time.time()
+    os.utime(src, (now - 100, now - 100))
+    os.utime(inc, (now - 100, now - 100))
+    os.utime(obj, (now - 50, now - 50))
+    assert not _build.object_is_stale(str(obj), str(src))
+    os.utime(inc, (now, now))                       # the included file is regenerated
+    assert _build.object_is_stale(str(obj), str(src))
+    # without a dependency file every non-source file of csrc counts (so slab_loop.inc does)
+    dep.unlink()
+    real_inc = os.path.join(_build.CSRC, "slab_loop.inc")
+    assert os.path.exists(real_inc)
+    os.utime(obj, (0, 0))
+    assert _build.object_is_stale(str(obj), str(src))
+    # the real build tree: the compiler's own list for kernels.o names the generated loop file
+    d = os.path.join(_build.HERE, "build", "kernels.d")
+    if os.path.exists(d):
+        assert any(p.endswith("slab_loop.inc") for p in _build._depfile_deps(d))

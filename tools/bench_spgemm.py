@@ -22,16 +22,20 @@ def main():
     ap.add_argument("--variants", type=str, default="400,351")
     ap.add_argument("--fma", type=int, default=0)
     ap.add_argument("--complex", type=int, default=0, help="Hermitian complex operand (BASELINE configs[4] family)")
+    ap.add_argument("--permute", type=int, default=None, metavar="SEED", help="operand under a seeded random relabelling")
     args = ap.parse_args()
     import ntpoly_amd as nt
-    from gen import banded_triplets
+    from gen import banded_triplets, permuted_banded_triplets
     from bench import trs2_step
     nt.init_comm()
     nt.ConstructGlobalProcessGrid(1, 1, 1)
     nt.set_option("time_kernels", 1)
     nt.set_option("spgemm_fma", args.fma)
     n, h, thr = args.n, args.halfband, args.threshold
-    col, row, val = banded_triplets(n, h, complex_=bool(args.complex))
+    if args.permute is None:
+        col, row, val = banded_triplets(n, h, complex_=bool(args.complex))
+    else:
+        col, row, val = permuted_banded_triplets(n, h, args.permute, complex_=bool(args.complex))
     H = nt.Matrix_ps.from_triplets(n, col, row, val)
     del col, row, val
     e_min, e_max = nt.EigenBounds.GershgorinBounds(H)
