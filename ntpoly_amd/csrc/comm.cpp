@@ -4,6 +4,7 @@
 // (ntpoly_amd.host.init_comm_from_env: a file in /tmp, no torch) and handed in through comm_init().
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -196,6 +197,7 @@ void comm_get_unique_id(char out[128]) {
 void comm_init(const char idbytes[128], int rank, int nranks) {
   Comm& c = world();
   if (c.tr) comm_finalize();
+  c.user_init = true;
   c.rank = rank;
   c.nranks = nranks;
   const char* f = std::getenv("NTPOLY_AMD_FORCE_RCCL");
@@ -221,6 +223,103 @@ void comm_init(const char idbytes[128], int rank, int nranks) {
   auto* t = new RcclTransport();
   NCCL_CHECK(ncclCommInitRank(&t->comm, c.nranks, id, c.rank));
   c.tr = t;
+}
+
+// ------------------------------------------------------------------ the caller's MPI communicator
+// The reference binds the communicator handed to ConstructProcessGrid (ProcessGridModule.F90:130-197,
+// Source/CPlusPlus/ProcessGrid.cc:12-48: a Fortran handle made with MPI_Comm_c2f).  A program written against the
+// reference therefore runs under `mpiexec -n P` with MPI already initialised in the process and never calls this
+// engine's own bootstrap.  The engine does not link MPI; when the program has loaded one, its entry points are found
+// with dlsym and used ONCE, for rank / size and to broadcast the RCCL unique id -- the data plane stays RCCL.
+// Two C ABIs are understood: the MPICH family (MPICH, Intel MPI, MVAPICH, Cray: handles are ints, Fortran and C
+// handles coincide, MPI_BYTE = 0x4c00010d) and Open MPI (handles are pointers, MPI_Comm_f2c converts, MPI_BYTE is the
+// address of ompi_mpi_byte).  Must run before the first HIP call of the process: the GPU is chosen from the rank.
+namespace {
+int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : dflt;
+}
+// size of the launch according to the process managers' environment (1 when none is visible)
+int launcher_world_size() {
+  for (const char* name : {"PMI_SIZE", "OMPI_COMM_WORLD_SIZE", "PMIX_SIZE", "SLURM_NTASKS", "WORLD_SIZE"}) {
+    const int n = env_int(name, 0);
+    if (n > 1) return n;
+  }
+  return 1;
+}
+int launcher_local_rank(int rank) {
+  for (const char* name : {"LOCAL_RANK", "MPI_LOCALRANKID", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"}) {
+    const char* v = std::getenv(name);
+    if (v && *v) return std::atoi(v);
+  }
+  return rank;  // one node: every rank is local
+}
+}  // namespace
+
+bool comm_bind_mpi(int fcomm) {
+  Comm& c = world();
+  if (c.tr || c.nranks > 1) return true;       // the engine already has its communicator (ntpoly_amd_init_comm)
+  if (c.user_init) return false;               // an explicit single-rank bootstrap
+  static bool tried = false;
+  if (tried) return false;
+  tried = true;
+  using fn_initialized = int (*)(int*);
+  auto initialized = reinterpret_cast<fn_initialized>(dlsym(RTLD_DEFAULT, "MPI_Initialized"));
+  int inited = 0;
+  if (initialized) initialized(&inited);
+  if (!inited) {
+    // no MPI in this process.  A multi-process launch that never called ntpoly_amd_init_comm would run P identical
+    // single-rank solves on GPU 0 and let all of them write the same files: refuse.
+    const int n = launcher_world_size();
+    if (n > 1 && !std::getenv("NTPOLY_AMD_ALLOW_REPLICAS"))
+      NTP_FATAL("this process is one of " + std::to_string(n) + " launched together, but no communicator was given to the engine: "
+                "initialise MPI before constructing the process grid (the communicator argument is then honoured), or call "
+                "ntpoly_amd_init_comm (ntpoly_amd.host.init_comm_from_env); NTPOLY_AMD_ALLOW_REPLICAS=1 runs independent replicas");
+    return false;
+  }
+  int rank = 0, size = 1;
+  char id[128];
+  std::memset(id, 0, sizeof(id));
+  const bool ompi = dlsym(RTLD_DEFAULT, "ompi_mpi_comm_world") != nullptr;
+  if (ompi) {
+    using f2c_t = void* (*)(int);
+    using rank_t = int (*)(void*, int*);
+    using bcast_t = int (*)(void*, int, void*, int, void*);
+    auto f2c = reinterpret_cast<f2c_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_f2c"));
+    auto frank = reinterpret_cast<rank_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_rank"));
+    auto fsize = reinterpret_cast<rank_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_size"));
+    auto fbcast = reinterpret_cast<bcast_t>(dlsym(RTLD_DEFAULT, "MPI_Bcast"));
+    void* byte_t = dlsym(RTLD_DEFAULT, "ompi_mpi_byte");
+    if (!f2c || !frank || !fsize || !fbcast || !byte_t) NTP_FATAL("Open MPI is loaded but its entry points were not found");
+    void* comm = f2c(fcomm);
+    if (frank(comm, &rank) != 0 || fsize(comm, &size) != 0) NTP_FATAL("the communicator handed to the process grid is not valid");
+    if (size > 1) {
+      if (rank == 0) comm_get_unique_id(id);
+      if (fbcast(id, 128, byte_t, 0, comm) != 0) NTP_FATAL("MPI_Bcast of the RCCL id failed");
+    }
+  } else {
+    using rank_t = int (*)(int, int*);
+    using bcast_t = int (*)(void*, int, int, int, int);
+    auto frank = reinterpret_cast<rank_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_rank"));
+    auto fsize = reinterpret_cast<rank_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_size"));
+    auto fbcast = reinterpret_cast<bcast_t>(dlsym(RTLD_DEFAULT, "MPI_Bcast"));
+    if (!frank || !fsize || !fbcast) NTP_FATAL("an MPI library is loaded but its entry points were not found");
+    const int comm = fcomm;                 // MPICH ABI: MPI_Comm_f2c is the identity
+    constexpr int kMpichByte = 0x4c00010d;  // MPI_BYTE
+    if (frank(comm, &rank) != 0 || fsize(comm, &size) != 0) NTP_FATAL("the communicator handed to the process grid is not valid");
+    if (size > 1) {
+      if (rank == 0) comm_get_unique_id(id);
+      if (fbcast(id, 128, kMpichByte, 0, comm) != 0) NTP_FATAL("MPI_Bcast of the RCCL id failed");
+    }
+  }
+  if (size <= 1) return false;
+  // one process per GPU: the device follows the node-local rank, and must be chosen before the runtime is touched
+  Context& x = ctx();
+  if (x.initialised)
+    NTP_FATAL("the process grid must be constructed before any other engine call that touches the GPU when ranks come from MPI");
+  if (!std::getenv("LOCAL_RANK")) setenv("LOCAL_RANK", std::to_string(launcher_local_rank(rank)).c_str(), 1);
+  comm_init(id, rank, size);
+  return true;
 }
 
 void comm_finalize() {

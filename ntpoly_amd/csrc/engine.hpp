@@ -35,12 +35,16 @@ struct Comm {
   int rank = 0, nranks = 1;
   Transport* tr = nullptr;
   bool force = false;    // tests: run the multi-rank code paths even with a single rank
+  bool user_init = false;  // ntpoly_amd_init_comm was called (also with one rank): the caller's MPI communicator is not consulted
   bool active() const { return tr != nullptr && (nranks > 1 || force); }
 };
 Comm& world();
 void comm_get_unique_id(char out[128]);
 void comm_init(const char id[128], int rank, int nranks);
 void comm_finalize();
+// ranks from the caller's MPI communicator (Fortran handle), when the process has initialised an MPI library and the
+// engine has no communicator yet; true when a multi-rank communicator exists afterwards
+bool comm_bind_mpi(int fortran_comm);
 void comm_allreduce_sum(double* host_vals, int n);
 void comm_allreduce_min(double* host_vals, int n);
 void comm_allreduce_max(double* host_vals, int n);

@@ -14,6 +14,12 @@ struct SpgemmStats {
   int slab = 0;                // 1 when the register-slab kernel computed the product
   int64_t bin_cols[6] = {0, 0, 0, 0, 0, 0};
   int64_t overflow_cols = 0;   // columns that left the LDS hash for the HBM accumulator
+  // grouped LDS-hash path (spgemm_grouped.hip): 1 when it computed the product; columns handed back to the per-column
+  // kernels, table class reached, min-hash clustering used, union ratio (1 = the columns of a group are identical)
+  int grouped = 0;
+  int64_t gh_failed_cols = 0, gh_groups = 0, gh_tile_rows = 0;
+  int gh_level = 0, gh_minhash = 0;
+  double gh_union_ratio = 0;
   float ms_total = 0.f;        // filled only when timing is enabled
   float ms_numeric = 0.f;
 };
@@ -40,7 +46,10 @@ struct EngineOptions {
                                // timing experiments on the three-slab real kernel: 401..404 ablations (WRONG results:
                                // no slab loads / no multiplier loads / no arithmetic / cache-hot multipliers), 405 plain
                                // loop + rotating prefetch, 406 lean periods, 407 both (= the default loop), 408 / 409
-                               // two / three workgroups per CU, 410 plain loop and three slabs also for narrow windows
+                               // two / three workgroups per CU, 410 plain loop and three slabs also for narrow windows;
+                               // 500 grouped LDS-hash kernel for every multiply the slab kernels do not take (automatic: when
+                               // at least half of the columns have row windows beyond the direct-mapped LDS kernels),
+                               // 501 never the grouped kernel (one column per wave LDS hash, the previous path)
 };
 EngineOptions& options();
 SpgemmStats& last_spgemm_stats();
@@ -150,5 +159,8 @@ void dense_zero_columns(double* d_dense, int64_t ld, int32_t rows, int32_t c_fir
 void dense_eigh(double* d_A, int32_t n, bool cplx, double* d_W);
 void dense_cholesky(const double* d_A, double* d_L, int32_t n, double threshold, int32_t rank);
 int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n);
+// the same without the read-back: out[0..n] = exclusive prefix sums, out[n] = total; asynchronous on the engine stream
+void scan_i32_async(const int32_t* d_in, int64_t* d_out, int64_t n);
+void scan_i64_async(const int64_t* d_in, int64_t* d_out, int64_t n);
 
 }  // namespace ntp

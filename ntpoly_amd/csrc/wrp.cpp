@@ -138,6 +138,14 @@ void ntpoly_amd_last_spgemm_stats(long long* out, float* ms_numeric, float* ms_t
   *ms_numeric = s.ms_numeric;
   *ms_total = s.ms_total;
 }
+// grouped LDS-hash path of the last SpGEMM: out[0..5] = used, columns handed back to the per-column kernels, groups,
+// table class, min-hash clustering used, steps (sum of the groups' row unions of B); ratio = steps / (nnz(B) / columns per group)
+void ntpoly_amd_last_grouped_stats(long long* out, double* ratio) {
+  const SpgemmStats& s = last_spgemm_stats();
+  out[0] = s.grouped; out[1] = s.gh_failed_cols; out[2] = s.gh_groups; out[3] = s.gh_level; out[4] = s.gh_minhash;
+  out[5] = s.gh_tile_rows;
+  *ratio = s.gh_union_ratio;
+}
 void ntpoly_amd_reset_spgemm_accum() {
   flush_spgemm_timers();
   spgemm_accum() = SpgemmAccum();
@@ -196,15 +204,15 @@ void ntpoly_amd_triplets_get(const int* ih_list, int* col, int* row, double* val
 // ===================================================================== ProcessGrid_c.h
 void ConstructGlobalProcessGrid_wrp(const int* world_comm, const int* process_rows, const int* process_columns,
                                     const int* process_slices) {
-  (void)world_comm;  // the MPI communicator of the reference; ranks come from ntpoly_amd_init_comm
+  comm_bind_mpi(*world_comm);  // the reference's MPI communicator (ProcessGrid.cc:14): honoured when MPI is initialised
   construct_grid(global_grid(), *process_rows, *process_columns, *process_slices);
 }
 void ConstructGlobalProcessGrid_onlyslice_wrp(const int* world_comm, const int* process_slices) {
-  (void)world_comm;
+  comm_bind_mpi(*world_comm);
   construct_grid_default(global_grid(), *process_slices);
 }
 void ConstructGlobalProcessGrid_default_wrp(const int* world_comm) {
-  (void)world_comm;
+  comm_bind_mpi(*world_comm);
   construct_grid_default(global_grid(), 1);
 }
 void CopyProcessGrid_wrp(const int* ih_old_grid, int* ih_new_grid) {
@@ -221,19 +229,19 @@ void WriteGlobalProcessGridInfo_wrp() { write_grid_info(global_grid()); }
 void DestructGlobalProcessGrid_wrp() {}
 void ConstructProcessGrid_wrp(int* ih_grid, const int* world_comm, const int* process_rows, const int* process_columns,
                               const int* process_slices) {
-  (void)world_comm;
+  comm_bind_mpi(*world_comm);
   ProcessGrid* g = new ProcessGrid();
   construct_grid(*g, *process_rows, *process_columns, *process_slices);
   put(ih_grid, g);
 }
 void ConstructProcessGrid_onlyslice_wrp(int* ih_grid, const int* world_comm, const int* process_slices) {
-  (void)world_comm;
+  comm_bind_mpi(*world_comm);
   ProcessGrid* g = new ProcessGrid();
   construct_grid_default(*g, *process_slices);
   put(ih_grid, g);
 }
 void ConstructProcessGrid_default_wrp(int* ih_grid, const int* world_comm) {
-  (void)world_comm;
+  comm_bind_mpi(*world_comm);
   ProcessGrid* g = new ProcessGrid();
   construct_grid_default(*g, 1);
   put(ih_grid, g);

@@ -862,6 +862,15 @@ def last_spgemm_stats():
                 bins=[out[5 + k] for k in range(6)], overflow=out[11], slab=out[12], ms_numeric=a.value, ms_total=t.value)
 
 
+def last_grouped_stats():
+    """grouped LDS-hash path of the last SpGEMM (csrc/spgemm_grouped.hip)"""
+    out = (C.c_longlong * 6)()
+    r = C.c_double()
+    lib.ntpoly_amd_last_grouped_stats(out, C.byref(r))
+    return dict(used=int(out[0]), failed_cols=int(out[1]), groups=int(out[2]), level=int(out[3]), minhash=int(out[4]),
+                tile_rows=int(out[5]), union_ratio=r.value)
+
+
 def reset_spgemm_accum():
     lib.ntpoly_amd_reset_spgemm_accum()
 

@@ -612,6 +612,7 @@ CONTAINS
     REAL(NTREAL) :: energy, mu
     CHARACTER(len=32) :: solver
     INTEGER :: u
+    INTEGER(KIND=8) :: knnz
     CALL make_grid(2)
     solver = sarg(5)
     CALL load_ps(sarg(6), H)
@@ -658,11 +659,12 @@ CONTAINS
     END SELECT
     IF (IsRoot()) CALL DeactivateLogger
     CALL store_ps(sarg(13), K)
+    knnz = GetMatrixSize(K)   ! collective: every rank calls it
     IF (IsRoot()) THEN
        OPEN(NEWUNIT=u, FILE=TRIM(sarg(15)), STATUS="REPLACE")
        WRITE(u, '(A,ES26.17E3)') "energy ", energy
        WRITE(u, '(A,ES26.17E3)') "mu ", mu
-       WRITE(u, '(A,I0)') "nnz ", GetMatrixSize(K)
+       WRITE(u, '(A,I0)') "nnz ", knnz
        CLOSE(u)
     END IF
     CALL DestructProcessGrid

@@ -647,8 +647,12 @@ def gen_scale_logs(tmp):
         isq = "identity" if solver in ("trs2", "trs4") else "none"
         run(["solve", nranks, 1, 1, solver, tmp + "/H.tri", isq, repr(nel), repr(thr), repr(conv), maxit,
              int(monitor), tmp + "/K.tri", tmp + "/log.yaml", tmp + "/s.txt"], nranks=nranks)
-        rows, cols, c, r, v = read_tri(tmp + "/K.tri")
+        parts = [read_tri(tmp + "/K.tri.%d" % q) for q in range(nranks)] if nranks > 1 else [read_tri(tmp + "/K.tri")]
+        c = np.concatenate([q[2] for q in parts])
+        r = np.concatenate([q[3] for q in parts])
+        v = np.concatenate([q[4] for q in parts])
         sc = {k: float(x) for k, x in (ln.split() for ln in open(tmp + "/s.txt"))}
+        assert len(v) == int(sc["nnz"])
         lc, le, total = parse_log(tmp + "/log.yaml")
         pre = "c%03d_" % len(cases)
         d[pre + "log_convergence"] = np.array(lc)

@@ -82,11 +82,12 @@ def test_local_increment_golden(nt):
         exact(mB.triplets(), g.tri(i, "C"), "case %d %s" % (i, c))
 
 
-@pytest.mark.parametrize("force_bin,variant", [(-1, -1), (-1, 0), (2, 321), (3, 361), (-1, 351), (4, -1), (5, -1), (6, -1), (-1, 400)])
+@pytest.mark.parametrize("force_bin,variant", [(-1, -1), (-1, 0), (2, 321), (3, 361), (-1, 351), (4, -1), (5, -1), (6, -1), (-1, 400),
+                                               (-1, 500), (-1, 501)])
 def test_ps_gemm_golden(nt, force_bin, variant):
     """test_psmatrixalgebra.py:193-218 through MatrixMultiply_ps_wrp; every kernel path (column-pair
     kernel, first-generation window kernel, other generations, LDS window sizes, LDS hash, HBM
-    accumulator) must give the same bits."""
+    accumulator, grouped LDS hash) must give the same bits."""
     nt.set_option("spgemm_force_bin", force_bin)
     nt.set_option("spgemm_variant", variant)
     try:
@@ -566,7 +567,7 @@ def test_fuzz_spgemm_vs_oracle(nt, seed):
         dense_branch = min(A.nnz, B.nnz) / float(n * n) > 0.1
         Ao, Bo, Co = (O.Mat.from_triplets(n, n, *nt.Matrix_ps.from_scipy(M).triplets()) for M in (A, B, C0))
         want = O.ps_multiply(Ao, Bo, Co if beta != 0.0 else None, alpha, beta, thr).triplets()
-        for fb, var in ((-1, -1), (5, -1), (6, -1), (-1, 0), (-1, 400)):
+        for fb, var in ((-1, -1), (5, -1), (6, -1), (-1, 0), (-1, 400), (-1, 500)):
             nt.set_option("spgemm_force_bin", fb)
             nt.set_option("spgemm_variant", var)
             try:
@@ -658,3 +659,113 @@ def test_hash_table_classes_vs_oracle(nt, density, expect_overflow):
     dense_branch = A.nnz / float(n * n) > 0.1
     assert not dense_branch
     exact(C.triplets(), (n, n, oc, orow, ov), "hash classes density %g" % density)
+
+
+def _grouped_case(nt, A, B, thr, alpha=1.0):
+    """C = alpha*A*B through the grouped LDS-hash kernel (forced) against the oracle, bit for bit; returns its statistics"""
+    from oracle import oracle_py as O
+    mA, mB = nt.Matrix_ps.from_scipy(A), (nt.Matrix_ps.from_scipy(B) if B is not A else None)
+    n = A.shape[0]
+    C = nt.Matrix_ps(n)
+    nt.set_option("spgemm_variant", 500)
+    try:
+        C.Gemm(mA, mB if mB is not None else mA, None, alpha, 0.0, thr)
+        st = nt.last_spgemm_stats()
+        gs = nt.last_grouped_stats()
+    finally:
+        nt.set_option("spgemm_variant", -1)
+    Ao = O.Mat.from_triplets(n, n, *mA.triplets())
+    Bo = O.Mat.from_triplets(n, n, *mB.triplets()) if mB is not None else Ao
+    oc, orow, ov = O.ps_multiply(Ao, Bo, None, alpha, 0.0, thr).triplets()
+    assert st["slab"] == 0
+    exact(C.triplets(), (n, n, oc, orow, ov), "grouped hash")
+    return st, gs
+
+
+@pytest.mark.parametrize("n,h,holes,thr,cplx,same", [(8192, 50, 0.0, 1e-8, False, True), (6000, 100, 0.15, 1e-7, False, False),
+                                                       (5000, 30, 0.3, 0.0, False, False), (7000, 160, 0.0, 1e-8, False, True),
+                                                       (4096, 50, 0.0, 1e-8, True, True), (3001, 37, 0.3, 0.0, True, False),
+                                                       (4097, 300, 0.0, 1e-6, False, True)])
+def test_grouped_hash_permuted_vs_oracle(nt, n, h, holes, thr, cplx, same):
+    """banded operands under a random symmetric relabelling (what LoadBalancerModule.F90:14-52 hands the multiply): no
+    run structure, every row window spans the matrix.  The grouped LDS-hash kernel must find the similar columns
+    (min-hash clustering), compute every group without falling back, and equal the oracle bit for bit."""
+    import scipy.sparse as sp
+    from gen import permuted_banded_triplets
+    rng = np.random.default_rng(n + h)
+    mats = []
+    for t in range(1 if same else 2):
+        col, row, val = permuted_banded_triplets(n, h, 42, shift=0.1 * t, complex_=cplx)
+        keep = (rng.random(len(val)) >= holes) | (col == row)
+        mats.append(sp.csc_matrix((val[keep], (row[keep] - 1, col[keep] - 1)), shape=(n, n)))
+    A = mats[0]
+    B = A if same else mats[1]
+    st, gs = _grouped_case(nt, A, B, thr, alpha=1.0 if same else -0.5)
+    assert gs["used"] == 1 and gs["minhash"] == 1, gs
+    assert gs["failed_cols"] <= n // 20, gs    # (a group that straddles two clusters may outgrow the largest table)
+    assert gs["union_ratio"] < 2.5, gs
+
+
+def test_grouped_hash_natural_order_and_fallback(nt):
+    """(1) a 3-D lattice operator in its natural order (adjacent columns are similar, no clustering needed); (2) an
+    operand whose columns have nothing in common (uniformly random pattern): the row unions outgrow every table class,
+    all groups are handed back to the per-column LDS hash, and the result is still the oracle's."""
+    import scipy.sparse as sp
+    L = 18
+    idx = np.arange(L ** 3).reshape(L, L, L)
+    rows, cols, vals = [], [], []
+    rng = np.random.default_rng(5)
+    for dx in range(-2, 3):
+        for dy in range(-2, 3):
+            for dz in range(-2, 3):
+                if dx * dx + dy * dy + dz * dz > 5:
+                    continue
+                src = idx[max(0, -dx):L - max(0, dx), max(0, -dy):L - max(0, dy), max(0, -dz):L - max(0, dz)].ravel()
+                dst = idx[max(0, dx):L - max(0, -dx), max(0, dy):L - max(0, -dy), max(0, dz):L - max(0, -dz)].ravel()
+                rows.append(dst); cols.append(src)
+                vals.append(rng.uniform(-1, 1, len(src)) * np.exp(-0.5 * (dx * dx + dy * dy + dz * dz)))
+    A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(L ** 3, L ** 3))
+    A.sort_indices()
+    st, gs = _grouped_case(nt, A, A, 1e-9)
+    assert gs["used"] == 1 and gs["failed_cols"] == 0, gs
+    n = 6000
+    R = sp.random(n, n, 0.006, random_state=np.random.default_rng(7), format="csc", data_rvs=lambda k: rng.uniform(-1, 1, k))
+    R.sort_indices()
+    st, gs = _grouped_case(nt, R, R, 1e-6)
+    assert gs["used"] == 1 and gs["failed_cols"] > n // 2, gs    # forced: the automatic rule declines such operands
+    C = nt.Matrix_ps(n)
+    mR = nt.Matrix_ps.from_scipy(R)
+    C.Gemm(mR, mR, None, 1.0, 0.0, 1e-6)
+    assert nt.last_grouped_stats()["used"] == 0 and nt.last_grouped_stats()["union_ratio"] > 6.0
+
+
+def test_grouped_hash_full_size_permuted_config2(nt):
+    """the permuted configs[1]-family operand (N = 65 536, 201 entries per row, seed 42) through the
+    DEFAULT dispatch -- the grouped LDS-hash kernel -- against the oracle at full size, bit for bit; the one-column-per
+    -wave hash (variant 501) gives the same bits."""
+    from oracle import oracle_py as O
+    from gen import permuted_banded_triplets
+    n, h = 65536, 100
+    col, row, val = permuted_banded_triplets(n, h, 42)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    C = nt.Matrix_ps(n)
+    nt.set_option("time_kernels", 1)
+    try:
+        C.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+        st, gs = nt.last_spgemm_stats(), nt.last_grouped_stats()
+    finally:
+        nt.set_option("time_kernels", 0)
+    assert st["slab"] == 0 and gs["used"] == 1 and gs["minhash"] == 1 and gs["failed_cols"] == 0, (st, gs)
+    assert st["products"] > 2.6e9
+    got = C.triplets()
+    Ao = O.Mat.from_triplets(n, n, col, row, val)
+    oc, orow, ov = O.ps_multiply(Ao, Ao, None, 1.0, 0.0, 1e-8).triplets()
+    exact(got, (n, n, oc, orow, ov), "permuted config 2 (h = 100) vs oracle")
+    nt.set_option("spgemm_variant", 501)
+    try:
+        C2 = nt.Matrix_ps(n)
+        C2.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+    finally:
+        nt.set_option("spgemm_variant", -1)
+    g2 = C2.triplets()
+    assert np.array_equal(got[0], g2[0]) and np.array_equal(got[1], g2[1]) and np.array_equal(got[2], g2[2])

@@ -72,6 +72,7 @@ def main():
                 assert sig == ref or args.fma, ("variant %d differs" % v, sig, ref)
             res[v].append((st["ms_numeric"], st["ms_total"]))
     st = nt.last_spgemm_stats()
+    print("grouped path:", nt.last_grouped_stats())
     print("max span per bin:", nt.last_spgemm_stats())
     print("operand nnz %d, products %.3e, nnz_c %d, bins %s" % (st["nnz_a"], st["products"], st["nnz_c"], st["bins"]))
     for v in variants:
