@@ -2356,10 +2356,10 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     unsigned long long nonempty = 0;
     for (int i = 1; i <= 6; ++i) nonempty += hstats[i];
     const bool want = nonempty > 0 && options().spgemm_force_bin <= 0 &&
-                      (sv_opt == 500 || (sv_opt < 0 && hstats[5] * 2 >= nonempty));
+                      (sv_opt == 500 || (sv_opt >= 511 && sv_opt <= 525) || (sv_opt < 0 && hstats[5] * 2 >= nonempty));
     if (want) {
       GroupedInfo gi;
-      if (spgemm_grouped(A, B, tmpoff.p, tmp_inner.p, tmp_val.p, count.p, bin.p, alpha, threshold, dr, sv_opt == 500, &gi)) {
+      if (spgemm_grouped(A, B, tmpoff.p, tmp_inner.p, tmp_val.p, count.p, bin.p, alpha, threshold, dr, sv_opt >= 500, &gi)) {
         for (int i = 1; i <= 6; ++i) hstats[i] = 0;
         hstats[5] = (unsigned long long)gi.failed_cols;   // what the grouped kernel handed back: per-column LDS hash below
         st.grouped = 1;

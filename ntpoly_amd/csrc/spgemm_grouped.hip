@@ -95,6 +95,97 @@ __global__ void k_gh_pad(int32_t* __restrict__ cols, int n, int npad) {
   if (i < npad) cols[i] = -1;
 }
 
+// ---- clusters and the order inside them
+// A cluster = a run of equal first signatures in the sorted order (columns that share their min-hash row).  Inside a
+// cluster the columns are ordered along a line: ref1 = the cluster's first column, ref2 = the column that shares the
+// fewest rows with ref1 (an end of the cluster), and the sort key is the number of rows shared with ref2, descending.
+// For a banded matrix under a relabelling this recovers the hidden order inside every cluster exactly (the overlap of
+// two columns falls by one per position of distance); in general it is a one-dimensional embedding by Jaccard distance.
+__global__ void k_gh_cluster_flags(const unsigned long long* __restrict__ sig_sorted, int32_t* __restrict__ flag, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  flag[p] = (p == 0 || (sig_sorted[p] >> 32) != (sig_sorted[p - 1] >> 32)) ? 1 : 0;
+}
+// cid[p] = cluster of position p; cstart[c] = first position of cluster c (cstart[nc] = n is written by the caller's fill)
+__global__ void k_gh_cluster_ids(const int32_t* __restrict__ flag, const int64_t* __restrict__ excl, int32_t* __restrict__ cid,
+                                 int32_t* __restrict__ cstart, unsigned long long* __restrict__ best, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n) return;
+  if (p == n) {
+    cstart[excl[n]] = n;
+    return;
+  }
+  const int c = (int)excl[p] + flag[p] - 1;
+  cid[p] = c;
+  if (flag[p]) {
+    cstart[c] = p;
+    best[c] = ~0ull;
+  }
+}
+// ov[p] = rows shared by the column at position p and its cluster's reference column (ref_pos == nullptr: the cluster's
+// first column; else the position stored in the low half of ref_pos[cluster]); optionally tracks the per-cluster minimum
+__global__ __launch_bounds__(256) void k_gh_overlap(Csc B, const int32_t* __restrict__ order, const int32_t* __restrict__ cid,
+                                                    const int32_t* __restrict__ cstart,
+                                                    const unsigned long long* __restrict__ ref_pos, int32_t* __restrict__ ov,
+                                                    unsigned long long* __restrict__ best, int n) {
+  const int p = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (p >= n) return;
+  const int lane = lane_id();
+  const int c = cid[p];
+  const int rp = ref_pos ? (int)(ref_pos[c] & 0xffffffffu) : cstart[c];
+  const int j = order[p], r = order[rp];
+  const int64_t rs = B.outer[r], re = B.outer[r + 1];
+  int cnt = 0;
+  for (int64_t q = B.outer[j] + lane; q < B.outer[j + 1]; q += WAVE) {
+    const int k = B.inner[q];
+    int64_t lo = rs, hi = re;   // first entry of the reference column that is >= k
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (B.inner[mid] < k) lo = mid + 1;
+      else hi = mid;
+    }
+    cnt += (lo < re && B.inner[lo] == k) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+  if (lane == 0) {
+    ov[p] = cnt;
+    if (best) atomicMin(&best[c], ((unsigned long long)(unsigned)cnt << 32) | (unsigned)p);
+  }
+}
+__global__ void k_gh_order_keys(const int32_t* __restrict__ cid, const int32_t* __restrict__ ov,
+                                unsigned long long* __restrict__ key, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) key[p] = ((unsigned long long)(unsigned)cid[p] << 32) | (unsigned)(0x7fffffff - ov[p]);
+}
+// groups never straddle clusters: a cluster of m columns is cut into ceil(m / G) groups of nearly equal size
+__global__ void k_gh_cluster_groups(const int32_t* __restrict__ cstart, int32_t* __restrict__ ng, int nc, int G) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nc) ng[c] = (cstart[c + 1] - cstart[c] + G - 1) / G;
+}
+__global__ void k_gh_fill_groups(const int32_t* __restrict__ order, const int32_t* __restrict__ cid,
+                                 const int32_t* __restrict__ cstart, const int64_t* __restrict__ goff,
+                                 int32_t* __restrict__ cols, int n, int G) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int c = cid[p];
+  const int m = cstart[c + 1] - cstart[c], r = p - cstart[c];
+  const int ng = (m + G - 1) / G, base = m / ng, rem = m % ng;   // `rem` groups hold base + 1 columns
+  int b, i;
+  if (r < rem * (base + 1)) {
+    b = r / (base + 1);
+    i = r % (base + 1);
+  } else {
+    const int r2 = r - rem * (base + 1);
+    b = rem + r2 / base;
+    i = r2 % base;
+  }
+  cols[((int64_t)goff[c] + b) * G + i] = order[p];
+}
+__global__ void k_gh_fill_i32(int32_t* __restrict__ a, int64_t n, int32_t v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
 // ------------------------------------------------------------------ union of the B rows of a group, multiplier tile
 // FILL = false: grp_kn[g] = |union| (-1 when it exceeds GH_KCAP), grp_maxlen[g] = longest A column over the union.
 // FILL = true : recs[off + t] = step t (k ascending), tile[(off + t) * G + c] = B(k_t, column c of the group) or 0.
@@ -119,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gh_union(Csc A, Csc B, const int32_t* _
     if (col < 0) continue;
     const int64_t s = B.outer[col], e = B.outer[col + 1];
     for (int64_t p0 = s; p0 < e; p0 += WAVE) {
-      if (*(volatile int*)&ctl[0] > GH_KCAP) break;
+      if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > GH_KCAP) break;
       const int64_t p = p0 + lane;
       bool fresh = false;
       if (p < e) {
@@ -235,15 +326,15 @@ __global__ void k_gh_init_state(const int32_t* __restrict__ grp_kn, int32_t* __r
 }
 
 // ------------------------------------------------------------------ numeric kernel
-// One workgroup per group.  The walk over the union of the B rows is cut into PHASES of up to KB consecutive steps
-// (KB = as many columns of A as fit GH_MAXLEN entries, at most 4): one barrier, one round of load latencies and one
-// round of hash probes serve KB steps.  Software pipeline, iteration i:
-//   L(i+2)  request the entries of the A columns of phase i+2 and its KB rows of multipliers (registers)
-//   S(i+1)  hash the rows of phase i+1 (requested one iteration ago) to slots, scatter the values into x[set(i+1)],
-//           put the multipliers into LDS
+// One workgroup (NW waves) per group.  The walk over the union of the B rows is cut into PHASES of KB = NW / WPC
+// consecutive steps: WPC waves share one column of A (a wave takes every WPC-th chunk of 64 entries), so the KB columns
+// of a phase are hashed and scattered concurrently and ONE barrier, one round of load latencies and one round of hash
+// probes serve KB steps.  Software pipeline, iteration i:
+//   L(i+2)  request the first PF chunks of this wave's share of its column of phase i+2 (registers)
+//   S(i+1)  hash the rows of phase i+1 (requested one iteration ago) to slots, scatter the values into x[set(i+1)]
 //   F(i)    products of phase i: for its steps in ascending k, every owned chunk of slots reads x[set(i)], multiplies
-//           with the G multipliers (LDS broadcast reads) into the register sums and writes zeros back (the reader owns
-//           the slot, so the two sets need no other cleaning)
+//           with the G multipliers (SGPRs: one scalar load of the tile row, requested one step ahead) into the register
+//           sums and writes zeros back (the reader owns the slot, so the two sets need no other cleaning)
 //   barrier
 template <int CAP>
 struct GhTable {
@@ -251,24 +342,21 @@ struct GhTable {
   static constexpr int SHIFT = CAP <= 512 ? 22 : CAP <= 1024 ? 21 : 20;        // top bits of the multiplicative hash
 };
 
-template <typename T, int NW, int SL>
-__global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL <= 2 ? 4 : 2)))) void k_spgemm_ghash(
+template <typename T, int NW, int SL, int WPC>
+__global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL == 1 && !Sc<T>::cplx) ? 6 : 2))) void k_spgemm_ghash(
     Csc A, const int32_t* __restrict__ cols, const int32_t* __restrict__ grp_kn, const int32_t* __restrict__ grp_maxlen,
     const int64_t* __restrict__ grp_off, const GhRec* __restrict__ recs, const T* __restrict__ tiles,
     const int64_t* __restrict__ tmpoff, int32_t* __restrict__ out_inner, T* __restrict__ out_val,
     int32_t* __restrict__ count, uint8_t* __restrict__ grp_state, unsigned long long* __restrict__ stats, double alpha,
-    double threshold, int dense_rule, int ngroups) {
+    double threshold, int dense_rule, int ngroups, int ablate) {
   constexpr int G = GhG<T>::value;
   constexpr int NT = NW * WAVE, CAP = NT * SL, TH = GhTable<CAP>::TH, SHIFT = GhTable<CAP>::SHIFT;
-  constexpr int EF = GH_MAXLEN / NT;   // entries per thread and phase
-  // steps per phase the two x sets may hold: 32 KB of LDS for them (48 KB for the largest table class)
-  constexpr int XB = (CAP <= 1024 ? 32768 : 49152) / (2 * CAP * (int)sizeof(T));
-  constexpr int KBX = XB >= 4 ? 4 : XB >= 2 ? 2 : 1;
+  constexpr int KB = NW / WPC;   // steps per phase
+  constexpr int PF = 2;          // chunks of a wave's share requested a phase ahead
   constexpr unsigned long long EMPTY = ~0ull;
-  static_assert(EF >= 1 && EF * NT == GH_MAXLEN, "threads per workgroup must divide GH_MAXLEN");
+  static_assert(NW % WPC == 0 && KB >= 1 && 2 * KB * CAP >= 2 * CAP, "geometry");
   __shared__ unsigned long long htab[TH];   // (row << 32 | slot); the epilogue sorts (row, slot) pairs in the same memory
-  __shared__ T xbuf[2][KBX][CAP];           // slot-indexed copies of the A columns of two consecutive phases
-  __shared__ T mult[2][KBX][G];             // their rows of multipliers
+  __shared__ T xbuf[2][KB][CAP];            // slot-indexed copies of the A columns of two consecutive phases
   __shared__ int slot_row[CAP];
   __shared__ int ctl[4];                    // [0] slots handed out, [1], [2] overflow seen while scattering an even / odd
                                             // phase (read after the barrier that ends that scatter, rewritten two
@@ -280,15 +368,13 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL <=
   const int kn = grp_kn[gi];
   if (kn <= 0) return;
   const int tid = threadIdx.x, wave = uni_i32(tid / WAVE), lane = lane_id();
-  const int maxlen = grp_maxlen[gi];
-  if (maxlen > GH_MAXLEN) {  // a column of A longer than one phase scatters: the group goes to the fallback
+  if (grp_maxlen[gi] > GH_MAXLEN) {  // a column of A too long for the scatter of one phase: the group goes to the fallback
     if (tid == 0) atomicAdd(&stats[0], 1ull);
     return;
   }
-  const int kb_n = min(KBX, GH_MAXLEN / max(1, maxlen));   // steps per phase: their columns hold <= GH_MAXLEN entries together
-  const int nph = (kn + kb_n - 1) / kb_n;
+  const int nph = (kn + KB - 1) / KB;
   for (int s = tid; s < TH; s += NT) htab[s] = EMPTY;
-  for (int s = tid; s < 2 * KBX * CAP; s += NT) (&xbuf[0][0][0])[s] = Sc<T>::zero();
+  for (int s = tid; s < 2 * KB * CAP; s += NT) (&xbuf[0][0][0])[s] = Sc<T>::zero();
   for (int s = tid; s < CAP; s += NT) slot_row[s] = -1;
   if (tid < 4) ctl[tid] = 0;
   __syncthreads();
@@ -298,6 +384,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL <=
   const int64_t off = grp_off[gi];
   const GhRec* __restrict__ rec = recs + off;
   const T* __restrict__ tile = tiles + off * G;
+  const int my_kb = wave / WPC, my_part = wave % WPC;   // this wave's column of a phase and its share of it
 
   T acc[SL][G];
 #pragma unroll
@@ -305,124 +392,179 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL <=
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[s][g] = Sc<T>::zero();
 
-  // registers of one phase in flight: this thread's entries (row, value, step within the phase) and its multiplier
   struct Fetch {
-    int idx[EF];
-    T val[EF];
-    int kbs;    // 2 bits per entry
-    T m;
+    int idx[PF];
+    T val[PF];
+    int64_t start;   // this wave's column of the phase (wave-uniform), kept so that the scatter need not load it again
+    int len;
   };
-  // L: request phase `ph`
+  // L: first PF chunks of this wave's share of column (ph, my_kb).  The step record comes in through the vector path
+  // (requested one phase earlier as `rnext`, lane 0) -- a scalar load here would be a cold miss on the critical path.
+  int64_t rn_start = 0;   // record of this wave's column of the NEXT phase to be loaded (lane 0 holds it)
+  int rn_len = 0;
+  auto request_rec = [&](int ph) {
+    const int t = ph * KB + my_kb;
+    rn_start = 0;
+    rn_len = 0;
+    if (t < kn && lane == 0) {
+      rn_start = rec[t].start;
+      rn_len = rec[t].len;
+    }
+  };
+  long long warm = 0;   // keeps the cache warm-up loads alive (never stored)
   auto load_phase = [&](int ph, Fetch& f) {
-    const int t0 = ph * kb_n;
-    int64_t st[4];
-    int pre[5];
-    pre[0] = 0;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int t = min(t0 + kb, kn - 1);
-      const bool on = kb < kb_n && t0 + kb < kn;
-      st[kb] = rec[t].start;
-      pre[kb + 1] = pre[kb] + (on ? rec[t].len : 0);
+    const int64_t start = readlane_i64(rn_start, 0);
+    const int len = readlane_i32(rn_len, 0);
+    request_rec(ph + 1);
+    // the multiplier rows of that phase are read with scalar loads later: pull them into L2 now
+    if (wave == 0 && lane < KB * G * (int)sizeof(T) / 8) {
+      const int64_t w = (int64_t)ph * KB * G * (int)sizeof(T) / 8 + lane;
+      if (w < (int64_t)kn * G * (int)sizeof(T) / 8) warm += reinterpret_cast<const long long*>(tile)[w];
     }
-    f.kbs = 0;
+    f.start = start;
+    f.len = len;
 #pragma unroll
-    for (int e = 0; e < EF; ++e) {
-      const int q = e * NT + tid;
-      f.idx[e] = -1;
-      f.val[e] = Sc<T>::zero();
-      if (e * NT >= pre[4]) continue;
-      if (q < pre[4]) {
-        const int kb = (q >= pre[1] ? 1 : 0) + (q >= pre[2] ? 1 : 0) + (q >= pre[3] ? 1 : 0);
-        const int64_t base = kb == 0 ? st[0] : kb == 1 ? st[1] - pre[1] : kb == 2 ? st[2] - pre[2] : st[3] - pre[3];
-        f.idx[e] = Ai[base + q];
-        f.val[e] = Av[base + q];
-        f.kbs |= kb << (2 * e);
+    for (int c = 0; c < PF; ++c) {
+      const int q = (c * WPC + my_part) * WAVE + lane;
+      f.idx[c] = -1;
+      f.val[c] = Sc<T>::zero();
+      if (q < len) {
+        f.idx[c] = Ai[start + q];
+        f.val[c] = Av[start + q];
       }
     }
-    const int nrow = min(kb_n, kn - t0);
-    f.m = Sc<T>::zero();
-    if (tid < nrow * G) f.m = tile[(int64_t)t0 * G + tid];
   };
-  // S: rows -> slots (first touch allocates), values into xbuf[set], multipliers into mult[set]
-  auto scatter_phase = [&](int ph, int set, const Fetch& f) {
-#pragma unroll
-    for (int e = 0; e < EF; ++e) {
-      const int i = f.idx[e];
-      if (i >= 0) {
-        unsigned h = gh_hash((unsigned)i) >> SHIFT;
-        int mine = -1, slot = -1;
-        for (;;) {
-          const unsigned long long cur = *(volatile unsigned long long*)&htab[h];
-          if ((int)(cur >> 32) == i) { slot = (int)(cur & 0xffffffffu); break; }
-          if (cur == EMPTY) {
-            if (mine < 0) {
-              mine = atomicAdd(&ctl[0], 1);
-              if (mine >= CAP) { ctl[1 + (ph & 1)] = 1; break; }
-            }
-            const unsigned long long want = ((unsigned long long)(unsigned)i << 32) | (unsigned)mine;
-            const unsigned long long old = atomicCAS(&htab[h], EMPTY, want);
-            if (old == EMPTY) { slot_row[mine] = i; slot = mine; break; }
-            if ((int)(old >> 32) == i) { slot = (int)(old & 0xffffffffu); break; }  // same row, inserted meanwhile: `mine` stays a hole
-          }
-          h = (h + 1) & (TH - 1);
+  // row -> slot (first touch allocates the next one); -1 when the table class is exhausted.  Insertion is two-step so
+  // that concurrent first touches of one row (the KB columns of a phase overlap heavily) never waste a slot: the bucket
+  // is claimed with the slot field PENDING, the winner then draws the slot number and publishes it; whoever meets a
+  // pending entry of its own row re-reads the bucket (the winner finishes inside the same loop iteration, so lanes of
+  // one wave cannot wait on each other forever).
+  constexpr unsigned PENDING = 0x7fffffffu, NOSLOT = 0x7ffffffeu;
+  auto slot_of = [&](int i, int par) -> int {
+    unsigned h = gh_hash((unsigned)i) >> SHIFT;
+    for (;;) {
+      const unsigned long long cur = __hip_atomic_load(&htab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((int)(cur >> 32) == i) {
+        const unsigned sl = (unsigned)(cur & 0xffffffffu);
+        if (sl == PENDING) continue;
+        return sl == NOSLOT ? -1 : (int)sl;
+      }
+      if (cur == EMPTY) {
+        const unsigned long long claim = ((unsigned long long)(unsigned)i << 32) | PENDING;
+        const unsigned long long old = atomicCAS(&htab[h], EMPTY, claim);
+        if (old == EMPTY) {
+          const int mine = atomicAdd(&ctl[0], 1);
+          const bool ok = mine < CAP;
+          if (ok) slot_row[mine] = i;
+          else ctl[1 + par] = 1;
+          __hip_atomic_store(&htab[h], ((unsigned long long)(unsigned)i << 32) | (ok ? (unsigned)mine : NOSLOT), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+          return ok ? mine : -1;
         }
-        if (slot >= 0) xbuf[set][(f.kbs >> (2 * e)) & 3][slot] = f.val[e];
+        if ((int)(old >> 32) == i) continue;   // the same row is being inserted by somebody else: read it again
+      }
+      h = (h + 1) & (TH - 1);
+    }
+  };
+  // S: values of column (ph, my_kb) into xbuf[set][my_kb]
+  auto scatter_phase = [&](int ph, int set, const Fetch& f) {
+    const int par = ph & 1;
+#pragma unroll
+    for (int c = 0; c < PF; ++c) {
+      const int i = f.idx[c];
+      if (i >= 0) {
+        const int slot = slot_of(i, par);
+        if (slot >= 0) xbuf[set][my_kb][slot] = f.val[c];
       }
     }
-    if (tid < KBX * G) (&mult[set][0][0])[tid] = f.m;
+    // the rest of a long column: loaded here
+    const int64_t start = uni_i64(f.start);
+    const int len = uni_i32(f.len);
+    for (int q0 = (PF * WPC + my_part) * WAVE; q0 < len; q0 += WPC * WAVE) {
+      const int q = q0 + lane;
+      if (q < len) {
+        const int slot = slot_of(Ai[start + q], par);
+        if (slot >= 0) xbuf[set][my_kb][slot] = Av[start + q];
+      }
+    }
   };
 
   Fetch fc, fn;
+  request_rec(0);
   load_phase(0, fc);
-  if (nph > 1) load_phase(1, fn);
+  load_phase(1, fn);
   scatter_phase(0, 0, fc);
   __syncthreads();
   bool overflow = ctl[1] != 0;   // (phase 0 is even)
+  // (ablate & 8: in-kernel stamps of wave 0 -- cycles spent in the load / scatter / product / barrier parts, summed into stats[8..12])
+  unsigned long long st_load = 0, st_scat = 0, st_fp = 0, st_bar = 0;
   for (int ph = 0; ph < nph && !overflow; ++ph) {
     const int set = ph & 1;
+    unsigned long long c0s = 0, c1s = 0, c2s = 0, c3s = 0;
+    if (ablate & 8) c0s = __builtin_amdgcn_s_memtime();
     fc = fn;
-    if (ph + 2 < nph) load_phase(ph + 2, fn);
-    if (ph + 1 < nph) scatter_phase(ph + 1, set ^ 1, fc);
+    load_phase(ph + 2, fn);
+    if (ablate & 8) c1s = __builtin_amdgcn_s_memtime();
+    if (ph + 1 < nph && !(ablate & 2)) scatter_phase(ph + 1, set ^ 1, fc);
+    if (ablate & 8) c2s = __builtin_amdgcn_s_memtime();
     // products of phase ph: chunks that hold slots handed out before the last barrier
-    const int nsl = uni_i32(min(*(volatile int*)&ctl[0], CAP));
-    const int nstep = min(kb_n, kn - ph * kb_n);
-    for (int kb = 0; kb < nstep; ++kb) {
-      T xv[SL];
-      bool act[SL];
+    const int nsl = uni_i32(min(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), CAP));
+    const int t0 = ph * KB;
+    const int nstep = min(KB, kn - t0);
+    // the multipliers (wave-uniform: scalar registers) are fetched two rows per round trip of the scalar cache
+    for (int kb = 0; kb < nstep; kb += 2) {
+      const T* __restrict__ brow = tile + (int64_t)(t0 + kb) * G;
+      T b0[G], b1[G];
 #pragma unroll
-      for (int s = 0; s < SL; ++s) {
-        const int c0 = (wave + NW * s) * WAVE;
-        act[s] = c0 < nsl;
-        xv[s] = Sc<T>::zero();
-        if (act[s]) {
-          xv[s] = xbuf[set][kb][c0 + lane];
-          act[s] = __ballot(!Sc<T>::is_zero(xv[s])) != 0ull;
-          if (act[s]) xbuf[set][kb][c0 + lane] = Sc<T>::zero();
-        }
+      for (int g = 0; g < G; ++g) {
+        b0[g] = brow[g];
+        b1[g] = brow[G + g];   // (the tile is padded by 8 rows: the row after the last one exists)
       }
 #pragma unroll
-      for (int g0 = 0; g0 < G; g0 += 4) {
-        T m[4];
+      for (int half = 0; half < 2; ++half) {
+        if (kb + half < nstep) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) m[g] = mult[set][kb][g0 + g];
+          for (int s = 0; s < SL; ++s) {
+            const int c0 = (wave + NW * s) * WAVE;
+            if ((c0 < nsl && !(ablate & 1)) || (ablate & 3) == 2) {   // (ablate: timing experiments, wrong results)
+              const T xv = xbuf[set][kb + half][c0 + lane];
+              if (__ballot(!Sc<T>::is_zero(xv)) != 0ull || (ablate & 3) == 2) {
+                xbuf[set][kb + half][c0 + lane] = Sc<T>::zero();
 #pragma unroll
-        for (int s = 0; s < SL; ++s) {
-          if (act[s]) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[s][g0 + g] = Sc<T>::add(acc[s][g0 + g], Sc<T>::mul(xv[s], m[g]));
+                for (int g = 0; g < G; ++g) acc[s][g] = Sc<T>::add(acc[s][g], Sc<T>::mul(xv, half ? b1[g] : b0[g]));
+              }
+            }
           }
         }
       }
     }
+    if (ablate & 8) c3s = __builtin_amdgcn_s_memtime();
     __syncthreads();
     overflow = ctl[1 + ((ph + 1) & 1)] != 0;
+    if (ablate & 8) {
+      st_load += c1s - c0s;
+      st_scat += c2s - c1s;
+      st_fp += c3s - c2s;
+      st_bar += __builtin_amdgcn_s_memtime() - c3s;
+    }
   }
+  if ((ablate & 8) && tid == 0) {
+    atomicAdd(&stats[8], st_load);
+    atomicAdd(&stats[9], st_scat);
+    atomicAdd(&stats[10], st_fp);
+    atomicAdd(&stats[11], st_bar);
+    atomicAdd(&stats[12], (unsigned long long)nph);
+  }
+  if (warm == 0x7fffffffffffffffll && kn < 0) stats[7] = (unsigned long long)warm;   // (never true: keeps the warm-up loads)
   if (overflow) {  // the row union outgrew this table class: the group stays "to do" for the next one
     if (tid == 0) atomicAdd(&stats[0], 1ull);
     return;
   }
 
+  if (ablate & 4) {
+    if (tid == 0) grp_state[gi] = 1;
+    return;
+  }
   // ---- epilogue: rows in ascending order, then column by column through LDS
   const int nsl = min(ctl[0], CAP);
   int p2 = 64;
@@ -532,13 +674,15 @@ __global__ void k_gh_finish(const int32_t* __restrict__ cols, const uint8_t* __r
   }
 }
 
-template <typename T, int NW, int SL>
+template <typename T, int NW, int SL, int WPC>
 void launch_ghash(const DevMat& A, int ngroups, const int32_t* cols, const int32_t* grp_kn, const int32_t* grp_maxlen,
                   const int64_t* grp_off, const GhRec* recs, const double* tiles, const int64_t* tmpoff, int32_t* tmp_inner,
                   double* tmp_val, int32_t* count, uint8_t* state, unsigned long long* stats, double alpha, double thr, int dr) {
-  hipLaunchKernelGGL((k_spgemm_ghash<T, NW, SL>), dim3(xcd_grid(ngroups)), dim3(NW * WAVE), 0, stream(), view(A), cols, grp_kn,
+  const int sv = options().spgemm_variant;
+  const int ablate = (sv >= 511 && sv <= 525) ? sv - 510 : 0;   // bits: 1 no products, 2 no hashing / scatter, 4 no epilogue
+  hipLaunchKernelGGL((k_spgemm_ghash<T, NW, SL, WPC>), dim3(xcd_grid(ngroups)), dim3(NW * WAVE), 0, stream(), view(A), cols, grp_kn,
                      grp_maxlen, grp_off, recs, reinterpret_cast<const T*>(tiles), tmpoff, tmp_inner,
-                     reinterpret_cast<T*>(tmp_val), count, state, stats, alpha, thr, dr, ngroups);
+                     reinterpret_cast<T*>(tmp_val), count, state, stats, alpha, thr, dr, ngroups, ablate);
 }
 
 }  // namespace
@@ -548,86 +692,150 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
                     GroupedInfo* info) {
   const int n = B.cols;
   const int G = A.cplx ? 8 : 16;
-  const int ngroups = cdiv(n, G), npad = ngroups * G;
+  int ngroups = cdiv(n, G);
   GroupedInfo gi;
-  gi.groups = ngroups;
-  DevBuf<int32_t> cols((size_t)npad), cols2, grp_kn((size_t)ngroups), grp_maxlen((size_t)ngroups), kn_pos((size_t)ngroups);
-  DevBuf<int32_t> grp_kn2, grp_maxlen2;
-  DevBuf<int64_t> grp_off((size_t)ngroups + 1);
-  DevBuf<uint8_t> state((size_t)ngroups);
-  DevBuf<unsigned long long> stats(8);
+  DevBuf<int32_t> cols, grp_kn, grp_maxlen, kn_pos;
+  DevBuf<int64_t> grp_off;
+  DevBuf<uint8_t> state;
+  DevBuf<unsigned long long> stats(16);
 
-  auto count_pass = [&](const int32_t* c, int32_t* kn, int32_t* ml) {
+  auto count_pass = [&](const int32_t* c, int32_t* kn, int32_t* ml, int ng) {
     dispatch_type(A.cplx, [&](auto tag) {
       using T = decltype(tag);
-      hipLaunchKernelGGL((k_gh_union<T, false>), dim3(xcd_grid(ngroups)), dim3(256), 0, stream(), view(A), view(B), c, kn, ml,
-                         (const int64_t*)nullptr, (GhRec*)nullptr, (T*)nullptr, ngroups);
+      hipLaunchKernelGGL((k_gh_union<T, false>), dim3(xcd_grid(ng)), dim3(256), 0, stream(), view(A), view(B), c, kn, ml,
+                         (const int64_t*)nullptr, (GhRec*)nullptr, (T*)nullptr, ng);
     });
   };
   // steps of the numeric kernel = sum of the groups' unions; *cost: the same with unusable groups (union beyond the
   // tile builder's capacity) counted at that capacity, so that they do not make an ordering look good
-  auto total_of = [&](const int32_t* kn, int64_t* cost) -> int64_t {
+  auto total_of = [&](const int32_t* kn, int32_t* pos, int64_t* off, uint8_t* st, int ng, int64_t* cost) -> int64_t {
     stats.zero();
-    hipLaunchKernelGGL(k_gh_init_state, dim3(cdiv(ngroups, 256)), dim3(256), 0, stream(), kn, kn_pos.p, state.p, stats.p, ngroups);
-    scan_i32_async(kn_pos.p, grp_off.p, (int64_t)ngroups);
+    hipLaunchKernelGGL(k_gh_init_state, dim3(cdiv(ng, 256)), dim3(256), 0, stream(), kn, pos, st, stats.p, ng);
+    scan_i32_async(pos, off, (int64_t)ng);
     int64_t total = 0;
     unsigned long long nbad = 0;
     ScalarFetch f;
-    f.add(grp_off.p + ngroups, 1, &total);
+    f.add(off + ng, 1, &total);
     f.add(stats.p, 1, &nbad);
     f.run();
     *cost = total + (int64_t)nbad * GH_KCAP;
     return total;
   };
 
-  // natural order first: adjacent columns of a locally ordered matrix are similar
-  hipLaunchKernelGGL(k_gh_iota, dim3(cdiv(npad, 256)), dim3(256), 0, stream(), cols.p, n, npad);
-  count_pass(cols.p, grp_kn.p, grp_maxlen.p);
-  int64_t cost = 0;
-  int64_t total = total_of(grp_kn.p, &cost);
+  // The column order of the last multiply of this dimension is kept: purification iterates keep their similarity
+  // structure from one multiply to the next, so the clustering is only redone when the kept order stops paying
+  // (its union ratio has grown by more than 15 % since it was made).
+  struct OrderCache {
+    int n = -1, ngroups = 0, minhash = 0;
+    double ratio0 = 0;
+    DevBuf<int32_t> cols;
+  };
+  static OrderCache* cache[2] = {new OrderCache(), new OrderCache()};   // real / complex (leaked on purpose, like the context)
+  OrderCache& oc = *cache[A.cplx ? 1 : 0];
   const double ideal = std::max(1.0, (double)B.nnz / (double)G);
-  double ratio = (double)cost / ideal;
-  if (ratio > 1.5) {
-    // cluster the columns by min-hash signature and count again
-    DevBuf<unsigned long long> sig((size_t)n), sig_sorted((size_t)n);
-    DevBuf<int32_t> ids((size_t)n);
-    cols2.alloc((size_t)npad);
-    grp_kn2.alloc((size_t)ngroups);
-    grp_maxlen2.alloc((size_t)ngroups);
-    hipLaunchKernelGGL(k_gh_signature, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(B), sig.p, ids.p);
-    size_t tmp_bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, sig.p, sig_sorted.p, ids.p, cols2.p, (size_t)n, 0, 64, stream());
-    DevBuf<char> tmp(tmp_bytes + 16);
-    if (rocprim::radix_sort_pairs(tmp.p, tmp_bytes, sig.p, sig_sorted.p, ids.p, cols2.p, (size_t)n, 0, 64, stream()) != hipSuccess)
-      NTP_FATAL("radix sort failed");
-    if (npad > n) hipLaunchKernelGGL(k_gh_pad, dim3(cdiv(npad - n, 256)), dim3(256), 0, stream(), cols2.p, n, npad);
-    count_pass(cols2.p, grp_kn2.p, grp_maxlen2.p);
-    int64_t cost2 = 0;
-    const int64_t total2 = total_of(grp_kn2.p, &cost2);
-    if (cost2 < cost) {
-      std::swap(cols, cols2);
-      std::swap(grp_kn, grp_kn2);
-      std::swap(grp_maxlen, grp_maxlen2);
-      total = total2;
-      cost = cost2;
-      ratio = (double)cost / ideal;
-      gi.minhash = 1;
-    } else {
-      total = total_of(grp_kn.p, &cost);  // offsets and states of the natural order again
-    }
+  int64_t cost = 0, total = 0;
+  double ratio = 0;
+  bool reuse = false;
+  if (oc.n == n && oc.ngroups > 0) {
+    ngroups = oc.ngroups;
+    grp_kn.alloc((size_t)ngroups); grp_maxlen.alloc((size_t)ngroups); kn_pos.alloc((size_t)ngroups);
+    grp_off.alloc((size_t)ngroups + 1); state.alloc((size_t)ngroups);
+    count_pass(oc.cols.p, grp_kn.p, grp_maxlen.p, ngroups);
+    total = total_of(grp_kn.p, kn_pos.p, grp_off.p, state.p, ngroups, &cost);
+    ratio = (double)cost / ideal;
+    reuse = ratio <= std::max(1.3, 1.15 * oc.ratio0);
+    gi.minhash = oc.minhash;
   }
+  if (!reuse) {
+    // natural order first: adjacent columns of a locally ordered matrix are similar
+    ngroups = cdiv(n, G);
+    cols.alloc((size_t)ngroups * G);
+    grp_kn.alloc((size_t)ngroups); grp_maxlen.alloc((size_t)ngroups); kn_pos.alloc((size_t)ngroups);
+    grp_off.alloc((size_t)ngroups + 1); state.alloc((size_t)ngroups);
+    gi.minhash = 0;
+    hipLaunchKernelGGL(k_gh_iota, dim3(cdiv(ngroups * G, 256)), dim3(256), 0, stream(), cols.p, n, ngroups * G);
+    count_pass(cols.p, grp_kn.p, grp_maxlen.p, ngroups);
+    total = total_of(grp_kn.p, kn_pos.p, grp_off.p, state.p, ngroups, &cost);
+    ratio = (double)cost / ideal;
+    if (ratio > 1.5) {
+      // cluster the columns by min-hash signature, order every cluster along a line, cut it into groups, count again
+      DevBuf<unsigned long long> sig((size_t)n), sig_sorted((size_t)n), best((size_t)n + 1);
+      DevBuf<int32_t> ids((size_t)n), order((size_t)n), order2((size_t)n), flag((size_t)n), cid((size_t)n), cstart((size_t)n + 1),
+          ov((size_t)n), ng_c((size_t)n);
+      DevBuf<int64_t> excl((size_t)n + 1), goff((size_t)n + 1);
+      hipLaunchKernelGGL(k_gh_signature, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(B), sig.p, ids.p);
+      size_t tmp_bytes = 0;
+      (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, sig.p, sig_sorted.p, ids.p, order.p, (size_t)n, 0, 64, stream());
+      DevBuf<char> tmp(tmp_bytes + 16);
+      if (rocprim::radix_sort_pairs(tmp.p, tmp_bytes, sig.p, sig_sorted.p, ids.p, order.p, (size_t)n, 0, 64, stream()) != hipSuccess)
+        NTP_FATAL("radix sort failed");
+      hipLaunchKernelGGL(k_gh_cluster_flags, dim3(cdiv(n, 256)), dim3(256), 0, stream(), sig_sorted.p, flag.p, n);
+      scan_i32_async(flag.p, excl.p, (int64_t)n);
+      hipLaunchKernelGGL(k_gh_cluster_ids, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), flag.p, excl.p, cid.p, cstart.p, best.p, n);
+      const int nb = cdiv((int64_t)n * WAVE, 256);
+      hipLaunchKernelGGL(k_gh_overlap, dim3(nb), dim3(256), 0, stream(), view(B), order.p, cid.p, cstart.p,
+                         (const unsigned long long*)nullptr, ov.p, best.p, n);
+      hipLaunchKernelGGL(k_gh_overlap, dim3(nb), dim3(256), 0, stream(), view(B), order.p, cid.p, cstart.p, best.p, ov.p,
+                         (unsigned long long*)nullptr, n);
+      hipLaunchKernelGGL(k_gh_order_keys, dim3(cdiv(n, 256)), dim3(256), 0, stream(), cid.p, ov.p, sig.p, n);
+      if (rocprim::radix_sort_pairs(tmp.p, tmp_bytes, sig.p, sig_sorted.p, order.p, order2.p, (size_t)n, 0, 64, stream()) != hipSuccess)
+        NTP_FATAL("radix sort failed");
+      int64_t nc = 0;
+      {
+        ScalarFetch f;
+        f.add(excl.p + n, 1, &nc);
+        f.run();
+      }
+      hipLaunchKernelGGL(k_gh_cluster_groups, dim3(cdiv(nc, 256)), dim3(256), 0, stream(), cstart.p, ng_c.p, (int)nc, G);
+      scan_i32_async(ng_c.p, goff.p, nc);
+      int64_t ng2 = 0;
+      {
+        ScalarFetch f;
+        f.add(goff.p + nc, 1, &ng2);
+        f.run();
+      }
+      DevBuf<int32_t> cols2((size_t)ng2 * G), grp_kn2((size_t)ng2), grp_maxlen2((size_t)ng2), kn_pos2((size_t)ng2);
+      DevBuf<int64_t> grp_off2((size_t)ng2 + 1);
+      DevBuf<uint8_t> state2((size_t)ng2);
+      hipLaunchKernelGGL(k_gh_fill_i32, dim3(cdiv(ng2 * G, 256)), dim3(256), 0, stream(), cols2.p, ng2 * G, -1);
+      hipLaunchKernelGGL(k_gh_fill_groups, dim3(cdiv(n, 256)), dim3(256), 0, stream(), order2.p, cid.p, cstart.p, goff.p, cols2.p, n, G);
+      count_pass(cols2.p, grp_kn2.p, grp_maxlen2.p, (int)ng2);
+      int64_t cost2 = 0;
+      const int64_t total2 = total_of(grp_kn2.p, kn_pos2.p, grp_off2.p, state2.p, (int)ng2, &cost2);
+      if (cost2 < cost) {
+        cols = std::move(cols2);
+        grp_kn = std::move(grp_kn2);
+        grp_maxlen = std::move(grp_maxlen2);
+        grp_off = std::move(grp_off2);
+        state = std::move(state2);
+        ngroups = (int)ng2;
+        total = total2;
+        cost = cost2;
+        ratio = (double)cost / ideal;
+        gi.minhash = 1;
+      }
+    }
+    oc.n = n;
+    oc.ngroups = ngroups;
+    oc.minhash = gi.minhash;
+    oc.ratio0 = ratio;
+    oc.cols = std::move(cols);
+  }
+  const int32_t* colp = oc.cols.p;
+  gi.groups = ngroups;
   gi.union_ratio = ratio;
   gi.tile_rows = total;
   if (ratio > 6.0 && !force) {
     if (info) *info = gi;
     return false;
   }
+  const int npad = ngroups * G;
 
   DevBuf<GhRec> recs((size_t)total + 8);
   DevBuf<double> tiles(((size_t)total + 8) * (size_t)G * A.wval());
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((k_gh_union<T, true>), dim3(xcd_grid(ngroups)), dim3(256), 0, stream(), view(A), view(B), cols.p, grp_kn.p,
+    hipLaunchKernelGGL((k_gh_union<T, true>), dim3(xcd_grid(ngroups)), dim3(256), 0, stream(), view(A), view(B), colp, grp_kn.p,
                        grp_maxlen.p, grp_off.p, recs.p, reinterpret_cast<T*>(tiles.p), ngroups);
   });
 
@@ -640,19 +848,22 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
     dispatch_type(A.cplx, [&](auto tag) {
       using T = decltype(tag);
       if (level == 0)
-        launch_ghash<T, 4, 2>(A, ngroups, cols.p, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
+        launch_ghash<T, 8, 1, 2>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
                               count, state.p, stats.p, alpha, threshold, dense_rule);
       else if (level == 1)
-        launch_ghash<T, 8, 2>(A, ngroups, cols.p, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
+        launch_ghash<T, 8, 2, 4>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
                               count, state.p, stats.p, alpha, threshold, dense_rule);
       else
-        launch_ghash<T, 8, 3>(A, ngroups, cols.p, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
+        launch_ghash<T, 8, 3, 4>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
                               count, state.p, stats.p, alpha, threshold, dense_rule);
     });
-    unsigned long long h[2] = {0, 0};
+    unsigned long long h[16] = {0};
     ScalarFetch f;
-    f.add(stats.p, 2, h);
+    f.add(stats.p, 16, h);
     f.run();
+    if (options().spgemm_variant == 518 && h[12])
+      std::fprintf(stderr, "[ghash stamps, level %d] cycles per phase (wave 0): load %.0f scatter %.0f products %.0f barrier %.0f (phases %llu)\n",
+                   level, (double)h[8] / h[12], (double)h[9] / h[12], (double)h[10] / h[12], (double)h[11] / h[12], h[12]);
     gi.level = level;
     const int64_t left = (int64_t)h[0];
     if (level == first) {
@@ -666,9 +877,9 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
   }
   stats.zero();
   if (A.cplx)
-    hipLaunchKernelGGL(k_gh_finish<8>, dim3(cdiv(npad, 256)), dim3(256), 0, stream(), cols.p, state.p, bin_arr, count, stats.p, ngroups);
+    hipLaunchKernelGGL(k_gh_finish<8>, dim3(cdiv(npad, 256)), dim3(256), 0, stream(), colp, state.p, bin_arr, count, stats.p, ngroups);
   else
-    hipLaunchKernelGGL(k_gh_finish<16>, dim3(cdiv(npad, 256)), dim3(256), 0, stream(), cols.p, state.p, bin_arr, count, stats.p, ngroups);
+    hipLaunchKernelGGL(k_gh_finish<16>, dim3(cdiv(npad, 256)), dim3(256), 0, stream(), colp, state.p, bin_arr, count, stats.p, ngroups);
   unsigned long long h[4] = {0, 0, 0, 0};
   {
     ScalarFetch f;
