@@ -14,9 +14,9 @@ sides, max over ranks).  Rank 0 prints ONE JSON line.
 Extra objects in the line:
   roofline     -- the dominant kernel (SpGEMM numeric, k_spgemm_slab): algorithmic bytes
                   12*(nnzA+nnzB+nnzC)+4*(cols...) per launch / its HIP-event time, vs 8 TB/s HBM
-  cpu_baseline -- the oracle (C restatement, kind "port") timed on the host cores on a bounded
-                  sample (N_s rows of the same generator), scaled linearly in N (cost is O(N) at
-                  fixed bandwidth) -- reported, not the target
+  cpu_baseline -- the oracle (C restatement, kind "port") timed on all host cores at the FULL size, three
+                  iterations of the same region (two runs differenced) -- reported, not the target
+  trs2_wrp_check -- the same rate measured through the reference's entry point TRS2_wrp ((t(25) - t(5)) / 20)
 """
 import argparse
 import json
@@ -55,31 +55,71 @@ def trs2_step_unfused(nt, X, X2, WH, pool, trace_target, thr):
     return sigma, float(np.real(X.Dot(WH)))
 
 
-def cpu_baseline(n_full, h, thr, warmup, steps):
-    """oracle (port) on a bounded sample: time iterations warmup+1 .. warmup+steps at N_s rows"""
+def cpu_baseline(n, h, thr, warmup, steps, permute=None):
+    """the oracle (C restatement with OpenMP, kind "port") at the FULL configuration size on all host cores: TRS2 run
+    twice in one process, with `warmup` and with `warmup + steps` iterations; the difference is `steps` iterations of
+    the same region the GPU line times (setup excluded), as BASELINE.md section 2 measures the reference."""
     from oracle import oracle_py as O
-    from gen import banded_triplets
-    n_s = min(n_full, 32768)
-    steps = max(1, min(steps, 4))
-    col, row, val = banded_triplets(n_s, h)
-    H = O.Mat.from_triplets(n_s, n_s, col, row, val)
-    I = O.Mat.identity(n_s)
+    from gen import banded_triplets, permuted_banded_triplets
+    steps = max(3, min(steps, 3))
+    if permute is None:
+        col, row, val = banded_triplets(n, h)
+    else:
+        col, row, val = permuted_banded_triplets(n, h, permute)
+    H = O.Mat.from_triplets(n, n, col, row, val)
+    del col, row, val
+    I = O.Mat.identity(n)
 
     def run(iters):
         p = O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr, monitor_convergence=False)
         t0 = time.perf_counter()
-        O.density("trs2", H, I, n_s / 2.0, p)
+        O.density("trs2", H, I, n / 2.0, p)
         return time.perf_counter() - t0
 
     t_w = run(warmup) if warmup > 0 else 0.0
     t_all = run(warmup + steps)
-    per_iter_sample = max(1e-9, (t_all - t_w) / steps)
-    per_iter_full = per_iter_sample * (n_full / float(n_s))
-    return {"value": 1.0 / per_iter_full, "unit": "iters/s", "cores": int(O.lib().oracle_num_threads()),
+    per_iter = max(1e-9, (t_all - t_w) / steps)
+    return {"value": 1.0 / per_iter, "unit": "iters/s", "cores": int(O.lib().oracle_num_threads()),
             "kind": "port",
-            "sample": "oracle TRS2 (OpenMP) iterations %d..%d at N_s=%d rows of the same generator (h=%d, thr=%g): "
-                      "%.3f s/iter, scaled x%d to N=%d (O(N) cost at fixed band)" % (
-                          warmup + 1, warmup + steps, n_s, h, thr, per_iter_sample, n_full // n_s, n_full)}
+            "sample": "oracle TRS2 (OpenMP, all host cores) at the full size N=%d (h=%d, thr=%g%s): iterations %d..%d, "
+                      "(t(%d iterations) - t(%d iterations)) / %d = %.3f s/iter; no scaling" % (
+                          n, h, thr, "" if permute is None else ", relabelled with seed %d" % permute, warmup + 1,
+                          warmup + steps, warmup + steps, warmup, steps, per_iter)}
+
+
+def trs2_wrp_check(nt, H, n, thr, n1=5, n2=25):
+    """cross-check of `value` through the reference's own entry point: TRS2_wrp (the whole solver: setup, loop, final
+    transformation) with max_iterations n1 and n2, monitor off; (t(n2) - t(n1)) / (n2 - n1) is the time of one loop
+    iteration as BASELINE.md section 2 measures it for the reference."""
+    ISQ = nt.Matrix_ps(n)
+    ISQ.FillIdentity()
+    ts = {}
+    for iters in (n1, n1, n2):      # the first call warms the allocator
+        p = nt.SolverParameters()
+        p.SetConvergeDiff(1e-30)
+        p.SetThreshold(thr)
+        p.SetMaxIterations(iters)
+        p.SetMonitorConvergence(False)
+        K = nt.Matrix_ps(n)
+        nt.synchronize()
+        t0 = time.perf_counter()
+        nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, p)
+        nt.synchronize()
+        ts[iters] = time.perf_counter() - t0
+        del K
+    per = (ts[n2] - ts[n1]) / (n2 - n1)
+    return {"iters_per_s": 1.0 / per, "ms_per_iter": 1e3 * per,
+            "method": "TRS2_wrp with max_iterations %d and %d (monitor off): (t(%d) - t(%d)) / %d" % (n1, n2, n2, n1, n2 - n1)}
+
+
+def sources_sha16():
+    """fingerprint of the kernel sources a committed PMC traffic figure belongs to"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "slab_loop.inc", "spgemm_grouped.hip"):
+        with open(os.path.join(ROOT, "ntpoly_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -91,6 +131,7 @@ def main():
     ap.add_argument("--halfband", type=int, default=100)
     ap.add_argument("--threshold", type=float, default=1e-8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-wrp-check", action="store_true", help="skip the TRS2_wrp-differenced cross-check of the value")
     ap.add_argument("--permute", type=int, default=None, metavar="SEED",
                     help="run on P^T H P under a seeded random relabelling (SURVEY 8(d): the load-balanced / "
                          "unstructured operand; the SpGEMM leaves the run-based kernels for the LDS hash path)")
@@ -157,18 +198,21 @@ def main():
     m1 = nt.malloc_stats()
     acc = nt.spgemm_accum()
     st = nt.last_spgemm_stats()
+    gs = nt.last_grouped_stats()
     nnz_x = X.GetSize()
-    nnz_x2 = X2.GetSize()
 
     if rank == 0:
-        # HBM traffic of the dominant kernel comes from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
-        # runs of this same command; they cannot be collected from inside the process): the committed summary
-        # profiles/r01_v11_pmc_traffic.json (tools/collect_profiles.sh + tools/pmc_traffic_json.py) holds the corrected
-        # bytes per launch
-        traffic = None
+        # HBM traffic of the dominant kernel comes from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of
+        # this same command; they cannot be collected from inside the process): profiles/<tag>_pmc_traffic*.json holds
+        # the corrected bytes per launch together with a fingerprint of the kernel sources it was measured on -- a
+        # figure measured on other sources is not reported (null)
+        traffic, traffic_src = None, None
+        tname = "r02_pmc_traffic.json" if args.permute is None else "r02_pmc_traffic_permute.json"
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_v11_pmc_traffic.json")) as f:
-                traffic = float(json.load(f)["hbm_bytes_per_launch"]) if (n, h, thr, world) == (262144, 100, 1e-8, 1) else None
+            with open(os.path.join(ROOT, "profiles", tname)) as f:
+                tj = json.load(f)
+            if (n, h, thr, world) == (262144, 100, 1e-8, 1) and tj.get("sources_sha16") == sources_sha16():
+                traffic, traffic_src = float(tj["hbm_bytes_per_launch"]), "profiles/" + tname
         except Exception:
             traffic = None
         iters_per_s = args.steps / elapsed
@@ -191,11 +235,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "TRS2 purification (BASELINE configs[2]): banded H N=%d halfband=%d (%d nnz/row), "
+            "config": {"workload": "TRS2 purification (BASELINE configs[2]): banded H N=%d halfband=%d (%d nnz/row)%s, "
                                    "threshold=%g, ISQ=I, trace=N/2; timed iterations %d..%d" % (
-                                       n, h, 2 * h + 1, thr, args.warmup + 1, args.warmup + args.steps),
+                                       n, h, 2 * h + 1,
+                                       "" if args.permute is None else " under a random symmetric relabelling (seed %d)" % args.permute,
+                                       thr, args.warmup + 1, args.warmup + args.steps),
                        "n": n, "halfband": h, "threshold": thr, "nnz_H": int(nnz_h), "nnz_X_end": int(nnz_x),
-                       "nnz_X2_end": int(nnz_x2), "energy_end": energy,
+                       "nnz_product_last": int(st.get("nnz_c", -1)), "energy_end": energy,
+                       "permute_seed": args.permute,
                        "decomposition": "1-D column panels, %d GPU(s)" % world,
                        "hipMalloc_in_timed_region": {"calls": m1[0] - m0[0], "ms": m1[1] - m0[1]}},
             "spgemm_nnz_out_per_s": world * acc["nnz_c"] / (ms_spgemm * 1e-3),
@@ -203,18 +250,30 @@ def main():
             "spgemm_ms_per_call": ms_spgemm / calls,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_spgemm_slab (SpGEMM numeric phase)" if st.get("slab") else "k_spgemm_pair3 (SpGEMM numeric phase)",
+                         "kernel": ("k_spgemm_slab" if st.get("slab") else "k_spgemm_ghash (grouped LDS hash)" if gs.get("used")
+                                    else "k_spgemm_pair3 / k_spgemm_hash") + " (SpGEMM numeric phase)",
                          "alg_bytes_per_launch": acc["alg_bytes"] / calls, "ms_per_launch": ms_numeric / calls,
+                         "traffic_source": traffic_src,
                          "note": "rank-0 panel; algorithmic bytes = 12*(nnzA+nnzB+nnzC)+4*(colsA+colsB+colsC+3); traffic = bytes "
-                                 "per launch from the committed PMC passes (profiles/r01_v11_pmc_traffic.json)"},
+                                 "per launch from the committed PMC passes of this command (null when the kernel sources "
+                                 "have changed since)"},
         }
         # the numeric kernel is FP64-ALU side bound: 2 flops per product against the vector peak for SEPARATE multiply and
         # add instructions (78.6 TFLOP/s counts an FMA as 2 flops per instruction -> 39.3 for unfused mul + add)
         tfl = 2.0 * acc["products"] / (ms_numeric * 1e-3) / 1e12
         line["roofline_compute"] = {"bound": "fp64 vector ALU (unfused mul+add)", "achieved": tfl, "peak": 39.3,
                                     "unit": "TFLOP/s", "frac": tfl / 39.3}
+        if gs.get("used"):
+            line["grouped_hash"] = gs
+    check = None
+    if not args.no_wrp_check:
+        del X, X2
+        check = trs2_wrp_check(nt, H, n, thr)       # (collective: every rank takes part)
+    if rank == 0:
+        if check:
+            line["trs2_wrp_check"] = check
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, h, thr, args.warmup, args.steps)
+            line["cpu_baseline"] = cpu_baseline(n, h, thr, args.warmup, args.steps, args.permute)
         print(json.dumps(line), flush=True)
     if world > 1:
         nt.barrier()

@@ -53,10 +53,26 @@ def object_is_stale(obj, src):
     return os.path.getmtime(obj) <= max(map(os.path.getmtime, deps))
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+ASAN_LIB = os.path.join(HERE, "libntpoly_amd_asan.so")
+ASAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+
+
+def build_sanitized(force=False, verbose=False):
+    """The same library with AddressSanitizer + UndefinedBehaviorSanitizer on the HOST side (the analogue of the
+    reference's -fcheck=all debug leg, Targets/Linux.cmake:20-22): ntpoly_amd/libntpoly_amd_asan.so.  Device code is
+    compiled as usual (GPU sanitizers are not available on this pool); tests/test_abi_cpu.py drives the host-only
+    entry points of this build under the sanitizer runtime."""
+    return build(force=force, verbose=verbose, lib=ASAN_LIB, objdir=os.path.join(HERE, "build_asan"),
+                 flags=[f for f in FLAGS if f != "-O3"] + ASAN_FLAGS, link_extra=["-fsanitize=address,undefined"])
+
+
+def build(force=False, verbose=False, lib=None, objdir=None, flags=None, link_extra=()):
+    custom = lib is not None
+    lib = lib or LIB
+    flags = flags or FLAGS
+    if not force and not custom and not _stale():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = objdir or os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
@@ -66,7 +82,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if not force and not object_is_stale(obj, src):
             continue
-        cmd = [HIPCC] + FLAGS + ["-MMD", "-MF", obj[:-2] + ".d", "-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + flags + ["-MMD", "-MF", obj[:-2] + ".d", "-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -80,13 +96,15 @@ def build(force=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [
+    if custom and not procs and os.path.exists(lib) and os.path.getmtime(lib) >= max(map(os.path.getmtime, objs)):
+        return lib
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + list(link_extra) + [
         "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout)
         raise RuntimeError("link failed")
-    return LIB
+    return lib
 
 
 FLANG = os.environ.get("FLANG", "/opt/rocm/lib/llvm/bin/flang")
@@ -123,5 +141,8 @@ def build_fortran(force=False):
 
 
 if __name__ == "__main__":
+    if "--asan" in sys.argv:
+        print(build_sanitized(force="--force" in sys.argv, verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_fortran(force="--force" in sys.argv))

@@ -10,7 +10,8 @@ import os
 
 SIZE_wrp = 12  # Source/C/Wrapper.h:4
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libntpoly_amd.so")
+# NTPOLY_AMD_LIB: another build of the SAME library (the host-sanitizer build of ntpoly_amd/_build.py build_sanitized)
+LIB_PATH = os.environ.get("NTPOLY_AMD_LIB") or os.path.join(HERE, "libntpoly_amd.so")
 
 
 class NativeLibraryMissing(ImportError):

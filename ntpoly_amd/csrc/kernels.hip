@@ -2359,11 +2359,14 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                       (sv_opt == 500 || (sv_opt >= 511 && sv_opt <= 525) || (sv_opt < 0 && hstats[5] * 2 >= nonempty));
     if (want) {
       GroupedInfo gi;
-      if (spgemm_grouped(A, B, tmpoff.p, tmp_inner.p, tmp_val.p, count.p, bin.p, alpha, threshold, dr, sv_opt >= 500, &gi)) {
+      hipEvent_t late = timing ? get_event() : nullptr;   // "numeric" = the grouped kernel launches, not its planning passes
+      if (spgemm_grouped(A, B, tmpoff.p, tmp_inner.p, tmp_val.p, count.p, bin.p, alpha, threshold, dr, sv_opt >= 500, &gi, late)) {
         for (int i = 1; i <= 6; ++i) hstats[i] = 0;
         hstats[5] = (unsigned long long)gi.failed_cols;   // what the grouped kernel handed back: per-column LDS hash below
         st.grouped = 1;
+        if (late) std::swap(t_num.a, late);
       }
+      if (late) event_pool().push_back(late);
       st.gh_failed_cols = gi.failed_cols;
       st.gh_groups = gi.groups;
       st.gh_level = gi.level;

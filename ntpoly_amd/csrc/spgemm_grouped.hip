@@ -17,7 +17,7 @@
 // hash probe and of an LDS write instead of a CAS and a read-modify-write, and the A column is read once per group.
 // The epilogue sorts the (row, slot) pairs of the group once (bitonic, in LDS), gathers every column's sums in row
 // order through LDS, prunes (sparse_includes/PruneList.f90:22, strict >) and compacts with ballot + popcount prefix.
-// Results are bit-identical to the per-column kernels and to the oracle: every C(i, j) sees the same products in the
+// Results are bit-identical to the per-column kernels and to the reference: every C(i, j) sees the same products in the
 // same ascending-k order with the same unfused multiply and add.
 //
 // Groups whose row union outgrows a table class are retried with the next class (512 / 1024 / 1536 slots) and are
@@ -689,7 +689,7 @@ void launch_ghash(const DevMat& A, int ngroups, const int32_t* cols, const int32
 
 bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int32_t* tmp_inner, double* tmp_val,
                     int32_t* count, uint8_t* bin_arr, double alpha, double threshold, int dense_rule, bool force,
-                    GroupedInfo* info) {
+                    GroupedInfo* info, hipEvent_t numeric_begin) {
   const int n = B.cols;
   const int G = A.cplx ? 8 : 16;
   int ngroups = cdiv(n, G);
@@ -839,6 +839,7 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
                        grp_maxlen.p, grp_off.p, recs.p, reinterpret_cast<T*>(tiles.p), ngroups);
   });
 
+  if (numeric_begin) HIP_CHECK(hipEventRecord(numeric_begin, stream()));
   static int hint[2] = {0, 0};  // table class that took most groups last time (real / complex)
   int& start = hint[A.cplx ? 1 : 0];
   int64_t todo = ngroups;

@@ -25,6 +25,6 @@ struct GroupedInfo {
 // otherwise bin_arr[j] is GH_BIN_DONE or GH_BIN_HASH on return.
 bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int32_t* tmp_inner, double* tmp_val,
                     int32_t* count, uint8_t* bin_arr, double alpha, double threshold, int dense_rule, bool force,
-                    GroupedInfo* info);
+                    GroupedInfo* info, hipEvent_t numeric_begin = nullptr);   // recorded before the first numeric launch
 
 }  // namespace ntp

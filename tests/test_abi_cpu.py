@@ -124,3 +124,85 @@ def test_fortran_module_layer_builds():
     syms = subprocess.run(["nm", "-D", "--defined-only", _build.LIB], capture_output=True, text=True).stdout
     have = set(ln.split()[-1] for ln in syms.splitlines() if ln.strip())
     assert len(names) > 70 and not sorted(names - have)
+
+
+def test_multi_process_launch_without_communicator_is_refused():
+    """P processes launched together (a process manager's environment says so) that construct the process
+    grid without having given the engine a communicator -- no MPI initialised in the process, no ntpoly_amd_init_comm --
+    must not silently run P identical single-rank solves: the grid constructor aborts with a message before any GPU call."""
+    import subprocess
+    import sys
+    code = ("import ntpoly_amd as nt\n"
+            "nt.ConstructGlobalProcessGrid()\n"
+            "print('constructed')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PMI_SIZE="2", PMI_RANK="0", PYTHONPATH=root)
+    env.pop("NTPOLY_AMD_ALLOW_REPLICAS", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "constructed" not in r.stdout
+    assert "no communicator was given to the engine" in r.stdout
+    # the same program alone (no launcher environment) is a legitimate single-rank run up to the point where it needs a GPU
+    env2 = {k: v for k, v in env.items() if not k.startswith("PMI_")}
+    r2 = subprocess.run([sys.executable, "-c", code], env=env2, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert "constructed" in r2.stdout
+
+
+def test_host_side_under_address_and_ub_sanitizers(tmp_path):
+    """The host side of the library built with -fsanitize=address,undefined (ntpoly_amd._build.build_sanitized, the
+    analogue of the reference's -fcheck=all leg, Targets/Linux.cmake:20-22) and driven through the host-only part of the
+    C ABI: triplet lists (append / resize / set / get / sort / symmetrize through the Python mirror), permutations,
+    solver parameters, the logger, the single-rank grid, and the fatal path of a multi-process launch without a
+    communicator.  Any sanitizer report fails the test.  (GPU sanitizers are not available on this pool.)"""
+    import glob
+    import subprocess
+    import sys
+    from ntpoly_amd import _build
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt:
+        pytest.skip("no AddressSanitizer runtime in this image")
+    lib = _build.build_sanitized()
+    code = r'''
+import numpy as np
+import ntpoly_amd as nt
+from ntpoly_amd.capi import lib
+assert "asan" in nt.capi.LIB_PATH
+tl = nt.TripletList_r()
+rng = np.random.default_rng(1)
+for k in range(300):
+    tl.Append(int(rng.integers(1, 40)), int(rng.integers(1, 40)), float(rng.normal()))
+assert tl.GetSize() == 300
+c, r, v = tl.arrays()
+tl2 = nt.TripletList_r(10)
+tl2.set_arrays(c, r, v)
+c2, r2, v2 = tl2.arrays()
+assert np.array_equal(c, c2) and np.array_equal(v, v2)
+t = tl.GetTripletAt(7)
+tc = nt.TripletList_c()
+tc.Append(3, 4, 1.5 - 2j)
+assert tc.GetSize() == 1
+for n in (1, 7, 64):
+    p = nt.Permutation(n)
+    p.SetReversePermutation()
+    p.SetDefaultPermutation()
+    p.set_lookup(np.arange(n, 0, -1))
+sp = nt.SolverParameters()
+sp.SetConvergeDiff(1e-7); sp.SetMaxIterations(11); sp.SetVerbosity(False); sp.SetThreshold(1e-9)
+sp.SetStepThreshold(1e-3); sp.SetMonitorConvergence(True)
+pp = nt.Permutation(12)
+sp.SetLoadBalance(pp)
+nt.init_comm()
+nt.ConstructGlobalProcessGrid(1, 1, 1)
+assert nt.GetGlobalIsRoot()
+nt.ActivateLogger(True, r"%s")
+nt.WriteGridInfo()
+nt.DeactivateLogger()
+print("HOST-OK")
+''' % str(tmp_path / "log.yaml")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LD_PRELOAD=rt[-1], NTPOLY_AMD_LIB=lib, PYTHONPATH=root,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert "HOST-OK" in r.stdout, r.stdout[-4000:]
+    assert "AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout, r.stdout[-4000:]
+    assert r.returncode == 0, r.stdout[-2000:]

@@ -281,6 +281,44 @@ def test_reference_examples_link_and_run(tmp_path, binary):
     assert np.linalg.norm(D - Dref) <= 5e-5
 
 
+@pytest.mark.parametrize("binary", ["premade_cxx", "premade_f90"])
+def test_reference_examples_under_mpiexec_two_ranks(tmp_path, binary):
+    """a program written against the reference runs UNCHANGED under `mpiexec -n 2`: it initialises
+    MPI itself and hands MPI_COMM_WORLD to ConstructGlobalProcessGrid (Examples/PremadeMatrix/main.cc:57-60,
+    main.f90:74); the engine takes rank and size from that communicator (ProcessGrid.cc:12-48,
+    ProcessGridModule.F90:130-197) -- no call of the engine's own bootstrap anywhere.  The two ranks share the box's one
+    GPU through the shared-memory test transport; the result must be the reference's shipped density."""
+    import subprocess
+    import uuid
+    import scipy.io
+    import scipy.sparse as sp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", binary)
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(exe) or not os.path.exists(mpiexec):
+        pytest.skip("oracle/_ref/%s or %s is not available" % (binary, mpiexec))
+    g = Golden("solvers")
+    i_h = [i for i, c in enumerate(g.cases) if c["tag"] == "premade_trs2_nel5"][0]
+    i_s = [i for i, c in enumerate(g.cases) if c["tag"] == "premade_isq"][0]
+    for name, t in (("Hamiltonian.mtx", g.tri(i_h, "H")), ("Overlap.mtx", g.tri(i_s, "H"))):
+        m = sp.coo_matrix((t[4], (t[3] - 1, t[2] - 1)), shape=(t[0], t[1]))
+        scipy.io.mmwrite(str(tmp_path / name), m)
+    out = tmp_path / "Density.mtx"
+    env = dict(os.environ, NTPOLY_AMD_COMM="shm:" + uuid.uuid4().hex[:12])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([mpiexec, "-n", "2", exe, "--process_rows", "2", "--process_columns", "1", "--process_slices", "1",
+                        "--hamiltonian", str(tmp_path / "Hamiltonian.mtx"), "--overlap", str(tmp_path / "Overlap.mtx"),
+                        "--number_of_electrons", "5", "--threshold", "1e-6", "--converge_overlap", "1e-3",
+                        "--converge_density", "1e-5", "--density", str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("Density Matrix Solver") == 1, r.stdout[-3000:]     # only the root logs: the ranks are one job
+    D = scipy.io.mmread(str(out)).toarray()
+    Dref = to_dense(g.tri(None, "premade_density_reference"))
+    assert np.linalg.norm(D - Dref) <= 5e-5
+
+
 def test_fortran_solver_family_modules(tmp_path):
     """Part 2 of the Fortran module layer (LinearSolversModule, EigenSolversModule, ExponentialSolversModule,
     PolynomialSolversModule, LoadBalancerModule, DenseSolversModule, ...): tests/fortran/solver_families.f90, written
