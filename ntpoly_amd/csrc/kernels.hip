@@ -674,6 +674,19 @@ __global__ __launch_bounds__(256) void k_slab_plan(int ncols, const int32_t* __r
   const int j = b * J + lane;
   const bool has = lane < J && j < ncols && blast[min(j, ncols - 1)] >= 0;
   const int kmin = wave_min_i32(has ? bfirst[j] : INT_MAX), kmax = wave_max_i32(has ? blast[j] : -1);
+  if (kmax >= kmin && kmax - kmin >= 4096) {
+    // a k range far beyond any multiplier tile (at most 1023 rows): the operand is not run-like and the slab kernels
+    // will be declined -- do not walk the range (for a relabelled matrix it is the whole dimension, in every block)
+    if (lane == 0) {
+      blk_lo[b] = 0;
+      blk_w[b] = 1 << 30;
+      blk_kmin[b] = kmin;
+      blk_kn[b] = kmax - kmin + 1;
+      bsz[b] = 0;
+      tsz[b] = 0;
+    }
+    return;
+  }
   int lo = INT_MAX, hi = -1;
   // (a block whose columns are all empty has kmin = INT_MAX: kmin + lane must not be formed)
   for (int k = (kmax >= kmin) ? kmin + lane : 0; k <= kmax; k += WAVE) {
@@ -1407,8 +1420,10 @@ __global__ void k_inc_plan(Csc A, Csc B, int32_t* __restrict__ lo_arr, int32_t* 
   if (ae > as) { lo = min(lo, A.inner[as]); hi = max(hi, A.inner[ae - 1]); }
   if (be > bs) { lo = min(lo, B.inner[bs]); hi = max(hi, B.inner[be - 1]); }
   const int span = hi >= lo ? hi - lo + 1 : 0;
-  int bin = span == 0 ? 0 : span <= 512 ? 1 : span <= 2048 ? 2 : 3;
-  if (span > 0 && force_seq) bin = 3;
+  // 1, 2: direct-mapped LDS windows; 3: rank merge (columns scattered over the row range, both together <= 2048
+  // entries); 4: sequential two-pointer merge
+  int bin = span == 0 ? 0 : span <= 512 ? 1 : span <= 2048 ? 2 : ((ae - as) + (be - bs) <= 2048 ? 3 : 4);
+  if (span > 0 && force_seq) bin = force_seq == 2 ? ((ae - as) + (be - bs) <= 2048 ? 3 : 4) : 4;
   lo_arr[j] = span > 0 ? lo : 0;
   span_arr[j] = span;
   bin_arr[j] = (uint8_t)bin;
@@ -1558,6 +1573,180 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
       cnt += __popcll(m);
     }
     if (lane == 0) count[j] = cnt;
+  }
+  if constexpr (DOT) {
+    dx = wave_sum_f64(dx);
+    dy = wave_sum_f64(dy);
+    if (lane == 0) {
+      red[2 * wave] = dx;
+      red[2 * wave + 1] = dy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sx = 0.0, sy = 0.0;
+      for (int w = 0; w < NW; ++w) {
+        sx = __dadd_rn(sx, red[2 * w]);
+        sy = __dadd_rn(sy, red[2 * w + 1]);
+      }
+      dot_partial[2 * b] = sx;
+      dot_partial[2 * b + 1] = sy;
+    }
+    if (trace_partial) {  // block-uniform
+      dt = wave_sum_f64(dt);
+      __syncthreads();
+      if (lane == 0) red[wave] = dt;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double st = 0.0;
+        for (int w = 0; w < NW; ++w) st = __dadd_rn(st, red[w]);
+        trace_partial[2 * b] = st;
+        trace_partial[2 * b + 1] = 0.0;
+      }
+    }
+  }
+}
+
+// Columns whose rows scatter over the whole range (operands under a load-balancing permutation): one wave per column,
+// merge by RANK.  Both row lists go to LDS; every entry finds its rank in the other list by binary search, which gives
+// its place p = (#A rows < r) + (#B rows < r) in the merged order (a row present in both lists gets ONE place, written
+// by the B side) and decides the AddSparseVectors rule on its own (the "tail" test is a comparison with the other
+// column's last row, as in the window kernel).  Kept entries are written at their merged place, a bitmap over the
+// places is prefix-summed, and the column is compacted in place, 64 places per round.  With DOT the kept entries are
+// also multiplied with D (binary search in its column) and the diagonal entry is picked up for the trace.
+constexpr int INC_MERGE_CAP = 2048;
+template <typename T, bool DOT>
+__global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
+    Csc A, Csc B, Csc D, const uint8_t* __restrict__ bin_arr, int my_bin, int32_t* __restrict__ out_inner,
+    T* __restrict__ out_val, int32_t* __restrict__ count, double alpha, double beta, double threshold,
+    double* __restrict__ dot_partial, int nblocks, double* __restrict__ trace_partial, int col_offset) {
+  constexpr int NW = 4, NWORD = INC_MERGE_CAP / 64, DCAP = DOT ? 1024 : 1;   // (longer columns of D are searched in memory)
+  __shared__ int rows_all[NW][INC_MERGE_CAP];
+  __shared__ int drows_all[NW][DCAP];
+  __shared__ unsigned long long bits_all[NW][NWORD];
+  __shared__ double red[2 * NW];
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  const int j = b * NW + wave;
+  double dx = 0.0, dy = 0.0, dt = 0.0;
+  const bool mine = (j < A.cols) && (bin_arr[j < A.cols ? j : 0] == my_bin);
+  if (mine) {
+    const T* __restrict__ Av = static_cast<const T*>(A.val);
+    const T* __restrict__ Bv = static_cast<const T*>(B.val);
+    const T* __restrict__ Dv = static_cast<const T*>(D.val);
+    const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = B.outer[j + 1];
+    const int na = (int)(ae - as), nb = (int)(be - bs);
+    int* ra = rows_all[wave];
+    int* rb = ra + na;
+    unsigned long long* bits = bits_all[wave];
+    for (int i = lane; i < na; i += WAVE) ra[i] = A.inner[as + i];
+    for (int i = lane; i < nb; i += WAVE) rb[i] = B.inner[bs + i];
+    int* rd = drows_all[wave];
+    const int64_t ds = DOT ? D.outer[j] : 0;
+    const int nd = DOT ? (int)(D.outer[j + 1] - ds) : 0;
+    if constexpr (DOT) {
+      if (nd <= DCAP)
+        for (int i = lane; i < nd; i += WAVE) rd[i] = D.inner[ds + i];
+    }
+    if (lane < NWORD) bits[lane] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    const int amax = na ? ra[na - 1] : -1, bmax = nb ? rb[nb - 1] : -1;
+    const int64_t base = as + bs;
+    // A side: entries whose row is not in B
+    for (int i = lane; i < na; i += WAVE) {
+      const int r = ra[i];
+      int lo = 0, hi = nb;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (rb[mid] < r) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < nb && rb[lo] == r) continue;
+      const T v = Sc<T>::scale(alpha, Av[as + i]);
+      if (r > bmax || Sc<T>::mag(v) > threshold) {
+        const int p = i + lo;
+        out_inner[base + p] = r;
+        out_val[base + p] = v;
+        atomicOr(&bits[p >> 6], 1ull << (p & 63));
+      }
+    }
+    // B side (scaled first, as AddSparseVectors sees it), with the matching A entry where there is one
+    for (int i = lane; i < nb; i += WAVE) {
+      const int r = rb[i];
+      int lo = 0, hi = na;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ra[mid] < r) lo = mid + 1;
+        else hi = mid;
+      }
+      const bool both = lo < na && ra[lo] == r;
+      const T wb = Sc<T>::scale(beta, Bv[bs + i]);
+      T v;
+      bool keep;
+      if (both) {
+        v = Sc<T>::add(Sc<T>::scale(alpha, Av[as + lo]), wb);
+        keep = Sc<T>::mag(v) > threshold;
+      } else {
+        v = wb;
+        keep = r > amax || Sc<T>::mag(v) > threshold;
+      }
+      if (keep) {
+        const int p = i + lo;
+        out_inner[base + p] = r;
+        out_val[base + p] = v;
+        atomicOr(&bits[p >> 6], 1ull << (p & 63));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();   // the entries written above are read back by other lanes below
+    // compaction in place: round k moves places [64k, 64k + 64) down to [pre_k, ...)
+    const int nplace = na + nb;
+    int run = 0;
+    for (int k = 0; k * 64 < nplace; ++k) {
+      const unsigned long long w = bits[k];
+      const bool kept = (w >> lane) & 1ull;
+      int r = 0;
+      T v = Sc<T>::zero();
+      if (kept) {
+        r = out_inner[base + k * 64 + lane];
+        v = out_val[base + k * 64 + lane];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (kept) {
+        const int64_t pos = base + run + __popcll(w & lanemask_lt());
+        out_inner[pos] = r;
+        out_val[pos] = v;
+        if constexpr (DOT) {
+          if (r == col_offset + j) dt = Sc<T>::re(v);
+          int lo = 0, hi = nd;
+          if (nd <= DCAP) {
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (rd[mid] < r) lo = mid + 1;
+              else hi = mid;
+            }
+          } else {
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (D.inner[ds + mid] < r) lo = mid + 1;
+              else hi = mid;
+            }
+          }
+          if (lo < nd && (nd <= DCAP ? rd[lo] : D.inner[ds + lo]) == r) {
+            if constexpr (Sc<T>::cplx) {
+              const double2 pr = Sc<double2>::mul(Sc<double2>::conj(v), Dv[ds + lo]);
+              dx = __dadd_rn(dx, pr.x);
+              dy = __dadd_rn(dy, pr.y);
+            } else {
+              dx = __dadd_rn(dx, __dmul_rn(v, Dv[ds + lo]));
+            }
+          }
+        }
+      }
+      run += __popcll(w);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) count[j] = run;
   }
   if constexpr (DOT) {
     dx = wave_sum_f64(dx);
@@ -2586,16 +2775,18 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
     a_total.alloc((size_t)n + 1);
     scan_async<int32_t>(A.v.cnt, a_total.p, (int64_t)n);
   }
-  const bool fuse_dot = D != nullptr && dot_out != nullptr && hs[3] == 0;
+  const bool fuse_dot = D != nullptr && dot_out != nullptr && hs[4] == 0;
   const int nb1 = cdiv(n, 4), nb2 = n;
-  DevBuf<double> part1, part2, tpart1, tpart2;
+  DevBuf<double> part1, part2, part3, tpart1, tpart2, tpart3;
   const bool fuse_trace = fuse_dot && trace_out != nullptr;
   if (fuse_dot) {  // every (non-padding) block of the merge kernels writes its slot: no zero fill needed
     if (hs[1]) part1.alloc((size_t)2 * nb1);
     if (hs[2]) part2.alloc((size_t)2 * nb2);
+    if (hs[3]) part3.alloc((size_t)2 * nb1);
     if (fuse_trace) {
       if (hs[1]) tpart1.alloc((size_t)2 * nb1);
       if (hs[2]) tpart2.alloc((size_t)2 * nb2);
+      if (hs[3]) tpart3.alloc((size_t)2 * nb1);
     }
   }
   dispatch_type(A.cplx, [&](auto tag) {
@@ -2619,17 +2810,27 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
                            lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb2, (double*)nullptr, 0);
     }
     if (hs[3]) {
-      hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), A.v, view(B), bin.p, 3,
+      if (fuse_dot)
+        hipLaunchKernelGGL((k_inc_merge<T, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv, bin.p, 3,
+                           tmp_inner.p, tv, count.p, alpha, beta, threshold, part3.p, nb1, tpart3.p, trace_col_offset);
+      else
+        hipLaunchKernelGGL((k_inc_merge<T, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv, bin.p, 3,
+                           tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1, (double*)nullptr, 0);
+    }
+    if (hs[4]) {
+      hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), A.v, view(B), bin.p, 4,
                          tmp_inner.p, tv, count.p, alpha, beta, threshold);
     }
   });
   DevBuf<double> dres;
   if (fuse_dot) {
-    dres.alloc(8);  // pairs that are not produced are not read either (see the sums below)
+    dres.alloc(12);  // pairs that are not produced are not read either (see the sums below)
     if (hs[1]) reduce_sum2_async(part1.p, nb1, dres.p);
     if (hs[2]) reduce_sum2_async(part2.p, nb2, dres.p + 2);
     if (fuse_trace && hs[1]) reduce_sum2_async(tpart1.p, nb1, dres.p + 4);
     if (fuse_trace && hs[2]) reduce_sum2_async(tpart2.p, nb2, dres.p + 6);
+    if (hs[3]) reduce_sum2_async(part3.p, nb1, dres.p + 8);
+    if (fuse_trace && hs[3]) reduce_sum2_async(tpart3.p, nb1, dres.p + 10);
   }
   DevMat R;
   R.rows = A.rows;
@@ -2638,11 +2839,11 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
   R.outer.alloc((size_t)n + 1);
   scan_async<int32_t>(count.p, R.outer.p, (int64_t)n);
   int64_t nnz = 0;
-  double hd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double hd[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   {
     ScalarFetch f;
     f.add(R.outer.p + n, 1, &nnz);
-    if (fuse_dot) f.add(dres.p, 8, hd);
+    if (fuse_dot) f.add(dres.p, 12, hd);
     int64_t a_nnz = 0;
     if (A.loose) f.add(a_total.p + n, 1, &a_nnz);
     if (d_extra && extra_out) f.add(d_extra, 1, extra_out);
@@ -2662,13 +2863,14 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
   B = std::move(R);
   if (dot_out && D) {
     if (fuse_dot) {
-      dot_out[0] = (hs[1] ? hd[0] : 0.0) + (hs[2] ? hd[2] : 0.0);
-      dot_out[1] = (hs[1] ? hd[1] : 0.0) + (hs[2] ? hd[3] : 0.0);
+      dot_out[0] = (hs[1] ? hd[0] : 0.0) + (hs[2] ? hd[2] : 0.0) + (hs[3] ? hd[8] : 0.0);
+      dot_out[1] = (hs[1] ? hd[1] : 0.0) + (hs[2] ? hd[3] : 0.0) + (hs[3] ? hd[9] : 0.0);
     } else {
       dot(B, *D, dot_out);
     }
   }
-  if (trace_out) *trace_out = fuse_trace ? (hs[1] ? hd[4] : 0.0) + (hs[2] ? hd[6] : 0.0) : trace(B, trace_col_offset);
+  if (trace_out)
+    *trace_out = fuse_trace ? (hs[1] ? hd[4] : 0.0) + (hs[2] ? hd[6] : 0.0) + (hs[3] ? hd[10] : 0.0) : trace(B, trace_col_offset);
 }
 }  // namespace
 

@@ -26,7 +26,7 @@ struct SpgemmStats {
 
 struct EngineOptions {
   int spgemm_force_bin = -1;   // tests: force every non-empty column through one path (1..5), 6 = HBM fallback
-  int increment_force_seq = 0; // tests: force the sequential-merge fallback
+  int increment_force_seq = 0; // tests: 1 force the sequential-merge fallback, 2 force the rank-merge kernel (columns of <= 2048 entries)
   int time_kernels = 0;        // record HIP-event timings in SpgemmStats
   int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
                                // reference built with FP contraction computes); 0: separate multiply and add (default, bit-

@@ -191,7 +191,7 @@ def test_local_matrix_api(nt):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("force_seq", [0, 1])
+@pytest.mark.parametrize("force_seq", [0, 1, 2])   # automatic / sequential merge / rank merge (with the fused dot and trace)
 def test_fused_trs2_step_equals_call_sequence(nt, cplx, force_seq):
     """ntpoly_amd_trs2_step (fused Scale+Increment+Dot pass) against the same iteration spelled with the
     reference's individual entry points (DensityMatrixSolversModule.F90:380-404): X bit-identical,

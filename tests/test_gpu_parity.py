@@ -110,7 +110,7 @@ def test_ps_gemm_golden(nt, force_bin, variant):
         nt.set_option("spgemm_variant", -1)
 
 
-@pytest.mark.parametrize("force_seq", [0, 1])
+@pytest.mark.parametrize("force_seq", [0, 1, 2])   # automatic / sequential merge / rank merge
 def test_ps_increment_golden(nt, force_seq):
     nt.set_option("increment_force_seq", force_seq)
     try:
@@ -615,7 +615,7 @@ def test_fuzz_elementwise_vs_oracle(nt, seed):
         Ao, Bo = O.Mat.from_triplets(n, n, *mA.triplets()), O.Mat.from_triplets(n, n, *mB.triplets())
         tag = "seed %d case %d n=%d cplx=%d thr=%g" % (seed, case, n, cplx, thr)
         want = O.increment(Ao, Bo, alpha, thr).triplets()
-        for force_seq in (0, 1):
+        for force_seq in (0, 1, 2):
             nt.set_option("increment_force_seq", force_seq)
             try:
                 R = nt.Matrix_ps(mB)
