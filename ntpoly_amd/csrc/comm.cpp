@@ -31,6 +31,10 @@ Comm& world() {
   static Comm* c = new Comm();
   return *c;
 }
+ExchangeStats& exchange_stats() {
+  static ExchangeStats* e = new ExchangeStats();
+  return *e;
+}
 
 static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
 
@@ -447,12 +451,12 @@ void halo_segment(int32_t dim, int P, int s, int32_t kmin, int32_t kmax, int32_t
 // Range-restricted panel exchange ("halo"): rank q only needs the columns of A whose index appears
 // as a row of its B panel, i.e. the contiguous range [kmin_q, kmax_q].  For banded operands that is
 // its own panel plus a halo of one bandwidth on each side (KBs..MBs instead of the whole matrix);
-// for permuted operands it degenerates to the full gather.  Protocol (all on the engine stream, TWO host
-// synchronisations):
-//   1. every rank computes (kmin, kmax, nnz(A_loc), nnz(B_loc)) on the device; one all-gather of these records;
-//      read-back #1 (also yields the global nnz the caller needs for the dense-branch rule)
-//   2. every owner looks up, on the device, the entry offsets at the boundaries of the segment each requester
-//      needs -> one row of the P x P count matrix; one all-gather of the rows; read-back #2
+// for permuted operands it degenerates to the full gather.  Protocol (all on the engine stream, ONE host
+// synchronisation):
+//   1. every rank computes (kmin, kmax, nnz(A_loc), nnz(B_loc)) on the device; these records and the column offsets
+//      of every panel (8 bytes per column: 2 MB at N = 262 144) are all-gathered back to back
+//   2. a kernel derives the whole P x P count matrix and the owner's send bounds from the gathered arrays; one
+//      read-back brings requests, counts and bounds (and the global nnz for the dense-branch rule) to the host
 //   3. one group of send / recv per (owner, requester) pair with a non-empty segment: column offsets of the
 //      segment, row ids, values; the own segment is a device copy
 //   4. segments are re-based into one dim-wide matrix whose other columns are empty, so the SpGEMM
@@ -476,15 +480,42 @@ void gather_needed_begin(HaloExchange& hx, const PSMatrix& m, const DevMat& Bloc
   hx.P = P;
   const int ov_opt = options().halo_overlap;
   const bool probe = may_overlap && ov_opt > 0;
-  // 1. requests (+ the interior column range of my B panel when the caller can split its multiply)
-  std::vector<int64_t> req((size_t)4 * P + 8, 0);
+  // 1. requests (+ the interior column range of my B panel when the caller can split its multiply) and the column
+  //    offsets of every panel travel in two all-gathers enqueued back to back; the count matrix and my send bounds are
+  //    then computed on the device, and ONE read-back brings everything the host needs to post the send / recv group
+  int32_t maxw = 0;
+  for (int q = 0; q < P; ++q) {
+    int32_t a0, a1;
+    panel_range(dim, P, q, &a0, &a1);
+    maxw = std::max(maxw, a1 - a0);
+  }
+  const int pitch = maxw + 1;
+  std::vector<int64_t> req((size_t)4 * P + 8, 0), bound((size_t)2 * P, 0), cnt((size_t)P * P, 0);
   {
-    DevBuf<int64_t> d((size_t)4 * P + 8);
+    DevBuf<int64_t> d((size_t)4 * P + 8), d_outer_all((size_t)P * pitch), d_bound((size_t)2 * P), d_cnt((size_t)P * P);
     halo_request_async(Bloc, m.loc.nnz, d.p + 4 * me);
     if (probe) halo_interior_async(Bloc, m.c0, m.c1, d.p + 4 * P);
+    HIP_CHECK(hipMemcpyAsync(d_outer_all.p + (size_t)me * pitch, m.loc.outer.p, sizeof(int64_t) * (size_t)(m.c1 - m.c0 + 1),
+                             hipMemcpyDeviceToDevice, stream()));
     tr.allgather(d.p + 4 * me, d.p, 4 * sizeof(int64_t));
-    d.download(req.data(), (size_t)4 * P + (probe ? 8 : 0));
+    tr.allgather(d_outer_all.p + (size_t)me * pitch, d_outer_all.p, (size_t)pitch * sizeof(int64_t));
+    halo_counts_async(d.p, d_outer_all.p, pitch, dim, P, me, d_cnt.p, d_bound.p);
+    const size_t nreq = (size_t)4 * P + (probe ? 8 : 0);
+    if (nreq + (size_t)P * P + 2 * P <= 500) {
+      ScalarFetch f;
+      f.add(d.p, (int)nreq, req.data());
+      f.add(d_bound.p, 2 * P, bound.data());
+      f.add(d_cnt.p, P * P, cnt.data());
+      f.run();
+    } else {  // many ranks: plain copies, still one synchronisation
+      HIP_CHECK(hipMemcpyAsync(req.data(), d.p, nreq * 8, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipMemcpyAsync(bound.data(), d_bound.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, stream()));
+      sync_stream();
+    }
+    exchange_stats().host_syncs += 1;
   }
+  exchange_stats().exchanges += 1;
   nnz_global[0] = nnz_global[1] = 0;
   for (int q = 0; q < P; ++q) {
     nnz_global[0] += req[(size_t)4 * q + 2];
@@ -495,28 +526,11 @@ void gather_needed_begin(HaloExchange& hx, const PSMatrix& m, const DevMat& Bloc
   const int32_t kmin = kmin_of(me), kmax = kmax_of(me);
   hx.kmin = kmin;
   hx.kmax = kmax;
-  // 2. what I send to every requester: segment boundaries (host arithmetic), entry offsets and counts (device)
+  // 2. segment boundaries of what I send to every requester (host arithmetic, the same as the device's)
   std::vector<int32_t> sab((size_t)2 * P);
   for (int q = 0; q < P; ++q) halo_segment(dim, P, me, kmin_of(q), kmax_of(q), &sab[(size_t)q], &sab[(size_t)P + q]);
   const int32_t* sa = sab.data();
   const int32_t* sb = sab.data() + P;
-  std::vector<int64_t> bound((size_t)2 * P, 0), cnt((size_t)P * P, 0);
-  {
-    DevBuf<int32_t> d_sab((size_t)2 * P);
-    d_sab.upload(sab.data(), (size_t)2 * P);
-    DevBuf<int64_t> d_bound((size_t)2 * P), d_cnt((size_t)P * P);
-    halo_bounds_async(m.loc, m.c0, d_sab.p, d_sab.p + P, P, d_bound.p, d_cnt.p + (size_t)me * P);
-    tr.allgather(d_cnt.p + (size_t)me * P, d_cnt.p, (size_t)P * sizeof(int64_t));
-    ScalarFetch f;
-    if ((size_t)P * P + 2 * P <= 500) {
-      f.add(d_bound.p, 2 * P, bound.data());
-      f.add(d_cnt.p, P * P, cnt.data());
-      f.run();
-    } else {
-      d_bound.download(bound.data(), (size_t)2 * P);
-      d_cnt.download(cnt.data(), (size_t)P * P);
-    }
-  }
   // 3. receive layout: sources in rank order (their segments tile [kmin, kmax] in ascending columns)
   hx.ra.assign((size_t)P, 0);
   hx.rb.assign((size_t)P, 0);

@@ -39,6 +39,9 @@ struct Comm {
   bool active() const { return tr != nullptr && (nranks > 1 || force); }
 };
 Comm& world();
+// halo exchanges of the distributed multiply since the start, and the host synchronisations they needed
+struct ExchangeStats { long long exchanges = 0, host_syncs = 0; };
+ExchangeStats& exchange_stats();
 void comm_get_unique_id(char out[128]);
 void comm_init(const char id[128], int rank, int nranks);
 void comm_finalize();

@@ -1618,7 +1618,9 @@ template <typename T, bool DOT>
 __global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
     Csc A, Csc B, Csc D, const uint8_t* __restrict__ bin_arr, int my_bin, int32_t* __restrict__ out_inner,
     T* __restrict__ out_val, int32_t* __restrict__ count, double alpha, double beta, double threshold,
-    double* __restrict__ dot_partial, int nblocks, double* __restrict__ trace_partial, int col_offset) {
+    double* __restrict__ dot_partial, int nblocks, double* __restrict__ trace_partial, int col_offset, int row_block) {
+  // row_block > 0: the AddSparseVectors rule is applied per segment of `row_block` rows (the reference adds the
+  // matrices block by block, so "the other column is exhausted" is decided inside each row block)
   constexpr int NW = 4, NWORD = INC_MERGE_CAP / 64, DCAP = DOT ? 1024 : 1;   // (longer columns of D are searched in memory)
   __shared__ int rows_all[NW][INC_MERGE_CAP];
   __shared__ int drows_all[NW][DCAP];
@@ -1652,6 +1654,19 @@ __global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
     __builtin_amdgcn_wave_barrier();
     const int amax = na ? ra[na - 1] : -1, bmax = nb ? rb[nb - 1] : -1;
     const int64_t base = as + bs;
+    // last row of list `l` inside the row block of r (or -1): the largest entry below the block's end, if it is in the block
+    auto last_in_block = [&](const int* l, int n, int r) -> int {
+      const int e = (r / row_block + 1) * row_block;
+      int lo = 0, hi = n;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (l[mid] < e) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo == 0) return -1;
+      const int v = l[lo - 1];
+      return v >= e - row_block ? v : -1;
+    };
     // A side: entries whose row is not in B
     for (int i = lane; i < na; i += WAVE) {
       const int r = ra[i];
@@ -1663,7 +1678,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
       }
       if (lo < nb && rb[lo] == r) continue;
       const T v = Sc<T>::scale(alpha, Av[as + i]);
-      if (r > bmax || Sc<T>::mag(v) > threshold) {
+      const int blast = row_block > 0 ? last_in_block(rb, nb, r) : bmax;
+      if (r > blast || Sc<T>::mag(v) > threshold) {
         const int p = i + lo;
         out_inner[base + p] = r;
         out_val[base + p] = v;
@@ -1688,7 +1704,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
         keep = Sc<T>::mag(v) > threshold;
       } else {
         v = wb;
-        keep = r > amax || Sc<T>::mag(v) > threshold;
+        const int alast = row_block > 0 ? last_in_block(ra, na, r) : amax;
+        keep = r > alast || Sc<T>::mag(v) > threshold;
       }
       if (keep) {
         const int p = i + lo;
@@ -1784,15 +1801,27 @@ __global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
 template <typename T>
 __global__ void k_inc_seq(Csc A, Csc B, const uint8_t* __restrict__ bin_arr, int my_bin,
                           int32_t* __restrict__ out_inner, T* __restrict__ out_val,
-                          int32_t* __restrict__ count, double alpha, double beta, double threshold) {
+                          int32_t* __restrict__ count, double alpha, double beta, double threshold, int row_block) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.cols) return;
   if (bin_arr[j] != my_bin) return;
   const T* __restrict__ Av = static_cast<const T*>(A.val);
   const T* __restrict__ Bv = static_cast<const T*>(B.val);
-  int64_t aa = A.outer[j], ea = col_end(A, j), bb = B.outer[j], eb = B.outer[j + 1];
+  int64_t aa = A.outer[j], bb = B.outer[j];
+  const int64_t ea_all = col_end(A, j), eb_all = B.outer[j + 1];
   int64_t cc = aa + bb;
   const int64_t c0 = cc;
+  // (row_block > 0: the merge runs row block by row block, as the reference adds block by block)
+  for (int seg_end = row_block > 0 ? row_block : INT_MAX; aa < ea_all || bb < eb_all;
+       seg_end = row_block > 0 ? seg_end + row_block : INT_MAX) {
+  int64_t ea = aa, eb = bb;
+  if (row_block > 0) {
+    while (ea < ea_all && A.inner[ea] < seg_end) ++ea;
+    while (eb < eb_all && B.inner[eb] < seg_end) ++eb;
+  } else {
+    ea = ea_all;
+    eb = eb_all;
+  }
   while (aa < ea && bb < eb) {
     const int ia = A.inner[aa], ib = B.inner[bb];
     if (ia == ib) {
@@ -1811,6 +1840,7 @@ __global__ void k_inc_seq(Csc A, Csc B, const uint8_t* __restrict__ bin_arr, int
   }
   for (; aa < ea; ++aa) { out_inner[cc] = A.inner[aa]; out_val[cc] = Sc<T>::scale(alpha, Av[aa]); ++cc; }
   for (; bb < eb; ++bb) { out_inner[cc] = B.inner[bb]; out_val[cc] = Sc<T>::scale(beta, Bv[bb]); ++cc; }
+  }
   count[j] = (int32_t)(cc - c0);
 }
 
@@ -2740,7 +2770,7 @@ struct MergeOperand {
 };
 void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D,
                 double* dot_out, double* trace_out, int32_t trace_col_offset, int64_t* a_nnz_out,
-                const int64_t* d_extra = nullptr, int64_t* extra_out = nullptr) {
+                const int64_t* d_extra = nullptr, int64_t* extra_out = nullptr, int row_block = 0) {
   if (A.rows != B.rows || A.cols != B.cols) NTP_FATAL("increment: shape mismatch");
   if (A.cplx != B.cplx) NTP_FATAL("increment: mixed scalar types must be up-cast by the caller");
   if (D && (D->rows != A.rows || D->cols != A.cols || D->cplx != A.cplx)) NTP_FATAL("increment: dot operand mismatch");
@@ -2753,7 +2783,7 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
   DevBuf<uint8_t> bin(n);
   DevBuf<unsigned long long> stats(16);
   hipLaunchKernelGGL(k_inc_plan, dim3(cdiv(n, 256)), dim3(256), 0, stream(), A.v, view(B), lo.p, span.p, bin.p,
-                     stats.p, count.p, options().increment_force_seq);
+                     stats.p, count.p, row_block > 0 ? 2 : options().increment_force_seq);   // (blocked rule: rank / sequential merge)
   hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, (const int64_t*)nullptr,
                      (const int32_t*)nullptr, n, stats.p);
   unsigned long long hs[16];
@@ -2812,14 +2842,14 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
     if (hs[3]) {
       if (fuse_dot)
         hipLaunchKernelGGL((k_inc_merge<T, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv, bin.p, 3,
-                           tmp_inner.p, tv, count.p, alpha, beta, threshold, part3.p, nb1, tpart3.p, trace_col_offset);
+                           tmp_inner.p, tv, count.p, alpha, beta, threshold, part3.p, nb1, tpart3.p, trace_col_offset, row_block);
       else
         hipLaunchKernelGGL((k_inc_merge<T, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv, bin.p, 3,
-                           tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1, (double*)nullptr, 0);
+                           tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1, (double*)nullptr, 0, row_block);
     }
     if (hs[4]) {
       hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), A.v, view(B), bin.p, 4,
-                         tmp_inner.p, tv, count.p, alpha, beta, threshold);
+                         tmp_inner.p, tv, count.p, alpha, beta, threshold, row_block);
     }
   });
   DevBuf<double> dres;
@@ -2873,6 +2903,11 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
     *trace_out = fuse_trace ? (hs[1] ? hd[4] : 0.0) + (hs[2] ? hd[6] : 0.0) + (hs[3] ? hd[10] : 0.0) : trace(B, trace_col_offset);
 }
 }  // namespace
+
+void increment_blocked(const DevMat& A, DevMat& B, double alpha, double threshold, int32_t row_block) {
+  const MergeOperand a{view(A), A.rows, A.cols, A.cplx, A.nnz, false};
+  axpby_impl(a, B, alpha, 1.0, threshold, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, row_block);
+}
 
 void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
            double* trace_out, int32_t trace_col_offset) {
@@ -3209,7 +3244,40 @@ __global__ void k_halo_bounds(const int64_t* __restrict__ outer, int c0, const i
   bound[2 * q + 1] = b;
   cnt_row[q] = b - a;
 }
+// the whole P x P count matrix from the gathered column offsets of all panels: cnt[s * P + q] = entries of rank s's
+// panel inside the column range rank q asked for; bound[2q], bound[2q + 1] = entry offsets of MY panel at the ends of
+// the segment requester q gets from me.  req = gathered (kmin, kmax, nnzA, nnzB) records, outer_all = gathered panel
+// offsets, `pitch` entries per rank.  Same arithmetic as halo_segment / panel_range on the host.
+__global__ void k_halo_counts(const long long* __restrict__ req, const long long* __restrict__ outer_all, int pitch, int dim, int P,
+                              int me, long long* __restrict__ cnt, long long* __restrict__ bound) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P * P) return;
+  const int s = t / P, q = t % P;
+  const int c0 = (int)(((long long)dim * s) / P), c1 = (int)(((long long)dim * (s + 1)) / P);
+  const long long klo = req[4 * q], khi = req[4 * q + 1];
+  int a = c0, b = c0;
+  if (khi >= klo) {
+    const int lo = max(c0, (int)klo), hi = min(c1, (int)khi + 1);
+    if (hi > lo) {
+      a = lo;
+      b = hi;
+    }
+  }
+  const long long oa = outer_all[(size_t)s * pitch + (a - c0)], ob = outer_all[(size_t)s * pitch + (b - c0)];
+  cnt[t] = ob - oa;
+  if (s == me) {
+    bound[2 * q] = oa;
+    bound[2 * q + 1] = ob;
+  }
+}
 }  // namespace
+
+void halo_counts_async(const int64_t* d_req, const int64_t* d_outer_all, int pitch, int32_t dim, int P, int me, int64_t* d_cnt,
+                       int64_t* d_bound) {
+  hipLaunchKernelGGL(k_halo_counts, dim3(cdiv((int64_t)P * P, 256)), dim3(256), 0, stream(),
+                     reinterpret_cast<const long long*>(d_req), reinterpret_cast<const long long*>(d_outer_all), pitch, dim, P, me,
+                     reinterpret_cast<long long*>(d_cnt), reinterpret_cast<long long*>(d_bound));
+}
 
 namespace {
 __global__ void k_halo_interior(Csc B, int c0, int c1, long long* __restrict__ out) {
@@ -3286,6 +3354,59 @@ DevMat column_slice(const DevMat& A, int32_t c0, int32_t c1) {
     HIP_CHECK(hipMemcpyAsync(R.inner.p, A.inner.p + h[0], sizeof(int32_t) * (size_t)R.nnz, hipMemcpyDeviceToDevice, stream()));
     HIP_CHECK(hipMemcpyAsync(R.val.p, A.val.p + h[0] * (int64_t)A.wval(), sizeof(double) * (size_t)R.nnz * A.wval(), hipMemcpyDeviceToDevice, stream()));
   }
+  return R;
+}
+
+namespace {
+__global__ void k_mask_len(const int64_t* __restrict__ outer, int32_t* __restrict__ len, int cols, int col_offset, int block,
+                           int slices, int slice) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  const bool keep = ((col_offset + j) / block) % slices == slice;
+  len[j] = keep ? (int32_t)(outer[j + 1] - outer[j]) : 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_mask_copy(Csc A, const int64_t* __restrict__ dst_outer, int32_t* __restrict__ dst_inner,
+                                                   T* __restrict__ dst_val) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= A.cols) return;
+  const int64_t d0 = dst_outer[j], n = dst_outer[j + 1] - d0, s0 = A.outer[j];
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  for (int64_t t = lane_id(); t < n; t += WAVE) {
+    dst_inner[d0 + t] = A.inner[s0 + t];
+    dst_val[d0 + t] = Av[s0 + t];
+  }
+}
+}  // namespace
+
+DevMat mask_columns(const DevMat& A, int32_t col_offset, int32_t block, int32_t slices, int32_t slice) {
+  DevMat R;
+  R.rows = A.rows;
+  R.cols = A.cols;
+  R.cplx = A.cplx;
+  R.outer.alloc((size_t)A.cols + 1);
+  if (A.cols == 0) {
+    R.reset_empty(A.rows, 0, A.cplx);
+    return R;
+  }
+  DevBuf<int32_t> len((size_t)A.cols);
+  hipLaunchKernelGGL(k_mask_len, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), A.outer.p, len.p, A.cols, col_offset, block,
+                     slices, slice);
+  scan_async<int32_t>(len.p, R.outer.p, (int64_t)A.cols);
+  int64_t nnz = 0;
+  {
+    ScalarFetch f;
+    f.add(R.outer.p + A.cols, 1, &nnz);
+    f.run();
+  }
+  R.nnz = nnz;
+  R.inner.alloc((size_t)nnz + kIndexSlack);
+  R.val.alloc(((size_t)nnz + kIndexSlack) * R.wval());
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_mask_copy<T>), dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), R.outer.p,
+                       R.inner.p, reinterpret_cast<T*>(R.val.p));
+  });
   return R;
 }
 

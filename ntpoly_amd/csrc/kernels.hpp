@@ -35,6 +35,8 @@ struct EngineOptions {
                                // 0: SetParametersLoadBalance is ignored -- the same results up to summation order (a
                                // symmetric permutation only relabels entries), but banded operands stay on the run-based
                                // kernels (a random permutation costs ~25x in SpGEMM time and turns the halo into a full gather)
+  int virtual_grid = 0;        // tests: a process grid of any rows x columns x slices may be constructed on the ranks there
+                               // are (the shape only selects the summation semantics of the multiply: slices > 1)
   int halo_overlap = 1;        // distributed multiply: 0 exchange then multiply, 1 overlap the exchange with the interior
                                // columns when the halo is a sizeable part of the panel, 2 always split, 3 split even
                                // with an empty halo (tests; also NTPOLY_AMD_HALO_OVERLAP in the environment)
@@ -86,6 +88,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
 
 // B <- alpha*A + B (AddSparseVectors semantics), same shape and scalar type.
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold);
+// the same with the rule applied per block of `row_block` rows (the reference adds distributed matrices block by
+// block: whether "the other column is exhausted" is decided inside each row block)
+void increment_blocked(const DevMat& A, DevMat& B, double alpha, double threshold, int32_t row_block);
 // B <- alpha*A + beta*B (B scaled first, then the same rules); if D and dot_out are given, also
 // dot_out = sum conj(B_new) .* D, evaluated in the same pass
 void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
@@ -128,6 +133,10 @@ DevMat remap_general(const DevMat& A, const int32_t* d_row_map, const int32_t* d
 DevMat transpose_slice(const DevMat& A, int32_t col_lo, int32_t col_hi);
 // columns [c0, c1) of A as a new matrix
 DevMat column_slice(const DevMat& A, int32_t c0, int32_t c1);
+// A with only the columns of one K slice kept (the others empty): column j (global index col_offset + j) is kept when
+// ((col_offset + j) / block) % slices == slice -- the share of the inner dimension one process slice of the reference
+// multiplies (MatrixMultiply.f90:74-80, 102-110)
+DevMat mask_columns(const DevMat& A, int32_t col_offset, int32_t block, int32_t slices, int32_t slice);
 // concatenate column panels (all with the same rows / scalar type)
 DevMat concat_columns(const std::vector<const DevMat*>& parts);
 
@@ -146,6 +155,9 @@ void halo_request_async(const DevMat& B, int64_t nnz_a, int64_t* d_out4);
 // interior columns of a B panel (empty, or every row in [c0, c1)): d_out5 = {first interior column, last interior
 // column, number of interior columns, entry offset of the first, entry offset one past the last}
 void halo_interior_async(const DevMat& B, int32_t c0, int32_t c1, int64_t* d_out5);
+// the P x P count matrix and my send bounds from the gathered requests and the gathered panel offsets (one kernel)
+void halo_counts_async(const int64_t* d_req, const int64_t* d_outer_all, int pitch, int32_t dim, int P, int me, int64_t* d_cnt,
+                       int64_t* d_bound);
 void halo_bounds_async(const DevMat& A, int32_t c0, const int32_t* d_sa, const int32_t* d_sb, int P, int64_t* d_bound,
                        int64_t* d_cnt_row);
 

@@ -40,7 +40,7 @@ bool global_grid_constructed() { return g_grid_built; }
 void construct_grid(ProcessGrid& g, int rows, int cols, int slices) {
   const Comm& c = world();
   // grid sanity check (ProcessGridModule.F90:162-176): fatal if the shape does not match
-  if (rows * cols * slices != c.nranks)
+  if (rows * cols * slices != c.nranks && !options().virtual_grid)
     NTP_FATAL("process grid " + std::to_string(rows) + "x" + std::to_string(cols) + "x" + std::to_string(slices) +
               " does not match " + std::to_string(c.nranks) + " processes");
   g.num_rows = rows;
@@ -325,18 +325,14 @@ void ps_to_real(const PSMatrix& a, PSMatrix& out) {
 // (M1-M3) and multiplies them with its own panel of B; C comes out in the same panel layout, so
 // there is no reduction step (slices == 1 semantics: working_threshold = threshold,
 // distributed_algebra_includes/MatrixMultiply.f90:25-29).
-void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha, double beta, double threshold) {
-  if (A.dim != B.dim) NTP_FATAL("MatrixMultiply: dimension mismatch");
-  // up-casting of mixed real/complex operands (PSMatrixAlgebraModule.F90:171-188)
-  if (A.cplx != B.cplx) {
-    PSMatrix Ac, Bc;
-    ps_to_complex(A, Ac);
-    ps_to_complex(B, Bc);
-    ps_multiply(Ac, Bc, C, alpha, beta, threshold);
-    return;
-  }
+namespace {
+// alpha * A * B with the threshold, local panel of the result (slices == 1 semantics: every output entry is one sum
+// over the whole inner dimension in ascending order)
+DevMat multiply_panel(const PSMatrix& A, const PSMatrix& B, double alpha, double threshold, double a_fraction = 1.0) {
   // dense-branch rule of the local multiply (GemmMatrix.f90:49-61): only the order of threshold and
-  // alpha differs here, the arithmetic is the same hash-free sparse kernel
+  // alpha differs here, the arithmetic is the same hash-free sparse kernel.  a_fraction: share of the inner dimension
+  // A is populated over (a process slice's operand: its density is that of the populated part, as in the
+  // reference's per-block test)
   int64_t nz[2] = {A.loc.nnz, B.loc.nnz};
   const double denom = (double)A.dim * (double)A.dim;
   DevMat AB;
@@ -345,7 +341,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     // exchange returns the global nnz for the dense-branch rule
     HaloExchange hx;
     gather_needed_begin(hx, A, B.loc, nz, true);
-    const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
+    const bool dense_rule = denom > 0 && std::min((double)nz[0] / (denom * a_fraction), (double)nz[1] / denom) > 0.1;
     const ColRange need{hx.kmin, hx.kmax + 1};   // the rows of the B panel name these columns only
     if (!hx.overlapped) {
       hx.finish();
@@ -388,8 +384,50 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
       AB = parts.size() == 1 ? std::move(Cint) : concat_columns(parts);
     }
   } else {
-    const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
+    const bool dense_rule = denom > 0 && std::min((double)nz[0] / (denom * a_fraction), (double)nz[1] / denom) > 0.1;
     spgemm(A.loc, B.loc, AB, alpha, threshold, dense_rule);
+  }
+  return AB;
+}
+}  // namespace
+
+void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha, double beta, double threshold) {
+  if (A.dim != B.dim) NTP_FATAL("MatrixMultiply: dimension mismatch");
+  // up-casting of mixed real/complex operands (PSMatrixAlgebraModule.F90:171-188)
+  if (A.cplx != B.cplx) {
+    PSMatrix Ac, Bc;
+    ps_to_complex(A, Ac);
+    ps_to_complex(B, Bc);
+    ps_multiply(Ac, Bc, C, alpha, beta, threshold);
+    return;
+  }
+  DevMat AB;
+  const int S = A.grid ? A.grid->num_slices : 1;
+  if (S <= 1) {
+    AB = multiply_panel(A, B, alpha, threshold);
+  } else {
+    // Process slices (the reference's 2.5-D algorithm, MatrixMultiply.f90:25-29, 74-80, 230-267): slice s multiplies
+    // its share of the inner dimension -- the blocks g with g % S == s, block = padded dimension / (max(rows, columns)
+    // * S * block multiplier) -- with threshold / (1000 S); the partial products are then summed in slice order by
+    // IncrementMatrix, only the last addition with the caller's threshold (comm_includes/ReduceAndSumMatrixCleanup.f90
+    // :11-32), so entries below the threshold survive where the rule copies tails unfiltered.  This engine keeps its
+    // column panels and reproduces those sums: S multiplies over masked copies of A, S increments.  (Block multiplier 1
+    // = the reference run with fewer threads than blocks.)
+    const ProcessGrid& g = *A.grid;
+    const int64_t lcm = (int64_t)S * g.num_cols * g.num_rows;
+    const int64_t padded = ((int64_t)A.dim + lcm - 1) / lcm * lcm;
+    const int32_t block = (int32_t)(padded / ((int64_t)std::max(g.num_rows, g.num_cols) * S));
+    const double working = threshold / ((double)S * 1000.0);
+    AB.reset_empty(A.dim, B.c1 - B.c0, A.cplx);
+    for (int s = 0; s < S; ++s) {
+      PSMatrix As;
+      As.grid = A.grid; As.dim = A.dim; As.cplx = A.cplx; As.c0 = A.c0; As.c1 = A.c1;
+      As.loc = mask_columns(A.loc, A.c0, block, S, s);
+      int64_t kcount = 0;   // columns of the whole matrix in this slice's share
+      for (int64_t k0 = (int64_t)s * block; k0 < A.dim; k0 += (int64_t)S * block) kcount += std::min<int64_t>(block, A.dim - k0);
+      DevMat part = multiply_panel(As, B, alpha, working, std::max(1e-300, (double)kcount / (double)A.dim));
+      increment_blocked(part, AB, 1.0, s == S - 1 ? threshold : 0.0, block);   // (row blocks = inner-dimension blocks)
+    }
   }
   // beta handling (MatrixMultiply.f90:324-329)
   if (std::fabs(beta) < 2.2250738585072014e-308 || !C.constructed() || C.dim != A.dim) {
@@ -448,7 +486,7 @@ void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, dou
 // register-slab kernel computes X*X the product is never compacted: the merge kernel reads it from its slots.
 void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
   out[2] = out[3] = 0.0;
-  if (B.cplx || D.cplx != B.cplx) {
+  if (B.cplx || D.cplx != B.cplx || (B.grid && B.grid->num_slices > 1)) {   // (process slices: the K-split sums of ps_multiply)
     ps_multiply(B, B, scratch, 1.0, 0.0, threshold);
     ps_axpby_dot(scratch, B, -1.0, 2.0, threshold, D, out, want_trace);
     return;

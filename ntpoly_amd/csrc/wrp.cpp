@@ -125,6 +125,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "spgemm_variant") options().spgemm_variant = *value;
   else if (n == "halo_overlap") options().halo_overlap = *value;
   else if (n == "load_balance") options().load_balance = *value;
+  else if (n == "virtual_grid") options().virtual_grid = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used
@@ -145,6 +146,11 @@ void ntpoly_amd_last_grouped_stats(long long* out, double* ratio) {
   out[0] = s.grouped; out[1] = s.gh_failed_cols; out[2] = s.gh_groups; out[3] = s.gh_level; out[4] = s.gh_minhash;
   out[5] = s.gh_tile_rows;
   *ratio = s.gh_union_ratio;
+}
+// out[0] = halo exchanges of distributed multiplies so far, out[1] = host synchronisations inside them
+void ntpoly_amd_exchange_stats(long long* out) {
+  out[0] = exchange_stats().exchanges;
+  out[1] = exchange_stats().host_syncs;
 }
 void ntpoly_amd_reset_spgemm_accum() {
   flush_spgemm_timers();

@@ -871,6 +871,13 @@ def last_grouped_stats():
                 tile_rows=int(out[5]), union_ratio=r.value)
 
 
+def exchange_stats():
+    """(halo exchanges of distributed multiplies so far, host synchronisations inside them)"""
+    out = (C.c_longlong * 2)()
+    lib.ntpoly_amd_exchange_stats(out)
+    return int(out[0]), int(out[1])
+
+
 def reset_spgemm_accum():
     lib.ntpoly_amd_reset_spgemm_accum()
 

@@ -672,6 +672,40 @@ def gen_scale_logs(tmp):
     save("scale_logs", d, dict(kind="scale_logs", cases=cases))
 
 
+def gen_slices(tmp):
+    """K-split (process slices > 1) semantics of the reference's distributed multiply (MatrixMultiply.f90:25-29,
+    230-267, comm_includes/ReduceAndSumMatrixCleanup.f90): every slice multiplies its share of the inner dimension
+    with threshold / (1000 slices), the partial products are summed in slice order, the last addition applies the
+    caller's threshold by the IncrementMatrix rules.  Results therefore depend on the grid; recorded here for several
+    grids, two thresholds, A != B, alpha != 1, a dimension that needs padding, real and complex."""
+    rng = np.random.default_rng(777)
+    d, cases = {}, []
+    for ci, (n, dens, cplx) in enumerate([(250, 0.05, False), (197, 0.08, True)]):
+        A = rnd(rng, n, n, dens, cplx)
+        B = rnd(rng, n, n, dens, cplx)
+        write_tri(tmp + "/A.tri", n, n, *tri(A))
+        write_tri(tmp + "/B.tri", n, n, *tri(B))
+        put(d, "m%d_A" % ci, A.shape, tri(A))
+        put(d, "m%d_B" % ci, B.shape, tri(B))
+        for (pr, pc, ps) in [(1, 1, 2), (1, 1, 4), (2, 1, 2), (1, 2, 2), (2, 2, 2), (1, 1, 1)]:
+            for thr in (1e-6, 2e-2):
+                nr = pr * pc * ps
+                run(["pgemm", pr, pc, ps, tmp + "/A.tri", tmp + "/B.tri", "none", "-0.7", "0.0", repr(thr),
+                     tmp + "/C.tri"], nranks=nr)
+                parts = [read_tri(tmp + "/C.tri" + ("" if nr == 1 else ".%d" % rk)) for rk in range(nr)]
+                c = np.concatenate([q[2] for q in parts])
+                r = np.concatenate([q[3] for q in parts])
+                v = np.concatenate([q[4] for q in parts])
+                key = c.astype(np.int64) * (n + 1) + r      # slices replicate the matrix: keep one copy
+                _, first = np.unique(key, return_index=True)
+                c, r, v = c[first], r[first], v[first]
+                tag = "m%d_C_%d%d%d_%g" % (ci, pr, pc, ps, thr)
+                put(d, tag, (n, n), (c, r, v))
+                cases.append(dict(matrix=ci, n=n, cplx=cplx, grid=[pr, pc, ps], thr=thr, alpha=-0.7, key=tag, nnz=int(len(c))))
+                print(tag, len(c), flush=True)
+    save("ps_gemm_slices", d, dict(kind="ps_gemm_slices", cases=cases))
+
+
 def main():
     if not os.path.exists(DRV):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

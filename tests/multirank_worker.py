@@ -42,7 +42,10 @@ def main():
     t2.set_arrays(col, row, val * 1.01)
     B.FillFromTripletList(t2, prepartitioned=True)
     C = nt.Matrix_ps(n)
+    x0 = nt.exchange_stats()
     C.Gemm(A, B, None, 0.5, 0.0, 1e-7)
+    x1 = nt.exchange_stats()
+    res["exchanges"], res["exchange_host_syncs"] = x1[0] - x0[0], x1[1] - x0[1]
     keep("AB", C)
     res["AB_trace"], res["AB_norm"], res["AB_dot"] = C.Trace(), C.Norm(), float(np.real(C.Dot(A)))
     AT = nt.Matrix_ps(n)

@@ -82,6 +82,10 @@ def test_multirank_equals_single_rank(world, reference, tmp_path):
     for r in range(world):
         assert parts[r]["foe_energy"] == pytest.approx(float(reference["foe_energy"]), rel=1e-12)
         assert parts[r]["foe_mu"] == pytest.approx(float(reference["foe_mu"]), rel=1e-12)
+    # one distributed multiply = one halo exchange with at most ONE host synchronisation
+    for r in range(world):
+        assert int(parts[r]["exchanges"]) == 1 and int(parts[r]["exchange_host_syncs"]) <= 1, (r, parts[r]["exchanges"],
+                                                                                              parts[r]["exchange_host_syncs"])
     for r in range(world):
         for s in ("AB_trace", "AB_norm", "AB_dot", "trs2_energy", "trs2_mu"):
             assert parts[r][s] == pytest.approx(float(reference[s]), rel=1e-12, abs=1e-12), (s, r)

@@ -1,14 +1,20 @@
 #!/bin/bash
 # Collects the judged profile artefacts of one version into gpurun_out/<tag>/ (run on the GPU box through gpurun):
-#   tools/collect_profiles.sh <tag>
+#   tools/collect_profiles.sh <tag> [extra bench.py arguments, e.g. --permute 42]
 # 1. bench line (with cpu_baseline)   2. rocprofv3 --kernel-trace --stats of the same bench command
 # 3. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs, kernel trace only) of the same bench command
-tag=$1
+# 4. the traffic summary of the dominant kernel (tools/pmc_traffic_json.py), with the fingerprint of the kernel sources
+tag=$1; shift
+extra="$@"
+kern=k_spgemm_slab
+case "$extra" in *permute*) kern=k_spgemm_ghash;; esac
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$tag
-timeout 600 python3 bench.py --gpus 1 --steps 10 --warmup 2 > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats -o run -- python3 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/$tag/stats.log 2>&1
+timeout 900 python3 bench.py --gpus 1 --steps 10 --warmup 3 $extra > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
+timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats -o run -- python3 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-wrp-check $extra > gpurun_out/$tag/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/$tag/pmc_$c -o run --output-format csv -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/$tag/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/$tag/pmc_$c -o run --output-format csv -- python3 bench.py --gpus 1 --steps 4 --warmup 3 --no-cpu-baseline --no-wrp-check $extra > gpurun_out/$tag/pmc_$c.log 2>&1
 done
-ls -R gpurun_out/$tag | head -30
+python3 tools/prof_summary.py gpurun_out/$tag/stats/run_results.db > gpurun_out/$tag/kernel_stats.csv
+python3 tools/pmc_traffic_json.py gpurun_out/$tag $kern gpurun_out/$tag/pmc_traffic.json
+head -12 gpurun_out/$tag/kernel_stats.csv

@@ -4,10 +4,23 @@
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE under-counts 64-byte reads by 2x (MI355X_MICROARCH.md, HBM
 section; calibrated on k_scale, which reads and writes the same number of bytes)."""
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sources_sha16():
+    """fingerprint of the kernel sources the figure belongs to (bench.py reports the traffic only for these sources)"""
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "slab_loop.inc", "spgemm_grouped.hip"):
+        with open(os.path.join(ROOT, "ntpoly_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path):
@@ -29,7 +42,8 @@ def main():
     if "k_scale" in f and "k_scale" in w:
         cal = (sum(w["k_scale"]) / len(w["k_scale"])) / (sum(f["k_scale"]) / len(f["k_scale"]))
     out = {"kernel": fk, "launches": len(fetch), "fetch_size_KB_avg": fa, "write_size_KB_avg": wa, "fetch_correction": 2.0,
-           "k_scale_write_over_fetch": cal, "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
+           "k_scale_write_over_fetch": cal, "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0,
+           "sources_sha16": sources_sha16()}
     s = json.dumps(out, indent=1)
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(s + "\n")
