@@ -1920,6 +1920,27 @@ __global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ 
         if (A.inner[p] == col_offset + j) tr = __dadd_rn(tr, Sc<T>::re(Av[p]));
       }
       __builtin_amdgcn_wave_barrier();
+    } else if (be - bs <= W) {
+      // rows scattered over the whole range (relabelled operands): the row ids of B's column go to LDS (in the window's
+      // memory) and A's entries search them there
+      int* rows = reinterpret_cast<int*>(win);
+      const int nb = (int)(be - bs);
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (c * WAVE + lane < nb) rows[c * WAVE + lane] = bi[c];
+      for (int q = CH * WAVE + lane; q < nb; q += WAVE) rows[q] = B.inner[bs + q];
+      __builtin_amdgcn_wave_barrier();
+      for (int64_t p = as + lane; p < ae; p += WAVE) {
+        const int r = A.inner[p];
+        int l = 0, h = nb;
+        while (l < h) {
+          const int mid = (l + h) >> 1;
+          if (rows[mid] < r) l = mid + 1; else h = mid;
+        }
+        if (l < nb && rows[l] == r) accum(Av[p], Bv[bs + l]);
+        if (r == col_offset + j) tr = __dadd_rn(tr, Sc<T>::re(Av[p]));
+      }
+      __builtin_amdgcn_wave_barrier();
     } else {
       for (int64_t p = as + lane; p < ae; p += WAVE) {
         const int r = A.inner[p];
@@ -2143,6 +2164,10 @@ __global__ void k_shift_outer(const int64_t* __restrict__ in, int64_t* __restric
 __global__ void k_rebase_i64(const int64_t* __restrict__ in, int64_t* __restrict__ out, int n, int64_t add) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] - in[0] + add;
+}
+__global__ void k_linear_i64(int64_t* __restrict__ out, int64_t n, int64_t step) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i * step;
 }
 __global__ void k_fill_i64(int64_t* __restrict__ out, int64_t n, int64_t v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2400,7 +2425,46 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   const int slab_rows = A.cplx ? 8 * SLAB_CSL * WAVE : (options().spgemm_fma ? SLAB_NW : 8) * SLAB_SL * WAVE;  // (the fused loop exists for 4 waves)
   const size_t esz = A.cplx ? 16 : 8;
   const int sv_opt = options().spgemm_variant;
-  const bool slab_try = options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4) &&
+  // ---- grouped LDS-hash kernel FIRST when the previous multiply of this dimension was computed by it without a
+  // single column handed back and its kept min-hash column order still fits this operand (spgemm_grouped mode 2 checks
+  // that): no slab planning, no per-column plan -- fixed output slots of the largest table class per column
+  DevBuf<int32_t> tmp_inner;
+  DevBuf<double> tmp_val;
+  static int grouped_first_n[2] = {-1, -1};
+  bool grouped_done = false;
+  const int dr = dense_rule ? 1 : 0;
+  if (grouped_first_n[A.cplx ? 1 : 0] == n && sv_opt < 0 && options().spgemm_force_bin <= 0 && m == A.cols && (int64_t)n * 1536 < (1ll << 33)) {
+    constexpr int64_t kSlot = 1536;   // rows of the largest table class: no column of a finished group holds more
+    tmp_total = (int64_t)n * kSlot;
+    tmp_inner.alloc((size_t)tmp_total + kIndexSlack);
+    tmp_val.alloc(((size_t)tmp_total + kIndexSlack) * A.wval());
+    bin.alloc(n);
+    hipLaunchKernelGGL(k_linear_i64, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), tmpoff.p, (int64_t)n + 1, kSlot);
+    GroupedInfo gi;
+    t_num.start();
+    hipEvent_t late = timing ? get_event() : nullptr;
+    const bool ok = spgemm_grouped(A, B, tmpoff.p, tmp_inner.p, tmp_val.p, count.p, bin.p, alpha, threshold, dr, 2, &gi, late);
+    if (ok && gi.failed_cols == 0) {
+      grouped_done = true;
+      if (late) std::swap(t_num.a, late);
+      st.grouped = 1;
+      st.products = gi.products;
+      st.bin_cols[5] = n;
+      st.gh_failed_cols = 0;
+      st.gh_groups = gi.groups;
+      st.gh_level = gi.level;
+      st.gh_minhash = gi.minhash;
+      st.gh_union_ratio = gi.union_ratio;
+      st.gh_tile_rows = gi.tile_rows;
+    } else {
+      grouped_first_n[A.cplx ? 1 : 0] = -1;   // (columns it may have written are recomputed below)
+      count.zero();
+      tmp_inner.release();
+      tmp_val.release();
+    }
+    if (late) event_pool().push_back(late);
+  }
+  const bool slab_try = !grouped_done && options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4) &&
                         A.nnz < 1000000000LL && B.nnz < 1000000000LL;
   const int snb = cdiv(n, SJ);
   DevBuf<int32_t> bfirst_own, blast_own, blen_own, aspan, blk_lo, blk_w, blk_kmin, blk_kn;
@@ -2450,7 +2514,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       hipLaunchKernelGGL((k_slab_tmpoff<SLAB_CJ>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
     else
       hipLaunchKernelGGL((k_slab_tmpoff<SLAB_J>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
-  } else {
+  } else if (!grouped_done) {
     // ---- general plan: per output column its row window, product count, upper bound and kernel bin
     lo.alloc(n); span.alloc(n); bin.alloc(n); ub.alloc((size_t)n + 1); ip.alloc(n);
     hipLaunchKernelGGL(k_spgemm_plan, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(B), cmin.p,
@@ -2470,12 +2534,13 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   st.tmp_entries = tmp_total;
 
   // + slack: a loose product is read by kernels that fetch whole 64-entry chunks past a column's end
-  DevBuf<int32_t> tmp_inner((size_t)tmp_total + kIndexSlack);
-  DevBuf<double> tmp_val(((size_t)tmp_total + kIndexSlack) * A.wval());
+  if (!grouped_done) {
+    tmp_inner.alloc((size_t)tmp_total + kIndexSlack);
+    tmp_val.alloc(((size_t)tmp_total + kIndexSlack) * A.wval());
+  }
   DevBuf<int32_t> tmp2_inner;
   DevBuf<double> tmp2_val;
   DevBuf<int64_t> tmpoff2;
-  const int dr = dense_rule ? 1 : 0;
   DevBuf<double> aexp, bblk;
   DevBuf<int64_t> blk_prod, blk_prod_scan;
   if (use_slab) {
@@ -2516,7 +2581,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     }
     scan_async<int64_t>(blk_prod.p, blk_prod_scan.p, (int64_t)snb);  // total = products of this multiply
   }
-  t_num.start();
+  if (!grouped_done) t_num.start();
   if (use_slab && A.cplx) {
     if ((int64_t)hstats[16] <= SLAB_CNW * SLAB_CSL * WAVE)
       hipLaunchKernelGGL((k_spgemm_slab_c<SLAB_CNW>), dim3(xcd_grid(snb)), dim3(SLAB_CNW * WAVE), 0, stream(),
@@ -2571,7 +2636,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   }
   // ---- operands without run structure: groups of similar columns share the fetch and the hashing of the A columns
   // (spgemm_grouped.hip); taken when most columns are beyond the direct-mapped LDS windows
-  if (!use_slab) {
+  if (!use_slab && !grouped_done) {
     unsigned long long nonempty = 0;
     for (int i = 1; i <= 6; ++i) nonempty += hstats[i];
     const bool want = nonempty > 0 && options().spgemm_force_bin <= 0 &&
@@ -2579,11 +2644,13 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     if (want) {
       GroupedInfo gi;
       hipEvent_t late = timing ? get_event() : nullptr;   // "numeric" = the grouped kernel launches, not its planning passes
-      if (spgemm_grouped(A, B, tmpoff.p, tmp_inner.p, tmp_val.p, count.p, bin.p, alpha, threshold, dr, sv_opt >= 500, &gi, late)) {
+      if (spgemm_grouped(A, B, tmpoff.p, tmp_inner.p, tmp_val.p, count.p, bin.p, alpha, threshold, dr, sv_opt >= 500 ? 1 : 0, &gi, late)) {
         for (int i = 1; i <= 6; ++i) hstats[i] = 0;
         hstats[5] = (unsigned long long)gi.failed_cols;   // what the grouped kernel handed back: per-column LDS hash below
         st.grouped = 1;
         if (late) std::swap(t_num.a, late);
+        // the next multiply of this dimension goes to the grouped kernel first (see the top of this function)
+        if (gi.failed_cols == 0 && gi.minhash && sv_opt < 0) grouped_first_n[A.cplx ? 1 : 0] = n;
       }
       if (late) event_pool().push_back(late);
       st.gh_failed_cols = gi.failed_cols;

@@ -314,6 +314,105 @@ __global__ __launch_bounds__(256) void k_gh_union(Csc A, Csc B, const int32_t* _
   }
 }
 
+// The tile builder proper (the FILL = true branch above is kept for unions beyond 1024 rows): hash set sized for the
+// union, positions looked up through the same table instead of a binary search.  KH buckets, unions of at most KH / 2.
+template <typename T, int KH>
+__global__ __launch_bounds__(256) void k_gh_fill(Csc A, Csc B, const int32_t* __restrict__ cols,
+                                                 const int32_t* __restrict__ grp_kn, const int64_t* __restrict__ grp_off,
+                                                 GhRec* __restrict__ recs, T* __restrict__ tiles, int ngroups,
+                                                 unsigned long long* __restrict__ nproducts) {
+  constexpr int G = GhG<T>::value, KMAX = KH / 2;
+  __shared__ int hk[KH];      // row ids
+  __shared__ int hp[KH];      // position of the bucket's row in the sorted union
+  __shared__ unsigned long long uk[KMAX];   // (row << 32 | bucket), sorted by row
+  __shared__ int ctl[2];
+  const int gi = xcd_block(ngroups);
+  if (gi < 0) return;
+  const int kn = grp_kn[gi];
+  if (kn <= 0) return;
+  const int tid = threadIdx.x, wave = tid / WAVE, lane = lane_id();
+  for (int s = tid; s < KH; s += 256) hk[s] = -1;
+  if (tid < 2) ctl[tid] = 0;
+  __syncthreads();
+  constexpr int SH = KH == 2048 ? 21 : 19;
+  for (int c = wave; c < G; c += 4) {
+    const int col = cols[gi * G + c];
+    if (col < 0) continue;
+    const int64_t s = B.outer[col], e = B.outer[col + 1];
+    for (int64_t p = s + lane; p < e; p += WAVE) {
+      const int k = B.inner[p];
+      unsigned h = gh_hash((unsigned)k) >> SH;
+      for (;;) {
+        const int old = atomicCAS(&hk[h], -1, k);
+        if (old == -1 || old == k) break;
+        h = (h + 1) & (KH - 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (int s0 = 0; s0 < KH; s0 += 256) {
+    const int k = hk[s0 + tid];
+    const bool occ = k >= 0;
+    const unsigned long long m = __ballot(occ);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&ctl[0], __popcll(m));
+    base = __shfl(base, 0, WAVE);
+    if (occ) uk[base + __popcll(m & lanemask_lt())] = ((unsigned long long)(unsigned)k << 32) | (unsigned)(s0 + tid);
+  }
+  int p2 = 64;
+  while (p2 < kn) p2 <<= 1;
+  __syncthreads();
+  for (int s = kn + tid; s < p2; s += 256) uk[s] = ~0ull;
+  __syncthreads();
+  for (int kk = 2; kk <= p2; kk <<= 1) {
+    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+      for (int t = tid; t < p2; t += 256) {
+        const int ixj = t ^ jj;
+        if (ixj > t) {
+          const unsigned long long x = uk[t], y = uk[ixj];
+          const bool up = (t & kk) == 0;
+          if ((x > y) == up) {
+            uk[t] = y;
+            uk[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int64_t off = grp_off[gi];
+  for (int t = tid; t < kn; t += 256) {
+    const unsigned long long e = uk[t];
+    const int k = (int)(e >> 32);
+    hp[(int)(e & 0xffffffffu)] = t;
+    GhRec r;
+    r.start = A.outer[k];
+    r.len = (int32_t)(A.outer[k + 1] - r.start);
+    r.k = k;
+    recs[off + t] = r;
+  }
+  T* __restrict__ tile = tiles + off * G;
+  for (int i = tid; i < kn * G; i += 256) tile[i] = Sc<T>::zero();
+  __threadfence_block();
+  __syncthreads();
+  const T* __restrict__ Bv = static_cast<const T*>(B.val);
+  long long np = 0;   // intermediate products of this group's columns (statistics)
+  for (int c = wave; c < G; c += 4) {
+    const int col = cols[gi * G + c];
+    if (col < 0) continue;
+    const int64_t s = B.outer[col], e = B.outer[col + 1];
+    for (int64_t p = s + lane; p < e; p += WAVE) {
+      const int k = B.inner[p];
+      unsigned h = gh_hash((unsigned)k) >> SH;
+      while (hk[h] != k) h = (h + 1) & (KH - 1);
+      tile[(int64_t)hp[h] * G + c] = Bv[p];
+      np += A.outer[k + 1] - A.outer[k];
+    }
+  }
+  np = wave_sum_i64(np);
+  if (lane == 0 && np) atomicAdd(nproducts, (unsigned long long)np);
+}
+
 // groups whose union is empty need no numeric work; unusable ones (kn < 0) stay "to do" and end in the fallback
 __global__ void k_gh_init_state(const int32_t* __restrict__ grp_kn, int32_t* __restrict__ kn_pos,
                                 uint8_t* __restrict__ state, unsigned long long* __restrict__ nbad, int ngroups) {
@@ -323,6 +422,7 @@ __global__ void k_gh_init_state(const int32_t* __restrict__ grp_kn, int32_t* __r
   kn_pos[g] = kn > 0 ? kn : 0;
   state[g] = kn == 0 ? 1 : 0;
   if (kn < 0) atomicAdd(nbad, 1ull);
+  if (kn > 0) atomicMax(nbad + 1, (unsigned long long)kn);
 }
 
 // ------------------------------------------------------------------ numeric kernel
@@ -688,8 +788,9 @@ void launch_ghash(const DevMat& A, int ngroups, const int32_t* cols, const int32
 }  // namespace
 
 bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int32_t* tmp_inner, double* tmp_val,
-                    int32_t* count, uint8_t* bin_arr, double alpha, double threshold, int dense_rule, bool force,
+                    int32_t* count, uint8_t* bin_arr, double alpha, double threshold, int dense_rule, int mode,
                     GroupedInfo* info, hipEvent_t numeric_begin) {
+  const bool force = mode == 1;
   const int n = B.cols;
   const int G = A.cplx ? 8 : 16;
   int ngroups = cdiv(n, G);
@@ -708,17 +809,19 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
   };
   // steps of the numeric kernel = sum of the groups' unions; *cost: the same with unusable groups (union beyond the
   // tile builder's capacity) counted at that capacity, so that they do not make an ordering look good
+  int64_t max_kn = 0;   // largest union of the order counted last
   auto total_of = [&](const int32_t* kn, int32_t* pos, int64_t* off, uint8_t* st, int ng, int64_t* cost) -> int64_t {
     stats.zero();
     hipLaunchKernelGGL(k_gh_init_state, dim3(cdiv(ng, 256)), dim3(256), 0, stream(), kn, pos, st, stats.p, ng);
     scan_i32_async(pos, off, (int64_t)ng);
     int64_t total = 0;
-    unsigned long long nbad = 0;
+    unsigned long long nb[2] = {0, 0};
     ScalarFetch f;
     f.add(off + ng, 1, &total);
-    f.add(stats.p, 1, &nbad);
+    f.add(stats.p, 2, nb);
     f.run();
-    *cost = total + (int64_t)nbad * GH_KCAP;
+    *cost = total + (int64_t)nb[0] * GH_KCAP;
+    max_kn = (int64_t)nb[1];
     return total;
   };
 
@@ -746,6 +849,10 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
     reuse = ratio <= std::max(1.3, 1.15 * oc.ratio0);
     gi.minhash = oc.minhash;
   }
+  if (mode == 2 && !(reuse && oc.minhash)) {
+    if (info) *info = gi;
+    return false;
+  }
   if (!reuse) {
     // natural order first: adjacent columns of a locally ordered matrix are similar
     ngroups = cdiv(n, G);
@@ -757,6 +864,7 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
     count_pass(cols.p, grp_kn.p, grp_maxlen.p, ngroups);
     total = total_of(grp_kn.p, kn_pos.p, grp_off.p, state.p, ngroups, &cost);
     ratio = (double)cost / ideal;
+    const int64_t max_kn_natural = max_kn;
     if (ratio > 1.5) {
       // cluster the columns by min-hash signature, order every cluster along a line, cut it into groups, count again
       DevBuf<unsigned long long> sig((size_t)n), sig_sorted((size_t)n), best((size_t)n + 1);
@@ -813,6 +921,8 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
         cost = cost2;
         ratio = (double)cost / ideal;
         gi.minhash = 1;
+      } else {
+        max_kn = max_kn_natural;
       }
     }
     oc.n = n;
@@ -833,10 +943,16 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
 
   DevBuf<GhRec> recs((size_t)total + 8);
   DevBuf<double> tiles(((size_t)total + 8) * (size_t)G * A.wval());
+  DevBuf<unsigned long long> prod(1);
+  prod.zero();
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((k_gh_union<T, true>), dim3(xcd_grid(ngroups)), dim3(256), 0, stream(), view(A), view(B), colp, grp_kn.p,
-                       grp_maxlen.p, grp_off.p, recs.p, reinterpret_cast<T*>(tiles.p), ngroups);
+    if (max_kn <= 1024)
+      hipLaunchKernelGGL((k_gh_fill<T, 2048>), dim3(xcd_grid(ngroups)), dim3(256), 0, stream(), view(A), view(B), colp, grp_kn.p,
+                         grp_off.p, recs.p, reinterpret_cast<T*>(tiles.p), ngroups, prod.p);
+    else
+      hipLaunchKernelGGL((k_gh_fill<T, 8192>), dim3(xcd_grid(ngroups)), dim3(256), 0, stream(), view(A), view(B), colp, grp_kn.p,
+                         grp_off.p, recs.p, reinterpret_cast<T*>(tiles.p), ngroups, prod.p);
   });
 
   if (numeric_begin) HIP_CHECK(hipEventRecord(numeric_begin, stream()));
@@ -881,12 +997,14 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
     hipLaunchKernelGGL(k_gh_finish<8>, dim3(cdiv(npad, 256)), dim3(256), 0, stream(), colp, state.p, bin_arr, count, stats.p, ngroups);
   else
     hipLaunchKernelGGL(k_gh_finish<16>, dim3(cdiv(npad, 256)), dim3(256), 0, stream(), colp, state.p, bin_arr, count, stats.p, ngroups);
-  unsigned long long h[4] = {0, 0, 0, 0};
+  unsigned long long h[4] = {0, 0, 0, 0}, hprod = 0;
   {
     ScalarFetch f;
     f.add(stats.p, 4, h);
+    f.add(prod.p, 1, &hprod);
     f.run();
   }
+  gi.products = (int64_t)hprod;
   gi.failed_cols = (int64_t)h[2];
   gi.failed_groups = (int64_t)h[3];
   if (info) *info = gi;
