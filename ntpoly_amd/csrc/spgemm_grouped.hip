@@ -461,7 +461,6 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
   __shared__ int ctl[4];                    // [0] slots handed out, [1], [2] overflow seen while scattering an even / odd
                                             // phase (read after the barrier that ends that scatter, rewritten two
                                             // barriers later: every thread reads the same value), [3] valid rows (epilogue)
-  __shared__ int cnt_s[SL * NW][2];
   const int gi = xcd_block(ngroups);
   if (gi < 0) return;
   if (grp_state[gi] != 0) return;
@@ -648,6 +647,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
       st_bar += __builtin_amdgcn_s_memtime() - c3s;
     }
   }
+  const unsigned long long epi0 = (ablate & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
   if ((ablate & 8) && tid == 0) {
     atomicAdd(&stats[8], st_load);
     atomicAdd(&stats[9], st_scat);
@@ -665,22 +665,35 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
     if (tid == 0) grp_state[gi] = 1;
     return;
   }
-  // ---- epilogue: rows in ascending order, then column by column through LDS
+  // ---- epilogue.  The (row, slot) pairs of the group are sorted once (bitonic in LDS; stages whose partners lie in
+  // the same 64 elements are private to a wave and need no workgroup barrier), which gives every slot its rank in row
+  // order.  The sums never leave their registers: for every column the owner of a slot sets a bit at the slot's RANK in
+  // a per-column bitmap when the entry survives the prune rule (PruneList.f90:22), a prefix over the bitmap words turns
+  // a rank into the output position, and the owner writes row and value there -- the column comes out sorted.
   const int nsl = min(ctl[0], CAP);
   int p2 = 64;
   while (p2 < nsl) p2 <<= 1;
   unsigned long long* skey = htab;
-  T* colbuf = &xbuf[0][0][0];   // two columns of CAP sums each (xbuf holds >= 2 * CAP elements)
+  constexpr int NWORD = CAP / 64;
+  int* rank_s = reinterpret_cast<int*>(&xbuf[0][0][0]);                                  // [CAP]
+  unsigned long long* bm = reinterpret_cast<unsigned long long*>(rank_s + CAP);          // [G][NWORD]
+  int* pre = reinterpret_cast<int*>(bm + G * NWORD);                                     // [G][NWORD]
+  long long* colbase = reinterpret_cast<long long*>(pre + G * NWORD);                    // [G]
+  static_assert(sizeof(int) * CAP + (sizeof(unsigned long long) + sizeof(int)) * G * NWORD + sizeof(long long) * G <=
+                    sizeof(T) * 2 * KB * CAP, "epilogue arrays fit the x buffers");
   __syncthreads();
   for (int s = tid; s < p2; s += NT) {
     const int row = s < nsl ? slot_row[s] : -1;
-    const bool ok = row >= 0;
-    skey[s] = ok ? (((unsigned long long)(unsigned)row << 32) | (unsigned)s) : EMPTY;
-    const int nv = __popcll(__ballot(ok));
-    if (lane == 0 && nv) atomicAdd(&ctl[3], nv);
+    skey[s] = row >= 0 ? (((unsigned long long)(unsigned)row << 32) | (unsigned)s) : EMPTY;
+  }
+  for (int s = tid; s < G * NWORD; s += NT) bm[s] = 0ull;
+  if (tid < G) {
+    const int col = cols[gi * G + tid];
+    colbase[tid] = col >= 0 ? tmpoff[col] : 0;
   }
   __syncthreads();
   for (int kk = 2; kk <= p2; kk <<= 1) {
+    if ((kk >> 1) > 32) __syncthreads();   // the wave-private stages of the previous round are read across waves now
     for (int jj = kk >> 1; jj > 0; jj >>= 1) {
       for (int t = tid; t < p2; t += NT) {
         const int ixj = t ^ jj;
@@ -693,65 +706,62 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
           }
         }
       }
-      __syncthreads();
+      if (jj > 32) __syncthreads();                                   // partners in other waves' elements
+      else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // same wave: its LDS writes before its next reads
     }
   }
-  const int nvalid = ctl[3];
+  __syncthreads();
+  for (int r = tid; r < nsl; r += NT) {
+    const unsigned long long e = skey[r];
+    if (e != EMPTY) rank_s[(int)(e & 0xffffffffu)] = r;
+  }
   if (tid == 0) atomicMax(&stats[1], (unsigned long long)nsl);
+  __syncthreads();
+  unsigned long long keepbits = 0;   // bit s * G + g
+  int myrank[SL], myrow[SL];
 #pragma unroll
-  for (int g0 = 0; g0 < G; g0 += 2) {
+  for (int s = 0; s < SL; ++s) {
+    const int slot = (wave + NW * s) * WAVE + lane;
+    myrow[s] = slot < nsl ? slot_row[slot] : -1;
+    myrank[s] = myrow[s] >= 0 ? rank_s[slot] : 0;
+    if (myrow[s] >= 0) {
 #pragma unroll
-    for (int s = 0; s < SL; ++s) {
-      const int c0 = (wave + NW * s) * WAVE;
-      colbuf[c0 + lane] = acc[s][g0];
-      colbuf[CAP + c0 + lane] = acc[s][g0 + 1];
-    }
-    __syncthreads();
-    unsigned keepbits = 0;
-#pragma unroll
-    for (int rd = 0; rd < SL; ++rd) {
-      const int r = rd * NT + tid;
-      const bool valid = r < nvalid;
-      const int slot = valid ? (int)(skey[r] & 0xffffffffu) : 0;
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const T v = valid ? colbuf[cb * CAP + slot] : Sc<T>::zero();
-        const bool keep = valid && (Sc<T>::mag(dense_rule ? v : Sc<T>::scale(alpha, v)) > threshold);
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) cnt_s[rd * NW + wave][cb] = __popcll(m);
-        keepbits |= keep ? (1u << (rd * 2 + cb)) : 0u;
-      }
-    }
-    __syncthreads();
-    if (tid < 2) {
-      int run = 0;
-      for (int seg = 0; seg < SL * NW; ++seg) {
-        const int c = cnt_s[seg][tid];
-        cnt_s[seg][tid] = run;
-        run += c;
-      }
-      const int col = cols[gi * G + g0 + tid];
-      if (col >= 0) count[col] = run;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rd = 0; rd < SL; ++rd) {
-      const int r = rd * NT + tid;
-      const unsigned long long key = r < nvalid ? skey[r] : 0ull;
-      const int slot = (int)(key & 0xffffffffu);
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const bool keep = (keepbits >> (rd * 2 + cb)) & 1u;
-        const unsigned long long m = __ballot(keep);
-        if (keep) {
-          const int col = cols[gi * G + g0 + cb];
-          const int64_t pos = tmpoff[col] + cnt_s[rd * NW + wave][cb] + __popcll(m & lanemask_lt());
-          out_inner[pos] = (int)(key >> 32);
-          out_val[pos] = Sc<T>::scale(alpha, colbuf[cb * CAP + slot]);
+      for (int g = 0; g < G; ++g) {
+        const T v = acc[s][g];
+        if (Sc<T>::mag(dense_rule ? v : Sc<T>::scale(alpha, v)) > threshold) {
+          keepbits |= 1ull << (s * G + g);
+          atomicOr(&bm[g * NWORD + (myrank[s] >> 6)], 1ull << (myrank[s] & 63));
         }
       }
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = tid; i < G * NWORD; i += NT) {
+    const int g = i / NWORD, w = i % NWORD;
+    int run = 0;
+    for (int w2 = 0; w2 < w; ++w2) run += __popcll(bm[g * NWORD + w2]);
+    pre[i] = run;
+    if (w == NWORD - 1) {
+      const int col = cols[gi * G + g];
+      if (col >= 0) count[col] = run + __popcll(bm[i]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if ((keepbits >> (s * G + g)) & 1ull) {
+        const int w = myrank[s] >> 6, bit = myrank[s] & 63;
+        const int64_t pos = colbase[g] + pre[g * NWORD + w] + __popcll(bm[g * NWORD + w] & ((1ull << bit) - 1ull));
+        out_inner[pos] = myrow[s];
+        out_val[pos] = Sc<T>::scale(alpha, acc[s][g]);
+      }
+    }
+  }
+  if ((ablate & 8) && tid == 0) {
+    atomicAdd(&stats[13], __builtin_amdgcn_s_memtime() - epi0);
+    atomicAdd(&stats[14], 1ull);
   }
   if (tid == 0) grp_state[gi] = 1;
 }
@@ -979,8 +989,10 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
     f.add(stats.p, 16, h);
     f.run();
     if (options().spgemm_variant == 518 && h[12])
-      std::fprintf(stderr, "[ghash stamps, level %d] cycles per phase (wave 0): load %.0f scatter %.0f products %.0f barrier %.0f (phases %llu)\n",
-                   level, (double)h[8] / h[12], (double)h[9] / h[12], (double)h[10] / h[12], (double)h[11] / h[12], h[12]);
+      std::fprintf(stderr, "[ghash stamps, level %d] cycles per phase (wave 0): load %.0f scatter %.0f products %.0f barrier %.0f (phases %llu); "
+                   "per group: loop %.0f epilogue %.0f (groups %llu)\n",
+                   level, (double)h[8] / h[12], (double)h[9] / h[12], (double)h[10] / h[12], (double)h[11] / h[12], h[12],
+                   (double)(h[8] + h[9] + h[10] + h[11]) / std::max(1ull, h[14]), (double)h[13] / std::max(1ull, h[14]), h[14]);
     gi.level = level;
     const int64_t left = (int64_t)h[0];
     if (level == first) {
