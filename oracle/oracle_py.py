@@ -180,6 +180,48 @@ def ps_multiply(A, B, Cin=None, alpha=1.0, beta=0.0, threshold=0.0):
     return Mat(lib().oracle_ps_multiply(A.ptr, B.ptr, _p(Cin), alpha, beta, threshold))
 
 
+def ps_multiply_sliced(A, B, alpha, threshold, rows, cols, slices):
+    """alpha*A*B as the reference computes it on a rows x cols x slices process grid with slices > 1
+    (distributed_algebra_includes/MatrixMultiply.f90:25-29, 74-80, 230-267; comm_includes/
+    ReduceAndSumMatrixCleanup.f90:11-32; block multiplier 1): the inner dimension is cut into blocks of
+    padded_dim / (max(rows, cols) * slices) columns dealt round-robin to the slices; slice s multiplies its share
+    with threshold / (1000 * slices); the partial products are added in slice order by IncrementMatrix applied
+    block by block (the same block size along the rows), the caller's threshold only in the last addition.
+    Built from the oracle's own gemm / increment on sub-matrices (scipy only cuts and stacks)."""
+    import scipy.sparse as sp
+    n = A.rows
+    lcm = slices * cols * rows
+    padded = (n + lcm - 1) // lcm * lcm
+    block = padded // (max(rows, cols) * slices)
+    working = threshold / (slices * 1000.0)
+    As, Bs = A.to_scipy().tocsc(), B
+    is_c = A.is_complex
+    total = None    # list of row-block matrices (scipy csc), None = empty
+    nblk = (n + block - 1) // block
+    acc = [None] * nblk
+    for s in range(slices):
+        keep = ((np.arange(n) // block) % slices) == s
+        Am = As @ sp.diags(keep.astype(float))      # columns outside the slice's share removed (exact: x*1, x*0 dropped)
+        Am = sp.csc_matrix(Am)
+        Am.eliminate_zeros()
+        Am.sort_indices()
+        if is_c:
+            Am = Am.astype(np.complex128)
+        part = ps_multiply(Mat.from_scipy(Am) if Am.nnz else Mat.from_triplets(n, n, [], [], np.zeros(0, complex if is_c else float)),
+                           Bs, None, alpha, 0.0, working).to_scipy().tocsr()
+        thr = threshold if s == slices - 1 else 0.0
+        for g in range(nblk):
+            r0, r1 = g * block, min(n, (g + 1) * block)
+            pb = sp.csc_matrix(part[r0:r1, :])
+            pb.sort_indices()
+            if acc[g] is None:
+                acc[g] = Mat.from_triplets(r1 - r0, n, [], [], np.zeros(0, complex if is_c else float))
+            acc[g] = increment(Mat.from_scipy(pb), acc[g], 1.0, thr)
+    out = sp.vstack([a.to_scipy() for a in acc]).tocsc()
+    out.sort_indices()
+    return Mat.from_scipy(out)
+
+
 def increment(A, B, alpha=1.0, threshold=0.0):
     return Mat(lib().oracle_increment(A.ptr, B.ptr, alpha, threshold))
 
