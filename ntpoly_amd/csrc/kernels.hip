@@ -2640,7 +2640,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     unsigned long long nonempty = 0;
     for (int i = 1; i <= 6; ++i) nonempty += hstats[i];
     const bool want = nonempty > 0 && options().spgemm_force_bin <= 0 &&
-                      (sv_opt == 500 || (sv_opt >= 511 && sv_opt <= 525) || (sv_opt < 0 && hstats[5] * 2 >= nonempty));
+                      (sv_opt == 500 || (sv_opt >= 511 && sv_opt <= 541) || (sv_opt < 0 && hstats[5] * 2 >= nonempty));
     if (want) {
       GroupedInfo gi;
       hipEvent_t late = timing ? get_event() : nullptr;   // "numeric" = the grouped kernel launches, not its planning passes

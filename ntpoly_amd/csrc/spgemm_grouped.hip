@@ -436,10 +436,14 @@ __global__ void k_gh_init_state(const int32_t* __restrict__ grp_kn, int32_t* __r
 //           with the G multipliers (SGPRs: one scalar load of the tile row, requested one step ahead) into the register
 //           sums and writes zeros back (the reader owns the slot, so the two sets need no other cleaning)
 //   barrier
-template <int CAP>
+template <int CAP, int ELEM>
 struct GhTable {
-  static constexpr int TH = CAP <= 512 ? 1024 : CAP <= 1024 ? 2048 : 4096;    // buckets (load <= 1/2 ... 3/8)
-  static constexpr int SHIFT = CAP <= 512 ? 22 : CAP <= 1024 ? 21 : 20;        // top bits of the multiplicative hash
+  // entries of the table: four per slot (load <= 1/4), in buckets of two read together -- with linear probing over
+  // single entries at load 1/2 the slowest of the 64 lanes of a probe needed 4-6 rounds of LDS latency, and the
+  // lookups were 45 % of the kernel (profiles/README.md item 28).  (Complex values at the largest class: LDS allows
+  // load 3/8 only.)
+  static constexpr int TH = CAP <= 512 ? 2048 : CAP <= 1024 ? 4096 : (ELEM > 8 ? 4096 : 8192);
+  static constexpr int SHIFT = TH == 2048 ? 22 : TH == 4096 ? 21 : 20;   // top bits of the multiplicative hash -> bucket (TH / 2 of them)
 };
 
 template <typename T, int NW, int SL, int WPC>
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
     int32_t* __restrict__ count, uint8_t* __restrict__ grp_state, unsigned long long* __restrict__ stats, double alpha,
     double threshold, int dense_rule, int ngroups, int ablate) {
   constexpr int G = GhG<T>::value;
-  constexpr int NT = NW * WAVE, CAP = NT * SL, TH = GhTable<CAP>::TH, SHIFT = GhTable<CAP>::SHIFT;
+  constexpr int NT = NW * WAVE, CAP = NT * SL, TH = GhTable<CAP, (int)sizeof(T)>::TH, SHIFT = GhTable<CAP, (int)sizeof(T)>::SHIFT;
   constexpr int KB = NW / WPC;   // steps per phase
   constexpr int PF = 2;          // chunks of a wave's share requested a phase ahead
   constexpr unsigned long long EMPTY = ~0ull;
@@ -540,29 +544,34 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
   // one wave cannot wait on each other forever).
   constexpr unsigned PENDING = 0x7fffffffu, NOSLOT = 0x7ffffffeu;
   auto slot_of = [&](int i, int par) -> int {
-    unsigned h = gh_hash((unsigned)i) >> SHIFT;
+    if (ablate & 16) return (int)(gh_hash((unsigned)i) >> SHIFT) & (CAP - 1);   // (timing experiment: no table, wrong results)
+    constexpr unsigned NBUCK = TH / 2;
+    unsigned b = gh_hash((unsigned)i) >> SHIFT;
     for (;;) {
-      const unsigned long long cur = __hip_atomic_load(&htab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if ((int)(cur >> 32) == i) {
-        const unsigned sl = (unsigned)(cur & 0xffffffffu);
+      const unsigned long long e0 = __hip_atomic_load(&htab[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned long long e1 = __hip_atomic_load(&htab[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const bool m0 = (int)(e0 >> 32) == i, m1 = (int)(e1 >> 32) == i;
+      if (m0 || m1) {
+        const unsigned sl = (unsigned)((m0 ? e0 : e1) & 0xffffffffu);
         if (sl == PENDING) continue;
         return sl == NOSLOT ? -1 : (int)sl;
       }
-      if (cur == EMPTY) {
+      if (e0 == EMPTY || e1 == EMPTY) {   // not in the table: claim the first free entry of the bucket
+        const unsigned at = 2 * b + (e0 == EMPTY ? 0u : 1u);
         const unsigned long long claim = ((unsigned long long)(unsigned)i << 32) | PENDING;
-        const unsigned long long old = atomicCAS(&htab[h], EMPTY, claim);
+        const unsigned long long old = atomicCAS(&htab[at], EMPTY, claim);
         if (old == EMPTY) {
           const int mine = atomicAdd(&ctl[0], 1);
           const bool ok = mine < CAP;
           if (ok) slot_row[mine] = i;
           else ctl[1 + par] = 1;
-          __hip_atomic_store(&htab[h], ((unsigned long long)(unsigned)i << 32) | (ok ? (unsigned)mine : NOSLOT), __ATOMIC_RELAXED,
+          __hip_atomic_store(&htab[at], ((unsigned long long)(unsigned)i << 32) | (ok ? (unsigned)mine : NOSLOT), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_WORKGROUP);
           return ok ? mine : -1;
         }
-        if ((int)(old >> 32) == i) continue;   // the same row is being inserted by somebody else: read it again
+        continue;   // somebody else took that entry (the same row, or another one): look at the bucket again
       }
-      h = (h + 1) & (TH - 1);
+      b = (b + 1) & (NBUCK - 1);
     }
   };
   // S: values of column (ph, my_kb) into xbuf[set][my_kb]
@@ -789,7 +798,7 @@ void launch_ghash(const DevMat& A, int ngroups, const int32_t* cols, const int32
                   const int64_t* grp_off, const GhRec* recs, const double* tiles, const int64_t* tmpoff, int32_t* tmp_inner,
                   double* tmp_val, int32_t* count, uint8_t* state, unsigned long long* stats, double alpha, double thr, int dr) {
   const int sv = options().spgemm_variant;
-  const int ablate = (sv >= 511 && sv <= 525) ? sv - 510 : 0;   // bits: 1 no products, 2 no hashing / scatter, 4 no epilogue
+  const int ablate = (sv >= 511 && sv <= 541) ? sv - 510 : 0;   // bits: 1 no products, 2 no hashing / scatter, 4 no epilogue
   hipLaunchKernelGGL((k_spgemm_ghash<T, NW, SL, WPC>), dim3(xcd_grid(ngroups)), dim3(NW * WAVE), 0, stream(), view(A), cols, grp_kn,
                      grp_maxlen, grp_off, recs, reinterpret_cast<const T*>(tiles), tmpoff, tmp_inner,
                      reinterpret_cast<T*>(tmp_val), count, state, stats, alpha, thr, dr, ngroups, ablate);
@@ -951,8 +960,11 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
   }
   const int npad = ngroups * G;
 
-  DevBuf<GhRec> recs((size_t)total + 8);
-  DevBuf<double> tiles(((size_t)total + 8) * (size_t)G * A.wval());
+  // (a quarter of headroom: the unions grow from one purification step to the next, and a block of the caching
+  // allocator that fits the next multiply as well saves a hipMalloc of hundreds of MB inside the solver loop)
+  const size_t tile_rows_cap = (size_t)total + (size_t)total / 4 + 8;
+  DevBuf<GhRec> recs(tile_rows_cap);
+  DevBuf<double> tiles(tile_rows_cap * (size_t)G * A.wval());
   DevBuf<unsigned long long> prod(1);
   prod.zero();
   dispatch_type(A.cplx, [&](auto tag) {
