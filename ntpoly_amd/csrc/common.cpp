@@ -46,6 +46,8 @@ struct Pool {
   std::mutex mu;
   std::map<size_t, std::vector<void*>> free_lists;
   std::map<void*, size_t> live;
+  std::map<const void*, unsigned long long> serial_of;
+  unsigned long long next_serial = 1;
   size_t in_use = 0, cached = 0;
   long long n_malloc = 0;     // hipMalloc calls (cache misses)
   double ms_malloc = 0.0;     // host time spent in them
@@ -81,10 +83,19 @@ void* dev_alloc(size_t bytes) {
   std::lock_guard<std::mutex> g(P.mu);
   auto it = P.free_lists.find(b);
   void* p = nullptr;
+  size_t got = b;
+  if (it == P.free_lists.end() || it->second.empty()) {
+    // no block of this class: a cached block of a larger class (up to twice the size) serves as well -- buffers whose
+    // sizes drift from one solver iteration to the next then keep circulating instead of forcing a hipMalloc
+    it = P.free_lists.end();
+    if (b >= ((size_t)1 << 20))
+      for (auto jt = P.free_lists.upper_bound(b); jt != P.free_lists.end() && jt->first <= 2 * b; ++jt)
+        if (!jt->second.empty()) { it = jt; got = jt->first; break; }
+  }
   if (it != P.free_lists.end() && !it->second.empty()) {
     p = it->second.back();
     it->second.pop_back();
-    P.cached -= b;
+    P.cached -= got;
   } else {
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, b);
@@ -101,8 +112,9 @@ void* dev_alloc(size_t bytes) {
     P.n_malloc += 1;
     P.ms_malloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
-  P.live[p] = b;
-  P.in_use += b;
+  P.live[p] = got;
+  P.serial_of[p] = P.next_serial++;
+  P.in_use += got;
   return p;
 }
 
@@ -114,9 +126,17 @@ void dev_free(void* p) {
   if (it == P.live.end()) NTP_FATAL("dev_free of an unknown pointer");
   const size_t b = it->second;
   P.live.erase(it);
+  P.serial_of.erase(p);
   P.in_use -= b;
   P.free_lists[b].push_back(p);
   P.cached += b;
+}
+
+unsigned long long dev_alloc_serial(const void* p) {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> g(P.mu);
+  auto it = P.serial_of.find(p);
+  return it == P.serial_of.end() ? 0ull : it->second;
 }
 
 void dev_release_cache() {
@@ -142,6 +162,9 @@ void DevMat::reset_empty(int32_t r, int32_t c, bool z) {
   cols = c;
   cplx = z;
   nnz = 0;
+  cnt.release();
+  slots = 0;
+  zero_free = 0;
   outer.alloc((size_t)c + 1);
   outer.zero();
   inner.alloc(kIndexSlack);
@@ -153,6 +176,9 @@ void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
   cols = c;
   cplx = z;
   nnz = nz;
+  cnt.release();
+  slots = 0;
+  zero_free = 0;
   outer.alloc((size_t)c + 1);
   inner.alloc((size_t)nz + kIndexSlack);
   val.alloc(((size_t)nz + kIndexSlack) * (z ? 2 : 1));
@@ -160,6 +186,18 @@ void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
 
 DevMat DevMat::clone() const {
   DevMat R;
+  if (loose()) {  // the slots as they are
+    R.rows = rows; R.cols = cols; R.cplx = cplx; R.nnz = nnz; R.slots = slots; R.zero_free = zero_free;
+    R.outer.alloc((size_t)cols + 1);
+    R.cnt.alloc((size_t)cols);
+    R.inner.alloc((size_t)slots + kIndexSlack);
+    R.val.alloc(((size_t)slots + kIndexSlack) * wval());
+    HIP_CHECK(hipMemcpyAsync(R.outer.p, outer.p, sizeof(int64_t) * ((size_t)cols + 1), hipMemcpyDeviceToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(R.cnt.p, cnt.p, sizeof(int32_t) * (size_t)cols, hipMemcpyDeviceToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(R.inner.p, inner.p, sizeof(int32_t) * (size_t)slots, hipMemcpyDeviceToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(R.val.p, val.p, sizeof(double) * (size_t)slots * wval(), hipMemcpyDeviceToDevice, stream()));
+    return R;
+  }
   R.alloc(rows, cols, cplx, nnz);
   HIP_CHECK(hipMemcpyAsync(R.outer.p, outer.p, sizeof(int64_t) * ((size_t)cols + 1), hipMemcpyDeviceToDevice, stream()));
   if (nnz) {

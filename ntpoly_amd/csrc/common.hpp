@@ -58,6 +58,9 @@ struct ScalarFetch {
 // handed out again immediately (stream order protects it).
 void* dev_alloc(size_t bytes);
 void dev_free(void* p);
+// serial number of the live allocation p was handed out by (0 if unknown): tells a block apart from an earlier one
+// that lived at the same address
+unsigned long long dev_alloc_serial(const void* p);
 void dev_release_cache();
 size_t dev_bytes_in_use();
 size_t dev_bytes_cached();
@@ -122,6 +125,16 @@ struct DevMat {
   DevBuf<int64_t> outer;
   DevBuf<int32_t> inner;
   DevBuf<double> val;
+  // "loose" storage (an iterate between two steps of a purification loop, kernels.hpp): column j holds the entries
+  // outer[j] .. outer[j] + cnt[j] of inner / val, `slots` entries are addressable.  cnt.p == nullptr: packed, column j
+  // ends at outer[j + 1].  Only the functions that say so accept a loose matrix; pack() converts.
+  DevBuf<int32_t> cnt;
+  int64_t slots = 0;
+  bool loose() const { return cnt.p != nullptr; }
+  // 1: no stored value is exactly zero (verified, or true by construction: every entry passed |v| > threshold or is a
+  // scaled copy of one that did); 0: not known.  The fused purification steps (kernels.hpp, SlabFusion) read a zero of
+  // the expanded columns as "no entry", which needs this.
+  mutable int zero_free = 0;
 
   DevMat() = default;
   DevMat(int32_t r, int32_t c, bool z) { reset_empty(r, c, z); }

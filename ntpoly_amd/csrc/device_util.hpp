@@ -113,7 +113,15 @@ struct Csc {
   const int32_t* cnt = nullptr;  // "loose" columns (a product left in its upper-bound slots): column j holds the
                                  // entries outer[j] .. outer[j] + cnt[j]; nullptr = packed (ends at outer[j + 1])
 };
-inline Csc view(const DevMat& m) { return Csc{m.rows, m.cols, m.outer.p, m.inner.p, m.val.p}; }
+inline Csc view(const DevMat& m) {
+  if (m.loose()) NTP_FATAL("internal: a loose matrix reached a kernel that reads packed columns (pack() it first)");
+  return Csc{m.rows, m.cols, m.outer.p, m.inner.p, m.val.p};
+}
+inline Csc lview(const DevMat& m) {  // for the kernels that end a column at col_end()
+  Csc v{m.rows, m.cols, m.outer.p, m.inner.p, m.val.p};
+  v.cnt = m.cnt.p;
+  return v;
+}
 __device__ inline int64_t col_end(const Csc& M, int j) { return M.cnt ? M.outer[j] + M.cnt[j] : M.outer[j + 1]; }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

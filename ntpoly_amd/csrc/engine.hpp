@@ -134,6 +134,7 @@ void ps_scale(PSMatrix& A, double c);
 void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[4],
                   bool want_trace = false);  // out[2] = trace(B_new) on request
 void ps_dot_trace(const PSMatrix& A, const PSMatrix& B, double out[4], bool want_trace);
+void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace);
 // B <- 2B - B*B (threshold on the product and on the merge, TRS2's sigma > 0 update), out = dot(B_new, D), trace(B_new);
 // the product goes from the numeric kernel's slots straight into the merge when the slab kernel computes it
 void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace);

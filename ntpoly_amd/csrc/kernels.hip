@@ -187,7 +187,7 @@ __global__ void k_col_extent(Csc A, int32_t* __restrict__ cmin, int32_t* __restr
                              int32_t* __restrict__ clen) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= A.cols) return;
-  const int64_t s = A.outer[k], e = A.outer[k + 1];
+  const int64_t s = A.outer[k], e = col_end(A, k);
   clen[k] = (int32_t)(e - s);
   cmin[k] = (e > s) ? A.inner[s] : INT_MAX;
   cmax[k] = (e > s) ? A.inner[e - 1] : -1;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_slab_expand_b(Csc B, const int32_t* __r
     const int jj = wave + 4 * q;
     const int j = b * J + jj;
     if (j >= B.cols) break;
-    const int64_t s = B.outer[j], e = B.outer[j + 1];
+    const int64_t s = B.outer[j], e = col_end(B, j);
     if (e <= s) continue;
     const int first = readlane_i32(idx[q][0], 0);
     T* __restrict__ dst = fuse_a ? aexp + aeoff[j] - first : nullptr;
@@ -842,6 +842,7 @@ __global__ void k_slab_runs(const int32_t* __restrict__ cmin, const int32_t* __r
   runs[k] = r;
 }
 
+constexpr int SLAB_DTILE = 4096;   // doubles of LDS for the D columns of a block (fused epilogues): 32 KB, four workgroups per CU
 typedef double v8d __attribute__((ext_vector_type(8)));
 #include "slab_loop.inc"
 
@@ -853,13 +854,37 @@ typedef double v8d __attribute__((ext_vector_type(8)));
 // before it.  The whole loop is ONE inline-asm block over fixed physical registers (slab_loop.inc, generated
 // by tools/gen_slab_asm.py, register map there): with separate asm statements the compiler is free to copy a
 // register between them -- including one whose asynchronous load has not landed yet.
-template <int J, int SL, int NW, int MODE>  // MODE 0 unfused, 1 fma, 2..4 ablations (timing experiments, wrong results)
+//
+// EPI (fused epilogues of the purification steps, A = B = X real, one rank): the partial sums never leave the
+// registers as a product --
+//   1: result = the pruned product; its dot with D and its trace are accumulated on the way (TRS2, sigma < 0)
+//   2: result = am * product + bm * X merged by the AddSparseVectors rules (inc_decide), plus dot and trace (sigma > 0):
+//      X(r, j) is read back from the expanded runs the loop has just multiplied with (cache-hot), D(r, j) from the
+//      expanded copy of D kept for the whole solve.
+// Both leave the result LOOSE in the upper-bound slots.  A zero of the expanded X is read as "no entry": the host
+// makes sure X stores no zero value (DevMat::zero_free).  Where a column of X leaves its block's row window the kernel
+// raises fz.flag and the host repeats the step on the unfused path.
+struct SlabFuseArgs {
+  double am = 0, bm = 0, thr_m = 0;
+  const double* xexp = nullptr;      // expanded columns of X
+  const int64_t* xoff = nullptr;
+  const int32_t *xmin = nullptr, *xmax = nullptr;
+  const double* dexp = nullptr;      // expanded columns of D
+  const int64_t* doff = nullptr;
+  const int32_t *dmin = nullptr, *dmax = nullptr;
+  double* part = nullptr;            // [2 * nblocks]: (dot, trace) of the block
+  long long* pnnz = nullptr;         // [nblocks]: kept entries of the product
+  int* flag = nullptr;
+  int col_offset = 0;
+};
+
+template <int J, int SL, int NW, int MODE, int EPI = 0>  // MODE 0 unfused, 1 fma, 2..4 ablations (timing experiments, wrong results)
 __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_spgemm_slab(
     const SlabRun* __restrict__ runs, const double* __restrict__ bblk,
     const int64_t* __restrict__ blk_boff, const int32_t* __restrict__ blk_kmin, const int32_t* __restrict__ blk_kn,
     const int32_t* __restrict__ blk_lo, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
     int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count, double alpha,
-    double threshold, int dense_rule, int ncols, int nblocks) {
+    double threshold, int dense_rule, int ncols, int nblocks, const SlabFuseArgs* __restrict__ fzp) {
   static_assert(J == 16 && SL == 3 && (NW == 4 || ((NW == 6 || NW == 8) && MODE == 0)), "register map / wave rotation of slab_loop.inc");
   __shared__ int cnt_s[NW * SL][J];
   const int b = xcd_block(nblocks);
@@ -867,6 +892,39 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
   const int wave = uni_i32(threadIdx.x / WAVE), lane = lane_id();
   const int lo = blk_lo[b], kmin = blk_kmin[b], kn = blk_kn[b], w = blk_w[b];
   if (kn == 0) return;
+  // fused epilogues: what they read per column is staged in LDS before the loop starts (the loads overlap with the
+  // other workgroups' loops; after the loop the registers are too few to hide sixteen dependent round trips) --
+  // the extents of the X and D columns and the expanded D columns themselves (SLAB_DTILE doubles, checked on the host)
+  __shared__ double dtile[EPI != 0 ? SLAB_DTILE : 1];
+  __shared__ int cs_dmin[J], cs_dn[J], cs_dofs[J], cs_xmin[J], cs_xn[J], cs_xl[J];
+  __shared__ long long cs_xoff[J];
+  if constexpr (EPI != 0) {
+    const SlabFuseArgs fz0 = *fzp;
+    if (threadIdx.x < J) {
+      const int j = b * J + threadIdx.x, jc = min(j, ncols - 1);
+      const int df = fz0.dmin[jc], dl = fz0.dmax[jc];
+      cs_dmin[threadIdx.x] = df;
+      cs_dn[threadIdx.x] = (j < ncols && dl >= df) ? dl - df + 1 : 0;
+      if constexpr (EPI == 2) {
+        const int xf = fz0.xmin[jc], xl = j < ncols ? fz0.xmax[jc] : -1;
+        cs_xmin[threadIdx.x] = xf;
+        cs_xl[threadIdx.x] = xl;
+        cs_xn[threadIdx.x] = xl >= xf ? xl - xf + 1 : 0;
+        cs_xoff[threadIdx.x] = fz0.xoff[jc];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int ofs = 0;
+      for (int jj = 0; jj < J; ++jj) { cs_dofs[jj] = ofs; ofs += cs_dn[jj]; }
+    }
+    __syncthreads();
+    for (int jj = 0; jj < J; ++jj) {
+      const int dn = cs_dn[jj], ofs = cs_dofs[jj];
+      const double* src = fz0.dexp + fz0.doff[min(b * J + jj, ncols - 1)];
+      for (int i = threadIdx.x; i < dn; i += NW * WAVE) dtile[ofs + i] = src[i];
+    }
+  }
   const int rbase = lo + WAVE * wave;  // slab s of this wave starts at row rbase + 64*NW*s
   const SlabRun* rp = runs + kmin;        // record of step kk: rp[kk]
   const double* bq = bblk + (MODE == 5 ? 0 : blk_boff[b]);  // multipliers of step kk: bq[kk*J .. kk*J+J)
@@ -905,6 +963,162 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     acc[2][jj] = accL2[jj]; acc[2][jj + 8] = accH2[jj];
   }
 
+  if constexpr (EPI != 0) {
+    // ---- fused epilogues (see above).  The arguments come from memory only now: held in SGPRs across the loop they
+    // would not fit beside the registers the loop owns.  The code below is branch-free per element and walks the
+    // columns one at a time (fences keep the per-column scalars from being hoisted together): the 96 partial sums
+    // leave the compiler very few registers of either kind.
+    asm volatile("" ::: "memory");
+    const SlabFuseArgs fz = *fzp;
+    __shared__ int amax_s[NW * SL][J];
+    __shared__ int amax_f[J];
+    __shared__ double red_s[2 * NW];
+    __shared__ long long pn_s[NW];
+    // (lane s * J + jj of amaxv / cntv keeps the scalar of slab s, column jj)
+    int pn = 0, amaxv = -1;
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        const double v = acc[s][jj];
+        const double sv = __dmul_rn(alpha, v);
+        const bool ha = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+        const unsigned long long m = __ballot(ha);
+        pn += __popcll(m);
+        if constexpr (EPI == 2) {
+          const int last = m ? lo + WAVE * (wave + NW * s) + 63 - __clzll((long long)m) : -1;
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(amaxv) : "s"(last), "n"(s * J + jj));
+        }
+      }
+    }
+    if constexpr (EPI == 2) {
+      if (lane < SL * J) amax_s[wave + NW * (lane / J)][lane % J] = amaxv;
+    }
+    if (lane == 0) pn_s[wave] = pn;
+    __syncthreads();
+    if (threadIdx.x < J) {
+      if constexpr (EPI == 2) {
+        int mx = -1;
+        for (int m = 0; m < NW * SL; ++m) mx = max(mx, amax_s[m][threadIdx.x]);
+        amax_f[threadIdx.x] = mx;
+        const int j = b * J + threadIdx.x;
+        if (j < ncols) {  // every stored row of X(:, j) must be a row of this block's window
+          const int f = cs_xmin[threadIdx.x], l = cs_xl[threadIdx.x];
+          if (l >= f && (f < lo || l >= lo + w)) atomicOr(fz.flag, 1);
+        }
+      }
+    }
+    if (threadIdx.x == 0) {
+      long long t = 0;
+      for (int q = 0; q < NW; ++q) t += pn_s[q];
+      fz.pnnz[b] = t;
+    }
+    __syncthreads();
+    unsigned keepbits[SL];
+    double dsum = 0.0, tsum = 0.0;
+    int cntv = 0;
+#pragma unroll
+    for (int s = 0; s < SL; ++s) keepbits[s] = 0u;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int j = b * J + jj;
+      int xf = 0, xn = 0, xl = -1, amax = -1;   // xn: rows of the run of X(:, j), 0 = empty
+      const double* xcol = fz.xexp;
+      if constexpr (EPI == 2) {
+        xf = cs_xmin[jj];
+        xl = cs_xl[jj];
+        xn = cs_xn[jj];
+        xcol = fz.xexp + cs_xoff[jj];
+        amax = amax_f[jj];
+      }
+      const int df = cs_dmin[jj], dn = cs_dn[jj];
+      const double* dcol = dtile + cs_dofs[jj];
+#pragma unroll
+      for (int s = 0; s < SL; ++s) {
+        const int r = lo + WAVE * (wave + NW * s) + lane;
+        double v = acc[s][jj];
+        asm volatile("" : "+v"(v));   // (recomputed, not 48 lane masks carried over from the first pass)
+        const double sv = __dmul_rn(alpha, v);
+        const bool ha = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+        bool keep;
+        double o;
+        if constexpr (EPI == 1) {
+          keep = ha;
+          o = sv;
+        } else {
+          const unsigned off = (unsigned)(r - xf);
+          const bool inb = off < (unsigned)xn;
+          const double braw = xcol[inb ? off : 0u];    // (an empty column reads the first word of its neighbour)
+          const double bv = inb ? braw : 0.0;
+          const bool hb = bv != 0.0;
+          const double bs = __dmul_rn(fz.bm, bv);
+          const double wa = __dmul_rn(fz.am, sv);
+          const double both = __dadd_rn(wa, bs);
+          o = ha ? (hb ? both : wa) : bs;                       // (neither: bs = 0)
+          const bool tail = ha ? (!hb && r > xl) : (r > amax);   // the rest of one column beyond the other's end
+          keep = (ha || hb) && (tail || fabs(o) > fz.thr_m);
+        }
+        const unsigned doffs = (unsigned)(r - df);
+        const bool ind = doffs < (unsigned)dn;
+        const double draw = dcol[ind ? doffs : 0u];
+        const double dv = (ind && keep) ? draw : 0.0;
+        dsum = __dadd_rn(dsum, __dmul_rn(keep ? o : 0.0, dv));
+        tsum = __dadd_rn(tsum, (keep && r == j + fz.col_offset) ? o : 0.0);
+        keepbits[s] |= keep ? (1u << jj) : 0u;
+        asm volatile("" : "+v"(keepbits[s]));
+        acc[s][jj] = o;
+        const unsigned long long m = __ballot(keep);
+        {
+          const int pc = (int)__popcll(m);
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(pc), "n"(s * J + jj));
+        }
+      }
+      // (everything of this column is consumed here: its lane masks and loaded values do not outlive it)
+      asm volatile("" : "+v"(dsum), "+v"(tsum), "+v"(cntv));
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < SL; ++s) asm volatile("" : "+v"(keepbits[s]));   // (the bits, not 48 lane masks kept in scalar registers)
+    if (lane < SL * J) cnt_s[wave + NW * (lane / J)][lane % J] = cntv;
+    dsum = wave_sum_f64(dsum);
+    tsum = wave_sum_f64(tsum);
+    if (lane == 0) { red_s[2 * wave] = dsum; red_s[2 * wave + 1] = tsum; }
+    __syncthreads();
+    if (threadIdx.x < J) {
+      int run = 0;
+      for (int m = 0; m < NW * SL; ++m) {
+        const int c = cnt_s[m][threadIdx.x];
+        cnt_s[m][threadIdx.x] = run;
+        run += c;
+      }
+      const int j = b * J + threadIdx.x;
+      if (j < ncols) count[j] = run;
+    }
+    if (threadIdx.x == 64) {
+      double x = 0.0, y = 0.0;
+      for (int q = 0; q < NW; ++q) { x = __dadd_rn(x, red_s[2 * q]); y = __dadd_rn(y, red_s[2 * q + 1]); }
+      fz.part[2 * b] = x;
+      fz.part[2 * b + 1] = y;
+    }
+    __syncthreads();
+    const int64_t tbase = blk_toff[b];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      const int r = lo + WAVE * (wave + NW * s) + lane;
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        const bool keep = (keepbits[s] >> jj) & 1u;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+          const int64_t pos = tbase + (int64_t)jj * w + cnt_s[wave + NW * s][jj] + __popcll(m & lanemask_lt());
+          out_inner[pos] = r;
+          out_val[pos] = acc[s][jj];
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: prune, count per (slab, column), prefix over slabs, write in row order
 #pragma unroll
   for (int s = 0; s < SL; ++s) {
@@ -1415,7 +1629,7 @@ __global__ void k_inc_plan(Csc A, Csc B, int32_t* __restrict__ lo_arr, int32_t* 
   if (blockIdx.x == 0 && threadIdx.x < 16) stats[threadIdx.x] = 0ull;  // the histogram kernel that follows adds into it
   if (j >= A.cols) return;
   count[j] = 0;  // columns of the empty bin are never visited by a merge kernel
-  const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = B.outer[j + 1];
+  const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = col_end(B, j);
   int lo = INT_MAX, hi = -1;
   if (ae > as) { lo = min(lo, A.inner[as]); hi = max(hi, A.inner[ae - 1]); }
   if (be > bs) { lo = min(lo, B.inner[bs]); hi = max(hi, B.inner[be - 1]); }
@@ -1455,7 +1669,8 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
     Csc A, Csc B, Csc D, const int32_t* __restrict__ lo_arr, const int32_t* __restrict__ span_arr,
     const uint8_t* __restrict__ bin_arr, int my_bin, int32_t* __restrict__ out_inner,
     T* __restrict__ out_val, int32_t* __restrict__ count, double alpha, double beta, double threshold,
-    double* __restrict__ dot_partial, int nblocks, double* __restrict__ trace_partial, int col_offset) {
+    double* __restrict__ dot_partial, int nblocks, double* __restrict__ trace_partial, int col_offset,
+    const int64_t* __restrict__ dstoff) {
   __shared__ T wa_all[NW * W];
   __shared__ T wb_all[NW * W];
   __shared__ T wd_all[DOT ? NW * W : 1];
@@ -1476,7 +1691,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
     const T* __restrict__ Av = static_cast<const T*>(A.val);
     const T* __restrict__ Bv = static_cast<const T*>(B.val);
     const T* __restrict__ Dv = static_cast<const T*>(D.val);
-    const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = B.outer[j + 1];
+    const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = col_end(B, j);
     const int64_t ds = DOT ? D.outer[j] : 0, de = DOT ? D.outer[j + 1] : 0;
     // All operand loads of the column are requested up front (CH chunks of 64 entries per operand, reading past
     // the column end is harmless: DevMat keeps kIndexSlack entries of slack), so the column costs one memory
@@ -1543,7 +1758,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_inc_window(
       }
       __builtin_amdgcn_wave_barrier();
     }
-    const int64_t base = as + bs;  // upper-bound slot: every column may keep all of A and B
+    const int64_t base = dstoff[j];  // upper-bound slot: every column may keep all of A and B
     int cnt = 0;
     for (int s0 = 0; s0 < span; s0 += WAVE) {
       const int s = s0 + lane;
@@ -1618,7 +1833,8 @@ template <typename T, bool DOT>
 __global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
     Csc A, Csc B, Csc D, const uint8_t* __restrict__ bin_arr, int my_bin, int32_t* __restrict__ out_inner,
     T* __restrict__ out_val, int32_t* __restrict__ count, double alpha, double beta, double threshold,
-    double* __restrict__ dot_partial, int nblocks, double* __restrict__ trace_partial, int col_offset, int row_block) {
+    double* __restrict__ dot_partial, int nblocks, double* __restrict__ trace_partial, int col_offset, int row_block,
+    const int64_t* __restrict__ dstoff) {
   // row_block > 0: the AddSparseVectors rule is applied per segment of `row_block` rows (the reference adds the
   // matrices block by block, so "the other column is exhausted" is decided inside each row block)
   constexpr int NW = 4, NWORD = INC_MERGE_CAP / 64, DCAP = DOT ? 1024 : 1;   // (longer columns of D are searched in memory)
@@ -1636,7 +1852,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
     const T* __restrict__ Av = static_cast<const T*>(A.val);
     const T* __restrict__ Bv = static_cast<const T*>(B.val);
     const T* __restrict__ Dv = static_cast<const T*>(D.val);
-    const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = B.outer[j + 1];
+    const int64_t as = A.outer[j], ae = col_end(A, j), bs = B.outer[j], be = col_end(B, j);
     const int na = (int)(ae - as), nb = (int)(be - bs);
     int* ra = rows_all[wave];
     int* rb = ra + na;
@@ -1653,7 +1869,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
     if (lane < NWORD) bits[lane] = 0ull;
     __builtin_amdgcn_wave_barrier();
     const int amax = na ? ra[na - 1] : -1, bmax = nb ? rb[nb - 1] : -1;
-    const int64_t base = as + bs;
+    const int64_t base = dstoff[j];
     // last row of list `l` inside the row block of r (or -1): the largest entry below the block's end, if it is in the block
     auto last_in_block = [&](const int* l, int n, int r) -> int {
       const int e = (r / row_block + 1) * row_block;
@@ -1801,15 +2017,16 @@ __global__ __launch_bounds__(4 * WAVE) void k_inc_merge(
 template <typename T>
 __global__ void k_inc_seq(Csc A, Csc B, const uint8_t* __restrict__ bin_arr, int my_bin,
                           int32_t* __restrict__ out_inner, T* __restrict__ out_val,
-                          int32_t* __restrict__ count, double alpha, double beta, double threshold, int row_block) {
+                          int32_t* __restrict__ count, double alpha, double beta, double threshold, int row_block,
+                          const int64_t* __restrict__ dstoff) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.cols) return;
   if (bin_arr[j] != my_bin) return;
   const T* __restrict__ Av = static_cast<const T*>(A.val);
   const T* __restrict__ Bv = static_cast<const T*>(B.val);
   int64_t aa = A.outer[j], bb = B.outer[j];
-  const int64_t ea_all = col_end(A, j), eb_all = B.outer[j + 1];
-  int64_t cc = aa + bb;
+  const int64_t ea_all = col_end(A, j), eb_all = col_end(B, j);
+  int64_t cc = dstoff[j];
   const int64_t c0 = cc;
   // (row_block > 0: the merge runs row block by row block, as the reference adds block by block)
   for (int seg_end = row_block > 0 ? row_block : INT_MAX; aa < ea_all || bb < eb_all;
@@ -1849,6 +2066,15 @@ __global__ void k_sum_outer(const int64_t* __restrict__ a, const int64_t* __rest
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j <= n) out[j] = a[j] + b[j];
 }
+__global__ void k_pick2_i64(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t* __restrict__ out) {
+  out[0] = a[0];
+  out[1] = b ? b[0] : 0;
+}
+// entries of column j of A plus those of column j of B (either may be loose): the tight output slots of a merge
+__global__ void k_sum_counts(Csc A, Csc B, int32_t* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < A.cols) out[j] = (int32_t)(col_end(A, j) - A.outer[j]) + (int32_t)(col_end(B, j) - B.outer[j]);
+}
 
 // ------------------------------------------------------------------ dot / pairwise / trace / norms
 // sum_j sum_i conj(A_ij) B_ij.  One wave per column: lanes stride over A's column and find the
@@ -1880,7 +2106,7 @@ __global__ __launch_bounds__(256) void k_dot(Csc A, Csc B, double* __restrict__ 
     }
   };
   for (int j = b * 4 + wave; j < A.cols; j += nblocks * 4) {
-    const int64_t bs = B.outer[j], be = B.outer[j + 1], as = A.outer[j], ae = A.outer[j + 1];
+    const int64_t bs = B.outer[j], be = B.outer[j + 1], as = A.outer[j], ae = col_end(A, j);
     if (ae == as || (be == bs && !trace_partial)) continue;
     int ai[CH], bi[CH];
     T av[CH], bv[CH];
@@ -2028,7 +2254,7 @@ __global__ __launch_bounds__(256) void k_trace(Csc A, int col_offset, double* __
   double x = 0;
   for (int j = blockIdx.x * 256 + threadIdx.x; j < A.cols; j += gridDim.x * 256) {
     const int r = j + col_offset;
-    int64_t l = A.outer[j], h = A.outer[j + 1];
+    int64_t l = A.outer[j], h = col_end(A, j);
     const int64_t e = h;
     while (l < h) {
       const int64_t mid = (l + h) >> 1;
@@ -2334,6 +2560,77 @@ struct EventTimer {
 };
 }  // namespace
 
+namespace {
+// counts the operations that change the values of a matrix in place (scale, conjugate, scale_columns): part of the key
+// of the cache below, together with the serial number of the value buffer's allocation
+unsigned long long& value_epoch() {
+  static unsigned long long e = 0;
+  return e;
+}
+// D of a fused purification step (SlabFusion), expanded once: dexp[doff[j] + (r - dmin[j])] = D(r, j), zero in the holes
+struct DotOperand {
+  const void* val = nullptr;
+  unsigned long long serial = 0, epoch = 0;
+  int64_t nnz = -1;
+  int32_t cols = 0;
+  DevBuf<int32_t> dmin, dmax;
+  DevBuf<int64_t> doff;
+  DevBuf<double> dexp;
+  int64_t max_tile = 0;   // largest sum of the spans of 16 consecutive columns (the kernel keeps that tile in LDS)
+};
+// stored values that are exactly zero (real matrices; columns may be loose): one wave per column
+__global__ __launch_bounds__(256) void k_count_zero_values(Csc A, unsigned long long* __restrict__ out) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= A.cols) return;
+  const int lane = lane_id();
+  const double* __restrict__ v = static_cast<const double*>(A.val);
+  int c = 0;
+  for (int64_t p = A.outer[j] + lane, e = col_end(A, j); p < e; p += WAVE) c += v[p] == 0.0 ? 1 : 0;
+  const unsigned long long m = __ballot(c != 0);
+  if (m && lane == 0) atomicAdd(out, 1ull);
+}
+__global__ void k_span_block_max(const int32_t* __restrict__ span, int n, int J, unsigned long long* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b * J >= n) return;
+  unsigned long long t = 0;
+  for (int j = b * J; j < min(n, (b + 1) * J); ++j) t += (unsigned long long)span[j];
+  atomicMax(out, t);
+}
+const DotOperand& dot_operand(const DevMat& D) {
+  static DotOperand* c = new DotOperand();
+  const unsigned long long ser = dev_alloc_serial(D.val.p);
+  if (c->val == D.val.p && c->serial == ser && ser != 0 && c->epoch == value_epoch() && c->nnz == D.nnz && c->cols == D.cols)
+    return *c;
+  const int n = D.cols;
+  c->dmin.alloc((size_t)n); c->dmax.alloc((size_t)n); c->doff.alloc((size_t)n + 1);
+  DevBuf<int32_t> dlen((size_t)n), dspan((size_t)n);
+  hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(D), c->dmin.p, c->dmax.p, dlen.p);
+  hipLaunchKernelGGL(k_span_of, dim3(cdiv(n, 256)), dim3(256), 0, stream(), c->dmin.p, c->dmax.p, dspan.p, n);
+  scan_async<int32_t>(dspan.p, c->doff.p, (int64_t)n);
+  DevBuf<unsigned long long> tmax(1);
+  tmax.zero();
+  hipLaunchKernelGGL(k_span_block_max, dim3(cdiv(cdiv(n, SLAB_J), 256)), dim3(256), 0, stream(), dspan.p, n, SLAB_J, tmax.p);
+  int64_t total = 0;
+  unsigned long long hmax = 0;
+  {
+    ScalarFetch f;
+    f.add(c->doff.p + n, 1, &total);
+    f.add(tmax.p, 1, &hmax);
+    f.run();
+  }
+  c->max_tile = (int64_t)hmax;
+  c->dexp.alloc((size_t)total + 1);
+  hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(D), c->dmin.p,
+                     c->doff.p, c->dexp.p);
+  c->val = D.val.p;
+  c->serial = ser;
+  c->epoch = value_epoch();
+  c->nnz = D.nnz;
+  c->cols = n;
+  return *c;
+}
+}  // namespace
+
 void flush_spgemm_timers() {
   auto& pend = pending_timings();
   if (pend.empty()) return;
@@ -2378,8 +2675,9 @@ void launch_window(int bin, const DevMat& A, const DevMat& B, const int32_t* lo,
 }  // namespace
 
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule,
-            LooseProduct* loose, const ColRange* arange) {
+            LooseProduct* loose, const ColRange* arange, SlabFusion* fuse) {
   if (loose) loose->valid = false;
+  if (fuse) fuse->done = false;
   if (A.cols != B.rows) NTP_FATAL("spgemm: inner dimensions differ");
   if (A.cplx != B.cplx) NTP_FATAL("spgemm: mixed scalar types must be up-cast by the caller");
   const int32_t m = A.rows, n = B.cols;
@@ -2402,8 +2700,12 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<int32_t> cmin_own((size_t)nka), cmax_own((size_t)nka), clen_own((size_t)nka);
   struct Biased { int32_t* p; };
   const Biased cmin{cmin_own.p - ka}, cmax{cmax_own.p - ka}, clen{clen_own.p - ka};
-  Csc Ar = view(A);
+  // loose operands (an iterate left in its merge slots): the register-slab path of X * X reads them as they are,
+  // every other path gets packed copies
+  const bool loose_in = A.loose() || B.loose();
+  Csc Ar = lview(A);
   Ar.outer += ka;
+  if (Ar.cnt) Ar.cnt += ka;
   Ar.cols = nka;
   if (nka) hipLaunchKernelGGL(k_col_extent, dim3(cdiv(nka, 256)), dim3(256), 0, stream(), Ar, cmin_own.p, cmax_own.p, clen_own.p);
   DevBuf<int32_t> lo, span, count(n);
@@ -2433,7 +2735,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   static int grouped_first_n[2] = {-1, -1};
   bool grouped_done = false;
   const int dr = dense_rule ? 1 : 0;
-  if (grouped_first_n[A.cplx ? 1 : 0] == n && sv_opt < 0 && options().spgemm_force_bin <= 0 && m == A.cols && (int64_t)n * 1536 < (1ll << 33)) {
+  if (!loose_in && grouped_first_n[A.cplx ? 1 : 0] == n && sv_opt < 0 && options().spgemm_force_bin <= 0 && m == A.cols && (int64_t)n * 1536 < (1ll << 33)) {
     constexpr int64_t kSlot = 1536;   // rows of the largest table class: no column of a finished group holds more
     tmp_total = (int64_t)n * kSlot;
     tmp_inner.alloc((size_t)tmp_total + kIndexSlack);
@@ -2476,7 +2778,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     const int32_t *bfirst = cmin.p, *blast = cmax.p;
     if (&A != &B) {
       bfirst_own.alloc(n); blast_own.alloc(n); blen_own.alloc(n);
-      hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(B), bfirst_own.p, blast_own.p, blen_own.p);
+      hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), lview(B), bfirst_own.p, blast_own.p, blen_own.p);
       bfirst = bfirst_own.p; blast = blast_own.p;
     }
     aspan.alloc((size_t)nka); aeoff.alloc((size_t)nka + 1);   // local ids 0 .. nka (column ka + id)
@@ -2506,6 +2808,20 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
                             (double)slab_tot[0] >= 48.0 * (double)hstats[18];  // mean run of the non-empty columns >= 48 rows
     use_slab = fits && (dense_runs || sv_opt / 100 == 4);
+  }
+  if (loose_in && !(use_slab && &A == &B)) {
+    if (timing) {
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+    }
+    DevMat Ap = packed_copy(A);
+    if (&A == &B) {
+      spgemm(Ap, Ap, C, alpha, threshold, dense_rule, loose, arange, nullptr);
+    } else {
+      DevMat Bp = packed_copy(B);
+      spgemm(Ap, Bp, C, alpha, threshold, dense_rule, loose, arange, nullptr);
+    }
+    return;
   }
   st.slab = use_slab ? 1 : 0;
   if (use_slab) {
@@ -2543,6 +2859,10 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<int64_t> tmpoff2;
   DevBuf<double> aexp, bblk;
   DevBuf<int64_t> blk_prod, blk_prod_scan;
+  DevBuf<double> fz_part;
+  DevBuf<int64_t> fz_pnnz, fz_flag;
+  DevBuf<char> fz_args;
+  bool fuse_now = false;
   if (use_slab) {
     blk_prod.alloc(snb); blk_prod.zero(); blk_prod_scan.alloc((size_t)snb + 1);
     aexp.alloc(((size_t)slab_tot[0] + 1) * A.wval());
@@ -2569,14 +2889,14 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
         hipLaunchKernelGGL(k_slab_expand_a<double2>, dim3(cdiv((int64_t)nka * WAVE, 256)), dim3(256), 0, stream(),
                            Ar, cmin_own.p, aeoff.p, ae);
       hipLaunchKernelGGL((k_slab_expand_b<double2, SLAB_CJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * esz,
-                         stream(), view(B), blk_kmin.p, blk_kn.p, blk_boff.p, reinterpret_cast<double2*>(bblk.p), snb, pitch,
+                         stream(), lview(B), blk_kmin.p, blk_kn.p, blk_boff.p, reinterpret_cast<double2*>(bblk.p), snb, pitch,
                          same ? 1 : 0, aeoff.p, ae, clen_opt, blk_prod.p);
     } else {
       if (!same)
         hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)nka * WAVE, 256)), dim3(256), 0, stream(),
                            Ar, cmin_own.p, aeoff.p, aexp.p);
       hipLaunchKernelGGL((k_slab_expand_b<double, SLAB_J>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * esz,
-                         stream(), view(B), blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p,
+                         stream(), lview(B), blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p,
                          aexp.p, clen_opt, blk_prod.p);
     }
     scan_async<int64_t>(blk_prod.p, blk_prod_scan.p, (int64_t)snb);  // total = products of this multiply
@@ -2601,7 +2921,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, SLAB_NW, decltype(fma_tag)::value>), dim3(xcd_grid(snb)),
                          dim3(SLAB_NW * WAVE), occ_lds, stream(), reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p,
                          blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha,
-                         threshold, dr, n, snb);
+                         threshold, dr, n, snb, (const SlabFuseArgs*)nullptr);
     };
     const int abl = (sv_opt / 100 == 4) ? sv_opt % 100 : 0;  // 401..403: ablations for timing experiments
     // narrow windows: one / two slabs per wave (more resident waves); 410 keeps three slabs for comparison
@@ -2612,14 +2932,59 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                          reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
                          blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
     };
-    if (max_w_now > 6 * SLAB_SL * WAVE)         // 1153 .. 1536 rows: eight waves per workgroup
+    // fused epilogue of a purification step (SlabFusion): the same loop, the result leaves the registers merged
+    fuse_now = fuse != nullptr && fuse->mode != 0 && &A == &B && !arange && m == n && abl == 0 && !options().spgemm_fma &&
+               sv_opt < 0 && fuse->D && !fuse->D->cplx && !fuse->D->loose() && fuse->D->rows == m && fuse->D->cols == n;
+    if (fuse_now && fuse->mode == 2 && A.zero_free != 1) {
+      // the merge reads a zero of the expanded columns of X as "no entry": make sure no stored value is one (once per
+      // solve: the results of the fused steps are zero-free by construction)
+      DevBuf<unsigned long long> zc(1);
+      zc.zero();
+      hipLaunchKernelGGL(k_count_zero_values, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), lview(A), zc.p);
+      unsigned long long hz = 0;
+      ScalarFetch f;
+      f.add(zc.p, 1, &hz);
+      f.run();
+      if (hz == 0) A.zero_free = 1;
+      else fuse_now = false;
+    }
+    const DotOperand* dop_p = fuse_now ? &dot_operand(*fuse->D) : nullptr;
+    if (fuse_now && dop_p->max_tile > SLAB_DTILE) fuse_now = false;   // (D columns too wide for the LDS tile)
+    if (fuse_now) {
+      const DotOperand& dop = *dop_p;
+      fz_part.alloc((size_t)2 * snb); fz_part.zero();
+      fz_pnnz.alloc((size_t)snb + 1); fz_pnnz.zero();
+      fz_flag.alloc(2); fz_flag.zero();
+      SlabFuseArgs fz;
+      fz.am = fuse->am; fz.bm = fuse->bm; fz.thr_m = fuse->threshold;
+      fz.xexp = aexp.p; fz.xoff = aeoff.p; fz.xmin = cmin_own.p; fz.xmax = cmax_own.p;
+      fz.dexp = dop.dexp.p; fz.doff = dop.doff.p; fz.dmin = dop.dmin.p; fz.dmax = dop.dmax.p;
+      fz.part = fz_part.p; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz.p); fz.flag = reinterpret_cast<int*>(fz_flag.p);
+      fz.col_offset = fuse->col_offset;
+      fz_args.alloc(sizeof(SlabFuseArgs));
+      fz_args.upload(reinterpret_cast<const char*>(&fz), sizeof(SlabFuseArgs));
+      auto launch_fused = [&](auto nw_tag, auto mode_tag, auto epi_tag) {
+        constexpr int FNW = decltype(nw_tag)::value;
+        hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, FNW, decltype(mode_tag)::value, decltype(epi_tag)::value>),
+                           dim3(xcd_grid(snb)), dim3(FNW * WAVE), 0, stream(), reinterpret_cast<const SlabRun*>(runs.p) - ka,
+                           bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p,
+                           count.p, alpha, threshold, dr, n, snb, reinterpret_cast<const SlabFuseArgs*>(fz_args.p));
+      };
+      auto by_mode = [&](auto nw_tag, auto mode_tag) {
+        if (fuse->mode == 1) launch_fused(nw_tag, mode_tag, std::integral_constant<int, 1>{});
+        else launch_fused(nw_tag, mode_tag, std::integral_constant<int, 2>{});
+      };
+      if (max_w_now > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
+      else if (max_w_now > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
+      else by_mode(std::integral_constant<int, SLAB_NW>{}, std::integral_constant<int, 8>{});
+    } else if (max_w_now > 6 * SLAB_SL * WAVE)         // 1153 .. 1536 rows: eight waves per workgroup
       hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, 8, 0>), dim3(xcd_grid(snb)), dim3(8 * WAVE), 0, stream(),
                          reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
-                         blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
+                         blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb, (const SlabFuseArgs*)nullptr);
     else if (max_w_now > SLAB_NW * SLAB_SL * WAVE)   // 769 .. 1152 rows: six waves per workgroup
       hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, 6, 0>), dim3(xcd_grid(snb)), dim3(6 * WAVE), 0, stream(),
                          reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
-                         blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
+                         blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb, (const SlabFuseArgs*)nullptr);
     else if (abl == 0 && !options().spgemm_fma && sv_opt != 410 && max_w_now <= SLAB_NW * WAVE) launch_narrow(std::integral_constant<int, 1>{});
     else if (abl == 0 && !options().spgemm_fma && sv_opt != 410 && max_w_now <= 2 * SLAB_NW * WAVE) launch_narrow(std::integral_constant<int, 2>{});
     else if (abl == 1) launch_slab(std::integral_constant<int, 2>{});
@@ -2751,6 +3116,64 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   }
   t_num.stop();
 
+  if (fuse_now) {
+    // one read-back: entries of the result, (dot, trace), the kernel's objections, the product's own entry count
+    DevBuf<double> res(2);
+    reduce_sum2_async(fz_part.p, snb, res.p);
+    DevBuf<int64_t> total((size_t)n + 1), ptot((size_t)snb + 2);
+    scan_async<int32_t>(count.p, total.p, (int64_t)n);
+    scan_async<int64_t>(fz_pnnz.p, ptot.p, (int64_t)snb);
+    int64_t nnz = 0, flagv[2] = {0, 0}, pnz = 0;
+    unsigned long long slab_products = 0;
+    double hd[2] = {0, 0};
+    {
+      ScalarFetch f;
+      f.add(total.p + n, 1, &nnz);
+      f.add(res.p, 2, hd);
+      f.add(fz_flag.p, 1, flagv);
+      f.add(ptot.p + snb, 1, &pnz);
+      f.add(blk_prod_scan.p + snb, 1, &slab_products);
+      f.run();
+    }
+    t_all.stop();
+    if (timing) {
+      if (pending_timings().size() >= 4096) flush_spgemm_timers();
+      pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+    }
+    if ((int32_t)flagv[0] != 0) {   // (see SlabFuseArgs) the step is repeated without the fusion
+      fuse->done = false;
+      fuse->refused += 1;
+      spgemm(A, B, C, alpha, threshold, dense_rule, loose, arange, nullptr);
+      return;
+    }
+    DevMat R;
+    R.rows = m;
+    R.cols = n;
+    R.cplx = false;
+    R.nnz = nnz;
+    R.slots = tmp_total;
+    R.zero_free = 1;   // kept entries passed |v| > threshold (> = 0) or are scaled copies of entries that did
+    R.outer = std::move(tmpoff);
+    R.cnt = std::move(count);
+    R.inner = std::move(tmp_inner);
+    R.val = std::move(tmp_val);
+    fuse->result = std::move(R);
+    fuse->done = true;
+    fuse->dot = hd[0];
+    fuse->trace = hd[1];
+    fuse->product_nnz = pnz;
+    st.products = (int64_t)slab_products;
+    st.nnz_c = pnz;
+    st.fused = fuse->mode;
+    last_spgemm_stats() = st;
+    SpgemmAccum& acc = spgemm_accum();
+    acc.calls += 1;
+    acc.products += st.products;
+    acc.nnz_c += pnz;
+    acc.alg_bytes += 12.0 * (double)(A.nnz + B.nnz + pnz) + 4.0 * ((double)A.cols + B.cols + n + 3);
+    return;
+  }
+
   if (loose && use_slab) {
     // hand the slots over as they are: the consumer (axpby) reads the columns in place and reports the exact nnz
     loose->valid = true;
@@ -2837,7 +3260,10 @@ struct MergeOperand {
 };
 void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D,
                 double* dot_out, double* trace_out, int32_t trace_col_offset, int64_t* a_nnz_out,
-                const int64_t* d_extra = nullptr, int64_t* extra_out = nullptr, int row_block = 0) {
+                const int64_t* d_extra = nullptr, int64_t* extra_out = nullptr, int row_block = 0,
+                bool keep_loose = false) {
+  // B may be loose.  keep_loose: the result stays in the (tight) slots the merge kernels wrote it to -- no compaction
+  // pass; B is a loose matrix on return
   if (A.rows != B.rows || A.cols != B.cols) NTP_FATAL("increment: shape mismatch");
   if (A.cplx != B.cplx) NTP_FATAL("increment: mixed scalar types must be up-cast by the caller");
   if (D && (D->rows != A.rows || D->cols != A.cols || D->cplx != A.cplx)) NTP_FATAL("increment: dot operand mismatch");
@@ -2849,7 +3275,8 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
   DevBuf<int32_t> lo(n), span(n), count(n);
   DevBuf<uint8_t> bin(n);
   DevBuf<unsigned long long> stats(16);
-  hipLaunchKernelGGL(k_inc_plan, dim3(cdiv(n, 256)), dim3(256), 0, stream(), A.v, view(B), lo.p, span.p, bin.p,
+  const Csc Bv = lview(B);
+  hipLaunchKernelGGL(k_inc_plan, dim3(cdiv(n, 256)), dim3(256), 0, stream(), A.v, Bv, lo.p, span.p, bin.p,
                      stats.p, count.p, row_block > 0 ? 2 : options().increment_force_seq);   // (blocked rule: rank / sequential merge)
   hipLaunchKernelGGL(k_bin_hist, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, stream(), bin.p, (const int64_t*)nullptr,
                      (const int32_t*)nullptr, n, stats.p);
@@ -2861,12 +3288,20 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
   }
   // output slot of column j = A.outer[j] + B.outer[j] (room for all of both columns; for a loose A the slots are
   // simply further apart)
+  // (with a loose B or a result that stays loose the slots are placed by the actual column lengths: they would
+  // otherwise move further apart with every step)
   const int64_t cap = A.slots + B.nnz;
   const size_t wv = A.cplx ? 2 : 1;
-  DevBuf<int32_t> tmp_inner((size_t)cap);
-  DevBuf<double> tmp_val((size_t)cap * wv);
+  DevBuf<int32_t> tmp_inner((size_t)cap + kIndexSlack);
+  DevBuf<double> tmp_val(((size_t)cap + kIndexSlack) * wv);
   DevBuf<int64_t> srcoff((size_t)n + 1);
-  hipLaunchKernelGGL(k_sum_outer, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), A.v.outer, B.outer.p, srcoff.p, n);
+  if (keep_loose || B.loose()) {
+    DevBuf<int32_t> both((size_t)n);
+    hipLaunchKernelGGL(k_sum_counts, dim3(cdiv(n, 256)), dim3(256), 0, stream(), A.v, Bv, both.p);
+    scan_async<int32_t>(both.p, srcoff.p, (int64_t)n);
+  } else {
+    hipLaunchKernelGGL(k_sum_outer, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), A.v.outer, B.outer.p, srcoff.p, n);
+  }
   DevBuf<int64_t> a_total;  // exact nnz of a loose first operand
   if (A.loose) {
     a_total.alloc((size_t)n + 1);
@@ -2892,31 +3327,31 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
     const Csc dv = D ? view(*D) : A.v;
     if (hs[1]) {
       if (fuse_dot)
-        hipLaunchKernelGGL((k_inc_window<T, 512, 4, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv,
-                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, part1.p, nb1, tpart1.p, trace_col_offset);
+        hipLaunchKernelGGL((k_inc_window<T, 512, 4, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, Bv, dv,
+                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, part1.p, nb1, tpart1.p, trace_col_offset, srcoff.p);
       else
-        hipLaunchKernelGGL((k_inc_window<T, 512, 4, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv,
-                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1, (double*)nullptr, 0);
+        hipLaunchKernelGGL((k_inc_window<T, 512, 4, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, Bv, dv,
+                           lo.p, span.p, bin.p, 1, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1, (double*)nullptr, 0, srcoff.p);
     }
     if (hs[2]) {
       if (fuse_dot)
-        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, true>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), A.v, view(B), dv,
-                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, part2.p, nb2, tpart2.p, trace_col_offset);
+        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, true>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), A.v, Bv, dv,
+                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, part2.p, nb2, tpart2.p, trace_col_offset, srcoff.p);
       else
-        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, false>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), A.v, view(B), dv,
-                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb2, (double*)nullptr, 0);
+        hipLaunchKernelGGL((k_inc_window<T, 2048, 1, false>), dim3(xcd_grid(nb2)), dim3(WAVE), 0, stream(), A.v, Bv, dv,
+                           lo.p, span.p, bin.p, 2, tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb2, (double*)nullptr, 0, srcoff.p);
     }
     if (hs[3]) {
       if (fuse_dot)
-        hipLaunchKernelGGL((k_inc_merge<T, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv, bin.p, 3,
-                           tmp_inner.p, tv, count.p, alpha, beta, threshold, part3.p, nb1, tpart3.p, trace_col_offset, row_block);
+        hipLaunchKernelGGL((k_inc_merge<T, true>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, Bv, dv, bin.p, 3,
+                           tmp_inner.p, tv, count.p, alpha, beta, threshold, part3.p, nb1, tpart3.p, trace_col_offset, row_block, srcoff.p);
       else
-        hipLaunchKernelGGL((k_inc_merge<T, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, view(B), dv, bin.p, 3,
-                           tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1, (double*)nullptr, 0, row_block);
+        hipLaunchKernelGGL((k_inc_merge<T, false>), dim3(xcd_grid(nb1)), dim3(256), 0, stream(), A.v, Bv, dv, bin.p, 3,
+                           tmp_inner.p, tv, count.p, alpha, beta, threshold, (double*)nullptr, nb1, (double*)nullptr, 0, row_block, srcoff.p);
     }
     if (hs[4]) {
-      hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), A.v, view(B), bin.p, 4,
-                         tmp_inner.p, tv, count.p, alpha, beta, threshold, row_block);
+      hipLaunchKernelGGL((k_inc_seq<T>), dim3(cdiv(n, 64)), dim3(64), 0, stream(), A.v, Bv, bin.p, 4,
+                         tmp_inner.p, tv, count.p, alpha, beta, threshold, row_block, srcoff.p);
     }
   });
   DevBuf<double> dres;
@@ -2948,15 +3383,23 @@ void axpby_impl(const MergeOperand& A, DevMat& B, double alpha, double beta, dou
     if (A.loose && a_nnz_out) *a_nnz_out = a_nnz;
   }
   R.nnz = nnz;
-  R.inner.alloc((size_t)nnz + kIndexSlack);
-  R.val.alloc(((size_t)nnz + kIndexSlack) * R.wval());
-  const int nblocks = cdiv(n, 4);
-  dispatch_type(A.cplx, [&](auto tag) {
-    using T = decltype(tag);
-    hipLaunchKernelGGL((k_compact<T>), dim3(xcd_grid(nblocks)), dim3(256), 0, stream(), n, srcoff.p, nullptr, nullptr,
-                       R.outer.p, tmp_inner.p, reinterpret_cast<const T*>(tmp_val.p), nullptr, nullptr, R.inner.p,
-                       reinterpret_cast<T*>(R.val.p), nblocks);
-  });
+  if (keep_loose) {
+    R.outer = std::move(srcoff);
+    R.cnt = std::move(count);
+    R.inner = std::move(tmp_inner);
+    R.val = std::move(tmp_val);
+    R.slots = cap;
+  } else {
+    R.inner.alloc((size_t)nnz + kIndexSlack);
+    R.val.alloc(((size_t)nnz + kIndexSlack) * R.wval());
+    const int nblocks = cdiv(n, 4);
+    dispatch_type(A.cplx, [&](auto tag) {
+      using T = decltype(tag);
+      hipLaunchKernelGGL((k_compact<T>), dim3(xcd_grid(nblocks)), dim3(256), 0, stream(), n, srcoff.p, nullptr, nullptr,
+                         R.outer.p, tmp_inner.p, reinterpret_cast<const T*>(tmp_val.p), nullptr, nullptr, R.inner.p,
+                         reinterpret_cast<T*>(R.val.p), nblocks);
+    });
+  }
   B = std::move(R);
   if (dot_out && D) {
     if (fuse_dot) {
@@ -2982,15 +3425,109 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
   axpby_impl(a, B, alpha, beta, threshold, D, dot_out, trace_out, trace_col_offset, nullptr);
 }
 
+namespace {
+void dot_trace_impl(const DevMat& A, const DevMat& B, double out[2], double* trace_out, int32_t col_offset,
+                    const int64_t* d_extra, int n_extra, int64_t* extra_out);
+}
+DevMat packed_copy(const DevMat& M) {
+  if (!M.loose()) return M.clone();
+  DevMat R;
+  R.rows = M.rows;
+  R.cols = M.cols;
+  R.cplx = M.cplx;
+  R.zero_free = M.zero_free;
+  const int n = M.cols;
+  R.outer.alloc((size_t)n + 1);
+  scan_async<int32_t>(M.cnt.p, R.outer.p, (int64_t)n);
+  int64_t nnz = 0;
+  {
+    ScalarFetch f;
+    f.add(R.outer.p + n, 1, &nnz);
+    f.run();
+  }
+  R.nnz = nnz;
+  R.inner.alloc((size_t)nnz + kIndexSlack);
+  R.val.alloc(((size_t)nnz + kIndexSlack) * R.wval());
+  const int nblocks = cdiv(n, 4);
+  if (n)
+    dispatch_type(M.cplx, [&](auto tag) {
+      using T = decltype(tag);
+      hipLaunchKernelGGL((k_compact<T>), dim3(xcd_grid(nblocks)), dim3(256), 0, stream(), n, M.outer.p, nullptr, nullptr,
+                         R.outer.p, M.inner.p, reinterpret_cast<const T*>(M.val.p), nullptr, nullptr, R.inner.p,
+                         reinterpret_cast<T*>(R.val.p), nblocks);
+    });
+  return R;
+}
+
+void pack(DevMat& M) {
+  if (M.loose()) M = packed_copy(M);
+}
+
+bool square_keep_loose(DevMat& X, double threshold, bool dense_rule, const DevMat& D, double out[2], double* trace_out,
+                       int32_t col_offset) {
+  if (X.cplx || D.cplx || X.rows != X.cols) return false;
+  LooseProduct L;
+  DevMat AB;
+  SlabFusion fu;
+  fu.mode = options().fused_update ? 1 : 0;
+  fu.D = &D;
+  fu.col_offset = col_offset;
+  spgemm(X, X, AB, 1.0, threshold, dense_rule, &L, nullptr, fu.mode ? &fu : nullptr);
+  if (fu.done) {  // dot and trace came out of the multiply's epilogue
+    X = std::move(fu.result);
+    out[0] = fu.dot;
+    out[1] = 0.0;
+    if (trace_out) *trace_out = fu.trace;
+    return true;
+  }
+  if (!L.valid) {  // another kernel computed it (packed)
+    X = std::move(AB);
+    dot_trace(X, D, out, trace_out, col_offset);
+    return true;
+  }
+  const int n = L.cols;
+  DevBuf<int64_t> total((size_t)n + 1);
+  scan_async<int32_t>(L.count.p, total.p, (int64_t)n);
+  DevMat R;
+  R.rows = L.rows;
+  R.cols = n;
+  R.cplx = false;
+  R.slots = L.slots;
+  R.nnz = L.slots;  // (not known yet; non-zero keeps the reduction from returning early)
+  R.outer = std::move(L.start);
+  R.cnt = std::move(L.count);
+  R.inner = std::move(L.inner);
+  R.val = std::move(L.val);
+  int64_t extra[2] = {-1, 0};
+  DevBuf<int64_t> ex(2);
+  hipLaunchKernelGGL(k_pick2_i64, dim3(1), dim3(1), 0, stream(), total.p + n,
+                     L.prod_index >= 0 ? L.prod_scan.p + L.prod_index : (const int64_t*)nullptr, ex.p);
+  dot_trace_impl(R, D, out, trace_out, col_offset, ex.p, 2, extra);
+  if (extra[0] < 0) {
+    ScalarFetch f;
+    f.add(ex.p, 2, extra);
+    f.run();
+  }
+  R.nnz = extra[0];
+  X = std::move(R);
+  SpgemmAccum& acc = spgemm_accum();
+  acc.nnz_c += extra[0];
+  acc.alg_bytes += 12.0 * (double)extra[0];
+  acc.products += extra[1];
+  last_spgemm_stats().nnz_c = extra[0];
+  last_spgemm_stats().products = extra[1];
+  return true;
+}
+
 void axpby(const LooseProduct& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
-           double* trace_out, int32_t trace_col_offset, int64_t* a_nnz_out) {
+           double* trace_out, int32_t trace_col_offset, int64_t* a_nnz_out, bool keep_loose) {
   if (!A.valid) NTP_FATAL("axpby: invalid loose product");
   Csc v{A.rows, A.cols, A.start.p, A.inner.p, A.val.p};
   v.cnt = A.count.p;
   const MergeOperand a{v, A.rows, A.cols, false, A.slots, true};
   int64_t a_nnz = 0, products = 0;
   axpby_impl(a, B, alpha, beta, threshold, D, dot_out, trace_out, trace_col_offset, &a_nnz,
-             A.prod_index >= 0 ? A.prod_scan.p + A.prod_index : nullptr, &products);
+             A.prod_index >= 0 ? A.prod_scan.p + A.prod_index : nullptr, &products, 0, keep_loose);
   if (a_nnz_out) *a_nnz_out = a_nnz;
   // the multiply that produced A could not account for its output: do it now
   SpgemmAccum& acc = spgemm_accum();
@@ -3041,6 +3578,12 @@ void finish_sum2(DevBuf<double>& partial, int nb, double out[2]) {
 void dot(const DevMat& A, const DevMat& B, double out[2]) { dot_trace(A, B, out, nullptr, 0); }
 
 void dot_trace(const DevMat& A, const DevMat& B, double out[2], double* trace_out, int32_t col_offset) {
+  dot_trace_impl(A, B, out, trace_out, col_offset, nullptr, 0, nullptr);
+}
+namespace {
+// A may be loose.  d_extra: device scalars fetched with the result (one read-back for everything)
+void dot_trace_impl(const DevMat& A, const DevMat& B, double out[2], double* trace_out, int32_t col_offset,
+                    const int64_t* d_extra, int n_extra, int64_t* extra_out) {
   if (A.rows != B.rows || A.cols != B.cols || A.cplx != B.cplx) NTP_FATAL("dot: operand mismatch");
   out[0] = out[1] = 0;
   if (trace_out) *trace_out = 0.0;
@@ -3054,7 +3597,7 @@ void dot_trace(const DevMat& A, const DevMat& B, double out[2], double* trace_ou
   if (trace_out) tpartial.alloc((size_t)2 * nb);
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(256), 0, stream(), view(A), view(B), partial.p, nb,
+    hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(256), 0, stream(), lview(A), view(B), partial.p, nb,
                        trace_out ? tpartial.p : (double*)nullptr, col_offset);
   });
   DevBuf<double> res(4);
@@ -3063,11 +3606,13 @@ void dot_trace(const DevMat& A, const DevMat& B, double out[2], double* trace_ou
   double h[4] = {0, 0, 0, 0};
   ScalarFetch f;
   f.add(res.p, trace_out ? 4 : 2, h);
+  if (d_extra && n_extra) f.add(d_extra, n_extra, extra_out);
   f.run();
   out[0] = h[0];
   out[1] = h[1];
   if (trace_out) *trace_out = h[2];
 }
+}  // namespace
 
 void grand_sum(const DevMat& A, double out[2]) {
   out[0] = out[1] = 0;
@@ -3088,7 +3633,7 @@ double trace(const DevMat& A, int32_t col_offset) {
   DevBuf<double> partial((size_t)2 * nb);
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((k_trace<T>), dim3(nb), dim3(256), 0, stream(), view(A), col_offset, partial.p);
+    hipLaunchKernelGGL((k_trace<T>), dim3(nb), dim3(256), 0, stream(), lview(A), col_offset, partial.p);
   });
   double out[2];
   finish_sum2(partial, nb, out);
@@ -3130,6 +3675,8 @@ void gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx) {
 }
 
 void scale(DevMat& A, double c) {
+  pack(A);
+  value_epoch() += 1;
   const int64_t n = A.nnz * (int64_t)A.wval();
   if (n == 0) return;
   hipLaunchKernelGGL(k_scale, dim3(std::min(cdiv(n, 256), 8192)), dim3(256), 0, stream(), A.val.p, n, c);
@@ -3148,6 +3695,8 @@ __global__ __launch_bounds__(256) void k_scale_columns(const int64_t* __restrict
 
 // values of column j *= factor[j] (factor: cols scalars of the matrix' type, device memory)
 void scale_columns(DevMat& A, const double* d_factor) {
+  pack(A);
+  value_epoch() += 1;
   if (A.nnz == 0) return;
   dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
@@ -3157,6 +3706,8 @@ void scale_columns(DevMat& A, const double* d_factor) {
 }
 
 void conjugate(DevMat& A) {
+  pack(A);
+  value_epoch() += 1;
   if (!A.cplx || A.nnz == 0) return;
   hipLaunchKernelGGL(k_conj, dim3(std::min(cdiv(A.nnz, 256), 8192)), dim3(256), 0, stream(), A.val.p, A.nnz);
 }

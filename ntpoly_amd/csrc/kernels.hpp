@@ -12,6 +12,7 @@ struct SpgemmStats {
                                // only counted when the time_kernels option is on (it costs a gather per entry of B)
   int64_t tmp_entries = 0;     // upper-bound entries reserved for the numeric pass
   int slab = 0;                // 1 when the register-slab kernel computed the product
+  int fused = 0;               // 1 / 2: with the fused epilogue of a purification step (SlabFusion::mode)
   int64_t bin_cols[6] = {0, 0, 0, 0, 0, 0};
   int64_t overflow_cols = 0;   // columns that left the LDS hash for the HBM accumulator
   // grouped LDS-hash path (spgemm_grouped.hip): 1 when it computed the product; columns handed back to the per-column
@@ -37,6 +38,10 @@ struct EngineOptions {
                                // kernels (a random permutation costs ~25x in SpGEMM time and turns the halo into a full gather)
   int virtual_grid = 0;        // tests: a process grid of any rows x columns x slices may be constructed on the ranks there
                                // are (the shape only selects the summation semantics of the multiply: slices > 1)
+  int fused_update = 1;        // TRS2 on one rank, real operands: the update X <- 2X - X*X (or X*X), its energy and its trace
+                               // come out of the epilogue of the register-slab kernel; 0: separate merge / reduction passes
+  int loose_iterates = 1;      // TRS2 on one rank, real operands: the iterate X stays in the slots the update / the slab
+                               // kernel wrote it to between the steps (no compaction pass per iteration); 0: packed
   int halo_overlap = 1;        // distributed multiply: 0 exchange then multiply, 1 overlap the exchange with the interior
                                // columns when the halo is a sizeable part of the panel, 2 always split, 3 split even
                                // with an empty halo (tests; also NTPOLY_AMD_HALO_OVERLAP in the environment)
@@ -83,8 +88,24 @@ struct LooseProduct {
 // arange: the columns [a, b) of A that the rows of B can name, when the caller knows them (gathered operands are
 // dim wide but populated over the halo range only): the per-column planning work then covers that range only
 struct ColRange { int32_t a, b; };
+// A purification step computed inside the register-slab kernel (A = B = X, real, one rank): the product never exists as
+// a matrix.  mode 1: result = X * X; mode 2: result = am * (X * X) + bm * X, merged by the AddSparseVectors rules with
+// `threshold`.  Either way dot = sum result .* D and trace = trace(result) come out of the same kernel and the result
+// is left LOOSE (no compaction).  done = false on return: the multiply took another path, or the kernel met a case it
+// does not decide (SlabFuseArgs in kernels.hip) -- the product was then computed the ordinary way (C / *loose).
+struct SlabFusion {
+  int mode = 0;
+  double am = 0, bm = 0, threshold = 0;
+  const DevMat* D = nullptr;
+  int32_t col_offset = 0;
+  bool done = false;
+  DevMat result;
+  double dot = 0, trace = 0;
+  int64_t product_nnz = 0;
+  int64_t refused = 0;
+};
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold,
-            bool dense_rule, LooseProduct* loose = nullptr, const ColRange* arange = nullptr);
+            bool dense_rule, LooseProduct* loose = nullptr, const ColRange* arange = nullptr, SlabFusion* fuse = nullptr);
 
 // B <- alpha*A + B (AddSparseVectors semantics), same shape and scalar type.
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold);
@@ -97,7 +118,19 @@ void axpby(const DevMat& A, DevMat& B, double alpha, double beta, double thresho
            double* trace_out = nullptr, int32_t trace_col_offset = 0);  // trace_out: also trace(B_new), same pass
 // the same with the first operand taken from a loose product (its exact nnz is learned on the way and returned)
 void axpby(const LooseProduct& A, DevMat& B, double alpha, double beta, double threshold, const DevMat* D, double* dot_out,
-           double* trace_out, int32_t trace_col_offset, int64_t* a_nnz_out);
+           double* trace_out, int32_t trace_col_offset, int64_t* a_nnz_out, bool keep_loose = false);
+// keep_loose: B (packed or loose on entry) is left LOOSE -- its columns stay in the slots the merge kernels wrote them
+// to and the compaction pass does not run.  Loose matrices (DevMat::loose()) are accepted by spgemm (both operands the
+// same matrix: the register-slab path reads the slots directly; otherwise packed copies are made), by the second
+// operand of axpby(LooseProduct, ...), by the first operand of dot_trace / trace and by clone(); everything else
+// needs pack() first and says so loudly.
+DevMat packed_copy(const DevMat& M);
+void pack(DevMat& M);
+// X <- X * X with the result left loose when the register-slab kernel computes it, out = dot(X_new, D), *trace_out =
+// trace(X_new): the sigma < 0 step of TRS2 without a compaction pass.  false: operand types this path does not serve
+// (nothing done).
+bool square_keep_loose(DevMat& X, double threshold, bool dense_rule, const DevMat& D, double out[2], double* trace_out,
+                       int32_t col_offset);
 // C = A .* B on the intersection of the patterns (conj_a: conjugate A first)
 void pairwise(const DevMat& A, const DevMat& B, DevMat& C, bool conj_a);
 // out = sum conj(A) .* B  (out[1] = imaginary part, 0 for real)

@@ -487,6 +487,7 @@ void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, dou
 void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
   out[2] = out[3] = 0.0;
   if (B.cplx || D.cplx != B.cplx || (B.grid && B.grid->num_slices > 1)) {   // (process slices: the K-split sums of ps_multiply)
+    pack(B.loc);
     ps_multiply(B, B, scratch, 1.0, 0.0, threshold);
     ps_axpby_dot(scratch, B, -1.0, 2.0, threshold, D, out, want_trace);
     return;
@@ -495,6 +496,9 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
   int64_t nz[2] = {B.loc.nnz, B.loc.nnz};
   LooseProduct L;
   DevMat AB;
+  // one rank: the iterate may stay loose from step to step (kernels.hpp, axpby keep_loose)
+  const bool keep_loose = !world().active() && options().loose_iterates != 0;
+  if (!keep_loose) pack(B.loc);
   if (world().active()) {
     HaloExchange hx;
     gather_needed_begin(hx, B, B.loc, nz, false);
@@ -504,16 +508,48 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
     spgemm(hx.full, B.loc, AB, 1.0, threshold, dense_rule, &L, &need);
   } else {
     const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
-    spgemm(B.loc, B.loc, AB, 1.0, threshold, dense_rule, &L);
+    SlabFusion fu;   // the whole update inside the multiply's epilogue when the register-slab kernel takes it
+    fu.mode = keep_loose && options().fused_update ? 2 : 0;
+    fu.am = -1.0;
+    fu.bm = 2.0;
+    fu.threshold = threshold;
+    fu.D = &D.loc;
+    fu.col_offset = B.c0;
+    spgemm(B.loc, B.loc, AB, 1.0, threshold, dense_rule, &L, nullptr, fu.mode ? &fu : nullptr);
+    if (fu.done) {
+      B.loc = std::move(fu.result);
+      out[0] = fu.dot;
+      out[1] = 0.0;
+      out[2] = fu.trace;
+      return;
+    }
   }
   if (L.valid) {
-    axpby(L, B.loc, -1.0, 2.0, threshold, &D.loc, out, want_trace ? &out[2] : nullptr, B.c0, nullptr);
+    axpby(L, B.loc, -1.0, 2.0, threshold, &D.loc, out, want_trace ? &out[2] : nullptr, B.c0, nullptr, keep_loose);
   } else {
+    pack(B.loc);
     scratch.grid = B.grid; scratch.dim = B.dim; scratch.c0 = B.c0; scratch.c1 = B.c1; scratch.cplx = B.cplx;
     scratch.loc = std::move(AB);
     axpby(scratch.loc, B.loc, -1.0, 2.0, threshold, &D.loc, out, want_trace ? &out[2] : nullptr, B.c0);
   }
   comm_allreduce_sum(out, want_trace ? 3 : 2);
+}
+
+// B <- B * B, out = dot(B_new, D) (+ trace(B_new)): the sigma < 0 step of TRS2.  On one rank with real operands the
+// product stays loose (no compaction pass); otherwise multiply, swap and reduce as before.
+void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
+  out[2] = out[3] = 0.0;
+  const bool keep_loose = !world().active() && options().loose_iterates != 0 && !B.cplx && !D.cplx &&
+                          !(B.grid && B.grid->num_slices > 1);
+  if (keep_loose) {
+    const double denom = (double)B.dim * (double)B.dim;
+    const bool dense_rule = denom > 0 && (double)B.loc.nnz / denom > 0.1;
+    if (square_keep_loose(B.loc, threshold, dense_rule, D.loc, out, want_trace ? &out[2] : nullptr, B.c0)) return;
+  }
+  pack(B.loc);
+  ps_multiply(B, B, scratch, 1.0, 0.0, threshold);
+  std::swap(B.loc, scratch.loc);  // B <- B*B; scratch is recomputed by the next multiply, so no copy
+  ps_dot_trace(B, D, out, want_trace);
 }
 
 // dot(A, B) and trace(A) from one pass

@@ -236,9 +236,7 @@ double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_tar
   if (*sigma > 0.0) {
     ps_square_update_dot(X, X2, threshold, WH, out, trace_io != nullptr);  // X2 = X*X; X = 2X - X2; energy; trace
   } else {
-    ps_multiply(X, X, X2, 1.0, 0.0, threshold);
-    std::swap(X.loc, X2.loc);  // X <- X2; X2 is scratch (recomputed by the next multiply), so no copy
-    ps_dot_trace(X, WH, out, trace_io != nullptr);
+    ps_square_dot(X, X2, threshold, WH, out, trace_io != nullptr);         // X = X*X; energy; trace
   }
   if (trace_io) *trace_io = out[2];
   return out[0];
@@ -281,6 +279,7 @@ void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
     }
   }
   const int total_iterations = II - 1;
+  pack(X.loc);  // (the steps leave the iterate loose, kernels.hpp)
   last_trace().loop_ms = ms_since(t1);
   if (p.be_verbose) {
     log_exit();

@@ -22,6 +22,21 @@ T* get(const int* ih) {
   if (!p) NTP_FATAL("null handle passed to the C ABI");
   return p;
 }
+// every entry point sees packed matrices; only the TRS2 step below passes its iterate on as it is (kernels.hpp, pack())
+template <>
+PSMatrix* get<PSMatrix>(const int* ih) {
+  PSMatrix* p;
+  std::memcpy(&p, ih, sizeof(p));
+  if (!p) NTP_FATAL("null handle passed to the C ABI");
+  if (p->loc.loose()) pack(p->loc);
+  return p;
+}
+PSMatrix* get_unpacked(const int* ih) {
+  PSMatrix* p;
+  std::memcpy(&p, ih, sizeof(p));
+  if (!p) NTP_FATAL("null handle passed to the C ABI");
+  return p;
+}
 template <typename T>
 void put(int* ih, T* p) {
   std::memset(ih, 0, sizeof(int) * SIZE_wrp);
@@ -126,6 +141,8 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "halo_overlap") options().halo_overlap = *value;
   else if (n == "load_balance") options().load_balance = *value;
   else if (n == "virtual_grid") options().virtual_grid = *value;
+  else if (n == "loose_iterates") options().loose_iterates = *value;
+  else if (n == "fused_update") options().fused_update = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used
@@ -910,7 +927,7 @@ void InverseSquareRoot_wrp(const int* ih_Input, int* ih_Output, const int* ih_so
 // (accumulated in the pass that evaluates the energy), exactly what the solver loop hands from iteration to iteration.
 void ntpoly_amd_trs2_step(int* ih_X, int* ih_X2, const int* ih_WH, const double* trace, const double* threshold,
                           double* energy_out, double* sigma_out, double* trace_io) {
-  *energy_out = trs2_step(*get<PSMatrix>(ih_X), *get<PSMatrix>(ih_X2), *get<PSMatrix>(ih_WH), *trace, *threshold, sigma_out,
+  *energy_out = trs2_step(*get_unpacked(ih_X), *get<PSMatrix>(ih_X2), *get<PSMatrix>(ih_WH), *trace, *threshold, sigma_out,
                           trace_io);
 }
 // extension: the reference's optional order_in argument (SquareRootSolversModule.F90:30-61) is not
