@@ -2631,6 +2631,11 @@ const DotOperand& dot_operand(const DevMat& D) {
 }
 }  // namespace
 
+long long* fusion_counts() {
+  static long long c[3] = {0, 0, 0};
+  return c;
+}
+
 void flush_spgemm_timers() {
   auto& pend = pending_timings();
   if (pend.empty()) return;
@@ -3143,6 +3148,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     if ((int32_t)flagv[0] != 0) {   // (see SlabFuseArgs) the step is repeated without the fusion
       fuse->done = false;
       fuse->refused += 1;
+      fusion_counts()[2] += 1;
       spgemm(A, B, C, alpha, threshold, dense_rule, loose, arange, nullptr);
       return;
     }
@@ -3159,6 +3165,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     R.val = std::move(tmp_val);
     fuse->result = std::move(R);
     fuse->done = true;
+    fusion_counts()[fuse->mode == 1 ? 0 : 1] += 1;
     fuse->dot = hd[0];
     fuse->trace = hd[1];
     fuse->product_nnz = pnz;

@@ -106,6 +106,8 @@ struct SlabFusion {
 };
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold,
             bool dense_rule, LooseProduct* loose = nullptr, const ColRange* arange = nullptr, SlabFusion* fuse = nullptr);
+// since start: [0] steps computed with SlabFusion mode 1, [1] mode 2, [2] fused steps repeated on the unfused path
+long long* fusion_counts();
 
 // B <- alpha*A + B (AddSparseVectors semantics), same shape and scalar type.
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold);

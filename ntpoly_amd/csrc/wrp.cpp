@@ -169,6 +169,11 @@ void ntpoly_amd_exchange_stats(long long* out) {
   out[0] = exchange_stats().exchanges;
   out[1] = exchange_stats().host_syncs;
 }
+// out[0..2]: purification steps computed inside the SpGEMM kernel's epilogue (X*X; 2X - X*X) and fused steps that had
+// to be repeated on the unfused path, since start
+void ntpoly_amd_fusion_counts(long long* out) {
+  for (int q = 0; q < 3; ++q) out[q] = fusion_counts()[q];
+}
 void ntpoly_amd_reset_spgemm_accum() {
   flush_spgemm_timers();
   spgemm_accum() = SpgemmAccum();

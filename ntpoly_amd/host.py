@@ -862,6 +862,13 @@ def last_spgemm_stats():
                 bins=[out[5 + k] for k in range(6)], overflow=out[11], slab=out[12], ms_numeric=a.value, ms_total=t.value)
 
 
+def fusion_counts():
+    """(steps X*X, steps 2X - X*X) computed inside the SpGEMM kernel's epilogue and fused steps repeated unfused"""
+    out = (C.c_longlong * 3)()
+    lib.ntpoly_amd_fusion_counts(out)
+    return dict(square=out[0], update=out[1], repeated=out[2])
+
+
 def last_grouped_stats():
     """grouped LDS-hash path of the last SpGEMM (csrc/spgemm_grouped.hip)"""
     out = (C.c_longlong * 6)()

@@ -802,3 +802,78 @@ def test_process_slices_semantics_vs_reference(nt):
     finally:
         nt.ConstructGlobalProcessGrid(1, 1, 1)
         nt.set_option("virtual_grid", 0)
+
+
+# ------------------------------------------------------------------ fused purification steps / loose iterates
+def _trs2_run(nt, n, col, row, val, thr, iters, fused, loose):
+    nt.set_option("fused_update", fused)
+    nt.set_option("loose_iterates", loose)
+    try:
+        H = nt.Matrix_ps.from_triplets(n, col, row, val)
+        ISQ = nt.Matrix_ps(n)
+        ISQ.FillIdentity()
+        K = nt.Matrix_ps(n)
+        p = nt.SolverParameters()
+        p.SetConvergeDiff(1e-30)
+        p.SetThreshold(thr)
+        p.SetMaxIterations(iters)
+        p.SetMonitorConvergence(False)
+        before = nt.fusion_counts()
+        energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, p)
+        after = nt.fusion_counts()
+        tr = nt.solver_trace()
+        return dict(energy=energy, mu=mu, tr=tr, K=K.triplets(),
+                    counts={k: after[k] - before[k] for k in after})
+    finally:
+        nt.set_option("fused_update", 1)
+        nt.set_option("loose_iterates", 1)
+
+
+@pytest.mark.parametrize("case", ["banded", "holes", "tall", "wide_d", "stored_zeros"])
+def test_trs2_fused_steps_match_the_separate_passes(nt, case):
+    """The TRS2 step computed inside the SpGEMM kernel's epilogue (kernels.hpp SlabFusion: X*X or 2X - X*X, energy and
+    trace in one kernel, the iterate left in its slots) against the same solve with the product, the merge and the
+    reductions as separate passes (the path the goldens and the oracle pin): identical sigma sequence, identical
+    density bit for bit, energies to reduction-order roundoff.  'stored_zeros': X holds stored zeros (threshold 0 and
+    explicit zeros in H), which the merge inside the kernel cannot tell from holes -- it must step aside.  'wide_d':
+    the columns of WH do not fit the kernel's LDS tile."""
+    rng = np.random.default_rng(11)
+    if case == "tall":
+        n, h, thr, iters = 6144, 110, 1e-11, 10     # row windows beyond 768 rows: the six / eight wave geometries
+    elif case == "wide_d":
+        n, h, thr, iters = 6144, 300, 1e-6, 8       # sixteen columns of WH exceed the LDS tile: no fusion, same results
+    elif case == "stored_zeros":
+        n, h, thr, iters = 768, 6, 0.0, 4
+    else:
+        n, h, thr, iters = 8192, 40, 1e-7, 14
+    col, row, val = banded_triplets(n, h)
+    if case == "holes":      # symmetric holes: columns with several runs, ragged block windows
+        a, b = np.minimum(col, row).astype(np.int64), np.maximum(col, row).astype(np.int64)
+        keep = (((a * 2654435761 + b * 40503) >> 7) % 10 >= 3) | (col == row)
+        col, row, val = col[keep], row[keep], val[keep]
+    if case == "stored_zeros":
+        off = np.abs(col.astype(np.int64) - row) == 3
+        val = np.where(off, 0.0, val)
+    ref = _trs2_run(nt, n, col, row, val, thr, iters, fused=0, loose=0)
+    assert ref["counts"]["square"] == ref["counts"]["update"] == 0
+    for fused, loose in ((1, 1), (0, 1)):
+        got = _trs2_run(nt, n, col, row, val, thr, iters, fused=fused, loose=loose)
+        tag = (case, fused, loose)
+        assert got["tr"]["iterations"] == ref["tr"]["iterations"] == iters, tag
+        assert np.array_equal(got["tr"]["sigma"], ref["tr"]["sigma"]), tag
+        assert np.array_equal(got["tr"]["nnz"], ref["tr"]["nnz"]), tag
+        assert np.allclose(got["tr"]["energy"], ref["tr"]["energy"], rtol=1e-12, atol=1e-12), tag
+        for q in range(2):
+            assert np.array_equal(got["K"][q], ref["K"][q]), tag
+        assert np.array_equal(got["K"][2], ref["K"][2]), tag
+        c = got["counts"]
+        if fused and case == "wide_d":
+            assert c["square"] == c["update"] == c["repeated"] == 0, (tag, c)
+        elif fused and case != "stored_zeros":
+            # (an operand full of holes may take another SpGEMM path in the first iterations: nothing to fuse into)
+            assert c["repeated"] == 0 and iters - 2 <= c["square"] + c["update"] <= iters, (tag, c)
+            assert c["update"] > 0 and c["square"] > 0, (tag, c)
+        # ('stored_zeros': a merge that would read the stored zeros is not fused; once a step has produced the iterate
+        # inside the kernel every entry is non-zero and the following steps may be -- the equalities above are the test)
+        if not fused:
+            assert c["square"] == c["update"] == 0, (tag, c)
