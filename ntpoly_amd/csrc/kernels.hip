@@ -2466,6 +2466,51 @@ void reduce_sum2_async(const double* part, int n, double* out_dev) {
 }
 }  // namespace
 
+// Totals of a fused purification step in two launches: sum count[0..n) (entries of the result), sum a[0..m) and
+// sum b[0..m) (entries of the product, products), sum of the (dot, trace) pairs part[0..2m) -- fixed shapes and orders,
+// so the sums are reproducible.  out: 3 x int64 then 2 x double (as raw 8-byte words).
+constexpr int FT_BLOCKS = 64;
+__global__ __launch_bounds__(256) void k_fused_totals(const int32_t* __restrict__ count, int n, const long long* __restrict__ a,
+                                                      const long long* __restrict__ b, const double* __restrict__ part,
+                                                      int m, const double* __restrict__ lvl_in, double* __restrict__ out,
+                                                      int stage) {
+  __shared__ long long si[3][4];
+  __shared__ double sd[2][4];
+  const int wave = threadIdx.x / WAVE, lane = lane_id();
+  long long c = 0, x = 0, y = 0;
+  double d = 0.0, t = 0.0;
+  if (stage == 0) {   // block g of FT_BLOCKS takes a contiguous chunk of every array
+    const int g = blockIdx.x;
+    const int n0 = (int)((int64_t)n * g / FT_BLOCKS), n1 = (int)((int64_t)n * (g + 1) / FT_BLOCKS);
+    for (int i = n0 + threadIdx.x; i < n1; i += 256) c += count[i];
+    const int m0 = (int)((int64_t)m * g / FT_BLOCKS), m1 = (int)((int64_t)m * (g + 1) / FT_BLOCKS);
+    for (int i = m0 + threadIdx.x; i < m1; i += 256) {
+      x += a[i];
+      if (b) y += b[i];
+      d = __dadd_rn(d, part[2 * i]);
+      t = __dadd_rn(t, part[2 * i + 1]);
+    }
+  } else {
+    const long long* li = reinterpret_cast<const long long*>(lvl_in);
+    for (int g = threadIdx.x; g < FT_BLOCKS; g += 256) {
+      c += li[5 * g]; x += li[5 * g + 1]; y += li[5 * g + 2];
+      d = __dadd_rn(d, lvl_in[5 * g + 3]);
+      t = __dadd_rn(t, lvl_in[5 * g + 4]);
+    }
+  }
+  c = wave_sum_i64(c); x = wave_sum_i64(x); y = wave_sum_i64(y);
+  d = wave_sum_f64(d); t = wave_sum_f64(t);
+  if (lane == 0) { si[0][wave] = c; si[1][wave] = x; si[2][wave] = y; sd[0][wave] = d; sd[1][wave] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long* oi = reinterpret_cast<long long*>(out) + (stage == 0 ? 5 * blockIdx.x : 0);
+    double* od = out + (stage == 0 ? 5 * blockIdx.x : 0);
+    for (int q = 0; q < 3; ++q) oi[q] = si[q][0] + si[q][1] + si[q][2] + si[q][3];
+    od[3] = __dadd_rn(__dadd_rn(sd[0][0], sd[0][1]), __dadd_rn(sd[0][2], sd[0][3]));
+    od[4] = __dadd_rn(__dadd_rn(sd[1][0], sd[1][1]), __dadd_rn(sd[1][2], sd[1][3]));
+  }
+}
+
 void scan_i32_async(const int32_t* d_in, int64_t* d_out, int64_t n) { scan_async<int32_t>(d_in, d_out, n); }
 void scan_i64_async(const int64_t* d_in, int64_t* d_out, int64_t n) { scan_async<int64_t>(d_in, d_out, n); }
 
@@ -2863,13 +2908,21 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<double> tmp2_val;
   DevBuf<int64_t> tmpoff2;
   DevBuf<double> aexp, bblk;
-  DevBuf<int64_t> blk_prod, blk_prod_scan;
-  DevBuf<double> fz_part;
-  DevBuf<int64_t> fz_pnnz, fz_flag;
+  // one zeroed block of 8-byte words: [flag 2 | entries of the product per block snb + 1 | products per block snb |
+  // (dot, trace) per block 2 snb] -- blocks without work write nothing
+  DevBuf<int64_t> zwords, blk_prod_scan;
+  int64_t *blk_prod = nullptr, *fz_pnnz = nullptr, *fz_flag = nullptr;
+  double* fz_part = nullptr;
   DevBuf<char> fz_args;
   bool fuse_now = false;
   if (use_slab) {
-    blk_prod.alloc(snb); blk_prod.zero(); blk_prod_scan.alloc((size_t)snb + 1);
+    zwords.alloc((size_t)4 * snb + 4);
+    zwords.zero();
+    fz_flag = zwords.p;
+    fz_pnnz = zwords.p + 2;
+    blk_prod = zwords.p + 3 + snb;
+    fz_part = reinterpret_cast<double*>(zwords.p + 3 + 2 * (size_t)snb);
+    blk_prod_scan.alloc((size_t)snb + 1);
     aexp.alloc(((size_t)slab_tot[0] + 1) * A.wval());
     bblk.alloc(((size_t)slab_tot[1] + 16 * SJ) * A.wval());  // slack: the loop prefetches a few rows past the last tile
     const bool same = (&A == &B);
@@ -2895,16 +2948,15 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                            Ar, cmin_own.p, aeoff.p, ae);
       hipLaunchKernelGGL((k_slab_expand_b<double2, SLAB_CJ>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * esz,
                          stream(), lview(B), blk_kmin.p, blk_kn.p, blk_boff.p, reinterpret_cast<double2*>(bblk.p), snb, pitch,
-                         same ? 1 : 0, aeoff.p, ae, clen_opt, blk_prod.p);
+                         same ? 1 : 0, aeoff.p, ae, clen_opt, blk_prod);
     } else {
       if (!same)
         hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)nka * WAVE, 256)), dim3(256), 0, stream(),
                            Ar, cmin_own.p, aeoff.p, aexp.p);
       hipLaunchKernelGGL((k_slab_expand_b<double, SLAB_J>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SJ * esz,
                          stream(), lview(B), blk_kmin.p, blk_kn.p, blk_boff.p, bblk.p, snb, pitch, same ? 1 : 0, aeoff.p,
-                         aexp.p, clen_opt, blk_prod.p);
+                         aexp.p, clen_opt, blk_prod);
     }
-    scan_async<int64_t>(blk_prod.p, blk_prod_scan.p, (int64_t)snb);  // total = products of this multiply
   }
   if (!grouped_done) t_num.start();
   if (use_slab && A.cplx) {
@@ -2957,14 +3009,11 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     if (fuse_now && dop_p->max_tile > SLAB_DTILE) fuse_now = false;   // (D columns too wide for the LDS tile)
     if (fuse_now) {
       const DotOperand& dop = *dop_p;
-      fz_part.alloc((size_t)2 * snb); fz_part.zero();
-      fz_pnnz.alloc((size_t)snb + 1); fz_pnnz.zero();
-      fz_flag.alloc(2); fz_flag.zero();
       SlabFuseArgs fz;
       fz.am = fuse->am; fz.bm = fuse->bm; fz.thr_m = fuse->threshold;
       fz.xexp = aexp.p; fz.xoff = aeoff.p; fz.xmin = cmin_own.p; fz.xmax = cmax_own.p;
       fz.dexp = dop.dexp.p; fz.doff = dop.doff.p; fz.dmin = dop.dmin.p; fz.dmax = dop.dmax.p;
-      fz.part = fz_part.p; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz.p); fz.flag = reinterpret_cast<int*>(fz_flag.p);
+      fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
       fz.col_offset = fuse->col_offset;
       fz_args.alloc(sizeof(SlabFuseArgs));
       fz_args.upload(reinterpret_cast<const char*>(&fz), sizeof(SlabFuseArgs));
@@ -3120,25 +3169,29 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     sync_stream();  // ws is released below
   }
   t_num.stop();
+  if (use_slab && !fuse_now) scan_async<int64_t>(blk_prod, blk_prod_scan.p, (int64_t)snb);  // total = products of this multiply
 
   if (fuse_now) {
     // one read-back: entries of the result, (dot, trace), the kernel's objections, the product's own entry count
-    DevBuf<double> res(2);
-    reduce_sum2_async(fz_part.p, snb, res.p);
-    DevBuf<int64_t> total((size_t)n + 1), ptot((size_t)snb + 2);
-    scan_async<int32_t>(count.p, total.p, (int64_t)n);
-    scan_async<int64_t>(fz_pnnz.p, ptot.p, (int64_t)snb);
+    DevBuf<double> lvl((size_t)5 * FT_BLOCKS), tot(5);
+    hipLaunchKernelGGL(k_fused_totals, dim3(FT_BLOCKS), dim3(256), 0, stream(), count.p, n,
+                       reinterpret_cast<const long long*>(fz_pnnz), reinterpret_cast<const long long*>(blk_prod),
+                       fz_part, snb, (const double*)nullptr, lvl.p, 0);
+    hipLaunchKernelGGL(k_fused_totals, dim3(1), dim3(256), 0, stream(), (const int32_t*)nullptr, 0, (const long long*)nullptr,
+                       (const long long*)nullptr, (const double*)nullptr, 0, lvl.p, tot.p, 1);
     int64_t nnz = 0, flagv[2] = {0, 0}, pnz = 0;
     unsigned long long slab_products = 0;
     double hd[2] = {0, 0};
     {
+      unsigned long long raw[5] = {0, 0, 0, 0, 0};
       ScalarFetch f;
-      f.add(total.p + n, 1, &nnz);
-      f.add(res.p, 2, hd);
-      f.add(fz_flag.p, 1, flagv);
-      f.add(ptot.p + snb, 1, &pnz);
-      f.add(blk_prod_scan.p + snb, 1, &slab_products);
+      f.add(tot.p, 5, raw);
+      f.add(fz_flag, 1, flagv);
       f.run();
+      nnz = (int64_t)raw[0];
+      pnz = (int64_t)raw[1];
+      slab_products = raw[2];
+      std::memcpy(hd, &raw[3], 2 * sizeof(double));
     }
     t_all.stop();
     if (timing) {
