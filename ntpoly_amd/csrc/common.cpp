@@ -163,6 +163,7 @@ void DevMat::reset_empty(int32_t r, int32_t c, bool z) {
   cplx = z;
   nnz = 0;
   cnt.release();
+  slab.reset();
   slots = 0;
   zero_free = 0;
   outer.alloc((size_t)c + 1);
@@ -177,6 +178,7 @@ void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
   cplx = z;
   nnz = nz;
   cnt.release();
+  slab.reset();
   slots = 0;
   zero_free = 0;
   outer.alloc((size_t)c + 1);
@@ -185,6 +187,7 @@ void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
 }
 
 DevMat DevMat::clone() const {
+  if (expanded()) return packed_copy(*this);
   DevMat R;
   if (loose()) {  // the slots as they are
     R.rows = rows; R.cols = cols; R.cplx = cplx; R.nnz = nnz; R.slots = slots; R.zero_free = zero_free;

@@ -9,6 +9,7 @@
 #include <map>
 #include <string>
 #include <utility>
+#include <memory>
 #include <vector>
 
 namespace ntp {
@@ -118,6 +119,20 @@ struct DevBuf {
 // a column instead of clamping every lane (never dereferenced as data)
 constexpr size_t kIndexSlack = 1024;
 
+// A real square iterate of a purification loop kept in the form the register-slab SpGEMM kernel consumes (written by
+// the kernel's fused epilogue, kernels.hpp SlabFusion; read by the next multiply X * X without any preparation pass):
+//   column j: rows first[j] .. last[j] (first > last: empty) as a dense run at val[off[j] ...], zeros = no entry;
+//   block b of 16 columns: the same entries as a row-major tile (k - kmin_b) x 16 at tiles[tile_off[b] ...], where
+//   kmin_b .. kmax_b is the union of the blocks' column ranges.
+// count[j] = entries of column j.  pack() turns it into compressed columns.
+struct SlabForm {
+  DevBuf<int32_t> first, last, count;
+  DevBuf<int64_t> off;        // cols + 1
+  DevBuf<int64_t> tile_off;   // blocks + 1
+  DevBuf<double> val, tiles;
+  int64_t slots = 0;          // doubles addressable in val / tiles
+};
+
 struct DevMat {
   int32_t rows = 0, cols = 0;
   bool cplx = false;
@@ -135,6 +150,9 @@ struct DevMat {
   // scaled copy of one that did); 0: not known.  The fused purification steps (kernels.hpp, SlabFusion) read a zero of
   // the expanded columns as "no entry", which needs this.
   mutable int zero_free = 0;
+  // set: the entries live in *slab (outer / inner / val are empty, nnz is valid); see SlabForm
+  std::unique_ptr<SlabForm> slab;
+  bool expanded() const { return slab != nullptr; }
 
   DevMat() = default;
   DevMat(int32_t r, int32_t c, bool z) { reset_empty(r, c, z); }
@@ -145,6 +163,8 @@ struct DevMat {
   DevMat clone() const;
   size_t wval() const { return cplx ? 2 : 1; }
 };
+
+DevMat packed_copy(const DevMat& M);   // kernels.hip: compressed columns from any storage form
 
 // host-side triplets, NTPoly convention: 1-based (index_column, index_row, value)
 struct HostTriplets {

@@ -872,6 +872,8 @@ struct SlabFuseArgs {
   const double* dexp = nullptr;      // expanded columns of D
   const int64_t* doff = nullptr;
   const int32_t *dmin = nullptr, *dmax = nullptr;
+  int32_t *ofirst = nullptr, *olast = nullptr;   // first / last row of every column of the result
+  double* tiles = nullptr;           // the result as tiles (SlabForm::tiles), block b at blk_toff[b]
   double* part = nullptr;            // [2 * nblocks]: (dot, trace) of the block
   long long* pnnz = nullptr;         // [nblocks]: kept entries of the product
   int* flag = nullptr;
@@ -891,7 +893,13 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
   if (b < 0) return;
   const int wave = uni_i32(threadIdx.x / WAVE), lane = lane_id();
   const int lo = blk_lo[b], kmin = blk_kmin[b], kn = blk_kn[b], w = blk_w[b];
-  if (kn == 0) return;
+  if (kn == 0) {
+    if constexpr (EPI != 0) {   // (no entries in these columns of X: none in the result)
+      const int j = b * J + threadIdx.x;
+      if (threadIdx.x < J && j < ncols) { fzp->ofirst[j] = INT_MAX; fzp->olast[j] = -1; }
+    }
+    return;
+  }
   // fused epilogues: what they read per column is staged in LDS before the loop starts (the loads overlap with the
   // other workgroups' loops; after the loop the registers are too few to hide sixteen dependent round trips) --
   // the extents of the X and D columns and the expanded D columns themselves (SLAB_DTILE doubles, checked on the host)
@@ -970,8 +978,8 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     // leave the compiler very few registers of either kind.
     asm volatile("" ::: "memory");
     const SlabFuseArgs fz = *fzp;
-    __shared__ int amax_s[NW * SL][J];
-    __shared__ int amax_f[J];
+    __shared__ int amax_s[NW * SL][J], first_s[NW * SL][J];
+    __shared__ int amax_f[J], col_first[J], col_last[J];
     __shared__ double red_s[2 * NW];
     __shared__ long long pn_s[NW];
     // (lane s * J + jj of amaxv / cntv keeps the scalar of slab s, column jj)
@@ -1014,11 +1022,8 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
       fz.pnnz[b] = t;
     }
     __syncthreads();
-    unsigned keepbits[SL];
     double dsum = 0.0, tsum = 0.0;
-    int cntv = 0;
-#pragma unroll
-    for (int s = 0; s < SL; ++s) keepbits[s] = 0u;
+    int cntv = 0, firstv = INT_MAX, lastv = -1;   // (lane s * J + jj: entries / first / last kept row of that slab and column)
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) {
       __builtin_amdgcn_sched_barrier(0);
@@ -1065,35 +1070,45 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
         const double dv = (ind && keep) ? draw : 0.0;
         dsum = __dadd_rn(dsum, __dmul_rn(keep ? o : 0.0, dv));
         tsum = __dadd_rn(tsum, (keep && r == j + fz.col_offset) ? o : 0.0);
-        keepbits[s] |= keep ? (1u << jj) : 0u;
-        asm volatile("" : "+v"(keepbits[s]));
-        acc[s][jj] = o;
+        acc[s][jj] = keep ? o : 0.0;   // the slab form of the result: a zero is "no entry"
         const unsigned long long m = __ballot(keep);
         {
           const int pc = (int)__popcll(m);
+          const int row0 = lo + WAVE * (wave + NW * s);
+          const int fr = m ? row0 + (int)__builtin_ctzll(m) : INT_MAX, lr = m ? row0 + 63 - __clzll((long long)m) : -1;
           asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(pc), "n"(s * J + jj));
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(firstv) : "s"(fr), "n"(s * J + jj));
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(lastv) : "s"(lr), "n"(s * J + jj));
         }
       }
       // (everything of this column is consumed here: its lane masks and loaded values do not outlive it)
-      asm volatile("" : "+v"(dsum), "+v"(tsum), "+v"(cntv));
+      asm volatile("" : "+v"(dsum), "+v"(tsum), "+v"(cntv), "+v"(firstv), "+v"(lastv));
     }
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < SL; ++s) asm volatile("" : "+v"(keepbits[s]));   // (the bits, not 48 lane masks kept in scalar registers)
-    if (lane < SL * J) cnt_s[wave + NW * (lane / J)][lane % J] = cntv;
+    if (lane < SL * J) {
+      cnt_s[wave + NW * (lane / J)][lane % J] = cntv;
+      first_s[wave + NW * (lane / J)][lane % J] = firstv;
+      amax_s[wave + NW * (lane / J)][lane % J] = lastv;    // (the array of the first pass, free again)
+    }
     dsum = wave_sum_f64(dsum);
     tsum = wave_sum_f64(tsum);
     if (lane == 0) { red_s[2 * wave] = dsum; red_s[2 * wave + 1] = tsum; }
     __syncthreads();
-    if (threadIdx.x < J) {
-      int run = 0;
+    if (threadIdx.x < J) {   // entries, first and last row of every column of the block
+      int run = 0, cf = INT_MAX, cl = -1;
       for (int m = 0; m < NW * SL; ++m) {
-        const int c = cnt_s[m][threadIdx.x];
-        cnt_s[m][threadIdx.x] = run;
-        run += c;
+        run += cnt_s[m][threadIdx.x];
+        cf = min(cf, first_s[m][threadIdx.x]);
+        cl = max(cl, amax_s[m][threadIdx.x]);
       }
+      col_first[threadIdx.x] = cf;
+      col_last[threadIdx.x] = cl;
       const int j = b * J + threadIdx.x;
-      if (j < ncols) count[j] = run;
+      if (j < ncols) {
+        count[j] = run;
+        fz.ofirst[j] = cf;
+        fz.olast[j] = cl;
+      }
     }
     if (threadIdx.x == 64) {
       double x = 0.0, y = 0.0;
@@ -1102,19 +1117,31 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
       fz.part[2 * b + 1] = y;
     }
     __syncthreads();
+    // ---- the result in slab form (SlabForm): every column as a dense run, the block as a row-major tile
     const int64_t tbase = blk_toff[b];
+    int tk0 = INT_MAX, tk1 = -1;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      tk0 = min(tk0, col_first[jj]);
+      tk1 = max(tk1, col_last[jj]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const int cf = col_first[jj], cn = col_last[jj] - cf;   // (empty: cn < 0)
+      double* __restrict__ dst = out_val + tbase + (int64_t)jj * w;
+#pragma unroll
+      for (int s = 0; s < SL; ++s) {
+        const unsigned o = (unsigned)(lo + WAVE * (wave + NW * s) + lane - cf);
+        if (cn >= 0 && o <= (unsigned)cn) dst[o] = acc[s][jj];
+      }
+    }
+    double2* __restrict__ tile = reinterpret_cast<double2*>(fz.tiles + tbase);
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
-      const int r = lo + WAVE * (wave + NW * s) + lane;
+      const unsigned o = (unsigned)(lo + WAVE * (wave + NW * s) + lane - tk0);
+      if (tk1 >= tk0 && o <= (unsigned)(tk1 - tk0)) {
 #pragma unroll
-      for (int jj = 0; jj < J; ++jj) {
-        const bool keep = (keepbits[s] >> jj) & 1u;
-        const unsigned long long m = __ballot(keep);
-        if (keep) {
-          const int64_t pos = tbase + (int64_t)jj * w + cnt_s[wave + NW * s][jj] + __popcll(m & lanemask_lt());
-          out_inner[pos] = r;
-          out_val[pos] = acc[s][jj];
-        }
+        for (int q = 0; q < J / 2; ++q) tile[(size_t)o * (J / 2) + q] = make_double2(acc[s][2 * q], acc[s][2 * q + 1]);
       }
     }
     return;
@@ -2728,6 +2755,16 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
             LooseProduct* loose, const ColRange* arange, SlabFusion* fuse) {
   if (loose) loose->valid = false;
   if (fuse) fuse->done = false;
+  if (A.expanded() || B.expanded()) {   // (the steps on the slab form are slab_step's; everything else wants columns)
+    DevMat Ap = packed_copy(A);
+    if (&A == &B) {
+      spgemm(Ap, Ap, C, alpha, threshold, dense_rule, loose, arange, fuse);
+    } else {
+      DevMat Bp = packed_copy(B);
+      spgemm(Ap, Bp, C, alpha, threshold, dense_rule, loose, arange, fuse);
+    }
+    return;
+  }
   if (A.cols != B.rows) NTP_FATAL("spgemm: inner dimensions differ");
   if (A.cplx != B.cplx) NTP_FATAL("spgemm: mixed scalar types must be up-cast by the caller");
   const int32_t m = A.rows, n = B.cols;
@@ -2914,6 +2951,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   int64_t *blk_prod = nullptr, *fz_pnnz = nullptr, *fz_flag = nullptr;
   double* fz_part = nullptr;
   DevBuf<char> fz_args;
+  DevBuf<int32_t> fz_first, fz_last;
+  DevBuf<double> fz_tiles;
   bool fuse_now = false;
   if (use_slab) {
     zwords.alloc((size_t)4 * snb + 4);
@@ -3015,6 +3054,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       fz.dexp = dop.dexp.p; fz.doff = dop.doff.p; fz.dmin = dop.dmin.p; fz.dmax = dop.dmax.p;
       fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
       fz.col_offset = fuse->col_offset;
+      fz_first.alloc((size_t)n); fz_last.alloc((size_t)n);
+      fz_tiles.alloc((size_t)tmp_total + kIndexSlack);
+      fz.ofirst = fz_first.p; fz.olast = fz_last.p; fz.tiles = fz_tiles.p;
       fz_args.alloc(sizeof(SlabFuseArgs));
       fz_args.upload(reinterpret_cast<const char*>(&fz), sizeof(SlabFuseArgs));
       auto launch_fused = [&](auto nw_tag, auto mode_tag, auto epi_tag) {
@@ -3210,12 +3252,16 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     R.cols = n;
     R.cplx = false;
     R.nnz = nnz;
-    R.slots = tmp_total;
     R.zero_free = 1;   // kept entries passed |v| > threshold (> = 0) or are scaled copies of entries that did
-    R.outer = std::move(tmpoff);
-    R.cnt = std::move(count);
-    R.inner = std::move(tmp_inner);
-    R.val = std::move(tmp_val);
+    R.slab.reset(new SlabForm());
+    R.slab->first = std::move(fz_first);
+    R.slab->last = std::move(fz_last);
+    R.slab->count = std::move(count);
+    R.slab->off = std::move(tmpoff);
+    R.slab->tile_off = std::move(blk_toff);
+    R.slab->val = std::move(tmp_val);
+    R.slab->tiles = std::move(fz_tiles);
+    R.slab->slots = tmp_total;
     fuse->result = std::move(R);
     fuse->done = true;
     fusion_counts()[fuse->mode == 1 ? 0 : 1] += 1;
@@ -3302,6 +3348,177 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   acc.nnz_c += nnz;
   const double per = A.cplx ? 20.0 : 12.0;
   acc.alg_bytes += per * (double)(A.nnz + B.nnz + nnz) + 4.0 * ((double)A.cols + B.cols + n + 3);
+}
+
+
+// -------------------------------------------------------------------------------------
+// A purification step on an iterate that is already in slab form (SlabForm): plan from the column extents, run
+// records, the fused kernel, the totals -- no pass over the entries outside the kernel itself.
+namespace {
+// compressed columns from the slab form: one wave per column, the non-zeros of its run in row order
+__global__ __launch_bounds__(256) void k_pack_slab(int ncols, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                                   const int64_t* __restrict__ off, const double* __restrict__ val,
+                                                   const int64_t* __restrict__ outer, int32_t* __restrict__ inner,
+                                                   double* __restrict__ out) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= ncols) return;
+  const int lane = lane_id();
+  const int f = first[j], l = last[j];
+  int64_t pos = outer[j];
+  const double* __restrict__ src = val + off[j];
+  for (int r0 = f; r0 <= l; r0 += WAVE) {
+    const int r = r0 + lane;
+    const double v = r <= l ? src[r - f] : 0.0;
+    const unsigned long long m = __ballot(v != 0.0);
+    if (v != 0.0) {
+      const int64_t q = pos + __popcll(m & lanemask_lt());
+      inner[q] = r;
+      out[q] = v;
+    }
+    pos += __popcll(m);
+  }
+}
+}  // namespace
+
+bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
+  fu.done = false;
+  if (!X.expanded() || X.cplx || X.rows != X.cols || !fu.D || fu.D->cplx || fu.D->loose() || fu.D->expanded() ||
+      fu.D->rows != X.rows || fu.D->cols != X.cols || (fu.mode != 1 && fu.mode != 2))
+    return false;
+  if (options().spgemm_variant >= 0 || options().spgemm_fma || options().spgemm_force_bin > 0 || !options().fused_update)
+    return false;
+  const SlabForm& in = *X.slab;
+  const int n = X.cols, snb = cdiv(n, SLAB_J);
+  const DotOperand& dop = dot_operand(*fu.D);
+  if (dop.max_tile > SLAB_DTILE) return false;
+  const bool timing = options().time_kernels != 0;
+  EventTimer t_all(timing), t_num(timing);
+  t_all.start();
+  SpgemmStats st;
+  st.nnz_a = st.nnz_b = X.nnz;
+  // ---- plan (column extents only)
+  DevBuf<int32_t> blk_lo(snb), blk_w(snb), blk_kmin(snb), blk_kn(snb), count((size_t)n), ofirst((size_t)n), olast((size_t)n);
+  DevBuf<int64_t> bsz(snb), tsz(snb), blk_toff((size_t)snb + 1), tmpoff((size_t)n + 1);
+  // [flag 2 | product entries per block snb + 1 | (unused) snb | (dot, trace) per block 2 snb | plan statistics 24]
+  DevBuf<int64_t> zwords((size_t)4 * snb + 4 + 24);
+  zwords.zero();
+  count.zero();
+  int64_t* fz_flag = zwords.p;
+  int64_t* fz_pnnz = zwords.p + 2;
+  double* fz_part = reinterpret_cast<double*>(zwords.p + 3 + 2 * (size_t)snb);
+  unsigned long long* stats = reinterpret_cast<unsigned long long*>(zwords.p + 4 * (size_t)snb + 4);
+  hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, in.first.p,
+                     in.last.p, in.first.p, in.last.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
+  hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, (const int32_t*)nullptr, 0, stats);
+  scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
+  int64_t tmp_total = 0;
+  unsigned long long hst[3] = {0, 0, 0};
+  {
+    ScalarFetch f;
+    f.add(blk_toff.p + snb, 1, &tmp_total);
+    f.add(stats + 16, 3, hst);
+    f.run();
+  }
+  const int64_t max_w = (int64_t)hst[0];
+  auto give_up = [&]() {
+    if (timing) {
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+    }
+    return false;
+  };
+  if (max_w <= 0 || max_w > 8 * SLAB_SL * WAVE) return give_up();
+  hipLaunchKernelGGL((k_slab_tmpoff<SLAB_J>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
+  DevBuf<char> runs(((size_t)n + 4) * sizeof(SlabRun));
+  hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(n + 4, 256)), dim3(256), 0, stream(), in.first.p, in.last.p, in.off.p,
+                     reinterpret_cast<const char*>(in.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), n);
+  DevBuf<double> oval((size_t)tmp_total + kIndexSlack), otiles((size_t)tmp_total + kIndexSlack);
+  SlabFuseArgs fz;
+  fz.am = fu.am; fz.bm = fu.bm; fz.thr_m = fu.threshold;
+  fz.xexp = in.val.p; fz.xoff = in.off.p; fz.xmin = in.first.p; fz.xmax = in.last.p;
+  fz.dexp = dop.dexp.p; fz.doff = dop.doff.p; fz.dmin = dop.dmin.p; fz.dmax = dop.dmax.p;
+  fz.ofirst = ofirst.p; fz.olast = olast.p; fz.tiles = otiles.p;
+  fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
+  fz.col_offset = fu.col_offset;
+  DevBuf<char> fz_args(sizeof(SlabFuseArgs));
+  fz_args.upload(reinterpret_cast<const char*>(&fz), sizeof(SlabFuseArgs));
+  const int dr = dense_rule ? 1 : 0;
+  t_num.start();
+  auto launch = [&](auto nw_tag, auto mode_tag, auto epi_tag) {
+    constexpr int FNW = decltype(nw_tag)::value;
+    hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, FNW, decltype(mode_tag)::value, decltype(epi_tag)::value>),
+                       dim3(xcd_grid(snb)), dim3(FNW * WAVE), 0, stream(), reinterpret_cast<const SlabRun*>(runs.p),
+                       in.tiles.p, in.tile_off.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, (int32_t*)nullptr,
+                       oval.p, count.p, 1.0, threshold, dr, n, snb, reinterpret_cast<const SlabFuseArgs*>(fz_args.p));
+  };
+  auto by_mode = [&](auto nw_tag, auto mode_tag) {
+    if (fu.mode == 1) launch(nw_tag, mode_tag, std::integral_constant<int, 1>{});
+    else launch(nw_tag, mode_tag, std::integral_constant<int, 2>{});
+  };
+  if (max_w > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
+  else if (max_w > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
+  else by_mode(std::integral_constant<int, SLAB_NW>{}, std::integral_constant<int, 8>{});
+  t_num.stop();
+  DevBuf<double> lvl((size_t)5 * FT_BLOCKS), tot(5);
+  hipLaunchKernelGGL(k_fused_totals, dim3(FT_BLOCKS), dim3(256), 0, stream(), count.p, n,
+                     reinterpret_cast<const long long*>(fz_pnnz), (const long long*)nullptr, fz_part, snb,
+                     (const double*)nullptr, lvl.p, 0);
+  hipLaunchKernelGGL(k_fused_totals, dim3(1), dim3(256), 0, stream(), (const int32_t*)nullptr, 0, (const long long*)nullptr,
+                     (const long long*)nullptr, (const double*)nullptr, 0, lvl.p, tot.p, 1);
+  unsigned long long raw[5] = {0, 0, 0, 0, 0};
+  int64_t flagv[1] = {0};
+  {
+    ScalarFetch f;
+    f.add(tot.p, 5, raw);
+    f.add(fz_flag, 1, flagv);
+    f.run();
+  }
+  t_all.stop();
+  if (timing) {
+    if (pending_timings().size() >= 4096) flush_spgemm_timers();
+    pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+  }
+  if ((int32_t)flagv[0] != 0) {   // (SlabFuseArgs) X is untouched: the caller repeats the step on the unfused path
+    fu.refused += 1;
+    fusion_counts()[2] += 1;
+    return false;
+  }
+  const int64_t nnz = (int64_t)raw[0], pnz = (int64_t)raw[1];
+  double hd[2];
+  std::memcpy(hd, &raw[3], 2 * sizeof(double));
+  const int64_t nnz_in = X.nnz;
+  DevMat R;
+  R.rows = X.rows;
+  R.cols = n;
+  R.cplx = false;
+  R.nnz = nnz;
+  R.zero_free = 1;
+  R.slab.reset(new SlabForm());
+  R.slab->first = std::move(ofirst);
+  R.slab->last = std::move(olast);
+  R.slab->count = std::move(count);
+  R.slab->off = std::move(tmpoff);
+  R.slab->tile_off = std::move(blk_toff);
+  R.slab->val = std::move(oval);
+  R.slab->tiles = std::move(otiles);
+  R.slab->slots = tmp_total;
+  X = std::move(R);
+  fu.done = true;
+  fu.dot = hd[0];
+  fu.trace = hd[1];
+  fu.product_nnz = pnz;
+  fusion_counts()[fu.mode == 1 ? 0 : 1] += 1;
+  st.slab = 1;
+  st.fused = fu.mode;
+  st.nnz_c = pnz;
+  st.tmp_entries = tmp_total;
+  st.products = -1;   // not counted on this path
+  last_spgemm_stats() = st;
+  SpgemmAccum& acc = spgemm_accum();
+  acc.calls += 1;
+  acc.nnz_c += pnz;
+  acc.alg_bytes += 12.0 * (double)(2 * nnz_in + pnz) + 4.0 * (3.0 * n + 3);
+  return true;
 }
 
 // -------------------------------------------------------------------------------------
@@ -3490,6 +3707,30 @@ void dot_trace_impl(const DevMat& A, const DevMat& B, double out[2], double* tra
                     const int64_t* d_extra, int n_extra, int64_t* extra_out);
 }
 DevMat packed_copy(const DevMat& M) {
+  if (M.expanded()) {
+    const SlabForm& f = *M.slab;
+    DevMat R;
+    R.rows = M.rows;
+    R.cols = M.cols;
+    R.cplx = false;
+    R.zero_free = 1;
+    const int n = M.cols;
+    R.outer.alloc((size_t)n + 1);
+    scan_async<int32_t>(f.count.p, R.outer.p, (int64_t)n);
+    int64_t nnz = 0;
+    {
+      ScalarFetch ft;
+      ft.add(R.outer.p + n, 1, &nnz);
+      ft.run();
+    }
+    R.nnz = nnz;
+    R.inner.alloc((size_t)nnz + kIndexSlack);
+    R.val.alloc((size_t)nnz + kIndexSlack);
+    if (n)
+      hipLaunchKernelGGL(k_pack_slab, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, f.first.p, f.last.p,
+                         f.off.p, f.val.p, R.outer.p, R.inner.p, R.val.p);
+    return R;
+  }
   if (!M.loose()) return M.clone();
   DevMat R;
   R.rows = M.rows;
@@ -3520,7 +3761,7 @@ DevMat packed_copy(const DevMat& M) {
 }
 
 void pack(DevMat& M) {
-  if (M.loose()) M = packed_copy(M);
+  if (M.loose() || M.expanded()) M = packed_copy(M);
 }
 
 bool square_keep_loose(DevMat& X, double threshold, bool dense_rule, const DevMat& D, double out[2], double* trace_out,
@@ -3532,6 +3773,15 @@ bool square_keep_loose(DevMat& X, double threshold, bool dense_rule, const DevMa
   fu.mode = options().fused_update ? 1 : 0;
   fu.D = &D;
   fu.col_offset = col_offset;
+  if (X.expanded()) {
+    if (slab_step(X, fu, threshold, dense_rule)) {
+      out[0] = fu.dot;
+      out[1] = 0.0;
+      if (trace_out) *trace_out = fu.trace;
+      return true;
+    }
+    pack(X);
+  }
   spgemm(X, X, AB, 1.0, threshold, dense_rule, &L, nullptr, fu.mode ? &fu : nullptr);
   if (fu.done) {  // dot and trace came out of the multiply's epilogue
     X = std::move(fu.result);
@@ -3645,6 +3895,11 @@ namespace {
 void dot_trace_impl(const DevMat& A, const DevMat& B, double out[2], double* trace_out, int32_t col_offset,
                     const int64_t* d_extra, int n_extra, int64_t* extra_out) {
   if (A.rows != B.rows || A.cols != B.cols || A.cplx != B.cplx) NTP_FATAL("dot: operand mismatch");
+  if (A.expanded()) {
+    DevMat P = packed_copy(A);
+    dot_trace_impl(P, B, out, trace_out, col_offset, d_extra, n_extra, extra_out);
+    return;
+  }
   out[0] = out[1] = 0;
   if (trace_out) *trace_out = 0.0;
   if (A.nnz == 0) return;
@@ -3689,6 +3944,10 @@ void grand_sum(const DevMat& A, double out[2]) {
 
 double trace(const DevMat& A, int32_t col_offset) {
   if (A.nnz == 0) return 0.0;
+  if (A.expanded()) {
+    DevMat P = packed_copy(A);
+    return trace(P, col_offset);
+  }
   const int nb = std::min(cdiv(A.cols, 256), 1024);
   DevBuf<double> partial((size_t)2 * nb);
   dispatch_type(A.cplx, [&](auto tag) {

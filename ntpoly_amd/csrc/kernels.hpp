@@ -106,6 +106,9 @@ struct SlabFusion {
 };
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold,
             bool dense_rule, LooseProduct* loose = nullptr, const ColRange* arange = nullptr, SlabFusion* fuse = nullptr);
+// the same step on an iterate already in slab form (DevMat::slab, written by a previous fused step): X is replaced by
+// the result (again in slab form).  false: not taken (X unchanged; pack() it and use spgemm)
+bool slab_step(DevMat& X, SlabFusion& fuse, double threshold, bool dense_rule);
 // since start: [0] steps computed with SlabFusion mode 1, [1] mode 2, [2] fused steps repeated on the unfused path
 long long* fusion_counts();
 

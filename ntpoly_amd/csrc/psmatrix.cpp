@@ -515,6 +515,15 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
     fu.threshold = threshold;
     fu.D = &D.loc;
     fu.col_offset = B.c0;
+    if (B.loc.expanded()) {   // the iterate is in the kernel's own form already: no preparation pass at all
+      if (fu.mode && slab_step(B.loc, fu, threshold, dense_rule)) {
+        out[0] = fu.dot;
+        out[1] = 0.0;
+        out[2] = fu.trace;
+        return;
+      }
+      pack(B.loc);
+    }
     spgemm(B.loc, B.loc, AB, 1.0, threshold, dense_rule, &L, nullptr, fu.mode ? &fu : nullptr);
     if (fu.done) {
       B.loc = std::move(fu.result);
