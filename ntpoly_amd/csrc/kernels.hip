@@ -876,6 +876,8 @@ struct SlabFuseArgs {
   double* tiles = nullptr;           // the result as tiles (SlabForm::tiles), block b at blk_toff[b]
   double* part = nullptr;            // [2 * nblocks]: (dot, trace) of the block
   long long* pnnz = nullptr;         // [nblocks]: kept entries of the product
+  const int32_t* in_count = nullptr; // statistics (operand in slab form): entries per column of X; with prod set, the
+  long long* prod = nullptr;         // block counts its intermediate products from its multiplier tile before the loop
   int* flag = nullptr;
   int col_offset = 0;
 };
@@ -931,6 +933,25 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
       const int dn = cs_dn[jj], ofs = cs_dofs[jj];
       const double* src = fz0.dexp + fz0.doff[min(b * J + jj, ncols - 1)];
       for (int i = threadIdx.x; i < dn; i += NW * WAVE) dtile[ofs + i] = src[i];
+    }
+    if (fz0.prod) {   // products of this block = sum over the tile rows k of (non-zero multipliers) * (entries of A(:, k))
+      const double* __restrict__ tile = bblk + blk_boff[b];
+      long long p = 0;
+      for (int k = threadIdx.x; k < kn; k += NW * WAVE) {
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < J; ++q) c += tile[(size_t)k * J + q] != 0.0 ? 1 : 0;
+        p += (long long)c * fz0.in_count[kmin + k];
+      }
+      p = wave_sum_i64(p);
+      __shared__ long long prod_s[NW];
+      if (lane == 0) prod_s[wave] = p;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int q = 0; q < NW; ++q) t += prod_s[q];
+        fz0.prod[b] = t;
+      }
     }
   }
   const int rbase = lo + WAVE * wave;  // slab s of this wave starts at row rbase + 64*NW*s
@@ -3440,6 +3461,11 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   fz.ofirst = ofirst.p; fz.olast = olast.p; fz.tiles = otiles.p;
   fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
   fz.col_offset = fu.col_offset;
+  int64_t* blk_prod = zwords.p + 3 + snb;
+  if (timing) {   // (statistics only)
+    fz.in_count = in.count.p;
+    fz.prod = reinterpret_cast<long long*>(blk_prod);
+  }
   DevBuf<char> fz_args(sizeof(SlabFuseArgs));
   fz_args.upload(reinterpret_cast<const char*>(&fz), sizeof(SlabFuseArgs));
   const int dr = dense_rule ? 1 : 0;
@@ -3461,7 +3487,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   t_num.stop();
   DevBuf<double> lvl((size_t)5 * FT_BLOCKS), tot(5);
   hipLaunchKernelGGL(k_fused_totals, dim3(FT_BLOCKS), dim3(256), 0, stream(), count.p, n,
-                     reinterpret_cast<const long long*>(fz_pnnz), (const long long*)nullptr, fz_part, snb,
+                     reinterpret_cast<const long long*>(fz_pnnz), reinterpret_cast<const long long*>(blk_prod), fz_part, snb,
                      (const double*)nullptr, lvl.p, 0);
   hipLaunchKernelGGL(k_fused_totals, dim3(1), dim3(256), 0, stream(), (const int32_t*)nullptr, 0, (const long long*)nullptr,
                      (const long long*)nullptr, (const double*)nullptr, 0, lvl.p, tot.p, 1);
@@ -3512,10 +3538,11 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   st.fused = fu.mode;
   st.nnz_c = pnz;
   st.tmp_entries = tmp_total;
-  st.products = -1;   // not counted on this path
+  st.products = timing ? (int64_t)raw[2] : -1;   // (counted only with the timers on)
   last_spgemm_stats() = st;
   SpgemmAccum& acc = spgemm_accum();
   acc.calls += 1;
+  if (timing) acc.products += (int64_t)raw[2];
   acc.nnz_c += pnz;
   acc.alg_bytes += 12.0 * (double)(2 * nnz_in + pnz) + 4.0 * (3.0 * n + 3);
   return true;

@@ -808,6 +808,7 @@ def test_process_slices_semantics_vs_reference(nt):
 def _trs2_run(nt, n, col, row, val, thr, iters, fused, loose):
     nt.set_option("fused_update", fused)
     nt.set_option("loose_iterates", loose)
+    nt.set_option("time_kernels", 1)     # (the statistics below are kept only with the timers on)
     try:
         H = nt.Matrix_ps.from_triplets(n, col, row, val)
         ISQ = nt.Matrix_ps(n)
@@ -819,14 +820,17 @@ def _trs2_run(nt, n, col, row, val, thr, iters, fused, loose):
         p.SetMaxIterations(iters)
         p.SetMonitorConvergence(False)
         before = nt.fusion_counts()
+        nt.reset_spgemm_accum()
         energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, p)
+        acc = nt.spgemm_accum()
         after = nt.fusion_counts()
         tr = nt.solver_trace()
-        return dict(energy=energy, mu=mu, tr=tr, K=K.triplets(),
+        return dict(energy=energy, mu=mu, tr=tr, K=K.triplets(), acc=acc,
                     counts={k: after[k] - before[k] for k in after})
     finally:
         nt.set_option("fused_update", 1)
         nt.set_option("loose_iterates", 1)
+        nt.set_option("time_kernels", 0)
 
 
 @pytest.mark.parametrize("case", ["banded", "holes", "tall", "wide_d", "stored_zeros"])
@@ -866,6 +870,10 @@ def test_trs2_fused_steps_match_the_separate_passes(nt, case):
         for q in range(2):
             assert np.array_equal(got["K"][q], ref["K"][q]), tag
         assert np.array_equal(got["K"][2], ref["K"][2]), tag
+        # the statistics of the multiplies: the same intermediate products and product entries on every path
+        assert got["acc"]["calls"] == ref["acc"]["calls"], tag
+        assert got["acc"]["products"] == ref["acc"]["products"], tag
+        assert got["acc"]["nnz_c"] == ref["acc"]["nnz_c"], tag
         c = got["counts"]
         if fused and case == "wide_d":
             assert c["square"] == c["update"] == c["repeated"] == 0, (tag, c)
