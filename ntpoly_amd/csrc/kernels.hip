@@ -1004,29 +1004,25 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     __shared__ double red_s[2 * NW];
     __shared__ long long pn_s[NW];
     // (lane s * J + jj of amaxv / cntv keeps the scalar of slab s, column jj)
-    int pn = 0, amaxv = -1;
+    if constexpr (EPI == 2) {   // first pass: last kept row of every product column, entries of the product
+      int pn = 0, amaxv = -1;
 #pragma unroll
-    for (int s = 0; s < SL; ++s) {
+      for (int s = 0; s < SL; ++s) {
 #pragma unroll
-      for (int jj = 0; jj < J; ++jj) {
-        const double v = acc[s][jj];
-        const double sv = __dmul_rn(alpha, v);
-        const bool ha = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
-        const unsigned long long m = __ballot(ha);
-        pn += __popcll(m);
-        if constexpr (EPI == 2) {
+        for (int jj = 0; jj < J; ++jj) {
+          const double v = acc[s][jj];
+          const double sv = __dmul_rn(alpha, v);
+          const bool ha = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+          const unsigned long long m = __ballot(ha);
+          pn += __popcll(m);
           const int last = m ? lo + WAVE * (wave + NW * s) + 63 - __clzll((long long)m) : -1;
           asm("v_writelane_b32 %0, %1, %2" : "+v"(amaxv) : "s"(last), "n"(s * J + jj));
         }
       }
-    }
-    if constexpr (EPI == 2) {
       if (lane < SL * J) amax_s[wave + NW * (lane / J)][lane % J] = amaxv;
-    }
-    if (lane == 0) pn_s[wave] = pn;
-    __syncthreads();
-    if (threadIdx.x < J) {
-      if constexpr (EPI == 2) {
+      if (lane == 0) pn_s[wave] = pn;
+      __syncthreads();
+      if (threadIdx.x < J) {
         int mx = -1;
         for (int m = 0; m < NW * SL; ++m) mx = max(mx, amax_s[m][threadIdx.x]);
         amax_f[threadIdx.x] = mx;
@@ -1036,13 +1032,13 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
           if (l >= f && (f < lo || l >= lo + w)) atomicOr(fz.flag, 1);
         }
       }
+      if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int q = 0; q < NW; ++q) t += pn_s[q];
+        fz.pnnz[b] = t;
+      }
+      __syncthreads();
     }
-    if (threadIdx.x == 0) {
-      long long t = 0;
-      for (int q = 0; q < NW; ++q) t += pn_s[q];
-      fz.pnnz[b] = t;
-    }
-    __syncthreads();
     double dsum = 0.0, tsum = 0.0;
     int cntv = 0, firstv = INT_MAX, lastv = -1;   // (lane s * J + jj: entries / first / last kept row of that slab and column)
 #pragma unroll
@@ -1124,6 +1120,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       col_first[threadIdx.x] = cf;
       col_last[threadIdx.x] = cl;
+      if constexpr (EPI == 1) amax_f[threadIdx.x] = run;   // (the product is the result: its entries per column)
       const int j = b * J + threadIdx.x;
       if (j < ncols) {
         count[j] = run;
@@ -1138,6 +1135,13 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
       fz.part[2 * b + 1] = y;
     }
     __syncthreads();
+    if constexpr (EPI == 1) {
+      if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int jj = 0; jj < J; ++jj) t += amax_f[jj];
+        fz.pnnz[b] = t;
+      }
+    }
     // ---- the result in slab form (SlabForm): every column as a dense run, the block as a row-major tile
     const int64_t tbase = blk_toff[b];
     int tk0 = INT_MAX, tk1 = -1;
@@ -3453,7 +3457,10 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   DevBuf<char> runs(((size_t)n + 4) * sizeof(SlabRun));
   hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(n + 4, 256)), dim3(256), 0, stream(), in.first.p, in.last.p, in.off.p,
                      reinterpret_cast<const char*>(in.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), n);
-  DevBuf<double> oval((size_t)tmp_total + kIndexSlack), otiles((size_t)tmp_total + kIndexSlack);
+  // (a fifth more than needed: the iterates fill in over the first steps of a solve, and a block that is too small
+  // next time costs a hipMalloc inside the loop)
+  const size_t oslots = (size_t)tmp_total + (size_t)tmp_total / 5 + kIndexSlack;
+  DevBuf<double> oval(oslots), otiles(oslots);
   SlabFuseArgs fz;
   fz.am = fu.am; fz.bm = fu.bm; fz.thr_m = fu.threshold;
   fz.xexp = in.val.p; fz.xoff = in.off.p; fz.xmin = in.first.p; fz.xmax = in.last.p;
