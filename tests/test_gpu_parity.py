@@ -833,7 +833,7 @@ def _trs2_run(nt, n, col, row, val, thr, iters, fused, loose):
         nt.set_option("time_kernels", 0)
 
 
-@pytest.mark.parametrize("case", ["banded", "holes", "tall", "wide_d", "stored_zeros"])
+@pytest.mark.parametrize("case", ["banded", "holes", "ragged", "threshold0", "tall", "wide_d", "stored_zeros"])
 def test_trs2_fused_steps_match_the_separate_passes(nt, case):
     """The TRS2 step computed inside the SpGEMM kernel's epilogue (kernels.hpp SlabFusion: X*X or 2X - X*X, energy and
     trace in one kernel, the iterate left in its slots) against the same solve with the product, the merge and the
@@ -848,6 +848,10 @@ def test_trs2_fused_steps_match_the_separate_passes(nt, case):
         n, h, thr, iters = 6144, 300, 1e-6, 8       # sixteen columns of WH exceed the LDS tile: no fusion, same results
     elif case == "stored_zeros":
         n, h, thr, iters = 768, 6, 0.0, 4
+    elif case == "ragged":
+        n, h, thr, iters = 4099, 25, 1e-6, 12       # last block of 16 columns incomplete
+    elif case == "threshold0":
+        n, h, thr, iters = 1024, 10, 0.0, 5         # nothing is ever dropped
     else:
         n, h, thr, iters = 8192, 40, 1e-7, 14
     col, row, val = banded_triplets(n, h)
