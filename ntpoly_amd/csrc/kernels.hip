@@ -896,9 +896,15 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
   const int wave = uni_i32(threadIdx.x / WAVE), lane = lane_id();
   const int lo = blk_lo[b], kmin = blk_kmin[b], kn = blk_kn[b], w = blk_w[b];
   if (kn == 0) {
-    if constexpr (EPI != 0) {   // (no entries in these columns of X: none in the result)
+    if constexpr (EPI != 0) {   // no product entries in these columns
       const int j = b * J + threadIdx.x;
-      if (threadIdx.x < J && j < ncols) { fzp->ofirst[j] = INT_MAX; fzp->olast[j] = -1; }
+      if (threadIdx.x < J && j < ncols) {
+        fzp->ofirst[j] = INT_MAX;
+        fzp->olast[j] = -1;
+        // (EPI 2: ... and none in the result only if the columns of X are empty as well; otherwise -- columns of X
+        // whose rows name empty columns, an unsymmetric pattern -- the step is not this kernel's)
+        if (EPI == 2 && fzp->xmax[j] >= fzp->xmin[j]) atomicOr(fzp->flag, 1);
+      }
     }
     return;
   }
@@ -3054,19 +3060,25 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                          blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb);
     };
     // fused epilogue of a purification step (SlabFusion): the same loop, the result leaves the registers merged
-    fuse_now = fuse != nullptr && fuse->mode != 0 && &A == &B && !arange && m == n && abl == 0 && !options().spgemm_fma &&
-               sv_opt < 0 && fuse->D && !fuse->D->cplx && !fuse->D->loose() && fuse->D->rows == m && fuse->D->cols == n;
-    if (fuse_now && fuse->mode == 2 && A.zero_free != 1) {
+    // (one rank: A and B are the iterate itself; a rank of several: B is its column panel [panel_c0, panel_c0 + n) of
+    // the iterate and A holds -- at least -- those columns, as the gathered halo operand does)
+    const bool whole = &A == &B && !arange && m == n && fuse && fuse->panel_c0 < 0;
+    const bool panel = fuse && fuse->panel_c0 >= 0 && &A != &B && A.cols == m && ka <= fuse->panel_c0 && fuse->panel_c0 + n <= kb;
+    const int xshift = panel ? fuse->panel_c0 - ka : 0;   // own column j = local column xshift + j of the A-side arrays
+    fuse_now = fuse != nullptr && fuse->mode != 0 && (whole || panel) && abl == 0 && !options().spgemm_fma &&
+               sv_opt < 0 && fuse->D && !fuse->D->cplx && !fuse->D->loose() && !fuse->D->expanded() && fuse->D->rows == m &&
+               fuse->D->cols == n;
+    if (fuse_now && fuse->mode == 2 && B.zero_free != 1) {
       // the merge reads a zero of the expanded columns of X as "no entry": make sure no stored value is one (once per
       // solve: the results of the fused steps are zero-free by construction)
       DevBuf<unsigned long long> zc(1);
       zc.zero();
-      hipLaunchKernelGGL(k_count_zero_values, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), lview(A), zc.p);
+      hipLaunchKernelGGL(k_count_zero_values, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), lview(B), zc.p);
       unsigned long long hz = 0;
       ScalarFetch f;
       f.add(zc.p, 1, &hz);
       f.run();
-      if (hz == 0) A.zero_free = 1;
+      if (hz == 0) B.zero_free = 1;
       else fuse_now = false;
     }
     const DotOperand* dop_p = fuse_now ? &dot_operand(*fuse->D) : nullptr;
@@ -3075,7 +3087,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       const DotOperand& dop = *dop_p;
       SlabFuseArgs fz;
       fz.am = fuse->am; fz.bm = fuse->bm; fz.thr_m = fuse->threshold;
-      fz.xexp = aexp.p; fz.xoff = aeoff.p; fz.xmin = cmin_own.p; fz.xmax = cmax_own.p;
+      fz.xexp = aexp.p; fz.xoff = aeoff.p + xshift; fz.xmin = cmin_own.p + xshift; fz.xmax = cmax_own.p + xshift;
       fz.dexp = dop.dexp.p; fz.doff = dop.doff.p; fz.dmin = dop.dmin.p; fz.dmax = dop.dmax.p;
       fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
       fz.col_offset = fuse->col_offset;
@@ -3405,9 +3417,31 @@ __global__ __launch_bounds__(256) void k_pack_slab(int ncols, const int32_t* __r
 }
 }  // namespace
 
-bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
+namespace {
+// run records from run addresses (panel steps: the runs of the halo columns sit in the receive buffer)
+__global__ void k_slab_runs_addr(const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                 const unsigned long long* __restrict__ addr, unsigned long long fallback,
+                                 SlabRun* __restrict__ runs, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n + 4) return;
+  const bool any = k < n && last[k] >= first[k];
+  SlabRun r;
+  const unsigned long long a = any ? addr[k] : fallback;
+  r.addr_lo = (uint32_t)a;
+  r.addr_hi = (uint32_t)(a >> 32) & 0xffffu;
+  r.nbytes = any ? (uint32_t)(last[k] - first[k] + 1) * 8u : 0u;
+  r.flags = kBufferFlags;
+  r.first = any ? first[k] : (1 << 30);
+  r.first8 = any ? first[k] * 8 : 0;
+  r.span62 = any ? (last[k] - first[k] + 1) + 62 : 0;
+  r.pad = 0;
+  runs[k] = r;
+}
+}  // namespace
+
+bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, const SlabHalo* halo) {
   fu.done = false;
-  if (!X.expanded() || X.cplx || X.rows != X.cols || !fu.D || fu.D->cplx || fu.D->loose() || fu.D->expanded() ||
+  if (!X.expanded() || X.cplx || (!halo && X.rows != X.cols) || !fu.D || fu.D->cplx || fu.D->loose() || fu.D->expanded() ||
       fu.D->rows != X.rows || fu.D->cols != X.cols || (fu.mode != 1 && fu.mode != 2))
     return false;
   if (options().spgemm_variant >= 0 || options().spgemm_fma || options().spgemm_force_bin > 0 || !options().fused_update)
@@ -3432,8 +3466,13 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   int64_t* fz_pnnz = zwords.p + 2;
   double* fz_part = reinterpret_cast<double*>(zwords.p + 3 + 2 * (size_t)snb);
   unsigned long long* stats = reinterpret_cast<unsigned long long*>(zwords.p + 4 * (size_t)snb + 4);
+  // (A side: the iterate's own columns, or -- a panel step -- the columns ka .. kb of the distributed iterate,
+  // addressed with global column numbers through biased pointers)
+  const int ka = halo ? halo->ka : 0, nka = halo ? halo->kb - halo->ka : n;
+  const int32_t* afirst = halo ? halo->first - ka : in.first.p;
+  const int32_t* alast = halo ? halo->last - ka : in.last.p;
   hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, in.first.p,
-                     in.last.p, in.first.p, in.last.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
+                     in.last.p, afirst, alast, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
   hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, (const int32_t*)nullptr, 0, stats);
   scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
   int64_t tmp_total = 0;
@@ -3454,9 +3493,13 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   };
   if (max_w <= 0 || max_w > 8 * SLAB_SL * WAVE) return give_up();
   hipLaunchKernelGGL((k_slab_tmpoff<SLAB_J>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
-  DevBuf<char> runs(((size_t)n + 4) * sizeof(SlabRun));
-  hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(n + 4, 256)), dim3(256), 0, stream(), in.first.p, in.last.p, in.off.p,
-                     reinterpret_cast<const char*>(in.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), n);
+  DevBuf<char> runs(((size_t)nka + 4) * sizeof(SlabRun));
+  if (halo)
+    hipLaunchKernelGGL(k_slab_runs_addr, dim3(cdiv(nka + 4, 256)), dim3(256), 0, stream(), halo->first, halo->last, halo->addr,
+                       (unsigned long long)reinterpret_cast<uintptr_t>(in.val.p), reinterpret_cast<SlabRun*>(runs.p), nka);
+  else
+    hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(n + 4, 256)), dim3(256), 0, stream(), in.first.p, in.last.p, in.off.p,
+                       reinterpret_cast<const char*>(in.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), n);
   // (a fifth more than needed: the iterates fill in over the first steps of a solve, and a block that is too small
   // next time costs a hipMalloc inside the loop)
   const size_t oslots = (size_t)tmp_total + (size_t)tmp_total / 5 + kIndexSlack;
@@ -3469,8 +3512,8 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
   fz.col_offset = fu.col_offset;
   int64_t* blk_prod = zwords.p + 3 + snb;
-  if (timing) {   // (statistics only)
-    fz.in_count = in.count.p;
+  if (timing && (!halo || halo->count)) {   // (statistics only; the tile rows are global column numbers)
+    fz.in_count = halo ? halo->count - ka : in.count.p;
     fz.prod = reinterpret_cast<long long*>(blk_prod);
   }
   DevBuf<char> fz_args(sizeof(SlabFuseArgs));
@@ -3480,7 +3523,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   auto launch = [&](auto nw_tag, auto mode_tag, auto epi_tag) {
     constexpr int FNW = decltype(nw_tag)::value;
     hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, FNW, decltype(mode_tag)::value, decltype(epi_tag)::value>),
-                       dim3(xcd_grid(snb)), dim3(FNW * WAVE), 0, stream(), reinterpret_cast<const SlabRun*>(runs.p),
+                       dim3(xcd_grid(snb)), dim3(FNW * WAVE), 0, stream(), reinterpret_cast<const SlabRun*>(runs.p) - ka,
                        in.tiles.p, in.tile_off.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, (int32_t*)nullptr,
                        oval.p, count.p, 1.0, threshold, dr, n, snb, reinterpret_cast<const SlabFuseArgs*>(fz_args.p));
   };
@@ -3535,7 +3578,8 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   R.slab->val = std::move(oval);
   R.slab->tiles = std::move(otiles);
   R.slab->slots = tmp_total;
-  X = std::move(R);
+  if (halo) fu.result = std::move(R);   // (the ranks agree first: the caller installs it)
+  else X = std::move(R);
   fu.done = true;
   fu.dot = hd[0];
   fu.trace = hd[1];
@@ -3545,11 +3589,12 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule) {
   st.fused = fu.mode;
   st.nnz_c = pnz;
   st.tmp_entries = tmp_total;
-  st.products = timing ? (int64_t)raw[2] : -1;   // (counted only with the timers on)
+  const bool counted = timing && (!halo || halo->count);
+  st.products = counted ? (int64_t)raw[2] : -1;   // (counted only with the timers on)
   last_spgemm_stats() = st;
   SpgemmAccum& acc = spgemm_accum();
   acc.calls += 1;
-  if (timing) acc.products += (int64_t)raw[2];
+  if (counted) acc.products += (int64_t)raw[2];
   acc.nnz_c += pnz;
   acc.alg_bytes += 12.0 * (double)(2 * nnz_in + pnz) + 4.0 * (3.0 * n + 3);
   return true;
@@ -4297,6 +4342,108 @@ void halo_bounds_async(const DevMat& A, int32_t c0, const int32_t* d_sa, const i
   if (P > 1024) NTP_FATAL("halo_bounds: too many ranks");
   hipLaunchKernelGGL(k_halo_bounds, dim3(1), dim3(1024), 0, stream(), A.outer.p, c0, d_sa, d_sb, P,
                      reinterpret_cast<long long*>(d_bound), reinterpret_cast<long long*>(d_cnt_row));
+}
+
+// ------------------------------------------------------------------ halo exchange of a panel in slab form
+namespace {
+__global__ void k_slab_request(const int32_t* __restrict__ first, const int32_t* __restrict__ last, int n, long long nnz,
+                               long long* __restrict__ out4) {
+  // out4[0], out4[1] were preset to (INT_MAX, -1)
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool has = j < n && last[j] >= first[j];
+  const int lo = wave_min_i32(has ? first[j] : INT_MAX), hi = wave_max_i32(has ? last[j] : -1);
+  if (lane_id() == 0 && hi >= lo) {
+    atomicMin(&out4[0], (long long)lo);
+    atomicMax(&out4[1], (long long)hi);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out4[2] = out4[3] = nnz;
+}
+__global__ void k_slab_extents(const int32_t* __restrict__ first, const int32_t* __restrict__ last, int n,
+                               long long* __restrict__ ext, int32_t* __restrict__ span) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int f = first[j], l = last[j];
+  ext[j] = (long long)(unsigned)f | ((long long)l << 32);
+  span[j] = l >= f ? l - f + 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_slab_pack_runs(const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                                        const int64_t* __restrict__ off, const double* __restrict__ val,
+                                                        const int64_t* __restrict__ pre, int ja, int jb, double* __restrict__ dst) {
+  const int j = ja + (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= jb) return;
+  const int lane = lane_id();
+  const int f = first[j], l = last[j];
+  const double* __restrict__ src = val + off[j];
+  double* __restrict__ d = dst + (pre[j] - pre[ja]);
+  for (int i = lane; i <= l - f; i += WAVE) d[i] = src[i];
+}
+// extents and run addresses of the columns ka .. kb a rank needs: its own from its buffers, the others from the
+// receive buffer (source s: its segment [ra_s, rb_s) packed back to back at recv + zoff[s])
+__global__ void k_slab_halo_layout(const long long* __restrict__ ext_all, const long long* __restrict__ pre_all, int pitch,
+                                   int dim, int P, int me, int ka, int kb, const int32_t* __restrict__ ra,
+                                   const int64_t* __restrict__ zoff, const double* __restrict__ recv,
+                                   const int64_t* __restrict__ own_off, const double* __restrict__ own_val,
+                                   int32_t* __restrict__ first, int32_t* __restrict__ last,
+                                   unsigned long long* __restrict__ addr, const long long* __restrict__ cnt_all,
+                                   int32_t* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kb - ka) return;
+  const int k = ka + i;
+  int s = (int)(((long long)k * P) / dim);   // owner: the panel whose range holds k
+  while (s > 0 && (int)(((long long)dim * s) / P) > k) --s;
+  while (s + 1 < P && (int)(((long long)dim * (s + 1)) / P) <= k) ++s;
+  const int c0 = (int)(((long long)dim * s) / P);
+  const long long e = ext_all[(size_t)s * pitch + (k - c0)];
+  first[i] = (int)(unsigned)(e & 0xffffffffll);
+  last[i] = (int)(e >> 32);
+  const double* p;
+  if (s == me) p = own_val + own_off[k - c0];
+  else p = recv + zoff[s] + (pre_all[(size_t)s * pitch + (k - c0)] - pre_all[(size_t)s * pitch + (ra[s] - c0)]);
+  addr[i] = (unsigned long long)reinterpret_cast<uintptr_t>(p);
+  if (count) count[i] = (int32_t)cnt_all[(size_t)s * pitch + (k - c0)];
+}
+__global__ void k_widen_i32(const int32_t* __restrict__ src, long long* __restrict__ dst, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) dst[j] = src[j];
+}
+}  // namespace
+
+void slab_request_async(const DevMat& X, int64_t* d_out4) {
+  const long long init[2] = {INT_MAX, -1};
+  HIP_CHECK(hipMemcpyAsync(d_out4, init, sizeof(init), hipMemcpyHostToDevice, stream()));
+  hipLaunchKernelGGL(k_slab_request, dim3(std::max(1, cdiv(X.cols, 256))), dim3(256), 0, stream(), X.slab->first.p,
+                     X.slab->last.p, X.cols, (long long)X.nnz, reinterpret_cast<long long*>(d_out4));
+}
+
+void slab_extents_async(const DevMat& X, int64_t* d_ext, int64_t* d_pre) {
+  const int n = X.cols;
+  DevBuf<int32_t> span((size_t)n);
+  hipLaunchKernelGGL(k_slab_extents, dim3(cdiv(n, 256)), dim3(256), 0, stream(), X.slab->first.p, X.slab->last.p, n,
+                     reinterpret_cast<long long*>(d_ext), span.p);
+  scan_async<int32_t>(span.p, d_pre, (int64_t)n);
+}
+
+void slab_pack_runs_async(const DevMat& X, const int64_t* d_pre, int32_t ja, int32_t jb, double* dst) {
+  if (jb <= ja) return;
+  const SlabForm& f = *X.slab;
+  hipLaunchKernelGGL(k_slab_pack_runs, dim3(cdiv((int64_t)(jb - ja) * WAVE, 256)), dim3(256), 0, stream(), f.first.p, f.last.p,
+                     f.off.p, f.val.p, d_pre, ja, jb, dst);
+}
+
+void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, int pitch, int32_t dim, int P, int me,
+                            int32_t ka, int32_t kb, const int32_t* d_ra, const int64_t* d_zoff, const double* d_recv,
+                            const DevMat& X, int32_t* d_first, int32_t* d_last, unsigned long long* d_addr,
+                            const int64_t* d_cnt_all, int32_t* d_count) {
+  if (kb <= ka) return;
+  hipLaunchKernelGGL(k_slab_halo_layout, dim3(cdiv(kb - ka, 256)), dim3(256), 0, stream(),
+                     reinterpret_cast<const long long*>(d_ext_all), reinterpret_cast<const long long*>(d_pre_all), pitch, dim, P, me,
+                     ka, kb, d_ra, d_zoff, d_recv, X.slab->off.p, X.slab->val.p, d_first, d_last, d_addr,
+                     reinterpret_cast<const long long*>(d_cnt_all), d_count);
+}
+
+void slab_counts_async(const DevMat& X, int64_t* d_cnt64) {
+  hipLaunchKernelGGL(k_widen_i32, dim3(cdiv(X.cols, 256)), dim3(256), 0, stream(), X.slab->count.p,
+                     reinterpret_cast<long long*>(d_cnt64), X.cols);
 }
 
 void row_range(const DevMat& A, int32_t* lo, int32_t* hi) {

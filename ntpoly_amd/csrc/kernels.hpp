@@ -98,6 +98,7 @@ struct SlabFusion {
   double am = 0, bm = 0, threshold = 0;
   const DevMat* D = nullptr;
   int32_t col_offset = 0;
+  int32_t panel_c0 = -1;      // >= 0: B is the column panel [panel_c0, panel_c0 + cols) of the iterate, A holds those columns
   bool done = false;
   DevMat result;
   double dot = 0, trace = 0;
@@ -108,7 +109,26 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
             bool dense_rule, LooseProduct* loose = nullptr, const ColRange* arange = nullptr, SlabFusion* fuse = nullptr);
 // the same step on an iterate already in slab form (DevMat::slab, written by a previous fused step): X is replaced by
 // the result (again in slab form).  false: not taken (X unchanged; pack() it and use spgemm)
-bool slab_step(DevMat& X, SlabFusion& fuse, double threshold, bool dense_rule);
+struct SlabHalo {   // A side of a panel step: the columns ka .. kb (global numbers) of the distributed iterate
+  int32_t ka = 0, kb = 0;
+  const int32_t* first = nullptr;            // [kb - ka] device: extents of column ka + i
+  const int32_t* last = nullptr;
+  const unsigned long long* addr = nullptr;  // [kb - ka] device: address of its run (own buffer or receive buffer)
+  const int32_t* count = nullptr;            // [kb - ka] device, optional (statistics): entries of the column
+};
+// halo != nullptr: X is this rank's column panel; on success the result is left in fuse.result (not installed)
+bool slab_step(DevMat& X, SlabFusion& fuse, double threshold, bool dense_rule, const SlabHalo* halo = nullptr);
+// halo exchange of a panel in slab form (psmatrix.cpp ps_slab_step_dist): request record (first row, last row, nnz, nnz),
+// packed extents (first | last << 32) + prefix of the spans, runs of the local columns [ja, jb) packed back to back, and
+// the layout of the columns a rank needs (extents, run addresses in its own buffer or in the receive buffer)
+void slab_request_async(const DevMat& X, int64_t* d_out4);
+void slab_extents_async(const DevMat& X, int64_t* d_ext, int64_t* d_pre);
+void slab_pack_runs_async(const DevMat& X, const int64_t* d_pre, int32_t ja, int32_t jb, double* dst);
+void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, int pitch, int32_t dim, int P, int me,
+                            int32_t ka, int32_t kb, const int32_t* d_ra, const int64_t* d_zoff, const double* d_recv,
+                            const DevMat& X, int32_t* d_first, int32_t* d_last, unsigned long long* d_addr,
+                            const int64_t* d_cnt_all = nullptr, int32_t* d_count = nullptr);   // (statistics: entries per column)
+void slab_counts_async(const DevMat& X, int64_t* d_cnt64);
 // since start: [0] steps computed with SlabFusion mode 1, [1] mode 2, [2] fused steps repeated on the unfused path
 long long* fusion_counts();
 

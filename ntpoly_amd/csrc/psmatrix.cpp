@@ -482,6 +482,146 @@ void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, dou
   comm_allreduce_sum(out, want_trace ? 3 : 2);
 }
 
+namespace {
+// One TRS2 step of a rank whose panel is in slab form (kernels.hpp SlabForm): the halo travels as dense column runs
+// (8 bytes per row of a column's span, no row ids, no offsets: every rank derives the layout from the all-gathered
+// column extents), the run records of the kernel address the received runs where they land, the multiplier tiles are
+// local.  Protocol, all on the engine stream with ONE host synchronisation: (1) all-gather of the request records
+// (first / last row of the panel, nnz), of the packed extents and of the prefix sums of the spans; (2) a kernel
+// derives who sends how many doubles to whom, one read-back; (3) the runs of the requested columns are packed per
+// requester and exchanged in one send / recv group; (4) layout kernel, then slab_step.  Collective: every rank calls it.
+// Returns this rank's success; the result is in fu.result (the caller installs it when all ranks succeeded).
+bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold) {
+  Comm& c = world();
+  Transport& tr = *c.tr;
+  const int P = c.nranks, me = c.rank;
+  const int32_t dim = B.dim;
+  int32_t maxw = 0;
+  for (int q = 0; q < P; ++q) {
+    int32_t a0, a1;
+    panel_range(dim, P, q, &a0, &a1);
+    maxw = std::max(maxw, a1 - a0);
+  }
+  const int pitch = maxw + 1;
+  std::vector<int64_t> req((size_t)4 * P, 0), bound((size_t)2 * P, 0), cnt((size_t)P * P, 0);
+  DevBuf<int64_t> d_req((size_t)4 * P), d_ext_all((size_t)P * pitch), d_pre_all((size_t)P * pitch), d_bound((size_t)2 * P),
+      d_cnt((size_t)P * P);
+  slab_request_async(B.loc, d_req.p + 4 * me);
+  slab_extents_async(B.loc, d_ext_all.p + (size_t)me * pitch, d_pre_all.p + (size_t)me * pitch);
+  tr.allgather(d_req.p + 4 * me, d_req.p, 4 * sizeof(int64_t));
+  tr.allgather(d_ext_all.p + (size_t)me * pitch, d_ext_all.p, (size_t)pitch * sizeof(int64_t));
+  tr.allgather(d_pre_all.p + (size_t)me * pitch, d_pre_all.p, (size_t)pitch * sizeof(int64_t));
+  DevBuf<int64_t> d_cnt_all;   // statistics (timers on): entries per column of every panel, for the product count
+  if (options().time_kernels) {
+    d_cnt_all.alloc((size_t)P * pitch);
+    slab_counts_async(B.loc, d_cnt_all.p + (size_t)me * pitch);
+    tr.allgather(d_cnt_all.p + (size_t)me * pitch, d_cnt_all.p, (size_t)pitch * sizeof(int64_t));
+  }
+  halo_counts_async(d_req.p, d_pre_all.p, pitch, dim, P, me, d_cnt.p, d_bound.p);   // (counts in doubles here)
+  if ((size_t)4 * P + (size_t)P * P + 2 * P <= 500) {
+    ScalarFetch f;
+    f.add(d_req.p, 4 * P, req.data());
+    f.add(d_bound.p, 2 * P, bound.data());
+    f.add(d_cnt.p, P * P, cnt.data());
+    f.run();
+  } else {
+    HIP_CHECK(hipMemcpyAsync(req.data(), d_req.p, (size_t)4 * P * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(bound.data(), d_bound.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, stream()));
+    sync_stream();
+  }
+  exchange_stats().host_syncs += 1;
+  exchange_stats().exchanges += 1;
+  int64_t nnz_global = 0;
+  for (int q = 0; q < P; ++q) nnz_global += req[(size_t)4 * q + 2];
+  auto kmin_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? 0 : (int32_t)lo; };
+  auto kmax_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? -1 : (int32_t)hi; };
+  const int32_t kmin = kmin_of(me), kmax = kmax_of(me);
+  // what I send: my columns inside every requester's range, packed per requester
+  std::vector<int32_t> sa((size_t)P), sb((size_t)P);
+  std::vector<int64_t> soff((size_t)P + 1, 0);
+  for (int q = 0; q < P; ++q) {
+    halo_segment(dim, P, me, kmin_of(q), kmax_of(q), &sa[(size_t)q], &sb[(size_t)q]);
+    soff[(size_t)q + 1] = soff[(size_t)q] + (q == me ? 0 : cnt[(size_t)me * P + q]);
+  }
+  DevBuf<double> sendbuf((size_t)soff[(size_t)P] + 1);
+  for (int q = 0; q < P; ++q)
+    if (q != me && cnt[(size_t)me * P + q] > 0)
+      slab_pack_runs_async(B.loc, d_pre_all.p + (size_t)me * pitch, sa[(size_t)q] - B.c0, sb[(size_t)q] - B.c0,
+                           sendbuf.p + soff[(size_t)q]);
+  // what I receive: the segments of the other owners tile [kmin, kmax] in rank order
+  std::vector<int32_t> ra((size_t)P), rb((size_t)P);
+  std::vector<int64_t> zoff((size_t)P + 1, 0);
+  for (int s = 0; s < P; ++s) {
+    halo_segment(dim, P, s, kmin, kmax, &ra[(size_t)s], &rb[(size_t)s]);
+    zoff[(size_t)s + 1] = zoff[(size_t)s] + (s == me ? 0 : cnt[(size_t)s * P + me]);
+  }
+  DevBuf<double> recvbuf((size_t)zoff[(size_t)P] + kIndexSlack);
+  tr.group_begin();
+  for (int q = 0; q < P; ++q) {
+    const int64_t m = cnt[(size_t)me * P + q];
+    if (q != me && m > 0) tr.send(sendbuf.p + soff[(size_t)q], (size_t)m * sizeof(double), q);
+  }
+  for (int s = 0; s < P; ++s) {
+    const int64_t m = cnt[(size_t)s * P + me];
+    if (s != me && m > 0) tr.recv(recvbuf.p + zoff[(size_t)s], (size_t)m * sizeof(double), s);
+  }
+  tr.group_end();
+  if (kmax < kmin) return false;   // (an empty panel: nothing to multiply; the caller's consensus takes the other path)
+  // layout of the columns I need
+  const int32_t ka = kmin, kb = kmax + 1;
+  DevBuf<int32_t> d_ra((size_t)P), nfirst((size_t)(kb - ka)), nlast((size_t)(kb - ka));
+  DevBuf<int64_t> d_zoff((size_t)P);
+  DevBuf<unsigned long long> naddr((size_t)(kb - ka));
+  d_ra.upload(ra.data(), (size_t)P);
+  d_zoff.upload(zoff.data(), (size_t)P);
+  DevBuf<int32_t> ncount;
+  if (d_cnt_all.p) ncount.alloc((size_t)(kb - ka));
+  slab_halo_layout_async(d_ext_all.p, d_pre_all.p, pitch, dim, P, me, ka, kb, d_ra.p, d_zoff.p, recvbuf.p, B.loc, nfirst.p,
+                         nlast.p, naddr.p, d_cnt_all.p, ncount.p);
+  SlabHalo halo;
+  halo.ka = ka;
+  halo.kb = kb;
+  halo.first = nfirst.p;
+  halo.last = nlast.p;
+  halo.addr = naddr.p;
+  halo.count = ncount.p;
+  const double denom = (double)dim * (double)dim;
+  const bool dense_rule = denom > 0 && (double)nnz_global / denom > 0.1;
+  // (the buffers above are released on return: the allocator is stream ordered, and slab_step ends with a read-back)
+  return slab_step(B.loc, fu, threshold, dense_rule, &halo);
+}
+
+// TRS2 step across ranks with the fused kernel (mode 1: X <- X*X, mode 2: X <- 2X - X*X; energy and trace in out).
+// true: done on every rank.  false: nothing changed (the panel is in compressed columns again), the caller runs
+// the separate passes.  Collective.
+bool dist_fused_step(PSMatrix& B, int mode, double threshold, const PSMatrix& D, double out[4]) {
+  if (!B.loc.expanded()) return false;
+  const int P = world().nranks;
+  SlabFusion fu;
+  fu.mode = mode;
+  fu.am = -1.0;
+  fu.bm = 2.0;
+  fu.threshold = threshold;
+  fu.D = &D.loc;
+  fu.col_offset = B.c0;
+  fu.panel_c0 = B.c0;
+  const bool ok = slab_exchange_and_step(B, fu, threshold);
+  double v[4] = {ok ? fu.dot : 0.0, 0.0, ok ? fu.trace : 0.0, ok ? 1.0 : 0.0};
+  comm_allreduce_sum(v, 4);
+  if (v[3] == (double)P) {
+    B.loc = std::move(fu.result);
+    out[0] = v[0];
+    out[1] = 0.0;
+    out[2] = v[2];
+    out[3] = 0.0;
+    return true;
+  }
+  pack(B.loc);   // (some rank could not: every rank repeats the step on the unfused, equally collective path)
+  return false;
+}
+}  // namespace
+
 // TRS2, sigma > 0 (DensityMatrixSolversModule.F90:388-396): X2 = X*X; X = 2X - X2; energy = dot(X, D).  When the
 // register-slab kernel computes X*X the product is never compacted: the merge kernel reads it from its slots.
 void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
@@ -498,6 +638,8 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
   DevMat AB;
   // one rank: the iterate may stay loose from step to step (kernels.hpp, axpby keep_loose)
   const bool keep_loose = !world().active() && options().loose_iterates != 0;
+  const bool dist_fused = world().active() && options().fused_update != 0 && options().loose_iterates != 0;
+  if (dist_fused && dist_fused_step(B, 2, threshold, D, out)) return;
   if (!keep_loose) pack(B.loc);
   if (world().active()) {
     HaloExchange hx;
@@ -505,7 +647,38 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
     hx.finish();
     const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
     const ColRange need{hx.kmin, hx.kmax + 1};
-    spgemm(hx.full, B.loc, AB, 1.0, threshold, dense_rule, &L, &need);
+    SlabFusion fu;   // (as on one rank; B is the panel [c0, c1) of the iterate whose needed columns hx.full holds)
+    fu.mode = dist_fused ? 2 : 0;
+    fu.am = -1.0;
+    fu.bm = 2.0;
+    fu.threshold = threshold;
+    fu.D = &D.loc;
+    fu.col_offset = B.c0;
+    fu.panel_c0 = B.c0;
+    spgemm(hx.full, B.loc, AB, 1.0, threshold, dense_rule, &L, &need, fu.mode ? &fu : nullptr);
+    if (dist_fused) {
+      // the ranks must agree on the form of the iterate (the next step's exchange depends on it): slab form only if
+      // every rank's kernel produced it
+      if (fu.done) {
+        out[0] = fu.dot;
+        out[1] = 0.0;
+        out[2] = fu.trace;
+      } else if (L.valid) {
+        axpby(L, B.loc, -1.0, 2.0, threshold, &D.loc, out, &out[2], B.c0, nullptr, false);
+      } else {
+        scratch.grid = B.grid; scratch.dim = B.dim; scratch.c0 = B.c0; scratch.c1 = B.c1; scratch.cplx = B.cplx;
+        scratch.loc = std::move(AB);
+        axpby(scratch.loc, B.loc, -1.0, 2.0, threshold, &D.loc, out, &out[2], B.c0);
+      }
+      out[3] = fu.done ? 1.0 : 0.0;
+      comm_allreduce_sum(out, 4);
+      if (fu.done) {
+        B.loc = std::move(fu.result);
+        if (out[3] != (double)world().nranks) pack(B.loc);
+      }
+      out[3] = 0.0;
+      return;
+    }
   } else {
     const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
     SlabFusion fu;   // the whole update inside the multiply's epilogue when the register-slab kernel takes it
@@ -554,6 +727,43 @@ void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMat
     const double denom = (double)B.dim * (double)B.dim;
     const bool dense_rule = denom > 0 && (double)B.loc.nnz / denom > 0.1;
     if (square_keep_loose(B.loc, threshold, dense_rule, D.loc, out, want_trace ? &out[2] : nullptr, B.c0)) return;
+  }
+  const bool dist_fused = world().active() && options().fused_update != 0 && options().loose_iterates != 0 && !B.cplx &&
+                          !D.cplx && !(B.grid && B.grid->num_slices > 1);
+  if (dist_fused) {
+    if (dist_fused_step(B, 1, threshold, D, out)) return;
+    // from compressed panels: the product with the fused epilogue (energy, trace, slab form) where the kernel takes it
+    pack(B.loc);
+    const double denom = (double)B.dim * (double)B.dim;
+    int64_t nz[2] = {B.loc.nnz, B.loc.nnz};
+    HaloExchange hx;
+    gather_needed_begin(hx, B, B.loc, nz, false);
+    hx.finish();
+    const bool dense_rule = denom > 0 && std::min((double)nz[0] / denom, (double)nz[1] / denom) > 0.1;
+    const ColRange need{hx.kmin, hx.kmax + 1};
+    SlabFusion fu;
+    fu.mode = 1;
+    fu.D = &D.loc;
+    fu.col_offset = B.c0;
+    fu.panel_c0 = B.c0;
+    DevMat AB;
+    spgemm(hx.full, B.loc, AB, 1.0, threshold, dense_rule, nullptr, &need, &fu);
+    if (fu.done) {
+      out[0] = fu.dot;
+      out[1] = 0.0;
+      out[2] = fu.trace;
+    } else {
+      B.loc = std::move(AB);
+      dot_trace(B.loc, D.loc, out, &out[2], B.c0);
+    }
+    out[3] = fu.done ? 1.0 : 0.0;
+    comm_allreduce_sum(out, 4);
+    if (fu.done) {
+      B.loc = std::move(fu.result);
+      if (out[3] != (double)world().nranks) pack(B.loc);
+    }
+    out[3] = 0.0;
+    return;
   }
   pack(B.loc);
   ps_multiply(B, B, scratch, 1.0, 0.0, threshold);

@@ -73,7 +73,16 @@ def main():
     p.SetThreshold(1e-7)
     p.SetConvergeDiff(1e-9)
     K = nt.Matrix_ps(n)
+    f0, e0 = nt.fusion_counts(), nt.exchange_stats()
+    nt.set_option("time_kernels", 1)     # (the multiplies' statistics are kept only with the timers on)
+    nt.reset_spgemm_accum()
     energy, mu = nt.DensityMatrixSolvers.TRS2(A, Ident, n / 2.0, K, p)
+    acc = nt.spgemm_accum()
+    nt.set_option("time_kernels", 0)
+    res["trs2_products"], res["trs2_nnz_c"] = acc["products"], acc["nnz_c"]
+    f1, e1 = nt.fusion_counts(), nt.exchange_stats()
+    res["trs2_fused"] = np.array([f1[k] - f0[k] for k in ("square", "update", "repeated")])
+    res["trs2_exchanges"] = np.array([e1[0] - e0[0], e1[1] - e0[1]])
     tr = nt.solver_trace()
     res["trs2_energy"], res["trs2_mu"], res["trs2_iters"] = energy, mu, tr["iterations"]
     res["trs2_log"] = np.array(tr["energy"])

@@ -65,6 +65,17 @@ def test_multirank_equals_single_rank(world, reference, tmp_path):
             assert np.allclose(got[2], want[2], rtol=0, atol=1e-10)
         else:
             assert all(np.array_equal(g, w) for g, w in zip(got, want)), tag
+    # the TRS2 steps ran inside the SpGEMM kernel on every rank (fused epilogue, panels in slab form, halo exchanged as
+    # dense column runs: psmatrix.cpp dist_fused_step), with one host synchronisation per exchange
+    for r in range(world):
+        sq, up, rep = parts[r]["trs2_fused"]
+        iters = int(parts[r]["trs2_iters"])
+        assert rep == 0 and iters - 1 <= sq + up <= iters, (world, r, sq, up, rep, iters)
+        ex, syncs = parts[r]["trs2_exchanges"]
+        assert ex >= iters and syncs == ex, (world, r, ex, syncs)
+    # ... and counted the same intermediate products and product entries as the one-rank solve
+    assert sum(int(parts[r]["trs2_products"]) for r in range(world)) == int(reference["trs2_products"])
+    assert sum(int(parts[r]["trs2_nnz_c"]) for r in range(world)) == int(reference["trs2_nnz_c"])
     # overlapped halo exchange (interior / boundary split): bit-identical to the plain product and to one rank
     for tag, base in (("AB_ov", "AB"), ("AA_ov", "AA")):
         got = cat(parts, tag)
