@@ -3419,6 +3419,12 @@ __global__ __launch_bounds__(256) void k_pack_slab(int ncols, const int32_t* __r
 
 namespace {
 // run records from run addresses (panel steps: the runs of the halo columns sit in the receive buffer)
+__global__ void k_pack_reduce4(const double* __restrict__ tot, const int* __restrict__ flag, double* __restrict__ out) {
+  out[0] = tot[3];
+  out[1] = 0.0;
+  out[2] = tot[4];
+  out[3] = flag[0] == 0 ? 1.0 : 0.0;
+}
 __global__ void k_slab_runs_addr(const int32_t* __restrict__ first, const int32_t* __restrict__ last,
                                  const unsigned long long* __restrict__ addr, unsigned long long fallback,
                                  SlabRun* __restrict__ runs, int n) {
@@ -3543,11 +3549,19 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
                      (const long long*)nullptr, (const double*)nullptr, 0, lvl.p, tot.p, 1);
   unsigned long long raw[5] = {0, 0, 0, 0, 0};
   int64_t flagv[1] = {0};
+  DevBuf<double> red4;
+  if (halo && halo->reduce) {   // (dot, 0, trace, this rank succeeded) summed over the ranks, read back with the totals
+    red4.alloc(4);
+    hipLaunchKernelGGL(k_pack_reduce4, dim3(1), dim3(1), 0, stream(), tot.p, reinterpret_cast<const int*>(fz_flag), red4.p);
+    halo->reduce->allreduce(red4.p);
+  }
   {
     ScalarFetch f;
     f.add(tot.p, 5, raw);
     f.add(fz_flag, 1, flagv);
+    if (red4.p) f.add(red4.p, 4, halo->reduce->reduced);
     f.run();
+    if (red4.p) halo->reduce->done = true;
   }
   t_all.stop();
   if (timing) {

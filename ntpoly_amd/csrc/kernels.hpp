@@ -109,12 +109,18 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
             bool dense_rule, LooseProduct* loose = nullptr, const ColRange* arange = nullptr, SlabFusion* fuse = nullptr);
 // the same step on an iterate already in slab form (DevMat::slab, written by a previous fused step): X is replaced by
 // the result (again in slab form).  false: not taken (X unchanged; pack() it and use spgemm)
+struct SlabReduce {   // panel steps: the sum over the ranks rides on the step's own read-back
+  void (*allreduce)(double* dev4) = nullptr;   // enqueues an all-reduce (sum) of 4 doubles on the engine stream
+  double reduced[4] = {0, 0, 0, 0};            // (dot, 0, trace, number of ranks whose kernel succeeded)
+  bool done = false;                           // the collective was entered (false: the step gave up before its kernel)
+};
 struct SlabHalo {   // A side of a panel step: the columns ka .. kb (global numbers) of the distributed iterate
   int32_t ka = 0, kb = 0;
   const int32_t* first = nullptr;            // [kb - ka] device: extents of column ka + i
   const int32_t* last = nullptr;
   const unsigned long long* addr = nullptr;  // [kb - ka] device: address of its run (own buffer or receive buffer)
   const int32_t* count = nullptr;            // [kb - ka] device, optional (statistics): entries of the column
+  SlabReduce* reduce = nullptr;
 };
 // halo != nullptr: X is this rank's column panel; on success the result is left in fuse.result (not installed)
 bool slab_step(DevMat& X, SlabFusion& fuse, double threshold, bool dense_rule, const SlabHalo* halo = nullptr);

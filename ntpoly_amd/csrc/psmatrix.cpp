@@ -491,7 +491,9 @@ namespace {
 // derives who sends how many doubles to whom, one read-back; (3) the runs of the requested columns are packed per
 // requester and exchanged in one send / recv group; (4) layout kernel, then slab_step.  Collective: every rank calls it.
 // Returns this rank's success; the result is in fu.result (the caller installs it when all ranks succeeded).
-bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold) {
+void dev_allreduce4(double* d) { world().tr->allreduce(d, 4, true, 0); }
+
+bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabReduce& red) {
   Comm& c = world();
   Transport& tr = *c.tr;
   const int P = c.nranks, me = c.rank;
@@ -586,6 +588,8 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold) {
   halo.last = nlast.p;
   halo.addr = naddr.p;
   halo.count = ncount.p;
+  red.allreduce = &dev_allreduce4;
+  halo.reduce = &red;
   const double denom = (double)dim * (double)dim;
   const bool dense_rule = denom > 0 && (double)nnz_global / denom > 0.1;
   // (the buffers above are released on return: the allocator is stream ordered, and slab_step ends with a read-back)
@@ -606,9 +610,15 @@ bool dist_fused_step(PSMatrix& B, int mode, double threshold, const PSMatrix& D,
   fu.D = &D.loc;
   fu.col_offset = B.c0;
   fu.panel_c0 = B.c0;
-  const bool ok = slab_exchange_and_step(B, fu, threshold);
-  double v[4] = {ok ? fu.dot : 0.0, 0.0, ok ? fu.trace : 0.0, ok ? 1.0 : 0.0};
-  comm_allreduce_sum(v, 4);
+  SlabReduce red;
+  const bool ok = slab_exchange_and_step(B, fu, threshold, red);
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (red.done) {   // the sums came back with the step's totals
+    for (int q = 0; q < 4; ++q) v[q] = red.reduced[q];
+  } else {          // this rank gave up before its kernel: it still owes the other ranks the collective
+    comm_allreduce_sum(v, 4);
+  }
+  (void)ok;
   if (v[3] == (double)P) {
     B.loc = std::move(fu.result);
     out[0] = v[0];
