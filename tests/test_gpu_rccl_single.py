@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_forced_rccl_paths_match_golden():
     env = dict(os.environ, NTPOLY_AMD_FORCE_RCCL="1")
     sel = "test_ps_gemm_golden and -1--1 or test_ps_scalars_golden or test_solvers_golden or test_premade_fixture or " \
-          "test_load_balanced_solver_matches or test_ps_increment_golden"
+          "test_load_balanced_solver_matches or test_ps_increment_golden or test_trs2_fused_steps_match"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q",
                         "-m", "gpu", "-k", sel], env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
