@@ -186,6 +186,7 @@ def main():
         _, energy, tr_x = trs2_step(nt, X, X2, H, pool, trace_target, thr, tr_x)
     nt.reset_spgemm_accum()
     m0 = nt.malloc_stats()
+    fz0 = nt.fusion_counts()
     fence()
     t0 = time.perf_counter()
     nnz_trace = []
@@ -196,6 +197,8 @@ def main():
     if world > 1:
         elapsed = nt.allreduce_max(elapsed)
     m1 = nt.malloc_stats()
+    fz1 = nt.fusion_counts()
+    fused = {k: fz1[k] - fz0[k] for k in fz1}
     acc = nt.spgemm_accum()
     st = nt.last_spgemm_stats()
     gs = nt.last_grouped_stats()
@@ -251,7 +254,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("k_spgemm_slab" if st.get("slab") else "k_spgemm_ghash (grouped LDS hash)" if gs.get("used")
-                                    else "k_spgemm_pair3 / k_spgemm_hash") + " (SpGEMM numeric phase)",
+                                    else "k_spgemm_pair3 / k_spgemm_hash") +
+                                   (" (SpGEMM numeric phase with the TRS2 update, energy and trace in its epilogue)"
+                                    if fused["square"] + fused["update"] > 0 else " (SpGEMM numeric phase)"),
                          "alg_bytes_per_launch": acc["alg_bytes"] / calls, "ms_per_launch": ms_numeric / calls,
                          "traffic_source": traffic_src,
                          "note": "rank-0 panel; algorithmic bytes = 12*(nnzA+nnzB+nnzC)+4*(colsA+colsB+colsC+3); traffic = bytes "
@@ -263,6 +268,8 @@ def main():
         tfl = 2.0 * acc["products"] / (ms_numeric * 1e-3) / 1e12
         line["roofline_compute"] = {"bound": "fp64 vector ALU (unfused mul+add)", "achieved": tfl, "peak": 39.3,
                                     "unit": "TFLOP/s", "frac": tfl / 39.3}
+        # timed steps computed inside the SpGEMM kernel (X*X; 2X - X*X) and fused steps that had to be repeated unfused
+        line["fused_steps"] = fused
         if gs.get("used"):
             line["grouped_hash"] = gs
     check = None
