@@ -135,6 +135,10 @@ void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, 
                             const DevMat& X, int32_t* d_first, int32_t* d_last, unsigned long long* d_addr,
                             const int64_t* d_cnt_all = nullptr, int32_t* d_count = nullptr);   // (statistics: entries per column)
 void slab_counts_async(const DevMat& X, int64_t* d_cnt64);
+// relabel.hip: a bandwidth-reducing order of a symmetric pattern (Cuthill-McKee, breadth-first levels on the device):
+// newpos[old index] = new index, *bandwidth = max |new row - new column|.  false: not a square packed matrix, or
+// more components than the search is willing to chain
+bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidth);
 // since start: [0] steps computed with SlabFusion mode 1, [1] mode 2, [2] fused steps repeated on the unfused path
 long long* fusion_counts();
 

@@ -169,6 +169,18 @@ void ntpoly_amd_exchange_stats(long long* out) {
   out[0] = exchange_stats().exchanges;
   out[1] = exchange_stats().host_syncs;
 }
+// tests: the bandwidth-reducing order of a (one-rank, real or complex) matrix' pattern; newpos[old] = new (0-based),
+// returns 1 on success
+int ntpoly_amd_band_order(const int* ih, int* newpos, long long* bandwidth) {
+  PSMatrix& m = *get<PSMatrix>(ih);
+  DevBuf<int32_t> pos;
+  int64_t bw = 0;
+  if (!find_band_order(m.loc, pos, &bw)) return 0;
+  HIP_CHECK(hipMemcpyAsync(newpos, pos.p, sizeof(int32_t) * (size_t)m.loc.cols, hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  *bandwidth = bw;
+  return 1;
+}
 // out[0..2]: purification steps computed inside the SpGEMM kernel's epilogue (X*X; 2X - X*X) and fused steps that had
 // to be repeated on the unfused path, since start
 void ntpoly_amd_fusion_counts(long long* out) {

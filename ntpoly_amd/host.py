@@ -862,6 +862,15 @@ def last_spgemm_stats():
                 bins=[out[5 + k] for k in range(6)], overflow=out[11], slab=out[12], ms_numeric=a.value, ms_total=t.value)
 
 
+def band_order(M):
+    """(new position of every index, bandwidth) of the bandwidth-reducing order of M's pattern (csrc/relabel.hip), or None"""
+    pos = np.zeros(M.GetActualDimension(), dtype=np.int32)
+    bw = C.c_longlong()
+    lib.ntpoly_amd_band_order.restype = C.c_int
+    ok = lib.ntpoly_amd_band_order(M.ih, pos.ctypes.data_as(C.c_void_p), C.byref(bw))
+    return (pos, int(bw.value)) if ok else None
+
+
 def fusion_counts():
     """(steps X*X, steps 2X - X*X) computed inside the SpGEMM kernel's epilogue and fused steps repeated unfused"""
     out = (C.c_longlong * 3)()
