@@ -131,6 +131,12 @@ struct SlabForm {
   DevBuf<int64_t> tile_off;   // blocks + 1
   DevBuf<double> val, tiles;
   int64_t slots = 0;          // doubles addressable in val / tiles
+  // Label-ordered form (optional): the indices are a bandwidth-reducing RELABELLING of the matrix the caller handed
+  // in; lab[index] = the caller's index.  The arithmetic follows the caller's labels (order of the k steps, "last
+  // row" of a column: plast[j] = largest label among the entries of column j, -1 if empty), so results are those of
+  // the caller's matrix bit for bit; pack() renames them back.
+  DevBuf<int32_t> lab, plast;
+  bool labelled() const { return lab.p != nullptr; }
 };
 
 struct DevMat {

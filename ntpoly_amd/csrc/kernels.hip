@@ -878,6 +878,15 @@ struct SlabFuseArgs {
   long long* pnnz = nullptr;         // [nblocks]: kept entries of the product
   const int32_t* in_count = nullptr; // statistics (operand in slab form): entries per column of X; with prod set, the
   long long* prod = nullptr;         // block counts its intermediate products from its multiplier tile before the loop
+  // label-ordered steps (the data sits in a bandwidth-reducing order, the arithmetic follows the ORIGINAL labels
+  // lab[index]): the k steps of a block come in ascending label -- per-block run records blkruns[rec_off(b) + t] and
+  // the multiplier tile handed to the kernel are in that order, steps[...] names the column of step t -- and "beyond
+  // the other column's last row" compares labels: xplast[j] = largest label in X(:, j), oplast[j] the result's
+  const int32_t* lab = nullptr;
+  const SlabRun* blkruns = nullptr;
+  const int32_t* steps = nullptr;
+  const int32_t* xplast = nullptr;
+  int32_t* oplast = nullptr;
   int* flag = nullptr;
   int col_offset = 0;
 };
@@ -901,6 +910,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
       if (threadIdx.x < J && j < ncols) {
         fzp->ofirst[j] = INT_MAX;
         fzp->olast[j] = -1;
+        if (fzp->oplast) fzp->oplast[j] = -1;
         // (EPI 2: ... and none in the result only if the columns of X are empty as well; otherwise -- columns of X
         // whose rows name empty columns, an unsymmetric pattern -- the step is not this kernel's)
         if (EPI == 2 && fzp->xmax[j] >= fzp->xmin[j]) atomicOr(fzp->flag, 1);
@@ -912,7 +922,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
   // other workgroups' loops; after the loop the registers are too few to hide sixteen dependent round trips) --
   // the extents of the X and D columns and the expanded D columns themselves (SLAB_DTILE doubles, checked on the host)
   __shared__ double dtile[EPI != 0 ? SLAB_DTILE : 1];
-  __shared__ int cs_dmin[J], cs_dn[J], cs_dofs[J], cs_xmin[J], cs_xn[J], cs_xl[J];
+  __shared__ int cs_dmin[J], cs_dn[J], cs_dofs[J], cs_xmin[J], cs_xn[J], cs_xl[J], cs_xpl[J];
   __shared__ long long cs_xoff[J];
   if constexpr (EPI != 0) {
     const SlabFuseArgs fz0 = *fzp;
@@ -925,6 +935,8 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int xf = fz0.xmin[jc], xl = j < ncols ? fz0.xmax[jc] : -1;
         cs_xmin[threadIdx.x] = xf;
         cs_xl[threadIdx.x] = xl;
+        // position of the last entry of X(:, j) in the order the rules are stated in: its row, or its largest label
+        cs_xpl[threadIdx.x] = (fz0.lab && j < ncols && xl >= xf) ? fz0.xplast[jc] : xl;
         cs_xn[threadIdx.x] = xl >= xf ? xl - xf + 1 : 0;
         cs_xoff[threadIdx.x] = fz0.xoff[jc];
       }
@@ -947,7 +959,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
         int c = 0;
 #pragma unroll
         for (int q = 0; q < J; ++q) c += tile[(size_t)k * J + q] != 0.0 ? 1 : 0;
-        p += (long long)c * fz0.in_count[kmin + k];
+        p += (long long)c * fz0.in_count[fz0.steps ? fz0.steps[blk_boff[b] / J + 4 * (int64_t)b + k] : kmin + k];
       }
       p = wave_sum_i64(p);
       __shared__ long long prod_s[NW];
@@ -962,6 +974,10 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
   }
   const int rbase = lo + WAVE * wave;  // slab s of this wave starts at row rbase + 64*NW*s
   const SlabRun* rp = runs + kmin;        // record of step kk: rp[kk]
+  if constexpr (EPI != 0) {               // (label-ordered steps: the block's own record list)
+    const SlabRun* br = fzp->blkruns;
+    if (br) rp = br + (blk_boff[b] / J + 4 * (int64_t)b);
+  }
   const double* bq = bblk + (MODE == 5 ? 0 : blk_boff[b]);  // multipliers of step kk: bq[kk*J .. kk*J+J)
   const unsigned r0 = (unsigned)(rbase + lane) * 8u;
   const int e0 = rbase + WAVE - 1, e1 = e0 + WAVE * NW, e2 = e1 + WAVE * NW;
@@ -1005,11 +1021,18 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     // leave the compiler very few registers of either kind.
     asm volatile("" ::: "memory");
     const SlabFuseArgs fz = *fzp;
-    __shared__ int amax_s[NW * SL][J], first_s[NW * SL][J];
+    __shared__ int amax_s[NW * SL][J], first_s[NW * SL][J], plast_s[NW * SL][J];
     __shared__ int amax_f[J], col_first[J], col_last[J];
     __shared__ double red_s[2 * NW];
     __shared__ long long pn_s[NW];
     // (lane s * J + jj of amaxv / cntv keeps the scalar of slab s, column jj)
+    const bool labelled = fz.lab != nullptr;   // positions are labels, not rows (label-ordered steps, SlabFuseArgs)
+    int prow[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      const int r = lo + WAVE * (wave + NW * s) + lane;
+      prow[s] = labelled ? fz.lab[min(r, ncols - 1)] : r;
+    }
     if constexpr (EPI == 2) {   // first pass: last kept row of every product column, entries of the product
       int pn = 0, amaxv = -1;
 #pragma unroll
@@ -1021,7 +1044,8 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
           const bool ha = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
           const unsigned long long m = __ballot(ha);
           pn += __popcll(m);
-          const int last = m ? lo + WAVE * (wave + NW * s) + 63 - __clzll((long long)m) : -1;
+          int last = m ? lo + WAVE * (wave + NW * s) + 63 - __clzll((long long)m) : -1;
+          if (labelled) last = uni_i32(wave_max_i32(ha ? prow[s] : -1));
           asm("v_writelane_b32 %0, %1, %2" : "+v"(amaxv) : "s"(last), "n"(s * J + jj));
         }
       }
@@ -1047,6 +1071,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
     double dsum = 0.0, tsum = 0.0;
     int cntv = 0, firstv = INT_MAX, lastv = -1;   // (lane s * J + jj: entries / first / last kept row of that slab and column)
+    int plastv = -1;                              // (... and, label-ordered, the largest label among the kept rows)
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) {
       __builtin_amdgcn_sched_barrier(0);
@@ -1055,7 +1080,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
       const double* xcol = fz.xexp;
       if constexpr (EPI == 2) {
         xf = cs_xmin[jj];
-        xl = cs_xl[jj];
+        xl = cs_xpl[jj];      // (position of the column's last entry: row or label, as prow)
         xn = cs_xn[jj];
         xcol = fz.xexp + cs_xoff[jj];
         amax = amax_f[jj];
@@ -1084,7 +1109,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
           const double wa = __dmul_rn(fz.am, sv);
           const double both = __dadd_rn(wa, bs);
           o = ha ? (hb ? both : wa) : bs;                       // (neither: bs = 0)
-          const bool tail = ha ? (!hb && r > xl) : (r > amax);   // the rest of one column beyond the other's end
+          const bool tail = ha ? (!hb && prow[s] > xl) : (prow[s] > amax);   // the rest of one column beyond the other's end
           keep = (ha || hb) && (tail || fabs(o) > fz.thr_m);
         }
         const unsigned doffs = (unsigned)(r - df);
@@ -1102,27 +1127,33 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
           asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(pc), "n"(s * J + jj));
           asm("v_writelane_b32 %0, %1, %2" : "+v"(firstv) : "s"(fr), "n"(s * J + jj));
           asm("v_writelane_b32 %0, %1, %2" : "+v"(lastv) : "s"(lr), "n"(s * J + jj));
+          if (labelled) {
+            const int pl = uni_i32(wave_max_i32(keep ? prow[s] : -1));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(plastv) : "s"(pl), "n"(s * J + jj));
+          }
         }
       }
       // (everything of this column is consumed here: its lane masks and loaded values do not outlive it)
-      asm volatile("" : "+v"(dsum), "+v"(tsum), "+v"(cntv), "+v"(firstv), "+v"(lastv));
+      asm volatile("" : "+v"(dsum), "+v"(tsum), "+v"(cntv), "+v"(firstv), "+v"(lastv), "+v"(plastv));
     }
     asm volatile("" ::: "memory");
     if (lane < SL * J) {
       cnt_s[wave + NW * (lane / J)][lane % J] = cntv;
       first_s[wave + NW * (lane / J)][lane % J] = firstv;
       amax_s[wave + NW * (lane / J)][lane % J] = lastv;    // (the array of the first pass, free again)
+      plast_s[wave + NW * (lane / J)][lane % J] = plastv;
     }
     dsum = wave_sum_f64(dsum);
     tsum = wave_sum_f64(tsum);
     if (lane == 0) { red_s[2 * wave] = dsum; red_s[2 * wave + 1] = tsum; }
     __syncthreads();
     if (threadIdx.x < J) {   // entries, first and last row of every column of the block
-      int run = 0, cf = INT_MAX, cl = -1;
+      int run = 0, cf = INT_MAX, cl = -1, pl = -1;
       for (int m = 0; m < NW * SL; ++m) {
         run += cnt_s[m][threadIdx.x];
         cf = min(cf, first_s[m][threadIdx.x]);
         cl = max(cl, amax_s[m][threadIdx.x]);
+        pl = max(pl, plast_s[m][threadIdx.x]);
       }
       col_first[threadIdx.x] = cf;
       col_last[threadIdx.x] = cl;
@@ -1132,6 +1163,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
         count[j] = run;
         fz.ofirst[j] = cf;
         fz.olast[j] = cl;
+        if (labelled) fz.oplast[j] = pl;
       }
     }
     if (threadIdx.x == 64) {
@@ -3443,6 +3475,67 @@ __global__ void k_slab_runs_addr(const int32_t* __restrict__ first, const int32_
   r.pad = 0;
   runs[k] = r;
 }
+
+// label-ordered steps: the columns kmin .. kmin + kn - 1 of a block sorted by label give the order of its k steps; the
+// block's run records, its step list and its multiplier tile rows are written in that order (records and steps at
+// tile_off[b] / J + 4 b, four empty records behind the last for the loop's look-ahead)
+__global__ __launch_bounds__(256) void k_slab_order_steps(const int32_t* __restrict__ lab, const int32_t* __restrict__ blk_kmin,
+                                                          const int32_t* __restrict__ blk_kn, const int64_t* __restrict__ tile_off,
+                                                          const double* __restrict__ tiles_in, const SlabRun* __restrict__ runs,
+                                                          int ncols, double* __restrict__ tiles_out, SlabRun* __restrict__ blkruns,
+                                                          int32_t* __restrict__ steps, int nblocks) {
+  extern __shared__ unsigned long long sk[];
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int kn = blk_kn[b], kmin = blk_kmin[b];
+  if (kn == 0) return;
+  int m = 1;
+  while (m < kn) m <<= 1;
+  for (int i = threadIdx.x; i < m; i += blockDim.x)
+    sk[i] = i < kn ? (((unsigned long long)(unsigned)lab[kmin + i] << 32) | (unsigned)i) : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          const unsigned long long x = sk[i], y = sk[l];
+          if ((x > y) == up) { sk[i] = y; sk[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int64_t toff = tile_off[b];
+  const int64_t rbase = toff / SLAB_J + 4 * (int64_t)b;
+  for (int t = threadIdx.x; t < kn + 4; t += blockDim.x) {
+    if (t < kn) {
+      const int k = kmin + (int)(unsigned)(sk[t] & 0xffffffffull);
+      steps[rbase + t] = k;
+      blkruns[rbase + t] = runs[k];
+    } else {
+      steps[rbase + t] = ncols;
+      blkruns[rbase + t] = runs[ncols];   // (an empty record: the tail of the record array)
+    }
+  }
+  const double2* __restrict__ src = reinterpret_cast<const double2*>(tiles_in + toff);
+  double2* __restrict__ dst = reinterpret_cast<double2*>(tiles_out + toff);
+  for (int i = threadIdx.x; i < kn * (SLAB_J / 2); i += blockDim.x) {
+    const int t = i / (SLAB_J / 2), q = i % (SLAB_J / 2);
+    dst[(size_t)t * (SLAB_J / 2) + q] = src[(size_t)(unsigned)(sk[t] & 0xffffffffull) * (SLAB_J / 2) + q];
+  }
+}
+// largest label among the entries of every column
+__global__ __launch_bounds__(256) void k_col_plast(Csc A, const int32_t* __restrict__ lab, int32_t* __restrict__ plast) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= A.cols) return;
+  const int lane = lane_id();
+  int mx = -1;
+  for (int64_t p = A.outer[j] + lane, e = A.outer[j + 1]; p < e; p += WAVE) mx = max(mx, lab[A.inner[p]]);
+  mx = wave_max_i32(mx);
+  if (lane == 0) plast[j] = mx;
+}
 }  // namespace
 
 bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, const SlabHalo* halo) {
@@ -3498,6 +3591,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     return false;
   };
   if (max_w <= 0 || max_w > 8 * SLAB_SL * WAVE) return give_up();
+  if (in.labelled() && (int64_t)hst[1] > 2048) return give_up();   // (the per-block sort of the steps)
   hipLaunchKernelGGL((k_slab_tmpoff<SLAB_J>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
   DevBuf<char> runs(((size_t)nka + 4) * sizeof(SlabRun));
   if (halo)
@@ -3518,6 +3612,29 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
   fz.col_offset = fu.col_offset;
   int64_t* blk_prod = zwords.p + 3 + snb;
+  // label-ordered steps (SlabForm::lab): the block's records and tile rows sorted by label
+  const bool labelled = in.labelled() && !halo;
+  if (in.labelled() && halo) return give_up();
+  DevBuf<double> tiles_ord;
+  DevBuf<char> blkruns;
+  DevBuf<int32_t> steps, oplast;
+  if (labelled) {
+    const size_t nrec = in.tiles.n / SLAB_J + 4 * (size_t)snb + 8;
+    tiles_ord.alloc(in.tiles.n);
+    blkruns.alloc(nrec * sizeof(SlabRun));
+    steps.alloc(nrec);
+    oplast.alloc((size_t)n);
+    int m = 1;
+    while (m < (int)hst[1]) m <<= 1;
+    hipLaunchKernelGGL(k_slab_order_steps, dim3(xcd_grid(snb)), dim3(256), (size_t)m * 8, stream(), in.lab.p, blk_kmin.p, blk_kn.p,
+                       in.tile_off.p, in.tiles.p, reinterpret_cast<const SlabRun*>(runs.p), n, tiles_ord.p,
+                       reinterpret_cast<SlabRun*>(blkruns.p), steps.p, snb);
+    fz.lab = in.lab.p;
+    fz.blkruns = reinterpret_cast<const SlabRun*>(blkruns.p);
+    fz.steps = steps.p;
+    fz.xplast = in.plast.p;
+    fz.oplast = oplast.p;
+  }
   if (timing && (!halo || halo->count)) {   // (statistics only; the tile rows are global column numbers)
     fz.in_count = halo ? halo->count - ka : in.count.p;
     fz.prod = reinterpret_cast<long long*>(blk_prod);
@@ -3530,7 +3647,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     constexpr int FNW = decltype(nw_tag)::value;
     hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, FNW, decltype(mode_tag)::value, decltype(epi_tag)::value>),
                        dim3(xcd_grid(snb)), dim3(FNW * WAVE), 0, stream(), reinterpret_cast<const SlabRun*>(runs.p) - ka,
-                       in.tiles.p, in.tile_off.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, (int32_t*)nullptr,
+                       labelled ? tiles_ord.p : in.tiles.p, in.tile_off.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, (int32_t*)nullptr,
                        oval.p, count.p, 1.0, threshold, dr, n, snb, reinterpret_cast<const SlabFuseArgs*>(fz_args.p));
   };
   auto by_mode = [&](auto nw_tag, auto mode_tag) {
@@ -3592,6 +3709,10 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   R.slab->val = std::move(oval);
   R.slab->tiles = std::move(otiles);
   R.slab->slots = tmp_total;
+  if (labelled) {
+    R.slab->lab = std::move(X.slab->lab);
+    R.slab->plast = std::move(oplast);
+  }
   if (halo) fu.result = std::move(R);   // (the ranks agree first: the caller installs it)
   else X = std::move(R);
   fu.done = true;
@@ -3611,6 +3732,67 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   if (counted) acc.products += (int64_t)raw[2];
   acc.nnz_c += pnz;
   acc.alg_bytes += 12.0 * (double)(2 * nnz_in + pnz) + 4.0 * (3.0 * n + 3);
+  return true;
+}
+
+// Compressed columns -> slab form, with labels: Xs is the matrix in a bandwidth-reducing order (relabel.hip), lab[index]
+// = the caller's index.  false: the columns are not run-like enough for the register-slab kernel (nothing changed).
+bool slab_from_csc(DevMat& Xs, DevBuf<int32_t>& lab) {
+  if (Xs.cplx || Xs.loose() || Xs.expanded() || Xs.rows != Xs.cols || Xs.nnz == 0) return false;
+  const int n = Xs.cols, snb = cdiv(n, SLAB_J);
+  std::unique_ptr<SlabForm> f(new SlabForm());
+  f->first.alloc((size_t)n); f->last.alloc((size_t)n); f->count.alloc((size_t)n); f->off.alloc((size_t)n + 1);
+  f->tile_off.alloc((size_t)snb + 1); f->plast.alloc((size_t)n);
+  DevBuf<int32_t> span((size_t)n), blk_lo(snb), blk_w(snb), blk_kmin(snb), blk_kn(snb);
+  DevBuf<int64_t> bsz(snb), tsz(snb), dummy(snb);
+  DevBuf<unsigned long long> stats(24);
+  stats.zero();
+  hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(Xs), f->first.p, f->last.p, f->count.p);
+  hipLaunchKernelGGL(k_span_of, dim3(cdiv(n, 256)), dim3(256), 0, stream(), f->first.p, f->last.p, span.p, n);
+  scan_async<int32_t>(span.p, f->off.p, (int64_t)n);
+  hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, f->first.p, f->last.p,
+                     f->first.p, f->last.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
+  hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, (const int32_t*)nullptr, 0, stats.p);
+  scan_async<int64_t>(bsz.p, f->tile_off.p, (int64_t)snb);
+  int64_t tot_val = 0, tot_tiles = 0;
+  unsigned long long hst[2] = {0, 0};
+  {
+    ScalarFetch ft;
+    ft.add(f->off.p + n, 1, &tot_val);
+    ft.add(f->tile_off.p + snb, 1, &tot_tiles);
+    ft.add(stats.p + 16, 2, hst);
+    ft.run();
+  }
+  const int64_t max_w = (int64_t)hst[0], max_kn = (int64_t)hst[1];
+  const int pitch = ((int)max_kn + 1) | 1;
+  if (max_w <= 0 || max_w > 8 * SLAB_SL * WAVE || (size_t)pitch * SLAB_J * 8 > 128 * 1024) return false;
+  if ((double)tot_val > 2.0 * (double)Xs.nnz) return false;   // (mostly holes: no band was recovered)
+  f->val.alloc((size_t)tot_val + kIndexSlack);
+  f->tiles.alloc((size_t)tot_tiles + 16 * SLAB_J + kIndexSlack);
+  hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(Xs), f->first.p,
+                     f->off.p, f->val.p);
+  if ((size_t)pitch * SLAB_J * 8 > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_slab_expand_b<double, SLAB_J>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL((k_slab_expand_b<double, SLAB_J>), dim3(xcd_grid(snb)), dim3(256), (size_t)pitch * SLAB_J * 8, stream(), view(Xs),
+                     blk_kmin.p, blk_kn.p, f->tile_off.p, f->tiles.p, snb, pitch, 0, (const int64_t*)nullptr, (double*)nullptr,
+                     (const int32_t*)nullptr, dummy.p);
+  hipLaunchKernelGGL(k_col_plast, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(Xs), lab.p, f->plast.p);
+  f->slots = std::max(tot_val, tot_tiles);
+  f->lab = std::move(lab);
+  DevMat R;
+  R.rows = Xs.rows;
+  R.cols = n;
+  R.cplx = false;
+  R.nnz = Xs.nnz;
+  R.zero_free = Xs.zero_free;
+  R.slab = std::move(f);
+  Xs = std::move(R);
   return true;
 }
 
@@ -3822,6 +4004,11 @@ DevMat packed_copy(const DevMat& M) {
     if (n)
       hipLaunchKernelGGL(k_pack_slab, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, f.first.p, f.last.p,
                          f.off.p, f.val.p, R.outer.p, R.inner.p, R.val.p);
+    if (f.labelled()) {   // back to the caller's labels (entry (i, j) -> (lab[i], lab[j]), columns sorted again)
+      DevMat Q = remap_general(R, f.lab.p, f.lab.p, M.rows, 0, n, false);
+      Q.zero_free = 1;
+      return Q;
+    }
     return R;
   }
   if (!M.loose()) return M.clone();
@@ -3866,6 +4053,14 @@ bool square_keep_loose(DevMat& X, double threshold, bool dense_rule, const DevMa
   fu.mode = options().fused_update ? 1 : 0;
   fu.D = &D;
   fu.col_offset = col_offset;
+  if (fu.mode && !X.expanded() && !X.loose()) relabel_enter(X, D);   // (a band hidden under the labels)
+  if (X.expanded() && X.slab->labelled()) {
+    fu.D = relabelled_operand(D);
+    if (!fu.D) {
+      pack(X);
+      fu.D = &D;
+    }
+  }
   if (X.expanded()) {
     if (slab_step(X, fu, threshold, dense_rule)) {
       out[0] = fu.dot;
@@ -3874,6 +4069,7 @@ bool square_keep_loose(DevMat& X, double threshold, bool dense_rule, const DevMa
       return true;
     }
     pack(X);
+    fu.D = &D;
   }
   spgemm(X, X, AB, 1.0, threshold, dense_rule, &L, nullptr, fu.mode ? &fu : nullptr);
   if (fu.done) {  // dot and trace came out of the multiply's epilogue
@@ -4458,6 +4654,95 @@ void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, 
 void slab_counts_async(const DevMat& X, int64_t* d_cnt64) {
   hipLaunchKernelGGL(k_widen_i32, dim3(cdiv(X.cols, 256)), dim3(256), 0, stream(), X.slab->count.p,
                      reinterpret_cast<long long*>(d_cnt64), X.cols);
+}
+
+// ------------------------------------------------------------------ relabelled operands (label-ordered slab steps)
+namespace {
+struct RelabelCache {   // one entry: the order found for the pattern of D, D in that order
+  const void* val = nullptr;
+  unsigned long long serial = 0, epoch = 0;
+  int64_t nnz = -1;
+  int32_t cols = 0;
+  bool usable = false;
+  DevBuf<int32_t> newpos, lab;
+  DevMat Dr;
+};
+RelabelCache& relabel_cache() {
+  static RelabelCache* c = new RelabelCache();
+  return *c;
+}
+bool relabel_key_matches(const RelabelCache& c, const DevMat& D) {
+  return c.val == D.val.p && c.serial == dev_alloc_serial(D.val.p) && c.serial != 0 && c.epoch == value_epoch() && c.nnz == D.nnz &&
+         c.cols == D.cols;
+}
+__global__ void k_invert_perm(const int32_t* __restrict__ newpos, int n, int32_t* __restrict__ lab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lab[newpos[i]] = i;
+}
+}  // namespace
+
+const DevMat* relabelled_operand(const DevMat& D) {
+  RelabelCache& c = relabel_cache();
+  return (relabel_key_matches(c, D) && c.usable) ? &c.Dr : nullptr;
+}
+
+bool relabel_enter(DevMat& X, const DevMat& D) {
+  if (!options().label_order || !options().fused_update || !options().loose_iterates) return false;
+  if (X.cplx || D.cplx || X.loose() || X.expanded() || D.loose() || D.expanded() || X.rows != X.cols || D.rows != X.rows ||
+      D.cols != X.cols || X.nnz == 0 || D.nnz == 0 || X.cols < 64)
+    return false;
+  const int n = X.cols;
+  RelabelCache& c = relabel_cache();
+  if (relabel_key_matches(c, D) && !c.usable) return false;   // (tried for this operand: no band in it)
+  {   // run-like as it stands?  Then there is nothing to recover (the slab kernels take it directly)
+    DevBuf<int32_t> f((size_t)n), l((size_t)n), cnt((size_t)n), span((size_t)n);
+    DevBuf<int64_t> pre((size_t)n + 1);
+    DevBuf<unsigned long long> zc(1);
+    zc.zero();
+    hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(X), f.p, l.p, cnt.p);
+    hipLaunchKernelGGL(k_span_of, dim3(cdiv(n, 256)), dim3(256), 0, stream(), f.p, l.p, span.p, n);
+    scan_async<int32_t>(span.p, pre.p, (int64_t)n);
+    if (X.zero_free != 1)
+      hipLaunchKernelGGL(k_count_zero_values, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(X), zc.p);
+    int64_t tot = 0;
+    unsigned long long hz = 0;
+    ScalarFetch ft;
+    ft.add(pre.p + n, 1, &tot);
+    ft.add(zc.p, 1, &hz);
+    ft.run();
+    if ((double)tot <= 2.0 * (double)X.nnz) return false;
+    if (hz != 0) return false;   // (stored zeros: the slab form cannot tell them from holes)
+    X.zero_free = 1;
+  }
+  if (!relabel_key_matches(c, D)) {
+    c.val = D.val.p;
+    c.serial = dev_alloc_serial(D.val.p);
+    c.epoch = value_epoch();
+    c.nnz = D.nnz;
+    c.cols = D.cols;
+    c.usable = false;
+    c.Dr = DevMat();
+    int64_t bw = 0;
+    DevBuf<int32_t> pos;
+    if (!find_band_order(D, pos, &bw)) return false;
+    // worth it when the band holds the entries densely: rows per column of the band against entries per column
+    if (bw > 700 || (double)(2 * bw + 1) > 3.0 * (double)D.nnz / (double)n) return false;
+    c.newpos = std::move(pos);
+    c.lab.alloc((size_t)n);
+    hipLaunchKernelGGL(k_invert_perm, dim3(cdiv(n, 256)), dim3(256), 0, stream(), c.newpos.p, n, c.lab.p);
+    c.Dr = remap_general(D, c.newpos.p, c.newpos.p, n, 0, n, false);
+    c.usable = true;
+  }
+  DevMat Xr = remap_general(X, c.newpos.p, c.newpos.p, n, 0, n, false);
+  Xr.zero_free = 1;
+  DevBuf<int32_t> lab((size_t)n);
+  HIP_CHECK(hipMemcpyAsync(lab.p, c.lab.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  if (!slab_from_csc(Xr, lab)) {
+    c.usable = false;
+    return false;
+  }
+  X = std::move(Xr);
+  return true;
 }
 
 void row_range(const DevMat& A, int32_t* lo, int32_t* hi) {

@@ -40,6 +40,8 @@ struct EngineOptions {
                                // are (the shape only selects the summation semantics of the multiply: slices > 1)
   int fused_update = 1;        // TRS2 on one rank, real operands: the update X <- 2X - X*X (or X*X), its energy and its trace
                                // come out of the epilogue of the register-slab kernel; 0: separate merge / reduction passes
+  int label_order = 1;         // TRS2 on one rank: an operand without run structure is searched for a hidden band (relabel.hip)
+                               // and, if there is one, the loop runs in that order with label-ordered arithmetic; 0: never
   int loose_iterates = 1;      // TRS2 on one rank, real operands: the iterate X stays in the slots the update / the slab
                                // kernel wrote it to between the steps (no compaction pass per iteration); 0: packed
   int halo_overlap = 1;        // distributed multiply: 0 exchange then multiply, 1 overlap the exchange with the interior
@@ -135,6 +137,15 @@ void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, 
                             const DevMat& X, int32_t* d_first, int32_t* d_last, unsigned long long* d_addr,
                             const int64_t* d_cnt_all = nullptr, int32_t* d_count = nullptr);   // (statistics: entries per column)
 void slab_counts_async(const DevMat& X, int64_t* d_cnt64);
+// compressed columns -> labelled slab form (SlabForm::lab; Xs = the matrix in the bandwidth-reducing order, lab[index] = the
+// caller's index); false (nothing changed): its columns are not run-like
+bool slab_from_csc(DevMat& Xs, DevBuf<int32_t>& lab);
+// Operands that arrive relabelled (a band hidden by a symmetric permutation): relabel_enter finds a bandwidth-reducing
+// order from the pattern of D (cached per operand, also when nothing was found), renames X into it and turns it into
+// labelled slab form; relabelled_operand(D) = D in that order (the cache's copy) or nullptr.  The steps then follow
+// the caller's labels (kernels.hip, SlabFuseArgs::lab), pack() renames back.  One rank, real operands.
+bool relabel_enter(DevMat& X, const DevMat& D);
+const DevMat* relabelled_operand(const DevMat& D);
 // relabel.hip: a bandwidth-reducing order of a symmetric pattern (Cuthill-McKee, breadth-first levels on the device):
 // newpos[old index] = new index, *bandwidth = max |new row - new column|.  false: not a square packed matrix, or
 // more components than the search is willing to chain

@@ -698,6 +698,15 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
     fu.threshold = threshold;
     fu.D = &D.loc;
     fu.col_offset = B.c0;
+    // an operand without run structure may hide a band under its labels (kernels.hpp relabel_enter)
+    if (fu.mode && !B.loc.expanded() && !B.loc.loose()) relabel_enter(B.loc, D.loc);
+    if (B.loc.expanded() && B.loc.slab->labelled()) {
+      fu.D = relabelled_operand(D.loc);
+      if (!fu.D) {   // (D changed under the loop: back to the caller's labels)
+        pack(B.loc);
+        fu.D = &D.loc;
+      }
+    }
     if (B.loc.expanded()) {   // the iterate is in the kernel's own form already: no preparation pass at all
       if (fu.mode && slab_step(B.loc, fu, threshold, dense_rule)) {
         out[0] = fu.dot;
@@ -706,6 +715,7 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
         return;
       }
       pack(B.loc);
+      fu.D = &D.loc;
     }
     spgemm(B.loc, B.loc, AB, 1.0, threshold, dense_rule, &L, nullptr, fu.mode ? &fu : nullptr);
     if (fu.done) {
