@@ -4068,6 +4068,7 @@ bool square_keep_loose(DevMat& X, double threshold, bool dense_rule, const DevMa
       if (trace_out) *trace_out = fu.trace;
       return true;
     }
+    if (X.slab->labelled()) relabel_giveup(D);
     pack(X);
     fu.D = &D;
   }
@@ -4680,6 +4681,11 @@ __global__ void k_invert_perm(const int32_t* __restrict__ newpos, int n, int32_t
   if (i < n) lab[newpos[i]] = i;
 }
 }  // namespace
+
+void relabel_giveup(const DevMat& D) {   // a step on the relabelled form was refused: do not enter it again for this operand
+  RelabelCache& c = relabel_cache();
+  if (relabel_key_matches(c, D)) c.usable = false;
+}
 
 const DevMat* relabelled_operand(const DevMat& D) {
   RelabelCache& c = relabel_cache();

@@ -146,6 +146,7 @@ bool slab_from_csc(DevMat& Xs, DevBuf<int32_t>& lab);
 // the caller's labels (kernels.hip, SlabFuseArgs::lab), pack() renames back.  One rank, real operands.
 bool relabel_enter(DevMat& X, const DevMat& D);
 const DevMat* relabelled_operand(const DevMat& D);
+void relabel_giveup(const DevMat& D);
 // relabel.hip: a bandwidth-reducing order of a symmetric pattern (Cuthill-McKee, breadth-first levels on the device):
 // newpos[old index] = new index, *bandwidth = max |new row - new column|.  false: not a square packed matrix, or
 // more components than the search is willing to chain

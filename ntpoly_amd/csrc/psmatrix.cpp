@@ -714,6 +714,7 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
         out[2] = fu.trace;
         return;
       }
+      if (B.loc.slab->labelled()) relabel_giveup(D.loc);
       pack(B.loc);
       fu.D = &D.loc;
     }

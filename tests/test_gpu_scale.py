@@ -180,3 +180,36 @@ def test_headline_config2_vs_oracle_full_size(nt):
     # pattern and to the last bits in value
     assert len(kv) == len(ov) and np.array_equal(kc, oc) and np.array_equal(kr, orow)
     assert np.abs(kv - ov).max() <= 1e-13
+
+
+def test_headline_config2_relabelled_full_size(nt):
+    """BASELINE configs[2] under a random symmetric relabelling (N = 262 144, 201 per row) at FULL size: the loop in the
+    recovered band order with label-ordered arithmetic (relabel.hip, fused slab kernel) against the same solve on the
+    relabelled matrix as it stands (grouped LDS-hash SpGEMM, itself compared with the oracle at this size in
+    test_gpu_parity.py::test_grouped_hash_full_size_permuted_config2): 8 TRS2 iterations, sigma / entry counts per
+    iteration and the density bit for bit."""
+    from gen import permuted_banded_triplets
+    n, h, thr, iters = 262144, 100, 1e-8, 8
+    col, row, val = permuted_banded_triplets(n, h, 42)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    del col, row, val
+    ISQ = nt.Matrix_ps(n)
+    ISQ.FillIdentity()
+    res = []
+    for label_order in (0, 1):
+        nt.set_option("label_order", label_order)
+        try:
+            K = nt.Matrix_ps(n)
+            f0 = nt.fusion_counts()
+            energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, _fixed_iteration_params(nt, iters, thr))
+            f1 = nt.fusion_counts()
+            tr = nt.solver_trace()
+            res.append((energy, tr, K.triplets(), f1["square"] + f1["update"] - f0["square"] - f0["update"]))
+        finally:
+            nt.set_option("label_order", 1)
+    (e0, t0, k0, fused0), (e1, t1, k1, fused1) = res
+    assert fused0 == 0 and fused1 == iters
+    assert np.array_equal(t0["sigma"], t1["sigma"]) and np.array_equal(t0["nnz"], t1["nnz"])
+    assert np.allclose(t0["energy"], t1["energy"], rtol=1e-11, atol=0) and e0 == pytest.approx(e1, rel=1e-11)
+    for q in range(3):
+        assert np.array_equal(k0[q], k1[q]), q
