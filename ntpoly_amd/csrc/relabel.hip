@@ -5,12 +5,13 @@
 // original ones (the order of the k steps of a product, the "beyond the other column's last row" test of the merge;
 // kernels.hip, label-ordered slab steps).  This file only finds the order.
 //
-// Levels are expanded one kernel at a time (one wave per frontier vertex, neighbours claimed with a compare-and-swap on
-// their level), every level is then ordered by the smallest position among a vertex's neighbours in the previous level
-// (which makes the order of a relabelled band exact) and the positions are handed out.  The start vertex is
-// pseudo-peripheral: a search from vertex 0's component, restarted from a vertex of its last level.  Unreached
-// vertices (other components) start further searches.  A few thousand tiny launches for a band of 262 144 columns:
-// a one-off cost per solve, outside the iteration.
+// A search is ONE launch of a few co-resident workgroups (k_bfs_multi: a wave per frontier vertex, neighbours claimed with a
+// compare-and-swap on their level, levels separated by a barrier over the grid); positions are handed out in discovery
+// order.  The start vertex is pseudo-peripheral: the search is restarted from the least connected vertex of its last
+// level while the searches keep getting deeper.  Unreached vertices (other components) start further searches.  The
+// order inside the levels is then settled by barycenter rounds (key = mean position of a vertex' neighbourhood, one
+// device sort per round), which make the order of a relabelled band exact.  A one-off cost per solve (N = 262 144,
+// 201 per row: see profiles/README.md), outside the iteration.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -30,81 +31,6 @@ __global__ void k_fill_i32v(int32_t* __restrict__ p, int64_t n, int32_t v) {
   if (i < n) p[i] = v;
 }
 
-// one wave per frontier vertex: unreached neighbours join the next level
-__global__ __launch_bounds__(256) void k_bfs_expand(const int64_t* __restrict__ outer, const int32_t* __restrict__ inner,
-                                                    const int32_t* __restrict__ frontier, int nf, int level,
-                                                    int32_t* __restrict__ dist, int32_t* __restrict__ next,
-                                                    int32_t* __restrict__ next_count) {
-  const int w = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  if (w >= nf) return;
-  const int lane = lane_id();
-  const int v = frontier[w];
-  for (int64_t p = outer[v] + lane, e = outer[v + 1]; p < e; p += WAVE) {
-    const int u = inner[p];
-    if (dist[u] < 0 && atomicCAS(&dist[u], -1, level + 1) == -1) next[atomicAdd(next_count, 1)] = u;
-  }
-}
-
-// key of a vertex of the new level: the smallest position among its neighbours of the previous level
-__global__ __launch_bounds__(256) void k_bfs_keys(const int64_t* __restrict__ outer, const int32_t* __restrict__ inner,
-                                                  const int32_t* __restrict__ level_list, int nl, int level,
-                                                  const int32_t* __restrict__ dist, const int32_t* __restrict__ pos,
-                                                  unsigned long long* __restrict__ keys) {
-  const int w = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  if (w >= nl) return;
-  const int lane = lane_id();
-  const int v = level_list[w];
-  int best = INT_MAX;
-  for (int64_t p = outer[v] + lane, e = outer[v + 1]; p < e; p += WAVE) {
-    const int u = inner[p];
-    if (dist[u] == level - 1) best = min(best, pos[u]);
-  }
-  best = wave_min_i32(best);
-  if (lane == 0) keys[w] = ((unsigned long long)(unsigned)best << 32) | (unsigned)v;   // ties: by vertex number
-}
-
-// sort of one level's keys inside one workgroup (levels of a band are a bandwidth wide); larger levels: by chunks of
-// the grid (odd-even merge passes would be better; levels that wide mean there is no band to recover anyway)
-__global__ __launch_bounds__(1024) void k_sort_small(unsigned long long* __restrict__ keys, int n) {
-  extern __shared__ unsigned long long sk[];
-  int m = 1;
-  while (m < n) m <<= 1;
-  for (int i = threadIdx.x; i < m; i += blockDim.x) sk[i] = i < n ? keys[i] : ~0ull;
-  __syncthreads();
-  for (int k = 2; k <= m; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const int l = i ^ j;
-        if (l > i) {
-          const bool up = (i & k) == 0;
-          const unsigned long long a = sk[i], b = sk[l];
-          if ((a > b) == up) { sk[i] = b; sk[l] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = sk[i];
-}
-
-__global__ void k_assign_pos(const unsigned long long* __restrict__ keys, int nl, int base, int32_t* __restrict__ pos,
-                             int32_t* __restrict__ level_list) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nl) return;
-  const int v = (int)(unsigned)(keys[i] & 0xffffffffull);
-  pos[v] = base + i;
-  level_list[i] = v;   // the next expansion walks the level in its final order
-}
-
-// the vertex of a level with the fewest neighbours (ends of a band have about half the neighbours of its middle)
-__global__ void k_min_degree(const int64_t* __restrict__ outer, const int32_t* __restrict__ list, int nl,
-                             unsigned long long* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nl) return;
-  const int v = list[i];
-  atomicMin(out, ((unsigned long long)(outer[v + 1] - outer[v]) << 32) | (unsigned)v);
-}
-
 // first vertex that no search has reached yet
 __global__ void k_first_unreached(const int32_t* __restrict__ dist, int n, int32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,14 +40,17 @@ __global__ void k_first_unreached(const int32_t* __restrict__ dist, int n, int32
 // largest |new row - new column| over the entries
 __global__ __launch_bounds__(256) void k_bandwidth(const int64_t* __restrict__ outer, const int32_t* __restrict__ inner,
                                                    int n, const int32_t* __restrict__ pos, int32_t* __restrict__ out) {
-  const int v = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  if (v >= n) return;
+  __shared__ int sw[4];
   const int lane = lane_id();
   int w = 0;
-  const int pv = pos[v];
-  for (int64_t p = outer[v] + lane, e = outer[v + 1]; p < e; p += WAVE) w = max(w, abs(pos[inner[p]] - pv));
+  for (int v = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE; v < n; v += gridDim.x * (blockDim.x / WAVE)) {
+    const int pv = pos[v];
+    for (int64_t p = outer[v] + lane, e = outer[v + 1]; p < e; p += WAVE) w = max(w, abs(pos[inner[p]] - pv));
+  }
   w = wave_max_i32(w);
-  if (lane == 0) atomicMax(out, w);
+  if (lane == 0) sw[threadIdx.x / WAVE] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, max(max(sw[0], sw[1]), max(sw[2], sw[3])));
 }
 
 // refinement: key of a vertex = mean position of its neighbours and itself (fixed point).  The breadth-first order
@@ -148,63 +77,94 @@ __global__ void k_pos_from_order(const int32_t* __restrict__ order, int n, int32
   if (i < n) pos[order[i]] = i;
 }
 
-constexpr int kMaxLevelSorted = 4096;   // levels up to this size are ordered (48 KB of LDS); wider ones keep discovery order
+// One whole breadth-first search in ONE launch of a few co-resident workgroups: levels are separated by a barrier over
+// the grid (an atomic counter in memory), not by launches and host round trips -- a band of 262 144 columns has 2 600
+// levels of a hundred vertices.  Positions are handed out in discovery order; the order inside a level is settled by
+// the barycenter rounds afterwards.  ctl: [0] barrier counter, [1..3] rotating level-size counters (level L appends to
+// ctl[1 + L % 3]; the counter of level L + 1 is cleared during level L, two barriers after its last reader).
+// out[0] = vertices reached, out[1] = levels, out[2] = the vertex of the last level with the fewest neighbours.
+constexpr int kBfsBlocks = 32;
+__device__ inline void grid_barrier(unsigned* __restrict__ counter, unsigned nblocks, unsigned& epoch) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(counter, 1u);
+    const unsigned want = nblocks * (epoch + 1);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+    __threadfence();
+  }
+  __syncthreads();
+  epoch += 1;
+}
+__global__ __launch_bounds__(1024) void k_bfs_multi(const int64_t* __restrict__ outer, const int32_t* __restrict__ inner,
+                                                    int start, int base, int32_t* __restrict__ dist, int32_t* __restrict__ pos,
+                                                    int32_t* __restrict__ cur, int32_t* __restrict__ nxt,
+                                                    unsigned* __restrict__ ctl, unsigned long long* __restrict__ best,
+                                                    long long* __restrict__ out) {
+  const int lane = lane_id();
+  const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, nwaves = gridDim.x * (blockDim.x / WAVE);
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+  unsigned epoch = 0;
+  if (gtid == 0) {
+    cur[0] = start;
+    dist[start] = 0;
+    pos[start] = base;
+  }
+  grid_barrier(ctl, gridDim.x, epoch);
+  int reached = 1, level = 0, nf = 1;
+  for (;;) {
+    unsigned* cnt = ctl + 1 + level % 3;
+    if (gtid == 0) __hip_atomic_store(ctl + 1 + (level + 1) % 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int w = gwave; w < nf; w += nwaves) {
+      const int v = __hip_atomic_load(cur + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int64_t p = outer[v] + lane, e = outer[v + 1]; p < e; p += WAVE) {
+        const int u = inner[p];
+        if (__hip_atomic_load(dist + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0 && atomicCAS(&dist[u], -1, level + 1) == -1)
+          __hip_atomic_store(nxt + atomicAdd(cnt, 1u), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    grid_barrier(ctl, gridDim.x, epoch);
+    const int nl = (int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nl == 0) break;
+    for (int i = gtid; i < nl; i += nthreads)
+      pos[__hip_atomic_load(nxt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = base + reached + i;
+    reached += nl;
+    level += 1;
+    nf = nl;
+    int32_t* t = cur; cur = nxt; nxt = t;
+  }
+  // the least connected vertex of the last level (cur holds it, nf entries)
+  for (int i = gtid; i < nf; i += nthreads) {
+    const int v = __hip_atomic_load(cur + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicMin(best, ((unsigned long long)(outer[v + 1] - outer[v]) << 32) | (unsigned)v);
+  }
+  grid_barrier(ctl, gridDim.x, epoch);
+  if (gtid == 0) {
+    out[0] = reached;
+    out[1] = level;
+    out[2] = (long long)(unsigned)(__hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffffull);
+  }
+}
 
-// one search from `start` over the unreached part; positions from `base` on.  Returns the number of vertices reached;
-// *last_vertex = a vertex of the last level
 int bfs_from(const DevMat& A, int start, int base, DevBuf<int32_t>& dist, DevBuf<int32_t>& pos, DevBuf<int32_t>& cur,
              DevBuf<int32_t>& nxt, DevBuf<int32_t>& counter, DevBuf<unsigned long long>& keys, int* last_vertex, int* levels) {
-  int reached = 0, level = 0, nf = 1;
-  {
-    const int32_t h[2] = {start, 0};
-    HIP_CHECK(hipMemcpyAsync(cur.p, &h[0], sizeof(int32_t), hipMemcpyHostToDevice, stream()));
-    HIP_CHECK(hipMemcpyAsync(dist.p + start, &h[1], sizeof(int32_t), hipMemcpyHostToDevice, stream()));
-    const int32_t b = base;
-    HIP_CHECK(hipMemcpyAsync(pos.p + start, &b, sizeof(int32_t), hipMemcpyHostToDevice, stream()));
-    sync_stream();
-  }
-  reached = 1;
-  *last_vertex = start;
-  while (nf > 0) {
-    counter.zero();
-    hipLaunchKernelGGL(k_bfs_expand, dim3(cdiv((int64_t)nf * WAVE, 256)), dim3(256), 0, stream(), A.outer.p, A.inner.p, cur.p, nf,
-                       level, dist.p, nxt.p, counter.p);
-    int32_t nl = 0;
-    {
-      ScalarFetch f;   // (8-byte words: the counter buffer holds two ints)
-      long long raw = 0;
-      f.add(counter.p, 1, &raw);
-      f.run();
-      nl = (int32_t)(raw & 0xffffffffll);
-    }
-    if (nl == 0) break;
-    hipLaunchKernelGGL(k_bfs_keys, dim3(cdiv((int64_t)nl * WAVE, 256)), dim3(256), 0, stream(), A.outer.p, A.inner.p, nxt.p, nl,
-                       level + 1, dist.p, pos.p, keys.p);
-    if (nl <= kMaxLevelSorted) {
-      int m = 1;
-      while (m < nl) m <<= 1;
-      hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(std::min(1024, std::max(64, m / 2))), (size_t)m * 8, stream(), keys.p, nl);
-    }
-    hipLaunchKernelGGL(k_assign_pos, dim3(cdiv(nl, 256)), dim3(256), 0, stream(), keys.p, nl, base + reached, pos.p, nxt.p);
-    reached += nl;
-    std::swap(cur.p, nxt.p);
-    std::swap(cur.n, nxt.n);
-    nf = nl;
-    level += 1;
-  }
-  {   // a vertex of the last level: the one with the fewest neighbours
-    DevBuf<unsigned long long> best(1);
-    const unsigned long long init = ~0ull;
-    best.upload(&init, 1);
-    hipLaunchKernelGGL(k_min_degree, dim3(cdiv(std::max(nf, 1), 256)), dim3(256), 0, stream(), A.outer.p, cur.p, nf, best.p);
-    unsigned long long raw = 0;
-    ScalarFetch f;
-    f.add(best.p, 1, &raw);
-    f.run();
-    *last_vertex = nf > 0 ? (int)(unsigned)(raw & 0xffffffffull) : start;
-  }
-  *levels = level;
-  return reached;
+  (void)counter;
+  (void)keys;
+  DevBuf<long long> out(3);
+  DevBuf<unsigned> ctl(4);
+  DevBuf<unsigned long long> best(1);
+  ctl.zero();
+  const unsigned long long init = ~0ull;
+  best.upload(&init, 1);
+  hipLaunchKernelGGL(k_bfs_multi, dim3(kBfsBlocks), dim3(1024), 0, stream(), A.outer.p, A.inner.p, start, base, dist.p, pos.p, cur.p,
+                     nxt.p, ctl.p, best.p, out.p);
+  long long h[3] = {0, 0, 0};
+  ScalarFetch f;
+  f.add(out.p, 3, h);
+  f.run();
+  *levels = (int)h[1];
+  *last_vertex = (int)h[2];
+  return (int)h[0];
 }
 
 }  // namespace
@@ -253,7 +213,7 @@ bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidt
   auto bandwidth_of = [&](const int32_t* p) {
     DevBuf<int32_t> bw(2);
     bw.zero();
-    hipLaunchKernelGGL(k_bandwidth, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), A.outer.p, A.inner.p, n, p, bw.p);
+    hipLaunchKernelGGL(k_bandwidth, dim3(std::min(cdiv((int64_t)n * WAVE, 256), 2048)), dim3(256), 0, stream(), A.outer.p, A.inner.p, n, p, bw.p);
     long long raw = 0;
     ScalarFetch f;
     f.add(bw.p, 1, &raw);
