@@ -1036,17 +1036,22 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     if constexpr (EPI == 2) {   // first pass: last kept row of every product column, entries of the product
       int pn = 0, amaxv = -1;
 #pragma unroll
-      for (int s = 0; s < SL; ++s) {
+      for (int jj = 0; jj < J; ++jj) {
+        int lmax = -1;   // (labelled: this lane's largest kept label of the column, reduced over the wave once per column)
 #pragma unroll
-        for (int jj = 0; jj < J; ++jj) {
+        for (int s = 0; s < SL; ++s) {
           const double v = acc[s][jj];
           const double sv = __dmul_rn(alpha, v);
           const bool ha = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
           const unsigned long long m = __ballot(ha);
           pn += __popcll(m);
-          int last = m ? lo + WAVE * (wave + NW * s) + 63 - __clzll((long long)m) : -1;
-          if (labelled) last = uni_i32(wave_max_i32(ha ? prow[s] : -1));
-          asm("v_writelane_b32 %0, %1, %2" : "+v"(amaxv) : "s"(last), "n"(s * J + jj));
+          const int last = m ? lo + WAVE * (wave + NW * s) + 63 - __clzll((long long)m) : -1;
+          if (!labelled) asm("v_writelane_b32 %0, %1, %2" : "+v"(amaxv) : "s"(last), "n"(s * J + jj));
+          lmax = max(lmax, ha ? prow[s] : -1);
+        }
+        if (labelled) {
+          const int last = uni_i32(wave_max_i32(lmax));
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(amaxv) : "s"(last), "n"(jj));
         }
       }
       if (lane < SL * J) amax_s[wave + NW * (lane / J)][lane % J] = amaxv;
@@ -1087,6 +1092,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       const int df = cs_dmin[jj], dn = cs_dn[jj];
       const double* dcol = dtile + cs_dofs[jj];
+      int lmaxk = -1;
 #pragma unroll
       for (int s = 0; s < SL; ++s) {
         const int r = lo + WAVE * (wave + NW * s) + lane;
@@ -1127,11 +1133,12 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
           asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(pc), "n"(s * J + jj));
           asm("v_writelane_b32 %0, %1, %2" : "+v"(firstv) : "s"(fr), "n"(s * J + jj));
           asm("v_writelane_b32 %0, %1, %2" : "+v"(lastv) : "s"(lr), "n"(s * J + jj));
-          if (labelled) {
-            const int pl = uni_i32(wave_max_i32(keep ? prow[s] : -1));
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(plastv) : "s"(pl), "n"(s * J + jj));
-          }
         }
+        lmaxk = max(lmaxk, keep ? prow[s] : -1);
+      }
+      if (labelled) {   // the largest label among the kept rows of the column: one reduction over the wave per column
+        const int pl = uni_i32(wave_max_i32(lmaxk));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(plastv) : "s"(pl), "n"(jj));
       }
       // (everything of this column is consumed here: its lane masks and loaded values do not outlive it)
       asm volatile("" : "+v"(dsum), "+v"(tsum), "+v"(cntv), "+v"(firstv), "+v"(lastv), "+v"(plastv));
