@@ -35,7 +35,13 @@ def main():
     root, pat = sys.argv[1], sys.argv[2]
     f = per_kernel(root + "/pmc_FETCH_SIZE/run_counter_collection.csv")
     w = per_kernel(root + "/pmc_WRITE_SIZE/run_counter_collection.csv")
-    fk = pat if pat in f else [k for k in f if pat in k][0]   # exact kernel name first
+    # (a comma-separated list of candidates: the one with the most counted bytes is the dominant kernel of the run)
+    cands = []
+    for q in pat.split(","):
+        cands += [q] if q in f else [k for k in f if q in k]
+    if not cands:
+        raise SystemExit("no kernel matching %r in the counter files" % pat)
+    fk = max(cands, key=lambda k: sum(f[k]))
     fetch, write = f[fk][1:] or f[fk], w[fk][1:] or w[fk]   # drop the first (cold) launch
     fa, wa = sum(fetch) / len(fetch), sum(write) / len(write)
     cal = None
