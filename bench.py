@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--halfband", type=int, default=100)
     ap.add_argument("--threshold", type=float, default=1e-8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-label-order", action="store_true",
+                    help="with --permute: do not look for a band hidden under the labels (option label_order = 0): the "
+                         "relabelled operand runs on the grouped LDS-hash SpGEMM as it stands")
     ap.add_argument("--no-wrp-check", action="store_true", help="skip the TRS2_wrp-differenced cross-check of the value")
     ap.add_argument("--permute", type=int, default=None, metavar="SEED",
                     help="run on P^T H P under a seeded random relabelling (SURVEY 8(d): the load-balanced / "
@@ -149,6 +152,8 @@ def main():
     n, h, thr = args.n, args.halfband, args.threshold
     nt.ConstructGlobalProcessGrid(1, world, 1)  # column panels: one per GPU
     nt.set_option("time_kernels", 1)
+    if args.no_label_order:
+        nt.set_option("label_order", 0)
 
     # ---- setup (untimed): Hamiltonian panel, X0 = (e_max*I - H)/(e_max - e_min)  (:344-371)
     H = nt.Matrix_ps(n)
