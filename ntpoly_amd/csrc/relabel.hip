@@ -31,6 +31,18 @@ __global__ void k_fill_i32v(int32_t* __restrict__ p, int64_t n, int32_t v) {
   if (i < n) p[i] = v;
 }
 
+__global__ void k_min_degree_all(const int64_t* __restrict__ outer, int n, unsigned long long* __restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long key = ~0ull;
+  if (v < n) key = ((unsigned long long)(outer[v + 1] - outer[v]) << 32) | (unsigned)v;
+  // (one atomic per wave)
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(key, o, WAVE);
+    key = other < key ? other : key;
+  }
+  if (lane_id() == 0 && key != ~0ull) atomicMin(out, key);
+}
+
 // first vertex that no search has reached yet
 __global__ void k_first_unreached(const int32_t* __restrict__ dist, int n, int32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,7 +95,7 @@ __global__ void k_pos_from_order(const int32_t* __restrict__ order, int n, int32
 // the barycenter rounds afterwards.  ctl: [0] barrier counter, [1..3] rotating level-size counters (level L appends to
 // ctl[1 + L % 3]; the counter of level L + 1 is cleared during level L, two barriers after its last reader).
 // out[0] = vertices reached, out[1] = levels, out[2] = the vertex of the last level with the fewest neighbours.
-constexpr int kBfsBlocks = 32;
+constexpr int kBfsBlocks = 8;
 __device__ inline void grid_barrier(unsigned* __restrict__ counter, unsigned nblocks, unsigned& epoch) {
   __threadfence();
   __syncthreads();
@@ -180,6 +192,18 @@ bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidt
   };
   int done = 0, start = 0, guard = 0;
   reset();
+  {   // first start: the least connected vertex (an end of a band has about half the neighbours of its middle)
+    DevBuf<unsigned long long> best(1);
+    const unsigned long long init = ~0ull;
+    best.upload(&init, 1);
+    hipLaunchKernelGGL(k_min_degree_all, dim3(cdiv(n, 256)), dim3(256), 0, stream(), A.outer.p, n, best.p);
+    unsigned long long raw = 0;
+    ScalarFetch f;
+    f.add(best.p, 1, &raw);
+    f.run();
+    start = (int)(unsigned)(raw & 0xffffffffull);
+    if (start < 0 || start >= n) start = 0;
+  }
   while (done < n && guard++ < 64) {
     // pseudo-peripheral start inside this component: search, restart from the least connected vertex of the last
     // level, while the searches keep getting deeper (at most three times)
