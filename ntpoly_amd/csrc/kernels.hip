@@ -898,7 +898,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int32_t* __restrict__ blk_lo, const int32_t* __restrict__ blk_w, const int64_t* __restrict__ blk_toff,
     int32_t* __restrict__ out_inner, double* __restrict__ out_val, int32_t* __restrict__ count, double alpha,
     double threshold, int dense_rule, int ncols, int nblocks, const SlabFuseArgs* __restrict__ fzp) {
-  static_assert(J == 16 && SL == 3 && (NW == 4 || ((NW == 6 || NW == 8) && MODE == 0)), "register map / wave rotation of slab_loop.inc");
+  static_assert(J == 16 && SL == 3 && (NW == 4 || ((NW == 6 || NW == 8) && (MODE == 0 || MODE == 9))), "register map / wave rotation of slab_loop.inc");
   __shared__ int cnt_s[NW * SL][J];
   const int b = xcd_block(nblocks);
   if (b < 0) return;
@@ -996,6 +996,14 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     asm volatile(SLAB_LOOP_ASM_ABL2 SLAB_LOOP_OPERANDS);  // no multiplier loads
   } else if constexpr (MODE == 4) {
     asm volatile(SLAB_LOOP_ASM_ABL3 SLAB_LOOP_OPERANDS);  // no arithmetic
+  } else if constexpr (MODE == 9) {
+    // label-ordered steps: the multiplier row of a step sits at the byte offset its run record names
+    asm volatile(SLAB_LOOP_ASM_ROWOFF
+                 : "=&{v[2:17]}"(accL0), "=&{v[18:33]}"(accH0), "=&{v[34:49]}"(accL1), "=&{v[50:65]}"(accH1),
+                   "=&{v[66:81]}"(accL2), "=&{v[82:97]}"(accH2)
+                 : [rp] "s"(rp), [bq] "s"(bq), [kn] "s"(kn), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [r0] "v"(r0),
+                   [c1] "n"(WAVE * NW * 8), [c2] "n"(2 * WAVE * NW * 8), [wv] "s"(wave)
+                 : SLAB_LOOP_ROWOFF_CLOBBERS);
   } else if constexpr (MODE == 8) {
     asm volatile(SLAB_LOOP_ASM_LEANPF SLAB_LOOP_OPERANDS);  // lean periods + rotating scalar-cache prefetch
   } else if constexpr (MODE == 7) {
@@ -3491,6 +3499,8 @@ __global__ __launch_bounds__(256) void k_slab_order_steps(const int32_t* __restr
                                                           const double* __restrict__ tiles_in, const SlabRun* __restrict__ runs,
                                                           int ncols, double* __restrict__ tiles_out, SlabRun* __restrict__ blkruns,
                                                           int32_t* __restrict__ steps, int nblocks) {
+  // tiles_out == nullptr: the tile stays as it is and every record names its row (pad = byte offset of row k - kmin):
+  // the row-offset variant of the loop (SLAB_LOOP_ASM_ROWOFF) reads the multipliers there
   extern __shared__ unsigned long long sk[];
   const int b = xcd_block(nblocks);
   if (b < 0) return;
@@ -3518,14 +3528,18 @@ __global__ __launch_bounds__(256) void k_slab_order_steps(const int32_t* __restr
   const int64_t rbase = toff / SLAB_J + 4 * (int64_t)b;
   for (int t = threadIdx.x; t < kn + 4; t += blockDim.x) {
     if (t < kn) {
-      const int k = kmin + (int)(unsigned)(sk[t] & 0xffffffffull);
-      steps[rbase + t] = k;
-      blkruns[rbase + t] = runs[k];
+      const int i = (int)(unsigned)(sk[t] & 0xffffffffull);
+      const int k = kmin + i;
+      if (steps) steps[rbase + t] = k;
+      SlabRun r = runs[k];
+      r.pad = i * (int)(SLAB_J * sizeof(double));
+      blkruns[rbase + t] = r;
     } else {
-      steps[rbase + t] = ncols;
+      if (steps) steps[rbase + t] = ncols;
       blkruns[rbase + t] = runs[ncols];   // (an empty record: the tail of the record array)
     }
   }
+  if (!tiles_out) return;
   const double2* __restrict__ src = reinterpret_cast<const double2*>(tiles_in + toff);
   double2* __restrict__ dst = reinterpret_cast<double2*>(tiles_out + toff);
   for (int i = threadIdx.x; i < kn * (SLAB_J / 2); i += blockDim.x) {
@@ -3625,12 +3639,16 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   DevBuf<double> tiles_ord;
   DevBuf<char> blkruns;
   DevBuf<int32_t> steps, oplast;
+  // (the loop variant that takes a step's multiplier row from its record needs no copy of the tiles in step order)
+  const bool rowoff = labelled && options().label_rowoff != 0;
   if (labelled) {
     const size_t nrec = in.tiles.n / SLAB_J + 4 * (size_t)snb + 8;
-    tiles_ord.alloc(in.tiles.n);
     blkruns.alloc(nrec * sizeof(SlabRun));
-    steps.alloc(nrec);
     oplast.alloc((size_t)n);
+    if (!rowoff) {
+      tiles_ord.alloc(in.tiles.n);
+      steps.alloc(nrec);
+    }
     int m = 1;
     while (m < (int)hst[1]) m <<= 1;
     hipLaunchKernelGGL(k_slab_order_steps, dim3(xcd_grid(snb)), dim3(256), (size_t)m * 8, stream(), in.lab.p, blk_kmin.p, blk_kn.p,
@@ -3654,14 +3672,18 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     constexpr int FNW = decltype(nw_tag)::value;
     hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, FNW, decltype(mode_tag)::value, decltype(epi_tag)::value>),
                        dim3(xcd_grid(snb)), dim3(FNW * WAVE), 0, stream(), reinterpret_cast<const SlabRun*>(runs.p) - ka,
-                       labelled ? tiles_ord.p : in.tiles.p, in.tile_off.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, (int32_t*)nullptr,
+                       (labelled && !rowoff) ? tiles_ord.p : in.tiles.p, in.tile_off.p, blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, (int32_t*)nullptr,
                        oval.p, count.p, 1.0, threshold, dr, n, snb, reinterpret_cast<const SlabFuseArgs*>(fz_args.p));
   };
   auto by_mode = [&](auto nw_tag, auto mode_tag) {
     if (fu.mode == 1) launch(nw_tag, mode_tag, std::integral_constant<int, 1>{});
     else launch(nw_tag, mode_tag, std::integral_constant<int, 2>{});
   };
-  if (max_w > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
+  if (rowoff) {
+    if (max_w > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{});
+    else if (max_w > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 9>{});
+    else by_mode(std::integral_constant<int, SLAB_NW>{}, std::integral_constant<int, 9>{});
+  } else if (max_w > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
   else if (max_w > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
   else by_mode(std::integral_constant<int, SLAB_NW>{}, std::integral_constant<int, 8>{});
   t_num.stop();

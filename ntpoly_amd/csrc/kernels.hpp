@@ -42,6 +42,8 @@ struct EngineOptions {
                                // come out of the epilogue of the register-slab kernel; 0: separate merge / reduction passes
   int label_order = 1;         // TRS2 on one rank: an operand without run structure is searched for a hidden band (relabel.hip)
                                // and, if there is one, the loop runs in that order with label-ordered arithmetic; 0: never
+  int label_rowoff = 1;        // label-ordered steps: the loop takes a step's multiplier row from its run record (no copy of
+                               // the tiles in step order); 0: the tiles are copied in step order before every launch
   int loose_iterates = 1;      // TRS2 on one rank, real operands: the iterate X stays in the slots the update / the slab
                                // kernel wrote it to between the steps (no compaction pass per iteration); 0: packed
   int halo_overlap = 1;        // distributed multiply: 0 exchange then multiply, 1 overlap the exchange with the interior

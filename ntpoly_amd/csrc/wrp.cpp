@@ -144,6 +144,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "loose_iterates") options().loose_iterates = *value;
   else if (n == "fused_update") options().fused_update = *value;
   else if (n == "label_order") options().label_order = *value;
+  else if (n == "label_rowoff") options().label_rowoff = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used

@@ -40,11 +40,16 @@ def sp(n):
     return "s[%d:%d]" % (n, n + 1)
 
 
-def issue(aset, lines, ablate=0):
+RO = [100, 101]  # row-offset variant: byte offset of the multiplier row of step k (from the pad word of its record)
+
+
+def issue(aset, lines, ablate=0, ro=None):
     """copy first/span62 of the record that just landed, issue the SL slab loads of that step"""
     f, s = FS[aset]
     lines.append("s_mov_b32 s%d, s29" % f)
     lines.append("s_mov_b32 s%d, s30" % s)
+    if ro is not None:
+        lines.append("s_mov_b32 s%d, s31" % ro)
     lines.append("v_sub_u32 v%d, %%[r0], s28" % VOFF)
     for i in range(1, SL):
         lines.append("v_add_u32 v%d, %%[c%d], v%d" % (VOFF + i, i, VOFF))
@@ -54,8 +59,12 @@ def issue(aset, lines, ablate=0):
         lines.append("buffer_load_dwordx2 %s, v%d, s[24:27], 0 offen" % (vp(A_SET[aset] + 2 * i), VOFF + i))
 
 
-def load_b(bset, off, lines, ablate=0):
+def load_b(bset, off, lines, ablate=0, ro=None):
     if ablate == 2:
+        return
+    if ro is not None:   # the row of the step is named by its record, not by its position
+        lines.append("s_load_dwordx16 s[%d:%d], s[16:17], s%d" % (B_SET[bset], B_SET[bset] + 15, ro))
+        lines.append("s_load_dwordx16 s[%d:%d], s[16:17], s%d offset:0x40" % (B_SET[bset] + 16, B_SET[bset] + 31, ro))
         return
     lines.append("s_load_dwordx16 s[%d:%d], s[16:17], 0x%x" % (B_SET[bset], B_SET[bset] + 15, off))
     lines.append("s_load_dwordx16 s[%d:%d], s[16:17], 0x%x" % (B_SET[bset] + 16, B_SET[bset] + 31, off + 0x40))
@@ -84,23 +93,40 @@ def compute(aset, bset, lines, label, fused, ablate=0):
         lines.append("%s:" % skip)
 
 
-def step(L, label, t, fused, ablate, pf, lean):
+def step(L, label, t, fused, ablate, pf, lean, rowoff=False):
     """one k step at position t of the period.  lean: the pointers stay at the period start (immediate offsets carry
-    the step) and there is no exit test -- the caller guarantees a whole period"""
+    the step) and there is no exit test -- the caller guarantees a whole period.  rowoff: the multiplier row of a step
+    sits at the byte offset its run record names (pad word), s[16:17] stays at the tile"""
     L.append("s_waitcnt lgkmcnt(0)")
-    issue((t + 2) % NA, L, ablate)
+    issue((t + 2) % NA, L, ablate, RO[t % 2] if rowoff else None)      # (step t+2; RO[t%2] held step t's, consumed)
     if lean:
         boff, roff = 0x80 * (t + 1), 0x20 * (t + 3)
     else:
         # pointers advance once per step: s[16:17] -> multipliers of step t+1, s[14:15] -> record of step t+1
-        L.append("s_add_u32 s16, s16, 0x80")
-        L.append("s_addc_u32 s17, s17, 0")
+        if not rowoff:
+            L.append("s_add_u32 s16, s16, 0x80")
+            L.append("s_addc_u32 s17, s17, 0")
         L.append("s_add_u32 s14, s14, 0x20")
         L.append("s_addc_u32 s15, s15, 0")
         boff, roff = 0, 0x40
-    load_b((t + 1) % NB, boff, L, ablate)
+    load_b((t + 1) % NB, boff, L, ablate, RO[(t + 1) % 2] if rowoff else None)
     L.append("s_load_dwordx8 s[24:31], s[14:15], 0x%x" % roff)   # record of step t+3
-    if pf:
+    if rowoff and pf:
+        # (row-offset variant) the row of step t+2 -- its offset has just arrived with its record -- is pulled into the
+        # scalar cache by one wave of the block per step, the waves taking turns as below
+        skip = "%d" % label[0]
+        label[0] += 1
+        if lean:
+            L.append("s_add_i32 s19, s18, %d" % t)
+            L.append("s_and_b32 s19, s19, 3")
+        else:
+            L.append("s_and_b32 s19, s18, 3")
+        L.append("s_cmp_lg_u32 s19, %[wv]")
+        L.append("s_cbranch_scc1 %sf" % skip)
+        L.append("s_load_dword vcc_lo, s[16:17], s%d" % RO[t % 2])   # (destination: a register the loop does not use)
+        L.append("s_load_dword vcc_lo, s[16:17], s%d offset:0x40" % RO[t % 2])
+        L.append("%s:" % skip)
+    elif pf:
         # scalar-cache prefetch of the multiplier row PF steps further on, issued by ONE wave of the block per
         # step (the wave whose index equals step mod 4): s_waitcnt lgkmcnt(0) makes the issuing wave sit out the
         # full miss latency at its next step, so the four waves take turns and each stalls once in four steps
@@ -123,7 +149,7 @@ def step(L, label, t, fused, ablate, pf, lean):
     compute(t % NA, t % NB, L, label, fused, ablate)
 
 
-def build(fused, ablate=0, pf=0, lean=False):
+def build(fused, ablate=0, pf=0, lean=False, rowoff=False):
     L = []
     label = [10]
     for i in range(SL * J):
@@ -133,11 +159,11 @@ def build(fused, ablate=0, pf=0, lean=False):
     # prologue: slabs of steps 0 and 1, multipliers of step 0, record of step 2
     L.append("s_load_dwordx8 s[24:31], s[14:15], 0x0")
     L.append("s_waitcnt lgkmcnt(0)")
-    issue(0, L, ablate)
+    issue(0, L, ablate, RO[0] if rowoff else None)
     L.append("s_load_dwordx8 s[24:31], s[14:15], 0x20")
     L.append("s_waitcnt lgkmcnt(0)")
-    issue(1, L, ablate)
-    load_b(0, 0, L, ablate)
+    issue(1, L, ablate, RO[1] if rowoff else None)
+    load_b(0, 0, L, ablate, RO[0] if rowoff else None)
     L.append("s_load_dwordx8 s[24:31], s[14:15], 0x40")
     L.append("s_mov_b32 s18, 0")
     period = NA * NB
@@ -148,9 +174,10 @@ def build(fused, ablate=0, pf=0, lean=False):
         L.append("s_cmp_lt_i32 s19, %d" % period)
         L.append("s_cbranch_scc1 4f")
         for t in range(period):
-            step(L, label, t, fused, ablate, pf, True)
-        L.append("s_add_u32 s16, s16, 0x%x" % (0x80 * period))
-        L.append("s_addc_u32 s17, s17, 0")
+            step(L, label, t, fused, ablate, pf, True, rowoff)
+        if not rowoff:
+            L.append("s_add_u32 s16, s16, 0x%x" % (0x80 * period))
+            L.append("s_addc_u32 s17, s17, 0")
         L.append("s_add_u32 s14, s14, 0x%x" % (0x20 * period))
         L.append("s_addc_u32 s15, s15, 0")
         L.append("s_add_i32 s18, s18, %d" % period)
@@ -160,7 +187,7 @@ def build(fused, ablate=0, pf=0, lean=False):
         L.append("s_cbranch_scc1 2f")
     L.append("1:")
     for t in range(period):
-        step(L, label, t, fused, ablate, pf, False)
+        step(L, label, t, fused, ablate, pf, False, rowoff)
         L.append("s_add_i32 s18, s18, 1")
         L.append("s_cmp_ge_i32 s18, %[kn]")
         if t + 1 < period:
@@ -294,6 +321,16 @@ def main():
         out.append('  ""')
         print(name, len(L), "instructions")
     out.append("#define SLAB_LOOP_CLOBBERS " + ", ".join('"%s"' % c for c in sclob + vclob) + ', "vcc", "scc", "memory"')
+    # label-ordered steps: the multiplier row of a step at the byte offset its record names (lean periods, no rotating
+    # prefetch: the rows are not consecutive); two more SGPRs carry the offsets of the steps in flight
+    L = build(False, 0, PF, True, True)
+    out.append("#define SLAB_LOOP_ASM_ROWOFF \\")
+    for ln in L:
+        out.append('  "%s\\n\\t" \\' % ln)
+    out.append('  ""')
+    print("SLAB_LOOP_ASM_ROWOFF", len(L), "instructions")
+    out.append("#define SLAB_LOOP_ROWOFF_CLOBBERS " + ", ".join('"%s"' % c for c in sclob + ["s100", "s101"] + vclob) +
+               ', "vcc", "scc", "memory"')
     # narrower row windows: fewer slabs per wave = fewer accumulator registers = more waves per SIMD (the loop is
     # latency bound: time ~ 1 / occupancy, profiles/README.md item 14)
     for sl in (1, 2):
