@@ -908,6 +908,16 @@ def test_trs2_relabelled_operand_label_ordered_steps(nt, n, h, thr, iters, holes
     ref = _trs2_run(nt, n, col, row, val, thr, iters, fused=0, loose=0, label_order=0)
     assert ref["counts"]["square"] == ref["counts"]["update"] == 0
     got = _trs2_run(nt, n, col, row, val, thr, iters, fused=1, loose=1, label_order=1)
+    # (the same with the tiles copied into step order before every launch instead of the loop variant that takes a
+    # step's multiplier row from its run record)
+    nt.set_option("label_rowoff", 0)
+    try:
+        got2 = _trs2_run(nt, n, col, row, val, thr, iters, fused=1, loose=1, label_order=1)
+    finally:
+        nt.set_option("label_rowoff", 1)
+    for q in range(3):
+        assert np.array_equal(got2["K"][q], ref["K"][q]), q
+    assert got2["counts"]["square"] + got2["counts"]["update"] == iters
     assert got["tr"]["iterations"] == ref["tr"]["iterations"] == iters
     assert np.array_equal(got["tr"]["sigma"], ref["tr"]["sigma"])
     assert np.array_equal(got["tr"]["nnz"], ref["tr"]["nnz"])
