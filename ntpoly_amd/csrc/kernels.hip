@@ -2473,16 +2473,28 @@ __global__ void k_remap_gather(const unsigned long long* __restrict__ keys, cons
                                int64_t nkeep, const T* __restrict__ val, int32_t* __restrict__ inner_out,
                                T* __restrict__ val_out, int32_t* __restrict__ colcount) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= nkeep) return;
-  const unsigned long long k = keys[p];
-  inner_out[p] = (int32_t)(k & 0xffffffffull);
-  val_out[p] = val[payload[p]];
-  atomicAdd(&colcount[(int)(k >> 32)], 1);
+  const bool live = p < nkeep;
+  const unsigned long long k = live ? keys[p] : ~0ull;
+  if (live) {
+    inner_out[p] = (int32_t)(k & 0xffffffffull);
+    val_out[p] = val[payload[p]];
+  }
+  // the keys are sorted by column: one atomic per run of equal columns inside the wave, not one per entry
+  const int col = (int)(k >> 32), lane = lane_id();
+  const int prev = __shfl_up(col, 1, WAVE);
+  const bool leader = live && (lane == 0 || col != prev);
+  const unsigned long long heads = __ballot(leader), alive = __ballot(live);
+  if (leader) {
+    const unsigned long long later = heads & ~((2ull << lane) - 1ull);   // leaders after this lane
+    const int end = later ? __builtin_ctzll(later) : (int)__popcll(alive);   // (live lanes are a prefix of the wave)
+    atomicAdd(&colcount[col], end - lane);
+  }
 }
 __global__ void k_count_valid(const unsigned long long* __restrict__ keys, int64_t n,
                               unsigned long long* __restrict__ out) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n && keys[p] != ~0ull) atomicAdd(out, 1ull);
+  const unsigned long long m = __ballot(p < n && keys[p] != ~0ull);   // (one atomic per wave, not per entry)
+  if (m && lane_id() == 0) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 
 // column slicing / concatenation

@@ -181,8 +181,8 @@ int bfs_from(const DevMat& A, int start, int base, DevBuf<int32_t>& dist, DevBuf
 
 }  // namespace
 
-bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidth_out) {
-  if (A.loose() || A.expanded() || A.rows != A.cols || A.cols < 2) return false;
+namespace {
+bool band_order_attempt(const DevMat& A, int max_rounds, DevBuf<int32_t>& newpos, int64_t* bandwidth_out) {
   const int n = A.cols;
   DevBuf<int32_t> dist((size_t)n), pos((size_t)n), cur((size_t)n), nxt((size_t)n), counter(2);
   DevBuf<unsigned long long> keys((size_t)n);
@@ -212,9 +212,9 @@ bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidt
     HIP_CHECK(hipMemcpyAsync(dist_keep.p, dist.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
     HIP_CHECK(hipMemcpyAsync(pos_keep.p, pos.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
     int from = start, prev_levels = -1;
-    for (int round = 0; round < 4; ++round) {
+    for (int round = 0; round < max_rounds; ++round) {
       reached = bfs_from(A, from, done, dist, pos, cur, nxt, counter, keys, &last, &levels);
-      if (round == 3 || (round > 0 && levels <= prev_levels)) break;   // this search's order stands
+      if (round + 1 == max_rounds || (round > 0 && levels <= prev_levels)) break;   // this search's order stands
       prev_levels = levels;
       from = last;
       HIP_CHECK(hipMemcpyAsync(dist.p, dist_keep.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
@@ -268,6 +268,26 @@ bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidt
   }
   if (bandwidth_out) *bandwidth_out = best;
   newpos = std::move(pos);
+  return true;
+}
+}  // namespace
+
+bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidth_out) {
+  if (A.loose() || A.expanded() || A.rows != A.cols || A.cols < 2) return false;
+  // one search from the least connected vertex usually is the end of a band already: restarts from the far end
+  // (pseudo-peripheral iteration) only when the band found is not tight around the entries
+  int64_t bw = 0;
+  if (!band_order_attempt(A, 1, newpos, &bw)) return false;
+  const double per_col = (double)A.nnz / (double)A.cols;
+  if ((double)(2 * bw + 1) > 1.25 * per_col + 2.0) {
+    DevBuf<int32_t> pos2;
+    int64_t bw2 = 0;
+    if (band_order_attempt(A, 4, pos2, &bw2) && bw2 < bw) {
+      newpos = std::move(pos2);
+      bw = bw2;
+    }
+  }
+  if (bandwidth_out) *bandwidth_out = bw;
   return true;
 }
 
