@@ -2492,9 +2492,15 @@ __global__ void k_remap_gather(const unsigned long long* __restrict__ keys, cons
 }
 __global__ void k_count_valid(const unsigned long long* __restrict__ keys, int64_t n,
                               unsigned long long* __restrict__ out) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long m = __ballot(p < n && keys[p] != ~0ull);   // (one atomic per wave, not per entry)
-  if (m && lane_id() == 0) atomicAdd(out, (unsigned long long)__popcll(m));
+  // (a few thousand atomics on the one counter, not one per entry or per wave: they serialise in L2)
+  __shared__ unsigned long long sc[4];
+  unsigned long long c = 0;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
+    c += keys[p] != ~0ull ? 1ull : 0ull;
+  c = (unsigned long long)wave_sum_i64((int64_t)c);
+  if (lane_id() == 0) sc[threadIdx.x / WAVE] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sc[0] + sc[1] + sc[2] + sc[3]);
 }
 
 // column slicing / concatenation
@@ -4429,7 +4435,7 @@ DevMat remap_impl(const DevMat& A, const int32_t* d_row_map, const int32_t* d_co
                        reinterpret_cast<const T*>(A.val.p), nnz, d_row_map, d_col_map, transpose_after ? 1 : 0, col_lo,
                        col_hi, drop_zero ? 1 : 0, keys.p, pay.p);
   });
-  hipLaunchKernelGGL(k_count_valid, dim3(cdiv(nnz, 256)), dim3(256), 0, stream(), keys.p, nnz, nvalid.p);
+  hipLaunchKernelGGL(k_count_valid, dim3(std::min(cdiv(nnz, 256), 2048)), dim3(256), 0, stream(), keys.p, nnz, nvalid.p);
   size_t tmp_bytes = 0;
   HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.p, keys2.p, pay.p, pay2.p, (size_t)nnz, 0, 64, stream()));
   DevBuf<char> tmp(tmp_bytes);
