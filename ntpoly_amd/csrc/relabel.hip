@@ -159,9 +159,7 @@ __global__ __launch_bounds__(1024) void k_bfs_multi(const int64_t* __restrict__ 
 }
 
 int bfs_from(const DevMat& A, int start, int base, DevBuf<int32_t>& dist, DevBuf<int32_t>& pos, DevBuf<int32_t>& cur,
-             DevBuf<int32_t>& nxt, DevBuf<int32_t>& counter, DevBuf<unsigned long long>& keys, int* last_vertex, int* levels) {
-  (void)counter;
-  (void)keys;
+             DevBuf<int32_t>& nxt, int* last_vertex, int* levels) {
   DevBuf<long long> out(3);
   DevBuf<unsigned> ctl(4);
   DevBuf<unsigned long long> best(1);
@@ -184,8 +182,7 @@ int bfs_from(const DevMat& A, int start, int base, DevBuf<int32_t>& dist, DevBuf
 namespace {
 bool band_order_attempt(const DevMat& A, int max_rounds, DevBuf<int32_t>& newpos, int64_t* bandwidth_out) {
   const int n = A.cols;
-  DevBuf<int32_t> dist((size_t)n), pos((size_t)n), cur((size_t)n), nxt((size_t)n), counter(2);
-  DevBuf<unsigned long long> keys((size_t)n);
+  DevBuf<int32_t> dist((size_t)n), pos((size_t)n), cur((size_t)n), nxt((size_t)n);
   auto reset = [&]() {
     hipLaunchKernelGGL(k_fill_i32v, dim3(cdiv(n, 256)), dim3(256), 0, stream(), dist.p, (int64_t)n, -1);
     hipLaunchKernelGGL(k_fill_i32v, dim3(cdiv(n, 256)), dim3(256), 0, stream(), pos.p, (int64_t)n, -1);
@@ -213,7 +210,7 @@ bool band_order_attempt(const DevMat& A, int max_rounds, DevBuf<int32_t>& newpos
     HIP_CHECK(hipMemcpyAsync(pos_keep.p, pos.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
     int from = start, prev_levels = -1;
     for (int round = 0; round < max_rounds; ++round) {
-      reached = bfs_from(A, from, done, dist, pos, cur, nxt, counter, keys, &last, &levels);
+      reached = bfs_from(A, from, done, dist, pos, cur, nxt, &last, &levels);
       if (round + 1 == max_rounds || (round > 0 && levels <= prev_levels)) break;   // this search's order stands
       prev_levels = levels;
       from = last;
