@@ -20,14 +20,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     import ntpoly_amd as nt
-    from gen import banded_triplets
+    from gen import banded_triplets, permuted_banded_triplets
     nt.init_comm()
     nt.ConstructGlobalProcessGrid(1, 1, 1)
     nt.set_option("time_kernels", 1)
     out = {}
 
-    def product(n, h, thr, reps=5, complex_=False):
-        col, row, val = banded_triplets(n, h, complex_=complex_)
+    def product(n, h, thr, reps=5, complex_=False, permute=None):
+        if permute is None:
+            col, row, val = banded_triplets(n, h, complex_=complex_)
+        else:
+            col, row, val = permuted_banded_triplets(n, h, permute, complex_=complex_)
         A = nt.Matrix_ps.from_triplets(n, col, row, val)
         del col, row, val
         C = nt.Matrix_ps(n)
@@ -45,13 +48,43 @@ def main():
         dt, st = best
         per = 20 if complex_ else 12
         alg = per * (st["nnz_a"] + st["nnz_b"] + st["nnz_c"]) + 4 * (3 * n + 3)
-        return dict(n=n, halfband=h, threshold=thr, wall_ms=1e3 * dt, kernel_ms=st["ms_numeric"], nnz_out=st["nnz_c"],
+        gs = nt.last_grouped_stats()
+        return dict(n=n, halfband=h, threshold=thr, permute_seed=permute, grouped_hash=int(gs.get("used", 0)), wall_ms=1e3 * dt, kernel_ms=st["ms_numeric"], nnz_out=st["nnz_c"],
                     products=st["products"], nnz_out_per_s=st["nnz_c"] / dt, products_per_s=st["products"] / (st["ms_numeric"] * 1e-3),
                     alg_GBps_kernel=alg / (st["ms_numeric"] * 1e-3) / 1e9, slab=st["slab"])
 
     out["config1_thr0"] = product(65536, 50, 0.0)
     out["config1_thr1e-8"] = product(65536, 50, 1e-8)
     out["config3_one_product_1gpu"] = product(1048576, 100, 1e-8, reps=3)
+    # the same operand under the seeded relabelling ("with and without random permutation"): one product on
+    # the grouped LDS-hash kernel (a single multiply has no loop to amortise a recovered band order over)
+    out["config3_one_product_1gpu_relabelled"] = product(1048576, 100, 1e-8, reps=3, permute=42)
+    # TRS2 on the configs[3] operand, natural order and relabelled (label-ordered slab steps)
+    for tag, perm in (("config3_trs2_1gpu", None), ("config3_trs2_1gpu_relabelled", 42)):
+        n3, h3 = 1048576, 100
+        col, row, val = banded_triplets(n3, h3) if perm is None else permuted_banded_triplets(n3, h3, perm)
+        H3 = nt.Matrix_ps.from_triplets(n3, col, row, val)
+        del col, row, val
+        I3 = nt.Matrix_ps(n3)
+        I3.FillIdentity()
+        res = []
+        for iters in (4, 4, 14):   # (the first solve warms the allocator up and, relabelled, finds the band order)
+            K3 = nt.Matrix_ps(n3)
+            p3 = nt.SolverParameters()
+            p3.SetThreshold(1e-8)
+            p3.SetConvergeDiff(1e-30)
+            p3.SetMaxIterations(iters)
+            p3.SetMonitorConvergence(False)
+            nt.synchronize()
+            t0 = time.perf_counter()
+            e3, _ = nt.DensityMatrixSolvers.TRS2(H3, I3, n3 / 2.0, K3, p3)
+            nt.synchronize()
+            res.append((time.perf_counter() - t0, e3, K3.GetSize()))
+            del K3
+        out[tag] = dict(n=n3, halfband=h3, threshold=1e-8, permute_seed=perm, ms_per_iteration=1e3 * (res[2][0] - res[1][0]) / 10,
+                        wall_s_first_solve_4_iterations=res[0][0], wall_s_14_iterations=res[2][0], energy_14=res[2][1],
+                        nnz_K_14=res[2][2])
+        del H3, I3
 
     n, h, thr = 131072, 50, 1e-8
     col, row, val = banded_triplets(n, h, complex_=True, shift=2.0)
