@@ -130,6 +130,7 @@ DevMat gather_panels(const DevMat& loc, const std::vector<int32_t>& widths);
 void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha, double beta, double threshold);
 void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold);
 void ps_scale(PSMatrix& A, double c);
+void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold);   // ScaleMatrix + IncrementMatrix, one pass
 // B <- alpha*A + beta*B with the increment rules and, fused, out = dot(B_new, D) (TRS2 update + energy)
 void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[4],
                   bool want_trace = false);  // out[2] = trace(B_new) on request

@@ -2433,14 +2433,23 @@ __global__ void k_identity(int64_t* __restrict__ outer, int32_t* __restrict__ in
 template <typename T>
 __global__ void k_identity_check(Csc A, int col_offset, unsigned long long* __restrict__ flags) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= A.cols) return;
   const T* __restrict__ Av = static_cast<const T*>(A.val);
-  for (int64_t p = A.outer[j]; p < A.outer[j + 1]; ++p) {
-    bool one;
-    if constexpr (Sc<T>::cplx) one = hypot(Av[p].x - 1.0, Av[p].y) <= 2.2250738585072014e-308;
-    else one = fabs(Av[p] - 1.0) <= 2.2250738585072014e-308;
-    if (A.inner[p] != j + col_offset || !one) atomicAdd(&flags[0], 1ull);
-    else atomicAdd(&flags[1], 1ull);
+  long long bad = 0, good = 0;
+  if (j < A.cols) {
+    for (int64_t p = A.outer[j]; p < A.outer[j + 1]; ++p) {
+      bool one;
+      if constexpr (Sc<T>::cplx) one = hypot(Av[p].x - 1.0, Av[p].y) <= 2.2250738585072014e-308;
+      else one = fabs(Av[p] - 1.0) <= 2.2250738585072014e-308;
+      if (A.inner[p] != j + col_offset || !one) bad += 1;
+      else good += 1;
+    }
+  }
+  // (one pair of atomics per wave: every entry adding to the same two counters serialises in L2)
+  bad = wave_sum_i64(bad);
+  good = wave_sum_i64(good);
+  if (lane_id() == 0) {
+    if (bad) atomicAdd(&flags[0], (unsigned long long)bad);
+    if (good) atomicAdd(&flags[1], (unsigned long long)good);
   }
 }
 
@@ -2764,8 +2773,13 @@ __global__ void k_span_block_max(const int32_t* __restrict__ span, int n, int J,
   for (int j = b * J; j < min(n, (b + 1) * J); ++j) t += (unsigned long long)span[j];
   atomicMax(out, t);
 }
-const DotOperand& dot_operand(const DevMat& D) {
+DotOperand*& dot_operand_slot() {
   static DotOperand* c = new DotOperand();
+  return c;
+}
+void drop_dot_operand() { *dot_operand_slot() = DotOperand(); }
+const DotOperand& dot_operand(const DevMat& D) {
+  DotOperand* c = dot_operand_slot();
   const unsigned long long ser = dev_alloc_serial(D.val.p);
   if (c->val == D.val.p && c->serial == ser && ser != 0 && c->epoch == value_epoch() && c->nnz == D.nnz && c->cols == D.cols)
     return *c;
@@ -4732,6 +4746,11 @@ __global__ void k_invert_perm(const int32_t* __restrict__ newpos, int n, int32_t
 void relabel_giveup(const DevMat& D) {   // a step on the relabelled form was refused: do not enter it again for this operand
   RelabelCache& c = relabel_cache();
   if (relabel_key_matches(c, D)) c.usable = false;
+}
+
+void drop_operand_caches() {   // the device memory kept between solves (expanded D, D in the recovered order)
+  relabel_cache() = RelabelCache();
+  drop_dot_operand();
 }
 
 const DevMat* relabelled_operand(const DevMat& D) {

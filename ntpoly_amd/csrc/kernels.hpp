@@ -149,6 +149,7 @@ bool slab_from_csc(DevMat& Xs, DevBuf<int32_t>& lab);
 bool relabel_enter(DevMat& X, const DevMat& D);
 const DevMat* relabelled_operand(const DevMat& D);
 void relabel_giveup(const DevMat& D);
+void drop_operand_caches();   // frees what the fused / relabelled TRS2 paths keep between solves
 // relabel.hip: a bandwidth-reducing order of a symmetric pattern (Cuthill-McKee, breadth-first levels on the device):
 // newpos[old index] = new index, *bandwidth = max |new row - new column|.  false: not a square packed matrix, or
 // more components than the search is willing to chain

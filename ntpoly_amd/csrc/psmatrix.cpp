@@ -468,6 +468,18 @@ void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold
 
 void ps_scale(PSMatrix& A, double c) { scale(A.loc, c); }
 
+// B <- alpha*A + beta*B: ScaleMatrix(B, beta) followed by IncrementMatrix(A, B, alpha, threshold) in one pass (the
+// merge kernels scale B's values as they read them: the same products, the same rules, bit for bit)
+void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold) {
+  if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
+  if (A.cplx != B.cplx || &A == &B) {
+    ps_scale(B, beta);
+    ps_increment(A, B, alpha, threshold);
+    return;
+  }
+  axpby(A.loc, B.loc, alpha, beta, threshold, nullptr, nullptr);
+}
+
 void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[4],
                   bool want_trace) {
   out[2] = out[3] = 0.0;

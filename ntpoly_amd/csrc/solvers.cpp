@@ -420,8 +420,7 @@ void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
   for (II = 1; II <= p.max_iterations; ++II) {                     // :586-638
     ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
     ps_copy(X2, Fx);
-    ps_scale(Fx, -3.0);
-    ps_increment(X, Fx, 4.0, 0.0);
+    ps_axpby(X, Fx, 4.0, -3.0, 0.0);                                // ScaleMatrix(Fx, -3); IncrementMatrix(X, Fx, 4)
     ps_copy(IMat, Gx);
     ps_increment(X, Gx, -2.0, 0.0);
     ps_increment(X2, Gx, 1.0, 0.0);
@@ -431,17 +430,16 @@ void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
     else sigma_array[(size_t)II] = (trace - trace_fx) / trace_gx;
     if (sigma_array[(size_t)II] > sigma_max) {
       ps_copy(X, Temp);
-      ps_scale(Temp, 2.0);
-      ps_increment(X2, Temp, -1.0, 0.0);
+      ps_axpby(X2, Temp, -1.0, 2.0, 0.0);                           // ScaleMatrix(Temp, 2); IncrementMatrix(X2, Temp, -1)
     } else if (sigma_array[(size_t)II] < sigma_min) {
       ps_copy(X2, Temp);
     } else {
-      ps_scale(Gx, sigma_array[(size_t)II]);
-      ps_increment(Fx, Gx, 1.0, 0.0);
+      ps_axpby(Fx, Gx, 1.0, sigma_array[(size_t)II], 0.0);          // ScaleMatrix(Gx, sigma); IncrementMatrix(Fx, Gx)
       ps_multiply(X2, Gx, Temp, 1.0, 0.0, p.threshold);
     }
-    // :630-631 IncrementMatrix(TempMat, X_k, -1) is overwritten by the copy that follows it
-    ps_copy(Temp, X);
+    // :630-631 IncrementMatrix(TempMat, X_k, -1) is overwritten by the copy that follows it; the copy itself is a
+    // hand-over here (Temp is rebuilt in every iteration)
+    std::swap(X.loc, Temp.loc);
     energy_old = energy_value;
     energy_value = real_dot(X, WH);
     monitor_append(mon, energy_value - energy_old);

@@ -218,7 +218,10 @@ void ntpoly_amd_memory(long long* in_use, long long* cached) {
   *in_use = (long long)dev_bytes_in_use();
   *cached = (long long)dev_bytes_cached();
 }
-void ntpoly_amd_release_cache() { dev_release_cache(); }
+void ntpoly_amd_release_cache() {
+  drop_operand_caches();
+  dev_release_cache();
+}
 // hipMalloc calls the caching allocator had to make so far, and the host milliseconds they took
 void ntpoly_amd_malloc_stats(long long* calls, double* ms) { dev_malloc_stats(calls, ms); }
 // bulk triplet transfer (the reference ABI moves triplets one at a time)
