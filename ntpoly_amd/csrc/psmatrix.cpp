@@ -498,8 +498,8 @@ namespace {
 // One TRS2 step of a rank whose panel is in slab form (kernels.hpp SlabForm): the halo travels as dense column runs
 // (8 bytes per row of a column's span, no row ids, no offsets: every rank derives the layout from the all-gathered
 // column extents), the run records of the kernel address the received runs where they land, the multiplier tiles are
-// local.  Protocol, all on the engine stream with ONE host synchronisation: (1) all-gather of the request records
-// (first / last row of the panel, nnz), of the packed extents and of the prefix sums of the spans; (2) a kernel
+// local.  Protocol, all on the engine stream with ONE host synchronisation: (1) ONE all-gather of a record per rank:
+// request (first / last row of the panel, nnz), packed extents, prefix sums of the spans; (2) a kernel
 // derives who sends how many doubles to whom, one read-back; (3) the runs of the requested columns are packed per
 // requester and exchanged in one send / recv group; (4) layout kernel, then slab_step.  Collective: every rank calls it.
 // Returns this rank's success; the result is in fu.result (the caller installs it when all ranks succeeded).
@@ -516,22 +516,24 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
     panel_range(dim, P, q, &a0, &a1);
     maxw = std::max(maxw, a1 - a0);
   }
-  const int pitch = maxw + 1;
+  // ONE all-gather per step: every rank contributes a record of `pitch` 8-byte words -- its request (4 words), the
+  // packed extents of its columns, the prefix sums of their spans and, for the statistics (timers on), their entry
+  // counts; the kernels below read the sections through the common stride
+  const int wcols = maxw + 1;
+  const bool with_counts = options().time_kernels != 0;
+  const int pitch = 4 + (with_counts ? 3 : 2) * wcols;
   std::vector<int64_t> req((size_t)4 * P, 0), bound((size_t)2 * P, 0), cnt((size_t)P * P, 0);
-  DevBuf<int64_t> d_req((size_t)4 * P), d_ext_all((size_t)P * pitch), d_pre_all((size_t)P * pitch), d_bound((size_t)2 * P),
-      d_cnt((size_t)P * P);
-  slab_request_async(B.loc, d_req.p + 4 * me);
-  slab_extents_async(B.loc, d_ext_all.p + (size_t)me * pitch, d_pre_all.p + (size_t)me * pitch);
-  tr.allgather(d_req.p + 4 * me, d_req.p, 4 * sizeof(int64_t));
-  tr.allgather(d_ext_all.p + (size_t)me * pitch, d_ext_all.p, (size_t)pitch * sizeof(int64_t));
-  tr.allgather(d_pre_all.p + (size_t)me * pitch, d_pre_all.p, (size_t)pitch * sizeof(int64_t));
-  DevBuf<int64_t> d_cnt_all;   // statistics (timers on): entries per column of every panel, for the product count
-  if (options().time_kernels) {
-    d_cnt_all.alloc((size_t)P * pitch);
-    slab_counts_async(B.loc, d_cnt_all.p + (size_t)me * pitch);
-    tr.allgather(d_cnt_all.p + (size_t)me * pitch, d_cnt_all.p, (size_t)pitch * sizeof(int64_t));
-  }
-  halo_counts_async(d_req.p, d_pre_all.p, pitch, dim, P, me, d_cnt.p, d_bound.p);   // (counts in doubles here)
+  DevBuf<int64_t> d_all((size_t)P * pitch), d_req((size_t)4 * P), d_bound((size_t)2 * P), d_cnt((size_t)P * P);
+  int64_t* mine = d_all.p + (size_t)me * pitch;
+  const int64_t *d_ext_all = d_all.p + 4, *d_pre_all = d_all.p + 4 + wcols;
+  const int64_t* d_cnt_all = with_counts ? d_all.p + 4 + 2 * (size_t)wcols : nullptr;
+  slab_request_async(B.loc, mine);
+  slab_extents_async(B.loc, mine + 4, mine + 4 + wcols);
+  if (with_counts) slab_counts_async(B.loc, mine + 4 + 2 * (size_t)wcols);
+  tr.allgather(mine, d_all.p, (size_t)pitch * sizeof(int64_t));
+  HIP_CHECK(hipMemcpy2DAsync(d_req.p, 4 * sizeof(int64_t), d_all.p, (size_t)pitch * sizeof(int64_t), 4 * sizeof(int64_t), (size_t)P,
+                             hipMemcpyDeviceToDevice, stream()));
+  halo_counts_async(d_req.p, d_pre_all, pitch, dim, P, me, d_cnt.p, d_bound.p);   // (counts in doubles here)
   if ((size_t)4 * P + (size_t)P * P + 2 * P <= 500) {
     ScalarFetch f;
     f.add(d_req.p, 4 * P, req.data());
@@ -561,7 +563,7 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   DevBuf<double> sendbuf((size_t)soff[(size_t)P] + 1);
   for (int q = 0; q < P; ++q)
     if (q != me && cnt[(size_t)me * P + q] > 0)
-      slab_pack_runs_async(B.loc, d_pre_all.p + (size_t)me * pitch, sa[(size_t)q] - B.c0, sb[(size_t)q] - B.c0,
+      slab_pack_runs_async(B.loc, d_pre_all + (size_t)me * pitch, sa[(size_t)q] - B.c0, sb[(size_t)q] - B.c0,
                            sendbuf.p + soff[(size_t)q]);
   // what I receive: the segments of the other owners tile [kmin, kmax] in rank order
   std::vector<int32_t> ra((size_t)P), rb((size_t)P);
@@ -590,9 +592,9 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   d_ra.upload(ra.data(), (size_t)P);
   d_zoff.upload(zoff.data(), (size_t)P);
   DevBuf<int32_t> ncount;
-  if (d_cnt_all.p) ncount.alloc((size_t)(kb - ka));
-  slab_halo_layout_async(d_ext_all.p, d_pre_all.p, pitch, dim, P, me, ka, kb, d_ra.p, d_zoff.p, recvbuf.p, B.loc, nfirst.p,
-                         nlast.p, naddr.p, d_cnt_all.p, ncount.p);
+  if (d_cnt_all) ncount.alloc((size_t)(kb - ka));
+  slab_halo_layout_async(d_ext_all, d_pre_all, pitch, dim, P, me, ka, kb, d_ra.p, d_zoff.p, recvbuf.p, B.loc, nfirst.p,
+                         nlast.p, naddr.p, d_cnt_all, ncount.p);
   SlabHalo halo;
   halo.ka = ka;
   halo.kb = kb;
