@@ -339,8 +339,7 @@ void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace,
     double alpha;
     if (trace_value > trace) {
       alpha = 2.0 / (2.0 - Beta);
-      ps_scale(X, alpha);
-      ps_increment(IMat, X, 1.0 - alpha, 0.0);
+      ps_axpby(IMat, X, 1.0 - alpha, alpha, 0.0);                   // ScaleMatrix(X, alpha); IncrementMatrix(I, X, 1 - alpha)
       ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
       std::swap(X.loc, X2.loc);  // CopyMatrix(X_k2, X_k); X2 is scratch
       Beta = (alpha * Beta + 1 - alpha) * (alpha * Beta + 1 - alpha);
@@ -348,8 +347,7 @@ void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace,
     } else {
       alpha = 2.0 / (1.0 + BetaBar);
       ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
-      ps_scale(X, 2 * alpha);
-      ps_increment(X2, X, -1.0 * alpha * alpha, 0.0);
+      ps_axpby(X2, X, -1.0 * alpha * alpha, 2 * alpha, 0.0);        // ScaleMatrix(X, 2 alpha); IncrementMatrix(X2, X, -alpha^2)
       Beta = 2.0 * alpha * Beta - alpha * alpha * Beta * Beta;
       BetaBar = 2.0 * alpha * BetaBar - alpha * alpha * BetaBar * BetaBar;
     }
@@ -535,8 +533,7 @@ void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K
       a2 = (1.0 + sg) / (1.0 - sg);
       a3 = -1.0 / (1.0 - sg);
     }
-    ps_scale(X, a1);
-    ps_increment(X2, X, a2, p.threshold);
+    ps_axpby(X2, X, a2, a1, p.threshold);                           // ScaleMatrix(X, a1); IncrementMatrix(X2, X, a2)
     ps_increment(X3, X, a3, p.threshold);
     energy_old = energy_value;
     energy_value = real_dot(X, WH);
@@ -702,7 +699,7 @@ void sign_core(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters& 
     ps_multiply(Out, Temp1, Temp2, 0.5 * alpha_k, 0.0, p.threshold);
     ps_increment(Temp2, Out, -1.0, 0.0);
     const double norm_value = ps_norm(Out);
-    ps_copy(Temp2, Out);
+    std::swap(Out.loc, Temp2.loc);   // CopyMatrix(Temp2, Out): Temp2 is rebuilt by the next multiply
     monitor_append(mon, norm_value);
     trace_rec(norm_value, 0.0, alpha_k, Out);
     if (monitor_converged(mon, p.be_verbose)) break;
@@ -793,8 +790,7 @@ void invert_core(const PSMatrix& InputMat, PSMatrix& OutputMat, const SolverPara
     norm_value = ps_norm(Temp2);
     PSMatrix T2;
     ps_multiply(Temp1, Out, T2, -1.0, 0.0, p.threshold);
-    ps_scale(Out, 2.0);
-    ps_increment(T2, Out, 1.0, p.threshold);
+    ps_axpby(T2, Out, 1.0, 2.0, p.threshold);                       // ScaleMatrix(Out, 2); IncrementMatrix(T2, Out)
     monitor_append(mon, norm_value);
     trace_rec(norm_value, 0.0, sigma, Out);
     if (monitor_converged(mon, p.be_verbose)) break;
@@ -867,13 +863,12 @@ void isr_order2(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
     ps_increment(X, Temp, -1.0, 0.0);
     const double norm_value = ps_norm(Temp);
     ps_copy(Identity, T);
-    ps_scale(T, 3.0);
-    ps_increment(X, T, -1.0, 0.0);
+    ps_axpby(X, T, -1.0, 3.0, 0.0);                                 // ScaleMatrix(T, 3); IncrementMatrix(X, T, -1)
     ps_scale(T, 0.5);
-    ps_copy(ISR, Temp);
+    std::swap(ISR, Temp);                                           // CopyMatrix(ISR, Temp): ISR is rebuilt by the multiply
     ps_multiply(Temp, T, ISR, 1.0, 0.0, p.threshold);
     ps_scale(ISR, std::sqrt(lambda));
-    ps_copy(SR, Temp);
+    std::swap(SR, Temp);
     ps_multiply(T, Temp, SR, 1.0, 0.0, p.threshold);
     ps_scale(SR, std::sqrt(lambda));
     monitor_append(mon, norm_value);
@@ -924,8 +919,7 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
     const double norm_value = ps_norm(X);
     if (order == 3) {                                              // :425-433
       ps_multiply(X, X, Temp, 1.0, 0.0, p.threshold);
-      ps_scale(X, -0.5);
-      ps_increment(Identity, X, 1.0, 0.0);
+      ps_axpby(Identity, X, 1.0, -0.5, 0.0);                        // ScaleMatrix(X, -1/2); IncrementMatrix(I, X)
       ps_increment(Temp, X, 0.375, 0.0);
     } else {                                                       // :434-479 (Knuth's 2-multiply quartic)
       const double aa = -40.0 / 35.0, bb = 48.0 / 35.0, cc = -64.0 / 35.0, dd = 128.0 / 35.0;
@@ -936,17 +930,16 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
       ps_multiply(X, X, Temp, 1.0, 0.0, p.threshold);
       ps_increment(X, Temp, a, 0.0);
       ps_copy(Identity, Temp2);
-      ps_scale(Temp2, b);
-      ps_increment(X, Temp2, 1.0, 0.0);
+      ps_axpby(X, Temp2, 1.0, b, 0.0);                              // ScaleMatrix(Temp2, b); IncrementMatrix(X, Temp2)
       ps_increment(Temp, Temp2, 1.0, 0.0);
       ps_increment(Identity, Temp, c, 0.0);
       ps_multiply(Temp2, Temp, X, 1.0, 0.0, p.threshold);
       ps_increment(Identity, X, d, 0.0);
       ps_scale(X, 35.0 / 128.0);
     }
-    ps_copy(ISR, Temp);                                            // :483-485
+    std::swap(ISR, Temp);                                          // :483-485 (the copy is a hand-over: ISR is rebuilt)
     ps_multiply(X, Temp, ISR, 1.0, 0.0, p.threshold);
-    ps_copy(SR, Temp);                                             // :488-490
+    std::swap(SR, Temp);                                           // :488-490
     ps_multiply(Temp, X, SR, 1.0, 0.0, p.threshold);
     monitor_append(mon, norm_value);
     trace_rec(norm_value, 0.0, lambda, ISR);
