@@ -952,14 +952,16 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
       const double* src = fz0.dexp + fz0.doff[min(b * J + jj, ncols - 1)];
       for (int i = threadIdx.x; i < dn; i += NW * WAVE) dtile[ofs + i] = src[i];
     }
-    if (fz0.prod) {   // products of this block = sum over the tile rows k of (non-zero multipliers) * (entries of A(:, k))
+    if (fz0.prod) {   // products of this block = sum over the tile rows k of (non-zero multipliers) * (entries of A(:, k));
+                      // always run when the operand is in slab form: reading the tile here also pulls it into L2 before
+                      // the loop asks for its rows one by one (2.5 % of the step; without in_count the sum is not used)
       const double* __restrict__ tile = bblk + blk_boff[b];
       long long p = 0;
       for (int k = threadIdx.x; k < kn; k += NW * WAVE) {
         int c = 0;
 #pragma unroll
         for (int q = 0; q < J; ++q) c += tile[(size_t)k * J + q] != 0.0 ? 1 : 0;
-        p += (long long)c * fz0.in_count[fz0.steps ? fz0.steps[blk_boff[b] / J + 4 * (int64_t)b + k] : kmin + k];
+        p += (long long)c * (fz0.in_count ? fz0.in_count[fz0.steps ? fz0.steps[blk_boff[b] / J + 4 * (int64_t)b + k] : kmin + k] : 1);
       }
       p = wave_sum_i64(p);
       __shared__ long long prod_s[NW];
@@ -3692,10 +3694,10 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     fz.xplast = in.plast.p;
     fz.oplast = oplast.p;
   }
-  if (timing && (!halo || halo->count)) {   // (statistics only; the tile rows are global column numbers)
-    fz.in_count = halo ? halo->count - ka : in.count.p;
-    fz.prod = reinterpret_cast<long long*>(blk_prod);
-  }
+  // the block's pass over its multiplier tile before the loop: always (it warms L2); with the entry counts of the
+  // columns at hand it also counts the products (the tile rows are global column numbers)
+  fz.prod = reinterpret_cast<long long*>(blk_prod);
+  if (!halo || halo->count) fz.in_count = halo ? halo->count - ka : in.count.p;
   DevBuf<char> fz_args(sizeof(SlabFuseArgs));
   fz_args.upload(reinterpret_cast<const char*>(&fz), sizeof(SlabFuseArgs));
   const int dr = dense_rule ? 1 : 0;
@@ -3785,8 +3787,8 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   st.fused = fu.mode;
   st.nnz_c = pnz;
   st.tmp_entries = tmp_total;
-  const bool counted = timing && (!halo || halo->count);
-  st.products = counted ? (int64_t)raw[2] : -1;   // (counted only with the timers on)
+  const bool counted = !halo || halo->count;
+  st.products = counted ? (int64_t)raw[2] : -1;   // (panel steps: only when the entry counts travelled with the extents)
   last_spgemm_stats() = st;
   SpgemmAccum& acc = spgemm_accum();
   acc.calls += 1;
