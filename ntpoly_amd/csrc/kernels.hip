@@ -11,6 +11,8 @@
 #include "kernels.hpp"
 #include "device_util.hpp"
 #include "spgemm_grouped.hpp"
+#include "slab_types.hpp"
+#include "spgemm_tile.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -230,7 +232,6 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const int32_t* __restrict__
 }
 
 // register-slab kernel geometry: J output columns per workgroup, SL slabs of 64 rows per wave, NW waves
-constexpr int SLAB_J = 16, SLAB_SL = 3, SLAB_NW = 4;
 constexpr int SLAB_CJ = 8, SLAB_CSL = 2, SLAB_CNW = 6;  // complex operands
 
 // bins: 0 empty | 1..4 LDS direct window of 512/1024/2048/4096 rows | 5 LDS hash | 6 HBM accumulator
@@ -812,16 +813,6 @@ __global__ void k_slab_tmpoff(int ncols, const int32_t* __restrict__ blk_w, cons
   tmpoff[j] = blk_toff[b] + (int64_t)(j % J) * blk_w[b];
 }
 
-// Run record of an expanded column of A, 32 bytes, fetched by ONE s_load_dwordx8: words 0-3 are the buffer
-// descriptor of the run (base address, bytes, flags) used as-is by buffer_load; first8 = 8 * first row turns a
-// row offset into a run offset; (first, span62 = rows + 62) give the one-compare test "does the run touch
-// the slab that ends at row e": (unsigned)(e - first) <= span62.
-struct alignas(32) SlabRun {
-  uint32_t addr_lo, addr_hi, nbytes, flags;
-  int32_t first8, first, span62, pad;
-};
-constexpr uint32_t kBufferFlags = 0x00020000u;  // raw buffer, 32-bit data format (gfx9 family word 3)
-
 // n + 4 records: the tail is empty (pipelined prefetch past the last column)
 __global__ void k_slab_runs(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax,
                             const int64_t* __restrict__ aeoff, const char* __restrict__ aexp, int elem_bytes,
@@ -864,32 +855,6 @@ typedef double v8d __attribute__((ext_vector_type(8)));
 // Both leave the result LOOSE in the upper-bound slots.  A zero of the expanded X is read as "no entry": the host
 // makes sure X stores no zero value (DevMat::zero_free).  Where a column of X leaves its block's row window the kernel
 // raises fz.flag and the host repeats the step on the unfused path.
-struct SlabFuseArgs {
-  double am = 0, bm = 0, thr_m = 0;
-  const double* xexp = nullptr;      // expanded columns of X
-  const int64_t* xoff = nullptr;
-  const int32_t *xmin = nullptr, *xmax = nullptr;
-  const double* dexp = nullptr;      // expanded columns of D
-  const int64_t* doff = nullptr;
-  const int32_t *dmin = nullptr, *dmax = nullptr;
-  int32_t *ofirst = nullptr, *olast = nullptr;   // first / last row of every column of the result
-  double* tiles = nullptr;           // the result as tiles (SlabForm::tiles), block b at blk_toff[b]
-  double* part = nullptr;            // [2 * nblocks]: (dot, trace) of the block
-  long long* pnnz = nullptr;         // [nblocks]: kept entries of the product
-  const int32_t* in_count = nullptr; // statistics (operand in slab form): entries per column of X; with prod set, the
-  long long* prod = nullptr;         // block counts its intermediate products from its multiplier tile before the loop
-  // label-ordered steps (the data sits in a bandwidth-reducing order, the arithmetic follows the ORIGINAL labels
-  // lab[index]): the k steps of a block come in ascending label -- per-block run records blkruns[rec_off(b) + t] and
-  // the multiplier tile handed to the kernel are in that order, steps[...] names the column of step t -- and "beyond
-  // the other column's last row" compares labels: xplast[j] = largest label in X(:, j), oplast[j] the result's
-  const int32_t* lab = nullptr;
-  const SlabRun* blkruns = nullptr;
-  const int32_t* steps = nullptr;
-  const int32_t* xplast = nullptr;
-  int32_t* oplast = nullptr;
-  int* flag = nullptr;
-  int col_offset = 0;
-};
 
 template <int J, int SL, int NW, int MODE, int EPI = 0>  // MODE 0 unfused, 1 fma, 2..4 ablations (timing experiments, wrong results)
 __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_spgemm_slab(
@@ -2841,6 +2806,29 @@ void flush_spgemm_timers() {
 }
 
 namespace {
+// compressed columns from the slab form: one wave per column, the non-zeros of its run in row order
+__global__ __launch_bounds__(256) void k_pack_slab(int ncols, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                                   const int64_t* __restrict__ off, const double* __restrict__ val,
+                                                   const int64_t* __restrict__ outer, int32_t* __restrict__ inner,
+                                                   double* __restrict__ out) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= ncols) return;
+  const int lane = lane_id();
+  const int f = first[j], l = last[j];
+  int64_t pos = outer[j];
+  const double* __restrict__ src = val + off[j];
+  for (int r0 = f; r0 <= l; r0 += WAVE) {
+    const int r = r0 + lane;
+    const double v = r <= l ? src[r - f] : 0.0;
+    const unsigned long long m = __ballot(v != 0.0);
+    if (v != 0.0) {
+      const int64_t q = pos + __popcll(m & lanemask_lt());
+      inner[q] = r;
+      out[q] = v;
+    }
+    pos += __popcll(m);
+  }
+}
 template <int MAXCH, int NW>
 void launch_pair3(int bin_lo, int bin_hi, int wrt, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
                   const uint8_t* binarr, const int64_t* tmpoff, int32_t* out_inner, double* out_val, int32_t* count,
@@ -2923,7 +2911,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   const int SJ = A.cplx ? SLAB_CJ : SLAB_J;
   // widest row window the slab kernels take: real 6 waves x 3 slabs = 1152 rows, complex 8 waves x 2 slabs = 1024
   // (the usual geometries are 4 x 3 and 6 x 2 = 768 rows; the wider workgroups serve operands with longer runs)
-  const int slab_rows = A.cplx ? 8 * SLAB_CSL * WAVE : (options().spgemm_fma ? SLAB_NW : 8) * SLAB_SL * WAVE;  // (the fused loop exists for 4 waves)
+  // (option spgemm_fma: 1 = the MFMA tile kernel, spgemm_tile.hip -- any window; 3 = the v_fma_f64 loop of the slab kernel, 4 waves)
+  const int slab_rows = A.cplx ? 8 * SLAB_CSL * WAVE : (options().spgemm_fma == 1 ? 16384 : (options().spgemm_fma ? SLAB_NW : 8) * SLAB_SL * WAVE);
   const size_t esz = A.cplx ? 16 : 8;
   const int sv_opt = options().spgemm_variant;
   // ---- grouped LDS-hash kernel FIRST when the previous multiply of this dimension was computed by it without a
@@ -3023,6 +3012,14 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     return;
   }
   st.slab = use_slab ? 1 : 0;
+  // real run-like operands under option spgemm_fma = 1: the same plan and operands, numeric phase on the matrix cores
+  const bool use_tile = use_slab && !A.cplx && options().spgemm_fma == 1 && sv_opt < 0 &&
+                        spgemm_tile_fits((int)hstats[17], (int)hstats[16]);
+  if (use_slab && !A.cplx && options().spgemm_fma == 1 && !use_tile && (int64_t)hstats[16] > SLAB_NW * SLAB_SL * WAVE) {
+    // (neither the tile kernel -- k range beyond its LDS tile -- nor the four-wave FMA loop: general kernels)
+    use_slab = false;
+    st.slab = 0;
+  }
   if (use_slab) {
     tmp_total = slab_tot[2];
     if (A.cplx)
@@ -3065,6 +3062,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<char> fz_args;
   DevBuf<int32_t> fz_first, fz_last;
   DevBuf<double> fz_tiles;
+  DevBuf<int64_t> tile_ooff, tile_otoff;   // (tile kernel: where every column's run / every block's tile rows start)
   bool fuse_now = false;
   if (use_slab) {
     zwords.alloc((size_t)4 * snb + 4);
@@ -3146,7 +3144,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     const bool whole = &A == &B && !arange && m == n && fuse && fuse->panel_c0 < 0;
     const bool panel = fuse && fuse->panel_c0 >= 0 && &A != &B && A.cols == m && ka <= fuse->panel_c0 && fuse->panel_c0 + n <= kb;
     const int xshift = panel ? fuse->panel_c0 - ka : 0;   // own column j = local column xshift + j of the A-side arrays
-    fuse_now = fuse != nullptr && fuse->mode != 0 && (whole || panel) && abl == 0 && !options().spgemm_fma &&
+    fuse_now = fuse != nullptr && fuse->mode != 0 && (whole || panel) && abl == 0 && (!options().spgemm_fma || use_tile) &&
                sv_opt < 0 && fuse->D && !fuse->D->cplx && !fuse->D->loose() && !fuse->D->expanded() && fuse->D->rows == m &&
                fuse->D->cols == n;
     if (fuse_now && fuse->mode == 2 && B.zero_free != 1) {
@@ -3163,7 +3161,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       else fuse_now = false;
     }
     const DotOperand* dop_p = fuse_now ? &dot_operand(*fuse->D) : nullptr;
-    if (fuse_now && dop_p->max_tile > SLAB_DTILE) fuse_now = false;   // (D columns too wide for the LDS tile)
+    if (fuse_now && !use_tile && dop_p->max_tile > SLAB_DTILE) fuse_now = false;   // (D columns too wide for the LDS tile)
     if (fuse_now) {
       const DotOperand& dop = *dop_p;
       SlabFuseArgs fz;
@@ -3188,9 +3186,33 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
         if (fuse->mode == 1) launch_fused(nw_tag, mode_tag, std::integral_constant<int, 1>{});
         else launch_fused(nw_tag, mode_tag, std::integral_constant<int, 2>{});
       };
-      if (max_w_now > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
+      if (use_tile) {
+        tile_ooff.alloc((size_t)n + 1);
+        tile_otoff.alloc((size_t)snb + 1);
+        TileLaunch tl;
+        tl.runs = reinterpret_cast<const SlabRun*>(runs.p) - ka;
+        tl.bblk = bblk.p; tl.blk_boff = blk_boff.p; tl.blk_kmin = blk_kmin.p; tl.blk_kn = blk_kn.p; tl.blk_lo = blk_lo.p;
+        tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = tmp_val.p; tl.count = count.p;
+        tl.ofirst = fz_first.p; tl.olast = fz_last.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
+        tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
+        tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = fuse->mode; tl.fz = fz_args.p;
+        launch_spgemm_tile(tl);
+        HIP_CHECK(hipMemcpyAsync(tile_ooff.p + n, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(tile_otoff.p + snb, blk_toff.p + snb, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
+      } else if (max_w_now > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
       else if (max_w_now > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
       else by_mode(std::integral_constant<int, SLAB_NW>{}, std::integral_constant<int, 8>{});
+    } else if (use_tile) {   // the product as dense column runs in the slots; compressed columns by the pack pass below
+      fz_first.alloc((size_t)n); fz_last.alloc((size_t)n);
+      tile_ooff.alloc((size_t)n + 1);
+      TileLaunch tl;
+      tl.runs = reinterpret_cast<const SlabRun*>(runs.p) - ka;
+      tl.bblk = bblk.p; tl.blk_boff = blk_boff.p; tl.blk_kmin = blk_kmin.p; tl.blk_kn = blk_kn.p; tl.blk_lo = blk_lo.p;
+      tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = tmp_val.p; tl.count = count.p;
+      tl.ofirst = fz_first.p; tl.olast = fz_last.p; tl.ooff = tile_ooff.p;
+      tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
+      tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = 0;
+      launch_spgemm_tile(tl);
     } else if (max_w_now > 6 * SLAB_SL * WAVE)         // 1153 .. 1536 rows: eight waves per workgroup
       hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, 8, 0>), dim3(xcd_grid(snb)), dim3(8 * WAVE), 0, stream(),
                          reinterpret_cast<const SlabRun*>(runs.p) - ka, bblk.p, blk_boff.p, blk_kmin.p, blk_kn.p, blk_lo.p,
@@ -3375,8 +3397,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     R.slab->first = std::move(fz_first);
     R.slab->last = std::move(fz_last);
     R.slab->count = std::move(count);
-    R.slab->off = std::move(tmpoff);
-    R.slab->tile_off = std::move(blk_toff);
+    R.slab->off = use_tile ? std::move(tile_ooff) : std::move(tmpoff);
+    R.slab->tile_off = use_tile ? std::move(tile_otoff) : std::move(blk_toff);
     R.slab->val = std::move(tmp_val);
     R.slab->tiles = std::move(fz_tiles);
     R.slab->slots = tmp_total;
@@ -3398,7 +3420,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     return;
   }
 
-  if (loose && use_slab) {
+  if (loose && use_slab && !use_tile) {
     // hand the slots over as they are: the consumer (axpby) reads the columns in place and reports the exact nnz
     loose->valid = true;
     loose->rows = m;
@@ -3446,7 +3468,10 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   C.inner.alloc((size_t)nnz + kIndexSlack);
   C.val.alloc(((size_t)nnz + kIndexSlack) * C.wval());
   const int nblocks = cdiv(n, 4);
-  dispatch_type(A.cplx, [&](auto tag) {
+  if (use_tile)   // (the tile kernel left dense runs: one wave per column collects the non-zeros in row order)
+    hipLaunchKernelGGL(k_pack_slab, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fz_first.p, fz_last.p,
+                       tile_ooff.p, tmp_val.p, C.outer.p, C.inner.p, C.val.p);
+  else dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
     hipLaunchKernelGGL((k_compact<T>), dim3(xcd_grid(nblocks)), dim3(256), 0, stream(), n, tmpoff.p,
                        overflow ? tmpoff2.p : nullptr, overflow ? bin.p : nullptr, C.outer.p, tmp_inner.p,
@@ -3473,29 +3498,6 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
 // A purification step on an iterate that is already in slab form (SlabForm): plan from the column extents, run
 // records, the fused kernel, the totals -- no pass over the entries outside the kernel itself.
 namespace {
-// compressed columns from the slab form: one wave per column, the non-zeros of its run in row order
-__global__ __launch_bounds__(256) void k_pack_slab(int ncols, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
-                                                   const int64_t* __restrict__ off, const double* __restrict__ val,
-                                                   const int64_t* __restrict__ outer, int32_t* __restrict__ inner,
-                                                   double* __restrict__ out) {
-  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  if (j >= ncols) return;
-  const int lane = lane_id();
-  const int f = first[j], l = last[j];
-  int64_t pos = outer[j];
-  const double* __restrict__ src = val + off[j];
-  for (int r0 = f; r0 <= l; r0 += WAVE) {
-    const int r = r0 + lane;
-    const double v = r <= l ? src[r - f] : 0.0;
-    const unsigned long long m = __ballot(v != 0.0);
-    if (v != 0.0) {
-      const int64_t q = pos + __popcll(m & lanemask_lt());
-      inner[q] = r;
-      out[q] = v;
-    }
-    pos += __popcll(m);
-  }
-}
 }  // namespace
 
 namespace {
@@ -3598,12 +3600,14 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   if (!X.expanded() || X.cplx || (!halo && X.rows != X.cols) || !fu.D || fu.D->cplx || fu.D->loose() || fu.D->expanded() ||
       fu.D->rows != X.rows || fu.D->cols != X.cols || (fu.mode != 1 && fu.mode != 2))
     return false;
-  if (options().spgemm_variant >= 0 || options().spgemm_fma || options().spgemm_force_bin > 0 || !options().fused_update)
+  const bool tile = options().spgemm_fma == 1;   // FMA arithmetic: the MFMA tile kernel (spgemm_tile.hip)
+  if (options().spgemm_variant >= 0 || (options().spgemm_fma && !tile) || options().spgemm_force_bin > 0 || !options().fused_update)
     return false;
   const SlabForm& in = *X.slab;
+  if (tile && in.labelled()) return false;
   const int n = X.cols, snb = cdiv(n, SLAB_J);
   const DotOperand& dop = dot_operand(*fu.D);
-  if (dop.max_tile > SLAB_DTILE) return false;
+  if (!tile && dop.max_tile > SLAB_DTILE) return false;
   const bool timing = options().time_kernels != 0;
   EventTimer t_all(timing), t_num(timing);
   t_all.start();
@@ -3645,7 +3649,8 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     }
     return false;
   };
-  if (max_w <= 0 || max_w > 8 * SLAB_SL * WAVE) return give_up();
+  if (max_w <= 0 || (!tile && max_w > 8 * SLAB_SL * WAVE)) return give_up();
+  if (tile && !spgemm_tile_fits((int)hst[1], (int)max_w)) return give_up();
   if (in.labelled() && (int64_t)hst[1] > 2048) return give_up();   // (the per-block sort of the steps)
   hipLaunchKernelGGL((k_slab_tmpoff<SLAB_J>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
   DevBuf<char> runs(((size_t)nka + 4) * sizeof(SlabRun));
@@ -3713,7 +3718,21 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     if (fu.mode == 1) launch(nw_tag, mode_tag, std::integral_constant<int, 1>{});
     else launch(nw_tag, mode_tag, std::integral_constant<int, 2>{});
   };
-  if (rowoff) {
+  DevBuf<int64_t> tile_ooff, tile_otoff;
+  if (tile) {
+    tile_ooff.alloc((size_t)n + 1);
+    tile_otoff.alloc((size_t)snb + 1);
+    TileLaunch tl;
+    tl.runs = reinterpret_cast<const SlabRun*>(runs.p) - ka;
+    tl.bblk = in.tiles.p; tl.blk_boff = in.tile_off.p; tl.blk_kmin = blk_kmin.p; tl.blk_kn = blk_kn.p; tl.blk_lo = blk_lo.p;
+    tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = oval.p; tl.count = count.p;
+    tl.ofirst = ofirst.p; tl.olast = olast.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
+    tl.alpha = 1.0; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
+    tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = fz_args.p;
+    launch_spgemm_tile(tl);
+    HIP_CHECK(hipMemcpyAsync(tile_ooff.p + n, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(tile_otoff.p + snb, blk_toff.p + snb, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
+  } else if (rowoff) {
     if (max_w > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{});
     else if (max_w > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 9>{});
     else by_mode(std::integral_constant<int, SLAB_NW>{}, std::integral_constant<int, 9>{});
@@ -3767,8 +3786,8 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   R.slab->first = std::move(ofirst);
   R.slab->last = std::move(olast);
   R.slab->count = std::move(count);
-  R.slab->off = std::move(tmpoff);
-  R.slab->tile_off = std::move(blk_toff);
+  R.slab->off = tile ? std::move(tile_ooff) : std::move(tmpoff);
+  R.slab->tile_off = tile ? std::move(tile_otoff) : std::move(blk_toff);
   R.slab->val = std::move(oval);
   R.slab->tiles = std::move(otiles);
   R.slab->slots = tmp_total;

@@ -1,0 +1,527 @@
+// SpGEMM numeric phase on the FP64 matrix cores (gfx950, v_mfma_f64_16x16x4_f64) for run-like real operands -- the
+// operands and the results of the register-slab kernel (kernels.hip, MultiplyBlock.f90:9-36 + PruneList.f90:8-38),
+// walked the other way round.
+//
+// A workgroup owns a block of 16 consecutive output columns and the row window [lo, lo + w) they can touch, as the
+// slab kernel does.  The window is cut into TILES of 16 rows; a wave takes one tile at a time and walks the k range of
+// the block that can reach it in groups of four consecutive k:
+//
+//     P(16 rows x 16 columns) += A(16 rows x 4 k) * B(4 k x 16 columns)        one v_mfma_f64_16x16x4_f64
+//
+// A comes from the expanded columns (dense runs, holes = 0; lane l reads row r0 + l % 16 of column k0 + l / 16, zero
+// outside the run), B from the block's multiplier tile, copied to LDS once per block (lane l reads row k0 + l / 16,
+// column l % 16: one conflict-free ds_read_b64).  The partial sums of a tile are 8 VGPRs and leave the registers when
+// the tile's k range is done, so nothing about the window has to fit the register file: the epilogue (prune, the
+// fused purification update, energy, trace, the result in slab form) runs per tile, hidden behind the other waves'
+// matrix instructions.
+//
+// Arithmetic: the matrix instruction accumulates its four products in ascending k with ONE rounding each -- it is a
+// chain of fma(), bit for bit (tools/micro/mfma_f64_probe.hip checks this on the device) -- and the groups follow in
+// ascending k, so every C(i, j) is the FMA chain over ascending k that option spgemm_fma = 1 of the slab kernel
+// computes and that the reference computes when it is built with FP contraction: the two
+// kernels agree bit for bit, and both with the contracted reference build.  Zero padding is exact (fma(0, b, x) = x).
+#include "spgemm_tile.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include "device_util.hpp"
+#include "kernels.hpp"
+
+namespace ntp {
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef const double __attribute__((address_space(1)))* gptr_t;   // (loads through it are global_load, not flat_load)
+
+// run of column k as the tile loop wants it: rz = address of (hypothetical) row 0, valid rows first .. last
+struct alignas(16) TileRec {
+  unsigned long long rz;
+  int32_t first;
+  uint32_t span;     // last - first; an empty run: first = INT_MAX, span = 0 (no row passes (unsigned)(r - first) <= span)
+};
+constexpr int TILE_PF = 6;           // k groups in flight per wave
+constexpr int TILE_RPAD = 4 * (TILE_PF + 2), TILE_BPAD = 4;   // records / multiplier rows behind the last group (pipeline look-ahead)
+// an element of X whose fate depends on the last kept row of the product column (decided when the block is done)
+struct alignas(16) TileDefer {
+  int32_t r, jj, prow, pad;
+  double o, d;
+};
+constexpr int TILE_NW = 4;           // waves per workgroup
+constexpr int TILE_DEFER = 128;      // deferred elements per block (more: the step is refused)
+
+
+struct TileArgs {
+  const SlabRun* runs;
+  const double* bblk;
+  const int64_t* blk_boff;
+  const int32_t *blk_kmin, *blk_kn, *blk_lo, *blk_w;
+  const int64_t* blk_toff;
+  double* out_val;
+  int32_t* count;
+  int32_t *ofirst, *olast;
+  int64_t* ooff;
+  int64_t* otoff;
+  double alpha, threshold;
+  int dense_rule, ncols, nblocks;
+  int k4max, tmax;
+  const SlabFuseArgs* fz;
+  const double* zero;   // 16 bytes of zeros: where the lanes outside a run load from
+};
+
+__host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax) {
+  return (size_t)(k4max + TILE_BPAD) * 16 * 8 + (size_t)(k4max + TILE_RPAD) * sizeof(TileRec) + (size_t)tmax * 12 + TILE_DEFER * sizeof(TileDefer) + 16 * 5 * 4 +
+         2 * TILE_NW * 8 + 64;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_spgemm_tile(const TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = xcd_block(a.nblocks);
+  if (b < 0) return;
+  const int tid = threadIdx.x, wave = uni_i32(tid / WAVE), lane = lane_id();
+  const int lo = a.blk_lo[b], w = a.blk_w[b], kmin = a.blk_kmin[b], kn = a.blk_kn[b];
+  const int64_t tbase = a.blk_toff[b];
+  if (kn == 0) {   // no product entries in these columns
+    const int j = b * SLAB_J + tid;
+    if (tid < SLAB_J && j < a.ncols) {
+      a.ofirst[j] = INT_MAX;
+      a.olast[j] = -1;
+      a.ooff[j] = tbase + (int64_t)tid * w;
+      if constexpr (EPI != 0) {
+        if (a.fz->oplast) a.fz->oplast[j] = -1;
+        // (EPI 2: ... and none in the result only if the columns of X are empty as well; otherwise the step is not ours)
+        if (EPI == 2 && a.fz->xmax[j] >= a.fz->xmin[j]) atomicOr(a.fz->flag, 1);
+      }
+    }
+    if (EPI != 0 && tid == 0) a.otoff[b] = tbase;
+    return;
+  }
+  // ---- LDS
+  double* Bs = reinterpret_cast<double*>(smem);                                    // [k4max][16]
+  TileRec* recs = reinterpret_cast<TileRec*>(Bs + (size_t)(a.k4max + TILE_BPAD) * 16);   // [k4max + TILE_RPAD]
+  int* kgmin = reinterpret_cast<int*>(recs + a.k4max + TILE_RPAD);                 // [tmax]
+  int* kgmax = kgmin + a.tmax;
+  unsigned* colmask = reinterpret_cast<unsigned*>(kgmax + a.tmax);
+  TileDefer* dlist = reinterpret_cast<TileDefer*>(colmask + a.tmax + ((4 - (3 * a.tmax) % 4) % 4));
+  int* col_cnt = reinterpret_cast<int*>(dlist + TILE_DEFER);                       // [16] each
+  int* col_first = col_cnt + 16;
+  int* col_last = col_first + 16;
+  int* col_pmax = col_last + 16;
+  int* col_plast = col_pmax + 16;
+  double* red = reinterpret_cast<double*>(col_plast + 16);                         // [2 * NW]
+  int* misc = reinterpret_cast<int*>(red + 2 * TILE_NW);                           // [0] deferred, [1] product entries, [2..3] products
+
+  const int KG = (kn + 3) >> 2, K4 = KG * 4;
+  const int T = (w + 15) >> 4;
+  {  // multiplier tile -> LDS (rows kn .. K4 zero)
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(a.bblk + a.blk_boff[b]);
+    double2* dst = reinterpret_cast<double2*>(Bs);
+    for (int i = tid; i < (K4 + TILE_BPAD) * 8; i += TILE_NW * WAVE) dst[i] = i < kn * 8 ? src[i] : make_double2(0.0, 0.0);
+  }
+  {
+    const SlabRun* __restrict__ rp = a.runs + kmin;
+    for (int i = tid; i < K4 + TILE_RPAD; i += TILE_NW * WAVE) {
+      TileRec rec;
+      rec.rz = 0;
+      rec.first = INT_MAX;
+      rec.span = 0u;
+      if (i < kn) {
+        const SlabRun r = rp[i];
+        const int rows = (int)(r.nbytes >> 3);
+        if (rows > 0) {
+          const unsigned long long addr = (unsigned long long)r.addr_lo | ((unsigned long long)r.addr_hi << 32);
+          rec.rz = addr - (unsigned long long)((long long)r.first * 8);
+          rec.first = r.first;
+          rec.span = (uint32_t)(rows - 1);
+        }
+      }
+      recs[i] = rec;
+    }
+  }
+  for (int t = tid; t < T; t += TILE_NW * WAVE) {
+    kgmin[t] = INT_MAX;
+    kgmax[t] = -1;
+    colmask[t] = 0u;
+  }
+  if (tid < 16) {
+    col_cnt[tid] = 0;
+    col_first[tid] = INT_MAX;
+    col_last[tid] = -1;
+    col_pmax[tid] = -1;
+    col_plast[tid] = -1;
+  }
+  if (tid < 4) misc[tid] = 0;
+  __syncthreads();
+  // k groups that can reach a tile: [kgmin[t], kgmax[t]]
+  for (int g = tid; g < KG; g += TILE_NW * WAVE) {
+    int rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const TileRec rec = recs[4 * g + u];
+      if (rec.first != INT_MAX) {
+        rmin = min(rmin, rec.first);
+        rmax = max(rmax, rec.first + (int)rec.span);
+      }
+    }
+    if (rmax >= rmin) {
+      const int t0 = max(0, (rmin - lo) >> 4), t1 = min(T - 1, (rmax - lo) >> 4);
+      for (int t = t0; t <= t1; ++t) {
+        atomicMin(&kgmin[t], g);
+        atomicMax(&kgmax[t], g);
+      }
+    }
+  }
+  if constexpr (EPI != 0) {
+    if (a.fz->prod) {   // products of this block = sum over the tile rows k of (non-zero multipliers) * (entries of A(:, k))
+      const int32_t* __restrict__ in_count = a.fz->in_count;
+      long long p = 0;
+      for (int k = tid; k < kn; k += TILE_NW * WAVE) {
+        int c = 0;
+#pragma unroll
+        for (int qq = 0; qq < SLAB_J; ++qq) c += Bs[(size_t)k * SLAB_J + ((qq + tid) & 15)] != 0.0 ? 1 : 0;
+        p += (long long)c * (in_count ? in_count[kmin + k] : 1);
+      }
+      p = wave_sum_i64(p);
+      if (lane == 0 && p) atomicAdd(reinterpret_cast<unsigned long long*>(misc + 2), (unsigned long long)p);
+    }
+  }
+  __syncthreads();
+
+  // ---- per-lane constants: this lane's column is jj = lane % 16 in every tile
+  const int jj = lane & 15, q = lane >> 4;
+  const int j = b * SLAB_J + jj;
+  const bool colv = j < a.ncols;
+  const int jc = min(j, a.ncols - 1);
+  const double* const zp = a.zero;
+  const unsigned long long zaddr = reinterpret_cast<unsigned long long>(zp);
+  double* const orun = a.out_val + (tbase + (int64_t)jj * w - lo);          // orun[r] = slot of row r of column j
+  [[maybe_unused]] double* otile = nullptr;
+  [[maybe_unused]] int xf = INT_MAX, xlrow = -1, xpl = -1, df = INT_MAX, dl = -1;
+  [[maybe_unused]] const double *xrz = zp, *drz = zp;
+  [[maybe_unused]] const int32_t* lab = nullptr;
+  [[maybe_unused]] double am = 0, bm = 0, thr_m = 0;
+  [[maybe_unused]] int diag = -1;
+  if constexpr (EPI != 0) {
+    const SlabFuseArgs* __restrict__ fz = a.fz;
+    otile = fz->tiles + (tbase - (int64_t)lo * SLAB_J + jj);                // otile[r * 16] = row r, column jj of the tile
+    lab = fz->lab;
+    const int d0 = fz->dmin[jc], d1 = fz->dmax[jc];
+    if (colv && d1 >= d0) {
+      df = d0;
+      dl = d1;
+      drz = fz->dexp + (fz->doff[jc] - d0);
+    }
+    diag = j + fz->col_offset;
+    if constexpr (EPI == 2) {
+      am = fz->am; bm = fz->bm; thr_m = fz->thr_m;
+      const int x0 = fz->xmin[jc], x1 = fz->xmax[jc];
+      if (colv && x1 >= x0) {
+        xf = x0;
+        xlrow = x1;
+        xrz = fz->xexp + (fz->xoff[jc] - x0);
+        xpl = lab ? fz->xplast[jc] : x1;
+        if (x0 < lo || x1 >= lo + w) atomicOr(fz->flag, 1);   // every stored row of X(:, j) must be a row of this block's window
+      }
+    }
+  }
+  const double alpha = a.alpha, thr = a.threshold;
+  const bool dense_rule = a.dense_rule != 0;
+  double dsum = 0.0, tsum = 0.0;
+  int pn = 0;
+  const int rend = lo + w;
+  const int mid = (T - 1) >> 1;
+
+  for (int ts = wave; ts < T; ts += TILE_NW) {   // centre first: the tiles in the middle of the window have the longest k ranges
+    const int t = (ts & 1) ? mid + ((ts + 1) >> 1) : mid - (ts >> 1);
+    const int r0 = lo + 16 * t;
+    const int g0 = uni_i32(kgmin[t]), g1 = uni_i32(kgmax[t]);
+    // what the epilogue reads, requested before the loop
+    [[maybe_unused]] double xv[4], dv[4];
+    [[maybe_unused]] int prow[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = r0 + 4 * v + q;
+      if constexpr (EPI == 2) xv[v] = *(gptr_t)(((r >= xf) & (r <= xlrow)) ? xrz + r : zp);
+      if constexpr (EPI != 0) {
+        dv[v] = *(gptr_t)(((r >= df) & (r <= dl)) ? drz + r : zp);
+        prow[v] = lab ? lab[min(r, a.ncols - 1)] : r;
+      }
+    }
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    if (g1 >= g0) {
+      // Software pipeline over the k groups g0 .. g1 (records and multiplier rows are padded behind the last group, and
+      // a group beyond kgmax[t] has no row in this tile, so nothing below needs a bound): the record of group g + PF + 1
+      // is read from LDS while the run load of group g + PF is issued from the record read one step earlier, the
+      // multiplier row of g + 1 is read, and group g -- operands landed PF steps / one step ago -- is multiplied.
+      const int rl = r0 + jj;                      // A operand: row rl, column 4 g + q
+      const unsigned long long r8 = (unsigned long long)((long long)rl * 8);
+      const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(recs) + q;     // record of group g: rq[4 g]
+      const double* __restrict__ bq = Bs + lane;                                   // multiplier of group g: bq[64 g]
+      auto run_load = [&](const uint4 raw) -> double {
+        const unsigned long long rz = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
+        const bool ok = (unsigned)(rl - (int)raw.z) <= raw.w;
+        return *reinterpret_cast<gptr_t>(ok ? rz + r8 : zaddr);
+      };
+      double ring[TILE_PF];
+#pragma unroll
+      for (int u = 0; u < TILE_PF; ++u) ring[u] = run_load(rq[4 * (g0 + u)]);
+      uint4 rec_c = rq[4 * (g0 + TILE_PF)];
+      double b_c = bq[64 * g0];
+      int g = g0;
+      for (; g + TILE_PF - 1 <= g1; g += TILE_PF) {
+#pragma unroll
+        for (int u = 0; u < TILE_PF; ++u) {
+          const uint4 rec_n = rq[4 * (g + u + TILE_PF + 1)];
+          const double av = ring[u];
+          ring[u] = run_load(rec_c);
+          const double b_n = bq[64 * (g + u + 1)];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b_c, acc, 0, 0, 0);
+          rec_c = rec_n;
+          b_c = b_n;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TILE_PF - 1; ++u) {
+        if (g + u <= g1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u], bq[64 * (g + u)], acc, 0, 0, 0);
+      }
+    }
+    // ---- epilogue of the tile: lane holds rows r0 + 4 v + q (v = 0..3) of column jj
+    double res[4];
+    unsigned long long anykeep = 0;
+    int c_l = 0, f_l = INT_MAX, l_l = -1, pm_l = -1, pl_l = -1;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = r0 + 4 * v + q;
+      const double vv = acc[v];
+      const double sv = __dmul_rn(alpha, vv);
+      const bool ha = dense_rule ? (fabs(vv) > thr) : (fabs(sv) > thr);
+      bool keep;
+      double o;
+      if constexpr (EPI != 2) {
+        keep = ha;
+        o = sv;
+      } else {
+        const double bv = xv[v];
+        const bool hb = bv != 0.0;
+        const double bs = __dmul_rn(bm, bv);
+        const double wa = __dmul_rn(am, sv);
+        const double both = __dadd_rn(wa, bs);
+        o = ha ? (hb ? both : wa) : bs;                        // (neither: bs = 0)
+        const bool big = fabs(o) > thr_m;
+        // AddSparseVectors (inc_decide): both present -> threshold on the sum; one present -> threshold unless it lies
+        // beyond the other column's last entry.  "Beyond the product column's last kept entry" is not known yet for an
+        // element of X alone that fails the threshold: decided when the block is done (dlist)
+        if (ha) {
+          keep = (!hb && prow[v] > xpl) || big;
+        } else {
+          keep = hb && big;
+          if (hb && !big) {
+            const int slot = atomicAdd(&misc[0], 1);
+            if (slot < TILE_DEFER) {
+              TileDefer e;
+              e.r = r; e.jj = jj; e.prow = prow[v]; e.pad = 0; e.o = o; e.d = dv[v];
+              dlist[slot] = e;
+            }
+          }
+        }
+      }
+      pn += (int)__popcll(__ballot(ha));
+      anykeep |= __ballot(keep);
+      if constexpr (EPI != 0) {
+        dsum = __dadd_rn(dsum, __dmul_rn(keep ? o : 0.0, keep ? dv[v] : 0.0));
+        tsum = __dadd_rn(tsum, (keep && r == diag) ? o : 0.0);
+        pm_l = max(pm_l, ha ? prow[v] : -1);
+        pl_l = max(pl_l, keep ? prow[v] : -1);
+      }
+      c_l += keep ? 1 : 0;
+      f_l = min(f_l, keep ? r : INT_MAX);
+      l_l = max(l_l, keep ? r : -1);
+      res[v] = keep ? o : 0.0;
+    }
+    const unsigned cm = (unsigned)((anykeep | (anykeep >> 16) | (anykeep >> 32) | (anykeep >> 48)) & 0xffffull);
+    if (c_l) {
+      atomicAdd(&col_cnt[jj], c_l);
+      atomicMin(&col_first[jj], f_l);
+      atomicMax(&col_last[jj], l_l);
+      if constexpr (EPI != 0) {
+        if (lab) atomicMax(&col_plast[jj], pl_l);
+      }
+    }
+    if constexpr (EPI == 2) {
+      if (pm_l >= 0) atomicMax(&col_pmax[jj], pm_l);
+    }
+    if ((cm >> jj) & 1u) {   // the column has an entry in this tile: its 16 rows are written (zeros = holes)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = r0 + 4 * v + q;
+        if (r < rend) orun[r] = res[v];
+      }
+    }
+    if constexpr (EPI != 0) {
+      if (cm) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = r0 + 4 * v + q;
+          if (r < rend) otile[(int64_t)r * SLAB_J] = res[v];
+        }
+      }
+    }
+    if (lane == 0) colmask[t] = cm;
+  }
+  // ---- the block
+  if constexpr (EPI != 0) {
+    dsum = wave_sum_f64(dsum);
+    tsum = wave_sum_f64(tsum);
+    if (lane == 0) {
+      red[2 * wave] = dsum;
+      red[2 * wave + 1] = tsum;
+    }
+  }
+  if (lane == 0 && pn) atomicAdd(&misc[1], pn);
+  __syncthreads();
+  if constexpr (EPI == 2) {
+    // the deferred elements: kept (unfiltered) where they lie beyond the last kept entry of the product column.  Only
+    // the decision and the column statistics here; the values are stored after the holes have been zeroed (below)
+    const int nd = misc[0];
+    if (nd > TILE_DEFER) {
+      if (tid == 0) atomicOr(a.fz->flag, 1);
+    } else {
+      for (int i = tid; i < nd; i += TILE_NW * WAVE) {
+        TileDefer e = dlist[i];
+        const bool kept = e.prow > col_pmax[e.jj];
+        if (kept) {
+          atomicAdd(&col_cnt[e.jj], 1);
+          atomicMin(&col_first[e.jj], e.r);
+          atomicMax(&col_last[e.jj], e.r);
+          if (lab) atomicMax(&col_plast[e.jj], e.prow);
+        }
+        e.pad = kept ? 1 : 0;
+        dlist[i] = e;
+      }
+    }
+    __syncthreads();
+  }
+  // entries, first and last row of every column; where its run and the block's tile rows start
+  if (tid < SLAB_J) {
+    const int jt = b * SLAB_J + tid;
+    const int cf = col_first[tid], cl = col_last[tid];
+    if (jt < a.ncols) {
+      a.count[jt] = col_cnt[tid];
+      a.ofirst[jt] = cf;
+      a.olast[jt] = cl;
+      a.ooff[jt] = tbase + (int64_t)tid * w + (cl >= cf ? cf - lo : 0);
+      if constexpr (EPI != 0) {
+        if (lab) a.fz->oplast[jt] = col_plast[tid];
+      }
+    }
+  }
+  int tk0 = INT_MAX, tk1 = -1;
+#pragma unroll
+  for (int c = 0; c < SLAB_J; ++c) {
+    tk0 = min(tk0, col_first[c]);
+    tk1 = max(tk1, col_last[c]);
+  }
+  if constexpr (EPI != 0) {
+    if (tid == 0) {
+      a.otoff[b] = tbase + (tk1 >= tk0 ? (int64_t)(tk0 - lo) * SLAB_J : 0);
+      a.fz->pnnz[b] = misc[1];
+      if (a.fz->prod) a.fz->prod[b] = *reinterpret_cast<long long*>(misc + 2);
+    }
+    if (tid == 64) {
+      double x = 0.0, y = 0.0;
+      for (int qq = 0; qq < TILE_NW; ++qq) {
+        x = __dadd_rn(x, red[2 * qq]);
+        y = __dadd_rn(y, red[2 * qq + 1]);
+      }
+      if constexpr (EPI == 2) {   // kept deferred elements, in (row, column) order: reproducible sums
+        const int nd = min(misc[0], TILE_DEFER);
+        int lr = -1, lj = -1;
+        for (int n2 = 0; n2 < nd; ++n2) {
+          int best = -1, br = INT_MAX, bj = INT_MAX;
+          for (int m2 = 0; m2 < nd; ++m2) {
+            const int r2 = dlist[m2].r, j2 = dlist[m2].jj;
+            const bool after = r2 > lr || (r2 == lr && j2 > lj);
+            if (dlist[m2].pad && after && (r2 < br || (r2 == br && j2 < bj))) { best = m2; br = r2; bj = j2; }
+          }
+          if (best < 0) break;
+          const TileDefer e = dlist[best];
+          x = __dadd_rn(x, __dmul_rn(e.o, e.d));
+          if (e.r == b * SLAB_J + e.jj + a.fz->col_offset) y = __dadd_rn(y, e.o);
+          lr = br; lj = bj;
+        }
+      }
+      a.fz->part[2 * b] = x;
+      a.fz->part[2 * b + 1] = y;
+    }
+  }
+  // holes: a tile strictly inside a column's run (inside the block's tile rows) that was skipped above holds zeros
+  for (int p = tid; p < T * SLAB_J; p += TILE_NW * WAVE) {
+    const int t = p >> 4, c = p & 15;
+    const unsigned cmk = colmask[t];
+    const int cf = col_first[c], cl = col_last[c];
+    const int r0 = lo + 16 * t;
+    if (cl >= cf && r0 + 15 >= cf && r0 <= cl && !((cmk >> c) & 1u)) {
+      double* dst = a.out_val + (tbase + (int64_t)c * w - lo);
+      for (int r = r0; r < min(r0 + 16, rend); ++r) dst[r] = 0.0;
+    }
+    if constexpr (EPI != 0) {
+      if (tk1 >= tk0 && r0 + 15 >= tk0 && r0 <= tk1 && cmk == 0u) {
+        double* dst = a.fz->tiles + (tbase - (int64_t)lo * SLAB_J + c);
+        for (int r = r0; r < min(r0 + 16, rend); ++r) dst[(int64_t)r * SLAB_J] = 0.0;
+      }
+    }
+  }
+  if constexpr (EPI == 2) {
+    const int nd = min(misc[0], TILE_DEFER);
+    if (nd > 0) {
+      __syncthreads();   // (the zeros above first)
+      for (int i = tid; i < nd; i += TILE_NW * WAVE) {
+        const TileDefer e = dlist[i];
+        if (!e.pad) continue;
+        a.out_val[tbase + (int64_t)e.jj * w + (e.r - lo)] = e.o;
+        a.fz->tiles[tbase + (int64_t)(e.r - lo) * SLAB_J + e.jj] = e.o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool spgemm_tile_fits(int max_kn, int max_w) {
+  const int k4 = (max_kn + 3) & ~3, tm = (max_w + 15) >> 4;
+  return max_kn > 0 && max_w > 0 && tile_lds_bytes(k4, tm) <= 150 * 1024;
+}
+
+void launch_spgemm_tile(const TileLaunch& L) {
+  TileArgs a;
+  a.runs = static_cast<const SlabRun*>(L.runs);
+  a.bblk = L.bblk; a.blk_boff = L.blk_boff; a.blk_kmin = L.blk_kmin; a.blk_kn = L.blk_kn; a.blk_lo = L.blk_lo; a.blk_w = L.blk_w;
+  a.blk_toff = L.blk_toff; a.out_val = L.out_val; a.count = L.count; a.ofirst = L.ofirst; a.olast = L.olast; a.ooff = L.ooff;
+  a.otoff = L.otoff; a.alpha = L.alpha; a.threshold = L.threshold; a.dense_rule = L.dense_rule; a.ncols = L.ncols;
+  a.nblocks = L.nblocks;
+  a.k4max = (L.max_kn + 3) & ~3;
+  a.tmax = (L.max_w + 15) >> 4;
+  a.fz = static_cast<const SlabFuseArgs*>(L.fz);
+  static DevBuf<double>* zeros = nullptr;   // (never freed: lives as long as the library)
+  if (!zeros) {
+    zeros = new DevBuf<double>(2);
+    zeros->zero();
+  }
+  a.zero = zeros->p;
+  const size_t lds = tile_lds_bytes(a.k4max, a.tmax);
+  static size_t raised[3] = {0, 0, 0};
+  auto go = [&](auto epi_tag) {
+    constexpr int E = decltype(epi_tag)::value;
+    if (lds > 64 * 1024 && lds > raised[E]) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    150 * 1024));
+      raised[E] = 150 * 1024;
+    }
+    hipLaunchKernelGGL((k_spgemm_tile<E>), dim3(xcd_grid(L.nblocks)), dim3(TILE_NW * WAVE), lds, stream(), a);
+  };
+  if (L.epi == 0) go(std::integral_constant<int, 0>{});
+  else if (L.epi == 1) go(std::integral_constant<int, 1>{});
+  else go(std::integral_constant<int, 2>{});
+}
+
+}  // namespace ntp

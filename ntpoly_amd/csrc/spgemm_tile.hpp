@@ -1,0 +1,36 @@
+// MFMA tile kernel for run-like real operands (spgemm_tile.hip): the same operands and results as the register-slab
+// kernel of kernels.hip, computed tile by tile on the FP64 matrix cores.  Included by kernels.hip after slab_types.hpp.
+#pragma once
+#include "slab_types.hpp"
+
+namespace ntp {
+
+// One launch = one multiply of the local panel.  Operands exactly as the register-slab kernel takes them: run records
+// of the expanded columns of A, the per-block multiplier tiles of B, the plan (row window, k range, output slots).
+// Results (every EPI): the columns of the result as dense runs in their upper-bound slots -- column j of block b at
+// out_val[blk_toff[b] + (j % 16) * blk_w[b] + (r - blk_lo[b])], zeros = no entry -- plus per column the number of kept
+// entries, the first / last kept row and ooff[j] = where the run [first, last] starts.  EPI 1 / 2 (fused purification
+// steps, SlabFuseArgs) also write the block as a row-major tile (fz.tiles, origin row blk_lo[b]; otoff[b] = where the
+// rows [min first, max last] start) and the block's (dot, trace), product entries and product count.
+struct TileLaunch {
+  const void* runs = nullptr;        // SlabRun of column k of A at runs[k] (a pointer biased by the first column is fine)
+  const double* bblk = nullptr;
+  const int64_t* blk_boff = nullptr;
+  const int32_t *blk_kmin = nullptr, *blk_kn = nullptr, *blk_lo = nullptr, *blk_w = nullptr;
+  const int64_t* blk_toff = nullptr;
+  double* out_val = nullptr;
+  int32_t* count = nullptr;
+  int32_t *ofirst = nullptr, *olast = nullptr;
+  int64_t* ooff = nullptr;           // [ncols]
+  int64_t* otoff = nullptr;          // [nblocks] (EPI != 0)
+  double alpha = 1.0, threshold = 0.0;
+  int dense_rule = 0, ncols = 0, nblocks = 0;
+  int max_kn = 0, max_w = 0;         // largest k range / row window of any block (sizes the workgroup's LDS)
+  int epi = 0;
+  const void* fz = nullptr;          // device copy of SlabFuseArgs (EPI != 0)
+};
+// false: the geometry does not fit (k range beyond the LDS tile); nothing was launched
+bool spgemm_tile_fits(int max_kn, int max_w);
+void launch_spgemm_tile(const TileLaunch& a);
+
+}  // namespace ntp
