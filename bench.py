@@ -138,6 +138,11 @@ def main():
     ap.add_argument("--permute", type=int, default=None, metavar="SEED",
                     help="run on P^T H P under a seeded random relabelling (SURVEY 8(d): the load-balanced / "
                          "unstructured operand; the SpGEMM leaves the run-based kernels for the LDS hash path)")
+    ap.add_argument("--arithmetic", choices=("fma", "unfused"), default="fma",
+                    help="fma: every product entry is the chain of fma() over ascending k (one rounding per product) that "
+                         "the reference computes when built with FP contraction -- run on the FP64 matrix cores "
+                         "(v_mfma_f64_16x16x4_f64, option spgemm_fma = 1); unfused: separate multiply and add, the "
+                         "reference's default x86-64 build bit for bit (v_mul_f64 + v_add_f64 register-slab kernel)")
     args = ap.parse_args()
 
     import ntpoly_amd as nt
@@ -152,6 +157,7 @@ def main():
     n, h, thr = args.n, args.halfband, args.threshold
     nt.ConstructGlobalProcessGrid(1, world, 1)  # column panels: one per GPU
     nt.set_option("time_kernels", 1)
+    nt.set_option("spgemm_fma", 1 if args.arithmetic == "fma" else 0)
     if args.no_label_order:
         nt.set_option("label_order", 0)
 

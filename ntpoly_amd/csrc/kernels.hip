@@ -668,7 +668,9 @@ __global__ __launch_bounds__(256) void k_slab_plan(int ncols, const int32_t* __r
                                                    const int32_t* __restrict__ cmax, int32_t* __restrict__ blk_lo,
                                                    int32_t* __restrict__ blk_w, int32_t* __restrict__ blk_kmin,
                                                    int32_t* __restrict__ blk_kn, int64_t* __restrict__ bsz,
-                                                   int64_t* __restrict__ tsz, int nblocks) {
+                                                   int64_t* __restrict__ tsz, int nblocks, int align16 = 0) {
+  // align16 (MFMA tile kernel): the window starts at a multiple of 16 rows and is a multiple of 16 rows long, so that a
+  // column's slot keeps every row r at a position = r (mod 16): a 16-row tile segment of a run is one 128-byte line
   const int b = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   if (b >= nblocks) return;
   const int lane = lane_id();
@@ -700,6 +702,10 @@ __global__ __launch_bounds__(256) void k_slab_plan(int ncols, const int32_t* __r
   lo = wave_min_i32(lo);
   hi = wave_max_i32(hi);
   if (lane != 0) return;
+  if (align16 && hi > lo) {
+    lo &= ~15;
+    hi = (hi + 15) & ~15;
+  }
   const int w = (hi > lo) ? hi - lo : 0;
   const int kn = (w > 0 && kmax >= kmin) ? kmax - kmin + 1 : 0;
   blk_lo[b] = w > 0 ? lo : 0;
@@ -2954,7 +2960,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     }
     if (late) event_pool().push_back(late);
   }
-  const bool slab_try = !grouped_done && options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4) &&
+  const bool slab_try = !grouped_done && options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4 || sv_opt / 100 == 6) &&
                         A.nnz < 1000000000LL && B.nnz < 1000000000LL;
   const int snb = cdiv(n, SJ);
   DevBuf<int32_t> bfirst_own, blast_own, blen_own, aspan, blk_lo, blk_w, blk_kmin, blk_kn;
@@ -2979,7 +2985,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                          blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
     else
       hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst,
-                         blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
+                         blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb,
+                         options().spgemm_fma == 1 ? 1 : 0);
     hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, aspan.p, nka, stats.p);
     scan_async<int64_t>(bsz.p, blk_boff.p, (int64_t)snb);
     scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
@@ -3013,7 +3020,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   }
   st.slab = use_slab ? 1 : 0;
   // real run-like operands under option spgemm_fma = 1: the same plan and operands, numeric phase on the matrix cores
-  const bool use_tile = use_slab && !A.cplx && options().spgemm_fma == 1 && sv_opt < 0 &&
+  const bool use_tile = use_slab && !A.cplx && options().spgemm_fma == 1 && (sv_opt < 0 || sv_opt / 100 == 6) &&
                         spgemm_tile_fits((int)hstats[17], (int)hstats[16]);
   if (use_slab && !A.cplx && options().spgemm_fma == 1 && !use_tile && (int64_t)hstats[16] > SLAB_NW * SLAB_SL * WAVE) {
     // (neither the tile kernel -- k range beyond its LDS tile -- nor the four-wave FMA loop: general kernels)
@@ -3145,7 +3152,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     const bool panel = fuse && fuse->panel_c0 >= 0 && &A != &B && A.cols == m && ka <= fuse->panel_c0 && fuse->panel_c0 + n <= kb;
     const int xshift = panel ? fuse->panel_c0 - ka : 0;   // own column j = local column xshift + j of the A-side arrays
     fuse_now = fuse != nullptr && fuse->mode != 0 && (whole || panel) && abl == 0 && (!options().spgemm_fma || use_tile) &&
-               sv_opt < 0 && fuse->D && !fuse->D->cplx && !fuse->D->loose() && !fuse->D->expanded() && fuse->D->rows == m &&
+               (sv_opt < 0 || (use_tile && sv_opt / 100 == 6)) && fuse->D && !fuse->D->cplx && !fuse->D->loose() && !fuse->D->expanded() && fuse->D->rows == m &&
                fuse->D->cols == n;
     if (fuse_now && fuse->mode == 2 && B.zero_free != 1) {
       // the merge reads a zero of the expanded columns of X as "no entry": make sure no stored value is one (once per
@@ -3267,7 +3274,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     using T = decltype(tag);
     T* tv = reinterpret_cast<T*>(tmp_val.p);
     int variant = options().spgemm_variant;
-    if (variant / 100 == 4 || variant / 100 == 5) variant = -1;  // slab / grouped kernel requested but not applicable
+    if (variant / 100 == 4 || variant / 100 == 5 || variant / 100 == 6) variant = -1;  // slab / grouped kernel requested but not applicable
     if constexpr (!Sc<T>::cplx) {
       // real operands that are not run-like: column-pair kernel, register-set depth from the mean column length of A
       if (variant < 0 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {
@@ -3601,7 +3608,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
       fu.D->rows != X.rows || fu.D->cols != X.cols || (fu.mode != 1 && fu.mode != 2))
     return false;
   const bool tile = options().spgemm_fma == 1;   // FMA arithmetic: the MFMA tile kernel (spgemm_tile.hip)
-  if (options().spgemm_variant >= 0 || (options().spgemm_fma && !tile) || options().spgemm_force_bin > 0 || !options().fused_update)
+  if ((options().spgemm_variant >= 0 && !(tile && options().spgemm_variant / 100 == 6)) || (options().spgemm_fma && !tile) || options().spgemm_force_bin > 0 || !options().fused_update)
     return false;
   const SlabForm& in = *X.slab;
   if (tile && in.labelled()) return false;
@@ -3630,7 +3637,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   const int32_t* afirst = halo ? halo->first - ka : in.first.p;
   const int32_t* alast = halo ? halo->last - ka : in.last.p;
   hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, in.first.p,
-                     in.last.p, afirst, alast, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
+                     in.last.p, afirst, alast, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb, tile ? 1 : 0);
   hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, (const int32_t*)nullptr, 0, stats);
   scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
   int64_t tmp_total = 0;

@@ -24,6 +24,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "device_util.hpp"
 #include "kernels.hpp"
 
@@ -39,15 +43,14 @@ struct alignas(16) TileRec {
   int32_t first;
   uint32_t span;     // last - first; an empty run: first = INT_MAX, span = 0 (no row passes (unsigned)(r - first) <= span)
 };
-constexpr int TILE_PF = 6;           // k groups in flight per wave
-constexpr int TILE_RPAD = 4 * (TILE_PF + 2), TILE_BPAD = 4;   // records / multiplier rows behind the last group (pipeline look-ahead)
+constexpr int TILE_PF = 12;          // run loads (k groups) in flight per wave; a multiple of 3
+constexpr int TILE_RPAD = 4, TILE_BPAD = 0;   // one group of empty records behind the last (the pipeline's look-ahead is clamped to it)
 // an element of X whose fate depends on the last kept row of the product column (decided when the block is done)
 struct alignas(16) TileDefer {
   int32_t r, jj, prow, pad;
   double o, d;
 };
-constexpr int TILE_NW = 4;           // waves per workgroup
-constexpr int TILE_DEFER = 128;      // deferred elements per block (more: the step is refused)
+constexpr int TILE_DEFER = 64;       // deferred elements per block (more: the step is refused)
 
 
 struct TileArgs {
@@ -66,15 +69,24 @@ struct TileArgs {
   int k4max, tmax;
   const SlabFuseArgs* fz;
   const double* zero;   // 16 bytes of zeros: where the lanes outside a run load from
+#ifdef NTP_TILE_STAMPS
+  long long* stamps;    // diagnostic build: [block][wave][64] s_memtime stamps
+#endif
 };
 
 __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax) {
-  return (size_t)(k4max + TILE_BPAD) * 16 * 8 + (size_t)(k4max + TILE_RPAD) * sizeof(TileRec) + (size_t)tmax * 12 + TILE_DEFER * sizeof(TileDefer) + 16 * 5 * 4 +
-         2 * TILE_NW * 8 + 64;
+  return (size_t)(k4max + TILE_BPAD) * 16 * 8 + (size_t)(k4max + TILE_RPAD) * sizeof(TileRec) + (size_t)tmax * 4 + (size_t)(k4max / 4 + 1) * 8 + 16 + TILE_DEFER * sizeof(TileDefer) + 16 * 5 * 4 +
+         2 * 8 * 8 + 64;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_spgemm_tile(const TileArgs a) {
+#ifdef NTP_TILE_STAMPS
+#define STAMP(i) do { if (lane == 0 && b % 97 == 0 && b / 97 < 64 && (i) < 64) a.stamps[((b / 97) * 8 + wave) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+template <int EPI, int TILE_NW>
+__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_spgemm_tile(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = xcd_block(a.nblocks);
   if (b < 0) return;
@@ -96,53 +108,85 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3
     if (EPI != 0 && tid == 0) a.otoff[b] = tbase;
     return;
   }
+  STAMP(0);
   // ---- LDS
   double* Bs = reinterpret_cast<double*>(smem);                                    // [k4max][16]
   TileRec* recs = reinterpret_cast<TileRec*>(Bs + (size_t)(a.k4max + TILE_BPAD) * 16);   // [k4max + TILE_RPAD]
-  int* kgmin = reinterpret_cast<int*>(recs + a.k4max + TILE_RPAD);                 // [tmax]
-  int* kgmax = kgmin + a.tmax;
-  unsigned* colmask = reinterpret_cast<unsigned*>(kgmax + a.tmax);
-  TileDefer* dlist = reinterpret_cast<TileDefer*>(colmask + a.tmax + ((4 - (3 * a.tmax) % 4) % 4));
+  int* grmin = reinterpret_cast<int*>(recs + a.k4max + TILE_RPAD);                 // [k4max / 4 + 1]: first / last row any
+  int* grmax = grmin + (a.k4max / 4 + 1);                                          // column of a k group reaches
+  unsigned* colmask = reinterpret_cast<unsigned*>(grmax + (a.k4max / 4 + 1));      // [tmax]
+  TileDefer* dlist = reinterpret_cast<TileDefer*>(colmask + ((a.tmax + 2 * (a.k4max / 4 + 1) + 3) & ~3) - 2 * (a.k4max / 4 + 1));
   int* col_cnt = reinterpret_cast<int*>(dlist + TILE_DEFER);                       // [16] each
   int* col_first = col_cnt + 16;
   int* col_last = col_first + 16;
   int* col_pmax = col_last + 16;
   int* col_plast = col_pmax + 16;
-  double* red = reinterpret_cast<double*>(col_plast + 16);                         // [2 * NW]
-  int* misc = reinterpret_cast<int*>(red + 2 * TILE_NW);                           // [0] deferred, [1] product entries, [2..3] products
+  double* red = reinterpret_cast<double*>(col_plast + 16);                         // [2 * 8]
+  int* misc = reinterpret_cast<int*>(red + 2 * 8);                           // [0] deferred, [1] product entries, [2..3] products
 
   const int KG = (kn + 3) >> 2, K4 = KG * 4;
   const int T = (w + 15) >> 4;
-  {  // multiplier tile -> LDS (rows kn .. K4 zero)
-    const double2* __restrict__ src = reinterpret_cast<const double2*>(a.bblk + a.blk_boff[b]);
-    double2* dst = reinterpret_cast<double2*>(Bs);
-    for (int i = tid; i < (K4 + TILE_BPAD) * 8; i += TILE_NW * WAVE) dst[i] = i < kn * 8 ? src[i] : make_double2(0.0, 0.0);
+  // ---- block prologue: multiplier tile -> LDS (rows kn .. K4 zero; requested first, stored last: the loads are in
+  // flight while the records are built), run records + row range of every k group (one thread per group), then the k
+  // groups that can reach a tile are found by the wave that takes the tile (a ballot over the groups' row ranges)
+  if (kn > 0 && w > 0 && tbase >= 0) STAMP(56);
+  constexpr int NT = TILE_NW * WAVE, BCH = 6;
+  const double2* __restrict__ bsrc = reinterpret_cast<const double2*>(a.bblk + a.blk_boff[b]);
+  double2* bdst = reinterpret_cast<double2*>(Bs);
+  double2 btmp[BCH];
+#pragma unroll
+  for (int u = 0; u < BCH; ++u) {
+    const int i = tid + u * NT;
+    btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
   }
   {
-    const SlabRun* __restrict__ rp = a.runs + kmin;
-    for (int i = tid; i < K4 + TILE_RPAD; i += TILE_NW * WAVE) {
+    // one thread per record (all loads independent and in flight together with the tile's), the row range of a k
+    // group = min / max over its four records: two quad-permute steps
+    const uint4* __restrict__ rp = reinterpret_cast<const uint4*>(a.runs + kmin);
+    for (int i0 = 0; i0 < K4 + 4; i0 += NT) {
+      const int i = i0 + tid;
+      const int ic = min(i, kn - 1);
+      const uint4 r0 = rp[2 * ic], r1 = rp[2 * ic + 1];      // (addr_lo, addr_hi, nbytes, flags), (first8, first, span62, pad)
+      STAMP(57);
+      if (r0.z + r1.y == 0x7fffffffu) STAMP(59);
+      STAMP(58);
+      const int rows = i < kn ? (int)(r0.z >> 3) : 0;
+      const int first = (int)r1.y;
       TileRec rec;
       rec.rz = 0;
       rec.first = INT_MAX;
       rec.span = 0u;
-      if (i < kn) {
-        const SlabRun r = rp[i];
-        const int rows = (int)(r.nbytes >> 3);
-        if (rows > 0) {
-          const unsigned long long addr = (unsigned long long)r.addr_lo | ((unsigned long long)r.addr_hi << 32);
-          rec.rz = addr - (unsigned long long)((long long)r.first * 8);
-          rec.first = r.first;
-          rec.span = (uint32_t)(rows - 1);
+      int rmin = INT_MAX, rmax = -1;
+      if (rows > 0) {
+        const unsigned long long addr = (unsigned long long)r0.x | ((unsigned long long)r0.y << 32);
+        rec.rz = addr - (unsigned long long)((long long)first * 8);
+        rec.first = first;
+        rec.span = (uint32_t)(rows - 1);
+        rmin = first;
+        rmax = first + rows - 1;
+      }
+      rmin = min(rmin, __builtin_amdgcn_mov_dpp(rmin, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+      rmax = max(rmax, __builtin_amdgcn_mov_dpp(rmax, 0xb1, 0xf, 0xf, false));
+      rmin = min(rmin, __builtin_amdgcn_mov_dpp(rmin, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+      rmax = max(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x4e, 0xf, 0xf, false));
+      if (i < K4 + 4) {
+        recs[i] = rec;
+        if ((i & 3) == 0) {
+          grmin[i >> 2] = rmin;
+          grmax[i >> 2] = rmax;
         }
       }
-      recs[i] = rec;
     }
   }
-  for (int t = tid; t < T; t += TILE_NW * WAVE) {
-    kgmin[t] = INT_MAX;
-    kgmax[t] = -1;
-    colmask[t] = 0u;
+  STAMP(60);
+#pragma unroll
+  for (int u = 0; u < BCH; ++u) {
+    const int i = tid + u * NT;
+    if (i < K4 * 8) bdst[i] = btmp[u];
   }
+  for (int i = tid + BCH * NT; i < K4 * 8; i += NT) bdst[i] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+  STAMP(61);
+  for (int t = tid; t < T; t += NT) colmask[t] = 0u;
   if (tid < 16) {
     col_cnt[tid] = 0;
     col_first[tid] = INT_MAX;
@@ -152,25 +196,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3
   }
   if (tid < 4) misc[tid] = 0;
   __syncthreads();
-  // k groups that can reach a tile: [kgmin[t], kgmax[t]]
-  for (int g = tid; g < KG; g += TILE_NW * WAVE) {
-    int rmin = INT_MAX, rmax = -1;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const TileRec rec = recs[4 * g + u];
-      if (rec.first != INT_MAX) {
-        rmin = min(rmin, rec.first);
-        rmax = max(rmax, rec.first + (int)rec.span);
-      }
-    }
-    if (rmax >= rmin) {
-      const int t0 = max(0, (rmin - lo) >> 4), t1 = min(T - 1, (rmax - lo) >> 4);
-      for (int t = t0; t <= t1; ++t) {
-        atomicMin(&kgmin[t], g);
-        atomicMax(&kgmax[t], g);
-      }
-    }
-  }
+  STAMP(62);
+  STAMP(63);
   if constexpr (EPI != 0) {
     if (a.fz->prod) {   // products of this block = sum over the tile rows k of (non-zero multipliers) * (entries of A(:, k))
       const int32_t* __restrict__ in_count = a.fz->in_count;
@@ -186,6 +213,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3
     }
   }
   __syncthreads();
+  STAMP(1);
 
   // ---- per-lane constants: this lane's column is jj = lane % 16 in every tile
   const int jj = lane & 15, q = lane >> 4;
@@ -231,10 +259,23 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3
   const int rend = lo + w;
   const int mid = (T - 1) >> 1;
 
-  for (int ts = wave; ts < T; ts += TILE_NW) {   // centre first: the tiles in the middle of the window have the longest k ranges
+  [[maybe_unused]] int sidx = 4;
+  for (int ti = 0;; ++ti) {   // (snake order over the waves: every wave gets tiles from both ends of each round)
+    const int ts = ti * TILE_NW + ((ti & 1) ? TILE_NW - 1 - wave : wave);
+    if (ti * TILE_NW >= T) break;
+    if (ts >= T) continue;
+    STAMP(sidx); ++sidx;   // centre first: the tiles in the middle of the window have the longest k ranges
     const int t = (ts & 1) ? mid + ((ts + 1) >> 1) : mid - (ts >> 1);
     const int r0 = lo + 16 * t;
-    const int g0 = uni_i32(kgmin[t]), g1 = uni_i32(kgmax[t]);
+    int g0 = INT_MAX, g1 = -1;   // the k groups that can reach the tile: a ballot over the groups' row ranges
+    for (int c = 0; c < KG; c += WAVE) {
+      const int gq = min(c + lane, KG);
+      const unsigned long long m = __ballot(grmin[gq] <= r0 + 15 && grmax[gq] >= r0);   // (group KG: empty, never true)
+      if (m) {
+        if (g0 == INT_MAX) g0 = c + (int)__builtin_ctzll(m);
+        g1 = c + 63 - (int)__builtin_clzll(m);
+      }
+    }
     // what the epilogue reads, requested before the loop
     [[maybe_unused]] double xv[4], dv[4];
     [[maybe_unused]] int prow[4];
@@ -250,34 +291,51 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     if (g1 >= g0) {
       // Software pipeline over the k groups g0 .. g1 (records and multiplier rows are padded behind the last group, and
-      // a group beyond kgmax[t] has no row in this tile, so nothing below needs a bound): the record of group g + PF + 1
+      // a group beyond g1 has no row in this tile, so nothing below needs a bound): the record of group g + PF + 1
       // is read from LDS while the run load of group g + PF is issued from the record read one step earlier, the
       // multiplier row of g + 1 is read, and group g -- operands landed PF steps / one step ago -- is multiplied.
       const int rl = r0 + jj;                      // A operand: row rl, column 4 g + q
       const unsigned long long r8 = (unsigned long long)((long long)rl * 8);
       const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(recs) + q;     // record of group g: rq[4 g]
       const double* __restrict__ bq = Bs + lane;                                   // multiplier of group g: bq[64 g]
+#ifdef NTP_TILE_ABL_NOLOAD
+      const unsigned long long abl_base = reinterpret_cast<unsigned long long>(a.out_val) & ~0x3fffull;   // (any mapped memory)
+#endif
       auto run_load = [&](const uint4 raw) -> double {
         const unsigned long long rz = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
-        const bool ok = (unsigned)(rl - (int)raw.z) <= raw.w;
+        bool ok = (unsigned)(rl - (int)raw.z) <= raw.w;
+#ifdef NTP_TILE_ABL_NOLOAD
+        return *reinterpret_cast<gptr_t>(ok ? abl_base + ((rz + r8 - abl_base) & 0x3ff8ull) : zaddr);   // ablation (wrong results): a 16 KB window
+#else
         return *reinterpret_cast<gptr_t>(ok ? rz + r8 : zaddr);
+#endif
       };
-      double ring[TILE_PF];
+      // slot u of the ring holds the A operand of group g + u; it is refilled (group g + u + PF) right after the matrix
+      // instruction that read it has been issued, so no value is ever copied from one register to another.  PF run
+      // loads per wave stay in flight: they return in order, so one HBM miss holds back everything behind it and the
+      // depth has to cover a miss, not a hit.  The multiplier rows come from LDS two slots ahead (three registers).
+      double ring[TILE_PF], bb[3];
+      const int KGm1 = KG - 1;
 #pragma unroll
-      for (int u = 0; u < TILE_PF; ++u) ring[u] = run_load(rq[4 * (g0 + u)]);
-      uint4 rec_c = rq[4 * (g0 + TILE_PF)];
-      double b_c = bq[64 * g0];
+      for (int u = 0; u < TILE_PF; ++u) ring[u] = run_load(rq[4 * min(g0 + u, KG)]);
+      bb[0] = bq[64 * g0];
+      bb[1] = bq[64 * min(g0 + 1, KGm1)];
+      bb[2] = 0.0;
+      uint4 raw = rq[4 * min(g0 + TILE_PF, KG)];
       int g = g0;
+      STAMP(sidx);
       for (; g + TILE_PF - 1 <= g1; g += TILE_PF) {
 #pragma unroll
         for (int u = 0; u < TILE_PF; ++u) {
-          const uint4 rec_n = rq[4 * (g + u + TILE_PF + 1)];
-          const double av = ring[u];
-          ring[u] = run_load(rec_c);
-          const double b_n = bq[64 * (g + u + 1)];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b_c, acc, 0, 0, 0);
-          rec_c = rec_n;
-          b_c = b_n;
+          // (the order is pinned: record read one slot ahead | matrix instruction | refill of the slot it has read)
+          const uint4 raw_n = rq[4 * min(g + u + TILE_PF + 1, KG)];
+          __builtin_amdgcn_sched_barrier(0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u], bb[u % 3], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          ring[u] = run_load(raw);
+          bb[(u + 2) % 3] = bq[64 * min(g + u + 2, KGm1)];
+          raw = raw_n;
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
@@ -285,6 +343,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3
         if (g + u <= g1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u], bq[64 * (g + u)], acc, 0, 0, 0);
       }
     }
+    ++sidx; STAMP(sidx); ++sidx;
     // ---- epilogue of the tile: lane holds rows r0 + 4 v + q (v = 0..3) of column jj
     double res[4];
     unsigned long long anykeep = 0;
@@ -367,7 +426,9 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3
       }
     }
     if (lane == 0) colmask[t] = cm;
+    STAMP(sidx); ++sidx;
   }
+  STAMP(2);
   // ---- the block
   if constexpr (EPI != 0) {
     dsum = wave_sum_f64(dsum);
@@ -379,6 +440,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(3
   }
   if (lane == 0 && pn) atomicAdd(&misc[1], pn);
   __syncthreads();
+  STAMP(3);
   if constexpr (EPI == 2) {
     // the deferred elements: kept (unfiltered) where they lie beyond the last kept entry of the product column.  Only
     // the decision and the column statistics here; the values are stored after the holes have been zeroed (below)
@@ -508,20 +570,42 @@ void launch_spgemm_tile(const TileLaunch& L) {
     zeros->zero();
   }
   a.zero = zeros->p;
+#ifdef NTP_TILE_STAMPS
+  static DevBuf<long long>* stamps = nullptr;
+  if (!stamps) stamps = new DevBuf<long long>(64 * 8 * 64);
+  stamps->zero();
+  a.stamps = stamps->p;
+#endif
   const size_t lds = tile_lds_bytes(a.k4max, a.tmax);
-  static size_t raised[3] = {0, 0, 0};
-  auto go = [&](auto epi_tag) {
-    constexpr int E = decltype(epi_tag)::value;
-    if (lds > 64 * 1024 && lds > raised[E]) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static size_t raised[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  // waves per workgroup: eight when the LDS tile allows at most two workgroups per CU (the k range of a purification
+  // iterate: ~50 KB), four when three or more fit
+  const bool wide = 3 * lds > 160 * 1024;
+  auto go = [&](auto epi_tag, auto nw_tag) {
+    constexpr int E = decltype(epi_tag)::value, NW = decltype(nw_tag)::value;
+    if (lds > 64 * 1024 && lds > raised[E][NW / 8]) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile<E, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     150 * 1024));
-      raised[E] = 150 * 1024;
+      raised[E][NW / 8] = 150 * 1024;
     }
-    hipLaunchKernelGGL((k_spgemm_tile<E>), dim3(xcd_grid(L.nblocks)), dim3(TILE_NW * WAVE), lds, stream(), a);
+    hipLaunchKernelGGL((k_spgemm_tile<E, NW>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
   };
-  if (L.epi == 0) go(std::integral_constant<int, 0>{});
-  else if (L.epi == 1) go(std::integral_constant<int, 1>{});
-  else go(std::integral_constant<int, 2>{});
+  auto by_nw = [&](auto epi_tag) {
+    const int nw = options().spgemm_variant == 604 ? 4 : options().spgemm_variant == 608 ? 8 : (wide ? 8 : 4);
+    if (nw == 8) go(epi_tag, std::integral_constant<int, 8>{});
+    else go(epi_tag, std::integral_constant<int, 4>{});
+  };
+  if (L.epi == 0) by_nw(std::integral_constant<int, 0>{});
+  else if (L.epi == 1) by_nw(std::integral_constant<int, 1>{});
+  else by_nw(std::integral_constant<int, 2>{});
+#ifdef NTP_TILE_STAMPS
+  if (const char* f = std::getenv("NTP_TILE_STAMPS_FILE")) {
+    std::vector<long long> h(64 * 8 * 64);
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    HIP_CHECK(hipMemcpy(h.data(), stamps->p, h.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
+  }
+#endif
 }
 
 }  // namespace ntp
