@@ -143,6 +143,8 @@ def main():
                          "the reference computes when built with FP contraction -- run on the FP64 matrix cores "
                          "(v_mfma_f64_16x16x4_f64, option spgemm_fma = 1); unfused: separate multiply and add, the "
                          "reference's default x86-64 build bit for bit (v_mul_f64 + v_add_f64 register-slab kernel)")
+    ap.add_argument("--tile-rows", type=int, default=None, help="experiments: option tile_rows (1, 2, 4)")
+    ap.add_argument("--tile-waves", type=int, default=None, help="experiments: option tile_waves (4, 8)")
     args = ap.parse_args()
 
     import ntpoly_amd as nt
@@ -158,6 +160,10 @@ def main():
     nt.ConstructGlobalProcessGrid(1, world, 1)  # column panels: one per GPU
     nt.set_option("time_kernels", 1)
     nt.set_option("spgemm_fma", 1 if args.arithmetic == "fma" else 0)
+    if args.tile_rows is not None:
+        nt.set_option("tile_rows", args.tile_rows)
+    if args.tile_waves is not None:
+        nt.set_option("tile_waves", args.tile_waves)
     if args.no_label_order:
         nt.set_option("label_order", 0)
 

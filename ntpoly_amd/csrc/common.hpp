@@ -131,6 +131,9 @@ struct SlabForm {
   DevBuf<int64_t> tile_off;   // blocks + 1
   DevBuf<double> val, tiles;
   int64_t slots = 0;          // doubles addressable in val / tiles
+  int row_pad = 1;            // > 1 (a multiple of 16): every column's slot holds row r at a position = r (mod row_pad) and reads as
+                              // ZERO from the multiple of row_pad below its first row to the one above its last (results of the
+                              // MFMA tile kernel, spgemm_tile.hpp, which reads several consecutive rows per lane)
   // Label-ordered form (optional): the indices are a bandwidth-reducing RELABELLING of the matrix the caller handed
   // in; lab[index] = the caller's index.  The arithmetic follows the caller's labels (order of the k steps, "last
   // row" of a column: plast[j] = largest label among the entries of column j, -1 if empty), so results are those of

@@ -659,6 +659,31 @@ __global__ __launch_bounds__(256) void k_slab_expand_a(Csc A, const int32_t* __r
   }
 }
 
+// Expanded columns for the MFMA tile kernel (spgemm_tile.hpp, rows per lane > 1): the run of column k sits in a slot that
+// starts at a multiple of `al` rows below its first row and ends at one above its last, position = row (mod al), the
+// pads zero -- a lane may then read R consecutive rows that only touch the run.  span[k] = slot size; after the scan of
+// the slot sizes k_aligned_offsets moves every offset to the position of the column's first row and zeroes the pads.
+__global__ void k_span_aligned(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax, int32_t* __restrict__ span, int n, int al) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int f = cmin[k], l = cmax[k];
+  span[k] = l >= f ? (l / al + 1) * al - f / al * al : 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_aligned_offsets(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax,
+                                                         int64_t* __restrict__ off, T* __restrict__ exp, int n, int al) {
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (k >= n) return;
+  const int lane = lane_id();
+  const int f = cmin[k], l = cmax[k];
+  if (l < f) return;
+  const int64_t slot = off[k];
+  const int head = f - f / al * al, tail = (l / al + 1) * al - 1 - l;
+  for (int i = lane; i < head; i += WAVE) exp[slot + i] = Sc<T>::zero();
+  for (int i = lane; i < tail; i += WAVE) exp[slot + head + (l - f + 1) + i] = Sc<T>::zero();
+  if (lane == 0) off[k] = slot + head;
+}
+
 // per block of J output columns (one wave each): k range = union of the columns' row ranges in B, row window =
 // union of the runs of A(:, k) over that k range (a superset of the rows actually touched when B has holes --
 // harmless, the window only has to contain them), sizes of the B tile and of the output slots.
@@ -702,9 +727,9 @@ __global__ __launch_bounds__(256) void k_slab_plan(int ncols, const int32_t* __r
   lo = wave_min_i32(lo);
   hi = wave_max_i32(hi);
   if (lane != 0) return;
-  if (align16 && hi > lo) {
-    lo &= ~15;
-    hi = (hi + 15) & ~15;
+  if (align16 > 0 && hi > lo) {   // (a multiple of 16: the rows of a tile of the MFMA kernel)
+    lo = lo / align16 * align16;
+    hi = (hi + align16 - 1) / align16 * align16;
   }
   const int w = (hi > lo) ? hi - lo : 0;
   const int kn = (w > 0 && kmax >= kmin) ? kmax - kmin + 1 : 0;
@@ -2727,6 +2752,7 @@ struct DotOperand {
   DevBuf<int64_t> doff;
   DevBuf<double> dexp;
   int64_t max_tile = 0;   // largest sum of the spans of 16 consecutive columns (the kernel keeps that tile in LDS)
+  int align = 1;          // columns in aligned zero-padded slots of that many rows (k_span_aligned), 1: packed back to back
 };
 // stored values that are exactly zero (real matrices; columns may be loose): one wave per column
 __global__ __launch_bounds__(256) void k_count_zero_values(Csc A, unsigned long long* __restrict__ out) {
@@ -2754,13 +2780,17 @@ void drop_dot_operand() { *dot_operand_slot() = DotOperand(); }
 const DotOperand& dot_operand(const DevMat& D) {
   DotOperand* c = dot_operand_slot();
   const unsigned long long ser = dev_alloc_serial(D.val.p);
-  if (c->val == D.val.p && c->serial == ser && ser != 0 && c->epoch == value_epoch() && c->nnz == D.nnz && c->cols == D.cols)
+  const int want_al = options().spgemm_fma == 1 ? tile_expand_align() : 1;
+  if (c->val == D.val.p && c->serial == ser && ser != 0 && c->epoch == value_epoch() && c->nnz == D.nnz && c->cols == D.cols &&
+      c->align == want_al)
     return *c;
   const int n = D.cols;
   c->dmin.alloc((size_t)n); c->dmax.alloc((size_t)n); c->doff.alloc((size_t)n + 1);
   DevBuf<int32_t> dlen((size_t)n), dspan((size_t)n);
   hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(D), c->dmin.p, c->dmax.p, dlen.p);
-  hipLaunchKernelGGL(k_span_of, dim3(cdiv(n, 256)), dim3(256), 0, stream(), c->dmin.p, c->dmax.p, dspan.p, n);
+  const int al = options().spgemm_fma == 1 ? tile_expand_align() : 1;   // (the MFMA tile kernel reads R rows at a time)
+  if (al > 1) hipLaunchKernelGGL(k_span_aligned, dim3(cdiv(n, 256)), dim3(256), 0, stream(), c->dmin.p, c->dmax.p, dspan.p, n, al);
+  else hipLaunchKernelGGL(k_span_of, dim3(cdiv(n, 256)), dim3(256), 0, stream(), c->dmin.p, c->dmax.p, dspan.p, n);
   scan_async<int32_t>(dspan.p, c->doff.p, (int64_t)n);
   DevBuf<unsigned long long> tmax(1);
   tmax.zero();
@@ -2775,6 +2805,10 @@ const DotOperand& dot_operand(const DevMat& D) {
   }
   c->max_tile = (int64_t)hmax;
   c->dexp.alloc((size_t)total + 1);
+  if (al > 1)
+    hipLaunchKernelGGL(k_aligned_offsets<double>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), c->dmin.p, c->dmax.p,
+                       c->doff.p, c->dexp.p, n, al);
+  c->align = al;
   hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(D), c->dmin.p,
                      c->doff.p, c->dexp.p);
   c->val = D.val.p;
@@ -2963,6 +2997,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   const bool slab_try = !grouped_done && options().spgemm_force_bin <= 0 && (sv_opt < 0 || sv_opt / 100 == 4 || sv_opt / 100 == 6) &&
                         A.nnz < 1000000000LL && B.nnz < 1000000000LL;
   const int snb = cdiv(n, SJ);
+  const bool tile_expand = !A.cplx && options().spgemm_fma == 1;
   DevBuf<int32_t> bfirst_own, blast_own, blen_own, aspan, blk_lo, blk_w, blk_kmin, blk_kn;
   DevBuf<int64_t> aeoff, bsz, tsz, blk_boff, blk_toff;
   DevBuf<char> runs;
@@ -2976,7 +3011,11 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       bfirst = bfirst_own.p; blast = blast_own.p;
     }
     aspan.alloc((size_t)nka); aeoff.alloc((size_t)nka + 1);   // local ids 0 .. nka (column ka + id)
-    hipLaunchKernelGGL(k_span_of, dim3(cdiv(nka, 256)), dim3(256), 0, stream(), cmin_own.p, cmax_own.p, aspan.p, nka);
+    // (real operands under option spgemm_fma = 1: aligned, zero-padded slots for the MFMA tile kernel)
+    if (tile_expand)
+      hipLaunchKernelGGL(k_span_aligned, dim3(cdiv(nka, 256)), dim3(256), 0, stream(), cmin_own.p, cmax_own.p, aspan.p, nka, tile_expand_align());
+    else
+      hipLaunchKernelGGL(k_span_of, dim3(cdiv(nka, 256)), dim3(256), 0, stream(), cmin_own.p, cmax_own.p, aspan.p, nka);
     scan_async<int32_t>(aspan.p, aeoff.p, (int64_t)nka);
     blk_lo.alloc(snb); blk_w.alloc(snb); blk_kmin.alloc(snb); blk_kn.alloc(snb);
     bsz.alloc(snb); tsz.alloc(snb); blk_boff.alloc((size_t)snb + 1); blk_toff.alloc((size_t)snb + 1);
@@ -2986,7 +3025,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     else
       hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst,
                          blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb,
-                         options().spgemm_fma == 1 ? 1 : 0);
+                         options().spgemm_fma == 1 ? tile_expand_align() : 0);
     hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, aspan.p, nka, stats.p);
     scan_async<int64_t>(bsz.p, blk_boff.p, (int64_t)snb);
     scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
@@ -3082,6 +3121,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     aexp.alloc(((size_t)slab_tot[0] + 1) * A.wval());
     bblk.alloc(((size_t)slab_tot[1] + 16 * SJ) * A.wval());  // slack: the loop prefetches a few rows past the last tile
     const bool same = (&A == &B);
+    if (tile_expand && nka)
+      hipLaunchKernelGGL(k_aligned_offsets<double>, dim3(cdiv((int64_t)nka * WAVE, 256)), dim3(256), 0, stream(), cmin_own.p,
+                         cmax_own.p, aeoff.p, aexp.p, nka, tile_expand_align());
     runs.alloc(((size_t)nka + 4) * sizeof(SlabRun));
     hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(nka + 4, 256)), dim3(256), 0, stream(), cmin_own.p, cmax_own.p, aeoff.p,
                        reinterpret_cast<const char*>(aexp.p), (int)esz, reinterpret_cast<SlabRun*>(runs.p), nka);
@@ -3202,7 +3244,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
         tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = tmp_val.p; tl.count = count.p;
         tl.ofirst = fz_first.p; tl.olast = fz_last.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
         tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
-        tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = fuse->mode; tl.fz = fz_args.p;
+        tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = fuse->mode; tl.fz = fz_args.p; tl.rows = tile_rows();
         launch_spgemm_tile(tl);
         HIP_CHECK(hipMemcpyAsync(tile_ooff.p + n, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
         HIP_CHECK(hipMemcpyAsync(tile_otoff.p + snb, blk_toff.p + snb, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
@@ -3218,7 +3260,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = tmp_val.p; tl.count = count.p;
       tl.ofirst = fz_first.p; tl.olast = fz_last.p; tl.ooff = tile_ooff.p;
       tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
-      tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = 0;
+      tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = 0; tl.rows = tile_rows();
       launch_spgemm_tile(tl);
     } else if (max_w_now > 6 * SLAB_SL * WAVE)         // 1153 .. 1536 rows: eight waves per workgroup
       hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, 8, 0>), dim3(xcd_grid(snb)), dim3(8 * WAVE), 0, stream(),
@@ -3404,6 +3446,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     R.slab->first = std::move(fz_first);
     R.slab->last = std::move(fz_last);
     R.slab->count = std::move(count);
+    R.slab->row_pad = use_tile ? tile_expand_align() : 1;
     R.slab->off = use_tile ? std::move(tile_ooff) : std::move(tmpoff);
     R.slab->tile_off = use_tile ? std::move(tile_otoff) : std::move(blk_toff);
     R.slab->val = std::move(tmp_val);
@@ -3612,6 +3655,13 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     return false;
   const SlabForm& in = *X.slab;
   if (tile && in.labelled()) return false;
+  // rows per lane of the tile kernel: what the option asks for, if the runs of X (and of D) are padded for it; the runs
+  // of a halo sit packed in the receive buffer: one row per lane there
+  int trows = 1;
+  if (tile && !halo) {
+    trows = tile_rows();
+    while (trows > 1 && (in.row_pad % (16 * trows) != 0)) trows >>= 1;
+  }
   const int n = X.cols, snb = cdiv(n, SLAB_J);
   const DotOperand& dop = dot_operand(*fu.D);
   if (!tile && dop.max_tile > SLAB_DTILE) return false;
@@ -3637,7 +3687,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   const int32_t* afirst = halo ? halo->first - ka : in.first.p;
   const int32_t* alast = halo ? halo->last - ka : in.last.p;
   hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, in.first.p,
-                     in.last.p, afirst, alast, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb, tile ? 1 : 0);
+                     in.last.p, afirst, alast, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb, tile ? 16 * tile_rows() : 0);
   hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, (const int32_t*)nullptr, 0, stats);
   scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
   int64_t tmp_total = 0;
@@ -3735,7 +3785,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = oval.p; tl.count = count.p;
     tl.ofirst = ofirst.p; tl.olast = olast.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
     tl.alpha = 1.0; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
-    tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = fz_args.p;
+    tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = fz_args.p; tl.rows = trows;
     launch_spgemm_tile(tl);
     HIP_CHECK(hipMemcpyAsync(tile_ooff.p + n, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
     HIP_CHECK(hipMemcpyAsync(tile_otoff.p + snb, blk_toff.p + snb, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
@@ -3793,6 +3843,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   R.slab->first = std::move(ofirst);
   R.slab->last = std::move(olast);
   R.slab->count = std::move(count);
+  R.slab->row_pad = tile ? 16 * trows : 1;
   R.slab->off = tile ? std::move(tile_ooff) : std::move(tmpoff);
   R.slab->tile_off = tile ? std::move(tile_otoff) : std::move(blk_toff);
   R.slab->val = std::move(oval);

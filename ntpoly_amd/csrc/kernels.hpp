@@ -32,6 +32,8 @@ struct EngineOptions {
   int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
                                // reference built with FP contraction computes); 0: separate multiply and add (default, bit-
                                // identical to the reference built without contraction)
+  int tile_rows = 2;           // MFMA tile kernel (spgemm_fma = 1): consecutive rows per lane of the A operand, 1 / 2 / 4 (spgemm_tile.hpp)
+  int tile_waves = 0;          // ... waves per workgroup, 4 / 8 (0: chosen from the LDS footprint)
   int load_balance = 1;        // 1: solvers permute with the caller's load-balancing permutation as the reference does;
                                // 0: SetParametersLoadBalance is ignored -- the same results up to summation order (a
                                // symmetric permutation only relabels entries), but banded operands stay on the run-based

@@ -35,7 +35,25 @@ namespace ntp {
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-typedef const double __attribute__((address_space(1)))* gptr_t;   // (loads through it are global_load, not flat_load)
+typedef double v2d __attribute__((ext_vector_type(2)));
+// R consecutive rows of a column as one value: a lane of the A operand loads them with ONE address computation and
+// feeds R matrix instructions (rows r0 + R i + m, m = 0 .. R - 1, of a tile of 16 R rows)
+template <int R> struct RowVec;
+template <> struct RowVec<1> { typedef double type; };
+template <> struct RowVec<2> { typedef v2d type; };
+template <> struct RowVec<4> { typedef v4d type; };
+template <int R> __device__ inline double rv_get(const typename RowVec<R>::type& x, int m) { return x[m]; }
+template <> __device__ inline double rv_get<1>(const double& x, int) { return x; }
+template <int R> __device__ inline void rv_set(typename RowVec<R>::type& x, int m, double v) { x[m] = v; }
+template <> __device__ inline void rv_set<1>(double& x, int, double v) { x = v; }
+// (loads through address space 1 are global_load, not flat_load)
+template <int R> __device__ inline typename RowVec<R>::type rv_load(unsigned long long addr) {
+  return *reinterpret_cast<const typename RowVec<R>::type __attribute__((address_space(1)))*>(addr);
+}
+template <int R> __device__ inline typename RowVec<R>::type rv_load(const double* p) { return rv_load<R>(reinterpret_cast<unsigned long long>(p)); }
+template <int R> __device__ inline void rv_store(double* p, const typename RowVec<R>::type& v) {
+  *reinterpret_cast<typename RowVec<R>::type __attribute__((address_space(1)))*>(reinterpret_cast<unsigned long long>(p)) = v;
+}
 
 // run of column k as the tile loop wants it: rz = address of (hypothetical) row 0, valid rows first .. last
 struct alignas(16) TileRec {
@@ -43,7 +61,7 @@ struct alignas(16) TileRec {
   int32_t first;
   uint32_t span;     // last - first; an empty run: first = INT_MAX, span = 0 (no row passes (unsigned)(r - first) <= span)
 };
-constexpr int TILE_PF = 12;          // run loads (k groups) in flight per wave; a multiple of 3
+constexpr int TILE_PF = 6;           // run loads (k groups) in flight per wave; a multiple of 3
 constexpr int TILE_RPAD = 4, TILE_BPAD = 0;   // one group of empty records behind the last (the pipeline's look-ahead is clamped to it)
 // an element of X whose fate depends on the last kept row of the product column (decided when the block is done)
 struct alignas(16) TileDefer {
@@ -85,8 +103,8 @@ __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax) {
 #define STAMP(i) do { } while (0)
 #endif
 
-template <int EPI, int TILE_NW>
-__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_spgemm_tile(const TileArgs a) {
+template <int EPI, int TILE_NW, int R>
+__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(EPI == 0 ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = xcd_block(a.nblocks);
   if (b < 0) return;
@@ -125,7 +143,9 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4
   int* misc = reinterpret_cast<int*>(red + 2 * 8);                           // [0] deferred, [1] product entries, [2..3] products
 
   const int KG = (kn + 3) >> 2, K4 = KG * 4;
-  const int T = (w + 15) >> 4;
+  constexpr int TROWS = 16 * R;   // rows of a tile: R matrix instructions per k group (the window is a multiple, the host sees to it)
+  typedef typename RowVec<R>::type VR;
+  const int T = (w + TROWS - 1) / TROWS;
   // ---- block prologue: multiplier tile -> LDS (rows kn .. K4 zero; requested first, stored last: the loads are in
   // flight while the records are built), run records + row range of every k group (one thread per group), then the k
   // groups that can reach a tile are found by the wave that takes the tile (a ballot over the groups' row ranges)
@@ -160,8 +180,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4
       if (rows > 0) {
         const unsigned long long addr = (unsigned long long)r0.x | ((unsigned long long)r0.y << 32);
         rec.rz = addr - (unsigned long long)((long long)first * 8);
-        rec.first = first;
-        rec.span = (uint32_t)(rows - 1);
+        rec.first = first - (R - 1);               // a lane's rows ra .. ra + R - 1 touch the run iff (unsigned)(ra - rec.first) <= rec.span
+        rec.span = (uint32_t)(rows - 1 + (R - 1));
         rmin = first;
         rmax = first + rows - 1;
       }
@@ -266,55 +286,52 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4
     if (ts >= T) continue;
     STAMP(sidx); ++sidx;   // centre first: the tiles in the middle of the window have the longest k ranges
     const int t = (ts & 1) ? mid + ((ts + 1) >> 1) : mid - (ts >> 1);
-    const int r0 = lo + 16 * t;
+    const int r0 = lo + TROWS * t;
     int g0 = INT_MAX, g1 = -1;   // the k groups that can reach the tile: a ballot over the groups' row ranges
     for (int c = 0; c < KG; c += WAVE) {
       const int gq = min(c + lane, KG);
-      const unsigned long long m = __ballot(grmin[gq] <= r0 + 15 && grmax[gq] >= r0);   // (group KG: empty, never true)
+      const unsigned long long m = __ballot(grmin[gq] <= r0 + TROWS - 1 && grmax[gq] >= r0);   // (group KG: empty, never true)
       if (m) {
         if (g0 == INT_MAX) g0 = c + (int)__builtin_ctzll(m);
         g1 = c + 63 - (int)__builtin_clzll(m);
       }
     }
-    // what the epilogue reads, requested before the loop
-    [[maybe_unused]] double xv[4], dv[4];
-    [[maybe_unused]] int prow[4];
+    // what the epilogue reads, requested before the loop: this lane's elements are rows r0 + R (4 v + q) + m of column jj
+    [[maybe_unused]] VR xv[4], dv[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int r = r0 + 4 * v + q;
-      if constexpr (EPI == 2) xv[v] = *(gptr_t)(((r >= xf) & (r <= xlrow)) ? xrz + r : zp);
+      const int rb = r0 + R * (4 * v + q);
+      if constexpr (EPI == 2) xv[v] = rv_load<R>(((rb + R - 1 >= xf) & (rb <= xlrow)) ? xrz + rb : zp);
       if constexpr (EPI != 0) {
-        dv[v] = *(gptr_t)(((r >= df) & (r <= dl)) ? drz + r : zp);
-        prow[v] = lab ? lab[min(r, a.ncols - 1)] : r;
+        dv[v] = rv_load<R>(((rb + R - 1 >= df) & (rb <= dl)) ? drz + rb : zp);
       }
     }
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    v4d acc[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) acc[m] = v4d{0.0, 0.0, 0.0, 0.0};
     if (g1 >= g0) {
       // Software pipeline over the k groups g0 .. g1 (records and multiplier rows are padded behind the last group, and
       // a group beyond g1 has no row in this tile, so nothing below needs a bound): the record of group g + PF + 1
       // is read from LDS while the run load of group g + PF is issued from the record read one step earlier, the
       // multiplier row of g + 1 is read, and group g -- operands landed PF steps / one step ago -- is multiplied.
-      const int rl = r0 + jj;                      // A operand: row rl, column 4 g + q
+      const int rl = r0 + R * jj;                  // A operand: rows rl .. rl + R - 1, column 4 g + q
       const unsigned long long r8 = (unsigned long long)((long long)rl * 8);
       const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(recs) + q;     // record of group g: rq[4 g]
       const double* __restrict__ bq = Bs + lane;                                   // multiplier of group g: bq[64 g]
 #ifdef NTP_TILE_ABL_NOLOAD
       const unsigned long long abl_base = reinterpret_cast<unsigned long long>(a.out_val) & ~0x3fffull;   // (any mapped memory)
 #endif
-      auto run_load = [&](const uint4 raw) -> double {
+      auto run_load = [&](const uint4 raw) -> VR {
         const unsigned long long rz = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
-        bool ok = (unsigned)(rl - (int)raw.z) <= raw.w;
-#ifdef NTP_TILE_ABL_NOLOAD
-        return *reinterpret_cast<gptr_t>(ok ? abl_base + ((rz + r8 - abl_base) & 0x3ff8ull) : zaddr);   // ablation (wrong results): a 16 KB window
-#else
-        return *reinterpret_cast<gptr_t>(ok ? rz + r8 : zaddr);
-#endif
+        const bool ok = (unsigned)(rl - (int)raw.z) <= raw.w;
+        return rv_load<R>(ok ? rz + r8 : zaddr);
       };
       // slot u of the ring holds the A operand of group g + u; it is refilled (group g + u + PF) right after the matrix
       // instruction that read it has been issued, so no value is ever copied from one register to another.  PF run
       // loads per wave stay in flight: they return in order, so one HBM miss holds back everything behind it and the
       // depth has to cover a miss, not a hit.  The multiplier rows come from LDS two slots ahead (three registers).
-      double ring[TILE_PF], bb[3];
+      VR ring[TILE_PF];
+      double bb[3];
       const int KGm1 = KG - 1;
 #pragma unroll
       for (int u = 0; u < TILE_PF; ++u) ring[u] = run_load(rq[4 * min(g0 + u, KG)]);
@@ -330,7 +347,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4
           // (the order is pinned: record read one slot ahead | matrix instruction | refill of the slot it has read)
           const uint4 raw_n = rq[4 * min(g + u + TILE_PF + 1, KG)];
           __builtin_amdgcn_sched_barrier(0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u], bb[u % 3], acc, 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < R; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(rv_get<R>(ring[u], m), bb[u % 3], acc[m], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           ring[u] = run_load(raw);
           bb[(u + 2) % 3] = bq[64 * min(g + u + 2, KGm1)];
@@ -340,62 +358,75 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4
       }
 #pragma unroll
       for (int u = 0; u < TILE_PF - 1; ++u) {
-        if (g + u <= g1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u], bq[64 * (g + u)], acc, 0, 0, 0);
+        if (g + u <= g1) {
+          const double bt = bq[64 * (g + u)];
+#pragma unroll
+          for (int m = 0; m < R; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(rv_get<R>(ring[u], m), bt, acc[m], 0, 0, 0);
+        }
       }
     }
     ++sidx; STAMP(sidx); ++sidx;
-    // ---- epilogue of the tile: lane holds rows r0 + 4 v + q (v = 0..3) of column jj
-    double res[4];
+    // ---- epilogue of the tile: lane holds rows r0 + R (4 v + q) + m (v = 0..3, m = 0..R-1) of column jj
+    VR res[4];
     unsigned long long anykeep = 0;
     int c_l = 0, f_l = INT_MAX, l_l = -1, pm_l = -1, pl_l = -1;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int r = r0 + 4 * v + q;
-      const double vv = acc[v];
-      const double sv = __dmul_rn(alpha, vv);
-      const bool ha = dense_rule ? (fabs(vv) > thr) : (fabs(sv) > thr);
-      bool keep;
-      double o;
-      if constexpr (EPI != 2) {
-        keep = ha;
-        o = sv;
-      } else {
-        const double bv = xv[v];
-        const bool hb = bv != 0.0;
-        const double bs = __dmul_rn(bm, bv);
-        const double wa = __dmul_rn(am, sv);
-        const double both = __dadd_rn(wa, bs);
-        o = ha ? (hb ? both : wa) : bs;                        // (neither: bs = 0)
-        const bool big = fabs(o) > thr_m;
-        // AddSparseVectors (inc_decide): both present -> threshold on the sum; one present -> threshold unless it lies
-        // beyond the other column's last entry.  "Beyond the product column's last kept entry" is not known yet for an
-        // element of X alone that fails the threshold: decided when the block is done (dlist)
-        if (ha) {
-          keep = (!hb && prow[v] > xpl) || big;
+#pragma unroll
+      for (int m = 0; m < R; ++m) {
+        const int r = r0 + R * (4 * v + q) + m;
+        const double vv = acc[m][v];
+        const double sv = __dmul_rn(alpha, vv);
+        const bool ha = dense_rule ? (fabs(vv) > thr) : (fabs(sv) > thr);
+        bool keep;
+        double o;
+        [[maybe_unused]] double dval = 0.0;
+        [[maybe_unused]] int pr = r;
+        if constexpr (EPI != 0) {
+          dval = rv_get<R>(dv[v], m);
+          pr = r;   // (label-ordered operands are not routed here yet: positions are rows)
+        }
+        if constexpr (EPI != 2) {
+          keep = ha;
+          o = sv;
         } else {
-          keep = hb && big;
-          if (hb && !big) {
-            const int slot = atomicAdd(&misc[0], 1);
-            if (slot < TILE_DEFER) {
-              TileDefer e;
-              e.r = r; e.jj = jj; e.prow = prow[v]; e.pad = 0; e.o = o; e.d = dv[v];
-              dlist[slot] = e;
+          const double bv = rv_get<R>(xv[v], m);
+          const bool hb = bv != 0.0;
+          const double bs = __dmul_rn(bm, bv);
+          const double wa = __dmul_rn(am, sv);
+          const double both = __dadd_rn(wa, bs);
+          o = ha ? (hb ? both : wa) : bs;                        // (neither: bs = 0)
+          const bool big = fabs(o) > thr_m;
+          // AddSparseVectors (inc_decide): both present -> threshold on the sum; one present -> threshold unless it lies
+          // beyond the other column's last entry.  "Beyond the product column's last kept entry" is not known yet for an
+          // element of X alone that fails the threshold: decided when the block is done (dlist)
+          if (ha) {
+            keep = (!hb && pr > xpl) || big;
+          } else {
+            keep = hb && big;
+            if (hb && !big) {
+              const int slot = atomicAdd(&misc[0], 1);
+              if (slot < TILE_DEFER) {
+                TileDefer e;
+                e.r = r; e.jj = jj; e.prow = pr; e.pad = 0; e.o = o; e.d = dval;
+                dlist[slot] = e;
+              }
             }
           }
         }
+        pn += (int)__popcll(__ballot(ha));
+        anykeep |= __ballot(keep);
+        if constexpr (EPI != 0) {
+          dsum = __dadd_rn(dsum, __dmul_rn(keep ? o : 0.0, keep ? dval : 0.0));
+          tsum = __dadd_rn(tsum, (keep && r == diag) ? o : 0.0);
+          pm_l = max(pm_l, ha ? pr : -1);
+          pl_l = max(pl_l, keep ? pr : -1);
+        }
+        c_l += keep ? 1 : 0;
+        f_l = min(f_l, keep ? r : INT_MAX);
+        l_l = max(l_l, keep ? r : -1);
+        rv_set<R>(res[v], m, keep ? o : 0.0);
       }
-      pn += (int)__popcll(__ballot(ha));
-      anykeep |= __ballot(keep);
-      if constexpr (EPI != 0) {
-        dsum = __dadd_rn(dsum, __dmul_rn(keep ? o : 0.0, keep ? dv[v] : 0.0));
-        tsum = __dadd_rn(tsum, (keep && r == diag) ? o : 0.0);
-        pm_l = max(pm_l, ha ? prow[v] : -1);
-        pl_l = max(pl_l, keep ? prow[v] : -1);
-      }
-      c_l += keep ? 1 : 0;
-      f_l = min(f_l, keep ? r : INT_MAX);
-      l_l = max(l_l, keep ? r : -1);
-      res[v] = keep ? o : 0.0;
     }
     const unsigned cm = (unsigned)((anykeep | (anykeep >> 16) | (anykeep >> 32) | (anykeep >> 48)) & 0xffffull);
     if (c_l) {
@@ -409,19 +440,16 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4
     if constexpr (EPI == 2) {
       if (pm_l >= 0) atomicMax(&col_pmax[jj], pm_l);
     }
-    if ((cm >> jj) & 1u) {   // the column has an entry in this tile: its 16 rows are written (zeros = holes)
+    if ((cm >> jj) & 1u) {   // the column has an entry in this tile: its 16 R rows are written (zeros = holes)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = r0 + 4 * v + q;
-        if (r < rend) orun[r] = res[v];
-      }
+      for (int v = 0; v < 4; ++v) rv_store<R>(orun + (r0 + R * (4 * v + q)), res[v]);
     }
     if constexpr (EPI != 0) {
       if (cm) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int r = r0 + 4 * v + q;
-          if (r < rend) otile[(int64_t)r * SLAB_J] = res[v];
+#pragma unroll
+          for (int m = 0; m < R; ++m) otile[(int64_t)(r0 + R * (4 * v + q) + m) * SLAB_J] = rv_get<R>(res[v], m);
         }
       }
     }
@@ -521,15 +549,15 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4
     const int t = p >> 4, c = p & 15;
     const unsigned cmk = colmask[t];
     const int cf = col_first[c], cl = col_last[c];
-    const int r0 = lo + 16 * t;
-    if (cl >= cf && r0 + 15 >= cf && r0 <= cl && !((cmk >> c) & 1u)) {
+    const int r0 = lo + TROWS * t;
+    if (cl >= cf && r0 + TROWS - 1 >= cf && r0 <= cl && !((cmk >> c) & 1u)) {
       double* dst = a.out_val + (tbase + (int64_t)c * w - lo);
-      for (int r = r0; r < min(r0 + 16, rend); ++r) dst[r] = 0.0;
+      for (int r = r0; r < min(r0 + TROWS, rend); ++r) dst[r] = 0.0;
     }
     if constexpr (EPI != 0) {
-      if (tk1 >= tk0 && r0 + 15 >= tk0 && r0 <= tk1 && cmk == 0u) {
+      if (tk1 >= tk0 && r0 + TROWS - 1 >= tk0 && r0 <= tk1 && cmk == 0u) {
         double* dst = a.fz->tiles + (tbase - (int64_t)lo * SLAB_J + c);
-        for (int r = r0; r < min(r0 + 16, rend); ++r) dst[(int64_t)r * SLAB_J] = 0.0;
+        for (int r = r0; r < min(r0 + TROWS, rend); ++r) dst[(int64_t)r * SLAB_J] = 0.0;
       }
     }
   }
@@ -549,6 +577,11 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(4
 
 }  // namespace
 
+int tile_rows() {
+  const int r = options().tile_rows;
+  return r == 4 ? 4 : r == 1 ? 1 : 2;
+}
+
 bool spgemm_tile_fits(int max_kn, int max_w) {
   const int k4 = (max_kn + 3) & ~3, tm = (max_w + 15) >> 4;
   return max_kn > 0 && max_w > 0 && tile_lds_bytes(k4, tm) <= 150 * 1024;
@@ -562,11 +595,12 @@ void launch_spgemm_tile(const TileLaunch& L) {
   a.otoff = L.otoff; a.alpha = L.alpha; a.threshold = L.threshold; a.dense_rule = L.dense_rule; a.ncols = L.ncols;
   a.nblocks = L.nblocks;
   a.k4max = (L.max_kn + 3) & ~3;
-  a.tmax = (L.max_w + 15) >> 4;
+  const int trows = 16 * (L.rows == 4 ? 4 : L.rows == 2 ? 2 : 1);
+  a.tmax = (L.max_w + trows - 1) / trows;
   a.fz = static_cast<const SlabFuseArgs*>(L.fz);
   static DevBuf<double>* zeros = nullptr;   // (never freed: lives as long as the library)
   if (!zeros) {
-    zeros = new DevBuf<double>(2);
+    zeros = new DevBuf<double>(8);
     zeros->zero();
   }
   a.zero = zeros->p;
@@ -577,23 +611,28 @@ void launch_spgemm_tile(const TileLaunch& L) {
   a.stamps = stamps->p;
 #endif
   const size_t lds = tile_lds_bytes(a.k4max, a.tmax);
-  static size_t raised[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-  // waves per workgroup: eight when the LDS tile allows at most two workgroups per CU (the k range of a purification
-  // iterate: ~50 KB), four when three or more fit
+  // waves per workgroup: eight when the LDS tile allows at most two workgroups per CU, four when three or more fit
+  // (option tile_waves overrides)
   const bool wide = 3 * lds > 160 * 1024;
-  auto go = [&](auto epi_tag, auto nw_tag) {
-    constexpr int E = decltype(epi_tag)::value, NW = decltype(nw_tag)::value;
-    if (lds > 64 * 1024 && lds > raised[E][NW / 8]) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile<E, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  const int nw = options().tile_waves == 4 || options().tile_waves == 8 ? options().tile_waves : (wide ? 8 : 4);
+  auto go = [&](auto epi_tag, auto nw_tag, auto r_tag) {
+    constexpr int E = decltype(epi_tag)::value, NW = decltype(nw_tag)::value, RR = decltype(r_tag)::value;
+    static size_t raised = 0;   // (one per instantiation)
+    if (lds > 64 * 1024 && lds > raised) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile<E, NW, RR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     150 * 1024));
-      raised[E][NW / 8] = 150 * 1024;
+      raised = 150 * 1024;
     }
-    hipLaunchKernelGGL((k_spgemm_tile<E, NW>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
+    hipLaunchKernelGGL((k_spgemm_tile<E, NW, RR>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
+  };
+  auto by_r = [&](auto epi_tag, auto nw_tag) {
+    if (L.rows == 4) go(epi_tag, nw_tag, std::integral_constant<int, 4>{});
+    else if (L.rows == 2) go(epi_tag, nw_tag, std::integral_constant<int, 2>{});
+    else go(epi_tag, nw_tag, std::integral_constant<int, 1>{});
   };
   auto by_nw = [&](auto epi_tag) {
-    const int nw = options().spgemm_variant == 604 ? 4 : options().spgemm_variant == 608 ? 8 : (wide ? 8 : 4);
-    if (nw == 8) go(epi_tag, std::integral_constant<int, 8>{});
-    else go(epi_tag, std::integral_constant<int, 4>{});
+    if (nw == 8) by_r(epi_tag, std::integral_constant<int, 8>{});
+    else by_r(epi_tag, std::integral_constant<int, 4>{});
   };
   if (L.epi == 0) by_nw(std::integral_constant<int, 0>{});
   else if (L.epi == 1) by_nw(std::integral_constant<int, 1>{});

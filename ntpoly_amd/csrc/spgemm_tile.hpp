@@ -27,10 +27,17 @@ struct TileLaunch {
   int dense_rule = 0, ncols = 0, nblocks = 0;
   int max_kn = 0, max_w = 0;         // largest k range / row window of any block (sizes the workgroup's LDS)
   int epi = 0;
+  int rows = 1;                      // R = 1, 2 or 4 consecutive rows per lane of the A operand (tiles of 16 R rows).  R > 1 needs
+                                     // (1) blk_lo and blk_w multiples of 16 R and (2) every expanded column of A (and of X, D in the
+                                     // fused epilogues) readable and ZERO from the multiple of R below its first row to the one
+                                     // above its last (tile_expand_align(): the expansions and this kernel's own results are)
   const void* fz = nullptr;          // device copy of SlabFuseArgs (EPI != 0)
 };
 // false: the geometry does not fit (k range beyond the LDS tile); nothing was launched
 bool spgemm_tile_fits(int max_kn, int max_w);
+// rows per lane the engine uses (option tile_rows: 1, 2 or 4) and the alignment it implies for windows and expanded columns
+int tile_rows();
+inline int tile_expand_align() { return 16 * tile_rows(); }
 void launch_spgemm_tile(const TileLaunch& a);
 
 }  // namespace ntp

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--variants", type=str, default="400,351")
     ap.add_argument("--fma", type=int, default=0)
+    ap.add_argument("--rows", type=int, default=2)
+    ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--complex", type=int, default=0, help="Hermitian complex operand (BASELINE configs[4] family)")
     ap.add_argument("--permute", type=int, default=None, metavar="SEED", help="operand under a seeded random relabelling")
     args = ap.parse_args()
@@ -31,6 +33,8 @@ def main():
     nt.ConstructGlobalProcessGrid(1, 1, 1)
     nt.set_option("time_kernels", 1)
     nt.set_option("spgemm_fma", args.fma)
+    nt.set_option("tile_rows", args.rows)
+    nt.set_option("tile_waves", args.waves)
     n, h, thr = args.n, args.halfband, args.threshold
     if args.permute is None:
         col, row, val = banded_triplets(n, h, complex_=bool(args.complex))

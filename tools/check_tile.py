@@ -45,12 +45,16 @@ def main():
     ap.add_argument("--threshold", type=float, default=1e-8)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=2)
+    ap.add_argument("--waves", type=int, default=0)
     args = ap.parse_args()
     import ntpoly_amd as nt
     from bench import trs2_step
     nt.init_comm()
     nt.ConstructGlobalProcessGrid(1, 1, 1)
     nt.set_option("time_kernels", 1)
+    nt.set_option("tile_rows", args.rows)
+    nt.set_option("tile_waves", args.waves)
     n, h, thr = args.n, args.halfband, args.threshold
     ok = True
     # ---- single products on an iterate
