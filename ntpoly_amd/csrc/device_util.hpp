@@ -24,6 +24,10 @@ struct Sc<double> {
   __device__ static inline double zero() { return 0.0; }
   __device__ static inline double mul(double a, double b) { return __dmul_rn(a, b); }
   __device__ static inline double add(double a, double b) { return __dadd_rn(a, b); }
+  // acc + a * b: two roundings (the reference's default build) or one (option spgemm_fma: its FP-contracted build)
+  __device__ static inline double fmadd(double a, double b, double acc, bool fma) {
+    return fma ? __fma_rn(a, b, acc) : __dadd_rn(acc, __dmul_rn(a, b));
+  }
   __device__ static inline double scale(double s, double v) { return __dmul_rn(s, v); }
   __device__ static inline double mag(double v) { return fabs(v); }
   __device__ static inline double conj(double v) { return v; }
@@ -42,6 +46,7 @@ struct Sc<double2> {
   __device__ static inline double2 add(double2 a, double2 b) {
     return make_double2(__dadd_rn(a.x, b.x), __dadd_rn(a.y, b.y));
   }
+  __device__ static inline double2 fmadd(double2 a, double2 b, double2 acc, bool) { return add(acc, mul(a, b)); }   // (complex: always unfused)
   __device__ static inline double2 scale(double s, double2 v) {
     return make_double2(__dmul_rn(s, v.x), __dmul_rn(s, v.y));
   }

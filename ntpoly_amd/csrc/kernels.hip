@@ -359,6 +359,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_spgemm_window(
   if (j >= B.cols) return;
   if (bin_arr[j] != my_bin) return;
   T* acc = acc_all + wave * W;
+  const bool fma = (dense_rule & 2) != 0;   // (option spgemm_fma: one rounding per product)
   const int span = span_arr[j], lo = lo_arr[j];
   for (int s = lane; s < span; s += WAVE) acc[s] = Sc<T>::zero();
 
@@ -389,10 +390,8 @@ __global__ __launch_bounds__(NW* WAVE) void k_spgemm_window(
         const T a0 = Av[as + q];
         const int i1 = v1 ? Ai[as + q1] : lo;
         const T a1 = v1 ? Av[as + q1] : Sc<T>::zero();
-        const T p0v = Sc<T>::mul(a0, bk);
-        const T p1v = Sc<T>::mul(a1, bk);
-        acc[i0 - lo] = Sc<T>::add(acc[i0 - lo], p0v);
-        if (v1) acc[i1 - lo] = Sc<T>::add(acc[i1 - lo], p1v);
+        acc[i0 - lo] = Sc<T>::fmadd(a0, bk, acc[i0 - lo], fma);
+        if (v1) acc[i1 - lo] = Sc<T>::fmadd(a1, bk, acc[i1 - lo], fma);
       }
       // the next k may hit the same rows: keep this wave's LDS traffic in program order
       __builtin_amdgcn_wave_barrier();
@@ -405,7 +404,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_spgemm_window(
     const int s = s0 + lane;
     const T v = (s < span) ? acc[s] : Sc<T>::zero();
     const T sv = Sc<T>::scale(alpha, v);
-    const bool keep = (s < span) && (dense_rule ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
+    const bool keep = (s < span) && ((dense_rule & 1) ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
     const unsigned long long m = __ballot(keep);
     if (keep) {
       const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
@@ -614,7 +613,7 @@ __global__ __launch_bounds__(NW* WAVE) void k_spgemm_pair3(
       const int s = s0 + lane;
       const double v = (s < span) ? acc[s] : 0.0;
       const double sv = __dmul_rn(alpha, v);
-      const bool keep = (s < span) && (dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold));
+      const bool keep = (s < span) && ((dense_rule & 1) ? (fabs(v) > threshold) : (fabs(sv) > threshold));
       const unsigned long long m = __ballot(keep);
       if (keep) {
         const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
@@ -1048,7 +1047,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int s = 0; s < SL; ++s) {
           const double v = acc[s][jj];
           const double sv = __dmul_rn(alpha, v);
-          const bool ha = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+          const bool ha = (dense_rule & 1) ? (fabs(v) > threshold) : (fabs(sv) > threshold);
           const unsigned long long m = __ballot(ha);
           pn += __popcll(m);
           const int last = m ? lo + WAVE * (wave + NW * s) + 63 - __clzll((long long)m) : -1;
@@ -1105,7 +1104,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
         double v = acc[s][jj];
         asm volatile("" : "+v"(v));   // (recomputed, not 48 lane masks carried over from the first pass)
         const double sv = __dmul_rn(alpha, v);
-        const bool ha = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+        const bool ha = (dense_rule & 1) ? (fabs(v) > threshold) : (fabs(sv) > threshold);
         bool keep;
         double o;
         if constexpr (EPI == 1) {
@@ -1229,7 +1228,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     for (int jj = 0; jj < J; ++jj) {
       const double v = acc[s][jj];
       const double sv = __dmul_rn(alpha, v);
-      const bool keep = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+      const bool keep = (dense_rule & 1) ? (fabs(v) > threshold) : (fabs(sv) > threshold);
       const unsigned long long m = __ballot(keep);
       if (lane == 0) cnt_s[wave + NW * s][jj] = __popcll(m);
     }
@@ -1254,7 +1253,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
     for (int jj = 0; jj < J; ++jj) {
       const double v = acc[s][jj];
       const double sv = __dmul_rn(alpha, v);
-      const bool keep = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+      const bool keep = (dense_rule & 1) ? (fabs(v) > threshold) : (fabs(sv) > threshold);
       const unsigned long long m = __ballot(keep);
       if (keep) {
         const int64_t pos = tbase + (int64_t)jj * w + cnt_s[wave + NW * s][jj] + __popcll(m & lanemask_lt());
@@ -1325,7 +1324,7 @@ void k_spgemm_slab_n(const SlabRun* __restrict__ runs, const double* __restrict_
     for (int jj = 0; jj < J; ++jj) {
       const double v = acc[s][jj];
       const double sv = __dmul_rn(alpha, v);
-      const bool keep = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+      const bool keep = (dense_rule & 1) ? (fabs(v) > threshold) : (fabs(sv) > threshold);
       const unsigned long long m = __ballot(keep);
       if (lane == 0) cnt_s[wave + NW * s][jj] = __popcll(m);
     }
@@ -1350,7 +1349,7 @@ void k_spgemm_slab_n(const SlabRun* __restrict__ runs, const double* __restrict_
     for (int jj = 0; jj < J; ++jj) {
       const double v = acc[s][jj];
       const double sv = __dmul_rn(alpha, v);
-      const bool keep = dense_rule ? (fabs(v) > threshold) : (fabs(sv) > threshold);
+      const bool keep = (dense_rule & 1) ? (fabs(v) > threshold) : (fabs(sv) > threshold);
       const unsigned long long m = __ballot(keep);
       if (keep) {
         const int64_t pos = tbase + (int64_t)jj * w + cnt_s[wave + NW * s][jj] + __popcll(m & lanemask_lt());
@@ -1406,7 +1405,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(5, 5))
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) {
       const T v = acc[s][jj];
-      const bool keep = Sc<T>::mag(dense_rule ? v : Sc<T>::scale(alpha, v)) > threshold;
+      const bool keep = Sc<T>::mag((dense_rule & 1) ? v : Sc<T>::scale(alpha, v)) > threshold;
       const unsigned long long m = __ballot(keep);
       keepbits |= keep ? (1u << (s * J + jj)) : 0u;
       if (lane == 0) cnt_s[wave + NW * s][jj] = __popcll(m);
@@ -1519,7 +1518,7 @@ __global__ __launch_bounds__(WAVE) void k_spgemm_hash(
               if (old == i) break;
               h = (h + 1) & (SLOTS - 1);
             }
-            vals[h] = Sc<T>::add(vals[h], Sc<T>::mul(ca[c], bk));
+            vals[h] = Sc<T>::fmadd(ca[c], bk, vals[h], (dense_rule & 2) != 0);
           }
           filled += __popcll(__ballot(fresh));
           __builtin_amdgcn_wave_barrier();
@@ -1591,7 +1590,7 @@ __global__ __launch_bounds__(WAVE) void k_spgemm_hash(
     const int row = in ? keys[s] : 0;
     const T v = in ? vals[s] : Sc<T>::zero();
     const T sv = Sc<T>::scale(alpha, v);
-    const bool keep = in && (dense_rule ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
+    const bool keep = in && ((dense_rule & 1) ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
     const unsigned long long mk = __ballot(keep);
     if (keep) {
       const int64_t pos = base + cnt + __popcll(mk & lanemask_lt());
@@ -1639,10 +1638,9 @@ __global__ __launch_bounds__(WAVE) void k_spgemm_hbm(
           __hip_atomic_store(slot, __dadd_rn(ox, pr.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(slot + 1, __dadd_rn(oy, pr.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-          const double pr = __dmul_rn(Av[as + q], bk);
           double* slot = acc + (size_t)i;
           const double o = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(slot, __dadd_rn(o, pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot, Sc<double>::fmadd(Av[as + q], bk, o, (dense_rule & 2) != 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       // all of this step's stores must have reached L2 before the next step reads them
@@ -1668,7 +1666,7 @@ __global__ __launch_bounds__(WAVE) void k_spgemm_hbm(
         }
       }
       const T sv = Sc<T>::scale(alpha, v);
-      const bool keep = in && (dense_rule ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
+      const bool keep = in && ((dense_rule & 1) ? (Sc<T>::mag(v) > threshold) : (Sc<T>::mag(sv) > threshold));
       const unsigned long long m = __ballot(keep);
       if (keep) {
         const int64_t pos = base + cnt + __popcll(m & lanemask_lt());
@@ -2555,6 +2553,9 @@ EngineOptions& options() {
   static EngineOptions* o = [] {
     auto* e = new EngineOptions();
     if (const char* v = std::getenv("NTPOLY_AMD_HALO_OVERLAP")) e->halo_overlap = std::atoi(v);  // see kernels.hpp
+    if (const char* v = std::getenv("NTPOLY_AMD_SPGEMM_FMA")) e->spgemm_fma = std::atoi(v);
+    if (const char* v = std::getenv("NTPOLY_AMD_TILE_ROWS")) e->tile_rows = std::atoi(v);
+    if (const char* v = std::getenv("NTPOLY_AMD_TILE_WAVES")) e->tile_waves = std::atoi(v);
     return e;
   }();
   return *o;
@@ -2962,7 +2963,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<double> tmp_val;
   static int grouped_first_n[2] = {-1, -1};
   bool grouped_done = false;
-  const int dr = dense_rule ? 1 : 0;
+  // (bit 0: the dense branch's order of threshold and alpha; bit 1: FMA accumulation, option spgemm_fma, real operands)
+  const int dr = (dense_rule ? 1 : 0) | ((options().spgemm_fma && !A.cplx) ? 2 : 0);
   if (!loose_in && grouped_first_n[A.cplx ? 1 : 0] == n && sv_opt < 0 && options().spgemm_force_bin <= 0 && m == A.cols && (int64_t)n * 1536 < (1ll << 33)) {
     constexpr int64_t kSlot = 1536;   // rows of the largest table class: no column of a finished group holds more
     tmp_total = (int64_t)n * kSlot;
@@ -3039,7 +3041,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     const int64_t max_w = (int64_t)hstats[16], max_kn = (int64_t)hstats[17];
     // (the multiplier tile of a block is staged in LDS by the expansion kernel: up to 128 KB, requested explicitly)
     const bool fits = max_w > 0 && max_w <= slab_rows && ((max_kn + 1) | 1) * SJ * (int64_t)esz <= 128 * 1024;
-    const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
+    // (aligned slots, tile_expand: up to two alignment units of zero padding per column are not holes)
+    const double pad_allow = tile_expand ? 2.0 * (double)tile_expand_align() * (double)nka : 0.0;
+    const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz + pad_allow && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
                             (double)slab_tot[0] >= 48.0 * (double)hstats[18];  // mean run of the non-empty columns >= 48 rows
     use_slab = fits && (dense_runs || sv_opt / 100 == 4);
   }
@@ -3319,7 +3323,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     if (variant / 100 == 4 || variant / 100 == 5 || variant / 100 == 6) variant = -1;  // slab / grouped kernel requested but not applicable
     if constexpr (!Sc<T>::cplx) {
       // real operands that are not run-like: column-pair kernel, register-set depth from the mean column length of A
-      if (variant < 0 && A.nnz < 500000000LL && B.nnz < 2000000000LL) {
+      // (its accumulate is an LDS atomic add of the rounded product: no FMA form -- under option spgemm_fma the window
+      // kernels below take these columns)
+      if (variant < 0 && !options().spgemm_fma && A.nnz < 500000000LL && B.nnz < 2000000000LL) {
         const double avg = (double)A.nnz / (double)std::max(1, nka);
         const int need = (int)std::ceil(avg / 64.0);
         variant = 300 + 10 * std::min(6, std::max(2, need)) + 1;

@@ -639,7 +639,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
               if (__ballot(!Sc<T>::is_zero(xv)) != 0ull || (ablate & 3) == 2) {
                 xbuf[set][kb + half][c0 + lane] = Sc<T>::zero();
 #pragma unroll
-                for (int g = 0; g < G; ++g) acc[s][g] = Sc<T>::add(acc[s][g], Sc<T>::mul(xv, half ? b1[g] : b0[g]));
+                for (int g = 0; g < G; ++g) acc[s][g] = Sc<T>::fmadd(xv, half ? b1[g] : b0[g], acc[s][g], (dense_rule & 2) != 0);
               }
             }
           }
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const T v = acc[s][g];
-        if (Sc<T>::mag(dense_rule ? v : Sc<T>::scale(alpha, v)) > threshold) {
+        if (Sc<T>::mag((dense_rule & 1) ? v : Sc<T>::scale(alpha, v)) > threshold) {
           keepbits |= 1ull << (s * G + g);
           atomicOr(&bm[g * NWORD + (myrank[s] >> 6)], 1ull << (myrank[s] & 63));
         }

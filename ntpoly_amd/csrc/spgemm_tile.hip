@@ -150,7 +150,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
   // flight while the records are built), run records + row range of every k group (one thread per group), then the k
   // groups that can reach a tile are found by the wave that takes the tile (a ballot over the groups' row ranges)
   if (kn > 0 && w > 0 && tbase >= 0) STAMP(56);
-  constexpr int NT = TILE_NW * WAVE, BCH = 6;
+  constexpr int NT = TILE_NW * WAVE, BCH = 3072 / NT;   // (in flight together: the tile of a k range of 384, 48 KB)
   const double2* __restrict__ bsrc = reinterpret_cast<const double2*>(a.bblk + a.blk_boff[b]);
   double2* bdst = reinterpret_cast<double2*>(Bs);
   double2 btmp[BCH];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
     }
   }
   const double alpha = a.alpha, thr = a.threshold;
-  const bool dense_rule = a.dense_rule != 0;
+  const bool dense_rule = (a.dense_rule & 1) != 0;
   double dsum = 0.0, tsum = 0.0;
   int pn = 0;
   const int rend = lo + w;

@@ -146,8 +146,20 @@ void omat_conjugate(omat *m) {
 }
 
 /* ------------------------------------------------------------ generic kernels */
+/* Arithmetic of the real multiply kernel: 0 = separate multiply and add (the reference's default x86-64 build),
+ * 1 = one rounding per product, fma(a, b, acc) (the reference built with FP contraction, build_ref.py --fma). */
+static int oracle_fma_mode = 0;
+void oracle_set_fma(int on) { oracle_fma_mode = on ? 1 : 0; }
+int oracle_get_fma(void) { return oracle_fma_mode; }
+static inline double muladd_r(double a, double b, double acc) {
+  if (oracle_fma_mode) return fma(a, b, acc);
+  const double prod = a * b;
+  return acc + prod;
+}
+
 #define T double
 #define FN(name) name##_r
+#define MULADD_T(a, b, acc) muladd_r((a), (b), (acc))
 #define ABS_T(x) fabs(x)
 #define CONJ_T(x) (x)
 #define REAL_T(x) (x)
@@ -155,6 +167,7 @@ void omat_conjugate(omat *m) {
 #include "ntpoly_oracle_kernels.inc"
 #undef T
 #undef FN
+#undef MULADD_T
 #undef ABS_T
 #undef CONJ_T
 #undef REAL_T
@@ -162,6 +175,7 @@ void omat_conjugate(omat *m) {
 
 #define T double _Complex
 #define FN(name) name##_c
+#define MULADD_T(a, b, acc) ((acc) + (a) * (b))
 #define ABS_T(x) cabs(x)
 #define CONJ_T(x) conj(x)
 #define REAL_T(x) creal(x)
@@ -169,6 +183,7 @@ void omat_conjugate(omat *m) {
 #include "ntpoly_oracle_kernels.inc"
 #undef T
 #undef FN
+#undef MULADD_T
 #undef ABS_T
 #undef CONJ_T
 #undef REAL_T

@@ -107,6 +107,9 @@ void omonitor_append(omonitor *m, double v);
 int omonitor_converged(const omonitor *m);
 
 int oracle_num_threads(void);
+/* arithmetic of the real multiply kernel: 1 = fma(a, b, acc), the reference built with FP contraction; 0 (default) unfused */
+void oracle_set_fma(int on);
+int oracle_get_fma(void);
 
 #ifdef __cplusplus
 }

@@ -95,8 +95,21 @@ def lib():
         L.omonitor_append.argtypes = [C.POINTER(OMonitor), C.c_double]
         L.omonitor_converged.argtypes = [C.POINTER(OMonitor)]
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_fma.argtypes = [C.c_int]
+        L.oracle_get_fma.restype = C.c_int
         _LIB = L
     return _LIB
+
+
+def set_fma(on):
+    """arithmetic of the real multiply kernel: True = fma(a, b, acc), what the reference computes when built with FP
+    contraction (oracle/build_ref.py --fma; pinned by tests/golden/ps_gemm_fma.npz); False (default) = separate multiply
+    and add, its default build"""
+    lib().oracle_set_fma(1 if on else 0)
+
+
+def get_fma():
+    return bool(lib().oracle_get_fma())
 
 
 class Mat:

@@ -28,6 +28,21 @@ def nt():
     return nt
 
 
+@pytest.fixture(params=["unfused", "fma"])
+def arith(request, nt):
+    """both arithmetic modes of the engine against the SAME reference numbers: "unfused" is the
+    reference's default build bit for bit in every product; "fma" (option spgemm_fma = 1: the FMA chain of its
+    FP-contracted build, on the FP64 matrix cores for run-like operands) must meet the tolerance contract -- the same
+    iteration counts as the reference's logs, energies to 1e-11, result scalars as stated below"""
+    from oracle import oracle_py as O
+    if request.param == "fma":
+        nt.set_option("spgemm_fma", 1)
+        O.set_fma(True)
+    yield request.param
+    nt.set_option("spgemm_fma", 0)
+    O.set_fma(False)
+
+
 def _fixed_iteration_params(nt, iters, thr=1e-8):
     p = nt.SolverParameters()
     p.SetConvergeDiff(1e-30)
@@ -47,7 +62,7 @@ BASELINE_ROWS = [
 
 
 @pytest.mark.parametrize("n,h,e2,e8,nnz8", BASELINE_ROWS)
-def test_trs2_baseline_golden_scalars(nt, n, h, e2, e8, nnz8):
+def test_trs2_baseline_golden_scalars(nt, arith, n, h, e2, e8, nnz8):
     col, row, val = banded_triplets(n, h)
     H = nt.Matrix_ps.from_triplets(n, col, row, val)
     ISQ = nt.Matrix_ps(n)
@@ -68,7 +83,7 @@ def _scale_cases():
 
 
 @pytest.mark.parametrize("idx,c", _scale_cases(), ids=lambda v: v["tag"] if isinstance(v, dict) else str(v))
-def test_scale_logs_vs_reference(nt, idx, c):
+def test_scale_logs_vs_reference(nt, arith, idx, c):
     g = Golden("scale_logs")
     n, h = c["n"], c["h"]
     col, row, val = banded_triplets(n, h, complex_=c["cplx"], shift=c["shift"])
@@ -151,10 +166,11 @@ def test_config4_sign_of_the_indefinite_operand(nt):
     assert S.GetSize() > 20 * n        # not a diagonal matrix
 
 
-def test_headline_config2_vs_oracle_full_size(nt):
+def test_headline_config2_vs_oracle_full_size(nt, arith):
     """BASELINE configs[2] at FULL size (N = 262 144, 201 entries per row, threshold 1e-8, ISQ = I, trace = N/2): the
     first 8 TRS2 iterations of the engine against the same 8 iterations of the oracle (the C restatement pinned to the
-    reference's goldens) -- sigma and energy of every iteration, and the resulting density entry by entry."""
+    reference's goldens) in the same arithmetic mode -- sigma and energy of every iteration, and the resulting density
+    entry by entry."""
     from oracle import oracle_py as O
     n, h, thr, iters = 262144, 100, 1e-8, 8
     col, row, val = banded_triplets(n, h)

@@ -54,6 +54,28 @@ def test_local_gemm_vs_reference():
     assert n_exact >= 40
 
 
+def test_fma_mode_vs_contracted_reference_build():
+    """The oracle's second arithmetic mode (oracle_py.set_fma: fma(a, b, acc) in the real multiply kernel) against the
+    products of the REAL reference built with FP contraction (oracle/build_ref.py --fma, make_golden.py ps_gemm_fma):
+    bit-exact.  This pins what the engine's FMA arithmetic (option spgemm_fma, the MFMA tile kernel) is compared with
+    in tests/test_gpu_fma.py.  The default mode must NOT reproduce these products."""
+    g = Golden("ps_gemm_fma")
+    assert not O.get_fma()
+    O.set_fma(True)
+    try:
+        for i, c in enumerate(g.cases):
+            A = mat(g.tri(i, "A"))
+            B = A if c["same"] else mat(g.tri(i, "B"))
+            got = O.ps_multiply(A, B, None, c["alpha"], 0.0, c["thr"])
+            assert_bitexact(got.triplets(), g.tri(i, "C"), "fma " + c["tag"])
+    finally:
+        O.set_fma(False)
+    A = mat(g.tri(1, "A"))
+    got = O.ps_multiply(A, A, None, 1.0, 0.0, g.cases[1]["thr"]).triplets()
+    want = g.tri(1, "C")
+    assert not (len(got[2]) == len(want[4]) and np.array_equal(got[2], want[4]))
+
+
 def test_local_increment_vs_reference():
     g = Golden("local_increment")
     for i, c in enumerate(g.cases):
