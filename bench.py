@@ -55,13 +55,13 @@ def trs2_step_unfused(nt, X, X2, WH, pool, trace_target, thr):
     return sigma, float(np.real(X.Dot(WH)))
 
 
-def cpu_baseline(n, h, thr, warmup, steps, permute=None):
-    """the oracle (C restatement with OpenMP, kind "port") at the FULL configuration size on all host cores: TRS2 run
-    twice in one process, with `warmup` and with `warmup + steps` iterations; the difference is `steps` iterations of
-    the same region the GPU line times (setup excluded), as BASELINE.md section 2 measures the reference."""
+def cpu_baseline(n, h, thr, warmup, steps, permute=None, fma=False):
+    """the oracle (C restatement with OpenMP, kind "port") at the FULL configuration size on all host cores, in the
+    arithmetic mode the GPU line ran in: TRS2 with warmup, warmup + 1, warmup + 2 and warmup + 3 iterations in one
+    process; the three differences are three samples of ONE iteration of the region the GPU line times (setup
+    excluded, as BASELINE.md section 2 measures the reference); the value is their median."""
     from oracle import oracle_py as O
     from gen import banded_triplets, permuted_banded_triplets
-    steps = max(3, min(steps, 3))
     if permute is None:
         col, row, val = banded_triplets(n, h)
     else:
@@ -69,6 +69,7 @@ def cpu_baseline(n, h, thr, warmup, steps, permute=None):
     H = O.Mat.from_triplets(n, n, col, row, val)
     del col, row, val
     I = O.Mat.identity(n)
+    O.set_fma(fma)
 
     def run(iters):
         p = O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr, monitor_convergence=False)
@@ -76,15 +77,19 @@ def cpu_baseline(n, h, thr, warmup, steps, permute=None):
         O.density("trs2", H, I, n / 2.0, p)
         return time.perf_counter() - t0
 
-    t_w = run(warmup) if warmup > 0 else 0.0
-    t_all = run(warmup + steps)
-    per_iter = max(1e-9, (t_all - t_w) / steps)
+    try:
+        ts = [run(warmup + k) for k in range(4)]
+    finally:
+        O.set_fma(False)
+    samples = sorted(max(1e-9, ts[k + 1] - ts[k]) for k in range(3))
+    per_iter = samples[1]
     return {"value": 1.0 / per_iter, "unit": "iters/s", "cores": int(O.lib().oracle_num_threads()),
             "kind": "port",
-            "sample": "oracle TRS2 (OpenMP, all host cores) at the full size N=%d (h=%d, thr=%g%s): iterations %d..%d, "
-                      "(t(%d iterations) - t(%d iterations)) / %d = %.3f s/iter; no scaling" % (
-                          n, h, thr, "" if permute is None else ", relabelled with seed %d" % permute, warmup + 1,
-                          warmup + steps, warmup + steps, warmup, steps, per_iter)}
+            "sample": "oracle TRS2 (OpenMP, all host cores, %s arithmetic) at the full size N=%d (h=%d, thr=%g%s): iterations "
+                      "%d..%d, three single-iteration samples t(k + 1 iterations) - t(k iterations) = %s s, median %.3f s/iter; "
+                      "no scaling" % ("fma" if fma else "unfused", n, h, thr,
+                                      "" if permute is None else ", relabelled with seed %d" % permute, warmup + 1,
+                                      warmup + 3, "/".join("%.3f" % x for x in samples), per_iter)}
 
 
 def trs2_wrp_check(nt, H, n, thr, n1=5, n2=25):
@@ -116,7 +121,7 @@ def sources_sha16():
     """fingerprint of the kernel sources a committed PMC traffic figure belongs to"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "slab_loop.inc", "spgemm_grouped.hip"):
+    for f in ("kernels.hip", "slab_loop.inc", "spgemm_grouped.hip", "spgemm_tile.hip"):
         with open(os.path.join(ROOT, "ntpoly_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -227,11 +232,13 @@ def main():
         # the corrected bytes per launch together with a fingerprint of the kernel sources it was measured on -- a
         # figure measured on other sources is not reported (null)
         traffic, traffic_src = None, None
-        tname = "r02_pmc_traffic.json" if args.permute is None else "r02_pmc_traffic_permute.json"
+        tname = ("r03_pmc_traffic%s.json" if args.arithmetic == "fma" else "r03_pmc_traffic_unfused%s.json") % (
+            "" if args.permute is None else "_permute")
         try:
             with open(os.path.join(ROOT, "profiles", tname)) as f:
                 tj = json.load(f)
-            if (n, h, thr, world) == (262144, 100, 1e-8, 1) and tj.get("sources_sha16") == sources_sha16():
+            if (n, h, thr, world) == (262144, 100, 1e-8, 1) and tj.get("sources_sha16") == sources_sha16() and \
+                    args.tile_rows is None and args.tile_waves is None:
                 traffic, traffic_src = float(tj["hbm_bytes_per_launch"]), "profiles/" + tname
         except Exception:
             traffic = None
@@ -260,6 +267,11 @@ def main():
                                        n, h, 2 * h + 1,
                                        "" if args.permute is None else " under a random symmetric relabelling (seed %d)" % args.permute,
                                        thr, args.warmup + 1, args.warmup + args.steps),
+                       "arithmetic": ("fma: every product entry is the chain of fma() over ascending k (one rounding per product), "
+                                      "the reference's FP-contracted build bit for bit (tests/golden/ps_gemm_fma.npz); run-like "
+                                      "operands on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, spgemm_tile.hip)"
+                                      if args.arithmetic == "fma" else
+                                      "unfused: separate v_mul_f64 + v_add_f64, the reference's default x86-64 build bit for bit"),
                        "n": n, "halfband": h, "threshold": thr, "nnz_H": int(nnz_h), "nnz_X_end": int(nnz_x),
                        "nnz_product_last": int(st.get("nnz_c", -1)), "energy_end": energy,
                        "permute_seed": args.permute,
@@ -270,7 +282,7 @@ def main():
             "spgemm_ms_per_call": ms_spgemm / calls,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("k_spgemm_slab" if st.get("slab") else "k_spgemm_ghash (grouped LDS hash)" if gs.get("used")
+                         "kernel": (("k_spgemm_tile" if args.arithmetic == "fma" else "k_spgemm_slab") if st.get("slab") else "k_spgemm_ghash (grouped LDS hash)" if gs.get("used")
                                     else "k_spgemm_pair3 / k_spgemm_hash") +
                                    (" (SpGEMM numeric phase with the TRS2 update, energy and trace in its epilogue)"
                                     if fused["square"] + fused["update"] > 0 else " (SpGEMM numeric phase)"),
@@ -280,11 +292,16 @@ def main():
                                  "per launch from the committed PMC passes of this command (null when the kernel sources "
                                  "have changed since)"},
         }
-        # the numeric kernel is FP64-ALU side bound: 2 flops per product against the vector peak for SEPARATE multiply and
-        # add instructions (78.6 TFLOP/s counts an FMA as 2 flops per instruction -> 39.3 for unfused mul + add)
+        # compute-side view: 2 flops per product against the FP64 peak of the arithmetic mode -- 78.6 TFLOP/s for fused
+        # multiply-adds (vector FMA and the f64 matrix instruction have the same rate on gfx950), 39.3 for SEPARATE
+        # multiply and add instructions
         tfl = 2.0 * acc["products"] / (ms_numeric * 1e-3) / 1e12
-        line["roofline_compute"] = {"bound": "fp64 vector ALU (unfused mul+add)", "achieved": tfl, "peak": 39.3,
-                                    "unit": "TFLOP/s", "frac": tfl / 39.3}
+        if args.arithmetic == "fma":
+            line["roofline_compute"] = {"bound": "fp64 matrix cores (v_mfma_f64_16x16x4_f64, one FMA per product)", "achieved": tfl,
+                                        "peak": 78.6, "unit": "TFLOP/s", "frac": tfl / 78.6}
+        else:
+            line["roofline_compute"] = {"bound": "fp64 vector ALU (unfused mul+add)", "achieved": tfl, "peak": 39.3,
+                                        "unit": "TFLOP/s", "frac": tfl / 39.3}
         # timed steps computed inside the SpGEMM kernel (X*X; 2X - X*X) and fused steps that had to be repeated unfused
         line["fused_steps"] = fused
         if gs.get("used"):
@@ -297,7 +314,7 @@ def main():
         if check:
             line["trs2_wrp_check"] = check
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, h, thr, args.warmup, args.steps, args.permute)
+            line["cpu_baseline"] = cpu_baseline(n, h, thr, args.warmup, args.steps, args.permute, fma=args.arithmetic == "fma")
         print(json.dumps(line), flush=True)
     if world > 1:
         nt.barrier()

@@ -367,6 +367,24 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
     }
     ++sidx; STAMP(sidx); ++sidx;
     // ---- epilogue of the tile: lane holds rows r0 + R (4 v + q) + m (v = 0..3, m = 0..R-1) of column jj
+    {  // tiles in which nothing can be kept (about half of a window: the products beyond the band that survives the
+       // threshold, no entry of X) are done here: nothing to merge, count or store
+      bool live = false;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          const double vv = acc[m][v];
+          live |= dense_rule ? (fabs(vv) > thr) : (fabs(__dmul_rn(alpha, vv)) > thr);
+          if constexpr (EPI == 2) live |= rv_get<R>(xv[v], m) != 0.0;
+        }
+      }
+      if (__ballot(live) == 0ull) {
+        if (lane == 0) colmask[t] = 0u;
+        STAMP(sidx); ++sidx;
+        continue;
+      }
+    }
     VR res[4];
     unsigned long long anykeep = 0;
     int c_l = 0, f_l = INT_MAX, l_l = -1, pm_l = -1, pl_l = -1;
