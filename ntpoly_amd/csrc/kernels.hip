@@ -3660,13 +3660,12 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   if ((options().spgemm_variant >= 0 && !(tile && options().spgemm_variant / 100 == 6)) || (options().spgemm_fma && !tile) || options().spgemm_force_bin > 0 || !options().fused_update)
     return false;
   const SlabForm& in = *X.slab;
-  if (tile && in.labelled()) return false;
   // rows per lane of the tile kernel: what the option asks for, if the runs of X (and of D) are padded for it; the runs
   // of a halo sit packed in the receive buffer: one row per lane there
   int trows = 1;
   if (tile && !halo) {
     trows = tile_rows();
-    while (trows > 1 && (in.row_pad % (16 * trows) != 0)) trows >>= 1;
+    while (trows > 1 && in.row_pad % trows != 0) trows >>= 1;   // (row groups start at multiples of R: the pads must cover them)
   }
   const int n = X.cols, snb = cdiv(n, SLAB_J);
   const DotOperand& dop = dot_operand(*fu.D);
@@ -3736,7 +3735,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   fz.col_offset = fu.col_offset;
   int64_t* blk_prod = zwords.p + 3 + snb;
   // label-ordered steps (SlabForm::lab): the block's records and tile rows sorted by label
-  const bool labelled = in.labelled() && !halo;
+  const bool labelled = in.labelled() && !halo && !tile;   // (the tile kernel walks the k steps in position order: no sorted records)
   if (in.labelled() && halo) return give_up();
   DevBuf<double> tiles_ord;
   DevBuf<char> blkruns;
@@ -3759,6 +3758,13 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     fz.lab = in.lab.p;
     fz.blkruns = reinterpret_cast<const SlabRun*>(blkruns.p);
     fz.steps = steps.p;
+    fz.xplast = in.plast.p;
+    fz.oplast = oplast.p;
+  }
+  const bool tile_labelled = tile && in.labelled() && !halo;   // (labels only steer the epilogue's "beyond the last entry" tests)
+  if (tile_labelled) {
+    oplast.alloc((size_t)n);
+    fz.lab = in.lab.p;
     fz.xplast = in.plast.p;
     fz.oplast = oplast.p;
   }
@@ -3791,7 +3797,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = oval.p; tl.count = count.p;
     tl.ofirst = ofirst.p; tl.olast = olast.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
     tl.alpha = 1.0; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
-    tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = fz_args.p; tl.rows = trows;
+    tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = fz_args.p; tl.rows = trows; tl.labelled = tile_labelled;
     launch_spgemm_tile(tl);
     HIP_CHECK(hipMemcpyAsync(tile_ooff.p + n, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
     HIP_CHECK(hipMemcpyAsync(tile_otoff.p + snb, blk_toff.p + snb, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
@@ -3855,7 +3861,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   R.slab->val = std::move(oval);
   R.slab->tiles = std::move(otiles);
   R.slab->slots = tmp_total;
-  if (labelled) {
+  if (labelled || tile_labelled) {
     R.slab->lab = std::move(X.slab->lab);
     R.slab->plast = std::move(oplast);
   }
@@ -3894,7 +3900,9 @@ bool slab_from_csc(DevMat& Xs, DevBuf<int32_t>& lab) {
   DevBuf<unsigned long long> stats(24);
   stats.zero();
   hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(Xs), f->first.p, f->last.p, f->count.p);
-  hipLaunchKernelGGL(k_span_of, dim3(cdiv(n, 256)), dim3(256), 0, stream(), f->first.p, f->last.p, span.p, n);
+  const int al = options().spgemm_fma == 1 ? tile_expand_align() : 1;   // (aligned zero-padded slots for the MFMA tile kernel)
+  if (al > 1) hipLaunchKernelGGL(k_span_aligned, dim3(cdiv(n, 256)), dim3(256), 0, stream(), f->first.p, f->last.p, span.p, n, al);
+  else hipLaunchKernelGGL(k_span_of, dim3(cdiv(n, 256)), dim3(256), 0, stream(), f->first.p, f->last.p, span.p, n);
   scan_async<int32_t>(span.p, f->off.p, (int64_t)n);
   hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, f->first.p, f->last.p,
                      f->first.p, f->last.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
@@ -3912,8 +3920,12 @@ bool slab_from_csc(DevMat& Xs, DevBuf<int32_t>& lab) {
   const int64_t max_w = (int64_t)hst[0], max_kn = (int64_t)hst[1];
   const int pitch = ((int)max_kn + 1) | 1;
   if (max_w <= 0 || max_w > 8 * SLAB_SL * WAVE || (size_t)pitch * SLAB_J * 8 > 128 * 1024) return false;
-  if ((double)tot_val > 2.0 * (double)Xs.nnz) return false;   // (mostly holes: no band was recovered)
+  if ((double)tot_val > 2.0 * (double)Xs.nnz + (al > 1 ? 2.0 * al * (double)n : 0.0)) return false;   // (mostly holes: no band was recovered)
   f->val.alloc((size_t)tot_val + kIndexSlack);
+  if (al > 1)
+    hipLaunchKernelGGL(k_aligned_offsets<double>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), f->first.p, f->last.p,
+                       f->off.p, f->val.p, n, al);
+  f->row_pad = al;
   f->tiles.alloc((size_t)tot_tiles + 16 * SLAB_J + kIndexSlack);
   hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(Xs), f->first.p,
                      f->off.p, f->val.p);

@@ -103,7 +103,7 @@ __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax) {
 #define STAMP(i) do { } while (0)
 #endif
 
-template <int EPI, int TILE_NW, int R>
+template <int EPI, int TILE_NW, int R, bool LAB>
 __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(EPI == 0 ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = xcd_block(a.nblocks);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
         xf = x0;
         xlrow = x1;
         xrz = fz->xexp + (fz->xoff[jc] - x0);
-        xpl = lab ? fz->xplast[jc] : x1;
+        xpl = LAB ? fz->xplast[jc] : x1;
         if (x0 < lo || x1 >= lo + w) atomicOr(fz->flag, 1);   // every stored row of X(:, j) must be a row of this block's window
       }
     }
@@ -298,12 +298,17 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
     }
     // what the epilogue reads, requested before the loop: this lane's elements are rows r0 + R (4 v + q) + m of column jj
     [[maybe_unused]] VR xv[4], dv[4];
+    [[maybe_unused]] int plab[4][R];   // (label-ordered operands: the caller's label of every row of this lane)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int rb = r0 + R * (4 * v + q);
       if constexpr (EPI == 2) xv[v] = rv_load<R>(((rb + R - 1 >= xf) & (rb <= xlrow)) ? xrz + rb : zp);
       if constexpr (EPI != 0) {
         dv[v] = rv_load<R>(((rb + R - 1 >= df) & (rb <= dl)) ? drz + rb : zp);
+        if constexpr (LAB) {
+#pragma unroll
+          for (int m = 0; m < R; ++m) plab[v][m] = lab[min(rb + m, a.ncols - 1)];
+        }
       }
     }
     v4d acc[R];
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
         [[maybe_unused]] int pr = r;
         if constexpr (EPI != 0) {
           dval = rv_get<R>(dv[v], m);
-          pr = r;   // (label-ordered operands are not routed here yet: positions are rows)
+          if constexpr (LAB) pr = plab[v][m];   // ("beyond the other column's last entry" compares the caller's labels)
         }
         if constexpr (EPI != 2) {
           keep = ha;
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
       atomicMin(&col_first[jj], f_l);
       atomicMax(&col_last[jj], l_l);
       if constexpr (EPI != 0) {
-        if (lab) atomicMax(&col_plast[jj], pl_l);
+        if constexpr (LAB) atomicMax(&col_plast[jj], pl_l);
       }
     }
     if constexpr (EPI == 2) {
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
           atomicAdd(&col_cnt[e.jj], 1);
           atomicMin(&col_first[e.jj], e.r);
           atomicMax(&col_last[e.jj], e.r);
-          if (lab) atomicMax(&col_plast[e.jj], e.prow);
+          if constexpr (LAB) atomicMax(&col_plast[e.jj], e.prow);
         }
         e.pad = kept ? 1 : 0;
         dlist[i] = e;
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
       a.olast[jt] = cl;
       a.ooff[jt] = tbase + (int64_t)tid * w + (cl >= cf ? cf - lo : 0);
       if constexpr (EPI != 0) {
-        if (lab) a.fz->oplast[jt] = col_plast[tid];
+        if constexpr (LAB) a.fz->oplast[jt] = col_plast[tid];
       }
     }
   }
@@ -633,20 +638,29 @@ void launch_spgemm_tile(const TileLaunch& L) {
   // (option tile_waves overrides)
   const bool wide = 3 * lds > 160 * 1024;
   const int nw = options().tile_waves == 4 || options().tile_waves == 8 ? options().tile_waves : (wide ? 8 : 4);
-  auto go = [&](auto epi_tag, auto nw_tag, auto r_tag) {
+  auto go = [&](auto epi_tag, auto nw_tag, auto r_tag, auto lab_tag) {
     constexpr int E = decltype(epi_tag)::value, NW = decltype(nw_tag)::value, RR = decltype(r_tag)::value;
+    constexpr bool LB = decltype(lab_tag)::value;
     static size_t raised = 0;   // (one per instantiation)
     if (lds > 64 * 1024 && lds > raised) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile<E, NW, RR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile<E, NW, RR, LB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     150 * 1024));
       raised = 150 * 1024;
     }
-    hipLaunchKernelGGL((k_spgemm_tile<E, NW, RR>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
+    hipLaunchKernelGGL((k_spgemm_tile<E, NW, RR, LB>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
   };
   auto by_r = [&](auto epi_tag, auto nw_tag) {
-    if (L.rows == 4) go(epi_tag, nw_tag, std::integral_constant<int, 4>{});
-    else if (L.rows == 2) go(epi_tag, nw_tag, std::integral_constant<int, 2>{});
-    else go(epi_tag, nw_tag, std::integral_constant<int, 1>{});
+    constexpr int E0 = decltype(epi_tag)::value;
+    if constexpr (E0 != 0) {
+      if (L.labelled) {   // (label-ordered operands: two or one rows per lane)
+        if (L.rows >= 2) go(epi_tag, nw_tag, std::integral_constant<int, 2>{}, std::true_type{});
+        else go(epi_tag, nw_tag, std::integral_constant<int, 1>{}, std::true_type{});
+        return;
+      }
+    }
+    if (L.rows == 4) go(epi_tag, nw_tag, std::integral_constant<int, 4>{}, std::false_type{});
+    else if (L.rows == 2) go(epi_tag, nw_tag, std::integral_constant<int, 2>{}, std::false_type{});
+    else go(epi_tag, nw_tag, std::integral_constant<int, 1>{}, std::false_type{});
   };
   auto by_nw = [&](auto epi_tag) {
     if (nw == 8) by_r(epi_tag, std::integral_constant<int, 8>{});

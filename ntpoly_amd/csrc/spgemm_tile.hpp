@@ -32,6 +32,9 @@ struct TileLaunch {
                                      // fused epilogues) readable and ZERO from the multiple of R below its first row to the one
                                      // above its last (tile_expand_align(): the expansions and this kernel's own results are)
   const void* fz = nullptr;          // device copy of SlabFuseArgs (EPI != 0)
+  bool labelled = false;             // fz carries labels (SlabFuseArgs::lab, xplast, oplast): the epilogue's "beyond the last entry"
+                                     // tests compare the caller's labels.  The k steps are walked in POSITION order (the rounding
+                                     // of a product entry then differs from the label-ordered chain in its last bits: tolerance mode)
 };
 // false: the geometry does not fit (k range beyond the LDS tile); nothing was launched
 bool spgemm_tile_fits(int max_kn, int max_w);

@@ -198,6 +198,46 @@ def test_headline_config2_vs_oracle_full_size(nt, arith):
     assert np.abs(kv - ov).max() <= 1e-13
 
 
+@pytest.mark.parametrize("label_order", [1, 0])
+def test_relabelled_trs2_vs_oracle(nt, arith, label_order):
+    """TRS2 on a randomly relabelled band (seed 42, N = 32 768, h = 100, 8 iterations) against the ORACLE's solve of the
+    same relabelled matrix, in both arithmetic modes: through the recovered band order with label-aware steps
+    (label_order = 1: relabel.hip + the fused slab / tile kernels) and on the relabelled matrix as it stands
+    (label_order = 0: grouped LDS-hash SpGEMM) -- sigma of every iteration, energies 1e-11, the density with the same
+    pattern and values to 1e-13.  (In FMA arithmetic the label-aware tile kernel walks the k steps in position order:
+    a product entry may differ from the oracle's chain over ascending labels in its last bits.)"""
+    from gen import permuted_banded_triplets
+    from oracle import oracle_py as O
+    n, h, thr, iters = 32768, 100, 1e-8, 8
+    col, row, val = permuted_banded_triplets(n, h, 42)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    ISQ = nt.Matrix_ps(n)
+    ISQ.FillIdentity()
+    nt.set_option("label_order", label_order)
+    try:
+        K = nt.Matrix_ps(n)
+        f0 = nt.fusion_counts()
+        energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, _fixed_iteration_params(nt, iters, thr))
+        f1 = nt.fusion_counts()
+        tr = nt.solver_trace()
+    finally:
+        nt.set_option("label_order", 1)
+    fused = f1["square"] + f1["update"] - f0["square"] - f0["update"]
+    assert fused == (iters if label_order else 0), (fused, f1, f0)
+    Ho = O.Mat.from_triplets(n, n, col, row, val)
+    Ko, e_o, mu_o, tro = O.density("trs2", Ho, O.Mat.identity(n), n / 2.0,
+                                   O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr,
+                                            monitor_convergence=False))
+    assert tr["iterations"] == tro["iterations"] == iters
+    assert np.array_equal(np.asarray(tr["sigma"]), np.asarray(tro["sigma"]))
+    assert np.allclose(tr["energy"], tro["energy"], rtol=1e-11, atol=0)
+    kc, kr, kv = K.triplets()
+    oc, orow, ov = Ko.triplets()
+    ko, oo = np.lexsort((kr, kc)), np.lexsort((orow, oc))
+    assert len(kv) == len(ov) and np.array_equal(kc[ko], oc[oo]) and np.array_equal(kr[ko], orow[oo])
+    assert np.abs(kv[ko] - ov[oo]).max() <= 1e-13
+
+
 def test_headline_config2_relabelled_full_size(nt):
     """BASELINE configs[2] under a random symmetric relabelling (N = 262 144, 201 per row) at FULL size: the loop in the
     recovered band order with label-ordered arithmetic (relabel.hip, fused slab kernel) against the same solve on the
