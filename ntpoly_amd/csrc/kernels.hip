@@ -3043,9 +3043,16 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     const bool fits = max_w > 0 && max_w <= slab_rows && ((max_kn + 1) | 1) * SJ * (int64_t)esz <= 128 * 1024;
     // (aligned slots, tile_expand: up to two alignment units of zero padding per column are not holes)
     const double pad_allow = tile_expand ? 2.0 * (double)tile_expand_align() * (double)nka : 0.0;
-    const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz + pad_allow && (double)slab_tot[1] <= 1.5 * (double)B.nnz + 4096.0 &&
+    // (the tile kernel's work follows the runs of A and the k range, not the entries of B: a sparse B inside wide column
+    // extents -- 3 I - X^2 near convergence -- only has to keep its multiplier tiles within twice the size of A)
+    const double btile_allow = tile_expand ? std::max(1.5 * (double)B.nnz + 4096.0, 2.0 * (double)A.nnz) : 1.5 * (double)B.nnz + 4096.0;
+    const bool dense_runs = (double)slab_tot[0] <= 1.5 * (double)A.nnz + pad_allow && (double)slab_tot[1] <= btile_allow &&
                             (double)slab_tot[0] >= 48.0 * (double)hstats[18];  // mean run of the non-empty columns >= 48 rows
     use_slab = fits && (dense_runs || sv_opt / 100 == 4);
+    if (!use_slab && std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
+      std::fprintf(stderr, "spgemm: no slab path: n %d nnzA %lld nnzB %lld max_w %lld max_kn %lld fits %d runsA %lld tilesB %lld nonempty %llu same %d\n", n,
+                   (long long)A.nnz, (long long)B.nnz, (long long)max_w, (long long)max_kn, (int)fits, (long long)slab_tot[0],
+                   (long long)slab_tot[1], hstats[18], (int)(&A == &B));
   }
   if (loose_in && !(use_slab && &A == &B)) {
     if (timing) {

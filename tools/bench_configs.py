@@ -4,8 +4,12 @@ bench.py measures configs[2]).  Prints one JSON object.
 
   configs[1]  local A*A, banded N = 65 536, h = 50 (101 nnz/row), threshold 0 and 1e-8
   configs[3]  the N = 1 048 576, h = 100 operand as ONE A*A on one GPU (the 8-GPU config's whole problem)
-  configs[4]  Hermitian complex N = 131 072, h = 50, H + 2I: SignFunction and InverseSquareRoot
+  configs[4]  Hermitian complex N = 131 072, h = 50: SignFunction of the indefinite H, InverseSquareRoot of H + 2I
+  configs[2] operand under the other solvers of the path: TRS4, real SignFunction / InverseSquareRoot (N = 262 144)
+
+  --arithmetic fma|unfused   option spgemm_fma (real operands; complex ones always run unfused)
 """
+import argparse
 import json
 import os
 import sys
@@ -19,12 +23,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arithmetic", choices=("fma", "unfused"), default="fma")
+    ap.add_argument("--only", default="", help="comma-separated subset: products,config3,solvers,complex")
+    args = ap.parse_args()
+    only = set(x for x in args.only.split(",") if x)
     import ntpoly_amd as nt
     from gen import banded_triplets, permuted_banded_triplets
     nt.init_comm()
     nt.ConstructGlobalProcessGrid(1, 1, 1)
     nt.set_option("time_kernels", 1)
-    out = {}
+    nt.set_option("spgemm_fma", 1 if args.arithmetic == "fma" else 0)
+    out = {"arithmetic": args.arithmetic}
+
+    def want(tag):
+        return not only or tag in only
 
     def product(n, h, thr, reps=5, complex_=False, permute=None):
         if permute is None:
@@ -53,14 +66,17 @@ def main():
                     products=st["products"], nnz_out_per_s=st["nnz_c"] / dt, products_per_s=st["products"] / (st["ms_numeric"] * 1e-3),
                     alg_GBps_kernel=alg / (st["ms_numeric"] * 1e-3) / 1e9, slab=st["slab"])
 
-    out["config1_thr0"] = product(65536, 50, 0.0)
-    out["config1_thr1e-8"] = product(65536, 50, 1e-8)
-    out["config3_one_product_1gpu"] = product(1048576, 100, 1e-8, reps=3)
+    if want("products"):
+        out["config1_thr0"] = product(65536, 50, 0.0)
+        out["config1_thr1e-8"] = product(65536, 50, 1e-8)
+        out["config2_one_product"] = product(262144, 100, 1e-8)
+    if want("config3"):
+        out["config3_one_product_1gpu"] = product(1048576, 100, 1e-8, reps=3)
     # the same operand under the seeded relabelling ("with and without random permutation"): one product on
     # the grouped LDS-hash kernel (a single multiply has no loop to amortise a recovered band order over)
-    out["config3_one_product_1gpu_relabelled"] = product(1048576, 100, 1e-8, reps=3, permute=42)
+        out["config3_one_product_1gpu_relabelled"] = product(1048576, 100, 1e-8, reps=3, permute=42)
     # TRS2 on the configs[3] operand, natural order and relabelled (label-ordered slab steps)
-    for tag, perm in (("config3_trs2_1gpu", None), ("config3_trs2_1gpu_relabelled", 42)):
+    for tag, perm in (("config3_trs2_1gpu", None), ("config3_trs2_1gpu_relabelled", 42)) if want("config3") else ():
         n3, h3 = 1048576, 100
         col, row, val = banded_triplets(n3, h3) if perm is None else permuted_banded_triplets(n3, h3, perm)
         H3 = nt.Matrix_ps.from_triplets(n3, col, row, val)
@@ -86,15 +102,7 @@ def main():
                         nnz_K_24=res[3][2])
         del H3, I3
 
-    n, h, thr = 131072, 50, 1e-8
-    col, row, val = banded_triplets(n, h, complex_=True, shift=2.0)
-    H = nt.Matrix_ps.from_triplets(n, col, row, val)
-    del col, row, val
-    p = nt.SolverParameters()
-    p.SetThreshold(thr)
-    p.SetConvergeDiff(1e-10)
-    for name, fn in (("sign", lambda o: nt.SignSolvers.ComputeSign(H, o, p)),
-                     ("inverse_square_root", lambda o: nt.SquareRootSolvers.InverseSquareRoot(H, o, p))):
+    def timed_solver(fn, n):
         O = nt.Matrix_ps(n)
         fn(O)   # warm-up
         dt = None
@@ -106,8 +114,62 @@ def main():
             d1 = time.perf_counter() - t0
             dt = d1 if dt is None else min(dt, d1)
         tr = nt.solver_trace()
-        out["config4_" + name] = dict(n=n, halfband=h, threshold=thr, wall_s=dt, iterations=tr["iterations"],
-                                      s_per_iteration=dt / max(1, tr["iterations"]), nnz_result=O.GetSize())
+        return dict(n=n, wall_s=dt, iterations=tr["iterations"], s_per_iteration=dt / max(1, tr["iterations"]),
+                    nnz_result=O.GetSize())
+
+    if want("solvers"):
+        # the headline operand under the other solvers the path serves (real arithmetic): TRS4 by differencing two
+        # iteration caps, SignFunction on the indefinite H, InverseSquareRoot on H + 2I
+        n, h, thr = 262144, 100, 1e-8
+        col, row, val = banded_triplets(n, h)
+        H = nt.Matrix_ps.from_triplets(n, col, row, val)
+        I = nt.Matrix_ps(n)
+        I.FillIdentity()
+        res = []
+        for iters in (4, 14, 4, 14):
+            K = nt.Matrix_ps(n)
+            p = nt.SolverParameters()
+            p.SetThreshold(thr)
+            p.SetConvergeDiff(1e-30)
+            p.SetMaxIterations(iters)
+            p.SetMonitorConvergence(False)
+            nt.synchronize()
+            t0 = time.perf_counter()
+            e, _ = nt.DensityMatrixSolvers.TRS4(H, I, n / 2.0, K, p)
+            nt.synchronize()
+            res.append((time.perf_counter() - t0, e, K.GetSize()))
+            del K
+        out["config2_trs4"] = dict(n=n, halfband=h, threshold=thr, ms_per_iteration=1e3 * (res[3][0] - res[2][0]) / 10,
+                                   energy_14=res[3][1], nnz_K_14=res[3][2])
+        p = nt.SolverParameters()
+        p.SetThreshold(thr)
+        p.SetConvergeDiff(1e-8)
+        out["config2_sign_real_indefinite"] = timed_solver(lambda o: nt.SignSolvers.ComputeSign(H, o, p), n)
+        H.Increment(I, 2.0, 0.0)
+        out["config2_inverse_square_root_real"] = timed_solver(lambda o: nt.SquareRootSolvers.InverseSquareRoot(H, o, p), n)
+        del H, I
+
+    if want("complex"):
+        n, h, thr = 131072, 50, 1e-8
+        p = nt.SolverParameters()
+        p.SetThreshold(thr)
+        p.SetConvergeDiff(1e-8)
+        # SignFunction of the INDEFINITE Hermitian H (the operand of tests/test_gpu_scale.py::
+        # test_config4_sign_of_the_indefinite_operand: eigenvalues of both signs, sign(H) far from the identity)
+        col, row, val = banded_triplets(n, h, complex_=True)
+        H = nt.Matrix_ps.from_triplets(n, col, row, val)
+        del col, row, val
+        r = timed_solver(lambda o: nt.SignSolvers.ComputeSign(H, o, p), n)
+        r.update(halfband=h, threshold=thr, operand="H (indefinite)")
+        out["config4_sign"] = r
+        del H
+        col, row, val = banded_triplets(n, h, complex_=True, shift=2.0)
+        H = nt.Matrix_ps.from_triplets(n, col, row, val)
+        del col, row, val
+        p.SetConvergeDiff(1e-10)
+        r = timed_solver(lambda o: nt.SquareRootSolvers.InverseSquareRoot(H, o, p), n)
+        r.update(halfband=h, threshold=thr, operand="H + 2 I")
+        out["config4_inverse_square_root"] = r
     print(json.dumps(out, indent=1))
 
 
