@@ -84,6 +84,9 @@ struct ShmTransport : Transport {
   std::vector<Pending> sends, recvs;
   std::vector<char> host;
 
+  // (the test transport moves bytes through host memory and has to wait for the stream where RCCL enqueues a collective:
+  // its waits are not host synchronisations of the ENGINE and stay out of host_sync_count())
+  static void transport_wait() { HIP_CHECK(hipStreamSynchronize(stream())); }
   ShmHeader* hdr() { return reinterpret_cast<ShmHeader*>(base); }
   char* mailbox(int s, int q) { return base + 4096 + ((size_t)s * P + q) * box; }
   void barrier() {
@@ -103,7 +106,7 @@ struct ShmTransport : Transport {
 
   void allgather(const void* send, void* recv, size_t bytes) override {
     check(bytes);
-    sync_stream();
+    transport_wait();
     d2h(mailbox(rank, rank), send, bytes);
     barrier();
     for (int s = 0; s < P; ++s) h2d(static_cast<char*>(recv) + (size_t)s * bytes, mailbox(s, s), bytes);
@@ -112,7 +115,7 @@ struct ShmTransport : Transport {
   void allreduce(void* buf, size_t count, bool is_f64, int op) override {
     const size_t bytes = count * 8;
     check(bytes);
-    sync_stream();
+    transport_wait();
     d2h(mailbox(rank, rank), buf, bytes);
     barrier();
     host.resize(bytes);
@@ -135,7 +138,7 @@ struct ShmTransport : Transport {
   }
   void bcast(const void* send, void* recv, size_t bytes, int root) override {
     check(bytes);
-    sync_stream();
+    transport_wait();
     if (rank == root) d2h(mailbox(root, root), send, bytes);
     barrier();
     h2d(recv, mailbox(root, root), bytes);
@@ -145,7 +148,7 @@ struct ShmTransport : Transport {
   void send(const void* p, size_t bytes, int peer) override { sends.push_back({p, nullptr, bytes, peer}); }
   void recv(void* p, size_t bytes, int peer) override { recvs.push_back({nullptr, p, bytes, peer}); }
   void group_end() override {
-    sync_stream();
+    transport_wait();
     std::vector<size_t> off((size_t)P, 0);
     for (const Pending& m : sends) {  // messages to one peer are appended in posting order
       if (off[(size_t)m.peer] + m.bytes > box) NTP_FATAL("shm transport: mailbox overflow (NTPOLY_AMD_SHM_MB)");
@@ -243,10 +246,17 @@ int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);
   return (v && *v) ? std::atoi(v) : dflt;
 }
-// size of the launch according to the process managers' environment (1 when none is visible)
+// size of the launch this process is a RANK of, according to the process managers' environment (1 when none says so).
+// Only variables that identify this very process as one of several count -- its rank together with the size of its
+// step: an allocation-wide SLURM_NTASKS or a stray WORLD_SIZE around a serial process does not.
 int launcher_world_size() {
-  for (const char* name : {"PMI_SIZE", "OMPI_COMM_WORLD_SIZE", "PMIX_SIZE", "SLURM_NTASKS", "WORLD_SIZE"}) {
-    const int n = env_int(name, 0);
+  const struct { const char* rank; const char* size; } pairs[] = {
+      {"PMI_RANK", "PMI_SIZE"}, {"PMIX_RANK", "PMIX_SIZE"}, {"OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE"},
+      {"SLURM_PROCID", "SLURM_STEP_NUM_TASKS"}, {"RANK", "WORLD_SIZE"}};
+  for (const auto& p : pairs) {
+    const char* r = std::getenv(p.rank);
+    if (!r || !*r) continue;
+    const int n = env_int(p.size, 0);
     if (n > 1) return n;
   }
   return 1;
@@ -258,65 +268,128 @@ int launcher_local_rank(int rank) {
   }
   return rank;  // one node: every rank is local
 }
+void refuse_replicas() {
+  // A multi-process launch that hands the engine no communicator would run P identical single-rank solves on GPU 0 and
+  // let all of them write the same files: refuse.
+  const int n = launcher_world_size();
+  if (n > 1 && !std::getenv("NTPOLY_AMD_ALLOW_REPLICAS"))
+    NTP_FATAL("this process is one of " + std::to_string(n) + " launched together, but no communicator was given to the engine: "
+              "initialise MPI before constructing the process grid (the communicator argument is then honoured), or call "
+              "ntpoly_amd_init_comm (ntpoly_amd.host.init_comm_from_env); NTPOLY_AMD_ALLOW_REPLICAS=1 runs independent replicas");
+}
+
+// The MPI library the program has loaded, found once.  abi: 0 none / not initialised, 1 MPICH family, 2 Open MPI.
+struct MpiLib {
+  int abi = 0;
+  // MPICH family: handles are ints
+  int (*rank_i)(int, int*) = nullptr;
+  int (*size_i)(int, int*) = nullptr;
+  int (*bcast_i)(void*, int, int, int, int) = nullptr;
+  // Open MPI: handles are pointers
+  void* (*f2c)(int) = nullptr;
+  int (*rank_p)(void*, int*) = nullptr;
+  int (*size_p)(void*, int*) = nullptr;
+  int (*bcast_p)(void*, int, void*, int, void*) = nullptr;
+  void* byte_p = nullptr;
+  void* null_p = nullptr;
+};
+const MpiLib& mpi_lib() {
+  static MpiLib* lib = [] {
+    auto* m = new MpiLib();
+    using fn_initialized = int (*)(int*);
+    auto initialized = reinterpret_cast<fn_initialized>(dlsym(RTLD_DEFAULT, "MPI_Initialized"));
+    int inited = 0;
+    if (initialized) initialized(&inited);
+    if (!inited) return m;
+    // which ABI?  Asked, not assumed: the library names itself
+    using fn_version = int (*)(char*, int*);
+    auto version = reinterpret_cast<fn_version>(dlsym(RTLD_DEFAULT, "MPI_Get_library_version"));
+    std::string name;
+    if (version) {
+      std::vector<char> buf(8192 + 1, 0);   // (MPI_MAX_LIBRARY_VERSION_STRING is 8192 in MPICH, 256 in Open MPI)
+      int len = 0;
+      if (version(buf.data(), &len) == 0) name.assign(buf.data());
+    }
+    const bool is_ompi = name.find("Open MPI") != std::string::npos && dlsym(RTLD_DEFAULT, "ompi_mpi_comm_world") != nullptr;
+    const bool is_mpich = !is_ompi && (name.find("MPICH") != std::string::npos || name.find("Intel(R) MPI") != std::string::npos ||
+                                       name.find("MVAPICH") != std::string::npos || name.find("CRAY MPICH") != std::string::npos);
+    if (is_ompi) {
+      m->f2c = reinterpret_cast<void* (*)(int)>(dlsym(RTLD_DEFAULT, "MPI_Comm_f2c"));
+      m->rank_p = reinterpret_cast<int (*)(void*, int*)>(dlsym(RTLD_DEFAULT, "MPI_Comm_rank"));
+      m->size_p = reinterpret_cast<int (*)(void*, int*)>(dlsym(RTLD_DEFAULT, "MPI_Comm_size"));
+      m->bcast_p = reinterpret_cast<int (*)(void*, int, void*, int, void*)>(dlsym(RTLD_DEFAULT, "MPI_Bcast"));
+      m->byte_p = dlsym(RTLD_DEFAULT, "ompi_mpi_byte");
+      m->null_p = dlsym(RTLD_DEFAULT, "ompi_mpi_comm_null");
+      if (!m->f2c || !m->rank_p || !m->size_p || !m->bcast_p || !m->byte_p) NTP_FATAL("Open MPI is loaded but its entry points were not found");
+      m->abi = 2;
+    } else if (is_mpich) {
+      m->rank_i = reinterpret_cast<int (*)(int, int*)>(dlsym(RTLD_DEFAULT, "MPI_Comm_rank"));
+      m->size_i = reinterpret_cast<int (*)(int, int*)>(dlsym(RTLD_DEFAULT, "MPI_Comm_size"));
+      m->bcast_i = reinterpret_cast<int (*)(void*, int, int, int, int)>(dlsym(RTLD_DEFAULT, "MPI_Bcast"));
+      if (!m->rank_i || !m->size_i || !m->bcast_i) NTP_FATAL("an MPICH-family MPI library is loaded but its entry points were not found");
+      m->abi = 1;
+    } else {
+      NTP_FATAL("MPI is initialised in this process, but the library (\"" + name.substr(0, 80) +
+                "\") is neither of the MPICH family nor Open MPI: its handle ABI is not known to the engine; bootstrap with "
+                "ntpoly_amd_init_comm instead");
+    }
+    return m;
+  }();
+  return *lib;
+}
+// rank and size of the communicator behind a Fortran handle; false: not a communicator (0, a null or a malformed handle
+// -- "no communicator given": callers that never touch MPI pass 0)
+bool mpi_rank_size(const MpiLib& m, int fcomm, int* rank, int* size) {
+  if (m.abi == 1) {
+    // MPICH handle layout: bits 30-31 kind (1 builtin, 2 direct, 3 indirect), bits 26-29 object type (1 = communicator)
+    const unsigned h = (unsigned)fcomm;
+    if ((h >> 30) == 0u || ((h >> 26) & 0xfu) != 1u) return false;
+    return m.rank_i(fcomm, rank) == 0 && m.size_i(fcomm, size) == 0;
+  }
+  if (m.abi == 2) {
+    if (fcomm < 0) return false;
+    void* comm = m.f2c(fcomm);
+    if (!comm || comm == m.null_p) return false;
+    return m.rank_p(comm, rank) == 0 && m.size_p(comm, size) == 0;
+  }
+  return false;
+}
 }  // namespace
 
 bool comm_bind_mpi(int fcomm) {
   Comm& c = world();
-  if (c.tr || c.nranks > 1) return true;       // the engine already has its communicator (ntpoly_amd_init_comm)
-  if (c.user_init) return false;               // an explicit single-rank bootstrap
-  static bool tried = false;
-  if (tried) return false;
-  tried = true;
-  using fn_initialized = int (*)(int*);
-  auto initialized = reinterpret_cast<fn_initialized>(dlsym(RTLD_DEFAULT, "MPI_Initialized"));
-  int inited = 0;
-  if (initialized) initialized(&inited);
-  if (!inited) {
-    // no MPI in this process.  A multi-process launch that never called ntpoly_amd_init_comm would run P identical
-    // single-rank solves on GPU 0 and let all of them write the same files: refuse.
-    const int n = launcher_world_size();
-    if (n > 1 && !std::getenv("NTPOLY_AMD_ALLOW_REPLICAS"))
-      NTP_FATAL("this process is one of " + std::to_string(n) + " launched together, but no communicator was given to the engine: "
-                "initialise MPI before constructing the process grid (the communicator argument is then honoured), or call "
-                "ntpoly_amd_init_comm (ntpoly_amd.host.init_comm_from_env); NTPOLY_AMD_ALLOW_REPLICAS=1 runs independent replicas");
+  const bool bound = c.tr || c.nranks > 1;       // the engine already has its communicator
+  if (!bound && c.user_init) return false;       // an explicit single-rank bootstrap
+  const MpiLib& m = mpi_lib();
+  int rank = 0, size = 1;
+  if (m.abi == 0 || !mpi_rank_size(m, fcomm, &rank, &size)) {
+    // no MPI in this process, or no communicator in the argument (0 / null / malformed: a caller that does not use MPI)
+    if (bound) return true;
+    static bool checked = false;
+    if (!checked) {
+      checked = true;
+      refuse_replicas();
+    }
     return false;
   }
-  int rank = 0, size = 1;
-  char id[128];
-  std::memset(id, 0, sizeof(id));
-  const bool ompi = dlsym(RTLD_DEFAULT, "ompi_mpi_comm_world") != nullptr;
-  if (ompi) {
-    using f2c_t = void* (*)(int);
-    using rank_t = int (*)(void*, int*);
-    using bcast_t = int (*)(void*, int, void*, int, void*);
-    auto f2c = reinterpret_cast<f2c_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_f2c"));
-    auto frank = reinterpret_cast<rank_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_rank"));
-    auto fsize = reinterpret_cast<rank_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_size"));
-    auto fbcast = reinterpret_cast<bcast_t>(dlsym(RTLD_DEFAULT, "MPI_Bcast"));
-    void* byte_t = dlsym(RTLD_DEFAULT, "ompi_mpi_byte");
-    if (!f2c || !frank || !fsize || !fbcast || !byte_t) NTP_FATAL("Open MPI is loaded but its entry points were not found");
-    void* comm = f2c(fcomm);
-    if (frank(comm, &rank) != 0 || fsize(comm, &size) != 0) NTP_FATAL("the communicator handed to the process grid is not valid");
-    if (size > 1) {
-      if (rank == 0) comm_get_unique_id(id);
-      if (fbcast(id, 128, byte_t, 0, comm) != 0) NTP_FATAL("MPI_Bcast of the RCCL id failed");
-    }
-  } else {
-    using rank_t = int (*)(int, int*);
-    using bcast_t = int (*)(void*, int, int, int, int);
-    auto frank = reinterpret_cast<rank_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_rank"));
-    auto fsize = reinterpret_cast<rank_t>(dlsym(RTLD_DEFAULT, "MPI_Comm_size"));
-    auto fbcast = reinterpret_cast<bcast_t>(dlsym(RTLD_DEFAULT, "MPI_Bcast"));
-    if (!frank || !fsize || !fbcast) NTP_FATAL("an MPI library is loaded but its entry points were not found");
-    const int comm = fcomm;                 // MPICH ABI: MPI_Comm_f2c is the identity
-    constexpr int kMpichByte = 0x4c00010d;  // MPI_BYTE
-    if (frank(comm, &rank) != 0 || fsize(comm, &size) != 0) NTP_FATAL("the communicator handed to the process grid is not valid");
-    if (size > 1) {
-      if (rank == 0) comm_get_unique_id(id);
-      if (fbcast(id, 128, kMpichByte, 0, comm) != 0) NTP_FATAL("MPI_Bcast of the RCCL id failed");
-    }
+  if (bound) {
+    // one communicator per process: a later grid on a communicator of another size cannot be served by the one the
+    // engine is bound to (a sub-communicator of the same size, e.g. a duplicate, is the same set of ranks)
+    if (size != c.nranks)
+      NTP_FATAL("the engine is bound to a communicator of " + std::to_string(c.nranks) + " ranks; a process grid on a communicator of " +
+                std::to_string(size) + " ranks is not supported (one communicator per process)");
+    return true;
   }
   if (size <= 1) return false;
+  char id[128];
+  std::memset(id, 0, sizeof(id));
+  if (rank == 0) comm_get_unique_id(id);
+  if (m.abi == 1) {
+    constexpr int kMpichByte = 0x4c00010d;  // MPI_BYTE
+    if (m.bcast_i(id, 128, kMpichByte, 0, fcomm) != 0) NTP_FATAL("MPI_Bcast of the RCCL id failed");
+  } else {
+    if (m.bcast_p(id, 128, m.byte_p, 0, m.f2c(fcomm)) != 0) NTP_FATAL("MPI_Bcast of the RCCL id failed");
+  }
   // one process per GPU: the device follows the node-local rank, and must be chosen before the runtime is touched
   Context& x = ctx();
   if (x.initialised)
@@ -471,6 +544,7 @@ hipEvent_t halo_event(int which) {
 }  // namespace
 
 void gather_needed_begin(HaloExchange& hx, const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2], bool may_overlap) {
+  const long long syncs_before = host_sync_count();   // (measured, not asserted: ExchangeStats::host_syncs)
   Comm& c = world();
   const int32_t dim = m.dim;
   if (!c.active()) NTP_FATAL("gather_needed without an active communicator");
@@ -513,8 +587,8 @@ void gather_needed_begin(HaloExchange& hx, const PSMatrix& m, const DevMat& Bloc
       HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, stream()));
       sync_stream();
     }
-    exchange_stats().host_syncs += 1;
   }
+  exchange_stats().host_syncs += host_sync_count() - syncs_before;
   exchange_stats().exchanges += 1;
   nnz_global[0] = nnz_global[1] = 0;
   for (int q = 0; q < P; ++q) {

@@ -38,7 +38,14 @@ void ensure_init() {
   c.initialised = true;
 }
 
-void sync_stream() { HIP_CHECK(hipStreamSynchronize(ctx().stream)); }
+long long& host_sync_count() {
+  static long long n = 0;
+  return n;
+}
+void sync_stream() {
+  host_sync_count() += 1;   // (every host wait on the engine stream goes through here: ScalarFetch::run, DevBuf::download)
+  HIP_CHECK(hipStreamSynchronize(ctx().stream));
+}
 
 // ---------------------------------------------------------------- caching allocator
 namespace {

@@ -39,6 +39,7 @@ Context& ctx();
 void ensure_init();  // fails loudly when no GPU is present
 inline hipStream_t stream() { return ctx().stream; }
 void sync_stream();
+long long& host_sync_count();   // host waits on the engine stream so far (counted in sync_stream itself)
 
 // Batched read-back of small results: up to 8 device segments of 8-byte words are copied by ONE tiny kernel into
 // host-mapped pinned memory and the stream is synchronised once (a hipMemcpyAsync per scalar costs a copy

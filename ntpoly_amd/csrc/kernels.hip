@@ -987,12 +987,14 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
   : SLAB_LOOP_CLOBBERS
   if constexpr (MODE == 1) {
     asm volatile(SLAB_LOOP_ASM_FMA SLAB_LOOP_OPERANDS);  // option spgemm_fma: one rounding per product (v_fma_f64)
+#ifdef NTP_ABLATIONS
   } else if constexpr (MODE == 2) {
     asm volatile(SLAB_LOOP_ASM_ABL1 SLAB_LOOP_OPERANDS);  // no slab loads
   } else if constexpr (MODE == 3) {
     asm volatile(SLAB_LOOP_ASM_ABL2 SLAB_LOOP_OPERANDS);  // no multiplier loads
   } else if constexpr (MODE == 4) {
     asm volatile(SLAB_LOOP_ASM_ABL3 SLAB_LOOP_OPERANDS);  // no arithmetic
+#endif
   } else if constexpr (MODE == 9) {
     // label-ordered steps: the multiplier row of a step sits at the byte offset its run record names
     asm volatile(SLAB_LOOP_ASM_ROWOFF
@@ -3189,7 +3191,12 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                          blk_kmin.p, blk_kn.p, blk_lo.p, blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha,
                          threshold, dr, n, snb, (const SlabFuseArgs*)nullptr);
     };
-    const int abl = (sv_opt / 100 == 4) ? sv_opt % 100 : 0;  // 401..403: ablations for timing experiments
+    int abl = (sv_opt / 100 == 4) ? sv_opt % 100 : 0;  // 401..404: ablations for timing experiments (WRONG results)
+#ifndef NTP_ABLATIONS
+    // (the wrong-result loop variants are compiled only into the experiment build, -DNTP_ABLATIONS -- tools/bench_spgemm.py;
+    // in the product library the option values select the ordinary loop)
+    if (abl >= 1 && abl <= 4) abl = 0;
+#endif
     // narrow windows: one / two slabs per wave (more resident waves); 410 keeps three slabs for comparison
     const int64_t max_w_now = (int64_t)hstats[16];
     auto launch_narrow = [&](auto sl_tag) {
@@ -3283,10 +3290,12 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
                          blk_w.p, blk_toff.p, tmp_inner.p, tmp_val.p, count.p, alpha, threshold, dr, n, snb, (const SlabFuseArgs*)nullptr);
     else if (abl == 0 && !options().spgemm_fma && sv_opt != 410 && max_w_now <= SLAB_NW * WAVE) launch_narrow(std::integral_constant<int, 1>{});
     else if (abl == 0 && !options().spgemm_fma && sv_opt != 410 && max_w_now <= 2 * SLAB_NW * WAVE) launch_narrow(std::integral_constant<int, 2>{});
+#ifdef NTP_ABLATIONS
     else if (abl == 1) launch_slab(std::integral_constant<int, 2>{});
     else if (abl == 2) launch_slab(std::integral_constant<int, 3>{});
     else if (abl == 3) launch_slab(std::integral_constant<int, 4>{});
     else if (abl == 4) launch_slab(std::integral_constant<int, 5>{});
+#endif
     else if (abl == 5) launch_slab(std::integral_constant<int, 6>{});
     else if (abl == 6) launch_slab(std::integral_constant<int, 7>{});
     else if (abl == 7) launch_slab(std::integral_constant<int, 8>{});

@@ -32,6 +32,10 @@ struct EngineOptions {
   int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
                                // reference built with FP contraction computes); 0: separate multiply and add (default, bit-
                                // identical to the reference built without contraction)
+  int operand_cache = 1;       // 1: the expanded WH (and WH in a recovered band order) of a purification solve stays on the
+                               // device for the next solve on the same operand (SCF loops): at most 8 (nnz + 32 n) + 12 nnz + 8 n
+                               // bytes, replaced when the operand changes; 0: freed at the end of every solve;
+                               // ntpoly_amd_release_cache() frees it at any time
   int tile_rows = 2;           // MFMA tile kernel (spgemm_fma = 1): consecutive rows per lane of the A operand, 1 / 2 / 4 (spgemm_tile.hpp)
   int tile_waves = 0;          // ... waves per workgroup, 4 / 8 (0: chosen from the LDS footprint)
   int load_balance = 1;        // 1: solvers permute with the caller's load-balancing permutation as the reference does;
@@ -57,7 +61,9 @@ struct EngineOptions {
                                // for everything (first generation); 3<MAXCH><NW> column-pair kernel with that geometry;
                                // 400 register-slab kernel whenever it fits (also when its run-density test says no);
                                // timing experiments on the three-slab real kernel: 401..404 ablations (WRONG results:
-                               // no slab loads / no multiplier loads / no arithmetic / cache-hot multipliers), 405 plain
+                               // no slab loads / no multiplier loads / no arithmetic / cache-hot multipliers; compiled only
+                               // with -DNTP_ABLATIONS, NTPOLY_AMD_EXTRA_FLAGS of ntpoly_amd/_build.py -- the product library
+                               // runs the ordinary loop for these values), 405 plain
                                // loop + rotating prefetch, 406 lean periods, 407 both (= the default loop), 408 / 409
                                // two / three workgroups per CU, 410 plain loop and three slabs also for narrow windows;
                                // 500 grouped LDS-hash kernel for every multiply the slab kernels do not take (automatic: when

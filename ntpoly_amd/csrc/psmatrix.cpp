@@ -506,6 +506,7 @@ namespace {
 void dev_allreduce4(double* d) { world().tr->allreduce(d, 4, true, 0); }
 
 bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabReduce& red) {
+  const long long syncs_before = host_sync_count();
   Comm& c = world();
   Transport& tr = *c.tr;
   const int P = c.nranks, me = c.rank;
@@ -546,7 +547,7 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
     HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, stream()));
     sync_stream();
   }
-  exchange_stats().host_syncs += 1;
+  exchange_stats().host_syncs += host_sync_count() - syncs_before;   // (the exchange's own: measured in sync_stream)
   exchange_stats().exchanges += 1;
   int64_t nnz_global = 0;
   for (int q = 0; q < P; ++q) nnz_global += req[(size_t)4 * q + 2];

@@ -96,6 +96,7 @@ __global__ void k_pos_from_order(const int32_t* __restrict__ order, int n, int32
 // ctl[1 + L % 3]; the counter of level L + 1 is cleared during level L, two barriers after its last reader).
 // out[0] = vertices reached, out[1] = levels, out[2] = the vertex of the last level with the fewest neighbours.
 constexpr int kBfsBlocks = 8;
+constexpr int kBfsLevelMax = 4096;   // vertices of a level ranked in LDS (16 KB)
 __device__ inline void grid_barrier(unsigned* __restrict__ counter, unsigned nblocks, unsigned& epoch) {
   __threadfence();
   __syncthreads();
@@ -138,8 +139,24 @@ __global__ __launch_bounds__(1024) void k_bfs_multi(const int64_t* __restrict__ 
     grid_barrier(ctl, gridDim.x, epoch);
     const int nl = (int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nl == 0) break;
-    for (int i = gtid; i < nl; i += nthreads)
-      pos[__hip_atomic_load(nxt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = base + reached + i;
+    // positions inside the level: by vertex number, not by the order in which the atomics above happened to arrive -- the
+    // recovered order (and with it the path a borderline operand takes) is the same from run to run.  Levels that fit
+    // the workgroup's LDS copy are ranked there; a wider level (no band in sight) keeps its arrival order.
+    if (nl <= kBfsLevelMax) {
+      __shared__ int lvl[kBfsLevelMax];
+      for (int i = threadIdx.x; i < nl; i += blockDim.x) lvl[i] = __hip_atomic_load(nxt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      for (int i = gtid; i < nl; i += nthreads) {
+        const int v = lvl[i];
+        int rank = 0;
+        for (int q = 0; q < nl; ++q) rank += lvl[q] < v ? 1 : 0;
+        pos[v] = base + reached + rank;
+      }
+      __syncthreads();
+    } else {
+      for (int i = gtid; i < nl; i += nthreads)
+        pos[__hip_atomic_load(nxt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = base + reached + i;
+    }
     reached += nl;
     level += 1;
     nf = nl;
@@ -166,8 +183,18 @@ int bfs_from(const DevMat& A, int start, int base, DevBuf<int32_t>& dist, DevBuf
   ctl.zero();
   const unsigned long long init = ~0ull;
   best.upload(&init, 1);
-  hipLaunchKernelGGL(k_bfs_multi, dim3(kBfsBlocks), dim3(1024), 0, stream(), A.outer.p, A.inner.p, start, base, dist.p, pos.p, cur.p,
-                     nxt.p, ctl.p, best.p, out.p);
+  {
+    // the grid barrier needs all workgroups resident at once: a cooperative launch makes the runtime CHECK that (a
+    // CU-masked or partitioned device that cannot hold them refuses the launch instead of hanging in the barrier)
+    const int64_t* a_outer = A.outer.p;
+    const int32_t* a_inner = A.inner.p;
+    int32_t *p_dist = dist.p, *p_pos = pos.p, *p_cur = cur.p, *p_nxt = nxt.p;
+    unsigned* p_ctl = ctl.p;
+    unsigned long long* p_best = best.p;
+    long long* p_out = out.p;
+    void* args[] = {&a_outer, &a_inner, &start, &base, &p_dist, &p_pos, &p_cur, &p_nxt, &p_ctl, &p_best, &p_out};
+    HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_bfs_multi), dim3(kBfsBlocks), dim3(1024), args, 0, stream()));
+  }
   long long h[3] = {0, 0, 0};
   ScalarFetch f;
   f.add(out.p, 3, h);

@@ -219,6 +219,9 @@ void density_setup(const PSMatrix& H, const PSMatrix& ISQ, const SolverParameter
 void density_finish(PSMatrix& X, const PSMatrix& ISQT, const PSMatrix& ISQ, PSMatrix& K, const SolverParameters& p) {
   if (p.do_load_balancing) ps_permute(X, X, p.balance_permutation, true);
   ps_similarity(X, ISQT, ISQ, K, p.threshold);
+  // what the fused / relabelled steps keep for the NEXT solve on the same operand (the expanded WH, WH in the recovered
+  // band order: about 8 (nnz + 32 columns) + 12 nnz + 8 n bytes, 1.3 GB at N = 262 144) goes now when the caller said so
+  if (!options().operand_cache) drop_operand_caches();
 }
 }  // namespace
 
@@ -234,7 +237,7 @@ double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_tar
   *sigma = (trace_target - trace_value < 0.0) ? -1.0 : 1.0;
   double out[4] = {0, 0, 0, 0};
   if (*sigma > 0.0) {
-    ps_square_update_dot(X, X2, threshold, WH, out, trace_io != nullptr);  // X2 = X*X; X = 2X - X2; energy; trace
+    ps_square_update_dot(X, X2, threshold, WH, out, trace_io != nullptr);  // X = 2X - X*X; energy; trace (X2: scratch -- holds X*X only on the unfused path)
   } else {
     ps_square_dot(X, X2, threshold, WH, out, trace_io != nullptr);         // X = X*X; energy; trace
   }

@@ -798,7 +798,12 @@ void launch_ghash(const DevMat& A, int ngroups, const int32_t* cols, const int32
                   const int64_t* grp_off, const GhRec* recs, const double* tiles, const int64_t* tmpoff, int32_t* tmp_inner,
                   double* tmp_val, int32_t* count, uint8_t* state, unsigned long long* stats, double alpha, double thr, int dr) {
   const int sv = options().spgemm_variant;
+#ifdef NTP_ABLATIONS
   const int ablate = (sv >= 511 && sv <= 541) ? sv - 510 : 0;   // bits: 1 no products, 2 no hashing / scatter, 4 no epilogue
+#else
+  // (the wrong-result experiment bits exist only in the experiment build, -DNTP_ABLATIONS; 518 = in-kernel stamps stays)
+  const int ablate = (sv == 518) ? 8 : 0;
+#endif
   hipLaunchKernelGGL((k_spgemm_ghash<T, NW, SL, WPC>), dim3(xcd_grid(ngroups)), dim3(NW * WAVE), 0, stream(), view(A), cols, grp_kn,
                      grp_maxlen, grp_off, recs, reinterpret_cast<const T*>(tiles), tmpoff, tmp_inner,
                      reinterpret_cast<T*>(tmp_val), count, state, stats, alpha, thr, dr, ngroups, ablate);

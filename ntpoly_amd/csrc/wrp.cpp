@@ -136,6 +136,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   if (n == "spgemm_force_bin") options().spgemm_force_bin = *value;
   else if (n == "increment_force_seq") options().increment_force_seq = *value;
   else if (n == "spgemm_fma") options().spgemm_fma = *value;
+  else if (n == "operand_cache") options().operand_cache = *value;
   else if (n == "tile_rows") options().tile_rows = *value;
   else if (n == "tile_waves") options().tile_waves = *value;
   else if (n == "time_kernels") options().time_kernels = *value;
@@ -168,10 +169,13 @@ void ntpoly_amd_last_grouped_stats(long long* out, double* ratio) {
   out[5] = s.gh_tile_rows;
   *ratio = s.gh_union_ratio;
 }
-// out[0] = halo exchanges of distributed multiplies so far, out[1] = host synchronisations inside them
+// out[0] = halo exchanges of distributed multiplies so far, out[1] = host synchronisations inside them (counted where the
+// host waits: sync_stream), out[2] = ALL host synchronisations of the process so far: a caller brackets a call with two
+// reads to learn what the whole call cost (exchange, plan, totals)
 void ntpoly_amd_exchange_stats(long long* out) {
   out[0] = exchange_stats().exchanges;
   out[1] = exchange_stats().host_syncs;
+  out[2] = host_sync_count();
 }
 // tests: the bandwidth-reducing order of a (one-rank, real or complex) matrix' pattern; newpos[old] = new (0-based),
 // returns 1 on success

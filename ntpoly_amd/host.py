@@ -96,8 +96,10 @@ def init_comm_from_env(timeout=300.0):
     # a per-launch nonce keeps a stale file of an earlier (crashed) launch from being taken for this one's id
     # (an explicitly named file may be shared by ranks of different parents: NTPOLY_AMD_RDV_NONCE stands in for the pid)
     who = os.environ.get("NTPOLY_AMD_RDV_NONCE", "") if os.environ.get("NTPOLY_AMD_RDV") else str(os.getppid())
-    nonce = (os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("MASTER_PORT", "0") + ":" +
-             who).encode()[:64].ljust(64, b"\0")
+    # (an elastic restart of a crashed worker group keeps run id, port and parent: the restart count tells the new
+    # group's file from the dead group's)
+    nonce = (os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") + ":" +
+             os.environ.get("MASTER_PORT", "0") + ":" + who).encode()[:64].ljust(64, b"\0")
     if rank == 0:
         uid = get_unique_id()
         try:
@@ -589,7 +591,9 @@ class DensityMatrixSolvers:
 
 def trs2_step(X, X2, WH, trace, threshold, trace_x=None):
     """one TRS2 iteration (what TRS2_wrp runs inside its loop) -> (sigma, energy, trace of the new X);
-    trace_x = trace of X from the previous step's return value (None: computed)"""
+    trace_x = trace of X from the previous step's return value (None: computed).  X2 is SCRATCH: on the fused path the
+    product X*X never exists as a matrix (it is merged into X inside the SpGEMM kernel's epilogue) and X2 is left
+    untouched; only the unfused path leaves X*X in it."""
     e, sg = C.c_double(), C.c_double()
     tr = C.c_double(float("nan") if trace_x is None else trace_x)
     lib.ntpoly_amd_trs2_step(X.ih, X2.ih, WH.ih, d(trace), d(threshold), C.byref(e), C.byref(sg), C.byref(tr))
@@ -888,10 +892,11 @@ def last_grouped_stats():
 
 
 def exchange_stats():
-    """(halo exchanges of distributed multiplies so far, host synchronisations inside them)"""
-    out = (C.c_longlong * 2)()
+    """(halo exchanges of distributed multiplies so far, host synchronisations inside them, ALL host synchronisations of
+    the process so far) -- the synchronisations are counted where the host waits (sync_stream in csrc/common.cpp)"""
+    out = (C.c_longlong * 3)()
     lib.ntpoly_amd_exchange_stats(out)
-    return int(out[0]), int(out[1])
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def reset_spgemm_accum():

@@ -45,7 +45,7 @@ def main():
     x0 = nt.exchange_stats()
     C.Gemm(A, B, None, 0.5, 0.0, 1e-7)
     x1 = nt.exchange_stats()
-    res["exchanges"], res["exchange_host_syncs"] = x1[0] - x0[0], x1[1] - x0[1]
+    res["exchanges"], res["exchange_host_syncs"], res["gemm_host_syncs"] = x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]
     keep("AB", C)
     res["AB_trace"], res["AB_norm"], res["AB_dot"] = C.Trace(), C.Norm(), float(np.real(C.Dot(A)))
     AT = nt.Matrix_ps(n)

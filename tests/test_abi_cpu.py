@@ -145,6 +145,16 @@ def test_multi_process_launch_without_communicator_is_refused():
     env2 = {k: v for k, v in env.items() if not k.startswith("PMI_")}
     r2 = subprocess.run([sys.executable, "-c", code], env=env2, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert "constructed" in r2.stdout
+    # a SERIAL process inside a multi-task allocation (SLURM_NTASKS, a stray WORLD_SIZE) is not a rank of a
+    # launch -- only a rank variable together with the size of its step says so
+    env3 = dict(env2, SLURM_NTASKS="8", WORLD_SIZE="4")
+    for k in ("RANK", "SLURM_PROCID", "PMIX_RANK", "OMPI_COMM_WORLD_RANK"):
+        env3.pop(k, None)
+    r3 = subprocess.run([sys.executable, "-c", code], env=env3, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert "constructed" in r3.stdout, r3.stdout
+    env4 = dict(env3, SLURM_PROCID="1", SLURM_STEP_NUM_TASKS="8")
+    r4 = subprocess.run([sys.executable, "-c", code], env=env4, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r4.returncode != 0 and "no communicator was given to the engine" in r4.stdout
 
 
 def test_host_side_under_address_and_ub_sanitizers(tmp_path):

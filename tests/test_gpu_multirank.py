@@ -71,8 +71,11 @@ def test_multirank_equals_single_rank(world, reference, tmp_path):
         sq, up, rep = parts[r]["trs2_fused"]
         iters = int(parts[r]["trs2_iters"])
         assert rep == 0 and iters - 1 <= sq + up <= iters, (world, r, sq, up, rep, iters)
+        # host synchronisations MEASURED inside the steps (counter in sync_stream): a panel step in slab form makes three
+        # host round trips -- exchange layout, plan, totals -- the first step (from compressed
+        # columns) a few more
         ex, syncs = parts[r]["trs2_exchanges"]
-        assert ex >= iters and syncs == ex, (world, r, ex, syncs)
+        assert ex >= iters and ex <= syncs <= 3 * ex + 6, (world, r, ex, syncs)
     # ... and counted the same intermediate products and product entries as the one-rank solve
     assert sum(int(parts[r]["trs2_products"]) for r in range(world)) == int(reference["trs2_products"])
     assert sum(int(parts[r]["trs2_nnz_c"]) for r in range(world)) == int(reference["trs2_nnz_c"])
@@ -93,10 +96,12 @@ def test_multirank_equals_single_rank(world, reference, tmp_path):
     for r in range(world):
         assert parts[r]["foe_energy"] == pytest.approx(float(reference["foe_energy"]), rel=1e-12)
         assert parts[r]["foe_mu"] == pytest.approx(float(reference["foe_mu"]), rel=1e-12)
-    # one distributed multiply = one halo exchange with at most ONE host synchronisation
+    # one distributed multiply = one halo exchange with ONE host synchronisation inside the exchange (both MEASURED: the
+    # counter lives in sync_stream), and a bounded number for the whole call (exchange, plan, nnz read-back)
     for r in range(world):
-        assert int(parts[r]["exchanges"]) == 1 and int(parts[r]["exchange_host_syncs"]) <= 1, (r, parts[r]["exchanges"],
+        assert int(parts[r]["exchanges"]) == 1 and int(parts[r]["exchange_host_syncs"]) == 1, (r, parts[r]["exchanges"],
                                                                                               parts[r]["exchange_host_syncs"])
+        assert 1 <= int(parts[r]["gemm_host_syncs"]) <= 6, (r, parts[r]["gemm_host_syncs"])
     for r in range(world):
         for s in ("AB_trace", "AB_norm", "AB_dot", "trs2_energy", "trs2_mu"):
             assert parts[r][s] == pytest.approx(float(reference[s]), rel=1e-12, abs=1e-12), (s, r)
