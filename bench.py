@@ -55,14 +55,16 @@ def trs2_step_unfused(nt, X, X2, WH, pool, trace_target, thr):
     return sigma, float(np.real(X.Dot(WH)))
 
 
-def cpu_baseline(n, h, thr, warmup, steps, permute=None, fma=False):
+def cpu_baseline(n, h, thr, warmup, steps, permute=None, fma=False, lattice=None):
     """the oracle (C restatement with OpenMP, kind "port") at the FULL configuration size on all host cores, in the
     arithmetic mode the GPU line ran in: TRS2 with warmup, warmup + 1, warmup + 2 and warmup + 3 iterations in one
     process; the three differences are three samples of ONE iteration of the region the GPU line times (setup
     excluded, as BASELINE.md section 2 measures the reference); the value is their median."""
     from oracle import oracle_py as O
-    from gen import banded_triplets, permuted_banded_triplets
-    if permute is None:
+    from gen import banded_triplets, permuted_banded_triplets, lattice_triplets
+    if lattice is not None:
+        col, row, val = lattice_triplets(lattice)
+    elif permute is None:
         col, row, val = banded_triplets(n, h)
     else:
         col, row, val = permuted_banded_triplets(n, h, permute)
@@ -88,6 +90,7 @@ def cpu_baseline(n, h, thr, warmup, steps, permute=None, fma=False):
             "sample": "oracle TRS2 (OpenMP, all host cores, %s arithmetic) at the full size N=%d (h=%d, thr=%g%s): iterations "
                       "%d..%d, three single-iteration samples t(k + 1 iterations) - t(k iterations) = %s s, median %.3f s/iter; "
                       "no scaling" % ("fma" if fma else "unfused", n, h, thr,
+                                      (", %d^3 lattice" % lattice) if lattice is not None else
                                       "" if permute is None else ", relabelled with seed %d" % permute, warmup + 1,
                                       warmup + 3, "/".join("%.3f" % x for x in samples), per_iter)}
 
@@ -143,6 +146,10 @@ def main():
     ap.add_argument("--permute", type=int, default=None, metavar="SEED",
                     help="run on P^T H P under a seeded random relabelling (SURVEY 8(d): the load-balanced / "
                          "unstructured operand; the SpGEMM leaves the run-based kernels for the LDS hash path)")
+    ap.add_argument("--lattice", type=int, default=None, metavar="L",
+                    help="run on the Hamiltonian of an L x L x L lattice (tests/gen.py lattice_triplets: 203 entries per row, "
+                         "no band any relabelling could recover; N = L^3, e.g. 64 -> 262 144): the operand the north star's "
+                         "LDS-hash SpGEMM exists for")
     ap.add_argument("--arithmetic", choices=("fma", "unfused"), default="fma",
                     help="fma: every product entry is the chain of fma() over ascending k (one rounding per product) that "
                          "the reference computes when built with FP contraction -- run on the FP64 matrix cores "
@@ -162,6 +169,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
 
     n, h, thr = args.n, args.halfband, args.threshold
+    if args.lattice is not None:
+        n = args.lattice ** 3
     nt.ConstructGlobalProcessGrid(1, world, 1)  # column panels: one per GPU
     nt.set_option("time_kernels", 1)
     nt.set_option("spgemm_fma", 1 if args.arithmetic == "fma" else 0)
@@ -175,7 +184,10 @@ def main():
     # ---- setup (untimed): Hamiltonian panel, X0 = (e_max*I - H)/(e_max - e_min)  (:344-371)
     H = nt.Matrix_ps(n)
     c0, c1 = H.local_columns()
-    if args.permute is None:
+    if args.lattice is not None:
+        from gen import lattice_triplets
+        col, row, val = lattice_triplets(args.lattice, c0=c0, c1=c1)
+    elif args.permute is None:
         col, row, val = banded_triplets(n, h, c0=c0, c1=c1)
     else:
         col, row, val = permuted_banded_triplets(n, h, args.permute, c0=c0, c1=c1)
@@ -233,11 +245,11 @@ def main():
         # figure measured on other sources is not reported (null)
         traffic, traffic_src = None, None
         tname = ("r03_pmc_traffic%s.json" if args.arithmetic == "fma" else "r03_pmc_traffic_unfused%s.json") % (
-            "" if args.permute is None else "_permute")
+            "_lattice" if args.lattice is not None else "" if args.permute is None else "_permute")
         try:
             with open(os.path.join(ROOT, "profiles", tname)) as f:
                 tj = json.load(f)
-            if (n, h, thr, world) == (262144, 100, 1e-8, 1) and tj.get("sources_sha16") == sources_sha16() and \
+            if (n, thr, world) == (262144, 1e-8, 1) and (h == 100 or args.lattice is not None) and tj.get("sources_sha16") == sources_sha16() and \
                     args.tile_rows is None and args.tile_waves is None:
                 traffic, traffic_src = float(tj["hbm_bytes_per_launch"]), "profiles/" + tname
         except Exception:
@@ -262,11 +274,16 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "TRS2 purification (BASELINE configs[2]): banded H N=%d halfband=%d (%d nnz/row)%s, "
-                                   "threshold=%g, ISQ=I, trace=N/2; timed iterations %d..%d" % (
-                                       n, h, 2 * h + 1,
-                                       "" if args.permute is None else " under a random symmetric relabelling (seed %d)" % args.permute,
-                                       thr, args.warmup + 1, args.warmup + args.steps),
+            "config": {"workload": ("TRS2 purification on a 3-D lattice Hamiltonian (no band structure): %d^3 = %d sites, couplings within "
+                                    "distance sqrt(13) (203 nnz/row), threshold=%g, ISQ=I, trace=N/2; timed iterations %d..%d" % (
+                                        args.lattice, n, thr, args.warmup + 1, args.warmup + args.steps))
+                       if args.lattice is not None else
+                       "TRS2 purification (BASELINE configs[2]): banded H N=%d halfband=%d (%d nnz/row)%s, "
+                       "threshold=%g, ISQ=I, trace=N/2; timed iterations %d..%d" % (
+                           n, h, 2 * h + 1,
+                           "" if args.permute is None else " under a random symmetric relabelling (seed %d)" % args.permute,
+                           thr, args.warmup + 1, args.warmup + args.steps),
+                       "lattice": args.lattice,
                        "arithmetic": ("fma: every product entry is the chain of fma() over ascending k (one rounding per product), "
                                       "the reference's FP-contracted build bit for bit (tests/golden/ps_gemm_fma.npz); run-like "
                                       "operands on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, spgemm_tile.hip)"
@@ -314,7 +331,8 @@ def main():
         if check:
             line["trs2_wrp_check"] = check
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, h, thr, args.warmup, args.steps, args.permute, fma=args.arithmetic == "fma")
+            line["cpu_baseline"] = cpu_baseline(n, h, thr, args.warmup, args.steps, args.permute, fma=args.arithmetic == "fma",
+                                                lattice=args.lattice)
         print(json.dumps(line), flush=True)
     if world > 1:
         nt.barrier()

@@ -2690,6 +2690,14 @@ void ScalarFetch::run() {
   n = 0;
 }
 
+static int64_t exclusive_scan_i64_from_i32(const int32_t* d_in, int64_t* d_out, int64_t n) {
+  scan_async<int32_t>(d_in, d_out, n);
+  int64_t total = 0;
+  ScalarFetch f;
+  f.add(d_out + n, 1, &total);
+  f.run();
+  return total;
+}
 int64_t exclusive_scan_i64(const int64_t* d_in, int64_t* d_out, int64_t n) {
   scan_async<int64_t>(d_in, d_out, n);
   int64_t total = 0;
@@ -2894,6 +2902,172 @@ void launch_window(int bin, const DevMat& A, const DevMat& B, const int32_t* lo,
 }
 }  // namespace
 
+// ------------------------------------------------------------------ row strips (products with wide scattered columns)
+// Operands whose product columns hold more distinct rows than the grouped kernel's largest table (a 3-D Hamiltonian:
+// ~3 000 rows per column scattered over +-40 000) are multiplied in S row STRIPS of A: strip s keeps the rows whose
+// block (row >> shift) is = s (mod S), so every column of A * B falls apart into S pieces of ~1/S of its rows, each
+// small enough for the tables.  C(i, j) only depends on row i of A: every piece is the exact product restricted to its
+// rows (same products, same ascending k, same prune), and the pieces of a column interleave block by block.
+namespace {
+struct StripCtx { bool active = false, failed = false; };
+// the strip count that worked for the last multiply of a dimension that needed strips: [0] dimension, [1] strips
+int* strips_memory(bool cplx) {
+  static int m[2][2] = {{-1, 0}, {-1, 0}};
+  return m[cplx ? 1 : 0];
+}
+StripCtx& strip_ctx() {
+  static StripCtx c;
+  return c;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_strip_count(Csc A, int shift, int S, int s, int32_t* __restrict__ cnt) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= A.cols) return;
+  const int lane = lane_id();
+  int c = 0;
+  for (int64_t p = A.outer[j] + lane, e = A.outer[j + 1]; p < e; p += WAVE) c += ((A.inner[p] >> shift) % S) == s ? 1 : 0;
+  c = (int)wave_sum_i64(c);
+  if (lane == 0) cnt[j] = c;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_strip_fill(Csc A, int shift, int S, int s, const int64_t* __restrict__ outer,
+                                                    int32_t* __restrict__ inner, T* __restrict__ val) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= A.cols) return;
+  const int lane = lane_id();
+  const T* __restrict__ Av = static_cast<const T*>(A.val);
+  int64_t pos = outer[j];
+  for (int64_t p0 = A.outer[j], e = A.outer[j + 1]; p0 < e; p0 += WAVE) {
+    const int64_t p = p0 + lane;
+    const bool in = p < e && ((A.inner[p] >> shift) % S) == s;
+    const unsigned long long m = __ballot(in);
+    if (in) {
+      const int64_t q = pos + __popcll(m & lanemask_lt());
+      inner[q] = A.inner[p];
+      val[q] = Av[p];
+    }
+    pos += __popcll(m);
+  }
+}
+struct StripCols { const int64_t* outer[16]; const int32_t* inner[16]; const void* val[16]; };
+__global__ void k_strip_total(StripCols P, int S, int n, int32_t* __restrict__ total) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int t = 0;
+  for (int s = 0; s < S; ++s) t += (int)(P.outer[s][j + 1] - P.outer[s][j]);
+  total[j] = t;
+}
+// column j of the result = its S pieces interleaved block by block (blocks of 1 << shift rows; block b belongs to piece
+// b % S and its entries sit together there, in row order): one wave per column, a lane per block
+template <typename T>
+__global__ __launch_bounds__(256) void k_strip_merge(StripCols P, int S, int shift, int n, const int64_t* __restrict__ outer,
+                                                     int32_t* __restrict__ inner, T* __restrict__ val) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= n) return;
+  const int lane = lane_id();
+  int rmin = INT_MAX, rmax = -1;
+  for (int s = 0; s < S; ++s) {
+    const int64_t a = P.outer[s][j], e = P.outer[s][j + 1];
+    if (e > a) {
+      rmin = min(rmin, P.inner[s][a]);
+      rmax = max(rmax, P.inner[s][e - 1]);
+    }
+  }
+  if (rmax < rmin) return;
+  int64_t base = outer[j];
+  for (int b0 = rmin >> shift; b0 <= (rmax >> shift); b0 += WAVE) {
+    const int b = b0 + lane;
+    const int s = b % S;
+    const int64_t a = P.outer[s][j], e = P.outer[s][j + 1];
+    // entries of piece s with row >> shift == b: [lo, hi)
+    int64_t lo = a, hi = e;
+    if (b <= (rmax >> shift)) {
+      const int r0 = b << shift;
+      int64_t x = a, y = e;
+      while (x < y) { const int64_t m = (x + y) >> 1; if (P.inner[s][m] < r0) x = m + 1; else y = m; }
+      lo = x;
+      y = e;
+      const long long r1 = ((long long)(b + 1)) << shift;
+      while (x < y) { const int64_t m = (x + y) >> 1; if ((long long)P.inner[s][m] < r1) x = m + 1; else y = m; }
+      hi = x;
+    } else {
+      lo = hi = a;
+    }
+    const int c = (int)(hi - lo);
+    int incl = c;   // inclusive prefix over the lanes
+    for (int o = 1; o < WAVE; o <<= 1) {
+      const int t = __shfl_up(incl, o, WAVE);
+      if (lane >= o) incl += t;
+    }
+    const int64_t dst = base + incl - c;
+    const T* __restrict__ sv = static_cast<const T*>(P.val[s]);
+    for (int i = 0; i < c; ++i) {
+      inner[dst + i] = P.inner[s][lo + i];
+      val[dst + i] = sv[lo + i];
+    }
+    base += __shfl(incl, WAVE - 1, WAVE);
+  }
+}
+__global__ void k_span_sum(const int32_t* __restrict__ cmin, const int32_t* __restrict__ cmax, int n, unsigned long long* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  long long v = (k < n && cmax[k] >= cmin[k]) ? (cmax[k] - cmin[k] + 1) : 0;
+  v = wave_sum_i64(v);
+  if (lane_id() == 0 && v) atomicAdd(out, (unsigned long long)v);
+}
+}  // namespace
+
+// C = alpha * A * B through S row strips of A (see above).  false: a strip still overflowed the grouped tables (C unset).
+static bool spgemm_striped(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, int S,
+                           int shift) {
+  const int n = B.cols;
+  std::vector<DevMat> piece((size_t)S);
+  StripCtx& ctx = strip_ctx();
+  for (int s = 0; s < S; ++s) {
+    DevMat As;
+    As.rows = A.rows; As.cols = A.cols; As.cplx = A.cplx; As.zero_free = A.zero_free;
+    DevBuf<int32_t> cnt((size_t)A.cols);
+    As.outer.alloc((size_t)A.cols + 1);
+    dispatch_type(A.cplx, [&](auto tag) {
+      using T = decltype(tag);
+      hipLaunchKernelGGL((k_strip_count<T>), dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), shift, S, s, cnt.p);
+    });
+    As.nnz = exclusive_scan_i64_from_i32(cnt.p, As.outer.p, A.cols);
+    As.inner.alloc((size_t)As.nnz + kIndexSlack);
+    As.val.alloc(((size_t)As.nnz + kIndexSlack) * As.wval());
+    dispatch_type(A.cplx, [&](auto tag) {
+      using T = decltype(tag);
+      hipLaunchKernelGGL((k_strip_fill<T>), dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A), shift, S, s,
+                         As.outer.p, As.inner.p, reinterpret_cast<T*>(As.val.p));
+    });
+    ctx.active = true;
+    ctx.failed = false;
+    spgemm(As, B, piece[(size_t)s], alpha, threshold, dense_rule, nullptr, nullptr, nullptr);
+    ctx.active = false;
+    if (ctx.failed) return false;
+  }
+  StripCols P;
+  for (int s = 0; s < 16; ++s) {
+    const DevMat& m = piece[(size_t)std::min(s, S - 1)];
+    P.outer[s] = m.outer.p; P.inner[s] = m.inner.p; P.val[s] = m.val.p;
+  }
+  DevBuf<int32_t> total((size_t)n);
+  hipLaunchKernelGGL(k_strip_total, dim3(cdiv(n, 256)), dim3(256), 0, stream(), P, S, n, total.p);
+  C.rows = A.rows; C.cols = n; C.cplx = A.cplx;
+  C.cnt.release();
+  C.slab.reset();
+  C.outer.alloc((size_t)n + 1);
+  C.nnz = exclusive_scan_i64_from_i32(total.p, C.outer.p, n);
+  C.inner.alloc((size_t)C.nnz + kIndexSlack);
+  C.val.alloc(((size_t)C.nnz + kIndexSlack) * C.wval());
+  dispatch_type(A.cplx, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((k_strip_merge<T>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), P, S, shift, n, C.outer.p,
+                       C.inner.p, reinterpret_cast<T*>(C.val.p));
+  });
+  sync_stream();   // (the pieces are released on return)
+  return true;
+}
+
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule,
             LooseProduct* loose, const ColRange* arange, SlabFusion* fuse) {
   if (loose) loose->valid = false;
@@ -3069,6 +3243,42 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       spgemm(Ap, Bp, C, alpha, threshold, dense_rule, loose, arange, nullptr);
     }
     return;
+  }
+  // a dimension whose products needed row strips last time (columns with more distinct rows than the grouped kernel's
+  // tables hold): straight to the strips, without the attempt on the whole operand
+  if (!use_slab && !grouped_done && !loose_in && !arange && sv_opt < 0 && options().spgemm_force_bin <= 0 && !strip_ctx().active &&
+      strips_memory(A.cplx)[0] == n && strips_memory(A.cplx)[1] >= 2 && m == A.cols) {
+    DevBuf<unsigned long long> ssum(1);
+    ssum.zero();
+    if (nka) hipLaunchKernelGGL(k_span_sum, dim3(cdiv(nka, 256)), dim3(256), 0, stream(), cmin_own.p, cmax_own.p, nka, ssum.p);
+    unsigned long long span_sum = 0;
+    {
+      ScalarFetch f;
+      f.add(ssum.p, 1, &span_sum);
+      f.run();
+    }
+    const double avg_span = (double)span_sum / (double)std::max(1, nka);
+    const int S = strips_memory(A.cplx)[1];
+    int shift = 6;
+    while ((1 << (shift + 1)) * 8.0 * S <= avg_span && shift < 24) ++shift;
+    if (timing) {
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+    }
+    if (spgemm_striped(A, B, C, alpha, threshold, dense_rule, S, shift)) {
+      SpgemmStats& ls = last_spgemm_stats();
+      ls.nnz_a = A.nnz;
+      ls.nnz_c = C.nnz;
+      ls.strips = S;
+      SpgemmAccum& ac = spgemm_accum();
+      ac.calls -= S - 1;
+      ac.alg_bytes -= (double)(S - 1) * ((A.cplx ? 20.0 : 12.0) * (double)B.nnz + 4.0 * (2.0 * n + A.cols + 3.0));
+      return;
+    }
+    strips_memory(A.cplx)[0] = -1;   // (did not fit this time: the ordinary path decides again)
+    t_all = EventTimer(timing);
+    t_num = EventTimer(timing);
+    t_all.start();
   }
   st.slab = use_slab ? 1 : 0;
   // real run-like operands under option spgemm_fma = 1: the same plan and operands, numeric phase on the matrix cores
@@ -3329,6 +3539,65 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       st.gh_minhash = gi.minhash;
       st.gh_union_ratio = gi.union_ratio;
       st.gh_tile_rows = gi.tile_rows;
+      // Most groups outgrew the largest table: the columns of the product hold too many distinct rows (a 3-D
+      // Hamiltonian).  Inside a strip multiply that is the answer; otherwise multiply in row strips of A (above), with
+      // twice the strips until every piece fits; the strip count that worked is remembered per dimension.
+      if (gi.failed_cols * 10 > (int64_t)n && sv_opt < 0 && !arange && !loose_in) {
+        StripCtx& sc = strip_ctx();
+        if (sc.active) {
+          sc.failed = true;
+          if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
+            std::fprintf(stderr, "spgemm strip: %lld of %d columns failed (groups %lld, table class %d, union ratio %.2f, nnzA %lld)\n",
+                         (long long)gi.failed_cols, n, (long long)gi.groups, gi.level, gi.union_ratio, (long long)A.nnz);
+          if (timing) {
+            event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+            event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+          }
+          C.reset_empty(m, n, A.cplx);
+          return;
+        }
+        int* mem = strips_memory(A.cplx);
+        DevBuf<unsigned long long> ssum(1);
+        ssum.zero();
+        if (nka) hipLaunchKernelGGL(k_span_sum, dim3(cdiv(nka, 256)), dim3(256), 0, stream(), cmin_own.p, cmax_own.p, nka, ssum.p);
+        unsigned long long span_sum = 0;
+        {
+          ScalarFetch f;
+          f.add(ssum.p, 1, &span_sum);
+          f.run();
+        }
+        const double avg_span = (double)span_sum / (double)std::max(1, nka);
+        if (timing) {   // (the strip multiplies time themselves)
+          event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+          event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+        }
+        for (int S = (mem[0] == n && mem[1] >= 2) ? mem[1] : 2; S <= 8; S *= 2) {
+          // blocks of rows: about eight per strip inside a column's extent, at least 64 rows
+          int shift = 6;
+          while ((1 << (shift + 1)) * 8.0 * S <= avg_span && shift < 24) ++shift;
+          if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
+            std::fprintf(stderr, "spgemm: %lld of %d columns beyond the grouped tables; trying %d strips, blocks of %d rows (mean extent %.0f)\n",
+                         (long long)gi.failed_cols, n, S, 1 << shift, avg_span);
+          if (spgemm_striped(A, B, C, alpha, threshold, dense_rule, S, shift)) {
+            mem[0] = n;
+            mem[1] = S;
+            SpgemmStats& ls = last_spgemm_stats();
+            ls.nnz_a = A.nnz;
+            ls.nnz_c = C.nnz;
+            ls.strips = S;
+            // (the strip multiplies accounted for themselves: one multiply, B read once as far as the algorithm goes)
+            SpgemmAccum& ac = spgemm_accum();
+            ac.calls -= S - 1;
+            ac.alg_bytes -= (double)(S - 1) * ((A.cplx ? 20.0 : 12.0) * (double)B.nnz + 4.0 * (2.0 * n + A.cols + 3.0));
+            return;
+          }
+        }
+        // (not even eight strips: the per-column kernels below take the columns; timers were handed back above)
+        t_all = EventTimer(timing);
+        t_num = EventTimer(timing);
+        t_all.start();
+        t_num.start();
+      }
     }
   }
   unsigned long long hash_big = 0;  // columns that outgrew the small hash table

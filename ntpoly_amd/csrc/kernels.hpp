@@ -18,6 +18,8 @@ struct SpgemmStats {
   // grouped LDS-hash path (spgemm_grouped.hip): 1 when it computed the product; columns handed back to the per-column
   // kernels, table class reached, min-hash clustering used, union ratio (1 = the columns of a group are identical)
   int grouped = 0;
+  int strips = 0;              // > 0: the product was computed in that many row strips of A (columns with too many distinct rows for
+                               // the grouped kernel's tables: kernels.hip spgemm_striped)
   int64_t gh_failed_cols = 0, gh_groups = 0, gh_tile_rows = 0;
   int gh_level = 0, gh_minhash = 0;
   double gh_union_ratio = 0;

@@ -213,8 +213,10 @@ __global__ __launch_bounds__(256) void k_gh_union(Csc A, Csc B, const int32_t* _
       if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > GH_KCAP) break;
       const int64_t p = p0 + lane;
       bool fresh = false;
-      if (p < e) {
-        const int k = B.inner[p];
+      const int k = p < e ? B.inner[p] : -1;
+      // (a row of B whose column of A is empty is no step: nothing to multiply -- row strips of A, kernels.hip
+      // spgemm_striped, leave most columns of a strip empty)
+      if (k >= 0 && A.outer[k + 1] > A.outer[k]) {
         unsigned h = (gh_hash((unsigned)k) >> 19) & (GH_KH - 1);
         for (;;) {
           const int old = atomicCAS(&hk[h], -1, k);
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(256) void k_gh_union(Csc A, Csc B, const int32_t* _
       const int64_t s = B.outer[col], e = B.outer[col + 1];
       for (int64_t p = s + lane; p < e; p += WAVE) {
         const int k = B.inner[p];
+        if (A.outer[k + 1] <= A.outer[k]) continue;   // (no step: see the union above)
         int lo = 0, hi = kn - 1;  // position of k in the sorted union
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(256) void k_gh_fill(Csc A, Csc B, const int32_t* __
     const int64_t s = B.outer[col], e = B.outer[col + 1];
     for (int64_t p = s + lane; p < e; p += WAVE) {
       const int k = B.inner[p];
+      if (A.outer[k + 1] <= A.outer[k]) continue;   // (an empty column of A is no step, as in k_gh_union)
       unsigned h = gh_hash((unsigned)k) >> SH;
       for (;;) {
         const int old = atomicCAS(&hk[h], -1, k);
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(256) void k_gh_fill(Csc A, Csc B, const int32_t* __
     const int64_t s = B.outer[col], e = B.outer[col + 1];
     for (int64_t p = s + lane; p < e; p += WAVE) {
       const int k = B.inner[p];
+      if (A.outer[k + 1] <= A.outer[k]) continue;
       unsigned h = gh_hash((unsigned)k) >> SH;
       while (hk[h] != k) h = (h + 1) & (KH - 1);
       tile[(int64_t)hp[h] * G + c] = Bv[p];
