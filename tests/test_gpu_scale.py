@@ -238,6 +238,79 @@ def test_relabelled_trs2_vs_oracle(nt, arith, label_order):
     assert np.abs(kv[ko] - ov[oo]).max() <= 1e-13
 
 
+def test_lattice_vs_oracle(nt, arith):
+    """An operand WITHOUT band structure that no relabelling can repair (tests/gen.py lattice_triplets: a 3-D lattice,
+    203 couplings per site, column extents of +-3 L^2 rows): products through the grouped LDS-hash kernel -- in row
+    strips of A where a column of the product holds more distinct rows than its tables (kernels.hip spgemm_striped) --
+    bit-exact against the oracle at 32^3 sites, and 6 TRS2 iterations at 24^3 (sigma, energies 1e-11, density pattern
+    equal and values 1e-13), in both arithmetic modes."""
+    from gen import lattice_triplets
+    from oracle import oracle_py as O
+    L, thr = 32, 1e-8
+    n = L ** 3
+    col, row, val = lattice_triplets(L)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    Ho = O.Mat.from_triplets(n, n, col, row, val)
+    C = nt.Matrix_ps(n)
+    C.Gemm(H, H, None, 1.0, 0.0, thr)
+    assert nt.last_spgemm_stats()["slab"] == 0
+    want = O.ps_multiply(Ho, Ho, None, 1.0, 0.0, thr)
+    D = nt.Matrix_ps(n)
+    D.Gemm(C, H, None, -0.5, 0.0, 1e-6)
+    want2 = O.ps_multiply(want, Ho, None, -0.5, 0.0, 1e-6)
+    for got, ref, tag in ((C, want, "H*H"), (D, want2, "(H*H)*H")):
+        kc, kr, kv = got.triplets()
+        oc, orow, ov = ref.triplets()
+        ko, oo = np.lexsort((kr, kc)), np.lexsort((orow, oc))
+        assert len(kv) == len(ov) and np.array_equal(kc[ko], oc[oo]) and np.array_equal(kr[ko], orow[oo]), tag
+        assert np.array_equal(kv[ko], ov[oo]), tag
+    del H, C, D, Ho, want, want2
+    L, iters = 24, 6
+    n = L ** 3
+    col, row, val = lattice_triplets(L)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    ISQ = nt.Matrix_ps(n)
+    ISQ.FillIdentity()
+    K = nt.Matrix_ps(n)
+    energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, _fixed_iteration_params(nt, iters, thr))
+    tr = nt.solver_trace()
+    Ho = O.Mat.from_triplets(n, n, col, row, val)
+    Ko, e_o, mu_o, tro = O.density("trs2", Ho, O.Mat.identity(n), n / 2.0,
+                                   O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr,
+                                            monitor_convergence=False))
+    assert np.array_equal(np.asarray(tr["sigma"]), np.asarray(tro["sigma"]))
+    assert np.allclose(tr["energy"], tro["energy"], rtol=1e-11, atol=0)
+    kc, kr, kv = K.triplets()
+    oc, orow, ov = Ko.triplets()
+    ko, oo = np.lexsort((kr, kc)), np.lexsort((orow, oc))
+    assert len(kv) == len(ov) and np.array_equal(kc[ko], oc[oo]) and np.array_equal(kr[ko], orow[oo])
+    assert np.abs(kv[ko] - ov[oo]).max() <= 1e-13
+
+
+def test_lattice_full_size_properties(nt):
+    """the 64^3 = 262 144-site lattice (bench.py --lattice 64) by size-independent properties: H * H through the strip
+    decomposition is symmetric to roundoff, trace(H * H) = sum of the squares of H's entries up to what the threshold
+    drops, the diagonal of H * H is the column norm squared, and a second multiply of the same dimension (which goes
+    straight to the remembered strip count) gives the same bits."""
+    from gen import lattice_triplets
+    L, thr = 64, 1e-8
+    n = L ** 3
+    col, row, val = lattice_triplets(L)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    fro2 = float((val * val).sum())
+    del col, row, val
+    C = nt.Matrix_ps(n)
+    C.Gemm(H, H, None, 1.0, 0.0, thr)
+    assert nt.last_spgemm_stats()["slab"] == 0
+    assert C.GetSize() > 2 * H.GetSize()
+    assert float(np.real(C.Trace())) == pytest.approx(fro2, rel=1e-12)
+    assert C.MeasureAsymmetry() <= 1e-12
+    C2 = nt.Matrix_ps(n)
+    C2.Gemm(H, H, None, 1.0, 0.0, thr)
+    C2.Increment(C, -1.0, 0.0)
+    assert C2.Norm() == 0.0
+
+
 def test_headline_config2_relabelled_full_size(nt):
     """BASELINE configs[2] under a random symmetric relabelling (N = 262 144, 201 per row) at FULL size: the loop in the
     recovered band order with label-ordered arithmetic (relabel.hip, fused slab kernel) against the same solve on the
