@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(world, tmp_path):
-    out = str(tmp_path / ("w%d" % world))
+def run_world(world, tmp_path, arith="unfused"):
+    out = str(tmp_path / ("w%d%s" % (world, arith)))
     name = "t%s" % uuid.uuid4().hex[:12]
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", NTPOLY_AMD_COMM="shm:" + name,
-                   NTPOLY_AMD_SHM_MB="8")
+                   NTPOLY_AMD_SHM_MB="8", NTPOLY_AMD_SPGEMM_FMA="1" if arith == "fma" else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -48,13 +48,23 @@ def cat(parts, tag):
 
 
 @pytest.fixture(scope="module")
-def reference(tmp_path_factory):
-    return run_world(1, tmp_path_factory.mktemp("ref"))[0]
+def references(tmp_path_factory):
+    """the one-rank run in either arithmetic mode (made on first use)"""
+    cache = {}
+
+    def get(arith):
+        if arith not in cache:
+            cache[arith] = run_world(1, tmp_path_factory.mktemp("ref_" + arith), arith)[0]
+        return cache[arith]
+    return get
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_multirank_equals_single_rank(world, reference, tmp_path):
-    parts = run_world(world, tmp_path)
+# (FMA arithmetic, option spgemm_fma = 1: the panel steps run on the MFMA tile kernel -- one row per lane, the halo
+# runs sit packed in the receive buffer -- and must reproduce the one-rank FMA run the same way)
+@pytest.mark.parametrize("world,arith", [(2, "unfused"), (3, "unfused"), (4, "unfused"), (2, "fma"), (4, "fma")])
+def test_multirank_equals_single_rank(world, arith, references, tmp_path):
+    reference = references(arith)
+    parts = run_world(world, tmp_path, arith)
     # panels tile the columns in rank order
     assert parts[0]["c0"] == 0 and all(parts[r]["c1"] == parts[r + 1]["c0"] for r in range(world - 1))
     for tag in ("AB", "ABT", "GG", "K"):

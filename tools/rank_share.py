@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""A MODEL of the 1 / 2 / 4 / 8-GPU strong-scaling curve of the headline workload from measurements on ONE GPU (no
+multi-GPU node is available to this project's boxes; the real curve is the driver's SCALE_rNN.json when it has one).
+
+One rank of P owns N / P columns of every matrix.  Its per-step work is measured here for what it is on the device:
+TRS2 steps on a banded operand of dimension N / P with the same half bandwidth (a panel of N / P columns of an N-wide
+band has the work of an (N / P)-wide band, boundary columns aside), through the same entry point as bench.py, with every
+launch and every host read-back of a one-rank step inside the timed region.  A panel step then adds, per step:
+
+  * one more host round trip than the one-rank step (exchange layout; DESIGN.md section 5: three instead of two) --
+    its cost is measured as the wall time of a device-to-host read-back of one scalar on the idle stream;
+  * the halo: the runs of the columns within one bandwidth of the panel's two edges, sent over two xGMI links at once,
+    bytes / (153 GB/s per link);
+  * the all-gather of one 8-byte extent record per column of the whole matrix over a ring of P - 1 hops.
+
+    python3 tools/rank_share.py [--n 262144] [--arithmetic fma] > profiles/r03_rank_share.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+XGMI_LINK_GBS = 153.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=262144)
+    ap.add_argument("--halfband", type=int, default=100)
+    ap.add_argument("--threshold", type=float, default=1e-8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arithmetic", choices=("fma", "unfused"), default="fma")
+    args = ap.parse_args()
+    import ntpoly_amd as nt
+    from gen import banded_triplets
+    from bench import trs2_step
+    nt.init_comm()
+    nt.ConstructGlobalProcessGrid(1, 1, 1)
+    nt.set_option("time_kernels", 1)
+    nt.set_option("spgemm_fma", 1 if args.arithmetic == "fma" else 0)
+    h, thr = args.halfband, args.threshold
+
+    # one host round trip: a scalar read back from an idle stream
+    tiny = nt.Matrix_ps(64)
+    tiny.FillIdentity()
+    tiny.Trace()
+    nt.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        tiny.Trace()
+    sync_us = (time.perf_counter() - t0) / 200 * 1e6
+
+    rows = []
+    for P in (1, 2, 4, 8):
+        n = args.n // P
+        col, row, val = banded_triplets(n, h)
+        H = nt.Matrix_ps.from_triplets(n, col, row, val)
+        del col, row, val
+        e_min, e_max = nt.EigenBounds.GershgorinBounds(H)
+        Ident = nt.Matrix_ps(n)
+        Ident.FillIdentity()
+        X = nt.Matrix_ps(H)
+        X.Scale(-1.0)
+        X.Increment(Ident, e_max, 0.0)
+        X.Scale(1.0 / (e_max - e_min))
+        X2 = nt.Matrix_ps(n)
+        pool = nt.PMatrixMemoryPool(H)
+        tr = None
+        for _ in range(args.warmup):
+            _, _, tr = trs2_step(nt, X, X2, H, pool, n / 2.0, thr, tr)
+        nt.reset_spgemm_accum()
+        s0 = nt.exchange_stats()[2]
+        nt.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _, energy, tr = trs2_step(nt, X, X2, H, pool, n / 2.0, thr, tr)
+        nt.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        syncs = (nt.exchange_stats()[2] - s0) / args.steps
+        acc = nt.spgemm_accum()
+        per_col = X.GetSize() / n                       # entries per column of the iterate = rows of a run
+        halo_bytes = 2.0 * (per_col / 2.0) * per_col * 8.0   # both edges: (bandwidth of X) columns x (run length) x 8 B
+        t_halo_us = (halo_bytes / 2.0) / (XGMI_LINK_GBS * 1e3) if P > 1 else 0.0      # two links in parallel
+        t_gather_us = (8.0 * args.n * (P - 1) / P) / (XGMI_LINK_GBS * 1e3) if P > 1 else 0.0
+        extra_sync_us = sync_us if P > 1 else 0.0
+        model_ms = dt * 1e3 + (extra_sync_us + t_halo_us + t_gather_us) * 1e-3
+        rows.append(dict(ranks=P, panel_columns=n, measured_share_ms_per_step=dt * 1e3,
+                         kernel_ms_per_step=acc["ms_numeric"] / max(1, acc["calls"]),
+                         host_syncs_per_step_measured=syncs, halo_bytes_per_step=halo_bytes, halo_us=t_halo_us,
+                         extent_allgather_us=t_gather_us, extra_host_round_trip_us=extra_sync_us,
+                         modelled_ms_per_step=model_ms, modelled_iters_per_s=1e3 / model_ms))
+        del H, X, X2, Ident, pool
+    base = rows[0]["modelled_ms_per_step"]
+    for r in rows:
+        r["modelled_speedup"] = base / r["modelled_ms_per_step"]
+        r["modelled_efficiency"] = r["modelled_speedup"] / r["ranks"]
+    print(json.dumps({
+        "what": "MODEL, not a measurement of several GPUs: one rank's share of a P-rank TRS2 step measured on ONE MI355X "
+                "(banded operand of dimension N / P, every launch and read-back of the step included) + one extra host round "
+                "trip + halo bytes / 153 GB/s per xGMI link + a ring all-gather of 8 B per column",
+        "n": args.n, "halfband": h, "threshold": thr, "arithmetic": args.arithmetic,
+        "host_round_trip_us": sync_us, "xgmi_link_GBps": XGMI_LINK_GBS, "table": rows}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
