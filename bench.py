@@ -57,9 +57,9 @@ def trs2_step_unfused(nt, X, X2, WH, pool, trace_target, thr):
 
 def cpu_baseline(n, h, thr, warmup, steps, permute=None, fma=False, lattice=None):
     """the oracle (C restatement with OpenMP, kind "port") at the FULL configuration size on all host cores, in the
-    arithmetic mode the GPU line ran in: TRS2 with warmup, warmup + 1, warmup + 2 and warmup + 3 iterations in one
-    process; the three differences are three samples of ONE iteration of the region the GPU line times (setup
-    excluded, as BASELINE.md section 2 measures the reference); the value is their median."""
+    arithmetic mode the GPU line ran in: one TRS2 solve of warmup + 3 iterations; the last three iterations, timed one by
+    one, are three samples of the region the GPU line times (setup excluded, as BASELINE.md section 2 measures the
+    reference); the value is their median."""
     from oracle import oracle_py as O
     from gen import banded_triplets, permuted_banded_triplets, lattice_triplets
     if lattice is not None:
@@ -73,22 +73,21 @@ def cpu_baseline(n, h, thr, warmup, steps, permute=None, fma=False, lattice=None
     I = O.Mat.identity(n)
     O.set_fma(fma)
 
-    def run(iters):
-        p = O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr, monitor_convergence=False)
-        t0 = time.perf_counter()
-        O.density("trs2", H, I, n / 2.0, p)
-        return time.perf_counter() - t0
-
+    # ONE run of warmup + 3 iterations; the oracle stamps the wall clock at the end of every iteration (otrace.stamp), so
+    # the last three differences are three samples of one iteration of the region the GPU line times
+    iters = max(1, warmup) + 3
     try:
-        ts = [run(warmup + k) for k in range(4)]
+        p = O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr, monitor_convergence=False)
+        _, _, _, tro = O.density("trs2", H, I, n / 2.0, p)
     finally:
         O.set_fma(False)
-    samples = sorted(max(1e-9, ts[k + 1] - ts[k]) for k in range(3))
-    per_iter = samples[1]
+    st = tro["stamp"]
+    samples = sorted(max(1e-9, float(st[k] - st[k - 1])) for k in range(max(1, len(st) - 3), len(st)))
+    per_iter = samples[len(samples) // 2]
     return {"value": 1.0 / per_iter, "unit": "iters/s", "cores": int(O.lib().oracle_num_threads()),
             "kind": "port",
             "sample": "oracle TRS2 (OpenMP, all host cores, %s arithmetic) at the full size N=%d (h=%d, thr=%g%s): iterations "
-                      "%d..%d, three single-iteration samples t(k + 1 iterations) - t(k iterations) = %s s, median %.3f s/iter; "
+                      "%d..%d of one solve, three single-iteration samples (wall clock stamped by the oracle after every iteration) = %s s, median %.3f s/iter; "
                       "no scaling" % ("fma" if fma else "unfused", n, h, thr,
                                       (", %d^3 lattice" % lattice) if lattice is not None else
                                       "" if permute is None else ", relabelled with seed %d" % permute, warmup + 1,

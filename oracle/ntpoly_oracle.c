@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -371,6 +372,7 @@ otrace *otrace_new(int32_t cap) {
   t->energy = (double *)calloc((size_t)cap + 1, sizeof(double));
   t->sigma = (double *)calloc((size_t)cap + 1, sizeof(double));
   t->nnz = (int64_t *)calloc((size_t)cap + 1, sizeof(int64_t));
+  t->stamp = (double *)calloc((size_t)cap + 1, sizeof(double));
   return t;
 }
 void otrace_free(otrace *t) {
@@ -379,6 +381,7 @@ void otrace_free(otrace *t) {
   free(t->energy);
   free(t->sigma);
   free(t->nnz);
+  free(t->stamp);
   free(t);
 }
 static void trace_rec(otrace *t, int it, double value, double energy, double sigma, int64_t nnz) {
@@ -387,6 +390,11 @@ static void trace_rec(otrace *t, int it, double value, double energy, double sig
   t->energy[it] = energy;
   t->sigma[it] = sigma;
   t->nnz[it] = nnz;
+  {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    t->stamp[it] = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+  }
   t->iterations = it + 1;
 }
 

@@ -82,6 +82,7 @@ typedef struct otrace {
   double *energy;      /* TRS2/TRS4 energy per iteration (else 0) */
   double *sigma;       /* TRS2 sigma per iteration */
   int64_t *nnz;        /* nnz of the iterate after the update */
+  double *stamp;       /* monotonic wall clock (seconds) when the iteration was recorded: differences time single iterations */
 } otrace;
 otrace *otrace_new(int32_t cap);
 void otrace_free(otrace *t);

@@ -29,7 +29,7 @@ class OParams(C.Structure):
 class _OTrace(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("cap", C.c_int32), ("value", C.POINTER(C.c_double)),
                 ("energy", C.POINTER(C.c_double)), ("sigma", C.POINTER(C.c_double)),
-                ("nnz", C.POINTER(C.c_int64))]
+                ("nnz", C.POINTER(C.c_int64)), ("stamp", C.POINTER(C.c_double))]
 
 
 class OMonitor(C.Structure):
@@ -297,7 +297,8 @@ def _trace_out(t):
                value=np.array([t.contents.value[i] for i in range(n)]),
                energy=np.array([t.contents.energy[i] for i in range(n)]),
                sigma=np.array([t.contents.sigma[i] for i in range(n)]),
-               nnz=np.array([t.contents.nnz[i] for i in range(n)], dtype=np.int64))
+               nnz=np.array([t.contents.nnz[i] for i in range(n)], dtype=np.int64),
+               stamp=np.array([t.contents.stamp[i] for i in range(n)]))
     lib().otrace_free(t)
     return out
 
