@@ -87,6 +87,7 @@ struct TileArgs {
   int k4max, tmax;
   const SlabFuseArgs* fz;
   const double* zero;   // 16 bytes of zeros: where the lanes outside a run load from
+  int ablate;           // experiment build (-DNTP_ABLATIONS) only
 #ifdef NTP_TILE_STAMPS
   long long* stamps;    // diagnostic build: [block][wave][64] s_memtime stamps
 #endif
@@ -296,21 +297,25 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
         g1 = c + 63 - (int)__builtin_clzll(m);
       }
     }
-    // what the epilogue reads, requested before the loop: this lane's elements are rows r0 + R (4 v + q) + m of column jj
+    // what the epilogue reads -- this lane's elements are rows r0 + R (4 v + q) + m of column jj -- is requested when
+    // the main loop is through (before its last PF - 1 groups and the group-range bookkeeping of the epilogue): held
+    // across the whole loop these values cost a wave of occupancy
     [[maybe_unused]] VR xv[4], dv[4];
     [[maybe_unused]] int plab[4][R];   // (label-ordered operands: the caller's label of every row of this lane)
+    auto epilogue_loads = [&]() {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int rb = r0 + R * (4 * v + q);
-      if constexpr (EPI == 2) xv[v] = rv_load<R>(((rb + R - 1 >= xf) & (rb <= xlrow)) ? xrz + rb : zp);
-      if constexpr (EPI != 0) {
-        dv[v] = rv_load<R>(((rb + R - 1 >= df) & (rb <= dl)) ? drz + rb : zp);
-        if constexpr (LAB) {
+      for (int v = 0; v < 4; ++v) {
+        const int rb = r0 + R * (4 * v + q);
+        if constexpr (EPI == 2) xv[v] = rv_load<R>(((rb + R - 1 >= xf) & (rb <= xlrow)) ? xrz + rb : zp);
+        if constexpr (EPI != 0) {
+          dv[v] = rv_load<R>(((rb + R - 1 >= df) & (rb <= dl)) ? drz + rb : zp);
+          if constexpr (LAB) {
 #pragma unroll
-          for (int m = 0; m < R; ++m) plab[v][m] = lab[min(rb + m, a.ncols - 1)];
+            for (int m = 0; m < R; ++m) plab[v][m] = lab[min(rb + m, a.ncols - 1)];
+          }
         }
       }
-    }
+    };
     v4d acc[R];
 #pragma unroll
     for (int m = 0; m < R; ++m) acc[m] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -326,9 +331,17 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
 #ifdef NTP_TILE_ABL_NOLOAD
       const unsigned long long abl_base = reinterpret_cast<unsigned long long>(a.out_val) & ~0x3fffull;   // (any mapped memory)
 #endif
+#ifdef NTP_ABLATIONS
+      const unsigned long long abl_base = reinterpret_cast<unsigned long long>(a.out_val) & ~0x3fffull;   // (any mapped memory)
+#endif
       auto run_load = [&](const uint4 raw) -> VR {
         const unsigned long long rz = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
         const bool ok = (unsigned)(rl - (int)raw.z) <= raw.w;
+#ifdef NTP_ABLATIONS
+        // (experiment build, WRONG results: option spgemm_variant 601 makes every run load hit a 16 KB window -- what the
+        // loop costs when the operand comes from L1)
+        if (a.ablate == 1) return rv_load<R>(ok ? abl_base + ((rz + r8 - abl_base) & 0x3fe0ull) : zaddr);
+#endif
         return rv_load<R>(ok ? rz + r8 : zaddr);
       };
       // slot u of the ring holds the A operand of group g + u; it is refilled (group g + u + PF) right after the matrix
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      epilogue_loads();
 #pragma unroll
       for (int u = 0; u < TILE_PF - 1; ++u) {
         if (g + u <= g1) {
@@ -370,7 +384,14 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
         }
       }
     }
+    else epilogue_loads();   // (no k group reaches the tile: entries of X alone)
     ++sidx; STAMP(sidx); ++sidx;
+#ifdef NTP_ABLATIONS
+    if (a.ablate == 2) {   // (experiment build, WRONG results: no epilogue at all)
+      if (acc[0][0] == 1.2345e300) colmask[t] = 1u;
+      continue;
+    }
+#endif
     // ---- epilogue of the tile: lane holds rows r0 + R (4 v + q) + m (v = 0..3, m = 0..R-1) of column jj
     {  // tiles in which nothing can be kept (about half of a window: the products beyond the band that survives the
        // threshold, no entry of X) are done here: nothing to merge, count or store
@@ -627,6 +648,7 @@ void launch_spgemm_tile(const TileLaunch& L) {
     zeros->zero();
   }
   a.zero = zeros->p;
+  a.ablate = options().spgemm_variant == 601 ? 1 : options().spgemm_variant == 602 ? 2 : 0;
 #ifdef NTP_TILE_STAMPS
   static DevBuf<long long>* stamps = nullptr;
   if (!stamps) stamps = new DevBuf<long long>(64 * 8 * 64);
@@ -637,7 +659,8 @@ void launch_spgemm_tile(const TileLaunch& L) {
   // waves per workgroup: eight when the LDS tile allows at most two workgroups per CU, four when three or more fit
   // (option tile_waves overrides)
   const bool wide = 3 * lds > 160 * 1024;
-  const int nw = options().tile_waves == 4 || options().tile_waves == 8 ? options().tile_waves : (wide ? 8 : 4);
+  const int tw = options().tile_waves;
+  const int nw = (tw == 4 || tw == 5 || tw == 6 || tw == 8) ? tw : (wide ? 8 : 4);
   auto go = [&](auto epi_tag, auto nw_tag, auto r_tag, auto lab_tag) {
     constexpr int E = decltype(epi_tag)::value, NW = decltype(nw_tag)::value, RR = decltype(r_tag)::value;
     constexpr bool LB = decltype(lab_tag)::value;
@@ -664,6 +687,8 @@ void launch_spgemm_tile(const TileLaunch& L) {
   };
   auto by_nw = [&](auto epi_tag) {
     if (nw == 8) by_r(epi_tag, std::integral_constant<int, 8>{});
+    else if (nw == 6) by_r(epi_tag, std::integral_constant<int, 6>{});
+    else if (nw == 5) by_r(epi_tag, std::integral_constant<int, 5>{});
     else by_r(epi_tag, std::integral_constant<int, 4>{});
   };
   if (L.epi == 0) by_nw(std::integral_constant<int, 0>{});
