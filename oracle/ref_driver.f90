@@ -613,6 +613,9 @@ CONTAINS
     CHARACTER(len=32) :: solver
     INTEGER :: u
     INTEGER(KIND=8) :: knnz
+    TYPE(Permutation_t) :: perm
+    CHARACTER(len=512) :: permfile
+    INTEGER :: pstat, pn, pi
     CALL make_grid(2)
     solver = sarg(5)
     CALL load_ps(sarg(6), H)
@@ -624,9 +627,33 @@ CONTAINS
     END IF
     IF (IsRoot()) CALL ActivateLogger(start_document_in=.TRUE., &
          & file_name_in=TRIM(sarg(14)))
-    CALL ConstructSolverParameters(sp, converge_diff_in=rarg(10), &
-         & threshold_in=rarg(9), max_iterations_in=iarg(11), &
-         & be_verbose_in=.TRUE., monitor_convergence_in=(iarg(12) .NE. 0))
+    !! REF_PERM=<file>: a load-balancing permutation given explicitly (one 1-based index_lookup value per line), so that
+    !! the engine can be driven with the very same permutation (the reference's own comes from the Fortran RNG)
+    CALL GET_ENVIRONMENT_VARIABLE("REF_PERM", permfile, STATUS=pstat)
+    IF (pstat .EQ. 0 .AND. LEN_TRIM(permfile) .GT. 0) THEN
+       pn = H%actual_matrix_dimension
+       ALLOCATE(perm%index_lookup(H%logical_matrix_dimension))
+       ALLOCATE(perm%reverse_index_lookup(H%logical_matrix_dimension))
+       DO pi = 1, H%logical_matrix_dimension   ! (rows of the padding stay where they are)
+          perm%index_lookup(pi) = pi
+       END DO
+       OPEN(NEWUNIT=u, FILE=TRIM(permfile), STATUS="OLD")
+       DO pi = 1, pn
+          READ(u, *) perm%index_lookup(pi)
+       END DO
+       CLOSE(u)
+       DO pi = 1, H%logical_matrix_dimension
+          perm%reverse_index_lookup(perm%index_lookup(pi)) = pi
+       END DO
+       CALL ConstructSolverParameters(sp, converge_diff_in=rarg(10), &
+            & threshold_in=rarg(9), max_iterations_in=iarg(11), &
+            & be_verbose_in=.TRUE., monitor_convergence_in=(iarg(12) .NE. 0), &
+            & BalancePermutation_in=perm)
+    ELSE
+       CALL ConstructSolverParameters(sp, converge_diff_in=rarg(10), &
+            & threshold_in=rarg(9), max_iterations_in=iarg(11), &
+            & be_verbose_in=.TRUE., monitor_convergence_in=(iarg(12) .NE. 0))
+    END IF
     energy = 0; mu = 0
     SELECT CASE(TRIM(solver))
     CASE("trs2")

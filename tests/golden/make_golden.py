@@ -672,6 +672,50 @@ def gen_scale_logs(tmp):
     save("scale_logs", d, dict(kind="scale_logs", cases=cases))
 
 
+def gen_scale_logs_lb(tmp):
+    """a LOAD-BALANCED converged TRS2 solve of the REAL reference on 8 ranks at N = 16 384, h = 100
+    (DensityMatrixSolversModule.F90 with do_load_balancing: LoadBalancerModule.F90:14-52 permutes H and the result with
+    the solver parameters' permutation).  The permutation is given to the reference explicitly (ref_driver REF_PERM;
+    its own would come from the Fortran RNG) and stored with the case, so the engine is driven with the very same one.
+    APPENDS the case to tests/golden/scale_logs.npz (the other cases are kept as they are)."""
+    path = os.path.join(OUT, "scale_logs.npz")
+    old = np.load(path, allow_pickle=False)
+    d = {k: old[k] for k in old.files if k != "meta"}
+    meta = json.loads(str(old["meta"]))
+    cases = [c for c in meta["cases"] if c["tag"] != "banded16384_h100_trs2_lb"]
+    n, h, nranks, thr, conv = 16384, 100, 8, 1e-8, 1e-6
+    H = banded(n, h, False)
+    write_tri(tmp + "/H.tri", n, n, *tri(H))
+    perm = (np.random.default_rng(20260716).permutation(n) + 1).astype(np.int32)   # index_lookup, 1-based
+    np.savetxt(tmp + "/perm.txt", perm, fmt="%d")
+    ENV["REF_PERM"] = tmp + "/perm.txt"
+    try:
+        run(["solve", nranks, 1, 1, "trs2", tmp + "/H.tri", "identity", repr(n / 2.0), repr(thr), repr(conv), 1000, 1,
+             tmp + "/K.tri", tmp + "/log.yaml", tmp + "/s.txt"], nranks=nranks)
+    finally:
+        del ENV["REF_PERM"]
+    parts = [read_tri(tmp + "/K.tri.%d" % q) for q in range(nranks)]
+    c = np.concatenate([q[2] for q in parts])
+    r = np.concatenate([q[3] for q in parts])
+    v = np.concatenate([q[4] for q in parts])
+    sc = {k: float(x) for k, x in (ln.split() for ln in open(tmp + "/s.txt"))}
+    assert len(v) == int(sc["nnz"])
+    lc, le, total = parse_log(tmp + "/log.yaml")
+    pre = "c%03d_" % len(cases)
+    d[pre + "log_convergence"] = np.array(lc)
+    d[pre + "log_energy"] = np.array(le)
+    d[pre + "perm"] = perm
+    diag = v[c == r]
+    cases.append(dict(tag="banded16384_h100_trs2_lb", solver="trs2", n=n, h=h, cplx=False, shift=0.0, nel=n / 2.0, thr=thr,
+                      conv=conv, maxit=1000, monitor=True, energy=sc["energy"], mu=sc["mu"], nnz=int(sc["nnz"]),
+                      total_iterations_logged=total, grid=[nranks, 1, 1], load_balanced=True,
+                      trace_re=float(np.real(diag).sum()), frob2=float((np.abs(v) ** 2).sum()),
+                      sum_re=float(np.real(v).sum()), sum_im=float(np.imag(v).sum())))
+    print("banded16384_h100_trs2_lb iterations", total, "nnz", int(sc["nnz"]), flush=True)
+    meta["cases"] = cases
+    save("scale_logs", d, meta)
+
+
 def gen_slices(tmp):
     """K-split (process slices > 1) semantics of the reference's distributed multiply (MatrixMultiply.f90:25-29,
     230-267, comm_includes/ReduceAndSumMatrixCleanup.f90): every slice multiplies its share of the inner dimension
