@@ -3,9 +3,10 @@ well beyond the small goldens, and one full-size comparison of the headline work
 
   * TRS2 energies after 2 and 8 iterations and nnz(K) measured with the reference itself
     (flang build, 8 ranks) at N = 8 192 / 16 384 (h = 50 and h = 100) / 32 768 -- scalars, asserted here;
-  * tests/golden/scale_logs.npz (make_golden.py scale_logs, the reference on 8 ranks): per-iteration convergence /
-    energy logs of converged TRS2 and TRS4 solves at N = 16 384, h = 100, and of the complex InverseSquareRoot (H + 2I)
-    and SignFunction (the indefinite H) at N = 8 192 -- iteration counts must be equal, energies 1e-11;
+  * tests/golden/scale_logs.npz (make_golden.py scale_logs / scale_logs_lb, the reference on 8 ranks): per-iteration
+    convergence / energy logs of converged TRS2 and TRS4 solves at N = 16 384, h = 100 -- TRS2 also LOAD-BALANCED under
+    a stored permutation -- and of the complex InverseSquareRoot (H + 2I) and SignFunction (the indefinite H) at
+    N = 8 192 -- iteration counts must be equal, energies 1e-11;
   * configs[4] SignFunction on the UNSHIFTED Hermitian H (sign != I), by its defining properties at N = 131 072;
   * configs[2] itself (N = 262 144, 201 per row): 8 TRS2 iterations against the oracle's, energies and the density.
 """
@@ -93,6 +94,13 @@ def test_scale_logs_vs_reference(nt, arith, idx, c):
     p.SetConvergeDiff(c["conv"])
     p.SetMaxIterations(c["maxit"])
     p.SetMonitorConvergence(c["monitor"])
+    if c.get("load_balanced"):
+        # the reference ran WITH load balancing (LoadBalancerModule.F90:14-52) under a permutation it was handed
+        # explicitly (oracle/ref_driver.f90 REF_PERM); the engine is driven with the same one: the relabelled operand,
+        # the recovery of its band, the label-aware steps and the way back are all on the path of this solve
+        perm = nt.Permutation(n)
+        perm.set_lookup(g.arr(idx, "perm"))
+        p.SetLoadBalance(perm)
     K = nt.Matrix_ps(n)
     if c["solver"] in ("trs2", "trs4"):
         ISQ = nt.Matrix_ps(n)
