@@ -126,12 +126,24 @@ constexpr size_t kIndexSlack = 1024;
 //   block b of 16 columns: the same entries as a row-major tile (k - kmin_b) x 16 at tiles[tile_off[b] ...], where
 //   kmin_b .. kmax_b is the union of the blocks' column ranges.
 // count[j] = entries of column j.  pack() turns it into compressed columns.
+// block windows / k ranges of a step X * X on a slab-form X (k_slab_plan) and the three sizes a launch needs from them
+struct SlabPlan {
+  DevBuf<int32_t> blk_lo, blk_w, blk_kmin, blk_kn;
+  DevBuf<int64_t> blk_toff;   // blocks + 1
+  int64_t total = 0;          // output slots
+  int max_w = 0, max_kn = 0;  // widest window, longest k range
+  int align = 0;              // window alignment the plan was made for
+};
 struct SlabForm {
   DevBuf<int32_t> first, last, count;
   DevBuf<int64_t> off;        // cols + 1
   DevBuf<int64_t> tile_off;   // blocks + 1
   DevBuf<double> val, tiles;
   int64_t slots = 0;          // doubles addressable in val / tiles
+  // the plan of the NEXT step on this iterate (kernels.hip slab_step, option plan_ahead): blocks' windows and k ranges
+  // follow from the column extents alone, so the step that produced the iterate computes them right behind its
+  // kernel and reads their sizes back together with its own results -- the next step launches without a read-back
+  std::unique_ptr<SlabPlan> next_plan;
   int row_pad = 1;            // > 1 (a multiple of 16): every column's slot holds row r at a position = r (mod row_pad) and reads as
                               // ZERO from the multiple of row_pad below its first row to the one above its last (results of the
                               // MFMA tile kernel, spgemm_tile.hpp, which reads several consecutive rows per lane)

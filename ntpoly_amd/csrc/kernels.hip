@@ -2558,6 +2558,7 @@ EngineOptions& options() {
     if (const char* v = std::getenv("NTPOLY_AMD_SPGEMM_FMA")) e->spgemm_fma = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_TILE_ROWS")) e->tile_rows = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_TILE_WAVES")) e->tile_waves = std::atoi(v);
+    if (const char* v = std::getenv("NTPOLY_AMD_PLAN_AHEAD")) e->plan_ahead = std::atoi(v);
     return e;
   }();
   return *o;
@@ -3936,6 +3937,23 @@ __global__ __launch_bounds__(256) void k_col_plast(Csc A, const int32_t* __restr
 }
 }  // namespace
 
+namespace {
+// the plan of a step X * X from the column extents of X (device arrays of n columns; a panel step: the extents of the
+// columns ka .. of the distributed iterate on the A side); sizes are left on the device in stats[16..18] / blk_toff[snb]
+void launch_slab_plan(SlabPlan& P, int n, const int32_t* first, const int32_t* last, const int32_t* afirst, const int32_t* alast,
+                      int align, unsigned long long* stats) {
+  const int snb = cdiv(n, SLAB_J);
+  P.blk_lo.alloc(snb); P.blk_w.alloc(snb); P.blk_kmin.alloc(snb); P.blk_kn.alloc(snb);
+  P.blk_toff.alloc((size_t)snb + 1);
+  P.align = align;
+  DevBuf<int64_t> bsz(snb), tsz(snb);
+  hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, first, last, afirst,
+                     alast, P.blk_lo.p, P.blk_w.p, P.blk_kmin.p, P.blk_kn.p, bsz.p, tsz.p, snb, align);
+  hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), P.blk_w.p, P.blk_kn.p, snb, (const int32_t*)nullptr, 0, stats);
+  scan_async<int64_t>(tsz.p, P.blk_toff.p, (int64_t)snb);
+}
+}  // namespace
+
 bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, const SlabHalo* halo) {
   fu.done = false;
   if (!X.expanded() || X.cplx || (!halo && X.rows != X.cols) || !fu.D || fu.D->cplx || fu.D->loose() || fu.D->expanded() ||
@@ -3960,34 +3978,44 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   t_all.start();
   SpgemmStats st;
   st.nnz_a = st.nnz_b = X.nnz;
-  // ---- plan (column extents only)
-  DevBuf<int32_t> blk_lo(snb), blk_w(snb), blk_kmin(snb), blk_kn(snb), count((size_t)n), ofirst((size_t)n), olast((size_t)n);
-  DevBuf<int64_t> bsz(snb), tsz(snb), blk_toff((size_t)snb + 1), tmpoff((size_t)n + 1);
-  // [flag 2 | product entries per block snb + 1 | (unused) snb | (dot, trace) per block 2 snb | plan statistics 24]
-  DevBuf<int64_t> zwords((size_t)4 * snb + 4 + 24);
+  // ---- plan (column extents only): left behind by the step that produced X (option plan_ahead), or made here and
+  // read back before the launch
+  DevBuf<int32_t> count((size_t)n), ofirst((size_t)n), olast((size_t)n);
+  DevBuf<int64_t> tmpoff((size_t)n + 1);
+  // [flag 2 | product entries per block snb + 1 | (unused) snb | (dot, trace) per block 2 snb | plan statistics 24 |
+  //  statistics of the next step's plan 24]
+  DevBuf<int64_t> zwords((size_t)4 * snb + 4 + 48);
   zwords.zero();
   count.zero();
   int64_t* fz_flag = zwords.p;
   int64_t* fz_pnnz = zwords.p + 2;
   double* fz_part = reinterpret_cast<double*>(zwords.p + 3 + 2 * (size_t)snb);
   unsigned long long* stats = reinterpret_cast<unsigned long long*>(zwords.p + 4 * (size_t)snb + 4);
+  unsigned long long* next_stats = stats + 24;
   // (A side: the iterate's own columns, or -- a panel step -- the columns ka .. kb of the distributed iterate,
   // addressed with global column numbers through biased pointers)
   const int ka = halo ? halo->ka : 0, nka = halo ? halo->kb - halo->ka : n;
-  const int32_t* afirst = halo ? halo->first - ka : in.first.p;
-  const int32_t* alast = halo ? halo->last - ka : in.last.p;
-  hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, in.first.p,
-                     in.last.p, afirst, alast, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb, tile ? 16 * tile_rows() : 0);
-  hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, (const int32_t*)nullptr, 0, stats);
-  scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
-  int64_t tmp_total = 0;
-  unsigned long long hst[3] = {0, 0, 0};
-  {
+  const int plan_align = tile ? 16 * tile_rows() : 0;
+  SlabPlan own_plan;
+  SlabPlan* plan = &own_plan;
+  if (!halo && in.next_plan && in.next_plan->align == plan_align && (int64_t)in.next_plan->blk_lo.n == snb) {
+    plan = in.next_plan.get();
+  } else {
+    const int32_t* afirst = halo ? halo->first - ka : in.first.p;
+    const int32_t* alast = halo ? halo->last - ka : in.last.p;
+    launch_slab_plan(own_plan, n, in.first.p, in.last.p, afirst, alast, plan_align, stats);
+    unsigned long long hs[3] = {0, 0, 0};
     ScalarFetch f;
-    f.add(blk_toff.p + snb, 1, &tmp_total);
-    f.add(stats + 16, 3, hst);
+    f.add(own_plan.blk_toff.p + snb, 1, &own_plan.total);
+    f.add(stats + 16, 3, hs);
     f.run();
+    own_plan.max_w = (int)hs[0];
+    own_plan.max_kn = (int)hs[1];
   }
+  DevBuf<int32_t>&blk_lo = plan->blk_lo, &blk_w = plan->blk_w, &blk_kmin = plan->blk_kmin, &blk_kn = plan->blk_kn;
+  DevBuf<int64_t>& blk_toff = plan->blk_toff;
+  const int64_t tmp_total = plan->total;
+  const unsigned long long hst[2] = {(unsigned long long)plan->max_w, (unsigned long long)plan->max_kn};
   const int64_t max_w = (int64_t)hst[0];
   auto give_up = [&]() {
     if (timing) {
@@ -4108,15 +4136,33 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     hipLaunchKernelGGL(k_pack_reduce4, dim3(1), dim3(1), 0, stream(), tot.p, reinterpret_cast<const int*>(fz_flag), red4.p);
     halo->reduce->allreduce(red4.p);
   }
+  // the plan of the next step on the result, right behind this one's kernel: its sizes come back with the totals
+  std::unique_ptr<SlabPlan> next;
+  unsigned long long next_hs[3] = {0, 0, 0};
+  if (tile && !halo && options().plan_ahead != 0) {
+    next.reset(new SlabPlan());
+    launch_slab_plan(*next, n, ofirst.p, olast.p, ofirst.p, olast.p, plan_align, next_stats);
+  }
   {
     ScalarFetch f;
     f.add(tot.p, 5, raw);
     f.add(fz_flag, 1, flagv);
     if (red4.p) f.add(red4.p, 4, halo->reduce->reduced);
+    if (next) {
+      f.add(next->blk_toff.p + snb, 1, &next->total);
+      f.add(next_stats + 16, 3, next_hs);
+    }
     f.run();
     if (red4.p) halo->reduce->done = true;
   }
   t_all.stop();
+  if (next) {
+    next->max_w = (int)next_hs[0];
+    next->max_kn = (int)next_hs[1];
+  }
+  if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
+    std::fprintf(stderr, "[slab_step] mode %d slots %lld w %llu kn %llu in-slots %lld nnz-in %lld plan %s\n", fu.mode, (long long)tmp_total,
+                 hst[0], hst[1], (long long)in.slots, (long long)X.nnz, plan == &own_plan ? "made here" : "left by the step before");
   if (timing) {
     if (pending_timings().size() >= 4096) flush_spgemm_timers();
     pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
@@ -4141,8 +4187,9 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   R.slab->last = std::move(olast);
   R.slab->count = std::move(count);
   R.slab->row_pad = tile ? 16 * trows : 1;
+  R.slab->next_plan = std::move(next);
   R.slab->off = tile ? std::move(tile_ooff) : std::move(tmpoff);
-  R.slab->tile_off = tile ? std::move(tile_otoff) : std::move(blk_toff);
+  R.slab->tile_off = tile ? std::move(tile_otoff) : std::move(own_plan.blk_toff);   // (not the tile kernel: never a plan from before)
   R.slab->val = std::move(oval);
   R.slab->tiles = std::move(otiles);
   R.slab->slots = tmp_total;

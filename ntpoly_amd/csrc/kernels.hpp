@@ -34,6 +34,9 @@ struct EngineOptions {
   int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
                                // reference built with FP contraction computes); 0: separate multiply and add (default, bit-
                                // identical to the reference built without contraction)
+  int plan_ahead = 1;          // TRS2 steps on the slab form (tile kernel, one rank): the step plans its successor behind its own kernel and
+                               // reads the sizes back with its results -- one host round trip per step instead of two;
+                               // 0: every step makes its plan and reads it back before the launch
   int operand_cache = 1;       // 1: the expanded WH (and WH in a recovered band order) of a purification solve stays on the
                                // device for the next solve on the same operand (SCF loops): at most 8 (nnz + 32 n) + 12 nnz + 8 n
                                // bytes, replaced when the operand changes; 0: freed at the end of every solve;

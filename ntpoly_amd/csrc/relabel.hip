@@ -91,12 +91,14 @@ __global__ void k_pos_from_order(const int32_t* __restrict__ order, int n, int32
 
 // One whole breadth-first search in ONE launch of a few co-resident workgroups: levels are separated by a barrier over
 // the grid (an atomic counter in memory), not by launches and host round trips -- a band of 262 144 columns has 2 600
-// levels of a hundred vertices.  Positions are handed out in discovery order; the order inside a level is settled by
-// the barycenter rounds afterwards.  ctl: [0] barrier counter, [1..3] rotating level-size counters (level L appends to
+// levels of a hundred vertices.  Inside a level the vertices are placed Cuthill-McKee fashion, by the position of their
+// FIRST neighbour in the level before (key[], an atomicMin during the expansion), ties by vertex number: the same
+// order from run to run, and one that already follows the band (the barycenter rounds afterwards only polish it;
+// placing a level by vertex number alone -- tried -- costs them a fifth of the recovered bandwidth).  ctl: [0] barrier counter, [1..3] rotating level-size counters (level L appends to
 // ctl[1 + L % 3]; the counter of level L + 1 is cleared during level L, two barriers after its last reader).
 // out[0] = vertices reached, out[1] = levels, out[2] = the vertex of the last level with the fewest neighbours.
 constexpr int kBfsBlocks = 8;
-constexpr int kBfsLevelMax = 4096;   // vertices of a level ranked in LDS (16 KB)
+constexpr int kBfsLevelMax = 2048;   // vertices of a level ranked in LDS (24 KB)
 __device__ inline void grid_barrier(unsigned* __restrict__ counter, unsigned nblocks, unsigned& epoch) {
   __threadfence();
   __syncthreads();
@@ -111,7 +113,7 @@ __device__ inline void grid_barrier(unsigned* __restrict__ counter, unsigned nbl
 }
 __global__ __launch_bounds__(1024) void k_bfs_multi(const int64_t* __restrict__ outer, const int32_t* __restrict__ inner,
                                                     int start, int base, int32_t* __restrict__ dist, int32_t* __restrict__ pos,
-                                                    int32_t* __restrict__ cur, int32_t* __restrict__ nxt,
+                                                    int32_t* __restrict__ cur, int32_t* __restrict__ nxt, int32_t* __restrict__ key,
                                                     unsigned* __restrict__ ctl, unsigned long long* __restrict__ best,
                                                     long long* __restrict__ out) {
   const int lane = lane_id();
@@ -124,33 +126,48 @@ __global__ __launch_bounds__(1024) void k_bfs_multi(const int64_t* __restrict__ 
     pos[start] = base;
   }
   grid_barrier(ctl, gridDim.x, epoch);
+  // every workgroup ranks the whole level in its own LDS (a hundred vertices: ten comparisons per thread) and so knows
+  // the placed order of the frontier without reading what another workgroup wrote since the last barrier
+  __shared__ unsigned long long lvl[kBfsLevelMax];
+  __shared__ int srt[kBfsLevelMax];
+  bool placed = false;   // the frontier's placed order is in srt (otherwise: arrival order, in cur)
   int reached = 1, level = 0, nf = 1;
   for (;;) {
     unsigned* cnt = ctl + 1 + level % 3;
     if (gtid == 0) __hip_atomic_store(ctl + 1 + (level + 1) % 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int fbase = base + reached - nf;   // position of the frontier's first vertex
     for (int w = gwave; w < nf; w += nwaves) {
-      const int v = __hip_atomic_load(cur + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int v = placed ? srt[w] : __hip_atomic_load(cur + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int pv = fbase + w;
       for (int64_t p = outer[v] + lane, e = outer[v + 1]; p < e; p += WAVE) {
         const int u = inner[p];
-        if (__hip_atomic_load(dist + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0 && atomicCAS(&dist[u], -1, level + 1) == -1)
+        const int d = __hip_atomic_load(dist + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d < 0 && atomicCAS(&dist[u], -1, level + 1) == -1)
           __hip_atomic_store(nxt + atomicAdd(cnt, 1u), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d < 0 || d == level + 1) atomicMin(&key[u], pv);   // (a vertex of the next level, whoever claimed it)
       }
     }
     grid_barrier(ctl, gridDim.x, epoch);
     const int nl = (int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nl == 0) break;
-    // positions inside the level: by vertex number, not by the order in which the atomics above happened to arrive -- the
-    // recovered order (and with it the path a borderline operand takes) is the same from run to run.  Levels that fit
-    // the workgroup's LDS copy are ranked there; a wider level (no band in sight) keeps its arrival order.
-    if (nl <= kBfsLevelMax) {
-      __shared__ int lvl[kBfsLevelMax];
-      for (int i = threadIdx.x; i < nl; i += blockDim.x) lvl[i] = __hip_atomic_load(nxt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // positions inside the level: by (first neighbour in the level before, vertex number), not by the order in which
+    // the atomics above happened to arrive -- the recovered order (and with it the path a borderline operand takes) is
+    // the same from run to run.  A level wider than the LDS copy (no band in sight) keeps its arrival order.
+    placed = nl <= kBfsLevelMax;
+    if (placed) {
+      for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+        const int v = __hip_atomic_load(nxt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int kv = __hip_atomic_load(key + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lvl[i] = ((unsigned long long)(unsigned)kv << 32) | (unsigned)v;
+      }
       __syncthreads();
-      for (int i = gtid; i < nl; i += nthreads) {
-        const int v = lvl[i];
+      for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+        const unsigned long long me = lvl[i];
         int rank = 0;
-        for (int q = 0; q < nl; ++q) rank += lvl[q] < v ? 1 : 0;
-        pos[v] = base + reached + rank;
+        for (int q = 0; q < nl; ++q) rank += lvl[q] < me ? 1 : 0;
+        const int v = (int)(unsigned)(me & 0xffffffffull);
+        srt[rank] = v;
+        if (i % (int)gridDim.x == (int)blockIdx.x) pos[v] = base + reached + rank;
       }
       __syncthreads();
     } else {
@@ -178,6 +195,8 @@ __global__ __launch_bounds__(1024) void k_bfs_multi(const int64_t* __restrict__ 
 int bfs_from(const DevMat& A, int start, int base, DevBuf<int32_t>& dist, DevBuf<int32_t>& pos, DevBuf<int32_t>& cur,
              DevBuf<int32_t>& nxt, int* last_vertex, int* levels) {
   DevBuf<long long> out(3);
+  DevBuf<int32_t> key((size_t)A.cols);
+  hipLaunchKernelGGL(k_fill_i32v, dim3(cdiv(A.cols, 256)), dim3(256), 0, stream(), key.p, (int64_t)A.cols, INT_MAX);
   DevBuf<unsigned> ctl(4);
   DevBuf<unsigned long long> best(1);
   ctl.zero();
@@ -188,11 +207,11 @@ int bfs_from(const DevMat& A, int start, int base, DevBuf<int32_t>& dist, DevBuf
     // CU-masked or partitioned device that cannot hold them refuses the launch instead of hanging in the barrier)
     const int64_t* a_outer = A.outer.p;
     const int32_t* a_inner = A.inner.p;
-    int32_t *p_dist = dist.p, *p_pos = pos.p, *p_cur = cur.p, *p_nxt = nxt.p;
+    int32_t *p_dist = dist.p, *p_pos = pos.p, *p_cur = cur.p, *p_nxt = nxt.p, *p_key = key.p;
     unsigned* p_ctl = ctl.p;
     unsigned long long* p_best = best.p;
     long long* p_out = out.p;
-    void* args[] = {&a_outer, &a_inner, &start, &base, &p_dist, &p_pos, &p_cur, &p_nxt, &p_ctl, &p_best, &p_out};
+    void* args[] = {&a_outer, &a_inner, &start, &base, &p_dist, &p_pos, &p_cur, &p_nxt, &p_key, &p_ctl, &p_best, &p_out};
     HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_bfs_multi), dim3(kBfsBlocks), dim3(1024), args, 0, stream()));
   }
   long long h[3] = {0, 0, 0};

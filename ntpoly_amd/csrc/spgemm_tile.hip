@@ -21,6 +21,7 @@
 // computes and that the reference computes when it is built with FP contraction: the two
 // kernels agree bit for bit, and both with the contracted reference build.  Zero padding is exact (fma(0, b, x) = x).
 #include "spgemm_tile.hpp"
+#include <string>
 
 #include <hip/hip_runtime.h>
 
@@ -90,11 +91,13 @@ struct TileArgs {
   int ablate;           // experiment build (-DNTP_ABLATIONS) only
 #ifdef NTP_TILE_STAMPS
   long long* stamps;    // diagnostic build: [block][wave][64] s_memtime stamps
+  long long* blkdur;    // diagnostic build: [block][4] = start, end (s_memtime), deferred elements, k range
 #endif
 };
 
-__host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax) {
-  return (size_t)(k4max + TILE_BPAD) * 16 * 8 + (size_t)(k4max + TILE_RPAD) * sizeof(TileRec) + (size_t)tmax * 4 + (size_t)(k4max / 4 + 1) * 8 + 16 + TILE_DEFER * sizeof(TileDefer) + 16 * 5 * 4 +
+// (lab_rows: label-aware instantiations keep the caller's labels of the window's rows in LDS)
+__host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax, int lab_rows = 0) {
+  return (size_t)lab_rows * 4 + (size_t)(k4max + TILE_BPAD) * 16 * 8 + (size_t)(k4max + TILE_RPAD) * sizeof(TileRec) + (size_t)tmax * 4 + (size_t)(k4max / 4 + 1) * 8 + 16 + TILE_DEFER * sizeof(TileDefer) + 16 * 5 * 4 +
          2 * 8 * 8 + 64;
 }
 
@@ -105,7 +108,7 @@ __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax) {
 #endif
 
 template <int EPI, int TILE_NW, int R, bool LAB>
-__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(EPI == 0 ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
+__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((EPI == 0 || R <= 2) ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = xcd_block(a.nblocks);
   if (b < 0) return;
@@ -128,6 +131,9 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
     return;
   }
   STAMP(0);
+#ifdef NTP_TILE_STAMPS
+  if (tid == 0 && a.blkdur) a.blkdur[4 * b] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- LDS
   double* Bs = reinterpret_cast<double*>(smem);                                    // [k4max][16]
   TileRec* recs = reinterpret_cast<TileRec*>(Bs + (size_t)(a.k4max + TILE_BPAD) * 16);   // [k4max + TILE_RPAD]
@@ -142,6 +148,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
   int* col_plast = col_pmax + 16;
   double* red = reinterpret_cast<double*>(col_plast + 16);                         // [2 * 8]
   int* misc = reinterpret_cast<int*>(red + 2 * 8);                           // [0] deferred, [1] product entries, [2..3] products
+  [[maybe_unused]] int* labs = misc + 4;                                     // LAB: [tmax * 16 R] the caller's label of every row of the window
 
   const int KG = (kn + 3) >> 2, K4 = KG * 4;
   constexpr int TROWS = 16 * R;   // rows of a tile: R matrix instructions per k group (the window is a multiple, the host sees to it)
@@ -233,6 +240,10 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
       if (lane == 0 && p) atomicAdd(reinterpret_cast<unsigned long long*>(misc + 2), (unsigned long long)p);
     }
   }
+  if constexpr (LAB) {
+    const int32_t* __restrict__ lab_g = a.fz->lab;
+    for (int i = tid; i < T * TROWS; i += TILE_NW * WAVE) labs[i] = lab_g[min(lo + i, a.ncols - 1)];
+  }
   __syncthreads();
   STAMP(1);
 
@@ -247,13 +258,11 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
   [[maybe_unused]] double* otile = nullptr;
   [[maybe_unused]] int xf = INT_MAX, xlrow = -1, xpl = -1, df = INT_MAX, dl = -1;
   [[maybe_unused]] const double *xrz = zp, *drz = zp;
-  [[maybe_unused]] const int32_t* lab = nullptr;
   [[maybe_unused]] double am = 0, bm = 0, thr_m = 0;
   [[maybe_unused]] int diag = -1;
   if constexpr (EPI != 0) {
     const SlabFuseArgs* __restrict__ fz = a.fz;
     otile = fz->tiles + (tbase - (int64_t)lo * SLAB_J + jj);                // otile[r * 16] = row r, column jj of the tile
-    lab = fz->lab;
     const int d0 = fz->dmin[jc], d1 = fz->dmax[jc];
     if (colv && d1 >= d0) {
       df = d0;
@@ -301,7 +310,6 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
     // the main loop is through (before its last PF - 1 groups and the group-range bookkeeping of the epilogue): held
     // across the whole loop these values cost a wave of occupancy
     [[maybe_unused]] VR xv[4], dv[4];
-    [[maybe_unused]] int plab[4][R];   // (label-ordered operands: the caller's label of every row of this lane)
     auto epilogue_loads = [&]() {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
@@ -309,10 +317,6 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
         if constexpr (EPI == 2) xv[v] = rv_load<R>(((rb + R - 1 >= xf) & (rb <= xlrow)) ? xrz + rb : zp);
         if constexpr (EPI != 0) {
           dv[v] = rv_load<R>(((rb + R - 1 >= df) & (rb <= dl)) ? drz + rb : zp);
-          if constexpr (LAB) {
-#pragma unroll
-            for (int m = 0; m < R; ++m) plab[v][m] = lab[min(rb + m, a.ncols - 1)];
-          }
         }
       }
     };
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
         [[maybe_unused]] int pr = r;
         if constexpr (EPI != 0) {
           dval = rv_get<R>(dv[v], m);
-          if constexpr (LAB) pr = plab[v][m];   // ("beyond the other column's last entry" compares the caller's labels)
+          if constexpr (LAB) pr = labs[r - lo];   // ("beyond the other column's last entry" compares the caller's labels)
         }
         if constexpr (EPI != 2) {
           keep = ha;
@@ -451,9 +455,9 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
             if (hb && !big) {
               const int slot = atomicAdd(&misc[0], 1);
               if (slot < TILE_DEFER) {
-                TileDefer e;
-                e.r = r; e.jj = jj; e.prow = pr; e.pad = 0; e.o = o; e.d = dval;
-                dlist[slot] = e;
+                *reinterpret_cast<int4*>(&dlist[slot]) = make_int4(r, jj, pr, 0);
+                dlist[slot].o = o;
+                dlist[slot].d = dval;
               }
             }
           }
@@ -521,16 +525,31 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
       if (tid == 0) atomicOr(a.fz->flag, 1);
     } else {
       for (int i = tid; i < nd; i += TILE_NW * WAVE) {
-        TileDefer e = dlist[i];
-        const bool kept = e.prow > col_pmax[e.jj];
+        const int4 e = *reinterpret_cast<const int4*>(&dlist[i]);   // (r, jj, prow, pad)
+        const bool kept = e.z > col_pmax[e.y];
         if (kept) {
-          atomicAdd(&col_cnt[e.jj], 1);
-          atomicMin(&col_first[e.jj], e.r);
-          atomicMax(&col_last[e.jj], e.r);
-          if constexpr (LAB) atomicMax(&col_plast[e.jj], e.prow);
+          atomicAdd(&col_cnt[e.y], 1);
+          atomicMin(&col_first[e.y], e.x);
+          atomicMax(&col_last[e.y], e.x);
+          if constexpr (LAB) atomicMax(&col_plast[e.y], e.z);
         }
-        e.pad = kept ? 1 : 0;
-        dlist[i] = e;
+        dlist[i].pad = kept ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    // the kept ones contribute to the sums in (row, column) order -- reproducible, whatever order the list was filled
+    // in: every element finds its rank among the kept ones and leaves its terms there (the multiplier tile is no longer
+    // needed: k4max >= 8 rows of 16 hold 2 x TILE_DEFER values)
+    if (nd <= TILE_DEFER && tid < nd) {
+      const TileDefer e = dlist[tid];
+      if (e.pad) {
+        int rank = 0;
+        for (int m2 = 0; m2 < nd; ++m2) {
+          const TileDefer f = dlist[m2];
+          rank += (f.pad && (f.r < e.r || (f.r == e.r && f.jj < e.jj))) ? 1 : 0;
+        }
+        Bs[rank] = __dmul_rn(e.o, e.d);
+        Bs[TILE_DEFER + rank] = (e.r == b * SLAB_J + e.jj + a.fz->col_offset) ? e.o : 0.0;
       }
     }
     __syncthreads();
@@ -567,21 +586,13 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
         x = __dadd_rn(x, red[2 * qq]);
         y = __dadd_rn(y, red[2 * qq + 1]);
       }
-      if constexpr (EPI == 2) {   // kept deferred elements, in (row, column) order: reproducible sums
+      if constexpr (EPI == 2) {   // kept deferred elements, in (row, column) order (ranked above)
         const int nd = min(misc[0], TILE_DEFER);
-        int lr = -1, lj = -1;
-        for (int n2 = 0; n2 < nd; ++n2) {
-          int best = -1, br = INT_MAX, bj = INT_MAX;
-          for (int m2 = 0; m2 < nd; ++m2) {
-            const int r2 = dlist[m2].r, j2 = dlist[m2].jj;
-            const bool after = r2 > lr || (r2 == lr && j2 > lj);
-            if (dlist[m2].pad && after && (r2 < br || (r2 == br && j2 < bj))) { best = m2; br = r2; bj = j2; }
-          }
-          if (best < 0) break;
-          const TileDefer e = dlist[best];
-          x = __dadd_rn(x, __dmul_rn(e.o, e.d));
-          if (e.r == b * SLAB_J + e.jj + a.fz->col_offset) y = __dadd_rn(y, e.o);
-          lr = br; lj = bj;
+        int nk = 0;
+        for (int m2 = 0; m2 < nd; ++m2) nk += dlist[m2].pad;
+        for (int m2 = 0; m2 < nk; ++m2) {
+          x = __dadd_rn(x, Bs[m2]);
+          y = __dadd_rn(y, Bs[TILE_DEFER + m2]);
         }
       }
       a.fz->part[2 * b] = x;
@@ -617,6 +628,14 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(E
       }
     }
   }
+  STAMP(55);
+#ifdef NTP_TILE_STAMPS
+  if (tid == 0 && a.blkdur) {
+    a.blkdur[4 * b + 1] = __builtin_amdgcn_s_memtime();
+    a.blkdur[4 * b + 2] = EPI == 2 ? misc[0] : 0;
+    a.blkdur[4 * b + 3] = kn;
+  }
+#endif
 }
 
 }  // namespace
@@ -627,8 +646,8 @@ int tile_rows() {
 }
 
 bool spgemm_tile_fits(int max_kn, int max_w) {
-  const int k4 = (max_kn + 3) & ~3, tm = (max_w + 15) >> 4;
-  return max_kn > 0 && max_w > 0 && tile_lds_bytes(k4, tm) <= 150 * 1024;
+  const int k4 = std::max(8, (max_kn + 3) & ~3), tm = (max_w + 15) >> 4;
+  return max_kn > 0 && max_w > 0 && tile_lds_bytes(k4, tm, 16 * tm + 64) <= 150 * 1024;   // (with the labels of a label-aware step)
 }
 
 void launch_spgemm_tile(const TileLaunch& L) {
@@ -638,7 +657,7 @@ void launch_spgemm_tile(const TileLaunch& L) {
   a.blk_toff = L.blk_toff; a.out_val = L.out_val; a.count = L.count; a.ofirst = L.ofirst; a.olast = L.olast; a.ooff = L.ooff;
   a.otoff = L.otoff; a.alpha = L.alpha; a.threshold = L.threshold; a.dense_rule = L.dense_rule; a.ncols = L.ncols;
   a.nblocks = L.nblocks;
-  a.k4max = (L.max_kn + 3) & ~3;
+  a.k4max = std::max(8, (L.max_kn + 3) & ~3);   // (>= 8: the multiplier tile doubles as scratch for 2 x TILE_DEFER sums)
   const int trows = 16 * (L.rows == 4 ? 4 : L.rows == 2 ? 2 : 1);
   a.tmax = (L.max_w + trows - 1) / trows;
   a.fz = static_cast<const SlabFuseArgs*>(L.fz);
@@ -654,10 +673,16 @@ void launch_spgemm_tile(const TileLaunch& L) {
   if (!stamps) stamps = new DevBuf<long long>(64 * 8 * 64);
   stamps->zero();
   a.stamps = stamps->p;
+  static DevBuf<long long>* blkdur = nullptr;
+  if (!blkdur || blkdur->n < (size_t)4 * L.nblocks) { delete blkdur; blkdur = new DevBuf<long long>((size_t)4 * L.nblocks); }
+  blkdur->zero();
+  a.blkdur = blkdur->p;
 #endif
-  const size_t lds = tile_lds_bytes(a.k4max, a.tmax);
-  // waves per workgroup: eight when the LDS tile allows at most two workgroups per CU, four when three or more fit
-  // (option tile_waves overrides)
+  const size_t lds = tile_lds_bytes(a.k4max, a.tmax, (L.labelled && L.epi != 0) ? a.tmax * trows : 0);
+  // waves per workgroup (option tile_waves overrides): four when three or more workgroups fit a CU's LDS (more
+  // independent blocks: the prologue of one runs under the main loop of the others), eight when only two fit.  (Every
+  // default instantiation -- one or two rows per lane -- stays within 128 registers per lane, four waves per SIMD, so two
+  // workgroups of eight are resident together; six waves, tried where only three waves fit a SIMD, were slower.)
   const bool wide = 3 * lds > 160 * 1024;
   const int tw = options().tile_waves;
   const int nw = (tw == 4 || tw == 5 || tw == 6 || tw == 8) ? tw : (wide ? 8 : 4);
@@ -672,34 +697,39 @@ void launch_spgemm_tile(const TileLaunch& L) {
     }
     hipLaunchKernelGGL((k_spgemm_tile<E, NW, RR, LB>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
   };
-  auto by_r = [&](auto epi_tag, auto nw_tag) {
-    constexpr int E0 = decltype(epi_tag)::value;
-    if constexpr (E0 != 0) {
-      if (L.labelled) {   // (label-ordered operands: two or one rows per lane)
-        if (L.rows >= 2) go(epi_tag, nw_tag, std::integral_constant<int, 2>{}, std::true_type{});
-        else go(epi_tag, nw_tag, std::integral_constant<int, 1>{}, std::true_type{});
+  auto by_nw = [&](auto epi_tag, auto r_tag, auto lab_tag) {
+    if (nw == 4) go(epi_tag, std::integral_constant<int, 4>{}, r_tag, lab_tag);
+    else if (nw == 5) go(epi_tag, std::integral_constant<int, 5>{}, r_tag, lab_tag);
+    else if (nw == 6) go(epi_tag, std::integral_constant<int, 6>{}, r_tag, lab_tag);
+    else go(epi_tag, std::integral_constant<int, 8>{}, r_tag, lab_tag);
+  };
+  auto by_r = [&](auto epi_tag) {
+    constexpr int E = decltype(epi_tag)::value;
+    using F = std::false_type; using T = std::true_type;
+    using R1 = std::integral_constant<int, 1>; using R2 = std::integral_constant<int, 2>; using R4 = std::integral_constant<int, 4>;
+    if constexpr (E != 0) {
+      if (L.labelled) {   // (two or one rows per lane; the layout of four is one of two as well)
+        if (L.rows >= 2) by_nw(epi_tag, R2{}, T{});
+        else by_nw(epi_tag, R1{}, T{});
         return;
       }
     }
-    if (L.rows == 4) go(epi_tag, nw_tag, std::integral_constant<int, 4>{}, std::false_type{});
-    else if (L.rows == 2) go(epi_tag, nw_tag, std::integral_constant<int, 2>{}, std::false_type{});
-    else go(epi_tag, nw_tag, std::integral_constant<int, 1>{}, std::false_type{});
+    if (L.rows == 4) by_nw(epi_tag, R4{}, F{});
+    else if (L.rows == 2) by_nw(epi_tag, R2{}, F{});
+    else by_nw(epi_tag, R1{}, F{});
   };
-  auto by_nw = [&](auto epi_tag) {
-    if (nw == 8) by_r(epi_tag, std::integral_constant<int, 8>{});
-    else if (nw == 6) by_r(epi_tag, std::integral_constant<int, 6>{});
-    else if (nw == 5) by_r(epi_tag, std::integral_constant<int, 5>{});
-    else by_r(epi_tag, std::integral_constant<int, 4>{});
-  };
-  if (L.epi == 0) by_nw(std::integral_constant<int, 0>{});
-  else if (L.epi == 1) by_nw(std::integral_constant<int, 1>{});
-  else by_nw(std::integral_constant<int, 2>{});
+  if (L.epi == 0) by_r(std::integral_constant<int, 0>{});
+  else if (L.epi == 1) by_r(std::integral_constant<int, 1>{});
+  else by_r(std::integral_constant<int, 2>{});
 #ifdef NTP_TILE_STAMPS
   if (const char* f = std::getenv("NTP_TILE_STAMPS_FILE")) {
     std::vector<long long> h(64 * 8 * 64);
     HIP_CHECK(hipStreamSynchronize(stream()));
     HIP_CHECK(hipMemcpy(h.data(), stamps->p, h.size() * 8, hipMemcpyDeviceToHost));
     if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
+    std::vector<long long> hb((size_t)4 * L.nblocks);
+    HIP_CHECK(hipMemcpy(hb.data(), blkdur->p, hb.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* fp = std::fopen((std::string(f) + ".blocks").c_str(), "wb")) { std::fwrite(hb.data(), 8, hb.size(), fp); std::fclose(fp); }
   }
 #endif
 }

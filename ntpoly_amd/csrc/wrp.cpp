@@ -136,6 +136,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   if (n == "spgemm_force_bin") options().spgemm_force_bin = *value;
   else if (n == "increment_force_seq") options().increment_force_seq = *value;
   else if (n == "spgemm_fma") options().spgemm_fma = *value;
+  else if (n == "plan_ahead") options().plan_ahead = *value;
   else if (n == "operand_cache") options().operand_cache = *value;
   else if (n == "tile_rows") options().tile_rows = *value;
   else if (n == "tile_waves") options().tile_waves = *value;
