@@ -4000,6 +4000,8 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   SlabPlan* plan = &own_plan;
   if (!halo && in.next_plan && in.next_plan->align == plan_align && (int64_t)in.next_plan->blk_lo.n == snb) {
     plan = in.next_plan.get();
+  } else if (halo && halo->plan && halo->plan->align == plan_align && (int64_t)halo->plan->blk_lo.n == snb) {
+    plan = halo->plan;
   } else {
     const int32_t* afirst = halo ? halo->first - ka : in.first.p;
     const int32_t* alast = halo ? halo->last - ka : in.last.p;
@@ -4189,7 +4191,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   R.slab->row_pad = tile ? 16 * trows : 1;
   R.slab->next_plan = std::move(next);
   R.slab->off = tile ? std::move(tile_ooff) : std::move(tmpoff);
-  R.slab->tile_off = tile ? std::move(tile_otoff) : std::move(own_plan.blk_toff);   // (not the tile kernel: never a plan from before)
+  R.slab->tile_off = tile ? std::move(tile_otoff) : std::move(plan->blk_toff);   // (the slab loop's result keeps the plan's tile offsets)
   R.slab->val = std::move(oval);
   R.slab->tiles = std::move(otiles);
   R.slab->slots = tmp_total;
@@ -5108,6 +5110,31 @@ __global__ void k_widen_i32(const int32_t* __restrict__ src, long long* __restri
   if (j < n) dst[j] = src[j];
 }
 }  // namespace
+
+namespace {
+__global__ void k_unpack_extents(const long long* __restrict__ ext_all, int pitch, int dim, int P, int32_t* __restrict__ gfirst,
+                                 int32_t* __restrict__ glast) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= dim) return;
+  int s = (int)(((long long)k * P) / dim);   // owner: the panel whose range holds k
+  while (s > 0 && (int)(((long long)dim * s) / P) > k) --s;
+  while (s + 1 < P && (int)(((long long)dim * (s + 1)) / P) <= k) ++s;
+  const int c0 = (int)(((long long)dim * s) / P);
+  const long long e = ext_all[(size_t)s * pitch + (k - c0)];
+  gfirst[k] = (int)(unsigned)(e & 0xffffffffll);
+  glast[k] = (int)(e >> 32);
+}
+}  // namespace
+
+void slab_plan_panel_async(const DevMat& X, const int64_t* d_ext_all, int pitch, int32_t dim, int P, SlabPlan& plan,
+                           DevBuf<int32_t>& gfirst, DevBuf<int32_t>& glast, unsigned long long* stats24) {
+  gfirst.alloc((size_t)dim);
+  glast.alloc((size_t)dim);
+  hipLaunchKernelGGL(k_unpack_extents, dim3(cdiv(dim, 256)), dim3(256), 0, stream(), reinterpret_cast<const long long*>(d_ext_all),
+                     pitch, dim, P, gfirst.p, glast.p);
+  const bool tile = options().spgemm_fma == 1;
+  launch_slab_plan(plan, X.cols, X.slab->first.p, X.slab->last.p, gfirst.p, glast.p, tile ? 16 * tile_rows() : 0, stats24);
+}
 
 void slab_request_async(const DevMat& X, int64_t* d_out4) {
   const long long init[2] = {INT_MAX, -1};

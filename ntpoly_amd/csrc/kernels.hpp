@@ -138,7 +138,16 @@ struct SlabHalo {   // A side of a panel step: the columns ka .. kb (global numb
   const unsigned long long* addr = nullptr;  // [kb - ka] device: address of its run (own buffer or receive buffer)
   const int32_t* count = nullptr;            // [kb - ka] device, optional (statistics): entries of the column
   SlabReduce* reduce = nullptr;
+  // optional: the plan of this step, made by the caller from the all-gathered extents and read back together with the
+  // exchange layout (slab_plan_panel_async) -- the step then launches without a read-back of its own (and may keep
+  // the plan's buffers for its result)
+  SlabPlan* plan = nullptr;
 };
+// the plan of a panel step from the all-gathered packed extents (record stride `pitch`, extents at d_ext_all): flat
+// extent arrays of all `dim` columns are left in gfirst / glast, the plan's sizes on the device in plan.blk_toff[blocks]
+// and stats24[16..17] (stats24: 24 zeroed words)
+void slab_plan_panel_async(const DevMat& X, const int64_t* d_ext_all, int pitch, int32_t dim, int P, SlabPlan& plan,
+                           DevBuf<int32_t>& gfirst, DevBuf<int32_t>& glast, unsigned long long* stats24);
 // halo != nullptr: X is this rank's column panel; on success the result is left in fuse.result (not installed)
 bool slab_step(DevMat& X, SlabFusion& fuse, double threshold, bool dense_rule, const SlabHalo* halo = nullptr);
 // halo exchange of a panel in slab form (psmatrix.cpp ps_slab_step_dist): request record (first row, last row, nnz, nnz),

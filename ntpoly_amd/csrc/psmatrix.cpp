@@ -535,18 +535,33 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   HIP_CHECK(hipMemcpy2DAsync(d_req.p, 4 * sizeof(int64_t), d_all.p, (size_t)pitch * sizeof(int64_t), 4 * sizeof(int64_t), (size_t)P,
                              hipMemcpyDeviceToDevice, stream()));
   halo_counts_async(d_req.p, d_pre_all, pitch, dim, P, me, d_cnt.p, d_bound.p);   // (counts in doubles here)
+  // the step's plan (block windows and k ranges follow from the extents alone) is made here, from the gathered
+  // extents, so that its sizes come back in the same read-back as the exchange layout
+  SlabPlan plan;
+  DevBuf<int32_t> gfirst, glast;
+  DevBuf<int64_t> plan_stats(24);
+  plan_stats.zero();
+  unsigned long long plan_hs[2] = {0, 0};
+  const int snb = (B.loc.cols + 15) / 16;
+  slab_plan_panel_async(B.loc, d_ext_all, pitch, dim, P, plan, gfirst, glast, reinterpret_cast<unsigned long long*>(plan_stats.p));
   if ((size_t)4 * P + (size_t)P * P + 2 * P <= 500) {
     ScalarFetch f;
     f.add(d_req.p, 4 * P, req.data());
     f.add(d_bound.p, 2 * P, bound.data());
     f.add(d_cnt.p, P * P, cnt.data());
+    f.add(plan.blk_toff.p + snb, 1, &plan.total);
+    f.add(plan_stats.p + 16, 2, plan_hs);
     f.run();
   } else {
     HIP_CHECK(hipMemcpyAsync(req.data(), d_req.p, (size_t)4 * P * 8, hipMemcpyDeviceToHost, stream()));
     HIP_CHECK(hipMemcpyAsync(bound.data(), d_bound.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, stream()));
     HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(&plan.total, plan.blk_toff.p + snb, 8, hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(plan_hs, plan_stats.p + 16, 16, hipMemcpyDeviceToHost, stream()));
     sync_stream();
   }
+  plan.max_w = (int)plan_hs[0];
+  plan.max_kn = (int)plan_hs[1];
   exchange_stats().host_syncs += host_sync_count() - syncs_before;   // (the exchange's own: measured in sync_stream)
   exchange_stats().exchanges += 1;
   int64_t nnz_global = 0;
@@ -603,6 +618,7 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   halo.last = nlast.p;
   halo.addr = naddr.p;
   halo.count = ncount.p;
+  halo.plan = &plan;
   red.allreduce = &dev_allreduce4;
   halo.reduce = &red;
   const double denom = (double)dim * (double)dim;

@@ -82,7 +82,7 @@ def main():
     res["trs2_products"], res["trs2_nnz_c"] = acc["products"], acc["nnz_c"]
     f1, e1 = nt.fusion_counts(), nt.exchange_stats()
     res["trs2_fused"] = np.array([f1[k] - f0[k] for k in ("square", "update", "repeated")])
-    res["trs2_exchanges"] = np.array([e1[0] - e0[0], e1[1] - e0[1]])
+    res["trs2_exchanges"] = np.array([e1[0] - e0[0], e1[1] - e0[1], e1[2] - e0[2]])
     tr = nt.solver_trace()
     res["trs2_energy"], res["trs2_mu"], res["trs2_iters"] = energy, mu, tr["iterations"]
     res["trs2_log"] = np.array(tr["energy"])

@@ -7,7 +7,7 @@ TRS2 steps on a banded operand of dimension N / P with the same half bandwidth (
 band has the work of an (N / P)-wide band, boundary columns aside), through the same entry point as bench.py, with every
 launch and every host read-back of a one-rank step inside the timed region.  A panel step then adds, per step:
 
-  * one more host round trip than the one-rank step (exchange layout; DESIGN.md section 5: three instead of two) --
+  * one more host round trip than the one-rank step (exchange layout + plan; DESIGN.md section 5: two instead of one) --
     its cost is measured as the wall time of a device-to-host read-back of one scalar on the idle stream;
   * the halo: the runs of the columns within one bandwidth of the panel's two edges, sent over two xGMI links at once,
     bytes / (153 GB/s per link);
