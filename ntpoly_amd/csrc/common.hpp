@@ -144,6 +144,10 @@ struct SlabForm {
   // follow from the column extents alone, so the step that produced the iterate computes them right behind its
   // kernel and reads their sizes back together with its own results -- the next step launches without a read-back
   std::unique_ptr<SlabPlan> next_plan;
+  // A matrix that STORES zero values (a Hamiltonian with a zero on its diagonal) cannot be told from its slab form
+  // alone: slab_enter keeps the compressed columns it came from here, the slab form is then a read-only view for
+  // products, dots and column norms (DevMat::zero_free = 0), and pack() hands the original back
+  std::shared_ptr<struct DevMat> origin;
   int row_pad = 1;            // > 1 (a multiple of 16): every column's slot holds row r at a position = r (mod row_pad) and reads as
                               // ZERO from the multiple of row_pad below its first row to the one above its last (results of the
                               // MFMA tile kernel, spgemm_tile.hpp, which reads several consecutive rows per lane)

@@ -85,6 +85,24 @@ void panel_range(int32_t dim, int nranks, int rank, int32_t* c0, int32_t* c1);
 void ps_construct_empty(PSMatrix& m, int32_t dim, const ProcessGrid* g, bool cplx);
 void ps_construct_like(PSMatrix& m, const PSMatrix& ref);
 void ps_copy(const PSMatrix& a, PSMatrix& b);
+// Slab session (psmatrix.cpp): while one is open -- a solver loop, one rank, real operands, FMA arithmetic, option
+// slab_algebra -- ps_multiply / ps_axpby / ps_increment / ps_copy / ps_scale / ps_dot / ps_norm / ps_gershgorin keep
+// their operands and results in slab form (kernels.hpp, slab algebra) instead of compressed columns; the loop's owner
+// packs what leaves it (ps_slab_leave).  Any operation that cannot be done in slab form packs its operands and takes
+// the general path; after one refusal the session stays off.
+struct SlabSession {
+  explicit SlabSession(bool eligible);
+  ~SlabSession();
+  SlabSession(const SlabSession&) = delete;
+  SlabSession& operator=(const SlabSession&) = delete;
+  void close();   // (the loop is over: what follows works on compressed columns again)
+  bool opened = false;
+};
+// Out = alpha A + beta B: CopyMatrix(B, Out); ScaleMatrix(Out, beta); IncrementMatrix(A, Out, alpha, threshold) -- in a
+// slab session one pass without the copy (and B, an identity say, is turned into slab form once instead of its copies)
+void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double alpha, double beta, double threshold);
+void ps_slab_leave(PSMatrix& m);
+const long long* slab_algebra_counts();   // [4] since start: products, merges / copies, other operations done in slab form; refusals   // back to compressed columns (no-op for a matrix that is not in slab form)
 void ps_fill_identity(PSMatrix& m);
 void ps_fill_permutation(PSMatrix& m, const std::vector<int32_t>& lookup /*1-based*/, bool rows);
 void ps_fill_from_triplets(PSMatrix& m, const HostTriplets& t);

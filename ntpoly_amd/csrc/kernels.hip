@@ -2559,6 +2559,7 @@ EngineOptions& options() {
     if (const char* v = std::getenv("NTPOLY_AMD_TILE_ROWS")) e->tile_rows = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_TILE_WAVES")) e->tile_waves = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_PLAN_AHEAD")) e->plan_ahead = std::atoi(v);
+    if (const char* v = std::getenv("NTPOLY_AMD_SLAB_ALGEBRA")) e->slab_algebra = std::atoi(v);
     return e;
   }();
   return *o;
@@ -4476,6 +4477,7 @@ void dot_trace_impl(const DevMat& A, const DevMat& B, double out[2], double* tra
 DevMat packed_copy(const DevMat& M) {
   if (M.expanded()) {
     const SlabForm& f = *M.slab;
+    if (f.origin) return f.origin->clone();
     DevMat R;
     R.rows = M.rows;
     R.cols = M.cols;
@@ -5432,6 +5434,432 @@ void to_triplets(const DevMat& A, int32_t col_offset, HostTriplets& out) {
   for (int32_t j = 0; j < A.cols; ++j)
     for (int64_t p = outer[(size_t)j]; p < outer[(size_t)j + 1]; ++p) out.col[(size_t)p] = j + 1 + col_offset;
   for (size_t i = 0; i < n; ++i) out.row[i] += 1;
+}
+
+
+// ------------------------------------------------------------------------------------- slab algebra
+// The vocabulary of the solver loops (product, B <- alpha A + beta B, copy, scale, dot, column norms) on matrices that
+// STAY in slab form between the operations (SlabForm: dense column runs in aligned zero-padded slots): a product leaves
+// its result where the tile kernel wrote it, the merges are passes over two runs per column, nothing is compacted to
+// compressed columns and expanded again.  Real, unlabelled, square, one rank, FMA arithmetic (the MFMA tile kernel);
+// every function refuses what it cannot take and leaves its operands as they were (the callers in psmatrix.cpp pack
+// and take the general path).  A zero inside a run reads as "no entry" (DevMat::zero_free).
+namespace {
+// slot of the union of two runs per column (B may be absent)
+__global__ void k_sa_span(const int32_t* __restrict__ fa, const int32_t* __restrict__ la, const int32_t* __restrict__ fb,
+                          const int32_t* __restrict__ lb, int n, int al, int32_t* __restrict__ span) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int f = fa[j], l = la[j];
+  if (fb) {
+    const int f2 = fb[j], l2 = lb[j];
+    if (l2 >= f2) {
+      if (l < f) { f = f2; l = l2; }
+      else { f = min(f, f2); l = max(l, l2); }
+    }
+  }
+  span[j] = l >= f ? (l / al + 1) * al - f / al * al : 0;
+}
+// B <- alpha A + beta B by the AddSparseVectors rules (inc_decide; B's values scaled by beta first, as ScaleMatrix
+// followed by IncrementMatrix), one wave per column, result in a fresh slot at base[j] (row r at base + r - a0, a0 =
+// the multiple of al below the union's first row; pads and dropped rows zero).  HAVE_B false: a copy of A (alpha = 1).
+// stat[0] |= 1 when a kept value is exactly zero (an unfiltered tail that underflowed: the slab form cannot hold it).
+template <bool HAVE_B>
+__global__ __launch_bounds__(256) void k_sa_axpby(int n, const int32_t* __restrict__ fa, const int32_t* __restrict__ la,
+                                                  const int64_t* __restrict__ offa, const double* __restrict__ va,
+                                                  const int32_t* __restrict__ fb, const int32_t* __restrict__ lb,
+                                                  const int64_t* __restrict__ offb, const double* __restrict__ vb,
+                                                  const int64_t* __restrict__ base, int al, double alpha, double beta, double thr,
+                                                  double* __restrict__ out, int32_t* __restrict__ ofirst, int32_t* __restrict__ olast,
+                                                  int32_t* __restrict__ ocount, int64_t* __restrict__ ooff,
+                                                  unsigned long long* __restrict__ stat) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= n) return;
+  const int lane = lane_id();
+  const int fA = fa[j], lA = la[j];
+  int fB = INT_MAX, lB = -1;
+  if (HAVE_B) { fB = fb[j]; lB = lb[j]; }
+  const bool anyA = lA >= fA, anyB = lB >= fB;
+  const int64_t slot = base[j];
+  if (!anyA && !anyB) {
+    if (lane == 0) { ofirst[j] = INT_MAX; olast[j] = -1; ocount[j] = 0; ooff[j] = slot; }
+    return;
+  }
+  const int f = anyA ? (anyB ? min(fA, fB) : fA) : fB, l = anyA ? (anyB ? max(lA, lB) : lA) : lB;
+  const int a0 = f / al * al, a1 = (l / al + 1) * al;
+  const int amax = anyA ? lA : -1, bmax = anyB ? lB : -1;
+  const double* __restrict__ pa = anyA ? va + (offa[j] - fA) : va;
+  const double* __restrict__ pb = (HAVE_B && anyB) ? vb + (offb[j] - fB) : va;
+  double* __restrict__ dst = out + (slot - a0);
+  int cnt = 0, kf = INT_MAX, kl = -1, zk = 0;
+  for (int r = a0 + lane; r < a1; r += WAVE) {
+    const double a = (anyA && r >= fA && r <= lA) ? pa[r] : 0.0;
+    const double b = (HAVE_B && anyB && r >= fB && r <= lB) ? pb[r] : 0.0;
+    const bool ha = a != 0.0, hb = b != 0.0;
+    const double wa = __dmul_rn(alpha, a), bs = HAVE_B ? __dmul_rn(beta, b) : 0.0;
+    double o = 0.0;
+    bool keep = false;
+    if (ha && hb) { o = __dadd_rn(wa, bs); keep = fabs(o) > thr; }
+    else if (ha) { o = wa; keep = (r > bmax) ? true : (fabs(wa) > thr); }
+    else if (hb) { o = bs; keep = (r > amax) ? true : (fabs(bs) > thr); }
+    dst[r] = keep ? o : 0.0;
+    zk |= (keep && o == 0.0) ? 1 : 0;
+    cnt += keep ? 1 : 0;
+    kf = min(kf, keep ? r : INT_MAX);
+    kl = max(kl, keep ? r : -1);
+  }
+  cnt = (int)wave_sum_i64(cnt);
+  kf = wave_min_i32(kf);
+  kl = wave_max_i32(kl);
+  if (__ballot(zk != 0) && lane == 0) atomicOr(stat, 1ull);
+  if (lane == 0) {
+    ofirst[j] = kf; olast[j] = kl; ocount[j] = cnt;
+    ooff[j] = slot + (cnt ? kf - a0 : 0);
+  }
+}
+// sum of a . b over the rows both columns hold, per column (x, 0) pairs for the deterministic two-level sum
+__global__ __launch_bounds__(256) void k_sa_dot(int n, const int32_t* __restrict__ fa, const int32_t* __restrict__ la,
+                                                const int64_t* __restrict__ offa, const double* __restrict__ va,
+                                                const int32_t* __restrict__ fb, const int32_t* __restrict__ lb,
+                                                const int64_t* __restrict__ offb, const double* __restrict__ vb,
+                                                double* __restrict__ part) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= n) return;
+  const int lane = lane_id();
+  const int f = max(fa[j], fb[j]), l = min(la[j], lb[j]);
+  double s = 0.0;
+  if (l >= f) {
+    const double* __restrict__ pa = va + (offa[j] - fa[j]);
+    const double* __restrict__ pb = vb + (offb[j] - fb[j]);
+    for (int r = f + lane; r <= l; r += WAVE) s = __dadd_rn(s, __dmul_rn(pa[r], pb[r]));
+  }
+  s = wave_sum_f64(s);
+  if (lane == 0) { part[2 * (size_t)j] = s; part[2 * (size_t)j + 1] = 0.0; }
+}
+// mode 0: out0[j] = sum |v| of column j; mode 1: (diagonal - sum |off-diagonal|, diagonal + sum |off-diagonal|)
+__global__ __launch_bounds__(256) void k_sa_colstat(int n, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                                    const int64_t* __restrict__ off, const double* __restrict__ val, int col_offset,
+                                                    int mode, double* __restrict__ out0, double* __restrict__ out1) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= n) return;
+  const int lane = lane_id();
+  const int f = first[j], l = last[j];
+  double r = 0.0, d = 0.0;
+  if (l >= f) {
+    const double* __restrict__ p = val + (off[j] - f);
+    for (int i = f + lane; i <= l; i += WAVE) {
+      const double v = p[i];
+      if (mode == 1 && i == j + col_offset) d = __dadd_rn(d, v);
+      else r = __dadd_rn(r, fabs(v));
+    }
+  }
+  r = wave_sum_f64(r);
+  d = wave_sum_f64(d);
+  if (lane == 0) {
+    if (mode == 0) out0[j] = r;
+    else { out0[j] = d - r; out1[j] = d + r; }
+  }
+}
+__global__ __launch_bounds__(256) void k_sa_scale(int n, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                                  const int64_t* __restrict__ off, double* __restrict__ val, double c) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= n) return;
+  const int f = first[j], l = last[j];
+  if (l < f) return;
+  double* __restrict__ p = val + (off[j] - f);
+  for (int i = f + lane_id(); i <= l; i += WAVE) p[i] = __dmul_rn(c, p[i]);
+}
+// sum of the entry counts of the columns (integers: any order gives the same total); out zeroed by the caller
+__global__ __launch_bounds__(256) void k_sa_sum_i32(const int32_t* __restrict__ v, int n, long long* __restrict__ out) {
+  __shared__ long long red[4];
+  long long s = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += v[i];
+  s = wave_sum_i64(s);
+  if (lane_id() == 0) red[threadIdx.x / WAVE] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long t = red[0] + red[1] + red[2] + red[3];
+    if (t) atomicAdd(reinterpret_cast<unsigned long long*>(out), (unsigned long long)t);
+  }
+}
+void sa_sum_counts(const int32_t* count, int n, DevBuf<long long>& tot) {
+  tot.alloc(1);
+  tot.zero();
+  hipLaunchKernelGGL(k_sa_sum_i32, dim3(std::max(1, std::min(256, cdiv(n, 1024)))), dim3(256), 0, stream(), count, n, tot.p);
+}
+bool sa_operand(const DevMat& M) {
+  return M.expanded() && !M.cplx && !M.slab->labelled() && M.rows == M.cols;
+}
+}  // namespace
+
+bool slab_enter(DevMat& M) {
+  if (M.expanded()) return sa_operand(M);
+  if (M.cplx || M.loose() || M.rows != M.cols || M.nnz == 0 || options().spgemm_fma != 1) return false;
+  const int n = M.cols;
+  std::unique_ptr<SlabForm> f(new SlabForm());
+  f->first.alloc((size_t)n); f->last.alloc((size_t)n); f->count.alloc((size_t)n); f->off.alloc((size_t)n + 1);
+  DevBuf<int32_t> span((size_t)n);
+  DevBuf<unsigned long long> zc(1);
+  zc.zero();
+  const int al = tile_expand_align();
+  hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(M), f->first.p, f->last.p, f->count.p);
+  hipLaunchKernelGGL(k_span_aligned, dim3(cdiv(n, 256)), dim3(256), 0, stream(), f->first.p, f->last.p, span.p, n, al);
+  scan_async<int32_t>(span.p, f->off.p, (int64_t)n);
+  if (M.zero_free != 1)
+    hipLaunchKernelGGL(k_count_zero_values, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(M), zc.p);
+  int64_t tot = 0;
+  unsigned long long hz = 0;
+  {
+    ScalarFetch ft;
+    ft.add(f->off.p + n, 1, &tot);
+    ft.add(zc.p, 1, &hz);
+    ft.run();
+  }
+  const bool dbg = std::getenv("NTPOLY_AMD_DEBUG_SPGEMM") != nullptr;
+  if (hz == 0) M.zero_free = 1;
+  if ((double)tot > 2.0 * (double)M.nnz + 2.0 * al * (double)n) {   // (mostly holes: not run-like)
+    if (dbg) std::fprintf(stderr, "[slab_enter] refused: slots %lld for %lld entries\n", (long long)tot, (long long)M.nnz);
+    return false;
+  }
+  f->val.alloc((size_t)tot + kIndexSlack);
+  hipLaunchKernelGGL(k_aligned_offsets<double>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), f->first.p, f->last.p,
+                     f->off.p, f->val.p, n, al);
+  hipLaunchKernelGGL(k_slab_expand_a<double>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(M), f->first.p,
+                     f->off.p, f->val.p);
+  f->row_pad = al;
+  f->slots = tot;
+  DevMat R;
+  R.rows = M.rows; R.cols = n; R.cplx = false; R.nnz = M.nnz; R.zero_free = hz == 0 ? 1 : 0;
+  if (hz != 0) {   // (stored zeros: the slab form is a read-only view, the compressed columns stay -- SlabForm::origin)
+    f->origin.reset(new DevMat(std::move(M)));
+  }
+  R.slab = std::move(f);
+  M = std::move(R);
+  return true;
+}
+
+// B <- alpha A + beta B (A == nullptr... see slab_clone); false: refused, B unchanged
+static bool sa_axpby_impl(const DevMat* A, const DevMat& Bin, DevMat& Out, double alpha, double beta, double thr) {
+  const DevMat& X = A ? *A : Bin;   // (clone: the one operand plays A)
+  const bool have_b = A != nullptr;
+  const SlabForm& fa = *X.slab;
+  const SlabForm* fb = have_b ? Bin.slab.get() : nullptr;
+  const int n = X.cols;
+  const int al = have_b ? std::max(fa.row_pad, fb->row_pad) : fa.row_pad;
+  if (have_b && (fa.row_pad != fb->row_pad && (al % fa.row_pad != 0 || al % fb->row_pad != 0))) return false;
+  const int64_t bound = fa.slots + (have_b ? fb->slots : 0) + 2LL * al * n;
+  std::unique_ptr<SlabForm> fo(new SlabForm());
+  fo->first.alloc((size_t)n); fo->last.alloc((size_t)n); fo->count.alloc((size_t)n); fo->off.alloc((size_t)n + 1);
+  DevBuf<int32_t> span((size_t)n);
+  DevBuf<int64_t> base((size_t)n + 1);
+  DevBuf<unsigned long long> stat(2);
+  stat.zero();
+  hipLaunchKernelGGL(k_sa_span, dim3(cdiv(n, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, have_b ? fb->first.p : nullptr,
+                     have_b ? fb->last.p : nullptr, n, al, span.p);
+  scan_async<int32_t>(span.p, base.p, (int64_t)n);
+  fo->val.alloc((size_t)bound + kIndexSlack);
+  if (have_b)
+    hipLaunchKernelGGL((k_sa_axpby<true>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
+                       fa.val.p, fb->first.p, fb->last.p, fb->off.p, fb->val.p, base.p, al, alpha, beta, thr, fo->val.p, fo->first.p,
+                       fo->last.p, fo->count.p, fo->off.p, stat.p);
+  else
+    hipLaunchKernelGGL((k_sa_axpby<false>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
+                       fa.val.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int64_t*)nullptr, (const double*)nullptr,
+                       base.p, al, 1.0, 0.0, 0.0, fo->val.p, fo->first.p, fo->last.p, fo->count.p, fo->off.p, stat.p);
+  DevBuf<long long> tot;
+  sa_sum_counts(fo->count.p, n, tot);
+  int64_t nnz = 0, slots = 0;
+  unsigned long long hs = 0;
+  {
+    ScalarFetch ft;
+    ft.add(tot.p, 1, &nnz);
+    ft.add(base.p + n, 1, &slots);
+    ft.add(stat.p, 1, &hs);
+    ft.run();
+  }
+  if (hs != 0) return false;
+  fo->row_pad = al;
+  fo->slots = slots;
+  DevMat R;
+  R.rows = X.rows; R.cols = n; R.cplx = false; R.nnz = nnz; R.zero_free = 1;
+  R.slab = std::move(fo);
+  Out = std::move(R);
+  return true;
+}
+
+bool slab_axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold) {
+  if (!sa_operand(A) || !sa_operand(B) || A.cols != B.cols || &A == &B) return false;
+  if (alpha == 0.0 || beta == 0.0) return false;   // (ScaleMatrix by zero leaves stored zeros: not a slab)
+  if (A.zero_free != 1 || B.zero_free != 1) return false;
+  DevMat R;
+  if (!sa_axpby_impl(&A, B, R, alpha, beta, threshold)) return false;
+  value_epoch() += 1;
+  B = std::move(R);
+  return true;
+}
+
+// Out = alpha A + beta B, B left as it is (CopyMatrix(B, Out) followed by the merge above, without the copy)
+bool slab_axpby_to(const DevMat& A, const DevMat& B, DevMat& Out, double alpha, double beta, double threshold) {
+  if (!sa_operand(A) || !sa_operand(B) || A.cols != B.cols || &A == &B) return false;
+  if (alpha == 0.0 || beta == 0.0 || A.zero_free != 1 || B.zero_free != 1) return false;
+  DevMat R;
+  if (!sa_axpby_impl(&A, B, R, alpha, beta, threshold)) return false;
+  Out = std::move(R);
+  return true;
+}
+
+bool slab_clone(const DevMat& A, DevMat& Out) {
+  if (!sa_operand(A) || A.zero_free != 1) return false;
+  return sa_axpby_impl(nullptr, A, Out, 1.0, 0.0, 0.0);
+}
+
+bool slab_scale(DevMat& A, double c) {
+  if (!sa_operand(A) || c == 0.0 || A.slab->origin) return false;
+  value_epoch() += 1;
+  SlabForm& f = *A.slab;
+  hipLaunchKernelGGL(k_sa_scale, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
+                     f.val.p, c);
+  f.tiles.release();       // (the multiplier tiles are rebuilt from the runs when the matrix is next a right operand)
+  f.tile_off.release();
+  f.next_plan.reset();
+  return true;
+}
+
+bool slab_dot(const DevMat& A, const DevMat& B, double out[2]) {
+  if (!sa_operand(A) || !sa_operand(B) || A.cols != B.cols) return false;
+  const int n = A.cols;
+  const SlabForm &fa = *A.slab, &fb = *B.slab;
+  DevBuf<double> part((size_t)2 * n), res(2);
+  hipLaunchKernelGGL(k_sa_dot, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p, fa.val.p,
+                     fb.first.p, fb.last.p, fb.off.p, fb.val.p, part.p);
+  reduce_sum2_async(part.p, n, res.p);
+  unsigned long long h[2] = {0, 0};
+  ScalarFetch ft;
+  ft.add(res.p, 2, h);
+  ft.run();
+  std::memcpy(out, h, sizeof(h));
+  return true;
+}
+
+bool slab_norm(const DevMat& A, double* out) {
+  if (!sa_operand(A)) return false;
+  const SlabForm& f = *A.slab;
+  DevBuf<double> cs((size_t)A.cols);
+  hipLaunchKernelGGL(k_sa_colstat, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
+                     f.val.p, 0, 0, cs.p, (double*)nullptr);
+  *out = max_of(cs, (size_t)A.cols);
+  return true;
+}
+
+bool slab_gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx) {
+  if (!sa_operand(A)) return false;
+  const SlabForm& f = *A.slab;
+  DevBuf<double> lo((size_t)A.cols), hi((size_t)A.cols), res(2);
+  hipLaunchKernelGGL(k_sa_colstat, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
+                     f.val.p, col_offset, 1, lo.p, hi.p);
+  hipLaunchKernelGGL(k_reduce_minmax, dim3(1), dim3(256), 0, stream(), lo.p, hi.p, (int64_t)A.cols, res.p);
+  double h[2];
+  res.download(h, 2);
+  *mn = h[0];
+  *mx = h[1];
+  return true;
+}
+
+// C = alpha A B with the threshold rule of the SpGEMM, on the MFMA tile kernel, operands and result in slab form
+bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {
+  if (!sa_operand(A) || !sa_operand(B) || A.cols != B.rows || options().spgemm_fma != 1 || options().spgemm_variant >= 0 ||
+      options().spgemm_force_bin > 0) {
+    if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM")) std::fprintf(stderr, "[slab_multiply] refused: operands / options\n");
+    return false;
+  }
+  const SlabForm &fa = *A.slab, &fb = *B.slab;
+  int trows = tile_rows();
+  while (trows > 1 && fa.row_pad % trows != 0) trows >>= 1;
+  if (fa.row_pad % 16 != 0) return false;
+  const int n = B.cols, snb = cdiv(n, SLAB_J);
+  const bool timing = options().time_kernels != 0;
+  EventTimer t_all(timing), t_num(timing);
+  t_all.start();
+  // ---- plan: windows and k ranges of the blocks; the sizes of the multiplier tiles when B has none yet
+  SlabPlan P;
+  DevBuf<unsigned long long> stats(24);
+  stats.zero();
+  const int plan_align = 16 * tile_rows();
+  // (the multiplier tiles of B, when a fused step left them; otherwise the kernel reads the runs of B's columns)
+  const bool have_tiles = fb.tiles.p != nullptr && (int64_t)fb.tile_off.n == (int64_t)snb + 1;
+  launch_slab_plan(P, n, fb.first.p, fb.last.p, fa.first.p, fa.last.p, plan_align, stats.p);
+  unsigned long long hs[3] = {0, 0, 0};
+  {
+    ScalarFetch f;
+    f.add(P.blk_toff.p + snb, 1, &P.total);
+    f.add(stats.p + 16, 3, hs);
+    f.run();
+  }
+  auto give_up = [&]() {
+    if (timing) {
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+    }
+    return false;
+  };
+  P.max_w = (int)hs[0];
+  P.max_kn = (int)hs[1];
+  if (P.max_w <= 0 || !spgemm_tile_fits(P.max_kn, P.max_w)) {
+    if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
+      std::fprintf(stderr, "[slab_multiply] refused: window %d rows, k range %d\n", P.max_w, P.max_kn);
+    return give_up();
+  }
+  DevBuf<char> runs(((size_t)A.cols + 4) * sizeof(SlabRun));
+  hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, fa.off.p,
+                     reinterpret_cast<const char*>(fa.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), A.cols);
+  const size_t oslots = (size_t)P.total + kIndexSlack;
+  std::unique_ptr<SlabForm> fo(new SlabForm());
+  fo->first.alloc((size_t)n); fo->last.alloc((size_t)n); fo->count.alloc((size_t)n); fo->off.alloc((size_t)n + 1);
+  fo->count.zero();
+  fo->val.alloc(oslots);
+  t_num.start();
+  TileLaunch tl;
+  tl.runs = reinterpret_cast<const SlabRun*>(runs.p);
+  if (have_tiles) {
+    tl.bblk = fb.tiles.p; tl.blk_boff = fb.tile_off.p;
+  } else {
+    tl.bblk = fb.val.p; tl.blk_boff = nullptr;
+    tl.brun_first = fb.first.p; tl.brun_last = fb.last.p; tl.brun_off = fb.off.p; tl.brun_val = fb.val.p;
+  }
+  tl.blk_kmin = P.blk_kmin.p; tl.blk_kn = P.blk_kn.p; tl.blk_lo = P.blk_lo.p;
+  tl.blk_w = P.blk_w.p; tl.blk_toff = P.blk_toff.p; tl.out_val = fo->val.p; tl.count = fo->count.p;
+  tl.ofirst = fo->first.p; tl.olast = fo->last.p; tl.ooff = fo->off.p; tl.otoff = nullptr;
+  tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = (dense_rule ? 1 : 0) | 2; tl.ncols = n; tl.nblocks = snb;
+  tl.max_kn = P.max_kn; tl.max_w = P.max_w; tl.epi = 0; tl.fz = nullptr; tl.rows = trows; tl.labelled = false;
+  launch_spgemm_tile(tl);
+  t_num.stop();
+  DevBuf<long long> tot;
+  sa_sum_counts(fo->count.p, n, tot);
+  int64_t nnz = 0;
+  {
+    ScalarFetch f;
+    f.add(tot.p, 1, &nnz);
+    f.run();
+  }
+  t_all.stop();
+  if (timing) {
+    if (pending_timings().size() >= 4096) flush_spgemm_timers();
+    pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+  }
+  fo->row_pad = 16 * trows;
+  fo->slots = P.total;
+  SpgemmStats st;
+  st.nnz_a = A.nnz; st.nnz_b = B.nnz; st.nnz_c = nnz; st.slab = 1; st.tmp_entries = P.total;
+  last_spgemm_stats() = st;
+  SpgemmAccum& acc = spgemm_accum();
+  acc.calls += 1;
+  acc.nnz_c += nnz;
+  acc.alg_bytes += 12.0 * ((double)A.nnz + (double)B.nnz + (double)nnz) + 4.0 * ((double)A.cols + 2.0 * n + 3.0);
+  DevMat R;
+  R.rows = A.rows; R.cols = n; R.cplx = false; R.nnz = nnz; R.zero_free = 1;
+  R.slab = std::move(fo);
+  C = std::move(R);
+  return true;
 }
 
 }  // namespace ntp

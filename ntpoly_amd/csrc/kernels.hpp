@@ -34,6 +34,8 @@ struct EngineOptions {
   int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
                                // reference built with FP contraction computes); 0: separate multiply and add (default, bit-
                                // identical to the reference built without contraction)
+  int slab_algebra = 1;        // solver loops (TRS4, sign, inverse, square roots; one rank, real, FMA arithmetic): iterates stay in slab form
+                               // between products, merges, dots and norms (psmatrix.cpp SlabSession); 0: compressed columns between the operations
   int plan_ahead = 1;          // TRS2 steps on the slab form (tile kernel, one rank): the step plans its successor behind its own kernel and
                                // reads the sizes back with its results -- one host round trip per step instead of two;
                                // 0: every step makes its plan and reads it back before the launch
@@ -161,6 +163,18 @@ void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, 
                             const DevMat& X, int32_t* d_first, int32_t* d_last, unsigned long long* d_addr,
                             const int64_t* d_cnt_all = nullptr, int32_t* d_count = nullptr);   // (statistics: entries per column)
 void slab_counts_async(const DevMat& X, int64_t* d_cnt64);
+// Slab algebra (kernels.hip, last section): the vocabulary of the solver loops on matrices that stay in slab form -- real,
+// unlabelled, square, one rank, FMA arithmetic.  Every function returns false and leaves its operands alone when it
+// cannot take them (the caller packs and takes the general path).
+bool slab_enter(DevMat& M);   // compressed columns -> slab form in place (false: not run-like, stored zeros, complex ...)
+bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule);
+bool slab_axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold);   // B <- alpha A + beta B
+bool slab_axpby_to(const DevMat& A, const DevMat& B, DevMat& Out, double alpha, double beta, double threshold);   // Out = alpha A + beta B
+bool slab_clone(const DevMat& A, DevMat& Out);
+bool slab_scale(DevMat& A, double c);
+bool slab_dot(const DevMat& A, const DevMat& B, double out[2]);
+bool slab_norm(const DevMat& A, double* out);   // max column abs-sum
+bool slab_gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx);
 // compressed columns -> labelled slab form (SlabForm::lab; Xs = the matrix in the bandwidth-reducing order, lab[index] = the
 // caller's index); false (nothing changed): its columns are not run-like
 bool slab_from_csc(DevMat& Xs, DevBuf<int32_t>& lab);

@@ -3,7 +3,10 @@
 // LoadBalancerModule.F90, PermutationModule.F90.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <numeric>
 #include <random>
 
@@ -102,8 +105,63 @@ void ps_construct_empty(PSMatrix& m, int32_t dim, const ProcessGrid* g, bool cpl
 
 void ps_construct_like(PSMatrix& m, const PSMatrix& ref) { ps_construct_empty(m, ref.dim, ref.grid, ref.cplx); }
 
+namespace {
+int g_slab_depth = 0;
+bool g_slab_failed = false;
+bool slab_on() { return g_slab_depth > 0 && !g_slab_failed; }
+// (the representation of an operand, not its value, changes: const operands are converted in place)
+DevMat& mut(const PSMatrix& m) { return const_cast<DevMat&>(m.loc); }
+int g_slab_refusals = 0;
+long long g_slab_counts[4] = {0, 0, 0, 0};   // products, merges / copies, other operations in slab form; refusals
+// an operation that cannot be done in slab form: its operands go back to compressed columns and the general path does
+// it (a Hamiltonian with stored zeros in the first merge of a loop); the session goes on, unless this keeps happening
+void slab_refused(std::initializer_list<const PSMatrix*> ms) {
+  g_slab_refusals += 1;
+  g_slab_counts[3] += 1;
+  if (g_slab_refusals > 8) g_slab_failed = true;
+  if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
+    std::fprintf(stderr, "[slab session] an operation was refused (%d so far)%s\n", g_slab_refusals,
+                 g_slab_failed ? ": compressed columns from here on" : "");
+  for (const PSMatrix* m : ms) pack(mut(*m));
+}
+// an operation outside the session, or after a refusal: no operand may stay in slab form
+void slab_pack_if(std::initializer_list<const PSMatrix*> ms) {
+  if (g_slab_depth == 0) return;   // (outside a session nothing is left in slab form by one)
+  for (const PSMatrix* m : ms)
+    if (m->loc.expanded() && !(m->loc.slab && m->loc.slab->labelled())) pack(mut(*m));
+}
+}  // namespace
+
+const long long* slab_algebra_counts() { return g_slab_counts; }
+
+SlabSession::SlabSession(bool eligible) {
+  opened = eligible && options().slab_algebra != 0 && options().spgemm_fma == 1 && options().spgemm_variant < 0 && !world().active();
+  if (opened) {
+    if (g_slab_depth == 0) { g_slab_failed = false; g_slab_refusals = 0; }
+    g_slab_depth += 1;
+  }
+}
+SlabSession::~SlabSession() { close(); }
+void SlabSession::close() {
+  if (opened) g_slab_depth -= 1;
+  opened = false;
+}
+void ps_slab_leave(PSMatrix& m) {
+  if (m.loc.expanded()) pack(m.loc);
+}
+
 void ps_copy(const PSMatrix& a, PSMatrix& b) {
   if (&a == &b) return;
+  if (slab_on() && a.loc.expanded()) {
+    DevMat t;
+    if (slab_clone(a.loc, t)) {
+      g_slab_counts[1] += 1;
+      b.grid = a.grid; b.dim = a.dim; b.cplx = a.cplx; b.c0 = a.c0; b.c1 = a.c1;
+      b.loc = std::move(t);
+      return;
+    }
+    slab_refused({&a});
+  }
   DevMat t = a.loc.clone();
   b.grid = a.grid;
   b.dim = a.dim;
@@ -403,6 +461,21 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   }
   DevMat AB;
   const int S = A.grid ? A.grid->num_slices : 1;
+  if (slab_on() && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 && A.loc.nnz > 0 && B.loc.nnz > 0) {
+    // (a slab session: operands are turned into slab form where they are, the product stays in it)
+    const double denom = (double)A.dim * (double)A.dim;
+    const bool dense_rule = denom > 0 && std::min((double)A.loc.nnz / denom, (double)B.loc.nnz / denom) > 0.1;
+    if (slab_enter(mut(A)) && (&A == &B || slab_enter(mut(B))) && slab_multiply(A.loc, B.loc, AB, alpha, threshold, dense_rule)) {
+      g_slab_counts[0] += 1;
+      C.grid = A.grid; C.dim = A.dim; C.c0 = B.c0; C.c1 = B.c1;
+      C.cplx = false;
+      C.loc = std::move(AB);
+      return;
+    }
+    slab_refused({&A, &B});
+  } else {
+    slab_pack_if({&A, &B});
+  }
   if (S <= 1) {
     AB = multiply_panel(A, B, alpha, threshold);
   } else {
@@ -450,6 +523,11 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
 // IncrementMatrix_ps (PSMatrixAlgebraModule.F90:414-460)
 void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold) {
   if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
+  if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && &A != &B) {
+    ps_axpby(A, B, alpha, 1.0, threshold);
+    return;
+  }
+  slab_pack_if({&A, &B});
   if (A.cplx && !B.cplx) {
     DevMat bc = to_complex(B.loc);
     increment(A.loc, bc, alpha, threshold);
@@ -466,18 +544,47 @@ void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold
   }
 }
 
-void ps_scale(PSMatrix& A, double c) { scale(A.loc, c); }
+void ps_scale(PSMatrix& A, double c) {
+  if (slab_on() && A.loc.expanded()) {
+    if (slab_scale(A.loc, c)) { g_slab_counts[2] += 1; return; }
+    slab_refused({&A});
+  }
+  scale(A.loc, c);
+}
 
 // B <- alpha*A + beta*B: ScaleMatrix(B, beta) followed by IncrementMatrix(A, B, alpha, threshold) in one pass (the
 // merge kernels scale B's values as they read them: the same products, the same rules, bit for bit)
 void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold) {
   if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
+  if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B) {
+    // (a slab session: the operand still in compressed columns -- an identity, the Hamiltonian -- is turned into slab form)
+    if (slab_enter(mut(A)) && slab_enter(B.loc) && slab_axpby(A.loc, B.loc, alpha, beta, threshold)) { g_slab_counts[1] += 1; return; }
+    slab_refused({&A, &B});
+  } else {
+    slab_pack_if({&A, &B});
+  }
   if (A.cplx != B.cplx || &A == &B) {
     ps_scale(B, beta);
     ps_increment(A, B, alpha, threshold);
     return;
   }
   axpby(A.loc, B.loc, alpha, beta, threshold, nullptr, nullptr);
+}
+
+void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double alpha, double beta, double threshold) {
+  if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B && A.dim == B.dim) {
+    DevMat R;
+    if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_axpby_to(A.loc, B.loc, R, alpha, beta, threshold)) {
+      g_slab_counts[1] += 1;
+      Out.grid = B.grid; Out.dim = B.dim; Out.cplx = false; Out.c0 = B.c0; Out.c1 = B.c1;
+      Out.loc = std::move(R);
+      return;
+    }
+    slab_refused({&A, &B});
+  }
+  ps_copy(B, Out);
+  if (beta == 1.0) ps_increment(A, Out, alpha, threshold);
+  else ps_axpby(A, Out, alpha, beta, threshold);
 }
 
 void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[4],
@@ -853,6 +960,12 @@ void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {
 // DotMatrix_psr/psc (PSMatrixAlgebraModule.F90:387-410, distributed_algebra_includes/DotMatrix.f90):
 // sum conj(A).B; fused, no Hadamard temporary.
 void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
+  if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx) {
+    if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_dot(A.loc, B.loc, out)) { g_slab_counts[2] += 1; return; }
+    slab_refused({&A, &B});
+  } else {
+    slab_pack_if({&A, &B});
+  }
   if (A.cplx != B.cplx) {
     PSMatrix Ac, Bc;
     ps_to_complex(A, Ac);
@@ -871,6 +984,13 @@ double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includ
 }
 
 double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns are local
+  if (slab_on() && A.loc.expanded()) {
+    double v = 0.0;
+    if (slab_norm(A.loc, &v)) { g_slab_counts[2] += 1; return v; }
+    slab_refused({&A});
+  } else {
+    slab_pack_if({&A});
+  }
   DevBuf<double> cs;
   column_abs_sums(A.loc, cs);
   double n = max_of(cs, (size_t)A.loc.cols);
@@ -885,6 +1005,17 @@ double ps_sigma(const PSMatrix& A) {  // MatrixSigma (distributed_algebra_includ
 
 void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {  // GershgorinBounds.f90:1-41
   double mn, mx;
+  if (slab_on() && A.loc.expanded()) {
+    if (slab_gershgorin(A.loc, A.c0, &mn, &mx)) {
+      g_slab_counts[2] += 1;
+      *e_min = mn;
+      *e_max = mx;
+      return;
+    }
+    slab_refused({&A});
+  } else {
+    slab_pack_if({&A});
+  }
   gershgorin(A.loc, A.c0, &mn, &mx);
   comm_allreduce_min(&mn, 1);
   comm_allreduce_max(&mx, 1);

@@ -418,20 +418,18 @@ void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
   auto t1 = Clock::now();
   double energy_value = 0.0, energy_old;
   int II;
+  SlabSession slab(!X.cplx && !WH.cplx);   // (the loop's matrices stay in slab form between its operations where they can)
   for (II = 1; II <= p.max_iterations; ++II) {                     // :586-638
     ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
-    ps_copy(X2, Fx);
-    ps_axpby(X, Fx, 4.0, -3.0, 0.0);                                // ScaleMatrix(Fx, -3); IncrementMatrix(X, Fx, 4)
-    ps_copy(IMat, Gx);
-    ps_increment(X, Gx, -2.0, 0.0);
+    ps_copy_axpby(X2, X, Fx, 4.0, -3.0, 0.0);                       // CopyMatrix(X2, Fx); ScaleMatrix(Fx, -3); IncrementMatrix(X, Fx, 4)
+    ps_copy_axpby(IMat, X, Gx, -2.0, 1.0, 0.0);                     // CopyMatrix(Identity, Gx); IncrementMatrix(X, Gx, -2)
     ps_increment(X2, Gx, 1.0, 0.0);
     const double trace_fx = real_dot(X2, Fx);
     const double trace_gx = real_dot(X2, Gx);
     if (std::fabs(trace_gx) < 1.0e-14) sigma_array[(size_t)II] = 0.5 * (sigma_max - sigma_min);
     else sigma_array[(size_t)II] = (trace - trace_fx) / trace_gx;
     if (sigma_array[(size_t)II] > sigma_max) {
-      ps_copy(X, Temp);
-      ps_axpby(X2, Temp, -1.0, 2.0, 0.0);                           // ScaleMatrix(Temp, 2); IncrementMatrix(X2, Temp, -1)
+      ps_copy_axpby(X, X2, Temp, -1.0, 2.0, 0.0);                   // CopyMatrix(X, Temp); ScaleMatrix(Temp, 2); IncrementMatrix(X2, Temp, -1)
     } else if (sigma_array[(size_t)II] < sigma_min) {
       ps_copy(X2, Temp);
     } else {
@@ -453,6 +451,8 @@ void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
     }
   }
   const int total_iterations = II - 1;
+  slab.close();
+  ps_slab_leave(X);
   last_trace().loop_ms = ms_since(t1);
   if (p.be_verbose) {
     log_exit();
@@ -688,6 +688,7 @@ void sign_core(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters& 
     log_enter();
   }
   int II;
+  SlabSession slab(!Out.cplx && !needs_transpose);
   for (II = 1; II <= p.max_iterations; ++II) {
     const double alpha_k = std::fmin(std::sqrt(3.0 / (1.0 + xk + xk * xk)), alpha);
     xk = 0.5 * alpha_k * xk * (3.0 - (alpha_k * alpha_k) * (xk * xk));
@@ -707,6 +708,8 @@ void sign_core(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters& 
     trace_rec(norm_value, 0.0, alpha_k, Out);
     if (monitor_converged(mon, p.be_verbose)) break;
   }
+  slab.close();
+  ps_slab_leave(Out);
   if (p.be_verbose) {
     log_exit();
     log_element("Total Iterations", II - 1);
@@ -785,11 +788,11 @@ void invert_core(const PSMatrix& InputMat, PSMatrix& OutputMat, const SolverPara
   }
   double norm_value = p.converge_diff + 1.0;
   int II;
+  SlabSession slab(!Out.cplx);
   for (II = 1; II <= p.max_iterations; ++II) {
     if (log_top && p.be_verbose && II > 1) log_list_element("Convergence", norm_value);
     ps_multiply(Out, Balanced, Temp1, 1.0, 0.0, p.threshold);
-    ps_copy(Identity, Temp2);
-    ps_increment(Temp1, Temp2, -1.0, 0.0);
+    ps_copy_axpby(Identity, Temp1, Temp2, -1.0, 1.0, 0.0);         // CopyMatrix(Identity, Temp2); IncrementMatrix(Temp1, Temp2, -1)
     norm_value = ps_norm(Temp2);
     PSMatrix T2;
     ps_multiply(Temp1, Out, T2, -1.0, 0.0, p.threshold);
@@ -798,6 +801,8 @@ void invert_core(const PSMatrix& InputMat, PSMatrix& OutputMat, const SolverPara
     trace_rec(norm_value, 0.0, sigma, Out);
     if (monitor_converged(mon, p.be_verbose)) break;
   }
+  slab.close();
+  ps_slab_leave(Out);
   if (p.be_verbose) {
     log_exit();
     log_element("Total Iterations", II - 1);
@@ -856,17 +861,16 @@ void isr_order2(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
     log_enter();
   }
   int II;
+  SlabSession slab(!SR.cplx);
   for (II = 1; II <= p.max_iterations; ++II) {
     ps_multiply(SR, ISR, X, 1.0, 0.0, p.threshold);
     ps_gershgorin(X, &e_min, &e_max);
     max_between = std::fmax(std::fabs(e_min), std::fabs(e_max));
     lambda = 1.0 / max_between;
     ps_scale(X, lambda);
-    ps_copy(Identity, Temp);
-    ps_increment(X, Temp, -1.0, 0.0);
+    ps_copy_axpby(Identity, X, Temp, -1.0, 1.0, 0.0);               // CopyMatrix(Identity, Temp); IncrementMatrix(X, Temp, -1)
     const double norm_value = ps_norm(Temp);
-    ps_copy(Identity, T);
-    ps_axpby(X, T, -1.0, 3.0, 0.0);                                 // ScaleMatrix(T, 3); IncrementMatrix(X, T, -1)
+    ps_copy_axpby(Identity, X, T, -1.0, 3.0, 0.0);                  // CopyMatrix(Identity, T); ScaleMatrix(T, 3); IncrementMatrix(X, T, -1)
     ps_scale(T, 0.5);
     std::swap(ISR, Temp);                                           // CopyMatrix(ISR, Temp): ISR is rebuilt by the multiply
     ps_multiply(Temp, T, ISR, 1.0, 0.0, p.threshold);
@@ -878,6 +882,9 @@ void isr_order2(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
     trace_rec(norm_value, 0.0, lambda, ISR);
     if (monitor_converged(mon, p.be_verbose)) break;
   }
+  slab.close();
+  ps_slab_leave(ISR);
+  ps_slab_leave(SR);
   if (p.be_verbose) {
     log_exit();
     log_element("Total Iterations", II);
@@ -916,6 +923,7 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
     log_enter();
   }
   int II;
+  SlabSession slab(!SR.cplx);
   for (II = 1; II <= p.max_iterations; ++II) {                     // :415-497
     ps_multiply(ISR, SR, X, 1.0, 0.0, p.threshold);
     ps_increment(Identity, X, -1.0, 0.0);
@@ -932,8 +940,7 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
       const double d = dd - b * c;
       ps_multiply(X, X, Temp, 1.0, 0.0, p.threshold);
       ps_increment(X, Temp, a, 0.0);
-      ps_copy(Identity, Temp2);
-      ps_axpby(X, Temp2, 1.0, b, 0.0);                              // ScaleMatrix(Temp2, b); IncrementMatrix(X, Temp2)
+      ps_copy_axpby(Identity, X, Temp2, 1.0, b, 0.0);               // CopyMatrix(Identity, Temp2); ScaleMatrix(Temp2, b); IncrementMatrix(X, Temp2)
       ps_increment(Temp, Temp2, 1.0, 0.0);
       ps_increment(Identity, Temp, c, 0.0);
       ps_multiply(Temp2, Temp, X, 1.0, 0.0, p.threshold);
@@ -948,6 +955,9 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
     trace_rec(norm_value, 0.0, lambda, ISR);
     if (monitor_converged(mon, p.be_verbose)) break;
   }
+  slab.close();
+  ps_slab_leave(ISR);
+  ps_slab_leave(SR);
   if (p.be_verbose) {
     log_exit();
     log_element("Total Iterations", II);

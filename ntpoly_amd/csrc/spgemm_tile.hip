@@ -87,6 +87,11 @@ struct TileArgs {
   int dense_rule, ncols, nblocks;
   int k4max, tmax;
   const SlabFuseArgs* fz;
+  // EPI 0 only, optional: the right operand as the runs of its columns (slab algebra: no multiplier tiles were built) --
+  // first / last row, offset of the first row and values; bblk / blk_boff are then unused
+  const int32_t *brun_first, *brun_last;
+  const int64_t* brun_off;
+  const double* brun_val;
   const double* zero;   // 16 bytes of zeros: where the lanes outside a run load from
   int ablate;           // experiment build (-DNTP_ABLATIONS) only
 #ifdef NTP_TILE_STAMPS
@@ -159,13 +164,34 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   // groups that can reach a tile are found by the wave that takes the tile (a ballot over the groups' row ranges)
   if (kn > 0 && w > 0 && tbase >= 0) STAMP(56);
   constexpr int NT = TILE_NW * WAVE, BCH = 3072 / NT;   // (in flight together: the tile of a k range of 384, 48 KB)
-  const double2* __restrict__ bsrc = reinterpret_cast<const double2*>(a.bblk + a.blk_boff[b]);
+  const double2* __restrict__ bsrc = reinterpret_cast<const double2*>(a.bblk + (a.blk_boff ? a.blk_boff[b] : 0));
   double2* bdst = reinterpret_cast<double2*>(Bs);
   double2 btmp[BCH];
+  // (the multiplier tile from the runs of the block's columns: a thread always serves the same column pair -- NT is a
+  // multiple of 8 -- and consecutive rows of a column go to threads 8 apart)
+  [[maybe_unused]] bool brun = false;
+  [[maybe_unused]] int bf0 = INT_MAX, bl0 = -1, bf1 = INT_MAX, bl1 = -1;
+  [[maybe_unused]] const double *bp0 = nullptr, *bp1 = nullptr;
+  if constexpr (EPI == 0) {
+    brun = a.brun_val != nullptr;
+    if (brun) {
+      const int c0 = b * SLAB_J + 2 * (tid & 7);
+      if (c0 < a.ncols) { bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0]; bp0 = a.brun_val + (a.brun_off[c0] - bf0); }
+      if (c0 + 1 < a.ncols) { bf1 = a.brun_first[c0 + 1]; bl1 = a.brun_last[c0 + 1]; bp1 = a.brun_val + (a.brun_off[c0 + 1] - bf1); }
+    }
+  }
+  auto brun_load = [&](int i) {
+    const int r = kmin + (i >> 3);
+    double2 v;
+    v.x = (i < kn * 8 && r >= bf0 && r <= bl0) ? bp0[r] : 0.0;
+    v.y = (i < kn * 8 && r >= bf1 && r <= bl1) ? bp1[r] : 0.0;
+    return v;
+  };
 #pragma unroll
   for (int u = 0; u < BCH; ++u) {
     const int i = tid + u * NT;
-    btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+    if (EPI == 0 && brun) btmp[u] = brun_load(i);
+    else btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
   }
   {
     // one thread per record (all loads independent and in flight together with the tile's), the row range of a k
@@ -212,7 +238,10 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     const int i = tid + u * NT;
     if (i < K4 * 8) bdst[i] = btmp[u];
   }
-  for (int i = tid + BCH * NT; i < K4 * 8; i += NT) bdst[i] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+  for (int i = tid + BCH * NT; i < K4 * 8; i += NT) {
+    if (EPI == 0 && brun) bdst[i] = brun_load(i);
+    else bdst[i] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+  }
   STAMP(61);
   for (int t = tid; t < T; t += NT) colmask[t] = 0u;
   if (tid < 16) {
@@ -661,6 +690,7 @@ void launch_spgemm_tile(const TileLaunch& L) {
   const int trows = 16 * (L.rows == 4 ? 4 : L.rows == 2 ? 2 : 1);
   a.tmax = (L.max_w + trows - 1) / trows;
   a.fz = static_cast<const SlabFuseArgs*>(L.fz);
+  a.brun_first = L.brun_first; a.brun_last = L.brun_last; a.brun_off = L.brun_off; a.brun_val = L.epi == 0 ? L.brun_val : nullptr;
   static DevBuf<double>* zeros = nullptr;   // (never freed: lives as long as the library)
   if (!zeros) {
     zeros = new DevBuf<double>(8);

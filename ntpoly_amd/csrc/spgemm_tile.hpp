@@ -32,6 +32,10 @@ struct TileLaunch {
                                      // fused epilogues) readable and ZERO from the multiple of R below its first row to the one
                                      // above its last (tile_expand_align(): the expansions and this kernel's own results are)
   const void* fz = nullptr;          // device copy of SlabFuseArgs (EPI != 0)
+  // epi 0, optional: the right operand as the runs of its columns instead of multiplier tiles (bblk / blk_boff unused)
+  const int32_t *brun_first = nullptr, *brun_last = nullptr;
+  const int64_t* brun_off = nullptr;
+  const double* brun_val = nullptr;
   bool labelled = false;             // fz carries labels (SlabFuseArgs::lab, xplast, oplast): the epilogue's "beyond the last entry"
                                      // tests compare the caller's labels.  The k steps are walked in POSITION order (the rounding
                                      // of a product entry then differs from the label-ordered chain in its last bits: tolerance mode)

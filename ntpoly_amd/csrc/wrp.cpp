@@ -137,6 +137,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "increment_force_seq") options().increment_force_seq = *value;
   else if (n == "spgemm_fma") options().spgemm_fma = *value;
   else if (n == "plan_ahead") options().plan_ahead = *value;
+  else if (n == "slab_algebra") options().slab_algebra = *value;
   else if (n == "operand_cache") options().operand_cache = *value;
   else if (n == "tile_rows") options().tile_rows = *value;
   else if (n == "tile_waves") options().tile_waves = *value;
@@ -194,6 +195,11 @@ int ntpoly_amd_band_order(const int* ih, int* newpos, long long* bandwidth) {
 // to be repeated on the unfused path, since start
 void ntpoly_amd_fusion_counts(long long* out) {
   for (int q = 0; q < 3; ++q) out[q] = fusion_counts()[q];
+}
+// out[0..3]: operations the solver loops did on matrices in slab form since start (products, merges / copies, scalings
+// / dots / norms) and operations that had to go back to compressed columns
+void ntpoly_amd_slab_algebra_counts(long long* out) {
+  for (int q = 0; q < 4; ++q) out[q] = slab_algebra_counts()[q];
 }
 void ntpoly_amd_reset_spgemm_accum() {
   flush_spgemm_timers();

@@ -882,6 +882,13 @@ def fusion_counts():
     return dict(square=out[0], update=out[1], repeated=out[2])
 
 
+def slab_algebra_counts():
+    """operations of the solver loops done on matrices in slab form since start, and those that went back to compressed columns"""
+    out = (C.c_longlong * 4)()
+    lib.ntpoly_amd_slab_algebra_counts(out)
+    return dict(products=out[0], merges=out[1], others=out[2], refusals=out[3])
+
+
 def last_grouped_stats():
     """grouped LDS-hash path of the last SpGEMM (csrc/spgemm_grouped.hip)"""
     out = (C.c_longlong * 6)()

@@ -1,0 +1,167 @@
+"""GPU: the solver loops on matrices that stay in slab form (option slab_algebra, FMA arithmetic, one rank: psmatrix.cpp
+SlabSession + kernels.hip "slab algebra") -- TRS4, SignFunction, Invert, InverseSquareRoot / SquareRoot.
+
+Three checks per solver: (1) the slab session really ran (ntpoly_amd_slab_algebra_counts: the loop's products were done
+in slab form, and the number of refusals is what the operand explains); (2) the result equals the
+one computed with the session off -- products, merges and scalings are the same arithmetic in the same order, so sign,
+inverse and square roots are equal BIT FOR BIT with the same pattern; TRS4's sigma is a quotient of two dots whose
+summation order differs, so its density agrees to 1e-10; (3) the result equals the oracle's FMA mode (the CPU
+restatement of the reference, pinned to the contracted reference build) within the solver tolerances of
+tests/test_gpu_parity.py.  Operands include a Hamiltonian with STORED ZEROS on its diagonal (the generator's h_ii = 0
+where 7919 i = 500 mod 1000): the slab form of such a matrix is a read-only view that keeps its compressed columns."""
+import numpy as np
+import pytest
+
+from gen import banded_triplets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nt():
+    import ntpoly_amd as nt
+    nt.init_comm()
+    nt.ConstructGlobalProcessGrid(1, 1, 1)
+    return nt
+
+
+@pytest.fixture()
+def fma(nt):
+    from oracle import oracle_py as O
+    nt.set_option("spgemm_fma", 1)
+    O.set_fma(True)
+    yield O
+    O.set_fma(False)
+    nt.set_option("spgemm_fma", 0)
+    nt.set_option("slab_algebra", 1)
+
+
+def srt(t):
+    c, r, v = t
+    o = np.lexsort((r, c))
+    return c[o], r[o], v[o]
+
+
+def same_pattern(a, b):
+    return len(a[2]) == len(b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def run(nt, solver, H, n, thr, conv, iters=None):
+    p = nt.SolverParameters()
+    p.SetThreshold(thr)
+    p.SetConvergeDiff(conv)
+    if iters:
+        p.SetMaxIterations(iters)
+        p.SetMonitorConvergence(False)
+    Out = nt.Matrix_ps(n)
+    extra = None
+    if solver == "trs4":
+        I = nt.Matrix_ps(n)
+        I.FillIdentity()
+        extra = nt.DensityMatrixSolvers.TRS4(H, I, n / 2.0, Out, p)
+    elif solver == "sign":
+        nt.SignSolvers.ComputeSign(H, Out, p)
+    elif solver == "invert":
+        nt.InverseSolvers.Invert(H, Out, p)
+    elif solver == "inverse_square_root":
+        nt.SquareRootSolvers.InverseSquareRoot(H, Out, p)
+    else:
+        nt.SquareRootSolvers.SquareRoot(H, Out, p)
+    tr = nt.solver_trace()
+    return srt(Out.triplets()), tr, extra
+
+
+ORDER2 = [("inverse_square_root", 4096, 20, 1e-8, 2.0)]
+CASES = [("trs4", 4096, 20, 1e-8, 0.0), ("trs4", 3000, 12, 1e-6, 0.0), ("sign", 4096, 20, 1e-8, 0.0), ("sign", 2048, 8, 1e-7, 0.3),
+         ("invert", 4096, 20, 1e-8, 2.0), ("inverse_square_root", 4096, 20, 1e-8, 2.0), ("square_root", 3000, 12, 1e-7, 2.0)]
+
+
+@pytest.mark.parametrize("solver,n,h,thr,shift", CASES)
+def test_slab_session_equals_compressed_columns_and_oracle(nt, fma, solver, n, h, thr, shift):
+    O = fma
+    col, row, val = banded_triplets(n, h, shift=shift)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    # (TRS4: a fixed number of iterations -- its sigma is a 0/0 quotient near convergence, where the stopping iteration is noise)
+    conv, iters = (1e-30, 14) if solver == "trs4" else (1e-8, None)
+    nt.set_option("slab_algebra", 0)
+    c0 = nt.slab_algebra_counts()
+    want, tr0, ex0 = run(nt, solver, H, n, thr, conv, iters)
+    c1 = nt.slab_algebra_counts()
+    assert c1 == c0   # (session off: nothing in slab form)
+    nt.set_option("slab_algebra", 1)
+    got, tr1, ex1 = run(nt, solver, H, n, thr, conv, iters)
+    c2 = nt.slab_algebra_counts()
+    # the loop's products ran in slab form (two per iteration, three for the square roots; TRS4: one or two), and at most
+    # the first merge on an operand with stored zeros was refused
+    per = {"trs4": 1, "sign": 2, "invert": 2, "inverse_square_root": 3, "square_root": 3}[solver]
+    assert c2["products"] - c1["products"] >= per * (tr1["iterations"] - 1), (c1, c2, tr1["iterations"])
+    assert c2["refusals"] - c1["refusals"] <= 1
+    assert tr0["iterations"] == tr1["iterations"]
+    assert same_pattern(got, want), "%s: pattern differs (%d vs %d entries)" % (solver, len(got[2]), len(want[2]))
+    if solver == "trs4":
+        assert np.abs(got[2] - want[2]).max() <= 1e-10
+        assert abs(ex0[0] - ex1[0]) <= 1e-9 * abs(ex0[0]) and abs(ex0[1] - ex1[1]) <= 1e-6
+    else:
+        assert np.array_equal(got[2], want[2]), "%s: max |d| = %g" % (solver, np.abs(got[2] - want[2]).max())
+        assert np.array_equal(np.asarray(tr0["value"]), np.asarray(tr1["value"])) or np.allclose(tr0["value"], tr1["value"], rtol=1e-12, atol=1e-14)
+    # the oracle's FMA mode (CPU restatement of the reference)
+    Ho = O.Mat.from_triplets(n, n, col, row, val)
+    if solver == "trs4":
+        po = O.params(converge_diff=conv, threshold=thr, max_iterations=iters, monitor_convergence=False)
+        Ko, e_o, mu_o, tro = O.density("trs4", Ho, O.Mat.identity(n), n / 2.0, po)
+        assert tr1["iterations"] == tro["iterations"] == iters
+        assert np.allclose(tr1["energy"], tro["energy"], rtol=1e-10, atol=1e-10)
+        assert np.allclose(tr1["sigma"], tro["sigma"], rtol=1e-6, atol=1e-8)
+        assert abs(e_o - ex1[0]) <= 1e-10 * abs(e_o)
+        w = srt(Ko.triplets())
+        # (TRS4's sigma is a 0/0 quotient near convergence: densities agree to the convergence level, not to roundoff)
+        import scipy.sparse as sp
+        G = sp.csr_matrix((got[2], (got[1] - 1, got[0] - 1)), shape=(n, n))
+        W = sp.csr_matrix((w[2], (w[1] - 1, w[0] - 1)), shape=(n, n))
+        assert abs(G - W).max() <= 1e-6
+    else:
+        po = O.params(converge_diff=conv, threshold=thr)
+        Oo, tro = O.matrix_function(solver, Ho, po)
+        assert tr1["iterations"] == tro["iterations"]
+        w = srt(Oo.triplets())
+        assert same_pattern(got, w)
+        assert np.abs(got[2] - w[2]).max() <= 1e-12 * max(1.0, np.abs(w[2]).max())
+
+
+def test_slab_session_runs_and_counts_its_refusals(nt, fma):
+    """full path check on a mid-size operand: with the session on the products of the loop come from slab_multiply
+    (accumulator: every call on the slab path), and the sign of an operand with stored zeros costs exactly one refusal
+    (its first merge) -- visible as two conversions from compressed columns instead of one"""
+    n, h, thr = 16384, 40, 1e-8
+    col, row, val = banded_triplets(n, h)
+    assert ((val == 0) & (col == row)).sum() > 0   # (the generator's zero diagonals)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    nt.set_option("slab_algebra", 1)
+    c0 = nt.slab_algebra_counts()
+    got, tr, _ = run(nt, "sign", H, n, thr, 1e-8)
+    c1 = nt.slab_algebra_counts()
+    assert c1["products"] - c0["products"] == 2 * tr["iterations"]
+    assert c1["refusals"] - c0["refusals"] == 1
+    nt.set_option("slab_algebra", 0)
+    want, tr0, _ = run(nt, "sign", H, n, thr, 1e-8)
+    assert tr0["iterations"] == tr["iterations"] and same_pattern(got, want) and np.array_equal(got[2], want[2])
+
+
+@pytest.mark.parametrize("solver,n,h,thr,shift", ORDER2)
+def test_second_order_square_root_in_slab_form(nt, fma, solver, n, h, thr, shift):
+    """NewtonSchultzISROrder2 (SquareRootSolversModule.F90: order 2) with the session on and off: bit for bit"""
+    col, row, val = banded_triplets(n, h, shift=shift)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    p = nt.SolverParameters()
+    p.SetThreshold(thr)
+    p.SetConvergeDiff(1e-8)
+    res = []
+    for on in (0, 1):
+        nt.set_option("slab_algebra", on)
+        c0 = nt.slab_algebra_counts()
+        Out = nt.Matrix_ps(n)
+        nt.SquareRootSolvers.with_order(H, Out, p, True, 2)
+        c1 = nt.slab_algebra_counts()
+        res.append((srt(Out.triplets()), nt.solver_trace()["iterations"], c1["products"] - c0["products"]))
+    assert res[0][2] == 0 and res[1][2] >= 3 * (res[1][1] - 1)
+    assert res[0][1] == res[1][1] and same_pattern(res[0][0], res[1][0]) and np.array_equal(res[0][0][2], res[1][0][2])
