@@ -3474,10 +3474,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
         tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = tmp_val.p; tl.count = count.p;
         tl.ofirst = fz_first.p; tl.olast = fz_last.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
         tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
-        tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = fuse->mode; tl.fz = fz_args.p; tl.rows = tile_rows();
-        launch_spgemm_tile(tl);
-        HIP_CHECK(hipMemcpyAsync(tile_ooff.p + n, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
-        HIP_CHECK(hipMemcpyAsync(tile_otoff.p + snb, blk_toff.p + snb, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
+        tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = fuse->mode; tl.fz = &fz; tl.rows = tile_rows();
+        launch_spgemm_tile(tl);   // (writes the end markers of tile_ooff / tile_otoff as well)
       } else if (max_w_now > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
       else if (max_w_now > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
       else by_mode(std::integral_constant<int, SLAB_NW>{}, std::integral_constant<int, 8>{});
@@ -4030,7 +4028,8 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   if (max_w <= 0 || (!tile && max_w > 8 * SLAB_SL * WAVE)) return give_up();
   if (tile && !spgemm_tile_fits((int)hst[1], (int)max_w)) return give_up();
   if (in.labelled() && (int64_t)hst[1] > 2048) return give_up();   // (the per-block sort of the steps)
-  hipLaunchKernelGGL((k_slab_tmpoff<SLAB_J>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
+  if (!tile)   // (the tile kernel writes the result's own offsets)
+    hipLaunchKernelGGL((k_slab_tmpoff<SLAB_J>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, blk_w.p, blk_toff.p, tmpoff.p);
   DevBuf<char> runs(((size_t)nka + 4) * sizeof(SlabRun));
   if (halo)
     hipLaunchKernelGGL(k_slab_runs_addr, dim3(cdiv(nka + 4, 256)), dim3(256), 0, stream(), halo->first, halo->last, halo->addr,
@@ -4088,8 +4087,11 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   // columns at hand it also counts the products (the tile rows are global column numbers)
   fz.prod = reinterpret_cast<long long*>(blk_prod);
   if (!halo || halo->count) fz.in_count = halo ? halo->count - ka : in.count.p;
-  DevBuf<char> fz_args(sizeof(SlabFuseArgs));
-  fz_args.upload(reinterpret_cast<const char*>(&fz), sizeof(SlabFuseArgs));
+  DevBuf<char> fz_args;
+  if (!tile) {   // (the slab loop reads them from memory after its loop; the tile kernel takes them by value)
+    fz_args.alloc(sizeof(SlabFuseArgs));
+    fz_args.upload(reinterpret_cast<const char*>(&fz), sizeof(SlabFuseArgs));
+  }
   const int dr = dense_rule ? 1 : 0;
   t_num.start();
   auto launch = [&](auto nw_tag, auto mode_tag, auto epi_tag) {
@@ -4113,10 +4115,8 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = oval.p; tl.count = count.p;
     tl.ofirst = ofirst.p; tl.olast = olast.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
     tl.alpha = 1.0; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
-    tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = fz_args.p; tl.rows = trows; tl.labelled = tile_labelled;
-    launch_spgemm_tile(tl);
-    HIP_CHECK(hipMemcpyAsync(tile_ooff.p + n, tmpoff.p + n, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
-    HIP_CHECK(hipMemcpyAsync(tile_otoff.p + snb, blk_toff.p + snb, sizeof(int64_t), hipMemcpyDeviceToDevice, stream()));
+    tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = &fz; tl.rows = trows; tl.labelled = tile_labelled;
+    launch_spgemm_tile(tl);   // (the fused epilogue's arguments travel by value; the kernel writes the end markers of the offsets)
   } else if (rowoff) {
     if (max_w > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{});
     else if (max_w > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 9>{});

@@ -86,7 +86,7 @@ struct TileArgs {
   double alpha, threshold;
   int dense_rule, ncols, nblocks;
   int k4max, tmax;
-  const SlabFuseArgs* fz;
+  SlabFuseArgs fzv;     // EPI != 0: the fused epilogue's arguments, by value (kernel arguments: scalar loads, no upload before the launch)
   // EPI 0 only, optional: the right operand as the runs of its columns (slab algebra: no multiplier tiles were built) --
   // first / last row, offset of the first row and values; bblk / blk_boff are then unused
   const int32_t *brun_first, *brun_last;
@@ -120,6 +120,10 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   const int tid = threadIdx.x, wave = uni_i32(tid / WAVE), lane = lane_id();
   const int lo = a.blk_lo[b], w = a.blk_w[b], kmin = a.blk_kmin[b], kn = a.blk_kn[b];
   const int64_t tbase = a.blk_toff[b];
+  if (b == 0 && tid == 0) {   // (the end markers of the result's offset arrays)
+    a.ooff[a.ncols] = a.blk_toff[a.nblocks];
+    if (EPI != 0 && a.otoff) a.otoff[a.nblocks] = a.blk_toff[a.nblocks];
+  }
   if (kn == 0) {   // no product entries in these columns
     const int j = b * SLAB_J + tid;
     if (tid < SLAB_J && j < a.ncols) {
@@ -127,9 +131,9 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       a.olast[j] = -1;
       a.ooff[j] = tbase + (int64_t)tid * w;
       if constexpr (EPI != 0) {
-        if (a.fz->oplast) a.fz->oplast[j] = -1;
+        if (a.fzv.oplast) a.fzv.oplast[j] = -1;
         // (EPI 2: ... and none in the result only if the columns of X are empty as well; otherwise the step is not ours)
-        if (EPI == 2 && a.fz->xmax[j] >= a.fz->xmin[j]) atomicOr(a.fz->flag, 1);
+        if (EPI == 2 && a.fzv.xmax[j] >= a.fzv.xmin[j]) atomicOr(a.fzv.flag, 1);
       }
     }
     if (EPI != 0 && tid == 0) a.otoff[b] = tbase;
@@ -256,8 +260,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   STAMP(62);
   STAMP(63);
   if constexpr (EPI != 0) {
-    if (a.fz->prod) {   // products of this block = sum over the tile rows k of (non-zero multipliers) * (entries of A(:, k))
-      const int32_t* __restrict__ in_count = a.fz->in_count;
+    if (a.fzv.prod) {   // products of this block = sum over the tile rows k of (non-zero multipliers) * (entries of A(:, k))
+      const int32_t* __restrict__ in_count = a.fzv.in_count;
       long long p = 0;
       for (int k = tid; k < kn; k += TILE_NW * WAVE) {
         int c = 0;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     }
   }
   if constexpr (LAB) {
-    const int32_t* __restrict__ lab_g = a.fz->lab;
+    const int32_t* __restrict__ lab_g = a.fzv.lab;
     for (int i = tid; i < T * TROWS; i += TILE_NW * WAVE) labs[i] = lab_g[min(lo + i, a.ncols - 1)];
   }
   __syncthreads();
@@ -290,24 +294,23 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   [[maybe_unused]] double am = 0, bm = 0, thr_m = 0;
   [[maybe_unused]] int diag = -1;
   if constexpr (EPI != 0) {
-    const SlabFuseArgs* __restrict__ fz = a.fz;
-    otile = fz->tiles + (tbase - (int64_t)lo * SLAB_J + jj);                // otile[r * 16] = row r, column jj of the tile
-    const int d0 = fz->dmin[jc], d1 = fz->dmax[jc];
+    otile = a.fzv.tiles + (tbase - (int64_t)lo * SLAB_J + jj);                // otile[r * 16] = row r, column jj of the tile
+    const int d0 = a.fzv.dmin[jc], d1 = a.fzv.dmax[jc];
     if (colv && d1 >= d0) {
       df = d0;
       dl = d1;
-      drz = fz->dexp + (fz->doff[jc] - d0);
+      drz = a.fzv.dexp + (a.fzv.doff[jc] - d0);
     }
-    diag = j + fz->col_offset;
+    diag = j + a.fzv.col_offset;
     if constexpr (EPI == 2) {
-      am = fz->am; bm = fz->bm; thr_m = fz->thr_m;
-      const int x0 = fz->xmin[jc], x1 = fz->xmax[jc];
+      am = a.fzv.am; bm = a.fzv.bm; thr_m = a.fzv.thr_m;
+      const int x0 = a.fzv.xmin[jc], x1 = a.fzv.xmax[jc];
       if (colv && x1 >= x0) {
         xf = x0;
         xlrow = x1;
-        xrz = fz->xexp + (fz->xoff[jc] - x0);
-        xpl = LAB ? fz->xplast[jc] : x1;
-        if (x0 < lo || x1 >= lo + w) atomicOr(fz->flag, 1);   // every stored row of X(:, j) must be a row of this block's window
+        xrz = a.fzv.xexp + (a.fzv.xoff[jc] - x0);
+        xpl = LAB ? a.fzv.xplast[jc] : x1;
+        if (x0 < lo || x1 >= lo + w) atomicOr(a.fzv.flag, 1);   // every stored row of X(:, j) must be a row of this block's window
       }
     }
   }
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     // the decision and the column statistics here; the values are stored after the holes have been zeroed (below)
     const int nd = misc[0];
     if (nd > TILE_DEFER) {
-      if (tid == 0) atomicOr(a.fz->flag, 1);
+      if (tid == 0) atomicOr(a.fzv.flag, 1);
     } else {
       for (int i = tid; i < nd; i += TILE_NW * WAVE) {
         const int4 e = *reinterpret_cast<const int4*>(&dlist[i]);   // (r, jj, prow, pad)
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
           rank += (f.pad && (f.r < e.r || (f.r == e.r && f.jj < e.jj))) ? 1 : 0;
         }
         Bs[rank] = __dmul_rn(e.o, e.d);
-        Bs[TILE_DEFER + rank] = (e.r == b * SLAB_J + e.jj + a.fz->col_offset) ? e.o : 0.0;
+        Bs[TILE_DEFER + rank] = (e.r == b * SLAB_J + e.jj + a.fzv.col_offset) ? e.o : 0.0;
       }
     }
     __syncthreads();
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       a.olast[jt] = cl;
       a.ooff[jt] = tbase + (int64_t)tid * w + (cl >= cf ? cf - lo : 0);
       if constexpr (EPI != 0) {
-        if constexpr (LAB) a.fz->oplast[jt] = col_plast[tid];
+        if constexpr (LAB) a.fzv.oplast[jt] = col_plast[tid];
       }
     }
   }
@@ -606,8 +609,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   if constexpr (EPI != 0) {
     if (tid == 0) {
       a.otoff[b] = tbase + (tk1 >= tk0 ? (int64_t)(tk0 - lo) * SLAB_J : 0);
-      a.fz->pnnz[b] = misc[1];
-      if (a.fz->prod) a.fz->prod[b] = *reinterpret_cast<long long*>(misc + 2);
+      a.fzv.pnnz[b] = misc[1];
+      if (a.fzv.prod) a.fzv.prod[b] = *reinterpret_cast<long long*>(misc + 2);
     }
     if (tid == 64) {
       double x = 0.0, y = 0.0;
@@ -624,8 +627,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
           y = __dadd_rn(y, Bs[TILE_DEFER + m2]);
         }
       }
-      a.fz->part[2 * b] = x;
-      a.fz->part[2 * b + 1] = y;
+      a.fzv.part[2 * b] = x;
+      a.fzv.part[2 * b + 1] = y;
     }
   }
   // holes: a tile strictly inside a column's run (inside the block's tile rows) that was skipped above holds zeros
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     }
     if constexpr (EPI != 0) {
       if (tk1 >= tk0 && r0 + TROWS - 1 >= tk0 && r0 <= tk1 && cmk == 0u) {
-        double* dst = a.fz->tiles + (tbase - (int64_t)lo * SLAB_J + c);
+        double* dst = a.fzv.tiles + (tbase - (int64_t)lo * SLAB_J + c);
         for (int r = r0; r < min(r0 + TROWS, rend); ++r) dst[(int64_t)r * SLAB_J] = 0.0;
       }
     }
@@ -653,7 +656,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
         const TileDefer e = dlist[i];
         if (!e.pad) continue;
         a.out_val[tbase + (int64_t)e.jj * w + (e.r - lo)] = e.o;
-        a.fz->tiles[tbase + (int64_t)(e.r - lo) * SLAB_J + e.jj] = e.o;
+        a.fzv.tiles[tbase + (int64_t)(e.r - lo) * SLAB_J + e.jj] = e.o;
       }
     }
   }
@@ -689,7 +692,7 @@ void launch_spgemm_tile(const TileLaunch& L) {
   a.k4max = std::max(8, (L.max_kn + 3) & ~3);   // (>= 8: the multiplier tile doubles as scratch for 2 x TILE_DEFER sums)
   const int trows = 16 * (L.rows == 4 ? 4 : L.rows == 2 ? 2 : 1);
   a.tmax = (L.max_w + trows - 1) / trows;
-  a.fz = static_cast<const SlabFuseArgs*>(L.fz);
+  if (L.fz) a.fzv = *static_cast<const SlabFuseArgs*>(L.fz);   // (a HOST copy: it travels with the kernel arguments)
   a.brun_first = L.brun_first; a.brun_last = L.brun_last; a.brun_off = L.brun_off; a.brun_val = L.epi == 0 ? L.brun_val : nullptr;
   static DevBuf<double>* zeros = nullptr;   // (never freed: lives as long as the library)
   if (!zeros) {

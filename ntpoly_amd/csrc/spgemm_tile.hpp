@@ -31,7 +31,7 @@ struct TileLaunch {
                                      // (1) blk_lo and blk_w multiples of 16 R and (2) every expanded column of A (and of X, D in the
                                      // fused epilogues) readable and ZERO from the multiple of R below its first row to the one
                                      // above its last (tile_expand_align(): the expansions and this kernel's own results are)
-  const void* fz = nullptr;          // device copy of SlabFuseArgs (EPI != 0)
+  const void* fz = nullptr;          // HOST copy of SlabFuseArgs (EPI != 0): passed on by value with the kernel arguments
   // epi 0, optional: the right operand as the runs of its columns instead of multiplier tiles (bblk / blk_boff unused)
   const int32_t *brun_first = nullptr, *brun_last = nullptr;
   const int64_t* brun_off = nullptr;
