@@ -1,3 +1,5 @@
+#include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include "common.hpp"
 
@@ -117,7 +119,13 @@ void* dev_alloc(size_t bytes) {
       HIP_CHECK(hipMalloc(&p, b));
     }
     P.n_malloc += 1;
-    P.ms_malloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    P.ms_malloc += ms;
+    static const bool dbg = std::getenv("NTPOLY_AMD_DEBUG_ALLOC") != nullptr;
+    if (dbg)
+      std::fprintf(stderr, "[dev_alloc] hipMalloc %.1f MB (asked %.1f MB) took %.1f ms%s; in use %.1f GB, cached %.1f GB\n", b / 1048576.0,
+                   bytes / 1048576.0, ms, e != hipSuccess ? " AFTER releasing the cache (out of memory)" : "", P.in_use / 1073741824.0,
+                   P.cached / 1073741824.0);
   }
   P.live[p] = got;
   P.serial_of[p] = P.next_serial++;

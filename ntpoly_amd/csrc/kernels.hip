@@ -2913,6 +2913,7 @@ void launch_window(int bin, const DevMat& A, const DevMat& B, const int32_t* lo,
 namespace {
 struct StripCtx { bool active = false, failed = false; };
 // the strip count that worked for the last multiply of a dimension that needed strips: [0] dimension, [1] strips
+constexpr int kMaxStrips = 16;   // (StripCols: what k_strip_total / k_strip_merge interleave)
 int* strips_memory(bool cplx) {
   static int m[2][2] = {{-1, 0}, {-1, 0}};
   return m[cplx ? 1 : 0];
@@ -3260,22 +3261,27 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       f.run();
     }
     const double avg_span = (double)span_sum / (double)std::max(1, nka);
-    const int S = strips_memory(A.cplx)[1];
-    int shift = 6;
-    while ((1 << (shift + 1)) * 8.0 * S <= avg_span && shift < 24) ++shift;
     if (timing) {
       event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
       event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
     }
-    if (spgemm_striped(A, B, C, alpha, threshold, dense_rule, S, shift)) {
-      SpgemmStats& ls = last_spgemm_stats();
-      ls.nnz_a = A.nnz;
-      ls.nnz_c = C.nnz;
-      ls.strips = S;
-      SpgemmAccum& ac = spgemm_accum();
-      ac.calls -= S - 1;
-      ac.alg_bytes -= (double)(S - 1) * ((A.cplx ? 20.0 : 12.0) * (double)B.nnz + 4.0 * (2.0 * n + A.cols + 3.0));
-      return;
+    // (the iterates of a solve fill in: when the remembered strip count no longer fits, twice the strips -- up to the 16
+    // the merge kernel interleaves -- before the whole-operand path, whose upper-bound slots are tens of GB here)
+    for (int S = strips_memory(A.cplx)[1]; S <= kMaxStrips; S *= 2) {
+      int shift = 6;
+      while ((1 << (shift + 1)) * 8.0 * S <= avg_span && shift < 24) ++shift;
+      if (spgemm_striped(A, B, C, alpha, threshold, dense_rule, S, shift)) {
+        strips_memory(A.cplx)[1] = S;
+        SpgemmStats& ls = last_spgemm_stats();
+        ls.nnz_a = A.nnz;
+        ls.nnz_c = C.nnz;
+        ls.strips = S;
+        SpgemmAccum& ac = spgemm_accum();
+        ac.calls -= S - 1;
+        ac.alg_bytes -= (double)(S - 1) * ((A.cplx ? 20.0 : 12.0) * (double)B.nnz + 4.0 * (2.0 * n + A.cols + 3.0));
+        return;
+      }
+      if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM")) std::fprintf(stderr, "spgemm: %d strips no longer fit\n", S);
     }
     strips_memory(A.cplx)[0] = -1;   // (did not fit this time: the ordinary path decides again)
     t_all = EventTimer(timing);
@@ -3542,7 +3548,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       // Most groups outgrew the largest table: the columns of the product hold too many distinct rows (a 3-D
       // Hamiltonian).  Inside a strip multiply that is the answer; otherwise multiply in row strips of A (above), with
       // twice the strips until every piece fits; the strip count that worked is remembered per dimension.
-      if (gi.failed_cols * 10 > (int64_t)n && sv_opt < 0 && !arange && !loose_in) {
+      static const int fail_pct = std::getenv("NTPOLY_AMD_STRIP_FAIL_PCT") ? std::atoi(std::getenv("NTPOLY_AMD_STRIP_FAIL_PCT")) : 10;
+      if (gi.failed_cols * 100 > (int64_t)n * fail_pct && sv_opt < 0 && !arange && !loose_in) {
         StripCtx& sc = strip_ctx();
         if (sc.active) {
           sc.failed = true;
@@ -3571,7 +3578,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
           event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
           event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
         }
-        for (int S = (mem[0] == n && mem[1] >= 2) ? mem[1] : 2; S <= 8; S *= 2) {
+        for (int S = (mem[0] == n && mem[1] >= 2) ? mem[1] : 2; S <= kMaxStrips; S *= 2) {
           // blocks of rows: about eight per strip inside a column's extent, at least 64 rows
           int shift = 6;
           while ((1 << (shift + 1)) * 8.0 * S <= avg_span && shift < 24) ++shift;
@@ -3592,7 +3599,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
             return;
           }
         }
-        // (not even eight strips: the per-column kernels below take the columns; timers were handed back above)
+        // (not even sixteen strips: the per-column kernels below take the columns; timers were handed back above)
         t_all = EventTimer(timing);
         t_num = EventTimer(timing);
         t_all.start();
@@ -3948,6 +3955,7 @@ void launch_slab_plan(SlabPlan& P, int n, const int32_t* first, const int32_t* l
   DevBuf<int64_t> bsz(snb), tsz(snb);
   hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, first, last, afirst,
                      alast, P.blk_lo.p, P.blk_w.p, P.blk_kmin.p, P.blk_kn.p, bsz.p, tsz.p, snb, align);
+  // (one workgroup doing the scan and the maxima in a single launch was tried: 50 us against the 20 of these four)
   hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), P.blk_w.p, P.blk_kn.p, snb, (const int32_t*)nullptr, 0, stats);
   scan_async<int64_t>(tsz.p, P.blk_toff.p, (int64_t)snb);
 }
@@ -3985,7 +3993,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   //  statistics of the next step's plan 24]
   DevBuf<int64_t> zwords((size_t)4 * snb + 4 + 48);
   zwords.zero();
-  count.zero();
+  if (!tile) count.zero();   // (the tile kernel writes the count of every column)
   int64_t* fz_flag = zwords.p;
   int64_t* fz_pnnz = zwords.p + 2;
   double* fz_part = reinterpret_cast<double*>(zwords.p + 3 + 2 * (size_t)snb);

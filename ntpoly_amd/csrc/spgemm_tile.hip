@@ -129,6 +129,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     if (tid < SLAB_J && j < a.ncols) {
       a.ofirst[j] = INT_MAX;
       a.olast[j] = -1;
+      a.count[j] = 0;
       a.ooff[j] = tbase + (int64_t)tid * w;
       if constexpr (EPI != 0) {
         if (a.fzv.oplast) a.fzv.oplast[j] = -1;
