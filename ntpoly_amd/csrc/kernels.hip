@@ -3973,9 +3973,11 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   // rows per lane of the tile kernel: what the option asks for, if the runs of X (and of D) are padded for it; the runs
   // of a halo sit packed in the receive buffer: one row per lane there
   int trows = 1;
-  if (tile && !halo) {
+  if (tile) {
     trows = tile_rows();
-    while (trows > 1 && in.row_pad % trows != 0) trows >>= 1;   // (row groups start at multiples of R: the pads must cover them)
+    // (row groups start at multiples of R: the pads must cover them -- of the iterate's own runs and of the runs a halo
+    // brought: the senders pack them into aligned zero-padded slots, SlabHalo::row_pad)
+    while (trows > 1 && (in.row_pad % (16 * trows) != 0 || (halo && halo->row_pad % (16 * trows) != 0))) trows >>= 1;
   }
   const int n = X.cols, snb = cdiv(n, SLAB_J);
   const DotOperand& dop = dot_operand(*fu.D);
@@ -5071,24 +5073,28 @@ __global__ void k_slab_request(const int32_t* __restrict__ first, const int32_t*
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) out4[2] = out4[3] = nnz;
 }
+// (al > 1: the runs travel in the aligned zero-padded slots the MFMA tile kernel reads several rows per lane from --
+// span = slot size, SlabForm::row_pad)
 __global__ void k_slab_extents(const int32_t* __restrict__ first, const int32_t* __restrict__ last, int n,
-                               long long* __restrict__ ext, int32_t* __restrict__ span) {
+                               long long* __restrict__ ext, int32_t* __restrict__ span, int al) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int f = first[j], l = last[j];
   ext[j] = (long long)(unsigned)f | ((long long)l << 32);
-  span[j] = l >= f ? l - f + 1 : 0;
+  span[j] = l >= f ? (l / al + 1) * al - f / al * al : 0;
 }
 __global__ __launch_bounds__(256) void k_slab_pack_runs(const int32_t* __restrict__ first, const int32_t* __restrict__ last,
                                                         const int64_t* __restrict__ off, const double* __restrict__ val,
-                                                        const int64_t* __restrict__ pre, int ja, int jb, double* __restrict__ dst) {
+                                                        const int64_t* __restrict__ pre, int ja, int jb, double* __restrict__ dst, int al) {
   const int j = ja + (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   if (j >= jb) return;
   const int lane = lane_id();
   const int f = first[j], l = last[j];
+  if (l < f) return;
   const double* __restrict__ src = val + off[j];
   double* __restrict__ d = dst + (pre[j] - pre[ja]);
-  for (int i = lane; i <= l - f; i += WAVE) d[i] = src[i];
+  const int a0 = f / al * al, a1 = (l / al + 1) * al;   // the slot: zeros around the run
+  for (int r = a0 + lane; r < a1; r += WAVE) d[r - a0] = (r >= f && r <= l) ? src[r - f] : 0.0;
 }
 // extents and run addresses of the columns ka .. kb a rank needs: its own from its buffers, the others from the
 // receive buffer (source s: its segment [ra_s, rb_s) packed back to back at recv + zoff[s])
@@ -5098,7 +5104,7 @@ __global__ void k_slab_halo_layout(const long long* __restrict__ ext_all, const 
                                    const int64_t* __restrict__ own_off, const double* __restrict__ own_val,
                                    int32_t* __restrict__ first, int32_t* __restrict__ last,
                                    unsigned long long* __restrict__ addr, const long long* __restrict__ cnt_all,
-                                   int32_t* __restrict__ count) {
+                                   int32_t* __restrict__ count, int al) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kb - ka) return;
   const int k = ka + i;
@@ -5111,7 +5117,7 @@ __global__ void k_slab_halo_layout(const long long* __restrict__ ext_all, const 
   last[i] = (int)(e >> 32);
   const double* p;
   if (s == me) p = own_val + own_off[k - c0];
-  else p = recv + zoff[s] + (pre_all[(size_t)s * pitch + (k - c0)] - pre_all[(size_t)s * pitch + (ra[s] - c0)]);
+  else p = recv + zoff[s] + (pre_all[(size_t)s * pitch + (k - c0)] - pre_all[(size_t)s * pitch + (ra[s] - c0)]) + (first[i] - first[i] / al * al);
   addr[i] = (unsigned long long)reinterpret_cast<uintptr_t>(p);
   if (count) count[i] = (int32_t)cnt_all[(size_t)s * pitch + (k - c0)];
 }
@@ -5157,7 +5163,7 @@ void slab_extents_async(const DevMat& X, int64_t* d_ext, int64_t* d_pre) {
   const int n = X.cols;
   DevBuf<int32_t> span((size_t)n);
   hipLaunchKernelGGL(k_slab_extents, dim3(cdiv(n, 256)), dim3(256), 0, stream(), X.slab->first.p, X.slab->last.p, n,
-                     reinterpret_cast<long long*>(d_ext), span.p);
+                     reinterpret_cast<long long*>(d_ext), span.p, std::max(1, X.slab->row_pad));
   scan_async<int32_t>(span.p, d_pre, (int64_t)n);
 }
 
@@ -5165,7 +5171,7 @@ void slab_pack_runs_async(const DevMat& X, const int64_t* d_pre, int32_t ja, int
   if (jb <= ja) return;
   const SlabForm& f = *X.slab;
   hipLaunchKernelGGL(k_slab_pack_runs, dim3(cdiv((int64_t)(jb - ja) * WAVE, 256)), dim3(256), 0, stream(), f.first.p, f.last.p,
-                     f.off.p, f.val.p, d_pre, ja, jb, dst);
+                     f.off.p, f.val.p, d_pre, ja, jb, dst, std::max(1, f.row_pad));
 }
 
 void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, int pitch, int32_t dim, int P, int me,
@@ -5176,7 +5182,7 @@ void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, 
   hipLaunchKernelGGL(k_slab_halo_layout, dim3(cdiv(kb - ka, 256)), dim3(256), 0, stream(),
                      reinterpret_cast<const long long*>(d_ext_all), reinterpret_cast<const long long*>(d_pre_all), pitch, dim, P, me,
                      ka, kb, d_ra, d_zoff, d_recv, X.slab->off.p, X.slab->val.p, d_first, d_last, d_addr,
-                     reinterpret_cast<const long long*>(d_cnt_all), d_count);
+                     reinterpret_cast<const long long*>(d_cnt_all), d_count, std::max(1, X.slab->row_pad));
 }
 
 void slab_counts_async(const DevMat& X, int64_t* d_cnt64) {
@@ -5782,7 +5788,7 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
   }
   const SlabForm &fa = *A.slab, &fb = *B.slab;
   int trows = tile_rows();
-  while (trows > 1 && fa.row_pad % trows != 0) trows >>= 1;
+  while (trows > 1 && fa.row_pad % (16 * trows) != 0) trows >>= 1;
   if (fa.row_pad % 16 != 0) return false;
   const int n = B.cols, snb = cdiv(n, SLAB_J);
   const bool timing = options().time_kernels != 0;

@@ -139,6 +139,7 @@ struct SlabHalo {   // A side of a panel step: the columns ka .. kb (global numb
   const int32_t* last = nullptr;
   const unsigned long long* addr = nullptr;  // [kb - ka] device: address of its run (own buffer or receive buffer)
   const int32_t* count = nullptr;            // [kb - ka] device, optional (statistics): entries of the column
+  int row_pad = 1;                           // the received runs sit in slots aligned to this many rows, zero padded (SlabForm::row_pad)
   SlabReduce* reduce = nullptr;
   // optional: the plan of this step, made by the caller from the all-gathered extents and read back together with the
   // exchange layout (slab_plan_panel_async) -- the step then launches without a read-back of its own (and may keep

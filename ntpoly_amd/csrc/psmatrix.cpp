@@ -725,6 +725,7 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   halo.last = nlast.p;
   halo.addr = naddr.p;
   halo.count = ncount.p;
+  halo.row_pad = std::max(1, B.loc.slab->row_pad);   // (every rank packs with the alignment of its panel: the same option everywhere)
   halo.plan = &plan;
   red.allreduce = &dev_allreduce4;
   halo.reduce = &red;
