@@ -5200,7 +5200,37 @@ struct RelabelCache {   // one entry: the order found for the pattern of D, D in
   bool usable = false;
   DevBuf<int32_t> newpos, lab;
   DevMat Dr;
+  // the sparsity pattern the order was found for (an order-independent sum of per-entry hashes + dimensions): the next
+  // operand with the SAME pattern and other values -- the next cycle of a self-consistent-field loop -- reuses the order
+  // (and the verdict "no band in it") without searching again
+  unsigned long long fingerprint = 0;
+  bool searched = false;
 };
+__global__ __launch_bounds__(256) void k_pattern_fingerprint(Csc A, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long red[4];
+  unsigned long long h = 0;
+  for (int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE; j < A.cols; j += gridDim.x * blockDim.x / WAVE) {
+    for (int64_t p = A.outer[j] + lane_id(); p < A.outer[j + 1]; p += WAVE) {
+      unsigned long long x = ((unsigned long long)(unsigned)j << 32) | (unsigned)A.inner[p];
+      x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;   // (murmur3 finaliser)
+      h += x;
+    }
+  }
+  h = (unsigned long long)wave_sum_i64((int64_t)h);
+  if (lane_id() == 0) red[threadIdx.x / WAVE] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+unsigned long long pattern_fingerprint(const DevMat& D) {
+  DevBuf<unsigned long long> acc(1);
+  acc.zero();
+  hipLaunchKernelGGL(k_pattern_fingerprint, dim3(1024), dim3(256), 0, stream(), view(D), acc.p);
+  unsigned long long h = 0;
+  ScalarFetch f;
+  f.add(acc.p, 1, &h);
+  f.run();
+  return h ^ ((unsigned long long)D.nnz * 0x9e3779b97f4a7c15ull) ^ (unsigned long long)D.cols;
+}
 RelabelCache& relabel_cache() {
   static RelabelCache* c = new RelabelCache();
   return *c;
@@ -5221,8 +5251,16 @@ void relabel_giveup(const DevMat& D) {   // a step on the relabelled form was re
 }
 
 void drop_operand_caches() {   // the device memory kept between solves (expanded D, D in the recovered order)
-  relabel_cache() = RelabelCache();
+  RelabelCache& c = relabel_cache();   // (the order itself -- 8 bytes per column -- and its pattern fingerprint stay)
+  c.Dr = DevMat();
+  c.val = nullptr;
+  c.serial = 0;
+  c.usable = false;
   drop_dot_operand();
+}
+long long& band_searches() {
+  static long long n = 0;
+  return n;
 }
 
 const DevMat* relabelled_operand(const DevMat& D) {
@@ -5259,6 +5297,9 @@ bool relabel_enter(DevMat& X, const DevMat& D) {
     X.zero_free = 1;
   }
   if (!relabel_key_matches(c, D)) {
+    const unsigned long long fp = pattern_fingerprint(D);
+    const bool same_pattern = c.searched && c.fingerprint == fp && c.cols == D.cols && c.nnz == D.nnz;
+    const bool had_order = same_pattern && c.newpos.p != nullptr && (int64_t)c.newpos.n == (int64_t)n;
     c.val = D.val.p;
     c.serial = dev_alloc_serial(D.val.p);
     c.epoch = value_epoch();
@@ -5266,14 +5307,21 @@ bool relabel_enter(DevMat& X, const DevMat& D) {
     c.cols = D.cols;
     c.usable = false;
     c.Dr = DevMat();
-    int64_t bw = 0;
-    DevBuf<int32_t> pos;
-    if (!find_band_order(D, pos, &bw)) return false;
-    // worth it when the band holds the entries densely: rows per column of the band against entries per column
-    if (bw > 700 || (double)(2 * bw + 1) > 3.0 * (double)D.nnz / (double)n) return false;
-    c.newpos = std::move(pos);
-    c.lab.alloc((size_t)n);
-    hipLaunchKernelGGL(k_invert_perm, dim3(cdiv(n, 256)), dim3(256), 0, stream(), c.newpos.p, n, c.lab.p);
+    if (same_pattern && !had_order) return false;   // (this pattern was searched before: no band in it)
+    if (!had_order) {
+      c.fingerprint = fp;
+      c.searched = true;
+      c.newpos.release();
+      int64_t bw = 0;
+      DevBuf<int32_t> pos;
+      band_searches() += 1;
+      if (!find_band_order(D, pos, &bw)) return false;
+      // worth it when the band holds the entries densely: rows per column of the band against entries per column
+      if (bw > 700 || (double)(2 * bw + 1) > 3.0 * (double)D.nnz / (double)n) return false;
+      c.newpos = std::move(pos);
+      c.lab.alloc((size_t)n);
+      hipLaunchKernelGGL(k_invert_perm, dim3(cdiv(n, 256)), dim3(256), 0, stream(), c.newpos.p, n, c.lab.p);
+    }
     c.Dr = remap_general(D, c.newpos.p, c.newpos.p, n, 0, n, false);
     c.usable = true;
   }

@@ -193,6 +193,7 @@ void drop_operand_caches();   // frees what the fused / relabelled TRS2 paths ke
 bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidth);
 // since start: [0] steps computed with SlabFusion mode 1, [1] mode 2, [2] fused steps repeated on the unfused path
 long long* fusion_counts();
+long long& band_searches();   // searches for a bandwidth-reducing order since start (one per sparsity PATTERN: relabel_enter)
 
 // B <- alpha*A + B (AddSparseVectors semantics), same shape and scalar type.
 void increment(const DevMat& A, DevMat& B, double alpha, double threshold);

@@ -201,6 +201,9 @@ void ntpoly_amd_fusion_counts(long long* out) {
 void ntpoly_amd_slab_algebra_counts(long long* out) {
   for (int q = 0; q < 4; ++q) out[q] = slab_algebra_counts()[q];
 }
+// searches for a bandwidth-reducing order since start: one per sparsity pattern, not per operand (the next cycle of an
+// SCF loop -- same pattern, other values -- reuses the order)
+void ntpoly_amd_band_searches(long long* out) { *out = band_searches(); }
 void ntpoly_amd_reset_spgemm_accum() {
   flush_spgemm_timers();
   spgemm_accum() = SpgemmAccum();

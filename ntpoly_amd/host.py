@@ -882,6 +882,13 @@ def fusion_counts():
     return dict(square=out[0], update=out[1], repeated=out[2])
 
 
+def band_searches():
+    """searches for a bandwidth-reducing order since start (one per sparsity pattern)"""
+    out = C.c_longlong()
+    lib.ntpoly_amd_band_searches(C.byref(out))
+    return int(out.value)
+
+
 def slab_algebra_counts():
     """operations of the solver loops done on matrices in slab form since start, and those that went back to compressed columns"""
     out = (C.c_longlong * 4)()

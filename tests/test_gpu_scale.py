@@ -246,6 +246,40 @@ def test_relabelled_trs2_vs_oracle(nt, arith, label_order):
     assert np.abs(kv[ko] - ov[oo]).max() <= 1e-13
 
 
+def test_band_order_is_found_once_per_pattern(nt):
+    """the next cycle of a self-consistent-field loop -- the same sparsity pattern with other values, in a new matrix -- reuses
+    the bandwidth-reducing order of the first (RelabelCache::fingerprint: no second search), with every step fused and
+    the result equal to a solve that searched (operand cache dropped, order kept; and with the cache reset by a
+    different pattern in between)"""
+    from gen import permuted_banded_triplets
+    n, h, thr, iters = 16384, 40, 1e-8, 6
+    nt.set_option("spgemm_fma", 1)
+    try:
+        col, row, val = permuted_banded_triplets(n, h, 7)
+        ISQ = nt.Matrix_ps(n)
+        ISQ.FillIdentity()
+        res = []
+        for cycle, shift in enumerate((0.0, 0.05, 0.05)):
+            if cycle == 2:   # (a different pattern in between: the order of the first is gone, the third solve searches again)
+                c2, r2, v2 = permuted_banded_triplets(n, h, 8)
+                H2 = nt.Matrix_ps.from_triplets(n, c2, r2, v2)
+                K2 = nt.Matrix_ps(n)
+                nt.DensityMatrixSolvers.TRS2(H2, ISQ, n / 2.0, K2, _fixed_iteration_params(nt, 2, thr))
+            v = val + shift * (col == row)
+            H = nt.Matrix_ps.from_triplets(n, col, row, v)
+            K = nt.Matrix_ps(n)
+            s0, f0 = nt.band_searches(), nt.fusion_counts()
+            e, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, _fixed_iteration_params(nt, iters, thr))
+            f1 = nt.fusion_counts()
+            res.append((nt.band_searches() - s0, f1["square"] + f1["update"] - f0["square"] - f0["update"], e, K.triplets()))
+        assert [r[0] for r in res] == [1, 0, 1], [r[0] for r in res]
+        assert all(r[1] == iters for r in res), [r[1] for r in res]
+        assert res[1][2] == res[2][2]
+        assert all(np.array_equal(a, b) for a, b in zip(res[1][3], res[2][3]))
+    finally:
+        nt.set_option("spgemm_fma", 0)
+
+
 def test_lattice_vs_oracle(nt, arith):
     """An operand WITHOUT band structure that no relabelling can repair (tests/gen.py lattice_triplets: a 3-D lattice,
     203 couplings per site, column extents of +-3 L^2 rows): products through the grouped LDS-hash kernel -- in row

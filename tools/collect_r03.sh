@@ -19,4 +19,11 @@ mkdir -p gpurun_out/${tag}_lattice
 timeout 900 python3 bench.py --lattice 64 --steps 4 --warmup 4 > gpurun_out/${tag}_lattice/bench.json 2> gpurun_out/${tag}_lattice/bench.err
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_lattice/stats -o run -- python3 bench.py --lattice 64 --steps 3 --warmup 3 --no-cpu-baseline --no-wrp-check > gpurun_out/${tag}_lattice/stats.log 2>&1
 python3 tools/prof_summary.py gpurun_out/${tag}_lattice/stats/run_results.db > gpurun_out/${tag}_lattice/kernel_stats.csv
+# TRS4 on the headline operand with the loop on compressed columns and in slab form: kernel statistics
+for sa in 0 1; do
+  NTPOLY_AMD_SLAB_ALGEBRA=$sa timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trs4_sa$sa -o run -- python3 tools/solver_iterations.py > gpurun_out/${tag}_trs4_sa$sa.log 2>&1
+  python3 tools/prof_summary.py gpurun_out/${tag}_trs4_sa$sa/run_results.db > gpurun_out/${tag}_trs4_sa${sa}_kernel_stats.csv
+done
+SOLVER=sign timeout 600 python3 tools/solver_iterations.py > gpurun_out/${tag}_sign_iterations.log 2>&1
+timeout 900 python3 tools/solve_time.py fma > gpurun_out/${tag}_solve_time.txt 2>&1
 echo "== done"; ls gpurun_out/${tag}*

@@ -13,5 +13,9 @@ for a in fma unfused; do [ -s gpurun_out/${tag}_other_configs_$a.json ] && cp gp
 [ -s gpurun_out/${tag}_rank_share.json ] && cp gpurun_out/${tag}_rank_share.json profiles/r03_rank_share.json
 [ -s gpurun_out/${tag}_lattice/bench.json ] && tail -1 gpurun_out/${tag}_lattice/bench.json > profiles/${tag}_lattice_bench.json
 [ -s gpurun_out/${tag}_lattice/kernel_stats.csv ] && cp gpurun_out/${tag}_lattice/kernel_stats.csv profiles/${tag}_lattice_kernel_stats.csv
+[ -s gpurun_out/${tag}_trs4_sa0_kernel_stats.csv ] && cp gpurun_out/${tag}_trs4_sa0_kernel_stats.csv profiles/r03_trs4_kernel_stats_before.csv
+[ -s gpurun_out/${tag}_trs4_sa1_kernel_stats.csv ] && cp gpurun_out/${tag}_trs4_sa1_kernel_stats.csv profiles/r03_trs4_kernel_stats_slab_algebra.csv
+[ -s gpurun_out/${tag}_solve_time.txt ] && grep -v "^W2\|^$" gpurun_out/${tag}_solve_time.txt > profiles/r03_solve_time.txt
+{ grep "ms per iteration" gpurun_out/${tag}_trs4_sa0.log gpurun_out/${tag}_trs4_sa1.log gpurun_out/${tag}_sign_iterations.log 2>/dev/null; } > profiles/r03_solver_iterations.txt
 { echo "== tools/micro/mfma_f64_probe.hip"; cat gpurun_out/mfma_probe.log; echo; echo "== tools/micro/mfma_layout.hip"; cat gpurun_out/mfma_layout.log; echo; echo "== tools/micro/mfma_f64_valu.hip"; cat gpurun_out/mfma_f64_valu.log; } > profiles/r03_micro_mfma_f64.txt 2>/dev/null
 ls -la profiles/ | grep r03
