@@ -132,8 +132,8 @@ def sources_sha16():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=262144)
     ap.add_argument("--halfband", type=int, default=100)
     ap.add_argument("--threshold", type=float, default=1e-8)
