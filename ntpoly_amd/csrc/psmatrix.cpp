@@ -128,7 +128,7 @@ void slab_refused(std::initializer_list<const PSMatrix*> ms) {
 void slab_pack_if(std::initializer_list<const PSMatrix*> ms) {
   if (g_slab_depth == 0) return;   // (outside a session nothing is left in slab form by one)
   for (const PSMatrix* m : ms)
-    if (m->loc.expanded() && !(m->loc.slab && m->loc.slab->labelled())) pack(mut(*m));
+    if (m->loc.expanded() || m->loc.loose()) pack(mut(*m));
 }
 }  // namespace
 
@@ -467,6 +467,11 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     const bool dense_rule = denom > 0 && std::min((double)A.loc.nnz / denom, (double)B.loc.nnz / denom) > 0.1;
     if (slab_enter(mut(A)) && (&A == &B || slab_enter(mut(B))) && slab_multiply(A.loc, B.loc, AB, alpha, threshold, dense_rule)) {
       g_slab_counts[0] += 1;
+      if (options().time_kernels != 0) {   // (statistics mode: the products a plan over compressed columns would have counted)
+        const long long pr = slab_product_count(A.loc, B.loc);
+        last_spgemm_stats().products = pr;
+        spgemm_accum().products += pr;
+      }
       C.grid = A.grid; C.dim = A.dim; C.c0 = B.c0; C.c1 = B.c1;
       C.cplx = false;
       C.loc = std::move(AB);
@@ -476,6 +481,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   } else {
     slab_pack_if({&A, &B});
   }
+  if ((C.loc.expanded() || C.loc.loose()) && &C != &A && &C != &B) pack(C.loc);   // (beta != 0 reads it below; otherwise it is replaced)
   if (S <= 1) {
     AB = multiply_panel(A, B, alpha, threshold);
   } else {

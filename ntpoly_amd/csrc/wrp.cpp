@@ -37,6 +37,16 @@ PSMatrix* get_unpacked(const int* ih) {
   if (!p) NTP_FATAL("null handle passed to the C ABI");
   return p;
 }
+// The vocabulary entry points (MatrixMultiply, IncrementMatrix, ScaleMatrix, CopyMatrix, DotMatrix, MatrixNorm) run
+// inside a slab session of their own (engine.hpp SlabSession; FMA arithmetic, one rank, real, option slab_algebra):
+// a caller's own loop over the C ABI then keeps its matrices in the tile kernel's operand form between its calls --
+// operands are converted where they are on first use, products stay where the kernel wrote them -- and every OTHER
+// entry point still sees compressed columns (get<PSMatrix> packs on access).  Session not open: packed as ever.
+struct ApiSession {
+  SlabSession s;
+  ApiSession() : s(true) {}
+  PSMatrix* mat(const int* ih) const { return s.opened ? get_unpacked(ih) : get<PSMatrix>(ih); }
+};
 template <typename T>
 void put(int* ih, T* p) {
   std::memset(ih, 0, sizeof(int) * SIZE_wrp);
@@ -519,8 +529,11 @@ void ConstructEmptyMatrixPG_ps_wrp(int* ih_this, const int* matrix_dim, const in
   ps_construct_empty(*m, *matrix_dim, get<ProcessGrid>(ih_grid), false);
   put(ih_this, m);
 }
-void CopyMatrix_ps_wrp(const int* ih_matA, int* ih_matB) { ps_copy(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB)); }
-void DestructMatrix_ps_wrp(int* ih_this) { delete get<PSMatrix>(ih_this); }
+void CopyMatrix_ps_wrp(const int* ih_matA, int* ih_matB) {
+  ApiSession ses;
+  ps_copy(*ses.mat(ih_matA), *ses.mat(ih_matB));
+}
+void DestructMatrix_ps_wrp(int* ih_this) { delete get_unpacked(ih_this); }
 void ConstructMatrixFromMatrixMarket_ps_wrp(int* ih_this, const char* file_name, const int* name_size) {
   PSMatrix* m = new PSMatrix();
   ps_read_matrix_market(*m, fstring(file_name, name_size), default_grid());
@@ -580,7 +593,7 @@ void FillMatrixPermutation_ps_wrp(int* ih_this, const int* ih_permutation, const
 void FillMatrixIdentity_ps_wrp(int* ih_this) { ps_fill_identity(*get<PSMatrix>(ih_this)); }
 void GetMatrixActualDimension_ps_wrp(const int* ih_this, int* size) { *size = get<PSMatrix>(ih_this)->dim; }
 void GetMatrixLogicalDimension_ps_wrp(const int* ih_this, int* size) { *size = get<PSMatrix>(ih_this)->dim; }
-void GetMatrixSize_ps_wrp(const int* ih_this, long int* size) { *size = (long int)ps_size(*get<PSMatrix>(ih_this)); }
+void GetMatrixSize_ps_wrp(const int* ih_this, long int* size) { *size = (long int)ps_size(*get_unpacked(ih_this)); }   // (the entry count is kept in every storage form)
 // PSMatrix_c.h:31 (wrapper PSMatrixModule_wrp.F90:259-266)
 void FillMatrixDense_ps_wrp(int* ih_this) { ps_fill_dense(*get<PSMatrix>(ih_this)); }
 // PSMatrix_c.h:37-44 (wrapper :344-391): blocks are [start, end) with 1-based indices, slices are inclusive
@@ -665,7 +678,8 @@ void ntpoly_amd_matrix_local_columns(const int* ih_this, int* c0, int* c1) {
 
 void DotMatrix_psr_wrp(const int* ih_matA, const int* ih_matB, double* product) {
   double out[2];
-  ps_dot(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), out);
+  ApiSession ses;
+  ps_dot(*ses.mat(ih_matA), *ses.mat(ih_matB), out);
   *product = out[0];
 }
 void DotMatrix_psc_wrp(const int* ih_matA, const int* ih_matB, double* product_real, double* product_imag) {
@@ -675,7 +689,8 @@ void DotMatrix_psc_wrp(const int* ih_matA, const int* ih_matB, double* product_r
   *product_imag = out[1];
 }
 void IncrementMatrix_ps_wrp(const int* ih_matA, int* ih_matB, const double* alpha_in, const double* threshold_in) {
-  ps_increment(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), *alpha_in, *threshold_in);
+  ApiSession ses;
+  ps_increment(*ses.mat(ih_matA), *ses.mat(ih_matB), *alpha_in, *threshold_in);
 }
 void MatrixPairwiseMultiply_ps_wrp(const int* ih_matA, const int* ih_matB, int* ih_matC) {
   ps_pairwise(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), *get<PSMatrix>(ih_matC));
@@ -683,11 +698,17 @@ void MatrixPairwiseMultiply_ps_wrp(const int* ih_matA, const int* ih_matB, int* 
 void MatrixMultiply_ps_wrp(const int* ih_matA, const int* ih_matB, int* ih_matC, const double* alpha_in,
                            const double* beta_in, const double* threshold_in, int* ih_memory_pool_in) {
   (void)ih_memory_pool_in;
-  ps_multiply(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), *get<PSMatrix>(ih_matC), *alpha_in, *beta_in,
-              *threshold_in);
+  ApiSession ses;
+  ps_multiply(*ses.mat(ih_matA), *ses.mat(ih_matB), *ses.mat(ih_matC), *alpha_in, *beta_in, *threshold_in);
 }
-void ScaleMatrix_ps_wrp(int* ih_this, const double* constant) { ps_scale(*get<PSMatrix>(ih_this), *constant); }
-double MatrixNorm_ps_wrp(const int* ih_this) { return ps_norm(*get<PSMatrix>(ih_this)); }
+void ScaleMatrix_ps_wrp(int* ih_this, const double* constant) {
+  ApiSession ses;
+  ps_scale(*ses.mat(ih_this), *constant);
+}
+double MatrixNorm_ps_wrp(const int* ih_this) {
+  ApiSession ses;
+  return ps_norm(*ses.mat(ih_this));
+}
 double MeasureAsymmetry_ps_wrp(const int* ih_this) { return ps_measure_asymmetry(*get<PSMatrix>(ih_this)); }
 void MatrixTrace_ps_wrp(const int* ih_this, double* trace_val) { *trace_val = ps_trace(*get<PSMatrix>(ih_this)); }
 int IsIdentity_ps_wrp(const int* ih_this) { return ps_is_identity(*get<PSMatrix>(ih_this)) ? 1 : 0; }

@@ -165,3 +165,42 @@ def test_second_order_square_root_in_slab_form(nt, fma, solver, n, h, thr, shift
         res.append((srt(Out.triplets()), nt.solver_trace()["iterations"], c1["products"] - c0["products"]))
     assert res[0][2] == 0 and res[1][2] >= 3 * (res[1][1] - 1)
     assert res[0][1] == res[1][1] and same_pattern(res[0][0], res[1][0]) and np.array_equal(res[0][0][2], res[1][0][2])
+
+
+def test_callers_own_loop_over_the_c_abi_stays_in_slab_form(nt, fma):
+    """A caller's own loop written against the C ABI -- here McWeeny steps X <- 3 X^2 - 2 X^3 spelled with
+    MatrixMultiply / CopyMatrix / ScaleMatrix / IncrementMatrix, then DotMatrix, MatrixNorm, GetMatrixSize -- runs its
+    vocabulary calls in slab form (every call is a slab session of its own: wrp.cpp ApiSession), and whatever reads the
+    matrices afterwards sees compressed columns: results, scalars and entry counts equal the ones with the option off
+    bit for bit (the dot to reduction order)."""
+    n, h, thr = 8192, 30, 1e-8
+    col, row, val = banded_triplets(n, h, shift=2.0)
+    pool = None
+    out = []
+    for on in (0, 1):
+        nt.set_option("slab_algebra", on)
+        c0 = nt.slab_algebra_counts()
+        X = nt.Matrix_ps.from_triplets(n, col, row, val)
+        X.Scale(0.2)
+        X2, X3, T = nt.Matrix_ps(n), nt.Matrix_ps(n), nt.Matrix_ps(n)
+        sizes = []
+        for it in range(4):
+            X2.Gemm(X, X, pool, 1.0, 0.0, thr)
+            X3.Gemm(X2, X, pool, 1.0, 0.0, thr)
+            nt.lib.CopyMatrix_ps_wrp(X2.ih, T.ih)
+            T.Scale(3.0)
+            T.Increment(X3, -2.0, thr)
+            nt.lib.CopyMatrix_ps_wrp(T.ih, X.ih)
+            sizes.append(X.GetSize())
+        d = float(np.real(X.Dot(X2)))
+        nrm = X.Norm()
+        tr = X.Trace()
+        c1 = nt.slab_algebra_counts()
+        out.append((srt(X.triplets()), srt(X3.triplets()), sizes, d, nrm, tr, c1["products"] - c0["products"],
+                    c1["merges"] - c0["merges"], c1["refusals"] - c0["refusals"]))
+    off, on = out
+    assert off[6] == 0 and on[6] == 8 and on[7] >= 12 and on[8] == 0, (off[6:], on[6:])
+    assert off[2] == on[2]
+    for a, b in ((off[0], on[0]), (off[1], on[1])):
+        assert same_pattern(a, b) and np.array_equal(a[2], b[2])
+    assert abs(off[3] - on[3]) <= 1e-12 * abs(off[3]) and off[4] == pytest.approx(on[4], rel=1e-13) and off[5] == pytest.approx(on[5], rel=1e-13)
