@@ -779,8 +779,17 @@ bool dist_fused_step(PSMatrix& B, int mode, double threshold, const PSMatrix& D,
 
 // TRS2, sigma > 0 (DensityMatrixSolversModule.F90:388-396): X2 = X*X; X = 2X - X2; energy = dot(X, D).  When the
 // register-slab kernel computes X*X the product is never compacted: the merge kernel reads it from its slots.
+namespace {
+// a fused TRS2 step reads the iterate's multiplier tiles; an iterate that the slab algebra left in slab form (runs only,
+// or the read-only view of a matrix with stored zeros) goes back to compressed columns first
+void trs2_iterate_form(PSMatrix& B) {
+  if (B.loc.expanded() && (B.loc.slab->tiles.p == nullptr || B.loc.slab->tile_off.p == nullptr || B.loc.slab->origin)) pack(B.loc);
+}
+}  // namespace
+
 void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
   out[2] = out[3] = 0.0;
+  trs2_iterate_form(B);
   if (B.cplx || D.cplx != B.cplx || (B.grid && B.grid->num_slices > 1)) {   // (process slices: the K-split sums of ps_multiply)
     pack(B.loc);
     ps_multiply(B, B, scratch, 1.0, 0.0, threshold);
@@ -887,6 +896,7 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
 // product stays loose (no compaction pass); otherwise multiply, swap and reduce as before.
 void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
   out[2] = out[3] = 0.0;
+  trs2_iterate_form(B);
   const bool keep_loose = !world().active() && options().loose_iterates != 0 && !B.cplx && !D.cplx &&
                           !(B.grid && B.grid->num_slices > 1);
   if (keep_loose) {

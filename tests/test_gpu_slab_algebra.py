@@ -204,3 +204,36 @@ def test_callers_own_loop_over_the_c_abi_stays_in_slab_form(nt, fma):
     for a, b in ((off[0], on[0]), (off[1], on[1])):
         assert same_pattern(a, b) and np.array_equal(a[2], b[2])
     assert abs(off[3] - on[3]) <= 1e-12 * abs(off[3]) and off[4] == pytest.approx(on[4], rel=1e-13) and off[5] == pytest.approx(on[5], rel=1e-13)
+
+
+def test_trs2_step_on_an_iterate_the_slab_algebra_left_behind(nt, fma):
+    """the step API (ntpoly_amd_trs2_step, what bench.py times) on an iterate that vocabulary calls have just touched --
+    scaled, copied, multiplied: slab form without multiplier tiles -- gives what it gives on compressed columns"""
+    n, h, thr = 8192, 30, 1e-8
+    col, row, val = banded_triplets(n, h)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    e_min, e_max = nt.EigenBounds.GershgorinBounds(H)
+    I = nt.Matrix_ps(n)
+    I.FillIdentity()
+    res = []
+    for on in (0, 1):
+        nt.set_option("slab_algebra", on)
+        X = nt.Matrix_ps(H)
+        X.Scale(-1.0)
+        X.Increment(I, e_max, 0.0)
+        X.Scale(1.0 / (e_max - e_min))
+        X2 = nt.Matrix_ps(n)
+        tr, log = None, []
+        for it in range(6):
+            if it == 3:   # (vocabulary calls between the steps: X <- (X * I) scaled by one)
+                T = nt.Matrix_ps(n)
+                T.Gemm(X, I, None, 1.0, 0.0, 0.0)
+                T.Scale(1.0)
+                nt.lib.CopyMatrix_ps_wrp(T.ih, X.ih)
+                tr = None
+            sigma, energy, tr = nt.trs2_step(X, X2, H, n / 2.0, thr, tr)
+            log.append((sigma, energy, tr))
+        res.append((log, srt(X.triplets())))
+    assert [l[0] for l in res[0][0]] == [l[0] for l in res[1][0]]
+    assert np.allclose([l[1] for l in res[0][0]], [l[1] for l in res[1][0]], rtol=1e-12, atol=1e-12)
+    assert same_pattern(res[0][1], res[1][1]) and np.abs(res[0][1][2] - res[1][1][2]).max() <= 1e-13
