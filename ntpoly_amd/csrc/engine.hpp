@@ -101,6 +101,10 @@ struct SlabSession {
 // Out = alpha A + beta B: CopyMatrix(B, Out); ScaleMatrix(Out, beta); IncrementMatrix(A, Out, alpha, threshold) -- in a
 // slab session one pass without the copy (and B, an identity say, is turned into slab form once instead of its copies)
 void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double alpha, double beta, double threshold);
+// IncrementMatrix(Identity, B, alpha, 0) where the caller KNOWS its first operand is the identity (built by
+// FillMatrixIdentity, possibly under the load balancer's permutation, which leaves it the identity): in a slab session one
+// value per column changes in place; otherwise the ordinary merge
+void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha);
 void ps_slab_leave(PSMatrix& m);
 const long long* slab_algebra_counts();   // [4] since start: products, merges / copies, other operations done in slab form; refusals   // back to compressed columns (no-op for a matrix that is not in slab form)
 void ps_fill_identity(PSMatrix& m);

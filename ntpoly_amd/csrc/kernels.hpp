@@ -176,6 +176,7 @@ bool slab_scale(DevMat& A, double c);
 bool slab_dot(const DevMat& A, const DevMat& B, double out[2]);
 bool slab_norm(const DevMat& A, double* out);   // max column abs-sum
 bool slab_gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx);
+bool slab_add_diagonal(DevMat& B, double alpha, int32_t col_offset);   // B <- B + alpha I in place (slab_stats.hip); false: not done
 long long slab_product_count(const DevMat& A, const DevMat& B);   // statistics (slab_stats.hip): intermediate products of A B
 // compressed columns -> labelled slab form (SlabForm::lab; Xs = the matrix in the bandwidth-reducing order, lab[index] = the
 // caller's index); false (nothing changed): its columns are not run-like

@@ -577,6 +577,14 @@ void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double 
   axpby(A.loc, B.loc, alpha, beta, threshold, nullptr, nullptr);
 }
 
+void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) {
+  if (slab_on() && B.loc.expanded() && !B.cplx && !Identity.cplx && Identity.dim == B.dim && slab_add_diagonal(B.loc, alpha, B.c0)) {
+    g_slab_counts[1] += 1;
+    return;
+  }
+  ps_increment(Identity, B, alpha, 0.0);
+}
+
 void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double alpha, double beta, double threshold) {
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B && A.dim == B.dim) {
     DevMat R;

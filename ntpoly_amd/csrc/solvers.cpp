@@ -699,7 +699,7 @@ void sign_core(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters& 
     } else {
       ps_multiply(Out, Out, Temp1, -1.0 * (alpha_k * alpha_k), 0.0, p.threshold);
     }
-    ps_increment(Identity, Temp1, 3.0, 0.0);
+    ps_increment_identity(Identity, Temp1, 3.0);                   // IncrementMatrix(Identity, Temp1, 3)
     ps_multiply(Out, Temp1, Temp2, 0.5 * alpha_k, 0.0, p.threshold);
     ps_increment(Temp2, Out, -1.0, 0.0);
     const double norm_value = ps_norm(Out);
@@ -926,7 +926,7 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
   SlabSession slab(!SR.cplx);
   for (II = 1; II <= p.max_iterations; ++II) {                     // :415-497
     ps_multiply(ISR, SR, X, 1.0, 0.0, p.threshold);
-    ps_increment(Identity, X, -1.0, 0.0);
+    ps_increment_identity(Identity, X, -1.0);
     const double norm_value = ps_norm(X);
     if (order == 3) {                                              // :425-433
       ps_multiply(X, X, Temp, 1.0, 0.0, p.threshold);
@@ -942,9 +942,9 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
       ps_increment(X, Temp, a, 0.0);
       ps_copy_axpby(Identity, X, Temp2, 1.0, b, 0.0);               // CopyMatrix(Identity, Temp2); ScaleMatrix(Temp2, b); IncrementMatrix(X, Temp2)
       ps_increment(Temp, Temp2, 1.0, 0.0);
-      ps_increment(Identity, Temp, c, 0.0);
+      ps_increment_identity(Identity, Temp, c);
       ps_multiply(Temp2, Temp, X, 1.0, 0.0, p.threshold);
-      ps_increment(Identity, X, d, 0.0);
+      ps_increment_identity(Identity, X, d);
       ps_scale(X, 35.0 / 128.0);
     }
     std::swap(ISR, Temp);                                          // :483-485 (the copy is a hand-over: ISR is rebuilt)
