@@ -105,6 +105,10 @@ void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double a
 // FillMatrixIdentity, possibly under the load balancer's permutation, which leaves it the identity): in a slab session one
 // value per column changes in place; otherwise the ordinary merge
 void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha);
+// TRS4's polynomial chain without its intermediates, for an X and X2 in slab form inside a slab session (false: not
+// done, the caller runs the sequence of merges and dots): the two traces, then P = Fx + sigma Gx
+bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx);
+bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatrix& P);
 void ps_slab_leave(PSMatrix& m);
 const long long* slab_algebra_counts();   // [4] since start: products, merges / copies, other operations done in slab form; refusals   // back to compressed columns (no-op for a matrix that is not in slab form)
 void ps_fill_identity(PSMatrix& m);

@@ -585,6 +585,22 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) 
   ps_increment(Identity, B, alpha, 0.0);
 }
 
+bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx) {
+  if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx) return false;
+  if (!slab_trs4_traces(X.loc, X2.loc, X.c0, trace_fx, trace_gx)) return false;
+  g_slab_counts[2] += 1;
+  return true;
+}
+bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatrix& P) {
+  if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx || sigma == 0.0) return false;
+  DevMat R;
+  if (!slab_trs4_operand(X.loc, X2.loc, sigma, X.c0, R)) return false;
+  P.grid = X.grid; P.dim = X.dim; P.cplx = false; P.c0 = X.c0; P.c1 = X.c1;
+  P.loc = std::move(R);
+  g_slab_counts[1] += 1;
+  return true;
+}
+
 void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double alpha, double beta, double threshold) {
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B && A.dim == B.dim) {
     DevMat R;

@@ -7,6 +7,10 @@
 //     one row both columns can share: both present -> alpha + b kept unless exactly zero; B has a hole there -> alpha).
 #include <hip/hip_runtime.h>
 
+#include <climits>
+#include <cstring>
+#include <memory>
+
 #include "device_util.hpp"
 #include "kernels.hpp"
 
@@ -98,6 +102,196 @@ bool slab_add_diagonal(DevMat& B, double alpha, int32_t col_offset) {
   B.nnz += (long long)h[1];
   f.tiles.release();      // (the multiplier tiles held the old diagonal; the next step's plan depends on the extents only)
   f.tile_off.release();
+  return true;
+}
+
+// ------------------------------------------------------------------ TRS4's polynomial chain in two passes
+// DensityMatrixSolversModule.F90:590-627 builds, with IncrementMatrix at threshold 0,
+//   Fx = 4 X - 3 X2,   Gx = (I - 2 X) + X2,   trace_fx = dot(X2, Fx),   trace_gx = dot(X2, Gx),   P = Fx + sigma Gx
+// element by element: fx = 4 x + (-3 x2), gx = x2 + ((-2 x) + d) (d = 1 on the diagonal), p = fx + sigma gx, every
+// operation rounded on its own and an absent entry entering as zero (adding an exact zero changes nothing, so the values
+// are those of the sequence of merges; an entry of the result is where the value is not zero).  Pass 1 reads X and X2
+// and leaves the two dots; pass 2 reads them again and writes P -- instead of four merges and two dots over
+// materialised Fx and Gx.
+namespace {
+struct Trs4Elem {
+  double fx, gx;
+};
+__device__ inline Trs4Elem trs4_elem(double x, double x2, double d) {
+  Trs4Elem e;
+  e.fx = __dadd_rn(__dmul_rn(4.0, x), __dmul_rn(-3.0, x2));
+  e.gx = __dadd_rn(x2, __dadd_rn(__dmul_rn(-2.0, x), d));
+  return e;
+}
+// MODE 0: part[2 j] = sum x2 fx, part[2 j + 1] = sum x2 gx of column j (summed by k_sa_sum_pairs).  MODE 1: out = fx + sigma gx into the slot at
+// base[j] (aligned union of the runs and the diagonal), kept count / first / last per column.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sa_trs4(int n, const int32_t* __restrict__ fa, const int32_t* __restrict__ la,
+                                                 const int64_t* __restrict__ offa, const double* __restrict__ va,
+                                                 const int32_t* __restrict__ fb, const int32_t* __restrict__ lb,
+                                                 const int64_t* __restrict__ offb, const double* __restrict__ vb, int col_offset,
+                                                 double sigma, int al, const int64_t* __restrict__ base, double* __restrict__ part,
+                                                 double* __restrict__ out, int32_t* __restrict__ ofirst, int32_t* __restrict__ olast,
+                                                 int32_t* __restrict__ ocount, int64_t* __restrict__ ooff) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= n) return;
+  const int lane = lane_id();
+  const int fA = fa[j], lA = la[j], fB = fb[j], lB = lb[j], dg = j + col_offset;
+  const bool anyA = lA >= fA, anyB = lB >= fB;
+  int f = dg, l = dg;   // (the identity's entry is always there)
+  if (anyA) { f = min(f, fA); l = max(l, lA); }
+  if (anyB) { f = min(f, fB); l = max(l, lB); }
+  const int a0 = f / al * al, a1 = (l / al + 1) * al;
+  const double* __restrict__ pa = anyA ? va + (offa[j] - fA) : va;
+  const double* __restrict__ pb = anyB ? vb + (offb[j] - fB) : vb;
+  if (MODE == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = a0 + lane; r < a1; r += WAVE) {
+      const double x = (anyA && r >= fA && r <= lA) ? pa[r] : 0.0;
+      const double x2 = (anyB && r >= fB && r <= lB) ? pb[r] : 0.0;
+      const Trs4Elem e = trs4_elem(x, x2, r == dg ? 1.0 : 0.0);
+      s0 = __dadd_rn(s0, __dmul_rn(x2, e.fx));
+      s1 = __dadd_rn(s1, __dmul_rn(x2, e.gx));
+    }
+    s0 = wave_sum_f64(s0);
+    s1 = wave_sum_f64(s1);
+    if (lane == 0) { part[2 * (size_t)j] = s0; part[2 * (size_t)j + 1] = s1; }
+  } else {
+    const int64_t slot = base[j];
+    double* __restrict__ dst = out + (slot - a0);
+    int cnt = 0, kf = INT_MAX, kl = -1;
+    for (int r = a0 + lane; r < a1; r += WAVE) {
+      const double x = (anyA && r >= fA && r <= lA) ? pa[r] : 0.0;
+      const double x2 = (anyB && r >= fB && r <= lB) ? pb[r] : 0.0;
+      const Trs4Elem e = trs4_elem(x, x2, r == dg ? 1.0 : 0.0);
+      const double p = __dadd_rn(e.fx, __dmul_rn(sigma, e.gx));
+      const bool keep = p != 0.0;
+      dst[r] = keep ? p : 0.0;
+      cnt += keep ? 1 : 0;
+      kf = min(kf, keep ? r : INT_MAX);
+      kl = max(kl, keep ? r : -1);
+    }
+    cnt = (int)wave_sum_i64(cnt);
+    kf = wave_min_i32(kf);
+    kl = wave_max_i32(kl);
+    if (lane == 0) {
+      ofirst[j] = kf; olast[j] = kl; ocount[j] = cnt;
+      ooff[j] = slot + (cnt ? kf - a0 : 0);
+    }
+  }
+}
+__global__ void k_sa_trs4_span(const int32_t* __restrict__ fa, const int32_t* __restrict__ la, const int32_t* __restrict__ fb,
+                               const int32_t* __restrict__ lb, int n, int col_offset, int al, int32_t* __restrict__ span) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int f = j + col_offset, l = j + col_offset;
+  if (la[j] >= fa[j]) { f = min(f, fa[j]); l = max(l, la[j]); }
+  if (lb[j] >= fb[j]) { f = min(f, fb[j]); l = max(l, lb[j]); }
+  span[j] = (l / al + 1) * al - f / al * al;
+}
+__global__ __launch_bounds__(256) void k_sa_count_sum(const int32_t* __restrict__ v, int n, unsigned long long* __restrict__ out) {
+  __shared__ long long red[4];
+  long long s = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += v[i];
+  s = wave_sum_i64(s);
+  if (lane_id() == 0) red[threadIdx.x / WAVE] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long t = red[0] + red[1] + red[2] + red[3];
+    if (t) atomicAdd(out, (unsigned long long)t);
+  }
+}
+// deterministic sum of n (a, b) pairs: fixed assignment of elements to threads, fixed tree -- the same bits every run
+__global__ __launch_bounds__(256) void k_sa_sum_pairs(const double* __restrict__ in, int n, int chunk, double* __restrict__ out) {
+  __shared__ double ra[256], rb[256];
+  const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+  double a = 0.0, b = 0.0;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    a = __dadd_rn(a, in[2 * (size_t)i]);
+    b = __dadd_rn(b, in[2 * (size_t)i + 1]);
+  }
+  ra[threadIdx.x] = a;
+  rb[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      ra[threadIdx.x] = __dadd_rn(ra[threadIdx.x], ra[threadIdx.x + o]);
+      rb[threadIdx.x] = __dadd_rn(rb[threadIdx.x], rb[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = ra[0]; out[2 * blockIdx.x + 1] = rb[0]; }
+}
+void sum_pairs_async(const double* part, int n, double* out2) {
+  const int chunk = 2048, g = cdiv(n, chunk);
+  if (g <= 1) {
+    hipLaunchKernelGGL(k_sa_sum_pairs, dim3(1), dim3(256), 0, stream(), part, n, std::max(n, 1), out2);
+    return;
+  }
+  DevBuf<double> lvl((size_t)2 * g);
+  hipLaunchKernelGGL(k_sa_sum_pairs, dim3(g), dim3(256), 0, stream(), part, n, chunk, lvl.p);
+  hipLaunchKernelGGL(k_sa_sum_pairs, dim3(1), dim3(256), 0, stream(), lvl.p, g, g, out2);
+}
+bool trs4_operands(const DevMat& X, const DevMat& X2) {
+  auto ok = [](const DevMat& M) {
+    return M.expanded() && !M.cplx && M.rows == M.cols && !M.slab->labelled() && !M.slab->origin && M.zero_free == 1;
+  };
+  return ok(X) && ok(X2) && X.cols == X2.cols && X.slab->row_pad == X2.slab->row_pad;
+}
+}  // namespace
+
+bool slab_trs4_traces(const DevMat& X, const DevMat& X2, int32_t col_offset, double* trace_fx, double* trace_gx) {
+  if (!trs4_operands(X, X2)) return false;
+  const SlabForm &fa = *X.slab, &fb = *X2.slab;
+  const int n = X.cols;
+  DevBuf<double> part((size_t)2 * n), res(2);
+  hipLaunchKernelGGL((k_sa_trs4<0>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p, fa.val.p,
+                     fb.first.p, fb.last.p, fb.off.p, fb.val.p, col_offset, 0.0, std::max(1, fa.row_pad), (const int64_t*)nullptr, part.p,
+                     (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
+  sum_pairs_async(part.p, n, res.p);
+  unsigned long long h[2] = {0, 0};
+  ScalarFetch ft;
+  ft.add(res.p, 2, h);
+  ft.run();
+  double d[2];
+  std::memcpy(d, h, sizeof(h));
+  *trace_fx = d[0];
+  *trace_gx = d[1];
+  return true;
+}
+
+bool slab_trs4_operand(const DevMat& X, const DevMat& X2, double sigma, int32_t col_offset, DevMat& Out) {
+  if (!trs4_operands(X, X2)) return false;
+  const SlabForm &fa = *X.slab, &fb = *X2.slab;
+  const int n = X.cols, al = std::max(1, fa.row_pad);
+  std::unique_ptr<SlabForm> fo(new SlabForm());
+  fo->first.alloc((size_t)n); fo->last.alloc((size_t)n); fo->count.alloc((size_t)n); fo->off.alloc((size_t)n + 1);
+  DevBuf<int32_t> span((size_t)n);
+  DevBuf<int64_t> base((size_t)n + 1);
+  hipLaunchKernelGGL(k_sa_trs4_span, dim3(cdiv(n, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, fb.first.p, fb.last.p, n, col_offset,
+                     al, span.p);
+  scan_i32_async(span.p, base.p, (int64_t)n);
+  const int64_t bound = fa.slots + fb.slots + 4LL * al * n;
+  fo->val.alloc((size_t)bound + kIndexSlack);
+  hipLaunchKernelGGL((k_sa_trs4<1>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p, fa.val.p,
+                     fb.first.p, fb.last.p, fb.off.p, fb.val.p, col_offset, sigma, al, base.p, (double*)nullptr, fo->val.p, fo->first.p,
+                     fo->last.p, fo->count.p, fo->off.p);
+  DevBuf<unsigned long long> tot(1);
+  tot.zero();
+  hipLaunchKernelGGL(k_sa_count_sum, dim3(std::max(1, std::min(256, cdiv(n, 1024)))), dim3(256), 0, stream(), fo->count.p, n, tot.p);
+  int64_t nnz = 0, slots = 0;
+  {
+    ScalarFetch ft;
+    ft.add(tot.p, 1, &nnz);
+    ft.add(base.p + n, 1, &slots);
+    ft.run();
+  }
+  fo->row_pad = al;
+  fo->slots = slots;
+  DevMat R;
+  R.rows = X.rows; R.cols = n; R.cplx = false; R.nnz = nnz; R.zero_free = 1;
+  R.slab = std::move(fo);
+  Out = std::move(R);
   return true;
 }
 

@@ -421,11 +421,17 @@ void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
   SlabSession slab(!X.cplx && !WH.cplx);   // (the loop's matrices stay in slab form between its operations where they can)
   for (II = 1; II <= p.max_iterations; ++II) {                     // :586-638
     ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
-    ps_copy_axpby(X2, X, Fx, 4.0, -3.0, 0.0);                       // CopyMatrix(X2, Fx); ScaleMatrix(Fx, -3); IncrementMatrix(X, Fx, 4)
-    ps_copy_axpby(IMat, X, Gx, -2.0, 1.0, 0.0);                     // CopyMatrix(Identity, Gx); IncrementMatrix(X, Gx, -2)
-    ps_increment(X2, Gx, 1.0, 0.0);
-    const double trace_fx = real_dot(X2, Fx);
-    const double trace_gx = real_dot(X2, Gx);
+    // Fx = 4 X - 3 X2, Gx = I - 2 X + X2 and their traces against X2: in a slab session one pass over X and X2 leaves the
+    // traces without building Fx and Gx (the same element arithmetic; IMat is the identity also under load balancing)
+    double trace_fx = 0.0, trace_gx = 0.0;
+    const bool chain_fused = ps_trs4_traces(X, X2, &trace_fx, &trace_gx);
+    if (!chain_fused) {
+      ps_copy_axpby(X2, X, Fx, 4.0, -3.0, 0.0);                     // CopyMatrix(X2, Fx); ScaleMatrix(Fx, -3); IncrementMatrix(X, Fx, 4)
+      ps_copy_axpby(IMat, X, Gx, -2.0, 1.0, 0.0);                   // CopyMatrix(Identity, Gx); IncrementMatrix(X, Gx, -2)
+      ps_increment(X2, Gx, 1.0, 0.0);
+      trace_fx = real_dot(X2, Fx);
+      trace_gx = real_dot(X2, Gx);
+    }
     if (std::fabs(trace_gx) < 1.0e-14) sigma_array[(size_t)II] = 0.5 * (sigma_max - sigma_min);
     else sigma_array[(size_t)II] = (trace - trace_fx) / trace_gx;
     if (sigma_array[(size_t)II] > sigma_max) {
@@ -433,7 +439,14 @@ void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
     } else if (sigma_array[(size_t)II] < sigma_min) {
       ps_copy(X2, Temp);
     } else {
-      ps_axpby(Fx, Gx, 1.0, sigma_array[(size_t)II], 0.0);          // ScaleMatrix(Gx, sigma); IncrementMatrix(Fx, Gx)
+      if (!(chain_fused && ps_trs4_operand(X, X2, sigma_array[(size_t)II], Gx))) {
+        if (chain_fused) {   // (the traces came from the fused pass but the operand cannot: build the intermediates now)
+          ps_copy_axpby(X2, X, Fx, 4.0, -3.0, 0.0);
+          ps_copy_axpby(IMat, X, Gx, -2.0, 1.0, 0.0);
+          ps_increment(X2, Gx, 1.0, 0.0);
+        }
+        ps_axpby(Fx, Gx, 1.0, sigma_array[(size_t)II], 0.0);        // ScaleMatrix(Gx, sigma); IncrementMatrix(Fx, Gx)
+      }
       ps_multiply(X2, Gx, Temp, 1.0, 0.0, p.threshold);
     }
     // :630-631 IncrementMatrix(TempMat, X_k, -1) is overwritten by the copy that follows it; the copy itself is a
