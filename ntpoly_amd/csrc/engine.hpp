@@ -109,6 +109,9 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha);
 // done, the caller runs the sequence of merges and dots): the two traces, then P = Fx + sigma Gx
 bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx);
 bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatrix& P);
+// MatrixNorm of alpha A + beta B (ScaleMatrix(B, beta); IncrementMatrix(A, B, alpha, 0); MatrixNorm(B)) for the loops
+// that build the sum only for its norm; false: not done (outside a slab session, operands in compressed columns ...)
+bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double beta, double* norm);
 void ps_slab_leave(PSMatrix& m);
 const long long* slab_algebra_counts();   // [4] since start: products, merges / copies, other operations done in slab form; refusals   // back to compressed columns (no-op for a matrix that is not in slab form)
 void ps_fill_identity(PSMatrix& m);

@@ -181,6 +181,7 @@ bool slab_add_diagonal(DevMat& B, double alpha, int32_t col_offset);   // B <- B
 // operand (4X - 3X2) + sigma (I - 2X + X2) of the iteration's second product
 bool slab_trs4_traces(const DevMat& X, const DevMat& X2, int32_t col_offset, double* trace_fx, double* trace_gx);
 bool slab_trs4_operand(const DevMat& X, const DevMat& X2, double sigma, int32_t col_offset, DevMat& Out);
+bool slab_norm_axpby(const DevMat& A, const DevMat& B, double alpha, double beta, double* out);   // MatrixNorm(alpha A + beta B), nothing built
 long long slab_product_count(const DevMat& A, const DevMat& B);   // statistics (slab_stats.hip): intermediate products of A B
 // compressed columns -> labelled slab form (SlabForm::lab; Xs = the matrix in the bandwidth-reducing order, lab[index] = the
 // caller's index); false (nothing changed): its columns are not run-like

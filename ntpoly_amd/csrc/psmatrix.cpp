@@ -585,6 +585,13 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) 
   ps_increment(Identity, B, alpha, 0.0);
 }
 
+bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double beta, double* norm) {
+  if (!slab_on() || A.cplx || B.cplx || A.dim != B.dim || &A == &B || !(A.loc.expanded() || B.loc.expanded())) return false;
+  if (!(slab_enter(mut(A)) && slab_enter(mut(B)) && slab_norm_axpby(A.loc, B.loc, alpha, beta, norm))) return false;
+  g_slab_counts[2] += 1;
+  return true;
+}
+
 bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx) {
   if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx) return false;
   if (!slab_trs4_traces(X.loc, X2.loc, X.c0, trace_fx, trace_gx)) return false;

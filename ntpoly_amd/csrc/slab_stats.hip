@@ -295,6 +295,49 @@ bool slab_trs4_operand(const DevMat& X, const DevMat& X2, double sigma, int32_t 
   return true;
 }
 
+// ------------------------------------------------------------------ MatrixNorm(alpha A + beta B) without the sum
+// The loops of SignFunction, Invert and the square roots build a difference (Out - Temp2, I - Temp1, I - X) only to
+// take its norm (max column abs-sum) for the convergence test.  One pass over the two runs of every column: the
+// element is (alpha a) + (beta b) as the merge would compute it, an entry the merge drops (an exact zero) adds nothing.
+namespace {
+__global__ __launch_bounds__(256) void k_sa_norm_axpby(int n, const int32_t* __restrict__ fa, const int32_t* __restrict__ la,
+                                                       const int64_t* __restrict__ offa, const double* __restrict__ va,
+                                                       const int32_t* __restrict__ fb, const int32_t* __restrict__ lb,
+                                                       const int64_t* __restrict__ offb, const double* __restrict__ vb, double alpha,
+                                                       double beta, double* __restrict__ colsum) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= n) return;
+  const int lane = lane_id();
+  const int fA = fa[j], lA = la[j], fB = fb[j], lB = lb[j];
+  const bool anyA = lA >= fA, anyB = lB >= fB;
+  double s = 0.0;
+  if (anyA || anyB) {
+    const int f = anyA ? (anyB ? min(fA, fB) : fA) : fB, l = anyA ? (anyB ? max(lA, lB) : lA) : lB;
+    const double* __restrict__ pa = anyA ? va + (offa[j] - fA) : va;
+    const double* __restrict__ pb = anyB ? vb + (offb[j] - fB) : vb;
+    for (int r = f + lane; r <= l; r += WAVE) {
+      const double a = (anyA && r >= fA && r <= lA) ? pa[r] : 0.0;
+      const double b = (anyB && r >= fB && r <= lB) ? pb[r] : 0.0;
+      s = __dadd_rn(s, fabs(__dadd_rn(__dmul_rn(alpha, a), __dmul_rn(beta, b))));
+    }
+  }
+  s = wave_sum_f64(s);
+  if (lane == 0) colsum[j] = s;
+}
+}  // namespace
+
+bool slab_norm_axpby(const DevMat& A, const DevMat& B, double alpha, double beta, double* out) {
+  auto ok = [](const DevMat& M) { return M.expanded() && !M.cplx && M.rows == M.cols && !M.slab->labelled(); };
+  if (!ok(A) || !ok(B) || A.cols != B.cols) return false;
+  const SlabForm &fa = *A.slab, &fb = *B.slab;
+  const int n = A.cols;
+  DevBuf<double> cs((size_t)n);
+  hipLaunchKernelGGL(k_sa_norm_axpby, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p, fa.val.p,
+                     fb.first.p, fb.last.p, fb.off.p, fb.val.p, alpha, beta, cs.p);
+  *out = max_of(cs, (size_t)n);
+  return true;
+}
+
 long long slab_product_count(const DevMat& A, const DevMat& B) {
   if (!A.expanded() || !B.expanded() || A.cplx || B.cplx) return 0;
   const SlabForm &fa = *A.slab, &fb = *B.slab;

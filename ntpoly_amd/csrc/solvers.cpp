@@ -714,8 +714,11 @@ void sign_core(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters& 
     }
     ps_increment_identity(Identity, Temp1, 3.0);                   // IncrementMatrix(Identity, Temp1, 3)
     ps_multiply(Out, Temp1, Temp2, 0.5 * alpha_k, 0.0, p.threshold);
-    ps_increment(Temp2, Out, -1.0, 0.0);
-    const double norm_value = ps_norm(Out);
+    double norm_value = 0.0;   // (the difference Out - Temp2 is only there for its norm)
+    if (!ps_norm_axpby(Temp2, Out, -1.0, 1.0, &norm_value)) {
+      ps_increment(Temp2, Out, -1.0, 0.0);
+      norm_value = ps_norm(Out);
+    }
     std::swap(Out.loc, Temp2.loc);   // CopyMatrix(Temp2, Out): Temp2 is rebuilt by the next multiply
     monitor_append(mon, norm_value);
     trace_rec(norm_value, 0.0, alpha_k, Out);
@@ -805,8 +808,10 @@ void invert_core(const PSMatrix& InputMat, PSMatrix& OutputMat, const SolverPara
   for (II = 1; II <= p.max_iterations; ++II) {
     if (log_top && p.be_verbose && II > 1) log_list_element("Convergence", norm_value);
     ps_multiply(Out, Balanced, Temp1, 1.0, 0.0, p.threshold);
-    ps_copy_axpby(Identity, Temp1, Temp2, -1.0, 1.0, 0.0);         // CopyMatrix(Identity, Temp2); IncrementMatrix(Temp1, Temp2, -1)
-    norm_value = ps_norm(Temp2);
+    if (!ps_norm_axpby(Temp1, Identity, -1.0, 1.0, &norm_value)) {   // (I - Temp1 is only there for its norm)
+      ps_copy_axpby(Identity, Temp1, Temp2, -1.0, 1.0, 0.0);       // CopyMatrix(Identity, Temp2); IncrementMatrix(Temp1, Temp2, -1)
+      norm_value = ps_norm(Temp2);
+    }
     PSMatrix T2;
     ps_multiply(Temp1, Out, T2, -1.0, 0.0, p.threshold);
     ps_axpby(T2, Out, 1.0, 2.0, p.threshold);                       // ScaleMatrix(Out, 2); IncrementMatrix(T2, Out)
@@ -881,8 +886,11 @@ void isr_order2(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
     max_between = std::fmax(std::fabs(e_min), std::fabs(e_max));
     lambda = 1.0 / max_between;
     ps_scale(X, lambda);
-    ps_copy_axpby(Identity, X, Temp, -1.0, 1.0, 0.0);               // CopyMatrix(Identity, Temp); IncrementMatrix(X, Temp, -1)
-    const double norm_value = ps_norm(Temp);
+    double norm_value = 0.0;   // (I - X is only there for its norm: Temp is handed over as storage below)
+    if (!ps_norm_axpby(X, Identity, -1.0, 1.0, &norm_value)) {
+      ps_copy_axpby(Identity, X, Temp, -1.0, 1.0, 0.0);             // CopyMatrix(Identity, Temp); IncrementMatrix(X, Temp, -1)
+      norm_value = ps_norm(Temp);
+    }
     ps_copy_axpby(Identity, X, T, -1.0, 3.0, 0.0);                  // CopyMatrix(Identity, T); ScaleMatrix(T, 3); IncrementMatrix(X, T, -1)
     ps_scale(T, 0.5);
     std::swap(ISR, Temp);                                           // CopyMatrix(ISR, Temp): ISR is rebuilt by the multiply
