@@ -176,13 +176,13 @@ bool slab_scale(DevMat& A, double c);
 bool slab_dot(const DevMat& A, const DevMat& B, double out[2]);
 bool slab_norm(const DevMat& A, double* out);   // max column abs-sum
 bool slab_gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx);
-bool slab_add_diagonal(DevMat& B, double alpha, int32_t col_offset);   // B <- B + alpha I in place (slab_stats.hip); false: not done
-// TRS4's polynomial chain on slab-form X and X2 (slab_stats.hip): dot(X2, 4X - 3X2), dot(X2, I - 2X + X2); then the right
+bool slab_add_diagonal(DevMat& B, double alpha, int32_t col_offset);   // B <- B + alpha I in place (slab_extra.hip); false: not done
+// TRS4's polynomial chain on slab-form X and X2 (slab_extra.hip): dot(X2, 4X - 3X2), dot(X2, I - 2X + X2); then the right
 // operand (4X - 3X2) + sigma (I - 2X + X2) of the iteration's second product
 bool slab_trs4_traces(const DevMat& X, const DevMat& X2, int32_t col_offset, double* trace_fx, double* trace_gx);
 bool slab_trs4_operand(const DevMat& X, const DevMat& X2, double sigma, int32_t col_offset, DevMat& Out);
 bool slab_norm_axpby(const DevMat& A, const DevMat& B, double alpha, double beta, double* out);   // MatrixNorm(alpha A + beta B), nothing built
-long long slab_product_count(const DevMat& A, const DevMat& B);   // statistics (slab_stats.hip): intermediate products of A B
+long long slab_product_count(const DevMat& A, const DevMat& B);   // statistics (slab_extra.hip): intermediate products of A B
 // compressed columns -> labelled slab form (SlabForm::lab; Xs = the matrix in the bandwidth-reducing order, lab[index] = the
 // caller's index); false (nothing changed): its columns are not run-like
 bool slab_from_csc(DevMat& Xs, DevBuf<int32_t>& lab);
