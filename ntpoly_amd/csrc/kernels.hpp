@@ -182,6 +182,7 @@ bool slab_add_diagonal(DevMat& B, double alpha, int32_t col_offset);   // B <- B
 bool slab_trs4_traces(const DevMat& X, const DevMat& X2, int32_t col_offset, double* trace_fx, double* trace_gx);
 bool slab_trs4_operand(const DevMat& X, const DevMat& X2, double sigma, int32_t col_offset, DevMat& Out);
 bool slab_norm_axpby(const DevMat& A, const DevMat& B, double alpha, double beta, double* out);   // MatrixNorm(alpha A + beta B), nothing built
+bool slab_trace(const DevMat& A, int32_t col_offset, double* out);   // sum of the diagonal entries held by the local columns
 long long slab_product_count(const DevMat& A, const DevMat& B);   // statistics (slab_extra.hip): intermediate products of A B
 // compressed columns -> labelled slab form (SlabForm::lab; Xs = the matrix in the bandwidth-reducing order, lab[index] = the
 // caller's index); false (nothing changed): its columns are not run-like

@@ -1026,6 +1026,16 @@ void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
 }
 
 double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includes/MatrixTrace.f90)
+  if (slab_on() && A.loc.expanded() && !A.cplx) {
+    double v = 0.0;
+    if (slab_trace(A.loc, A.c0, &v)) {
+      g_slab_counts[2] += 1;
+      return v;
+    }
+    slab_refused({&A});
+  } else {
+    slab_pack_if({&A});
+  }
   double t = trace(A.loc, A.c0);
   comm_allreduce_sum(&t, 1);
   return t;

@@ -338,6 +338,34 @@ bool slab_norm_axpby(const DevMat& A, const DevMat& B, double alpha, double beta
   return true;
 }
 
+// ------------------------------------------------------------------ MatrixTrace of a slab-form matrix
+namespace {
+__global__ __launch_bounds__(256) void k_sa_diag(int n, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                                 const int64_t* __restrict__ off, const double* __restrict__ val, int col_offset,
+                                                 double* __restrict__ part) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int d = j + col_offset, f = first[j], l = last[j];
+  part[2 * (size_t)j] = (l >= f && d >= f && d <= l) ? val[off[j] + (d - f)] : 0.0;
+  part[2 * (size_t)j + 1] = 0.0;
+}
+}  // namespace
+
+bool slab_trace(const DevMat& A, int32_t col_offset, double* out) {
+  if (!A.expanded() || A.cplx || A.slab->labelled()) return false;
+  const SlabForm& f = *A.slab;
+  const int n = A.cols;
+  DevBuf<double> part((size_t)2 * n), res(2);
+  hipLaunchKernelGGL(k_sa_diag, dim3(cdiv(n, 256)), dim3(256), 0, stream(), n, f.first.p, f.last.p, f.off.p, f.val.p, col_offset, part.p);
+  sum_pairs_async(part.p, n, res.p);
+  unsigned long long h[2] = {0, 0};
+  ScalarFetch ft;
+  ft.add(res.p, 2, h);
+  ft.run();
+  std::memcpy(out, &h[0], sizeof(double));
+  return true;
+}
+
 long long slab_product_count(const DevMat& A, const DevMat& B) {
   if (!A.expanded() || !B.expanded() || A.cplx || B.cplx) return 0;
   const SlabForm &fa = *A.slab, &fb = *B.slab;

@@ -710,7 +710,10 @@ double MatrixNorm_ps_wrp(const int* ih_this) {
   return ps_norm(*ses.mat(ih_this));
 }
 double MeasureAsymmetry_ps_wrp(const int* ih_this) { return ps_measure_asymmetry(*get<PSMatrix>(ih_this)); }
-void MatrixTrace_ps_wrp(const int* ih_this, double* trace_val) { *trace_val = ps_trace(*get<PSMatrix>(ih_this)); }
+void MatrixTrace_ps_wrp(const int* ih_this, double* trace_val) {
+  ApiSession ses;
+  *trace_val = ps_trace(*ses.mat(ih_this));
+}
 int IsIdentity_ps_wrp(const int* ih_this) { return ps_is_identity(*get<PSMatrix>(ih_this)) ? 1 : 0; }
 void SymmetrizeMatrix_ps_wrp(int* ih_this) { ps_symmetrize(*get<PSMatrix>(ih_this)); }
 
