@@ -237,3 +237,40 @@ def test_trs2_step_on_an_iterate_the_slab_algebra_left_behind(nt, fma):
     assert [l[0] for l in res[0][0]] == [l[0] for l in res[1][0]]
     assert np.allclose([l[1] for l in res[0][0]], [l[1] for l in res[1][0]], rtol=1e-12, atol=1e-12)
     assert same_pattern(res[0][1], res[1][1]) and np.abs(res[0][1][2] - res[1][1][2]).max() <= 1e-13
+
+
+@pytest.mark.parametrize("solver", ["trs4", "sign", "inverse_square_root"])
+def test_load_balanced_solves_fall_back_cleanly(nt, fma, solver):
+    """under the load balancer's random permutation the loop's matrices are not run-like: every operation of the session
+    is refused (operands back to compressed columns, the session gives up after a few) and the results are those of the
+    session-less run bit for bit"""
+    n, h, thr = 4096, 16, 1e-8
+    shift = 0.0 if solver != "inverse_square_root" else 2.0
+    col, row, val = banded_triplets(n, h, shift=shift)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    perm = nt.Permutation(n)
+    perm.SetRandomPermutation()
+    out = []
+    for on in (0, 1):
+        nt.set_option("slab_algebra", on)
+        p = nt.SolverParameters()
+        p.SetThreshold(thr)
+        p.SetConvergeDiff(1e-30 if solver == "trs4" else 1e-8)
+        p.SetLoadBalance(perm)
+        if solver == "trs4":
+            p.SetMaxIterations(10)
+            p.SetMonitorConvergence(False)
+        K = nt.Matrix_ps(n)
+        c0 = nt.slab_algebra_counts()
+        if solver == "trs4":
+            I = nt.Matrix_ps(n)
+            I.FillIdentity()
+            nt.DensityMatrixSolvers.TRS4(H, I, n / 2.0, K, p)
+        elif solver == "sign":
+            nt.SignSolvers.ComputeSign(H, K, p)
+        else:
+            nt.SquareRootSolvers.InverseSquareRoot(H, K, p)
+        c1 = nt.slab_algebra_counts()
+        out.append((srt(K.triplets()), nt.solver_trace()["iterations"], c1["products"] - c0["products"]))
+    assert out[1][2] == 0   # (nothing could run in slab form)
+    assert out[0][1] == out[1][1] and same_pattern(out[0][0], out[1][0]) and np.array_equal(out[0][0][2], out[1][0][2])
