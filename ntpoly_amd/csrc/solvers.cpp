@@ -337,6 +337,7 @@ void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace,
   auto t1 = Clock::now();
   double energy_value = 0.0, energy_old;
   int II;
+  SlabSession slab(!X.cplx && !WH.cplx);
   for (II = 1; II <= p.max_iterations; ++II) {                     // :1049-1081
     const double trace_value = ps_trace(X);
     double alpha;
@@ -365,6 +366,8 @@ void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace,
       log_exit();
     }
   }
+  slab.close();
+  ps_slab_leave(X);
   last_trace().loop_ms = ms_since(t1);
   if (p.be_verbose) {
     log_exit();
@@ -529,6 +532,7 @@ void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K
   auto t1 = Clock::now();
   double energy_value = 0.0, energy_old;
   int II;
+  SlabSession slab(!X.cplx && !WH.cplx);   // (the loop's matrices stay in slab form between its operations where they can)
   for (II = 1; II <= p.max_iterations; ++II) {                     // :145-200
     ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
     ps_multiply(X, X2, X3, 1.0, 0.0, p.threshold);
@@ -563,6 +567,8 @@ void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K
     }
   }
   const int total_iterations = II - 1;
+  slab.close();
+  ps_slab_leave(X);
   last_trace().loop_ms = ms_since(t1);
   if (p.be_verbose) {
     log_exit();
@@ -630,9 +636,10 @@ void solver_hpcp(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
   auto t1 = Clock::now();
   double energy_value = 0.0, energy_old, trace_value = 0.0;
   int II;
+  SlabSession slab(!D1.cplx && !WH.cplx);
   for (II = 1; II <= p.max_iterations; ++II) {                     // :836-872
     ps_copy(D1, DH);
-    ps_increment(IMat, DH, -1.0, 0.0);
+    ps_increment_identity(IMat, DH, -1.0);                         // IncrementMatrix(Identity, DH, -1)
     ps_scale(DH, -1.0);
     ps_multiply(D1, DH, DDH, 1.0, 0.0, p.threshold);
     trace_value = ps_trace(DDH);
@@ -652,6 +659,8 @@ void solver_hpcp(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
     }
   }
   const int total_iterations = II - 1;
+  slab.close();
+  ps_slab_leave(D1);
   last_trace().loop_ms = ms_since(t1);
   if (p.be_verbose) {
     log_exit();

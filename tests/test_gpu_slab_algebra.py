@@ -274,3 +274,45 @@ def test_load_balanced_solves_fall_back_cleanly(nt, fma, solver):
         out.append((srt(K.triplets()), nt.solver_trace()["iterations"], c1["products"] - c0["products"]))
     assert out[1][2] == 0   # (nothing could run in slab form)
     assert out[0][1] == out[1][1] and same_pattern(out[0][0], out[1][0]) and np.array_equal(out[0][0][2], out[1][0][2])
+
+
+@pytest.mark.parametrize("solver", ["pm", "hpcp", "scale_and_fold"])
+def test_other_purification_loops_in_slab_form(nt, fma, solver):
+    """PM, HPCP and ScaleAndFold (DensityMatrixSolversModule.F90) open the same session: their loops run in slab form
+    (products counted) and give the density of the session-less run -- same pattern, values to 1e-10 (their step sizes
+    are quotients of traces / dots whose summation order differs), energies to 1e-10 relative"""
+    n, h, thr, iters = 4096, 20, 1e-8, 12
+    col, row, val = banded_triplets(n, h)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    I = nt.Matrix_ps(n)
+    I.FillIdentity()
+    out = []
+    for on in (0, 1):
+        nt.set_option("slab_algebra", on)
+        p = nt.SolverParameters()
+        p.SetThreshold(thr)
+        p.SetConvergeDiff(1e-30)
+        p.SetMaxIterations(iters)
+        p.SetMonitorConvergence(False)
+        K = nt.Matrix_ps(n)
+        c0 = nt.slab_algebra_counts()
+        if solver == "pm":
+            e, mu = nt.DensityMatrixSolvers.PM(H, I, n / 2.0, K, p)
+        elif solver == "hpcp":
+            e, mu = nt.DensityMatrixSolvers.HPCP(H, I, n / 2.0, K, p)
+        else:
+            import ctypes as C
+            ev = C.c_double()
+            dd = lambda x: C.byref(C.c_double(x))
+            nt.lib.ScaleAndFold_wrp(H.ih, I.ih, dd(n / 2.0), K.ih, dd(-0.05), dd(0.05), C.byref(ev), p.ih)
+            e = ev.value
+        c1 = nt.slab_algebra_counts()
+        out.append((srt(K.triplets()), e if not isinstance(e, tuple) else e[0], nt.solver_trace()["iterations"], c1["products"] - c0["products"]))
+    off, on = out
+    assert off[3] == 0 and on[3] >= iters - 1, (off[3], on[3])
+    assert off[2] == on[2]
+    assert abs(off[1] - on[1]) <= 1e-10 * abs(off[1])
+    import scipy.sparse as sp
+    G = sp.csr_matrix((on[0][2], (on[0][1] - 1, on[0][0] - 1)), shape=(n, n))
+    W = sp.csr_matrix((off[0][2], (off[0][1] - 1, off[0][0] - 1)), shape=(n, n))
+    assert abs(G - W).max() <= 1e-9
