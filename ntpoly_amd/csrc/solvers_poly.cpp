@@ -60,6 +60,7 @@ void polynomial_horner(const PSMatrix& In, PSMatrix& Out, const std::vector<doub
   poly_header("Polynomial Solver", "Horner", nullptr, degree, p, false);
   Balanced b;
   balanced_setup(In, p, b);
+  SlabSession slab(!In.cplx);   // (engine.hpp: products, merges and scalings of the evaluation on matrices kept in slab form)
   PSMatrix R, Temporary;
   ps_copy(b.Identity, R);
   if (degree == 1) {
@@ -73,6 +74,8 @@ void polynomial_horner(const PSMatrix& In, PSMatrix& Out, const std::vector<doub
       ps_increment(b.Identity, R, c[(size_t)II - 1], 0.0);
     }
   }
+  slab.close();
+  ps_slab_leave(R);
   balanced_finish(R, p);
   Out = std::move(R);
   if (p.be_verbose) log_exit();
@@ -90,6 +93,7 @@ void polynomial_paterson_stockmeyer(const PSMatrix& In, PSMatrix& Out, const std
   PSMatrix Identity;
   ps_construct_like(Identity, In);
   ps_fill_identity(Identity);
+  SlabSession slab(!In.cplx);
   std::vector<PSMatrix> x_powers((size_t)s_value + 1);
   ps_construct_like(x_powers[0], In);
   ps_fill_identity(x_powers[0]);
@@ -127,6 +131,9 @@ void polynomial_paterson_stockmeyer(const PSMatrix& In, PSMatrix& Out, const std
     std::swap(R.loc, Temp.loc);
     ps_increment(Bk, R, 1.0, 0.0);
   }
+  slab.close();
+  ps_slab_leave(R);
+  ps_slab_leave(const_cast<PSMatrix&>(In));   // (the session may have turned the caller's operand into slab form where it was)
   Out = std::move(R);
   if (p.be_verbose) log_exit();
 }
@@ -138,6 +145,7 @@ void chebyshev_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<doub
   poly_header("Chebyshev Solver", "Standard", nullptr, degree, p, true);
   Balanced b;
   balanced_setup(In, p, b);
+  SlabSession slab(!In.cplx);
   PSMatrix Tk, Tkminus1, Tkminus2, R;
   ps_copy(b.Identity, Tkminus2);
   if (degree == 1) {
@@ -161,6 +169,8 @@ void chebyshev_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<doub
       }
     }
   }
+  slab.close();
+  ps_slab_leave(R);
   if (p.be_verbose) print_matrix_information(R);
   balanced_finish(R, p);
   Out = std::move(R);
@@ -201,6 +211,7 @@ void chebyshev_factorized(const PSMatrix& In, PSMatrix& Out, const std::vector<d
   poly_header("Chebyshev Solver", "Recursive", nullptr, degree, p, true);
   Balanced b;
   balanced_setup(In, p, b);
+  SlabSession slab(!In.cplx);
   int log2degree = 1;
   while ((1 << log2degree) <= degree) ++log2degree;
   std::vector<PSMatrix> T((size_t)log2degree);
@@ -216,6 +227,8 @@ void chebyshev_factorized(const PSMatrix& In, PSMatrix& Out, const std::vector<d
     }
     cheby_recursive(T, c, R, 1, p);
   }
+  slab.close();
+  ps_slab_leave(R);
   if (p.be_verbose) print_matrix_information(R);
   balanced_finish(R, p);
   Out = std::move(R);
@@ -229,6 +242,7 @@ void hermite_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<double
   poly_header("Hermite Solver", "Standard", nullptr, degree, p, true);
   Balanced b;
   balanced_setup(In, p, b);
+  SlabSession slab(!In.cplx);
   PSMatrix Hk, Hkminus1, Hkplus1, Hkprime, R;
   ps_copy(b.Identity, Hkminus1);
   ps_copy(Hkminus1, R);
@@ -251,6 +265,8 @@ void hermite_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<double
       }
     }
   }
+  slab.close();
+  ps_slab_leave(R);
   if (p.be_verbose) print_matrix_information(R);
   balanced_finish(R, p);
   Out = std::move(R);

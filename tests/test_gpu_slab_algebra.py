@@ -316,3 +316,46 @@ def test_other_purification_loops_in_slab_form(nt, fma, solver):
     G = sp.csr_matrix((on[0][2], (on[0][1] - 1, on[0][0] - 1)), shape=(n, n))
     W = sp.csr_matrix((off[0][2], (off[0][1] - 1, off[0][0] - 1)), shape=(n, n))
     assert abs(G - W).max() <= 1e-9
+
+
+@pytest.mark.parametrize("kind", ["horner", "paterson_stockmeyer", "chebyshev", "chebyshev_factorized", "hermite", "exponential"])
+def test_polynomial_evaluations_in_slab_form(nt, fma, kind):
+    """the matrix polynomials (Horner, Paterson-Stockmeyer, Chebyshev standard / recursive, Hermite) and two of the
+    functions built on them: their products, merges and scalings run in slab form under the session and give the
+    session-less result bit for bit (a zero coefficient is the one merge that goes back to compressed columns)"""
+    n, h, thr = 4096, 12, 1e-9
+    col, row, val = banded_triplets(n, h)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    H.Scale(0.25)   # (spectrum inside [-1, 1] for the orthogonal-polynomial recurrences)
+    coeffs = [0.3, -0.7, 0.0, 0.45, 0.2, -0.15, 0.05, 0.11, -0.02]
+    out = []
+    for on in (0, 1):
+        nt.set_option("slab_algebra", on)
+        p = nt.SolverParameters()
+        p.SetThreshold(thr)
+        Out = nt.Matrix_ps(n)
+        c0 = nt.slab_algebra_counts()
+        if kind in ("horner", "paterson_stockmeyer"):
+            P = nt.Polynomial(len(coeffs))
+            for k, c in enumerate(coeffs):
+                P.SetCoefficient(k, c)
+            (P.HornerCompute if kind == "horner" else P.PatersonStockmeyerCompute)(H, Out, p)
+        elif kind in ("chebyshev", "chebyshev_factorized"):
+            P = nt.ChebyshevPolynomial(len(coeffs))
+            for k, c in enumerate(coeffs):
+                P.SetCoefficient(k, c)
+            (P.Compute if kind == "chebyshev" else P.ComputeFactorized)(H, Out, p)
+        elif kind == "hermite":
+            P = nt.HermitePolynomial(len(coeffs))
+            for k, c in enumerate(coeffs):
+                P.SetCoefficient(k, c * 1e-2)
+            P.Compute(H, Out, p)
+        elif kind == "exponential":
+            nt.ExponentialSolvers.ComputeExponential(H, Out, p)
+        else:
+            nt.TrigonometrySolvers.Sine(H, Out, p)
+        c1 = nt.slab_algebra_counts()
+        out.append((srt(Out.triplets()), c1["products"] - c0["products"]))
+    off, on = out
+    assert off[1] == 0 and on[1] >= 2, (off[1], on[1])
+    assert same_pattern(off[0], on[0]) and np.array_equal(off[0][2], on[0][2]), np.abs(off[0][2] - on[0][2]).max() if same_pattern(off[0], on[0]) else "pattern"
