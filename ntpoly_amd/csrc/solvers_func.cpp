@@ -174,6 +174,7 @@ void scale_square_trig(const PSMatrix& In, PSMatrix& Out, const SolverParameters
   c[1] = 7.651976865579664e-01;  c[3] = -2.298069698638004e-01; c[5] = 4.953277928219409e-03;
   c[7] = -4.187667600472235e-05; c[9] = 1.884468822397086e-07;  c[11] = -5.261224549346905e-10;
   c[13] = 9.999906645345580e-13; c[15] = -2.083597362700025e-15; c[17] = 9.181480886537484e-17;
+  SlabSession slab(!Scaled.cplx);   // (engine.hpp: the Chebyshev evaluation and the squarings on matrices kept in slab form)
   ps_multiply(Scaled, Scaled, T2, 2.0, 0.0, p.threshold);
   ps_increment(Ident, T2, -1.0, 0.0);
   ps_multiply(T2, T2, T4, 2.0, 0.0, p.threshold);
@@ -204,6 +205,8 @@ void scale_square_trig(const PSMatrix& In, PSMatrix& Out, const SolverParameters
     ps_scale(R, 2.0);
     ps_increment(Ident, R, -1.0, 0.0);
   }
+  slab.close();
+  ps_slab_leave(R);
   if (p.do_load_balancing) {
     PSMatrix t;
     ps_permute(R, t, p.balance_permutation, true);

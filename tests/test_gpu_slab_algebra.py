@@ -318,7 +318,7 @@ def test_other_purification_loops_in_slab_form(nt, fma, solver):
     assert abs(G - W).max() <= 1e-9
 
 
-@pytest.mark.parametrize("kind", ["horner", "paterson_stockmeyer", "chebyshev", "chebyshev_factorized", "hermite", "exponential"])
+@pytest.mark.parametrize("kind", ["horner", "paterson_stockmeyer", "chebyshev", "chebyshev_factorized", "hermite", "exponential", "sine"])
 def test_polynomial_evaluations_in_slab_form(nt, fma, kind):
     """the matrix polynomials (Horner, Paterson-Stockmeyer, Chebyshev standard / recursive, Hermite) and two of the
     functions built on them: their products, merges and scalings run in slab form under the session and give the
