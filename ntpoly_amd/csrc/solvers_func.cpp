@@ -274,6 +274,7 @@ void inverse_root_impl(const PSMatrix& In, PSMatrix& Out, int root, const Solver
   }
   double norm_value = p.converge_diff + 1.0;
   int II;
+  SlabSession slab(!R.cplx && !Mk.cplx);   // (engine.hpp: the loop's matrices stay in slab form between its operations)
   for (II = 1; II <= p.max_iterations; ++II) {
     if (p.be_verbose && II > 1) log_list_element("Convergence", norm_value);
     ps_copy(Ident, Inter);
@@ -289,8 +290,10 @@ void inverse_root_impl(const PSMatrix& In, PSMatrix& Out, int root, const Solver
     }
     ps_multiply(InterP, Mk, Temp, 1.0, 0.0, p.threshold);
     ps_copy(Temp, Mk);
-    ps_increment(Ident, Temp, -1.0, 0.0);
-    norm_value = ps_norm(Temp);
+    if (!ps_norm_axpby(Ident, Temp, -1.0, 1.0, &norm_value)) {       // (Temp - I is only there for its norm)
+      ps_increment(Ident, Temp, -1.0, 0.0);
+      norm_value = ps_norm(Temp);
+    }
     monitor_append(mon, norm_value);
     if (monitor_converged(mon, p.be_verbose)) break;
   }
@@ -308,6 +311,8 @@ void inverse_root_impl(const PSMatrix& In, PSMatrix& Out, int root, const Solver
     ps_multiply(R, R, Temp, 1.0, 0.0, p.threshold);
     std::swap(R.loc, Temp.loc);
   }
+  slab.close();
+  ps_slab_leave(R);
   if (p.do_load_balancing) {
     PSMatrix t;
     ps_permute(R, t, p.balance_permutation, true);

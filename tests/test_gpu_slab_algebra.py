@@ -318,7 +318,7 @@ def test_other_purification_loops_in_slab_form(nt, fma, solver):
     assert abs(G - W).max() <= 1e-9
 
 
-@pytest.mark.parametrize("kind", ["horner", "paterson_stockmeyer", "chebyshev", "chebyshev_factorized", "hermite", "exponential", "sine"])
+@pytest.mark.parametrize("kind", ["horner", "paterson_stockmeyer", "chebyshev", "chebyshev_factorized", "hermite", "exponential", "sine", "inverse_root3", "root3"])
 def test_polynomial_evaluations_in_slab_form(nt, fma, kind):
     """the matrix polynomials (Horner, Paterson-Stockmeyer, Chebyshev standard / recursive, Hermite) and two of the
     functions built on them: their products, merges and scalings run in slab form under the session and give the
@@ -350,6 +350,13 @@ def test_polynomial_evaluations_in_slab_form(nt, fma, kind):
             for k, c in enumerate(coeffs):
                 P.SetCoefficient(k, c * 1e-2)
             P.Compute(H, Out, p)
+        elif kind in ("inverse_root3", "root3"):
+            H3 = nt.Matrix_ps(H)
+            I3 = nt.Matrix_ps(n)
+            I3.FillIdentity()
+            H3.Increment(I3, 1.5, 0.0)   # (positive definite)
+            p.SetConvergeDiff(1e-8)
+            (nt.RootSolvers.ComputeInverseRoot if kind == "inverse_root3" else nt.RootSolvers.ComputeRoot)(H3, Out, 3, p)
         elif kind == "exponential":
             nt.ExponentialSolvers.ComputeExponential(H, Out, p)
         else:
