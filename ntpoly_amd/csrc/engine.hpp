@@ -89,7 +89,7 @@ void ps_copy(const PSMatrix& a, PSMatrix& b);
 // slab_algebra -- ps_multiply / ps_axpby / ps_increment / ps_copy / ps_scale / ps_dot / ps_norm / ps_gershgorin keep
 // their operands and results in slab form (kernels.hpp, slab algebra) instead of compressed columns; the loop's owner
 // packs what leaves it (ps_slab_leave).  Any operation that cannot be done in slab form packs its operands and takes
-// the general path; after one refusal the session stays off.
+// the general path; after a handful of refusals the session stays off.
 struct SlabSession {
   explicit SlabSession(bool eligible);
   ~SlabSession();

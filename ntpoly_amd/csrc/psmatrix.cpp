@@ -118,7 +118,7 @@ long long g_slab_counts[4] = {0, 0, 0, 0};   // products, merges / copies, other
 void slab_refused(std::initializer_list<const PSMatrix*> ms) {
   g_slab_refusals += 1;
   g_slab_counts[3] += 1;
-  if (g_slab_refusals > 8) g_slab_failed = true;
+  if (g_slab_refusals > 4) g_slab_failed = true;
   if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
     std::fprintf(stderr, "[slab session] an operation was refused (%d so far)%s\n", g_slab_refusals,
                  g_slab_failed ? ": compressed columns from here on" : "");

@@ -532,7 +532,8 @@ void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K
   auto t1 = Clock::now();
   double energy_value = 0.0, energy_old;
   int II;
-  SlabSession slab(!X.cplx && !WH.cplx);   // (the loop's matrices stay in slab form between its operations where they can)
+  // (no slab session here: whenever sigma > 1/2 the update scales X by a1 = 0 -- stored zeros whose tails steer the merges
+  // that follow, which the slab form cannot hold -- so half the iterations would fall back and convert to and fro)
   for (II = 1; II <= p.max_iterations; ++II) {                     // :145-200
     ps_multiply(X, X, X2, 1.0, 0.0, p.threshold);
     ps_multiply(X, X2, X3, 1.0, 0.0, p.threshold);
@@ -567,8 +568,6 @@ void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K
     }
   }
   const int total_iterations = II - 1;
-  slab.close();
-  ps_slab_leave(X);
   last_trace().loop_ms = ms_since(t1);
   if (p.be_verbose) {
     log_exit();

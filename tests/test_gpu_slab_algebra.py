@@ -276,9 +276,10 @@ def test_load_balanced_solves_fall_back_cleanly(nt, fma, solver):
     assert out[0][1] == out[1][1] and same_pattern(out[0][0], out[1][0]) and np.array_equal(out[0][0][2], out[1][0][2])
 
 
-@pytest.mark.parametrize("solver", ["pm", "hpcp", "scale_and_fold"])
+@pytest.mark.parametrize("solver", ["hpcp", "scale_and_fold"])
 def test_other_purification_loops_in_slab_form(nt, fma, solver):
-    """PM, HPCP and ScaleAndFold (DensityMatrixSolversModule.F90) open the same session: their loops run in slab form
+    """HPCP and ScaleAndFold (DensityMatrixSolversModule.F90) open the same session (PM does not: its update scales the
+    iterate by zero in half its iterations, which leaves stored zeros no slab can hold): their loops run in slab form
     (products counted) and give the density of the session-less run -- same pattern, values to 1e-10 (their step sizes
     are quotients of traces / dots whose summation order differs), energies to 1e-10 relative"""
     n, h, thr, iters = 4096, 20, 1e-8, 12

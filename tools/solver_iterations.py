@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time per iteration of TRS4 / SignFunction on the headline operand (N = 262 144, h = 100, threshold 1e-8) by
 differencing solves capped at 4 and 14 iterations; host synchronisations per solve are printed as well.
-    SOLVER=trs4|sign ARITH=fma|unfused NTPOLY_AMD_SLAB_ALGEBRA=0|1 python3 tools/solver_iterations.py
+    SOLVER=trs4|sign|pm|hpcp ARITH=fma|unfused NTPOLY_AMD_SLAB_ALGEBRA=0|1 python3 tools/solver_iterations.py
 Under rocprofv3 --kernel-trace --stats this gives profiles/r03_trs4_kernel_stats_*.csv (tools/prof_summary.py)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -24,6 +24,10 @@ for iters in (4, 14, 4, 14):
         e, _ = nt.DensityMatrixSolvers.TRS4(H, I, n / 2.0, K, p)
     elif which == "sign":
         nt.SignSolvers.ComputeSign(H, K, p); e = 0
+    elif which == "pm":
+        e, _ = nt.DensityMatrixSolvers.PM(H, I, n / 2.0, K, p)
+    elif which == "hpcp":
+        e, _ = nt.DensityMatrixSolvers.HPCP(H, I, n / 2.0, K, p)
     nt.synchronize()
     walls = globals().setdefault("walls", {})
     walls[iters] = time.perf_counter() - t0
