@@ -3947,7 +3947,7 @@ namespace {
 // the plan of a step X * X from the column extents of X (device arrays of n columns; a panel step: the extents of the
 // columns ka .. of the distributed iterate on the A side); sizes are left on the device in stats[16..18] / blk_toff[snb]
 void launch_slab_plan(SlabPlan& P, int n, const int32_t* first, const int32_t* last, const int32_t* afirst, const int32_t* alast,
-                      int align, unsigned long long* stats) {
+                      int align, unsigned long long* stats, DevBuf<int64_t>* tile_offsets = nullptr) {
   const int snb = cdiv(n, SLAB_J);
   P.blk_lo.alloc(snb); P.blk_w.alloc(snb); P.blk_kmin.alloc(snb); P.blk_kn.alloc(snb);
   P.blk_toff.alloc((size_t)snb + 1);
@@ -3958,6 +3958,10 @@ void launch_slab_plan(SlabPlan& P, int n, const int32_t* first, const int32_t* l
   // (one workgroup doing the scan and the maxima in a single launch was tried: 50 us against the 20 of these four)
   hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), P.blk_w.p, P.blk_kn.p, snb, (const int32_t*)nullptr, 0, stats);
   scan_async<int64_t>(tsz.p, P.blk_toff.p, (int64_t)snb);
+  if (tile_offsets) {   // (where the multiplier tile of every block starts: the tiles of a right operand that has none yet)
+    tile_offsets->alloc((size_t)snb + 1);
+    scan_async<int64_t>(bsz.p, tile_offsets->p, (int64_t)snb);
+  }
 }
 }  // namespace
 
@@ -5656,14 +5660,16 @@ bool sa_operand(const DevMat& M) {
 
 bool slab_enter(DevMat& M) {
   if (M.expanded()) return sa_operand(M);
-  if (M.cplx || M.loose() || M.rows != M.cols || M.nnz == 0 || options().spgemm_fma != 1) return false;
+  if (M.cplx || M.loose() || M.rows != M.cols || M.nnz == 0 || (options().spgemm_fma != 0 && options().spgemm_fma != 1)) return false;
   const int n = M.cols;
   std::unique_ptr<SlabForm> f(new SlabForm());
   f->first.alloc((size_t)n); f->last.alloc((size_t)n); f->count.alloc((size_t)n); f->off.alloc((size_t)n + 1);
   DevBuf<int32_t> span((size_t)n);
   DevBuf<unsigned long long> zc(1);
   zc.zero();
-  const int al = tile_expand_align();
+  // (FMA arithmetic: aligned zero-padded slots for the MFMA tile kernel; unfused arithmetic: the runs packed back to back,
+  // as the register-slab kernel reads them)
+  const int al = options().spgemm_fma == 1 ? tile_expand_align() : 1;
   hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(M), f->first.p, f->last.p, f->count.p);
   hipLaunchKernelGGL(k_span_aligned, dim3(cdiv(n, 256)), dim3(256), 0, stream(), f->first.p, f->last.p, span.p, n, al);
   scan_async<int32_t>(span.p, f->off.p, (int64_t)n);
@@ -5827,8 +5833,170 @@ bool slab_gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx
   return true;
 }
 
-// C = alpha A B with the threshold rule of the SpGEMM, on the MFMA tile kernel, operands and result in slab form
+namespace {
+// multiplier tiles of the blocks of 16 columns from the columns' runs (the register-slab kernel reads its multipliers
+// from them as scalars): tile of block b = rows kmin .. kmin + kn of its columns, row-major 16 wide, at tiles + boff[b]
+// (an all-zero row pads odd k ranges)
+__global__ __launch_bounds__(256) void k_sa_tiles(int n, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                                  const int64_t* __restrict__ off, const double* __restrict__ val,
+                                                  const int32_t* __restrict__ blk_kmin, const int32_t* __restrict__ blk_kn,
+                                                  const int64_t* __restrict__ boff, double* __restrict__ tiles, int nblocks) {
+  const int b = xcd_block(nblocks);
+  if (b < 0) return;
+  const int kmin = blk_kmin[b], kn = blk_kn[b], kn2 = (kn + 1) & ~1;
+  const int c = threadIdx.x & 15, j = b * SLAB_J + c;
+  const bool colv = j < n;
+  const int f = colv ? first[j] : INT_MAX, l = colv ? last[j] : -1;
+  const double* __restrict__ p = (colv && l >= f) ? val + (off[j] - f) : val;
+  double* __restrict__ dst = tiles + boff[b];
+  for (int idx = threadIdx.x; idx < kn2 * SLAB_J; idx += 256) {
+    const int r = kmin + (idx >> 4);
+    dst[idx] = (r >= f && r <= l) ? p[r] : 0.0;
+  }
+}
+struct EmptyDot {   // "D" of the register-slab kernel's EPI 1 epilogue when only the pruned product is wanted: no entries
+  DevBuf<int32_t> dmin, dmax;
+  DevBuf<int64_t> doff;
+  DevBuf<double> dexp;
+  int n = 0;
+};
+const EmptyDot& empty_dot(int n) {
+  static EmptyDot* e = new EmptyDot();
+  if (e->n < n) {
+    e->dmin.alloc((size_t)n); e->dmax.alloc((size_t)n); e->doff.alloc((size_t)n + 1); e->dexp.alloc(8);
+    std::vector<int32_t> hmin((size_t)n, INT_MAX), hmax((size_t)n, -1);   // (once per dimension)
+    e->dmin.upload(hmin.data(), (size_t)n);
+    e->dmax.upload(hmax.data(), (size_t)n);
+    sync_stream();
+    e->doff.zero();
+    e->dexp.zero();
+    e->n = n;
+  }
+  return *e;
+}
+
+// Unfused arithmetic: C = alpha A B on the register-slab kernel (k_spgemm_slab with the epilogue that leaves the pruned
+// product in slab form -- EPI 1, the "X * X" step of TRS2 -- against an empty D), operands and result in slab form with
+// packed runs; the right operand's multiplier tiles are built from its runs when a fused kernel has not left them
+bool slab_multiply_loop(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {
+  const SlabForm &fa = *A.slab, &fb = *B.slab;
+  const int n = B.cols, snb = cdiv(n, SLAB_J);
+  const bool timing = options().time_kernels != 0;
+  EventTimer t_all(timing), t_num(timing);
+  t_all.start();
+  auto give_up = [&]() {
+    if (timing) {
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+    }
+    return false;
+  };
+  SlabPlan P;
+  // [flag 2 | product entries per block snb + 1 | (unused) snb | (dot, trace) per block 2 snb | plan statistics 24]
+  DevBuf<int64_t> zwords((size_t)4 * snb + 4 + 24);
+  zwords.zero();
+  int64_t* fz_flag = zwords.p;
+  int64_t* fz_pnnz = zwords.p + 2;
+  double* fz_part = reinterpret_cast<double*>(zwords.p + 3 + 2 * (size_t)snb);
+  unsigned long long* stats = reinterpret_cast<unsigned long long*>(zwords.p + 4 * (size_t)snb + 4);
+  const bool have_tiles = fb.tiles.p != nullptr && (int64_t)fb.tile_off.n == (int64_t)snb + 1;
+  DevBuf<int64_t> boff;
+  launch_slab_plan(P, n, fb.first.p, fb.last.p, fa.first.p, fa.last.p, 0, stats, have_tiles ? nullptr : &boff);
+  unsigned long long hs[3] = {0, 0, 0};
+  int64_t btotal = 0;
+  {
+    ScalarFetch f;
+    f.add(P.blk_toff.p + snb, 1, &P.total);
+    f.add(stats + 16, 3, hs);
+    if (!have_tiles) f.add(boff.p + snb, 1, &btotal);
+    f.run();
+  }
+  P.max_w = (int)hs[0];
+  P.max_kn = (int)hs[1];
+  const int64_t max_w = P.max_w;
+  if (max_w <= 0 || max_w > 8 * SLAB_SL * WAVE || (((int64_t)P.max_kn + 1) | 1) * SLAB_J * 8 > 128 * 1024) return give_up();
+  if (!have_tiles) {
+    SlabForm& mb = const_cast<SlabForm&>(fb);   // (a cache: the tiles are a function of the runs)
+    mb.tiles.alloc((size_t)btotal + 16 * SLAB_J + kIndexSlack);
+    hipLaunchKernelGGL(k_sa_tiles, dim3(xcd_grid(snb)), dim3(256), 0, stream(), n, fb.first.p, fb.last.p, fb.off.p, fb.val.p,
+                       P.blk_kmin.p, P.blk_kn.p, boff.p, mb.tiles.p, snb);
+    mb.tile_off = std::move(boff);
+  }
+  DevBuf<int64_t> tmpoff((size_t)n + 1);
+  hipLaunchKernelGGL((k_slab_tmpoff<SLAB_J>), dim3(cdiv(n + 1, 256)), dim3(256), 0, stream(), n, P.blk_w.p, P.blk_toff.p, tmpoff.p);
+  DevBuf<char> runs(((size_t)A.cols + 4) * sizeof(SlabRun));
+  hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, fa.off.p,
+                     reinterpret_cast<const char*>(fa.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), A.cols);
+  const size_t oslots = (size_t)P.total + kIndexSlack;
+  std::unique_ptr<SlabForm> fo(new SlabForm());
+  fo->first.alloc((size_t)n); fo->last.alloc((size_t)n); fo->count.alloc((size_t)n);
+  fo->count.zero();
+  fo->val.alloc(oslots);
+  fo->tiles.alloc(oslots);
+  const EmptyDot& ed = empty_dot(n);
+  SlabFuseArgs fz;
+  fz.dexp = ed.dexp.p; fz.doff = ed.doff.p; fz.dmin = ed.dmin.p; fz.dmax = ed.dmax.p;
+  fz.ofirst = fo->first.p; fz.olast = fo->last.p; fz.tiles = fo->tiles.p;
+  fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
+  fz.col_offset = 0;
+  DevBuf<char> fz_args(sizeof(SlabFuseArgs));
+  fz_args.upload(reinterpret_cast<const char*>(&fz), sizeof(SlabFuseArgs));
+  const int dr = dense_rule ? 1 : 0;
+  t_num.start();
+  auto launch = [&](auto nw_tag, auto mode_tag) {
+    constexpr int FNW = decltype(nw_tag)::value;
+    hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, FNW, decltype(mode_tag)::value, 1>), dim3(xcd_grid(snb)), dim3(FNW * WAVE), 0,
+                       stream(), reinterpret_cast<const SlabRun*>(runs.p), fb.tiles.p, fb.tile_off.p, P.blk_kmin.p, P.blk_kn.p,
+                       P.blk_lo.p, P.blk_w.p, P.blk_toff.p, (int32_t*)nullptr, fo->val.p, fo->count.p, alpha, threshold, dr, n, snb,
+                       reinterpret_cast<const SlabFuseArgs*>(fz_args.p));
+  };
+  if (max_w > 6 * SLAB_SL * WAVE) launch(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
+  else if (max_w > SLAB_NW * SLAB_SL * WAVE) launch(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
+  else launch(std::integral_constant<int, SLAB_NW>{}, std::integral_constant<int, 8>{});
+  t_num.stop();
+  DevBuf<long long> tot;
+  sa_sum_counts(fo->count.p, n, tot);
+  int64_t nnz = 0, flagv = 0;
+  {
+    ScalarFetch f;
+    f.add(tot.p, 1, &nnz);
+    f.add(fz_flag, 1, &flagv);
+    f.run();
+  }
+  t_all.stop();
+  if (timing) {
+    if (pending_timings().size() >= 4096) flush_spgemm_timers();
+    pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+  }
+  if ((int32_t)flagv != 0) return false;
+  fo->off = std::move(tmpoff);
+  fo->tile_off = std::move(P.blk_toff);
+  fo->row_pad = 1;
+  fo->slots = P.total;
+  SpgemmStats st;
+  st.nnz_a = A.nnz; st.nnz_b = B.nnz; st.nnz_c = nnz; st.slab = 1; st.tmp_entries = P.total;
+  last_spgemm_stats() = st;
+  SpgemmAccum& acc = spgemm_accum();
+  acc.calls += 1;
+  acc.nnz_c += nnz;
+  acc.alg_bytes += 12.0 * ((double)A.nnz + (double)B.nnz + (double)nnz) + 4.0 * ((double)A.cols + 2.0 * n + 3.0);
+  DevMat R;
+  R.rows = A.rows; R.cols = n; R.cplx = false; R.nnz = nnz; R.zero_free = 1;
+  R.slab = std::move(fo);
+  C = std::move(R);
+  return true;
+}
+}  // namespace
+
+// C = alpha A B with the threshold rule of the SpGEMM, operands and result in slab form: on the MFMA tile kernel in FMA
+// arithmetic, on the register-slab kernel in unfused arithmetic
 bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {
+  if (options().spgemm_fma == 0) {
+    if (!sa_operand(A) || !sa_operand(B) || A.cols != B.rows || options().spgemm_variant >= 0 || options().spgemm_force_bin > 0 ||
+        A.slab->row_pad != 1)
+      return false;
+    return slab_multiply_loop(A, B, C, alpha, threshold, dense_rule);
+  }
   if (!sa_operand(A) || !sa_operand(B) || A.cols != B.rows || options().spgemm_fma != 1 || options().spgemm_variant >= 0 ||
       options().spgemm_force_bin > 0) {
     if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM")) std::fprintf(stderr, "[slab_multiply] refused: operands / options\n");

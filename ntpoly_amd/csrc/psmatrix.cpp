@@ -135,7 +135,8 @@ void slab_pack_if(std::initializer_list<const PSMatrix*> ms) {
 const long long* slab_algebra_counts() { return g_slab_counts; }
 
 SlabSession::SlabSession(bool eligible) {
-  opened = eligible && options().slab_algebra != 0 && options().spgemm_fma == 1 && options().spgemm_variant < 0 && !world().active();
+  opened = eligible && options().slab_algebra != 0 && (options().spgemm_fma == 1 || options().spgemm_fma == 0) && options().spgemm_variant < 0 &&
+           options().spgemm_force_bin <= 0 && !world().active();
   if (opened) {
     if (g_slab_depth == 0) { g_slab_failed = false; g_slab_refusals = 0; }
     g_slab_depth += 1;

@@ -1,5 +1,6 @@
-"""GPU: the solver loops on matrices that stay in slab form (option slab_algebra, FMA arithmetic, one rank: psmatrix.cpp
-SlabSession + kernels.hip "slab algebra") -- TRS4, SignFunction, Invert, InverseSquareRoot / SquareRoot.
+"""GPU: the solver loops on matrices that stay in slab form (option slab_algebra, one rank, real operands, both arithmetic
+modes: psmatrix.cpp SlabSession + kernels.hip "slab algebra") -- TRS4, SignFunction, Invert, InverseSquareRoot / SquareRoot,
+HPCP, ScaleAndFold, the matrix polynomials and functions, a caller's own loop over the C ABI.
 
 Three checks per solver: (1) the slab session really ran (ntpoly_amd_slab_algebra_counts: the loop's products were done
 in slab form, and the number of refusals is what the operand explains); (2) the result equals the
@@ -25,11 +26,13 @@ def nt():
     return nt
 
 
-@pytest.fixture()
-def fma(nt):
+@pytest.fixture(params=[1, 0], ids=["fma", "unfused"])
+def fma(nt, request):
+    """both arithmetic modes: FMA (products on the MFMA tile kernel) and unfused, the library's default (products on the
+    register-slab kernel, runs packed back to back); the oracle is switched to the same mode"""
     from oracle import oracle_py as O
-    nt.set_option("spgemm_fma", 1)
-    O.set_fma(True)
+    nt.set_option("spgemm_fma", request.param)
+    O.set_fma(bool(request.param))
     yield O
     O.set_fma(False)
     nt.set_option("spgemm_fma", 0)
