@@ -148,6 +148,7 @@ struct SlabForm {
   // alone: slab_enter keeps the compressed columns it came from here, the slab form is then a read-only view for
   // products, dots and column norms (DevMat::zero_free = 0), and pack() hands the original back
   std::shared_ptr<struct DevMat> origin;
+  mutable int64_t span_sum = -1;   // sum of the runs' lengths (last - first + 1), computed on first use (slab_extra.hip slab_span_sum)
   int row_pad = 1;            // > 1 (a multiple of 16): every column's slot holds row r at a position = r (mod row_pad) and reads as
                               // ZERO from the multiple of row_pad below its first row to the one above its last (results of the
                               // MFMA tile kernel, spgemm_tile.hpp, which reads several consecutive rows per lane)

@@ -183,6 +183,7 @@ bool slab_trs4_traces(const DevMat& X, const DevMat& X2, int32_t col_offset, dou
 bool slab_trs4_operand(const DevMat& X, const DevMat& X2, double sigma, int32_t col_offset, DevMat& Out);
 bool slab_norm_axpby(const DevMat& A, const DevMat& B, double alpha, double beta, double* out);   // MatrixNorm(alpha A + beta B), nothing built
 bool slab_trace(const DevMat& A, int32_t col_offset, double* out);   // sum of the diagonal entries held by the local columns
+int64_t slab_span_sum(const DevMat& M);   // rows covered by the runs (cached in the form)
 long long slab_product_count(const DevMat& A, const DevMat& B);   // statistics (slab_extra.hip): intermediate products of A B
 // compressed columns -> labelled slab form (SlabForm::lab; Xs = the matrix in the bandwidth-reducing order, lab[index] = the
 // caller's index); false (nothing changed): its columns are not run-like

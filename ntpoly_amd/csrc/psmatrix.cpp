@@ -466,7 +466,15 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     // (a slab session: operands are turned into slab form where they are, the product stays in it)
     const double denom = (double)A.dim * (double)A.dim;
     const bool dense_rule = denom > 0 && std::min((double)A.loc.nnz / denom, (double)B.loc.nnz / denom) > 0.1;
-    if (slab_enter(mut(A)) && (&A == &B || slab_enter(mut(B))) && slab_multiply(A.loc, B.loc, AB, alpha, threshold, dense_rule)) {
+    // (unfused arithmetic: the register-slab kernel multiplies whole runs, zeros included -- operands that have become
+    // sparse inside wide extents, 3 I - X^2 near the end of a sign iteration, are better served by the general kernels,
+    // which the compressed-column path picks per product; the MFMA tile kernel of the FMA mode takes them as they are)
+    auto runs_dense = [](const DevMat& M) {
+      return options().spgemm_fma != 0 || !M.expanded() ||
+             (double)slab_span_sum(M) <= 1.5 * (double)M.nnz + 64.0 * (double)M.cols;
+    };
+    if (slab_enter(mut(A)) && (&A == &B || slab_enter(mut(B))) && runs_dense(A.loc) && runs_dense(B.loc) &&
+        slab_multiply(A.loc, B.loc, AB, alpha, threshold, dense_rule)) {
       g_slab_counts[0] += 1;
       if (options().time_kernels != 0) {   // (statistics mode: the products a plan over compressed columns would have counted)
         const long long pr = slab_product_count(A.loc, B.loc);

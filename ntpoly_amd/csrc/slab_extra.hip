@@ -366,6 +366,40 @@ bool slab_trace(const DevMat& A, int32_t col_offset, double* out) {
   return true;
 }
 
+// ------------------------------------------------------------------ how dense the runs are
+namespace {
+__global__ __launch_bounds__(256) void k_sa_span_sum(const int32_t* __restrict__ first, const int32_t* __restrict__ last, int n,
+                                                     unsigned long long* __restrict__ out) {
+  __shared__ long long red[4];
+  long long s = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += last[i] >= first[i] ? last[i] - first[i] + 1 : 0;
+  s = wave_sum_i64(s);
+  if (lane_id() == 0) red[threadIdx.x / WAVE] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long t = red[0] + red[1] + red[2] + red[3];
+    if (t) atomicAdd(out, (unsigned long long)t);
+  }
+}
+}  // namespace
+
+// rows covered by the runs of a slab-form matrix (kept in the form: its extents never change)
+int64_t slab_span_sum(const DevMat& M) {
+  if (!M.expanded()) return 0;
+  const SlabForm& f = *M.slab;
+  if (f.span_sum >= 0) return f.span_sum;
+  DevBuf<unsigned long long> acc(1);
+  acc.zero();
+  hipLaunchKernelGGL(k_sa_span_sum, dim3(std::max(1, std::min(256, cdiv(M.cols, 1024)))), dim3(256), 0, stream(), f.first.p, f.last.p, M.cols,
+                     acc.p);
+  unsigned long long h = 0;
+  ScalarFetch ft;
+  ft.add(acc.p, 1, &h);
+  ft.run();
+  f.span_sum = (int64_t)h;
+  return f.span_sum;
+}
+
 long long slab_product_count(const DevMat& A, const DevMat& B) {
   if (!A.expanded() || !B.expanded() || A.cplx || B.cplx) return 0;
   const SlabForm &fa = *A.slab, &fb = *B.slab;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 evidence in one GPU-box session: tools/collect_r03.sh <tag>   (everything lands under gpurun_out/<tag>*)
-tag=${1:-r03_v3}
+tag=${1:-r03_v4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 bash tools/collect_profiles.sh ${tag}
 bash tools/collect_profiles.sh ${tag}_unfused --arithmetic unfused

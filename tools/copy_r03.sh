@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies the judged artefacts of tools/collect_r03.sh <tag> from gpurun_out/ (scratch) into profiles/ (tracked)
-tag=${1:-r03_v3}
+tag=${1:-r03_v4}
 cd "$(dirname "$0")/.."
 for v in "" _unfused _permute; do
   d=gpurun_out/${tag}${v}
