@@ -75,23 +75,24 @@ def cpu_baseline(n, h, thr, warmup, steps, permute=None, fma=False, lattice=None
 
     # ONE run of warmup + 3 iterations; the oracle stamps the wall clock at the end of every iteration (otrace.stamp), so
     # the last three differences are three samples of one iteration of the region the GPU line times
-    iters = max(1, warmup) + 3
+    nsamp = 3 if lattice is not None else 5
+    iters = max(1, warmup) + nsamp
     try:
         p = O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr, monitor_convergence=False)
         _, _, _, tro = O.density("trs2", H, I, n / 2.0, p)
     finally:
         O.set_fma(False)
     st = tro["stamp"]
-    samples = sorted(max(1e-9, float(st[k] - st[k - 1])) for k in range(max(1, len(st) - 3), len(st)))
+    samples = sorted(max(1e-9, float(st[k] - st[k - 1])) for k in range(max(1, len(st) - nsamp), len(st)))
     per_iter = samples[len(samples) // 2]
     return {"value": 1.0 / per_iter, "unit": "iters/s", "cores": int(O.lib().oracle_num_threads()),
             "kind": "port",
             "sample": "oracle TRS2 (OpenMP, all host cores, %s arithmetic) at the full size N=%d (h=%d, thr=%g%s): iterations "
-                      "%d..%d of one solve, three single-iteration samples (wall clock stamped by the oracle after every iteration) = %s s, median %.3f s/iter; "
+                      "%d..%d of one solve, single-iteration samples (wall clock stamped by the oracle after every iteration) = %s s, median %.3f s/iter; "
                       "no scaling" % ("fma" if fma else "unfused", n, h, thr,
                                       (", %d^3 lattice" % lattice) if lattice is not None else
                                       "" if permute is None else ", relabelled with seed %d" % permute, warmup + 1,
-                                      warmup + 3, "/".join("%.3f" % x for x in samples), per_iter)}
+                                      warmup + nsamp, "/".join("%.3f" % x for x in samples), per_iter)}
 
 
 def trs2_wrp_check(nt, H, n, thr, n1=5, n2=25):
@@ -149,11 +150,13 @@ def main():
                     help="run on the Hamiltonian of an L x L x L lattice (tests/gen.py lattice_triplets: 203 entries per row, "
                          "no band any relabelling could recover; N = L^3, e.g. 64 -> 262 144): the operand the north star's "
                          "LDS-hash SpGEMM exists for")
-    ap.add_argument("--arithmetic", choices=("fma", "unfused"), default="fma",
+    ap.add_argument("--arithmetic", choices=("fma", "unfused"), default=None,
                     help="fma: every product entry is the chain of fma() over ascending k (one rounding per product) that "
                          "the reference computes when built with FP contraction -- run on the FP64 matrix cores "
                          "(v_mfma_f64_16x16x4_f64, option spgemm_fma = 1); unfused: separate multiply and add, the "
                          "reference's default x86-64 build bit for bit (v_mul_f64 + v_add_f64 register-slab kernel)")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="the timed region (warm-up + K steps from X0) is repeated this many times; the MEDIAN block is reported")
     ap.add_argument("--tile-rows", type=int, default=None, help="experiments: option tile_rows (1, 2, 4)")
     ap.add_argument("--tile-waves", type=int, default=None, help="experiments: option tile_waves (4, 8)")
     args = ap.parse_args()
@@ -172,6 +175,11 @@ def main():
         n = args.lattice ** 3
     nt.ConstructGlobalProcessGrid(1, world, 1)  # column panels: one per GPU
     nt.set_option("time_kernels", 1)
+    # the arithmetic a drop-in caller gets without asking (the library's default, or NTPOLY_AMD_ARITHMETIC from the
+    # environment) is what this line times unless --arithmetic says otherwise
+    lib_default = "fma" if nt.get_option("spgemm_fma") == 1 else "unfused"
+    if args.arithmetic is None:
+        args.arithmetic = lib_default
     nt.set_option("spgemm_fma", 1 if args.arithmetic == "fma" else 0)
     if args.tile_rows is not None:
         nt.set_option("tile_rows", args.tile_rows)
@@ -198,11 +206,6 @@ def main():
     e_min, e_max = nt.EigenBounds.GershgorinBounds(H)
     Ident = nt.Matrix_ps(n)
     Ident.FillIdentity()
-    X = nt.Matrix_ps(H)
-    X.Scale(-1.0)
-    X.Increment(Ident, e_max, 0.0)
-    X.Scale(1.0 / (e_max - e_min))
-    X2 = nt.Matrix_ps(n)
     pool = nt.PMatrixMemoryPool(H)
     trace_target = n / 2.0
 
@@ -214,28 +217,41 @@ def main():
             nt.barrier()
             nt.synchronize()
 
-    energy, tr_x = 0.0, None
-    for _ in range(args.warmup):
-        _, energy, tr_x = trs2_step(nt, X, X2, H, pool, trace_target, thr, tr_x)
-    nt.reset_spgemm_accum()
-    m0 = nt.malloc_stats()
-    fz0 = nt.fusion_counts()
-    fence()
-    t0 = time.perf_counter()
-    nnz_trace = []
-    for _ in range(args.steps):
-        _, energy, tr_x = trs2_step(nt, X, X2, H, pool, trace_target, thr, tr_x)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        elapsed = nt.allreduce_max(elapsed)
-    m1 = nt.malloc_stats()
-    fz1 = nt.fusion_counts()
-    fused = {k: fz1[k] - fz0[k] for k in fz1}
-    acc = nt.spgemm_accum()
-    st = nt.last_spgemm_stats()
-    gs = nt.last_grouped_stats()
-    nnz_x = X.GetSize()
+    # The timed region is short (20 steps = 34 ms on the headline), so ONE block of it carries +-3 % of noise (VERDICT r3
+    # weak 7).  The same region -- X0 from H, W untimed warm-up steps, barrier + device synchronise, exactly K timed
+    # steps, barrier + device synchronise, max over ranks -- is therefore run `--blocks` times (default 5), each time
+    # from scratch, and the line reports the MEDIAN block (its time, its kernel timers, its counters); `steps` stays K.
+    blocks = []
+    for blk in range(max(1, args.blocks)):
+        X = nt.Matrix_ps(H)
+        X.Scale(-1.0)
+        X.Increment(Ident, e_max, 0.0)
+        X.Scale(1.0 / (e_max - e_min))
+        X2 = nt.Matrix_ps(n)
+        energy, tr_x = 0.0, None
+        for _ in range(args.warmup):
+            _, energy, tr_x = trs2_step(nt, X, X2, H, pool, trace_target, thr, tr_x)
+        nt.reset_spgemm_accum()
+        m0 = nt.malloc_stats()
+        fz0 = nt.fusion_counts()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _, energy, tr_x = trs2_step(nt, X, X2, H, pool, trace_target, thr, tr_x)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            elapsed = nt.allreduce_max(elapsed)
+        m1 = nt.malloc_stats()
+        fz1 = nt.fusion_counts()
+        blocks.append(dict(elapsed=elapsed, energy=energy, m0=m0, m1=m1, fused={k: fz1[k] - fz0[k] for k in fz1}, acc=nt.spgemm_accum(),
+                           st=nt.last_spgemm_stats(), gs=nt.last_grouped_stats(), nnz_x=X.GetSize()))
+        if blk + 1 < max(1, args.blocks):
+            del X, X2
+    order = sorted(range(len(blocks)), key=lambda k: blocks[k]["elapsed"])
+    med = blocks[order[len(order) // 2]]
+    elapsed, energy, m0, m1, fused, acc, st, gs, nnz_x = (med[k] for k in ("elapsed", "energy", "m0", "m1", "fused", "acc", "st", "gs", "nnz_x"))
+    block_ms = [1e3 * b["elapsed"] for b in blocks]
 
     if rank == 0:
         # HBM traffic of the dominant kernel comes from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of
@@ -288,6 +304,8 @@ def main():
                                       "operands on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, spgemm_tile.hip)"
                                       if args.arithmetic == "fma" else
                                       "unfused: separate v_mul_f64 + v_add_f64, the reference's default x86-64 build bit for bit"),
+                       "arithmetic_default": lib_default,   # what an unmodified caller of the C ABI runs with
+                       "blocks_ms": block_ms,               # every repetition of the timed region; `value` is the median block
                        "n": n, "halfband": h, "threshold": thr, "nnz_H": int(nnz_h), "nnz_X_end": int(nnz_x),
                        "nnz_product_last": int(st.get("nnz_c", -1)), "energy_end": energy,
                        "permute_seed": args.permute,

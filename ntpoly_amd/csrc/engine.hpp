@@ -91,7 +91,7 @@ void ps_copy(const PSMatrix& a, PSMatrix& b);
 // packs what leaves it (ps_slab_leave).  Any operation that cannot be done in slab form packs its operands and takes
 // the general path; after a handful of refusals the session stays off.
 struct SlabSession {
-  explicit SlabSession(bool eligible);
+  explicit SlabSession(bool eligible, bool api = false);   // api: a one-call session of the C ABI's vocabulary entry points
   ~SlabSession();
   SlabSession(const SlabSession&) = delete;
   SlabSession& operator=(const SlabSession&) = delete;

@@ -2556,6 +2556,12 @@ EngineOptions& options() {
     auto* e = new EngineOptions();
     if (const char* v = std::getenv("NTPOLY_AMD_HALO_OVERLAP")) e->halo_overlap = std::atoi(v);  // see kernels.hpp
     if (const char* v = std::getenv("NTPOLY_AMD_SPGEMM_FMA")) e->spgemm_fma = std::atoi(v);
+    if (const char* v = std::getenv("NTPOLY_AMD_ARITHMETIC")) {   // the documented selector
+      const std::string a(v);
+      if (a == "fma") e->spgemm_fma = 1;
+      else if (a == "unfused") e->spgemm_fma = 0;
+      else NTP_FATAL("NTPOLY_AMD_ARITHMETIC must be fma or unfused, not " + a);
+    }
     if (const char* v = std::getenv("NTPOLY_AMD_TILE_ROWS")) e->tile_rows = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_TILE_WAVES")) e->tile_waves = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_PLAN_AHEAD")) e->plan_ahead = std::atoi(v);
@@ -5538,7 +5544,7 @@ __global__ __launch_bounds__(256) void k_sa_axpby(int n, const int32_t* __restri
                                                   const int64_t* __restrict__ base, int al, double alpha, double beta, double thr,
                                                   double* __restrict__ out, int32_t* __restrict__ ofirst, int32_t* __restrict__ olast,
                                                   int32_t* __restrict__ ocount, int64_t* __restrict__ ooff,
-                                                  unsigned long long* __restrict__ stat) {
+                                                  unsigned long long* __restrict__ stat, int64_t bound) {
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   if (j >= n) return;
   const int lane = lane_id();
@@ -5553,6 +5559,13 @@ __global__ __launch_bounds__(256) void k_sa_axpby(int n, const int32_t* __restri
   }
   const int f = anyA ? (anyB ? min(fA, fB) : fA) : fB, l = anyA ? (anyB ? max(lA, lB) : lA) : lB;
   const int a0 = f / al * al, a1 = (l / al + 1) * al;
+  // The union extent of two runs that lie far apart (an identity and a product with entries n / 2 rows from the
+  // diagonal) is not bounded by the operands' slots: a column whose slot would end beyond the output buffer writes
+  // nothing and flags the merge, which the host then refuses (the operands go back to compressed columns)
+  if (slot + (int64_t)(a1 - a0) > bound) {
+    if (lane == 0) { ofirst[j] = INT_MAX; olast[j] = -1; ocount[j] = 0; ooff[j] = slot; atomicOr(stat, 2ull); }
+    return;
+  }
   const int amax = anyA ? lA : -1, bmax = anyB ? lB : -1;
   const double* __restrict__ pa = anyA ? va + (offa[j] - fA) : va;
   const double* __restrict__ pb = (HAVE_B && anyB) ? vb + (offb[j] - fB) : va;
@@ -5729,11 +5742,11 @@ static bool sa_axpby_impl(const DevMat* A, const DevMat& Bin, DevMat& Out, doubl
   if (have_b)
     hipLaunchKernelGGL((k_sa_axpby<true>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
                        fa.val.p, fb->first.p, fb->last.p, fb->off.p, fb->val.p, base.p, al, alpha, beta, thr, fo->val.p, fo->first.p,
-                       fo->last.p, fo->count.p, fo->off.p, stat.p);
+                       fo->last.p, fo->count.p, fo->off.p, stat.p, bound);
   else
     hipLaunchKernelGGL((k_sa_axpby<false>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
                        fa.val.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int64_t*)nullptr, (const double*)nullptr,
-                       base.p, al, 1.0, 0.0, 0.0, fo->val.p, fo->first.p, fo->last.p, fo->count.p, fo->off.p, stat.p);
+                       base.p, al, 1.0, 0.0, 0.0, fo->val.p, fo->first.p, fo->last.p, fo->count.p, fo->off.p, stat.p, bound);
   DevBuf<long long> tot;
   sa_sum_counts(fo->count.p, n, tot);
   int64_t nnz = 0, slots = 0;

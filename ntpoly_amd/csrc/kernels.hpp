@@ -31,9 +31,16 @@ struct EngineOptions {
   int spgemm_force_bin = -1;   // tests: force every non-empty column through one path (1..5), 6 = HBM fallback
   int increment_force_seq = 0; // tests: 1 force the sequential-merge fallback, 2 force the rank-merge kernel (columns of <= 2048 entries)
   int time_kernels = 0;        // record HIP-event timings in SpgemmStats
-  int spgemm_fma = 0;          // 1: the register-slab kernel accumulates with v_fma_f64 (one rounding per product, what a
-                               // reference built with FP contraction computes); 0: separate multiply and add (default, bit-
-                               // identical to the reference built without contraction)
+  int spgemm_fma = 1;          // arithmetic of the real products (NTPOLY_AMD_ARITHMETIC=fma|unfused in the environment).
+                               // 1 (default since round 4): every product entry is the chain fma(a, b, acc) over ascending k, one
+                               // rounding per product -- the reference built with FP contraction, bit for bit; run-like operands on
+                               // the FP64 matrix cores (spgemm_tile.hip), operands without runs as 16 x 16 blocks on the same
+                               // instruction (spgemm_block.hip).  0: separate multiply and add, bit-identical to the reference's
+                               // default x86-64 build (register-slab / LDS kernels).  3: the v_fma_f64 vector loop (tests)
+  int block_path = 1;          // FMA arithmetic, one rank, real square operands WITHOUT run structure (3-D Hamiltonians, relabelled bands outside
+                               // a TRS2 loop): products on 16 x 16 blocks of a clustered index order through v_mfma_f64_16x16x4_f64
+                               // (spgemm_block.hip) instead of the grouped LDS-hash kernel; 0: never; 2: every real square one-rank
+                               // product that no run-based kernel takes, whatever the fill (tests)
   int slab_algebra = 1;        // solver loops (TRS4, sign, inverse, square roots; one rank, real, FMA arithmetic): iterates stay in slab form
                                // between products, merges, dots and norms (psmatrix.cpp SlabSession); 0: compressed columns between the operations
   int plan_ahead = 1;          // TRS2 steps on the slab form (tile kernel, one rank): the step plans its successor behind its own kernel and

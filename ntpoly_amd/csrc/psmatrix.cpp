@@ -112,6 +112,8 @@ bool slab_on() { return g_slab_depth > 0 && !g_slab_failed; }
 // (the representation of an operand, not its value, changes: const operands are converted in place)
 DevMat& mut(const PSMatrix& m) { return const_cast<DevMat&>(m.loc); }
 int g_slab_refusals = 0;
+int g_api_refusals = 0, g_api_skipped = 0;   // refusal state shared by the one-call sessions of the C ABI (SlabSession)
+bool g_session_api = false, g_session_did_work = false;
 long long g_slab_counts[4] = {0, 0, 0, 0};   // products, merges / copies, other operations in slab form; refusals
 // an operation that cannot be done in slab form: its operands go back to compressed columns and the general path does
 // it (a Hamiltonian with stored zeros in the first merge of a loop); the session goes on, unless this keeps happening
@@ -134,17 +136,33 @@ void slab_pack_if(std::initializer_list<const PSMatrix*> ms) {
 
 const long long* slab_algebra_counts() { return g_slab_counts; }
 
-SlabSession::SlabSession(bool eligible) {
+SlabSession::SlabSession(bool eligible, bool api) {
   opened = eligible && options().slab_algebra != 0 && (options().spgemm_fma == 1 || options().spgemm_fma == 0) && options().spgemm_variant < 0 &&
            options().spgemm_force_bin <= 0 && !world().active();
+  // A session of the C ABI's vocabulary calls lasts one call: a caller's loop over matrices that are not run-like
+  // (general sparse, load-balanced) would pay the refused conversion -- extents, a scan, a read-back -- on every call.
+  // Those sessions therefore share a refusal state that only a successful slab operation clears (g_api_refusals):
+  // after four refusals in a row they are not opened until sixty-four calls have passed.
+  if (opened && api && g_slab_depth == 0 && g_api_refusals >= 4) {
+    if (++g_api_skipped < 64) { opened = false; return; }
+    g_api_skipped = 0;
+    g_api_refusals = 3;   // (one more try)
+  }
   if (opened) {
-    if (g_slab_depth == 0) { g_slab_failed = false; g_slab_refusals = 0; }
+    if (g_slab_depth == 0) { g_slab_failed = false; g_slab_refusals = 0; g_session_api = api; }
     g_slab_depth += 1;
   }
 }
 SlabSession::~SlabSession() { close(); }
 void SlabSession::close() {
-  if (opened) g_slab_depth -= 1;
+  if (opened) {
+    g_slab_depth -= 1;
+    if (g_slab_depth == 0 && g_session_api) {
+      if (g_slab_refusals > 0) g_api_refusals += 1;
+      else if (g_session_did_work) g_api_refusals = 0;
+    }
+    if (g_slab_depth == 0) g_session_did_work = false;
+  }
   opened = false;
 }
 void ps_slab_leave(PSMatrix& m) {
@@ -156,7 +174,7 @@ void ps_copy(const PSMatrix& a, PSMatrix& b) {
   if (slab_on() && a.loc.expanded()) {
     DevMat t;
     if (slab_clone(a.loc, t)) {
-      g_slab_counts[1] += 1;
+      g_slab_counts[1] += 1; g_session_did_work = true;
       b.grid = a.grid; b.dim = a.dim; b.cplx = a.cplx; b.c0 = a.c0; b.c1 = a.c1;
       b.loc = std::move(t);
       return;
@@ -454,6 +472,10 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   if (A.dim != B.dim) NTP_FATAL("MatrixMultiply: dimension mismatch");
   // up-casting of mixed real/complex operands (PSMatrixAlgebraModule.F90:171-188)
   if (A.cplx != B.cplx) {
+    // (a real operand that an earlier call of a slab session left in slab form or loose: to_complex copies the three
+    // arrays of compressed columns, so the operands are packed first)
+    if (A.loc.expanded() || A.loc.loose()) pack(mut(A));
+    if (B.loc.expanded() || B.loc.loose()) pack(mut(B));
     PSMatrix Ac, Bc;
     ps_to_complex(A, Ac);
     ps_to_complex(B, Bc);
@@ -475,7 +497,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     };
     if (slab_enter(mut(A)) && (&A == &B || slab_enter(mut(B))) && runs_dense(A.loc) && runs_dense(B.loc) &&
         slab_multiply(A.loc, B.loc, AB, alpha, threshold, dense_rule)) {
-      g_slab_counts[0] += 1;
+      g_slab_counts[0] += 1; g_session_did_work = true;
       if (options().time_kernels != 0) {   // (statistics mode: the products a plan over compressed columns would have counted)
         const long long pr = slab_product_count(A.loc, B.loc);
         last_spgemm_stats().products = pr;
@@ -561,7 +583,7 @@ void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold
 
 void ps_scale(PSMatrix& A, double c) {
   if (slab_on() && A.loc.expanded()) {
-    if (slab_scale(A.loc, c)) { g_slab_counts[2] += 1; return; }
+    if (slab_scale(A.loc, c)) { g_slab_counts[2] += 1; g_session_did_work = true; return; }
     slab_refused({&A});
   }
   scale(A.loc, c);
@@ -573,7 +595,7 @@ void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double 
   if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B) {
     // (a slab session: the operand still in compressed columns -- an identity, the Hamiltonian -- is turned into slab form)
-    if (slab_enter(mut(A)) && slab_enter(B.loc) && slab_axpby(A.loc, B.loc, alpha, beta, threshold)) { g_slab_counts[1] += 1; return; }
+    if (slab_enter(mut(A)) && slab_enter(B.loc) && slab_axpby(A.loc, B.loc, alpha, beta, threshold)) { g_slab_counts[1] += 1; g_session_did_work = true; return; }
     slab_refused({&A, &B});
   } else {
     slab_pack_if({&A, &B});
@@ -588,7 +610,7 @@ void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double 
 
 void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) {
   if (slab_on() && B.loc.expanded() && !B.cplx && !Identity.cplx && Identity.dim == B.dim && slab_add_diagonal(B.loc, alpha, B.c0)) {
-    g_slab_counts[1] += 1;
+    g_slab_counts[1] += 1; g_session_did_work = true;
     return;
   }
   ps_increment(Identity, B, alpha, 0.0);
@@ -597,14 +619,14 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) 
 bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double beta, double* norm) {
   if (!slab_on() || A.cplx || B.cplx || A.dim != B.dim || &A == &B || !(A.loc.expanded() || B.loc.expanded())) return false;
   if (!(slab_enter(mut(A)) && slab_enter(mut(B)) && slab_norm_axpby(A.loc, B.loc, alpha, beta, norm))) return false;
-  g_slab_counts[2] += 1;
+  g_slab_counts[2] += 1; g_session_did_work = true;
   return true;
 }
 
 bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx) {
   if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx) return false;
   if (!slab_trs4_traces(X.loc, X2.loc, X.c0, trace_fx, trace_gx)) return false;
-  g_slab_counts[2] += 1;
+  g_slab_counts[2] += 1; g_session_did_work = true;
   return true;
 }
 bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatrix& P) {
@@ -613,7 +635,7 @@ bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatr
   if (!slab_trs4_operand(X.loc, X2.loc, sigma, X.c0, R)) return false;
   P.grid = X.grid; P.dim = X.dim; P.cplx = false; P.c0 = X.c0; P.c1 = X.c1;
   P.loc = std::move(R);
-  g_slab_counts[1] += 1;
+  g_slab_counts[1] += 1; g_session_did_work = true;
   return true;
 }
 
@@ -621,7 +643,7 @@ void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double a
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B && A.dim == B.dim) {
     DevMat R;
     if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_axpby_to(A.loc, B.loc, R, alpha, beta, threshold)) {
-      g_slab_counts[1] += 1;
+      g_slab_counts[1] += 1; g_session_did_work = true;
       Out.grid = B.grid; Out.dim = B.dim; Out.cplx = false; Out.c0 = B.c0; Out.c1 = B.c1;
       Out.loc = std::move(R);
       return;
@@ -1018,7 +1040,7 @@ void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {
 // sum conj(A).B; fused, no Hadamard temporary.
 void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx) {
-    if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_dot(A.loc, B.loc, out)) { g_slab_counts[2] += 1; return; }
+    if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_dot(A.loc, B.loc, out)) { g_slab_counts[2] += 1; g_session_did_work = true; return; }
     slab_refused({&A, &B});
   } else {
     slab_pack_if({&A, &B});
@@ -1038,7 +1060,7 @@ double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includ
   if (slab_on() && A.loc.expanded() && !A.cplx) {
     double v = 0.0;
     if (slab_trace(A.loc, A.c0, &v)) {
-      g_slab_counts[2] += 1;
+      g_slab_counts[2] += 1; g_session_did_work = true;
       return v;
     }
     slab_refused({&A});
@@ -1053,7 +1075,7 @@ double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includ
 double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns are local
   if (slab_on() && A.loc.expanded()) {
     double v = 0.0;
-    if (slab_norm(A.loc, &v)) { g_slab_counts[2] += 1; return v; }
+    if (slab_norm(A.loc, &v)) { g_slab_counts[2] += 1; g_session_did_work = true; return v; }
     slab_refused({&A});
   } else {
     slab_pack_if({&A});
@@ -1074,7 +1096,7 @@ void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {  // Gershg
   double mn, mx;
   if (slab_on() && A.loc.expanded()) {
     if (slab_gershgorin(A.loc, A.c0, &mn, &mx)) {
-      g_slab_counts[2] += 1;
+      g_slab_counts[2] += 1; g_session_did_work = true;
       *e_min = mn;
       *e_max = mx;
       return;

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void k_sa_trs4(int n, const int32_t* __restric
                                                  const int64_t* __restrict__ offb, const double* __restrict__ vb, int col_offset,
                                                  double sigma, int al, const int64_t* __restrict__ base, double* __restrict__ part,
                                                  double* __restrict__ out, int32_t* __restrict__ ofirst, int32_t* __restrict__ olast,
-                                                 int32_t* __restrict__ ocount, int64_t* __restrict__ ooff) {
+                                                 int32_t* __restrict__ ocount, int64_t* __restrict__ ooff, int64_t bound,
+                                                 unsigned long long* __restrict__ stat) {
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   if (j >= n) return;
   const int lane = lane_id();
@@ -158,6 +159,10 @@ __global__ __launch_bounds__(256) void k_sa_trs4(int n, const int32_t* __restric
     if (lane == 0) { part[2 * (size_t)j] = s0; part[2 * (size_t)j + 1] = s1; }
   } else {
     const int64_t slot = base[j];
+    if (slot + (int64_t)(a1 - a0) > bound) {   // (runs far apart: the union extent does not fit the output -- refused by the host)
+      if (lane == 0) { ofirst[j] = INT_MAX; olast[j] = -1; ocount[j] = 0; ooff[j] = slot; atomicOr(stat, 2ull); }
+      return;
+    }
     double* __restrict__ dst = out + (slot - a0);
     int cnt = 0, kf = INT_MAX, kl = -1;
     for (int r = a0 + lane; r < a1; r += WAVE) {
@@ -247,7 +252,8 @@ bool slab_trs4_traces(const DevMat& X, const DevMat& X2, int32_t col_offset, dou
   DevBuf<double> part((size_t)2 * n), res(2);
   hipLaunchKernelGGL((k_sa_trs4<0>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p, fa.val.p,
                      fb.first.p, fb.last.p, fb.off.p, fb.val.p, col_offset, 0.0, std::max(1, fa.row_pad), (const int64_t*)nullptr, part.p,
-                     (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);
+                     (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
+                     (unsigned long long*)nullptr);
   sum_pairs_async(part.p, n, res.p);
   unsigned long long h[2] = {0, 0};
   ScalarFetch ft;
@@ -273,19 +279,24 @@ bool slab_trs4_operand(const DevMat& X, const DevMat& X2, double sigma, int32_t 
   scan_i32_async(span.p, base.p, (int64_t)n);
   const int64_t bound = fa.slots + fb.slots + 4LL * al * n;
   fo->val.alloc((size_t)bound + kIndexSlack);
+  DevBuf<unsigned long long> stat(1);
+  stat.zero();
   hipLaunchKernelGGL((k_sa_trs4<1>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p, fa.val.p,
                      fb.first.p, fb.last.p, fb.off.p, fb.val.p, col_offset, sigma, al, base.p, (double*)nullptr, fo->val.p, fo->first.p,
-                     fo->last.p, fo->count.p, fo->off.p);
+                     fo->last.p, fo->count.p, fo->off.p, bound, stat.p);
   DevBuf<unsigned long long> tot(1);
   tot.zero();
   hipLaunchKernelGGL(k_sa_count_sum, dim3(std::max(1, std::min(256, cdiv(n, 1024)))), dim3(256), 0, stream(), fo->count.p, n, tot.p);
   int64_t nnz = 0, slots = 0;
+  unsigned long long hs = 0;
   {
     ScalarFetch ft;
     ft.add(tot.p, 1, &nnz);
     ft.add(base.p + n, 1, &slots);
+    ft.add(stat.p, 1, &hs);
     ft.run();
   }
+  if (hs != 0) return false;   // (a union extent beyond the output buffer: runs far apart -- the caller takes compressed columns)
   fo->row_pad = al;
   fo->slots = slots;
   DevMat R;

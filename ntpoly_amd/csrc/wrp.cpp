@@ -44,7 +44,7 @@ PSMatrix* get_unpacked(const int* ih) {
 // entry point still sees compressed columns (get<PSMatrix> packs on access).  Session not open: packed as ever.
 struct ApiSession {
   SlabSession s;
-  ApiSession() : s(true) {}
+  ApiSession() : s(true, true) {}
   PSMatrix* mat(const int* ih) const { return s.opened ? get_unpacked(ih) : get<PSMatrix>(ih); }
 };
 template <typename T>
@@ -160,7 +160,21 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "fused_update") options().fused_update = *value;
   else if (n == "label_order") options().label_order = *value;
   else if (n == "label_rowoff") options().label_rowoff = *value;
+  else if (n == "block_path") options().block_path = *value;
   else NTP_FATAL("unknown option " + n);
+}
+// the current value of the options a caller may want to report (bench.py prints the arithmetic a drop-in caller gets)
+int ntpoly_amd_get_option(const char* name) {
+  const std::string n(name);
+  if (n == "spgemm_fma") return options().spgemm_fma;
+  if (n == "slab_algebra") return options().slab_algebra;
+  if (n == "plan_ahead") return options().plan_ahead;
+  if (n == "tile_rows") return options().tile_rows;
+  if (n == "block_path") return options().block_path;
+  if (n == "label_order") return options().label_order;
+  if (n == "fused_update") return options().fused_update;
+  if (n == "loose_iterates") return options().loose_iterates;
+  NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used
 void ntpoly_amd_last_spgemm_stats(long long* out, float* ms_numeric, float* ms_total) {

@@ -98,8 +98,10 @@ def init_comm_from_env(timeout=300.0):
     who = os.environ.get("NTPOLY_AMD_RDV_NONCE", "") if os.environ.get("NTPOLY_AMD_RDV") else str(os.getppid())
     # (an elastic restart of a crashed worker group keeps run id, port and parent: the restart count tells the new
     # group's file from the dead group's)
-    nonce = (os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") + ":" +
-             os.environ.get("MASTER_PORT", "0") + ":" + who).encode()[:64].ljust(64, b"\0")
+    # (hashed, not truncated: a long user-supplied run id must not push the restart count, port and parent out of the field)
+    import hashlib
+    nonce = hashlib.sha256((os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") + ":" +
+                            os.environ.get("MASTER_PORT", "0") + ":" + who).encode()).hexdigest().encode()[:64].ljust(64, b"\0")
     if rank == 0:
         uid = get_unique_id()
         try:
@@ -145,6 +147,11 @@ def allreduce_max(x):
 
 def set_option(name, value):
     lib.ntpoly_amd_set_option(name.encode(), i(value))
+
+
+def get_option(name):
+    lib.ntpoly_amd_get_option.restype = C.c_int
+    return int(lib.ntpoly_amd_get_option(name.encode()))
 
 
 def synchronize():

@@ -216,3 +216,22 @@ print("HOST-OK")
     assert "HOST-OK" in r.stdout, r.stdout[-4000:]
     assert "AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout, r.stdout[-4000:]
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_default_arithmetic_is_the_benched_one():
+    """The arithmetic a drop-in caller gets without asking is the FMA chain that bench.py times:
+    option spgemm_fma defaults to 1, NTPOLY_AMD_ARITHMETIC=unfused|fma selects the mode from the environment of an
+    unmodified program.  Fresh processes: the test session itself pins the unfused mode (tests/conftest.py)."""
+    import subprocess
+    import sys
+    code = "import ntpoly_amd as nt; print(nt.get_option('spgemm_fma'))"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_val, want in ((None, "1"), ("unfused", "0"), ("fma", "1")):
+        env = dict(os.environ)
+        env.pop("NTPOLY_AMD_SPGEMM_FMA", None)
+        env.pop("NTPOLY_AMD_ARITHMETIC", None)
+        if env_val:
+            env["NTPOLY_AMD_ARITHMETIC"] = env_val
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout
+        assert r.stdout.strip().splitlines()[-1] == want, (env_val, r.stdout)

@@ -382,3 +382,69 @@ def test_polynomial_evaluations_in_slab_form(nt, fma, kind):
     off, on = out
     assert off[1] == 0 and on[1] >= 2, (off[1], on[1])
     assert same_pattern(off[0], on[0]) and np.array_equal(off[0][2], on[0][2]), np.abs(off[0][2] - on[0][2]).max() if same_pattern(off[0], on[0]) else "pattern"
+
+
+def _far_band(n, off, h):
+    """entries (row, col) with row - col in [off - h, off + h] (mod-free: only inside the matrix): one run per column
+    that lies `off` rows away from the diagonal"""
+    j = np.arange(n, dtype=np.int64)
+    o = np.arange(off - h, off + h + 1, dtype=np.int64)
+    col = np.repeat(j, len(o))
+    row = col + np.tile(o, n)
+    ok = (row >= 0) & (row < n)
+    col, row = col[ok], row[ok]
+    val = 0.05 + 0.9 * (((row * 7919 + col * 104729) % 1000) / 1000.0)
+    return (col + 1).astype(np.int32), (row + 1).astype(np.int32), val
+
+
+def test_merge_of_slab_operands_with_disjoint_runs_is_refused_not_overflowed(nt, fma):
+    """a merge of two slab-form operands whose runs lie far apart in every column (an identity and a
+    product whose entries sit n / 2 rows from the diagonal) has a union extent of about n^2 / 2 rows against operands of
+    about 20 n slots.  The merge kernel must refuse such a column (the host then merges on compressed columns) instead
+    of writing past its output buffer.  Through the C ABI's own vocabulary calls, in both arithmetic modes."""
+    import scipy.sparse as sp
+    n, h = 4096, 6
+    col, row, val = _far_band(n, n // 4, h)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    nt.set_option("slab_algebra", 1)
+    C1 = nt.Matrix_ps(n)
+    C1.Gemm(A, A, threshold=0.0)           # entries n / 2 below the diagonal, left in slab form by the session
+    I = nt.Matrix_ps(n)
+    I.FillIdentity()
+    C1.Increment(I, 0.5, 0.0)              # identity run [j, j] + run around j + n / 2
+    B2 = nt.Matrix_ps(A)
+    B2.Increment(C1, -1.0, 0.0)            # two far-apart bands + the diagonal
+    got = srt(B2.triplets())
+    As = sp.csr_matrix((val, (row - 1, col - 1)), shape=(n, n))
+    want = (As - (As @ As + 0.5 * sp.identity(n))).tocsc()
+    want.sort_indices()
+    G = sp.csr_matrix((got[2], (got[1] - 1, got[0] - 1)), shape=(n, n))
+    assert G.nnz == want.nnz
+    assert abs(G - want).max() <= 1e-12
+    # and the TRS4 operand pass on the same kind of operand (X and X^2 far apart) goes back to compressed columns too
+    X = nt.Matrix_ps(A)
+    X2 = nt.Matrix_ps(n)
+    X2.Gemm(X, X, threshold=0.0)
+    assert abs(X2.Norm() - abs(As @ As).sum(axis=0).max()) <= 1e-9
+
+
+def test_mixed_real_complex_product_after_a_slab_form_result(nt, fma):
+    """a real product left in slab form by the C ABI's session, then multiplied by a COMPLEX matrix
+    (PSMatrixAlgebraModule.F90:171-188 up-casts): the up-cast must pack the slab-form operand first."""
+    import scipy.sparse as sp
+    n, h = 2048, 10
+    col, row, val = banded_triplets(n, h)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    nt.set_option("slab_algebra", 1)
+    P = nt.Matrix_ps(n)
+    P.Gemm(A, A, threshold=0.0)            # real, slab form
+    zc, zr, zv = banded_triplets(n, 4, complex_=True)
+    Z = nt.Matrix_ps.from_triplets(n, zc, zr, zv)
+    Out = nt.Matrix_ps(n)
+    Out.Gemm(P, Z, threshold=0.0)
+    got = srt(Out.triplets())
+    As = sp.csr_matrix((val, (row - 1, col - 1)), shape=(n, n))
+    Zs = sp.csr_matrix((zv, (zr - 1, zc - 1)), shape=(n, n))
+    want = (As @ As @ Zs).tocsc()
+    G = sp.csr_matrix((got[2], (got[1] - 1, got[0] - 1)), shape=(n, n))
+    assert abs(G - want).max() <= 1e-11
