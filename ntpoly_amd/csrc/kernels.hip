@@ -13,6 +13,7 @@
 #include "spgemm_grouped.hpp"
 #include "slab_types.hpp"
 #include "spgemm_tile.hpp"
+#include "spgemm_block.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -3252,6 +3253,32 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       spgemm(Ap, Bp, C, alpha, threshold, dense_rule, loose, arange, nullptr);
     }
     return;
+  }
+  // ---- operands without run structure, FMA arithmetic, real, square, one rank: 16 x 16 blocks of a clustered index order
+  // on the FP64 matrix cores (spgemm_block.hip); declined (false) when the clustering finds no blocks worth it
+  if (!use_slab && !grouped_done && !loose_in && !arange && !A.cplx && options().spgemm_fma == 1 && options().block_path != 0 && sv_opt < 0 &&
+      options().spgemm_force_bin <= 0 && m == A.cols && n == m && !strip_ctx().active) {
+    BlockInfo bi;
+    if (spgemm_block(A, B, C, alpha, threshold, dense_rule, &bi, timing ? t_num.a : nullptr, timing ? t_num.b : nullptr)) {
+      t_all.stop();
+      if (timing) {
+        if (pending_timings().size() >= 4096) flush_spgemm_timers();
+        pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+      }
+      st.block = 1;
+      st.block_fill = bi.fill_a;
+      st.block_tile_products = bi.tile_products;
+      st.block_cand = bi.cand;
+      st.products = bi.products;
+      st.nnz_c = C.nnz;
+      last_spgemm_stats() = st;
+      SpgemmAccum& acc = spgemm_accum();
+      acc.calls += 1;
+      acc.products += st.products;
+      acc.nnz_c += C.nnz;
+      acc.alg_bytes += 12.0 * (double)(A.nnz + B.nnz + C.nnz) + 4.0 * ((double)A.cols + B.cols + n + 3);
+      return;
+    }
   }
   // a dimension whose products needed row strips last time (columns with more distinct rows than the grouped kernel's
   // tables hold): straight to the strips, without the attempt on the whole operand

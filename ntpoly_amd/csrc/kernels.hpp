@@ -23,6 +23,11 @@ struct SpgemmStats {
   int64_t gh_failed_cols = 0, gh_groups = 0, gh_tile_rows = 0;
   int gh_level = 0, gh_minhash = 0;
   double gh_union_ratio = 0;
+  // block path (spgemm_block.hip): 1 when it computed the product; tile fill of A, 16 x 16 x 16 tile products issued
+  // (4 matrix instructions each), candidate output super-tiles
+  int block = 0;
+  double block_fill = 0;
+  int64_t block_tile_products = 0, block_cand = 0;
   float ms_total = 0.f;        // filled only when timing is enabled
   float ms_numeric = 0.f;
 };

@@ -1,0 +1,1074 @@
+// Block-sparse SpGEMM on the FP64 matrix cores (gfx950, v_mfma_f64_16x16x4_f64) for real square operands WITHOUT run
+// structure -- the Hamiltonian of a 3-D system, a band hidden under a relabelling: the operands the run-based kernels
+// (register-slab, MFMA tile) cannot take and that the LDS-hash kernels multiply one scalar product at a time.
+//
+// The reference's arithmetic (MultiplyBlock.f90:9-36, PruneList.f90:8-38) fixes, per entry C(i, j), the chain of
+// multiply-adds over ascending k.  A symmetric relabelling of the index set only renames entries -- the reference's own
+// load balancer applies a random one (LoadBalancerModule.F90:14-52) -- so the engine is free to pick the labelling in
+// which it multiplies: here one that makes the matrix BLOCK sparse.
+//
+//  1. BlockOrder: the indices are clustered into blocks of <= 16 with similar neighbourhoods by heavy-edge matching on
+//     the graph of |A| (five levels, ties broken towards indices that share their high bits, so a lattice in natural
+//     order comes out as regular bricks), blocks into super-blocks of <= 4, super-blocks into a nested order.
+//  2. BlockForm: the matrix as dense 16 x 16 tiles (zero = no entry), 4 x 4 tiles to a super-tile with a 16-bit mask.
+//  3. Symbolic phase on super-tiles (a bitmap per super-column), numeric phase: one wave per candidate output
+//     super-tile (64 x 64 entries = 16 accumulator tiles in registers), intersecting the super-row of A with the
+//     super-column of B and walking the matches in ascending k:  P(16 x 16) += A(16 x 4) B(4 x 16) per instruction.
+//     Every tile of A loaded feeds up to four instructions groups, every tile of B up to four.
+//  4. Prune in the epilogue; kept tiles go to a pool; the result is turned back into compressed columns under the
+//     caller's labels.
+//
+// Arithmetic: the matrix instruction is a chain of fma() in ascending k (tools/micro/mfma_f64_probe.hip), instructions,
+// blocks and super-blocks follow in ascending POSITION, zeros are exact no-ops: C(i, j) is the FMA chain over ascending
+// position -- bit for bit what the reference's FP-contracted build computes on the matrix relabelled by `pos`
+// (tests/test_gpu_block.py runs the oracle on exactly that matrix), and within roundoff of the chain over ascending
+// labels (the tolerance contract of label-ordered operands).
+#include "spgemm_block.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce_by_key.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "device_util.hpp"
+
+namespace ntp {
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// in-tile index of in-block position o (an involution): four lane groups of the matrix instruction hold words
+// 4 g + q of a 16-word line, the instruction q consumes k = 4 q + g
+__host__ __device__ inline int phys(int o) { return 4 * (o & 3) + (o >> 2); }
+
+bool dbg() {
+  static const bool d = std::getenv("NTPOLY_AMD_DEBUG_SPGEMM") != nullptr;
+  return d;
+}
+
+// =====================================================================================================================
+// 1. clustering
+// =====================================================================================================================
+// One level of heavy-edge matching on a graph in CSR form (off, nbr, w; level 0 = the matrix' own compressed columns
+// with w = |value|).  A vertex picks its best free neighbour -- heaviest edge (quantised to 10 mantissa bits: sums
+// that differ by roundoff tie), then the neighbour whose representative index shares the most high bits with its own
+// (smallest xor: neighbours along the fastest-running coordinate of a lattice, 2 k with 2 k + 1), then the smallest
+// representative -- among those with size(a) + size(b) <= cap; mutual picks are matched.  A few rounds per level.
+__global__ __launch_bounds__(256) void k_match_pick(int nv, const int64_t* __restrict__ off, const int32_t* __restrict__ nbr,
+                                                    const float* __restrict__ w, const int32_t* __restrict__ csize,
+                                                    const int32_t* __restrict__ crep, const int32_t* __restrict__ mate, int cap,
+                                                    int32_t* __restrict__ best) {
+  const int a = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
+  if (a >= nv) return;
+  const int lane = lane_id();
+  if (mate[a] >= 0) {
+    if (lane == 0) best[a] = -1;
+    return;
+  }
+  const int sa = csize[a], ra = crep[a];
+  unsigned long long k1 = 0, k2 = ~0ull;
+  for (int64_t e = off[a] + lane; e < off[a + 1]; e += WAVE) {
+    const int b = nbr[e];
+    if (b == a || mate[b] >= 0 || sa + csize[b] > cap) continue;
+    const unsigned wq = __float_as_uint(w[e]) >> 13;
+    const unsigned x = (unsigned)(ra ^ crep[b]);
+    const unsigned long long c1 = (1ull << 62) | ((unsigned long long)wq << 32) | (unsigned long long)(0xFFFFFFFFu - x);
+    const unsigned long long c2 = ((unsigned long long)(unsigned)crep[b] << 32) | (unsigned)b;
+    if (c1 > k1 || (c1 == k1 && c2 < k2)) { k1 = c1; k2 = c2; }
+  }
+  unsigned long long m1 = k1;
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(m1, o, WAVE);
+    m1 = t > m1 ? t : m1;
+  }
+  unsigned long long m2 = (k1 == m1) ? k2 : ~0ull;
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(m2, o, WAVE);
+    m2 = t < m2 ? t : m2;
+  }
+  if (lane == 0) best[a] = (m1 == 0) ? -1 : (int)(m2 & 0xFFFFFFFFull);
+}
+__global__ __launch_bounds__(256) void k_match_mutual(int nv, const int32_t* __restrict__ best, int32_t* __restrict__ mate) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nv) return;
+  const int b = best[a];
+  if (b >= 0 && best[b] == a) mate[a] = b;
+}
+__global__ __launch_bounds__(256) void k_match_roots(int nv, const int32_t* __restrict__ mate, int32_t* __restrict__ flag) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nv) return;
+  flag[a] = (mate[a] < 0 || a < mate[a]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_match_newid(int nv, const int32_t* __restrict__ mate, const int64_t* __restrict__ excl,
+                                                     int32_t* __restrict__ newid, const int32_t* __restrict__ csize,
+                                                     const int32_t* __restrict__ crep, int32_t* __restrict__ csize2,
+                                                     int32_t* __restrict__ crep2) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nv) return;
+  const int root = (mate[a] < 0 || a < mate[a]) ? a : mate[a];
+  const int id = (int)excl[root];
+  newid[a] = id;
+  atomicAdd(&csize2[id], csize[a]);
+  atomicMin(&crep2[id], crep[a]);
+}
+// edges of the coarse graph: key = (new id of the source) << 32 | new id of the target; edges inside a cluster get a
+// key behind every real one
+__global__ __launch_bounds__(256) void k_coarse_keys(int nv, const int64_t* __restrict__ off, const int32_t* __restrict__ nbr,
+                                                     const float* __restrict__ w, const int32_t* __restrict__ newid, int nv2,
+                                                     unsigned long long* __restrict__ key, float* __restrict__ val) {
+  const int a = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
+  if (a >= nv) return;
+  const int lane = lane_id();
+  const unsigned na = (unsigned)newid[a];
+  for (int64_t e = off[a] + lane; e < off[a + 1]; e += WAVE) {
+    const unsigned nb = (unsigned)newid[nbr[e]];
+    key[e] = (na == nb) ? ((unsigned long long)(unsigned)nv2 << 32) : (((unsigned long long)na << 32) | nb);
+    val[e] = w[e];
+  }
+}
+// CSR of the coarse graph from its sorted unique keys (the group of in-cluster edges, if any, is the last one)
+__global__ __launch_bounds__(256) void k_coarse_csr(int64_t nu, const unsigned long long* __restrict__ ukey, int nv2,
+                                                    int64_t* __restrict__ off2, int32_t* __restrict__ nbr2) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i > nu) return;
+  // off2[v] = first edge whose source is >= v; thread i fills (source of edge i - 1, source of edge i]
+  const int64_t prev = (i == 0) ? -1 : (int64_t)(ukey[i - 1] >> 32);
+  int64_t cur = (i == nu) ? (int64_t)nv2 : (int64_t)(ukey[i] >> 32);
+  if (cur > nv2) cur = nv2;
+  for (int64_t v = std::max<int64_t>(prev + 1, 0); v <= cur && v <= nv2; ++v) off2[v] = i;
+  if (i < nu) nbr2[i] = (int32_t)(ukey[i] & 0xFFFFFFFFull);
+}
+__global__ __launch_bounds__(256) void k_abs_f32(int64_t n, const double* __restrict__ v, float* __restrict__ w) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) w[i] = (float)fabs(v[i]);
+}
+__global__ __launch_bounds__(256) void k_fill_i32(int64_t n, int32_t* __restrict__ p, int32_t v, int32_t step) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v + (int32_t)i * step;
+}
+
+struct Graph {
+  int32_t nv = 0;
+  int64_t ne = 0;
+  const int64_t* off = nullptr;
+  const int32_t* nbr = nullptr;
+  const float* w = nullptr;
+  DevBuf<int64_t> off_own;
+  DevBuf<int32_t> nbr_own;
+  DevBuf<float> w_own;
+};
+
+inline int grid1(int64_t n) { return (int)std::max<int64_t>(1, (n + 255) / 256); }
+inline int gridw(int64_t nwaves) { return (int)std::max<int64_t>(1, (nwaves * WAVE + 255) / 256); }
+
+// caps of the matching levels: index clusters up to 16 (levels 0..5), then in units of blocks (2, 4, 4), then doubling
+constexpr int kBlockLevels = 6, kSuperLevels = 3;
+const int kBlockCaps[kBlockLevels] = {2, 4, 8, 16, 16, 16};
+const int kSuperCaps[kSuperLevels] = {2, 4, 4};
+
+std::shared_ptr<BlockOrder> build_block_order(const DevMat& M) {
+  const int32_t n = M.cols;
+  std::shared_ptr<BlockOrder> bo(new BlockOrder());
+  bo->n = n;
+  bo->built_from_nnz = M.nnz;
+  Graph g;
+  g.nv = n;
+  g.ne = M.nnz;
+  g.off = M.outer.p;
+  g.nbr = M.inner.p;
+  g.w_own.alloc((size_t)std::max<int64_t>(1, M.nnz));
+  hipLaunchKernelGGL(k_abs_f32, dim3(grid1(M.nnz)), dim3(256), 0, stream(), M.nnz, M.val.p, g.w_own.p);
+  g.w = g.w_own.p;
+  DevBuf<int32_t> csize((size_t)n), crep((size_t)n);
+  hipLaunchKernelGGL(k_fill_i32, dim3(grid1(n)), dim3(256), 0, stream(), (int64_t)n, csize.p, 1, 0);
+  hipLaunchKernelGGL(k_fill_i32, dim3(grid1(n)), dim3(256), 0, stream(), (int64_t)n, crep.p, 0, 1);
+  std::vector<std::vector<int32_t>> maps;   // maps[l][cluster of state l] = cluster of state l + 1
+  int k16 = -1, k64 = -1;                   // states whose clusters are the blocks / the super-blocks
+  int level = 0;
+  while (true) {
+    int cap;
+    if (level < kBlockLevels) cap = kBlockCaps[level];
+    else if (level < kBlockLevels + kSuperLevels) cap = kSuperCaps[level - kBlockLevels];
+    else cap = 4 << std::min(24, level - kBlockLevels - kSuperLevels + 1);
+    if (level == kBlockLevels) {   // (from here on a cluster's size counts blocks)
+      k16 = level;
+      hipLaunchKernelGGL(k_fill_i32, dim3(grid1(g.nv)), dim3(256), 0, stream(), (int64_t)g.nv, csize.p, 1, 0);
+    }
+    if (level == kBlockLevels + kSuperLevels) k64 = level;
+    if (level >= kBlockLevels + kSuperLevels && (g.nv <= 1 || g.ne == 0 || level > 60)) break;
+    const int nv = g.nv;
+    DevBuf<int32_t> mate((size_t)nv), best((size_t)nv), flag((size_t)nv), newid((size_t)nv);
+    DevBuf<int64_t> excl((size_t)nv + 1);
+    HIP_CHECK(hipMemsetAsync(mate.p, 0xFF, sizeof(int32_t) * (size_t)nv, stream()));
+    if (g.ne > 0) {
+      for (int round = 0; round < 6; ++round) {
+        hipLaunchKernelGGL(k_match_pick, dim3(gridw(nv)), dim3(256), 0, stream(), nv, g.off, g.nbr, g.w, csize.p, crep.p, mate.p, cap, best.p);
+        hipLaunchKernelGGL(k_match_mutual, dim3(grid1(nv)), dim3(256), 0, stream(), nv, best.p, mate.p);
+      }
+    }
+    hipLaunchKernelGGL(k_match_roots, dim3(grid1(nv)), dim3(256), 0, stream(), nv, mate.p, flag.p);
+    scan_i32_async(flag.p, excl.p, (int64_t)nv);
+    int64_t nv2_64 = 0;
+    {
+      ScalarFetch f;
+      f.add(excl.p + nv, 1, &nv2_64);
+      f.run();
+    }
+    const int nv2 = (int)nv2_64;
+    DevBuf<int32_t> csize2((size_t)nv2), crep2((size_t)nv2);
+    csize2.zero();
+    HIP_CHECK(hipMemsetAsync(crep2.p, 0x7F, sizeof(int32_t) * (size_t)nv2, stream()));
+    hipLaunchKernelGGL(k_match_newid, dim3(grid1(nv)), dim3(256), 0, stream(), nv, mate.p, excl.p, newid.p, csize.p, crep.p, csize2.p, crep2.p);
+    maps.emplace_back((size_t)nv);
+    HIP_CHECK(hipMemcpyAsync(maps.back().data(), newid.p, sizeof(int32_t) * (size_t)nv, hipMemcpyDeviceToHost, stream()));
+    // coarse graph
+    Graph g2;
+    g2.nv = nv2;
+    if (g.ne > 0 && nv2 > 1) {
+      DevBuf<unsigned long long> key((size_t)g.ne), key_s((size_t)g.ne), ukey((size_t)g.ne);
+      DevBuf<float> val((size_t)g.ne), val_s((size_t)g.ne), uval((size_t)g.ne);
+      DevBuf<unsigned long long> ucount(1);
+      hipLaunchKernelGGL(k_coarse_keys, dim3(gridw(nv)), dim3(256), 0, stream(), nv, g.off, g.nbr, g.w, newid.p, nv2, key.p, val.p);
+      int bits = 1;
+      while ((1ll << bits) <= (long long)nv2) ++bits;
+      size_t tb = 0;
+      HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, key.p, key_s.p, val.p, val_s.p, (size_t)g.ne, 0, 32 + bits, stream()));
+      {
+        DevBuf<char> tmp(tb);
+        HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, key.p, key_s.p, val.p, val_s.p, (size_t)g.ne, 0, 32 + bits, stream()));
+      }
+      tb = 0;
+      HIP_CHECK(rocprim::reduce_by_key(nullptr, tb, key_s.p, val_s.p, (size_t)g.ne, ukey.p, uval.p, ucount.p, rocprim::plus<float>(),
+                                       rocprim::equal_to<unsigned long long>(), stream()));
+      {
+        DevBuf<char> tmp(tb);
+        HIP_CHECK(rocprim::reduce_by_key(tmp.p, tb, key_s.p, val_s.p, (size_t)g.ne, ukey.p, uval.p, ucount.p, rocprim::plus<float>(),
+                                         rocprim::equal_to<unsigned long long>(), stream()));
+      }
+      unsigned long long nu = 0, lastkey = 0;
+      {
+        ScalarFetch f;
+        f.add(ucount.p, 1, &nu);
+        f.run();
+      }
+      if (nu > 0) {
+        ScalarFetch f;
+        f.add(ukey.p + (nu - 1), 1, &lastkey);
+        f.run();
+        if ((lastkey >> 32) >= (unsigned long long)nv2) nu -= 1;   // (the in-cluster edges)
+      }
+      g2.ne = (int64_t)nu;
+      g2.off_own.alloc((size_t)nv2 + 1);
+      g2.nbr_own.alloc((size_t)std::max<unsigned long long>(1, nu));
+      g2.w_own.alloc((size_t)std::max<unsigned long long>(1, nu));
+      hipLaunchKernelGGL(k_coarse_csr, dim3(grid1((int64_t)nu + 1)), dim3(256), 0, stream(), (int64_t)nu, ukey.p, nv2, g2.off_own.p, g2.nbr_own.p);
+      if (nu) HIP_CHECK(hipMemcpyAsync(g2.w_own.p, uval.p, sizeof(float) * (size_t)nu, hipMemcpyDeviceToDevice, stream()));
+      sync_stream();   // (the temporaries of this level go out of scope; the allocator is stream ordered, the host vectors are not)
+      g2.off = g2.off_own.p;
+      g2.nbr = g2.nbr_own.p;
+      g2.w = g2.w_own.p;
+    } else {
+      sync_stream();
+      g2.ne = 0;
+    }
+    if (dbg()) std::fprintf(stderr, "[block order] level %d cap %d: %d -> %d clusters, %lld -> %lld edges\n", level, cap, nv, nv2, (long long)g.ne, (long long)g2.ne);
+    const bool stalled = nv2 == nv;
+    g = std::move(g2);
+    csize = std::move(csize2);
+    crep = std::move(crep2);
+    ++level;
+    if (stalled && level > kBlockLevels + kSuperLevels) break;
+  }
+  if (k64 < 0) k64 = kBlockLevels + kSuperLevels;
+  // ---- positions on the host: depth-first order of the cluster tree (children in ascending id)
+  const int T = (int)maps.size();   // states 0 .. T
+  std::vector<int32_t> seq;         // clusters of the current state in order
+  {
+    const size_t top = T > 0 ? (size_t)(*std::max_element(maps[T - 1].begin(), maps[T - 1].end())) + 1 : (size_t)n;
+    seq.resize(top);
+    for (size_t i = 0; i < top; ++i) seq[i] = (int32_t)i;
+  }
+  for (int l = T - 1; l >= 0; --l) {
+    const std::vector<int32_t>& mp = maps[(size_t)l];
+    const size_t np = seq.size();
+    std::vector<int64_t> cnt(np + 1, 0);
+    for (int32_t p : mp) cnt[(size_t)p + 1] += 1;
+    for (size_t i = 0; i < np; ++i) cnt[i + 1] += cnt[i];
+    std::vector<int32_t> child(mp.size());
+    {
+      std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+      for (size_t c = 0; c < mp.size(); ++c) child[(size_t)fill[(size_t)mp[c]]++] = (int32_t)c;   // ascending c inside a parent
+    }
+    std::vector<int32_t> next;
+    next.reserve(mp.size());
+    for (int32_t p : seq)
+      for (int64_t e = cnt[(size_t)p]; e < cnt[(size_t)p + 1]; ++e) next.push_back(child[(size_t)e]);
+    seq.swap(next);
+  }
+  // ancestors at the block and super-block states
+  std::vector<int32_t> a16((size_t)n), a64((size_t)n);
+  for (int32_t v = 0; v < n; ++v) {
+    int32_t c = v;
+    for (int l = 0; l < std::min(k16, T); ++l) c = maps[(size_t)l][(size_t)c];
+    a16[(size_t)v] = c;
+    for (int l = std::min(k16, T); l < std::min(k64, T); ++l) c = maps[(size_t)l][(size_t)c];
+    a64[(size_t)v] = c;
+  }
+  std::vector<int32_t> pos((size_t)n);
+  int32_t S = -1, bslot = 0, vslot = 0, cur16 = -1, cur64 = -1;
+  for (int32_t i = 0; i < n; ++i) {
+    const int32_t v = seq[(size_t)i];
+    if (a64[(size_t)v] != cur64) { S += 1; bslot = 0; vslot = 0; cur64 = a64[(size_t)v]; cur16 = a16[(size_t)v]; }
+    else if (a16[(size_t)v] != cur16) { bslot += 1; vslot = 0; cur16 = a16[(size_t)v]; }
+    if (bslot > 3 || vslot > 15) NTP_FATAL("internal: block order: a cluster exceeds its capacity");
+    pos[(size_t)v] = 64 * S + 16 * bslot + vslot;
+    vslot += 1;
+  }
+  bo->ns = S + 1;
+  std::vector<int32_t> lab((size_t)64 * (size_t)bo->ns, -1);
+  for (int32_t v = 0; v < n; ++v) lab[(size_t)pos[(size_t)v]] = v;
+  bo->pos.alloc((size_t)n);
+  bo->lab.alloc(lab.size());
+  bo->pos.upload(pos.data(), (size_t)n);
+  bo->lab.upload(lab.data(), lab.size());
+  sync_stream();
+  static unsigned long long serial = 0;
+  bo->serial = ++serial;
+  if (dbg()) std::fprintf(stderr, "[block order] n %d: %d super-blocks (%d positions, %.1f %% padding), %d levels\n", n, bo->ns, 64 * bo->ns,
+                          100.0 * (64.0 * bo->ns - n) / std::max(1.0, 64.0 * bo->ns), T);
+  return bo;
+}
+
+// =====================================================================================================================
+// 2. compressed columns <-> block form
+// =====================================================================================================================
+// A workgroup per super-column J (the <= 64 columns whose positions are 64 J .. 64 J + 63).  Pass 1 ORs, per super-row I,
+// the 16-bit tile mask of the super-tile (I, J) in LDS (two masks to a word) and counts super-tiles and tiles; pass 2
+// (after the scans) rebuilds the masks, lists the super-tiles in ascending I, zero-fills the column's tiles and
+// scatters the values.  Stored zeros are not entries of the block form (a zero factor contributes exact zeros).
+__device__ inline void bs_mark_column_masks(const Csc& M, const int32_t* __restrict__ pos, const int32_t* __restrict__ lab, int J,
+                                            unsigned* __restrict__ m2) {
+  const int wave = threadIdx.x / WAVE, lane = lane_id(), nw = blockDim.x / WAVE;
+  for (int c = wave; c < 64; c += nw) {
+    const int j = lab[64 * J + c];
+    if (j < 0) continue;
+    const double* __restrict__ v = static_cast<const double*>(M.val);
+    for (int64_t e = M.outer[j] + lane; e < M.outer[j + 1]; e += WAVE) {
+      if (v[e] == 0.0) continue;
+      const int pr = pos[M.inner[e]];
+      const int I = pr >> 6, bit = 4 * (c >> 4) + ((pr >> 4) & 3);
+      atomicOr(&m2[I >> 1], 1u << (bit + 16 * (I & 1)));
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_bs_count(Csc M, const int32_t* __restrict__ pos, const int32_t* __restrict__ lab, int ns,
+                                                  int32_t* __restrict__ cnt_st, int32_t* __restrict__ cnt_tile) {
+  extern __shared__ unsigned m2[];
+  __shared__ int red[2];
+  const int J = blockIdx.x;
+  for (int i = threadIdx.x; i < (ns + 1) / 2; i += blockDim.x) m2[i] = 0;
+  if (threadIdx.x < 2) red[threadIdx.x] = 0;
+  __syncthreads();
+  bs_mark_column_masks(M, pos, lab, J, m2);
+  __syncthreads();
+  int st = 0, tl = 0;
+  for (int i = threadIdx.x; i < (ns + 1) / 2; i += blockDim.x) {
+    const unsigned w = m2[i];
+    st += ((w & 0xFFFFu) != 0) + ((w >> 16) != 0);
+    tl += __popc(w);
+  }
+  st = (int)wave_sum_i64(st);
+  tl = (int)wave_sum_i64(tl);
+  if (lane_id() == 0) { atomicAdd(&red[0], st); atomicAdd(&red[1], tl); }
+  __syncthreads();
+  if (threadIdx.x == 0) { cnt_st[J] = red[0]; cnt_tile[J] = red[1]; }
+}
+__global__ __launch_bounds__(256) void k_bs_fill(Csc M, const int32_t* __restrict__ pos, const int32_t* __restrict__ lab, int ns,
+                                                 const int64_t* __restrict__ soff, const int64_t* __restrict__ tbase,
+                                                 int32_t* __restrict__ srow, int32_t* __restrict__ smask, int64_t* __restrict__ sbase,
+                                                 double* __restrict__ tiles) {
+  extern __shared__ unsigned m2[];          // (ns + 1) / 2 words of masks
+  __shared__ int wsum_st[8], wsum_tl[8];
+  const int J = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid / WAVE, nw = blockDim.x / WAVE;
+  const int nwords = (ns + 1) / 2;
+  for (int i = tid; i < nwords; i += blockDim.x) m2[i] = 0;
+  __syncthreads();
+  bs_mark_column_masks(M, pos, lab, J, m2);
+  __syncthreads();
+  // ordered enumeration: thread t owns the words [t * per, (t + 1) * per)
+  const int per = (nwords + blockDim.x - 1) / blockDim.x;
+  const int w0 = min(nwords, tid * per), w1 = min(nwords, w0 + per);
+  int st = 0, tl = 0;
+  for (int i = w0; i < w1; ++i) {
+    const unsigned w = m2[i];
+    st += ((w & 0xFFFFu) != 0) + ((w >> 16) != 0);
+    tl += __popc(w);
+  }
+  // exclusive scan over the workgroup (wave scan + wave totals)
+  int xs = st, xt = tl;
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const int a = __shfl_up(xs, o, WAVE), b = __shfl_up(xt, o, WAVE);
+    if (lane >= o) { xs += a; xt += b; }
+  }
+  if (lane == WAVE - 1) { wsum_st[wave] = xs; wsum_tl[wave] = xt; }
+  __syncthreads();
+  int bs = 0, bt = 0;
+  for (int k = 0; k < wave; ++k) { bs += wsum_st[k]; bt += wsum_tl[k]; }
+  int ks = bs + xs - st, kt = bt + xt - tl;   // exclusive
+  const int64_t s0 = soff[J], t0 = tbase[J];
+  for (int i = w0; i < w1; ++i) {
+    const unsigned w = m2[i];
+    for (int h = 0; h < 2; ++h) {
+      const unsigned mk = (w >> (16 * h)) & 0xFFFFu;
+      const int I = 2 * i + h;
+      if (mk && I < ns) {
+        srow[s0 + ks] = I;
+        smask[s0 + ks] = (int32_t)mk;
+        sbase[s0 + ks] = t0 + kt;
+        ks += 1;
+        kt += __popc(mk);
+      }
+    }
+  }
+  (void)nw;
+  // zero-fill the tiles of this super-column
+  const int64_t t1 = tbase[J + 1];
+  v2d* __restrict__ z = reinterpret_cast<v2d*>(tiles + t0 * 256);
+  const int64_t nz2 = (t1 - t0) * 128;
+  const v2d zero = {0.0, 0.0};
+  for (int64_t i = tid; i < nz2; i += blockDim.x) z[i] = zero;
+  __threadfence();
+  __syncthreads();
+  // scatter
+  const int64_t s1 = soff[J + 1];
+  for (int c = wave; c < 64; c += nw) {
+    const int j = lab[64 * J + c];
+    if (j < 0) continue;
+    const double* __restrict__ v = static_cast<const double*>(M.val);
+    for (int64_t e = M.outer[j] + lane; e < M.outer[j + 1]; e += WAVE) {
+      const double x = v[e];
+      if (x == 0.0) continue;
+      const int pr = pos[M.inner[e]];
+      const int I = pr >> 6, bit = 4 * (c >> 4) + ((pr >> 4) & 3);
+      int64_t lo = s0, hi = s1;   // (srow of this super-column was written above by this workgroup)
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (srow[mid] < I) lo = mid + 1; else hi = mid;
+      }
+      const unsigned mk = (unsigned)smask[lo];
+      const int64_t slot = sbase[lo] + __popc(mk & ((1u << bit) - 1u));
+      tiles[slot * 256 + phys(c & 15) * 16 + phys(pr & 15)] = x;
+    }
+  }
+}
+// super-tiles by super-row: keys (I << 32 | J) of every super-tile, sorted -> roff / rcol / ridx
+__global__ __launch_bounds__(256) void k_bs_row_keys(int ns, const int64_t* __restrict__ soff, const int32_t* __restrict__ srow,
+                                                     unsigned long long* __restrict__ key, int32_t* __restrict__ idx) {
+  const int J = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
+  if (J >= ns) return;
+  for (int64_t t = soff[J] + lane_id(); t < soff[J + 1]; t += WAVE) {
+    key[t] = ((unsigned long long)(unsigned)srow[t] << 32) | (unsigned)J;
+    idx[t] = (int32_t)t;
+  }
+}
+__global__ __launch_bounds__(256) void k_bs_row_csr(int64_t nst, const unsigned long long* __restrict__ key, int ns,
+                                                    int64_t* __restrict__ roff, int32_t* __restrict__ rcol) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i > nst) return;
+  const int64_t prev = (i == 0) ? -1 : (int64_t)(key[i - 1] >> 32);
+  const int64_t cur = (i == nst) ? (int64_t)ns : (int64_t)(key[i] >> 32);
+  for (int64_t v = prev + 1; v <= cur; ++v) roff[v] = i;
+  if (i < nst) rcol[i] = (int32_t)(key[i] & 0xFFFFFFFFull);
+}
+
+size_t bs_count_lds(int ns) { return (size_t)((ns + 1) / 2) * 4; }
+size_t bs_fill_lds(int ns) { return (size_t)((ns + 1) / 2) * 4; }
+constexpr int kMaxSuperBlocks = 60000;   // (LDS of the conversion kernels: 2 bytes per super-row -- dimensions up to 3.8 M)
+
+// compressed columns -> block form; false (nothing built) when the tiles would be emptier than min_fill
+bool to_block(const DevMat& M, const std::shared_ptr<BlockOrder>& bo, BlockForm& F, double min_fill, double* fill_out) {
+  const int ns = bo->ns;
+  DevBuf<int32_t> cnt_st((size_t)ns), cnt_tile((size_t)ns);
+  F.soff.alloc((size_t)ns + 1);
+  DevBuf<int64_t> tbase((size_t)ns + 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_count), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_fill), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done = true;
+  }
+  const Csc Mv = view(M);
+  hipLaunchKernelGGL(k_bs_count, dim3(ns), dim3(256), bs_count_lds(ns), stream(), Mv, bo->pos.p, bo->lab.p, ns, cnt_st.p, cnt_tile.p);
+  scan_i32_async(cnt_st.p, F.soff.p, (int64_t)ns);
+  scan_i32_async(cnt_tile.p, tbase.p, (int64_t)ns);
+  int64_t nst = 0, nt = 0;
+  {
+    ScalarFetch f;
+    f.add(F.soff.p + ns, 1, &nst);
+    f.add(tbase.p + ns, 1, &nt);
+    f.run();
+  }
+  const double fill = nt > 0 ? (double)M.nnz / (256.0 * (double)nt) : 0.0;
+  if (fill_out) *fill_out = fill;
+  if (nt == 0 || fill < min_fill) return false;
+  F.order = bo;
+  F.ns = ns;
+  F.nst = nst;
+  F.ntiles = nt;
+  F.nnz = M.nnz;
+  F.srow.alloc((size_t)nst);
+  F.smask.alloc((size_t)nst);
+  F.sbase.alloc((size_t)nst);
+  F.tiles.alloc((size_t)nt * 256);
+  hipLaunchKernelGGL(k_bs_fill, dim3(ns), dim3(256), bs_fill_lds(ns), stream(), Mv, bo->pos.p, bo->lab.p, ns, F.soff.p, tbase.p, F.srow.p,
+                     F.smask.p, F.sbase.p, F.tiles.p);
+  F.have_rows = false;
+  return true;
+}
+
+void build_rows(BlockForm& F) {
+  if (F.have_rows) return;
+  const int64_t nst = F.nst;
+  DevBuf<unsigned long long> key((size_t)nst), key_s((size_t)nst);
+  DevBuf<int32_t> idx((size_t)nst);
+  F.ridx.alloc((size_t)nst);
+  F.rcol.alloc((size_t)nst);
+  F.roff.alloc((size_t)F.ns + 1);
+  hipLaunchKernelGGL(k_bs_row_keys, dim3(gridw(F.ns)), dim3(256), 0, stream(), F.ns, F.soff.p, F.srow.p, key.p, idx.p);
+  size_t tb = 0;
+  HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, key.p, key_s.p, idx.p, F.ridx.p, (size_t)nst, 0, 64, stream()));
+  DevBuf<char> tmp(tb);
+  HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, key.p, key_s.p, idx.p, F.ridx.p, (size_t)nst, 0, 64, stream()));
+  hipLaunchKernelGGL(k_bs_row_csr, dim3(grid1(nst + 1)), dim3(256), 0, stream(), nst, key_s.p, F.ns, F.roff.p, F.rcol.p);
+  F.have_rows = true;
+}
+
+// =====================================================================================================================
+// 3. symbolic phase: candidate output super-tiles
+// =====================================================================================================================
+// super-column J of C can hold the super-rows of A's super-columns K named by B's super-column J: a bitmap of ns bits
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bs_symbolic(int ns, const int64_t* __restrict__ soffA, const int32_t* __restrict__ srowA,
+                                                     const int64_t* __restrict__ soffB, const int32_t* __restrict__ srowB,
+                                                     int32_t* __restrict__ ccount, const int64_t* __restrict__ coff,
+                                                     int32_t* __restrict__ ci, int32_t* __restrict__ cj) {
+  extern __shared__ unsigned bm[];
+  __shared__ int wsum[8];
+  __shared__ int total;
+  const int J = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid / WAVE, nw = blockDim.x / WAVE;
+  const int nwords = (ns + 31) / 32;
+  for (int i = tid; i < nwords; i += blockDim.x) bm[i] = 0;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  for (int64_t t = soffB[J] + wave; t < soffB[J + 1]; t += nw) {
+    const int K = srowB[t];
+    for (int64_t u = soffA[K] + lane; u < soffA[K + 1]; u += WAVE) {
+      const int I = srowA[u];
+      atomicOr(&bm[I >> 5], 1u << (I & 31));
+    }
+  }
+  __syncthreads();
+  const int per = (nwords + blockDim.x - 1) / blockDim.x;
+  const int w0 = min(nwords, tid * per), w1 = min(nwords, w0 + per);
+  int c = 0;
+  for (int i = w0; i < w1; ++i) c += __popc(bm[i]);
+  if (!FILL) {
+    c = (int)wave_sum_i64(c);
+    if (lane == 0) atomicAdd(&total, c);
+    __syncthreads();
+    if (tid == 0) ccount[J] = total;
+    return;
+  }
+  int x = c;
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const int a = __shfl_up(x, o, WAVE);
+    if (lane >= o) x += a;
+  }
+  if (lane == WAVE - 1) wsum[wave] = x;
+  __syncthreads();
+  int base = 0;
+  for (int k = 0; k < wave; ++k) base += wsum[k];
+  int64_t k = coff[J] + base + x - c;
+  for (int i = w0; i < w1; ++i) {
+    unsigned w = bm[i];
+    while (w) {
+      const int b = __ffs(w) - 1;
+      w &= w - 1;
+      ci[k] = 32 * i + b;
+      cj[k] = J;
+      ++k;
+    }
+  }
+}
+
+// =====================================================================================================================
+// 4. numeric phase
+// =====================================================================================================================
+struct BsArgs {
+  // left operand by super-rows, right operand by super-columns
+  const int64_t* roffA; const int32_t* rcolA; const int32_t* ridxA;
+  const int32_t* smaskA; const int64_t* sbaseA; const double* tilesA;
+  const int64_t* soffB; const int32_t* srowB; const int32_t* smaskB; const int64_t* sbaseB; const double* tilesB;
+  // candidates and results
+  int64_t ncand;
+  const int32_t *ci, *cj;
+  int32_t* cmask;        // [ncand] kept tiles of the candidate (0: nothing kept)
+  int64_t* cbase;        // [ncand] first tile slot in the pool
+  int32_t* ccnt;         // [ncand] kept entries
+  double* pool;          // tile pool of the result
+  int64_t pool_tiles;    // its capacity
+  unsigned long long* counters;   // [0] tiles handed out, [1] overflow flag, [2] tile products issued
+  double alpha, threshold;
+  int dense_rule;
+  int nwg;
+};
+
+__device__ inline v4d bs_zero4() { const v4d z = {0.0, 0.0, 0.0, 0.0}; return z; }
+
+// One wave per candidate super-tile (I, J): acc[a][b] = tile (row block a, column block b), 16 x 8 VGPRs.  The super-row
+// of A and the super-column of B are intersected 64 entries of A at a time (a lane per entry, binary search in B's
+// list); the matches are walked in ascending K.  Per K and per block kb of it: the tiles B(kb, b) of the pair that
+// exist are loaded (lane (g, n) reads the words 4 g .. 4 g + 3 of column n: 32 bytes), then every tile A(a, kb) that
+// exists (lane (g, m) reads row phys(m) of the columns 4 g + q, q = 0 .. 3) feeds 4 instructions per existing B tile.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bs_numeric(const BsArgs a) {
+  const int wg = xcd_block(a.nwg);
+  if (wg < 0) return;
+  const int lane = lane_id(), wave = uni_i32(threadIdx.x / WAVE);
+  const int64_t cand = (int64_t)wg * 4 + wave;
+  if (cand >= a.ncand) return;
+  const int I = uni_i32(a.ci[cand]), J = uni_i32(a.cj[cand]);
+  v4d acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = bs_zero4();
+  const int64_t ra0 = uni_i64(a.roffA[I]), ra1 = uni_i64(a.roffA[I + 1]);
+  const int64_t cb0 = uni_i64(a.soffB[J]), cb1 = uni_i64(a.soffB[J + 1]);
+  const int g = lane >> 4, m = lane & 15;
+  const int aoff = phys(m) + 64 * g;        // A role: word (4 g + q) * 16 + phys(m) = aoff + 16 q
+  const int boff = m * 16 + 4 * g;          // B role: words 4 g .. 4 g + 3 of column m
+  unsigned nprod = 0;
+  for (int64_t base = ra0; base < ra1; base += WAVE) {
+    const int64_t e = base + lane;
+    const bool in = e < ra1;
+    const int K = in ? a.rcolA[e] : INT_MAX;
+    const int ia = in ? a.ridxA[e] : 0;
+    int64_t lo = cb0, hi = cb1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (a.srowB[mid] < K) lo = mid + 1; else hi = mid;
+    }
+    const bool found = in && lo < cb1 && a.srowB[lo] == K;
+    const int ib = (int)(lo - cb0);
+    unsigned long long match = __ballot(found);
+    while (match) {
+      const int l = __ffsll((long long)match) - 1;
+      match &= match - 1;
+      const int ia_s = readlane_i32(ia, l);
+      const int64_t ib_s = cb0 + readlane_i32(ib, l);
+      const unsigned mA = (unsigned)uni_i32(a.smaskA[ia_s]), mB = (unsigned)uni_i32(a.smaskB[ib_s]);
+      const double* __restrict__ tA = a.tilesA + uni_i64(a.sbaseA[ia_s]) * 256;
+      const double* __restrict__ tB = a.tilesB + uni_i64(a.sbaseB[ib_s]) * 256;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const unsigned colA = (mA >> (4 * kb)) & 15u;            // row blocks a with a tile A(a, kb)
+        const unsigned rowB = (mB >> kb) & 0x1111u;              // bit 4 b: tile B(kb, b)
+        if (colA == 0 || rowB == 0) continue;
+        v4d bf[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          bf[b] = bs_zero4();
+          if (rowB & (1u << (4 * b))) {
+            const int slot = __popc(mB & ((1u << (4 * b + kb)) - 1u));
+            bf[b] = *reinterpret_cast<const v4d*>(tB + slot * 256 + boff);
+          }
+        }
+        double af[4][4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          if (colA & (1u << x)) {
+            const int slot = __popc(mA & ((1u << (4 * kb + x)) - 1u));
+            const double* __restrict__ p = tA + slot * 256 + aoff;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) af[x][q] = p[16 * q];
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          if (colA & (1u << x)) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              if (rowB & (1u << (4 * b))) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][q], bf[b][q], acc[x][b], 0, 0, 0);
+                nprod += 1;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue: prune (PruneList.f90:22: strict >; the dense branch tests before the scaling), kept tiles to the pool
+  const double alpha = a.alpha, thr = a.threshold;
+  const bool dense = (a.dense_rule & 1) != 0;
+  unsigned mC = 0;
+  int cnt = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = acc[x][b][r];
+        const double sv = __dmul_rn(alpha, v);
+        const bool keep = dense ? (fabs(v) > thr) : (fabs(sv) > thr);
+        acc[x][b][r] = keep ? sv : 0.0;
+        any |= keep;
+        cnt += keep ? 1 : 0;
+      }
+      if (__ballot(any) != 0ull) mC |= 1u << (4 * b + x);
+    }
+  cnt = (int)wave_sum_i64(cnt);
+  const int nt = __popc(mC);
+  int64_t slot0 = 0;
+  bool ok = true;
+  if (nt) {
+    unsigned long long s = 0;
+    if (lane == 0) s = atomicAdd(&a.counters[0], (unsigned long long)nt);
+    slot0 = uni_i64((int64_t)s);
+    if (slot0 + nt > a.pool_tiles) {
+      ok = false;
+      if (lane == 0) atomicOr(&a.counters[1], 1ull);
+    }
+  }
+  if (nt && ok) {
+    int rank = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        if (mC & (1u << (4 * b + x))) {
+          // lane (g, n) holds rows m' = g + 4 r of column n = in-tile rows phys(m') = 4 g + r: 32 contiguous bytes
+          *reinterpret_cast<v4d*>(a.pool + (slot0 + rank) * 256 + m * 16 + 4 * g) = acc[x][b];
+          rank += 1;
+        }
+      }
+  }
+  if (lane == 0) {
+    a.cmask[cand] = ok ? (int32_t)mC : 0;
+    a.cbase[cand] = slot0;
+    a.ccnt[cand] = ok ? cnt : 0;
+    if (nprod) atomicAdd(&a.counters[2], (unsigned long long)nprod);
+  }
+}
+
+// candidates that kept something -> the super-tiles of C (the candidates are ordered by super-column, then super-row)
+__global__ __launch_bounds__(256) void k_bs_flag(int64_t ncand, const int32_t* __restrict__ cmask, int32_t* __restrict__ flag) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < ncand) flag[i] = cmask[i] != 0 ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_bs_compact(int64_t ncand, const int32_t* __restrict__ cmask, const int64_t* __restrict__ cbase,
+                                                    const int32_t* __restrict__ ci, const int64_t* __restrict__ excl,
+                                                    int32_t* __restrict__ srow, int32_t* __restrict__ smask, int64_t* __restrict__ sbase) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= ncand || cmask[i] == 0) return;
+  const int64_t k = excl[i];
+  srow[k] = ci[i];
+  smask[k] = cmask[i];
+  sbase[k] = cbase[i];
+}
+__global__ __launch_bounds__(256) void k_bs_soff(int ns, const int64_t* __restrict__ coff, const int64_t* __restrict__ excl,
+                                                 int64_t* __restrict__ soff) {
+  const int J = blockIdx.x * blockDim.x + threadIdx.x;
+  if (J <= ns) soff[J] = excl[coff[J]];
+}
+
+// =====================================================================================================================
+// 5. block form -> compressed columns under the caller's labels
+// =====================================================================================================================
+// A wave per column position: lane (a, i) looks at row i of tile (a, cb) of every super-tile of the super-column.
+// FILL = false counts the entries (cnt[label]); FILL = true writes (row label, value) in position order at outer[label]
+// (the rows are sorted by label afterwards).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bs_unblock(int ns, const int64_t* __restrict__ soff, const int32_t* __restrict__ srow,
+                                                    const int32_t* __restrict__ smask, const int64_t* __restrict__ sbase,
+                                                    const double* __restrict__ tiles, const int32_t* __restrict__ lab,
+                                                    int32_t* __restrict__ cnt, const int64_t* __restrict__ outer,
+                                                    int32_t* __restrict__ inner, double* __restrict__ val) {
+  const int pc = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
+  if (pc >= 64 * ns) return;
+  const int j = lab[pc];
+  if (j < 0) return;
+  const int lane = lane_id(), J = pc >> 6, cb = (pc >> 4) & 3, a = lane >> 4, i = lane & 15;
+  const int bit = 4 * cb + a;
+  const int coloff = phys(pc & 15) * 16 + i;       // in-tile row i holds in-block position phys(i)
+  int64_t w = FILL ? outer[j] : 0;
+  int c = 0;
+  for (int64_t t = soff[J]; t < soff[J + 1]; ++t) {
+    const unsigned mk = (unsigned)smask[t];
+    if (((mk >> (4 * cb)) & 15u) == 0) continue;
+    double v = 0.0;
+    if (mk & (1u << bit)) v = tiles[(sbase[t] + __popc(mk & ((1u << bit) - 1u))) * 256 + coloff];
+    const bool nz = v != 0.0;
+    if (FILL) {
+      const unsigned long long bal = __ballot(nz);
+      if (nz) {
+        const int64_t at = w + __popcll(bal & lanemask_lt());
+        inner[at] = lab[64 * srow[t] + 16 * a + phys(i)];
+        val[at] = v;
+      }
+      w += __popcll(bal);
+    } else {
+      c += nz ? 1 : 0;
+    }
+  }
+  if (!FILL) {
+    c = (int)wave_sum_i64(c);
+    if (lane == 0) cnt[j] = c;
+  }
+}
+// statistics: intermediate products of A B = sum over the entries B(k, j) of the length of A(:, k)
+__global__ __launch_bounds__(256) void k_bs_products(Csc A, Csc B, unsigned long long* __restrict__ out) {
+  const int j = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
+  if (j >= B.cols) return;
+  long long s = 0;
+  for (int64_t e = B.outer[j] + lane_id(); e < B.outer[j + 1]; e += WAVE) {
+    const int k = B.inner[e];
+    s += A.outer[k + 1] - A.outer[k];
+  }
+  s = wave_sum_i64(s);
+  if (lane_id() == 0 && s) atomicAdd(out, (unsigned long long)s);
+}
+__global__ __launch_bounds__(256) void k_bs_sum_i32(int64_t n, const int32_t* __restrict__ x, unsigned long long* __restrict__ out) {
+  long long s = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += x[i];
+  s = wave_sum_i64(s);
+  if (lane_id() == 0 && s) atomicAdd(out, (unsigned long long)s);
+}
+
+void from_block(const BlockForm& F, int64_t nnz, DevMat& C) {
+  const BlockOrder& bo = *F.order;
+  const int n = bo.n, ns = F.ns;
+  DevMat R;
+  R.rows = n; R.cols = n; R.cplx = false; R.nnz = nnz; R.zero_free = 1;
+  R.outer.alloc((size_t)n + 1);
+  DevBuf<int32_t> cnt((size_t)n);
+  cnt.zero();
+  hipLaunchKernelGGL((k_bs_unblock<false>), dim3(gridw((int64_t)64 * ns)), dim3(256), 0, stream(), ns, F.soff.p, F.srow.p, F.smask.p, F.sbase.p,
+                     F.tiles.p, bo.lab.p, cnt.p, (const int64_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
+  scan_i32_async(cnt.p, R.outer.p, (int64_t)n);
+  R.inner.alloc((size_t)nnz + kIndexSlack);
+  R.val.alloc((size_t)nnz + kIndexSlack);
+  if (nnz > 0) {
+    DevBuf<int32_t> tin((size_t)nnz);
+    DevBuf<double> tval((size_t)nnz);
+    hipLaunchKernelGGL((k_bs_unblock<true>), dim3(gridw((int64_t)64 * ns)), dim3(256), 0, stream(), ns, F.soff.p, F.srow.p, F.smask.p,
+                       F.sbase.p, F.tiles.p, bo.lab.p, (int32_t*)nullptr, R.outer.p, tin.p, tval.p);
+    int bits = 1;
+    while ((1ll << bits) < (long long)n) ++bits;
+    size_t tb = 0;
+    HIP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, tb, tin.p, R.inner.p, tval.p, R.val.p, (unsigned)nnz, (unsigned)n, R.outer.p,
+                                                  R.outer.p + 1, 0, bits, stream()));
+    DevBuf<char> tmp(tb);
+    HIP_CHECK(rocprim::segmented_radix_sort_pairs(tmp.p, tb, tin.p, R.inner.p, tval.p, R.val.p, (unsigned)nnz, (unsigned)n, R.outer.p,
+                                                  R.outer.p + 1, 0, bits, stream()));
+  }
+  C = std::move(R);
+}
+
+// =====================================================================================================================
+// caches
+// =====================================================================================================================
+struct BlockCache {
+  std::shared_ptr<BlockOrder> order;     // the order of the last dimension multiplied
+  int32_t refused_n = -1;                // a dimension whose matrices have no blocks (remembered with the entry count it was tried on)
+  int64_t refused_nnz = 0;
+  int64_t pool_hint = 0;                 // tiles the last result of this dimension needed
+  int32_t pool_hint_n = -1;
+};
+BlockCache& cache() {
+  static BlockCache* c = new BlockCache();
+  return *c;
+}
+constexpr double kMinFill = 0.08;
+
+}  // namespace
+
+void drop_block_caches() {
+  cache().order.reset();
+  cache().refused_n = -1;
+  cache().pool_hint_n = -1;
+}
+
+bool block_order_for(const DevMat& M, std::vector<int32_t>& pos_host) {
+  if (M.cplx || M.rows != M.cols || M.loose() || M.expanded()) return false;
+  BlockCache& c = cache();
+  if (!c.order || c.order->n != M.cols) c.order = build_block_order(M);
+  pos_host.resize((size_t)M.cols);
+  HIP_CHECK(hipMemcpyAsync(pos_host.data(), c.order->pos.p, sizeof(int32_t) * (size_t)M.cols, hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  return true;
+}
+
+bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, BlockInfo* info,
+                  hipEvent_t ev_begin, hipEvent_t ev_end) {
+  if (info) *info = BlockInfo();
+  if (A.cplx || B.cplx || A.rows != A.cols || B.rows != B.cols || A.cols != B.rows) return false;
+  if (A.loose() || A.expanded() || B.loose() || B.expanded()) return false;
+  const int32_t n = A.cols;
+  if (n < 256 || A.nnz == 0 || B.nnz == 0) return false;
+  BlockCache& bc = cache();
+  const int force = options().block_path;
+  if (force != 2 && bc.refused_n == n && (double)A.nnz <= 1.5 * (double)bc.refused_nnz && (double)A.nnz >= 0.5 * (double)bc.refused_nnz) return false;
+  const double min_fill = force == 2 ? 0.0 : kMinFill;
+  bool fresh = false;
+  if (!bc.order || bc.order->n != n) {
+    bc.order = build_block_order(A);
+    fresh = true;
+  }
+  if (bc.order->ns > kMaxSuperBlocks) return false;
+  BlockForm FA, FB_own;
+  double fa = 0, fb = 0;
+  bool okA = to_block(A, bc.order, FA, min_fill, &fa);
+  if (!okA && !fresh) {   // (an order made from another matrix: once more from this one)
+    bc.order = build_block_order(A);
+    fresh = true;
+    if (bc.order->ns > kMaxSuperBlocks) return false;
+    okA = to_block(A, bc.order, FA, min_fill, &fa);
+  }
+  if (!okA) {
+    bc.refused_n = n;
+    bc.refused_nnz = A.nnz;
+    if (dbg()) std::fprintf(stderr, "[block path] refused: fill %.3f of A (n %d, %lld entries)\n", fa, n, (long long)A.nnz);
+    return false;
+  }
+  const bool same = &A == &B;
+  BlockForm* FB = &FA;
+  if (!same) {
+    if (!to_block(B, bc.order, FB_own, min_fill, &fb)) {
+      if (dbg()) std::fprintf(stderr, "[block path] refused: fill %.3f of B\n", fb);
+      return false;
+    }
+    FB = &FB_own;
+  } else {
+    fb = fa;
+  }
+  build_rows(FA);
+  const int ns = bc.order->ns;
+  // ---- symbolic
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_symbolic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_symbolic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_done = true;
+  }
+  const size_t sym_lds = (size_t)((ns + 31) / 32) * 4;
+  DevBuf<int32_t> ccount((size_t)ns);
+  DevBuf<int64_t> coff((size_t)ns + 1);
+  hipLaunchKernelGGL((k_bs_symbolic<false>), dim3(ns), dim3(256), sym_lds, stream(), ns, FA.soff.p, FA.srow.p, FB->soff.p, FB->srow.p, ccount.p,
+                     (const int64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+  scan_i32_async(ccount.p, coff.p, (int64_t)ns);
+  int64_t ncand = 0;
+  {
+    ScalarFetch f;
+    f.add(coff.p + ns, 1, &ncand);
+    f.run();
+  }
+  if (ncand == 0) {
+    C.reset_empty(n, n, false);
+    if (info) { info->used = 1; info->fill_a = fa; info->fill_b = fb; }
+    return true;
+  }
+  DevBuf<int32_t> ci((size_t)ncand), cj((size_t)ncand), cmask((size_t)ncand), ccnt((size_t)ncand);
+  DevBuf<int64_t> cbase((size_t)ncand);
+  hipLaunchKernelGGL((k_bs_symbolic<true>), dim3(ns), dim3(256), sym_lds, stream(), ns, FA.soff.p, FA.srow.p, FB->soff.p, FB->srow.p,
+                     (int32_t*)nullptr, coff.p, ci.p, cj.p);
+  // ---- numeric (the pool is sized from the last product of this dimension; an overflow is repeated with the exact size)
+  BlockForm FC;
+  FC.order = bc.order;
+  FC.ns = ns;
+  int64_t pool = std::max<int64_t>(1024, std::max(FA.ntiles, FB->ntiles) * 2);
+  if (bc.pool_hint_n == n) pool = std::max(pool, bc.pool_hint + bc.pool_hint / 4);
+  pool = std::min<int64_t>(pool, ncand * 16);
+  DevBuf<unsigned long long> counters(4);
+  unsigned long long hc[4] = {0, 0, 0, 0};
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    FC.tiles.alloc((size_t)pool * 256);
+    counters.zero();
+    BsArgs a;
+    a.roffA = FA.roff.p; a.rcolA = FA.rcol.p; a.ridxA = FA.ridx.p; a.smaskA = FA.smask.p; a.sbaseA = FA.sbase.p; a.tilesA = FA.tiles.p;
+    a.soffB = FB->soff.p; a.srowB = FB->srow.p; a.smaskB = FB->smask.p; a.sbaseB = FB->sbase.p; a.tilesB = FB->tiles.p;
+    a.ncand = ncand; a.ci = ci.p; a.cj = cj.p; a.cmask = cmask.p; a.cbase = cbase.p; a.ccnt = ccnt.p;
+    a.pool = FC.tiles.p; a.pool_tiles = pool; a.counters = counters.p;
+    a.alpha = alpha; a.threshold = threshold; a.dense_rule = dense_rule ? 1 : 0;
+    a.nwg = (int)((ncand + 3) / 4);
+    if (ev_begin) HIP_CHECK(hipEventRecord(ev_begin, stream()));
+    hipLaunchKernelGGL(k_bs_numeric, dim3(xcd_grid(a.nwg)), dim3(256), 0, stream(), a);
+    if (ev_end) HIP_CHECK(hipEventRecord(ev_end, stream()));
+    {
+      ScalarFetch f;
+      f.add(counters.p, 4, hc);
+      f.run();
+    }
+    if (hc[1] == 0) break;
+    if (attempt == 1) NTP_FATAL("internal: block SpGEMM: the tile pool overflowed twice");
+    pool = (int64_t)hc[0];
+  }
+  bc.pool_hint = (int64_t)hc[0];
+  bc.pool_hint_n = n;
+  // ---- the result's super-tiles and entry count
+  DevBuf<int32_t> flag((size_t)ncand);
+  DevBuf<int64_t> excl((size_t)ncand + 1);
+  DevBuf<unsigned long long> tot(2);
+  tot.zero();
+  const bool count_products = info != nullptr && options().time_kernels != 0;
+  if (count_products) hipLaunchKernelGGL(k_bs_products, dim3(gridw(n)), dim3(256), 0, stream(), view(A), view(B), tot.p + 1);
+  hipLaunchKernelGGL(k_bs_flag, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, cmask.p, flag.p);
+  scan_i32_async(flag.p, excl.p, ncand);
+  hipLaunchKernelGGL(k_bs_sum_i32, dim3(std::min(1024, grid1(ncand))), dim3(256), 0, stream(), ncand, ccnt.p, tot.p);
+  int64_t nstC = 0;
+  unsigned long long nnzC = 0, nprod = 0;
+  {
+    unsigned long long t2[2] = {0, 0};
+    ScalarFetch f;
+    f.add(excl.p + ncand, 1, &nstC);
+    f.add(tot.p, 2, t2);
+    f.run();
+    nnzC = t2[0];
+    nprod = t2[1];
+  }
+  FC.nst = nstC;
+  FC.ntiles = (int64_t)hc[0];
+  FC.nnz = (int64_t)nnzC;
+  FC.soff.alloc((size_t)ns + 1);
+  FC.srow.alloc((size_t)std::max<int64_t>(1, nstC));
+  FC.smask.alloc((size_t)std::max<int64_t>(1, nstC));
+  FC.sbase.alloc((size_t)std::max<int64_t>(1, nstC));
+  hipLaunchKernelGGL(k_bs_compact, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, cmask.p, cbase.p, ci.p, excl.p, FC.srow.p, FC.smask.p, FC.sbase.p);
+  hipLaunchKernelGGL(k_bs_soff, dim3(grid1(ns + 1)), dim3(256), 0, stream(), ns, coff.p, excl.p, FC.soff.p);
+  from_block(FC, (int64_t)nnzC, C);
+  if (info) {
+    info->used = 1;
+    info->fill_a = fa; info->fill_b = fb;
+    info->tiles_a = FA.ntiles; info->tiles_b = FB->ntiles; info->tiles_c = FC.ntiles;
+    info->cand = ncand;
+    info->tile_products = (int64_t)hc[2];
+    info->nnz_c = (int64_t)nnzC;
+    info->products = (int64_t)nprod;
+  }
+  if (dbg())
+    std::fprintf(stderr, "[block path] n %d: fill A %.3f B %.3f, tiles %lld x %lld -> %lld (of %lld candidates x 16), %lld tile products, %lld entries\n", n, fa,
+                 fb, (long long)FA.ntiles, (long long)FB->ntiles, (long long)FC.ntiles, (long long)ncand, (long long)hc[2], (long long)nnzC);
+  return true;
+}
+
+}  // namespace ntp

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "engine.hpp"
+#include "spgemm_block.hpp"
 #include "io.hpp"
 
 using namespace ntp;
@@ -195,6 +196,23 @@ void ntpoly_amd_last_grouped_stats(long long* out, double* ratio) {
   out[5] = s.gh_tile_rows;
   *ratio = s.gh_union_ratio;
 }
+// block path of the last SpGEMM (spgemm_block.hip): out[0..2] = used, 16 x 16 x 16 tile products issued, candidate output
+// super-tiles; fill = entries / (256 tiles) of the left operand
+void ntpoly_amd_last_block_stats(long long* out, double* fill) {
+  const SpgemmStats& s = last_spgemm_stats();
+  out[0] = s.block; out[1] = s.block_tile_products; out[2] = s.block_cand;
+  *fill = s.block_fill;
+}
+// tests: the block order the engine multiplies matrices of this dimension in (made from this matrix if there is none):
+// position[index] (0-based; positions ascend along the order of the k steps); returns 1 on success
+int ntpoly_amd_block_order(const int* ih, int* position) {
+  PSMatrix& m = *get<PSMatrix>(ih);
+  std::vector<int32_t> pos;
+  if (!block_order_for(m.loc, pos)) return 0;
+  std::memcpy(position, pos.data(), sizeof(int32_t) * pos.size());
+  return 1;
+}
+void ntpoly_amd_drop_block_caches() { drop_block_caches(); }
 // out[0] = halo exchanges of distributed multiplies so far, out[1] = host synchronisations inside them (counted where the
 // host waits: sync_stream), out[2] = ALL host synchronisations of the process so far: a caller brackets a call with two
 // reads to learn what the whole call cost (exchange, plan, totals)

@@ -912,6 +912,26 @@ def last_grouped_stats():
                 tile_rows=int(out[5]), union_ratio=r.value)
 
 
+def last_block_stats():
+    """block path of the last SpGEMM (csrc/spgemm_block.hip: 16 x 16 tiles of a clustered index order on the FP64 matrix cores)"""
+    out = (C.c_longlong * 3)()
+    r = C.c_double()
+    lib.ntpoly_amd_last_block_stats(out, C.byref(r))
+    return dict(used=int(out[0]), tile_products=int(out[1]), candidates=int(out[2]), fill=r.value)
+
+
+def block_order(M):
+    """position of every index in the block order the engine multiplies matrices of M's dimension in (made from M if none exists)"""
+    pos = np.zeros(M.GetActualDimension(), dtype=np.int32)
+    lib.ntpoly_amd_block_order.restype = C.c_int
+    ok = lib.ntpoly_amd_block_order(M.ih, pos.ctypes.data_as(C.c_void_p))
+    return pos if ok else None
+
+
+def drop_block_caches():
+    lib.ntpoly_amd_drop_block_caches()
+
+
 def exchange_stats():
     """(halo exchanges of distributed multiplies so far, host synchronisations inside them, ALL host synchronisations of
     the process so far) -- the synchronisations are counted where the host waits (sync_stream in csrc/common.cpp)"""

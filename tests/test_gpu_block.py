@@ -1,0 +1,176 @@
+"""GPU: the block path (csrc/spgemm_block.hip) -- real square operands WITHOUT run structure (3-D lattice Hamiltonians,
+relabelled bands) multiplied as 16 x 16 tiles of a clustered index order on the FP64 matrix cores, FMA arithmetic.
+
+Parity statement.  The engine picks a relabelling `pos` of the index set (as the reference's own load balancer does,
+LoadBalancerModule.F90:14-52) and computes every product entry as the chain of fma() over ascending POSITION.  So
+
+  (1) BIT FOR BIT: engine(A, B) == un-relabel( oracle_fma( relabel(A), relabel(B) ) ) -- the oracle (CPU restatement of
+      MultiplyBlock.f90:9-36 + PruneList.f90:8-38, FMA mode pinned to the contracted reference build) run on exactly
+      the relabelled matrices, order of positions = order of its k loop;
+  (2) TOLERANCE against the oracle on the caller's labels (chain over ascending label): every entry within 1e-13
+      relative of the product's scale, the same pattern except entries within roundoff of the threshold
+      (the contract of label-ordered operands).
+"""
+import numpy as np
+import pytest
+
+from gen import banded_triplets, lattice_triplets, permuted_banded_triplets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nt():
+    import ntpoly_amd as nt
+    nt.init_comm()
+    nt.ConstructGlobalProcessGrid(1, 1, 1)
+    return nt
+
+
+@pytest.fixture()
+def fma(nt):
+    from oracle import oracle_py as O
+    nt.set_option("spgemm_fma", 1)
+    nt.set_option("block_path", 1)
+    O.set_fma(True)
+    nt.drop_block_caches()
+    yield O
+    O.set_fma(False)
+    nt.set_option("spgemm_fma", 0)
+    nt.set_option("block_path", 1)
+    nt.set_option("slab_algebra", 1)
+
+
+def srt(t):
+    c, r, v = t
+    o = np.lexsort((r, c))
+    return c[o], r[o], v[o]
+
+
+def relabel(trip, rank):
+    """entries (col, row, val) 1-based moved to (rank[col], rank[row])"""
+    c, r, v = trip
+    return srt(((rank[c - 1] + 1).astype(np.int32), (rank[r - 1] + 1).astype(np.int32), v))
+
+
+def oracle_product_in_engine_order(O, n, ta, tb, pos, alpha, thr):
+    """oracle FMA product of the matrices relabelled by the engine's positions, mapped back to the caller's labels"""
+    order = np.argsort(pos, kind="stable")          # index at every rank
+    rank = np.empty(n, dtype=np.int64)
+    rank[order] = np.arange(n)
+    Ao = O.Mat.from_triplets(n, n, *relabel(ta, rank))
+    Bo = Ao if tb is ta else O.Mat.from_triplets(n, n, *relabel(tb, rank))
+    c, r, v = O.ps_multiply(Ao, Bo, None, alpha, 0.0, thr).triplets()
+    return srt(((order[c - 1] + 1).astype(np.int32), (order[r - 1] + 1).astype(np.int32), v))
+
+
+def exact(got, want, what):
+    g, w = srt(got), srt(want)
+    assert len(g[2]) == len(w[2]), "%s: %d vs %d entries" % (what, len(g[2]), len(w[2]))
+    assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]), what + ": pattern differs"
+    assert np.array_equal(g[2], w[2]), "%s: values differ, max |d| = %g" % (what, np.abs(g[2] - w[2]).max())
+
+
+def close(got, want, n, thr, what, rel=1e-13):
+    import scipy.sparse as sp
+    G = sp.csr_matrix((got[2], (got[1] - 1, got[0] - 1)), shape=(n, n))
+    W = sp.csr_matrix((want[2], (want[1] - 1, want[0] - 1)), shape=(n, n))
+    scale = max(1.0, np.abs(want[2]).max())
+    D = (G - W).tocoo()
+    bad = np.abs(D.data) > rel * scale
+    # entries present on one side only must sit at the threshold
+    assert np.all(np.abs(D.data[bad]) <= thr * (1 + 1e-9) + rel * scale), "%s: max |d| = %g" % (what, np.abs(D.data).max())
+    assert abs(G.nnz - W.nnz) <= max(8, 1e-5 * W.nnz), "%s: %d vs %d entries" % (what, G.nnz, W.nnz)
+
+
+def lattice_case(L, r2=13):
+    return lattice_triplets(L, r2=r2)
+
+
+CASES = [("lattice16", 1e-8, 1.0), ("lattice20", 1e-6, 0.5), ("lattice12", 0.0, -0.75), ("permuted_band", 1e-8, 1.0), ("lattice_ab", 1e-7, 1.0)]
+
+
+@pytest.mark.parametrize("kind,thr,alpha", CASES)
+def test_block_product_vs_oracle(nt, fma, kind, thr, alpha):
+    O = fma
+    if kind.startswith("lattice") and kind != "lattice_ab":
+        L = int(kind[7:])
+        n = L ** 3
+        ta = lattice_case(L)
+        tb = ta
+    elif kind == "lattice_ab":
+        L = 16
+        n = L ** 3
+        ta = lattice_case(L)
+        c, r, v = lattice_triplets(L, r2=6, shift=0.3)
+        tb = (c, r, v * 1.25)
+    else:
+        n = 6000
+        ta = permuted_banded_triplets(n, 40, 7)
+        tb = ta
+    A = nt.Matrix_ps.from_triplets(n, *ta)
+    B = A if tb is ta else nt.Matrix_ps.from_triplets(n, *tb)
+    nt.set_option("slab_algebra", 0)     # (the C ABI's session would try the slab form first; the refusal is tested elsewhere)
+    C = nt.Matrix_ps(n)
+    C.Gemm(A, B, None, alpha, 0.0, thr)
+    bs = nt.last_block_stats()
+    assert bs["used"] == 1, (kind, bs, nt.last_spgemm_stats())
+    assert bs["fill"] >= 0.08
+    got = srt(C.triplets())
+    pos = nt.block_order(A)
+    assert pos is not None and len(np.unique(pos)) == n
+    # (1) bit for bit against the oracle on the relabelled matrices
+    want_rel = oracle_product_in_engine_order(O, n, ta, tb, pos, alpha, thr)
+    exact(got, want_rel, kind + " (engine order)")
+    # (2) tolerance against the oracle on the caller's labels
+    Ao = O.Mat.from_triplets(n, n, *ta)
+    Bo = Ao if tb is ta else O.Mat.from_triplets(n, n, *tb)
+    want = srt(O.ps_multiply(Ao, Bo, None, alpha, 0.0, thr).triplets())
+    close(got, want, n, thr, kind + " (caller's labels)")
+
+
+def test_block_path_is_declined_for_unstructured_operands(nt, fma):
+    """a random sparse matrix has no blocks: the clustering is tried once, the product takes the LDS-hash path and is
+    bit-exact against the oracle on the caller's labels"""
+    O = fma
+    n, per = 4096, 12
+    rng = np.random.default_rng(5)
+    col = np.repeat(np.arange(1, n + 1, dtype=np.int32), per)
+    row = rng.integers(1, n + 1, size=n * per).astype(np.int32)
+    key = np.unique(col.astype(np.int64) * (n + 1) + row)
+    col, row = (key // (n + 1)).astype(np.int32), (key % (n + 1)).astype(np.int32)
+    val = rng.standard_normal(len(col))
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    nt.set_option("slab_algebra", 0)
+    C = nt.Matrix_ps(n)
+    C.Gemm(A, A, None, 1.0, 0.0, 1e-9)
+    assert nt.last_block_stats()["used"] == 0
+    Ao = O.Mat.from_triplets(n, n, col, row, val)
+    exact(C.triplets(), O.ps_multiply(Ao, Ao, None, 1.0, 0.0, 1e-9).triplets(), "random sparse")
+
+
+def test_lattice_trs2_through_the_block_path(nt, fma):
+    """TRS2 on a 16^3 lattice: every product of the loop on the block path; sigma sequence and entry counts as the oracle's
+    FMA mode on the caller's labels, energies 1e-11, density 1e-10 (the chain order differs: tolerance contract)"""
+    O = fma
+    L = 16
+    n = L ** 3
+    col, row, val = lattice_triplets(L)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    I = nt.Matrix_ps(n)
+    I.FillIdentity()
+    p = nt.SolverParameters()
+    p.SetThreshold(1e-8)
+    p.SetConvergeDiff(1e-30)
+    p.SetMaxIterations(10)
+    p.SetMonitorConvergence(False)
+    K = nt.Matrix_ps(n)
+    energy, mu = nt.DensityMatrixSolvers.TRS2(H, I, n / 2.0, K, p)
+    assert nt.last_block_stats()["used"] == 1
+    tr = nt.solver_trace()
+    Ho = O.Mat.from_triplets(n, n, col, row, val)
+    Ko, e_o, mu_o, tro = O.density("trs2", Ho, O.Mat.identity(n), n / 2.0,
+                                   O.params(converge_diff=1e-30, max_iterations=10, threshold=1e-8, monitor_convergence=False))
+    assert list(tr["sigma"]) == list(tro["sigma"])
+    assert abs(energy - e_o) <= 1e-11 * abs(e_o)
+    close(srt(K.triplets()), srt(Ko.triplets()), n, 1e-8, "density", rel=1e-10)
