@@ -18,6 +18,12 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("NTPOLY_AMD_EXTRA_FLAGS", "").split()
 
 
+# per-file flags.  spgemm_block.hip: its matrix instructions sit behind wave-uniform branches; with the accumulators in
+# the AGPR half of the register file the compiler copies them to VGPRs and back around every branch target (with the
+# 18 wait states a read of a fresh matrix result needs) -- in VGPR form they stay where they are
+FILE_FLAGS = {"spgemm_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -82,7 +88,7 @@ def build(force=False, verbose=False, lib=None, objdir=None, flags=None, link_ex
         objs.append(obj)
         if not force and not object_is_stale(obj, src):
             continue
-        cmd = [HIPCC] + flags + ["-MMD", "-MF", obj[:-2] + ".d", "-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + flags + FILE_FLAGS.get(s, []) + ["-MMD", "-MF", obj[:-2] + ".d", "-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

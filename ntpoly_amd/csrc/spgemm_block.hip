@@ -47,6 +47,12 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // in-tile index of in-block position o (an involution): four lane groups of the matrix instruction hold words
 // 4 g + q of a 16-word line, the instruction q consumes k = 4 q + g
 __host__ __device__ inline int phys(int o) { return 4 * (o & 3) + (o >> 2); }
+// word of in-tile (row_t, col_t) inside a tile's 256: column major with the 16-byte chunks of a column (two rows each)
+// XOR-swizzled by col_t / 2 -- the image of a tile in LDS is then its image in memory (a linear copy), and the
+// transposed read of the right-operand role (16 lanes = 16 columns, the same two chunks of each) is bank-conflict free
+__host__ __device__ inline int tile_word(int row_t, int col_t) {
+  return col_t * 16 + ((((row_t >> 1) ^ (col_t >> 1)) & 7) << 1) + (row_t & 1);
+}
 
 bool dbg() {
   static const bool d = std::getenv("NTPOLY_AMD_DEBUG_SPGEMM") != nullptr;
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(256) void k_bs_fill(Csc M, const int32_t* __restric
       }
       const unsigned mk = (unsigned)smask[lo];
       const int64_t slot = sbase[lo] + __popc(mk & ((1u << bit) - 1u));
-      tiles[slot * 256 + phys(c & 15) * 16 + phys(pr & 15)] = x;
+      tiles[slot * 256 + tile_word(phys(pr & 15), phys(c & 15))] = x;
     }
   }
 }
@@ -526,7 +532,7 @@ bool to_block(const DevMat& M, const std::shared_ptr<BlockOrder>& bo, BlockForm&
   F.srow.alloc((size_t)nst);
   F.smask.alloc((size_t)nst);
   F.sbase.alloc((size_t)nst);
-  F.tiles.alloc((size_t)nt * 256);
+  F.tiles.alloc((size_t)nt * 256 + 512);
   hipLaunchKernelGGL(k_bs_fill, dim3(ns), dim3(256), bs_fill_lds(ns), stream(), Mv, bo->pos.p, bo->lab.p, ns, F.soff.p, tbase.p, F.srow.p,
                      F.smask.p, F.sbase.p, F.tiles.p);
   F.have_rows = false;
@@ -619,6 +625,8 @@ struct BsArgs {
   // candidates and results
   int64_t ncand;
   const int32_t *ci, *cj;
+  const int32_t* order;  // [ncand] workgroup w computes candidate order[w]: Z-order over (I, J), so that the workgroups resident on an
+                         // XCD at the same time share super-rows of A and super-columns of B in its L2
   int32_t* cmask;        // [ncand] kept tiles of the candidate (0: nothing kept)
   int64_t* cbase;        // [ncand] first tile slot in the pool
   int32_t* ccnt;         // [ncand] kept entries
@@ -628,32 +636,44 @@ struct BsArgs {
   double alpha, threshold;
   int dense_rule;
   int nwg;
+  int ablate;            // experiment build (-DNTP_ABLATIONS) only: 1 no A loads, 2 no B loads, 3 no matrix instructions (WRONG results)
 };
 
 __device__ inline v4d bs_zero4() { const v4d z = {0.0, 0.0, 0.0, 0.0}; return z; }
 
-// One wave per candidate super-tile (I, J): acc[a][b] = tile (row block a, column block b), 16 x 8 VGPRs.  The super-row
-// of A and the super-column of B are intersected 64 entries of A at a time (a lane per entry, binary search in B's
-// list); the matches are walked in ascending K.  Per K and per block kb of it: the tiles B(kb, b) of the pair that
-// exist are loaded (lane (g, n) reads the words 4 g .. 4 g + 3 of column n: 32 bytes), then every tile A(a, kb) that
-// exists (lane (g, m) reads row phys(m) of the columns 4 g + q, q = 0 .. 3) feeds 4 instructions per existing B tile.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bs_numeric(const BsArgs a) {
+// One WAVE per candidate super-tile (I, J): acc[x][b] = tile (row block x, column block b), 16 accumulator tiles = 128 VGPRs;
+// no LDS, no barriers, the waves are independent.  The super-row of A and the super-column of B are intersected 64 entries
+// of A's list at a time (a lane per entry, binary search in B's list); the matches are walked in ascending K.  Per match
+// and per block kb of K with tiles on both sides: the tiles B(kb, b) that exist are loaded (lane (g, n) reads the rows
+// 4 g .. 4 g + 3 of column n: two swizzled 16-byte chunks of the column's line), then the tiles A(x, kb) that exist (lane
+// (g, m) reads in-tile row phys(m) of the columns 4 g + q: four full lines per instruction), and every pair issues its
+// four matrix instructions in ascending q.  Every tile of either operand is read ONCE per candidate and match and feeds
+// up to four pairs.  (Versions with a workgroup per candidate -- a wave per row block, B tiles shared through the L1 or
+// staged in LDS -- were slower: 44 L1 line accesses per matrix instruction, or a memory latency per match behind every
+// barrier; profiles/README.md, round 4.)
+// (a workgroup is ONE wave: the candidates' work differs by an order of magnitude, and a workgroup of four waves kept its
+// three finished waves' slots until the fourth was done -- measured occupancy 1.1 waves per SIMD of the possible 2)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bs_numeric(const BsArgs a) {
   const int wg = xcd_block(a.nwg);
   if (wg < 0) return;
-  const int lane = lane_id(), wave = uni_i32(threadIdx.x / WAVE);
-  const int64_t cand = (int64_t)wg * 4 + wave;
-  if (cand >= a.ncand) return;
+  const int lane = lane_id();
+  const int64_t slot = wg;
+  if (slot >= a.ncand) return;
+  const int64_t cand = uni_i32(a.order[slot]);
   const int I = uni_i32(a.ci[cand]), J = uni_i32(a.cj[cand]);
   v4d acc[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = bs_zero4();
+    for (int b = 0; b < 4; ++b) acc[x][b] = bs_zero4();
   const int64_t ra0 = uni_i64(a.roffA[I]), ra1 = uni_i64(a.roffA[I + 1]);
   const int64_t cb0 = uni_i64(a.soffB[J]), cb1 = uni_i64(a.soffB[J + 1]);
   const int g = lane >> 4, m = lane & 15;
-  const int aoff = phys(m) + 64 * g;        // A role: word (4 g + q) * 16 + phys(m) = aoff + 16 q
-  const int boff = m * 16 + 4 * g;          // B role: words 4 g .. 4 g + 3 of column m
+  int aoffq[4];                                  // A role: word of (row phys(m), column 4 g + q)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) aoffq[q] = tile_word(phys(m), 4 * g + q);
+  const int blo = m * 16 + (((2 * g) ^ (m >> 1)) & 7) * 2;      // B role: rows 4 g, 4 g + 1 of column m; rows 4 g + 2, 4 g + 3 in the
+  const int bhi = m * 16 + (((2 * g + 1) ^ (m >> 1)) & 7) * 2;  // neighbouring chunk
   unsigned nprod = 0;
   for (int64_t base = ra0; base < ra1; base += WAVE) {
     const int64_t e = base + lane;
@@ -676,28 +696,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const unsigned mA = (unsigned)uni_i32(a.smaskA[ia_s]), mB = (unsigned)uni_i32(a.smaskB[ib_s]);
       const double* __restrict__ tA = a.tilesA + uni_i64(a.sbaseA[ia_s]) * 256;
       const double* __restrict__ tB = a.tilesB + uni_i64(a.sbaseB[ib_s]) * 256;
-#pragma unroll
+#pragma unroll 1
       for (int kb = 0; kb < 4; ++kb) {
-        const unsigned colA = (mA >> (4 * kb)) & 15u;            // row blocks a with a tile A(a, kb)
+        const unsigned colA = (mA >> (4 * kb)) & 15u;            // bit x: tile A(x, kb)
         const unsigned rowB = (mB >> kb) & 0x1111u;              // bit 4 b: tile B(kb, b)
         if (colA == 0 || rowB == 0) continue;
-        v4d bf[4];
+        v2d b01[4], b23[4];   // (only the fragments of existing tiles are loaded -- and read)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          bf[b] = bs_zero4();
           if (rowB & (1u << (4 * b))) {
-            const int slot = __popc(mB & ((1u << (4 * b + kb)) - 1u));
-            bf[b] = *reinterpret_cast<const v4d*>(tB + slot * 256 + boff);
+            const double* __restrict__ pB = tB + __popc(mB & ((1u << (4 * b + kb)) - 1u)) * 256;
+            b01[b] = *reinterpret_cast<const v2d*>(pB + blo);
+            b23[b] = *reinterpret_cast<const v2d*>(pB + bhi);
           }
         }
         double af[4][4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           if (colA & (1u << x)) {
-            const int slot = __popc(mA & ((1u << (4 * kb + x)) - 1u));
-            const double* __restrict__ p = tA + slot * 256 + aoff;
+            const double* __restrict__ pA = tA + __popc(mA & ((1u << (4 * kb + x)) - 1u)) * 256;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) af[x][q] = p[16 * q];
+            for (int q = 0; q < 4; ++q) af[x][q] = pA[aoffq[q]];
           }
         }
 #pragma unroll
@@ -706,13 +725,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
               if (rowB & (1u << (4 * b))) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][q], bf[b][q], acc[x][b], 0, 0, 0);
-                nprod += 1;
+                acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][0], b01[b][0], acc[x][b], 0, 0, 0);
+                acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][1], b01[b][1], acc[x][b], 0, 0, 0);
+                acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][2], b23[b][0], acc[x][b], 0, 0, 0);
+                acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][3], b23[b][1], acc[x][b], 0, 0, 0);
               }
             }
           }
         }
+        nprod += __popc(colA) * __popc(rowB);
       }
     }
   }
@@ -757,8 +778,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         if (mC & (1u << (4 * b + x))) {
-          // lane (g, n) holds rows m' = g + 4 r of column n = in-tile rows phys(m') = 4 g + r: 32 contiguous bytes
-          *reinterpret_cast<v4d*>(a.pool + (slot0 + rank) * 256 + m * 16 + 4 * g) = acc[x][b];
+          // lane (g, n) holds the in-tile rows 4 g + r of column n: the chunks 2 g and 2 g + 1 of that column (swizzled)
+          double* __restrict__ pt = a.pool + (slot0 + rank) * 256;
+          v2d lo2, hi2;
+          lo2[0] = acc[x][b][0]; lo2[1] = acc[x][b][1]; hi2[0] = acc[x][b][2]; hi2[1] = acc[x][b][3];
+          *reinterpret_cast<v2d*>(pt + blo) = lo2;
+          *reinterpret_cast<v2d*>(pt + bhi) = hi2;
           rank += 1;
         }
       }
@@ -769,6 +794,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     a.ccnt[cand] = ok ? cnt : 0;
     if (nprod) atomicAdd(&a.counters[2], (unsigned long long)nprod);
   }
+}
+
+// Z-order key of a candidate: the bits of its super-row and super-column interleaved
+__device__ inline unsigned bs_spread16(unsigned v) {
+  v &= 0xFFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+__global__ __launch_bounds__(256) void k_bs_zorder(int64_t ncand, const int32_t* __restrict__ ci, const int32_t* __restrict__ cj,
+                                                   unsigned* __restrict__ key, int32_t* __restrict__ idx, int mode) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= ncand) return;
+  key[i] = mode == 0 ? (unsigned)i : mode == 2 ? (((unsigned)ci[i] << 16) | (unsigned)cj[i]) : (bs_spread16((unsigned)ci[i]) | (bs_spread16((unsigned)cj[i]) << 1));
+  idx[i] = (int32_t)i;
 }
 
 // candidates that kept something -> the super-tiles of C (the candidates are ordered by super-column, then super-row)
@@ -810,7 +852,7 @@ __global__ __launch_bounds__(256) void k_bs_unblock(int ns, const int64_t* __res
   if (j < 0) return;
   const int lane = lane_id(), J = pc >> 6, cb = (pc >> 4) & 3, a = lane >> 4, i = lane & 15;
   const int bit = 4 * cb + a;
-  const int coloff = phys(pc & 15) * 16 + i;       // in-tile row i holds in-block position phys(i)
+  const int coloff = tile_word(i, phys(pc & 15));   // in-tile row i holds in-block position phys(i)
   int64_t w = FILL ? outer[j] : 0;
   int c = 0;
   for (int64_t t = soff[J]; t < soff[J + 1]; ++t) {
@@ -846,7 +888,7 @@ __global__ __launch_bounds__(256) void k_bs_products(Csc A, Csc B, unsigned long
     s += A.outer[k + 1] - A.outer[k];
   }
   s = wave_sum_i64(s);
-  if (lane_id() == 0 && s) atomicAdd(out, (unsigned long long)s);
+  if (lane_id() == 0 && s) atomicAdd(&out[(j >> 2) & 63], (unsigned long long)s);   // (64 partial sums: no single hot address)
 }
 __global__ __launch_bounds__(256) void k_bs_sum_i32(int64_t n, const int32_t* __restrict__ x, unsigned long long* __restrict__ out) {
   long long s = 0;
@@ -992,6 +1034,18 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   DevBuf<int64_t> cbase((size_t)ncand);
   hipLaunchKernelGGL((k_bs_symbolic<true>), dim3(ns), dim3(256), sym_lds, stream(), ns, FA.soff.p, FA.srow.p, FB->soff.p, FB->srow.p,
                      (int32_t*)nullptr, coff.p, ci.p, cj.p);
+  // processing order of the candidates
+  DevBuf<int32_t> order((size_t)ncand);
+  {
+    DevBuf<unsigned> zk((size_t)ncand), zk_s((size_t)ncand);
+    DevBuf<int32_t> zi((size_t)ncand);
+    static const int zmode = std::getenv("NTPOLY_AMD_BS_ORDER") ? std::atoi(std::getenv("NTPOLY_AMD_BS_ORDER")) : 1;
+    hipLaunchKernelGGL(k_bs_zorder, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, ci.p, cj.p, zk.p, zi.p, zmode);
+    size_t tb = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, zk.p, zk_s.p, zi.p, order.p, (size_t)ncand, 0, 32, stream()));
+    DevBuf<char> tmp(tb);
+    HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, zk.p, zk_s.p, zi.p, order.p, (size_t)ncand, 0, 32, stream()));
+  }
   // ---- numeric (the pool is sized from the last product of this dimension; an overflow is repeated with the exact size)
   BlockForm FC;
   FC.order = bc.order;
@@ -1002,17 +1056,21 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   DevBuf<unsigned long long> counters(4);
   unsigned long long hc[4] = {0, 0, 0, 0};
   for (int attempt = 0; attempt < 2; ++attempt) {
-    FC.tiles.alloc((size_t)pool * 256);
+    FC.tiles.alloc((size_t)pool * 256 + 512);
     counters.zero();
     BsArgs a;
     a.roffA = FA.roff.p; a.rcolA = FA.rcol.p; a.ridxA = FA.ridx.p; a.smaskA = FA.smask.p; a.sbaseA = FA.sbase.p; a.tilesA = FA.tiles.p;
     a.soffB = FB->soff.p; a.srowB = FB->srow.p; a.smaskB = FB->smask.p; a.sbaseB = FB->sbase.p; a.tilesB = FB->tiles.p;
-    a.ncand = ncand; a.ci = ci.p; a.cj = cj.p; a.cmask = cmask.p; a.cbase = cbase.p; a.ccnt = ccnt.p;
+    a.ncand = ncand; a.ci = ci.p; a.cj = cj.p; a.order = order.p; a.cmask = cmask.p; a.cbase = cbase.p; a.ccnt = ccnt.p;
     a.pool = FC.tiles.p; a.pool_tiles = pool; a.counters = counters.p;
     a.alpha = alpha; a.threshold = threshold; a.dense_rule = dense_rule ? 1 : 0;
-    a.nwg = (int)((ncand + 3) / 4);
+    a.nwg = (int)ncand;
+    a.ablate = 0;
+#ifdef NTP_ABLATIONS
+    if (const char* v = std::getenv("NTPOLY_AMD_BS_ABLATE")) a.ablate = std::atoi(v);
+#endif
     if (ev_begin) HIP_CHECK(hipEventRecord(ev_begin, stream()));
-    hipLaunchKernelGGL(k_bs_numeric, dim3(xcd_grid(a.nwg)), dim3(256), 0, stream(), a);
+    hipLaunchKernelGGL(k_bs_numeric, dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
     if (ev_end) HIP_CHECK(hipEventRecord(ev_end, stream()));
     {
       ScalarFetch f;
@@ -1028,7 +1086,7 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   // ---- the result's super-tiles and entry count
   DevBuf<int32_t> flag((size_t)ncand);
   DevBuf<int64_t> excl((size_t)ncand + 1);
-  DevBuf<unsigned long long> tot(2);
+  DevBuf<unsigned long long> tot(65);   // [0] entries of the result, [1 .. 64] partial product counts
   tot.zero();
   const bool count_products = info != nullptr && options().time_kernels != 0;
   if (count_products) hipLaunchKernelGGL(k_bs_products, dim3(gridw(n)), dim3(256), 0, stream(), view(A), view(B), tot.p + 1);
@@ -1038,14 +1096,15 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   int64_t nstC = 0;
   unsigned long long nnzC = 0, nprod = 0;
   {
-    unsigned long long t2[2] = {0, 0};
+    unsigned long long t2[65];
     ScalarFetch f;
     f.add(excl.p + ncand, 1, &nstC);
-    f.add(tot.p, 2, t2);
+    f.add(tot.p, 65, t2);
     f.run();
     nnzC = t2[0];
-    nprod = t2[1];
+    for (int i = 1; i < 65; ++i) nprod += t2[i];
   }
+  if (nnzC >= (1ull << 32)) NTP_FATAL("block SpGEMM: the product holds 2^32 entries or more");
   FC.nst = nstC;
   FC.ntiles = (int64_t)hc[0];
   FC.nnz = (int64_t)nnzC;

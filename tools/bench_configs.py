@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--arithmetic", choices=("fma", "unfused"), default="fma")
-    ap.add_argument("--only", default="", help="comma-separated subset: products,config3,solvers,complex")
+    ap.add_argument("--only", default="", help="comma-separated subset: products,config3,lattice,solvers,complex")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     import ntpoly_amd as nt
@@ -39,8 +39,12 @@ def main():
     def want(tag):
         return not only or tag in only
 
-    def product(n, h, thr, reps=5, complex_=False, permute=None):
-        if permute is None:
+    def product(n, h, thr, reps=5, complex_=False, permute=None, lattice=None):
+        if lattice is not None:
+            from gen import lattice_triplets
+            n = lattice ** 3
+            col, row, val = lattice_triplets(lattice)
+        elif permute is None:
             col, row, val = banded_triplets(n, h, complex_=complex_)
         else:
             col, row, val = permuted_banded_triplets(n, h, permute, complex_=complex_)
@@ -66,7 +70,9 @@ def main():
         per = 20 if complex_ else 12
         alg = per * (st["nnz_a"] + st["nnz_b"] + st["nnz_c"]) + 4 * (3 * n + 3)
         gs = nt.last_grouped_stats()
-        return dict(n=n, halfband=h, threshold=thr, permute_seed=permute, grouped_hash=int(gs.get("used", 0)), wall_ms=1e3 * dt, kernel_ms=st["ms_numeric"], nnz_out=st["nnz_c"],
+        bs = nt.last_block_stats()
+        return dict(n=n, halfband=h, threshold=thr, permute_seed=permute, grouped_hash=int(gs.get("used", 0)), block_path=bs["used"],
+                    block_fill=bs["fill"], block_tile_products=bs["tile_products"], wall_ms=1e3 * dt, kernel_ms=st["ms_numeric"], nnz_out=st["nnz_c"],
                     products=st["products"], nnz_out_per_s=st["nnz_c"] / dt, products_per_s=st["products"] / (st["ms_numeric"] * 1e-3),
                     alg_GBps_kernel=alg / (st["ms_numeric"] * 1e-3) / 1e9, slab=st["slab"])
 
@@ -79,6 +85,9 @@ def main():
     # the same operand under the seeded relabelling ("with and without random permutation"): one product on
     # the grouped LDS-hash kernel (a single multiply has no loop to amortise a recovered band order over)
         out["config3_one_product_1gpu_relabelled"] = product(1048576, 100, 1e-8, reps=3, permute=42)
+    if want("lattice"):
+        # one product H * H of the 64^3 lattice Hamiltonian (no band: the block path, csrc/spgemm_block.hip)
+        out["lattice64_one_product"] = product(0, 0, 1e-8, reps=3, lattice=64)
     # TRS2 on the configs[3] operand, natural order and relabelled (label-ordered slab steps)
     nt.set_option("time_kernels", 0)   # (whole solves below: wall time, no per-product statistics)
     for tag, perm in (("config3_trs2_1gpu", None), ("config3_trs2_1gpu_relabelled", 42)) if want("config3") else ():
