@@ -179,6 +179,7 @@ void DevMat::reset_empty(int32_t r, int32_t c, bool z) {
   nnz = 0;
   cnt.release();
   slab.reset();
+  blk.reset();
   slots = 0;
   zero_free = 0;
   outer.alloc((size_t)c + 1);
@@ -194,6 +195,7 @@ void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
   nnz = nz;
   cnt.release();
   slab.reset();
+  blk.reset();
   slots = 0;
   zero_free = 0;
   outer.alloc((size_t)c + 1);
@@ -202,7 +204,7 @@ void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
 }
 
 DevMat DevMat::clone() const {
-  if (expanded()) return packed_copy(*this);
+  if (expanded() || blocked()) return packed_copy(*this);
   DevMat R;
   if (loose()) {  // the slots as they are
     R.rows = rows; R.cols = cols; R.cplx = cplx; R.nnz = nnz; R.slots = slots; R.zero_free = zero_free;

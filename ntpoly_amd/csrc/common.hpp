@@ -180,6 +180,12 @@ struct DevMat {
   // set: the entries live in *slab (outer / inner / val are empty, nnz is valid); see SlabForm
   std::unique_ptr<SlabForm> slab;
   bool expanded() const { return slab != nullptr; }
+  // set: the entries live in *blk as dense 16 x 16 tiles of a clustered index order (spgemm_block.hpp BlockForm; outer /
+  // inner / val are empty, nnz is valid).  Left behind by the block path's products where the caller can take it: the
+  // C ABI's MatrixMultiply (the next product of a caller's loop multiplies it as it is) and the TRS2 loop (its iterate).
+  // Everything else sees compressed columns: pack() converts, view() refuses.
+  std::shared_ptr<struct BlockForm> blk;
+  bool blocked() const { return blk != nullptr; }
 
   DevMat() = default;
   DevMat(int32_t r, int32_t c, bool z) { reset_empty(r, c, z); }

@@ -119,11 +119,11 @@ struct Csc {
                                  // entries outer[j] .. outer[j] + cnt[j]; nullptr = packed (ends at outer[j + 1])
 };
 inline Csc view(const DevMat& m) {
-  if (m.loose() || m.expanded()) NTP_FATAL("internal: a loose matrix reached a kernel that reads packed columns (pack() it first)");
+  if (m.loose() || m.expanded() || m.blocked()) NTP_FATAL("internal: a loose matrix reached a kernel that reads packed columns (pack() it first)");
   return Csc{m.rows, m.cols, m.outer.p, m.inner.p, m.val.p};
 }
 inline Csc lview(const DevMat& m) {  // for the kernels that end a column at col_end()
-  if (m.expanded()) NTP_FATAL("internal: a matrix in slab form reached a kernel that reads compressed columns (pack() it first)");
+  if (m.expanded() || m.blocked()) NTP_FATAL("internal: a matrix in slab / block form reached a kernel that reads compressed columns (pack() it first)");
   Csc v{m.rows, m.cols, m.outer.p, m.inner.p, m.val.p};
   v.cnt = m.cnt.p;
   return v;

@@ -2762,6 +2762,9 @@ unsigned long long& value_epoch() {
   static unsigned long long e = 0;
   return e;
 }
+}  // namespace
+unsigned long long matrix_value_epoch() { return value_epoch(); }
+namespace {
 // D of a fused purification step (SlabFusion), expanded once: dexp[doff[j] + (r - dmin[j])] = D(r, j), zero in the holes
 struct DotOperand {
   const void* val = nullptr;
@@ -3078,11 +3081,69 @@ static bool spgemm_striped(const DevMat& A, const DevMat& B, DevMat& C, double a
   return true;
 }
 
+namespace {
+// the block path (spgemm_block.hip) with spgemm()'s book-keeping around it
+int g_block_keep = 0;           // > 0: a caller that understands DevMat::blk is waiting for the product (BlockKeepScope)
+int32_t g_block_last_n = -1;    // dimension of the last product the block path computed from compressed columns
+bool block_eligible(const DevMat& A, const DevMat& B, const ColRange* arange) {
+  return !arange && !A.cplx && !B.cplx && options().spgemm_fma == 1 && options().block_path != 0 && options().spgemm_variant < 0 &&
+         options().spgemm_force_bin <= 0 && A.rows == A.cols && B.rows == B.cols && A.cols == B.rows;
+}
+bool try_block_path(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {
+  const bool timing = options().time_kernels != 0;
+  EventTimer t_all(timing), t_num(timing);
+  t_all.start();
+  BlockInfo bi;
+  SpgemmStats st;
+  st.nnz_a = A.nnz;
+  st.nnz_b = B.nnz;
+  const int32_t n = B.cols;
+  const int64_t nnz_a = A.nnz, nnz_b = B.nnz;   // (C may be one of the operands)
+  const int32_t acols = A.cols, bcols = B.cols;
+  if (!spgemm_block(A, B, C, alpha, threshold, dense_rule, &bi, timing ? t_num.a : nullptr, timing ? t_num.b : nullptr, g_block_keep > 0)) {
+    if (timing) {
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+    }
+    if (g_block_last_n == n) g_block_last_n = -1;
+    return false;
+  }
+  g_block_last_n = n;
+  t_all.stop();
+  if (timing) {
+    if (pending_timings().size() >= 4096) flush_spgemm_timers();
+    pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+  }
+  st.block = 1;
+  st.block_fill = bi.fill_a;
+  st.block_tile_products = bi.tile_products;
+  st.block_cand = bi.cand;
+  st.products = bi.products;
+  st.nnz_c = C.nnz;
+  last_spgemm_stats() = st;
+  SpgemmAccum& acc = spgemm_accum();
+  acc.calls += 1;
+  acc.products += st.products;
+  acc.nnz_c += C.nnz;
+  acc.alg_bytes += 12.0 * (double)(nnz_a + nnz_b + C.nnz) + 4.0 * ((double)acols + bcols + n + 3);
+  return true;
+}
+}  // namespace
+bool block_path_last(int32_t n) { return g_block_last_n == n; }
+BlockKeepScope::BlockKeepScope() { g_block_keep += 1; }
+BlockKeepScope::~BlockKeepScope() { g_block_keep -= 1; }
+
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule,
             LooseProduct* loose, const ColRange* arange, SlabFusion* fuse) {
   if (loose) loose->valid = false;
   if (fuse) fuse->done = false;
-  if (A.expanded() || B.expanded()) {   // (the steps on the slab form are slab_step's; everything else wants columns)
+  // operands in block form, or in compressed columns of a dimension whose last product the block path computed: the
+  // block path first (no run statistics, no per-column plan)
+  if ((A.blocked() || B.blocked() || g_block_last_n == B.cols) && !A.loose() && !B.loose() && !A.expanded() && !B.expanded() &&
+      A.nnz > 0 && B.nnz > 0 && block_eligible(A, B, arange) && !strip_ctx().active) {
+    if (try_block_path(A, B, C, alpha, threshold, dense_rule)) return;
+  }
+  if (A.expanded() || B.expanded() || A.blocked() || B.blocked()) {   // (the steps on the slab form are slab_step's; everything else wants columns)
     DevMat Ap = packed_copy(A);
     if (&A == &B) {
       spgemm(Ap, Ap, C, alpha, threshold, dense_rule, loose, arange, fuse);
@@ -3256,29 +3317,15 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   }
   // ---- operands without run structure, FMA arithmetic, real, square, one rank: 16 x 16 blocks of a clustered index order
   // on the FP64 matrix cores (spgemm_block.hip); declined (false) when the clustering finds no blocks worth it
-  if (!use_slab && !grouped_done && !loose_in && !arange && !A.cplx && options().spgemm_fma == 1 && options().block_path != 0 && sv_opt < 0 &&
-      options().spgemm_force_bin <= 0 && m == A.cols && n == m && !strip_ctx().active) {
-    BlockInfo bi;
-    if (spgemm_block(A, B, C, alpha, threshold, dense_rule, &bi, timing ? t_num.a : nullptr, timing ? t_num.b : nullptr)) {
-      t_all.stop();
-      if (timing) {
-        if (pending_timings().size() >= 4096) flush_spgemm_timers();
-        pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
-      }
-      st.block = 1;
-      st.block_fill = bi.fill_a;
-      st.block_tile_products = bi.tile_products;
-      st.block_cand = bi.cand;
-      st.products = bi.products;
-      st.nnz_c = C.nnz;
-      last_spgemm_stats() = st;
-      SpgemmAccum& acc = spgemm_accum();
-      acc.calls += 1;
-      acc.products += st.products;
-      acc.nnz_c += C.nnz;
-      acc.alg_bytes += 12.0 * (double)(A.nnz + B.nnz + C.nnz) + 4.0 * ((double)A.cols + B.cols + n + 3);
-      return;
+  if (!use_slab && !grouped_done && !loose_in && block_eligible(A, B, arange) && !strip_ctx().active) {
+    if (timing) {   // (the helper brings its own timers)
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
     }
+    if (try_block_path(A, B, C, alpha, threshold, dense_rule)) return;
+    t_all = EventTimer(timing);
+    t_num = EventTimer(timing);
+    t_all.start();
   }
   // a dimension whose products needed row strips last time (columns with more distinct rows than the grouped kernel's
   // tables hold): straight to the strips, without the attempt on the whole operand
@@ -4522,6 +4569,7 @@ void dot_trace_impl(const DevMat& A, const DevMat& B, double out[2], double* tra
                     const int64_t* d_extra, int n_extra, int64_t* extra_out);
 }
 DevMat packed_copy(const DevMat& M) {
+  if (M.blocked()) return block_unpack(M);   // (spgemm_block.hip)
   if (M.expanded()) {
     const SlabForm& f = *M.slab;
     if (f.origin) return f.origin->clone();
@@ -4582,7 +4630,7 @@ DevMat packed_copy(const DevMat& M) {
 }
 
 void pack(DevMat& M) {
-  if (M.loose() || M.expanded()) M = packed_copy(M);
+  if (M.loose() || M.expanded() || M.blocked()) M = packed_copy(M);
 }
 
 bool square_keep_loose(DevMat& X, double threshold, bool dense_rule, const DevMat& D, double out[2], double* trace_out,
@@ -5700,6 +5748,7 @@ bool sa_operand(const DevMat& M) {
 
 bool slab_enter(DevMat& M) {
   if (M.expanded()) return sa_operand(M);
+  if (M.blocked()) return false;
   if (M.cplx || M.loose() || M.rows != M.cols || M.nnz == 0 || (options().spgemm_fma != 0 && options().spgemm_fma != 1)) return false;
   const int n = M.cols;
   std::unique_ptr<SlabForm> f(new SlabForm());

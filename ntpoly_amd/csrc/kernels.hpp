@@ -138,6 +138,15 @@ struct SlabFusion {
 };
 void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold,
             bool dense_rule, LooseProduct* loose = nullptr, const ColRange* arange = nullptr, SlabFusion* fuse = nullptr);
+// while one is alive, a product that the block path computes (spgemm_block.hip) is left in block form (DevMat::blk): for
+// callers that hand it on to another product or pack() it themselves
+bool block_path_last(int32_t n);   // the last product of dimension n from compressed columns went through the block path
+struct BlockKeepScope {
+  BlockKeepScope();
+  ~BlockKeepScope();
+  BlockKeepScope(const BlockKeepScope&) = delete;
+  BlockKeepScope& operator=(const BlockKeepScope&) = delete;
+};
 // the same step on an iterate already in slab form (DevMat::slab, written by a previous fused step): X is replaced by
 // the result (again in slab form).  false: not taken (X unchanged; pack() it and use spgemm)
 struct SlabReduce {   // panel steps: the sum over the ranks rides on the step's own read-back
@@ -303,6 +312,9 @@ void halo_counts_async(const int64_t* d_req, const int64_t* d_outer_all, int pit
 void halo_bounds_async(const DevMat& A, int32_t c0, const int32_t* d_sa, const int32_t* d_sb, int P, int64_t* d_bound,
                        int64_t* d_cnt_row);
 
+// counts the operations that change the values of a matrix in place (scale, conjugate, ...): together with the serial
+// number of the value buffer's allocation it tells whether a cached derivative of a matrix is still that matrix
+unsigned long long matrix_value_epoch();
 // exclusive scan helper (device), out[n] = total; returns total (synchronises)
 // dense side (dense.hip): entry filter, sparse <-> dense (column major), Hermitian eigendecomposition (parallel
 // two-sided Jacobi), (pivoted) Cholesky on a dense copy

@@ -126,11 +126,17 @@ void slab_refused(std::initializer_list<const PSMatrix*> ms) {
                  g_slab_failed ? ": compressed columns from here on" : "");
   for (const PSMatrix* m : ms) pack(mut(*m));
 }
+// Block form (DevMat::blk: what the block path's products leave behind for the C ABI's MatrixMultiply and the TRS2 loop)
+// is understood by ps_multiply and the TRS2 steps only: every other operation takes compressed columns
+void unblock(std::initializer_list<const PSMatrix*> ms) {
+  for (const PSMatrix* m : ms)
+    if (m->loc.blocked()) pack(mut(*m));
+}
 // an operation outside the session, or after a refusal: no operand may stay in slab form
 void slab_pack_if(std::initializer_list<const PSMatrix*> ms) {
   if (g_slab_depth == 0) return;   // (outside a session nothing is left in slab form by one)
   for (const PSMatrix* m : ms)
-    if (m->loc.expanded() || m->loc.loose()) pack(mut(*m));
+    if (m->loc.expanded() || m->loc.loose() || m->loc.blocked()) pack(mut(*m));
 }
 }  // namespace
 
@@ -166,11 +172,12 @@ void SlabSession::close() {
   opened = false;
 }
 void ps_slab_leave(PSMatrix& m) {
-  if (m.loc.expanded()) pack(m.loc);
+  if (m.loc.expanded() || m.loc.blocked()) pack(m.loc);
 }
 
 void ps_copy(const PSMatrix& a, PSMatrix& b) {
   if (&a == &b) return;
+  unblock({&a});
   if (slab_on() && a.loc.expanded()) {
     DevMat t;
     if (slab_clone(a.loc, t)) {
@@ -474,8 +481,8 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   if (A.cplx != B.cplx) {
     // (a real operand that an earlier call of a slab session left in slab form or loose: to_complex copies the three
     // arrays of compressed columns, so the operands are packed first)
-    if (A.loc.expanded() || A.loc.loose()) pack(mut(A));
-    if (B.loc.expanded() || B.loc.loose()) pack(mut(B));
+    if (A.loc.expanded() || A.loc.loose() || A.loc.blocked()) pack(mut(A));
+    if (B.loc.expanded() || B.loc.loose() || B.loc.blocked()) pack(mut(B));
     PSMatrix Ac, Bc;
     ps_to_complex(A, Ac);
     ps_to_complex(B, Bc);
@@ -484,6 +491,23 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   }
   DevMat AB;
   const int S = A.grid ? A.grid->num_slices : 1;
+  // A one-call session of the C ABI on operands without run structure (or already in block form): the product goes
+  // through the block path and STAYS in block form (DevMat::blk) -- the next product of the caller's loop multiplies it
+  // as it is, every other entry point packs on access.  Solver loops (sessions of their own) take compressed columns.
+  const bool block_first = slab_on() && g_session_api && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 &&
+                           (A.loc.blocked() || B.loc.blocked() || block_path_last(A.dim));
+  if (block_first) {
+    BlockKeepScope keep;
+    const double denom = (double)A.dim * (double)A.dim;
+    const bool dense_rule = denom > 0 && std::min((double)A.loc.nnz / denom, (double)B.loc.nnz / denom) > 0.1;
+    spgemm(A.loc, B.loc, AB, alpha, threshold, dense_rule);
+    g_session_did_work = true;
+    C.grid = A.grid; C.dim = A.dim; C.c0 = B.c0; C.c1 = B.c1;
+    C.cplx = false;
+    C.loc = std::move(AB);
+    return;
+  }
+  unblock({&A, &B});
   if (slab_on() && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 && A.loc.nnz > 0 && B.loc.nnz > 0) {
     // (a slab session: operands are turned into slab form where they are, the product stays in it)
     const double denom = (double)A.dim * (double)A.dim;
@@ -512,7 +536,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   } else {
     slab_pack_if({&A, &B});
   }
-  if ((C.loc.expanded() || C.loc.loose()) && &C != &A && &C != &B) pack(C.loc);   // (beta != 0 reads it below; otherwise it is replaced)
+  if ((C.loc.expanded() || C.loc.loose() || C.loc.blocked()) && &C != &A && &C != &B) pack(C.loc);   // (beta != 0 reads it below; otherwise it is replaced)
   if (S <= 1) {
     AB = multiply_panel(A, B, alpha, threshold);
   } else {
@@ -560,6 +584,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
 // IncrementMatrix_ps (PSMatrixAlgebraModule.F90:414-460)
 void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold) {
   if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
+  unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && &A != &B) {
     ps_axpby(A, B, alpha, 1.0, threshold);
     return;
@@ -582,6 +607,7 @@ void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold
 }
 
 void ps_scale(PSMatrix& A, double c) {
+  unblock({&A});
   if (slab_on() && A.loc.expanded()) {
     if (slab_scale(A.loc, c)) { g_slab_counts[2] += 1; g_session_did_work = true; return; }
     slab_refused({&A});
@@ -593,6 +619,7 @@ void ps_scale(PSMatrix& A, double c) {
 // merge kernels scale B's values as they read them: the same products, the same rules, bit for bit)
 void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold) {
   if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
+  unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B) {
     // (a slab session: the operand still in compressed columns -- an identity, the Hamiltonian -- is turned into slab form)
     if (slab_enter(mut(A)) && slab_enter(B.loc) && slab_axpby(A.loc, B.loc, alpha, beta, threshold)) { g_slab_counts[1] += 1; g_session_did_work = true; return; }
@@ -609,6 +636,7 @@ void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double 
 }
 
 void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) {
+  unblock({&Identity, &B});
   if (slab_on() && B.loc.expanded() && !B.cplx && !Identity.cplx && Identity.dim == B.dim && slab_add_diagonal(B.loc, alpha, B.c0)) {
     g_slab_counts[1] += 1; g_session_did_work = true;
     return;
@@ -617,6 +645,7 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) 
 }
 
 bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double beta, double* norm) {
+  unblock({&A, &B});
   if (!slab_on() || A.cplx || B.cplx || A.dim != B.dim || &A == &B || !(A.loc.expanded() || B.loc.expanded())) return false;
   if (!(slab_enter(mut(A)) && slab_enter(mut(B)) && slab_norm_axpby(A.loc, B.loc, alpha, beta, norm))) return false;
   g_slab_counts[2] += 1; g_session_did_work = true;
@@ -624,12 +653,14 @@ bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double be
 }
 
 bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx) {
+  unblock({&X, &X2});
   if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx) return false;
   if (!slab_trs4_traces(X.loc, X2.loc, X.c0, trace_fx, trace_gx)) return false;
   g_slab_counts[2] += 1; g_session_did_work = true;
   return true;
 }
 bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatrix& P) {
+  unblock({&X, &X2});
   if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx || sigma == 0.0) return false;
   DevMat R;
   if (!slab_trs4_operand(X.loc, X2.loc, sigma, X.c0, R)) return false;
@@ -640,6 +671,7 @@ bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatr
 }
 
 void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double alpha, double beta, double threshold) {
+  unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B && A.dim == B.dim) {
     DevMat R;
     if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_axpby_to(A.loc, B.loc, R, alpha, beta, threshold)) {
@@ -1011,6 +1043,7 @@ void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMat
 
 // dot(A, B) and trace(A) from one pass
 void ps_dot_trace(const PSMatrix& A, const PSMatrix& B, double out[4], bool want_trace) {
+  unblock({&A, &B});
   out[2] = out[3] = 0.0;
   if (A.cplx != B.cplx) {
     ps_dot(A, B, out);
@@ -1022,6 +1055,7 @@ void ps_dot_trace(const PSMatrix& A, const PSMatrix& B, double out[4], bool want
 }
 
 void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {
+  unblock({&A, &B});
   if (A.cplx != B.cplx) {
     PSMatrix Ac, Bc;
     ps_to_complex(A, Ac);
@@ -1039,6 +1073,7 @@ void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {
 // DotMatrix_psr/psc (PSMatrixAlgebraModule.F90:387-410, distributed_algebra_includes/DotMatrix.f90):
 // sum conj(A).B; fused, no Hadamard temporary.
 void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
+  unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx) {
     if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_dot(A.loc, B.loc, out)) { g_slab_counts[2] += 1; g_session_did_work = true; return; }
     slab_refused({&A, &B});
@@ -1057,6 +1092,7 @@ void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
 }
 
 double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includes/MatrixTrace.f90)
+  unblock({&A});
   if (slab_on() && A.loc.expanded() && !A.cplx) {
     double v = 0.0;
     if (slab_trace(A.loc, A.c0, &v)) {
@@ -1073,6 +1109,7 @@ double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includ
 }
 
 double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns are local
+  unblock({&A});
   if (slab_on() && A.loc.expanded()) {
     double v = 0.0;
     if (slab_norm(A.loc, &v)) { g_slab_counts[2] += 1; g_session_did_work = true; return v; }
@@ -1093,6 +1130,7 @@ double ps_sigma(const PSMatrix& A) {  // MatrixSigma (distributed_algebra_includ
 }
 
 void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {  // GershgorinBounds.f90:1-41
+  unblock({&A});
   double mn, mx;
   if (slab_on() && A.loc.expanded()) {
     if (slab_gershgorin(A.loc, A.c0, &mn, &mx)) {
@@ -1113,6 +1151,7 @@ void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {  // Gershg
 }
 
 void ps_transpose(const PSMatrix& A, PSMatrix& AT) {  // TransposeMatrix_ps
+  unblock({&A});
   DevMat R;
   if (world().active()) {
     DevMat full = ps_gather_full(A);

@@ -930,7 +930,17 @@ void from_block(const BlockForm& F, int64_t nnz, DevMat& C) {
 // =====================================================================================================================
 // caches
 // =====================================================================================================================
+struct CachedForm {   // the block form of a matrix in compressed columns, valid while the matrix is what it was
+  const void* val = nullptr;
+  unsigned long long serial = 0, epoch = 0, order_serial = 0;
+  int64_t nnz = -1;
+  int32_t cols = 0;
+  std::shared_ptr<BlockForm> form;
+  unsigned long long used = 0;
+};
 struct BlockCache {
+  CachedForm forms[4];
+  unsigned long long clock = 0;
   std::shared_ptr<BlockOrder> order;     // the order of the last dimension multiplied
   int32_t refused_n = -1;                // a dimension whose matrices have no blocks (remembered with the entry count it was tried on)
   int64_t refused_nnz = 0;
@@ -946,6 +956,7 @@ constexpr double kMinFill = 0.08;
 }  // namespace
 
 void drop_block_caches() {
+  for (CachedForm& f : cache().forms) f = CachedForm();
   cache().order.reset();
   cache().refused_n = -1;
   cache().pool_hint_n = -1;
@@ -961,8 +972,52 @@ bool block_order_for(const DevMat& M, std::vector<int32_t>& pos_host) {
   return true;
 }
 
+DevMat block_unpack(const DevMat& M) {
+  DevMat R;
+  from_block(*M.blk, M.nnz, R);
+  return R;
+}
+
+namespace {
+// the block form of an operand: its own (DevMat::blk, made in the current order), the cached one, or a fresh conversion
+std::shared_ptr<BlockForm> operand_form(const DevMat& M, BlockCache& bc, double min_fill, double* fill, bool* converted) {
+  *converted = false;
+  if (M.blocked()) {
+    if (M.blk->order.get() == bc.order.get()) {
+      *fill = M.blk->ntiles > 0 ? (double)M.nnz / (256.0 * (double)M.blk->ntiles) : 0.0;
+      return M.blk;
+    }
+    // (made in an order that has been replaced since: through compressed columns)
+    DevMat P = block_unpack(M);
+    std::shared_ptr<BlockForm> F(new BlockForm());
+    *converted = true;
+    if (!to_block(P, bc.order, *F, min_fill, fill)) return nullptr;
+    sync_stream();   // (P is released on return)
+    return F;
+  }
+  const unsigned long long ser = dev_alloc_serial(M.val.p), ep = matrix_value_epoch();
+  for (CachedForm& f : bc.forms)
+    if (f.form && f.val == M.val.p && f.serial == ser && ser != 0 && f.epoch == ep && f.nnz == M.nnz && f.cols == M.cols &&
+        f.order_serial == bc.order->serial) {
+      f.used = ++bc.clock;
+      *fill = f.form->ntiles > 0 ? (double)M.nnz / (256.0 * (double)f.form->ntiles) : 0.0;
+      return f.form;
+    }
+  std::shared_ptr<BlockForm> F(new BlockForm());
+  *converted = true;
+  if (!to_block(M, bc.order, *F, min_fill, fill)) return nullptr;
+  CachedForm* slot = &bc.forms[0];
+  for (CachedForm& f : bc.forms)
+    if (!f.form) { slot = &f; break; } else if (f.used < slot->used) slot = &f;
+  slot->val = M.val.p; slot->serial = ser; slot->epoch = ep; slot->order_serial = bc.order->serial; slot->nnz = M.nnz; slot->cols = M.cols;
+  slot->form = F;
+  slot->used = ++bc.clock;
+  return F;
+}
+}  // namespace
+
 bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, BlockInfo* info,
-                  hipEvent_t ev_begin, hipEvent_t ev_end) {
+                  hipEvent_t ev_begin, hipEvent_t ev_end, bool keep_blocked) {
   if (info) *info = BlockInfo();
   if (A.cplx || B.cplx || A.rows != A.cols || B.rows != B.cols || A.cols != B.rows) return false;
   if (A.loose() || A.expanded() || B.loose() || B.expanded()) return false;
@@ -970,40 +1025,44 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   if (n < 256 || A.nnz == 0 || B.nnz == 0) return false;
   BlockCache& bc = cache();
   const int force = options().block_path;
-  if (force != 2 && bc.refused_n == n && (double)A.nnz <= 1.5 * (double)bc.refused_nnz && (double)A.nnz >= 0.5 * (double)bc.refused_nnz) return false;
+  const bool any_blocked = A.blocked() || B.blocked();
+  if (!any_blocked && force != 2 && bc.refused_n == n && (double)A.nnz <= 1.5 * (double)bc.refused_nnz && (double)A.nnz >= 0.5 * (double)bc.refused_nnz) return false;
   const double min_fill = force == 2 ? 0.0 : kMinFill;
   bool fresh = false;
   if (!bc.order || bc.order->n != n) {
+    if (A.blocked()) return false;   // (cannot happen: a blocked operand carries the order of its dimension)
     bc.order = build_block_order(A);
     fresh = true;
   }
   if (bc.order->ns > kMaxSuperBlocks) return false;
-  BlockForm FA, FB_own;
   double fa = 0, fb = 0;
-  bool okA = to_block(A, bc.order, FA, min_fill, &fa);
-  if (!okA && !fresh) {   // (an order made from another matrix: once more from this one)
+  bool conv = false;
+  std::shared_ptr<BlockForm> pFA = operand_form(A, bc, min_fill, &fa, &conv);
+  if (!pFA && !fresh && !A.blocked()) {   // (an order made from another matrix: once more from this one)
     bc.order = build_block_order(A);
     fresh = true;
     if (bc.order->ns > kMaxSuperBlocks) return false;
-    okA = to_block(A, bc.order, FA, min_fill, &fa);
+    pFA = operand_form(A, bc, min_fill, &fa, &conv);
   }
-  if (!okA) {
+  if (!pFA) {
     bc.refused_n = n;
     bc.refused_nnz = A.nnz;
     if (dbg()) std::fprintf(stderr, "[block path] refused: fill %.3f of A (n %d, %lld entries)\n", fa, n, (long long)A.nnz);
     return false;
   }
   const bool same = &A == &B;
-  BlockForm* FB = &FA;
+  std::shared_ptr<BlockForm> pFB = pFA;
   if (!same) {
-    if (!to_block(B, bc.order, FB_own, min_fill, &fb)) {
+    pFB = operand_form(B, bc, min_fill, &fb, &conv);
+    if (!pFB) {
       if (dbg()) std::fprintf(stderr, "[block path] refused: fill %.3f of B\n", fb);
       return false;
     }
-    FB = &FB_own;
   } else {
     fb = fa;
   }
+  BlockForm& FA = *pFA;
+  BlockForm* FB = pFB.get();
   build_rows(FA);
   const int ns = bc.order->ns;
   // ---- symbolic
@@ -1114,11 +1173,18 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   FC.sbase.alloc((size_t)std::max<int64_t>(1, nstC));
   hipLaunchKernelGGL(k_bs_compact, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, cmask.p, cbase.p, ci.p, excl.p, FC.srow.p, FC.smask.p, FC.sbase.p);
   hipLaunchKernelGGL(k_bs_soff, dim3(grid1(ns + 1)), dim3(256), 0, stream(), ns, coff.p, excl.p, FC.soff.p);
-  from_block(FC, (int64_t)nnzC, C);
+  if (keep_blocked) {
+    DevMat R;
+    R.rows = n; R.cols = n; R.cplx = false; R.nnz = (int64_t)nnzC; R.zero_free = 1;
+    R.blk.reset(new BlockForm(std::move(FC)));
+    C = std::move(R);
+  } else {
+    from_block(FC, (int64_t)nnzC, C);
+  }
   if (info) {
     info->used = 1;
     info->fill_a = fa; info->fill_b = fb;
-    info->tiles_a = FA.ntiles; info->tiles_b = FB->ntiles; info->tiles_c = FC.ntiles;
+    info->tiles_a = FA.ntiles; info->tiles_b = FB->ntiles; info->tiles_c = (int64_t)hc[0];
     info->cand = ncand;
     info->tile_products = (int64_t)hc[2];
     info->nnz_c = (int64_t)nnzC;
@@ -1126,7 +1192,7 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   }
   if (dbg())
     std::fprintf(stderr, "[block path] n %d: fill A %.3f B %.3f, tiles %lld x %lld -> %lld (of %lld candidates x 16), %lld tile products, %lld entries\n", n, fa,
-                 fb, (long long)FA.ntiles, (long long)FB->ntiles, (long long)FC.ntiles, (long long)ncand, (long long)hc[2], (long long)nnzC);
+                 fb, (long long)FA.ntiles, (long long)FB->ntiles, (long long)hc[0], (long long)ncand, (long long)hc[2], (long long)nnzC);
   return true;
 }
 

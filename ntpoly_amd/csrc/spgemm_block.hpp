@@ -60,8 +60,11 @@ struct BlockInfo {
 // C = alpha A B pruned (PruneList.f90:8-38) through the block path.  false: not taken (operands complex / not square /
 // the clustering finds no blocks worth the matrix cores); C untouched.  ev_begin / ev_end (optional): recorded around the
 // numeric kernel.
+// Operands: compressed columns (their block form is cached per matrix: value buffer, its allocation serial, the value
+// epoch) or block form (DevMat::blk).  keep_blocked: C is left in block form (C.blk; pack() converts).
 bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, BlockInfo* info,
-                  hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+                  hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, bool keep_blocked = false);
+DevMat block_unpack(const DevMat& M);   // block form -> compressed columns under the caller's labels
 // the block order the engine holds for matrices of M's dimension, made from M if there is none (tests / tools);
 // pos_host[index] = position
 bool block_order_for(const DevMat& M, std::vector<int32_t>& pos_host);

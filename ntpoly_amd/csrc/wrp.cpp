@@ -29,7 +29,7 @@ PSMatrix* get<PSMatrix>(const int* ih) {
   PSMatrix* p;
   std::memcpy(&p, ih, sizeof(p));
   if (!p) NTP_FATAL("null handle passed to the C ABI");
-  if (p->loc.loose() || p->loc.expanded()) pack(p->loc);
+  if (p->loc.loose() || p->loc.expanded() || p->loc.blocked()) pack(p->loc);
   return p;
 }
 PSMatrix* get_unpacked(const int* ih) {

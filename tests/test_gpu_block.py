@@ -174,3 +174,57 @@ def test_lattice_trs2_through_the_block_path(nt, fma):
     assert list(tr["sigma"]) == list(tro["sigma"])
     assert abs(energy - e_o) <= 1e-11 * abs(e_o)
     close(srt(K.triplets()), srt(Ko.triplets()), n, 1e-8, "density", rel=1e-10)
+
+
+def test_products_stay_in_block_form_across_c_abi_calls(nt, fma):
+    """A caller's loop over MatrixMultiply_ps_wrp on a lattice operand: from the second product on the result stays in block
+    form (DevMat::blk) and is multiplied as it is; every other entry point packs on access.  (A A) A through the
+    sessions equals the oracle on the relabelled matrices bit for bit, and Dot / Norm / Increment / Scale / Copy on a
+    block-form matrix give what they give on compressed columns."""
+    import scipy.sparse as sp
+    O = fma
+    L = 16
+    n = L ** 3
+    ta = lattice_triplets(L)
+    A = nt.Matrix_ps.from_triplets(n, *ta)
+    nt.set_option("slab_algebra", 1)
+    thr = 1e-7
+    C1 = nt.Matrix_ps(n)
+    C1.Gemm(A, A, None, 1.0, 0.0, thr)        # (first product of the dimension: compressed columns)
+    assert nt.last_block_stats()["used"] == 1
+    C2 = nt.Matrix_ps(n)
+    C2.Gemm(A, A, None, 1.0, 0.0, thr)        # block form from here on
+    C3 = nt.Matrix_ps(n)
+    C3.Gemm(C2, A, None, 0.5, 0.0, thr)       # a block-form operand
+    assert nt.last_block_stats()["used"] == 1
+    pos = nt.block_order(A)
+    order = np.argsort(pos, kind="stable")
+    rank = np.empty(n, dtype=np.int64)
+    rank[order] = np.arange(n)
+    Ao = O.Mat.from_triplets(n, n, *relabel(ta, rank))
+    P2 = O.ps_multiply(Ao, Ao, None, 1.0, 0.0, thr)
+    P3 = O.ps_multiply(P2, Ao, None, 0.5, 0.0, thr)
+    back = lambda M: srt(((order[M.triplets()[0] - 1] + 1).astype(np.int32), (order[M.triplets()[1] - 1] + 1).astype(np.int32), M.triplets()[2]))
+    exact(C1.triplets(), back(P2), "first product")
+    exact(C3.triplets(), back(P3), "(A A) A, block-form operand")
+    exact(C2.triplets(), back(P2), "second product (packed on access)")
+    # the other vocabulary calls on a block-form matrix
+    C4 = nt.Matrix_ps(n)
+    C4.Gemm(A, A, None, 1.0, 0.0, thr)
+    want = sp.csr_matrix((back(P2)[2], (back(P2)[1] - 1, back(P2)[0] - 1)), shape=(n, n))
+    assert abs(C4.Norm() - abs(want).sum(axis=0).max()) <= 1e-12 * abs(want).sum(axis=0).max()
+    C5 = nt.Matrix_ps(n)
+    C5.Gemm(A, A, None, 1.0, 0.0, thr)
+    d = C5.Dot(A)
+    As = sp.csr_matrix((ta[2], (ta[1] - 1, ta[0] - 1)), shape=(n, n))
+    assert abs(d - want.multiply(As).sum()) <= 1e-10 * max(1.0, abs(want.multiply(As).sum()))
+    C6 = nt.Matrix_ps(n)
+    C6.Gemm(A, A, None, 1.0, 0.0, thr)
+    C6.Scale(2.0)
+    C6.Increment(A, -1.0, 0.0)
+    G = sp.csr_matrix((srt(C6.triplets())[2], (srt(C6.triplets())[1] - 1, srt(C6.triplets())[0] - 1)), shape=(n, n))
+    assert abs(G - (2.0 * want - As)).max() <= 1e-12
+    C7 = nt.Matrix_ps(n)
+    C7.Gemm(A, A, None, 1.0, 0.0, thr)
+    C8 = nt.Matrix_ps(C7)                      # CopyMatrix of a block-form matrix
+    exact(C8.triplets(), back(P2), "copy")
