@@ -3130,6 +3130,46 @@ bool try_block_path(const DevMat& A, const DevMat& B, DevMat& C, double alpha, d
 }
 }  // namespace
 bool block_path_last(int32_t n) { return g_block_last_n == n; }
+// a TRS2 step in block form (spgemm_block.hip block_trs2_step) with spgemm()'s book-keeping
+bool trs2_block_step(DevMat& X, int mode, double threshold, bool dense_rule, const DevMat& D, double out[4]) {
+  if (!X.blocked() && g_block_last_n != X.cols) return false;
+  const bool timing = options().time_kernels != 0;
+  EventTimer t_all(timing), t_num(timing);
+  t_all.start();
+  BlockInfo bi;
+  SpgemmStats st;
+  st.nnz_a = X.nnz;
+  st.nnz_b = X.nnz;
+  const int64_t nnz_x = X.nnz;
+  const int32_t n = X.cols;
+  if (!block_trs2_step(X, mode, threshold, dense_rule, D, out, &bi, timing ? t_num.a : nullptr, timing ? t_num.b : nullptr)) {
+    if (timing) {
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+    }
+    return false;
+  }
+  t_all.stop();
+  if (timing) {
+    if (pending_timings().size() >= 4096) flush_spgemm_timers();
+    pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+  }
+  st.block = 1;
+  st.fused = mode;
+  st.block_fill = bi.fill_a;
+  st.block_tile_products = bi.tile_products;
+  st.block_cand = bi.cand;
+  st.products = bi.products;
+  st.nnz_c = bi.nnz_c;
+  last_spgemm_stats() = st;
+  SpgemmAccum& acc = spgemm_accum();
+  acc.calls += 1;
+  acc.products += st.products;
+  acc.nnz_c += bi.nnz_c;
+  acc.alg_bytes += 12.0 * (double)(2 * nnz_x + bi.nnz_c) + 4.0 * (3.0 * n + 3);
+  fusion_counts()[mode == 1 ? 0 : 1] += 1;
+  return true;
+}
 BlockKeepScope::BlockKeepScope() { g_block_keep += 1; }
 BlockKeepScope::~BlockKeepScope() { g_block_keep -= 1; }
 

@@ -881,8 +881,25 @@ void trs2_iterate_form(PSMatrix& B) {
 }
 }  // namespace
 
+namespace {
+// TRS2 steps of an iterate without run structure: block form from step to step (spgemm_block.hip), one rank, real
+bool trs2_block(PSMatrix& B, int mode, double threshold, const PSMatrix& D, double out[4]) {
+  if (world().active() || B.cplx || D.cplx || (B.grid && B.grid->num_slices > 1) || options().fused_update == 0 || options().loose_iterates == 0) {
+    if (B.loc.blocked()) pack(B.loc);
+    return false;
+  }
+  if (!B.loc.blocked() && (B.loc.expanded() || B.loc.loose() || !block_path_last(B.dim))) return false;
+  const double denom = (double)B.dim * (double)B.dim;
+  const bool dense_rule = denom > 0 && (double)B.loc.nnz / denom > 0.1;
+  if (trs2_block_step(B.loc, mode, threshold, dense_rule, D.loc, out)) return true;
+  if (B.loc.blocked()) pack(B.loc);
+  return false;
+}
+}  // namespace
+
 void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
   out[2] = out[3] = 0.0;
+  if (trs2_block(B, 2, threshold, D, out)) return;
   trs2_iterate_form(B);
   if (B.cplx || D.cplx != B.cplx || (B.grid && B.grid->num_slices > 1)) {   // (process slices: the K-split sums of ps_multiply)
     pack(B.loc);
@@ -990,6 +1007,7 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
 // product stays loose (no compaction pass); otherwise multiply, swap and reduce as before.
 void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
   out[2] = out[3] = 0.0;
+  if (trs2_block(B, 1, threshold, D, out)) return;
   trs2_iterate_form(B);
   const bool keep_loose = !world().active() && options().loose_iterates != 0 && !B.cplx && !D.cplx &&
                           !(B.grid && B.grid->num_slices > 1);

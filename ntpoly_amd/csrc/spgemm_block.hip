@@ -928,6 +928,279 @@ void from_block(const BlockForm& F, int64_t nnz, DevMat& C) {
 }
 
 // =====================================================================================================================
+// 6. the TRS2 update in block form
+// =====================================================================================================================
+// per column position: entries and largest row label
+__global__ __launch_bounds__(256) void k_bs_colstat(int ns, const int64_t* __restrict__ soff, const int32_t* __restrict__ srow,
+                                                    const int32_t* __restrict__ smask, const int64_t* __restrict__ sbase,
+                                                    const double* __restrict__ tiles, const int32_t* __restrict__ lab,
+                                                    int32_t* __restrict__ ccount, int32_t* __restrict__ plast) {
+  const int pc = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
+  if (pc >= 64 * ns) return;
+  const int lane = lane_id(), J = pc >> 6, cb = (pc >> 4) & 3, a = lane >> 4, i = lane & 15;
+  const int bit = 4 * cb + a;
+  const int coloff = tile_word(i, phys(pc & 15));
+  int c = 0, mx = -1;
+  for (int64_t t = soff[J]; t < soff[J + 1]; ++t) {
+    const unsigned mk = (unsigned)smask[t];
+    if ((mk & (1u << bit)) == 0) continue;
+    const double v = tiles[(sbase[t] + __popc(mk & ((1u << bit) - 1u))) * 256 + coloff];
+    if (v != 0.0) {
+      c += 1;
+      mx = max(mx, lab[64 * srow[t] + 16 * a + phys(i)]);
+    }
+  }
+  c = (int)wave_sum_i64(c);
+  mx = wave_max_i32(mx);
+  if (lane == 0) { ccount[pc] = c; plast[pc] = mx; }
+}
+// statistics: intermediate products of A B with both operands in block form = sum over the entries B(k, j) of the
+// entries of column k of A (ccountA by position)
+__global__ __launch_bounds__(256) void k_bs_products_blk(int ns, const int64_t* __restrict__ soff, const int32_t* __restrict__ srow,
+                                                         const int32_t* __restrict__ smask, const int64_t* __restrict__ sbase,
+                                                         const double* __restrict__ tiles, const int32_t* __restrict__ ccountA,
+                                                         unsigned long long* __restrict__ out) {
+  const int pc = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
+  if (pc >= 64 * ns) return;
+  const int lane = lane_id(), J = pc >> 6, cb = (pc >> 4) & 3, a = lane >> 4, i = lane & 15;
+  const int bit = 4 * cb + a;
+  const int coloff = tile_word(i, phys(pc & 15));
+  long long s = 0;
+  for (int64_t t = soff[J]; t < soff[J + 1]; ++t) {
+    const unsigned mk = (unsigned)smask[t];
+    if ((mk & (1u << bit)) == 0) continue;
+    const double v = tiles[(sbase[t] + __popc(mk & ((1u << bit) - 1u))) * 256 + coloff];
+    if (v != 0.0) s += ccountA[64 * srow[t] + 16 * a + phys(i)];
+  }
+  s = wave_sum_i64(s);
+  if (lane == 0 && s) atomicAdd(&out[(pc >> 2) & 63], (unsigned long long)s);
+}
+void block_colstat(BlockForm& F) {
+  if (F.have_stat) return;
+  const int ns = F.ns;
+  F.ccount.alloc((size_t)64 * ns);
+  F.plast.alloc((size_t)64 * ns);
+  hipLaunchKernelGGL(k_bs_colstat, dim3(gridw((int64_t)64 * ns)), dim3(256), 0, stream(), ns, F.soff.p, F.srow.p, F.smask.p, F.sbase.p, F.tiles.p,
+                     F.order->lab.p, F.ccount.p, F.plast.p);
+  F.have_stat = true;
+}
+
+// union of the super-tiles of two matrices, super-column by super-column (a bitmap per column, as the symbolic phase)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bs_union(int ns, const int64_t* __restrict__ soffA, const int32_t* __restrict__ srowA,
+                                                  const int64_t* __restrict__ soffB, const int32_t* __restrict__ srowB,
+                                                  int32_t* __restrict__ ccount, const int64_t* __restrict__ coff,
+                                                  int32_t* __restrict__ ci, int32_t* __restrict__ cj) {
+  extern __shared__ unsigned bm[];
+  __shared__ int wsum[8];
+  __shared__ int total;
+  const int J = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid / WAVE;
+  const int nwords = (ns + 31) / 32;
+  for (int i = tid; i < nwords; i += blockDim.x) bm[i] = 0;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  for (int64_t t = soffA[J] + tid; t < soffA[J + 1]; t += blockDim.x) { const int I = srowA[t]; atomicOr(&bm[I >> 5], 1u << (I & 31)); }
+  for (int64_t t = soffB[J] + tid; t < soffB[J + 1]; t += blockDim.x) { const int I = srowB[t]; atomicOr(&bm[I >> 5], 1u << (I & 31)); }
+  __syncthreads();
+  const int per = (nwords + blockDim.x - 1) / blockDim.x;
+  const int w0 = min(nwords, tid * per), w1 = min(nwords, w0 + per);
+  int c = 0;
+  for (int i = w0; i < w1; ++i) c += __popc(bm[i]);
+  if (!FILL) {
+    c = (int)wave_sum_i64(c);
+    if (lane == 0) atomicAdd(&total, c);
+    __syncthreads();
+    if (tid == 0) ccount[J] = total;
+    return;
+  }
+  int x = c;
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const int a = __shfl_up(x, o, WAVE);
+    if (lane >= o) x += a;
+  }
+  if (lane == WAVE - 1) wsum[wave] = x;
+  __syncthreads();
+  int base = 0;
+  for (int k = 0; k < wave; ++k) base += wsum[k];
+  int64_t k = coff[J] + base + x - c;
+  for (int i = w0; i < w1; ++i) {
+    unsigned w = bm[i];
+    while (w) {
+      const int b = __ffs(w) - 1;
+      w &= w - 1;
+      ci[k] = 32 * i + b;
+      cj[k] = J;
+      ++k;
+    }
+  }
+}
+
+struct BsMergeArgs {
+  // P = the product (role A of the merge, scaled by am), X = the iterate (role B, scaled by bm), D = the dot operand
+  const int64_t* soffP; const int32_t* srowP; const int32_t* smaskP; const int64_t* sbaseP; const double* tilesP; const int32_t* plastP;
+  const int64_t* soffX; const int32_t* srowX; const int32_t* smaskX; const int64_t* sbaseX; const double* tilesX; const int32_t* plastX;
+  const int64_t* soffD; const int32_t* srowD; const int32_t* smaskD; const int64_t* sbaseD; const double* tilesD;
+  const int32_t* lab;
+  int64_t ncand;
+  const int32_t *ci, *cj;
+  int32_t* cmask; int64_t* cbase; int32_t* ccnt;
+  double* pdot;          // [2 ncand]: (dot, trace) of the candidate
+  double* pool; int64_t pool_tiles;
+  unsigned long long* counters;   // [0] tiles handed out, [1] overflow / kept-zero flags
+  int32_t* ccount_out; int32_t* plast_out;   // per column position of the result (atomics)
+  double am, bm, thr;
+};
+__device__ inline int64_t bs_find(const int32_t* __restrict__ srow, int64_t lo, int64_t hi, int I) {
+  const int64_t end = hi;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (srow[mid] < I) lo = mid + 1; else hi = mid;
+  }
+  return (lo < end && srow[lo] == I) ? lo : -1;
+}
+// One wave per super-tile of the union (MODE 2) or of the product (MODE 1).  Lane l owns the words 4 l .. 4 l + 3 of every
+// tile (32 contiguous bytes).  MODE 2: result = am P + bm X element by element with the AddSparseVectors rules
+// (sparse_includes/AddSparseVectors.f90:21-70; inc_decide of kernels.hip): both present -> kept if |sum| > threshold; one
+// present -> kept if |value| > threshold, or unfiltered when its row LABEL lies beyond the other column's last label;
+// kept tiles go to the pool, the (dot with D, trace, entries) of the super-tile to the candidate's slots, entries and last
+// label per column to the result's column statistics.  MODE 1: the result is P itself: dot, trace only.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_bs_merge(const BsMergeArgs a) {
+  const int64_t cand = blockIdx.x;
+  if (cand >= a.ncand) return;
+  const int lane = lane_id();
+  const int I = uni_i32(a.ci[cand]), J = uni_i32(a.cj[cand]);
+  const int64_t tp = bs_find(a.srowP, a.soffP[J], a.soffP[J + 1], I);
+  const int64_t tx = MODE == 2 ? bs_find(a.srowX, a.soffX[J], a.soffX[J + 1], I) : -1;
+  const int64_t td = bs_find(a.srowD, a.soffD[J], a.soffD[J + 1], I);
+  const unsigned mP = tp >= 0 ? (unsigned)a.smaskP[tp] : 0u, mX = tx >= 0 ? (unsigned)a.smaskX[tx] : 0u, mD = td >= 0 ? (unsigned)a.smaskD[td] : 0u;
+  const double* __restrict__ bP = tp >= 0 ? a.tilesP + a.sbaseP[tp] * 256 : a.tilesP;
+  const double* __restrict__ bX = tx >= 0 ? a.tilesX + a.sbaseX[tx] * 256 : a.tilesP;
+  const double* __restrict__ bD = td >= 0 ? a.tilesD + a.sbaseD[td] * 256 : a.tilesP;
+  // this lane's four words of a tile: words 4 l + e -> in-tile (row, column) -> in-block positions
+  const int w0 = 4 * lane, col_t = w0 >> 4, ch = (w0 & 15) >> 1;   // (two chunks: ch, ch + 1; e = 0, 1 in the first, 2, 3 in the second)
+  int rowpos[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row_t = ((((ch + (e >> 1)) ^ (col_t >> 1)) & 7) << 1) | (e & 1);
+    rowpos[e] = phys(row_t);
+  }
+  const int colpos = phys(col_t);
+  double dsum = 0.0, tsum = 0.0;
+  v4d outv[16];
+  unsigned mC = 0;
+  int cnt = 0;
+  unsigned flags = 0;
+  const unsigned mU = MODE == 2 ? (mP | mX) : mP;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    if ((mU & (1u << t)) == 0) continue;
+    const int rb = t & 3, cb = t >> 2;
+    v4d p4 = bs_zero4(), x4 = bs_zero4(), d4 = bs_zero4();
+    if (mP & (1u << t)) p4 = *reinterpret_cast<const v4d*>(bP + __popc(mP & ((1u << t) - 1u)) * 256 + w0);
+    if (MODE == 2 && (mX & (1u << t))) x4 = *reinterpret_cast<const v4d*>(bX + __popc(mX & ((1u << t) - 1u)) * 256 + w0);
+    if (mD & (1u << t)) d4 = *reinterpret_cast<const v4d*>(bD + __popc(mD & ((1u << t) - 1u)) * 256 + w0);
+    const int pc = 64 * J + 16 * cb + colpos;
+    int lastP = -1, lastX = -1;
+    if (MODE == 2) { lastP = a.plastP[pc]; lastX = a.plastX[pc]; }
+    v4d o4 = bs_zero4();
+    bool any = false;
+    int kc = 0, kl = -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double o;
+      bool keep;
+      if (MODE == 2) {
+        const double p = p4[e], x = x4[e];
+        const bool ha = p != 0.0, hb = x != 0.0;
+        const double wa = __dmul_rn(a.am, p), bs = __dmul_rn(a.bm, x);
+        o = 0.0;
+        keep = false;
+        const int rl = (ha || hb) ? a.lab[64 * I + 16 * rb + rowpos[e]] : -1;
+        if (ha && hb) { o = __dadd_rn(wa, bs); keep = fabs(o) > a.thr; }
+        else if (ha) { o = wa; keep = (rl > lastX) ? true : (fabs(wa) > a.thr); }
+        else if (hb) { o = bs; keep = (rl > lastP) ? true : (fabs(bs) > a.thr); }
+        if (keep && o == 0.0) flags |= 2u;
+        if (keep) kl = max(kl, rl);
+      } else {
+        o = p4[e];
+        keep = o != 0.0;
+      }
+      o4[e] = keep ? o : 0.0;
+      any |= keep;
+      kc += keep ? 1 : 0;
+      if (keep) {
+        dsum = __dadd_rn(dsum, __dmul_rn(o, d4[e]));
+        if (I == J && rb == cb && rowpos[e] == colpos) tsum = __dadd_rn(tsum, o);
+      }
+    }
+    cnt += kc;
+    if (MODE == 2) {
+      outv[t] = o4;
+      if (__ballot(any) != 0ull) mC |= 1u << t;
+      // column statistics of the result: the 4 words of a lane lie in one column (16 lanes x 4 words... 4 lanes per column)
+      if (kc) { atomicAdd(&a.ccount_out[pc], kc); atomicMax(&a.plast_out[pc], kl); }
+    }
+  }
+  cnt = (int)wave_sum_i64(cnt);
+  dsum = wave_sum_f64(dsum);
+  tsum = wave_sum_f64(tsum);
+  if (MODE == 2) {
+    const int nt = __popc(mC);
+    int64_t slot0 = 0;
+    bool ok = true;
+    if (nt) {
+      unsigned long long s = 0;
+      if (lane == 0) s = atomicAdd(&a.counters[0], (unsigned long long)nt);
+      slot0 = uni_i64((int64_t)s);
+      if (slot0 + nt > a.pool_tiles) { ok = false; flags |= 1u; }
+    }
+    if (nt && ok) {
+      int rank = 0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (mC & (1u << t)) {
+          *reinterpret_cast<v4d*>(a.pool + (slot0 + rank) * 256 + w0) = outv[t];
+          rank += 1;
+        }
+      }
+    }
+    if (__ballot(flags != 0) != 0ull) {
+      unsigned f = flags;
+      for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o, WAVE);
+      if (lane == 0) atomicOr(&a.counters[1], (unsigned long long)f);
+    }
+    if (lane == 0) {
+      a.cmask[cand] = ok ? (int32_t)mC : 0;
+      a.cbase[cand] = slot0;
+      a.ccnt[cand] = ok ? cnt : 0;
+    }
+  }
+  if (lane == 0) { a.pdot[2 * cand] = dsum; a.pdot[2 * cand + 1] = tsum; }
+}
+// (dot, trace) pairs summed in a fixed shape: 256 partial sums, then one block
+__global__ __launch_bounds__(256) void k_bs_sum_pairs(int64_t n, const double* __restrict__ x, double* __restrict__ part) {
+  __shared__ double sh[2][4];
+  double s0 = 0.0, s1 = 0.0;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t b0 = blockIdx.x * per, b1 = min(n, b0 + per);
+  for (int64_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) { s0 = __dadd_rn(s0, x[2 * i]); s1 = __dadd_rn(s1, x[2 * i + 1]); }
+  s0 = wave_sum_f64(s0);
+  s1 = wave_sum_f64(s1);
+  if (lane_id() == 0) { sh[0][threadIdx.x / WAVE] = s0; sh[1][threadIdx.x / WAVE] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = __dadd_rn(__dadd_rn(sh[0][0], sh[0][1]), __dadd_rn(sh[0][2], sh[0][3]));
+    part[2 * blockIdx.x + 1] = __dadd_rn(__dadd_rn(sh[1][0], sh[1][1]), __dadd_rn(sh[1][2], sh[1][3]));
+  }
+}
+__global__ __launch_bounds__(256) void k_bs_expand_j(int ns, const int64_t* __restrict__ soff, int32_t* __restrict__ cj) {
+  const int J = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
+  if (J >= ns) return;
+  for (int64_t t = soff[J] + lane_id(); t < soff[J + 1]; t += WAVE) cj[t] = J;
+}
+
+// =====================================================================================================================
 // caches
 // =====================================================================================================================
 struct CachedForm {   // the block form of a matrix in compressed columns, valid while the matrix is what it was
@@ -972,6 +1245,131 @@ bool block_order_for(const DevMat& M, std::vector<int32_t>& pos_host) {
   return true;
 }
 
+namespace {
+void block_colstat(BlockForm& F);
+// C = alpha A B pruned, block form in, block form out (symbolic phase, numeric phase, the result's super-tiles)
+void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, double threshold, bool dense_rule, BlockForm& FC,
+                   unsigned long long* nnz_out, unsigned long long hc[4], int64_t* ncand_out, hipEvent_t ev_begin, hipEvent_t ev_end,
+                   unsigned long long* nprod_out, const DevMat* Acsc, const DevMat* Bcsc) {
+  const int32_t n = bc.order->n;
+  build_rows(FA);
+  const int ns = bc.order->ns;
+  // ---- symbolic
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_symbolic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_symbolic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_done = true;
+  }
+  const size_t sym_lds = (size_t)((ns + 31) / 32) * 4;
+  DevBuf<int32_t> ccount((size_t)ns);
+  DevBuf<int64_t> coff((size_t)ns + 1);
+  hipLaunchKernelGGL((k_bs_symbolic<false>), dim3(ns), dim3(256), sym_lds, stream(), ns, FA.soff.p, FA.srow.p, FB.soff.p, FB.srow.p, ccount.p,
+                     (const int64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+  scan_i32_async(ccount.p, coff.p, (int64_t)ns);
+  int64_t ncand = 0;
+  {
+    ScalarFetch f;
+    f.add(coff.p + ns, 1, &ncand);
+    f.run();
+  }
+  *ncand_out = ncand;
+  if (ncand == 0) return;
+  DevBuf<int32_t> ci((size_t)ncand), cj((size_t)ncand), cmask((size_t)ncand), ccnt((size_t)ncand);
+  DevBuf<int64_t> cbase((size_t)ncand);
+  hipLaunchKernelGGL((k_bs_symbolic<true>), dim3(ns), dim3(256), sym_lds, stream(), ns, FA.soff.p, FA.srow.p, FB.soff.p, FB.srow.p,
+                     (int32_t*)nullptr, coff.p, ci.p, cj.p);
+  // processing order of the candidates
+  DevBuf<int32_t> order((size_t)ncand);
+  {
+    DevBuf<unsigned> zk((size_t)ncand), zk_s((size_t)ncand);
+    DevBuf<int32_t> zi((size_t)ncand);
+    static const int zmode = std::getenv("NTPOLY_AMD_BS_ORDER") ? std::atoi(std::getenv("NTPOLY_AMD_BS_ORDER")) : 1;
+    hipLaunchKernelGGL(k_bs_zorder, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, ci.p, cj.p, zk.p, zi.p, zmode);
+    size_t tb = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, zk.p, zk_s.p, zi.p, order.p, (size_t)ncand, 0, 32, stream()));
+    DevBuf<char> tmp(tb);
+    HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, zk.p, zk_s.p, zi.p, order.p, (size_t)ncand, 0, 32, stream()));
+  }
+  // ---- numeric (the pool is sized from the last product of this dimension; an overflow is repeated with the exact size)
+  FC = BlockForm();
+  FC.order = bc.order;
+  FC.ns = ns;
+  int64_t pool = std::max<int64_t>(1024, std::max(FA.ntiles, FB.ntiles) * 2);
+  if (bc.pool_hint_n == n) pool = std::max(pool, bc.pool_hint + bc.pool_hint / 4);
+  pool = std::min<int64_t>(pool, ncand * 16);
+  DevBuf<unsigned long long> counters(4);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    FC.tiles.alloc((size_t)pool * 256 + 512);
+    counters.zero();
+    BsArgs a;
+    a.roffA = FA.roff.p; a.rcolA = FA.rcol.p; a.ridxA = FA.ridx.p; a.smaskA = FA.smask.p; a.sbaseA = FA.sbase.p; a.tilesA = FA.tiles.p;
+    a.soffB = FB.soff.p; a.srowB = FB.srow.p; a.smaskB = FB.smask.p; a.sbaseB = FB.sbase.p; a.tilesB = FB.tiles.p;
+    a.ncand = ncand; a.ci = ci.p; a.cj = cj.p; a.order = order.p; a.cmask = cmask.p; a.cbase = cbase.p; a.ccnt = ccnt.p;
+    a.pool = FC.tiles.p; a.pool_tiles = pool; a.counters = counters.p;
+    a.alpha = alpha; a.threshold = threshold; a.dense_rule = dense_rule ? 1 : 0;
+    a.nwg = (int)ncand;
+    a.ablate = 0;
+#ifdef NTP_ABLATIONS
+    if (const char* v = std::getenv("NTPOLY_AMD_BS_ABLATE")) a.ablate = std::atoi(v);
+#endif
+    if (ev_begin) HIP_CHECK(hipEventRecord(ev_begin, stream()));
+    hipLaunchKernelGGL(k_bs_numeric, dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
+    if (ev_end) HIP_CHECK(hipEventRecord(ev_end, stream()));
+    {
+      ScalarFetch f;
+      f.add(counters.p, 4, hc);
+      f.run();
+    }
+    if (hc[1] == 0) break;
+    if (attempt == 1) NTP_FATAL("internal: block SpGEMM: the tile pool overflowed twice");
+    pool = (int64_t)hc[0];
+  }
+  bc.pool_hint = (int64_t)hc[0];
+  bc.pool_hint_n = n;
+  // ---- the result's super-tiles and entry count
+  DevBuf<int32_t> flag((size_t)ncand);
+  DevBuf<int64_t> excl((size_t)ncand + 1);
+  DevBuf<unsigned long long> tot(65);   // [0] entries of the result, [1 .. 64] partial product counts
+  tot.zero();
+  if (nprod_out) {
+    if (Acsc && Bcsc) hipLaunchKernelGGL(k_bs_products, dim3(gridw(n)), dim3(256), 0, stream(), view(*Acsc), view(*Bcsc), tot.p + 1);
+    else {   // (operands in block form: entries per column of A, then the sum over the entries of B)
+      block_colstat(FA);
+      hipLaunchKernelGGL(k_bs_products_blk, dim3(gridw((int64_t)64 * ns)), dim3(256), 0, stream(), ns, FB.soff.p, FB.srow.p, FB.smask.p, FB.sbase.p,
+                         FB.tiles.p, FA.ccount.p, tot.p + 1);
+    }
+  }
+  hipLaunchKernelGGL(k_bs_flag, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, cmask.p, flag.p);
+  scan_i32_async(flag.p, excl.p, ncand);
+  hipLaunchKernelGGL(k_bs_sum_i32, dim3(std::min(1024, grid1(ncand))), dim3(256), 0, stream(), ncand, ccnt.p, tot.p);
+  int64_t nstC = 0;
+  unsigned long long nnzC = 0, nprod = 0;
+  {
+    unsigned long long t2[65];
+    ScalarFetch f;
+    f.add(excl.p + ncand, 1, &nstC);
+    f.add(tot.p, 65, t2);
+    f.run();
+    nnzC = t2[0];
+    for (int i = 1; i < 65; ++i) nprod += t2[i];
+  }
+  if (nnzC >= (1ull << 32)) NTP_FATAL("block SpGEMM: the product holds 2^32 entries or more");
+  *nnz_out = nnzC;
+  if (nprod_out) *nprod_out = nprod;
+  FC.nst = nstC;
+  FC.ntiles = (int64_t)hc[0];
+  FC.nnz = (int64_t)nnzC;
+  FC.soff.alloc((size_t)ns + 1);
+  FC.srow.alloc((size_t)std::max<int64_t>(1, nstC));
+  FC.smask.alloc((size_t)std::max<int64_t>(1, nstC));
+  FC.sbase.alloc((size_t)std::max<int64_t>(1, nstC));
+  hipLaunchKernelGGL(k_bs_compact, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, cmask.p, cbase.p, ci.p, excl.p, FC.srow.p, FC.smask.p, FC.sbase.p);
+  hipLaunchKernelGGL(k_bs_soff, dim3(grid1(ns + 1)), dim3(256), 0, stream(), ns, coff.p, excl.p, FC.soff.p);
+}
+
+}  // namespace
+
 DevMat block_unpack(const DevMat& M) {
   DevMat R;
   from_block(*M.blk, M.nnz, R);
@@ -1015,6 +1413,160 @@ std::shared_ptr<BlockForm> operand_form(const DevMat& M, BlockCache& bc, double 
   return F;
 }
 }  // namespace
+
+bool block_trs2_step(DevMat& X, int mode, double threshold, bool dense_rule, const DevMat& D, double out[4], BlockInfo* info,
+                     hipEvent_t ev_begin, hipEvent_t ev_end) {
+  if (info) *info = BlockInfo();
+  if (X.cplx || D.cplx || X.rows != X.cols || D.rows != X.rows || D.cols != X.cols || X.nnz == 0 || D.nnz == 0) return false;
+  if (X.loose() || X.expanded() || D.loose() || D.expanded() || D.blocked()) return false;
+  if (options().spgemm_fma != 1 || options().block_path == 0 || options().spgemm_variant >= 0 || options().spgemm_force_bin > 0) return false;
+  BlockCache& bc = cache();
+  const int32_t n = X.cols;
+  if (!bc.order || bc.order->n != n) return false;   // (only dimensions the block path has multiplied before)
+  const int ns = bc.order->ns;
+  std::shared_ptr<BlockForm> pFX;
+  double fx = 0, fd = 0;
+  if (X.blocked()) {
+    if (X.blk->order.get() != bc.order.get()) return false;
+    pFX = X.blk;
+    fx = pFX->ntiles > 0 ? (double)X.nnz / (256.0 * (double)pFX->ntiles) : 0.0;
+  } else {
+    pFX.reset(new BlockForm());   // (the iterate changes every step: not cached)
+    if (!to_block(X, bc.order, *pFX, options().block_path == 2 ? 0.0 : kMinFill, &fx)) return false;
+  }
+  bool conv = false;
+  std::shared_ptr<BlockForm> pFD = operand_form(D, bc, 0.0, &fd, &conv);
+  if (!pFD) return false;
+  BlockForm& FX = *pFX;
+  BlockForm& FD = *pFD;
+  BlockForm FP;
+  unsigned long long nnzP = 0, nprod = 0, hc[4] = {0, 0, 0, 0};
+  int64_t ncand = 0;
+  const bool count_products = info != nullptr && options().time_kernels != 0;
+  block_product(bc, FX, FX, 1.0, threshold, dense_rule, FP, &nnzP, hc, &ncand, ev_begin, ev_end, count_products ? &nprod : nullptr,
+                X.blocked() ? nullptr : &X, X.blocked() ? nullptr : &X);
+  if (ncand == 0 || nnzP == 0) return false;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_union<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_union<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_done = true;
+  }
+  DevBuf<double> part(512), res(2);
+  double hres[2] = {0, 0};
+  BsMergeArgs a;
+  a.soffP = FP.soff.p; a.srowP = FP.srow.p; a.smaskP = FP.smask.p; a.sbaseP = FP.sbase.p; a.tilesP = FP.tiles.p; a.plastP = nullptr;
+  a.soffX = FX.soff.p; a.srowX = FX.srow.p; a.smaskX = FX.smask.p; a.sbaseX = FX.sbase.p; a.tilesX = FX.tiles.p; a.plastX = nullptr;
+  a.soffD = FD.soff.p; a.srowD = FD.srow.p; a.smaskD = FD.smask.p; a.sbaseD = FD.sbase.p; a.tilesD = FD.tiles.p;
+  a.lab = bc.order->lab.p;
+  a.cmask = nullptr; a.cbase = nullptr; a.ccnt = nullptr; a.pool = nullptr; a.pool_tiles = 0; a.counters = nullptr;
+  a.ccount_out = nullptr; a.plast_out = nullptr;
+  a.am = -1.0; a.bm = 2.0; a.thr = threshold;
+  DevMat R;
+  R.rows = n; R.cols = n; R.cplx = false; R.zero_free = 1;
+  if (mode == 1) {
+    // X <- P: dot and trace over the product's own super-tiles
+    const int64_t nc = FP.nst;
+    DevBuf<int32_t> cj((size_t)nc);
+    DevBuf<double> pdot((size_t)2 * nc);
+    hipLaunchKernelGGL(k_bs_expand_j, dim3(gridw(ns)), dim3(256), 0, stream(), ns, FP.soff.p, cj.p);
+    a.ncand = nc; a.ci = FP.srow.p; a.cj = cj.p; a.pdot = pdot.p;
+    hipLaunchKernelGGL((k_bs_merge<1>), dim3((unsigned)nc), dim3(64), 0, stream(), a);
+    hipLaunchKernelGGL(k_bs_sum_pairs, dim3(256), dim3(256), 0, stream(), nc, pdot.p, part.p);
+    hipLaunchKernelGGL(k_bs_sum_pairs, dim3(1), dim3(256), 0, stream(), (int64_t)256, part.p, res.p);
+    {
+      ScalarFetch f;
+      f.add(res.p, 2, hres);
+      f.run();
+    }
+    R.nnz = (int64_t)nnzP;
+    R.blk.reset(new BlockForm(std::move(FP)));
+  } else {
+    block_colstat(FX);
+    block_colstat(FP);
+    a.plastP = FP.plast.p;
+    a.plastX = FX.plast.p;
+    const size_t lds = (size_t)((ns + 31) / 32) * 4;
+    DevBuf<int32_t> ucount((size_t)ns);
+    DevBuf<int64_t> uoff((size_t)ns + 1);
+    hipLaunchKernelGGL((k_bs_union<false>), dim3(ns), dim3(256), lds, stream(), ns, FX.soff.p, FX.srow.p, FP.soff.p, FP.srow.p, ucount.p,
+                       (const int64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+    scan_i32_async(ucount.p, uoff.p, (int64_t)ns);
+    int64_t nc = 0;
+    {
+      ScalarFetch f;
+      f.add(uoff.p + ns, 1, &nc);
+      f.run();
+    }
+    DevBuf<int32_t> ci((size_t)nc), cj((size_t)nc), cmask((size_t)nc), ccnt((size_t)nc), flag((size_t)nc);
+    DevBuf<int64_t> cbase((size_t)nc), excl((size_t)nc + 1);
+    DevBuf<double> pdot((size_t)2 * nc);
+    hipLaunchKernelGGL((k_bs_union<true>), dim3(ns), dim3(256), lds, stream(), ns, FX.soff.p, FX.srow.p, FP.soff.p, FP.srow.p, (int32_t*)nullptr,
+                       uoff.p, ci.p, cj.p);
+    BlockForm FN;
+    FN.order = bc.order;
+    FN.ns = ns;
+    const int64_t pool = FX.ntiles + FP.ntiles;   // (the union holds no more tiles than its operands together)
+    FN.tiles.alloc((size_t)pool * 256 + 512);
+    FN.ccount.alloc((size_t)64 * ns);
+    FN.plast.alloc((size_t)64 * ns);
+    FN.ccount.zero();
+    HIP_CHECK(hipMemsetAsync(FN.plast.p, 0xFF, sizeof(int32_t) * (size_t)64 * ns, stream()));
+    DevBuf<unsigned long long> counters(4), tot(1);
+    counters.zero();
+    tot.zero();
+    a.ncand = nc; a.ci = ci.p; a.cj = cj.p; a.cmask = cmask.p; a.cbase = cbase.p; a.ccnt = ccnt.p; a.pdot = pdot.p;
+    a.pool = FN.tiles.p; a.pool_tiles = pool; a.counters = counters.p; a.ccount_out = FN.ccount.p; a.plast_out = FN.plast.p;
+    hipLaunchKernelGGL((k_bs_merge<2>), dim3((unsigned)nc), dim3(64), 0, stream(), a);
+    hipLaunchKernelGGL(k_bs_sum_pairs, dim3(256), dim3(256), 0, stream(), nc, pdot.p, part.p);
+    hipLaunchKernelGGL(k_bs_sum_pairs, dim3(1), dim3(256), 0, stream(), (int64_t)256, part.p, res.p);
+    hipLaunchKernelGGL(k_bs_flag, dim3(grid1(nc)), dim3(256), 0, stream(), nc, cmask.p, flag.p);
+    scan_i32_async(flag.p, excl.p, nc);
+    hipLaunchKernelGGL(k_bs_sum_i32, dim3(std::min(1024, grid1(nc))), dim3(256), 0, stream(), nc, ccnt.p, tot.p);
+    unsigned long long hcnt[4] = {0, 0, 0, 0}, nnzN = 0;
+    int64_t nstN = 0;
+    {
+      ScalarFetch f;
+      f.add(res.p, 2, hres);
+      f.add(counters.p, 4, hcnt);
+      f.add(excl.p + nc, 1, &nstN);
+      f.add(tot.p, 1, &nnzN);
+      f.run();
+    }
+    if (hcnt[1] != 0) {   // (a kept value that is exactly zero: the block form cannot hold it -- compressed columns decide)
+      if (dbg()) std::fprintf(stderr, "[block trs2] merge refused (flags %llu)\n", hcnt[1]);
+      return false;
+    }
+    FN.nst = nstN;
+    FN.ntiles = (int64_t)hcnt[0];
+    FN.nnz = (int64_t)nnzN;
+    FN.have_stat = true;
+    FN.soff.alloc((size_t)ns + 1);
+    FN.srow.alloc((size_t)std::max<int64_t>(1, nstN));
+    FN.smask.alloc((size_t)std::max<int64_t>(1, nstN));
+    FN.sbase.alloc((size_t)std::max<int64_t>(1, nstN));
+    hipLaunchKernelGGL(k_bs_compact, dim3(grid1(nc)), dim3(256), 0, stream(), nc, cmask.p, cbase.p, ci.p, excl.p, FN.srow.p, FN.smask.p, FN.sbase.p);
+    hipLaunchKernelGGL(k_bs_soff, dim3(grid1(ns + 1)), dim3(256), 0, stream(), ns, uoff.p, excl.p, FN.soff.p);
+    sync_stream();   // (the candidate arrays are released on return)
+    R.nnz = (int64_t)nnzN;
+    R.blk.reset(new BlockForm(std::move(FN)));
+  }
+  X = std::move(R);
+  out[0] = hres[0];
+  out[1] = 0.0;
+  out[2] = hres[1];
+  out[3] = 0.0;
+  if (info) {
+    info->used = 1;
+    info->fill_a = fx; info->fill_b = fx;
+    info->tiles_a = FX.ntiles; info->tiles_b = FX.ntiles; info->tiles_c = (int64_t)hc[0];
+    info->cand = ncand;
+    info->tile_products = (int64_t)hc[2];
+    info->nnz_c = (int64_t)nnzP;
+    info->products = (int64_t)nprod;
+  }
+  return true;
+}
 
 bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, BlockInfo* info,
                   hipEvent_t ev_begin, hipEvent_t ev_end, bool keep_blocked) {
@@ -1063,116 +1615,17 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   }
   BlockForm& FA = *pFA;
   BlockForm* FB = pFB.get();
-  build_rows(FA);
-  const int ns = bc.order->ns;
-  // ---- symbolic
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_symbolic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_symbolic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_done = true;
-  }
-  const size_t sym_lds = (size_t)((ns + 31) / 32) * 4;
-  DevBuf<int32_t> ccount((size_t)ns);
-  DevBuf<int64_t> coff((size_t)ns + 1);
-  hipLaunchKernelGGL((k_bs_symbolic<false>), dim3(ns), dim3(256), sym_lds, stream(), ns, FA.soff.p, FA.srow.p, FB->soff.p, FB->srow.p, ccount.p,
-                     (const int64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
-  scan_i32_async(ccount.p, coff.p, (int64_t)ns);
+  BlockForm FC;
+  unsigned long long nnzC = 0, nprod = 0, hc[4] = {0, 0, 0, 0};
   int64_t ncand = 0;
-  {
-    ScalarFetch f;
-    f.add(coff.p + ns, 1, &ncand);
-    f.run();
-  }
+  const bool count_products = info != nullptr && options().time_kernels != 0;
+  block_product(bc, FA, *FB, alpha, threshold, dense_rule, FC, &nnzC, hc, &ncand, ev_begin, ev_end, count_products ? &nprod : nullptr,
+                (!A.blocked() && !B.blocked()) ? &A : nullptr, (!A.blocked() && !B.blocked()) ? &B : nullptr);
   if (ncand == 0) {
     C.reset_empty(n, n, false);
     if (info) { info->used = 1; info->fill_a = fa; info->fill_b = fb; }
     return true;
   }
-  DevBuf<int32_t> ci((size_t)ncand), cj((size_t)ncand), cmask((size_t)ncand), ccnt((size_t)ncand);
-  DevBuf<int64_t> cbase((size_t)ncand);
-  hipLaunchKernelGGL((k_bs_symbolic<true>), dim3(ns), dim3(256), sym_lds, stream(), ns, FA.soff.p, FA.srow.p, FB->soff.p, FB->srow.p,
-                     (int32_t*)nullptr, coff.p, ci.p, cj.p);
-  // processing order of the candidates
-  DevBuf<int32_t> order((size_t)ncand);
-  {
-    DevBuf<unsigned> zk((size_t)ncand), zk_s((size_t)ncand);
-    DevBuf<int32_t> zi((size_t)ncand);
-    static const int zmode = std::getenv("NTPOLY_AMD_BS_ORDER") ? std::atoi(std::getenv("NTPOLY_AMD_BS_ORDER")) : 1;
-    hipLaunchKernelGGL(k_bs_zorder, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, ci.p, cj.p, zk.p, zi.p, zmode);
-    size_t tb = 0;
-    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, zk.p, zk_s.p, zi.p, order.p, (size_t)ncand, 0, 32, stream()));
-    DevBuf<char> tmp(tb);
-    HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, zk.p, zk_s.p, zi.p, order.p, (size_t)ncand, 0, 32, stream()));
-  }
-  // ---- numeric (the pool is sized from the last product of this dimension; an overflow is repeated with the exact size)
-  BlockForm FC;
-  FC.order = bc.order;
-  FC.ns = ns;
-  int64_t pool = std::max<int64_t>(1024, std::max(FA.ntiles, FB->ntiles) * 2);
-  if (bc.pool_hint_n == n) pool = std::max(pool, bc.pool_hint + bc.pool_hint / 4);
-  pool = std::min<int64_t>(pool, ncand * 16);
-  DevBuf<unsigned long long> counters(4);
-  unsigned long long hc[4] = {0, 0, 0, 0};
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    FC.tiles.alloc((size_t)pool * 256 + 512);
-    counters.zero();
-    BsArgs a;
-    a.roffA = FA.roff.p; a.rcolA = FA.rcol.p; a.ridxA = FA.ridx.p; a.smaskA = FA.smask.p; a.sbaseA = FA.sbase.p; a.tilesA = FA.tiles.p;
-    a.soffB = FB->soff.p; a.srowB = FB->srow.p; a.smaskB = FB->smask.p; a.sbaseB = FB->sbase.p; a.tilesB = FB->tiles.p;
-    a.ncand = ncand; a.ci = ci.p; a.cj = cj.p; a.order = order.p; a.cmask = cmask.p; a.cbase = cbase.p; a.ccnt = ccnt.p;
-    a.pool = FC.tiles.p; a.pool_tiles = pool; a.counters = counters.p;
-    a.alpha = alpha; a.threshold = threshold; a.dense_rule = dense_rule ? 1 : 0;
-    a.nwg = (int)ncand;
-    a.ablate = 0;
-#ifdef NTP_ABLATIONS
-    if (const char* v = std::getenv("NTPOLY_AMD_BS_ABLATE")) a.ablate = std::atoi(v);
-#endif
-    if (ev_begin) HIP_CHECK(hipEventRecord(ev_begin, stream()));
-    hipLaunchKernelGGL(k_bs_numeric, dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
-    if (ev_end) HIP_CHECK(hipEventRecord(ev_end, stream()));
-    {
-      ScalarFetch f;
-      f.add(counters.p, 4, hc);
-      f.run();
-    }
-    if (hc[1] == 0) break;
-    if (attempt == 1) NTP_FATAL("internal: block SpGEMM: the tile pool overflowed twice");
-    pool = (int64_t)hc[0];
-  }
-  bc.pool_hint = (int64_t)hc[0];
-  bc.pool_hint_n = n;
-  // ---- the result's super-tiles and entry count
-  DevBuf<int32_t> flag((size_t)ncand);
-  DevBuf<int64_t> excl((size_t)ncand + 1);
-  DevBuf<unsigned long long> tot(65);   // [0] entries of the result, [1 .. 64] partial product counts
-  tot.zero();
-  const bool count_products = info != nullptr && options().time_kernels != 0;
-  if (count_products) hipLaunchKernelGGL(k_bs_products, dim3(gridw(n)), dim3(256), 0, stream(), view(A), view(B), tot.p + 1);
-  hipLaunchKernelGGL(k_bs_flag, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, cmask.p, flag.p);
-  scan_i32_async(flag.p, excl.p, ncand);
-  hipLaunchKernelGGL(k_bs_sum_i32, dim3(std::min(1024, grid1(ncand))), dim3(256), 0, stream(), ncand, ccnt.p, tot.p);
-  int64_t nstC = 0;
-  unsigned long long nnzC = 0, nprod = 0;
-  {
-    unsigned long long t2[65];
-    ScalarFetch f;
-    f.add(excl.p + ncand, 1, &nstC);
-    f.add(tot.p, 65, t2);
-    f.run();
-    nnzC = t2[0];
-    for (int i = 1; i < 65; ++i) nprod += t2[i];
-  }
-  if (nnzC >= (1ull << 32)) NTP_FATAL("block SpGEMM: the product holds 2^32 entries or more");
-  FC.nst = nstC;
-  FC.ntiles = (int64_t)hc[0];
-  FC.nnz = (int64_t)nnzC;
-  FC.soff.alloc((size_t)ns + 1);
-  FC.srow.alloc((size_t)std::max<int64_t>(1, nstC));
-  FC.smask.alloc((size_t)std::max<int64_t>(1, nstC));
-  FC.sbase.alloc((size_t)std::max<int64_t>(1, nstC));
-  hipLaunchKernelGGL(k_bs_compact, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, cmask.p, cbase.p, ci.p, excl.p, FC.srow.p, FC.smask.p, FC.sbase.p);
-  hipLaunchKernelGGL(k_bs_soff, dim3(grid1(ns + 1)), dim3(256), 0, stream(), ns, coff.p, excl.p, FC.soff.p);
   if (keep_blocked) {
     DevMat R;
     R.rows = n; R.cols = n; R.cplx = false; R.nnz = (int64_t)nnzC; R.zero_free = 1;

@@ -44,6 +44,10 @@ struct BlockForm {
   DevBuf<int64_t> roff;
   DevBuf<int32_t> rcol, ridx;
   bool have_rows = false;
+  // per column POSITION (64 ns): entries of the column and the largest LABEL among its rows (-1: empty) -- the "last row"
+  // of the AddSparseVectors rules in the caller's labels.  Written by the merge that produced the matrix, or on first use.
+  DevBuf<int32_t> ccount, plast;
+  bool have_stat = false;
 };
 
 struct BlockInfo {
@@ -65,6 +69,11 @@ struct BlockInfo {
 bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, BlockInfo* info,
                   hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, bool keep_blocked = false);
 DevMat block_unpack(const DevMat& M);   // block form -> compressed columns under the caller's labels
+// One TRS2 step on an iterate of a dimension the block path multiplies (DensityMatrixSolversModule.F90:380-404): mode 1:
+// X <- X X; mode 2: X <- 2 X - X X merged by the AddSparseVectors rules -- with out[0] = dot(X_new, D), out[2] = trace.
+// X: compressed columns or block form; it is left in BLOCK form.  false: not taken (X unchanged).
+bool block_trs2_step(DevMat& X, int mode, double threshold, bool dense_rule, const DevMat& D, double out[4], BlockInfo* info = nullptr,
+                     hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // the block order the engine holds for matrices of M's dimension, made from M if there is none (tests / tools);
 // pos_host[index] = position
 bool block_order_for(const DevMat& M, std::vector<int32_t>& pos_host);

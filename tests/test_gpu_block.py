@@ -228,3 +228,39 @@ def test_products_stay_in_block_form_across_c_abi_calls(nt, fma):
     C7.Gemm(A, A, None, 1.0, 0.0, thr)
     C8 = nt.Matrix_ps(C7)                      # CopyMatrix of a block-form matrix
     exact(C8.triplets(), back(P2), "copy")
+
+
+@pytest.mark.parametrize("L,thr", [(16, 1e-8), (12, 1e-5)])
+def test_block_form_trs2_steps_equal_the_separate_passes(nt, fma, L, thr):
+    """The TRS2 loop with the iterate kept in block form (product, AddSparseVectors merge with the tail rule in the caller's
+    labels, energy, trace: spgemm_block.hip block_trs2_step) against the same loop with the option fused_update off --
+    the block path's product followed by the merge / dot passes on compressed columns: the same arithmetic element by
+    element, so the density must be IDENTICAL (pattern and bits), the sigma sequence and the entry counts of every
+    iteration equal, energies to summation order."""
+    n = L ** 3
+    col, row, val = lattice_triplets(L)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    I = nt.Matrix_ps(n)
+    I.FillIdentity()
+    res = []
+    for fused in (0, 1):
+        nt.set_option("fused_update", fused)
+        try:
+            p = nt.SolverParameters()
+            p.SetThreshold(thr)
+            p.SetConvergeDiff(1e-30)
+            p.SetMaxIterations(14)
+            p.SetMonitorConvergence(False)
+            K = nt.Matrix_ps(n)
+            f0 = nt.fusion_counts()
+            energy, mu = nt.DensityMatrixSolvers.TRS2(H, I, n / 2.0, K, p)
+            f1 = nt.fusion_counts()
+        finally:
+            nt.set_option("fused_update", 1)
+        tr = nt.solver_trace()
+        res.append((srt(K.triplets()), energy, list(tr["sigma"]), list(tr["nnz"]), f1["square"] + f1["update"] - f0["square"] - f0["update"]))
+    sep, blk = res
+    assert sep[4] == 0 and blk[4] >= 12, (sep[4], blk[4])      # the steps after the first ran in block form
+    assert sep[2] == blk[2] and sep[3] == blk[3]
+    assert abs(sep[1] - blk[1]) <= 1e-12 * abs(sep[1])
+    exact(blk[0], sep[0], "density, block-form steps vs separate passes")
