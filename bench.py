@@ -124,7 +124,7 @@ def sources_sha16():
     """fingerprint of the kernel sources a committed PMC traffic figure belongs to"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "slab_loop.inc", "spgemm_grouped.hip", "spgemm_tile.hip"):
+    for f in ("kernels.hip", "slab_loop.inc", "spgemm_grouped.hip", "spgemm_tile.hip", "spgemm_block.hip"):
         with open(os.path.join(ROOT, "ntpoly_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -245,12 +245,12 @@ def main():
         m1 = nt.malloc_stats()
         fz1 = nt.fusion_counts()
         blocks.append(dict(elapsed=elapsed, energy=energy, m0=m0, m1=m1, fused={k: fz1[k] - fz0[k] for k in fz1}, acc=nt.spgemm_accum(),
-                           st=nt.last_spgemm_stats(), gs=nt.last_grouped_stats(), nnz_x=X.GetSize()))
+                           st=nt.last_spgemm_stats(), gs=nt.last_grouped_stats(), bs=nt.last_block_stats(), nnz_x=X.GetSize()))
         if blk + 1 < max(1, args.blocks):
             del X, X2
     order = sorted(range(len(blocks)), key=lambda k: blocks[k]["elapsed"])
     med = blocks[order[len(order) // 2]]
-    elapsed, energy, m0, m1, fused, acc, st, gs, nnz_x = (med[k] for k in ("elapsed", "energy", "m0", "m1", "fused", "acc", "st", "gs", "nnz_x"))
+    elapsed, energy, m0, m1, fused, acc, st, gs, bs, nnz_x = (med[k] for k in ("elapsed", "energy", "m0", "m1", "fused", "acc", "st", "gs", "bs", "nnz_x"))
     block_ms = [1e3 * b["elapsed"] for b in blocks]
 
     if rank == 0:
@@ -259,7 +259,7 @@ def main():
         # the corrected bytes per launch together with a fingerprint of the kernel sources it was measured on -- a
         # figure measured on other sources is not reported (null)
         traffic, traffic_src = None, None
-        tname = ("r03_pmc_traffic%s.json" if args.arithmetic == "fma" else "r03_pmc_traffic_unfused%s.json") % (
+        tname = ("r04_pmc_traffic%s.json" if args.arithmetic == "fma" else "r04_pmc_traffic_unfused%s.json") % (
             "_lattice" if args.lattice is not None else "" if args.permute is None else "_permute")
         try:
             with open(os.path.join(ROOT, "profiles", tname)) as f:
@@ -301,7 +301,8 @@ def main():
                        "lattice": args.lattice,
                        "arithmetic": ("fma: every product entry is the chain of fma() over ascending k (one rounding per product), "
                                       "the reference's FP-contracted build bit for bit (tests/golden/ps_gemm_fma.npz); run-like "
-                                      "operands on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, spgemm_tile.hip)"
+                                      "operands on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, spgemm_tile.hip), operands without runs "
+                                      "as 16x16 tiles of a clustered index order on the same instruction (spgemm_block.hip)"
                                       if args.arithmetic == "fma" else
                                       "unfused: separate v_mul_f64 + v_add_f64, the reference's default x86-64 build bit for bit"),
                        "arithmetic_default": lib_default,   # what an unmodified caller of the C ABI runs with
@@ -316,7 +317,9 @@ def main():
             "spgemm_ms_per_call": ms_spgemm / calls,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": (("k_spgemm_tile" if args.arithmetic == "fma" else "k_spgemm_slab") if st.get("slab") else "k_spgemm_ghash (grouped LDS hash)" if gs.get("used")
+                         "kernel": (("k_spgemm_tile" if args.arithmetic == "fma" else "k_spgemm_slab") if st.get("slab") else
+                                    "k_bs_numeric (block path: 16x16 tiles of a clustered index order on v_mfma_f64_16x16x4_f64, spgemm_block.hip)" if bs.get("used") else
+                                    "k_spgemm_ghash (grouped LDS hash)" if gs.get("used")
                                     else "k_spgemm_pair3 / k_spgemm_hash") +
                                    (" (SpGEMM numeric phase with the TRS2 update, energy and trace in its epilogue)"
                                     if fused["square"] + fused["update"] > 0 else " (SpGEMM numeric phase)"),
@@ -340,6 +343,12 @@ def main():
         line["fused_steps"] = fused
         if gs.get("used"):
             line["grouped_hash"] = gs
+        if bs.get("used"):
+            # block path: of the 16 x 16 x 16 tile products issued (4 matrix instructions each) only the products of two
+            # stored entries are the reference's multiply-adds -- the rest multiplies zeros of the tiles
+            issued = 4096.0 * bs["tile_products"]
+            line["block_path"] = dict(bs, useful_fraction_last_product=(st["products"] / issued if issued else None),
+                                      issued_tflops_last_product=(2.0 * issued / (st["ms_numeric"] * 1e-3) / 1e12 if st.get("ms_numeric") else None))
     check = None
     if not args.no_wrp_check:
         del X, X2

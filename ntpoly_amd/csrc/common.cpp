@@ -219,6 +219,7 @@ DevMat DevMat::clone() const {
     return R;
   }
   R.alloc(rows, cols, cplx, nnz);
+  R.block_hint = block_hint;
   HIP_CHECK(hipMemcpyAsync(R.outer.p, outer.p, sizeof(int64_t) * ((size_t)cols + 1), hipMemcpyDeviceToDevice, stream()));
   if (nnz) {
     HIP_CHECK(hipMemcpyAsync(R.inner.p, inner.p, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, stream()));

@@ -186,6 +186,10 @@ struct DevMat {
   // Everything else sees compressed columns: pack() converts, view() refuses.
   std::shared_ptr<struct BlockForm> blk;
   bool blocked() const { return blk != nullptr; }
+  // 1: a product with this matrix (in compressed columns) as an operand went through the block path -- the next one
+  // goes there first, without the run statistics of the slab / tile kernels.  A property of THIS matrix, not of its
+  // dimension: a banded matrix of the same size still finds its run-based kernel.
+  mutable int block_hint = 0;
 
   DevMat() = default;
   DevMat(int32_t r, int32_t c, bool z) { reset_empty(r, c, z); }

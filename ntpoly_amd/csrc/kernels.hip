@@ -3084,7 +3084,6 @@ static bool spgemm_striped(const DevMat& A, const DevMat& B, DevMat& C, double a
 namespace {
 // the block path (spgemm_block.hip) with spgemm()'s book-keeping around it
 int g_block_keep = 0;           // > 0: a caller that understands DevMat::blk is waiting for the product (BlockKeepScope)
-int32_t g_block_last_n = -1;    // dimension of the last product the block path computed from compressed columns
 bool block_eligible(const DevMat& A, const DevMat& B, const ColRange* arange) {
   return !arange && !A.cplx && !B.cplx && options().spgemm_fma == 1 && options().block_path != 0 && options().spgemm_variant < 0 &&
          options().spgemm_force_bin <= 0 && A.rows == A.cols && B.rows == B.cols && A.cols == B.rows;
@@ -3105,10 +3104,12 @@ bool try_block_path(const DevMat& A, const DevMat& B, DevMat& C, double alpha, d
       event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
       event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
     }
-    if (g_block_last_n == n) g_block_last_n = -1;
+    A.block_hint = 0;
+    B.block_hint = 0;
     return false;
   }
-  g_block_last_n = n;
+  A.block_hint = 1;   // (harmless when A or B is C: the result is new)
+  B.block_hint = 1;
   t_all.stop();
   if (timing) {
     if (pending_timings().size() >= 4096) flush_spgemm_timers();
@@ -3129,10 +3130,9 @@ bool try_block_path(const DevMat& A, const DevMat& B, DevMat& C, double alpha, d
   return true;
 }
 }  // namespace
-bool block_path_last(int32_t n) { return g_block_last_n == n; }
 // a TRS2 step in block form (spgemm_block.hip block_trs2_step) with spgemm()'s book-keeping
 bool trs2_block_step(DevMat& X, int mode, double threshold, bool dense_rule, const DevMat& D, double out[4]) {
-  if (!X.blocked() && g_block_last_n != X.cols) return false;
+  if (!X.blocked() && !X.block_hint) return false;
   const bool timing = options().time_kernels != 0;
   EventTimer t_all(timing), t_num(timing);
   t_all.start();
@@ -3168,6 +3168,7 @@ bool trs2_block_step(DevMat& X, int mode, double threshold, bool dense_rule, con
   acc.nnz_c += bi.nnz_c;
   acc.alg_bytes += 12.0 * (double)(2 * nnz_x + bi.nnz_c) + 4.0 * (3.0 * n + 3);
   fusion_counts()[mode == 1 ? 0 : 1] += 1;
+  X.block_hint = 1;
   return true;
 }
 BlockKeepScope::BlockKeepScope() { g_block_keep += 1; }
@@ -3179,7 +3180,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   if (fuse) fuse->done = false;
   // operands in block form, or in compressed columns of a dimension whose last product the block path computed: the
   // block path first (no run statistics, no per-column plan)
-  if ((A.blocked() || B.blocked() || g_block_last_n == B.cols) && !A.loose() && !B.loose() && !A.expanded() && !B.expanded() &&
+  if ((A.blocked() || B.blocked() || A.block_hint || B.block_hint) && !A.loose() && !B.loose() && !A.expanded() && !B.expanded() &&
       A.nnz > 0 && B.nnz > 0 && block_eligible(A, B, arange) && !strip_ctx().active) {
     if (try_block_path(A, B, C, alpha, threshold, dense_rule)) return;
   }
@@ -4711,6 +4712,7 @@ bool square_keep_loose(DevMat& X, double threshold, bool dense_rule, const DevMa
   }
   if (!L.valid) {  // another kernel computed it (packed)
     X = std::move(AB);
+    if (last_spgemm_stats().block) X.block_hint = 1;   // (the next TRS2 step takes the iterate in block form)
     dot_trace(X, D, out, trace_out, col_offset);
     return true;
   }

@@ -140,7 +140,6 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
             bool dense_rule, LooseProduct* loose = nullptr, const ColRange* arange = nullptr, SlabFusion* fuse = nullptr);
 // while one is alive, a product that the block path computes (spgemm_block.hip) is left in block form (DevMat::blk): for
 // callers that hand it on to another product or pack() it themselves
-bool block_path_last(int32_t n);   // the last product of dimension n from compressed columns went through the block path
 // One TRS2 step with the iterate in block form (X: compressed columns of a dimension the block path multiplies, or block
 // form; left in block form): mode 1: X <- X X, mode 2: X <- 2 X - X X by the AddSparseVectors rules; out[0] = dot(X, D),
 // out[2] = trace(X).  false: not taken, X unchanged.

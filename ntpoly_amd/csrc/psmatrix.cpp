@@ -495,7 +495,8 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   // through the block path and STAYS in block form (DevMat::blk) -- the next product of the caller's loop multiplies it
   // as it is, every other entry point packs on access.  Solver loops (sessions of their own) take compressed columns.
   const bool block_first = slab_on() && g_session_api && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 &&
-                           (A.loc.blocked() || B.loc.blocked() || block_path_last(A.dim));
+                           (A.loc.blocked() || B.loc.blocked() || A.loc.block_hint || B.loc.block_hint) && !A.loc.expanded() && !B.loc.expanded() &&
+                           !A.loc.loose() && !B.loc.loose();
   if (block_first) {
     BlockKeepScope keep;
     const double denom = (double)A.dim * (double)A.dim;
@@ -538,7 +539,16 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   }
   if ((C.loc.expanded() || C.loc.loose() || C.loc.blocked()) && &C != &A && &C != &B) pack(C.loc);   // (beta != 0 reads it below; otherwise it is replaced)
   if (S <= 1) {
-    AB = multiply_panel(A, B, alpha, threshold);
+    // (a one-call session of the C ABI: should the product turn out to belong to the block path -- decided inside spgemm()
+    // once the run-based kernels have declined -- it stays in block form, and the refusal above was not one)
+    const bool keep_block = g_slab_depth > 0 && g_session_api && !g_slab_failed && !A.cplx && std::fabs(beta) < 2.2250738585072014e-308;
+    if (keep_block) {
+      BlockKeepScope keep;
+      AB = multiply_panel(A, B, alpha, threshold);
+    } else {
+      AB = multiply_panel(A, B, alpha, threshold);
+    }
+    if (AB.blocked() && g_slab_refusals > 0) { g_slab_refusals -= 1; g_session_did_work = true; }
   } else {
     // Process slices (the reference's 2.5-D algorithm, MatrixMultiply.f90:25-29, 74-80, 230-267): slice s multiplies
     // its share of the inner dimension -- the blocks g with g % S == s, block = padded dimension / (max(rows, columns)
@@ -888,7 +898,7 @@ bool trs2_block(PSMatrix& B, int mode, double threshold, const PSMatrix& D, doub
     if (B.loc.blocked()) pack(B.loc);
     return false;
   }
-  if (!B.loc.blocked() && (B.loc.expanded() || B.loc.loose() || !block_path_last(B.dim))) return false;
+  if (!B.loc.blocked() && (B.loc.expanded() || B.loc.loose() || !B.loc.block_hint)) return false;
   const double denom = (double)B.dim * (double)B.dim;
   const bool dense_rule = denom > 0 && (double)B.loc.nnz / denom > 0.1;
   if (trs2_block_step(B.loc, mode, threshold, dense_rule, D.loc, out)) return true;
@@ -1000,6 +1010,7 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
     scratch.loc = std::move(AB);
     axpby(scratch.loc, B.loc, -1.0, 2.0, threshold, &D.loc, out, want_trace ? &out[2] : nullptr, B.c0);
   }
+  if (last_spgemm_stats().block) B.loc.block_hint = 1;   // (the next step takes the iterate in block form: trs2_block)
   comm_allreduce_sum(out, want_trace ? 3 : 2);
 }
 
@@ -1056,6 +1067,7 @@ void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMat
   pack(B.loc);
   ps_multiply(B, B, scratch, 1.0, 0.0, threshold);
   std::swap(B.loc, scratch.loc);  // B <- B*B; scratch is recomputed by the next multiply, so no copy
+  if (last_spgemm_stats().block) B.loc.block_hint = 1;
   ps_dot_trace(B, D, out, want_trace);
 }
 

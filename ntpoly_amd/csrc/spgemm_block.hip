@@ -1214,7 +1214,9 @@ struct CachedForm {   // the block form of a matrix in compressed columns, valid
 struct BlockCache {
   CachedForm forms[4];
   unsigned long long clock = 0;
-  std::shared_ptr<BlockOrder> order;     // the order of the last dimension multiplied
+  std::shared_ptr<BlockOrder> order;     // the order of the dimension being multiplied (one of `kept`)
+  std::shared_ptr<BlockOrder> kept[4];   // the orders of the last four dimensions: a dimension's order is made once and kept
+  unsigned long long kept_used[4] = {0, 0, 0, 0};
   int32_t refused_n = -1;                // a dimension whose matrices have no blocks (remembered with the entry count it was tried on)
   int64_t refused_nnz = 0;
   int64_t pool_hint = 0;                 // tiles the last result of this dimension needed
@@ -1224,6 +1226,27 @@ BlockCache& cache() {
   static BlockCache* c = new BlockCache();
   return *c;
 }
+// makes the kept order of dimension n the current one (false: there is none)
+bool select_order(BlockCache& bc, int32_t n) {
+  if (bc.order && bc.order->n == n) return true;
+  for (int i = 0; i < 4; ++i)
+    if (bc.kept[i] && bc.kept[i]->n == n) {
+      bc.order = bc.kept[i];
+      bc.kept_used[i] = ++bc.clock;
+      return true;
+    }
+  return false;
+}
+void install_order(BlockCache& bc, const std::shared_ptr<BlockOrder>& o) {
+  int slot = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (!bc.kept[i] || bc.kept[i]->n == o->n) { slot = i; break; }
+    if (bc.kept_used[i] < bc.kept_used[slot]) slot = i;
+  }
+  bc.kept[slot] = o;
+  bc.kept_used[slot] = ++bc.clock;
+  bc.order = o;
+}
 constexpr double kMinFill = 0.08;
 
 }  // namespace
@@ -1231,6 +1254,7 @@ constexpr double kMinFill = 0.08;
 void drop_block_caches() {
   for (CachedForm& f : cache().forms) f = CachedForm();
   cache().order.reset();
+  for (auto& k : cache().kept) k.reset();
   cache().refused_n = -1;
   cache().pool_hint_n = -1;
 }
@@ -1238,7 +1262,7 @@ void drop_block_caches() {
 bool block_order_for(const DevMat& M, std::vector<int32_t>& pos_host) {
   if (M.cplx || M.rows != M.cols || M.loose() || M.expanded()) return false;
   BlockCache& c = cache();
-  if (!c.order || c.order->n != M.cols) c.order = build_block_order(M);
+  if (!select_order(c, M.cols)) install_order(c, build_block_order(M));
   pos_host.resize((size_t)M.cols);
   HIP_CHECK(hipMemcpyAsync(pos_host.data(), c.order->pos.p, sizeof(int32_t) * (size_t)M.cols, hipMemcpyDeviceToHost, stream()));
   sync_stream();
@@ -1422,7 +1446,7 @@ bool block_trs2_step(DevMat& X, int mode, double threshold, bool dense_rule, con
   if (options().spgemm_fma != 1 || options().block_path == 0 || options().spgemm_variant >= 0 || options().spgemm_force_bin > 0) return false;
   BlockCache& bc = cache();
   const int32_t n = X.cols;
-  if (!bc.order || bc.order->n != n) return false;   // (only dimensions the block path has multiplied before)
+  if (!select_order(bc, n)) return false;   // (only dimensions the block path has multiplied before)
   const int ns = bc.order->ns;
   std::shared_ptr<BlockForm> pFX;
   double fx = 0, fd = 0;
@@ -1580,22 +1604,17 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   const bool any_blocked = A.blocked() || B.blocked();
   if (!any_blocked && force != 2 && bc.refused_n == n && (double)A.nnz <= 1.5 * (double)bc.refused_nnz && (double)A.nnz >= 0.5 * (double)bc.refused_nnz) return false;
   const double min_fill = force == 2 ? 0.0 : kMinFill;
-  bool fresh = false;
-  if (!bc.order || bc.order->n != n) {
-    if (A.blocked()) return false;   // (cannot happen: a blocked operand carries the order of its dimension)
-    bc.order = build_block_order(A);
-    fresh = true;
+  // The order of a dimension is made ONCE, from the first operand that is dense enough to say something about the index
+  // set (8 entries per column), and kept: the same product gives the same bits whenever it is computed.  An operand that
+  // does not tile well in it (fill below kMinFill) goes to the LDS-hash kernels.
+  if (!select_order(bc, n)) {
+    if (A.blocked() || A.nnz < 8LL * n) return false;
+    install_order(bc, build_block_order(A));
   }
   if (bc.order->ns > kMaxSuperBlocks) return false;
   double fa = 0, fb = 0;
   bool conv = false;
   std::shared_ptr<BlockForm> pFA = operand_form(A, bc, min_fill, &fa, &conv);
-  if (!pFA && !fresh && !A.blocked()) {   // (an order made from another matrix: once more from this one)
-    bc.order = build_block_order(A);
-    fresh = true;
-    if (bc.order->ns > kMaxSuperBlocks) return false;
-    pFA = operand_form(A, bc, min_fill, &fa, &conv);
-  }
   if (!pFA) {
     bc.refused_n = n;
     bc.refused_nnz = A.nnz;

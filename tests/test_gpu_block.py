@@ -264,3 +264,48 @@ def test_block_form_trs2_steps_equal_the_separate_passes(nt, fma, L, thr):
     assert sep[2] == blk[2] and sep[3] == blk[3]
     assert abs(sep[1] - blk[1]) <= 1e-12 * abs(sep[1])
     exact(blk[0], sep[0], "density, block-form steps vs separate passes")
+
+
+def _digest(c, r, v):
+    """order-independent digest of a set of entries (column, row, value bits): two 64-bit sums of mixed keys"""
+    k = (c.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (r.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F))
+    b = np.ascontiguousarray(v, dtype=np.float64).view(np.uint64)
+    with np.errstate(over="ignore"):
+        h = (k ^ (b * np.uint64(0xD6E8FEB86659FD93))) * np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(31)
+        return int(h.sum(dtype=np.uint64)), int((h * np.uint64(0x94D049BB133111EB)).sum(dtype=np.uint64)), len(v)
+
+
+def test_lattice64_product_bit_exact_at_the_benched_size(nt, fma):
+    """ONE product H * H of the 64^3 lattice Hamiltonian (N = 262 144, 50 M entries, 9.7e9 intermediate products, 140 M
+    entries out at threshold 1e-8 -- the operand `bench.py --lattice 64` runs on) through the block path against the oracle's
+    FMA mode on the relabelled matrix (about 12 s of oracle on the host cores): the same 140 M entries, bit for bit
+    (compared through an order-independent digest of (column, row, value bits))."""
+    O = fma
+    L = 64
+    n = L ** 3
+    thr = 1e-8
+    col, row, val = lattice_triplets(L)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    nt.set_option("slab_algebra", 0)
+    C = nt.Matrix_ps(n)
+    C.Gemm(A, A, None, 1.0, 0.0, thr)
+    assert nt.last_block_stats()["used"] == 1
+    gc, gr, gv = C.triplets()
+    del C
+    pos = nt.block_order(A)
+    del A
+    order = np.argsort(pos, kind="stable")
+    rank = np.empty(n, dtype=np.int64)
+    rank[order] = np.arange(n)
+    rc, rr, rv = relabel((col, row, val), rank)
+    del col, row, val
+    Ao = O.Mat.from_triplets(n, n, rc, rr, rv)
+    del rc, rr, rv
+    Co = O.ps_multiply(Ao, Ao, None, 1.0, 0.0, thr)
+    oc, orow, ov = Co.triplets()
+    del Co, Ao
+    assert len(ov) == len(gv), (len(ov), len(gv))
+    want = _digest(order[oc - 1] + 1, order[orow - 1] + 1, ov)
+    got = _digest(gc, gr, gv)
+    assert got == want

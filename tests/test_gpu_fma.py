@@ -38,6 +38,7 @@ def fma(nt):
     nt.set_option("tile_waves", 0)
     nt.set_option("spgemm_variant", -1)
     nt.set_option("spgemm_force_bin", -1)
+    nt.set_option("block_path", 1)
 
 
 def srt(t):
@@ -113,6 +114,9 @@ def test_other_real_kernels_fma_vs_oracle(nt, fma, force_bin, variant):
     A = nt.Matrix_ps.from_triplets(n, col, row, val)
     nt.set_option("spgemm_force_bin", force_bin)
     nt.set_option("spgemm_variant", variant)
+    # (this test is about the LDS kernels, whose chain runs over ascending LABEL; left to itself the engine multiplies a
+    # relabelled band through the block path -- chain over ascending position, tests/test_gpu_block.py)
+    nt.set_option("block_path", 0)
     C = nt.Matrix_ps(n)
     C.Gemm(A, A, None, 1.0, 0.0, thr)
     st = nt.last_spgemm_stats()

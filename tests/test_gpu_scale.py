@@ -288,6 +288,16 @@ def test_lattice_vs_oracle(nt, arith):
     equal and values 1e-13), in both arithmetic modes."""
     from gen import lattice_triplets
     from oracle import oracle_py as O
+    # (this test pins the LDS-hash kernels and their row strips, whose chain runs over ascending label, in both modes; in
+    # FMA arithmetic the engine's own choice for this operand is the block path: tests/test_gpu_block.py)
+    nt.set_option("block_path", 0)
+    try:
+        _lattice_vs_oracle_body(nt, O, lattice_triplets)
+    finally:
+        nt.set_option("block_path", 1)
+
+
+def _lattice_vs_oracle_body(nt, O, lattice_triplets):
     L, thr = 32, 1e-8
     n = L ** 3
     col, row, val = lattice_triplets(L)
@@ -384,3 +394,97 @@ def test_headline_config2_relabelled_full_size(nt):
     assert np.allclose(t0["energy"], t1["energy"], rtol=1e-11, atol=0) and e0 == pytest.approx(e1, rel=1e-11)
     for q in range(3):
         assert np.array_equal(k0[q], k1[q]), q
+
+
+def test_headline_fma_all_timed_iterations_vs_oracle(nt):
+    """bench.py times iterations 6..25 of the headline solve; the full-size comparison above covers 1..8.
+    Here ALL 25 iterations of BASELINE configs[2] (N = 262 144, h = 100, threshold 1e-8) in the arithmetic the bench
+    times (FMA) against 25 iterations of the oracle in the same mode (about 2 minutes of oracle on the host cores): sigma
+    and energy of every iteration, the density entry by entry, every step inside the tile kernel's fused epilogue and
+    NONE repeated (the deferred-element list of the near-idempotent iterates did not overflow)."""
+    from oracle import oracle_py as O
+    n, h, thr, iters = 262144, 100, 1e-8, 25
+    nt.set_option("spgemm_fma", 1)
+    O.set_fma(True)
+    try:
+        col, row, val = banded_triplets(n, h)
+        H = nt.Matrix_ps.from_triplets(n, col, row, val)
+        ISQ = nt.Matrix_ps(n)
+        ISQ.FillIdentity()
+        K = nt.Matrix_ps(n)
+        f0 = nt.fusion_counts()
+        energy, mu = nt.DensityMatrixSolvers.TRS2(H, ISQ, n / 2.0, K, _fixed_iteration_params(nt, iters, thr))
+        f1 = nt.fusion_counts()
+        tr = nt.solver_trace()
+        Ho = O.Mat.from_triplets(n, n, col, row, val)
+        del col, row, val
+        Ko, e_o, mu_o, tro = O.density("trs2", Ho, O.Mat.identity(n), n / 2.0,
+                                       O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr, monitor_convergence=False))
+    finally:
+        O.set_fma(False)
+        nt.set_option("spgemm_fma", 0)
+    assert f1["repeated"] - f0["repeated"] == 0
+    assert f1["square"] + f1["update"] - f0["square"] - f0["update"] >= iters - 1
+    assert tr["iterations"] == tro["iterations"] == iters
+    assert np.array_equal(np.asarray(tr["sigma"]), np.asarray(tro["sigma"]))
+    assert np.allclose(tr["energy"], tro["energy"], rtol=1e-11, atol=0)
+    kc, kr, kv = K.triplets()
+    oc, orow, ov = Ko.triplets()
+    assert len(kv) == len(ov) and np.array_equal(kc, oc) and np.array_equal(kr, orow)
+    assert np.abs(kv - ov).max() <= 1e-13
+
+
+@pytest.mark.parametrize("solver", ["trs4", "sign"])
+def test_slab_session_solvers_at_65536_vs_oracle(nt, solver):
+    """the slab algebra (TRS4 / SignFunction with their matrices kept in slab form between products,
+    merges and dots) against the oracle beyond N = 4 096: N = 65 536, h = 100, threshold 1e-8, FMA arithmetic, a fixed
+    number of iterations of each loop -- TRS4: energies 1e-10, density to the level its sigma quotients allow;
+    SignFunction of the indefinite H: the same pattern, values 1e-12."""
+    import scipy.sparse as sp
+    from oracle import oracle_py as O
+    n, h, thr = 65536, 100, 1e-8
+    nt.set_option("spgemm_fma", 1)
+    nt.set_option("slab_algebra", 1)
+    O.set_fma(True)
+    try:
+        col, row, val = banded_triplets(n, h)
+        H = nt.Matrix_ps.from_triplets(n, col, row, val)
+        Ho = O.Mat.from_triplets(n, n, col, row, val)
+        del col, row, val
+        Out = nt.Matrix_ps(n)
+        c0 = nt.slab_algebra_counts()
+        if solver == "trs4":
+            iters = 10
+            I = nt.Matrix_ps(n)
+            I.FillIdentity()
+            e, mu = nt.DensityMatrixSolvers.TRS4(H, I, n / 2.0, Out, _fixed_iteration_params(nt, iters, thr))
+            tr = nt.solver_trace()
+            Oo, e_o, mu_o, tro = O.density("trs4", Ho, O.Mat.identity(n), n / 2.0,
+                                           O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr, monitor_convergence=False))
+        else:
+            iters = 12
+            p = nt.SolverParameters()
+            p.SetThreshold(thr)
+            p.SetConvergeDiff(1e-30)
+            p.SetMaxIterations(iters)
+            nt.SignSolvers.ComputeSign(H, Out, p)
+            tr = nt.solver_trace()
+            Oo, tro = O.matrix_function("sign", Ho, O.params(converge_diff=1e-30, max_iterations=iters, threshold=thr))
+        c1 = nt.slab_algebra_counts()
+    finally:
+        O.set_fma(False)
+        nt.set_option("spgemm_fma", 0)
+    assert c1["products"] - c0["products"] >= iters - 1          # (the loop's products ran in slab form)
+    assert tr["iterations"] == tro["iterations"]
+    g = Out.triplets()
+    w = Oo.triplets()
+    G = sp.csr_matrix((g[2], (g[1] - 1, g[0] - 1)), shape=(n, n))
+    W = sp.csr_matrix((w[2], (w[1] - 1, w[0] - 1)), shape=(n, n))
+    if solver == "trs4":
+        assert np.allclose(tr["energy"], tro["energy"], rtol=1e-10, atol=1e-10)
+        assert abs(e - e_o) <= 1e-10 * abs(e_o)
+        assert abs(G - W).max() <= 1e-6
+    else:
+        assert G.nnz == W.nnz and (G != W).nnz == (abs(G - W) > 0).nnz
+        assert abs(G - W).max() <= 1e-12 * max(1.0, abs(W).max())
+        assert (abs(G) > 0).multiply(abs(W) > 0).nnz == W.nnz      # same pattern

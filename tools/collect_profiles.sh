@@ -6,7 +6,7 @@
 # 4. the traffic summary of the dominant kernel (tools/pmc_traffic_json.py), with the fingerprint of the kernel sources
 tag=$1; shift
 extra="$@"
-kern=k_spgemm_tile,k_spgemm_slab,k_spgemm_ghash   # (the dominant one of the run is picked)
+kern=k_spgemm_tile,k_spgemm_slab,k_spgemm_ghash,k_bs_numeric   # (the dominant one of the run is picked)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$tag
 timeout 900 python3 bench.py --gpus 1 --steps 10 --warmup 3 $extra > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def sources_sha16():
     """fingerprint of the kernel sources the figure belongs to (bench.py reports the traffic only for these sources)"""
     h = hashlib.sha256()
-    for f in ("kernels.hip", "slab_loop.inc", "spgemm_grouped.hip", "spgemm_tile.hip"):
+    for f in ("kernels.hip", "slab_loop.inc", "spgemm_grouped.hip", "spgemm_tile.hip", "spgemm_block.hip"):
         with open(os.path.join(ROOT, "ntpoly_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
