@@ -614,14 +614,51 @@ __global__ __launch_bounds__(256) void k_bs_symbolic(int ns, const int64_t* __re
   }
 }
 
+// slice masks of the tiles (BlockForm::quads): a wave per super-tile, lane l looks at the words 4 l .. 4 l + 3 of every tile
+__global__ __launch_bounds__(256) void k_bs_quads(int64_t nst, const int32_t* __restrict__ smask, const int64_t* __restrict__ sbase,
+                                                  const double* __restrict__ tiles, unsigned long long* __restrict__ quads) {
+  const int64_t s = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE;
+  if (s >= nst) return;
+  const int lane = lane_id();
+  const int w0 = 4 * lane, col_t = w0 >> 4, ch = (w0 & 15) >> 1;
+  const int cq = phys(col_t) >> 2;                       // column slice of this lane's words
+  int rq[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) rq[e] = phys(((((ch + (e >> 1)) ^ (col_t >> 1)) & 7) << 1) | (e & 1)) >> 2;
+  const unsigned mk = (unsigned)smask[s];
+  const double* __restrict__ base = tiles + sbase[s] * 256;
+  unsigned long long colq = 0, rowq = 0;
+  int rank = 0;
+  for (int t = 0; t < 16; ++t) {
+    if ((mk & (1u << t)) == 0) continue;
+    const v4d v = *reinterpret_cast<const v4d*>(base + rank * 256 + w0);
+    rank += 1;
+    unsigned c4 = 0, r4 = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (v[e] != 0.0) { c4 |= 1u << cq; r4 |= 1u << rq[e]; }
+    for (int o = 32; o > 0; o >>= 1) { c4 |= __shfl_xor(c4, o, WAVE); r4 |= __shfl_xor(r4, o, WAVE); }
+    colq |= (unsigned long long)c4 << (4 * t);
+    rowq |= (unsigned long long)r4 << (4 * t);
+  }
+  if (lane == 0) { quads[2 * s] = colq; quads[2 * s + 1] = rowq; }
+}
+void block_quads(BlockForm& F) {
+  if (F.have_quads) return;
+  F.quads.alloc((size_t)2 * std::max<int64_t>(1, F.nst));
+  if (F.nst > 0)
+    hipLaunchKernelGGL(k_bs_quads, dim3(gridw(F.nst)), dim3(256), 0, stream(), F.nst, F.smask.p, F.sbase.p, F.tiles.p, F.quads.p);
+  F.have_quads = true;
+}
+
 // =====================================================================================================================
 // 4. numeric phase
 // =====================================================================================================================
 struct BsArgs {
   // left operand by super-rows, right operand by super-columns
   const int64_t* roffA; const int32_t* rcolA; const int32_t* ridxA;
-  const int32_t* smaskA; const int64_t* sbaseA; const double* tilesA;
-  const int64_t* soffB; const int32_t* srowB; const int32_t* smaskB; const int64_t* sbaseB; const double* tilesB;
+  const int32_t* smaskA; const int64_t* sbaseA; const double* tilesA; const unsigned long long* quadsA;
+  const int64_t* soffB; const int32_t* srowB; const int32_t* smaskB; const int64_t* sbaseB; const double* tilesB; const unsigned long long* quadsB;
   // candidates and results
   int64_t ncand;
   const int32_t *ci, *cj;
@@ -632,7 +669,7 @@ struct BsArgs {
   int32_t* ccnt;         // [ncand] kept entries
   double* pool;          // tile pool of the result
   int64_t pool_tiles;    // its capacity
-  unsigned long long* counters;   // [0] tiles handed out, [1] overflow flag, [2] tile products issued
+  unsigned long long* counters;   // [0] tiles handed out, [1] overflow flag, [2] matrix instructions issued
   double alpha, threshold;
   int dense_rule;
   int nwg;
@@ -696,6 +733,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const unsigned mA = (unsigned)uni_i32(a.smaskA[ia_s]), mB = (unsigned)uni_i32(a.smaskB[ib_s]);
       const double* __restrict__ tA = a.tilesA + uni_i64(a.sbaseA[ia_s]) * 256;
       const double* __restrict__ tB = a.tilesB + uni_i64(a.sbaseB[ib_s]) * 256;
+      const unsigned long long cqA = (unsigned long long)uni_i64((int64_t)a.quadsA[2 * (int64_t)ia_s]);       // column slices of A's tiles
+      const unsigned long long rqB = (unsigned long long)uni_i64((int64_t)a.quadsB[2 * ib_s + 1]);            // row slices of B's tiles
 #pragma unroll 1
       for (int kb = 0; kb < 4; ++kb) {
         const unsigned colA = (mA >> (4 * kb)) & 15u;            // bit x: tile A(x, kb)
@@ -722,18 +761,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           if (colA & (1u << x)) {
+            const unsigned ca4 = (unsigned)(cqA >> (4 * (4 * kb + x))) & 15u;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
               if (rowB & (1u << (4 * b))) {
-                acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][0], b01[b][0], acc[x][b], 0, 0, 0);
-                acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][1], b01[b][1], acc[x][b], 0, 0, 0);
-                acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][2], b23[b][0], acc[x][b], 0, 0, 0);
-                acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][3], b23[b][1], acc[x][b], 0, 0, 0);
+                // instruction q = column slice q of the A tile times row slice q of the B tile: skipped when either is empty
+                const unsigned m4 = ca4 & ((unsigned)(rqB >> (4 * (4 * b + kb))) & 15u);
+                if (m4 & 1u) acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][0], b01[b][0], acc[x][b], 0, 0, 0);
+                if (m4 & 2u) acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][1], b01[b][1], acc[x][b], 0, 0, 0);
+                if (m4 & 4u) acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][2], b23[b][0], acc[x][b], 0, 0, 0);
+                if (m4 & 8u) acc[x][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][3], b23[b][1], acc[x][b], 0, 0, 0);
+                nprod += __popc(m4);
               }
             }
           }
         }
-        nprod += __popc(colA) * __popc(rowB);
       }
     }
   }
@@ -1277,6 +1319,8 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
                    unsigned long long* nprod_out, const DevMat* Acsc, const DevMat* Bcsc) {
   const int32_t n = bc.order->n;
   build_rows(FA);
+  block_quads(FA);
+  block_quads(FB);
   const int ns = bc.order->ns;
   // ---- symbolic
   static bool attr_done = false;
@@ -1329,6 +1373,7 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
     BsArgs a;
     a.roffA = FA.roff.p; a.rcolA = FA.rcol.p; a.ridxA = FA.ridx.p; a.smaskA = FA.smask.p; a.sbaseA = FA.sbase.p; a.tilesA = FA.tiles.p;
     a.soffB = FB.soff.p; a.srowB = FB.srow.p; a.smaskB = FB.smask.p; a.sbaseB = FB.sbase.p; a.tilesB = FB.tiles.p;
+    a.quadsA = FA.quads.p; a.quadsB = FB.quads.p;
     a.ncand = ncand; a.ci = ci.p; a.cj = cj.p; a.order = order.p; a.cmask = cmask.p; a.cbase = cbase.p; a.ccnt = ccnt.p;
     a.pool = FC.tiles.p; a.pool_tiles = pool; a.counters = counters.p;
     a.alpha = alpha; a.threshold = threshold; a.dense_rule = dense_rule ? 1 : 0;
@@ -1585,7 +1630,7 @@ bool block_trs2_step(DevMat& X, int mode, double threshold, bool dense_rule, con
     info->fill_a = fx; info->fill_b = fx;
     info->tiles_a = FX.ntiles; info->tiles_b = FX.ntiles; info->tiles_c = (int64_t)hc[0];
     info->cand = ncand;
-    info->tile_products = (int64_t)hc[2];
+    info->tile_products = (int64_t)((hc[2] + 3) / 4);   // (matrix instructions issued / 4: slices without entries are skipped)
     info->nnz_c = (int64_t)nnzP;
     info->products = (int64_t)nprod;
   }
@@ -1658,7 +1703,7 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
     info->fill_a = fa; info->fill_b = fb;
     info->tiles_a = FA.ntiles; info->tiles_b = FB->ntiles; info->tiles_c = (int64_t)hc[0];
     info->cand = ncand;
-    info->tile_products = (int64_t)hc[2];
+    info->tile_products = (int64_t)((hc[2] + 3) / 4);   // (matrix instructions issued / 4: slices without entries are skipped)
     info->nnz_c = (int64_t)nnzC;
     info->products = (int64_t)nprod;
   }

@@ -48,6 +48,12 @@ struct BlockForm {
   // of the AddSparseVectors rules in the caller's labels.  Written by the merge that produced the matrix, or on first use.
   DevBuf<int32_t> ccount, plast;
   bool have_stat = false;
+  // per super-tile two words of 16 x 4 bits (tile bit t at bits 4 t .. 4 t + 3): [2 s] which of the four 4-column slices
+  // (in-block positions 4 q .. 4 q + 3) of tile t hold an entry, [2 s + 1] which 4-row slices.  A matrix instruction q of a
+  // tile pair multiplies column slice q of the A tile with row slice q of the B tile: skipped when either is empty.
+  // Computed on first use as an operand (one pass over the tiles).
+  DevBuf<unsigned long long> quads;
+  bool have_quads = false;
 };
 
 struct BlockInfo {
