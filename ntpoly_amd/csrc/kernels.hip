@@ -4175,12 +4175,16 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   // (a fifth more than needed: the iterates fill in over the first steps of a solve, and a block that is too small
   // next time costs a hipMalloc inside the loop)
   const size_t oslots = (size_t)tmp_total + (size_t)tmp_total / 5 + kIndexSlack;
-  DevBuf<double> oval(oslots), otiles(oslots);
+  // (FMA arithmetic on one rank: the result carries runs only -- the next step's multiplier tiles come from the runs, which
+  // that step reads as its left operand anyway: a third less written per launch and no tile read at all; the unfused
+  // loop and the panel steps take their multiplier rows from tiles in memory and keep them)
+  const bool runs_only = tile && !halo && options().tile_runs_only != 0;
+  DevBuf<double> oval(oslots), otiles(runs_only ? 0 : oslots);
   SlabFuseArgs fz;
   fz.am = fu.am; fz.bm = fu.bm; fz.thr_m = fu.threshold;
   fz.xexp = in.val.p; fz.xoff = in.off.p; fz.xmin = in.first.p; fz.xmax = in.last.p;
   fz.dexp = dop.dexp.p; fz.doff = dop.doff.p; fz.dmin = dop.dmin.p; fz.dmax = dop.dmax.p;
-  fz.ofirst = ofirst.p; fz.olast = olast.p; fz.tiles = otiles.p;
+  fz.ofirst = ofirst.p; fz.olast = olast.p; fz.tiles = runs_only ? nullptr : otiles.p;
   fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
   fz.col_offset = fu.col_offset;
   int64_t* blk_prod = zwords.p + 3 + snb;
@@ -4246,7 +4250,12 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     tile_otoff.alloc((size_t)snb + 1);
     TileLaunch tl;
     tl.runs = reinterpret_cast<const SlabRun*>(runs.p) - ka;
-    tl.bblk = in.tiles.p; tl.blk_boff = in.tile_off.p; tl.blk_kmin = blk_kmin.p; tl.blk_kn = blk_kn.p; tl.blk_lo = blk_lo.p;
+    tl.bblk = in.tiles.p; tl.blk_boff = in.tile_off.p;
+    if (in.tiles.p == nullptr || in.tile_off.p == nullptr) {   // (the iterate carries runs only: the right operand from its runs)
+      tl.bblk = nullptr; tl.blk_boff = nullptr;
+      tl.brun_first = in.first.p; tl.brun_last = in.last.p; tl.brun_off = in.off.p; tl.brun_val = in.val.p;
+    }
+    tl.blk_kmin = blk_kmin.p; tl.blk_kn = blk_kn.p; tl.blk_lo = blk_lo.p;
     tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = oval.p; tl.count = count.p;
     tl.ofirst = ofirst.p; tl.olast = olast.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
     tl.alpha = 1.0; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
@@ -4329,7 +4338,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   R.slab->off = tile ? std::move(tile_ooff) : std::move(tmpoff);
   R.slab->tile_off = tile ? std::move(tile_otoff) : std::move(plan->blk_toff);   // (the slab loop's result keeps the plan's tile offsets)
   R.slab->val = std::move(oval);
-  R.slab->tiles = std::move(otiles);
+  if (runs_only) { R.slab->tile_off.release(); } else R.slab->tiles = std::move(otiles);
   R.slab->slots = tmp_total;
   if (labelled || tile_labelled) {
     R.slab->lab = std::move(X.slab->lab);

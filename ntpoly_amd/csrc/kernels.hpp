@@ -57,6 +57,9 @@ struct EngineOptions {
                                // ntpoly_amd_release_cache() frees it at any time
   int tile_rows = 2;           // MFMA tile kernel (spgemm_fma = 1): consecutive rows per lane of the A operand, 1 / 2 / 4 (spgemm_tile.hpp)
   int tile_waves = 0;          // ... waves per workgroup, 4 / 8 (0: chosen from the LDS footprint)
+  int tile_runs_only = 1;      // TRS2 steps on the tile kernel (one rank): the result is written as runs only and the next step builds its
+                               // multiplier tiles from them (1.5 GB -> 1.0 GB written per launch at the headline size, no tile read);
+                               // 0: runs + multiplier tiles as the unfused loop needs them
   int load_balance = 1;        // 1: solvers permute with the caller's load-balancing permutation as the reference does;
                                // 0: SetParametersLoadBalance is ignored -- the same results up to summation order (a
                                // symmetric permutation only relabels entries), but banded operands stay on the run-based

@@ -11,6 +11,7 @@
 #include <random>
 
 #include "engine.hpp"
+#include "spgemm_block.hpp"
 
 namespace ntp {
 
@@ -132,6 +133,14 @@ void unblock(std::initializer_list<const PSMatrix*> ms) {
   for (const PSMatrix* m : ms)
     if (m->loc.blocked()) pack(mut(*m));
 }
+// the block algebra (spgemm_block.hpp) takes an operation when an operand is in block form (one rank)
+bool blk_any(std::initializer_list<const PSMatrix*> ms) {
+  if (world().active()) return false;
+  for (const PSMatrix* m : ms)
+    if (m->loc.blocked()) return true;
+  return false;
+}
+long long g_block_counts[2] = {0, 0};   // operations of the block algebra; fallbacks to compressed columns
 // an operation outside the session, or after a refusal: no operand may stay in slab form
 void slab_pack_if(std::initializer_list<const PSMatrix*> ms) {
   if (g_slab_depth == 0) return;   // (outside a session nothing is left in slab form by one)
@@ -141,6 +150,7 @@ void slab_pack_if(std::initializer_list<const PSMatrix*> ms) {
 }  // namespace
 
 const long long* slab_algebra_counts() { return g_slab_counts; }
+const long long* block_algebra_counts() { return g_block_counts; }
 
 SlabSession::SlabSession(bool eligible, bool api) {
   opened = eligible && options().slab_algebra != 0 && (options().spgemm_fma == 1 || options().spgemm_fma == 0) && options().spgemm_variant < 0 &&
@@ -177,6 +187,16 @@ void ps_slab_leave(PSMatrix& m) {
 
 void ps_copy(const PSMatrix& a, PSMatrix& b) {
   if (&a == &b) return;
+  if (blk_any({&a})) {
+    DevMat t;
+    if (block_clone(a.loc, t)) {
+      g_block_counts[0] += 1;
+      b.grid = a.grid; b.dim = a.dim; b.cplx = a.cplx; b.c0 = a.c0; b.c1 = a.c1;
+      b.loc = std::move(t);
+      return;
+    }
+    g_block_counts[1] += 1;
+  }
   unblock({&a});
   if (slab_on() && a.loc.expanded()) {
     DevMat t;
@@ -494,7 +514,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   // A one-call session of the C ABI on operands without run structure (or already in block form): the product goes
   // through the block path and STAYS in block form (DevMat::blk) -- the next product of the caller's loop multiplies it
   // as it is, every other entry point packs on access.  Solver loops (sessions of their own) take compressed columns.
-  const bool block_first = slab_on() && g_session_api && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 &&
+  const bool block_first = slab_on() && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 &&
                            (A.loc.blocked() || B.loc.blocked() || A.loc.block_hint || B.loc.block_hint) && !A.loc.expanded() && !B.loc.expanded() &&
                            !A.loc.loose() && !B.loc.loose();
   if (block_first) {
@@ -541,7 +561,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
   if (S <= 1) {
     // (a one-call session of the C ABI: should the product turn out to belong to the block path -- decided inside spgemm()
     // once the run-based kernels have declined -- it stays in block form, and the refusal above was not one)
-    const bool keep_block = g_slab_depth > 0 && g_session_api && !g_slab_failed && !A.cplx && std::fabs(beta) < 2.2250738585072014e-308;
+    const bool keep_block = g_slab_depth > 0 && !g_slab_failed && !A.cplx && std::fabs(beta) < 2.2250738585072014e-308;
     if (keep_block) {
       BlockKeepScope keep;
       AB = multiply_panel(A, B, alpha, threshold);
@@ -594,6 +614,10 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
 // IncrementMatrix_ps (PSMatrixAlgebraModule.F90:414-460)
 void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold) {
   if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
+  if (blk_any({&A, &B}) && &A != &B && !A.cplx && !B.cplx) {
+    ps_axpby(A, B, alpha, 1.0, threshold);
+    return;
+  }
   unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && &A != &B) {
     ps_axpby(A, B, alpha, 1.0, threshold);
@@ -617,6 +641,10 @@ void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold
 }
 
 void ps_scale(PSMatrix& A, double c) {
+  if (blk_any({&A})) {
+    if (block_scale(A.loc, c)) { g_block_counts[0] += 1; return; }
+    g_block_counts[1] += 1;
+  }
   unblock({&A});
   if (slab_on() && A.loc.expanded()) {
     if (slab_scale(A.loc, c)) { g_slab_counts[2] += 1; g_session_did_work = true; return; }
@@ -629,6 +657,10 @@ void ps_scale(PSMatrix& A, double c) {
 // merge kernels scale B's values as they read them: the same products, the same rules, bit for bit)
 void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold) {
   if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
+  if (blk_any({&A, &B}) && !A.cplx && !B.cplx && &A != &B && !A.loc.expanded() && !B.loc.expanded() && !A.loc.loose() && !B.loc.loose()) {
+    if (block_axpby(A.loc, B.loc, alpha, beta, threshold)) { g_block_counts[0] += 1; return; }
+    g_block_counts[1] += 1;
+  }
   unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B) {
     // (a slab session: the operand still in compressed columns -- an identity, the Hamiltonian -- is turned into slab form)
@@ -681,6 +713,11 @@ bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatr
 }
 
 void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double alpha, double beta, double threshold) {
+  if (blk_any({&A, &B}) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B) {
+    ps_copy(B, Out);
+    ps_axpby(A, Out, alpha, beta, threshold);
+    return;
+  }
   unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B && A.dim == B.dim) {
     DevMat R;
@@ -887,7 +924,12 @@ namespace {
 // a fused TRS2 step reads the iterate's multiplier tiles; an iterate that the slab algebra left in slab form (runs only,
 // or the read-only view of a matrix with stored zeros) goes back to compressed columns first
 void trs2_iterate_form(PSMatrix& B) {
-  if (B.loc.expanded() && (B.loc.slab->tiles.p == nullptr || B.loc.slab->tile_off.p == nullptr || B.loc.slab->origin)) pack(B.loc);
+  if (!B.loc.expanded()) return;
+  // (the MFMA tile kernel on one rank builds its multiplier tiles from the runs; the unfused loop and the panel steps
+  // read them from memory)
+  const bool need_tiles = options().spgemm_fma != 1 || world().active();
+  const bool no_tiles = B.loc.slab->tiles.p == nullptr || B.loc.slab->tile_off.p == nullptr;
+  if (B.loc.slab->origin || (need_tiles && no_tiles)) pack(B.loc);
 }
 }  // namespace
 
@@ -1103,6 +1145,13 @@ void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {
 // DotMatrix_psr/psc (PSMatrixAlgebraModule.F90:387-410, distributed_algebra_includes/DotMatrix.f90):
 // sum conj(A).B; fused, no Hadamard temporary.
 void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
+  if (blk_any({&A, &B}) && !A.cplx && !B.cplx) {
+    double d = 0.0;
+    // (the sum runs over the super-tiles of its first operand: the one in block form)
+    const bool ok = A.loc.blocked() ? block_dot_trace(A.loc, B.loc, &d, nullptr) : block_dot_trace(B.loc, A.loc, &d, nullptr);
+    if (ok) { g_block_counts[0] += 1; out[0] = d; out[1] = 0.0; return; }
+    g_block_counts[1] += 1;
+  }
   unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx) {
     if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_dot(A.loc, B.loc, out)) { g_slab_counts[2] += 1; g_session_did_work = true; return; }
@@ -1122,6 +1171,11 @@ void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
 }
 
 double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includes/MatrixTrace.f90)
+  if (blk_any({&A}) && !A.cplx) {
+    double t = 0.0;
+    if (block_dot_trace(A.loc, A.loc, nullptr, &t)) { g_block_counts[0] += 1; return t; }
+    g_block_counts[1] += 1;
+  }
   unblock({&A});
   if (slab_on() && A.loc.expanded() && !A.cplx) {
     double v = 0.0;
@@ -1139,6 +1193,11 @@ double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includ
 }
 
 double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns are local
+  if (blk_any({&A}) && !A.cplx) {
+    double v = 0.0;
+    if (block_norm(A.loc, &v)) { g_block_counts[0] += 1; return v; }
+    g_block_counts[1] += 1;
+  }
   unblock({&A});
   if (slab_on() && A.loc.expanded()) {
     double v = 0.0;

@@ -1242,6 +1242,29 @@ __global__ __launch_bounds__(256) void k_bs_expand_j(int ns, const int64_t* __re
   for (int64_t t = soff[J] + lane_id(); t < soff[J + 1]; t += WAVE) cj[t] = J;
 }
 
+__global__ __launch_bounds__(256) void k_bs_scale(int64_t nwords, double* __restrict__ tiles, double c) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < nwords) tiles[i] = __dmul_rn(c, tiles[i]);
+}
+// max over the columns of the sum of |v| (non-negative doubles order like their bit patterns)
+__global__ __launch_bounds__(256) void k_bs_colabs_max(int ns, const int64_t* __restrict__ soff, const int32_t* __restrict__ smask,
+                                                       const int64_t* __restrict__ sbase, const double* __restrict__ tiles,
+                                                       unsigned long long* __restrict__ out) {
+  const int pc = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
+  if (pc >= 64 * ns) return;
+  const int lane = lane_id(), J = pc >> 6, cb = (pc >> 4) & 3, a = lane >> 4, i = lane & 15;
+  const int bit = 4 * cb + a;
+  const int coloff = tile_word(i, phys(pc & 15));
+  double s = 0.0;
+  for (int64_t t = soff[J]; t < soff[J + 1]; ++t) {
+    const unsigned mk = (unsigned)smask[t];
+    if ((mk & (1u << bit)) == 0) continue;
+    s = __dadd_rn(s, fabs(tiles[(sbase[t] + __popc(mk & ((1u << bit) - 1u))) * 256 + coloff]));
+  }
+  s = wave_sum_f64(s);
+  if (lane == 0) atomicMax(out, (unsigned long long)__double_as_longlong(s));
+}
+
 // =====================================================================================================================
 // caches
 // =====================================================================================================================
@@ -1442,6 +1465,7 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
 DevMat block_unpack(const DevMat& M) {
   DevMat R;
   from_block(*M.blk, M.nnz, R);
+  R.block_hint = 1;   // (its next product goes to the block path first)
   return R;
 }
 
@@ -1634,6 +1658,208 @@ bool block_trs2_step(DevMat& X, int mode, double threshold, bool dense_rule, con
     info->nnz_c = (int64_t)nnzP;
     info->products = (int64_t)nprod;
   }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// block algebra
+namespace {
+bool algebra_ok(const DevMat& M) {
+  return !M.cplx && M.rows == M.cols && !M.loose() && !M.expanded() && options().spgemm_fma == 1 && options().block_path != 0 &&
+         options().spgemm_variant < 0 && options().spgemm_force_bin <= 0;
+}
+// the form of an operand of the algebra in the order of its dimension (nullptr: none / other order)
+std::shared_ptr<BlockForm> algebra_form(const DevMat& M, BlockCache& bc) {
+  if (!algebra_ok(M) || M.nnz == 0 || !select_order(bc, M.cols)) return nullptr;
+  if (bc.order->ns > kMaxSuperBlocks) return nullptr;
+  double fill = 0;
+  bool conv = false;
+  if (M.blocked() && M.blk->order.get() != bc.order.get()) return nullptr;
+  return operand_form(M, bc, 0.0, &fill, &conv);
+}
+DevMat blocked_matrix(int32_t n, int64_t nnz, BlockForm&& F) {
+  DevMat R;
+  R.rows = n; R.cols = n; R.cplx = false; R.nnz = nnz; R.zero_free = 1; R.block_hint = 1;
+  R.blk.reset(new BlockForm(std::move(F)));
+  return R;
+}
+void set_dummy_d(BsMergeArgs& a, const int64_t* zero_soff) {
+  a.soffD = zero_soff; a.srowD = nullptr; a.smaskD = nullptr; a.sbaseD = nullptr; a.tilesD = nullptr;
+}
+}  // namespace
+
+bool block_axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold) {
+  if (&A == &B || alpha == 0.0 || beta == 0.0 || A.cols != B.cols) return false;
+  if (!A.blocked() && !B.blocked()) return false;
+  BlockCache& bc = cache();
+  std::shared_ptr<BlockForm> pA = algebra_form(A, bc), pB = algebra_form(B, bc);
+  if (!pA || !pB) return false;
+  BlockForm &FA = *pA, &FB = *pB;
+  const int32_t n = B.cols;
+  const int ns = bc.order->ns;
+  block_colstat(FA);
+  block_colstat(FB);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_union<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bs_union<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_done = true;
+  }
+  const size_t lds = (size_t)((ns + 31) / 32) * 4;
+  DevBuf<int32_t> ucount((size_t)ns);
+  DevBuf<int64_t> uoff((size_t)ns + 1), zsoff((size_t)ns + 1);
+  zsoff.zero();
+  hipLaunchKernelGGL((k_bs_union<false>), dim3(ns), dim3(256), lds, stream(), ns, FB.soff.p, FB.srow.p, FA.soff.p, FA.srow.p, ucount.p,
+                     (const int64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+  scan_i32_async(ucount.p, uoff.p, (int64_t)ns);
+  int64_t nc = 0;
+  {
+    ScalarFetch f;
+    f.add(uoff.p + ns, 1, &nc);
+    f.run();
+  }
+  if (nc == 0) return false;
+  DevBuf<int32_t> ci((size_t)nc), cj((size_t)nc), cmask((size_t)nc), ccnt((size_t)nc), flag((size_t)nc);
+  DevBuf<int64_t> cbase((size_t)nc), excl((size_t)nc + 1);
+  DevBuf<double> pdot((size_t)2 * nc);
+  hipLaunchKernelGGL((k_bs_union<true>), dim3(ns), dim3(256), lds, stream(), ns, FB.soff.p, FB.srow.p, FA.soff.p, FA.srow.p, (int32_t*)nullptr,
+                     uoff.p, ci.p, cj.p);
+  BlockForm FN;
+  FN.order = bc.order;
+  FN.ns = ns;
+  const int64_t pool = FA.ntiles + FB.ntiles;
+  FN.tiles.alloc((size_t)pool * 256 + 512);
+  FN.ccount.alloc((size_t)64 * ns);
+  FN.plast.alloc((size_t)64 * ns);
+  FN.ccount.zero();
+  HIP_CHECK(hipMemsetAsync(FN.plast.p, 0xFF, sizeof(int32_t) * (size_t)64 * ns, stream()));
+  DevBuf<unsigned long long> counters(4), tot(1);
+  counters.zero();
+  tot.zero();
+  BsMergeArgs a;
+  // (role P = A scaled by alpha, role X = B scaled by beta: IncrementMatrix(A, B, alpha) after ScaleMatrix(B, beta))
+  a.soffP = FA.soff.p; a.srowP = FA.srow.p; a.smaskP = FA.smask.p; a.sbaseP = FA.sbase.p; a.tilesP = FA.tiles.p; a.plastP = FA.plast.p;
+  a.soffX = FB.soff.p; a.srowX = FB.srow.p; a.smaskX = FB.smask.p; a.sbaseX = FB.sbase.p; a.tilesX = FB.tiles.p; a.plastX = FB.plast.p;
+  set_dummy_d(a, zsoff.p);
+  a.lab = bc.order->lab.p;
+  a.ncand = nc; a.ci = ci.p; a.cj = cj.p; a.cmask = cmask.p; a.cbase = cbase.p; a.ccnt = ccnt.p; a.pdot = pdot.p;
+  a.pool = FN.tiles.p; a.pool_tiles = pool; a.counters = counters.p; a.ccount_out = FN.ccount.p; a.plast_out = FN.plast.p;
+  a.am = alpha; a.bm = beta; a.thr = threshold;
+  hipLaunchKernelGGL((k_bs_merge<2>), dim3((unsigned)nc), dim3(64), 0, stream(), a);
+  hipLaunchKernelGGL(k_bs_flag, dim3(grid1(nc)), dim3(256), 0, stream(), nc, cmask.p, flag.p);
+  scan_i32_async(flag.p, excl.p, nc);
+  hipLaunchKernelGGL(k_bs_sum_i32, dim3(std::min(1024, grid1(nc))), dim3(256), 0, stream(), nc, ccnt.p, tot.p);
+  unsigned long long hcnt[4] = {0, 0, 0, 0}, nnzN = 0;
+  int64_t nstN = 0;
+  {
+    ScalarFetch f;
+    f.add(counters.p, 4, hcnt);
+    f.add(excl.p + nc, 1, &nstN);
+    f.add(tot.p, 1, &nnzN);
+    f.run();
+  }
+  if (hcnt[1] != 0) return false;   // (a kept value that is exactly zero: compressed columns decide)
+  FN.nst = nstN;
+  FN.ntiles = (int64_t)hcnt[0];
+  FN.nnz = (int64_t)nnzN;
+  FN.have_stat = true;
+  FN.soff.alloc((size_t)ns + 1);
+  FN.srow.alloc((size_t)std::max<int64_t>(1, nstN));
+  FN.smask.alloc((size_t)std::max<int64_t>(1, nstN));
+  FN.sbase.alloc((size_t)std::max<int64_t>(1, nstN));
+  hipLaunchKernelGGL(k_bs_compact, dim3(grid1(nc)), dim3(256), 0, stream(), nc, cmask.p, cbase.p, ci.p, excl.p, FN.srow.p, FN.smask.p, FN.sbase.p);
+  hipLaunchKernelGGL(k_bs_soff, dim3(grid1(ns + 1)), dim3(256), 0, stream(), ns, uoff.p, excl.p, FN.soff.p);
+  sync_stream();   // (the candidate arrays are released on return)
+  B = blocked_matrix(n, (int64_t)nnzN, std::move(FN));
+  return true;
+}
+
+bool block_scale(DevMat& A, double c) {
+  if (!A.blocked() || !algebra_ok(A) || c == 0.0) return false;
+  // (the tiles may be shared with a copy made by block_clone's cheap path: they are not -- clones are deep)
+  BlockForm& F = *A.blk;
+  const int64_t nw = F.ntiles * 256;
+  if (nw > 0) hipLaunchKernelGGL(k_bs_scale, dim3(grid1(nw)), dim3(256), 0, stream(), nw, F.tiles.p, c);
+  return true;
+}
+
+bool block_clone(const DevMat& A, DevMat& Out) {
+  if (!A.blocked() || !algebra_ok(A)) return false;
+  const BlockForm& F = *A.blk;
+  BlockForm G;
+  G.order = F.order; G.ns = F.ns; G.nst = F.nst; G.ntiles = F.ntiles; G.nnz = F.nnz;
+  auto dup = [](auto& dst, const auto& src, size_t count) {
+    using T = std::remove_reference_t<decltype(*src.p)>;
+    dst.alloc(std::max<size_t>(1, count));
+    if (count) HIP_CHECK(hipMemcpyAsync(dst.p, src.p, sizeof(T) * count, hipMemcpyDeviceToDevice, stream()));
+  };
+  dup(G.soff, F.soff, (size_t)F.ns + 1);
+  dup(G.srow, F.srow, (size_t)F.nst);
+  dup(G.smask, F.smask, (size_t)F.nst);
+  dup(G.sbase, F.sbase, (size_t)F.nst);
+  // (the tiles of the copy are packed: slot s of the copy = slot s of the original's pool, whose used part is contiguous)
+  G.tiles.alloc((size_t)F.ntiles * 256 + 512);
+  if (F.ntiles) HIP_CHECK(hipMemcpyAsync(G.tiles.p, F.tiles.p, sizeof(double) * (size_t)F.ntiles * 256, hipMemcpyDeviceToDevice, stream()));
+  if (F.have_stat) {
+    dup(G.ccount, F.ccount, (size_t)64 * F.ns);
+    dup(G.plast, F.plast, (size_t)64 * F.ns);
+    G.have_stat = true;
+  }
+  if (F.have_quads) {
+    dup(G.quads, F.quads, (size_t)2 * std::max<int64_t>(1, F.nst));
+    G.have_quads = true;
+  }
+  Out = blocked_matrix(A.cols, A.nnz, std::move(G));
+  return true;
+}
+
+bool block_dot_trace(const DevMat& A, const DevMat& B, double* dot, double* trace_a) {
+  if (A.cols != B.cols || (!A.blocked() && !B.blocked())) return false;
+  BlockCache& bc = cache();
+  std::shared_ptr<BlockForm> pA = algebra_form(A, bc), pB = algebra_form(B, bc);
+  if (!pA || !pB) return false;
+  BlockForm &FA = *pA, &FB = *pB;
+  const int ns = bc.order->ns;
+  const int64_t nc = FA.nst;
+  if (nc == 0) { if (dot) *dot = 0.0; if (trace_a) *trace_a = 0.0; return true; }
+  DevBuf<int32_t> cj((size_t)nc);
+  DevBuf<double> pdot((size_t)2 * nc), part(512), res(2);
+  hipLaunchKernelGGL(k_bs_expand_j, dim3(gridw(ns)), dim3(256), 0, stream(), ns, FA.soff.p, cj.p);
+  BsMergeArgs a;
+  a.soffP = FA.soff.p; a.srowP = FA.srow.p; a.smaskP = FA.smask.p; a.sbaseP = FA.sbase.p; a.tilesP = FA.tiles.p; a.plastP = nullptr;
+  a.soffX = nullptr; a.srowX = nullptr; a.smaskX = nullptr; a.sbaseX = nullptr; a.tilesX = nullptr; a.plastX = nullptr;
+  a.soffD = FB.soff.p; a.srowD = FB.srow.p; a.smaskD = FB.smask.p; a.sbaseD = FB.sbase.p; a.tilesD = FB.tiles.p;
+  a.lab = bc.order->lab.p;
+  a.ncand = nc; a.ci = FA.srow.p; a.cj = cj.p; a.cmask = nullptr; a.cbase = nullptr; a.ccnt = nullptr; a.pdot = pdot.p;
+  a.pool = nullptr; a.pool_tiles = 0; a.counters = nullptr; a.ccount_out = nullptr; a.plast_out = nullptr;
+  a.am = 1.0; a.bm = 0.0; a.thr = 0.0;
+  hipLaunchKernelGGL((k_bs_merge<1>), dim3((unsigned)nc), dim3(64), 0, stream(), a);
+  hipLaunchKernelGGL(k_bs_sum_pairs, dim3(256), dim3(256), 0, stream(), nc, pdot.p, part.p);
+  hipLaunchKernelGGL(k_bs_sum_pairs, dim3(1), dim3(256), 0, stream(), (int64_t)256, part.p, res.p);
+  double h[2] = {0, 0};
+  {
+    ScalarFetch f;
+    f.add(res.p, 2, h);
+    f.run();
+  }
+  if (dot) *dot = h[0];
+  if (trace_a) *trace_a = h[1];
+  return true;
+}
+
+bool block_norm(const DevMat& A, double* out) {
+  if (!A.blocked() || !algebra_ok(A)) return false;
+  const BlockForm& F = *A.blk;
+  DevBuf<unsigned long long> mx(1);
+  mx.zero();
+  hipLaunchKernelGGL(k_bs_colabs_max, dim3(gridw((int64_t)64 * F.ns)), dim3(256), 0, stream(), F.ns, F.soff.p, F.smask.p, F.sbase.p, F.tiles.p, mx.p);
+  unsigned long long h = 0;
+  {
+    ScalarFetch f;
+    f.add(mx.p, 1, &h);
+    f.run();
+  }
+  std::memcpy(out, &h, sizeof(double));
   return true;
 }
 

@@ -84,5 +84,15 @@ bool block_trs2_step(DevMat& X, int mode, double threshold, bool dense_rule, con
 // pos_host[index] = position
 bool block_order_for(const DevMat& M, std::vector<int32_t>& pos_host);
 void drop_block_caches();
+// Block algebra (one rank, real, FMA arithmetic): the vocabulary of the solver loops on matrices in block form -- the
+// counterpart of the slab algebra (kernels.hpp) for operands without runs.  Operands are in block form or in compressed
+// columns (converted through the per-matrix cache: an identity, the Hamiltonian).  The same element rules as on
+// compressed columns (AddSparseVectors with the tail rule in the caller's labels); dots and traces as fixed-shape sums.
+// Every function returns false and leaves its operands alone when it cannot take them.
+bool block_axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold);   // B <- alpha A + beta B
+bool block_scale(DevMat& A, double c);
+bool block_clone(const DevMat& A, DevMat& Out);
+bool block_dot_trace(const DevMat& A, const DevMat& B, double* dot, double* trace_a);   // sum a b; trace(A)
+bool block_norm(const DevMat& A, double* out);   // max column abs-sum
 
 }  // namespace ntp

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   [[maybe_unused]] bool brun = false;
   [[maybe_unused]] int bf0 = INT_MAX, bl0 = -1, bf1 = INT_MAX, bl1 = -1;
   [[maybe_unused]] const double *bp0 = nullptr, *bp1 = nullptr;
-  if constexpr (EPI == 0) {
+  {   // (EPI 0: the slab algebra's right operand; EPI 1 / 2: the iterate itself -- its runs are the kernel's left operand already)
     brun = a.brun_val != nullptr;
     if (brun) {
       const int c0 = b * SLAB_J + 2 * (tid & 7);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
 #pragma unroll
   for (int u = 0; u < BCH; ++u) {
     const int i = tid + u * NT;
-    if (EPI == 0 && brun) btmp[u] = brun_load(i);
+    if (brun) btmp[u] = brun_load(i);
     else btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
   }
   {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     if (i < K4 * 8) bdst[i] = btmp[u];
   }
   for (int i = tid + BCH * NT; i < K4 * 8; i += NT) {
-    if (EPI == 0 && brun) bdst[i] = brun_load(i);
+    if (brun) bdst[i] = brun_load(i);
     else bdst[i] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
   }
   STAMP(61);
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   [[maybe_unused]] double am = 0, bm = 0, thr_m = 0;
   [[maybe_unused]] int diag = -1;
   if constexpr (EPI != 0) {
-    otile = a.fzv.tiles + (tbase - (int64_t)lo * SLAB_J + jj);                // otile[r * 16] = row r, column jj of the tile
+    // (fzv.tiles == nullptr: the result carries runs only -- the next step builds its multiplier tile from them)
+    if (a.fzv.tiles) otile = a.fzv.tiles + (tbase - (int64_t)lo * SLAB_J + jj);   // otile[r * 16] = row r, column jj of the tile
     const int d0 = a.fzv.dmin[jc], d1 = a.fzv.dmax[jc];
     if (colv && d1 >= d0) {
       df = d0;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       for (int v = 0; v < 4; ++v) rv_store<R>(orun + (r0 + R * (4 * v + q)), res[v]);
     }
     if constexpr (EPI != 0) {
-      if (cm) {
+      if (cm && otile) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
 #pragma unroll
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       for (int r = r0; r < min(r0 + TROWS, rend); ++r) dst[r] = 0.0;
     }
     if constexpr (EPI != 0) {
-      if (tk1 >= tk0 && r0 + TROWS - 1 >= tk0 && r0 <= tk1 && cmk == 0u) {
+      if (a.fzv.tiles && tk1 >= tk0 && r0 + TROWS - 1 >= tk0 && r0 <= tk1 && cmk == 0u) {
         double* dst = a.fzv.tiles + (tbase - (int64_t)lo * SLAB_J + c);
         for (int r = r0; r < min(r0 + TROWS, rend); ++r) dst[(int64_t)r * SLAB_J] = 0.0;
       }
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
         const TileDefer e = dlist[i];
         if (!e.pad) continue;
         a.out_val[tbase + (int64_t)e.jj * w + (e.r - lo)] = e.o;
-        a.fzv.tiles[tbase + (int64_t)(e.r - lo) * SLAB_J + e.jj] = e.o;
+        if (a.fzv.tiles) a.fzv.tiles[tbase + (int64_t)(e.r - lo) * SLAB_J + e.jj] = e.o;
       }
     }
   }
@@ -694,7 +695,7 @@ void launch_spgemm_tile(const TileLaunch& L) {
   const int trows = 16 * (L.rows == 4 ? 4 : L.rows == 2 ? 2 : 1);
   a.tmax = (L.max_w + trows - 1) / trows;
   if (L.fz) a.fzv = *static_cast<const SlabFuseArgs*>(L.fz);   // (a HOST copy: it travels with the kernel arguments)
-  a.brun_first = L.brun_first; a.brun_last = L.brun_last; a.brun_off = L.brun_off; a.brun_val = L.epi == 0 ? L.brun_val : nullptr;
+  a.brun_first = L.brun_first; a.brun_last = L.brun_last; a.brun_off = L.brun_off; a.brun_val = L.brun_val;
   static DevBuf<double>* zeros = nullptr;   // (never freed: lives as long as the library)
   if (!zeros) {
     zeros = new DevBuf<double>(8);

@@ -162,6 +162,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "label_order") options().label_order = *value;
   else if (n == "label_rowoff") options().label_rowoff = *value;
   else if (n == "block_path") options().block_path = *value;
+  else if (n == "tile_runs_only") options().tile_runs_only = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // the current value of the options a caller may want to report (bench.py prints the arithmetic a drop-in caller gets)
@@ -240,6 +241,11 @@ void ntpoly_amd_fusion_counts(long long* out) {
 }
 // out[0..3]: operations the solver loops did on matrices in slab form since start (products, merges / copies, scalings
 // / dots / norms) and operations that had to go back to compressed columns
+// out[0] = vocabulary operations (copy, scale, merge, dot, trace, norm) done on matrices in block form, out[1] = fallbacks
+void ntpoly_amd_block_algebra_counts(long long* out) {
+  out[0] = block_algebra_counts()[0];
+  out[1] = block_algebra_counts()[1];
+}
 void ntpoly_amd_slab_algebra_counts(long long* out) {
   for (int q = 0; q < 4; ++q) out[q] = slab_algebra_counts()[q];
 }

@@ -928,6 +928,13 @@ def block_order(M):
     return pos if ok else None
 
 
+def block_algebra_counts():
+    """(operations of solver loops / C-ABI loops done on matrices in block form, fallbacks to compressed columns)"""
+    out = (C.c_longlong * 2)()
+    lib.ntpoly_amd_block_algebra_counts(out)
+    return dict(operations=int(out[0]), fallbacks=int(out[1]))
+
+
 def drop_block_caches():
     lib.ntpoly_amd_drop_block_caches()
 

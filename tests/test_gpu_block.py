@@ -309,3 +309,67 @@ def test_lattice64_product_bit_exact_at_the_benched_size(nt, fma):
     want = _digest(order[oc - 1] + 1, order[orow - 1] + 1, ov)
     got = _digest(gc, gr, gv)
     assert got == want
+
+
+@pytest.mark.parametrize("solver", ["sign", "invert", "trs4", "inverse_square_root"])
+def test_solver_loops_in_block_form(nt, fma, solver):
+    """The loops of SignFunction, Invert, TRS4 and InverseSquareRoot on a LATTICE operand (no runs: the slab algebra
+    declines): with the session on, products stay in block form and the loop's merges, scalings, copies, dots, traces and
+    norms run on tiles (block algebra, spgemm_block.hpp); with it off, every product is converted back and the merges run
+    on compressed columns.  Both use the block path's products and the same element rules, so sign / inverse / square
+    root agree BIT FOR BIT (same iteration count, same pattern, same values; TRS4, whose sigma is a quotient of dots
+    summed in another order, to 1e-10), and both agree with the oracle on the caller's labels within the solver
+    tolerances."""
+    import scipy.sparse as sp
+    O = fma
+    L, thr = 12, 1e-7
+    n = L ** 3
+    shift = 0.0 if solver in ("sign", "trs4") else 2.5
+    col, row, val = lattice_triplets(L, shift=shift)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    res = []
+    for on in (0, 1):
+        nt.set_option("slab_algebra", on)
+        p = nt.SolverParameters()
+        p.SetThreshold(thr)
+        p.SetConvergeDiff(1e-30 if solver == "trs4" else 1e-7)
+        if solver == "trs4":
+            p.SetMaxIterations(10)
+            p.SetMonitorConvergence(False)
+        Out = nt.Matrix_ps(n)
+        c0 = nt.block_algebra_counts()
+        if solver == "sign":
+            nt.SignSolvers.ComputeSign(H, Out, p)
+        elif solver == "invert":
+            nt.InverseSolvers.Invert(H, Out, p)
+        elif solver == "trs4":
+            I = nt.Matrix_ps(n)
+            I.FillIdentity()
+            nt.DensityMatrixSolvers.TRS4(H, I, n / 2.0, Out, p)
+        else:
+            nt.SquareRootSolvers.InverseSquareRoot(H, Out, p)
+        c1 = nt.block_algebra_counts()
+        res.append((srt(Out.triplets()), nt.solver_trace()["iterations"], c1["operations"] - c0["operations"], c1["fallbacks"] - c0["fallbacks"]))
+    off, on = res
+    assert off[2] == 0 and on[2] >= 2 * on[1], (off[2], on[2], on[1])     # the loop's vocabulary ran on tiles
+    assert off[1] == on[1]
+    G = sp.csr_matrix((on[0][2], (on[0][1] - 1, on[0][0] - 1)), shape=(n, n))
+    W = sp.csr_matrix((off[0][2], (off[0][1] - 1, off[0][0] - 1)), shape=(n, n))
+    if solver == "trs4":
+        assert abs(G - W).max() <= 1e-10
+    else:
+        exact(on[0], off[0], solver + ": block algebra vs compressed columns")
+    # the oracle on the caller's labels (tolerance: the chains run over positions)
+    Ho = O.Mat.from_triplets(n, n, col, row, val)
+    if solver == "trs4":
+        Ko, e_o, mu_o, tro = O.density("trs4", Ho, O.Mat.identity(n), n / 2.0,
+                                       O.params(converge_diff=1e-30, max_iterations=10, threshold=thr, monitor_convergence=False))
+        w = srt(Ko.triplets())
+        tol = 1e-6
+    else:
+        Oo, tro = O.matrix_function(solver, Ho, O.params(converge_diff=1e-7, threshold=thr))
+        assert tro["iterations"] == on[1]
+        w = srt(Oo.triplets())
+        tol = 1e-9
+    Wo = sp.csr_matrix((w[2], (w[1] - 1, w[0] - 1)), shape=(n, n))
+    assert abs(G - Wo).max() <= tol * max(1.0, abs(Wo).max())

@@ -16,4 +16,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/prof_summary.py gpurun_out/$tag/stats/run_results.db > gpurun_out/$tag/kernel_stats.csv
 python3 tools/pmc_traffic_json.py gpurun_out/$tag $kern gpurun_out/$tag/pmc_traffic.json
+# (gpurun merges at most 64 MiB back: the raw traces stay on the box)
+rm -rf gpurun_out/$tag/stats gpurun_out/$tag/pmc_FETCH_SIZE gpurun_out/$tag/pmc_WRITE_SIZE
 head -12 gpurun_out/$tag/kernel_stats.csv
