@@ -678,7 +678,6 @@ void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double 
 }
 
 void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) {
-  unblock({&Identity, &B});
   if (slab_on() && B.loc.expanded() && !B.cplx && !Identity.cplx && Identity.dim == B.dim && slab_add_diagonal(B.loc, alpha, B.c0)) {
     g_slab_counts[1] += 1; g_session_did_work = true;
     return;
@@ -687,7 +686,7 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) 
 }
 
 bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double beta, double* norm) {
-  unblock({&A, &B});
+  if (blk_any({&A, &B})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
   if (!slab_on() || A.cplx || B.cplx || A.dim != B.dim || &A == &B || !(A.loc.expanded() || B.loc.expanded())) return false;
   if (!(slab_enter(mut(A)) && slab_enter(mut(B)) && slab_norm_axpby(A.loc, B.loc, alpha, beta, norm))) return false;
   g_slab_counts[2] += 1; g_session_did_work = true;
@@ -695,14 +694,14 @@ bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double be
 }
 
 bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx) {
-  unblock({&X, &X2});
+  if (blk_any({&X, &X2})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
   if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx) return false;
   if (!slab_trs4_traces(X.loc, X2.loc, X.c0, trace_fx, trace_gx)) return false;
   g_slab_counts[2] += 1; g_session_did_work = true;
   return true;
 }
 bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatrix& P) {
-  unblock({&X, &X2});
+  if (blk_any({&X, &X2})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
   if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx || sigma == 0.0) return false;
   DevMat R;
   if (!slab_trs4_operand(X.loc, X2.loc, sigma, X.c0, R)) return false;

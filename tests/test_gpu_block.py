@@ -317,12 +317,11 @@ def test_solver_loops_in_block_form(nt, fma, solver):
     declines): with the session on, products stay in block form and the loop's merges, scalings, copies, dots, traces and
     norms run on tiles (block algebra, spgemm_block.hpp); with it off, every product is converted back and the merges run
     on compressed columns.  Both use the block path's products and the same element rules, so sign / inverse / square
-    root agree BIT FOR BIT (same iteration count, same pattern, same values; TRS4, whose sigma is a quotient of dots
-    summed in another order, to 1e-10), and both agree with the oracle on the caller's labels within the solver
-    tolerances."""
+    root agree to roundoff (same iteration count, values 1e-12; TRS4, whose sigma is a quotient of dots summed in another
+    order, to 1e-10), and both agree with the oracle on the caller's labels within the solver tolerances."""
     import scipy.sparse as sp
     O = fma
-    L, thr = 12, 1e-7
+    L, thr = 16, 1e-6      # (12^3 is too small: its iterates fill in until the tile kernel takes them)
     n = L ** 3
     shift = 0.0 if solver in ("sign", "trs4") else 2.5
     col, row, val = lattice_triplets(L, shift=shift)
@@ -355,10 +354,13 @@ def test_solver_loops_in_block_form(nt, fma, solver):
     assert off[1] == on[1]
     G = sp.csr_matrix((on[0][2], (on[0][1] - 1, on[0][0] - 1)), shape=(n, n))
     W = sp.csr_matrix((off[0][2], (off[0][1] - 1, off[0][0] - 1)), shape=(n, n))
+    # (with the session off some products of a loop take the LDS-hash kernels -- an operand like 3 I - X^2 is too sparse for
+    # tiles when it arrives in compressed columns -- whose chain runs over labels: the two runs agree to roundoff, not bit
+    # for bit; the element rules themselves are pinned bit for bit by test_block_form_trs2_steps_equal_the_separate_passes)
     if solver == "trs4":
         assert abs(G - W).max() <= 1e-10
     else:
-        exact(on[0], off[0], solver + ": block algebra vs compressed columns")
+        close(on[0], off[0], n, thr, solver + ": block algebra vs compressed columns", rel=1e-12)
     # the oracle on the caller's labels (tolerance: the chains run over positions)
     Ho = O.Mat.from_triplets(n, n, col, row, val)
     if solver == "trs4":
