@@ -3358,7 +3358,10 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   }
   // ---- operands without run structure, FMA arithmetic, real, square, one rank: 16 x 16 blocks of a clustered index order
   // on the FP64 matrix cores (spgemm_block.hip); declined (false) when the clustering finds no blocks worth it
-  if (!use_slab && !grouped_done && !loose_in && block_eligible(A, B, arange) && !strip_ctx().active) {
+  // (only operands whose row windows lie beyond the direct-mapped LDS kernels -- 4096 rows: those kernels multiply in label
+  // order and serve banded operands that merely failed the run-density test; the block path multiplies in its own order)
+  if (!use_slab && !grouped_done && !loose_in && block_eligible(A, B, arange) && !strip_ctx().active &&
+      (options().block_path == 2 || (slab_try && (int64_t)hstats[16] > 4096))) {
     if (timing) {   // (the helper brings its own timers)
       event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
       event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);

@@ -31,7 +31,9 @@ def nt():
 def fma(nt):
     from oracle import oracle_py as O
     nt.set_option("spgemm_fma", 1)
-    nt.set_option("block_path", 1)
+    # (2 = whatever the row windows: left to itself the engine keeps operands whose windows fit the direct-mapped LDS kernels
+    # -- 4096 rows, i.e. every lattice up to 16^3 -- away from the block path; the 64^3 test runs with the automatic rule)
+    nt.set_option("block_path", 2)
     O.set_fma(True)
     nt.drop_block_caches()
     yield O
@@ -133,7 +135,7 @@ def test_block_path_is_declined_for_unstructured_operands(nt, fma):
     """a random sparse matrix has no blocks: the clustering is tried once, the product takes the LDS-hash path and is
     bit-exact against the oracle on the caller's labels"""
     O = fma
-    n, per = 4096, 12
+    n, per = 8192, 12      # (row windows beyond the direct-mapped LDS kernels: the block path is asked, and declines on the fill)
     rng = np.random.default_rng(5)
     col = np.repeat(np.arange(1, n + 1, dtype=np.int32), per)
     row = rng.integers(1, n + 1, size=n * per).astype(np.int32)
@@ -142,6 +144,7 @@ def test_block_path_is_declined_for_unstructured_operands(nt, fma):
     val = rng.standard_normal(len(col))
     A = nt.Matrix_ps.from_triplets(n, col, row, val)
     nt.set_option("slab_algebra", 0)
+    nt.set_option("block_path", 1)
     C = nt.Matrix_ps(n)
     C.Gemm(A, A, None, 1.0, 0.0, 1e-9)
     assert nt.last_block_stats()["used"] == 0
@@ -288,6 +291,7 @@ def test_lattice64_product_bit_exact_at_the_benched_size(nt, fma):
     col, row, val = lattice_triplets(L)
     A = nt.Matrix_ps.from_triplets(n, col, row, val)
     nt.set_option("slab_algebra", 0)
+    nt.set_option("block_path", 1)      # (the engine's own choice at this size)
     C = nt.Matrix_ps(n)
     C.Gemm(A, A, None, 1.0, 0.0, thr)
     assert nt.last_block_stats()["used"] == 1

@@ -12,7 +12,13 @@ from gen import banded_triplets
 nt.init_comm(); nt.ConstructGlobalProcessGrid(1, 1, 1)
 nt.set_option("spgemm_fma", 1 if os.environ.get("ARITH", "fma") == "fma" else 0)
 n, h, thr = 262144, 100, 1e-8
-col, row, val = banded_triplets(n, h)
+if os.environ.get("LATTICE"):   # LATTICE=64: the 64^3 lattice Hamiltonian (block path; NTPOLY_AMD_SLAB_ALGEBRA also switches the block algebra)
+    from gen import lattice_triplets
+    L = int(os.environ["LATTICE"])
+    n = L ** 3
+    col, row, val = lattice_triplets(L)
+else:
+    col, row, val = banded_triplets(n, h)
 H = nt.Matrix_ps.from_triplets(n, col, row, val)
 I = nt.Matrix_ps(n); I.FillIdentity()
 which = os.environ.get("SOLVER", "trs4")
@@ -33,5 +39,5 @@ for iters in (4, 14, 4, 14):
     walls[iters] = time.perf_counter() - t0
     print(which, "iters", iters, "wall", time.perf_counter() - t0, "syncs", nt.exchange_stats()[2] - s0, "e", e, "nnz", K.GetSize(), flush=True)
     del K
-print("%s: %.2f ms per iteration (arithmetic %s, slab_algebra %s)" % (which, 1e3 * (walls[14] - walls[4]) / 10,
-      os.environ.get("ARITH", "fma"), os.environ.get("NTPOLY_AMD_SLAB_ALGEBRA", "1")))
+print("%s: %.2f ms per iteration (arithmetic %s, slab_algebra %s, lattice %s, block algebra operations %s)" % (which, 1e3 * (walls[14] - walls[4]) / 10,
+      os.environ.get("ARITH", "fma"), os.environ.get("NTPOLY_AMD_SLAB_ALGEBRA", "1"), os.environ.get("LATTICE"), nt.block_algebra_counts()))
