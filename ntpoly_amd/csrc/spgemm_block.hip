@@ -21,7 +21,7 @@
 // Arithmetic: the matrix instruction is a chain of fma() in ascending k (tools/micro/mfma_f64_probe.hip), instructions,
 // blocks and super-blocks follow in ascending POSITION, zeros are exact no-ops: C(i, j) is the FMA chain over ascending
 // position -- bit for bit what the reference's FP-contracted build computes on the matrix relabelled by `pos`
-// (tests/test_gpu_block.py runs the oracle on exactly that matrix), and within roundoff of the chain over ascending
+// (tests/test_gpu_block.py runs the CPU restatement of the reference on exactly that matrix), and within roundoff of the chain over ascending
 // labels (the tolerance contract of label-ordered operands).
 #include "spgemm_block.hpp"
 
@@ -678,29 +678,34 @@ struct BsArgs {
 
 __device__ inline v4d bs_zero4() { const v4d z = {0.0, 0.0, 0.0, 0.0}; return z; }
 
-// One WAVE per candidate super-tile (I, J): acc[x][b] = tile (row block x, column block b), 16 accumulator tiles = 128 VGPRs;
-// no LDS, no barriers, the waves are independent.  The super-row of A and the super-column of B are intersected 64 entries
-// of A's list at a time (a lane per entry, binary search in B's list); the matches are walked in ascending K.  Per match
-// and per block kb of K with tiles on both sides: the tiles B(kb, b) that exist are loaded (lane (g, n) reads the rows
-// 4 g .. 4 g + 3 of column n: two swizzled 16-byte chunks of the column's line), then the tiles A(x, kb) that exist (lane
+// One WORKGROUP of two waves per candidate super-tile (I, J); wave h owns the row blocks 2 h and 2 h + 1: acc[x][b] = tile
+// (row block 2 h + x, column block b), 8 accumulator tiles = 64 VGPRs; no LDS in the loop, no barriers before the
+// epilogue.  The super-row of A and the super-column of B are intersected 64 entries of A's list at a time (a lane per
+// entry, binary search in B's list; both waves do the same walk); the matches are walked in ascending K.  Per match and
+// per block kb of K with tiles on both sides: the tiles B(kb, b) that exist are loaded (lane (g, n) reads the rows
+// 4 g .. 4 g + 3 of column n: two swizzled 16-byte chunks of the column's line), then the wave's tiles A(2 h + x, kb) (lane
 // (g, m) reads in-tile row phys(m) of the columns 4 g + q: four full lines per instruction), and every pair issues its
-// four matrix instructions in ascending q.  Every tile of either operand is read ONCE per candidate and match and feeds
-// up to four pairs.  (Versions with a workgroup per candidate -- a wave per row block, B tiles shared through the L1 or
-// staged in LDS -- were slower: 44 L1 line accesses per matrix instruction, or a memory latency per match behind every
-// barrier; profiles/README.md, round 4.)
-// (a workgroup is ONE wave: the candidates' work differs by an order of magnitude, and a workgroup of four waves kept its
-// three finished waves' slots until the fourth was done -- measured occupancy 1.1 waves per SIMD of the possible 2)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bs_numeric(const BsArgs a) {
+// matrix instructions in ascending q -- those whose 4-wide slice of either tile is empty are skipped (BlockForm::quads).
+// History (profiles/README.md, round 4): a wave per row block with the B tiles through the L1 or staged in LDS (44 L1
+// line accesses per matrix instruction; a memory latency per match behind every barrier), one wave per candidate with 16
+// accumulator tiles (216 VGPRs, two waves per SIMD: 29.5 ms on the 64^3 iterate), two waves per candidate (135 VGPRs,
+// three waves per SIMD: 23.5 ms).
+// (a workgroup is ONE candidate: two waves, each owning two of the four row blocks -- 8 accumulator tiles = 64 VGPRs instead
+// of 128, so that three to four waves fit a SIMD and cover each other's load round trips; the two waves do the same walk
+// and finish together.  A workgroup of four DIFFERENT candidates kept its finished waves' slots until the last was done:
+// measured occupancy 1.1 waves per SIMD of the possible 2, profiles/r04_pmc_block_v6_wg4.txt)
+__global__ __launch_bounds__(128) void k_bs_numeric(const BsArgs a) {
+  __shared__ unsigned wmask[2];
+  __shared__ int wcount[2];
+  __shared__ long long slot_base;
   const int wg = xcd_block(a.nwg);
   if (wg < 0) return;
-  const int lane = lane_id();
-  const int64_t slot = wg;
-  if (slot >= a.ncand) return;
-  const int64_t cand = uni_i32(a.order[slot]);
+  const int lane = lane_id(), h = uni_i32(threadIdx.x / WAVE);     // h: row blocks 2 h, 2 h + 1
+  const int64_t cand = uni_i32(a.order[wg]);
   const int I = uni_i32(a.ci[cand]), J = uni_i32(a.cj[cand]);
-  v4d acc[4][4];
+  v4d acc[2][4];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < 2; ++x)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[x][b] = bs_zero4();
   const int64_t ra0 = uni_i64(a.roffA[I]), ra1 = uni_i64(a.roffA[I + 1]);
@@ -731,13 +736,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const int ia_s = readlane_i32(ia, l);
       const int64_t ib_s = cb0 + readlane_i32(ib, l);
       const unsigned mA = (unsigned)uni_i32(a.smaskA[ia_s]), mB = (unsigned)uni_i32(a.smaskB[ib_s]);
+      if (((mA >> (2 * h)) & 0x3333u) == 0) continue;            // no tile of A in this wave's row blocks
       const double* __restrict__ tA = a.tilesA + uni_i64(a.sbaseA[ia_s]) * 256;
       const double* __restrict__ tB = a.tilesB + uni_i64(a.sbaseB[ib_s]) * 256;
       const unsigned long long cqA = (unsigned long long)uni_i64((int64_t)a.quadsA[2 * (int64_t)ia_s]);       // column slices of A's tiles
       const unsigned long long rqB = (unsigned long long)uni_i64((int64_t)a.quadsB[2 * ib_s + 1]);            // row slices of B's tiles
 #pragma unroll 1
       for (int kb = 0; kb < 4; ++kb) {
-        const unsigned colA = (mA >> (4 * kb)) & 15u;            // bit x: tile A(x, kb)
+        const unsigned colA = (mA >> (4 * kb + 2 * h)) & 3u;     // bit x: tile A(2 h + x, kb)
         const unsigned rowB = (mB >> kb) & 0x1111u;              // bit 4 b: tile B(kb, b)
         if (colA == 0 || rowB == 0) continue;
         v2d b01[4], b23[4];   // (only the fragments of existing tiles are loaded -- and read)
@@ -749,19 +755,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             b23[b] = *reinterpret_cast<const v2d*>(pB + bhi);
           }
         }
-        double af[4][4];
+        double af[2][4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
+        for (int x = 0; x < 2; ++x) {
           if (colA & (1u << x)) {
-            const double* __restrict__ pA = tA + __popc(mA & ((1u << (4 * kb + x)) - 1u)) * 256;
+            const double* __restrict__ pA = tA + __popc(mA & ((1u << (4 * kb + 2 * h + x)) - 1u)) * 256;
 #pragma unroll
             for (int q = 0; q < 4; ++q) af[x][q] = pA[aoffq[q]];
           }
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
+        for (int x = 0; x < 2; ++x) {
           if (colA & (1u << x)) {
-            const unsigned ca4 = (unsigned)(cqA >> (4 * (4 * kb + x))) & 15u;
+            const unsigned ca4 = (unsigned)(cqA >> (4 * (4 * kb + 2 * h + x))) & 15u;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
               if (rowB & (1u << (4 * b))) {
@@ -782,12 +788,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // ---- epilogue: prune (PruneList.f90:22: strict >; the dense branch tests before the scaling), kept tiles to the pool
   const double alpha = a.alpha, thr = a.threshold;
   const bool dense = (a.dense_rule & 1) != 0;
-  unsigned mC = 0;
+  unsigned mine = 0;     // bit 4 b + 2 h + x
   int cnt = 0;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
+    for (int x = 0; x < 2; ++x) {
       bool any = false;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -798,44 +804,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         any |= keep;
         cnt += keep ? 1 : 0;
       }
-      if (__ballot(any) != 0ull) mC |= 1u << (4 * b + x);
+      if (__ballot(any) != 0ull) mine |= 1u << (4 * b + 2 * h + x);
     }
   cnt = (int)wave_sum_i64(cnt);
+  if (lane == 0) { wmask[h] = mine; wcount[h] = cnt; }
+  __syncthreads();
+  const unsigned mC = (unsigned)uni_i32((int)(wmask[0] | wmask[1]));
+  const int call = wcount[0] + wcount[1];
   const int nt = __popc(mC);
-  int64_t slot0 = 0;
-  bool ok = true;
-  if (nt) {
-    unsigned long long s = 0;
-    if (lane == 0) s = atomicAdd(&a.counters[0], (unsigned long long)nt);
-    slot0 = uni_i64((int64_t)s);
-    if (slot0 + nt > a.pool_tiles) {
-      ok = false;
-      if (lane == 0) atomicOr(&a.counters[1], 1ull);
-    }
+  if (threadIdx.x == 0) {
+    long long sl = 0;
+    if (nt) sl = (long long)atomicAdd(&a.counters[0], (unsigned long long)nt);
+    slot_base = sl;
   }
+  __syncthreads();
+  const int64_t slot0 = uni_i64(slot_base);
+  const bool ok = slot0 + nt <= a.pool_tiles;
   if (nt && ok) {
-    int rank = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        if (mC & (1u << (4 * b + x))) {
+      for (int x = 0; x < 2; ++x) {
+        const int bit = 4 * b + 2 * h + x;
+        if (mine & (1u << bit)) {
           // lane (g, n) holds the in-tile rows 4 g + r of column n: the chunks 2 g and 2 g + 1 of that column (swizzled)
-          double* __restrict__ pt = a.pool + (slot0 + rank) * 256;
+          double* __restrict__ pt = a.pool + (slot0 + __popc(mC & ((1u << bit) - 1u))) * 256;
           v2d lo2, hi2;
           lo2[0] = acc[x][b][0]; lo2[1] = acc[x][b][1]; hi2[0] = acc[x][b][2]; hi2[1] = acc[x][b][3];
           *reinterpret_cast<v2d*>(pt + blo) = lo2;
           *reinterpret_cast<v2d*>(pt + bhi) = hi2;
-          rank += 1;
         }
       }
   }
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
+    if (nt && !ok) atomicOr(&a.counters[1], 1ull);
     a.cmask[cand] = ok ? (int32_t)mC : 0;
     a.cbase[cand] = slot0;
-    a.ccnt[cand] = ok ? cnt : 0;
-    if (nprod) atomicAdd(&a.counters[2], (unsigned long long)nprod);
+    a.ccnt[cand] = ok ? call : 0;
   }
+  if (lane == 0 && nprod) atomicAdd(&a.counters[2], (unsigned long long)nprod);
 }
 
 // Z-order key of a candidate: the bits of its super-row and super-column interleaved
@@ -1406,7 +1413,7 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
     if (const char* v = std::getenv("NTPOLY_AMD_BS_ABLATE")) a.ablate = std::atoi(v);
 #endif
     if (ev_begin) HIP_CHECK(hipEventRecord(ev_begin, stream()));
-    hipLaunchKernelGGL(k_bs_numeric, dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
+    hipLaunchKernelGGL(k_bs_numeric, dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
     if (ev_end) HIP_CHECK(hipEventRecord(ev_end, stream()));
     {
       ScalarFetch f;
