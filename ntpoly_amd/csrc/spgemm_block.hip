@@ -615,16 +615,25 @@ __global__ __launch_bounds__(256) void k_bs_symbolic(int ns, const int64_t* __re
 }
 
 // slice masks of the tiles (BlockForm::quads): a wave per super-tile, lane l looks at the words 4 l .. 4 l + 3 of every tile
+// (statistics, optional: with ccountA = entries per column position of the LEFT operand the same pass counts the
+// intermediate products of the multiply, sum over the entries (k, j) of this matrix of ccountA[k])
 __global__ __launch_bounds__(256) void k_bs_quads(int64_t nst, const int32_t* __restrict__ smask, const int64_t* __restrict__ sbase,
-                                                  const double* __restrict__ tiles, unsigned long long* __restrict__ quads) {
+                                                  const double* __restrict__ tiles, unsigned long long* __restrict__ quads,
+                                                  const int32_t* __restrict__ srow, const int32_t* __restrict__ ccountA,
+                                                  unsigned long long* __restrict__ prod_out) {
   const int64_t s = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE;
   if (s >= nst) return;
   const int lane = lane_id();
   const int w0 = 4 * lane, col_t = w0 >> 4, ch = (w0 & 15) >> 1;
   const int cq = phys(col_t) >> 2;                       // column slice of this lane's words
-  int rq[4];
+  int rq[4], rpos[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) rq[e] = phys(((((ch + (e >> 1)) ^ (col_t >> 1)) & 7) << 1) | (e & 1)) >> 2;
+  for (int e = 0; e < 4; ++e) {
+    rpos[e] = phys(((((ch + (e >> 1)) ^ (col_t >> 1)) & 7) << 1) | (e & 1));   // in-block position of the row of word 4 l + e
+    rq[e] = rpos[e] >> 2;
+  }
+  const int rbase = ccountA ? 64 * srow[s] : 0;
+  long long prods = 0;
   const unsigned mk = (unsigned)smask[s];
   const double* __restrict__ base = tiles + sbase[s] * 256;
   unsigned long long colq = 0, rowq = 0;
@@ -636,19 +645,30 @@ __global__ __launch_bounds__(256) void k_bs_quads(int64_t nst, const int32_t* __
     unsigned c4 = 0, r4 = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (v[e] != 0.0) { c4 |= 1u << cq; r4 |= 1u << rq[e]; }
+      if (v[e] != 0.0) {
+        c4 |= 1u << cq;
+        r4 |= 1u << rq[e];
+        if (ccountA) prods += ccountA[rbase + 16 * (t & 3) + rpos[e]];
+      }
     for (int o = 32; o > 0; o >>= 1) { c4 |= __shfl_xor(c4, o, WAVE); r4 |= __shfl_xor(r4, o, WAVE); }
     colq |= (unsigned long long)c4 << (4 * t);
     rowq |= (unsigned long long)r4 << (4 * t);
   }
   if (lane == 0) { quads[2 * s] = colq; quads[2 * s + 1] = rowq; }
+  if (ccountA) {
+    prods = wave_sum_i64(prods);
+    if (lane == 0 && prods) atomicAdd(&prod_out[s & 63], (unsigned long long)prods);
+  }
 }
-void block_quads(BlockForm& F) {
-  if (F.have_quads) return;
+// ccountA / prod_out (optional, statistics): see k_bs_quads; true when the products were counted by this pass
+bool block_quads(BlockForm& F, const int32_t* ccountA = nullptr, unsigned long long* prod_out = nullptr) {
+  if (F.have_quads) return false;
   F.quads.alloc((size_t)2 * std::max<int64_t>(1, F.nst));
   if (F.nst > 0)
-    hipLaunchKernelGGL(k_bs_quads, dim3(gridw(F.nst)), dim3(256), 0, stream(), F.nst, F.smask.p, F.sbase.p, F.tiles.p, F.quads.p);
+    hipLaunchKernelGGL(k_bs_quads, dim3(gridw(F.nst)), dim3(256), 0, stream(), F.nst, F.smask.p, F.sbase.p, F.tiles.p, F.quads.p,
+                       F.srow.p, ccountA, prod_out);
   F.have_quads = true;
+  return ccountA != nullptr;
 }
 
 // =====================================================================================================================
@@ -1349,9 +1369,19 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
                    unsigned long long* nprod_out, const DevMat* Acsc, const DevMat* Bcsc) {
   const int32_t n = bc.order->n;
   build_rows(FA);
+  const int ns = bc.order->ns;
+  // (statistics with operands in block form: the products are counted by the pass that makes B's slice masks, from the
+  // entries per column of A -- no pass of their own)
+  DevBuf<unsigned long long> prod64(64);
+  bool prod_fused = false;
+  if (nprod_out && !(Acsc && Bcsc)) {
+    prod64.zero();
+    block_colstat(FA);
+    if (&FA == &FB) prod_fused = block_quads(FA, FA.ccount.p, prod64.p);
+    else { block_quads(FA); prod_fused = block_quads(FB, FA.ccount.p, prod64.p); }
+  }
   block_quads(FA);
   block_quads(FB);
-  const int ns = bc.order->ns;
   // ---- symbolic
   static bool attr_done = false;
   if (!attr_done) {
@@ -1433,7 +1463,9 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
   tot.zero();
   if (nprod_out) {
     if (Acsc && Bcsc) hipLaunchKernelGGL(k_bs_products, dim3(gridw(n)), dim3(256), 0, stream(), view(*Acsc), view(*Bcsc), tot.p + 1);
-    else {   // (operands in block form: entries per column of A, then the sum over the entries of B)
+    else if (prod_fused) {
+      HIP_CHECK(hipMemcpyAsync(tot.p + 1, prod64.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream()));
+    } else {   // (B's masks existed already: entries per column of A, then the sum over the entries of B)
       block_colstat(FA);
       hipLaunchKernelGGL(k_bs_products_blk, dim3(gridw((int64_t)64 * ns)), dim3(256), 0, stream(), ns, FB.soff.p, FB.srow.p, FB.smask.p, FB.sbase.p,
                          FB.tiles.p, FA.ccount.p, tot.p + 1);
