@@ -714,18 +714,23 @@ __device__ inline v4d bs_zero4() { const v4d z = {0.0, 0.0, 0.0, 0.0}; return z;
 // of 128, so that three to four waves fit a SIMD and cover each other's load round trips; the two waves do the same walk
 // and finish together.  A workgroup of four DIFFERENT candidates kept its finished waves' slots until the last was done:
 // measured occupancy 1.1 waves per SIMD of the possible 2, profiles/r04_pmc_block_v6_wg4.txt)
-__global__ __launch_bounds__(128) void k_bs_numeric(const BsArgs a) {
-  __shared__ unsigned wmask[2];
-  __shared__ int wcount[2];
+// HV = waves per candidate: 2 (each wave owns NX = 2 row blocks; operands with sparse tiles, where the waves' load round
+// trips pace the kernel) or 1 (one wave owns all four: every B tile is read once; operands with dense tiles -- a relabelled
+// band at fill 0.7: 4.7 ms against 6.7 with two waves)
+template <int HV>
+__global__ __launch_bounds__(64 * HV) void k_bs_numeric(const BsArgs a) {
+  constexpr int NX = 4 / HV;
+  __shared__ unsigned wmask[HV];
+  __shared__ int wcount[HV];
   __shared__ long long slot_base;
   const int wg = xcd_block(a.nwg);
   if (wg < 0) return;
-  const int lane = lane_id(), h = uni_i32(threadIdx.x / WAVE);     // h: row blocks 2 h, 2 h + 1
+  const int lane = lane_id(), h = uni_i32(threadIdx.x / WAVE);     // h: row blocks NX h .. NX h + NX - 1
   const int64_t cand = uni_i32(a.order[wg]);
   const int I = uni_i32(a.ci[cand]), J = uni_i32(a.cj[cand]);
-  v4d acc[2][4];
+  v4d acc[NX][4];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < NX; ++x)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[x][b] = bs_zero4();
   const int64_t ra0 = uni_i64(a.roffA[I]), ra1 = uni_i64(a.roffA[I + 1]);
@@ -756,14 +761,14 @@ __global__ __launch_bounds__(128) void k_bs_numeric(const BsArgs a) {
       const int ia_s = readlane_i32(ia, l);
       const int64_t ib_s = cb0 + readlane_i32(ib, l);
       const unsigned mA = (unsigned)uni_i32(a.smaskA[ia_s]), mB = (unsigned)uni_i32(a.smaskB[ib_s]);
-      if (((mA >> (2 * h)) & 0x3333u) == 0) continue;            // no tile of A in this wave's row blocks
+      if (((mA >> (NX * h)) & (NX == 2 ? 0x3333u : 0xFFFFu)) == 0) continue;            // no tile of A in this wave's row blocks
       const double* __restrict__ tA = a.tilesA + uni_i64(a.sbaseA[ia_s]) * 256;
       const double* __restrict__ tB = a.tilesB + uni_i64(a.sbaseB[ib_s]) * 256;
       const unsigned long long cqA = (unsigned long long)uni_i64((int64_t)a.quadsA[2 * (int64_t)ia_s]);       // column slices of A's tiles
       const unsigned long long rqB = (unsigned long long)uni_i64((int64_t)a.quadsB[2 * ib_s + 1]);            // row slices of B's tiles
 #pragma unroll 1
       for (int kb = 0; kb < 4; ++kb) {
-        const unsigned colA = (mA >> (4 * kb + 2 * h)) & 3u;     // bit x: tile A(2 h + x, kb)
+        const unsigned colA = (mA >> (4 * kb + NX * h)) & ((1u << NX) - 1u);     // bit x: tile A(NX h + x, kb)
         const unsigned rowB = (mB >> kb) & 0x1111u;              // bit 4 b: tile B(kb, b)
         if (colA == 0 || rowB == 0) continue;
         v2d b01[4], b23[4];   // (only the fragments of existing tiles are loaded -- and read)
@@ -775,19 +780,19 @@ __global__ __launch_bounds__(128) void k_bs_numeric(const BsArgs a) {
             b23[b] = *reinterpret_cast<const v2d*>(pB + bhi);
           }
         }
-        double af[2][4];
+        double af[NX][4];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < NX; ++x) {
           if (colA & (1u << x)) {
-            const double* __restrict__ pA = tA + __popc(mA & ((1u << (4 * kb + 2 * h + x)) - 1u)) * 256;
+            const double* __restrict__ pA = tA + __popc(mA & ((1u << (4 * kb + NX * h + x)) - 1u)) * 256;
 #pragma unroll
             for (int q = 0; q < 4; ++q) af[x][q] = pA[aoffq[q]];
           }
         }
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < NX; ++x) {
           if (colA & (1u << x)) {
-            const unsigned ca4 = (unsigned)(cqA >> (4 * (4 * kb + 2 * h + x))) & 15u;
+            const unsigned ca4 = (unsigned)(cqA >> (4 * (4 * kb + NX * h + x))) & 15u;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
               if (rowB & (1u << (4 * b))) {
@@ -808,12 +813,12 @@ __global__ __launch_bounds__(128) void k_bs_numeric(const BsArgs a) {
   // ---- epilogue: prune (PruneList.f90:22: strict >; the dense branch tests before the scaling), kept tiles to the pool
   const double alpha = a.alpha, thr = a.threshold;
   const bool dense = (a.dense_rule & 1) != 0;
-  unsigned mine = 0;     // bit 4 b + 2 h + x
+  unsigned mine = 0;     // bit 4 b + NX h + x
   int cnt = 0;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < NX; ++x) {
       bool any = false;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -824,13 +829,16 @@ __global__ __launch_bounds__(128) void k_bs_numeric(const BsArgs a) {
         any |= keep;
         cnt += keep ? 1 : 0;
       }
-      if (__ballot(any) != 0ull) mine |= 1u << (4 * b + 2 * h + x);
+      if (__ballot(any) != 0ull) mine |= 1u << (4 * b + NX * h + x);
     }
   cnt = (int)wave_sum_i64(cnt);
   if (lane == 0) { wmask[h] = mine; wcount[h] = cnt; }
   __syncthreads();
-  const unsigned mC = (unsigned)uni_i32((int)(wmask[0] | wmask[1]));
-  const int call = wcount[0] + wcount[1];
+  unsigned mall = 0;
+  int call = 0;
+#pragma unroll
+  for (int w = 0; w < HV; ++w) { mall |= wmask[w]; call += wcount[w]; }
+  const unsigned mC = (unsigned)uni_i32((int)mall);
   const int nt = __popc(mC);
   if (threadIdx.x == 0) {
     long long sl = 0;
@@ -844,8 +852,8 @@ __global__ __launch_bounds__(128) void k_bs_numeric(const BsArgs a) {
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const int bit = 4 * b + 2 * h + x;
+      for (int x = 0; x < NX; ++x) {
+        const int bit = 4 * b + NX * h + x;
         if (mine & (1u << bit)) {
           // lane (g, n) holds the in-tile rows 4 g + r of column n: the chunks 2 g and 2 g + 1 of that column (swizzled)
           double* __restrict__ pt = a.pool + (slot0 + __popc(mC & ((1u << bit) - 1u))) * 256;
@@ -999,30 +1007,6 @@ void from_block(const BlockForm& F, int64_t nnz, DevMat& C) {
 // =====================================================================================================================
 // 6. the TRS2 update in block form
 // =====================================================================================================================
-// per column position: entries and largest row label
-__global__ __launch_bounds__(256) void k_bs_colstat(int ns, const int64_t* __restrict__ soff, const int32_t* __restrict__ srow,
-                                                    const int32_t* __restrict__ smask, const int64_t* __restrict__ sbase,
-                                                    const double* __restrict__ tiles, const int32_t* __restrict__ lab,
-                                                    int32_t* __restrict__ ccount, int32_t* __restrict__ plast) {
-  const int pc = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE);
-  if (pc >= 64 * ns) return;
-  const int lane = lane_id(), J = pc >> 6, cb = (pc >> 4) & 3, a = lane >> 4, i = lane & 15;
-  const int bit = 4 * cb + a;
-  const int coloff = tile_word(i, phys(pc & 15));
-  int c = 0, mx = -1;
-  for (int64_t t = soff[J]; t < soff[J + 1]; ++t) {
-    const unsigned mk = (unsigned)smask[t];
-    if ((mk & (1u << bit)) == 0) continue;
-    const double v = tiles[(sbase[t] + __popc(mk & ((1u << bit) - 1u))) * 256 + coloff];
-    if (v != 0.0) {
-      c += 1;
-      mx = max(mx, lab[64 * srow[t] + 16 * a + phys(i)]);
-    }
-  }
-  c = (int)wave_sum_i64(c);
-  mx = wave_max_i32(mx);
-  if (lane == 0) { ccount[pc] = c; plast[pc] = mx; }
-}
 // statistics: intermediate products of A B with both operands in block form = sum over the entries B(k, j) of the
 // entries of column k of A (ccountA by position)
 __global__ __launch_bounds__(256) void k_bs_products_blk(int ns, const int64_t* __restrict__ soff, const int32_t* __restrict__ srow,
@@ -1044,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_bs_products_blk(int ns, const int64_t* 
   s = wave_sum_i64(s);
   if (lane == 0 && s) atomicAdd(&out[(pc >> 2) & 63], (unsigned long long)s);
 }
-// the same statistics, a wave per SUPER-TILE: every tile is read once, whole (lane l takes the words 4 l .. 4 l + 3, all in
+// per column position: entries and largest row label.  A wave per SUPER-TILE: every tile is read once, whole (lane l takes the words 4 l .. 4 l + 3, all in
 // in-tile column l / 4), the four lanes of a column are reduced and leave their part with two atomics per column position
 // (a wave per column position walks the super-column with 64 scattered words per step: three times slower)
 __global__ __launch_bounds__(256) void k_bs_colstat_st(int64_t nst, int ns, const int64_t* __restrict__ soff, const int32_t* __restrict__ srow,
@@ -1475,6 +1459,7 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
   FC = BlockForm();
   FC.order = bc.order;
   FC.ns = ns;
+  const bool dense_tiles = (double)FA.nnz > 0.5 * 256.0 * (double)FA.ntiles && (double)FB.nnz > 0.5 * 256.0 * (double)FB.ntiles;
   int64_t pool = std::max<int64_t>(1024, std::max(FA.ntiles, FB.ntiles) * 2);
   if (bc.pool_hint_n == n) pool = std::max(pool, bc.pool_hint + bc.pool_hint / 4);
   pool = std::min<int64_t>(pool, ncand * 16);
@@ -1495,7 +1480,9 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
     if (const char* v = std::getenv("NTPOLY_AMD_BS_ABLATE")) a.ablate = std::atoi(v);
 #endif
     if (ev_begin) HIP_CHECK(hipEventRecord(ev_begin, stream()));
-    hipLaunchKernelGGL(k_bs_numeric, dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
+    // (dense tiles: one wave per candidate; sparse tiles: two)
+    if (dense_tiles) hipLaunchKernelGGL((k_bs_numeric<1>), dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
+    else hipLaunchKernelGGL((k_bs_numeric<2>), dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
     if (ev_end) HIP_CHECK(hipEventRecord(ev_end, stream()));
     {
       ScalarFetch f;
