@@ -220,6 +220,7 @@ DevMat DevMat::clone() const {
   }
   R.alloc(rows, cols, cplx, nnz);
   R.block_hint = block_hint;
+  R.slab_hint = slab_hint;
   HIP_CHECK(hipMemcpyAsync(R.outer.p, outer.p, sizeof(int64_t) * ((size_t)cols + 1), hipMemcpyDeviceToDevice, stream()));
   if (nnz) {
     HIP_CHECK(hipMemcpyAsync(R.inner.p, inner.p, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, stream()));

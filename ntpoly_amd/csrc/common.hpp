@@ -190,6 +190,9 @@ struct DevMat {
   // goes there first, without the run statistics of the slab / tile kernels.  A property of THIS matrix, not of its
   // dimension: a banded matrix of the same size still finds its run-based kernel.
   mutable int block_hint = 0;
+  // -1: slab_enter found this matrix (in compressed columns) not run-like -- asked again, it says no at once instead of
+  // measuring the extents again (a caller's loop over the C ABI on a general sparse matrix asks at every call)
+  mutable int slab_hint = 0;
 
   DevMat() = default;
   DevMat(int32_t r, int32_t c, bool z) { reset_empty(r, c, z); }

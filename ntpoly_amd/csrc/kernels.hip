@@ -5802,7 +5802,7 @@ bool sa_operand(const DevMat& M) {
 
 bool slab_enter(DevMat& M) {
   if (M.expanded()) return sa_operand(M);
-  if (M.blocked()) return false;
+  if (M.blocked() || M.slab_hint < 0) return false;
   if (M.cplx || M.loose() || M.rows != M.cols || M.nnz == 0 || (options().spgemm_fma != 0 && options().spgemm_fma != 1)) return false;
   const int n = M.cols;
   std::unique_ptr<SlabForm> f(new SlabForm());
@@ -5830,6 +5830,7 @@ bool slab_enter(DevMat& M) {
   if (hz == 0) M.zero_free = 1;
   if ((double)tot > 2.0 * (double)M.nnz + 2.0 * al * (double)n) {   // (mostly holes: not run-like)
     if (dbg) std::fprintf(stderr, "[slab_enter] refused: slots %lld for %lld entries\n", (long long)tot, (long long)M.nnz);
+    M.slab_hint = -1;
     return false;
   }
   f->val.alloc((size_t)tot + kIndexSlack);

@@ -113,7 +113,6 @@ bool slab_on() { return g_slab_depth > 0 && !g_slab_failed; }
 // (the representation of an operand, not its value, changes: const operands are converted in place)
 DevMat& mut(const PSMatrix& m) { return const_cast<DevMat&>(m.loc); }
 int g_slab_refusals = 0;
-int g_api_refusals = 0, g_api_skipped = 0;   // refusal state shared by the one-call sessions of the C ABI (SlabSession)
 bool g_session_api = false, g_session_did_work = false;
 long long g_slab_counts[4] = {0, 0, 0, 0};   // products, merges / copies, other operations in slab form; refusals
 // an operation that cannot be done in slab form: its operands go back to compressed columns and the general path does
@@ -155,15 +154,8 @@ const long long* block_algebra_counts() { return g_block_counts; }
 SlabSession::SlabSession(bool eligible, bool api) {
   opened = eligible && options().slab_algebra != 0 && (options().spgemm_fma == 1 || options().spgemm_fma == 0) && options().spgemm_variant < 0 &&
            options().spgemm_force_bin <= 0 && !world().active();
-  // A session of the C ABI's vocabulary calls lasts one call: a caller's loop over matrices that are not run-like
-  // (general sparse, load-balanced) would pay the refused conversion -- extents, a scan, a read-back -- on every call.
-  // Those sessions therefore share a refusal state that only a successful slab operation clears (g_api_refusals):
-  // after four refusals in a row they are not opened until sixty-four calls have passed.
-  if (opened && api && g_slab_depth == 0 && g_api_refusals >= 4) {
-    if (++g_api_skipped < 64) { opened = false; return; }
-    g_api_skipped = 0;
-    g_api_refusals = 3;   // (one more try)
-  }
+  // (a one-call session of the C ABI on a matrix that is not run-like pays the refused conversion once: slab_enter leaves a
+  // mark on the matrix, DevMat::slab_hint, and says no at once when asked again)
   if (opened) {
     if (g_slab_depth == 0) { g_slab_failed = false; g_slab_refusals = 0; g_session_api = api; }
     g_slab_depth += 1;
@@ -173,10 +165,6 @@ SlabSession::~SlabSession() { close(); }
 void SlabSession::close() {
   if (opened) {
     g_slab_depth -= 1;
-    if (g_slab_depth == 0 && g_session_api) {
-      if (g_slab_refusals > 0) g_api_refusals += 1;
-      else if (g_session_did_work) g_api_refusals = 0;
-    }
     if (g_slab_depth == 0) g_session_did_work = false;
   }
   opened = false;
