@@ -89,13 +89,14 @@ def lattice_case(L, r2=13):
     return lattice_triplets(L, r2=r2)
 
 
-CASES = [("lattice16", 1e-8, 1.0), ("lattice20", 1e-6, 0.5), ("lattice12", 0.0, -0.75), ("permuted_band", 1e-8, 1.0), ("lattice_ab", 1e-7, 1.0)]
+CASES = [("lattice16", 1e-8, 1.0), ("lattice20", 1e-6, 0.5), ("lattice12", 0.0, -0.75), ("permuted_band", 1e-8, 1.0), ("lattice_ab", 1e-7, 1.0),
+         ("lattice_asym", 1e-9, 1.0)]
 
 
 @pytest.mark.parametrize("kind,thr,alpha", CASES)
 def test_block_product_vs_oracle(nt, fma, kind, thr, alpha):
     O = fma
-    if kind.startswith("lattice") and kind != "lattice_ab":
+    if kind.startswith("lattice") and kind not in ("lattice_ab", "lattice_asym"):
         L = int(kind[7:])
         n = L ** 3
         ta = lattice_case(L)
@@ -106,6 +107,14 @@ def test_block_product_vs_oracle(nt, fma, kind, thr, alpha):
         ta = lattice_case(L)
         c, r, v = lattice_triplets(L, r2=6, shift=0.3)
         tb = (c, r, v * 1.25)
+    elif kind == "lattice_asym":      # patterns that are NOT symmetric, operands that differ, columns left empty
+        L = 16
+        n = L ** 3
+        c, r, v = lattice_case(L)
+        keep = ((r.astype(np.int64) * 7 + c.astype(np.int64) * 13) % 5 != 0) & (c % 97 != 0)
+        ta = (c[keep], r[keep], v[keep] * (1.0 + 0.001 * (r[keep] % 11)))
+        keep = ((r.astype(np.int64) * 3 + c.astype(np.int64) * 17) % 7 != 0) & (r % 89 != 0)
+        tb = (c[keep], r[keep], v[keep] * (1.0 - 0.002 * (c[keep] % 5)))
     else:
         n = 6000
         ta = permuted_banded_triplets(n, 40, 7)
