@@ -2892,6 +2892,29 @@ __global__ __launch_bounds__(256) void k_pack_slab(int ncols, const int32_t* __r
     pos += __popcll(m);
   }
 }
+__global__ __launch_bounds__(256) void k_pack_slab_c(int ncols, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                                     const int64_t* __restrict__ off, const double2* __restrict__ val,
+                                                     const int64_t* __restrict__ outer, int32_t* __restrict__ inner,
+                                                     double2* __restrict__ out) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= ncols) return;
+  const int lane = lane_id();
+  const int f = first[j], l = last[j];
+  int64_t pos = outer[j];
+  const double2* __restrict__ src = val + off[j];
+  for (int r0 = f; r0 <= l; r0 += WAVE) {
+    const int r = r0 + lane;
+    const double2 v = r <= l ? src[r - f] : make_double2(0.0, 0.0);
+    const bool nz = v.x != 0.0 || v.y != 0.0;
+    const unsigned long long m = __ballot(nz);
+    if (nz) {
+      const int64_t q = pos + __popcll(m & lanemask_lt());
+      inner[q] = r;
+      out[q] = v;
+    }
+    pos += __popcll(m);
+  }
+}
 template <int MAXCH, int NW>
 void launch_pair3(int bin_lo, int bin_hi, int wrt, const DevMat& A, const DevMat& B, const int32_t* lo, const int32_t* span,
                   const uint8_t* binarr, const int64_t* tmpoff, int32_t* out_inner, double* out_val, int32_t* count,
@@ -3241,7 +3264,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   // widest row window the slab kernels take: real 6 waves x 3 slabs = 1152 rows, complex 8 waves x 2 slabs = 1024
   // (the usual geometries are 4 x 3 and 6 x 2 = 768 rows; the wider workgroups serve operands with longer runs)
   // (option spgemm_fma: 1 = the MFMA tile kernel, spgemm_tile.hip -- any window; 3 = the v_fma_f64 loop of the slab kernel, 4 waves)
-  const int slab_rows = A.cplx ? 8 * SLAB_CSL * WAVE : (options().spgemm_fma == 1 ? 16384 : (options().spgemm_fma ? SLAB_NW : 8) * SLAB_SL * WAVE);
+  // (complex operands under FMA arithmetic, option complex_tile: the MFMA tile kernel of spgemm_tile_c.hip -- any window)
+  const bool ctile_try = A.cplx && options().spgemm_fma == 1 && options().complex_tile != 0;
+  const int slab_rows = A.cplx ? (ctile_try ? 16384 : 8 * SLAB_CSL * WAVE) : (options().spgemm_fma == 1 ? 16384 : (options().spgemm_fma ? SLAB_NW : 8) * SLAB_SL * WAVE);
   const size_t esz = A.cplx ? 16 : 8;
   const int sv_opt = options().spgemm_variant;
   // ---- grouped LDS-hash kernel FIRST when the previous multiply of this dimension was computed by it without a
@@ -3311,7 +3336,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     bsz.alloc(snb); tsz.alloc(snb); blk_boff.alloc((size_t)snb + 1); blk_toff.alloc((size_t)snb + 1);
     if (A.cplx)
       hipLaunchKernelGGL((k_slab_plan<SLAB_CJ>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst,
-                         blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb);
+                         blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb, ctile_try ? 16 : 0);
     else
       hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, bfirst,
                          blast, cmin.p, cmax.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb,
@@ -3421,6 +3446,13 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     use_slab = false;
     st.slab = 0;
   }
+  // complex run-like operands under FMA arithmetic: the same plan and operands, numeric phase on the matrix cores
+  // (a geometry it does not take goes to the register-slab kernel when the window fits that one, to the general kernels otherwise)
+  const bool use_ctile = use_slab && ctile_try && (sv_opt < 0 || sv_opt == 400) && spgemm_tile_c_fits((int)hstats[17], (int)hstats[16]);
+  if (use_slab && A.cplx && !use_ctile && (int64_t)hstats[16] > 8 * SLAB_CSL * WAVE) {
+    use_slab = false;
+    st.slab = 0;
+  }
   if (use_slab) {
     tmp_total = slab_tot[2];
     if (A.cplx)
@@ -3512,7 +3544,19 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     }
   }
   if (!grouped_done) t_num.start();
-  if (use_slab && A.cplx) {
+  if (use_ctile) {   // the product as dense complex column runs in the slots; compressed columns by the pack pass below
+    fz_first.alloc((size_t)n); fz_last.alloc((size_t)n);
+    tile_ooff.alloc((size_t)n + 1);
+    TileLaunch tl;
+    tl.runs = reinterpret_cast<const SlabRun*>(runs.p) - ka;
+    tl.bblk = bblk.p; tl.blk_boff = blk_boff.p; tl.blk_kmin = blk_kmin.p; tl.blk_kn = blk_kn.p; tl.blk_lo = blk_lo.p;
+    tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = tmp_val.p; tl.count = count.p;
+    tl.ofirst = fz_first.p; tl.olast = fz_last.p; tl.ooff = tile_ooff.p;
+    tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
+    tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = 0;
+    launch_spgemm_tile_c(tl);
+    for (int i = 0; i < 7; ++i) hstats[i] = 0;
+  } else if (use_slab && A.cplx) {
     if ((int64_t)hstats[16] <= SLAB_CNW * SLAB_CSL * WAVE)
       hipLaunchKernelGGL((k_spgemm_slab_c<SLAB_CNW>), dim3(xcd_grid(snb)), dim3(SLAB_CNW * WAVE), 0, stream(),
                          reinterpret_cast<const SlabRun*>(runs.p) - ka, reinterpret_cast<const double2*>(bblk.p), blk_boff.p,
@@ -3892,7 +3936,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     return;
   }
 
-  if (loose && use_slab && !use_tile) {
+  if (loose && use_slab && !use_tile && !use_ctile) {
     // hand the slots over as they are: the consumer (axpby) reads the columns in place and reports the exact nnz
     loose->valid = true;
     loose->rows = m;
@@ -3943,6 +3987,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   if (use_tile)   // (the tile kernel left dense runs: one wave per column collects the non-zeros in row order)
     hipLaunchKernelGGL(k_pack_slab, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fz_first.p, fz_last.p,
                        tile_ooff.p, tmp_val.p, C.outer.p, C.inner.p, C.val.p);
+  else if (use_ctile)
+    hipLaunchKernelGGL(k_pack_slab_c, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fz_first.p, fz_last.p,
+                       tile_ooff.p, reinterpret_cast<const double2*>(tmp_val.p), C.outer.p, C.inner.p, reinterpret_cast<double2*>(C.val.p));
   else dispatch_type(A.cplx, [&](auto tag) {
     using T = decltype(tag);
     hipLaunchKernelGGL((k_compact<T>), dim3(xcd_grid(nblocks)), dim3(256), 0, stream(), n, tmpoff.p,

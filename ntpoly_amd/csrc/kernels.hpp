@@ -57,6 +57,9 @@ struct EngineOptions {
                                // ntpoly_amd_release_cache() frees it at any time
   int tile_rows = 2;           // MFMA tile kernel (spgemm_fma = 1): consecutive rows per lane of the A operand, 1 / 2 / 4 (spgemm_tile.hpp)
   int tile_waves = 0;          // ... waves per workgroup, 4 / 8 (0: chosen from the LDS footprint)
+  int complex_tile = 1;        // FMA arithmetic: run-like COMPLEX operands on the matrix cores (spgemm_tile_c.hip: two FMA chains per part of an
+                               // entry -- a tolerance mode, 1e-13 of the largest entry); 0: the register-slab kernel with the reference's
+                               // complex multiply-add, bit for bit (what unfused arithmetic always runs)
   int tile_runs_only = 1;      // TRS2 steps on the tile kernel (one rank): the result is written as runs only and the next step builds its
                                // multiplier tiles from them (1.5 GB -> 1.0 GB written per launch at the headline size, no tile read);
                                // 0: runs + multiplier tiles as the unfused loop needs them

@@ -46,5 +46,11 @@ bool spgemm_tile_fits(int max_kn, int max_w);
 int tile_rows();
 inline int tile_expand_align() { return 16 * tile_rows(); }
 void launch_spgemm_tile(const TileLaunch& a);
+// Complex run-like operands (spgemm_tile_c.hip): blocks of 8 complex columns, the operands of k_spgemm_slab_c (run records
+// of 16-byte elements, interleaved multiplier tiles in bblk), windows that start at and are a multiple of 16 rows; epi 0
+// only.  Results as above in complex slots: out_val[2 * slot + part], counts / first / last / ooff per column.
+// A tolerance mode (two FMA chains per part instead of the reference's eight roundings per product).
+bool spgemm_tile_c_fits(int max_kn, int max_w);
+void launch_spgemm_tile_c(const TileLaunch& a);
 
 }  // namespace ntp

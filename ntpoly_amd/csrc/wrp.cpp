@@ -163,6 +163,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "label_rowoff") options().label_rowoff = *value;
   else if (n == "block_path") options().block_path = *value;
   else if (n == "tile_runs_only") options().tile_runs_only = *value;
+  else if (n == "complex_tile") options().complex_tile = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // the current value of the options a caller may want to report (bench.py prints the arithmetic a drop-in caller gets)
@@ -176,6 +177,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "label_order") return options().label_order;
   if (n == "fused_update") return options().fused_update;
   if (n == "loose_iterates") return options().loose_iterates;
+  if (n == "complex_tile") return options().complex_tile;
   NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used

@@ -1,0 +1,118 @@
+"""Complex run-like operands on the FP64 matrix cores (ntpoly_amd/csrc/spgemm_tile_c.hip; option complex_tile = 1, the
+default under FMA arithmetic) against the oracle's complex multiply (MultiplyBlock.f90:9-36, PruneList.f90:8-38; the
+reference's complex multiply-add rounds every product and sum on its own).
+
+The kernel is a TOLERANCE mode (two FMA chains per part of an entry): entries within 1e-13 of the largest entry, the
+pattern identical except where |C(i, j)| lies within that distance of the threshold.  complex_tile = 0 in the same
+arithmetic mode is the bit-for-bit register-slab kernel: both are run and compared with each other as well, so a
+silently unchanged kernel choice cannot pass."""
+import numpy as np
+import pytest
+
+from gen import banded_triplets
+
+pytestmark = pytest.mark.gpu
+REL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def nt():
+    import ntpoly_amd as nt
+    nt.init_comm()
+    nt.ConstructGlobalProcessGrid(1, 1, 1)
+    return nt
+
+
+@pytest.fixture()
+def fma(nt):
+    nt.set_option("spgemm_fma", 1)
+    nt.set_option("complex_tile", 1)
+    yield
+    nt.set_option("complex_tile", 1)
+    nt.set_option("spgemm_fma", 0)
+
+
+def srt(t):
+    c, r, v = (np.asarray(x) for x in t)
+    o = np.lexsort((r, c))
+    return c[o], r[o], v[o]
+
+
+def close(got, want, n, thr, what):
+    import scipy.sparse as sp
+    G = sp.csr_matrix((got[2], (got[1] - 1, got[0] - 1)), shape=(n, n))
+    W = sp.csr_matrix((want[2], (want[1] - 1, want[0] - 1)), shape=(n, n))
+    scale = max(1.0, np.abs(want[2]).max())
+    D = (G - W).tocoo()
+    bad = np.abs(D.data) > REL * scale
+    # entries present on one side only must sit at the threshold
+    assert np.all(np.abs(D.data[bad]) <= thr * (1 + 1e-9) + REL * scale), "%s: max |d| = %g" % (what, np.abs(D.data).max())
+    assert abs(G.nnz - W.nnz) <= max(8, 1e-5 * W.nnz), "%s: %d vs %d entries" % (what, G.nnz, W.nnz)
+
+
+def holes_pair(n, h, holes, seed):
+    rng = np.random.default_rng(seed)
+    mats = []
+    for t in range(2):
+        col, row, val = banded_triplets(n, h, shift=0.1 * t, complex_=True)
+        keep = (rng.random(len(val)) >= holes) | (col == row)
+        mats.append((col[keep], row[keep], val[keep] * (1.0 + 0.01 * t)))
+    return mats
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("n,h,holes,thr,alpha", [(4096, 100, 0.0, 1e-8, 1.0), (3001, 37, 0.4, 0.0, 0.5), (5000, 180, 0.05, 1e-7, -0.75),
+                                                 (777, 3, 0.3, 1e-3, 2.0), (4500, 240, 0.1, 1e-8, 1.0), (5000, 320, 0.0, 1e-8, 1.0),
+                                                 (6144, 450, 0.05, 1e-7, 1.0)])
+def test_complex_tile_kernel_vs_oracle(nt, fma, waves, n, h, holes, thr, alpha):
+    """A * B with A != B and A * A on banded Hermitian-like complex operands with random holes (zero padding of the
+    expanded runs, tiles without survivors, windows beyond the 1024 rows of the register-slab kernel)."""
+    from oracle import oracle_py as O
+    mats = holes_pair(n, h, holes, n + h)
+    A = nt.Matrix_ps.from_triplets(n, *mats[0])
+    B = nt.Matrix_ps.from_triplets(n, *mats[1])
+    Ao = O.Mat.from_triplets(n, n, *mats[0])
+    Bo = O.Mat.from_triplets(n, n, *mats[1])
+    nt.set_option("tile_waves", waves)
+    nt.set_option("spgemm_variant", 400)   # (force the run-based path whatever the hole density)
+    try:
+        for (X, Y, Xo, Yo, tag) in ((A, B, Ao, Bo, "A*B"), (A, A, Ao, Ao, "A*A")):
+            C = nt.Matrix_ps(n)
+            C.Gemm(X, Y, None, alpha, 0.0, thr)
+            assert nt.last_spgemm_stats()["slab"] == 1
+            got = srt(C.triplets())
+            oc, orow, ov = O.ps_multiply(Xo, Yo, None, alpha, 0.0, thr).triplets()
+            want = srt((oc, orow, ov))
+            close(got, want, n, thr, "complex tile %s n=%d h=%d holes=%g" % (tag, n, h, holes))
+            if 4 * h + 2 + 16 <= 1024:   # the bit-for-bit kernel takes this window: it must agree with the oracle exactly, and
+                nt.set_option("complex_tile", 0)   # differ from the matrix-core kernel in the last bits of some entry
+                try:
+                    C0 = nt.Matrix_ps(n)
+                    C0.Gemm(X, Y, None, alpha, 0.0, thr)
+                finally:
+                    nt.set_option("complex_tile", 1)
+                g0 = srt(C0.triplets())
+                assert len(g0[2]) == len(want[2]) and np.array_equal(g0[2], want[2]), "register-slab kernel vs oracle " + tag
+                if h >= 30 and len(got[2]) == len(g0[2]):
+                    assert not np.array_equal(got[2], g0[2]), "the two kernels returned identical bits: was the tile kernel taken?"
+    finally:
+        nt.set_option("spgemm_variant", -1)
+        nt.set_option("tile_waves", 0)
+
+
+def test_complex_tile_solver_products(nt, fma):
+    """What the complex solver loops multiply (SquareRootSolversModule.F90:342-531): powers of a Hermitian operand, alpha and
+    beta in play, C = alpha A B + beta C -- the Gemm vocabulary around the kernel stays what it was."""
+    from oracle import oracle_py as O
+    n, h, thr = 6000, 60, 1e-9
+    col, row, val = banded_triplets(n, h, complex_=True)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    Ao = O.Mat.from_triplets(n, n, col, row, val)
+    A2 = nt.Matrix_ps(n)
+    A2.Gemm(A, A, None, 1.0, 0.0, thr)
+    A2o = O.ps_multiply(Ao, Ao, None, 1.0, 0.0, thr)
+    close(srt(A2.triplets()), srt(A2o.triplets()), n, thr, "A^2")
+    A3 = nt.Matrix_ps(A)
+    A3.Gemm(A2, A, None, 0.25, -1.5, thr)
+    A3o = O.ps_multiply(A2o, Ao, Ao, 0.25, -1.5, thr)
+    close(srt(A3.triplets()), srt(A3o.triplets()), n, thr, "0.25 A^2 A - 1.5 A")
