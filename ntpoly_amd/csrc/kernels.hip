@@ -3152,6 +3152,42 @@ bool try_block_path(const DevMat& A, const DevMat& B, DevMat& C, double alpha, d
   acc.alg_bytes += 12.0 * (double)(nnz_a + nnz_b + C.nnz) + 4.0 * ((double)acols + bcols + n + 3);
   return true;
 }
+// the thin-left kernel (spgemm_thin.hip) with spgemm()'s book-keeping around it
+bool try_thin_left(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {
+  const bool timing = options().time_kernels != 0;
+  EventTimer t_all(timing), t_num(timing);
+  t_all.start();
+  SpgemmStats st;
+  st.nnz_a = A.nnz;
+  st.nnz_b = B.nnz;
+  const int64_t nnz_a = A.nnz, nnz_b = B.nnz;   // (C may be one of the operands)
+  const int32_t acols = A.cols, bcols = B.cols, n = B.cols;
+  const bool cplx = A.cplx;
+  const int dr = (dense_rule ? 1 : 0) | ((options().spgemm_fma && !A.cplx) ? 2 : 0);
+  int64_t products = 0;
+  if (!spgemm_thin_left(A, B, C, alpha, threshold, dr, timing ? &products : nullptr, timing ? t_num.a : nullptr, timing ? t_num.b : nullptr)) {
+    if (timing) {
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+    }
+    return false;
+  }
+  t_all.stop();
+  if (timing) {
+    if (pending_timings().size() >= 4096) flush_spgemm_timers();
+    pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+  }
+  st.thin = 1;
+  st.products = products;
+  st.nnz_c = C.nnz;
+  last_spgemm_stats() = st;
+  SpgemmAccum& acc = spgemm_accum();
+  acc.calls += 1;
+  acc.products += st.products;
+  acc.nnz_c += C.nnz;
+  acc.alg_bytes += (cplx ? 20.0 : 12.0) * (double)(nnz_a + nnz_b + C.nnz) + 4.0 * ((double)acols + bcols + n + 3);
+  return true;
+}
 }  // namespace
 // a TRS2 step in block form (spgemm_block.hip block_trs2_step) with spgemm()'s book-keeping
 bool trs2_block_step(DevMat& X, int mode, double threshold, bool dense_rule, const DevMat& D, double out[4]) {
@@ -3227,6 +3263,11 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     C.reset_empty(m, n, A.cplx);
     last_spgemm_stats() = st;
     return;
+  }
+  // a thin left operand (an identity, a near-diagonal factor): the output-driven gather kernel, whatever the right operand's shape
+  if (!loose && !arange && !A.loose() && !B.loose() && options().thin_left != 0 && options().spgemm_variant < 0 && options().spgemm_force_bin <= 0 &&
+      !strip_ctx().active && A.rows == A.cols && A.nnz <= 8 * (int64_t)A.cols && B.nnz >= A.nnz) {
+    if (try_thin_left(A, B, C, alpha, threshold, dense_rule)) return;
   }
   const bool timing = options().time_kernels != 0;
   EventTimer t_all(timing), t_num(timing);
@@ -6230,14 +6271,74 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
       std::fprintf(stderr, "[slab_multiply] refused: window %d rows, k range %d\n", P.max_w, P.max_kn);
     return give_up();
   }
-  DevBuf<char> runs(((size_t)A.cols + 4) * sizeof(SlabRun));
-  hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, fa.off.p,
-                     reinterpret_cast<const char*>(fa.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), A.cols);
   const size_t oslots = (size_t)P.total + kIndexSlack;
   std::unique_ptr<SlabForm> fo(new SlabForm());
   fo->first.alloc((size_t)n); fo->last.alloc((size_t)n); fo->count.alloc((size_t)n); fo->off.alloc((size_t)n + 1);
   fo->count.zero();
   fo->val.alloc(oslots);
+  // ---- a thin operand (an identity, the near-diagonal factor of a square-root loop): the gather kernels of spgemm_thin.hip
+  // on the same plan and output slots -- a handful of products per entry instead of the whole k range of the block
+  const int thin_mode = (options().thin_left == 0 || fa.labelled() || fb.labelled() || A.rows != A.cols) ? 0
+                        : (A.nnz <= 8 * (int64_t)A.cols && B.nnz >= A.nnz)                                 ? 1
+                        : (B.nnz <= 8 * (int64_t)n)                                                          ? 2
+                                                                                                             : 0;
+  if (thin_mode) {
+    DevMat AT;
+    if (thin_mode == 1) {
+      DevMat Ap = packed_copy(A);
+      AT = transpose(Ap);
+    }
+    DevBuf<int> tflag(2);
+    tflag.zero();
+    t_num.start();
+    ThinSlabArgs ta;
+    ta.blk_lo = P.blk_lo.p; ta.blk_w = P.blk_w.p; ta.blk_toff = P.blk_toff.p;
+    ta.bfirst = fb.first.p; ta.blast = fb.last.p; ta.boff = fb.off.p; ta.bval = fb.val.p;
+    ta.afirst = fa.first.p; ta.alast = fa.last.p; ta.aoff = fa.off.p; ta.aval = fa.val.p;
+    if (thin_mode == 1) { ta.at_outer = AT.outer.p; ta.at_inner = AT.inner.p; ta.at_val = AT.val.p; }
+    ta.out_val = fo->val.p; ta.count = fo->count.p; ta.ofirst = fo->first.p; ta.olast = fo->last.p; ta.ooff = fo->off.p;
+    ta.alpha = alpha; ta.threshold = threshold; ta.dense_rule = dense_rule ? 1 : 0; ta.ncols = n; ta.nrows = A.rows; ta.flag = tflag.p;
+    launch_thin_slab(ta, thin_mode == 1);
+    t_num.stop();
+    DevBuf<long long> tot;
+    sa_sum_counts(fo->count.p, n, tot);
+    int64_t nnz = 0, fl = 0;
+    {
+      ScalarFetch f;
+      f.add(tot.p, 1, &nnz);
+      f.add(tflag.p, 1, &fl);
+      f.run();
+    }
+    if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
+      std::fprintf(stderr, "[slab_multiply] thin %s: nnzA %lld nnzB %lld nnzC %lld slots %lld max_w %d max_kn %d flag %d\n", thin_mode == 1 ? "left" : "right",
+                   (long long)A.nnz, (long long)B.nnz, (long long)nnz, (long long)P.total, P.max_w, P.max_kn, (int)fl);
+    if ((int)(fl & 0xffffffffll) == 0) {
+      t_all.stop();
+      if (timing) {
+        if (pending_timings().size() >= 4096) flush_spgemm_timers();
+        pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+      }
+      fo->row_pad = plan_align;
+      fo->slots = P.total;
+      SpgemmStats st;
+      st.nnz_a = A.nnz; st.nnz_b = B.nnz; st.nnz_c = nnz; st.slab = 1; st.thin = 1; st.tmp_entries = P.total;
+      last_spgemm_stats() = st;
+      SpgemmAccum& acc = spgemm_accum();
+      acc.calls += 1;
+      acc.nnz_c += nnz;
+      acc.alg_bytes += 12.0 * ((double)A.nnz + (double)B.nnz + (double)nnz) + 4.0 * ((double)A.cols + 2.0 * n + 3.0);
+      DevMat R;
+      R.rows = A.rows; R.cols = n; R.cplx = false; R.nnz = nnz; R.zero_free = 1;
+      R.slab = std::move(fo);
+      C = std::move(R);
+      return true;
+    }
+    // (a column of the right operand lists more non-zeros than the kernel holds: the tile kernel below)
+    fo->count.zero();
+  }
+  DevBuf<char> runs(((size_t)A.cols + 4) * sizeof(SlabRun));
+  hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, fa.off.p,
+                     reinterpret_cast<const char*>(fa.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), A.cols);
   t_num.start();
   TileLaunch tl;
   tl.runs = reinterpret_cast<const SlabRun*>(runs.p);

@@ -28,6 +28,7 @@ struct SpgemmStats {
   int block = 0;
   double block_fill = 0;
   int64_t block_tile_products = 0, block_cand = 0;
+  int thin = 0;                // 1: the thin-left kernel (spgemm_thin.hip) computed the product
   float ms_total = 0.f;        // filled only when timing is enabled
   float ms_numeric = 0.f;
 };
@@ -57,6 +58,8 @@ struct EngineOptions {
                                // ntpoly_amd_release_cache() frees it at any time
   int tile_rows = 2;           // MFMA tile kernel (spgemm_fma = 1): consecutive rows per lane of the A operand, 1 / 2 / 4 (spgemm_tile.hpp)
   int tile_waves = 0;          // ... waves per workgroup, 4 / 8 (0: chosen from the LDS footprint)
+  int thin_left = 1;           // products whose left operand holds a handful of entries per row (identities, near-diagonal factors of the
+                               // square-root loops): the output-driven gather kernel of spgemm_thin.hip, both arithmetic modes, bit for bit
   int complex_tile = 1;        // FMA arithmetic: run-like COMPLEX operands on the matrix cores (spgemm_tile_c.hip: two FMA chains per part of an
                                // entry -- a tolerance mode, 1e-13 of the largest entry); 0: the register-slab kernel with the reference's
                                // complex multiply-add, bit for bit (what unfused arithmetic always runs)
@@ -321,6 +324,32 @@ void halo_counts_async(const int64_t* d_req, const int64_t* d_outer_all, int pit
 void halo_bounds_async(const DevMat& A, int32_t c0, const int32_t* d_sa, const int32_t* d_sb, int P, int64_t* d_bound,
                        int64_t* d_cnt_row);
 
+// C = alpha A B for a thin left operand (spgemm_thin.hip); false: not taken (C untouched).  dense_rule_bits: bit 0 the
+// dense branch's order of threshold and alpha, bit 1 fma accumulation (real operands)
+bool spgemm_thin_left(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, int dense_rule_bits, int64_t* products,
+                      hipEvent_t ev_begin, hipEvent_t ev_end);
+// thin operands inside a slab session (spgemm_thin.hip; real, FMA arithmetic): the plan's block windows and output slots, B
+// (and, thin right operand, A) as the runs of the slab form, a thin left operand as the compressed columns of its transpose
+struct ThinSlabArgs {
+  const int32_t *blk_lo = nullptr, *blk_w = nullptr;
+  const int64_t* blk_toff = nullptr;
+  const int32_t *bfirst = nullptr, *blast = nullptr;
+  const int64_t* boff = nullptr;
+  const double* bval = nullptr;
+  const int32_t *afirst = nullptr, *alast = nullptr;
+  const int64_t* aoff = nullptr;
+  const double* aval = nullptr;
+  const int64_t* at_outer = nullptr;
+  const int32_t* at_inner = nullptr;
+  const double* at_val = nullptr;
+  double* out_val = nullptr;
+  int32_t *count = nullptr, *ofirst = nullptr, *olast = nullptr;
+  int64_t* ooff = nullptr;
+  double alpha = 1.0, threshold = 0.0;
+  int dense_rule = 0, ncols = 0, nrows = 0;
+  int* flag = nullptr;   // thin right operand: raised when a column lists more non-zeros than the kernel holds
+};
+void launch_thin_slab(const ThinSlabArgs& a, bool left);
 // counts the operations that change the values of a matrix in place (scale, conjugate, ...): together with the serial
 // number of the value buffer's allocation it tells whether a cached derivative of a matrix is still that matrix
 unsigned long long matrix_value_epoch();

@@ -164,6 +164,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "block_path") options().block_path = *value;
   else if (n == "tile_runs_only") options().tile_runs_only = *value;
   else if (n == "complex_tile") options().complex_tile = *value;
+  else if (n == "thin_left") options().thin_left = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // the current value of the options a caller may want to report (bench.py prints the arithmetic a drop-in caller gets)
@@ -178,6 +179,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "fused_update") return options().fused_update;
   if (n == "loose_iterates") return options().loose_iterates;
   if (n == "complex_tile") return options().complex_tile;
+  if (n == "thin_left") return options().thin_left;
   NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used
@@ -199,6 +201,8 @@ void ntpoly_amd_last_grouped_stats(long long* out, double* ratio) {
   out[5] = s.gh_tile_rows;
   *ratio = s.gh_union_ratio;
 }
+// 1: the last SpGEMM ran on the thin-left kernel (spgemm_thin.hip)
+int ntpoly_amd_last_spgemm_thin() { return last_spgemm_stats().thin; }
 // block path of the last SpGEMM (spgemm_block.hip): out[0..2] = used, 16 x 16 x 16 tile products issued, candidate output
 // super-tiles; fill = entries / (256 tiles) of the left operand
 void ntpoly_amd_last_block_stats(long long* out, double* fill) {

@@ -920,6 +920,12 @@ def last_block_stats():
     return dict(used=int(out[0]), tile_products=int(out[1]), candidates=int(out[2]), fill=r.value)
 
 
+def last_spgemm_thin():
+    """1: the last SpGEMM ran on the thin-left kernel (csrc/spgemm_thin.hip)"""
+    lib.ntpoly_amd_last_spgemm_thin.restype = C.c_int
+    return int(lib.ntpoly_amd_last_spgemm_thin())
+
+
 def block_order(M):
     """position of every index in the block order the engine multiplies matrices of M's dimension in (made from M if none exists)"""
     pos = np.zeros(M.GetActualDimension(), dtype=np.int32)

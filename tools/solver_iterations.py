@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time per iteration of TRS4 / SignFunction on the headline operand (N = 262 144, h = 100, threshold 1e-8) by
 differencing solves capped at 4 and 14 iterations; host synchronisations per solve are printed as well.
-    SOLVER=trs4|sign|pm|hpcp ARITH=fma|unfused NTPOLY_AMD_SLAB_ALGEBRA=0|1 python3 tools/solver_iterations.py
+    SOLVER=trs4|sign|isq|pm|hpcp ARITH=fma|unfused [CPLX=1] NTPOLY_AMD_SLAB_ALGEBRA=0|1 python3 tools/solver_iterations.py
 Under rocprofv3 --kernel-trace --stats this gives profiles/r03_trs4_kernel_stats_*.csv (tools/prof_summary.py)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -17,8 +17,11 @@ if os.environ.get("LATTICE"):   # LATTICE=64: the 64^3 lattice Hamiltonian (bloc
     L = int(os.environ["LATTICE"])
     n = L ** 3
     col, row, val = lattice_triplets(L)
+elif os.environ.get("CPLX"):    # CPLX=1: the configs[4] operand (Hermitian complex, N = 131 072, h = 50); SOLVER=sign (H) | isq (H + 2 I)
+    n, h = 131072, 50
+    col, row, val = banded_triplets(n, h, complex_=True, shift=2.0 if os.environ.get("SOLVER") == "isq" else 0.0)
 else:
-    col, row, val = banded_triplets(n, h)
+    col, row, val = banded_triplets(n, h, shift=2.0 if os.environ.get("SOLVER") == "isq" else 0.0)   # (isq: H + 2 I, positive definite)
 H = nt.Matrix_ps.from_triplets(n, col, row, val)
 I = nt.Matrix_ps(n); I.FillIdentity()
 which = os.environ.get("SOLVER", "trs4")
@@ -30,6 +33,8 @@ for iters in (4, 14, 4, 14):
         e, _ = nt.DensityMatrixSolvers.TRS4(H, I, n / 2.0, K, p)
     elif which == "sign":
         nt.SignSolvers.ComputeSign(H, K, p); e = 0
+    elif which == "isq":
+        nt.SquareRootSolvers.InverseSquareRoot(H, K, p); e = 0
     elif which == "pm":
         e, _ = nt.DensityMatrixSolvers.PM(H, I, n / 2.0, K, p)
     elif which == "hpcp":
