@@ -113,6 +113,7 @@ bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatr
 // that build the sum only for its norm; false: not done (outside a slab session, operands in compressed columns ...)
 bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double beta, double* norm);
 void ps_slab_leave(PSMatrix& m);
+const long long* column_fused_counts();   // [2] since start: IncrementMatrix(Identity, .) done in place, norms of differences taken without forming them (column_fused.hip)
 const long long* block_algebra_counts();  // [2] since start: operations done in block form (spgemm_block.hpp block algebra); fallbacks
 const long long* slab_algebra_counts();   // [4] since start: products, merges / copies, other operations done in slab form; refusals   // back to compressed columns (no-op for a matrix that is not in slab form)
 void ps_fill_identity(PSMatrix& m);

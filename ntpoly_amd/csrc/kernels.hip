@@ -183,6 +183,44 @@ __global__ __launch_bounds__(256) void k_reduce_minmax(const double* __restrict_
   }
 }
 
+// first stage for long vectors: block b reduces the elements b * 256 + t, (b + G) * 256 + t, ... to pmin[b] / pmax[b]
+// (min and max are exact in any grouping: the two stages return what the single block returns)
+__global__ __launch_bounds__(256) void k_reduce_minmax_part(const double* __restrict__ vmin, const double* __restrict__ vmax, int64_t n,
+                                                            double* __restrict__ pmin, double* __restrict__ pmax) {
+  __shared__ double smin[256], smax[256];
+  double mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (vmin) mn = fmin(mn, vmin[i]);
+    if (vmax) mx = fmax(mx, vmax[i]);
+  }
+  smin[threadIdx.x] = mn;
+  smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + o]);
+      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    pmin[blockIdx.x] = smin[0];
+    pmax[blockIdx.x] = smax[0];
+  }
+}
+// out[0] = min of vmin (+inf without), out[1] = max of vmax (-inf without)
+void launch_reduce_minmax(const double* vmin, const double* vmax, int64_t n, double* out) {
+  if (n <= 8192) {
+    hipLaunchKernelGGL(k_reduce_minmax, dim3(1), dim3(256), 0, stream(), vmin, vmax, n, out);
+    return;
+  }
+  const int G = (int)std::min<int64_t>(256, (n + 1023) / 1024);
+  DevBuf<double> part((size_t)2 * G);
+  hipLaunchKernelGGL(k_reduce_minmax_part, dim3(G), dim3(256), 0, stream(), vmin, vmax, n, part.p, part.p + G);
+  hipLaunchKernelGGL(k_reduce_minmax, dim3(1), dim3(256), 0, stream(), vmin ? part.p : (const double*)nullptr,
+                     vmax ? part.p + G : (const double*)nullptr, (int64_t)G, out);
+}
+
 // ------------------------------------------------------------------ SpGEMM: planning
 // first/last stored row and length of every column of A (compact arrays that stay L2-resident
 // while the plan kernel gathers them)
@@ -2764,6 +2802,7 @@ unsigned long long& value_epoch() {
 }
 }  // namespace
 unsigned long long matrix_value_epoch() { return value_epoch(); }
+void bump_matrix_value_epoch() { value_epoch() += 1; }
 namespace {
 // D of a fused purification step (SlabFusion), expanded once: dexp[doff[j] + (r - dmin[j])] = D(r, j), zero in the holes
 struct DotOperand {
@@ -4993,7 +5032,7 @@ void column_abs_sums(const DevMat& A, DevBuf<double>& out) {
 double max_of(const DevBuf<double>& v, size_t n) {
   if (n == 0) return 0.0;
   DevBuf<double> res(2);
-  hipLaunchKernelGGL(k_reduce_minmax, dim3(1), dim3(256), 0, stream(), (const double*)nullptr, v.p, (int64_t)n, res.p);
+  launch_reduce_minmax(nullptr, v.p, (int64_t)n, res.p);
   double h[2];
   res.download(h, 2);
   return h[1];
@@ -5007,7 +5046,7 @@ void gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx) {
     hipLaunchKernelGGL((k_colstat<T>), dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), view(A),
                        col_offset, 1, lo.p, hi.p);
   });
-  hipLaunchKernelGGL(k_reduce_minmax, dim3(1), dim3(256), 0, stream(), lo.p, hi.p, (int64_t)A.cols, res.p);
+  launch_reduce_minmax(lo.p, hi.p, (int64_t)A.cols, res.p);
   double h[2];
   res.download(h, 2);
   *mn = h[0];
@@ -6057,7 +6096,7 @@ bool slab_gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx
   DevBuf<double> lo((size_t)A.cols), hi((size_t)A.cols), res(2);
   hipLaunchKernelGGL(k_sa_colstat, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
                      f.val.p, col_offset, 1, lo.p, hi.p);
-  hipLaunchKernelGGL(k_reduce_minmax, dim3(1), dim3(256), 0, stream(), lo.p, hi.p, (int64_t)A.cols, res.p);
+  launch_reduce_minmax(lo.p, hi.p, (int64_t)A.cols, res.p);
   double h[2];
   res.download(h, 2);
   *mn = h[0];

@@ -60,6 +60,8 @@ struct EngineOptions {
   int tile_waves = 0;          // ... waves per workgroup, 4 / 8 (0: chosen from the LDS footprint)
   int thin_left = 1;           // products whose left operand holds a handful of entries per row (identities, near-diagonal factors of the
                                // square-root loops): the output-driven gather kernel of spgemm_thin.hip, both arithmetic modes, bit for bit
+  int column_fused = 1;        // IncrementMatrix(Identity, B) in place and the norm of a difference without forming it, on compressed columns
+                               // (column_fused.hip: complex solver loops, real ones outside slab sessions); 0: the merge kernels
   int complex_tile = 1;        // FMA arithmetic: run-like COMPLEX operands on the matrix cores (spgemm_tile_c.hip: two FMA chains per part of an
                                // entry -- a tolerance mode, 1e-13 of the largest entry); 0: the register-slab kernel with the reference's
                                // complex multiply-add, bit for bit (what unfused arithmetic always runs)
@@ -353,6 +355,11 @@ void launch_thin_slab(const ThinSlabArgs& a, bool left);
 // counts the operations that change the values of a matrix in place (scale, conjugate, ...): together with the serial
 // number of the value buffer's allocation it tells whether a cached derivative of a matrix is still that matrix
 unsigned long long matrix_value_epoch();
+void bump_matrix_value_epoch();
+// compressed columns without the merge pass (column_fused.hip): B <- B + alpha I in place when every local column stores its
+// diagonal entry (global columns c0 ...); max column abs-sum of alpha A + B without forming it.  false: not taken
+bool add_identity_inplace(DevMat& B, double alpha, int32_t c0);
+bool norm_axpy_columns(const DevMat& A, const DevMat& B, double alpha, double* norm);
 // exclusive scan helper (device), out[n] = total; returns total (synchronises)
 // dense side (dense.hip): entry filter, sparse <-> dense (column major), Hermitian eigendecomposition (parallel
 // two-sided Jacobi), (pivoted) Cholesky on a dense copy

@@ -139,6 +139,7 @@ bool blk_any(std::initializer_list<const PSMatrix*> ms) {
     if (m->loc.blocked()) return true;
   return false;
 }
+long long g_column_fused[2] = {0, 0};   // in-place identity increments, norms of differences (column_fused.hip)
 long long g_block_counts[2] = {0, 0};   // operations of the block algebra; fallbacks to compressed columns
 // an operation outside the session, or after a refusal: no operand may stay in slab form
 void slab_pack_if(std::initializer_list<const PSMatrix*> ms) {
@@ -150,6 +151,7 @@ void slab_pack_if(std::initializer_list<const PSMatrix*> ms) {
 
 const long long* slab_algebra_counts() { return g_slab_counts; }
 const long long* block_algebra_counts() { return g_block_counts; }
+const long long* column_fused_counts() { return g_column_fused; }
 
 SlabSession::SlabSession(bool eligible, bool api) {
   opened = eligible && options().slab_algebra != 0 && (options().spgemm_fma == 1 || options().spgemm_fma == 0) && options().spgemm_variant < 0 &&
@@ -670,15 +672,34 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) 
     g_slab_counts[1] += 1; g_session_did_work = true;
     return;
   }
+  // compressed columns that store their diagonal: one value per column changes, in place
+  if (options().column_fused != 0 && Identity.dim == B.dim && (!Identity.cplx || B.cplx) && !B.loc.expanded() && !B.loc.loose() && !B.loc.blocked() &&
+      add_identity_inplace(B.loc, alpha, B.c0)) {
+    g_column_fused[0] += 1;
+    return;
+  }
   ps_increment(Identity, B, alpha, 0.0);
 }
 
 bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double beta, double* norm) {
   if (blk_any({&A, &B})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
-  if (!slab_on() || A.cplx || B.cplx || A.dim != B.dim || &A == &B || !(A.loc.expanded() || B.loc.expanded())) return false;
-  if (!(slab_enter(mut(A)) && slab_enter(mut(B)) && slab_norm_axpby(A.loc, B.loc, alpha, beta, norm))) return false;
-  g_slab_counts[2] += 1; g_session_did_work = true;
-  return true;
+  if (slab_on() && !A.cplx && !B.cplx && A.dim == B.dim && &A != &B && (A.loc.expanded() || B.loc.expanded())) {
+    if (!(slab_enter(mut(A)) && slab_enter(mut(B)) && slab_norm_axpby(A.loc, B.loc, alpha, beta, norm))) return false;
+    g_slab_counts[2] += 1; g_session_did_work = true;
+    return true;
+  }
+  // compressed columns (complex loops, real ones outside a session): a dense window per column, the difference is never formed
+  auto cols = [](const PSMatrix& M) { return !M.loc.expanded() && !M.loc.loose() && !M.loc.blocked(); };
+  if (options().column_fused != 0 && beta == 1.0 && A.cplx == B.cplx && A.dim == B.dim && &A != &B && cols(A) && cols(B) && A.c0 == B.c0 && A.c1 == B.c1) {
+    double v = 0.0;
+    if (norm_axpy_columns(A.loc, B.loc, alpha, &v)) {
+      comm_allreduce_max(&v, 1);
+      *norm = v;
+      g_column_fused[1] += 1;
+      return true;
+    }
+  }
+  return false;
 }
 
 bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx) {

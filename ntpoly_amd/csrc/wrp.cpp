@@ -165,6 +165,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "tile_runs_only") options().tile_runs_only = *value;
   else if (n == "complex_tile") options().complex_tile = *value;
   else if (n == "thin_left") options().thin_left = *value;
+  else if (n == "column_fused") options().column_fused = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // the current value of the options a caller may want to report (bench.py prints the arithmetic a drop-in caller gets)
@@ -180,6 +181,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "loose_iterates") return options().loose_iterates;
   if (n == "complex_tile") return options().complex_tile;
   if (n == "thin_left") return options().thin_left;
+  if (n == "column_fused") return options().column_fused;
   NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used
@@ -248,6 +250,20 @@ void ntpoly_amd_fusion_counts(long long* out) {
 // out[0..3]: operations the solver loops did on matrices in slab form since start (products, merges / copies, scalings
 // / dots / norms) and operations that had to go back to compressed columns
 // out[0] = vocabulary operations (copy, scale, merge, dot, trace, norm) done on matrices in block form, out[1] = fallbacks
+// [2] since start: identity increments done in place, norms of differences taken from the operands (column_fused.hip)
+void ntpoly_amd_column_fused_counts(long long* out) {
+  out[0] = column_fused_counts()[0];
+  out[1] = column_fused_counts()[1];
+}
+// tests: the two vocabulary operations of the solver loops that have no entry point of their own in the reference's C ABI --
+// IncrementMatrix(Identity, B, alpha) as the loops call it, and the norm of alpha A + beta B (returns 0 when the engine would
+// form the difference instead)
+void ntpoly_amd_increment_identity(const int* ih_identity, int* ih_matB, const double* alpha) {
+  ps_increment_identity(*get<PSMatrix>(ih_identity), *get<PSMatrix>(ih_matB), *alpha);
+}
+int ntpoly_amd_norm_axpby(const int* ih_matA, const int* ih_matB, const double* alpha, const double* beta, double* norm) {
+  return ps_norm_axpby(*get<PSMatrix>(ih_matA), *get<PSMatrix>(ih_matB), *alpha, *beta, norm) ? 1 : 0;
+}
 void ntpoly_amd_block_algebra_counts(long long* out) {
   out[0] = block_algebra_counts()[0];
   out[1] = block_algebra_counts()[1];

@@ -934,6 +934,26 @@ def block_order(M):
     return pos if ok else None
 
 
+def increment_identity(Identity, B, alpha):
+    """IncrementMatrix(Identity, B, alpha) as the solver loops call it (in place where every column stores its diagonal)"""
+    lib.ntpoly_amd_increment_identity(Identity.ih, B.ih, d(alpha))
+
+
+def norm_axpby(A, B, alpha, beta):
+    """MatrixNorm(alpha A + beta B) without forming it; None when the engine would form the difference"""
+    r = C.c_double()
+    lib.ntpoly_amd_norm_axpby.restype = C.c_int
+    ok = lib.ntpoly_amd_norm_axpby(A.ih, B.ih, d(alpha), d(beta), C.byref(r))
+    return r.value if ok else None
+
+
+def column_fused_counts():
+    """operations on compressed columns done without the merge pass (csrc/column_fused.hip) since start"""
+    out = (C.c_longlong * 2)()
+    lib.ntpoly_amd_column_fused_counts(out)
+    return dict(identity_in_place=int(out[0]), norms_of_differences=int(out[1]))
+
+
 def block_algebra_counts():
     """(operations of solver loops / C-ABI loops done on matrices in block form, fallbacks to compressed columns)"""
     out = (C.c_longlong * 2)()
