@@ -143,9 +143,36 @@ def test_scale_logs_vs_reference(nt, arith, idx, c):
     assert float(np.real(kv).sum()) == pytest.approx(c["sum_re"], rel=1e-8, abs=1e-5)
 
 
-def test_config4_sign_of_the_indefinite_operand(nt):
+def test_config4_inverse_square_root_full_size(nt, arith):
+    """configs[4] InverseSquareRoot of the Hermitian complex H + 2 I at the benched size (N = 131 072, h = 50) in both
+    arithmetic modes (FMA: the complex matrix-core kernel and the thin-operand kernels): Z (H + 2 I) Z = I, Z Hermitian,
+    the reference's iteration count for this operand family (10)."""
+    n, h, thr = 131072, 50, 1e-8
+    col, row, val = banded_triplets(n, h, complex_=True, shift=2.0)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    del col, row, val
+    p = nt.SolverParameters()
+    p.SetThreshold(thr)
+    p.SetConvergeDiff(1e-10)
+    Z = nt.Matrix_ps(n)
+    nt.SquareRootSolvers.InverseSquareRoot(A, Z, p)
+    tr = nt.solver_trace()
+    assert tr["iterations"] == 10
+    ZA, ZAZ = nt.Matrix_ps(n), nt.Matrix_ps(n)
+    ZA.Gemm(Z, A, None, 1.0, 0.0, thr)
+    ZAZ.Gemm(ZA, Z, None, 1.0, 0.0, thr)
+    Ident = nt.Matrix_ps(n)
+    Ident.FillIdentity()
+    ZAZ.Increment(Ident, -1.0, 0.0)
+    assert ZAZ.Norm() <= 1e-5
+    assert Z.MeasureAsymmetry() <= 1e-6
+    assert Z.GetSize() > 100 * n
+
+
+def test_config4_sign_of_the_indefinite_operand(nt, arith):
     """configs[4] SignFunction on the Hermitian complex H itself (N = 131 072, h = 50; eigenvalues of both signs, so
-    sign(H) is far from the identity): S^2 = I, S Hermitian, S commutes with H, and |trace(S)| well below N."""
+    sign(H) is far from the identity), both arithmetic modes (FMA: the complex matrix-core kernel): S^2 = I, S Hermitian,
+    S commutes with H, and |trace(S)| well below N."""
     n, h, thr = 131072, 50, 1e-8
     col, row, val = banded_triplets(n, h, complex_=True)
     H = nt.Matrix_ps.from_triplets(n, col, row, val)
