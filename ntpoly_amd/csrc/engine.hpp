@@ -91,12 +91,16 @@ void ps_copy(const PSMatrix& a, PSMatrix& b);
 // packs what leaves it (ps_slab_leave).  Any operation that cannot be done in slab form packs its operands and takes
 // the general path; after a handful of refusals the session stays off.
 struct SlabSession {
-  explicit SlabSession(bool eligible, bool api = false);   // api: a one-call session of the C ABI's vocabulary entry points
+  // api: a one-call session of the C ABI's vocabulary entry points.  complex_ok: the loop's products, identity increments and
+  // norms of differences take COMPLEX operands in slab form too (FMA arithmetic, options complex_tile / complex_sessions);
+  // every other operation packs them first
+  explicit SlabSession(bool eligible, bool api = false, bool complex_ok = false);
   ~SlabSession();
   SlabSession(const SlabSession&) = delete;
   SlabSession& operator=(const SlabSession&) = delete;
   void close();   // (the loop is over: what follows works on compressed columns again)
   bool opened = false;
+  bool set_complex = false;
 };
 // Out = alpha A + beta B: CopyMatrix(B, Out); ScaleMatrix(Out, beta); IncrementMatrix(A, Out, alpha, threshold) -- in a
 // slab session one pass without the copy (and B, an identity say, is turned into slab form once instead of its copies)

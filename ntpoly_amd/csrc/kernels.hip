@@ -4756,7 +4756,7 @@ DevMat packed_copy(const DevMat& M) {
     DevMat R;
     R.rows = M.rows;
     R.cols = M.cols;
-    R.cplx = false;
+    R.cplx = M.cplx;
     R.zero_free = 1;
     const int n = M.cols;
     R.outer.alloc((size_t)n + 1);
@@ -4769,7 +4769,12 @@ DevMat packed_copy(const DevMat& M) {
     }
     R.nnz = nnz;
     R.inner.alloc((size_t)nnz + kIndexSlack);
-    R.val.alloc((size_t)nnz + kIndexSlack);
+    R.val.alloc(((size_t)nnz + kIndexSlack) * R.wval());
+    if (n && M.cplx) {   // (complex slab sessions: (re, im) interleaved runs)
+      hipLaunchKernelGGL(k_pack_slab_c, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, f.first.p, f.last.p, f.off.p,
+                         reinterpret_cast<const double2*>(f.val.p), R.outer.p, R.inner.p, reinterpret_cast<double2*>(R.val.p));
+      return R;
+    }
     if (n)
       hipLaunchKernelGGL(k_pack_slab, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, f.first.p, f.last.p,
                          f.off.p, f.val.p, R.outer.p, R.inner.p, R.val.p);
@@ -6418,6 +6423,156 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
   acc.alg_bytes += 12.0 * ((double)A.nnz + (double)B.nnz + (double)nnz) + 4.0 * ((double)A.cols + 2.0 * n + 3.0);
   DevMat R;
   R.rows = A.rows; R.cols = n; R.cplx = false; R.nnz = nnz; R.zero_free = 1;
+  R.slab = std::move(fo);
+  C = std::move(R);
+  return true;
+}
+
+
+// ------------------------------------------------------------------ complex operands in slab form (a session that allows them:
+// the SignFunction loop).  The same form -- a dense run of (re, im) pairs per column in a slot aligned to 16 rows -- produced and
+// consumed by the complex MFMA tile kernel (spgemm_tile_c.hip): between two products of a loop nothing is expanded or packed.
+namespace {
+__global__ __launch_bounds__(256) void k_count_zero_values_c(Csc A, unsigned long long* __restrict__ out) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= A.cols) return;
+  const int lane = lane_id();
+  const double2* __restrict__ v = static_cast<const double2*>(A.val);
+  int c = 0;
+  for (int64_t p = A.outer[j] + lane, e = col_end(A, j); p < e; p += WAVE) c += (v[p].x == 0.0 && v[p].y == 0.0) ? 1 : 0;
+  const unsigned long long m = __ballot(c != 0);
+  if (m && lane == 0) atomicAdd(out, 1ull);
+}
+}  // namespace
+bool sa_operand_c(const DevMat& M) {
+  return M.expanded() && M.cplx && !M.slab->labelled() && !M.slab->origin && M.rows == M.cols && M.slab->row_pad % 16 == 0;
+}
+bool slab_enter_c(DevMat& M) {
+  if (M.expanded()) return sa_operand_c(M);
+  if (!M.cplx || M.blocked() || M.loose() || M.rows != M.cols || M.nnz == 0 || M.slab_hint < 0 || options().spgemm_fma != 1 ||
+      options().complex_tile == 0)
+    return false;
+  const int n = M.cols, al = 16;
+  std::unique_ptr<SlabForm> f(new SlabForm());
+  f->first.alloc((size_t)n); f->last.alloc((size_t)n); f->count.alloc((size_t)n); f->off.alloc((size_t)n + 1);
+  DevBuf<int32_t> span((size_t)n);
+  DevBuf<unsigned long long> zc(1);
+  zc.zero();
+  hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(M), f->first.p, f->last.p, f->count.p);
+  hipLaunchKernelGGL(k_span_aligned, dim3(cdiv(n, 256)), dim3(256), 0, stream(), f->first.p, f->last.p, span.p, n, al);
+  scan_async<int32_t>(span.p, f->off.p, (int64_t)n);
+  if (M.zero_free != 1)
+    hipLaunchKernelGGL(k_count_zero_values_c, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(M), zc.p);
+  int64_t tot = 0;
+  unsigned long long hz = 0;
+  {
+    ScalarFetch ft;
+    ft.add(f->off.p + n, 1, &tot);
+    ft.add(zc.p, 1, &hz);
+    ft.run();
+  }
+  if (hz == 0) M.zero_free = 1;
+  // (stored zeros would read as "no entry"; mostly holes: not run-like)
+  if (hz != 0 || (double)tot > 2.0 * (double)M.nnz + 2.0 * al * (double)n) {
+    if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
+      std::fprintf(stderr, "[slab_enter_c] refused: slots %lld for %lld entries, columns with stored zeros %llu\n", (long long)tot, (long long)M.nnz, hz);
+    M.slab_hint = -1;
+    return false;
+  }
+  f->val.alloc(((size_t)tot + kIndexSlack) * 2);
+  hipLaunchKernelGGL(k_aligned_offsets<double2>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), f->first.p, f->last.p,
+                     f->off.p, reinterpret_cast<double2*>(f->val.p), n, al);
+  hipLaunchKernelGGL(k_slab_expand_a<double2>, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), view(M), f->first.p,
+                     f->off.p, reinterpret_cast<double2*>(f->val.p));
+  f->row_pad = al;
+  f->slots = tot;
+  DevMat R;
+  R.rows = M.rows; R.cols = n; R.cplx = true; R.nnz = M.nnz; R.zero_free = 1;
+  R.slab = std::move(f);
+  M = std::move(R);
+  return true;
+}
+
+// C = alpha A B with the threshold rule of the SpGEMM, complex operands and result in slab form (the complex MFMA tile kernel:
+// the tolerance mode of DESIGN.md section 4); false: not taken, C untouched
+bool slab_multiply_c(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {
+  if (!sa_operand_c(A) || !sa_operand_c(B) || A.cols != B.rows || options().spgemm_fma != 1 || options().complex_tile == 0 ||
+      options().spgemm_variant >= 0 || options().spgemm_force_bin > 0) {
+    if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM")) std::fprintf(stderr, "[slab_multiply_c] refused: operands / options\n");
+    return false;
+  }
+  const SlabForm &fa = *A.slab, &fb = *B.slab;
+  const int n = B.cols, snb = cdiv(n, SLAB_CJ);
+  const bool timing = options().time_kernels != 0;
+  EventTimer t_all(timing), t_num(timing);
+  t_all.start();
+  DevBuf<int32_t> blk_lo(snb), blk_w(snb), blk_kmin(snb), blk_kn(snb);
+  DevBuf<int64_t> bsz(snb), tsz(snb), blk_toff((size_t)snb + 1);
+  DevBuf<unsigned long long> stats(24);
+  stats.zero();
+  hipLaunchKernelGGL((k_slab_plan<SLAB_CJ>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, fb.first.p, fb.last.p, fa.first.p,
+                     fa.last.p, blk_lo.p, blk_w.p, blk_kmin.p, blk_kn.p, bsz.p, tsz.p, snb, 16);
+  hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), blk_w.p, blk_kn.p, snb, (const int32_t*)nullptr, 0, stats.p);
+  scan_async<int64_t>(tsz.p, blk_toff.p, (int64_t)snb);
+  int64_t total = 0;
+  unsigned long long hs[3] = {0, 0, 0};
+  {
+    ScalarFetch f;
+    f.add(blk_toff.p + snb, 1, &total);
+    f.add(stats.p + 16, 3, hs);
+    f.run();
+  }
+  const int max_w = (int)hs[0], max_kn = (int)hs[1];
+  if (max_w <= 0 || hs[0] > 16384 || !spgemm_tile_c_fits(max_kn, max_w)) {
+    if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM")) std::fprintf(stderr, "[slab_multiply_c] refused: window %llu rows, k range %llu\n", hs[0], hs[1]);
+    if (timing) {
+      event_pool().push_back(t_all.a); event_pool().push_back(t_all.b);
+      event_pool().push_back(t_num.a); event_pool().push_back(t_num.b);
+    }
+    return false;
+  }
+  DevBuf<char> runs(((size_t)A.cols + 4) * sizeof(SlabRun));
+  hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, fa.off.p,
+                     reinterpret_cast<const char*>(fa.val.p), 16, reinterpret_cast<SlabRun*>(runs.p), A.cols);
+  std::unique_ptr<SlabForm> fo(new SlabForm());
+  fo->first.alloc((size_t)n); fo->last.alloc((size_t)n); fo->count.alloc((size_t)n); fo->off.alloc((size_t)n + 1);
+  fo->count.zero();
+  fo->val.alloc(((size_t)total + kIndexSlack) * 2);
+  t_num.start();
+  TileLaunch tl;
+  tl.runs = reinterpret_cast<const SlabRun*>(runs.p);
+  tl.bblk = fb.val.p; tl.blk_boff = nullptr;
+  tl.brun_first = fb.first.p; tl.brun_last = fb.last.p; tl.brun_off = fb.off.p; tl.brun_val = fb.val.p;
+  tl.blk_kmin = blk_kmin.p; tl.blk_kn = blk_kn.p; tl.blk_lo = blk_lo.p; tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p;
+  tl.out_val = fo->val.p; tl.count = fo->count.p; tl.ofirst = fo->first.p; tl.olast = fo->last.p; tl.ooff = fo->off.p;
+  tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dense_rule ? 1 : 0; tl.ncols = n; tl.nblocks = snb;
+  tl.max_kn = max_kn; tl.max_w = max_w; tl.epi = 0;
+  launch_spgemm_tile_c(tl);
+  t_num.stop();
+  DevBuf<long long> tot;
+  sa_sum_counts(fo->count.p, n, tot);
+  int64_t nnz = 0;
+  {
+    ScalarFetch f;
+    f.add(tot.p, 1, &nnz);
+    f.run();
+  }
+  t_all.stop();
+  if (timing) {
+    if (pending_timings().size() >= 4096) flush_spgemm_timers();
+    pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
+  }
+  fo->row_pad = 16;
+  fo->slots = total;
+  SpgemmStats st;
+  st.nnz_a = A.nnz; st.nnz_b = B.nnz; st.nnz_c = nnz; st.slab = 1; st.tmp_entries = total;
+  last_spgemm_stats() = st;
+  SpgemmAccum& acc = spgemm_accum();
+  acc.calls += 1;
+  acc.nnz_c += nnz;
+  acc.alg_bytes += 20.0 * ((double)A.nnz + (double)B.nnz + (double)nnz) + 4.0 * ((double)A.cols + 2.0 * n + 3.0);
+  DevMat R;
+  R.rows = A.rows; R.cols = n; R.cplx = true; R.nnz = nnz; R.zero_free = 1;
   R.slab = std::move(fo);
   C = std::move(R);
   return true;

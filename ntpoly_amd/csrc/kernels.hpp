@@ -60,6 +60,8 @@ struct EngineOptions {
   int tile_waves = 0;          // ... waves per workgroup, 4 / 8 (0: chosen from the LDS footprint)
   int thin_left = 1;           // products whose left operand holds a handful of entries per row (identities, near-diagonal factors of the
                                // square-root loops): the output-driven gather kernel of spgemm_thin.hip, both arithmetic modes, bit for bit
+ int complex_sessions = 1;    // the complex SignFunction loop keeps its iterates in the complex tile kernel's operand form between products (no
+                               // expansion, no pack; FMA arithmetic with complex_tile); 0: compressed columns between the operations
   int column_fused = 1;        // IncrementMatrix(Identity, B) in place and the norm of a difference without forming it, on compressed columns
                                // (column_fused.hip: complex solver loops, real ones outside slab sessions); 0: the merge kernels
   int complex_tile = 1;        // FMA arithmetic: run-like COMPLEX operands on the matrix cores (spgemm_tile_c.hip: two FMA chains per part of an
@@ -204,6 +206,14 @@ void slab_counts_async(const DevMat& X, int64_t* d_cnt64);
 // cannot take them (the caller packs and takes the general path).
 bool slab_enter(DevMat& M);   // compressed columns -> slab form in place (false: not run-like, stored zeros, complex ...)
 bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule);
+// complex operands in slab form (FMA arithmetic, option complex_tile; a session that allows them): runs of (re, im) pairs in
+// slots aligned to 16 rows -- what the complex MFMA tile kernel reads and writes.  Each returns false when it does not take
+// its operands (nothing changed): the caller packs and the compressed-column path does the work.
+bool sa_operand_c(const DevMat& M);
+bool slab_enter_c(DevMat& M);
+bool slab_multiply_c(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule);
+bool slab_add_diagonal_c(DevMat& B, double alpha, int32_t col_offset);                      // slab_extra.hip
+bool slab_norm_axpby_c(const DevMat& A, const DevMat& B, double alpha, double beta, double* out);   // slab_extra.hip
 bool slab_axpby(const DevMat& A, DevMat& B, double alpha, double beta, double threshold);   // B <- alpha A + beta B
 bool slab_axpby_to(const DevMat& A, const DevMat& B, DevMat& Out, double alpha, double beta, double threshold);   // Out = alpha A + beta B
 bool slab_clone(const DevMat& A, DevMat& Out);

@@ -113,6 +113,7 @@ bool slab_on() { return g_slab_depth > 0 && !g_slab_failed; }
 // (the representation of an operand, not its value, changes: const operands are converted in place)
 DevMat& mut(const PSMatrix& m) { return const_cast<DevMat&>(m.loc); }
 int g_slab_refusals = 0;
+bool g_complex_session = false;   // the open session's loop takes complex operands in slab form (SlabSession complex_ok)
 bool g_session_api = false, g_session_did_work = false;
 long long g_slab_counts[4] = {0, 0, 0, 0};   // products, merges / copies, other operations in slab form; refusals
 // an operation that cannot be done in slab form: its operands go back to compressed columns and the general path does
@@ -153,9 +154,13 @@ const long long* slab_algebra_counts() { return g_slab_counts; }
 const long long* block_algebra_counts() { return g_block_counts; }
 const long long* column_fused_counts() { return g_column_fused; }
 
-SlabSession::SlabSession(bool eligible, bool api) {
+SlabSession::SlabSession(bool eligible, bool api, bool complex_ok) {
   opened = eligible && options().slab_algebra != 0 && (options().spgemm_fma == 1 || options().spgemm_fma == 0) && options().spgemm_variant < 0 &&
            options().spgemm_force_bin <= 0 && !world().active();
+  if (opened && complex_ok && options().complex_sessions != 0 && options().spgemm_fma == 1 && options().complex_tile != 0 && !g_complex_session) {
+    g_complex_session = true;
+    set_complex = true;
+  }
   // (a one-call session of the C ABI on a matrix that is not run-like pays the refused conversion once: slab_enter leaves a
   // mark on the matrix, DevMat::slab_hint, and says no at once when asked again)
   if (opened) {
@@ -165,6 +170,7 @@ SlabSession::SlabSession(bool eligible, bool api) {
 }
 SlabSession::~SlabSession() { close(); }
 void SlabSession::close() {
+  if (set_complex) { g_complex_session = false; set_complex = false; }
   if (opened) {
     g_slab_depth -= 1;
     if (g_slab_depth == 0) g_session_did_work = false;
@@ -519,6 +525,19 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     return;
   }
   unblock({&A, &B});
+  if (slab_on() && g_complex_session && A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 && A.loc.nnz > 0 && B.loc.nnz > 0) {
+    // (a session that takes complex operands: the iterates stay in the complex tile kernel's operand form)
+    const double denom = (double)A.dim * (double)A.dim;
+    const bool dense_rule = denom > 0 && std::min((double)A.loc.nnz / denom, (double)B.loc.nnz / denom) > 0.1;
+    if (slab_enter_c(mut(A)) && (&A == &B || slab_enter_c(mut(B))) && slab_multiply_c(A.loc, B.loc, AB, alpha, threshold, dense_rule)) {
+      g_slab_counts[0] += 1; g_session_did_work = true;
+      C.grid = A.grid; C.dim = A.dim; C.c0 = B.c0; C.c1 = B.c1;
+      C.cplx = true;
+      C.loc = std::move(AB);
+      return;
+    }
+    slab_refused({&A, &B});
+  }
   if (slab_on() && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 && A.loc.nnz > 0 && B.loc.nnz > 0) {
     // (a slab session: operands are turned into slab form where they are, the product stays in it)
     const double denom = (double)A.dim * (double)A.dim;
@@ -672,6 +691,10 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) 
     g_slab_counts[1] += 1; g_session_did_work = true;
     return;
   }
+  if (slab_on() && g_complex_session && B.loc.expanded() && B.cplx && Identity.dim == B.dim && slab_add_diagonal_c(B.loc, alpha, B.c0)) {
+    g_slab_counts[1] += 1; g_session_did_work = true;
+    return;
+  }
   // compressed columns that store their diagonal: one value per column changes, in place
   if (options().column_fused != 0 && Identity.dim == B.dim && (!Identity.cplx || B.cplx) && !B.loc.expanded() && !B.loc.loose() && !B.loc.blocked() &&
       add_identity_inplace(B.loc, alpha, B.c0)) {
@@ -685,6 +708,11 @@ bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double be
   if (blk_any({&A, &B})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
   if (slab_on() && !A.cplx && !B.cplx && A.dim == B.dim && &A != &B && (A.loc.expanded() || B.loc.expanded())) {
     if (!(slab_enter(mut(A)) && slab_enter(mut(B)) && slab_norm_axpby(A.loc, B.loc, alpha, beta, norm))) return false;
+    g_slab_counts[2] += 1; g_session_did_work = true;
+    return true;
+  }
+  if (slab_on() && g_complex_session && A.cplx && B.cplx && A.dim == B.dim && &A != &B && (A.loc.expanded() || B.loc.expanded())) {
+    if (!(slab_enter_c(mut(A)) && slab_enter_c(mut(B)) && slab_norm_axpby_c(A.loc, B.loc, alpha, beta, norm))) return false;
     g_slab_counts[2] += 1; g_session_did_work = true;
     return true;
   }

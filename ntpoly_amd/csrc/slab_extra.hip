@@ -349,6 +349,98 @@ bool slab_norm_axpby(const DevMat& A, const DevMat& B, double alpha, double beta
   return true;
 }
 
+// ------------------------------------------------------------------ complex operands in slab form (kernels.hpp slab_enter_c)
+namespace {
+// column j: the diagonal entry (global row col_offset + j) must be stored; newval[j] = alpha + it (AddSparseVectors: alpha * 1
+// rounded, then added); flag bit 0: no diagonal entry, bit 1: the sum is zero (the merge would drop it)
+__global__ void k_sa_diag_c(int n, const int32_t* __restrict__ first, const int32_t* __restrict__ last, const int64_t* __restrict__ off,
+                            double2* __restrict__ val, int col_offset, double alpha, int apply, double2* __restrict__ newval, int* __restrict__ flag) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int d = j + col_offset, f = first[j], l = last[j];
+  if (apply) {
+    val[off[j] + (d - f)] = newval[j];
+    return;
+  }
+  int fl = 0;
+  if (l < f || d < f || d > l) {
+    fl = 1;
+  } else {
+    const double2 old = val[off[j] + (d - f)];
+    if (old.x == 0.0 && old.y == 0.0) {
+      fl = 1;
+    } else {
+      const double2 one = make_double2(1.0, 0.0);
+      const double2 nv = Sc<double2>::add(Sc<double2>::scale(alpha, one), old);
+      newval[j] = nv;
+      if (nv.x == 0.0 && nv.y == 0.0) fl = 2;
+    }
+  }
+  if (fl) atomicOr(flag, fl);
+}
+__global__ __launch_bounds__(256) void k_sa_norm_axpby_c(int n, const int32_t* __restrict__ fa, const int32_t* __restrict__ la,
+                                                         const int64_t* __restrict__ offa, const double2* __restrict__ va,
+                                                         const int32_t* __restrict__ fb, const int32_t* __restrict__ lb,
+                                                         const int64_t* __restrict__ offb, const double2* __restrict__ vb, double alpha,
+                                                         double beta, double* __restrict__ colsum) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= n) return;
+  const int lane = lane_id();
+  const int fA = fa[j], lA = la[j], fB = fb[j], lB = lb[j];
+  const bool anyA = lA >= fA, anyB = lB >= fB;
+  double s = 0.0;
+  if (anyA || anyB) {
+    const int f = anyA ? (anyB ? min(fA, fB) : fA) : fB, l = anyA ? (anyB ? max(lA, lB) : lA) : lB;
+    const double2* __restrict__ pa = anyA ? va + (offa[j] - fA) : va;
+    const double2* __restrict__ pb = anyB ? vb + (offb[j] - fB) : vb;
+    for (int r = f + lane; r <= l; r += WAVE) {
+      const double2 a = (anyA && r >= fA && r <= lA) ? pa[r] : make_double2(0.0, 0.0);
+      const double2 b = (anyB && r >= fB && r <= lB) ? pb[r] : make_double2(0.0, 0.0);
+      const double2 v = Sc<double2>::add(Sc<double2>::scale(alpha, a), Sc<double2>::scale(beta, b));
+      s = __dadd_rn(s, Sc<double2>::mag(v));
+    }
+  }
+  s = wave_sum_f64(s);
+  if (lane == 0) colsum[j] = s;
+}
+}  // namespace
+
+// B <- B + alpha I on a complex slab-form matrix, in place; false: a column without a stored diagonal entry or a zero sum
+// (B untouched: the caller packs and merges)
+bool slab_add_diagonal_c(DevMat& B, double alpha, int32_t col_offset) {
+  if (!sa_operand_c(B) || B.zero_free != 1 || alpha == 0.0) return false;
+  SlabForm& f = *B.slab;
+  const int n = B.cols;
+  DevBuf<double> newval((size_t)2 * n);
+  DevBuf<int> flag(2);
+  flag.zero();
+  hipLaunchKernelGGL(k_sa_diag_c, dim3(cdiv(n, 256)), dim3(256), 0, stream(), n, f.first.p, f.last.p, f.off.p, reinterpret_cast<double2*>(f.val.p),
+                     col_offset, alpha, 0, reinterpret_cast<double2*>(newval.p), flag.p);
+  long long h = 0;
+  {
+    ScalarFetch ft;
+    ft.add(flag.p, 1, &h);
+    ft.run();
+  }
+  if ((int)(h & 0xffffffffll) != 0) return false;
+  hipLaunchKernelGGL(k_sa_diag_c, dim3(cdiv(n, 256)), dim3(256), 0, stream(), n, f.first.p, f.last.p, f.off.p, reinterpret_cast<double2*>(f.val.p),
+                     col_offset, alpha, 1, reinterpret_cast<double2*>(newval.p), flag.p);
+  return true;
+}
+
+// MatrixNorm(alpha A + beta B) of two complex slab-form matrices, nothing built
+bool slab_norm_axpby_c(const DevMat& A, const DevMat& B, double alpha, double beta, double* out) {
+  if (!sa_operand_c(A) || !sa_operand_c(B) || A.cols != B.cols) return false;
+  const SlabForm &fa = *A.slab, &fb = *B.slab;
+  const int n = A.cols;
+  DevBuf<double> cs((size_t)n);
+  hipLaunchKernelGGL(k_sa_norm_axpby_c, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
+                     reinterpret_cast<const double2*>(fa.val.p), fb.first.p, fb.last.p, fb.off.p, reinterpret_cast<const double2*>(fb.val.p), alpha,
+                     beta, cs.p);
+  *out = max_of(cs, (size_t)n);
+  return true;
+}
+
 // ------------------------------------------------------------------ MatrixTrace of a slab-form matrix
 namespace {
 __global__ __launch_bounds__(256) void k_sa_diag(int n, const int32_t* __restrict__ first, const int32_t* __restrict__ last,

@@ -709,7 +709,9 @@ void sign_core(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters& 
     log_enter();
   }
   int II;
-  SlabSession slab(!Out.cplx && !needs_transpose);
+  // (complex operands under FMA arithmetic: the loop's products, identity increment and norm take them in slab form as well)
+  const bool complex_session = Out.cplx && options().complex_sessions != 0 && options().spgemm_fma == 1 && options().complex_tile != 0;
+  SlabSession slab(!needs_transpose && (!Out.cplx || complex_session), false, complex_session);
   for (II = 1; II <= p.max_iterations; ++II) {
     const double alpha_k = std::fmin(std::sqrt(3.0 / (1.0 + xk + xk * xk)), alpha);
     xk = 0.5 * alpha_k * xk * (3.0 - (alpha_k * alpha_k) * (xk * xk));

@@ -63,6 +63,11 @@ struct TileCArgs {
   double alpha, threshold;
   int dense_rule, ncols, nblocks;
   int k4max, tmax;
+  // optional: the right operand as the runs of its columns (complex slab sessions: no multiplier tiles were built) -- first /
+  // last row, offset of the first row (in complex elements) and values; bblk / blk_boff are then unused
+  const int32_t *brun_first, *brun_last;
+  const int64_t* brun_off;
+  const double2* brun_val;
   const double* zero;      // 16 bytes of zeros
 };
 
@@ -103,13 +108,27 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))
   const int T = (w + 15) >> 4;
   // ---- block prologue: multiplier tile -> LDS (rows kn .. K4 zero), run records + row range of every k group
   constexpr int NT = NW * WAVE, BCH = 3072 / NT;
-  const double2* __restrict__ bsrc = a.bblk + a.blk_boff[b];
+  const bool brun = a.brun_val != nullptr;
+  const double2* __restrict__ bsrc = brun ? a.brun_val : a.bblk + a.blk_boff[b];
   double2* bdst = reinterpret_cast<double2*>(Bs);
   double2 btmp[BCH];
+  // (the multiplier tile from the runs of the block's columns: unit i of the tile is row kmin + i / 8 of column i % 8, and a
+  // thread always serves the same column -- NT is a multiple of 8)
+  int bf0 = INT_MAX, bl0 = -1;
+  const double2* bp0 = nullptr;
+  if (brun) {
+    const int c0 = b * CJ + (tid & 7);
+    if (c0 < a.ncols) { bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0]; bp0 = a.brun_val + (a.brun_off[c0] - bf0); }
+  }
+  auto brun_load = [&](int i) {
+    const int r = kmin + (i >> 3);
+    return (i < kn * 8 && r >= bf0 && r <= bl0) ? bp0[r] : make_double2(0.0, 0.0);
+  };
 #pragma unroll
   for (int u = 0; u < BCH; ++u) {
     const int i = tid + u * NT;
-    btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+    if (brun) btmp[u] = brun_load(i);
+    else btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
   }
   {
     const uint4* __restrict__ rp = reinterpret_cast<const uint4*>(a.runs + kmin);
@@ -150,7 +169,10 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))
     const int i = tid + u * NT;
     if (i < K4 * 8) bdst[i] = btmp[u];
   }
-  for (int i = tid + BCH * NT; i < K4 * 8; i += NT) bdst[i] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+  for (int i = tid + BCH * NT; i < K4 * 8; i += NT) {
+    if (brun) bdst[i] = brun_load(i);
+    else bdst[i] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+  }
   for (int t = tid; t < T; t += NT) colmask[t] = 0u;
   if (tid < CJ) {
     col_cnt[tid] = 0;
@@ -326,6 +348,8 @@ void launch_spgemm_tile_c(const TileLaunch& L) {
   TileCArgs a;
   a.runs = static_cast<const SlabRun*>(L.runs);
   a.bblk = reinterpret_cast<const double2*>(L.bblk);
+  a.brun_first = L.brun_first; a.brun_last = L.brun_last; a.brun_off = L.brun_off;
+  a.brun_val = reinterpret_cast<const double2*>(L.brun_val);
   a.blk_boff = L.blk_boff; a.blk_kmin = L.blk_kmin; a.blk_kn = L.blk_kn; a.blk_lo = L.blk_lo; a.blk_w = L.blk_w;
   a.blk_toff = L.blk_toff; a.out_val = L.out_val; a.count = L.count; a.ofirst = L.ofirst; a.olast = L.olast; a.ooff = L.ooff;
   a.alpha = L.alpha; a.threshold = L.threshold; a.dense_rule = L.dense_rule; a.ncols = L.ncols; a.nblocks = L.nblocks;

@@ -166,6 +166,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "complex_tile") options().complex_tile = *value;
   else if (n == "thin_left") options().thin_left = *value;
   else if (n == "column_fused") options().column_fused = *value;
+  else if (n == "complex_sessions") options().complex_sessions = *value;
   else NTP_FATAL("unknown option " + n);
 }
 // the current value of the options a caller may want to report (bench.py prints the arithmetic a drop-in caller gets)
@@ -182,6 +183,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "complex_tile") return options().complex_tile;
   if (n == "thin_left") return options().thin_left;
   if (n == "column_fused") return options().column_fused;
+  if (n == "complex_sessions") return options().complex_sessions;
   NTP_FATAL("unknown option " + n);
 }
 // statistics of the last SpGEMM: out[0..12]: nnzA, nnzB, nnzC, products, tmp_entries, bins[6], overflow, slab kernel used

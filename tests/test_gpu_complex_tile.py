@@ -116,3 +116,45 @@ def test_complex_tile_solver_products(nt, fma):
     A3.Gemm(A2, A, None, 0.25, -1.5, thr)
     A3o = O.ps_multiply(A2o, Ao, Ao, 0.25, -1.5, thr)
     close(srt(A3.triplets()), srt(A3o.triplets()), n, thr, "0.25 A^2 A - 1.5 A")
+
+
+def test_complex_sign_session_keeps_the_iterates_in_slab_form(nt, fma):
+    """SignFunction on a complex Hermitian operand (SignSolversModule.F90:150-258) with the loop's iterates kept in the complex
+    tile kernel's operand form between products (option complex_sessions; no expansion, no pack) against the same loop on
+    compressed columns: the products are the same kernel on the same values, the identity increment the same element rule --
+    the result is IDENTICAL, the iteration count equal, the convergence norms (another summation order) agree to 1e-12."""
+    n, h, thr = 8000, 40, 1e-8
+    col, row, val = banded_triplets(n, h, complex_=True)
+    H = nt.Matrix_ps.from_triplets(n, col, row, val)
+    res = {}
+    for opt in (1, 0):
+        nt.set_option("complex_sessions", opt)
+        try:
+            p = nt.SolverParameters()
+            p.SetThreshold(thr)
+            p.SetConvergeDiff(1e-9)
+            S = nt.Matrix_ps(n)
+            c0 = nt.slab_algebra_counts()
+            nt.SignSolvers.ComputeSign(H, S, p)
+            c1 = nt.slab_algebra_counts()
+            tr = nt.solver_trace()
+            res[opt] = (srt(S.triplets()), tr["iterations"], np.asarray(tr["value"]), {k: c1[k] - c0[k] for k in c0})
+        finally:
+            nt.set_option("complex_sessions", 1)
+    it = res[1][1]
+    assert it == res[0][1] and it >= 5
+    # (the generated H stores a few exact zeros, which a slab form would read as "no entry": the first iteration's two
+    # products are refused and run on compressed columns; every later operand is a product, zero-free by construction)
+    assert res[1][3]["products"] >= 2 * (it - 1) and res[1][3]["refusals"] <= 2, res[1][3]
+    assert res[1][3]["merges"] >= it - 1 and res[1][3]["others"] >= it - 1, res[1][3]
+    assert res[0][3]["products"] == 0
+    assert np.allclose(res[1][2], res[0][2], rtol=1e-12, atol=0)
+    a, b = res[1][0], res[0][0]
+    assert len(a[2]) == len(b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    # and it is the sign function: S^2 = I
+    S2 = nt.Matrix_ps(n)
+    S2.Gemm(S, S, None, 1.0, 0.0, thr)
+    Ident = nt.Matrix_ps(n)
+    Ident.FillIdentity()
+    S2.Increment(Ident, -1.0, 0.0)
+    assert S2.Norm() <= 1e-5
