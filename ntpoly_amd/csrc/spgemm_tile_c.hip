@@ -75,8 +75,10 @@ __host__ __device__ inline size_t tile_c_lds_bytes(int k4max, int tmax) {
   return (size_t)k4max * 16 * 8 + (size_t)(k4max + CRPAD) * sizeof(CRec) + (size_t)(k4max / 4 + 1) * 8 + (size_t)((tmax + 3) & ~3) * 4 + 3 * CJ * 4 + 64;
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_spgemm_tile_c(const TileCArgs a) {
+// R: tiles of 16 rows a wave multiplies together (they share the multiplier rows read from LDS and the run records: 2 R
+// matrix instructions per k group and R run loads per lane)
+template <int NW, int R>
+__global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 : 3, 8))) void k_spgemm_tile_c(const TileCArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = xcd_block(a.nblocks);
   if (b < 0) return;
@@ -191,76 +193,12 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))
   const bool dense_rule = (a.dense_rule & 1) != 0;
   const int smask = part ? 0 : (int)0x80000000u;   // the multiplier of the imaginary plane: -Im B in the real columns, Re B in the imaginary ones
   const int rend = lo + w;
-  const int mid = (T - 1) >> 1;
+  const int TS = (T + R - 1) / R;   // groups of R tiles
+  const int mid = (TS - 1) >> 1;
 
-  for (int ti = 0;; ++ti) {   // (snake order over the waves; centre first: the tiles in the middle of the window have the longest k ranges)
-    const int ts = ti * NW + ((ti & 1) ? NW - 1 - wave : wave);
-    if (ti * NW >= T) break;
-    if (ts >= T) continue;
-    const int t = (ts & 1) ? mid + ((ts + 1) >> 1) : mid - (ts >> 1);
-    const int r0 = lo + 16 * t;
-    int g0 = INT_MAX, g1 = -1;   // the k groups that can reach the tile: a ballot over the groups' row ranges
-    for (int c = 0; c < KG; c += WAVE) {
-      const int gq = min(c + lane, KG);
-      const unsigned long long m = __ballot(grmin[gq] <= r0 + 15 && grmax[gq] >= r0);   // (group KG: empty, never true)
-      if (m) {
-        if (g0 == INT_MAX) g0 = c + (int)__builtin_ctzll(m);
-        g1 = c + 63 - (int)__builtin_clzll(m);
-      }
-    }
-    if (g1 < g0) continue;   // (no k group reaches the tile: colmask[t] stays 0)
-    v4d accr = v4d{0.0, 0.0, 0.0, 0.0}, acci = v4d{0.0, 0.0, 0.0, 0.0};
-    {
-      const int rl = r0 + jj;                      // A operand: row rl, column 4 g + q
-      const unsigned long long r16 = (unsigned long long)((long long)rl * 16);
-      const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(recs) + q;     // record of group g: rq[4 g]
-      const double* __restrict__ bq = Bs + lane;                                   // B'(4 g + q, jj) = bq[64 g]
-      const double* __restrict__ bx = Bs + (lane ^ 1);                             // the other part of the same column
-      auto run_load = [&](const uint4 raw) -> v2d {
-        const unsigned long long rz = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
-        const bool ok = (unsigned)(rl - (int)raw.z) <= raw.w;
-        return ld_c(ok ? rz + r16 : zaddr);
-      };
-      auto swz = [&](double x) { return __hiloint2double(__double2hiint(x) ^ smask, __double2loint(x)); };
-      v2d ring[CPF];
-      double bb[3], bs[3];
-      const int KGm1 = KG - 1;
-#pragma unroll
-      for (int u = 0; u < CPF; ++u) ring[u] = run_load(rq[4 * min(g0 + u, KG)]);
-      bb[0] = bq[64 * g0];
-      bs[0] = swz(bx[64 * g0]);
-      bb[1] = bq[64 * min(g0 + 1, KGm1)];
-      bs[1] = swz(bx[64 * min(g0 + 1, KGm1)]);
-      bb[2] = 0.0;
-      bs[2] = 0.0;
-      uint4 raw = rq[4 * min(g0 + CPF, KG)];
-      int g = g0;
-      for (; g + CPF - 1 <= g1; g += CPF) {
-#pragma unroll
-        for (int u = 0; u < CPF; ++u) {
-          // (the order is pinned: record read one slot ahead | matrix instructions | refill of the slot they have read)
-          const uint4 raw_n = rq[4 * min(g + u + CPF + 1, KG)];
-          __builtin_amdgcn_sched_barrier(0);
-          accr = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u].x, bb[u % 3], accr, 0, 0, 0);
-          acci = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u].y, bs[u % 3], acci, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          ring[u] = run_load(raw);
-          bb[(u + 2) % 3] = bq[64 * min(g + u + 2, KGm1)];
-          bs[(u + 2) % 3] = swz(bx[64 * min(g + u + 2, KGm1)]);
-          raw = raw_n;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < CPF - 1; ++u) {
-        if (g + u <= g1) {
-          const double bt = bq[64 * (g + u)], bu = swz(bx[64 * (g + u)]);
-          accr = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u].x, bt, accr, 0, 0, 0);
-          acci = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u].y, bu, acci, 0, 0, 0);
-        }
-      }
-    }
-    // ---- epilogue of the tile: this lane holds part `part` of rows r0 + 4 v + q (v = 0..3) of complex column cc
+  // ---- epilogue of one tile of 16 rows (index t16, first row r0m): this lane holds part `part` of rows r0m + 4 v + q
+  // (v = 0..3) of complex column cc
+  auto epilogue = [&](const v4d& accr, const v4d& acci, int t16, int r0m) {
     double o[4];
     bool keep[4];
     bool amb_any = false, any = false;
@@ -284,7 +222,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))
       amb_any |= amb;
       any |= sure | amb;
     }
-    if (__ballot(any) == 0ull) continue;   // nothing of the tile survives: colmask[t] stays 0
+    if (__ballot(any) == 0ull) return;   // nothing of the tile survives: colmask[t16] stays 0
     if (__ballot(amb_any) != 0ull) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) keep[v] = hypot(tre[v], tim[v]) > thr;
@@ -293,7 +231,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))
     int c_l = 0, f_l = INT_MAX, l_l = -1;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int r = r0 + 4 * v + q;
+      const int r = r0m + 4 * v + q;
       anykeep |= __ballot(keep[v]);
       c_l += keep[v] ? 1 : 0;
       f_l = min(f_l, keep[v] ? r : INT_MAX);
@@ -308,9 +246,99 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(4, 8))
     }
     if ((cm >> jj) & 1u) {   // the column has an entry in this tile: its 16 rows are written (zeros = holes)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) orun[2 * (int64_t)(r0 + 4 * v + q)] = o[v];
+      for (int v = 0; v < 4; ++v) orun[2 * (int64_t)(r0m + 4 * v + q)] = o[v];
     }
-    if (lane == 0) colmask[t] = cm;
+    if (lane == 0) colmask[t16] = cm;
+  };
+
+  for (int ti = 0;; ++ti) {   // (snake order over the waves; centre first: the tiles in the middle of the window have the longest k ranges)
+    const int ts = ti * NW + ((ti & 1) ? NW - 1 - wave : wave);
+    if (ti * NW >= TS) break;
+    if (ts >= TS) continue;
+    const int t = (ts & 1) ? mid + ((ts + 1) >> 1) : mid - (ts >> 1);
+    const int r0 = lo + 16 * R * t;
+    int g0 = INT_MAX, g1 = -1;   // the k groups that can reach the tiles: a ballot over the groups' row ranges
+    for (int c = 0; c < KG; c += WAVE) {
+      const int gq = min(c + lane, KG);
+      const unsigned long long m = __ballot(grmin[gq] <= r0 + 16 * R - 1 && grmax[gq] >= r0);   // (group KG: empty, never true)
+      if (m) {
+        if (g0 == INT_MAX) g0 = c + (int)__builtin_ctzll(m);
+        g1 = c + 63 - (int)__builtin_clzll(m);
+      }
+    }
+    if (g1 < g0) continue;   // (no k group reaches the tiles: their colmask entries stay 0)
+    v4d accr[R], acci[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+      accr[m] = v4d{0.0, 0.0, 0.0, 0.0};
+      acci[m] = v4d{0.0, 0.0, 0.0, 0.0};
+    }
+    {
+      const int rl = r0 + jj;                      // A operand: rows rl + 16 m, column 4 g + q
+      const unsigned long long r16 = (unsigned long long)((long long)rl * 16);
+      const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(recs) + q;     // record of group g: rq[4 g]
+      const double* __restrict__ bq = Bs + lane;                                   // B'(4 g + q, jj) = bq[64 g]
+      const double* __restrict__ bx = Bs + (lane ^ 1);                             // the other part of the same column
+      auto run_load = [&](const uint4 raw, int m) -> v2d {
+        const unsigned long long rz = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
+        const bool ok = (unsigned)(rl + 16 * m - (int)raw.z) <= raw.w;
+        return ld_c(ok ? rz + r16 + 256ull * (unsigned)m : zaddr);
+      };
+      auto swz = [&](double x) { return __hiloint2double(__double2hiint(x) ^ smask, __double2loint(x)); };
+      v2d ring[CPF][R];
+      double bb[3], bs[3];
+      const int KGm1 = KG - 1;
+#pragma unroll
+      for (int u = 0; u < CPF; ++u) {
+        const uint4 rw = rq[4 * min(g0 + u, KG)];
+#pragma unroll
+        for (int m = 0; m < R; ++m) ring[u][m] = run_load(rw, m);
+      }
+      bb[0] = bq[64 * g0];
+      bs[0] = swz(bx[64 * g0]);
+      bb[1] = bq[64 * min(g0 + 1, KGm1)];
+      bs[1] = swz(bx[64 * min(g0 + 1, KGm1)]);
+      bb[2] = 0.0;
+      bs[2] = 0.0;
+      uint4 raw = rq[4 * min(g0 + CPF, KG)];
+      int g = g0;
+      for (; g + CPF - 1 <= g1; g += CPF) {
+#pragma unroll
+        for (int u = 0; u < CPF; ++u) {
+          // (the order is pinned: record read one slot ahead | matrix instructions | refill of the slot they have read)
+          const uint4 raw_n = rq[4 * min(g + u + CPF + 1, KG)];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < R; ++m) {
+            accr[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][m].x, bb[u % 3], accr[m], 0, 0, 0);
+            acci[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][m].y, bs[u % 3], acci[m], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < R; ++m) ring[u][m] = run_load(raw, m);
+          bb[(u + 2) % 3] = bq[64 * min(g + u + 2, KGm1)];
+          bs[(u + 2) % 3] = swz(bx[64 * min(g + u + 2, KGm1)]);
+          raw = raw_n;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < CPF - 1; ++u) {
+        if (g + u <= g1) {
+          const double bt = bq[64 * (g + u)], bu = swz(bx[64 * (g + u)]);
+#pragma unroll
+          for (int m = 0; m < R; ++m) {
+            accr[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][m].x, bt, accr[m], 0, 0, 0);
+            acci[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][m].y, bu, acci[m], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+      const int t16 = R * t + m;
+      if (t16 < T) epilogue(accr[m], acci[m], t16, r0 + 16 * m);   // (the window is a multiple of 16 rows, not of 16 R)
+    }
   }
   __syncthreads();
   // entries, first and last row of every column; where its run starts
@@ -366,17 +394,22 @@ void launch_spgemm_tile_c(const TileLaunch& L) {
   const bool wide = 3 * lds > 160 * 1024;
   const int tw = options().tile_waves;
   const int nw = (tw == 4 || tw == 8) ? tw : (wide ? 8 : 4);
-  auto go = [&](auto nw_tag) {
-    constexpr int NW = decltype(nw_tag)::value;
+  // R = 2 (two tiles per wave step) where the windows hold enough tiles for every wave to get a pair (option tile_rows = 1: one)
+  const int rr = (options().tile_rows == 1 || a.tmax < 2 * nw) ? 1 : 2;
+  auto go = [&](auto nw_tag, auto r_tag) {
+    constexpr int NW = decltype(nw_tag)::value, RR = decltype(r_tag)::value;
     static size_t raised = 0;   // (one per instantiation)
     if (lds > 64 * 1024 && lds > raised) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile_c<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile_c<NW, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       raised = 150 * 1024;
     }
-    hipLaunchKernelGGL((k_spgemm_tile_c<NW>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
+    hipLaunchKernelGGL((k_spgemm_tile_c<NW, RR>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
   };
-  if (nw == 4) go(std::integral_constant<int, 4>{});
-  else go(std::integral_constant<int, 8>{});
+  using R1 = std::integral_constant<int, 1>; using R2 = std::integral_constant<int, 2>;
+  if (nw == 4 && rr == 1) go(std::integral_constant<int, 4>{}, R1{});
+  else if (nw == 4) go(std::integral_constant<int, 4>{}, R2{});
+  else if (rr == 1) go(std::integral_constant<int, 8>{}, R1{});
+  else go(std::integral_constant<int, 8>{}, R2{});
 }
 
 }  // namespace ntp
