@@ -2,7 +2,7 @@
 # Round-4 evidence after the complex / thin-operand kernels: tools/collect_r04_final.sh <tag>  (everything under gpurun_out/<tag>*)
 # bench + kernel statistics + PMC traffic of the three bench workloads, the other BASELINE configs, a roofline line per
 # solver loop (real and complex) and the kernel statistics of the complex loops.
-tag=${1:-r04_v6}
+tag=${1:-r04_v7}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 bash tools/collect_profiles.sh ${tag}
 bash tools/collect_profiles.sh ${tag}_lattice --lattice 64
