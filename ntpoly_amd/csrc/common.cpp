@@ -182,6 +182,8 @@ void DevMat::reset_empty(int32_t r, int32_t c, bool z) {
   blk.reset();
   slots = 0;
   zero_free = 0;
+  block_hint = 0;   // hints describe the PATTERN that was stored here, not this object
+  slab_hint = 0;
   outer.alloc((size_t)c + 1);
   outer.zero();
   inner.alloc(kIndexSlack);
@@ -198,6 +200,8 @@ void DevMat::alloc(int32_t r, int32_t c, bool z, int64_t nz) {
   blk.reset();
   slots = 0;
   zero_free = 0;
+  block_hint = 0;
+  slab_hint = 0;
   outer.alloc((size_t)c + 1);
   inner.alloc((size_t)nz + kIndexSlack);
   val.alloc(((size_t)nz + kIndexSlack) * (z ? 2 : 1));

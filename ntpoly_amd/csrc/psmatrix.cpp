@@ -114,7 +114,6 @@ bool slab_on() { return g_slab_depth > 0 && !g_slab_failed; }
 DevMat& mut(const PSMatrix& m) { return const_cast<DevMat&>(m.loc); }
 int g_slab_refusals = 0;
 bool g_complex_session = false;   // the open session's loop takes complex operands in slab form (SlabSession complex_ok)
-bool g_session_api = false, g_session_did_work = false;
 long long g_slab_counts[4] = {0, 0, 0, 0};   // products, merges / copies, other operations in slab form; refusals
 // an operation that cannot be done in slab form: its operands go back to compressed columns and the general path does
 // it (a Hamiltonian with stored zeros in the first merge of a loop); the session goes on, unless this keeps happening
@@ -164,7 +163,7 @@ SlabSession::SlabSession(bool eligible, bool api, bool complex_ok) {
   // (a one-call session of the C ABI on a matrix that is not run-like pays the refused conversion once: slab_enter leaves a
   // mark on the matrix, DevMat::slab_hint, and says no at once when asked again)
   if (opened) {
-    if (g_slab_depth == 0) { g_slab_failed = false; g_slab_refusals = 0; g_session_api = api; }
+    if (g_slab_depth == 0) { g_slab_failed = false; g_slab_refusals = 0; }
     g_slab_depth += 1;
   }
 }
@@ -173,7 +172,6 @@ void SlabSession::close() {
   if (set_complex) { g_complex_session = false; set_complex = false; }
   if (opened) {
     g_slab_depth -= 1;
-    if (g_slab_depth == 0) g_session_did_work = false;
   }
   opened = false;
 }
@@ -197,7 +195,7 @@ void ps_copy(const PSMatrix& a, PSMatrix& b) {
   if (slab_on() && a.loc.expanded()) {
     DevMat t;
     if (slab_clone(a.loc, t)) {
-      g_slab_counts[1] += 1; g_session_did_work = true;
+      g_slab_counts[1] += 1;
       b.grid = a.grid; b.dim = a.dim; b.cplx = a.cplx; b.c0 = a.c0; b.c1 = a.c1;
       b.loc = std::move(t);
       return;
@@ -518,7 +516,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     const double denom = (double)A.dim * (double)A.dim;
     const bool dense_rule = denom > 0 && std::min((double)A.loc.nnz / denom, (double)B.loc.nnz / denom) > 0.1;
     spgemm(A.loc, B.loc, AB, alpha, threshold, dense_rule);
-    g_session_did_work = true;
+   
     C.grid = A.grid; C.dim = A.dim; C.c0 = B.c0; C.c1 = B.c1;
     C.cplx = false;
     C.loc = std::move(AB);
@@ -530,7 +528,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     const double denom = (double)A.dim * (double)A.dim;
     const bool dense_rule = denom > 0 && std::min((double)A.loc.nnz / denom, (double)B.loc.nnz / denom) > 0.1;
     if (slab_enter_c(mut(A)) && (&A == &B || slab_enter_c(mut(B))) && slab_multiply_c(A.loc, B.loc, AB, alpha, threshold, dense_rule)) {
-      g_slab_counts[0] += 1; g_session_did_work = true;
+      g_slab_counts[0] += 1;
       C.grid = A.grid; C.dim = A.dim; C.c0 = B.c0; C.c1 = B.c1;
       C.cplx = true;
       C.loc = std::move(AB);
@@ -551,7 +549,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     };
     if (slab_enter(mut(A)) && (&A == &B || slab_enter(mut(B))) && runs_dense(A.loc) && runs_dense(B.loc) &&
         slab_multiply(A.loc, B.loc, AB, alpha, threshold, dense_rule)) {
-      g_slab_counts[0] += 1; g_session_did_work = true;
+      g_slab_counts[0] += 1;
       if (options().time_kernels != 0) {   // (statistics mode: the products a plan over compressed columns would have counted)
         const long long pr = slab_product_count(A.loc, B.loc);
         last_spgemm_stats().products = pr;
@@ -577,7 +575,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     } else {
       AB = multiply_panel(A, B, alpha, threshold);
     }
-    if (AB.blocked() && g_slab_refusals > 0) { g_slab_refusals -= 1; g_session_did_work = true; }
+    if (AB.blocked() && g_slab_refusals > 0) { g_slab_refusals -= 1; }
   } else {
     // Process slices (the reference's 2.5-D algorithm, MatrixMultiply.f90:25-29, 74-80, 230-267): slice s multiplies
     // its share of the inner dimension -- the blocks g with g % S == s, block = padded dimension / (max(rows, columns)
@@ -656,7 +654,7 @@ void ps_scale(PSMatrix& A, double c) {
   }
   unblock({&A});
   if (slab_on() && A.loc.expanded()) {
-    if (slab_scale(A.loc, c)) { g_slab_counts[2] += 1; g_session_did_work = true; return; }
+    if (slab_scale(A.loc, c)) { g_slab_counts[2] += 1; return; }
     slab_refused({&A});
   }
   scale(A.loc, c);
@@ -673,7 +671,7 @@ void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double 
   unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B) {
     // (a slab session: the operand still in compressed columns -- an identity, the Hamiltonian -- is turned into slab form)
-    if (slab_enter(mut(A)) && slab_enter(B.loc) && slab_axpby(A.loc, B.loc, alpha, beta, threshold)) { g_slab_counts[1] += 1; g_session_did_work = true; return; }
+    if (slab_enter(mut(A)) && slab_enter(B.loc) && slab_axpby(A.loc, B.loc, alpha, beta, threshold)) { g_slab_counts[1] += 1; return; }
     slab_refused({&A, &B});
   } else {
     slab_pack_if({&A, &B});
@@ -688,11 +686,11 @@ void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double 
 
 void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) {
   if (slab_on() && B.loc.expanded() && !B.cplx && !Identity.cplx && Identity.dim == B.dim && slab_add_diagonal(B.loc, alpha, B.c0)) {
-    g_slab_counts[1] += 1; g_session_did_work = true;
+    g_slab_counts[1] += 1;
     return;
   }
   if (slab_on() && g_complex_session && B.loc.expanded() && B.cplx && Identity.dim == B.dim && slab_add_diagonal_c(B.loc, alpha, B.c0)) {
-    g_slab_counts[1] += 1; g_session_did_work = true;
+    g_slab_counts[1] += 1;
     return;
   }
   // compressed columns that store their diagonal: one value per column changes, in place
@@ -708,12 +706,12 @@ bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double be
   if (blk_any({&A, &B})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
   if (slab_on() && !A.cplx && !B.cplx && A.dim == B.dim && &A != &B && (A.loc.expanded() || B.loc.expanded())) {
     if (!(slab_enter(mut(A)) && slab_enter(mut(B)) && slab_norm_axpby(A.loc, B.loc, alpha, beta, norm))) return false;
-    g_slab_counts[2] += 1; g_session_did_work = true;
+    g_slab_counts[2] += 1;
     return true;
   }
   if (slab_on() && g_complex_session && A.cplx && B.cplx && A.dim == B.dim && &A != &B && (A.loc.expanded() || B.loc.expanded())) {
     if (!(slab_enter_c(mut(A)) && slab_enter_c(mut(B)) && slab_norm_axpby_c(A.loc, B.loc, alpha, beta, norm))) return false;
-    g_slab_counts[2] += 1; g_session_did_work = true;
+    g_slab_counts[2] += 1;
     return true;
   }
   // compressed columns (complex loops, real ones outside a session): a dense window per column, the difference is never formed
@@ -734,7 +732,7 @@ bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, dou
   if (blk_any({&X, &X2})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
   if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx) return false;
   if (!slab_trs4_traces(X.loc, X2.loc, X.c0, trace_fx, trace_gx)) return false;
-  g_slab_counts[2] += 1; g_session_did_work = true;
+  g_slab_counts[2] += 1;
   return true;
 }
 bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatrix& P) {
@@ -744,7 +742,7 @@ bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatr
   if (!slab_trs4_operand(X.loc, X2.loc, sigma, X.c0, R)) return false;
   P.grid = X.grid; P.dim = X.dim; P.cplx = false; P.c0 = X.c0; P.c1 = X.c1;
   P.loc = std::move(R);
-  g_slab_counts[1] += 1; g_session_did_work = true;
+  g_slab_counts[1] += 1;
   return true;
 }
 
@@ -758,7 +756,7 @@ void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double a
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B && A.dim == B.dim) {
     DevMat R;
     if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_axpby_to(A.loc, B.loc, R, alpha, beta, threshold)) {
-      g_slab_counts[1] += 1; g_session_did_work = true;
+      g_slab_counts[1] += 1;
       Out.grid = B.grid; Out.dim = B.dim; Out.cplx = false; Out.c0 = B.c0; Out.c1 = B.c1;
       Out.loc = std::move(R);
       return;
@@ -1190,7 +1188,7 @@ void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
   }
   unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx) {
-    if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_dot(A.loc, B.loc, out)) { g_slab_counts[2] += 1; g_session_did_work = true; return; }
+    if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_dot(A.loc, B.loc, out)) { g_slab_counts[2] += 1; return; }
     slab_refused({&A, &B});
   } else {
     slab_pack_if({&A, &B});
@@ -1216,7 +1214,7 @@ double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includ
   if (slab_on() && A.loc.expanded() && !A.cplx) {
     double v = 0.0;
     if (slab_trace(A.loc, A.c0, &v)) {
-      g_slab_counts[2] += 1; g_session_did_work = true;
+      g_slab_counts[2] += 1;
       return v;
     }
     slab_refused({&A});
@@ -1237,7 +1235,7 @@ double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns 
   unblock({&A});
   if (slab_on() && A.loc.expanded()) {
     double v = 0.0;
-    if (slab_norm(A.loc, &v)) { g_slab_counts[2] += 1; g_session_did_work = true; return v; }
+    if (slab_norm(A.loc, &v)) { g_slab_counts[2] += 1; return v; }
     slab_refused({&A});
   } else {
     slab_pack_if({&A});
@@ -1259,7 +1257,7 @@ void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {  // Gershg
   double mn, mx;
   if (slab_on() && A.loc.expanded()) {
     if (slab_gershgorin(A.loc, A.c0, &mn, &mx)) {
-      g_slab_counts[2] += 1; g_session_did_work = true;
+      g_slab_counts[2] += 1;
       *e_min = mn;
       *e_max = mx;
       return;

@@ -17,8 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def sources_sha16():
     """fingerprint of the kernel sources the figure belongs to (bench.py reports the traffic only for these sources)"""
     h = hashlib.sha256()
-    for f in ("kernels.hip", "slab_loop.inc", "spgemm_grouped.hip", "spgemm_tile.hip", "spgemm_block.hip"):
-        with open(os.path.join(ROOT, "ntpoly_amd", "csrc", f), "rb") as fh:
+    csrc = os.path.join(ROOT, "ntpoly_amd", "csrc")
+    # every device source and every header / generated loop they include: a figure belongs to ALL of them
+    for f in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".inc"))):
+        h.update(f.encode())
+        with open(os.path.join(csrc, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
