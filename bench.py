@@ -133,12 +133,189 @@ def sources_sha16():
     return h.hexdigest()[:16]
 
 
+def run_config3(nt, args, rank, world):
+    """BASELINE configs[3]: ONE distributed product C = A * A of the banded operand at N = 1 048 576, halfband 100 (201 per
+    row; --permute SEED: the same operand under the seeded random relabelling the reference's load balancer applies,
+    LoadBalancerModule.F90:14-52), through MatrixMultiply_ps_wrp exactly as distributed_algebra_includes/MatrixMultiply.f90
+    :92-267 is entered by a caller.  A step = one multiply (exchange + local product + prune); value = output entries per
+    second over all ranks; the roofline object is rank 0's numeric kernel."""
+    from gen import banded_triplets, permuted_banded_triplets
+    n = args.n if args.n is not None else 1048576
+    h, thr = args.halfband, args.threshold
+    nt.ConstructGlobalProcessGrid(1, world, 1)
+    nt.set_option("time_kernels", 1)
+    lib_default = "fma" if nt.get_option("spgemm_fma") == 1 else "unfused"
+    arithmetic = args.arithmetic or lib_default
+    nt.set_option("spgemm_fma", 1 if arithmetic == "fma" else 0)
+    A = nt.Matrix_ps(n)
+    c0, c1 = A.local_columns()
+    col, row, val = banded_triplets(n, h, c0=c0, c1=c1) if args.permute is None else permuted_banded_triplets(n, h, args.permute, c0=c0, c1=c1)
+    tl = nt.TripletList_r()
+    tl.set_arrays(col, row, val)
+    A.FillFromTripletList(tl, prepartitioned=True)
+    del col, row, val, tl
+    nnz_a = A.GetSize()
+    Cm = nt.Matrix_ps(n)
+    pool = nt.PMatrixMemoryPool(A)
+
+    def fence():
+        nt.synchronize()
+        if world > 1:
+            nt.barrier()
+            nt.synchronize()
+
+    # The timed region runs with the per-product statistics OFF (they cost a counting pass and a read-back of their own
+    # inside MatrixMultiply); the roofline object comes from one more, untimed, block of the same K multiplies with the
+    # HIP-event timers and the statistics on.
+    blocks = []
+    for blk in range(max(1, args.blocks) + 1):
+        stats_block = blk == max(1, args.blocks)
+        nt.set_option("time_kernels", 1 if stats_block else 0)
+        for _ in range(max(1, args.warmup)):
+            Cm.Gemm(A, A, pool, 1.0, 0.0, thr)
+        nt.reset_spgemm_accum()
+        m0 = nt.malloc_stats()
+        h0 = nt.exchange_stats()[2]
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            Cm.Gemm(A, A, pool, 1.0, 0.0, thr)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            elapsed = nt.allreduce_max(elapsed)
+        rec = dict(elapsed=elapsed, acc=nt.spgemm_accum(), st=nt.last_spgemm_stats(), gs=nt.last_grouped_stats(), bs=nt.last_block_stats(),
+                   m0=m0, m1=nt.malloc_stats(), syncs=nt.exchange_stats()[2] - h0)
+        if stats_block:
+            stats = rec
+        else:
+            blocks.append(rec)
+    nnz_c = Cm.GetSize()     # (collective; whole matrix)
+    order = sorted(range(len(blocks)), key=lambda k: blocks[k]["elapsed"])
+    med = blocks[order[len(order) // 2]]
+    if rank != 0:
+        return None
+    elapsed, acc, st, gs, bs = med["elapsed"], stats["acc"], stats["st"], stats["gs"], stats["bs"]
+    calls = max(1, acc["calls"])
+    ms_numeric = max(acc["ms_numeric"], 1e-9)
+    achieved = acc["alg_bytes"] / (ms_numeric * 1e-3) / 1e9
+    tfl = 2.0 * acc["products"] / (ms_numeric * 1e-3) / 1e12
+    kernel = ("k_spgemm_tile" if arithmetic == "fma" else "k_spgemm_slab") if st.get("slab") else \
+        "k_bs_numeric (block path)" if bs.get("used") else "k_spgemm_ghash (grouped LDS hash)" if gs.get("used") else "k_spgemm_pair3 / k_spgemm_hash"
+    line = {
+        "metric": "SpGEMM nnz-out/s, BASELINE configs[3]: one A*A, N=%d ~%d nnz/row" % (n, 2 * h + 1),
+        "value": nnz_c * args.steps / elapsed, "unit": "nnz-out/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "one distributed product A*A (BASELINE configs[3]): banded A N=%d halfband=%d%s, threshold=%g, 1-D column panels on %d rank(s)" % (
+                       n, h, "" if args.permute is None else " under a random symmetric relabelling (seed %d)" % args.permute, thr, world),
+                   "arithmetic": arithmetic, "arithmetic_default": lib_default, "blocks_ms": [1e3 * b["elapsed"] for b in blocks],
+                   "n": n, "halfband": h, "threshold": thr, "permute_seed": args.permute, "nnz_A": int(nnz_a), "nnz_C": int(nnz_c),
+                   "host_syncs_per_step": med["syncs"] / float(args.steps),
+                   "ms_per_step_with_statistics_on": 1e3 * stats["elapsed"] / args.steps,
+                   "hipMalloc_in_timed_region": {"calls": med["m1"][0] - med["m0"][0], "ms": med["m1"][1] - med["m0"][1]}},
+        "spgemm_products_per_s": world * acc["products"] / (ms_numeric * 1e-3),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": kernel + " (SpGEMM numeric phase, rank 0's panel)", "alg_bytes_per_launch": acc["alg_bytes"] / calls,
+                     "ms_per_launch": ms_numeric / calls,
+                     "note": "rank-0 panel; algorithmic bytes = 12*(nnzA+nnzB+nnzC)+4*(colsA+colsB+colsC+3) of the local product"},
+        "roofline_compute": {"bound": "fp64 matrix cores" if arithmetic == "fma" else "fp64 vector ALU (unfused mul+add)", "achieved": tfl,
+                             "peak": 78.6 if arithmetic == "fma" else 39.3, "unit": "TFLOP/s", "frac": tfl / (78.6 if arithmetic == "fma" else 39.3)},
+    }
+    if bs.get("used"):
+        line["block_path"] = bs
+    if gs.get("used"):
+        line["grouped_hash"] = gs
+    return line
+
+
+def transport_note(world):
+    """how the ranks of this run talk to each other (config.transport)"""
+    if world <= 1:
+        return "none (one rank)"
+    ndev = int(os.environ.get("NTPOLY_AMD_BENCH_DEVICES", "0"))
+    if os.environ.get("NTPOLY_AMD_COMM", "").startswith("shm:"):
+        return ("shared-memory TEST transport through host memory, %d ranks sharing %s GPU(s): a functional run of the "
+                "distributed path, NOT a scaling measurement" % (world, ndev if ndev else "the box's"))
+    return "RCCL over xGMI, one rank per GPU"
+
+
+def probe_device_count():
+    """number of GPUs visible, asked of a CHILD process: the parent of a self-launched multi-rank run never touches the GPU
+    (a process that has initialised HIP must neither fork workers that use the GPU nor be replaced by another program)"""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c",
+                        "import sys; sys.path.insert(0, %r); import ntpoly_amd; print(int(ntpoly_amd.lib.ntpoly_amd_device_count()))" % ROOT],
+                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def launch_ranks(world):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this very command, one rank each
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them), relay rank 0's
+    JSON line and exit with the first non-zero status of a child.  With fewer GPUs than ranks (a one-GPU box) the ranks
+    share the devices round-robin and talk over the engine's shared-memory TEST transport instead of RCCL
+    (NTPOLY_AMD_COMM=shm:<name>, csrc/comm.cpp): every line of the distributed path runs, the number is a functional
+    check and says so in `config.transport`."""
+    import socket
+    import subprocess
+    forced = os.environ.get("NTPOLY_AMD_COMM", "")
+    ndev = probe_device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible (the product has no CPU path)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    name = None
+    env0 = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                NTPOLY_AMD_BENCH_DEVICES=str(ndev))
+    if forced.startswith("shm:") or ndev < world:
+        name = forced[4:] if forced.startswith("shm:") and len(forced) > 4 else "bench_%d_%d" % (os.getpid(), port)
+        env0["NTPOLY_AMD_COMM"] = "shm:" + name
+    else:
+        # RCCL: rank 0 hands the unique id over through a file named here (host.init_comm_from_env)
+        env0["NTPOLY_AMD_RDV"] = "/tmp/ntpoly_amd_rdv_bench_%d_%d" % (os.getpid(), port)
+        env0["NTPOLY_AMD_RDV_NONCE"] = "%d:%d" % (os.getpid(), port)
+    procs = []
+    try:
+        for r in range(world):
+            env = dict(env0, RANK=str(r), LOCAL_RANK=str(r % ndev))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=(None if r == 0 else subprocess.DEVNULL)))
+        rc = 0
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                st = p.poll()
+                if st is None:
+                    continue
+                pending.remove(p)
+                if st != 0 and rc == 0:
+                    rc = st if st > 0 else 1
+                    for q in pending:      # a rank died: its peers would wait for it for ever
+                        q.terminate()
+            time.sleep(0.05)
+        return rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        if name is not None:
+            try:
+                os.unlink("/dev/shm/ntpoly_amd_" + name)
+            except OSError:
+                pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=262144)
+    ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--halfband", type=int, default=100)
     ap.add_argument("--threshold", type=float, default=1e-8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,7 +339,16 @@ def main():
                     help="the timed region (warm-up + K steps from X0) is repeated this many times; the MEDIAN block is reported")
     ap.add_argument("--tile-rows", type=int, default=None, help="experiments: option tile_rows (1, 2, 4)")
     ap.add_argument("--tile-waves", type=int, default=None, help="experiments: option tile_waves (4, 8)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3),
+                    help="2: the headline (TRS2 iterations at BASELINE configs[2]); 3: BASELINE configs[3], ONE distributed product "
+                         "A*A at N = 1 048 576, halfband 100 (with --permute SEED: under the load balancer's random relabelling), a "
+                         "step = one MatrixMultiply_ps_wrp, value = nnz-out/s over all ranks")
     args = ap.parse_args()
+
+    launched = int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        # no launcher around us: be the launcher (before anything touches the GPU in this process)
+        sys.exit(launch_ranks(args.gpus))
 
     import ntpoly_amd as nt
     from gen import banded_triplets, permuted_banded_triplets
@@ -173,7 +359,16 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
 
-    n, h, thr = args.n, args.halfband, args.threshold
+    if args.config == 3:
+        line = run_config3(nt, args, rank, world)
+        if rank == 0:
+            line["config"]["transport"] = transport_note(world)
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            nt.barrier()
+        return
+
+    n, h, thr = (args.n if args.n is not None else 262144), args.halfband, args.threshold
     if args.lattice is not None:
         n = args.lattice ** 3
     nt.ConstructGlobalProcessGrid(1, world, 1)  # column panels: one per GPU
@@ -313,7 +508,8 @@ def main():
                        "n": n, "halfband": h, "threshold": thr, "nnz_H": int(nnz_h), "nnz_X_end": int(nnz_x),
                        "nnz_product_last": int(st.get("nnz_c", -1)), "energy_end": energy,
                        "permute_seed": args.permute,
-                       "decomposition": "1-D column panels, %d GPU(s)" % world,
+                       "decomposition": "1-D column panels, %d rank(s)" % world,
+                       "transport": transport_note(world),
                        "hipMalloc_in_timed_region": {"calls": m1[0] - m0[0], "ms": m1[1] - m0[1]}},
             "spgemm_nnz_out_per_s": world * acc["nnz_c"] / (ms_spgemm * 1e-3),
             "spgemm_products_per_s": world * acc["products"] / (ms_numeric * 1e-3),
