@@ -339,6 +339,7 @@ def main():
                     help="the timed region (warm-up + K steps from X0) is repeated this many times; the MEDIAN block is reported")
     ap.add_argument("--tile-rows", type=int, default=None, help="experiments: option tile_rows (1, 2, 4)")
     ap.add_argument("--tile-waves", type=int, default=None, help="experiments: option tile_waves (4, 8)")
+    ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="experiments: any engine option (ntpoly_amd_set_option), e.g. tile2=0")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3),
                     help="2: the headline (TRS2 iterations at BASELINE configs[2]); 3: BASELINE configs[3], ONE distributed product "
                          "A*A at N = 1 048 576, halfband 100 (with --permute SEED: under the load balancer's random relabelling), a "
@@ -385,6 +386,9 @@ def main():
         nt.set_option("tile_waves", args.tile_waves)
     if args.no_label_order:
         nt.set_option("label_order", 0)
+    for kv in args.set:
+        k, v = kv.split("=")
+        nt.set_option(k, int(v))
 
     # ---- setup (untimed): Hamiltonian panel, X0 = (e_max*I - H)/(e_max - e_min)  (:344-371)
     H = nt.Matrix_ps(n)

@@ -140,6 +140,7 @@ struct SlabForm {
   DevBuf<int64_t> tile_off;   // blocks + 1
   DevBuf<double> val, tiles;
   int64_t slots = 0;          // doubles addressable in val / tiles
+  bool no_tile2 = false;      // a step on this iterate (or its predecessor) did not fit the two-block geometry of spgemm_tile2.hip: k_spgemm_tile from now on
   // the plan of the NEXT step on this iterate (kernels.hip slab_step, option plan_ahead): blocks' windows and k ranges
   // follow from the column extents alone, so the step that produced the iterate computes them right behind its
   // kernel and reads their sizes back together with its own results -- the next step launches without a read-back

@@ -2886,6 +2886,10 @@ long long* fusion_counts() {
   static long long c[3] = {0, 0, 0};
   return c;
 }
+long long* tile2_counts() {
+  static long long c[2] = {0, 0};
+  return c;
+}
 
 void flush_spgemm_timers() {
   auto& pend = pending_timings();
@@ -4375,6 +4379,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     else launch(nw_tag, mode_tag, std::integral_constant<int, 2>{});
   };
   DevBuf<int64_t> tile_ooff, tile_otoff;
+  bool used_tile2 = false;
   if (tile) {
     tile_ooff.alloc((size_t)n + 1);
     tile_otoff.alloc((size_t)snb + 1);
@@ -4390,7 +4395,11 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     tl.ofirst = ofirst.p; tl.olast = olast.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
     tl.alpha = 1.0; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
     tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = &fz; tl.rows = trows; tl.labelled = tile_labelled;
-    launch_spgemm_tile(tl);   // (the fused epilogue's arguments travel by value; the kernel writes the end markers of the offsets)
+    // (the fused epilogue's arguments travel by value; the kernel writes the end markers of the offsets.)  The two-block
+    // geometry first where it can apply: one rank, runs only, two rows per lane; a pair that does not fit after all leaves a
+    // mark that comes back with the totals -- the step is then repeated on k_spgemm_tile
+    if (!halo && options().tile2 != 0 && !in.no_tile2) used_tile2 = launch_spgemm_tile2(tl, reinterpret_cast<int*>(fz_flag) + 2);
+    if (!used_tile2) launch_spgemm_tile(tl);
   } else if (rowoff) {
     if (max_w > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{});
     else if (max_w > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 9>{});
@@ -4406,7 +4415,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   hipLaunchKernelGGL(k_fused_totals, dim3(1), dim3(256), 0, stream(), (const int32_t*)nullptr, 0, (const long long*)nullptr,
                      (const long long*)nullptr, (const double*)nullptr, 0, lvl.p, tot.p, 1);
   unsigned long long raw[5] = {0, 0, 0, 0, 0};
-  int64_t flagv[1] = {0};
+  int64_t flagv[2] = {0, 0};
   DevBuf<double> red4;
   if (halo && halo->reduce) {   // (dot, 0, trace, this rank succeeded) summed over the ranks, read back with the totals
     red4.alloc(4);
@@ -4423,7 +4432,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   {
     ScalarFetch f;
     f.add(tot.p, 5, raw);
-    f.add(fz_flag, 1, flagv);
+    f.add(fz_flag, 2, flagv);
     if (red4.p) f.add(red4.p, 4, halo->reduce->reduced);
     if (next) {
       f.add(next->blk_toff.p + snb, 1, &next->total);
@@ -4444,6 +4453,12 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     if (pending_timings().size() >= 4096) flush_spgemm_timers();
     pending_timings().push_back(TimedCall{{t_all.a, t_all.b, t_num.a, t_num.b}});
   }
+  if (used_tile2 && (int32_t)flagv[1] != 0) {   // a pair of blocks did not fit the two-block geometry: X is untouched, the same step on k_spgemm_tile
+    X.slab->no_tile2 = true;
+    tile2_counts()[1] += 1;
+    return slab_step(X, fu, threshold, dense_rule, halo);
+  }
+  if (used_tile2) tile2_counts()[0] += 1;
   if ((int32_t)flagv[0] != 0) {   // (SlabFuseArgs) X is untouched: the caller repeats the step on the unfused path
     fu.refused += 1;
     fusion_counts()[2] += 1;
@@ -4465,6 +4480,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   R.slab->count = std::move(count);
   R.slab->row_pad = tile ? 16 * trows : 1;
   R.slab->next_plan = std::move(next);
+  R.slab->no_tile2 = in.no_tile2;
   R.slab->off = tile ? std::move(tile_ooff) : std::move(tmpoff);
   R.slab->tile_off = tile ? std::move(tile_otoff) : std::move(plan->blk_toff);   // (the slab loop's result keeps the plan's tile offsets)
   R.slab->val = std::move(oval);
@@ -6397,16 +6413,37 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
   tl.ofirst = fo->first.p; tl.olast = fo->last.p; tl.ooff = fo->off.p; tl.otoff = nullptr;
   tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = (dense_rule ? 1 : 0) | 2; tl.ncols = n; tl.nblocks = snb;
   tl.max_kn = P.max_kn; tl.max_w = P.max_w; tl.epi = 0; tl.fz = nullptr; tl.rows = trows; tl.labelled = false;
-  launch_spgemm_tile(tl);
-  t_num.stop();
+  // the two-block geometry first (right operand by its runs); a pair of blocks that does not fit after all leaves a mark
+  // that comes back with the entry count, and the product is repeated on k_spgemm_tile
+  DevBuf<int> t2fail(2);
+  bool used_tile2 = false;
+  if (!have_tiles && options().tile2 != 0 && !fa.no_tile2 && !fb.no_tile2) {
+    t2fail.zero();
+    used_tile2 = launch_spgemm_tile2(tl, t2fail.p);
+  }
+  if (!used_tile2) launch_spgemm_tile(tl);
   DevBuf<long long> tot;
   sa_sum_counts(fo->count.p, n, tot);
-  int64_t nnz = 0;
+  int64_t nnz = 0, t2f = 0;
   {
     ScalarFetch f;
     f.add(tot.p, 1, &nnz);
+    if (used_tile2) f.add(t2fail.p, 1, &t2f);
     f.run();
   }
+  if (used_tile2 && (int)(t2f & 0xffffffffll) != 0) {
+    tile2_counts()[1] += 1;
+    A.slab->no_tile2 = true;     // (asked again with this operand: k_spgemm_tile at once)
+    fo->count.zero();
+    launch_spgemm_tile(tl);
+    sa_sum_counts(fo->count.p, n, tot);
+    ScalarFetch f;
+    f.add(tot.p, 1, &nnz);
+    f.run();
+  } else if (used_tile2) {
+    tile2_counts()[0] += 1;
+  }
+  t_num.stop();
   t_all.stop();
   if (timing) {
     if (pending_timings().size() >= 4096) flush_spgemm_timers();

@@ -67,6 +67,7 @@ struct EngineOptions {
   int complex_tile = 1;        // FMA arithmetic: run-like COMPLEX operands on the matrix cores (spgemm_tile_c.hip: two FMA chains per part of an
                                // entry -- a tolerance mode, 1e-13 of the largest entry); 0: the register-slab kernel with the reference's
                                // complex multiply-add, bit for bit (what unfused arithmetic always runs)
+  int tile2 = 0;               // run-like real operands in FMA arithmetic: the two-block chunk-streaming geometry of the MFMA kernel (spgemm_tile2.hip) where it fits; 0: k_spgemm_tile always
   int tile_runs_only = 1;      // TRS2 steps on the tile kernel (one rank): the result is written as runs only and the next step builds its
                                // multiplier tiles from them (1.5 GB -> 1.0 GB written per launch at the headline size, no tile read);
                                // 0: runs + multiplier tiles as the unfused loop needs them
@@ -247,6 +248,8 @@ void drop_operand_caches();   // frees what the fused / relabelled TRS2 paths ke
 bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidth);
 // since start: [0] steps computed with SlabFusion mode 1, [1] mode 2, [2] fused steps repeated on the unfused path
 long long* fusion_counts();
+// [0] multiplies done in the two-block geometry (spgemm_tile2.hip), [1] launches of it that did not fit and were repeated on k_spgemm_tile
+long long* tile2_counts();
 long long& band_searches();   // searches for a bandwidth-reducing order since start (one per sparsity PATTERN: relabel_enter)
 
 // B <- alpha*A + B (AddSparseVectors semantics), same shape and scalar type.

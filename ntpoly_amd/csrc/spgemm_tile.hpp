@@ -46,6 +46,12 @@ bool spgemm_tile_fits(int max_kn, int max_w);
 int tile_rows();
 inline int tile_expand_align() { return 16 * tile_rows(); }
 void launch_spgemm_tile(const TileLaunch& a);
+// The same multiply in the two-block geometry (spgemm_tile2.hip: pairs of column blocks share every fragment of A, the
+// multiplier rows stream through LDS in chunks): rows == 2, the right operand given by its runs (brun_*), not labelled.
+// false: not launched (the geometry cannot fit), call launch_spgemm_tile.  true: launched -- *fail (device, zeroed by the
+// caller) is set when some pair of blocks did not fit after all (window beyond 1024 rows, or a wave's two slabs in
+// progress together): NOTHING of the launch may be used then; the caller repeats it with launch_spgemm_tile.
+bool launch_spgemm_tile2(const TileLaunch& a, int* fail);
 // Complex run-like operands (spgemm_tile_c.hip): blocks of 8 complex columns, the operands of k_spgemm_slab_c (run records
 // of 16-byte elements, interleaved multiplier tiles in bblk), windows that start at and are a multiple of 16 rows; epi 0
 // only.  Results as above in complex slots: out_val[2 * slot + part], counts / first / last / ooff per column.

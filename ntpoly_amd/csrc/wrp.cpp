@@ -163,6 +163,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "label_rowoff") options().label_rowoff = *value;
   else if (n == "block_path") options().block_path = *value;
   else if (n == "tile_runs_only") options().tile_runs_only = *value;
+  else if (n == "tile2") options().tile2 = *value;
   else if (n == "complex_tile") options().complex_tile = *value;
   else if (n == "thin_left") options().thin_left = *value;
   else if (n == "column_fused") options().column_fused = *value;
@@ -176,6 +177,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "slab_algebra") return options().slab_algebra;
   if (n == "plan_ahead") return options().plan_ahead;
   if (n == "tile_rows") return options().tile_rows;
+  if (n == "tile2") return options().tile2;
   if (n == "block_path") return options().block_path;
   if (n == "label_order") return options().label_order;
   if (n == "fused_update") return options().fused_update;
@@ -248,6 +250,11 @@ int ntpoly_amd_band_order(const int* ih, int* newpos, long long* bandwidth) {
 // to be repeated on the unfused path, since start
 void ntpoly_amd_fusion_counts(long long* out) {
   for (int q = 0; q < 3; ++q) out[q] = fusion_counts()[q];
+}
+// out[0] = multiplies computed in the two-block geometry of the MFMA kernel (spgemm_tile2.hip) since start, out[1] = launches
+// of it whose geometry did not fit after all and were repeated on k_spgemm_tile
+void ntpoly_amd_tile2_counts(long long* out) {
+  for (int q = 0; q < 2; ++q) out[q] = tile2_counts()[q];
 }
 // out[0..3]: operations the solver loops did on matrices in slab form since start (products, merges / copies, scalings
 // / dots / norms) and operations that had to go back to compressed columns

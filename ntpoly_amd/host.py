@@ -889,6 +889,13 @@ def fusion_counts():
     return dict(square=out[0], update=out[1], repeated=out[2])
 
 
+def tile2_counts():
+    """(multiplies computed in the two-block geometry of the MFMA kernel, launches of it repeated on k_spgemm_tile)"""
+    out = (C.c_longlong * 2)()
+    lib.ntpoly_amd_tile2_counts(out)
+    return dict(done=out[0], repeated=out[1])
+
+
 def band_searches():
     """searches for a bandwidth-reducing order since start (one per sparsity pattern)"""
     out = C.c_longlong()
