@@ -67,7 +67,7 @@ struct EngineOptions {
   int complex_tile = 1;        // FMA arithmetic: run-like COMPLEX operands on the matrix cores (spgemm_tile_c.hip: two FMA chains per part of an
                                // entry -- a tolerance mode, 1e-13 of the largest entry); 0: the register-slab kernel with the reference's
                                // complex multiply-add, bit for bit (what unfused arithmetic always runs)
-  int tile2 = 0;               // run-like real operands in FMA arithmetic: the two-block chunk-streaming geometry of the MFMA kernel (spgemm_tile2.hip) where it fits; 0: k_spgemm_tile always
+  int tile2 = 0;               // run-like real operands in FMA arithmetic: the two-block chunk-streaming geometry of the MFMA kernel (spgemm_tile2.hip) (1) where it fits -- slower than k_spgemm_tile as measured in round 5 (profiles/README.md 83): 0 by default
   int tile_runs_only = 1;      // TRS2 steps on the tile kernel (one rank): the result is written as runs only and the next step builds its
                                // multiplier tiles from them (1.5 GB -> 1.0 GB written per launch at the headline size, no tile read);
                                // 0: runs + multiplier tiles as the unfused loop needs them

@@ -17,10 +17,9 @@ X2 = nt.Matrix_ps(n)
 tr = None
 for _ in range(int(os.environ.get("T2_WARM", "10"))):
     _, e, tr = nt.trs2_step(X, X2, H, n / 2.0, thr, tr)
-settings = [("tile2", {"tile2": 1}, "0"), ("tile", {"tile2": 0}, "0"), ("no epilogue", {"tile2": 1}, "1"), ("no mfma", {"tile2": 1}, "2"),
-            ("no epi, no mfma", {"tile2": 1}, "3"), ("no epi, no loads", {"tile2": 1}, "5"), ("no epi, no barriers", {"tile2": 1}, "9"),
-            ("no epi/mfma/loads", {"tile2": 1}, "7"), ("no epi/loads/barriers", {"tile2": 1}, "13"), ("only prologue+barriers", {"tile2": 1}, "7"),
-            ("nothing but structure", {"tile2": 1}, "15")]
+settings = [("tile2", {"tile2": 1}, "0"), ("tile", {"tile2": 0}, "0"), ("tile2 no epilogue", {"tile2": 1}, "1"), ("tile2 again", {"tile2": 1}, "0")]
+if os.environ.get('T2_ONLY'):
+    settings = [s_ for s_ in settings if s_[0] in (('tile2',) if os.environ['T2_ONLY'] == '2' else ('tile2', 'tile2 no epilogue'))]
 for name, opts, abl in settings:
     for k, v in opts.items():
         nt.set_option(k, v)
