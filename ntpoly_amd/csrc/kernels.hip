@@ -3308,7 +3308,9 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     return;
   }
   // a thin left operand (an identity, a near-diagonal factor): the output-driven gather kernel, whatever the right operand's shape
-  if (!loose && !arange && !A.loose() && !B.loose() && options().thin_left != 0 && options().spgemm_variant < 0 && options().spgemm_force_bin <= 0 &&
+  // (not with a fused purification step asked for: the gather kernel has no such epilogue, and a fused step's left operand
+  // is the iterate itself -- never thin)
+  if (!loose && !arange && !fuse && !A.loose() && !B.loose() && options().thin_left != 0 && options().spgemm_variant < 0 && options().spgemm_force_bin <= 0 &&
       !strip_ctx().active && A.rows == A.cols && A.nnz <= 8 * (int64_t)A.cols && B.nnz >= A.nnz) {
     if (try_thin_left(A, B, C, alpha, threshold, dense_rule)) return;
   }

@@ -717,10 +717,14 @@ bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double be
   // compressed columns (complex loops, real ones outside a session): a dense window per column, the difference is never formed
   auto cols = [](const PSMatrix& M) { return !M.loc.expanded() && !M.loc.loose() && !M.loc.blocked(); };
   if (options().column_fused != 0 && beta == 1.0 && A.cplx == B.cplx && A.dim == B.dim && &A != &B && cols(A) && cols(B) && A.c0 == B.c0 && A.c1 == B.c1) {
+    // (the decision is collective: a rank whose columns do not fit the kernel's window must not fall back alone -- one
+    // reduction carries the norm and "some rank declined" together, and every rank takes the same branch)
     double v = 0.0;
-    if (norm_axpy_columns(A.loc, B.loc, alpha, &v)) {
-      comm_allreduce_max(&v, 1);
-      *norm = v;
+    const bool ok = norm_axpy_columns(A.loc, B.loc, alpha, &v);
+    double pair[2] = {ok ? v : 0.0, ok ? 0.0 : 1.0};
+    comm_allreduce_max(pair, 2);
+    if (pair[1] == 0.0) {
+      *norm = pair[0];
       g_column_fused[1] += 1;
       return true;
     }

@@ -150,6 +150,10 @@ void print_parameters(const SolverParameters& p) {  // SolverParametersModule.F9
   log_element("Maximum Iterations", p.max_iterations);
   log_element("Step Threshold", p.step_thresh);
   log_element("Monitor Convergence", p.monitor_convergence);
+  // (not in the reference's log: which of its two builds the products of this run reproduce -- DESIGN.md section 4.
+  // "fma" = the FP-contracted build, every product entry one chain of fma(); "unfused" = the default x86-64 build,
+  // separate multiply and add; complex run-like operands in fma mode: two FMA chains per part, a tolerance mode)
+  log_element("Arithmetic", options().spgemm_fma == 0 ? "unfused" : "fma");
   log_exit();
 }
 

@@ -179,11 +179,14 @@ constexpr int kBlockLevels = 6, kSuperLevels = 3;
 const int kBlockCaps[kBlockLevels] = {2, 4, 8, 16, 16, 16};
 const int kSuperCaps[kSuperLevels] = {2, 4, 4};
 
+unsigned long long block_pattern_fp(const DevMat& M);
+
 std::shared_ptr<BlockOrder> build_block_order(const DevMat& M) {
   const int32_t n = M.cols;
   std::shared_ptr<BlockOrder> bo(new BlockOrder());
   bo->n = n;
   bo->built_from_nnz = M.nnz;
+  bo->seed_fp = block_pattern_fp(M);
   Graph g;
   g.nv = n;
   g.ne = M.nnz;
@@ -1328,6 +1331,33 @@ __global__ __launch_bounds__(256) void k_bs_colabs_max(int ns, const int64_t* __
   if (lane == 0) atomicMax(out, (unsigned long long)__double_as_longlong(s));
 }
 
+// order-independent fingerprint of a sparsity pattern (sum of per-entry hashes + dimensions): what a block order is keyed on
+__global__ __launch_bounds__(256) void k_bs_pattern_fp(int32_t cols, const int64_t* __restrict__ outer, const int32_t* __restrict__ inner,
+                                                        unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long red[4];
+  unsigned long long h = 0;
+  for (int j = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE); j < cols; j += (int)(gridDim.x * (int64_t)blockDim.x / WAVE)) {
+    for (int64_t q = outer[j] + lane_id(); q < outer[j + 1]; q += WAVE) {
+      unsigned long long x = ((unsigned long long)(unsigned)j << 32) | (unsigned)inner[q];
+      x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;   // (murmur3 finaliser)
+      h += x;
+    }
+  }
+  h = (unsigned long long)wave_sum_i64((int64_t)h);
+  if (lane_id() == 0) red[threadIdx.x / WAVE] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+unsigned long long block_pattern_fp(const DevMat& M) {   // (compressed columns)
+  DevBuf<unsigned long long> acc(1);
+  acc.zero();
+  hipLaunchKernelGGL(k_bs_pattern_fp, dim3(1024), dim3(256), 0, stream(), M.cols, M.outer.p, M.inner.p, acc.p);
+  unsigned long long h = 0;
+  HIP_CHECK(hipMemcpyAsync(&h, acc.p, sizeof(h), hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  return h ^ ((unsigned long long)M.nnz * 0x9e3779b97f4a7c15ull) ^ (unsigned long long)M.cols;
+}
+
 // =====================================================================================================================
 // caches
 // =====================================================================================================================
@@ -1354,27 +1384,40 @@ BlockCache& cache() {
   static BlockCache* c = new BlockCache();
   return *c;
 }
-// makes the kept order of dimension n the current one (false: there is none)
+// makes the most recently used kept order of dimension n the current one (false: there is none)
 bool select_order(BlockCache& bc, int32_t n) {
   if (bc.order && bc.order->n == n) return true;
+  int best = -1;
   for (int i = 0; i < 4; ++i)
-    if (bc.kept[i] && bc.kept[i]->n == n) {
+    if (bc.kept[i] && bc.kept[i]->n == n && (best < 0 || bc.kept_used[i] > bc.kept_used[best])) best = i;
+  if (best < 0) return false;
+  bc.order = bc.kept[best];
+  bc.kept_used[best] = ++bc.clock;
+  return true;
+}
+// the kept order of dimension n made from the pattern with fingerprint fp, made current (false: there is none)
+bool select_order_fp(BlockCache& bc, int32_t n, unsigned long long fp) {
+  for (int i = 0; i < 4; ++i)
+    if (bc.kept[i] && bc.kept[i]->n == n && bc.kept[i]->seed_fp == fp) {
       bc.order = bc.kept[i];
       bc.kept_used[i] = ++bc.clock;
       return true;
     }
   return false;
 }
+// keeps an order (four slots: one per (dimension, seed pattern), least recently used replaced) and makes it current
 void install_order(BlockCache& bc, const std::shared_ptr<BlockOrder>& o) {
   int slot = 0;
   for (int i = 0; i < 4; ++i) {
-    if (!bc.kept[i] || bc.kept[i]->n == o->n) { slot = i; break; }
+    if (!bc.kept[i] || (bc.kept[i]->n == o->n && bc.kept[i]->seed_fp == o->seed_fp)) { slot = i; break; }
     if (bc.kept_used[i] < bc.kept_used[slot]) slot = i;
   }
   bc.kept[slot] = o;
   bc.kept_used[slot] = ++bc.clock;
   bc.order = o;
 }
+// a pattern tiles "as well as the order's own" when its fill reaches this fraction of the fill the order's seed has in it
+constexpr double kSeedFillFraction = 0.75;
 constexpr double kMinFill = 0.08;
 
 }  // namespace
@@ -1956,14 +1999,42 @@ bool spgemm_block(const DevMat& A, const DevMat& B, DevMat& C, double alpha, dou
   // The order of a dimension is made ONCE, from the first operand that is dense enough to say something about the index
   // set (8 entries per column), and kept: the same product gives the same bits whenever it is computed.  An operand that
   // does not tile well in it (fill below kMinFill) goes to the LDS-hash kernels.
-  if (!select_order(bc, n)) {
-    if (A.blocked() || A.nnz < 8LL * n) return false;
+  // Which order: an operand already in block form brings its own (a loop's iterates stay in the order they were started
+  // in).  Operands in compressed columns take the most recently used order of the dimension -- as long as the left
+  // operand tiles in it about as well as the pattern the order was made from; a pattern that does not (another graph
+  // on the same index set: fill 0.28 in a foreign clustering against 0.41 in its own) gets an order of ITS OWN, kept
+  // beside the first under (dimension, pattern fingerprint).
+  if (A.blocked()) bc.order = A.blk->order;
+  else if (B.blocked()) bc.order = B.blk->order;
+  else if (!select_order(bc, n)) {
+    if (A.nnz < 8LL * n) return false;
     install_order(bc, build_block_order(A));
   }
   if (bc.order->ns > kMaxSuperBlocks) return false;
   double fa = 0, fb = 0;
   bool conv = false;
   std::shared_ptr<BlockForm> pFA = operand_form(A, bc, min_fill, &fa, &conv);
+  if (!any_blocked && A.nnz >= 8LL * n) {
+    if (bc.order->seed_fill <= 0.0 && bc.order->built_from_nnz == A.nnz && pFA) bc.order->seed_fill = fa;   // (the seed itself, first time)
+    if (fa < kSeedFillFraction * bc.order->seed_fill || !pFA) {
+      const unsigned long long fp = block_pattern_fp(A);
+      if (fp != bc.order->seed_fp) {
+        const std::shared_ptr<BlockOrder> before = bc.order;
+        double f2 = 0;
+        std::shared_ptr<BlockForm> p2;
+        if (!select_order_fp(bc, n, fp)) install_order(bc, build_block_order(A));
+        if (bc.order->ns <= kMaxSuperBlocks) p2 = operand_form(A, bc, min_fill, &f2, &conv);
+        if (p2 && bc.order->seed_fill <= 0.0) bc.order->seed_fill = f2;
+        if (p2 && f2 > fa) {   // its own order serves it better
+          if (dbg()) std::fprintf(stderr, "[block path] pattern %016llx: own order (fill %.3f against %.3f in the order of %016llx)\n", fp, f2, fa, before->seed_fp);
+          pFA = p2;
+          fa = f2;
+        } else {               // (no better: stay with the order in use)
+          bc.order = before;
+        }
+      }
+    }
+  }
   if (!pFA) {
     bc.refused_n = n;
     bc.refused_nnz = A.nnz;

@@ -21,6 +21,8 @@ struct BlockOrder {
   DevBuf<int32_t> pos;         // [n]      pos[index] = position
   DevBuf<int32_t> lab;         // [64 ns]  lab[position] = index or -1
   int64_t built_from_nnz = 0;  // entries of the matrix whose pattern it was made from
+  unsigned long long seed_fp = 0;   // fingerprint of that pattern (order-independent sum of per-entry hashes): the cache key beside n
+  double seed_fill = 0;        // fill of that matrix in its own order (entries / (256 tiles)): what another pattern's fill is compared with
   unsigned long long serial = 0;
 };
 

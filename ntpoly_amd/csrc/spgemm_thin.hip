@@ -17,6 +17,8 @@
 // straight into compressed columns.
 #include <hip/hip_runtime.h>
 
+#include <memory>
+
 #include <algorithm>
 
 #include "device_util.hpp"
@@ -410,7 +412,29 @@ bool spgemm_thin_left(const DevMat& A, const DevMat& B, DevMat& C, double alpha,
   // (a permuted operand) makes every column visit rows it has nothing in -- not this kernel's operand
   if ((int64_t)up + dn > 2048 || wmax <= 0 || (size_t)wmax * esz * THIN_NW > 64 * 1024) return false;
   if ((double)(up + dn) > 2.0 * (double)wmax + 64.0) return false;
-  DevMat AT = transpose(A);   // (rows of A as columns, ascending k inside each)
+  // rows of A as columns, ascending k inside each.  A solver loop multiplies by the same thin factor again and again (an
+  // identity, a preconditioner): its transpose is kept per matrix (value buffer, allocation serial, value epoch), two slots
+  struct KeptTranspose {
+    const void* val = nullptr;
+    unsigned long long serial = 0, epoch = 0, used = 0;
+    int64_t nnz = -1;
+    std::shared_ptr<DevMat> at;
+  };
+  static KeptTranspose kept[2];
+  static unsigned long long clock = 0;
+  const unsigned long long ser = dev_alloc_serial(A.val.p), ep = matrix_value_epoch();
+  std::shared_ptr<DevMat> pAT;
+  for (KeptTranspose& k : kept)
+    if (k.at && k.val == A.val.p && k.serial == ser && ser != 0 && k.epoch == ep && k.nnz == A.nnz && k.at->rows == A.cols && k.at->cols == A.rows) {
+      pAT = k.at;
+      k.used = ++clock;
+    }
+  if (!pAT) {
+    pAT.reset(new DevMat(transpose(A)));
+    KeptTranspose* slot = kept[0].used <= kept[1].used ? &kept[0] : &kept[1];
+    slot->val = A.val.p; slot->serial = ser; slot->epoch = ep; slot->nnz = A.nnz; slot->at = pAT; slot->used = ++clock;
+  }
+  const DevMat& AT = *pAT;
   const Csc ATv = view(AT);
   const int nblocks = cdiv(n, THIN_NW);
   const size_t lds = (size_t)wmax * esz * THIN_NW;

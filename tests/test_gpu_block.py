@@ -388,3 +388,37 @@ def test_solver_loops_in_block_form(nt, fma, solver):
         tol = 1e-9
     Wo = sp.csr_matrix((w[2], (w[1] - 1, w[0] - 1)), shape=(n, n))
     assert abs(G - Wo).max() <= tol * max(1.0, abs(Wo).max())
+
+
+def test_a_second_pattern_of_the_same_dimension_gets_an_order_of_its_own(nt, fma):
+    """The block order is keyed on (dimension, sparsity pattern), not on the dimension alone: a lattice in natural
+    order, then the SAME lattice under a random relabelling -- another graph on the same index set -- multiplied in one
+    process.  The second pattern does not inherit the clustering made for the first: it tiles as well as it does in a
+    fresh process, and its product has the same bits whatever was multiplied before it."""
+    from gen import random_permutation
+    L, thr = 16, 1e-8
+    n = L ** 3
+    t1 = lattice_case(L)
+    rank = random_permutation(n, 11)
+    t2 = relabel(t1, rank)
+    nt.set_option("slab_algebra", 0)
+
+    def product(trip):
+        A = nt.Matrix_ps.from_triplets(n, *trip)
+        C = nt.Matrix_ps(n)
+        C.Gemm(A, A, None, 1.0, 0.0, thr)
+        bs = nt.last_block_stats()
+        assert bs["used"] == 1, bs
+        return srt(C.triplets()), bs["fill"], nt.block_order(A).copy()
+
+    nt.drop_block_caches()
+    alone, fill_alone, pos_alone = product(t2)          # the relabelled lattice in a fresh cache
+    nt.drop_block_caches()
+    first, fill_first, pos_first = product(t1)          # history: the natural lattice first ...
+    after, fill_after, pos_after = product(t2)          # ... then the relabelled one
+    assert fill_after >= 0.95 * fill_alone, (fill_after, fill_alone, fill_first)
+    assert np.array_equal(pos_after, pos_alone)
+    exact(after, alone, "relabelled lattice after the natural one vs alone")
+    again, fill_again, pos_again = product(t1)          # and the first pattern finds ITS order again
+    assert np.array_equal(pos_again, pos_first)
+    exact(again, first, "natural lattice again")

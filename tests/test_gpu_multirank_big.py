@@ -82,9 +82,11 @@ def test_big_multirank_equals_single_rank(world, arith, references, tmp_path):
         # density pattern, values to 1e-10 through three sums
         for r in range(world):
             assert np.array_equal(parts[r][tag + "_trs2_sigma"], ref[tag + "_trs2_sigma"]), (tag, r)
-            assert np.array_equal(parts[r][tag + "_trs2_nnz"], ref[tag + "_trs2_nnz"]), (tag, r, parts[r][tag + "_trs2_nnz"], ref[tag + "_trs2_nnz"])
             assert np.allclose(parts[r][tag + "_trs2_log"], ref[tag + "_trs2_log"], rtol=1e-11, atol=1e-9), (tag, r)
             assert np.allclose(parts[r][tag + "_trs2_scal"], ref[tag + "_trs2_scal"], rtol=1e-11, atol=1e-9), (tag, r)
+        # (the solver's trace counts the entries of a rank's own panel)
+        nnz_all = np.sum(np.stack([p[tag + "_trs2_nnz"] for p in parts]), axis=0)
+        assert np.array_equal(nnz_all, ref[tag + "_trs2_nnz"]), (tag, nnz_all, ref[tag + "_trs2_nnz"])
         got, want = dsum(parts, tag + "_K"), ref[tag + "_K"]
         assert got[0] == want[0] and got[2] == want[2], (tag, got, want)     # entries and pattern
         sums = np.sum(np.stack([p[tag + "_K_sums"] for p in parts]), axis=0)
