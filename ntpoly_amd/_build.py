@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libntpoly_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["kernels.hip", "spgemm_tile.hip", "spgemm_tile2.hip", "spgemm_tile_c.hip", "spgemm_thin.hip", "column_fused.hip", "spgemm_grouped.hip", "spgemm_block.hip", "relabel.hip", "slab_extra.hip", "dense.hip", "common.cpp", "comm.cpp", "psmatrix.cpp", "solvers.cpp", "solvers_poly.cpp", "solvers_func.cpp", "solvers_extra.cpp", "io.cpp", "wrp.cpp"]
+SOURCES = ["kernels.hip", "spgemm_tile.hip", "spgemm_tile2.hip", "spgemm_tile_c.hip", "spgemm_thin.hip", "column_fused.hip", "spgemm_grouped.hip", "spgemm_block.hip", "relabel.hip", "slab_extra.hip", "dense.hip", "common.cpp", "comm.cpp", "psmatrix.cpp", "band_scope.cpp", "solvers.cpp", "solvers_poly.cpp", "solvers_func.cpp", "solvers_extra.cpp", "io.cpp", "wrp.cpp"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("NTPOLY_AMD_EXTRA_FLAGS", "").split()
 

@@ -270,6 +270,13 @@ void mcweeny_step(const PSMatrix& D, PSMatrix& DOut, const PSMatrix* S, double t
 double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_target, double threshold, double* sigma,
                  double* trace_io = nullptr);
 
+// band_scope.cpp: a solver on several ranks whose first operand hides a band under its labels runs on operands redistributed
+// in the recovered order (collective; false: not applicable -- the caller solves as it stands).  run(ins, outs) is the
+// solver itself on the relabelled operands; the outputs are carried back to the caller's labels
+bool band_scope_try(const std::vector<const PSMatrix*>& ins, const std::vector<PSMatrix*>& outs,
+                    const std::function<void(const std::vector<const PSMatrix*>&, const std::vector<PSMatrix*>&)>& run);
+const long long* band_scope_counts();
+
 // ------------------------------------------------------------------ solvers
 void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy, double* mu,
                  const SolverParameters& p);

@@ -5520,6 +5520,23 @@ unsigned long long pattern_fingerprint(const DevMat& D) {
   f.run();
   return h ^ ((unsigned long long)D.nnz * 0x9e3779b97f4a7c15ull) ^ (unsigned long long)D.cols;
 }
+}  // namespace
+unsigned long long pattern_fingerprint_of(const DevMat& A) { return pattern_fingerprint(A); }
+int64_t column_span_sum(const DevMat& A) {
+  const int n = A.cols;
+  if (n == 0 || A.nnz == 0) return 0;
+  DevBuf<int32_t> f((size_t)n), l((size_t)n), cnt((size_t)n), span((size_t)n);
+  DevBuf<int64_t> pre((size_t)n + 1);
+  hipLaunchKernelGGL(k_col_extent, dim3(cdiv(n, 256)), dim3(256), 0, stream(), view(A), f.p, l.p, cnt.p);
+  hipLaunchKernelGGL(k_span_of, dim3(cdiv(n, 256)), dim3(256), 0, stream(), f.p, l.p, span.p, n);
+  scan_async<int32_t>(span.p, pre.p, (int64_t)n);
+  int64_t tot = 0;
+  ScalarFetch ft;
+  ft.add(pre.p + n, 1, &tot);
+  ft.run();
+  return tot;
+}
+namespace {
 RelabelCache& relabel_cache() {
   static RelabelCache* c = new RelabelCache();
   return *c;

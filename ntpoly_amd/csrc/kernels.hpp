@@ -79,6 +79,7 @@ struct EngineOptions {
                                // are (the shape only selects the summation semantics of the multiply: slices > 1)
   int fused_update = 1;        // TRS2 on one rank, real operands: the update X <- 2X - X*X (or X*X), its energy and its trace
                                // come out of the epilogue of the register-slab kernel; 0: separate merge / reduction passes
+  int band_scope = 1;          // solvers on SEVERAL ranks: an operand without run structure is searched for a hidden band once per solve, the operands are redistributed in the recovered order, the results carried back (band_scope.cpp)
   int label_order = 1;         // TRS2 on one rank: an operand without run structure is searched for a hidden band (relabel.hip)
                                // and, if there is one, the loop runs in that order with label-ordered arithmetic; 0: never
   int label_rowoff = 1;        // label-ordered steps: the loop takes a step's multiplier row from its run record (no copy of
@@ -246,6 +247,10 @@ void drop_operand_caches();   // frees what the fused / relabelled TRS2 paths ke
 // newpos[old index] = new index, *bandwidth = max |new row - new column|.  false: not a square packed matrix, or
 // more components than the search is willing to chain
 bool find_band_order(const DevMat& A, DevBuf<int32_t>& newpos, int64_t* bandwidth);
+// sum over the columns of (last row - first row + 1) of a matrix in compressed columns (how run-like it is as it stands)
+int64_t column_span_sum(const DevMat& A);
+// order-independent fingerprint of a sparsity pattern (compressed columns)
+unsigned long long pattern_fingerprint_of(const DevMat& A);
 // since start: [0] steps computed with SlabFusion mode 1, [1] mode 2, [2] fused steps repeated on the unfused path
 long long* fusion_counts();
 // [0] multiplies done in the two-block geometry (spgemm_tile2.hip), [1] launches of it that did not fit and were repeated on k_spgemm_tile

@@ -251,6 +251,11 @@ double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_tar
 
 void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                  const SolverParameters& p) {
+  // (several ranks, an operand without runs: the whole solve in a recovered band order -- band_scope.cpp)
+  if (band_scope_try({&H, &ISQ}, {&K}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) {
+        solver_trs2(*in[0], *in[1], trace, *out[0], energy_out, mu_out, p);
+      }))
+    return;
   trace_reset();
   auto t0 = Clock::now();
   Monitor mon;
@@ -403,6 +408,11 @@ void mcweeny_step(const PSMatrix& D, PSMatrix& DOut, const PSMatrix* S, double t
 
 void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                  const SolverParameters& p) {
+  // (several ranks, an operand without runs: the whole solve in a recovered band order -- band_scope.cpp)
+  if (band_scope_try({&H, &ISQ}, {&K}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) {
+        solver_trs4(*in[0], *in[1], trace, *out[0], energy_out, mu_out, p);
+      }))
+    return;
   trace_reset();
   auto t0 = Clock::now();
   const double sigma_min = 0.0, sigma_max = 6.0;
@@ -508,6 +518,11 @@ void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
 // ------------------------------------------------------------------ PM
 void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                const SolverParameters& p) {
+  // (several ranks, an operand without runs: the whole solve in a recovered band order -- band_scope.cpp)
+  if (band_scope_try({&H, &ISQ}, {&K}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) {
+        solver_pm(*in[0], *in[1], trace, *out[0], energy_out, mu_out, p);
+      }))
+    return;
   trace_reset();
   auto t0 = Clock::now();
   Monitor mon;
@@ -607,6 +622,11 @@ void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K
 // ------------------------------------------------------------------ HPCP
 void solver_hpcp(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                  const SolverParameters& p) {
+  // (several ranks, an operand without runs: the whole solve in a recovered band order -- band_scope.cpp)
+  if (band_scope_try({&H, &ISQ}, {&K}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) {
+        solver_hpcp(*in[0], *in[1], trace, *out[0], energy_out, mu_out, p);
+      }))
+    return;
   trace_reset();
   auto t0 = Clock::now();
   Monitor mon;
@@ -751,6 +771,8 @@ void sign_core(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters& 
 }  // namespace
 
 void solver_sign(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p) {
+  if (band_scope_try({&A}, {&Out}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) { solver_sign(*in[0], *out[0], p); }))
+    return;
   trace_reset();
   if (p.be_verbose) {
     log_header("Sign Function Solver");
@@ -847,10 +869,14 @@ void invert_core(const PSMatrix& InputMat, PSMatrix& OutputMat, const SolverPara
 }  // namespace
 
 void solver_invert(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p) {
+  if (band_scope_try({&A}, {&Out}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) { solver_invert(*in[0], *out[0], p); }))
+    return;
   trace_reset();
   invert_core(A, Out, p, true);
 }
 void solver_pseudoinverse(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p) {
+  if (band_scope_try({&A}, {&Out}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) { solver_pseudoinverse(*in[0], *out[0], p); }))
+    return;
   trace_reset();
   invert_core(A, Out, p, false);
 }
@@ -1013,6 +1039,8 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
 }  // namespace
 
 void solver_square_root(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p, bool inverse, int order) {
+  if (band_scope_try({&A}, {&Out}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) { solver_square_root(*in[0], *out[0], p, inverse, order); }))
+    return;
   trace_reset();
   // SquareRootSelector (SquareRootSolversModule.F90:164-194): default order 5
   if (order == 2) isr_order2(A, Out, p, inverse);

@@ -160,6 +160,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "loose_iterates") options().loose_iterates = *value;
   else if (n == "fused_update") options().fused_update = *value;
   else if (n == "label_order") options().label_order = *value;
+  else if (n == "band_scope") options().band_scope = *value;
   else if (n == "label_rowoff") options().label_rowoff = *value;
   else if (n == "block_path") options().block_path = *value;
   else if (n == "tile_runs_only") options().tile_runs_only = *value;
@@ -180,6 +181,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "tile2") return options().tile2;
   if (n == "block_path") return options().block_path;
   if (n == "label_order") return options().label_order;
+  if (n == "band_scope") return options().band_scope;
   if (n == "fused_update") return options().fused_update;
   if (n == "loose_iterates") return options().loose_iterates;
   if (n == "complex_tile") return options().complex_tile;
@@ -255,6 +257,10 @@ void ntpoly_amd_fusion_counts(long long* out) {
 // of it whose geometry did not fit after all and were repeated on k_spgemm_tile
 void ntpoly_amd_tile2_counts(long long* out) {
   for (int q = 0; q < 2; ++q) out[q] = tile2_counts()[q];
+}
+// out[0] = solves that ran in a recovered band order across ranks (band_scope.cpp), out[1] = operands searched for one
+void ntpoly_amd_band_scope_counts(long long* out) {
+  for (int q = 0; q < 2; ++q) out[q] = band_scope_counts()[q];
 }
 // out[0..3]: operations the solver loops did on matrices in slab form since start (products, merges / copies, scalings
 // / dots / norms) and operations that had to go back to compressed columns

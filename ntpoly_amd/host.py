@@ -896,6 +896,13 @@ def tile2_counts():
     return dict(done=out[0], repeated=out[1])
 
 
+def band_scope_counts():
+    """(solves run in a recovered band order across ranks, operands searched for a hidden band)"""
+    out = (C.c_longlong * 2)()
+    lib.ntpoly_amd_band_scope_counts(out)
+    return dict(solves=out[0], searched=out[1])
+
+
 def band_searches():
     """searches for a bandwidth-reducing order since start (one per sparsity pattern)"""
     out = C.c_longlong()

@@ -76,9 +76,9 @@ def main():
         p.SetMaxIterations(6)
         p.SetMonitorConvergence(False)
         K = nt.Matrix_ps(n)
-        f0, e0 = nt.fusion_counts(), nt.exchange_stats()
+        f0, e0, b0 = nt.fusion_counts(), nt.exchange_stats(), nt.band_scope_counts()
         energy, mu = nt.DensityMatrixSolvers.TRS2(A, Ident, n / 2.0, K, p)
-        f1, e1 = nt.fusion_counts(), nt.exchange_stats()
+        f1, e1, b1 = nt.fusion_counts(), nt.exchange_stats(), nt.band_scope_counts()
         bs2 = nt.last_block_stats()
         tr = nt.solver_trace()
         res[tag + "_trs2_log"] = np.array(tr["energy"])
@@ -87,6 +87,7 @@ def main():
         res[tag + "_trs2_scal"] = np.array([energy, mu])
         res[tag + "_trs2_fused"] = np.array([f1[k] - f0[k] for k in ("square", "update", "repeated")])
         res[tag + "_trs2_block"] = np.array([int(bool(bs2.get("used")))])
+        res[tag + "_trs2_band_scope"] = np.array([b1["solves"] - b0["solves"], b1["searched"] - b0["searched"]])
         res[tag + "_trs2_syncs"] = np.array([e1[0] - e0[0], e1[1] - e0[1], e1[2] - e0[2]])
         kc, kr, kv = K.triplets()
         res[tag + "_K"] = digest(kc, kr, kv)

@@ -80,17 +80,31 @@ def test_big_multirank_equals_single_rank(world, arith, references, tmp_path):
             assert np.allclose(parts[r][tag + "_AA_scal"], ref[tag + "_AA_scal"], rtol=1e-12, atol=1e-12), (tag, r)
         # the solve: same sigma sequence, the same entry counts of every iterate, energies to reduction order, the same
         # density pattern, values to 1e-10 through three sums
+        sums = np.sum(np.stack([p[tag + "_K_sums"] for p in parts]), axis=0)
+        nnz_all = np.sum(np.stack([p[tag + "_trs2_nnz"] for p in parts]), axis=0)   # (the trace counts a rank's own panel)
+        got, want = dsum(parts, tag + "_K"), ref[tag + "_K"]
         for r in range(world):
             assert np.array_equal(parts[r][tag + "_trs2_sigma"], ref[tag + "_trs2_sigma"]), (tag, r)
-            assert np.allclose(parts[r][tag + "_trs2_log"], ref[tag + "_trs2_log"], rtol=1e-11, atol=1e-9), (tag, r)
-            assert np.allclose(parts[r][tag + "_trs2_scal"], ref[tag + "_trs2_scal"], rtol=1e-11, atol=1e-9), (tag, r)
-        # (the solver's trace counts the entries of a rank's own panel)
-        nnz_all = np.sum(np.stack([p[tag + "_trs2_nnz"] for p in parts]), axis=0)
-        assert np.array_equal(nnz_all, ref[tag + "_trs2_nnz"]), (tag, nnz_all, ref[tag + "_trs2_nnz"])
-        got, want = dsum(parts, tag + "_K"), ref[tag + "_K"]
-        assert got[0] == want[0] and got[2] == want[2], (tag, got, want)     # entries and pattern
-        sums = np.sum(np.stack([p[tag + "_K_sums"] for p in parts]), axis=0)
-        assert np.allclose(sums, ref[tag + "_K_sums"], rtol=1e-10, atol=1e-9), (tag, sums, ref[tag + "_K_sums"])
+        if tag == "perm":
+            # several ranks solve a relabelled band in its RECOVERED order (csrc/band_scope.cpp: the reference's load-balancer
+            # semantics -- the arithmetic of the solve, including "beyond the other column's last row" of every merge, in the
+            # permuted index space), one rank in the caller's labels: entries below the threshold survive a merge in different
+            # places, everything else agrees -- entry counts to 1e-4, energies and the density's sums to 1e-8
+            for r in range(world):
+                assert parts[r]["perm_trs2_band_scope"][0] == 1, (r, parts[r]["perm_trs2_band_scope"])
+                sq, up, rep = parts[r]["perm_trs2_fused"]
+                assert rep == 0 and sq + up >= 5, (r, sq, up, rep)     # fused panel steps on every rank
+                assert np.allclose(parts[r][tag + "_trs2_log"], ref[tag + "_trs2_log"], rtol=1e-8, atol=1e-7), (tag, r)
+            assert np.all(np.abs(nnz_all - ref[tag + "_trs2_nnz"]) <= 1e-4 * ref[tag + "_trs2_nnz"] + 8), (nnz_all, ref[tag + "_trs2_nnz"])
+            assert abs(int(got[0]) - int(want[0])) <= 1e-4 * int(want[0]) + 8
+            assert np.allclose(sums, ref[tag + "_K_sums"], rtol=1e-8, atol=1e-7), (tag, sums, ref[tag + "_K_sums"])
+        else:
+            for r in range(world):
+                assert np.allclose(parts[r][tag + "_trs2_log"], ref[tag + "_trs2_log"], rtol=1e-11, atol=1e-9), (tag, r)
+                assert np.allclose(parts[r][tag + "_trs2_scal"], ref[tag + "_trs2_scal"], rtol=1e-11, atol=1e-9), (tag, r)
+            assert np.array_equal(nnz_all, ref[tag + "_trs2_nnz"]), (tag, nnz_all, ref[tag + "_trs2_nnz"])
+            assert got[0] == want[0] and got[2] == want[2], (tag, got, want)     # entries and pattern
+            assert np.allclose(sums, ref[tag + "_K_sums"], rtol=1e-10, atol=1e-9), (tag, sums, ref[tag + "_K_sums"])
         print(world, arith, tag, "kernel (slab, block, ghash) per rank:", [p[tag + "_kernel"].tolist() for p in parts],
               "fused steps:", [p[tag + "_trs2_fused"].tolist() for p in parts], "syncs:", [p[tag + "_trs2_syncs"].tolist() for p in parts])
     # the banded operand in natural order: panel steps stay fused (slab form, halo as dense runs) on every rank
