@@ -10,7 +10,7 @@
 // gathered matrix (the same deterministic search on every rank, kept per pattern), the operands are redistributed in that
 // order, the solver runs on banded panels -- halo exchanges of a bandwidth instead of whole-matrix gathers, fused steps in
 // slab form -- and the results are carried back.  What comes out is the reference's result for the solve run under its load
-// balancer with this permutation: bit for bit the oracle's on the relabelled operands, and within the threshold of
+// balancer with this permutation: bit for bit the reference's on the relabelled operands, and within the threshold of
 // the solve on the caller's labels (entries below the threshold survive a merge where they lie beyond the other
 // column's last row: which ones do depends on the labels).
 #include <cstdio>
