@@ -293,6 +293,44 @@ MODULE NTPolyAMDBindings
      SUBROUTINE PowerBounds_c(a, v, sp) BIND(C, name="PowerBounds_wrp")
        IMPORT; INTEGER(c_int), INTENT(IN) :: a(*), sp(*); REAL(c_double), INTENT(OUT) :: v
      END SUBROUTINE
+     !! local matrices (Source/C/SMatrix_c.h) and the two entry points behind GatherMatrixToProcess / CommSplitMatrix
+     SUBROUTINE ConstructMatrixFromTripletList_lsr_wrp(ih, tl, r, c) BIND(C, name="ConstructMatrixFromTripletList_lsr_wrp")
+       IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*); INTEGER(c_int), INTENT(IN) :: tl(*), r, c
+     END SUBROUTINE
+     SUBROUTINE ConstructMatrixFromTripletList_lsc_wrp(ih, tl, r, c) BIND(C, name="ConstructMatrixFromTripletList_lsc_wrp")
+       IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*); INTEGER(c_int), INTENT(IN) :: tl(*), r, c
+     END SUBROUTINE
+     SUBROUTINE DestructMatrix_lsr_wrp(ih) BIND(C, name="DestructMatrix_lsr_wrp")
+       IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*)
+     END SUBROUTINE
+     SUBROUTINE DestructMatrix_lsc_wrp(ih) BIND(C, name="DestructMatrix_lsc_wrp")
+       IMPORT; INTEGER(c_int), INTENT(INOUT) :: ih(*)
+     END SUBROUTINE
+     SUBROUTINE GetMatrixRows_lsr_wrp(ih, n) BIND(C, name="GetMatrixRows_lsr_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*); INTEGER(c_int), INTENT(OUT) :: n
+     END SUBROUTINE
+     SUBROUTINE GetMatrixColumns_lsr_wrp(ih, n) BIND(C, name="GetMatrixColumns_lsr_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*); INTEGER(c_int), INTENT(OUT) :: n
+     END SUBROUTINE
+     SUBROUTINE GetMatrixRows_lsc_wrp(ih, n) BIND(C, name="GetMatrixRows_lsc_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*); INTEGER(c_int), INTENT(OUT) :: n
+     END SUBROUTINE
+     SUBROUTINE GetMatrixColumns_lsc_wrp(ih, n) BIND(C, name="GetMatrixColumns_lsc_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*); INTEGER(c_int), INTENT(OUT) :: n
+     END SUBROUTINE
+     SUBROUTINE MatrixToTripletList_lsr_wrp(ih, tl) BIND(C, name="MatrixToTripletList_lsr_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*); INTEGER(c_int), INTENT(INOUT) :: tl(*)
+     END SUBROUTINE
+     SUBROUTINE MatrixToTripletList_lsc_wrp(ih, tl) BIND(C, name="MatrixToTripletList_lsc_wrp")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*); INTEGER(c_int), INTENT(INOUT) :: tl(*)
+     END SUBROUTINE
+     SUBROUTINE ntpoly_amd_gather_matrix_to_process(ih, il, id) BIND(C, name="ntpoly_amd_gather_matrix_to_process")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*), id; INTEGER(c_int), INTENT(INOUT) :: il(*)
+     END SUBROUTINE
+     SUBROUTINE ntpoly_amd_comm_split_matrix(ih, is, color, split_slice) BIND(C, name="ntpoly_amd_comm_split_matrix")
+       IMPORT; INTEGER(c_int), INTENT(IN) :: ih(*); INTEGER(c_int), INTENT(INOUT) :: is(*); INTEGER(c_int), INTENT(OUT) :: color
+       LOGICAL(c_bool), INTENT(OUT) :: split_slice
+     END SUBROUTINE
   END INTERFACE
 CONTAINS
   !> Fortran string -> (character array, length) as the C ABI takes strings (PSMatrixModule_wrp.F90:73-90)
@@ -666,10 +704,120 @@ CONTAINS
   END SUBROUTINE SymmetrizeTripletList_c
 END MODULE TripletListModule
 
+MODULE SMatrixModule   !< SMatrixModule.F90:15-30: local matrices (Matrix_lsr / Matrix_lsc), what GatherMatrixToProcess hands back
+  USE NTPolyAMDBindings
+  USE TripletListModule, ONLY : TripletList_r, TripletList_c, SyncTripletListSize
+  IMPLICIT NONE
+  PRIVATE
+  TYPE, PUBLIC :: Matrix_lsr
+     INTEGER(c_int) :: ih(SIZE_wrp) = 0   !< opaque handle of the engine's local matrix
+     INTEGER :: rows = 0, columns = 0
+  END TYPE Matrix_lsr
+  TYPE, PUBLIC :: Matrix_lsc
+     INTEGER(c_int) :: ih(SIZE_wrp) = 0
+     INTEGER :: rows = 0, columns = 0
+  END TYPE Matrix_lsc
+  PUBLIC :: ConstructMatrixFromTripletList, DestructMatrix, GetMatrixRows, GetMatrixColumns, MatrixToTripletList, RefreshLocalMatrix
+  INTERFACE ConstructMatrixFromTripletList
+     MODULE PROCEDURE ConstructMatrixFromTripletList_lsr, ConstructMatrixFromTripletList_lsc
+  END INTERFACE ConstructMatrixFromTripletList
+  INTERFACE DestructMatrix
+     MODULE PROCEDURE DestructMatrix_lsr, DestructMatrix_lsc
+  END INTERFACE DestructMatrix
+  INTERFACE GetMatrixRows
+     MODULE PROCEDURE GetMatrixRows_lsr, GetMatrixRows_lsc
+  END INTERFACE GetMatrixRows
+  INTERFACE GetMatrixColumns
+     MODULE PROCEDURE GetMatrixColumns_lsr, GetMatrixColumns_lsc
+  END INTERFACE GetMatrixColumns
+  INTERFACE MatrixToTripletList
+     MODULE PROCEDURE MatrixToTripletList_lsr, MatrixToTripletList_lsc
+  END INTERFACE MatrixToTripletList
+  INTERFACE RefreshLocalMatrix   !< mirror the engine-side shape into the Fortran-visible members
+     MODULE PROCEDURE RefreshLocalMatrix_lsr, RefreshLocalMatrix_lsc
+  END INTERFACE RefreshLocalMatrix
+CONTAINS
+  SUBROUTINE RefreshLocalMatrix_lsr(this)
+    TYPE(Matrix_lsr), INTENT(INOUT) :: this
+    INTEGER(c_int) :: n
+    IF (ALL(this%ih .EQ. 0)) RETURN
+    CALL GetMatrixRows_lsr_wrp(this%ih, n); this%rows = n
+    CALL GetMatrixColumns_lsr_wrp(this%ih, n); this%columns = n
+  END SUBROUTINE RefreshLocalMatrix_lsr
+  SUBROUTINE RefreshLocalMatrix_lsc(this)
+    TYPE(Matrix_lsc), INTENT(INOUT) :: this
+    INTEGER(c_int) :: n
+    IF (ALL(this%ih .EQ. 0)) RETURN
+    CALL GetMatrixRows_lsc_wrp(this%ih, n); this%rows = n
+    CALL GetMatrixColumns_lsc_wrp(this%ih, n); this%columns = n
+  END SUBROUTINE RefreshLocalMatrix_lsc
+  SUBROUTINE ConstructMatrixFromTripletList_lsr(this, triplet_list, rows, columns)   !< SMatrixModule.F90 ConstructMatrixFromTripletList
+    TYPE(Matrix_lsr), INTENT(INOUT) :: this
+    TYPE(TripletList_r), INTENT(IN) :: triplet_list
+    INTEGER, INTENT(IN) :: rows, columns
+    CALL DestructMatrix_lsr(this)
+    CALL ConstructMatrixFromTripletList_lsr_wrp(this%ih, triplet_list%ih, INT(rows, c_int), INT(columns, c_int))
+    CALL RefreshLocalMatrix_lsr(this)
+  END SUBROUTINE ConstructMatrixFromTripletList_lsr
+  SUBROUTINE ConstructMatrixFromTripletList_lsc(this, triplet_list, rows, columns)
+    TYPE(Matrix_lsc), INTENT(INOUT) :: this
+    TYPE(TripletList_c), INTENT(IN) :: triplet_list
+    INTEGER, INTENT(IN) :: rows, columns
+    CALL DestructMatrix_lsc(this)
+    CALL ConstructMatrixFromTripletList_lsc_wrp(this%ih, triplet_list%ih, INT(rows, c_int), INT(columns, c_int))
+    CALL RefreshLocalMatrix_lsc(this)
+  END SUBROUTINE ConstructMatrixFromTripletList_lsc
+  SUBROUTINE DestructMatrix_lsr(this)
+    TYPE(Matrix_lsr), INTENT(INOUT) :: this
+    IF (ANY(this%ih .NE. 0)) CALL DestructMatrix_lsr_wrp(this%ih)
+    this%ih = 0; this%rows = 0; this%columns = 0
+  END SUBROUTINE DestructMatrix_lsr
+  SUBROUTINE DestructMatrix_lsc(this)
+    TYPE(Matrix_lsc), INTENT(INOUT) :: this
+    IF (ANY(this%ih .NE. 0)) CALL DestructMatrix_lsc_wrp(this%ih)
+    this%ih = 0; this%rows = 0; this%columns = 0
+  END SUBROUTINE DestructMatrix_lsc
+  PURE FUNCTION GetMatrixRows_lsr(this) RESULT(n)
+    TYPE(Matrix_lsr), INTENT(IN) :: this
+    INTEGER :: n
+    n = this%rows
+  END FUNCTION GetMatrixRows_lsr
+  PURE FUNCTION GetMatrixRows_lsc(this) RESULT(n)
+    TYPE(Matrix_lsc), INTENT(IN) :: this
+    INTEGER :: n
+    n = this%rows
+  END FUNCTION GetMatrixRows_lsc
+  PURE FUNCTION GetMatrixColumns_lsr(this) RESULT(n)
+    TYPE(Matrix_lsr), INTENT(IN) :: this
+    INTEGER :: n
+    n = this%columns
+  END FUNCTION GetMatrixColumns_lsr
+  PURE FUNCTION GetMatrixColumns_lsc(this) RESULT(n)
+    TYPE(Matrix_lsc), INTENT(IN) :: this
+    INTEGER :: n
+    n = this%columns
+  END FUNCTION GetMatrixColumns_lsc
+  SUBROUTINE MatrixToTripletList_lsr(this, triplet_list)   !< SMatrixModule.F90 MatrixToTripletList
+    TYPE(Matrix_lsr), INTENT(IN) :: this
+    TYPE(TripletList_r), INTENT(INOUT) :: triplet_list
+    IF (ALL(triplet_list%ih .EQ. 0)) CALL ConstructTripletList_r_wrp(triplet_list%ih, 0_c_int)
+    CALL MatrixToTripletList_lsr_wrp(this%ih, triplet_list%ih)
+    CALL SyncTripletListSize(triplet_list)
+  END SUBROUTINE MatrixToTripletList_lsr
+  SUBROUTINE MatrixToTripletList_lsc(this, triplet_list)
+    TYPE(Matrix_lsc), INTENT(IN) :: this
+    TYPE(TripletList_c), INTENT(INOUT) :: triplet_list
+    IF (ALL(triplet_list%ih .EQ. 0)) CALL ConstructTripletList_c_wrp(triplet_list%ih, 0_c_int)
+    CALL MatrixToTripletList_lsc_wrp(this%ih, triplet_list%ih)
+    CALL SyncTripletListSize(triplet_list)
+  END SUBROUTINE MatrixToTripletList_lsc
+END MODULE SMatrixModule
+
 MODULE PSMatrixModule   !< PSMatrixModule.F90:33-51 and the routines user code calls
   USE NTPolyAMDBindings
   USE DataTypesModule, ONLY : NTREAL, NTLONG
   USE TripletListModule, ONLY : TripletList_r, TripletList_c, SyncTripletListSize
+  USE SMatrixModule, ONLY : Matrix_lsr, Matrix_lsc, DestructLocalMatrix => DestructMatrix, RefreshLocalMatrix
   IMPLICIT NONE
   PRIVATE
   TYPE, PUBLIC :: Matrix_ps
@@ -681,7 +829,11 @@ MODULE PSMatrixModule   !< PSMatrixModule.F90:33-51 and the routines user code c
   PUBLIC :: ConstructEmptyMatrix, ConstructMatrixFromMatrixMarket, ConstructMatrixFromBinary, &
        & WriteMatrixToMatrixMarket, WriteMatrixToBinary, DestructMatrix, CopyMatrix, FillMatrixIdentity, &
        & FillMatrixFromTripletList, GetMatrixTripletList, GetMatrixSize, GetMatrixActualDimension, &
-       & GetMatrixLogicalDimension, TransposeMatrix, ConjugateMatrix, PrepareOutput, RefreshMatrix, PrintMatrix
+       & GetMatrixLogicalDimension, TransposeMatrix, ConjugateMatrix, PrepareOutput, RefreshMatrix, PrintMatrix, &
+       & GatherMatrixToProcess, CommSplitMatrix
+  INTERFACE GatherMatrixToProcess   !< PSMatrixModule.F90:160-165
+     MODULE PROCEDURE GatherMatrixToProcess_psr_id, GatherMatrixToProcess_psr_all, GatherMatrixToProcess_psc_id, GatherMatrixToProcess_psc_all
+  END INTERFACE GatherMatrixToProcess
   INTERFACE FillMatrixFromTripletList
      MODULE PROCEDURE FillMatrixFromTripletList_r, FillMatrixFromTripletList_c
   END INTERFACE FillMatrixFromTripletList
@@ -797,6 +949,61 @@ CONTAINS
     CALL GetMatrixTripletList_psc_wrp(this%ih, triplet_list%ih)
     CALL SyncTripletListSize(triplet_list)
   END SUBROUTINE GetMatrixTripletList_c
+  !> GatherMatrixToProcess (PSMatrixModule.F90:1704-1808): the whole matrix as a local matrix on the process with this rank
+  !> inside its slice (the other processes' local_mat is left alone) ...
+  SUBROUTINE GatherMatrixToProcess_psr_id(this, local_mat, within_slice_id)
+    TYPE(Matrix_ps), INTENT(IN) :: this
+    TYPE(Matrix_lsr), INTENT(INOUT) :: local_mat
+    INTEGER, INTENT(IN) :: within_slice_id
+    INTEGER(c_int) :: ihl(SIZE_wrp)
+    ihl = 0
+    CALL ntpoly_amd_gather_matrix_to_process(this%ih, ihl, INT(within_slice_id, c_int))
+    IF (ANY(ihl .NE. 0)) THEN
+       CALL DestructLocalMatrix(local_mat)
+       local_mat%ih = ihl
+       CALL RefreshLocalMatrix(local_mat)
+    END IF
+  END SUBROUTINE GatherMatrixToProcess_psr_id
+  !> ... or on every process
+  SUBROUTINE GatherMatrixToProcess_psr_all(this, local_mat)
+    TYPE(Matrix_ps), INTENT(IN) :: this
+    TYPE(Matrix_lsr), INTENT(INOUT) :: local_mat
+    CALL GatherMatrixToProcess_psr_id(this, local_mat, -1)
+  END SUBROUTINE GatherMatrixToProcess_psr_all
+  SUBROUTINE GatherMatrixToProcess_psc_id(this, local_mat, within_slice_id)
+    TYPE(Matrix_ps), INTENT(IN) :: this
+    TYPE(Matrix_lsc), INTENT(INOUT) :: local_mat
+    INTEGER, INTENT(IN) :: within_slice_id
+    INTEGER(c_int) :: ihl(SIZE_wrp)
+    ihl = 0
+    CALL ntpoly_amd_gather_matrix_to_process(this%ih, ihl, INT(within_slice_id, c_int))
+    IF (ANY(ihl .NE. 0)) THEN
+       CALL DestructLocalMatrix(local_mat)
+       local_mat%ih = ihl
+       CALL RefreshLocalMatrix(local_mat)
+    END IF
+  END SUBROUTINE GatherMatrixToProcess_psc_id
+  SUBROUTINE GatherMatrixToProcess_psc_all(this, local_mat)
+    TYPE(Matrix_ps), INTENT(IN) :: this
+    TYPE(Matrix_lsc), INTENT(INOUT) :: local_mat
+    CALL GatherMatrixToProcess_psc_id(this, local_mat, -1)
+  END SUBROUTINE GatherMatrixToProcess_psc_all
+  !> CommSplitMatrix (PSMatrixModule.F90:1489-1541): a copy of the matrix hosted on one half of the process grid.  One
+  !> process: the copy, colour 0, split along the slices (distributed_includes/CommSplitMatrix.f90:11-14); more: fatal -- the
+  !> engine has one communicator (csrc/wrp.cpp ntpoly_amd_comm_split_matrix)
+  SUBROUTINE CommSplitMatrix(this, split_mat, my_color, split_slice)
+    TYPE(Matrix_ps), INTENT(INOUT) :: this
+    TYPE(Matrix_ps), INTENT(INOUT) :: split_mat
+    INTEGER, INTENT(OUT) :: my_color
+    LOGICAL, INTENT(OUT) :: split_slice
+    INTEGER(c_int) :: color
+    LOGICAL(c_bool) :: ss
+    CALL DestructMatrix(split_mat)
+    CALL ntpoly_amd_comm_split_matrix(this%ih, split_mat%ih, color, ss)
+    CALL RefreshMatrix(split_mat)
+    my_color = color
+    split_slice = ss
+  END SUBROUTINE CommSplitMatrix
   !> PrintMatrix (PSMatrixModule.F90:1271-1290): MatrixMarket text to the console, or to a file
   SUBROUTINE PrintMatrix(this, file_name_in)
     TYPE(Matrix_ps) :: this

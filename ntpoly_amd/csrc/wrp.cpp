@@ -258,6 +258,36 @@ void ntpoly_amd_fusion_counts(long long* out) {
 void ntpoly_amd_tile2_counts(long long* out) {
   for (int q = 0; q < 2; ++q) out[q] = tile2_counts()[q];
 }
+// GatherMatrixToProcess (PSMatrixModule.F90:1704-1808, distributed_includes/GatherMatrixToProcess.f90, GatherMatrixToAll.f90):
+// the whole distributed matrix as a LOCAL matrix (Matrix_lsr / Matrix_lsc of its scalar type) -- on every process
+// (*within_slice_id < 0: the _all variants) or on the process with that rank inside its slice only (the _id variants: data
+// stays replicated across slices; the other processes' ih_local is left as it was).  The callee constructs the handle.
+void ntpoly_amd_gather_matrix_to_process(const int* ih_this, int* ih_local, const int* within_slice_id) {
+  const PSMatrix& m = *get<PSMatrix>(ih_this);
+  DevMat full = ps_gather_full(m);      // (collective: the panels travel to every rank; a process that is not the target drops them)
+  const ProcessGrid& g = m.grid ? *m.grid : global_grid();
+  const int slice_size = g.num_rows * g.num_cols;
+  const int in_slice = g.global_rank - slice_size * g.my_slice;
+  if (*within_slice_id >= 0 && *within_slice_id != in_slice) return;
+  auto* L = new LocalMat();
+  L->m = std::move(full);
+  put(ih_local, L);
+}
+// CommSplitMatrix (PSMatrixModule.F90:1489-1541, distributed_includes/CommSplitMatrix.f90): a copy of the matrix on one half
+// of the process grid.  On one process -- the reference's base case (:11-14) -- the copy itself, colour 0, "split along the
+// slices".  More processes need a grid on a sub-communicator; this engine has ONE RCCL communicator (its grids are shapes
+// over it), so the call is fatal there, as the reference is for grids it cannot build (ErrorModule.F90:193-205).  Only the
+// divide-and-conquer eigensolver of the reference, outside this engine's scope, calls it.
+void ntpoly_amd_comm_split_matrix(const int* ih_this, int* ih_split, int* my_color, bool* split_slice) {
+  const PSMatrix& m = *get<PSMatrix>(ih_this);
+  const ProcessGrid& g = m.grid ? *m.grid : global_grid();
+  if (g.total != 1) NTP_FATAL("CommSplitMatrix on " + std::to_string(g.total) + " processes needs a process grid on a sub-communicator, which this engine does not have");
+  auto* out = new PSMatrix();
+  ps_copy(m, *out);
+  put(ih_split, out);
+  *my_color = 0;
+  *split_slice = true;
+}
 // out[0] = solves that ran in a recovered band order across ranks (band_scope.cpp), out[1] = operands searched for one
 void ntpoly_amd_band_scope_counts(long long* out) {
   for (int q = 0; q < 2; ++q) out[q] = band_scope_counts()[q];

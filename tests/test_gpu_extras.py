@@ -342,6 +342,27 @@ def test_fortran_solver_family_modules(tmp_path):
     assert r.stdout.count("ok   ") == 7, r.stdout
 
 
+def test_fortran_gather_and_comm_split(tmp_path):
+    """GatherMatrixToProcess (to every process / to a process of the slice, real) and CommSplitMatrix of the Fortran module
+    layer (PSMatrixModule.F90:1489-1541, 1704-1808): tests/fortran/gather_split.f90 compiled with
+    flang against the product's modules, linked with libntpoly_amd_fortran.a + libntpoly_amd.so, checks itself."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flang = "/opt/rocm/lib/llvm/bin/flang"
+    pkg = os.path.join(root, "ntpoly_amd")
+    if not os.path.exists(flang) or not os.path.exists(os.path.join(pkg, "libntpoly_amd_fortran.a")):
+        pytest.skip("flang or the built Fortran layer is not available")
+    obj, exe = str(tmp_path / "gs.o"), str(tmp_path / "gs")
+    subprocess.run([flang, "-O1", "-c", os.path.join(root, "tests", "fortran", "gather_split.f90"), "-o", obj,
+                    "-I", os.path.join(pkg, "fortran_mod"), "-J", str(tmp_path)], check=True, cwd=str(tmp_path))
+    subprocess.run([flang, "-o", exe, obj, os.path.join(pkg, "libntpoly_amd_fortran.a"), "-L" + pkg, "-lntpoly_amd",
+                    "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], check=True, cwd=str(tmp_path))
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "ALL PASS" in r.stdout and "FAIL" not in r.stdout, r.stdout
+    assert r.stdout.count("ok   ") == 3, r.stdout
+
+
 def test_utilities_for_the_cxx_layer(nt):
     """FillMatrixDense, MatrixDiagonalScale, GetMatrixBlock, GetMatrixSlice, ResizeMatrix, McWeenyStep(S),
     EnergyDensityMatrix against numpy on a small banded matrix (semantics: PSMatrixModule.F90:958-990, 1036-1225,
