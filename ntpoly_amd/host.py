@@ -492,6 +492,18 @@ class Matrix_ps:
     def Symmetrize(self):
         lib.SymmetrizeMatrix_ps_wrp(self.ih)
 
+    def GatherMatrixToProcess(self, within_slice_id=None):
+        """the whole matrix as a LOCAL matrix on every process (None) or on the process with this rank inside its slice (the
+        others get None) -- PSMatrixModule.F90:1704-1808"""
+        cls = Matrix_lsc if self.IsComplex() else Matrix_lsr
+        ih = handle()
+        lib.ntpoly_amd_gather_matrix_to_process(self.ih, ih, i(-1 if within_slice_id is None else within_slice_id))
+        if not any(ih):
+            return None
+        out = cls.__new__(cls)
+        out.ih = ih
+        return out
+
 
 # ------------------------------------------------------------------ local matrices (config 2)
 class _Matrix_ls:

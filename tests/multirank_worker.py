@@ -51,6 +51,13 @@ def main():
     AT = nt.Matrix_ps(n)
     AT.Transpose(C)
     keep("ABT", AT)
+    # GatherMatrixToProcess (PSMatrixModule.F90:1704-1808): the whole product as a local matrix on every rank, and on rank 1
+    # of the slice only
+    Lall = C.GatherMatrixToProcess()
+    gc, gr, gv = Lall.triplets()
+    res["gather_all"] = np.array([len(gv), float(np.sum(gv)), float(np.sum(gv * gr)), float(np.sum(gv * gc))])
+    Lone = C.GatherMatrixToProcess(min(1, world - 1))
+    res["gather_one"] = np.array([-1.0 if Lone is None else float(len(Lone.triplets()[2]))])
     # the same product with the halo exchange overlapped: interior columns multiplied while the halo travels on the
     # communication stream, boundary columns afterwards (forced; by default only when the halo is large)
     nt.set_option("halo_overlap", 2)

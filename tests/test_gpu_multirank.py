@@ -75,6 +75,11 @@ def test_multirank_equals_single_rank(world, arith, references, tmp_path):
             assert np.allclose(got[2], want[2], rtol=0, atol=1e-10)
         else:
             assert all(np.array_equal(g, w) for g, w in zip(got, want)), tag
+    # GatherMatrixToProcess: every rank holds the whole product; the "to one process" variant leaves the others empty-handed
+    for r in range(world):
+        assert np.allclose(parts[r]["gather_all"], reference["gather_all"], rtol=1e-13, atol=0), (r, parts[r]["gather_all"])
+        want_one = float(reference["gather_all"][0]) if r == min(1, world - 1) else -1.0
+        assert float(parts[r]["gather_one"][0]) == want_one, (r, parts[r]["gather_one"])
     # the TRS2 steps ran inside the SpGEMM kernel on every rank (fused epilogue, panels in slab form, halo exchanged as
     # dense column runs: psmatrix.cpp dist_fused_step), with one host synchronisation per exchange
     for r in range(world):

@@ -201,6 +201,54 @@ def test_config4_sign_of_the_indefinite_operand(nt, arith):
     assert S.GetSize() > 20 * n        # not a diagonal matrix
 
 
+def test_config4_product_and_sign_iterations_vs_oracle_at_the_benched_size(nt, arith):
+    """configs[4] at the size the bench runs (complex Hermitian, N = 131 072, h = 50) against the ORACLE itself, not through
+    properties: one product A * A and three SignFunction iterations (SignSolversModule.F90:150-258), in both arithmetic
+    modes.  Unfused: the reference's complex multiply-add, bit for bit.  FMA: the complex matrix-core kernel, a tolerance
+    mode -- values to 1e-13 of the largest entry, patterns equal except within that distance of the threshold, the same
+    convergence values."""
+    from oracle import oracle_py as O
+    import scipy.sparse as sp
+    n, h, thr = 131072, 50, 1e-8
+    col, row, val = banded_triplets(n, h, complex_=True)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    Ao = O.Mat.from_triplets(n, n, col, row, val)
+    del col, row, val
+
+    def compare(got, want, what):
+        gc, gr, gv = got
+        wc, wr, wv = want
+        if arith == "unfused":
+            og, ow = np.lexsort((gr, gc)), np.lexsort((wr, wc))
+            assert len(gv) == len(wv), (what, len(gv), len(wv))
+            assert np.array_equal(gc[og], wc[ow]) and np.array_equal(gr[og], wr[ow]), what
+            assert np.array_equal(gv[og], wv[ow]), (what, np.abs(gv[og] - wv[ow]).max())
+            return
+        G = sp.csr_matrix((gv, (gr - 1, gc - 1)), shape=(n, n))
+        W = sp.csr_matrix((wv, (wr - 1, wc - 1)), shape=(n, n))
+        scale = np.abs(wv).max()
+        D = (G - W).tocoo()
+        big = np.abs(D.data) > 1e-13 * scale
+        assert np.all(np.abs(D.data[big]) <= thr * (1 + 1e-6) + 1e-13 * scale), (what, np.abs(D.data).max())   # (only entries at the threshold)
+        assert abs(G.nnz - W.nnz) <= max(8, 1e-6 * W.nnz), (what, G.nnz, W.nnz)
+
+    C = nt.Matrix_ps(n)
+    C.Gemm(A, A, None, 1.0, 0.0, thr)
+    compare(C.triplets(), O.ps_multiply(Ao, Ao, None, 1.0, 0.0, thr).triplets(), "A * A")
+    del C
+    p = nt.SolverParameters()
+    p.SetThreshold(thr)
+    p.SetConvergeDiff(1e-30)
+    p.SetMaxIterations(3)
+    S = nt.Matrix_ps(n)
+    nt.SignSolvers.ComputeSign(A, S, p)
+    tr = nt.solver_trace()
+    So, tro = O.matrix_function("sign", Ao, O.params(converge_diff=1e-30, max_iterations=3, threshold=thr))
+    assert tr["iterations"] == tro["iterations"] == 3
+    assert np.allclose(tr["value"], tro["value"], rtol=1e-9, atol=1e-12), (tr["value"], tro["value"])
+    compare(S.triplets(), So.triplets(), "three SignFunction iterations")
+
+
 def test_headline_config2_vs_oracle_full_size(nt, arith):
     """BASELINE configs[2] at FULL size (N = 262 144, 201 entries per row, threshold 1e-8, ISQ = I, trace = N/2): the
     first 8 TRS2 iterations of the engine against the same 8 iterations of the oracle (the C restatement pinned to the
