@@ -461,7 +461,7 @@ def main():
         # the corrected bytes per launch together with a fingerprint of the kernel sources it was measured on -- a
         # figure measured on other sources is not reported (null)
         traffic, traffic_src = None, None
-        tname = ("r04_pmc_traffic%s.json" if args.arithmetic == "fma" else "r04_pmc_traffic_unfused%s.json") % (
+        tname = ("r05_pmc_traffic%s.json" if args.arithmetic == "fma" else "r05_pmc_traffic_unfused%s.json") % (
             "_lattice" if args.lattice is not None else "" if args.permute is None else "_permute")
         try:
             with open(os.path.join(ROOT, "profiles", tname)) as f:

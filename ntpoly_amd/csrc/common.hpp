@@ -45,9 +45,9 @@ long long& host_sync_count();   // host waits on the engine stream so far (count
 // host-mapped pinned memory and the stream is synchronised once (a hipMemcpyAsync per scalar costs a copy
 // kernel and ~20 us of dispatch gap each).  fetch.add(dev_ptr, words, host_dst) ... fetch.run().
 struct ScalarFetch {
-  const void* src[8];
-  int words[8];
-  void* dst[8];
+  const void* src[16];
+  int words[16];
+  void* dst[16];
   int n = 0;
   void add(const void* dev, int words8, void* host_dst) {
     src[n] = dev; words[n] = words8; dst[n] = host_dst; ++n;

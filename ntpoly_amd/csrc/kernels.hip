@@ -2696,8 +2696,8 @@ void scan_i64_async(const int64_t* d_in, int64_t* d_out, int64_t n) { scan_async
 
 namespace {
 struct FetchArgs {
-  const unsigned long long* src[8];
-  int words[8];
+  const unsigned long long* src[16];
+  int words[16];
   int n;
 };
 __global__ __launch_bounds__(64) void k_fetch(FetchArgs a, unsigned long long* __restrict__ host_mapped) {
@@ -4431,6 +4431,23 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     next.reset(new SlabPlan());
     launch_slab_plan(*next, n, ofirst.p, olast.p, ofirst.p, olast.p, plan_align, next_stats);
   }
+  // the result as it stands on the device (its entry count comes back below)
+  DevMat R;
+  R.rows = X.rows;
+  R.cols = n;
+  R.cplx = false;
+  R.zero_free = 1;
+  R.slab.reset(new SlabForm());
+  R.slab->first = std::move(ofirst);
+  R.slab->last = std::move(olast);
+  R.slab->count = std::move(count);
+  R.slab->row_pad = tile ? 16 * trows : 1;
+  R.slab->no_tile2 = in.no_tile2;
+  R.slab->off = tile ? std::move(tile_ooff) : std::move(tmpoff);
+  if (tile) R.slab->tile_off = std::move(tile_otoff);   // (the slab loop's result takes the plan's tile offsets below, once the step has succeeded)
+  R.slab->val = std::move(oval);
+  if (runs_only) { R.slab->tile_off.release(); } else R.slab->tiles = std::move(otiles);
+  R.slab->slots = tmp_total;
   {
     ScalarFetch f;
     f.add(tot.p, 5, raw);
@@ -4440,6 +4457,9 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
       f.add(next->blk_toff.p + snb, 1, &next->total);
       f.add(next_stats + 16, 3, next_hs);
     }
+    // (a panel step: what the caller wants to know about the NEXT step -- its exchange layout and plan, from this result's
+    // extents -- rides on this read-back)
+    if (halo && halo->before_fetch) halo->before_fetch(R, reinterpret_cast<const long long*>(tot.p), f);
     f.run();
     if (red4.p) halo->reduce->done = true;
   }
@@ -4470,24 +4490,9 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
   double hd[2];
   std::memcpy(hd, &raw[3], 2 * sizeof(double));
   const int64_t nnz_in = X.nnz;
-  DevMat R;
-  R.rows = X.rows;
-  R.cols = n;
-  R.cplx = false;
   R.nnz = nnz;
-  R.zero_free = 1;
-  R.slab.reset(new SlabForm());
-  R.slab->first = std::move(ofirst);
-  R.slab->last = std::move(olast);
-  R.slab->count = std::move(count);
-  R.slab->row_pad = tile ? 16 * trows : 1;
   R.slab->next_plan = std::move(next);
-  R.slab->no_tile2 = in.no_tile2;
-  R.slab->off = tile ? std::move(tile_ooff) : std::move(tmpoff);
-  R.slab->tile_off = tile ? std::move(tile_otoff) : std::move(plan->blk_toff);   // (the slab loop's result keeps the plan's tile offsets)
-  R.slab->val = std::move(oval);
-  if (runs_only) { R.slab->tile_off.release(); } else R.slab->tiles = std::move(otiles);
-  R.slab->slots = tmp_total;
+  if (!tile) R.slab->tile_off = std::move(plan->blk_toff);   // (the slab loop's result keeps the plan's tile offsets)
   if (labelled || tile_labelled) {
     R.slab->lab = std::move(X.slab->lab);
     R.slab->plast = std::move(oplast);
@@ -5351,7 +5356,7 @@ void halo_bounds_async(const DevMat& A, int32_t c0, const int32_t* d_sa, const i
 // ------------------------------------------------------------------ halo exchange of a panel in slab form
 namespace {
 __global__ void k_slab_request(const int32_t* __restrict__ first, const int32_t* __restrict__ last, int n, long long nnz,
-                               long long* __restrict__ out4) {
+                               const long long* __restrict__ d_nnz, long long* __restrict__ out4) {
   // out4[0], out4[1] were preset to (INT_MAX, -1)
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const bool has = j < n && last[j] >= first[j];
@@ -5360,7 +5365,7 @@ __global__ void k_slab_request(const int32_t* __restrict__ first, const int32_t*
     atomicMin(&out4[0], (long long)lo);
     atomicMax(&out4[1], (long long)hi);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) out4[2] = out4[3] = nnz;
+  if (blockIdx.x == 0 && threadIdx.x == 0) out4[2] = out4[3] = d_nnz ? d_nnz[0] : nnz;
 }
 // (al > 1: the runs travel in the aligned zero-padded slots the MFMA tile kernel reads several rows per lane from --
 // span = slot size, SlabForm::row_pad)
@@ -5441,11 +5446,11 @@ void slab_plan_panel_async(const DevMat& X, const int64_t* d_ext_all, int pitch,
   launch_slab_plan(plan, X.cols, X.slab->first.p, X.slab->last.p, gfirst.p, glast.p, tile ? 16 * tile_rows() : 0, stats24);
 }
 
-void slab_request_async(const DevMat& X, int64_t* d_out4) {
+void slab_request_async(const DevMat& X, int64_t* d_out4, const long long* d_nnz) {
   const long long init[2] = {INT_MAX, -1};
   HIP_CHECK(hipMemcpyAsync(d_out4, init, sizeof(init), hipMemcpyHostToDevice, stream()));
   hipLaunchKernelGGL(k_slab_request, dim3(std::max(1, cdiv(X.cols, 256))), dim3(256), 0, stream(), X.slab->first.p,
-                     X.slab->last.p, X.cols, (long long)X.nnz, reinterpret_cast<long long*>(d_out4));
+                     X.slab->last.p, X.cols, (long long)X.nnz, d_nnz, reinterpret_cast<long long*>(d_out4));
 }
 
 void slab_extents_async(const DevMat& X, int64_t* d_ext, int64_t* d_pre) {
@@ -5832,13 +5837,14 @@ __global__ void k_sa_span(const int32_t* __restrict__ fa, const int32_t* __restr
 // followed by IncrementMatrix), one wave per column, result in a fresh slot at base[j] (row r at base + r - a0, a0 =
 // the multiple of al below the union's first row; pads and dropped rows zero).  HAVE_B false: a copy of A (alpha = 1).
 // stat[0] |= 1 when a kept value is exactly zero (an unfiltered tail that underflowed: the slab form cannot hold it).
-template <bool HAVE_B>
+// (T = double2: complex runs of (re, im) pairs, offsets in elements, threshold on the modulus -- the complex sessions)
+template <typename T, bool HAVE_B>
 __global__ __launch_bounds__(256) void k_sa_axpby(int n, const int32_t* __restrict__ fa, const int32_t* __restrict__ la,
-                                                  const int64_t* __restrict__ offa, const double* __restrict__ va,
+                                                  const int64_t* __restrict__ offa, const T* __restrict__ va,
                                                   const int32_t* __restrict__ fb, const int32_t* __restrict__ lb,
-                                                  const int64_t* __restrict__ offb, const double* __restrict__ vb,
+                                                  const int64_t* __restrict__ offb, const T* __restrict__ vb,
                                                   const int64_t* __restrict__ base, int al, double alpha, double beta, double thr,
-                                                  double* __restrict__ out, int32_t* __restrict__ ofirst, int32_t* __restrict__ olast,
+                                                  T* __restrict__ out, int32_t* __restrict__ ofirst, int32_t* __restrict__ olast,
                                                   int32_t* __restrict__ ocount, int64_t* __restrict__ ooff,
                                                   unsigned long long* __restrict__ stat, int64_t bound) {
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
@@ -5863,22 +5869,22 @@ __global__ __launch_bounds__(256) void k_sa_axpby(int n, const int32_t* __restri
     return;
   }
   const int amax = anyA ? lA : -1, bmax = anyB ? lB : -1;
-  const double* __restrict__ pa = anyA ? va + (offa[j] - fA) : va;
-  const double* __restrict__ pb = (HAVE_B && anyB) ? vb + (offb[j] - fB) : va;
-  double* __restrict__ dst = out + (slot - a0);
+  const T* __restrict__ pa = anyA ? va + (offa[j] - fA) : va;
+  const T* __restrict__ pb = (HAVE_B && anyB) ? vb + (offb[j] - fB) : va;
+  T* __restrict__ dst = out + (slot - a0);
   int cnt = 0, kf = INT_MAX, kl = -1, zk = 0;
   for (int r = a0 + lane; r < a1; r += WAVE) {
-    const double a = (anyA && r >= fA && r <= lA) ? pa[r] : 0.0;
-    const double b = (HAVE_B && anyB && r >= fB && r <= lB) ? pb[r] : 0.0;
-    const bool ha = a != 0.0, hb = b != 0.0;
-    const double wa = __dmul_rn(alpha, a), bs = HAVE_B ? __dmul_rn(beta, b) : 0.0;
-    double o = 0.0;
+    const T a = (anyA && r >= fA && r <= lA) ? pa[r] : Sc<T>::zero();
+    const T b = (HAVE_B && anyB && r >= fB && r <= lB) ? pb[r] : Sc<T>::zero();
+    const bool ha = !Sc<T>::is_zero(a), hb = !Sc<T>::is_zero(b);
+    const T wa = Sc<T>::scale(alpha, a), bs = HAVE_B ? Sc<T>::scale(beta, b) : Sc<T>::zero();
+    T o = Sc<T>::zero();
     bool keep = false;
-    if (ha && hb) { o = __dadd_rn(wa, bs); keep = fabs(o) > thr; }
-    else if (ha) { o = wa; keep = (r > bmax) ? true : (fabs(wa) > thr); }
-    else if (hb) { o = bs; keep = (r > amax) ? true : (fabs(bs) > thr); }
-    dst[r] = keep ? o : 0.0;
-    zk |= (keep && o == 0.0) ? 1 : 0;
+    if (ha && hb) { o = Sc<T>::add(wa, bs); keep = Sc<T>::mag(o) > thr; }
+    else if (ha) { o = wa; keep = (r > bmax) ? true : (Sc<T>::mag(wa) > thr); }
+    else if (hb) { o = bs; keep = (r > amax) ? true : (Sc<T>::mag(bs) > thr); }
+    dst[r] = keep ? o : Sc<T>::zero();
+    zk |= (keep && Sc<T>::is_zero(o)) ? 1 : 0;
     cnt += keep ? 1 : 0;
     kf = min(kf, keep ? r : INT_MAX);
     kl = max(kl, keep ? r : -1);
@@ -5912,8 +5918,9 @@ __global__ __launch_bounds__(256) void k_sa_dot(int n, const int32_t* __restrict
   if (lane == 0) { part[2 * (size_t)j] = s; part[2 * (size_t)j + 1] = 0.0; }
 }
 // mode 0: out0[j] = sum |v| of column j; mode 1: (diagonal - sum |off-diagonal|, diagonal + sum |off-diagonal|)
+template <typename T>
 __global__ __launch_bounds__(256) void k_sa_colstat(int n, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
-                                                    const int64_t* __restrict__ off, const double* __restrict__ val, int col_offset,
+                                                    const int64_t* __restrict__ off, const T* __restrict__ val, int col_offset,
                                                     int mode, double* __restrict__ out0, double* __restrict__ out1) {
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   if (j >= n) return;
@@ -5921,11 +5928,11 @@ __global__ __launch_bounds__(256) void k_sa_colstat(int n, const int32_t* __rest
   const int f = first[j], l = last[j];
   double r = 0.0, d = 0.0;
   if (l >= f) {
-    const double* __restrict__ p = val + (off[j] - f);
+    const T* __restrict__ p = val + (off[j] - f);
     for (int i = f + lane; i <= l; i += WAVE) {
-      const double v = p[i];
-      if (mode == 1 && i == j + col_offset) d = __dadd_rn(d, v);
-      else r = __dadd_rn(r, fabs(v));
+      const T v = p[i];
+      if (mode == 1 && i == j + col_offset) d = __dadd_rn(d, Sc<T>::re(v));   // (GershgorinBounds.f90: the real part of the diagonal)
+      else r = __dadd_rn(r, Sc<T>::mag(v));
     }
   }
   r = wave_sum_f64(r);
@@ -5935,14 +5942,15 @@ __global__ __launch_bounds__(256) void k_sa_colstat(int n, const int32_t* __rest
     else { out0[j] = d - r; out1[j] = d + r; }
   }
 }
+template <typename T>
 __global__ __launch_bounds__(256) void k_sa_scale(int n, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
-                                                  const int64_t* __restrict__ off, double* __restrict__ val, double c) {
+                                                  const int64_t* __restrict__ off, T* __restrict__ val, double c) {
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   if (j >= n) return;
   const int f = first[j], l = last[j];
   if (l < f) return;
-  double* __restrict__ p = val + (off[j] - f);
-  for (int i = f + lane_id(); i <= l; i += WAVE) p[i] = __dmul_rn(c, p[i]);
+  T* __restrict__ p = val + (off[j] - f);
+  for (int i = f + lane_id(); i <= l; i += WAVE) p[i] = Sc<T>::scale(c, p[i]);
 }
 // sum of the entry counts of the columns (integers: any order gives the same total); out zeroed by the caller
 __global__ __launch_bounds__(256) void k_sa_sum_i32(const int32_t* __restrict__ v, int n, long long* __restrict__ out) {
@@ -6020,6 +6028,7 @@ bool slab_enter(DevMat& M) {
 // B <- alpha A + beta B (A == nullptr... see slab_clone); false: refused, B unchanged
 static bool sa_axpby_impl(const DevMat* A, const DevMat& Bin, DevMat& Out, double alpha, double beta, double thr) {
   const DevMat& X = A ? *A : Bin;   // (clone: the one operand plays A)
+  const bool cplx = X.cplx;         // (complex sessions: runs of (re, im) pairs, offsets in elements)
   const bool have_b = A != nullptr;
   const SlabForm& fa = *X.slab;
   const SlabForm* fb = have_b ? Bin.slab.get() : nullptr;
@@ -6036,13 +6045,25 @@ static bool sa_axpby_impl(const DevMat* A, const DevMat& Bin, DevMat& Out, doubl
   hipLaunchKernelGGL(k_sa_span, dim3(cdiv(n, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, have_b ? fb->first.p : nullptr,
                      have_b ? fb->last.p : nullptr, n, al, span.p);
   scan_async<int32_t>(span.p, base.p, (int64_t)n);
-  fo->val.alloc((size_t)bound + kIndexSlack);
-  if (have_b)
-    hipLaunchKernelGGL((k_sa_axpby<true>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
+  fo->val.alloc(((size_t)bound + kIndexSlack) * (cplx ? 2 : 1));
+  if (cplx) {
+    const double2* va = reinterpret_cast<const double2*>(fa.val.p);
+    const double2* vb = have_b ? reinterpret_cast<const double2*>(fb->val.p) : nullptr;
+    double2* vo = reinterpret_cast<double2*>(fo->val.p);
+    if (have_b)
+      hipLaunchKernelGGL((k_sa_axpby<double2, true>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
+                         va, fb->first.p, fb->last.p, fb->off.p, vb, base.p, al, alpha, beta, thr, vo, fo->first.p, fo->last.p, fo->count.p,
+                         fo->off.p, stat.p, bound);
+    else
+      hipLaunchKernelGGL((k_sa_axpby<double2, false>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
+                         va, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int64_t*)nullptr, (const double2*)nullptr, base.p, al, 1.0, 0.0,
+                         0.0, vo, fo->first.p, fo->last.p, fo->count.p, fo->off.p, stat.p, bound);
+  } else if (have_b)
+    hipLaunchKernelGGL((k_sa_axpby<double, true>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
                        fa.val.p, fb->first.p, fb->last.p, fb->off.p, fb->val.p, base.p, al, alpha, beta, thr, fo->val.p, fo->first.p,
                        fo->last.p, fo->count.p, fo->off.p, stat.p, bound);
   else
-    hipLaunchKernelGGL((k_sa_axpby<false>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
+    hipLaunchKernelGGL((k_sa_axpby<double, false>), dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), n, fa.first.p, fa.last.p, fa.off.p,
                        fa.val.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int64_t*)nullptr, (const double*)nullptr,
                        base.p, al, 1.0, 0.0, 0.0, fo->val.p, fo->first.p, fo->last.p, fo->count.p, fo->off.p, stat.p, bound);
   DevBuf<long long> tot;
@@ -6060,7 +6081,7 @@ static bool sa_axpby_impl(const DevMat* A, const DevMat& Bin, DevMat& Out, doubl
   fo->row_pad = al;
   fo->slots = slots;
   DevMat R;
-  R.rows = X.rows; R.cols = n; R.cplx = false; R.nnz = nnz; R.zero_free = 1;
+  R.rows = X.rows; R.cols = n; R.cplx = cplx; R.nnz = nnz; R.zero_free = 1;
   R.slab = std::move(fo);
   Out = std::move(R);
   return true;
@@ -6096,7 +6117,7 @@ bool slab_scale(DevMat& A, double c) {
   if (!sa_operand(A) || c == 0.0 || A.slab->origin) return false;
   value_epoch() += 1;
   SlabForm& f = *A.slab;
-  hipLaunchKernelGGL(k_sa_scale, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
+  hipLaunchKernelGGL(k_sa_scale<double>, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
                      f.val.p, c);
   f.tiles.release();       // (the multiplier tiles are rebuilt from the runs when the matrix is next a right operand)
   f.tile_off.release();
@@ -6124,7 +6145,7 @@ bool slab_norm(const DevMat& A, double* out) {
   if (!sa_operand(A)) return false;
   const SlabForm& f = *A.slab;
   DevBuf<double> cs((size_t)A.cols);
-  hipLaunchKernelGGL(k_sa_colstat, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
+  hipLaunchKernelGGL(k_sa_colstat<double>, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
                      f.val.p, 0, 0, cs.p, (double*)nullptr);
   *out = max_of(cs, (size_t)A.cols);
   return true;
@@ -6134,7 +6155,7 @@ bool slab_gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx
   if (!sa_operand(A)) return false;
   const SlabForm& f = *A.slab;
   DevBuf<double> lo((size_t)A.cols), hi((size_t)A.cols), res(2);
-  hipLaunchKernelGGL(k_sa_colstat, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
+  hipLaunchKernelGGL(k_sa_colstat<double>, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
                      f.val.p, col_offset, 1, lo.p, hi.p);
   launch_reduce_minmax(lo.p, hi.p, (int64_t)A.cols, res.p);
   double h[2];
@@ -6631,6 +6652,49 @@ bool slab_multiply_c(const DevMat& A, const DevMat& B, DevMat& C, double alpha, 
   R.rows = A.rows; R.cols = n; R.cplx = true; R.nnz = nnz; R.zero_free = 1;
   R.slab = std::move(fo);
   C = std::move(R);
+  return true;
+}
+
+
+// ---- the rest of the loops' vocabulary on complex matrices in slab form (complex sessions of the inverse, square-root and
+// inverse-square-root loops: InverseSolversModule.F90:29-149, SquareRootSolversModule.F90:342-531): merge by the
+// AddSparseVectors rules with the threshold on the modulus, copy, scaling by a real constant, the largest column sum of moduli
+bool slab_axpby_c(const DevMat& A, DevMat& B, double alpha, double beta, double threshold) {
+  if (!sa_operand_c(A) || !sa_operand_c(B) || A.cols != B.cols || &A == &B) return false;
+  if (alpha == 0.0 || beta == 0.0 || A.zero_free != 1 || B.zero_free != 1) return false;
+  DevMat R;
+  if (!sa_axpby_impl(&A, B, R, alpha, beta, threshold)) return false;
+  value_epoch() += 1;
+  B = std::move(R);
+  return true;
+}
+bool slab_axpby_to_c(const DevMat& A, const DevMat& B, DevMat& Out, double alpha, double beta, double threshold) {
+  if (!sa_operand_c(A) || !sa_operand_c(B) || A.cols != B.cols || &A == &B) return false;
+  if (alpha == 0.0 || beta == 0.0 || A.zero_free != 1 || B.zero_free != 1) return false;
+  DevMat R;
+  if (!sa_axpby_impl(&A, B, R, alpha, beta, threshold)) return false;
+  Out = std::move(R);
+  return true;
+}
+bool slab_clone_c(const DevMat& A, DevMat& Out) {
+  if (!sa_operand_c(A) || A.zero_free != 1) return false;
+  return sa_axpby_impl(nullptr, A, Out, 1.0, 0.0, 0.0);
+}
+bool slab_scale_c(DevMat& A, double c) {
+  if (!sa_operand_c(A) || c == 0.0) return false;
+  value_epoch() += 1;
+  SlabForm& f = *A.slab;
+  hipLaunchKernelGGL(k_sa_scale<double2>, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
+                     reinterpret_cast<double2*>(f.val.p), c);
+  return true;
+}
+bool slab_norm_c(const DevMat& A, double* out) {
+  if (!sa_operand_c(A)) return false;
+  const SlabForm& f = *A.slab;
+  DevBuf<double> cs((size_t)A.cols);
+  hipLaunchKernelGGL(k_sa_colstat<double2>, dim3(cdiv((int64_t)A.cols * WAVE, 256)), dim3(256), 0, stream(), A.cols, f.first.p, f.last.p, f.off.p,
+                     reinterpret_cast<const double2*>(f.val.p), 0, 0, cs.p, (double*)nullptr);
+  *out = max_of(cs, (size_t)A.cols);
   return true;
 }
 

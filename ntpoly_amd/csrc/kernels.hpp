@@ -1,6 +1,7 @@
 // Launchers of the hand-written gfx950 kernels (kernels.hip).  Everything operates on
 // device-resident column-compressed matrices (DevMat) on ctx().stream.
 #pragma once
+#include <functional>
 #include "common.hpp"
 
 namespace ntp {
@@ -79,6 +80,7 @@ struct EngineOptions {
                                // are (the shape only selects the summation semantics of the multiply: slices > 1)
   int fused_update = 1;        // TRS2 on one rank, real operands: the update X <- 2X - X*X (or X*X), its energy and its trace
                                // come out of the epilogue of the register-slab kernel; 0: separate merge / reduction passes
+  int exchange_ahead = 1;      // panel steps across ranks: a step prepares the NEXT step's exchange (extents all-gathered, counts, plan) from its result and reads it back with its own totals -- one host round trip per panel step (psmatrix.cpp PanelExchange); 0: two
   int band_scope = 1;          // solvers on SEVERAL ranks: an operand without run structure is searched for a hidden band once per solve, the operands are redistributed in the recovered order, the results carried back (band_scope.cpp)
   int label_order = 1;         // TRS2 on one rank: an operand without run structure is searched for a hidden band (relabel.hip)
                                // and, if there is one, the loop runs in that order with label-ordered arithmetic; 0: never
@@ -180,6 +182,10 @@ struct SlabHalo {   // A side of a panel step: the columns ka .. kb (global numb
   const int32_t* count = nullptr;            // [kb - ka] device, optional (statistics): entries of the column
   int row_pad = 1;                           // the received runs sit in slots aligned to this many rows, zero padded (SlabForm::row_pad)
   SlabReduce* reduce = nullptr;
+  // optional: called once the step's kernel, totals and reduction are enqueued, BEFORE their read-back, with the result as
+  // it stands on the device (slab form; its entry count still on the device: d_nnz) -- what the caller enqueues and adds to
+  // the fetch rides on the step's own host round trip (psmatrix.cpp: the NEXT step's exchange layout and plan)
+  std::function<void(const DevMat& result, const long long* d_nnz, ScalarFetch& fetch)> before_fetch;
   // optional: the plan of this step, made by the caller from the all-gathered extents and read back together with the
   // exchange layout (slab_plan_panel_async) -- the step then launches without a read-back of its own (and may keep
   // the plan's buffers for its result)
@@ -195,7 +201,7 @@ bool slab_step(DevMat& X, SlabFusion& fuse, double threshold, bool dense_rule, c
 // halo exchange of a panel in slab form (psmatrix.cpp ps_slab_step_dist): request record (first row, last row, nnz, nnz),
 // packed extents (first | last << 32) + prefix of the spans, runs of the local columns [ja, jb) packed back to back, and
 // the layout of the columns a rank needs (extents, run addresses in its own buffer or in the receive buffer)
-void slab_request_async(const DevMat& X, int64_t* d_out4);
+void slab_request_async(const DevMat& X, int64_t* d_out4, const long long* d_nnz = nullptr);   // (d_nnz: the entry count is still on the device)
 void slab_extents_async(const DevMat& X, int64_t* d_ext, int64_t* d_pre);
 void slab_pack_runs_async(const DevMat& X, const int64_t* d_pre, int32_t ja, int32_t jb, double* dst);
 void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, int pitch, int32_t dim, int P, int me,
@@ -222,6 +228,12 @@ bool slab_clone(const DevMat& A, DevMat& Out);
 bool slab_scale(DevMat& A, double c);
 bool slab_dot(const DevMat& A, const DevMat& B, double out[2]);
 bool slab_norm(const DevMat& A, double* out);   // max column abs-sum
+// the same on complex matrices in slab form (complex sessions)
+bool slab_axpby_c(const DevMat& A, DevMat& B, double alpha, double beta, double threshold);
+bool slab_axpby_to_c(const DevMat& A, const DevMat& B, DevMat& Out, double alpha, double beta, double threshold);
+bool slab_clone_c(const DevMat& A, DevMat& Out);
+bool slab_scale_c(DevMat& A, double c);
+bool slab_norm_c(const DevMat& A, double* out);
 bool slab_gershgorin(const DevMat& A, int32_t col_offset, double* mn, double* mx);
 bool slab_add_diagonal(DevMat& B, double alpha, int32_t col_offset);   // B <- B + alpha I in place (slab_extra.hip); false: not done
 // TRS4's polynomial chain on slab-form X and X2 (slab_extra.hip): dot(X2, 4X - 3X2), dot(X2, I - 2X + X2); then the right

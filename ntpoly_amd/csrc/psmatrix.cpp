@@ -192,6 +192,15 @@ void ps_copy(const PSMatrix& a, PSMatrix& b) {
     g_block_counts[1] += 1;
   }
   unblock({&a});
+  if (slab_on() && g_complex_session && a.cplx && a.loc.expanded()) {   // (a session that takes complex operands)
+    DevMat t;
+    if (slab_clone_c(a.loc, t)) {
+      g_slab_counts[1] += 1;
+      b.grid = a.grid; b.dim = a.dim; b.cplx = true; b.c0 = a.c0; b.c1 = a.c1;
+      b.loc = std::move(t);
+      return;
+    }
+  }
   if (slab_on() && a.loc.expanded()) {
     DevMat t;
     if (slab_clone(a.loc, t)) {
@@ -653,6 +662,7 @@ void ps_scale(PSMatrix& A, double c) {
     g_block_counts[1] += 1;
   }
   unblock({&A});
+  if (slab_on() && g_complex_session && A.cplx && A.loc.expanded() && slab_scale_c(A.loc, c)) { g_slab_counts[2] += 1; return; }
   if (slab_on() && A.loc.expanded()) {
     if (slab_scale(A.loc, c)) { g_slab_counts[2] += 1; return; }
     slab_refused({&A});
@@ -669,7 +679,11 @@ void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double 
     g_block_counts[1] += 1;
   }
   unblock({&A, &B});
-  if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B) {
+  if (slab_on() && g_complex_session && (A.loc.expanded() || B.loc.expanded()) && A.cplx && B.cplx && &A != &B) {
+    // (a session that takes complex operands: the merge on runs of (re, im) pairs)
+    if (slab_enter_c(mut(A)) && slab_enter_c(B.loc) && slab_axpby_c(A.loc, B.loc, alpha, beta, threshold)) { g_slab_counts[1] += 1; return; }
+    slab_refused({&A, &B});
+  } else if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B) {
     // (a slab session: the operand still in compressed columns -- an identity, the Hamiltonian -- is turned into slab form)
     if (slab_enter(mut(A)) && slab_enter(B.loc) && slab_axpby(A.loc, B.loc, alpha, beta, threshold)) { g_slab_counts[1] += 1; return; }
     slab_refused({&A, &B});
@@ -757,7 +771,17 @@ void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double a
     return;
   }
   unblock({&A, &B});
-  if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B && A.dim == B.dim) {
+  if (slab_on() && g_complex_session && (A.loc.expanded() || B.loc.expanded()) && A.cplx && B.cplx && &A != &B && &Out != &A && &Out != &B &&
+      A.dim == B.dim) {
+    DevMat R;
+    if (slab_enter_c(mut(A)) && slab_enter_c(mut(B)) && slab_axpby_to_c(A.loc, B.loc, R, alpha, beta, threshold)) {
+      g_slab_counts[1] += 1;
+      Out.grid = B.grid; Out.dim = B.dim; Out.cplx = true; Out.c0 = B.c0; Out.c1 = B.c1;
+      Out.loc = std::move(R);
+      return;
+    }
+    slab_refused({&A, &B});
+  } else if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B && A.dim == B.dim) {
     DevMat R;
     if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_axpby_to(A.loc, B.loc, R, alpha, beta, threshold)) {
       g_slab_counts[1] += 1;
@@ -797,12 +821,29 @@ namespace {
 // Returns this rank's success; the result is in fu.result (the caller installs it when all ranks succeeded).
 void dev_allreduce4(double* d) { world().tr->allreduce(d, 4, true, 0); }
 
-bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabReduce& red) {
-  const long long syncs_before = host_sync_count();
-  Comm& c = world();
-  Transport& tr = *c.tr;
-  const int P = c.nranks, me = c.rank;
-  const int32_t dim = B.dim;
+// What a panel step must know before its halo can travel -- every rank's request, the column extents of the whole iterate,
+// who sends how much to whom, the step's plan -- is a function of the iterate's column extents alone.  It is PREPARED on the
+// device (one all-gather, three small kernels) and read back in one round trip: at the start of a step, or -- for every step
+// after the first -- by the step BEFORE it, from its result's extents, on that step's own read-back (SlabHalo::before_fetch):
+// a panel step then costs ONE host round trip, as a step on one rank does.
+struct PanelExchange {
+  int P = 0, me = 0, pitch = 0, wcols = 0, snb = 0;
+  int32_t dim = 0;
+  bool with_counts = false;
+  DevBuf<int64_t> d_all, d_req, d_bound, d_cnt, plan_stats;
+  SlabPlan plan;
+  DevBuf<int32_t> gfirst, glast;
+  std::vector<int64_t> req, bound, cnt;
+  unsigned long long plan_hs[2] = {0, 0};
+  const void* owner = nullptr;   // the value buffer of the iterate (in slab form) it was prepared for
+  const int64_t* d_ext_all() const { return d_all.p + 4; }
+  const int64_t* d_pre_all() const { return d_all.p + 4 + wcols; }
+  const int64_t* d_cnt_all() const { return with_counts ? d_all.p + 4 + 2 * (size_t)wcols : nullptr; }
+};
+std::unique_ptr<PanelExchange> g_pending_exchange;
+long long g_exchange_prefetched = 0;   // panel steps whose exchange layout came with the step before
+
+int panel_pitch(int32_t dim, int P, bool with_counts, int* wcols_out) {
   int32_t maxw = 0;
   for (int q = 0; q < P; ++q) {
     int32_t a0, a1;
@@ -812,48 +853,88 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   // ONE all-gather per step: every rank contributes a record of `pitch` 8-byte words -- its request (4 words), the
   // packed extents of its columns, the prefix sums of their spans and, for the statistics (timers on), their entry
   // counts; the kernels below read the sections through the common stride
-  const int wcols = maxw + 1;
-  const bool with_counts = options().time_kernels != 0;
-  const int pitch = 4 + (with_counts ? 3 : 2) * wcols;
-  std::vector<int64_t> req((size_t)4 * P, 0), bound((size_t)2 * P, 0), cnt((size_t)P * P, 0);
-  DevBuf<int64_t> d_all((size_t)P * pitch), d_req((size_t)4 * P), d_bound((size_t)2 * P), d_cnt((size_t)P * P);
-  int64_t* mine = d_all.p + (size_t)me * pitch;
-  const int64_t *d_ext_all = d_all.p + 4, *d_pre_all = d_all.p + 4 + wcols;
-  const int64_t* d_cnt_all = with_counts ? d_all.p + 4 + 2 * (size_t)wcols : nullptr;
-  slab_request_async(B.loc, mine);
-  slab_extents_async(B.loc, mine + 4, mine + 4 + wcols);
-  if (with_counts) slab_counts_async(B.loc, mine + 4 + 2 * (size_t)wcols);
-  tr.allgather(mine, d_all.p, (size_t)pitch * sizeof(int64_t));
-  HIP_CHECK(hipMemcpy2DAsync(d_req.p, 4 * sizeof(int64_t), d_all.p, (size_t)pitch * sizeof(int64_t), 4 * sizeof(int64_t), (size_t)P,
+  *wcols_out = maxw + 1;
+  return 4 + (with_counts ? 3 : 2) * (maxw + 1);
+}
+// enqueues the preparation for the panel Xl (slab form) and adds what the host needs of it to the fetch (collective)
+void exchange_prepare(const DevMat& Xl, int32_t dim, const long long* d_nnz, PanelExchange& pe, ScalarFetch& f) {
+  Comm& c = world();
+  Transport& tr = *c.tr;
+  pe.P = c.nranks;
+  pe.me = c.rank;
+  pe.dim = dim;
+  pe.with_counts = options().time_kernels != 0;
+  pe.pitch = panel_pitch(dim, pe.P, pe.with_counts, &pe.wcols);
+  pe.snb = (Xl.cols + 15) / 16;
+  const int P = pe.P;
+  pe.req.assign((size_t)4 * P, 0);
+  pe.bound.assign((size_t)2 * P, 0);
+  pe.cnt.assign((size_t)P * P, 0);
+  pe.d_all.alloc((size_t)P * pe.pitch);
+  pe.d_req.alloc((size_t)4 * P);
+  pe.d_bound.alloc((size_t)2 * P);
+  pe.d_cnt.alloc((size_t)P * P);
+  int64_t* mine = pe.d_all.p + (size_t)pe.me * pe.pitch;
+  slab_request_async(Xl, mine, d_nnz);
+  slab_extents_async(Xl, mine + 4, mine + 4 + pe.wcols);
+  if (pe.with_counts) slab_counts_async(Xl, mine + 4 + 2 * (size_t)pe.wcols);
+  tr.allgather(mine, pe.d_all.p, (size_t)pe.pitch * sizeof(int64_t));
+  HIP_CHECK(hipMemcpy2DAsync(pe.d_req.p, 4 * sizeof(int64_t), pe.d_all.p, (size_t)pe.pitch * sizeof(int64_t), 4 * sizeof(int64_t), (size_t)P,
                              hipMemcpyDeviceToDevice, stream()));
-  halo_counts_async(d_req.p, d_pre_all, pitch, dim, P, me, d_cnt.p, d_bound.p);   // (counts in doubles here)
+  halo_counts_async(pe.d_req.p, pe.d_pre_all(), pe.pitch, dim, P, pe.me, pe.d_cnt.p, pe.d_bound.p);   // (counts in doubles here)
   // the step's plan (block windows and k ranges follow from the extents alone) is made here, from the gathered
   // extents, so that its sizes come back in the same read-back as the exchange layout
-  SlabPlan plan;
-  DevBuf<int32_t> gfirst, glast;
-  DevBuf<int64_t> plan_stats(24);
-  plan_stats.zero();
-  unsigned long long plan_hs[2] = {0, 0};
-  const int snb = (B.loc.cols + 15) / 16;
-  slab_plan_panel_async(B.loc, d_ext_all, pitch, dim, P, plan, gfirst, glast, reinterpret_cast<unsigned long long*>(plan_stats.p));
-  if ((size_t)4 * P + (size_t)P * P + 2 * P <= 500) {
-    ScalarFetch f;
-    f.add(d_req.p, 4 * P, req.data());
-    f.add(d_bound.p, 2 * P, bound.data());
-    f.add(d_cnt.p, P * P, cnt.data());
-    f.add(plan.blk_toff.p + snb, 1, &plan.total);
-    f.add(plan_stats.p + 16, 2, plan_hs);
-    f.run();
+  pe.plan_stats.alloc(24);
+  pe.plan_stats.zero();
+  slab_plan_panel_async(Xl, pe.d_ext_all(), pe.pitch, dim, P, pe.plan, pe.gfirst, pe.glast, reinterpret_cast<unsigned long long*>(pe.plan_stats.p));
+  f.add(pe.d_req.p, 4 * P, pe.req.data());
+  f.add(pe.d_bound.p, 2 * P, pe.bound.data());
+  f.add(pe.d_cnt.p, P * P, pe.cnt.data());
+  f.add(pe.plan.blk_toff.p + pe.snb, 1, &pe.plan.total);
+  f.add(pe.plan_stats.p + 16, 2, pe.plan_hs);
+  pe.owner = Xl.slab->val.p;
+}
+bool exchange_fits_fetch(int P) { return (size_t)4 * P + (size_t)P * P + 2 * P <= 400; }
+
+bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabReduce& red, bool* owed_prefetch) {
+  const long long syncs_before = host_sync_count();
+  Comm& c = world();
+  Transport& tr = *c.tr;
+  const int P = c.nranks, me = c.rank;
+  const int32_t dim = B.dim;
+  const bool with_counts = options().time_kernels != 0;
+  const bool ahead = options().exchange_ahead != 0 && exchange_fits_fetch(P);
+  // the preparation: left behind by the step that produced this iterate, or made (and read back) here
+  std::unique_ptr<PanelExchange> pe;
+  if (g_pending_exchange && g_pending_exchange->owner == B.loc.slab->val.p && g_pending_exchange->dim == dim && g_pending_exchange->P == P &&
+      g_pending_exchange->with_counts == with_counts) {
+    pe = std::move(g_pending_exchange);
+    g_exchange_prefetched += 1;
   } else {
-    HIP_CHECK(hipMemcpyAsync(req.data(), d_req.p, (size_t)4 * P * 8, hipMemcpyDeviceToHost, stream()));
-    HIP_CHECK(hipMemcpyAsync(bound.data(), d_bound.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, stream()));
-    HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, stream()));
-    HIP_CHECK(hipMemcpyAsync(&plan.total, plan.blk_toff.p + snb, 8, hipMemcpyDeviceToHost, stream()));
-    HIP_CHECK(hipMemcpyAsync(plan_hs, plan_stats.p + 16, 16, hipMemcpyDeviceToHost, stream()));
-    sync_stream();
+    g_pending_exchange.reset();
+    pe.reset(new PanelExchange());
+    if (exchange_fits_fetch(P)) {
+      ScalarFetch f;
+      exchange_prepare(B.loc, dim, nullptr, *pe, f);
+      f.run();
+    } else {
+      ScalarFetch f;   // (too many ranks for one fetch: plain copies)
+      exchange_prepare(B.loc, dim, nullptr, *pe, f);
+      f.n = 0;
+      HIP_CHECK(hipMemcpyAsync(pe->req.data(), pe->d_req.p, (size_t)4 * P * 8, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipMemcpyAsync(pe->bound.data(), pe->d_bound.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipMemcpyAsync(pe->cnt.data(), pe->d_cnt.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipMemcpyAsync(&pe->plan.total, pe->plan.blk_toff.p + pe->snb, 8, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipMemcpyAsync(pe->plan_hs, pe->plan_stats.p + 16, 16, hipMemcpyDeviceToHost, stream()));
+      sync_stream();
+    }
   }
-  plan.max_w = (int)plan_hs[0];
-  plan.max_kn = (int)plan_hs[1];
+  const int pitch = pe->pitch;
+  std::vector<int64_t>&req = pe->req, &cnt = pe->cnt;
+  const int64_t *d_ext_all = pe->d_ext_all(), *d_pre_all = pe->d_pre_all(), *d_cnt_all = pe->d_cnt_all();
+  SlabPlan& plan = pe->plan;
+  plan.max_w = (int)pe->plan_hs[0];
+  plan.max_kn = (int)pe->plan_hs[1];
   exchange_stats().host_syncs += host_sync_count() - syncs_before;   // (the exchange's own: measured in sync_stream)
   exchange_stats().exchanges += 1;
   int64_t nnz_global = 0;
@@ -891,7 +972,10 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
     if (s != me && m > 0) tr.recv(recvbuf.p + zoff[(size_t)s], (size_t)m * sizeof(double), s);
   }
   tr.group_end();
-  if (kmax < kmin) return false;   // (an empty panel: nothing to multiply; the caller's consensus takes the other path)
+  if (kmax < kmin) {   // (an empty panel: nothing to multiply; the caller's consensus takes the other path)
+    if (ahead) *owed_prefetch = true;
+    return false;
+  }
   // layout of the columns I need
   const int32_t ka = kmin, kb = kmax + 1;
   DevBuf<int32_t> d_ra((size_t)P), nfirst((size_t)(kb - ka)), nlast((size_t)(kb - ka));
@@ -916,8 +1000,19 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   halo.reduce = &red;
   const double denom = (double)dim * (double)dim;
   const bool dense_rule = denom > 0 && (double)nnz_global / denom > 0.1;
+  // the NEXT step's preparation, from this step's result, on this step's read-back (option exchange_ahead)
+  std::unique_ptr<PanelExchange> next;
+  if (ahead) {
+    halo.before_fetch = [&](const DevMat& R, const long long* d_nnz, ScalarFetch& f) {
+      next.reset(new PanelExchange());
+      exchange_prepare(R, dim, d_nnz, *next, f);
+    };
+  }
   // (the buffers above are released on return: the allocator is stream ordered, and slab_step ends with a read-back)
-  return slab_step(B.loc, fu, threshold, dense_rule, &halo);
+  const bool ok = slab_step(B.loc, fu, threshold, dense_rule, &halo);
+  if (ahead && !next) *owed_prefetch = true;   // (this rank gave up before its kernel: it owes the others the all-gather)
+  if (ok && next) g_pending_exchange = std::move(next);
+  return ok;
 }
 
 // TRS2 step across ranks with the fused kernel (mode 1: X <- X*X, mode 2: X <- 2X - X*X; energy and trace in out).
@@ -935,14 +1030,24 @@ bool dist_fused_step(PSMatrix& B, int mode, double threshold, const PSMatrix& D,
   fu.col_offset = B.c0;
   fu.panel_c0 = B.c0;
   SlabReduce red;
-  const bool ok = slab_exchange_and_step(B, fu, threshold, red);
+  bool owed_prefetch = false;
+  const bool ok = slab_exchange_and_step(B, fu, threshold, red, &owed_prefetch);
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   if (red.done) {   // the sums came back with the step's totals
     for (int q = 0; q < 4; ++q) v[q] = red.reduced[q];
   } else {          // this rank gave up before its kernel: it still owes the other ranks the collective
     comm_allreduce_sum(v, 4);
   }
+  if (owed_prefetch && !red.done) {   // ... and the all-gather of the next step's preparation, which the others will discard
+    int wcols = 0;
+    const int pitch = panel_pitch(B.dim, P, options().time_kernels != 0, &wcols);
+    DevBuf<int64_t> dummy((size_t)P * pitch);
+    dummy.zero();
+    world().tr->allgather(dummy.p + (size_t)world().rank * pitch, dummy.p, (size_t)pitch * sizeof(int64_t));
+    sync_stream();
+  }
   (void)ok;
+  if (v[3] != (double)P) g_pending_exchange.reset();
   if (v[3] == (double)P) {
     B.loc = std::move(fu.result);
     out[0] = v[0];
@@ -1237,6 +1342,10 @@ double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns 
     g_block_counts[1] += 1;
   }
   unblock({&A});
+  if (slab_on() && g_complex_session && A.cplx && A.loc.expanded()) {
+    double v = 0.0;
+    if (slab_norm_c(A.loc, &v)) { g_slab_counts[2] += 1; return v; }
+  }
   if (slab_on() && A.loc.expanded()) {
     double v = 0.0;
     if (slab_norm(A.loc, &v)) { g_slab_counts[2] += 1; return v; }

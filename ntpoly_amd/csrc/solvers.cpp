@@ -840,7 +840,9 @@ void invert_core(const PSMatrix& InputMat, PSMatrix& OutputMat, const SolverPara
   }
   double norm_value = p.converge_diff + 1.0;
   int II;
-  SlabSession slab(!Out.cplx);
+  // (complex operands under FMA arithmetic: products, merges, scalings, copies and norms take them in slab form as well)
+  const bool complex_session = Out.cplx && options().complex_sessions != 0 && options().spgemm_fma == 1 && options().complex_tile != 0;
+  SlabSession slab(!Out.cplx || complex_session, false, complex_session);
   for (II = 1; II <= p.max_iterations; ++II) {
     if (log_top && p.be_verbose && II > 1) log_list_element("Convergence", norm_value);
     ps_multiply(Out, Balanced, Temp1, 1.0, 0.0, p.threshold);
@@ -984,7 +986,9 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
     log_enter();
   }
   int II;
-  SlabSession slab(!SR.cplx);
+  // (complex operands under FMA arithmetic: the loop's whole vocabulary takes them in slab form -- SquareRootSolversModule.F90:415-497)
+  const bool complex_session = SR.cplx && options().complex_sessions != 0 && options().spgemm_fma == 1 && options().complex_tile != 0;
+  SlabSession slab(!SR.cplx || complex_session, false, complex_session);
   for (II = 1; II <= p.max_iterations; ++II) {                     // :415-497
     ps_multiply(ISR, SR, X, 1.0, 0.0, p.threshold);
     ps_increment_identity(Identity, X, -1.0);

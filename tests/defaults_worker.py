@@ -75,7 +75,7 @@ def main():
     keep("mcweeny_X", X)
 
     # ---- 3. SignFunction_wrp on a complex Hermitian operand (complex tile kernel, complex session)
-    nc, hc = 4096, 24
+    nc, hc = 2048, 24
     Hc = nt.Matrix_ps.from_triplets(nc, *banded_triplets(nc, hc, complex_=True))
     ps = nt.SolverParameters()
     ps.SetThreshold(1e-8)

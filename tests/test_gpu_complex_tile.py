@@ -161,3 +161,58 @@ def test_complex_sign_session_keeps_the_iterates_in_slab_form(nt, fma):
     Ident.FillIdentity()
     S2.Increment(Ident, -1.0, 0.0)
     assert S2.Norm() <= 1e-5
+
+
+@pytest.mark.parametrize("solver", ["inverse_square_root", "square_root", "invert"])
+def test_complex_sessions_of_the_inverse_and_square_root_loops(nt, fma, solver):
+    """InverseSquareRoot / SquareRoot (order 5: SquareRootSolversModule.F90:342-531) and Invert (InverseSolversModule.F90:29-149)
+    on a complex Hermitian positive definite operand with the loop's matrices kept in the complex tile kernel's operand form
+    between the operations -- products, merges (AddSparseVectors rules, threshold on the modulus), scalings, copies, identity
+    increments, norms on runs of (re, im) pairs -- against the same loop on compressed columns: the same iteration count,
+    convergence values to roundoff, the result within 1e-13 of the largest entry, and F(A) what it should be."""
+    n, h, thr = 8000, 30, 1e-8
+    col, row, val = banded_triplets(n, h, complex_=True, shift=2.5)
+    A = nt.Matrix_ps.from_triplets(n, col, row, val)
+    res = {}
+    for opt in (1, 0):
+        nt.set_option("complex_sessions", opt)
+        try:
+            p = nt.SolverParameters()
+            p.SetThreshold(thr)
+            p.SetConvergeDiff(1e-8)
+            Out = nt.Matrix_ps(n)
+            c0 = nt.slab_algebra_counts()
+            if solver == "inverse_square_root":
+                nt.SquareRootSolvers.InverseSquareRoot(A, Out, p)
+            elif solver == "square_root":
+                nt.SquareRootSolvers.SquareRoot(A, Out, p)
+            else:
+                nt.InverseSolvers.Invert(A, Out, p)
+            c1 = nt.slab_algebra_counts()
+            tr = nt.solver_trace()
+            res[opt] = (srt(Out.triplets()), tr["iterations"], np.asarray(tr["value"]), {k: c1[k] - c0[k] for k in c0}, Out)
+        finally:
+            nt.set_option("complex_sessions", 1)
+    it = res[1][1]
+    assert it == res[0][1] and it >= 3, (res[1][1], res[0][1])
+    on, off = res[1][3], res[0][3]
+    assert off["products"] == 0
+    assert on["products"] >= 2 * (it - 1) and on["merges"] >= it - 1 and on["refusals"] <= 3, on
+    assert np.allclose(res[1][2], res[0][2], rtol=1e-8, atol=1e-12 * n), (res[1][2], res[0][2])
+    close(res[1][0], res[0][0], n, thr, solver + " with / without the complex session")
+    # what it is: Out A Out = I, Out Out = A, Out A = I
+    F = res[1][4]
+    T, U = nt.Matrix_ps(n), nt.Matrix_ps(n)
+    Ident = nt.Matrix_ps(n)
+    Ident.FillIdentity()
+    if solver == "inverse_square_root":
+        T.Gemm(F, A, None, 1.0, 0.0, thr)
+        U.Gemm(T, F, None, 1.0, 0.0, thr)
+        U.Increment(Ident, -1.0, 0.0)
+    elif solver == "square_root":
+        U.Gemm(F, F, None, 1.0, 0.0, thr)
+        U.Increment(A, -1.0, 0.0)
+    else:
+        U.Gemm(F, A, None, 1.0, 0.0, thr)
+        U.Increment(Ident, -1.0, 0.0)
+    assert U.Norm() <= 1e-4, U.Norm()

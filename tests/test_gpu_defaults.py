@@ -89,7 +89,7 @@ def test_callers_loop_on_a_lattice_with_defaults(defaults):
 
 def test_complex_sign_with_defaults_vs_oracle(defaults):
     from oracle import oracle_py as O
-    nc, hc = 4096, 24
+    nc, hc = 2048, 24
     Ho = O.Mat.from_triplets(nc, nc, *banded_triplets(nc, hc, complex_=True))
     po = O.params(converge_diff=1e-6, threshold=1e-8)
     So, tro = O.matrix_function("sign", Ho, po)

@@ -64,7 +64,7 @@ def holes_pair(n, h, holes, seed):
     return mats
 
 
-@pytest.mark.parametrize("rows,waves", [(1, 4), (1, 8), (2, 4), (2, 8), (4, 4), (4, 8)])
+@pytest.mark.parametrize("rows,waves", [(1, 4), (2, 4), (2, 8), (4, 4)])   # (suite budget: the two remaining geometries differ in occupancy only)
 @pytest.mark.parametrize("n,h,holes,thr,alpha", [(4096, 100, 0.0, 1e-8, 1.0), (4099, 140, 0.2, 1e-6, 0.5),
                                                  (3000, 30, 0.5, 0.0, -0.75), (5000, 320, 0.0, 1e-8, 1.0),
                                                  (777, 3, 0.3, 1e-3, 2.0), (6144, 450, 0.05, 1e-7, 1.0)])

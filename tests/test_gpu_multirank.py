@@ -86,13 +86,14 @@ def test_multirank_equals_single_rank(world, arith, references, tmp_path):
         sq, up, rep = parts[r]["trs2_fused"]
         iters = int(parts[r]["trs2_iters"])
         assert rep == 0 and iters - 1 <= sq + up <= iters, (world, r, sq, up, rep, iters)
-        # host synchronisations MEASURED (counter in sync_stream): ONE inside every exchange -- its layout and the
-        # step's plan come back together -- and over the whole solve two per panel step (exchange + plan, totals;
-        # DESIGN.md section 5) plus what the solver does around its loop (bounds, the first step from compressed columns,
-        # the chemical potential)
+        # host synchronisations MEASURED (counter in sync_stream): a panel step costs ONE -- the layout of its exchange and its
+        # plan were prepared by the step before it, from that step's result, and came back on that step's read-back of its
+        # totals (psmatrix.cpp PanelExchange, option exchange_ahead); only the first exchanges of the solve wait for their own
+        # layout.  Over the whole solve: one per panel step plus what the solver does around its loop (bounds, the first step
+        # from compressed columns, the chemical potential)
         ex, ex_syncs, syncs = parts[r]["trs2_exchanges"]
         print("world", world, "rank", r, "exchanges", ex, "syncs inside", ex_syncs, "syncs of the solve", syncs)
-        assert ex >= iters and ex_syncs == ex and 2 * ex <= syncs <= 2 * ex + 30, (world, r, ex, ex_syncs, syncs)
+        assert ex >= iters and ex_syncs <= 3 and ex <= syncs <= ex + 35, (world, r, ex, ex_syncs, syncs)
     # ... and counted the same intermediate products and product entries as the one-rank solve
     assert sum(int(parts[r]["trs2_products"]) for r in range(world)) == int(reference["trs2_products"])
     assert sum(int(parts[r]["trs2_nnz_c"]) for r in range(world)) == int(reference["trs2_nnz_c"])

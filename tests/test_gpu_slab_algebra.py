@@ -82,8 +82,17 @@ CASES = [("trs4", 4096, 20, 1e-8, 0.0), ("trs4", 3000, 12, 1e-6, 0.0), ("sign", 
          ("invert", 4096, 20, 1e-8, 2.0), ("inverse_square_root", 4096, 20, 1e-8, 2.0), ("square_root", 3000, 12, 1e-7, 2.0)]
 
 
+# (suite budget: every loop in FMA arithmetic -- the default, where the counts are exact; the unfused mode on one case of each
+# loop family whose merges differ: TRS4 and the inverse square root)
+UNFUSED_CASES = {("trs4", 4096), ("inverse_square_root", 4096), ("sign", 4096)}
+
+
 @pytest.mark.parametrize("solver,n,h,thr,shift", CASES)
 def test_slab_session_equals_compressed_columns_and_oracle(nt, fma, solver, n, h, thr, shift):
+    if not nt.slab_counts_exact and (solver, n) not in UNFUSED_CASES:
+        pytest.skip("unfused arithmetic: covered by the other cases of this loop family (suite budget)")
+    if nt.slab_counts_exact and (solver, n) == ("sign", 2048):
+        pytest.skip("FMA arithmetic: the larger SignFunction case covers it (suite budget)")
     O = fma
     col, row, val = banded_triplets(n, h, shift=shift)
     H = nt.Matrix_ps.from_triplets(n, col, row, val)
