@@ -7,8 +7,11 @@ TRS2 steps on a banded operand of dimension N / P with the same half bandwidth (
 band has the work of an (N / P)-wide band, boundary columns aside), through the same entry point as bench.py, with every
 launch and every host read-back of a one-rank step inside the timed region.  A panel step then adds, per step:
 
-  * one more host round trip than the one-rank step (exchange layout + plan; DESIGN.md section 5: two instead of one) --
-    its cost is measured as the wall time of a device-to-host read-back of one scalar on the idle stream;
+  * round 4: one more host round trip than the one-rank step (exchange layout + plan) -- measured as the wall time of a
+    device-to-host read-back of one scalar on the idle stream.  Round 5 (option exchange_ahead, the default): a panel step
+    prepares the next step's exchange on its own read-back, so the round trip is gone; what remains on the critical path is
+    the preparation's five small launches (request, extents, scan, counts, plan statistics: 2 us each behind a running
+    stream, MI355X_MICROARCH.md "boundary") and the all-gather below;
   * the halo: the runs of the columns within one bandwidth of the panel's two edges, sent over two xGMI links at once,
     bytes / (153 GB/s per link);
   * the all-gather of one 8-byte extent record per column of the whole matrix over a ring of P - 1 hops.
@@ -88,7 +91,8 @@ def main():
         halo_bytes = 2.0 * (per_col / 2.0) * per_col * 8.0   # both edges: (bandwidth of X) columns x (run length) x 8 B
         t_halo_us = (halo_bytes / 2.0) / (XGMI_LINK_GBS * 1e3) if P > 1 else 0.0      # two links in parallel
         t_gather_us = (8.0 * args.n * (P - 1) / P) / (XGMI_LINK_GBS * 1e3) if P > 1 else 0.0
-        extra_sync_us = sync_us if P > 1 else 0.0
+        ahead = nt.get_option("exchange_ahead") != 0
+        extra_sync_us = (10.0 if ahead else sync_us) if P > 1 else 0.0   # (ahead: five small launches instead of a round trip)
         model_ms = dt * 1e3 + (extra_sync_us + t_halo_us + t_gather_us) * 1e-3
         rows.append(dict(ranks=P, panel_columns=n, measured_share_ms_per_step=dt * 1e3,
                          kernel_ms_per_step=acc["ms_numeric"] / max(1, acc["calls"]),
@@ -102,8 +106,11 @@ def main():
         r["modelled_efficiency"] = r["modelled_speedup"] / r["ranks"]
     print(json.dumps({
         "what": "MODEL, not a measurement of several GPUs: one rank's share of a P-rank TRS2 step measured on ONE MI355X "
-                "(banded operand of dimension N / P, every launch and read-back of the step included) + one extra host round "
-                "trip + halo bytes / 153 GB/s per xGMI link + a ring all-gather of 8 B per column",
+                "(banded operand of dimension N / P, every launch and read-back of the step included) + the preparation of the next "
+                "step's exchange (five small launches; a host round trip with exchange_ahead = 0) + halo bytes / 153 GB/s per xGMI "
+                "link + a ring all-gather of 8 B per column.  A RELABELLED operand costs the same per step on several ranks: the "
+                "solver recovers the band once per solve and redistributes the operands (csrc/band_scope.cpp); TRS4 / sign / "
+                "square-root loops across ranks multiply panels through the halo exchange without slab sessions (not modelled)",
         "n": args.n, "halfband": h, "threshold": thr, "arithmetic": args.arithmetic,
         "host_round_trip_us": sync_us, "xgmi_link_GBps": XGMI_LINK_GBS, "table": rows}, indent=1))
 
