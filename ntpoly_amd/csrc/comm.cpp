@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -86,10 +87,25 @@ struct ShmTransport : Transport {
 
   // (the test transport moves bytes through host memory and has to wait for the stream where RCCL enqueues a collective:
   // its waits are not host synchronisations of the ENGINE and stay out of host_sync_count())
-  static void transport_wait() { HIP_CHECK(hipStreamSynchronize(stream())); }
+  // (NTPOLY_AMD_DEBUG_SYNC: time spent waiting for the stream and for the other ranks, printed when the transport closes)
+  double wait_ms = 0.0, barrier_ms = 0.0, copy_ms = 0.0;
+  long long waits = 0, slow_waits = 0;
+  bool dbg_sync = std::getenv("NTPOLY_AMD_DEBUG_SYNC") != nullptr;
+  void transport_wait() {
+    if (!dbg_sync) { HIP_CHECK(hipStreamSynchronize(stream())); return; }
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    wait_ms += ms; waits += 1; slow_waits += ms > 10.0 ? 1 : 0;
+  }
   ShmHeader* hdr() { return reinterpret_cast<ShmHeader*>(base); }
   char* mailbox(int s, int q) { return base + 4096 + ((size_t)s * P + q) * box; }
   void barrier() {
+    const auto tb0 = std::chrono::steady_clock::now();
+    barrier_impl();
+    if (dbg_sync) barrier_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+  }
+  void barrier_impl() {
     local_sense = 1 - local_sense;
     if (__sync_add_and_fetch(&hdr()->count, 1) == P) {
       hdr()->count = 0;
@@ -100,8 +116,18 @@ struct ShmTransport : Transport {
     }
     __sync_synchronize();
   }
-  void d2h(void* h, const void* d, size_t n) { if (n) HIP_CHECK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); }
-  void h2d(void* d, const void* h, size_t n) { if (n) HIP_CHECK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); }
+  void d2h(void* h, const void* d, size_t n) {
+    if (!n) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+    if (dbg_sync) copy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  void h2d(void* d, const void* h, size_t n) {
+    if (!n) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipMemcpy(d, h, n, hipMemcpyHostToDevice));
+    if (dbg_sync) copy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
   void check(size_t bytes) { if (bytes > box) NTP_FATAL("shm transport: message larger than the mailbox (NTPOLY_AMD_SHM_MB)"); }
 
   void allgather(const void* send, void* recv, size_t bytes) override {
@@ -166,6 +192,9 @@ struct ShmTransport : Transport {
     recvs.clear();
   }
   ~ShmTransport() override {
+    if (dbg_sync)
+      std::fprintf(stderr, "[shm transport] rank %d: %lld stream waits %.1f ms (%lld longer than 10 ms), barriers %.1f ms, staging copies %.1f ms\n",
+                   rank, waits, wait_ms, slow_waits, barrier_ms, copy_ms);
     if (base) munmap(base, total);
   }
 };

@@ -44,9 +44,34 @@ long long& host_sync_count() {
   static long long n = 0;
   return n;
 }
+namespace {
+// NTPOLY_AMD_DEBUG_SYNC: where the host waits -- calls and milliseconds spent in sync_stream(), printed at exit
+struct SyncClock {
+  bool on = std::getenv("NTPOLY_AMD_DEBUG_SYNC") != nullptr;
+  long long calls = 0, slow = 0;
+  double ms = 0.0;
+  ~SyncClock() {
+    if (on) std::fprintf(stderr, "[sync_stream] %lld waits, %.1f ms in them, %lld longer than 10 ms\n", calls, ms, slow);
+  }
+};
+SyncClock& sync_clock() {
+  static SyncClock c;
+  return c;
+}
+}  // namespace
 void sync_stream() {
   host_sync_count() += 1;   // (every host wait on the engine stream goes through here: ScalarFetch::run, DevBuf::download)
+  SyncClock& c = sync_clock();
+  if (!c.on) {
+    HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    return;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
   HIP_CHECK(hipStreamSynchronize(ctx().stream));
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  c.calls += 1;
+  c.ms += ms;
+  c.slow += ms > 10.0 ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- caching allocator
