@@ -735,48 +735,119 @@ __global__ __launch_bounds__(256) void k_slab_plan(int ncols, const int32_t* __r
   // align16 (MFMA tile kernel): the window starts at a multiple of 16 rows and is a multiple of 16 rows long, so that a
   // column's slot keeps every row r at a position = r (mod 16): a 16-row tile segment of a run is one 128-byte line
   const int b = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  if (b >= nblocks) return;
   const int lane = lane_id();
-  const int j = b * J + lane;
-  const bool has = lane < J && j < ncols && blast[min(j, ncols - 1)] >= 0;
-  const int kmin = wave_min_i32(has ? bfirst[j] : INT_MAX), kmax = wave_max_i32(has ? blast[j] : -1);
-  if (kmax >= kmin && kmax - kmin >= 4096) {
-    // a k range far beyond any multiplier tile (at most 1023 rows): the operand is not run-like and the slab kernels
-    // will be declined -- do not walk the range (for a relabelled matrix it is the whole dimension, in every block)
-    if (lane == 0) {
-      blk_lo[b] = 0;
-      blk_w[b] = 1 << 30;
-      blk_kmin[b] = kmin;
-      blk_kn[b] = kmax - kmin + 1;
-      bsz[b] = 0;
-      tsz[b] = 0;
+  if (b < nblocks) {
+    const int j = b * J + lane;
+    const bool has = lane < J && j < ncols && blast[min(j, ncols - 1)] >= 0;
+    const int kmin = wave_min_i32(has ? bfirst[j] : INT_MAX), kmax = wave_max_i32(has ? blast[j] : -1);
+    if (kmax >= kmin && kmax - kmin >= 4096) {
+      // a k range far beyond any multiplier tile (at most 1023 rows): the operand is not run-like and the slab kernels
+      // will be declined -- do not walk the range (for a relabelled matrix it is the whole dimension, in every block)
+      if (lane == 0) {
+        blk_lo[b] = 0;
+        blk_w[b] = 1 << 30;
+        blk_kmin[b] = kmin;
+        blk_kn[b] = kmax - kmin + 1;
+        bsz[b] = 0;
+        tsz[b] = 0;
+      }
+    } else {
+      int lo = INT_MAX, hi = -1;
+      // (a block whose columns are all empty has kmin = INT_MAX: kmin + lane must not be formed)
+      for (int k = (kmax >= kmin) ? kmin + lane : 0; k <= kmax; k += WAVE) {
+        const int c0 = cmin[k], c1 = cmax[k];
+        if (c1 >= c0) {
+          lo = min(lo, c0);
+          hi = max(hi, c1 + 1);
+        }
+      }
+      lo = wave_min_i32(lo);
+      hi = wave_max_i32(hi);
+      if (lane == 0) {
+        if (align16 > 0 && hi > lo) {   // (a multiple of 16: the rows of a tile of the MFMA kernel)
+          lo = lo / align16 * align16;
+          hi = (hi + align16 - 1) / align16 * align16;
+        }
+        const int w = (hi > lo) ? hi - lo : 0;
+        const int kn = (w > 0 && kmax >= kmin) ? kmax - kmin + 1 : 0;
+        blk_lo[b] = w > 0 ? lo : 0;
+        blk_w[b] = w;
+        blk_kmin[b] = kn > 0 ? kmin : 0;
+        blk_kn[b] = kn;
+        bsz[b] = (int64_t)((kn + 1) & ~1) * J;  // an all-zero row pads odd k ranges
+        tsz[b] = (int64_t)w * J;
+      }
     }
-    return;
   }
-  int lo = INT_MAX, hi = -1;
-  // (a block whose columns are all empty has kmin = INT_MAX: kmin + lane must not be formed)
-  for (int k = (kmax >= kmin) ? kmin + lane : 0; k <= kmax; k += WAVE) {
-    const int c0 = cmin[k], c1 = cmax[k];
-    if (c1 >= c0) {
-      lo = min(lo, c0);
-      hi = max(hi, c1 + 1);
+}
+
+// The maxima of the windows and k ranges (stats[16], stats[17]) and the exclusive prefix sums of the slot sizes in ONE launch
+// without any dependency between workgroups: workgroup g owns a contiguous part of the blocks and sums everything BEFORE its
+// part itself (at most a few hundred KB from L2, every load of a thread in flight together) -- redundant reads instead of a
+// second and a third launch.  toff/boff hold nblocks + 1 entries.
+constexpr int kOffParts = 64;
+__global__ __launch_bounds__(256) void k_slab_offsets(const int32_t* __restrict__ blk_w, const int32_t* __restrict__ blk_kn,
+                                                      const int64_t* __restrict__ tsz, const int64_t* __restrict__ bsz,
+                                                      int nblocks, int part, int64_t* __restrict__ toff,
+                                                      int64_t* __restrict__ boff, unsigned long long* __restrict__ stats) {
+  __shared__ long long wsum[2][4];
+  __shared__ int wmax[2][4];
+  const int lane = lane_id(), wave = threadIdx.x / WAVE;
+  const int p0 = blockIdx.x * part, p1 = min(nblocks, p0 + part);
+  if (p0 >= nblocks) return;
+  auto block_sum = [&](long long& a, long long& b) {   // both sums over the workgroup, returned to every thread
+    a = wave_sum_i64(a);
+    b = wave_sum_i64(b);
+    __syncthreads();
+    if (lane == 0) { wsum[0][wave] = a; wsum[1][wave] = b; }
+    __syncthreads();
+    a = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+    b = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+  };
+  long long carry_t = 0, carry_b = 0;
+  for (int i = threadIdx.x; i < p0; i += 256) {
+    carry_t += tsz[i];
+    if (boff) carry_b += bsz[i];
+  }
+  block_sum(carry_t, carry_b);
+  int mw = 0, mk = 0;
+  for (int base = p0; base < p1; base += 256) {
+    const int i = base + threadIdx.x;
+    const long long t = i < p1 ? (long long)tsz[i] : 0, b = (boff && i < p1) ? (long long)bsz[i] : 0;
+    if (i < p1) {
+      mw = max(mw, blk_w[i]);
+      mk = max(mk, blk_kn[i]);
     }
+    long long xt = t, xb = b;
+    for (int o = 1; o < WAVE; o <<= 1) {
+      const long long at = __shfl_up(xt, o, WAVE), ab = __shfl_up(xb, o, WAVE);
+      if (lane >= o) { xt += at; xb += ab; }
+    }
+    __syncthreads();
+    if (lane == WAVE - 1) { wsum[0][wave] = xt; wsum[1][wave] = xb; }
+    __syncthreads();
+    long long pt = carry_t + xt - t, pb = carry_b + xb - b;
+    for (int q = 0; q < wave; ++q) { pt += wsum[0][q]; pb += wsum[1][q]; }
+    if (i < p1) {
+      toff[i] = pt;
+      if (boff) boff[i] = pb;
+    }
+    carry_t += wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+    carry_b += wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
   }
-  lo = wave_min_i32(lo);
-  hi = wave_max_i32(hi);
-  if (lane != 0) return;
-  if (align16 > 0 && hi > lo) {   // (a multiple of 16: the rows of a tile of the MFMA kernel)
-    lo = lo / align16 * align16;
-    hi = (hi + align16 - 1) / align16 * align16;
+  if (p1 == nblocks && threadIdx.x == 0) {
+    toff[nblocks] = carry_t;
+    if (boff) boff[nblocks] = carry_b;
   }
-  const int w = (hi > lo) ? hi - lo : 0;
-  const int kn = (w > 0 && kmax >= kmin) ? kmax - kmin + 1 : 0;
-  blk_lo[b] = w > 0 ? lo : 0;
-  blk_w[b] = w;
-  blk_kmin[b] = kn > 0 ? kmin : 0;
-  blk_kn[b] = kn;
-  bsz[b] = (int64_t)((kn + 1) & ~1) * J;  // an all-zero row pads odd k ranges
-  tsz[b] = (int64_t)w * J;
+  mw = wave_max_i32(mw);
+  mk = wave_max_i32(mk);
+  __syncthreads();
+  if (lane == 0) { wmax[0][wave] = mw; wmax[1][wave] = mk; }
+  __syncthreads();
+  if (threadIdx.x == 0 && stats) {
+    atomicMax(&stats[16], (unsigned long long)max(max(wmax[0][0], wmax[0][1]), max(wmax[0][2], wmax[0][3])));
+    atomicMax(&stats[17], (unsigned long long)max(max(wmax[1][0], wmax[1][1]), max(wmax[1][2], wmax[1][3])));
+  }
 }
 
 // B tile of a block: bblk[boff + (k - kmin) * J + jj] = B(k, b*J + jj), zeros elsewhere.  Staged through LDS
@@ -4210,15 +4281,19 @@ void launch_slab_plan(SlabPlan& P, int n, const int32_t* first, const int32_t* l
   P.blk_toff.alloc((size_t)snb + 1);
   P.align = align;
   DevBuf<int64_t> bsz(snb), tsz(snb);
+  if (tile_offsets) tile_offsets->alloc((size_t)snb + 1);
   hipLaunchKernelGGL((k_slab_plan<SLAB_J>), dim3(cdiv((int64_t)snb * WAVE, 256)), dim3(256), 0, stream(), n, first, last, afirst,
                      alast, P.blk_lo.p, P.blk_w.p, P.blk_kmin.p, P.blk_kn.p, bsz.p, tsz.p, snb, align);
-  // (one workgroup doing the scan and the maxima in a single launch was tried: 50 us against the 20 of these four)
+  if (options().plan_fused != 0) {
+    // maxima and both prefix sums in ONE launch (k_slab_offsets) instead of four to seven
+    const int part = cdiv(cdiv(snb, kOffParts), 256) * 256;
+    hipLaunchKernelGGL(k_slab_offsets, dim3(cdiv(snb, part)), dim3(256), 0, stream(), P.blk_w.p, P.blk_kn.p, tsz.p, bsz.p, snb, part,
+                       P.blk_toff.p, tile_offsets ? tile_offsets->p : (int64_t*)nullptr, stats);
+    return;
+  }
   hipLaunchKernelGGL(k_slab_reduce, dim3(64), dim3(256), 0, stream(), P.blk_w.p, P.blk_kn.p, snb, (const int32_t*)nullptr, 0, stats);
   scan_async<int64_t>(tsz.p, P.blk_toff.p, (int64_t)snb);
-  if (tile_offsets) {   // (where the multiplier tile of every block starts: the tiles of a right operand that has none yet)
-    tile_offsets->alloc((size_t)snb + 1);
-    scan_async<int64_t>(bsz.p, tile_offsets->p, (int64_t)snb);
-  }
+  if (tile_offsets) scan_async<int64_t>(bsz.p, tile_offsets->p, (int64_t)snb);   // (where the multiplier tile of every block starts)
 }
 }  // namespace
 

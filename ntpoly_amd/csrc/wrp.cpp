@@ -162,6 +162,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "label_order") options().label_order = *value;
   else if (n == "band_scope") options().band_scope = *value;
   else if (n == "exchange_ahead") options().exchange_ahead = *value;
+  else if (n == "plan_fused") options().plan_fused = *value;
   else if (n == "label_rowoff") options().label_rowoff = *value;
   else if (n == "block_path") options().block_path = *value;
   else if (n == "tile_runs_only") options().tile_runs_only = *value;
@@ -184,6 +185,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "label_order") return options().label_order;
   if (n == "band_scope") return options().band_scope;
   if (n == "exchange_ahead") return options().exchange_ahead;
+  if (n == "plan_fused") return options().plan_fused;
   if (n == "fused_update") return options().fused_update;
   if (n == "loose_iterates") return options().loose_iterates;
   if (n == "complex_tile") return options().complex_tile;
