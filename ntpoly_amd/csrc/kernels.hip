@@ -2676,6 +2676,7 @@ EngineOptions& options() {
     if (const char* v = std::getenv("NTPOLY_AMD_TILE_WAVES")) e->tile_waves = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_PLAN_AHEAD")) e->plan_ahead = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_SLAB_ALGEBRA")) e->slab_algebra = std::atoi(v);
+    if (const char* v = std::getenv("NTPOLY_AMD_PANEL_SESSIONS")) e->panel_sessions = std::atoi(v);
     return e;
   }();
   return *o;
@@ -6045,15 +6046,18 @@ void sa_sum_counts(const int32_t* count, int n, DevBuf<long long>& tot) {
   tot.zero();
   hipLaunchKernelGGL(k_sa_sum_i32, dim3(std::max(1, std::min(256, cdiv(n, 1024)))), dim3(256), 0, stream(), count, n, tot.p);
 }
+bool g_panels_ok = false;   // a slab session across ranks (psmatrix.cpp): operands are column panels, rows != columns
 bool sa_operand(const DevMat& M) {
-  return M.expanded() && !M.cplx && !M.slab->labelled() && M.rows == M.cols;
+  return M.expanded() && !M.cplx && !M.slab->labelled() && (M.rows == M.cols || g_panels_ok);
 }
 }  // namespace
+void slab_allow_panels(bool on) { g_panels_ok = on; }
+bool slab_panels_ok() { return g_panels_ok; }
 
 bool slab_enter(DevMat& M) {
   if (M.expanded()) return sa_operand(M);
   if (M.blocked() || M.slab_hint < 0) return false;
-  if (M.cplx || M.loose() || M.rows != M.cols || M.nnz == 0 || (options().spgemm_fma != 0 && options().spgemm_fma != 1)) return false;
+  if (M.cplx || M.loose() || (M.rows != M.cols && !g_panels_ok) || M.nnz == 0 || (options().spgemm_fma != 0 && options().spgemm_fma != 1)) return false;
   const int n = M.cols;
   std::unique_ptr<SlabForm> f(new SlabForm());
   f->first.alloc((size_t)n); f->last.alloc((size_t)n); f->count.alloc((size_t)n); f->off.alloc((size_t)n + 1);
@@ -6397,22 +6401,29 @@ bool slab_multiply_loop(const DevMat& A, const DevMat& B, DevMat& C, double alph
 
 // C = alpha A B with the threshold rule of the SpGEMM, operands and result in slab form: on the MFMA tile kernel in FMA
 // arithmetic, on the register-slab kernel in unfused arithmetic
-bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {
+bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, const SlabHalo* left) {
+  // left (a panel product, psmatrix.cpp): A and B are column panels of the distributed operands; the columns of the left
+  // operand named by the rows of B's panel -- this rank's own and the halo -- are described by `left` (global column numbers)
+  if (left && (options().spgemm_fma != 1 || left->kb <= left->ka)) return false;
   if (options().spgemm_fma == 0) {
     if (!sa_operand(A) || !sa_operand(B) || A.cols != B.rows || options().spgemm_variant >= 0 || options().spgemm_force_bin > 0 ||
         A.slab->row_pad != 1)
       return false;
     return slab_multiply_loop(A, B, C, alpha, threshold, dense_rule);
   }
-  if (!sa_operand(A) || !sa_operand(B) || A.cols != B.rows || options().spgemm_fma != 1 || options().spgemm_variant >= 0 ||
+  if (!sa_operand(A) || !sa_operand(B) || (!left && A.cols != B.rows) || options().spgemm_fma != 1 || options().spgemm_variant >= 0 ||
       options().spgemm_force_bin > 0) {
     if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM")) std::fprintf(stderr, "[slab_multiply] refused: operands / options\n");
     return false;
   }
   const SlabForm &fa = *A.slab, &fb = *B.slab;
+  const int a_pad = left ? left->row_pad : fa.row_pad;
   int trows = tile_rows();
-  while (trows > 1 && fa.row_pad % (16 * trows) != 0) trows >>= 1;
-  if (fa.row_pad % 16 != 0) return false;
+  while (trows > 1 && a_pad % (16 * trows) != 0) trows >>= 1;
+  if (a_pad % 16 != 0) return false;
+  const int ka = left ? left->ka : 0, nka = left ? left->kb - left->ka : A.cols;
+  const int32_t* afirst = left ? left->first - ka : fa.first.p;   // (global column numbers through biased pointers)
+  const int32_t* alast = left ? left->last - ka : fa.last.p;
   const int n = B.cols, snb = cdiv(n, SLAB_J);
   const bool timing = options().time_kernels != 0;
   EventTimer t_all(timing), t_num(timing);
@@ -6424,7 +6435,7 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
   const int plan_align = 16 * tile_rows();
   // (the multiplier tiles of B, when a fused step left them; otherwise the kernel reads the runs of B's columns)
   const bool have_tiles = fb.tiles.p != nullptr && (int64_t)fb.tile_off.n == (int64_t)snb + 1;
-  launch_slab_plan(P, n, fb.first.p, fb.last.p, fa.first.p, fa.last.p, plan_align, stats.p);
+  launch_slab_plan(P, n, fb.first.p, fb.last.p, afirst, alast, plan_align, stats.p);
   unsigned long long hs[3] = {0, 0, 0};
   {
     ScalarFetch f;
@@ -6453,7 +6464,7 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
   fo->val.alloc(oslots);
   // ---- a thin operand (an identity, the near-diagonal factor of a square-root loop): the gather kernels of spgemm_thin.hip
   // on the same plan and output slots -- a handful of products per entry instead of the whole k range of the block
-  const int thin_mode = (options().thin_left == 0 || fa.labelled() || fb.labelled() || A.rows != A.cols) ? 0
+  const int thin_mode = (options().thin_left == 0 || fa.labelled() || fb.labelled() || A.rows != A.cols || left) ? 0
                         : (A.nnz <= 8 * (int64_t)A.cols && B.nnz >= A.nnz)                                 ? 1
                         : (B.nnz <= 8 * (int64_t)n)                                                          ? 2
                                                                                                              : 0;
@@ -6511,12 +6522,16 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
     // (a column of the right operand lists more non-zeros than the kernel holds: the tile kernel below)
     fo->count.zero();
   }
-  DevBuf<char> runs(((size_t)A.cols + 4) * sizeof(SlabRun));
-  hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, fa.off.p,
-                     reinterpret_cast<const char*>(fa.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), A.cols);
+  DevBuf<char> runs(((size_t)nka + 4) * sizeof(SlabRun));
+  if (left)
+    hipLaunchKernelGGL(k_slab_runs_addr, dim3(cdiv(nka + 4, 256)), dim3(256), 0, stream(), left->first, left->last, left->addr,
+                       (unsigned long long)reinterpret_cast<uintptr_t>(fa.val.p), reinterpret_cast<SlabRun*>(runs.p), nka);
+  else
+    hipLaunchKernelGGL(k_slab_runs, dim3(cdiv(A.cols + 4, 256)), dim3(256), 0, stream(), fa.first.p, fa.last.p, fa.off.p,
+                       reinterpret_cast<const char*>(fa.val.p), 8, reinterpret_cast<SlabRun*>(runs.p), A.cols);
   t_num.start();
   TileLaunch tl;
-  tl.runs = reinterpret_cast<const SlabRun*>(runs.p);
+  tl.runs = reinterpret_cast<const SlabRun*>(runs.p) - ka;
   if (have_tiles) {
     tl.bblk = fb.tiles.p; tl.blk_boff = fb.tile_off.p;
   } else {
@@ -6532,7 +6547,7 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
   // that comes back with the entry count, and the product is repeated on k_spgemm_tile
   DevBuf<int> t2fail(2);
   bool used_tile2 = false;
-  if (!have_tiles && options().tile2 != 0 && !fa.no_tile2 && !fb.no_tile2) {
+  if (!have_tiles && !left && options().tile2 != 0 && !fa.no_tile2 && !fb.no_tile2) {
     t2fail.zero();
     used_tile2 = launch_spgemm_tile2(tl, t2fail.p);
   }

@@ -80,6 +80,7 @@ struct EngineOptions {
                                // are (the shape only selects the summation semantics of the multiply: slices > 1)
   int fused_update = 1;        // TRS2 on one rank, real operands: the update X <- 2X - X*X (or X*X), its energy and its trace
                                // come out of the epilogue of the register-slab kernel; 0: separate merge / reduction passes
+  int panel_sessions = 1;      // slab sessions (TRS4, sign, inverse, square roots, polynomials ...) on more than one rank: the loops' matrices stay in slab form as column panels, a product exchanges the runs of the left operand's halo (psmatrix.cpp panel_slab_multiply); 0: compressed columns across ranks
   int plan_fused = 1;          // the maxima and prefix sums of a slab step's plan in ONE launch (k_slab_offsets: every workgroup sums what lies before its part itself) instead of four to seven; 0: separate launches
   int exchange_ahead = 1;      // panel steps across ranks: a step prepares the NEXT step's exchange (extents all-gathered, counts, plan) from its result and reads it back with its own totals -- one host round trip per panel step (psmatrix.cpp PanelExchange); 0: two
   int band_scope = 1;          // solvers on SEVERAL ranks: an operand without run structure is searched for a hidden band once per solve, the operands are redistributed in the recovered order, the results carried back (band_scope.cpp)
@@ -214,7 +215,9 @@ void slab_counts_async(const DevMat& X, int64_t* d_cnt64);
 // unlabelled, square, one rank, FMA arithmetic.  Every function returns false and leaves its operands alone when it
 // cannot take them (the caller packs and takes the general path).
 bool slab_enter(DevMat& M);   // compressed columns -> slab form in place (false: not run-like, stored zeros, complex ...)
-bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule);
+bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, const SlabHalo* left = nullptr);
+bool slab_panels_ok();
+void slab_allow_panels(bool on);   // a slab session across ranks: the operands of the slab algebra are column panels (rows != columns)
 // complex operands in slab form (FMA arithmetic, option complex_tile; a session that allows them): runs of (re, im) pairs in
 // slots aligned to 16 rows -- what the complex MFMA tile kernel reads and writes.  Each returns false when it does not take
 // its operands (nothing changed): the caller packs and the compressed-column path does the work.

@@ -154,9 +154,13 @@ const long long* block_algebra_counts() { return g_block_counts; }
 const long long* column_fused_counts() { return g_column_fused; }
 
 SlabSession::SlabSession(bool eligible, bool api, bool complex_ok) {
+  // (more than one rank: the loops' matrices are column panels in slab form, a product exchanges the runs of its left
+  // operand's halo -- panel_slab_multiply below; FMA arithmetic, real, the solvers' own sessions only: option panel_sessions)
+  const bool multi = world().active();
   opened = eligible && options().slab_algebra != 0 && (options().spgemm_fma == 1 || options().spgemm_fma == 0) && options().spgemm_variant < 0 &&
-           options().spgemm_force_bin <= 0 && !world().active();
-  if (opened && complex_ok && options().complex_sessions != 0 && options().spgemm_fma == 1 && options().complex_tile != 0 && !g_complex_session) {
+           options().spgemm_force_bin <= 0 && (!multi || (options().panel_sessions != 0 && options().spgemm_fma == 1 && !api));
+  if (opened && multi && g_slab_depth == 0) slab_allow_panels(true);
+  if (opened && !multi && complex_ok && options().complex_sessions != 0 && options().spgemm_fma == 1 && options().complex_tile != 0 && !g_complex_session) {
     g_complex_session = true;
     set_complex = true;
   }
@@ -172,6 +176,7 @@ void SlabSession::close() {
   if (set_complex) { g_complex_session = false; set_complex = false; }
   if (opened) {
     g_slab_depth -= 1;
+    if (g_slab_depth == 0) slab_allow_panels(false);
   }
   opened = false;
 }
@@ -433,6 +438,135 @@ void ps_to_real(const PSMatrix& a, PSMatrix& out) {
 // there is no reduction step (slices == 1 semantics: working_threshold = threshold,
 // distributed_algebra_includes/MatrixMultiply.f90:25-29).
 namespace {
+bool exchange_fits_fetch(int P);
+int panel_pitch(int32_t dim, int P, bool with_counts, int* wcols_out);
+long long g_panel_products[2] = {0, 0};   // products of slab sessions across ranks: done in slab form on every rank; declined
+
+// C = alpha A B of a slab session on more than one rank: A, B column panels in slab form, the result a column panel in slab
+// form (MatrixMultiply.f90:92-267 gathers blocks of both operands along the grid; here the rows of B's panel name the columns
+// of A that have to travel, as dense runs).  Protocol, all on the engine stream: (1) ONE all-gather of a record per rank --
+// request (first / last row of B's panel, entries of B, entries of A and the alignment of its runs; -1: this rank's panels are
+// not in slab form), packed extents of A's columns, prefix sums of their spans; (2) who sends how many doubles to whom, one
+// read-back; (3) the runs of the requested columns packed per requester, one send / recv group; (4) layout of the columns this
+// rank multiplies with, the tile kernel on them (slab_multiply with a left halo); (5) one reduction: did every rank's kernel
+// take its panel.  Collective; false (every rank alike): nothing done, the caller takes the compressed-column path.
+bool panel_slab_multiply(const PSMatrix& A, const PSMatrix& B, DevMat& AB, double alpha, double threshold) {
+  Comm& c = world();
+  Transport& tr = *c.tr;
+  const int P = c.nranks, me = c.rank;
+  const int32_t dim = A.dim;
+  const bool mine_ok = slab_on() && A.loc.nnz > 0 && B.loc.nnz > 0 && A.c0 == B.c0 && A.c1 == B.c1 && slab_enter(mut(A)) &&
+                       (&A == &B || slab_enter(mut(B))) && A.loc.slab->row_pad % 16 == 0 && A.loc.slab->row_pad < 4096;
+  int wcols = 0;
+  const int pitch = panel_pitch(dim, P, false, &wcols);
+  DevBuf<int64_t> d_all((size_t)P * pitch), d_req((size_t)4 * P), d_bound((size_t)2 * P), d_cnt((size_t)P * P);
+  int64_t* mine = d_all.p + (size_t)me * pitch;
+  if (mine_ok) {
+    slab_request_async(B.loc, mine);
+    slab_extents_async(A.loc, mine + 4, mine + 4 + wcols);
+    const long long w3 = (long long)A.loc.nnz * 4096 + A.loc.slab->row_pad;
+    HIP_CHECK(hipMemcpyAsync(mine + 3, &w3, sizeof(w3), hipMemcpyHostToDevice, stream()));
+  } else {
+    const long long rec[4] = {INT_MAX, -1, -1, 0};
+    HIP_CHECK(hipMemsetAsync(mine, 0, (size_t)pitch * sizeof(int64_t), stream()));
+    HIP_CHECK(hipMemcpyAsync(mine, rec, sizeof(rec), hipMemcpyHostToDevice, stream()));
+  }
+  tr.allgather(mine, d_all.p, (size_t)pitch * sizeof(int64_t));
+  HIP_CHECK(hipMemcpy2DAsync(d_req.p, 4 * sizeof(int64_t), d_all.p, (size_t)pitch * sizeof(int64_t), 4 * sizeof(int64_t), (size_t)P,
+                             hipMemcpyDeviceToDevice, stream()));
+  const int64_t *d_ext_all = d_all.p + 4, *d_pre_all = d_all.p + 4 + wcols;
+  halo_counts_async(d_req.p, d_pre_all, pitch, dim, P, me, d_cnt.p, d_bound.p);   // (counts in doubles)
+  std::vector<int64_t> req((size_t)4 * P, 0), cnt((size_t)P * P, 0);
+  if (exchange_fits_fetch(P)) {
+    ScalarFetch f;
+    f.add(d_req.p, 4 * P, req.data());
+    f.add(d_cnt.p, P * P, cnt.data());
+    f.run();
+  } else {
+    HIP_CHECK(hipMemcpyAsync(req.data(), d_req.p, (size_t)4 * P * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, stream()));
+    sync_stream();
+  }
+  exchange_stats().exchanges += 1;
+  int64_t nnz_a = 0, nnz_b = 0;
+  bool all_ok = true;
+  for (int q = 0; q < P; ++q) {
+    if (req[(size_t)4 * q + 2] < 0) { all_ok = false; break; }
+    nnz_b += req[(size_t)4 * q + 2];
+    nnz_a += req[(size_t)4 * q + 3] / 4096;
+    if (req[(size_t)4 * q + 3] % 4096 != req[3] % 4096) all_ok = false;   // (every panel's runs aligned alike)
+  }
+  if (!all_ok) {
+    g_panel_products[1] += 1;
+    return false;
+  }
+  const int row_pad = (int)(req[3] % 4096);
+  auto kmin_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? 0 : (int32_t)lo; };
+  auto kmax_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? -1 : (int32_t)hi; };
+  const int32_t kmin = kmin_of(me), kmax = kmax_of(me);
+  // what I send: my columns of A inside every requester's range, packed per requester
+  std::vector<int32_t> sa((size_t)P), sb((size_t)P);
+  std::vector<int64_t> soff((size_t)P + 1, 0);
+  for (int q = 0; q < P; ++q) {
+    halo_segment(dim, P, me, kmin_of(q), kmax_of(q), &sa[(size_t)q], &sb[(size_t)q]);
+    soff[(size_t)q + 1] = soff[(size_t)q] + (q == me ? 0 : cnt[(size_t)me * P + q]);
+  }
+  DevBuf<double> sendbuf((size_t)soff[(size_t)P] + 1);
+  for (int q = 0; q < P; ++q)
+    if (q != me && cnt[(size_t)me * P + q] > 0)
+      slab_pack_runs_async(A.loc, d_pre_all + (size_t)me * pitch, sa[(size_t)q] - A.c0, sb[(size_t)q] - A.c0, sendbuf.p + soff[(size_t)q]);
+  // what I receive: the segments of the other owners tile [kmin, kmax] in rank order
+  std::vector<int32_t> ra((size_t)P), rb((size_t)P);
+  std::vector<int64_t> zoff((size_t)P + 1, 0);
+  for (int s = 0; s < P; ++s) {
+    halo_segment(dim, P, s, kmin, kmax, &ra[(size_t)s], &rb[(size_t)s]);
+    zoff[(size_t)s + 1] = zoff[(size_t)s] + (s == me ? 0 : cnt[(size_t)s * P + me]);
+  }
+  DevBuf<double> recvbuf((size_t)zoff[(size_t)P] + kIndexSlack);
+  tr.group_begin();
+  for (int q = 0; q < P; ++q) {
+    const int64_t m = cnt[(size_t)me * P + q];
+    if (q != me && m > 0) tr.send(sendbuf.p + soff[(size_t)q], (size_t)m * sizeof(double), q);
+  }
+  for (int s = 0; s < P; ++s) {
+    const int64_t m = cnt[(size_t)s * P + me];
+    if (s != me && m > 0) tr.recv(recvbuf.p + zoff[(size_t)s], (size_t)m * sizeof(double), s);
+  }
+  tr.group_end();
+  bool ok = kmax >= kmin;
+  if (ok) {
+    const int32_t ka = kmin, kb = kmax + 1;
+    DevBuf<int32_t> d_ra((size_t)P), nfirst((size_t)(kb - ka)), nlast((size_t)(kb - ka));
+    DevBuf<int64_t> d_zoff((size_t)P);
+    DevBuf<unsigned long long> naddr((size_t)(kb - ka));
+    d_ra.upload(ra.data(), (size_t)P);
+    d_zoff.upload(zoff.data(), (size_t)P);
+    slab_halo_layout_async(d_ext_all, d_pre_all, pitch, dim, P, me, ka, kb, d_ra.p, d_zoff.p, recvbuf.p, A.loc, nfirst.p, nlast.p, naddr.p);
+    SlabHalo halo;
+    halo.ka = ka;
+    halo.kb = kb;
+    halo.first = nfirst.p;
+    halo.last = nlast.p;
+    halo.addr = naddr.p;
+    halo.row_pad = row_pad;
+    const double denom = (double)dim * (double)dim;
+    const bool dense_rule = denom > 0 && std::min((double)nnz_a / denom, (double)nnz_b / denom) > 0.1;
+    // (the buffers above are released on return: the allocator is stream ordered, and slab_multiply ends with a read-back)
+    ok = slab_multiply(A.loc, B.loc, AB, alpha, threshold, dense_rule, &halo);
+  }
+  double declined = ok ? 0.0 : 1.0;
+  comm_allreduce_max(&declined, 1);
+  if (declined != 0.0) {
+    g_panel_products[1] += 1;
+    return false;
+  }
+  g_panel_products[0] += 1;
+  return true;
+}
+}  // namespace
+const long long* panel_product_counts() { return g_panel_products; }
+
+namespace {
 // alpha * A * B with the threshold, local panel of the result (slices == 1 semantics: every output entry is one sum
 // over the whole inner dimension in ascending order)
 DevMat multiply_panel(const PSMatrix& A, const PSMatrix& B, double alpha, double threshold, double a_fraction = 1.0) {
@@ -545,7 +679,19 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
     }
     slab_refused({&A, &B});
   }
-  if (slab_on() && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 && A.loc.nnz > 0 && B.loc.nnz > 0) {
+  if (g_slab_depth > 0 && world().active() && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308) {
+    // (a slab session across ranks: collective -- every rank reports whether its panels are in slab form with the halo request)
+    if (panel_slab_multiply(A, B, AB, alpha, threshold)) {
+      g_slab_counts[0] += 1;
+      C.grid = A.grid; C.dim = A.dim; C.c0 = B.c0; C.c1 = B.c1;
+      C.cplx = false;
+      C.loc = std::move(AB);
+      return;
+    }
+    g_slab_counts[3] += 1;
+    for (const PSMatrix* m : {&A, &B})
+      if (m->loc.expanded() || m->loc.loose()) pack(mut(*m));
+  } else if (slab_on() && !world().active() && !A.cplx && S <= 1 && std::fabs(beta) < 2.2250738585072014e-308 && A.loc.nnz > 0 && B.loc.nnz > 0) {
     // (a slab session: operands are turned into slab form where they are, the product stays in it)
     const double denom = (double)A.dim * (double)A.dim;
     const bool dense_rule = denom > 0 && std::min((double)A.loc.nnz / denom, (double)B.loc.nnz / denom) > 0.1;
@@ -718,6 +864,18 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) 
 
 bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double beta, double* norm) {
   if (blk_any({&A, &B})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
+  if (world().active() && g_slab_depth > 0 && !A.cplx && !B.cplx && A.dim == B.dim && &A != &B) {
+    // (a session across ranks: the decision is collective -- one reduction carries the norm and "some rank declined")
+    double v = 0.0;
+    const bool ok = slab_on() && (A.loc.expanded() || B.loc.expanded()) && slab_enter(mut(A)) && slab_enter(mut(B)) &&
+                    slab_norm_axpby(A.loc, B.loc, alpha, beta, &v);
+    double pair[2] = {ok ? v : 0.0, ok ? 0.0 : 1.0};
+    comm_allreduce_max(pair, 2);
+    if (pair[1] != 0.0) return false;
+    *norm = pair[0];
+    g_slab_counts[2] += 1;
+    return true;
+  }
   if (slab_on() && !A.cplx && !B.cplx && A.dim == B.dim && &A != &B && (A.loc.expanded() || B.loc.expanded())) {
     if (!(slab_enter(mut(A)) && slab_enter(mut(B)) && slab_norm_axpby(A.loc, B.loc, alpha, beta, norm))) return false;
     g_slab_counts[2] += 1;
@@ -748,6 +906,19 @@ bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double be
 
 bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx) {
   if (blk_any({&X, &X2})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
+  if (world().active()) {
+    // (a session across ranks: the decision is collective -- the sums and "some rank declined" in one reduction)
+    if (g_slab_depth == 0 || X.cplx || X2.cplx) return false;
+    double t[3] = {0.0, 0.0, 0.0};
+    const bool ok = slab_on() && X.loc.expanded() && X2.loc.expanded() && slab_trs4_traces(X.loc, X2.loc, X.c0, &t[0], &t[1]);
+    if (!ok) { t[0] = t[1] = 0.0; t[2] = 1.0; }
+    comm_allreduce_sum(t, 3);
+    if (t[2] != 0.0) return false;
+    *trace_fx = t[0];
+    *trace_gx = t[1];
+    g_slab_counts[2] += 1;
+    return true;
+  }
   if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx) return false;
   if (!slab_trs4_traces(X.loc, X2.loc, X.c0, trace_fx, trace_gx)) return false;
   g_slab_counts[2] += 1;
@@ -1297,7 +1468,12 @@ void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
   }
   unblock({&A, &B});
   if (slab_on() && (A.loc.expanded() || B.loc.expanded()) && !A.cplx && !B.cplx) {
-    if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_dot(A.loc, B.loc, out)) { g_slab_counts[2] += 1; return; }
+    // (a rank whose operands left slab form computes its share from compressed columns: the sum over the ranks follows either way)
+    if (slab_enter(mut(A)) && slab_enter(mut(B)) && slab_dot(A.loc, B.loc, out)) {
+      g_slab_counts[2] += 1;
+      comm_allreduce_sum(out, 2);
+      return;
+    }
     slab_refused({&A, &B});
   } else {
     slab_pack_if({&A, &B});
@@ -1324,6 +1500,7 @@ double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includ
     double v = 0.0;
     if (slab_trace(A.loc, A.c0, &v)) {
       g_slab_counts[2] += 1;
+      comm_allreduce_sum(&v, 1);
       return v;
     }
     slab_refused({&A});
@@ -1348,7 +1525,11 @@ double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns 
   }
   if (slab_on() && A.loc.expanded()) {
     double v = 0.0;
-    if (slab_norm(A.loc, &v)) { g_slab_counts[2] += 1; return v; }
+    if (slab_norm(A.loc, &v)) {
+      g_slab_counts[2] += 1;
+      comm_allreduce_max(&v, 1);
+      return v;
+    }
     slab_refused({&A});
   } else {
     slab_pack_if({&A});
@@ -1371,6 +1552,8 @@ void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {  // Gershg
   if (slab_on() && A.loc.expanded()) {
     if (slab_gershgorin(A.loc, A.c0, &mn, &mx)) {
       g_slab_counts[2] += 1;
+      comm_allreduce_min(&mn, 1);
+      comm_allreduce_max(&mx, 1);
       *e_min = mn;
       *e_max = mx;
       return;

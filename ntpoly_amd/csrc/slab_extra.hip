@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_sa_add_diagonal(int n, const int32_t* _
 
 // B <- B + alpha I (IncrementMatrix(Identity, B, alpha, 0)); false: not done (B untouched) -- the caller merges
 bool slab_add_diagonal(DevMat& B, double alpha, int32_t col_offset) {
-  if (!B.expanded() || B.cplx || B.rows != B.cols || B.slab->labelled() || B.slab->origin || B.zero_free != 1 || alpha == 0.0) return false;
+  if (!B.expanded() || B.cplx || (B.rows != B.cols && !slab_panels_ok()) || B.slab->labelled() || B.slab->origin || B.zero_free != 1 || alpha == 0.0) return false;
   SlabForm& f = *B.slab;
   const int n = B.cols;
   DevBuf<unsigned long long> st(2);
@@ -239,7 +239,7 @@ void sum_pairs_async(const double* part, int n, double* out2) {
 }
 bool trs4_operands(const DevMat& X, const DevMat& X2) {
   auto ok = [](const DevMat& M) {
-    return M.expanded() && !M.cplx && M.rows == M.cols && !M.slab->labelled() && !M.slab->origin && M.zero_free == 1;
+    return M.expanded() && !M.cplx && (M.rows == M.cols || slab_panels_ok()) && !M.slab->labelled() && !M.slab->origin && M.zero_free == 1;
   };
   return ok(X) && ok(X2) && X.cols == X2.cols && X.slab->row_pad == X2.slab->row_pad;
 }
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_sa_norm_axpby(int n, const int32_t* __r
 }  // namespace
 
 bool slab_norm_axpby(const DevMat& A, const DevMat& B, double alpha, double beta, double* out) {
-  auto ok = [](const DevMat& M) { return M.expanded() && !M.cplx && M.rows == M.cols && !M.slab->labelled(); };
+  auto ok = [](const DevMat& M) { return M.expanded() && !M.cplx && (M.rows == M.cols || slab_panels_ok()) && !M.slab->labelled(); };
   if (!ok(A) || !ok(B) || A.cols != B.cols) return false;
   const SlabForm &fa = *A.slab, &fb = *B.slab;
   const int n = A.cols;

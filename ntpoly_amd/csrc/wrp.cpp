@@ -163,6 +163,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "band_scope") options().band_scope = *value;
   else if (n == "exchange_ahead") options().exchange_ahead = *value;
   else if (n == "plan_fused") options().plan_fused = *value;
+  else if (n == "panel_sessions") options().panel_sessions = *value;
   else if (n == "label_rowoff") options().label_rowoff = *value;
   else if (n == "block_path") options().block_path = *value;
   else if (n == "tile_runs_only") options().tile_runs_only = *value;
@@ -186,6 +187,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "band_scope") return options().band_scope;
   if (n == "exchange_ahead") return options().exchange_ahead;
   if (n == "plan_fused") return options().plan_fused;
+  if (n == "panel_sessions") return options().panel_sessions;
   if (n == "fused_update") return options().fused_update;
   if (n == "loose_iterates") return options().loose_iterates;
   if (n == "complex_tile") return options().complex_tile;
@@ -319,6 +321,11 @@ void ntpoly_amd_block_algebra_counts(long long* out) {
 }
 void ntpoly_amd_slab_algebra_counts(long long* out) {
   for (int q = 0; q < 4; ++q) out[q] = slab_algebra_counts()[q];
+}
+// products of slab sessions on more than one rank since start: done in slab form on every rank, declined (compressed columns)
+void ntpoly_amd_panel_product_counts(long long* out) {
+  out[0] = panel_product_counts()[0];
+  out[1] = panel_product_counts()[1];
 }
 // searches for a bandwidth-reducing order since start: one per sparsity pattern, not per operand (the next cycle of an
 // SCF loop -- same pattern, other values -- reuses the order)

@@ -929,6 +929,13 @@ def slab_algebra_counts():
     return dict(products=out[0], merges=out[1], others=out[2], refusals=out[3])
 
 
+def panel_product_counts():
+    """products of slab sessions on more than one rank since start: done in slab form on every rank, declined"""
+    out = (C.c_longlong * 2)()
+    lib.ntpoly_amd_panel_product_counts(out)
+    return dict(slab=out[0], declined=out[1])
+
+
 def last_grouped_stats():
     """grouped LDS-hash path of the last SpGEMM (csrc/spgemm_grouped.hip)"""
     out = (C.c_longlong * 6)()

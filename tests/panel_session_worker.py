@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""One rank of the slab-session-across-ranks test (tests/test_gpu_panel_sessions.py): the loops of TRS4, the sign function,
+the inverse square root and the inverse on a banded operand, with their matrices kept as column panels in slab form and the
+products exchanging runs (psmatrix.cpp panel_slab_multiply).  RANK / WORLD_SIZE / NTPOLY_AMD_COMM come from the environment;
+the ranks share ONE GPU and exchange through the shared-memory test transport.
+
+    python tests/panel_session_worker.py <out-prefix>
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    out = sys.argv[1]
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    n = int(os.environ.get("NTPOLY_AMD_PANEL_N", "16384"))
+    import ntpoly_amd as nt
+    from gen import banded_triplets
+    nt.init_comm(nt.get_unique_id(), rank, world)
+    nt.ConstructGlobalProcessGrid(1, world, 1)
+    res = {}
+
+    def banded(h, shift=0.0):
+        M = nt.Matrix_ps(n)
+        c0, c1 = M.local_columns()
+        t = nt.TripletList_r()
+        t.set_arrays(*banded_triplets(n, h, shift=shift, c0=c0, c1=c1))
+        M.FillFromTripletList(t, prepartitioned=True)
+        return M
+
+    def keep(tag, M):
+        c, r, v = M.triplets()
+        res[tag + "_col"], res[tag + "_row"], res[tag + "_val"] = c, r, v
+
+    def counted(tag, fn):
+        p0, s0, e0 = nt.panel_product_counts(), nt.slab_algebra_counts(), nt.exchange_stats()
+        fn()
+        p1, s1, e1 = nt.panel_product_counts(), nt.slab_algebra_counts(), nt.exchange_stats()
+        res[tag + "_panel"] = np.array([p1["slab"] - p0["slab"], p1["declined"] - p0["declined"]])
+        res[tag + "_slab"] = np.array([s1[k] - s0[k] for k in ("products", "merges", "others", "refusals")])
+        res[tag + "_exchanges"] = np.array([e1[0] - e0[0]])
+        tr = nt.solver_trace()
+        res[tag + "_iters"] = np.array([tr["iterations"]])
+
+    H = banded(20)
+    S = banded(12, shift=3.0)          # diagonally dominant, positive definite
+    Ident = nt.Matrix_ps(n)
+    Ident.FillIdentity()
+    p = nt.SolverParameters()
+    p.SetThreshold(1e-8)
+    p.SetConvergeDiff(1e-7)
+
+    # (TRS4 with a fixed number of iterations: at this threshold its energy differences stall around the convergence limit and
+    # the count of a converged solve depends on the last bits of the reductions, one rank or many, sessions or not)
+    p4 = nt.SolverParameters()
+    p4.SetThreshold(1e-8)
+    p4.SetConvergeDiff(1e-30)
+    p4.SetMaxIterations(14)
+    p4.SetMonitorConvergence(False)
+    K = nt.Matrix_ps(n)
+    out4 = {}
+    counted("trs4", lambda: out4.update(r=nt.DensityMatrixSolvers.TRS4(H, Ident, n / 2.0, K, p4)))
+    res["trs4_scal"] = np.array(out4["r"])
+    res["trs4_log"] = np.array(nt.solver_trace()["energy"])
+    keep("trs4_K", K)
+
+    Sg = nt.Matrix_ps(n)
+    counted("sign", lambda: nt.SignSolvers.ComputeSign(H, Sg, p))
+    keep("sign", Sg)
+
+    Z = nt.Matrix_ps(n)
+    counted("isq", lambda: nt.SquareRootSolvers.InverseSquareRoot(S, Z, p))
+    keep("isq", Z)
+
+    Iv = nt.Matrix_ps(n)
+    counted("inv", lambda: nt.InverseSolvers.Invert(S, Iv, p))
+    keep("inv", Iv)
+
+    np.savez(out + ".%d.npz" % rank, **res)
+    nt.DestructGlobalProcessGrid()
+
+
+if __name__ == "__main__":
+    main()
