@@ -6053,6 +6053,7 @@ bool sa_operand(const DevMat& M) {
 }  // namespace
 void slab_allow_panels(bool on) { g_panels_ok = on; }
 bool slab_panels_ok() { return g_panels_ok; }
+bool slab_plan_fits_tile(int max_kn, int max_w) { return max_w > 0 && spgemm_tile_fits(max_kn, max_w); }
 
 bool slab_enter(DevMat& M) {
   if (M.expanded()) return sa_operand(M);
@@ -6428,20 +6429,25 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
   const bool timing = options().time_kernels != 0;
   EventTimer t_all(timing), t_num(timing);
   t_all.start();
-  // ---- plan: windows and k ranges of the blocks; the sizes of the multiplier tiles when B has none yet
-  SlabPlan P;
-  DevBuf<unsigned long long> stats(24);
-  stats.zero();
+  // ---- plan: windows and k ranges of the blocks; the sizes of the multiplier tiles when B has none yet (a panel product:
+  // made by the caller from the gathered extents and read back with its exchange layout)
+  SlabPlan own_plan;
   const int plan_align = 16 * tile_rows();
+  const bool given_plan = left && left->plan && left->plan->align == plan_align && (int64_t)left->plan->blk_lo.n == snb;
+  SlabPlan& P = given_plan ? *left->plan : own_plan;
+  DevBuf<unsigned long long> stats(24);
   // (the multiplier tiles of B, when a fused step left them; otherwise the kernel reads the runs of B's columns)
   const bool have_tiles = fb.tiles.p != nullptr && (int64_t)fb.tile_off.n == (int64_t)snb + 1;
-  launch_slab_plan(P, n, fb.first.p, fb.last.p, afirst, alast, plan_align, stats.p);
-  unsigned long long hs[3] = {0, 0, 0};
-  {
+  if (!given_plan) {
+    stats.zero();
+    launch_slab_plan(P, n, fb.first.p, fb.last.p, afirst, alast, plan_align, stats.p);
+    unsigned long long hs[3] = {0, 0, 0};
     ScalarFetch f;
     f.add(P.blk_toff.p + snb, 1, &P.total);
     f.add(stats.p + 16, 3, hs);
     f.run();
+    P.max_w = (int)hs[0];
+    P.max_kn = (int)hs[1];
   }
   auto give_up = [&]() {
     if (timing) {
@@ -6450,8 +6456,6 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
     }
     return false;
   };
-  P.max_w = (int)hs[0];
-  P.max_kn = (int)hs[1];
   if (P.max_w <= 0 || !spgemm_tile_fits(P.max_kn, P.max_w)) {
     if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
       std::fprintf(stderr, "[slab_multiply] refused: window %d rows, k range %d\n", P.max_w, P.max_kn);
@@ -6559,6 +6563,7 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
     ScalarFetch f;
     f.add(tot.p, 1, &nnz);
     if (used_tile2) f.add(t2fail.p, 1, &t2f);
+    if (left && left->on_fetch) left->on_fetch(f);
     f.run();
   }
   if (used_tile2 && (int)(t2f & 0xffffffffll) != 0) {

@@ -192,7 +192,12 @@ struct SlabHalo {   // A side of a panel step: the columns ka .. kb (global numb
   // exchange layout (slab_plan_panel_async) -- the step then launches without a read-back of its own (and may keep
   // the plan's buffers for its result)
   SlabPlan* plan = nullptr;
+  // optional (slab_multiply with a left halo): called with the fetch of the product's entry count before it runs -- what the
+  // caller adds comes back on the same host round trip
+  std::function<void(ScalarFetch& fetch)> on_fetch;
 };
+// (could the tile kernel take a plan with these maxima: psmatrix.cpp decides a panel product before its exchange is over)
+bool slab_plan_fits_tile(int max_kn, int max_w);
 // the plan of a panel step from the all-gathered packed extents (record stride `pitch`, extents at d_ext_all): flat
 // extent arrays of all `dim` columns are left in gfirst / glast, the plan's sizes on the device in plan.blk_toff[blocks]
 // and stats24[16..17] (stats24: 24 zeroed words)

@@ -440,7 +440,7 @@ void ps_to_real(const PSMatrix& a, PSMatrix& out) {
 namespace {
 bool exchange_fits_fetch(int P);
 int panel_pitch(int32_t dim, int P, bool with_counts, int* wcols_out);
-long long g_panel_products[2] = {0, 0};   // products of slab sessions across ranks: done in slab form on every rank; declined
+long long g_panel_products[3] = {0, 0, 0};   // products of slab sessions across ranks: done in slab form on every rank; declined; host synchronisations inside the former
 
 // C = alpha A B of a slab session on more than one rank: A, B column panels in slab form, the result a column panel in slab
 // form (MatrixMultiply.f90:92-267 gathers blocks of both operands along the grid; here the rows of B's panel name the columns
@@ -455,6 +455,7 @@ bool panel_slab_multiply(const PSMatrix& A, const PSMatrix& B, DevMat& AB, doubl
   Transport& tr = *c.tr;
   const int P = c.nranks, me = c.rank;
   const int32_t dim = A.dim;
+  const long long syncs_before = host_sync_count();
   const bool mine_ok = slab_on() && A.loc.nnz > 0 && B.loc.nnz > 0 && A.c0 == B.c0 && A.c1 == B.c1 && slab_enter(mut(A)) &&
                        (&A == &B || slab_enter(mut(B))) && A.loc.slab->row_pad % 16 == 0 && A.loc.slab->row_pad < 4096;
   int wcols = 0;
@@ -476,17 +477,39 @@ bool panel_slab_multiply(const PSMatrix& A, const PSMatrix& B, DevMat& AB, doubl
                              hipMemcpyDeviceToDevice, stream()));
   const int64_t *d_ext_all = d_all.p + 4, *d_pre_all = d_all.p + 4 + wcols;
   halo_counts_async(d_req.p, d_pre_all, pitch, dim, P, me, d_cnt.p, d_bound.p);   // (counts in doubles)
+  // the product's plan (block windows and k ranges follow from the extents alone) from the gathered extents of A and the
+  // extents of this rank's panel of B: its sizes come back with the exchange layout -- the product itself then needs ONE
+  // more host round trip (its entry count), as on one rank
+  SlabPlan plan;
+  DevBuf<int32_t> gfirst, glast;
+  DevBuf<int64_t> plan_stats(24);
+  unsigned long long plan_hs[2] = {0, 0};
+  const int snb = (B.loc.cols + 15) / 16;
+  if (mine_ok) {
+    plan_stats.zero();
+    slab_plan_panel_async(B.loc, d_ext_all, pitch, dim, P, plan, gfirst, glast, reinterpret_cast<unsigned long long*>(plan_stats.p));
+  }
   std::vector<int64_t> req((size_t)4 * P, 0), cnt((size_t)P * P, 0);
   if (exchange_fits_fetch(P)) {
     ScalarFetch f;
     f.add(d_req.p, 4 * P, req.data());
     f.add(d_cnt.p, P * P, cnt.data());
+    if (mine_ok) {
+      f.add(plan.blk_toff.p + snb, 1, &plan.total);
+      f.add(plan_stats.p + 16, 2, plan_hs);
+    }
     f.run();
   } else {
     HIP_CHECK(hipMemcpyAsync(req.data(), d_req.p, (size_t)4 * P * 8, hipMemcpyDeviceToHost, stream()));
     HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)P * P * 8, hipMemcpyDeviceToHost, stream()));
+    if (mine_ok) {
+      HIP_CHECK(hipMemcpyAsync(&plan.total, plan.blk_toff.p + snb, 8, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipMemcpyAsync(plan_hs, plan_stats.p + 16, 16, hipMemcpyDeviceToHost, stream()));
+    }
     sync_stream();
   }
+  plan.max_w = (int)plan_hs[0];
+  plan.max_kn = (int)plan_hs[1];
   exchange_stats().exchanges += 1;
   int64_t nnz_a = 0, nnz_b = 0;
   bool all_ok = true;
@@ -533,7 +556,14 @@ bool panel_slab_multiply(const PSMatrix& A, const PSMatrix& B, DevMat& AB, doubl
     if (s != me && m > 0) tr.recv(recvbuf.p + zoff[(size_t)s], (size_t)m * sizeof(double), s);
   }
   tr.group_end();
-  bool ok = kmax >= kmin;
+  // "did every rank's kernel take its panel": known to a rank once its plan is back; the sum over the ranks is enqueued
+  // here and read back with the product's entry count
+  bool ok = kmax >= kmin && slab_plan_fits_tile(plan.max_kn, plan.max_w);
+  DevBuf<double> d_declined(4);
+  double declined[4] = {ok ? 0.0 : 1.0, 0.0, 0.0, 0.0};
+  d_declined.upload(declined, 4);
+  tr.allreduce(d_declined.p, 4, true, 0);
+  bool fetched = false;
   if (ok) {
     const int32_t ka = kmin, kb = kmax + 1;
     DevBuf<int32_t> d_ra((size_t)P), nfirst((size_t)(kb - ka)), nlast((size_t)(kb - ka));
@@ -549,18 +579,28 @@ bool panel_slab_multiply(const PSMatrix& A, const PSMatrix& B, DevMat& AB, doubl
     halo.last = nlast.p;
     halo.addr = naddr.p;
     halo.row_pad = row_pad;
+    halo.plan = &plan;
+    halo.on_fetch = [&](ScalarFetch& f) {
+      f.add(d_declined.p, 1, reinterpret_cast<unsigned long long*>(&declined[0]));
+      fetched = true;
+    };
     const double denom = (double)dim * (double)dim;
     const bool dense_rule = denom > 0 && std::min((double)nnz_a / denom, (double)nnz_b / denom) > 0.1;
     // (the buffers above are released on return: the allocator is stream ordered, and slab_multiply ends with a read-back)
-    ok = slab_multiply(A.loc, B.loc, AB, alpha, threshold, dense_rule, &halo);
+    if (!slab_multiply(A.loc, B.loc, AB, alpha, threshold, dense_rule, &halo))
+      NTP_FATAL("internal: a panel product was declined after its rank had agreed to it");
   }
-  double declined = ok ? 0.0 : 1.0;
-  comm_allreduce_max(&declined, 1);
-  if (declined != 0.0) {
+  if (!fetched) {
+    ScalarFetch f;
+    f.add(d_declined.p, 1, reinterpret_cast<unsigned long long*>(&declined[0]));
+    f.run();
+  }
+  if (declined[0] != 0.0) {
     g_panel_products[1] += 1;
     return false;
   }
   g_panel_products[0] += 1;
+  g_panel_products[2] += host_sync_count() - syncs_before;   // (measured in sync_stream: the exchange's and the product's)
   return true;
 }
 }  // namespace

@@ -322,10 +322,12 @@ void ntpoly_amd_block_algebra_counts(long long* out) {
 void ntpoly_amd_slab_algebra_counts(long long* out) {
   for (int q = 0; q < 4; ++q) out[q] = slab_algebra_counts()[q];
 }
-// products of slab sessions on more than one rank since start: done in slab form on every rank, declined (compressed columns)
+// products of slab sessions on more than one rank since start: done in slab form on every rank, declined (compressed columns),
+// host synchronisations inside the former (measured)
 void ntpoly_amd_panel_product_counts(long long* out) {
   out[0] = panel_product_counts()[0];
   out[1] = panel_product_counts()[1];
+  out[2] = panel_product_counts()[2];
 }
 // searches for a bandwidth-reducing order since start: one per sparsity pattern, not per operand (the next cycle of an
 // SCF loop -- same pattern, other values -- reuses the order)

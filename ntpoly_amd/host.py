@@ -931,9 +931,9 @@ def slab_algebra_counts():
 
 def panel_product_counts():
     """products of slab sessions on more than one rank since start: done in slab form on every rank, declined"""
-    out = (C.c_longlong * 2)()
+    out = (C.c_longlong * 3)()
     lib.ntpoly_amd_panel_product_counts(out)
-    return dict(slab=out[0], declined=out[1])
+    return dict(slab=out[0], declined=out[1], host_syncs=out[2])
 
 
 def last_grouped_stats():

@@ -42,7 +42,7 @@ def main():
         p0, s0, e0 = nt.panel_product_counts(), nt.slab_algebra_counts(), nt.exchange_stats()
         fn()
         p1, s1, e1 = nt.panel_product_counts(), nt.slab_algebra_counts(), nt.exchange_stats()
-        res[tag + "_panel"] = np.array([p1["slab"] - p0["slab"], p1["declined"] - p0["declined"]])
+        res[tag + "_panel"] = np.array([p1["slab"] - p0["slab"], p1["declined"] - p0["declined"], p1["host_syncs"] - p0["host_syncs"]])
         res[tag + "_slab"] = np.array([s1[k] - s0[k] for k in ("products", "merges", "others", "refusals")])
         res[tag + "_exchanges"] = np.array([e1[0] - e0[0]])
         tr = nt.solver_trace()

@@ -65,13 +65,16 @@ def test_panel_sessions_equal_single_rank(world, reference, tmp_path):
         assert np.allclose(got[2], want[2], rtol=0, atol=1e-10), (tag, float(np.max(np.abs(got[2] - want[2]))))
     for r in range(world):
         for loop in ("trs4", "sign", "isq", "inv"):
-            slab, declined = parts[r][loop + "_panel"]
+            slab, declined, syncs = parts[r][loop + "_panel"]
             iters = int(parts[r][loop + "_iters"][0])
-            print("world", world, "rank", r, loop, "iterations", iters, "panel products", slab, "declined", declined, "slab ops",
+            print("world", world, "rank", r, loop, "iterations", iters, "panel products", slab, "declined", declined, "host syncs inside", syncs, "slab ops",
                   parts[r][loop + "_slab"], "exchanges", parts[r][loop + "_exchanges"])
             assert iters == int(reference[loop + "_iters"][0]), (loop, r)
             # every product of the loop ran on the tile kernel with its operands in slab form, on every rank
             assert slab >= iters and declined <= 1, (loop, r, slab, declined, iters)
+            # ... at TWO host round trips each, as on one rank (MEASURED in sync_stream): the exchange layout with the product's
+            # plan, then the entry count with "every rank's kernel took its panel"; operands entering slab form add a few
+            assert syncs <= 2 * slab + 8, (loop, r, syncs, slab)
         assert np.allclose(parts[r]["trs4_scal"], reference["trs4_scal"], rtol=1e-11, atol=1e-9)
         assert np.allclose(parts[r]["trs4_log"], reference["trs4_log"], rtol=1e-11, atol=1e-9)
 

@@ -99,19 +99,43 @@ def main():
                          host_syncs_per_step_measured=syncs, halo_bytes_per_step=halo_bytes, halo_us=t_halo_us,
                          extent_allgather_us=t_gather_us, extra_host_round_trip_us=extra_sync_us,
                          modelled_ms_per_step=model_ms, modelled_iters_per_s=1e3 / model_ms))
-        del H, X, X2, Ident, pool
+        # ---- TRS4 (two products per iteration, the loop's matrices in slab form: a slab session on one rank, a session of
+        # column panels on several -- psmatrix.cpp panel_slab_multiply): the one-rank loop at N / P measured; each of a panel
+        # product's exchanges adds the halo of its left operand, the extent all-gather, the reduction of "every rank took its
+        # panel" (4 doubles) and eight small launches (request, extents + scan, counts, plan, pack, layout), and the two
+        # reductions of the traces ride on the loop's read-backs as on one rank
+        p4 = nt.SolverParameters()
+        p4.SetThreshold(thr)
+        p4.SetConvergeDiff(1e-30)
+        p4.SetMaxIterations(12)
+        p4.SetMonitorConvergence(False)
+        K = nt.Matrix_ps(n)
+        for _ in range(2):   # (the second solve is the warm one)
+            nt.DensityMatrixSolvers.TRS4(H, Ident, n / 2.0, K, p4)
+        tr4 = nt.solver_trace()
+        trs4_ms = tr4["loop_ms"] / max(1, tr4["iterations"])
+        per_col4 = K.GetSize() / n
+        halo4 = 2.0 * (per_col4 / 2.0) * per_col4 * 8.0
+        t_prod_us = ((halo4 / 2.0) / (XGMI_LINK_GBS * 1e3) + t_gather_us + 16.0 + 5.0) if P > 1 else 0.0
+        rows[-1].update(trs4_measured_share_ms_per_iteration=trs4_ms, trs4_halo_bytes_per_product=halo4,
+                        trs4_exchange_us_per_product=t_prod_us, trs4_modelled_ms_per_iteration=trs4_ms + 2.0 * t_prod_us * 1e-3)
+        del H, X, X2, Ident, pool, K
     rows = rows[1:]
     base = rows[0]["modelled_ms_per_step"]
     for r in rows:
         r["modelled_speedup"] = base / r["modelled_ms_per_step"]
         r["modelled_efficiency"] = r["modelled_speedup"] / r["ranks"]
+        r["trs4_modelled_speedup"] = rows[0]["trs4_modelled_ms_per_iteration"] / r["trs4_modelled_ms_per_iteration"]
+        r["trs4_modelled_efficiency"] = r["trs4_modelled_speedup"] / r["ranks"]
     print(json.dumps({
         "what": "MODEL, not a measurement of several GPUs: one rank's share of a P-rank TRS2 step measured on ONE MI355X "
                 "(banded operand of dimension N / P, every launch and read-back of the step included) + the preparation of the next "
                 "step's exchange (five small launches; a host round trip with exchange_ahead = 0) + halo bytes / 153 GB/s per xGMI "
                 "link + a ring all-gather of 8 B per column.  A RELABELLED operand costs the same per step on several ranks: the "
-                "solver recovers the band once per solve and redistributes the operands (csrc/band_scope.cpp); TRS4 / sign / "
-                "square-root loops across ranks multiply panels through the halo exchange without slab sessions (not modelled)",
+                "solver recovers the band once per solve and redistributes the operands (csrc/band_scope.cpp).  TRS4 rows: the one-rank "
+                "loop at N / P (slab session) + per product the halo of the left operand, the extent all-gather, eight small launches "
+                "and a 4-double reduction (sessions of column panels, option panel_sessions; tests/test_gpu_panel_sessions.py measures two "
+                "host round trips per product, as on one rank)",
         "n": args.n, "halfband": h, "threshold": thr, "arithmetic": args.arithmetic,
         "host_round_trip_us": sync_us, "xgmi_link_GBps": XGMI_LINK_GBS, "table": rows}, indent=1))
 
