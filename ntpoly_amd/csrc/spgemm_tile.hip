@@ -113,13 +113,23 @@ __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax, int lab_ro
 #endif
 
 template <int EPI, int TILE_NW, int R, bool LAB>
-__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((EPI == 0 || R <= 2) ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
+__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(((EPI == 0 || !LAB) && R <= 2) ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = xcd_block(a.nblocks);
   if (b < 0) return;
   const int tid = threadIdx.x, wave = uni_i32(tid / WAVE), lane = lane_id();
   const int lo = a.blk_lo[b], w = a.blk_w[b], kmin = a.blk_kmin[b], kn = a.blk_kn[b];
   const int64_t tbase = a.blk_toff[b];
+  // (the multiplier tile comes from the runs of the block's columns: their extents depend on the block's number only and are
+  // requested HERE, together with the plan's scalars -- a memory round trip less in front of the tile's values)
+  const bool brun = a.brun_val != nullptr;
+  int bf0 = INT_MAX, bl0 = -1, bf1 = INT_MAX, bl1 = -1;
+  const double *bp0 = nullptr, *bp1 = nullptr;
+  if (brun) {   // (EPI 0: the slab algebra's right operand; EPI 1 / 2: the iterate itself -- its runs are the kernel's left operand already)
+    const int c0 = b * SLAB_J + 2 * (tid & 7);
+    if (c0 < a.ncols) { bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0]; bp0 = a.brun_val + (a.brun_off[c0] - bf0); }
+    if (c0 + 1 < a.ncols) { bf1 = a.brun_first[c0 + 1]; bl1 = a.brun_last[c0 + 1]; bp1 = a.brun_val + (a.brun_off[c0 + 1] - bf1); }
+  }
   if (b == 0 && tid == 0) {   // (the end markers of the result's offset arrays)
     a.ooff[a.ncols] = a.blk_toff[a.nblocks];
     if (EPI != 0 && a.otoff) a.otoff[a.nblocks] = a.blk_toff[a.nblocks];
@@ -174,17 +184,6 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   double2 btmp[BCH];
   // (the multiplier tile from the runs of the block's columns: a thread always serves the same column pair -- NT is a
   // multiple of 8 -- and consecutive rows of a column go to threads 8 apart)
-  [[maybe_unused]] bool brun = false;
-  [[maybe_unused]] int bf0 = INT_MAX, bl0 = -1, bf1 = INT_MAX, bl1 = -1;
-  [[maybe_unused]] const double *bp0 = nullptr, *bp1 = nullptr;
-  {   // (EPI 0: the slab algebra's right operand; EPI 1 / 2: the iterate itself -- its runs are the kernel's left operand already)
-    brun = a.brun_val != nullptr;
-    if (brun) {
-      const int c0 = b * SLAB_J + 2 * (tid & 7);
-      if (c0 < a.ncols) { bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0]; bp0 = a.brun_val + (a.brun_off[c0] - bf0); }
-      if (c0 + 1 < a.ncols) { bf1 = a.brun_first[c0 + 1]; bl1 = a.brun_last[c0 + 1]; bp1 = a.brun_val + (a.brun_off[c0 + 1] - bf1); }
-    }
-  }
   auto brun_load = [&](int i) {
     const int r = kmin + (i >> 3);
     double2 v;
@@ -197,6 +196,15 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     const int i = tid + u * NT;
     if (brun) btmp[u] = brun_load(i);
     else btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+  }
+  // (label-aware kernels: the caller's labels of the window's rows are requested with the tile and the records -- not in a
+  // round trip of their own behind the barrier -- and stored with them)
+  constexpr int LABCH = LAB ? 4 : 0;
+  [[maybe_unused]] int labtmp[LABCH > 0 ? LABCH : 1];
+  if constexpr (LAB) {
+    const int32_t* __restrict__ lab_g = a.fzv.lab;
+#pragma unroll
+    for (int u = 0; u < LABCH; ++u) labtmp[u] = lab_g[min(lo + tid + u * NT, a.ncols - 1)];
   }
   {
     // one thread per record (all loads independent and in flight together with the tile's), the row range of a k
@@ -248,6 +256,11 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     else bdst[i] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
   }
   STAMP(61);
+  if constexpr (LAB) {
+#pragma unroll
+    for (int u = 0; u < LABCH; ++u)
+      if (tid + u * NT < T * TROWS) labs[tid + u * NT] = labtmp[u];
+  }
   for (int t = tid; t < T; t += NT) colmask[t] = 0u;
   if (tid < 16) {
     col_cnt[tid] = 0;
@@ -274,11 +287,11 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       if (lane == 0 && p) atomicAdd(reinterpret_cast<unsigned long long*>(misc + 2), (unsigned long long)p);
     }
   }
-  if constexpr (LAB) {
+  if constexpr (LAB) {   // (the labels beyond the first LABCH per thread, requested above)
     const int32_t* __restrict__ lab_g = a.fzv.lab;
-    for (int i = tid; i < T * TROWS; i += TILE_NW * WAVE) labs[i] = lab_g[min(lo + i, a.ncols - 1)];
+    for (int i = tid + LABCH * NT; i < T * TROWS; i += NT) labs[i] = lab_g[min(lo + i, a.ncols - 1)];
+    __syncthreads();
   }
-  __syncthreads();
   STAMP(1);
 
   // ---- per-lane constants: this lane's column is jj = lane % 16 in every tile
