@@ -2677,6 +2677,7 @@ EngineOptions& options() {
     if (const char* v = std::getenv("NTPOLY_AMD_PLAN_AHEAD")) e->plan_ahead = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_SLAB_ALGEBRA")) e->slab_algebra = std::atoi(v);
     if (const char* v = std::getenv("NTPOLY_AMD_PANEL_SESSIONS")) e->panel_sessions = std::atoi(v);
+    if (const char* v = std::getenv("NTPOLY_AMD_BLOCK_UNFUSED")) e->block_unfused = std::atoi(v);
     return e;
   }();
   return *o;
@@ -3223,7 +3224,7 @@ namespace {
 // the block path (spgemm_block.hip) with spgemm()'s book-keeping around it
 int g_block_keep = 0;           // > 0: a caller that understands DevMat::blk is waiting for the product (BlockKeepScope)
 bool block_eligible(const DevMat& A, const DevMat& B, const ColRange* arange) {
-  return !arange && !A.cplx && !B.cplx && options().spgemm_fma == 1 && options().block_path != 0 && options().spgemm_variant < 0 &&
+  return !arange && !A.cplx && !B.cplx && block_arithmetic_ok() && options().block_path != 0 && options().spgemm_variant < 0 &&
          options().spgemm_force_bin <= 0 && A.rows == A.cols && B.rows == B.cols && A.cols == B.rows;
 }
 bool try_block_path(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule) {

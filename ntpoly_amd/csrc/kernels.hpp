@@ -80,6 +80,7 @@ struct EngineOptions {
                                // are (the shape only selects the summation semantics of the multiply: slices > 1)
   int fused_update = 1;        // TRS2 on one rank, real operands: the update X <- 2X - X*X (or X*X), its energy and its trace
                                // come out of the epilogue of the register-slab kernel; 0: separate merge / reduction passes
+  int block_unfused = 0;       // the block path (spgemm_block.hip) in UNFUSED arithmetic too: products rounded, then added, on the vector units, in ascending POSITION of the block order -- the reference's default build on the matrix relabelled by that order (what its own load balancer does), 1e-13 of the sums over ascending labels.  0 (default): operands without runs keep the label-ordered kernels in unfused arithmetic, bit for bit the reference on the caller's labels
   int panel_sessions = 1;      // slab sessions (TRS4, sign, inverse, square roots, polynomials ...) on more than one rank: the loops' matrices stay in slab form as column panels, a product exchanges the runs of the left operand's halo (psmatrix.cpp panel_slab_multiply); 0: compressed columns across ranks
   int plan_fused = 1;          // the maxima and prefix sums of a slab step's plan in ONE launch (k_slab_offsets: every workgroup sums what lies before its part itself) instead of four to seven; 0: separate launches
   int exchange_ahead = 1;      // panel steps across ranks: a step prepares the NEXT step's exchange (extents all-gathered, counts, plan) from its result and reads it back with its own totals -- one host round trip per panel step (psmatrix.cpp PanelExchange); 0: two
@@ -221,6 +222,8 @@ void slab_counts_async(const DevMat& X, int64_t* d_cnt64);
 // cannot take them (the caller packs and takes the general path).
 bool slab_enter(DevMat& M);   // compressed columns -> slab form in place (false: not run-like, stored zeros, complex ...)
 bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, const SlabHalo* left = nullptr);
+// the arithmetic modes the block path computes: the FMA chain (matrix cores) and, on request, unfused (vector units)
+inline bool block_arithmetic_ok() { return options().spgemm_fma == 1 || (options().spgemm_fma == 0 && options().block_unfused != 0); }
 bool slab_panels_ok();
 void slab_allow_panels(bool on);   // a slab session across ranks: the operands of the slab algebra are column panels (rows != columns)
 // complex operands in slab form (FMA arithmetic, option complex_tile; a session that allows them): runs of (re, im) pairs in

@@ -720,8 +720,15 @@ __device__ inline v4d bs_zero4() { const v4d z = {0.0, 0.0, 0.0, 0.0}; return z;
 // HV = waves per candidate: 2 (each wave owns NX = 2 row blocks; operands with sparse tiles, where the waves' load round
 // trips pace the kernel) or 1 (one wave owns all four: every B tile is read once; operands with dense tiles -- a relabelled
 // band at fill 0.7: 4.7 ms against 6.7 with two waves)
-template <int HV>
-__global__ __launch_bounds__(64 * HV) void k_bs_numeric(const BsArgs a) {
+// UNF (unfused arithmetic, option spgemm_fma = 0: every product rounded, then added -- the reference's default x86-64 build):
+// the same walk with the tile products on the vector units.  Lane (g, n) owns the in-tile rows 4 g .. 4 g + 3 of in-tile
+// column n of every accumulator tile; per pair of tiles and per slice of four k positions that has entries on both sides it
+// adds round(A(row, k) B(k, n)) for the slice's positions k in ASCENDING POSITION -- with the matches, blocks and slices
+// walked in ascending position as well every entry is the reference's sum in ascending k of the relabelled matrix (zeros
+// inside a tile are exact no-ops).  The column of the B tile sits in 16 registers (one load per k, the lanes of a column
+// share their lines), the four rows of the A tile's column k are two 16-byte loads that the 16 lanes of a group share.
+template <int HV, bool UNF = false>
+__global__ __launch_bounds__(64 * HV) __attribute__((amdgpu_waves_per_eu(UNF ? 3 : 2, 8))) void k_bs_numeric(const BsArgs a) {
   constexpr int NX = 4 / HV;
   __shared__ unsigned wmask[HV];
   __shared__ int wcount[HV];
@@ -774,6 +781,41 @@ __global__ __launch_bounds__(64 * HV) void k_bs_numeric(const BsArgs a) {
         const unsigned colA = (mA >> (4 * kb + NX * h)) & ((1u << NX) - 1u);     // bit x: tile A(NX h + x, kb)
         const unsigned rowB = (mB >> kb) & 0x1111u;              // bit 4 b: tile B(kb, b)
         if (colA == 0 || rowB == 0) continue;
+        if constexpr (UNF) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            if (!(rowB & (1u << (4 * b)))) continue;
+            const double* __restrict__ pB = tB + __popc(mB & ((1u << (4 * b + kb)) - 1u)) * 256;
+            const unsigned rb4 = (unsigned)(rqB >> (4 * (4 * b + kb))) & 15u;     // row slices of B(kb, b) with entries
+            double bcol[16];      // bcol[k] = B(position k of the block, column n)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) bcol[k] = pB[tile_word(phys(k), m)];
+#pragma unroll
+            for (int x = 0; x < NX; ++x) {
+              if (!(colA & (1u << x))) continue;
+              const unsigned m4 = rb4 & ((unsigned)(cqA >> (4 * (4 * kb + NX * h + x))) & 15u);
+              if (m4 == 0u) continue;
+              const double* __restrict__ pA = tA + __popc(mA & ((1u << (4 * kb + NX * h + x)) - 1u)) * 256;
+#pragma unroll
+              for (int qq = 0; qq < 4; ++qq) {
+                if (!(m4 & (1u << qq))) continue;     // (slice qq = positions 4 qq .. 4 qq + 3: empty on one side)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int k = 4 * qq + kk, c = phys(k);
+                  const v2d a01 = *reinterpret_cast<const v2d*>(pA + c * 16 + ((((2 * g) ^ (c >> 1)) & 7) << 1));
+                  const v2d a23 = *reinterpret_cast<const v2d*>(pA + c * 16 + ((((2 * g + 1) ^ (c >> 1)) & 7) << 1));
+                  const double bv = bcol[k];
+                  acc[x][b][0] = __dadd_rn(acc[x][b][0], __dmul_rn(a01[0], bv));
+                  acc[x][b][1] = __dadd_rn(acc[x][b][1], __dmul_rn(a01[1], bv));
+                  acc[x][b][2] = __dadd_rn(acc[x][b][2], __dmul_rn(a23[0], bv));
+                  acc[x][b][3] = __dadd_rn(acc[x][b][3], __dmul_rn(a23[1], bv));
+                }
+                nprod += 1;
+              }
+            }
+          }
+          continue;
+        }
         v2d b01[4], b23[4];   // (only the fragments of existing tiles are loaded -- and read)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -1524,7 +1566,8 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
 #endif
     if (ev_begin) HIP_CHECK(hipEventRecord(ev_begin, stream()));
     // (dense tiles: one wave per candidate; sparse tiles: two)
-    if (dense_tiles) hipLaunchKernelGGL((k_bs_numeric<1>), dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
+    if (options().spgemm_fma == 0) hipLaunchKernelGGL((k_bs_numeric<2, true>), dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
+    else if (dense_tiles) hipLaunchKernelGGL((k_bs_numeric<1>), dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
     else hipLaunchKernelGGL((k_bs_numeric<2>), dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
     if (ev_end) HIP_CHECK(hipEventRecord(ev_end, stream()));
     {
@@ -1633,7 +1676,7 @@ bool block_trs2_step(DevMat& X, int mode, double threshold, bool dense_rule, con
   if (info) *info = BlockInfo();
   if (X.cplx || D.cplx || X.rows != X.cols || D.rows != X.rows || D.cols != X.cols || X.nnz == 0 || D.nnz == 0) return false;
   if (X.loose() || X.expanded() || D.loose() || D.expanded() || D.blocked()) return false;
-  if (options().spgemm_fma != 1 || options().block_path == 0 || options().spgemm_variant >= 0 || options().spgemm_force_bin > 0) return false;
+  if (!block_arithmetic_ok() || options().block_path == 0 || options().spgemm_variant >= 0 || options().spgemm_force_bin > 0) return false;
   BlockCache& bc = cache();
   const int32_t n = X.cols;
   if (!select_order(bc, n)) return false;   // (only dimensions the block path has multiplied before)
@@ -1786,7 +1829,7 @@ bool block_trs2_step(DevMat& X, int mode, double threshold, bool dense_rule, con
 // block algebra
 namespace {
 bool algebra_ok(const DevMat& M) {
-  return !M.cplx && M.rows == M.cols && !M.loose() && !M.expanded() && options().spgemm_fma == 1 && options().block_path != 0 &&
+  return !M.cplx && M.rows == M.cols && !M.loose() && !M.expanded() && block_arithmetic_ok() && options().block_path != 0 &&
          options().spgemm_variant < 0 && options().spgemm_force_bin <= 0;
 }
 // the form of an operand of the algebra in the order of its dimension (nullptr: none / other order)

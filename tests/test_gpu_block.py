@@ -43,6 +43,20 @@ def fma(nt):
     nt.set_option("slab_algebra", 1)
 
 
+@pytest.fixture()
+def unfused_block(nt):
+    """the block path in UNFUSED arithmetic (option block_unfused): every product rounded, then added, in ascending position"""
+    from oracle import oracle_py as O
+    nt.set_option("spgemm_fma", 0)
+    nt.set_option("block_unfused", 1)
+    nt.set_option("block_path", 2)
+    O.set_fma(False)
+    nt.drop_block_caches()
+    yield O
+    nt.set_option("block_unfused", 0)
+    nt.set_option("block_path", 1)
+
+
 def srt(t):
     c, r, v = t
     o = np.lexsort((r, c))
@@ -93,9 +107,7 @@ CASES = [("lattice16", 1e-8, 1.0), ("lattice20", 1e-6, 0.5), ("lattice12", 0.0, 
          ("lattice_asym", 1e-9, 1.0)]
 
 
-@pytest.mark.parametrize("kind,thr,alpha", CASES)
-def test_block_product_vs_oracle(nt, fma, kind, thr, alpha):
-    O = fma
+def block_product_case(nt, O, kind, thr, alpha):
     if kind.startswith("lattice") and kind not in ("lattice_ab", "lattice_asym"):
         L = int(kind[7:])
         n = L ** 3
@@ -138,6 +150,40 @@ def test_block_product_vs_oracle(nt, fma, kind, thr, alpha):
     Bo = Ao if tb is ta else O.Mat.from_triplets(n, n, *tb)
     want = srt(O.ps_multiply(Ao, Bo, None, alpha, 0.0, thr).triplets())
     close(got, want, n, thr, kind + " (caller's labels)")
+
+
+@pytest.mark.parametrize("kind,thr,alpha", CASES)
+def test_block_product_vs_oracle(nt, fma, kind, thr, alpha):
+    block_product_case(nt, fma, kind, thr, alpha)
+
+
+@pytest.mark.parametrize("kind,thr,alpha", [CASES[0], CASES[2], CASES[4], CASES[5]])
+def test_block_product_vs_oracle_unfused(nt, unfused_block, kind, thr, alpha):
+    """option block_unfused: the same parity statement in UNFUSED arithmetic (MultiplyBlock.f90:33 as the reference's default
+    x86-64 build computes it: product rounded, then added) -- bit for bit the oracle's unfused mode on the matrices relabelled
+    by the engine's positions, 1e-13 against the sums over ascending labels"""
+    block_product_case(nt, unfused_block, kind, thr, alpha)
+
+
+def test_unfused_arithmetic_keeps_the_label_order_by_default(nt):
+    """without the option a lattice product in unfused arithmetic stays off the block path: bit for bit the oracle on the caller's labels"""
+    from oracle import oracle_py as O
+    nt.set_option("spgemm_fma", 0)
+    nt.set_option("block_path", 2)
+    O.set_fma(False)
+    nt.drop_block_caches()
+    try:
+        L = 12
+        n = L ** 3
+        ta = lattice_case(L)
+        A = nt.Matrix_ps.from_triplets(n, *ta)
+        C = nt.Matrix_ps(n)
+        C.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+        assert nt.last_block_stats()["used"] == 0
+        Ao = O.Mat.from_triplets(n, n, *ta)
+        exact(C.triplets(), O.ps_multiply(Ao, Ao, None, 1.0, 0.0, 1e-8).triplets(), "unfused lattice on the caller's labels")
+    finally:
+        nt.set_option("block_path", 1)
 
 
 def test_block_path_is_declined_for_unstructured_operands(nt, fma):
