@@ -85,6 +85,16 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(R == 1
   const int tid = threadIdx.x, wave = uni_i32(tid / WAVE), lane = lane_id();
   const int lo = a.blk_lo[b], w = a.blk_w[b], kmin = a.blk_kmin[b], kn = a.blk_kn[b];
   const int64_t tbase = a.blk_toff[b];
+  // (the multiplier tile from the runs of the block's columns: unit i of the tile is row kmin + i / 8 of column i % 8, and a
+  // thread always serves the same column -- NT is a multiple of 8.  The columns' extents depend on the block's number only and
+  // are requested HERE, with the plan's scalars: a memory round trip less in front of the tile's values)
+  const bool brun = a.brun_val != nullptr;
+  int bf0 = INT_MAX, bl0 = -1;
+  const double2* bp0 = nullptr;
+  if (brun) {
+    const int c0 = b * CJ + (tid & 7);
+    if (c0 < a.ncols) { bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0]; bp0 = a.brun_val + (a.brun_off[c0] - bf0); }
+  }
   if (b == 0 && tid == 0) a.ooff[a.ncols] = a.blk_toff[a.nblocks];
   if (kn == 0) {   // no product entries in these columns
     const int j = b * CJ + tid;
@@ -110,18 +120,9 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(R == 1
   const int T = (w + 15) >> 4;
   // ---- block prologue: multiplier tile -> LDS (rows kn .. K4 zero), run records + row range of every k group
   constexpr int NT = NW * WAVE, BCH = 3072 / NT;
-  const bool brun = a.brun_val != nullptr;
   const double2* __restrict__ bsrc = brun ? a.brun_val : a.bblk + a.blk_boff[b];
   double2* bdst = reinterpret_cast<double2*>(Bs);
   double2 btmp[BCH];
-  // (the multiplier tile from the runs of the block's columns: unit i of the tile is row kmin + i / 8 of column i % 8, and a
-  // thread always serves the same column -- NT is a multiple of 8)
-  int bf0 = INT_MAX, bl0 = -1;
-  const double2* bp0 = nullptr;
-  if (brun) {
-    const int c0 = b * CJ + (tid & 7);
-    if (c0 < a.ncols) { bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0]; bp0 = a.brun_val + (a.brun_off[c0] - bf0); }
-  }
   auto brun_load = [&](int i) {
     const int r = kmin + (i >> 3);
     return (i < kn * 8 && r >= bf0 && r <= bl0) ? bp0[r] : make_double2(0.0, 0.0);
