@@ -697,7 +697,53 @@ struct BsArgs {
   int dense_rule;
   int nwg;
   int ablate;            // experiment build (-DNTP_ABLATIONS) only: 1 no A loads, 2 no B loads, 3 no matrix instructions (WRONG results)
+  // the matches of every candidate -- the K with super-tiles on both sides, ascending, as (index of A's super-tile, index of B's)
+  // -- found by k_bs_match before the numeric kernel (option block_match; nullptr: the numeric kernel searches itself)
+  const int64_t* moff;
+  const int32_t* mcnt;
+  const int2* mlist;
 };
+
+// The intersection of super-row I of A and super-column J of B for every candidate, ONCE and in a kernel of its own: a wave per
+// candidate with a handful of registers (eight and more waves per SIMD cover the seven dependent loads of a binary search)
+// instead of inside the numeric kernel, where three fat waves per SIMD wait for them and both waves of a candidate repeat
+// them.  Matches are written in ascending K (the order of the FMA chain).
+__global__ __launch_bounds__(256) void k_bs_match_bound(int64_t ncand, const int32_t* __restrict__ ci, const int32_t* __restrict__ cj,
+                                                        const int64_t* __restrict__ roffA, const int64_t* __restrict__ soffB,
+                                                        int32_t* __restrict__ bound) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= ncand) return;
+  const int I = ci[c], J = cj[c];
+  bound[c] = (int32_t)min(roffA[I + 1] - roffA[I], soffB[J + 1] - soffB[J]);
+}
+__global__ __launch_bounds__(256) void k_bs_match(int64_t ncand, const int32_t* __restrict__ ci, const int32_t* __restrict__ cj,
+                                                  const int64_t* __restrict__ roffA, const int32_t* __restrict__ rcolA,
+                                                  const int32_t* __restrict__ ridxA, const int64_t* __restrict__ soffB,
+                                                  const int32_t* __restrict__ srowB, const int64_t* __restrict__ moff,
+                                                  int2* __restrict__ mlist, int32_t* __restrict__ mcnt) {
+  const int64_t cand = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE;
+  if (cand >= ncand) return;
+  const int lane = lane_id();
+  const int I = ci[cand], J = cj[cand];
+  const int64_t ra0 = roffA[I], ra1 = roffA[I + 1], cb0 = soffB[J], cb1 = soffB[J + 1];
+  int2* __restrict__ out = mlist + moff[cand];
+  int cnt = 0;
+  for (int64_t base = ra0; base < ra1; base += WAVE) {
+    const int64_t e = base + lane;
+    const bool in = e < ra1;
+    const int K = in ? rcolA[e] : INT_MAX;
+    int64_t lo = cb0, hi = cb1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (srowB[mid] < K) lo = mid + 1; else hi = mid;
+    }
+    const bool found = in && lo < cb1 && srowB[lo] == K;
+    const unsigned long long m = __ballot(found);
+    if (found) out[cnt + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(ridxA[e], (int)lo);
+    cnt += (int)__popcll(m);
+  }
+  if (lane == 0) mcnt[cand] = cnt;
+}
 
 __device__ inline v4d bs_zero4() { const v4d z = {0.0, 0.0, 0.0, 0.0}; return z; }
 
@@ -752,18 +798,30 @@ __global__ __launch_bounds__(64 * HV) __attribute__((amdgpu_waves_per_eu(UNF ? 3
   const int blo = m * 16 + (((2 * g) ^ (m >> 1)) & 7) * 2;      // B role: rows 4 g, 4 g + 1 of column m; rows 4 g + 2, 4 g + 3 in the
   const int bhi = m * 16 + (((2 * g + 1) ^ (m >> 1)) & 7) * 2;  // neighbouring chunk
   unsigned nprod = 0;
-  for (int64_t base = ra0; base < ra1; base += WAVE) {
+  const bool listed = a.mlist != nullptr;
+  const int64_t m0 = listed ? uni_i64(a.moff[cand]) : 0;
+  const int64_t w0 = listed ? 0 : ra0, w1 = listed ? (int64_t)uni_i32(a.mcnt[cand]) : ra1;
+  for (int64_t base = w0; base < w1; base += WAVE) {
     const int64_t e = base + lane;
-    const bool in = e < ra1;
-    const int K = in ? a.rcolA[e] : INT_MAX;
-    const int ia = in ? a.ridxA[e] : 0;
-    int64_t lo = cb0, hi = cb1;
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (a.srowB[mid] < K) lo = mid + 1; else hi = mid;
+    const bool in = e < w1;
+    int ia, ib;
+    bool found;
+    if (listed) {   // (the matches were found by k_bs_match: 64 of them per load)
+      const int2 pr = in ? a.mlist[m0 + e] : make_int2(0, 0);
+      ia = pr.x;
+      ib = pr.y - (int)cb0;
+      found = in;
+    } else {
+      const int K = in ? a.rcolA[e] : INT_MAX;
+      ia = in ? a.ridxA[e] : 0;
+      int64_t lo = cb0, hi = cb1;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a.srowB[mid] < K) lo = mid + 1; else hi = mid;
+      }
+      found = in && lo < cb1 && a.srowB[lo] == K;
+      ib = (int)(lo - cb0);
     }
-    const bool found = in && lo < cb1 && a.srowB[lo] == K;
-    const int ib = (int)(lo - cb0);
     unsigned long long match = __ballot(found);
     while (match) {
       const int l = __ffsll((long long)match) - 1;
@@ -1540,6 +1598,27 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
     DevBuf<char> tmp(tb);
     HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, zk.p, zk_s.p, zi.p, order.p, (size_t)ncand, 0, 32, stream()));
   }
+  // ---- the matches of every candidate (option block_match): slots by the upper bound min(entries of A's super-row, entries of
+  // B's super-column), filled in ascending K by a wave per candidate
+  DevBuf<int64_t> moff;
+  DevBuf<int32_t> mcnt;
+  DevBuf<int2> mlist;
+  if (options().block_match != 0) {
+    DevBuf<int32_t> bound((size_t)ncand);
+    moff.alloc((size_t)ncand + 1);
+    mcnt.alloc((size_t)ncand);
+    hipLaunchKernelGGL(k_bs_match_bound, dim3(grid1(ncand)), dim3(256), 0, stream(), ncand, ci.p, cj.p, FA.roff.p, FB.soff.p, bound.p);
+    scan_i32_async(bound.p, moff.p, ncand);
+    int64_t mtotal = 0;
+    {
+      ScalarFetch f;
+      f.add(moff.p + ncand, 1, &mtotal);
+      f.run();
+    }
+    mlist.alloc((size_t)mtotal + 64);
+    hipLaunchKernelGGL(k_bs_match, dim3(gridw(ncand)), dim3(256), 0, stream(), ncand, ci.p, cj.p, FA.roff.p, FA.rcol.p, FA.ridx.p, FB.soff.p,
+                       FB.srow.p, moff.p, mlist.p, mcnt.p);
+  }
   // ---- numeric (the pool is sized from the last product of this dimension; an overflow is repeated with the exact size)
   FC = BlockForm();
   FC.order = bc.order;
@@ -1560,6 +1639,7 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
     a.pool = FC.tiles.p; a.pool_tiles = pool; a.counters = counters.p;
     a.alpha = alpha; a.threshold = threshold; a.dense_rule = dense_rule ? 1 : 0;
     a.nwg = (int)ncand;
+    a.moff = moff.p; a.mcnt = mcnt.p; a.mlist = mlist.p;
     a.ablate = 0;
 #ifdef NTP_ABLATIONS
     if (const char* v = std::getenv("NTPOLY_AMD_BS_ABLATE")) a.ablate = std::atoi(v);

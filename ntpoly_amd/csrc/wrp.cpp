@@ -164,6 +164,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "exchange_ahead") options().exchange_ahead = *value;
   else if (n == "plan_fused") options().plan_fused = *value;
   else if (n == "block_unfused") options().block_unfused = *value;
+  else if (n == "block_match") options().block_match = *value;
   else if (n == "panel_sessions") options().panel_sessions = *value;
   else if (n == "label_rowoff") options().label_rowoff = *value;
   else if (n == "block_path") options().block_path = *value;
@@ -189,6 +190,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "exchange_ahead") return options().exchange_ahead;
   if (n == "plan_fused") return options().plan_fused;
   if (n == "block_unfused") return options().block_unfused;
+  if (n == "block_match") return options().block_match;
   if (n == "panel_sessions") return options().panel_sessions;
   if (n == "fused_update") return options().fused_update;
   if (n == "loose_iterates") return options().loose_iterates;
