@@ -553,12 +553,13 @@ def main():
             line["block_path"] = dict(bs, useful_fraction_last_product=(st["products"] / issued if issued else None),
                                       issued_tflops_last_product=(2.0 * issued / (st["ms_numeric"] * 1e-3) / 1e12 if st.get("ms_numeric") else None))
     check = None
-    if not args.no_wrp_check or (world > 1 and args.permute is not None):
+    reordered = args.permute is not None or args.lattice is not None   # (operands the solver redistributes on several ranks)
+    if not args.no_wrp_check or (world > 1 and reordered):
         del X, X2
         check = trs2_wrp_check(nt, H, n, thr)       # (collective: every rank takes part)
-    if rank == 0 and world > 1 and args.permute is not None and check:
-        # A relabelled operand on several ranks: the SOLVER recovers the band once per solve and redistributes the operands
-        # (csrc/band_scope.cpp); the step API above works on the caller's distribution and cannot.  The line's value is
+    if rank == 0 and world > 1 and reordered and check:
+        # A relabelled or 3-D operand on several ranks: the SOLVER recovers the band (or takes the pattern's block order) once per
+        # solve and redistributes the operands (csrc/band_scope.cpp); the step API above works on the caller's distribution and cannot.  The line's value is
         # therefore the rate of the reference's own entry point, TRS2_wrp, differenced over two iteration counts.
         line["value_of_the_step_api"] = line["value"]
         line["value"] = check["iters_per_s"]

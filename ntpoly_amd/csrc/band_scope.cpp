@@ -18,13 +18,20 @@
 #include <functional>
 #include <vector>
 
+#include <algorithm>
+#include <numeric>
+
 #include "engine.hpp"
 #include "kernels.hpp"
+#include "spgemm_block.hpp"
 
 namespace ntp {
 namespace {
 struct BandOrderCache {
   bool searched = false, found = false;
+  bool block_tried = false, block_found = false;   // no band: the pattern's block order (spgemm_block.hip) instead
+  int32_t block_ns = 0;
+  std::vector<int32_t> block_pos;                  // block_pos[label] = position in [0, 64 block_ns)
   unsigned long long fingerprint = 0;
   int32_t n = 0;
   int64_t nnz = 0;
@@ -35,7 +42,8 @@ BandOrderCache& band_cache() {
   return *c;
 }
 int g_scope_depth = 0;
-long long g_scope_counts[2] = {0, 0};   // solves run in a recovered band order, operands looked at
+bool g_block_scope = false;             // the solve in progress runs on operands redistributed in a BLOCK order
+long long g_scope_counts[3] = {0, 0, 0};   // solves run in a recovered band order, operands looked at, solves run in a block order
 
 // out(map[r], map[c]) = in(r, c), column panels as the grid says (ps_permute with an explicit map)
 void relabel_ps(const PSMatrix& in, PSMatrix& out, const int32_t* d_map) {
@@ -54,6 +62,7 @@ void relabel_ps(const PSMatrix& in, PSMatrix& out, const int32_t* d_map) {
 }  // namespace
 
 const long long* band_scope_counts() { return g_scope_counts; }
+bool block_scope_active() { return g_block_scope; }
 
 bool band_scope_try(const std::vector<const PSMatrix*>& ins, const std::vector<PSMatrix*>& outs,
                     const std::function<void(const std::vector<const PSMatrix*>&, const std::vector<PSMatrix*>&)>& run) {
@@ -85,6 +94,9 @@ bool band_scope_try(const std::vector<const PSMatrix*>& ins, const std::vector<P
   if (!(c.searched && c.fingerprint == fp && c.n == n && c.nnz == full.nnz)) {
     c.searched = true;
     c.found = false;
+    c.block_tried = false;
+    c.block_found = false;
+    c.block_pos.clear();
     c.fingerprint = fp;
     c.n = n;
     c.nnz = full.nnz;
@@ -99,12 +111,42 @@ bool band_scope_try(const std::vector<const PSMatrix*>& ins, const std::vector<P
     if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
       std::fprintf(stderr, "[band scope] pattern %016llx: %s (bandwidth %lld)\n", fp, c.found ? "band recovered" : "no band", (long long)bw);
   }
+  // No band (a 3-D operand): the solve in the pattern's BLOCK order instead -- the index set clustered into blocks of 16 and
+  // super-blocks of 64 (spgemm_block.hip), the operands redistributed so that a rank owns a contiguous range of positions;
+  // its panel products then run on the block path (psmatrix.cpp multiply_panel) instead of the LDS hash.  Same contract as the
+  // band order: the reference's solve under its load balancer with this permutation.
+  bool block_mode = false;
+  std::vector<int32_t> perm;   // perm[label] = new label
+  if (!c.found && options().block_scope != 0 && options().block_path != 0 && options().spgemm_fma == 1 && !H.cplx) {
+    if (!c.block_tried) {
+      c.block_tried = true;
+      c.block_found = block_order_of_pattern(full, c.block_pos, &c.block_ns);
+      if (std::getenv("NTPOLY_AMD_DEBUG_SPGEMM"))
+        std::fprintf(stderr, "[band scope] pattern %016llx: %s\n", fp, c.block_found ? "block order" : "no block order");
+    }
+    if (c.block_found) {
+      // new labels = ranks of the positions (the padding slots of the order drop out); the order in the new labels keeps its
+      // positions -- monotone, so a panel of consecutive labels is a range of positions
+      std::vector<int32_t> idx((size_t)n);
+      std::iota(idx.begin(), idx.end(), 0);
+      std::sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return c.block_pos[(size_t)x] < c.block_pos[(size_t)y]; });
+      perm.resize((size_t)n);
+      std::vector<int32_t> pos_new((size_t)n);
+      for (int32_t i = 0; i < n; ++i) {
+        perm[(size_t)idx[(size_t)i]] = i;
+        pos_new[(size_t)i] = c.block_pos[(size_t)idx[(size_t)i]];
+      }
+      install_block_positions(n, c.block_ns, pos_new);
+      block_mode = true;
+    }
+  }
   full = DevMat();
-  if (!c.found) return false;
+  if (!c.found && !block_mode) return false;
+  const std::vector<int32_t>& fwd = block_mode ? perm : c.pos;
   std::vector<int32_t> inv((size_t)n);
-  for (int32_t i = 0; i < n; ++i) inv[(size_t)c.pos[(size_t)i]] = i;
+  for (int32_t i = 0; i < n; ++i) inv[(size_t)fwd[(size_t)i]] = i;
   DevBuf<int32_t> d_pos((size_t)n), d_inv((size_t)n);
-  d_pos.upload(c.pos.data(), (size_t)n);
+  d_pos.upload(fwd.data(), (size_t)n);
   d_inv.upload(inv.data(), (size_t)n);
   std::vector<PSMatrix> in_b(ins.size()), out_b(outs.size());
   std::vector<const PSMatrix*> in_p;
@@ -118,10 +160,12 @@ bool band_scope_try(const std::vector<const PSMatrix*>& ins, const std::vector<P
     out_p.push_back(&out_b[i]);
   }
   g_scope_depth += 1;
+  g_block_scope = block_mode;
   run(in_p, out_p);
+  g_block_scope = false;
   g_scope_depth -= 1;
   for (size_t i = 0; i < outs.size(); ++i) relabel_ps(out_b[i], *outs[i], d_inv.p);
-  g_scope_counts[0] += 1;
+  g_scope_counts[block_mode ? 2 : 0] += 1;
   return true;
 }
 

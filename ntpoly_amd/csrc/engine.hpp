@@ -119,6 +119,8 @@ bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double be
 void ps_slab_leave(PSMatrix& m);
 const long long* column_fused_counts();   // [2] since start: IncrementMatrix(Identity, .) done in place, norms of differences taken without forming them (column_fused.hip)
 const long long* block_algebra_counts();  // [2] since start: operations done in block form (spgemm_block.hpp block algebra); fallbacks
+long long block_scope_products();   // panel products of block-order solves that took the block path (psmatrix.cpp)
+bool block_scope_active();   // band_scope.cpp: the solve in progress runs on operands redistributed in a block order (several ranks)
 const long long* panel_product_counts();  // [3] products of slab sessions across ranks: in slab form on every rank; declined; host synchronisations inside the former
 const long long* slab_algebra_counts();   // [4] since start: products, merges / copies, other operations done in slab form; refusals   // back to compressed columns (no-op for a matrix that is not in slab form)
 void ps_fill_identity(PSMatrix& m);

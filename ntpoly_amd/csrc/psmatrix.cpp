@@ -440,6 +440,7 @@ void ps_to_real(const PSMatrix& a, PSMatrix& out) {
 namespace {
 bool exchange_fits_fetch(int P);
 int panel_pitch(int32_t dim, int P, bool with_counts, int* wcols_out);
+long long g_block_scope_products = 0;   // panel products of block-order solves (band_scope.cpp) that took the block path
 long long g_panel_products[3] = {0, 0, 0};   // products of slab sessions across ranks: done in slab form on every rank; declined; host synchronisations inside the former
 
 // C = alpha A B of a slab session on more than one rank: A, B column panels in slab form, the result a column panel in slab
@@ -605,6 +606,7 @@ bool panel_slab_multiply(const PSMatrix& A, const PSMatrix& B, DevMat& AB, doubl
 }
 }  // namespace
 const long long* panel_product_counts() { return g_panel_products; }
+long long block_scope_products() { return g_block_scope_products; }
 
 namespace {
 // alpha * A * B with the threshold, local panel of the result (slices == 1 semantics: every output entry is one sum
@@ -624,7 +626,32 @@ DevMat multiply_panel(const PSMatrix& A, const PSMatrix& B, double alpha, double
     gather_needed_begin(hx, A, B.loc, nz, true);
     const bool dense_rule = denom > 0 && std::min((double)nz[0] / (denom * a_fraction), (double)nz[1] / denom) > 0.1;
     const ColRange need{hx.kmin, hx.kmax + 1};   // the rows of the B panel name these columns only
-    if (!hx.overlapped) {
+    // A solve in a block order (band_scope.cpp: 3-D operands on several ranks): the panel of B as the columns c0 .. c1 of a
+    // square matrix whose other columns are empty, the product through the block path -- tiles of the order the scope
+    // installed, candidates in this rank's super-columns only -- and the panel's columns cut out of the result
+    const bool block_route = block_scope_active() && !A.cplx && !B.cplx && options().spgemm_fma == 1 && options().block_path != 0 &&
+                             a_fraction == 1.0;
+    if (block_route) {
+      hx.finish();
+      DevMat Csq;
+      {
+        MatView Bsq;
+        DevBuf<int64_t> pad_outer((size_t)B.dim + 1);
+        fill_i64(pad_outer.p, B.c0, 0);
+        copy_shift_i64(B.loc.outer.p, pad_outer.p + B.c0, (int64_t)(B.c1 - B.c0) + 1, 0);
+        fill_i64(pad_outer.p + B.c1 + 1, (int64_t)B.dim - B.c1, B.loc.nnz);
+        Bsq.alias(B.loc, pad_outer.p, B.dim, B.loc.nnz);
+        hx.full.block_hint = 1;   // (straight to the block path: no run statistics, no band search on the gathered operand)
+        spgemm(hx.full, Bsq.m, Csq, alpha, threshold, dense_rule);
+        sync_stream();   // (the padded offsets are released on leaving the scope)
+      }
+      if (last_spgemm_stats().block) g_block_scope_products += 1;
+      if (Csq.loose() || Csq.expanded() || Csq.blocked()) pack(Csq);
+      MatView Cv;
+      Cv.alias(Csq, Csq.outer.p + B.c0, B.c1 - B.c0, Csq.nnz);
+      AB = concat_columns({&Cv.m});
+      sync_stream();
+    } else if (!hx.overlapped) {
       hx.finish();
       spgemm(hx.full, B.loc, AB, alpha, threshold, dense_rule, nullptr, &need);
     } else {
@@ -1307,7 +1334,9 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
   out[2] = out[3] = 0.0;
   if (trs2_block(B, 2, threshold, D, out)) return;
   trs2_iterate_form(B);
-  if (B.cplx || D.cplx != B.cplx || (B.grid && B.grid->num_slices > 1)) {   // (process slices: the K-split sums of ps_multiply)
+  // (process slices: the K-split sums of ps_multiply; a solve in a block order across ranks, band_scope.cpp: the panel product
+  // on the block path of multiply_panel)
+  if (B.cplx || D.cplx != B.cplx || (B.grid && B.grid->num_slices > 1) || (block_scope_active() && world().active())) {
     pack(B.loc);
     ps_multiply(B, B, scratch, 1.0, 0.0, threshold);
     ps_axpby_dot(scratch, B, -1.0, 2.0, threshold, D, out, want_trace);
@@ -1424,7 +1453,7 @@ void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMat
     if (square_keep_loose(B.loc, threshold, dense_rule, D.loc, out, want_trace ? &out[2] : nullptr, B.c0)) return;
   }
   const bool dist_fused = world().active() && options().fused_update != 0 && options().loose_iterates != 0 && !B.cplx &&
-                          !D.cplx && !(B.grid && B.grid->num_slices > 1);
+                          !D.cplx && !(B.grid && B.grid->num_slices > 1) && !block_scope_active();
   if (dist_fused) {
     if (dist_fused_step(B, 1, threshold, D, out)) return;
     // from compressed panels: the product with the fused epilogue (energy, trace, slab form) where the kernel takes it

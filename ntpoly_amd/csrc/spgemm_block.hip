@@ -773,8 +773,10 @@ __device__ inline v4d bs_zero4() { const v4d z = {0.0, 0.0, 0.0, 0.0}; return z;
 // walked in ascending position as well every entry is the reference's sum in ascending k of the relabelled matrix (zeros
 // inside a tile are exact no-ops).  The column of the B tile sits in 16 registers (one load per k, the lanes of a column
 // share their lines), the four rows of the A tile's column k are two 16-byte loads that the 16 lanes of a group share.
-template <int HV, bool UNF = false>
-__global__ __launch_bounds__(64 * HV) __attribute__((amdgpu_waves_per_eu(UNF ? 3 : 2, 8))) void k_bs_numeric(const BsArgs a) {
+// LST: the candidates' matches come from k_bs_match (option block_match) -- a compile-time switch: as a run-time branch in the
+// walk it cost the kernel 30 % (19.8 -> 25.7 ms on the 64^3 iterate, same registers, 15 more waits)
+template <int HV, bool UNF = false, bool LST = false>
+__global__ __launch_bounds__(64 * HV) __attribute__((amdgpu_waves_per_eu(UNF ? 3 : 1, 8))) void k_bs_numeric(const BsArgs a) {
   constexpr int NX = 4 / HV;
   __shared__ unsigned wmask[HV];
   __shared__ int wcount[HV];
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(64 * HV) __attribute__((amdgpu_waves_per_eu(UNF ? 3
   const int blo = m * 16 + (((2 * g) ^ (m >> 1)) & 7) * 2;      // B role: rows 4 g, 4 g + 1 of column m; rows 4 g + 2, 4 g + 3 in the
   const int bhi = m * 16 + (((2 * g + 1) ^ (m >> 1)) & 7) * 2;  // neighbouring chunk
   unsigned nprod = 0;
-  const bool listed = a.mlist != nullptr;
+  constexpr bool listed = LST;
   const int64_t m0 = listed ? uni_i64(a.moff[cand]) : 0;
   const int64_t w0 = listed ? 0 : ra0, w1 = listed ? (int64_t)uni_i32(a.mcnt[cand]) : ra1;
   for (int64_t base = w0; base < w1; base += WAVE) {
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(64 * HV) __attribute__((amdgpu_waves_per_eu(UNF ? 3
     const bool in = e < w1;
     int ia, ib;
     bool found;
-    if (listed) {   // (the matches were found by k_bs_match: 64 of them per load)
+    if constexpr (listed) {   // (the matches were found by k_bs_match: 64 of them per load)
       const int2 pr = in ? a.mlist[m0 + e] : make_int2(0, 0);
       ia = pr.x;
       ib = pr.y - (int)cb0;
@@ -1540,6 +1542,39 @@ bool block_order_for(const DevMat& M, std::vector<int32_t>& pos_host) {
   return true;
 }
 
+bool block_order_of_pattern(const DevMat& M, std::vector<int32_t>& pos_host, int32_t* ns_out) {
+  if (M.cplx || M.rows != M.cols || M.loose() || M.expanded() || M.blocked() || M.nnz < 8LL * M.cols) return false;
+  BlockCache& c = cache();
+  const unsigned long long fp = block_pattern_fp(M);
+  if (!select_order_fp(c, M.cols, fp)) install_order(c, build_block_order(M));
+  if (c.order->ns > kMaxSuperBlocks) return false;
+  pos_host.resize((size_t)M.cols);
+  HIP_CHECK(hipMemcpyAsync(pos_host.data(), c.order->pos.p, sizeof(int32_t) * (size_t)M.cols, hipMemcpyDeviceToHost, stream()));
+  sync_stream();
+  if (ns_out) *ns_out = c.order->ns;
+  return true;
+}
+
+void install_block_positions(int32_t n, int32_t ns, const std::vector<int32_t>& pos) {
+  std::shared_ptr<BlockOrder> bo(new BlockOrder());
+  bo->n = n;
+  bo->ns = ns;
+  std::vector<int32_t> lab((size_t)64 * (size_t)ns, -1);
+  for (int32_t v = 0; v < n; ++v) lab[(size_t)pos[(size_t)v]] = v;
+  bo->pos.alloc((size_t)n);
+  bo->lab.alloc(lab.size());
+  bo->pos.upload(pos.data(), (size_t)n);
+  bo->lab.upload(lab.data(), lab.size());
+  sync_stream();
+  static unsigned long long serial = 1ull << 40;   // (apart from the serials of the orders build_block_order makes)
+  bo->serial = ++serial;
+  unsigned long long h = 0xcbf29ce484222325ull;      // (no pattern's fingerprint: the order is the caller's -- keyed on its positions,
+  for (int32_t v = 0; v < n; ++v) h = (h ^ (unsigned long long)(unsigned)pos[(size_t)v]) * 0x100000001b3ull;   // so that the same order finds its slot again)
+  bo->seed_fp = h | 1ull;
+  for (CachedForm& f : cache().forms) f = CachedForm();
+  install_order(cache(), bo);
+}
+
 namespace {
 void block_colstat(BlockForm& F);
 // C = alpha A B pruned, block form in, block form out (symbolic phase, numeric phase, the result's super-tiles)
@@ -1646,9 +1681,17 @@ void block_product(BlockCache& bc, BlockForm& FA, BlockForm& FB, double alpha, d
 #endif
     if (ev_begin) HIP_CHECK(hipEventRecord(ev_begin, stream()));
     // (dense tiles: one wave per candidate; sparse tiles: two)
-    if (options().spgemm_fma == 0) hipLaunchKernelGGL((k_bs_numeric<2, true>), dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
-    else if (dense_tiles) hipLaunchKernelGGL((k_bs_numeric<1>), dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
-    else hipLaunchKernelGGL((k_bs_numeric<2>), dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
+    const bool lst = a.mlist != nullptr;
+    if (options().spgemm_fma == 0) {
+      if (lst) hipLaunchKernelGGL((k_bs_numeric<2, true, true>), dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
+      else hipLaunchKernelGGL((k_bs_numeric<2, true>), dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
+    } else if (dense_tiles) {
+      if (lst) hipLaunchKernelGGL((k_bs_numeric<1, false, true>), dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
+      else hipLaunchKernelGGL((k_bs_numeric<1>), dim3(xcd_grid(a.nwg)), dim3(64), 0, stream(), a);
+    } else {
+      if (lst) hipLaunchKernelGGL((k_bs_numeric<2, false, true>), dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
+      else hipLaunchKernelGGL((k_bs_numeric<2>), dim3(xcd_grid(a.nwg)), dim3(128), 0, stream(), a);
+    }
     if (ev_end) HIP_CHECK(hipEventRecord(ev_end, stream()));
     {
       ScalarFetch f;

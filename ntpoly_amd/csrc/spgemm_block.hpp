@@ -85,6 +85,11 @@ bool block_trs2_step(DevMat& X, int mode, double threshold, bool dense_rule, con
 // the block order the engine holds for matrices of M's dimension, made from M if there is none (tests / tools);
 // pos_host[index] = position
 bool block_order_for(const DevMat& M, std::vector<int32_t>& pos_host);
+// the block order made FOR the pattern of M (kept under its fingerprint; made now if there is none): positions and super-blocks
+bool block_order_of_pattern(const DevMat& M, std::vector<int32_t>& pos_host, int32_t* ns_out);
+// an order given by explicit positions (pos[index] in [0, 64 ns), at most 16 indices per block of 16 positions) becomes the current
+// order of dimension n: a solve that has redistributed its operands in a block order (band_scope.cpp) multiplies in it
+void install_block_positions(int32_t n, int32_t ns, const std::vector<int32_t>& pos);
 void drop_block_caches();
 // Block algebra (one rank, real, FMA arithmetic): the vocabulary of the solver loops on matrices in block form -- the
 // counterpart of the slab algebra (kernels.hpp) for operands without runs.  Operands are in block form or in compressed

@@ -165,6 +165,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "plan_fused") options().plan_fused = *value;
   else if (n == "block_unfused") options().block_unfused = *value;
   else if (n == "block_match") options().block_match = *value;
+  else if (n == "block_scope") options().block_scope = *value;
   else if (n == "panel_sessions") options().panel_sessions = *value;
   else if (n == "label_rowoff") options().label_rowoff = *value;
   else if (n == "block_path") options().block_path = *value;
@@ -191,6 +192,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "plan_fused") return options().plan_fused;
   if (n == "block_unfused") return options().block_unfused;
   if (n == "block_match") return options().block_match;
+  if (n == "block_scope") return options().block_scope;
   if (n == "panel_sessions") return options().panel_sessions;
   if (n == "fused_update") return options().fused_update;
   if (n == "loose_iterates") return options().loose_iterates;
@@ -301,6 +303,12 @@ void ntpoly_amd_comm_split_matrix(const int* ih_this, int* ih_split, int* my_col
 // out[0] = solves that ran in a recovered band order across ranks (band_scope.cpp), out[1] = operands searched for one
 void ntpoly_amd_band_scope_counts(long long* out) {
   for (int q = 0; q < 2; ++q) out[q] = band_scope_counts()[q];
+}
+// solves that ran in a BLOCK order across ranks (operands without runs or band: 3-D Hamiltonians), panel products of such
+// solves that took the block path
+void ntpoly_amd_block_scope_counts(long long* out) {
+  out[0] = band_scope_counts()[2];
+  out[1] = block_scope_products();
 }
 // out[0..3]: operations the solver loops did on matrices in slab form since start (products, merges / copies, scalings
 // / dots / norms) and operations that had to go back to compressed columns

@@ -915,6 +915,13 @@ def band_scope_counts():
     return dict(solves=out[0], searched=out[1])
 
 
+def block_scope_counts():
+    """(solves run in a block order across ranks, panel products of such solves on the block path)"""
+    out = (C.c_longlong * 2)()
+    lib.ntpoly_amd_block_scope_counts(out)
+    return dict(solves=out[0], products=out[1])
+
+
 def band_searches():
     """searches for a bandwidth-reducing order since start (one per sparsity pattern)"""
     out = C.c_longlong()

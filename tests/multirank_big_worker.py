@@ -76,9 +76,10 @@ def main():
         p.SetMaxIterations(6)
         p.SetMonitorConvergence(False)
         K = nt.Matrix_ps(n)
-        f0, e0, b0 = nt.fusion_counts(), nt.exchange_stats(), nt.band_scope_counts()
+        f0, e0, b0, k0 = nt.fusion_counts(), nt.exchange_stats(), nt.band_scope_counts(), nt.block_scope_counts()
         energy, mu = nt.DensityMatrixSolvers.TRS2(A, Ident, n / 2.0, K, p)
-        f1, e1, b1 = nt.fusion_counts(), nt.exchange_stats(), nt.band_scope_counts()
+        f1, e1, b1, k1 = nt.fusion_counts(), nt.exchange_stats(), nt.band_scope_counts(), nt.block_scope_counts()
+        res[tag + "_trs2_block_scope"] = np.array([k1["solves"] - k0["solves"], k1["products"] - k0["products"]])
         bs2 = nt.last_block_stats()
         tr = nt.solver_trace()
         res[tag + "_trs2_log"] = np.array(tr["energy"])
