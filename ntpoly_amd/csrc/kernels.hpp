@@ -81,7 +81,7 @@ struct EngineOptions {
   int fused_update = 1;        // TRS2 on one rank, real operands: the update X <- 2X - X*X (or X*X), its energy and its trace
                                // come out of the epilogue of the register-slab kernel; 0: separate merge / reduction passes
   int block_scope = 1;         // several ranks, FMA arithmetic: a solve whose first operand has neither runs nor a hidden band (a 3-D Hamiltonian) runs in the pattern's block order -- operands redistributed so that a rank owns a range of positions, panel products on the block path instead of the LDS hash (band_scope.cpp); 0: the operands as they are
-  int block_match = 0;         // block path, an experiment (profiles/README.md 94): 1 = the matches of every candidate super-tile (the K with super-tiles on both sides) are found once, by a kernel of its own (k_bs_match), and read by the numeric kernel; 0: the numeric kernel searches itself.  Measured: no difference (40.3 against 40.2 iterations/s on the 64^3 lattice).  Results do not depend on it
+  int block_match = 0;         // block path, an experiment (profiles/README.md 94): 1 = the matches of every candidate super-tile (the K with super-tiles on both sides) are found once, by a kernel of its own (k_bs_match), and read by the numeric kernel; 0: the numeric kernel searches itself.  Measured: no difference (37.4 against 37.2 iterations/s on the 64^3 lattice).  Results do not depend on it
   int block_unfused = 0;       // the block path (spgemm_block.hip) in UNFUSED arithmetic too: products rounded, then added, on the vector units, in ascending POSITION of the block order -- the reference's default build on the matrix relabelled by that order (what its own load balancer does), 1e-13 of the sums over ascending labels.  0 (default): operands without runs keep the label-ordered kernels in unfused arithmetic, bit for bit the reference on the caller's labels
   int panel_sessions = 1;      // slab sessions (TRS4, sign, inverse, square roots, polynomials ...) on more than one rank: the loops' matrices stay in slab form as column panels, a product exchanges the runs of the left operand's halo (psmatrix.cpp panel_slab_multiply); 0: compressed columns across ranks
   int plan_fused = 1;          // the maxima and prefix sums of a slab step's plan in ONE launch (k_slab_offsets: every workgroup sums what lies before its part itself) instead of four to seven; 0: separate launches
