@@ -84,7 +84,7 @@ CASES = [("trs4", 4096, 20, 1e-8, 0.0), ("trs4", 3000, 12, 1e-6, 0.0), ("sign", 
 
 # (suite budget: every loop in FMA arithmetic -- the default, where the counts are exact; the unfused mode on one case of each
 # loop family whose merges differ: TRS4 and the inverse square root)
-UNFUSED_CASES = {("trs4", 4096), ("inverse_square_root", 4096), ("sign", 4096)}
+UNFUSED_CASES = {("trs4", 4096), ("inverse_square_root", 4096)}
 
 
 @pytest.mark.parametrize("solver,n,h,thr,shift", CASES)
