@@ -82,6 +82,44 @@ def main():
     counted("inv", lambda: nt.InverseSolvers.Invert(S, Iv, p))
     keep("inv", Iv)
 
+    # ---- the other loop families that open a session (polynomials, functions, density solvers beside TRS4) on a small
+    # operand: every collective of their vocabulary must be entered by every rank whatever form its panel is in
+    m = int(os.environ.get("NTPOLY_AMD_PANEL_M", "4096"))
+    n_big, n = n, m
+
+    def banded_m(h, shift=0.0, scale=1.0):
+        M = nt.Matrix_ps(m)
+        c0, c1 = M.local_columns()
+        t = nt.TripletList_r()
+        col, row, val = banded_triplets(m, h, shift=shift, c0=c0, c1=c1)
+        t.set_arrays(col, row, val * scale)
+        M.FillFromTripletList(t, prepartitioned=True)
+        return M
+
+    Hm = banded_m(10, scale=0.4)
+    Sm = banded_m(8, shift=3.0)
+    Im = nt.Matrix_ps(m)
+    Im.FillIdentity()
+    pm = nt.SolverParameters()
+    pm.SetThreshold(1e-9)
+    pm.SetConvergeDiff(1e-8)
+    poly = nt.Polynomial(5)
+    for k, cf in enumerate((0.3, -0.7, 0.25, 0.11, -0.05)):
+        poly.SetCoefficient(k, cf)
+    for tag, fn in (("horner", lambda O: poly.HornerCompute(Hm, O, pm)),
+                    ("paterson", lambda O: poly.PatersonStockmeyerCompute(Hm, O, pm)),
+                    ("exp", lambda O: nt.ExponentialSolvers.ComputeExponential(Hm, O, pm)),
+                    ("log", lambda O: nt.ExponentialSolvers.ComputeLogarithm(Sm, O, pm)),
+                    ("sine", lambda O: nt.TrigonometrySolvers.Sine(Hm, O, pm)),
+                    ("root3", lambda O: nt.RootSolvers.ComputeRoot(Sm, O, 3, pm)),
+                    ("sqrt", lambda O: nt.SquareRootSolvers.SquareRoot(Sm, O, pm)),
+                    ("hpcp", lambda O: nt.DensityMatrixSolvers.HPCP(Hm, Im, m / 2.0, O, pm)),
+                    ("pm", lambda O: nt.DensityMatrixSolvers.PM(Hm, Im, m / 2.0, O, pm))):
+        O = nt.Matrix_ps(m)
+        counted("m_" + tag, lambda: fn(O))
+        keep("m_" + tag, O)
+        del O
+
     np.savez(out + ".%d.npz" % rank, **res)
     nt.DestructGlobalProcessGrid()
 
