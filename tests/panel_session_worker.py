@@ -82,6 +82,31 @@ def main():
     counted("inv", lambda: nt.InverseSolvers.Invert(S, Iv, p))
     keep("inv", Iv)
 
+    # ---- TRS4 on a RELABELLED band: on several ranks the solver recovers the band (band_scope.cpp) and its loop then runs as a
+    # session of column panels in the recovered order
+    # (opt-in, NTPOLY_AMD_PANEL_PERM=1: two processes time-slicing ONE GPU over the test transport wait ~64 ms per step of a
+    # solve inside the band scope -- profiles/README.md 86 -- which makes this case minutes long on the one-GPU box)
+    from gen import permuted_banded_triplets
+    if os.environ.get("NTPOLY_AMD_PANEL_PERM", "0") != "1":
+        permuted_banded_triplets = None
+    if permuted_banded_triplets is not None:
+        Hp = nt.Matrix_ps(n)
+        c0, c1 = Hp.local_columns()
+        t = nt.TripletList_r()
+        t.set_arrays(*permuted_banded_triplets(n, 20, 42, c0=c0, c1=c1))
+        Hp.FillFromTripletList(t, prepartitioned=True)
+        del t
+        Kp = nt.Matrix_ps(n)
+        b0 = nt.band_scope_counts()
+        counted("trs4p", lambda: out4.update(p=nt.DensityMatrixSolvers.TRS4(Hp, Ident, n / 2.0, Kp, p4)))
+        b1 = nt.band_scope_counts()
+        res["trs4p_scope"] = np.array([b1["solves"] - b0["solves"]])
+        res["trs4p_scal"] = np.array(out4["p"])
+        res["trs4p_log"] = np.array(nt.solver_trace()["energy"])
+        kc, kr, kv = Kp.triplets()
+        res["trs4p_sums"] = np.array([float(len(kv)), float(np.sum(kv)), float(np.sum(kv * kv)), float(np.sum(np.abs(kv)))])
+        del Hp, Kp
+
     # ---- the other loop families that open a session (polynomials, functions, density solvers beside TRS4) on a small
     # operand: every collective of their vocabulary must be entered by every rank whatever form its panel is in
     m = int(os.environ.get("NTPOLY_AMD_PANEL_M", "4096"))

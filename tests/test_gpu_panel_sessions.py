@@ -78,6 +78,18 @@ def test_panel_sessions_equal_single_rank(world, reference, tmp_path):
             assert syncs <= 2 * slab + 8, (loop, r, syncs, slab)
         assert np.allclose(parts[r]["trs4_scal"], reference["trs4_scal"], rtol=1e-11, atol=1e-9)
         assert np.allclose(parts[r]["trs4_log"], reference["trs4_log"], rtol=1e-11, atol=1e-9)
+    # TRS4 on a relabelled band: the band scope around a session of column panels (contract of the band scope: energies 1e-8,
+    # entry counts 1e-4 against the one-rank solve on the caller's labels)
+    have_perm = "trs4p_sums" in parts[0] and "trs4p_sums" in reference    # (opt-in: NTPOLY_AMD_PANEL_PERM=1, see the worker)
+    sums = np.sum(np.stack([p["trs4p_sums"] for p in parts]), axis=0) if have_perm else None
+    for r in range(world if have_perm else 0):
+        assert int(parts[r]["trs4p_scope"][0]) == 1, (r, parts[r]["trs4p_scope"])
+        slab, declined, syncs = parts[r]["trs4p_panel"]
+        assert slab >= 14 and declined <= 1, (r, slab, declined)
+        assert np.allclose(parts[r]["trs4p_log"], reference["trs4p_log"], rtol=1e-8, atol=1e-7), r
+    if have_perm:
+        assert abs(sums[0] - reference["trs4p_sums"][0]) <= 1e-4 * reference["trs4p_sums"][0] + 8, (sums, reference["trs4p_sums"])
+        assert np.allclose(sums[1:], reference["trs4p_sums"][1:], rtol=1e-8, atol=1e-6), (sums, reference["trs4p_sums"])
     # polynomials, functions, the other density solvers: every collective of their loops is entered by every rank (the run
     # ends), same iteration counts, results to 1e-8 (HPCP divides by differences of traces: the reduction order shows at 3e-9)
     for tag in SMALL:
