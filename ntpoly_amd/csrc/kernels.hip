@@ -5485,9 +5485,15 @@ __global__ __launch_bounds__(256) void k_slab_pack_runs(const int32_t* __restric
 }
 // extents and run addresses of the columns ka .. kb a rank needs: its own from its buffers, the others from the
 // receive buffer (source s: its segment [ra_s, rb_s) packed back to back at recv + zoff[s])
+// (the segments of the receive buffer -- first column and offset per owner -- travel as kernel arguments when there are at most
+// 16 ranks: two small uploads less on the host's critical path behind a step's read-back)
+struct HaloSegs {
+  int32_t ra[16];
+  int64_t zoff[16];
+};
 __global__ void k_slab_halo_layout(const long long* __restrict__ ext_all, const long long* __restrict__ pre_all, int pitch,
-                                   int dim, int P, int me, int ka, int kb, const int32_t* __restrict__ ra,
-                                   const int64_t* __restrict__ zoff, const double* __restrict__ recv,
+                                   int dim, int P, int me, int ka, int kb, const int32_t* __restrict__ ra_p,
+                                   const int64_t* __restrict__ zoff_p, const HaloSegs segs, const double* __restrict__ recv,
                                    const int64_t* __restrict__ own_off, const double* __restrict__ own_val,
                                    int32_t* __restrict__ first, int32_t* __restrict__ last,
                                    unsigned long long* __restrict__ addr, const long long* __restrict__ cnt_all,
@@ -5504,7 +5510,11 @@ __global__ void k_slab_halo_layout(const long long* __restrict__ ext_all, const 
   last[i] = (int)(e >> 32);
   const double* p;
   if (s == me) p = own_val + own_off[k - c0];
-  else p = recv + zoff[s] + (pre_all[(size_t)s * pitch + (k - c0)] - pre_all[(size_t)s * pitch + (ra[s] - c0)]) + (first[i] - first[i] / al * al);
+  else {
+    const int ras = ra_p ? ra_p[s] : segs.ra[s];
+    const int64_t zs = zoff_p ? zoff_p[s] : segs.zoff[s];
+    p = recv + zs + (pre_all[(size_t)s * pitch + (k - c0)] - pre_all[(size_t)s * pitch + (ras - c0)]) + (first[i] - first[i] / al * al);
+  }
   addr[i] = (unsigned long long)reinterpret_cast<uintptr_t>(p);
   if (count) count[i] = (int32_t)cnt_all[(size_t)s * pitch + (k - c0)];
 }
@@ -5546,6 +5556,50 @@ void slab_request_async(const DevMat& X, int64_t* d_out4, const long long* d_nnz
                      X.slab->last.p, X.cols, (long long)X.nnz, d_nnz, reinterpret_cast<long long*>(d_out4));
 }
 
+namespace {
+// request (first / last row over the columns, entry count), packed extents, aligned spans and -- statistics -- the entry counts
+// of the columns in ONE pass: what k_slab_request + k_slab_extents + k_widen_i32 do, with a reduction over the workgroup in front of
+// the two atomics (a wave each hitting the same two addresses made the request 13.5 us at 32 768 columns)
+__global__ __launch_bounds__(256) void k_slab_export(const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                                                     const int32_t* __restrict__ count, int n, long long nnz,
+                                                     const long long* __restrict__ d_nnz, int al, long long* __restrict__ out4,
+                                                     long long* __restrict__ ext, int32_t* __restrict__ span,
+                                                     long long* __restrict__ cnt64) {
+  __shared__ int smin[4], smax[4];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = j < n;
+  const int f = in ? first[j] : INT_MAX, l = in ? last[j] : -1;
+  const bool has = in && l >= f;
+  if (in) {
+    ext[j] = (long long)(unsigned)f | ((long long)l << 32);
+    span[j] = l >= f ? (l / al + 1) * al - f / al * al : 0;
+    if (cnt64) cnt64[j] = count[j];
+  }
+  const int lo = wave_min_i32(has ? f : INT_MAX), hi = wave_max_i32(has ? l : -1);
+  if (lane_id() == 0) { smin[threadIdx.x / WAVE] = lo; smax[threadIdx.x / WAVE] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int blo = min(min(smin[0], smin[1]), min(smin[2], smin[3])), bhi = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    if (bhi >= blo) {   // out4[0], out4[1] were preset to (INT_MAX, -1)
+      atomicMin(&out4[0], (long long)blo);
+      atomicMax(&out4[1], (long long)bhi);
+    }
+    if (blockIdx.x == 0) out4[2] = out4[3] = d_nnz ? d_nnz[0] : nnz;
+  }
+}
+}  // namespace
+
+void slab_export_async(const DevMat& X, int64_t* d_out4, const long long* d_nnz, int64_t* d_ext, int64_t* d_pre, int64_t* d_cnt64) {
+  const int n = X.cols;
+  const long long init[2] = {INT_MAX, -1};
+  HIP_CHECK(hipMemcpyAsync(d_out4, init, sizeof(init), hipMemcpyHostToDevice, stream()));
+  DevBuf<int32_t> span((size_t)n);
+  hipLaunchKernelGGL(k_slab_export, dim3(std::max(1, cdiv(n, 256))), dim3(256), 0, stream(), X.slab->first.p, X.slab->last.p,
+                     X.slab->count.p, n, (long long)X.nnz, d_nnz, std::max(1, X.slab->row_pad), reinterpret_cast<long long*>(d_out4),
+                     reinterpret_cast<long long*>(d_ext), span.p, reinterpret_cast<long long*>(d_cnt64));
+  scan_async<int32_t>(span.p, d_pre, (int64_t)n);
+}
+
 void slab_extents_async(const DevMat& X, int64_t* d_ext, int64_t* d_pre) {
   const int n = X.cols;
   DevBuf<int32_t> span((size_t)n);
@@ -5564,11 +5618,18 @@ void slab_pack_runs_async(const DevMat& X, const int64_t* d_pre, int32_t ja, int
 void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, int pitch, int32_t dim, int P, int me,
                             int32_t ka, int32_t kb, const int32_t* d_ra, const int64_t* d_zoff, const double* d_recv,
                             const DevMat& X, int32_t* d_first, int32_t* d_last, unsigned long long* d_addr,
-                            const int64_t* d_cnt_all, int32_t* d_count) {
+                            const int64_t* d_cnt_all, int32_t* d_count, const int32_t* h_ra, const int64_t* h_zoff) {
   if (kb <= ka) return;
+  HaloSegs segs;
+  std::memset(&segs, 0, sizeof(segs));
+  if (h_ra && h_zoff && P <= 16) {   // (by value: d_ra / d_zoff are not read)
+    for (int q = 0; q < P; ++q) { segs.ra[q] = h_ra[q]; segs.zoff[q] = h_zoff[q]; }
+    d_ra = nullptr;
+    d_zoff = nullptr;
+  }
   hipLaunchKernelGGL(k_slab_halo_layout, dim3(cdiv(kb - ka, 256)), dim3(256), 0, stream(),
                      reinterpret_cast<const long long*>(d_ext_all), reinterpret_cast<const long long*>(d_pre_all), pitch, dim, P, me,
-                     ka, kb, d_ra, d_zoff, d_recv, X.slab->off.p, X.slab->val.p, d_first, d_last, d_addr,
+                     ka, kb, d_ra, d_zoff, segs, d_recv, X.slab->off.p, X.slab->val.p, d_first, d_last, d_addr,
                      reinterpret_cast<const long long*>(d_cnt_all), d_count, std::max(1, X.slab->row_pad));
 }
 

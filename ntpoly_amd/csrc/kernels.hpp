@@ -217,7 +217,10 @@ void slab_pack_runs_async(const DevMat& X, const int64_t* d_pre, int32_t ja, int
 void slab_halo_layout_async(const int64_t* d_ext_all, const int64_t* d_pre_all, int pitch, int32_t dim, int P, int me,
                             int32_t ka, int32_t kb, const int32_t* d_ra, const int64_t* d_zoff, const double* d_recv,
                             const DevMat& X, int32_t* d_first, int32_t* d_last, unsigned long long* d_addr,
-                            const int64_t* d_cnt_all = nullptr, int32_t* d_count = nullptr);   // (statistics: entries per column)
+                            const int64_t* d_cnt_all = nullptr, int32_t* d_count = nullptr,   // (statistics: entries per column)
+                            const int32_t* h_ra = nullptr, const int64_t* h_zoff = nullptr);   // (host copies of d_ra / d_zoff: passed by value up to 16 ranks, the device arrays are then not read)
+// request, extents + prefix sums of the spans and (d_cnt64 != nullptr) entry counts of a panel in one pass
+void slab_export_async(const DevMat& X, int64_t* d_out4, const long long* d_nnz, int64_t* d_ext, int64_t* d_pre, int64_t* d_cnt64);
 void slab_counts_async(const DevMat& X, int64_t* d_cnt64);
 // Slab algebra (kernels.hip, last section): the vocabulary of the solver loops on matrices that stay in slab form -- real,
 // unlabelled, square, one rank, FMA arithmetic.  Every function returns false and leaves its operands alone when it

@@ -570,9 +570,12 @@ bool panel_slab_multiply(const PSMatrix& A, const PSMatrix& B, DevMat& AB, doubl
     DevBuf<int32_t> d_ra((size_t)P), nfirst((size_t)(kb - ka)), nlast((size_t)(kb - ka));
     DevBuf<int64_t> d_zoff((size_t)P);
     DevBuf<unsigned long long> naddr((size_t)(kb - ka));
-    d_ra.upload(ra.data(), (size_t)P);
-    d_zoff.upload(zoff.data(), (size_t)P);
-    slab_halo_layout_async(d_ext_all, d_pre_all, pitch, dim, P, me, ka, kb, d_ra.p, d_zoff.p, recvbuf.p, A.loc, nfirst.p, nlast.p, naddr.p);
+    if (P > 16) {
+      d_ra.upload(ra.data(), (size_t)P);
+      d_zoff.upload(zoff.data(), (size_t)P);
+    }
+    slab_halo_layout_async(d_ext_all, d_pre_all, pitch, dim, P, me, ka, kb, d_ra.p, d_zoff.p, recvbuf.p, A.loc, nfirst.p, nlast.p, naddr.p,
+                           nullptr, nullptr, ra.data(), zoff.data());
     SlabHalo halo;
     halo.ka = ka;
     halo.kb = kb;
@@ -1113,9 +1116,7 @@ void exchange_prepare(const DevMat& Xl, int32_t dim, const long long* d_nnz, Pan
   pe.d_bound.alloc((size_t)2 * P);
   pe.d_cnt.alloc((size_t)P * P);
   int64_t* mine = pe.d_all.p + (size_t)pe.me * pe.pitch;
-  slab_request_async(Xl, mine, d_nnz);
-  slab_extents_async(Xl, mine + 4, mine + 4 + pe.wcols);
-  if (pe.with_counts) slab_counts_async(Xl, mine + 4 + 2 * (size_t)pe.wcols);
+  slab_export_async(Xl, mine, d_nnz, mine + 4, mine + 4 + pe.wcols, pe.with_counts ? mine + 4 + 2 * (size_t)pe.wcols : nullptr);
   tr.allgather(mine, pe.d_all.p, (size_t)pe.pitch * sizeof(int64_t));
   HIP_CHECK(hipMemcpy2DAsync(pe.d_req.p, 4 * sizeof(int64_t), pe.d_all.p, (size_t)pe.pitch * sizeof(int64_t), 4 * sizeof(int64_t), (size_t)P,
                              hipMemcpyDeviceToDevice, stream()));
@@ -1219,12 +1220,14 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   DevBuf<int32_t> d_ra((size_t)P), nfirst((size_t)(kb - ka)), nlast((size_t)(kb - ka));
   DevBuf<int64_t> d_zoff((size_t)P);
   DevBuf<unsigned long long> naddr((size_t)(kb - ka));
-  d_ra.upload(ra.data(), (size_t)P);
-  d_zoff.upload(zoff.data(), (size_t)P);
+  if (P > 16) {   // (up to 16 ranks the segments travel as kernel arguments)
+    d_ra.upload(ra.data(), (size_t)P);
+    d_zoff.upload(zoff.data(), (size_t)P);
+  }
   DevBuf<int32_t> ncount;
   if (d_cnt_all) ncount.alloc((size_t)(kb - ka));
   slab_halo_layout_async(d_ext_all, d_pre_all, pitch, dim, P, me, ka, kb, d_ra.p, d_zoff.p, recvbuf.p, B.loc, nfirst.p,
-                         nlast.p, naddr.p, d_cnt_all, ncount.p);
+                         nlast.p, naddr.p, d_cnt_all, ncount.p, ra.data(), zoff.data());
   SlabHalo halo;
   halo.ka = ka;
   halo.kb = kb;
