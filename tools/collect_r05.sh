@@ -3,7 +3,7 @@
 # bench + kernel statistics + PMC traffic of the three bench workloads, the self-launched multi-rank lines (shared-memory test
 # transport on a one-GPU box), BASELINE configs[3] (one rank, relabelled, two ranks), the other configs, a roofline line per
 # solver loop (real and complex), the rank-share model.
-tag=${1:-r05_v1}
+tag=${1:-r05_v4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 bash tools/collect_profiles.sh ${tag}
 bash tools/collect_profiles.sh ${tag}_lattice --lattice 64
