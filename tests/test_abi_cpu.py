@@ -235,3 +235,31 @@ def test_default_arithmetic_is_the_benched_one():
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
         assert r.returncode == 0, r.stdout
         assert r.stdout.strip().splitlines()[-1] == want, (env_val, r.stdout)
+
+
+def test_round5_options_defaults_and_round_trip():
+    """The options added in round 5 through the C ABI's option entry points (host only, no GPU): their defaults -- what a
+    drop-in caller gets -- and a set / get round trip; the environment selectors of the two that have one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    defaults = {"plan_fused": 1, "panel_sessions": 1, "block_scope": 1, "band_scope": 1, "exchange_ahead": 1, "block_unfused": 0,
+                "block_match": 0, "tile2": 0}
+    code = ("import ntpoly_amd as nt\n"
+            "names = %r\n"
+            "print(' '.join(str(nt.get_option(k)) for k in names))\n"
+            "for k in names: nt.set_option(k, 7)\n"
+            "print(' '.join(str(nt.get_option(k)) for k in names))\n") % (sorted(defaults),)
+    env = dict(os.environ)
+    for k in ("NTPOLY_AMD_PANEL_SESSIONS", "NTPOLY_AMD_BLOCK_UNFUSED"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    lines = r.stdout.strip().splitlines()[-2:]
+    assert lines[0].split() == [str(defaults[k]) for k in sorted(defaults)], r.stdout
+    assert lines[1].split() == ["7"] * len(defaults), r.stdout
+    env["NTPOLY_AMD_PANEL_SESSIONS"] = "0"
+    env["NTPOLY_AMD_BLOCK_UNFUSED"] = "1"
+    r = subprocess.run([sys.executable, "-c", "import ntpoly_amd as nt; print(nt.get_option('panel_sessions'), nt.get_option('block_unfused'))"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].split() == ["0", "1"], r.stdout
