@@ -120,11 +120,29 @@ def main():
         rows[-1].update(trs4_measured_share_ms_per_iteration=trs4_ms, trs4_halo_bytes_per_product=halo4,
                         trs4_exchange_us_per_product=t_prod_us, trs4_modelled_ms_per_iteration=trs4_ms + 2.0 * t_prod_us * 1e-3)
         del H, X, X2, Ident, pool, K
+        # ---- the same share through the PANEL path, measured: a child process with a 1-rank RCCL communicator
+        # (NTPOLY_AMD_FORCE_RCCL=1: every collective of a panel step is a real RCCL call, short-circuited by RCCL on one rank) times
+        # bench.py at N / P -- the exchange's preparation, its small kernels and uploads, the reduction record are all in it; what a
+        # real run adds on top is the halo's transfer and the collectives' own kernels
+        if P > 1:
+            import subprocess
+            env = dict(os.environ, NTPOLY_AMD_FORCE_RCCL="1")
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", str(n), "--steps", str(args.steps), "--warmup",
+                                str(args.warmup), "--blocks", "3", "--no-cpu-baseline", "--no-wrp-check"], env=env, cwd=ROOT,
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if line:
+                ms = json.loads(line[-1])["ms_per_step"]
+                rows[-1].update(panel_step_ms_through_1rank_rccl=ms,
+                                estimate_with_measured_machinery_ms=ms + (t_halo_us + t_gather_us) * 1e-3)
     rows = rows[1:]
     base = rows[0]["modelled_ms_per_step"]
     for r in rows:
         r["modelled_speedup"] = base / r["modelled_ms_per_step"]
         r["modelled_efficiency"] = r["modelled_speedup"] / r["ranks"]
+        if "estimate_with_measured_machinery_ms" in r:
+            r["estimate_with_measured_machinery_iters_per_s"] = 1e3 / r["estimate_with_measured_machinery_ms"]
+            r["estimate_with_measured_machinery_efficiency"] = base / r["estimate_with_measured_machinery_ms"] / r["ranks"]
         r["trs4_modelled_speedup"] = rows[0]["trs4_modelled_ms_per_iteration"] / r["trs4_modelled_ms_per_iteration"]
         r["trs4_modelled_efficiency"] = r["trs4_modelled_speedup"] / r["ranks"]
     print(json.dumps({
@@ -135,7 +153,9 @@ def main():
                 "solver recovers the band once per solve and redistributes the operands (csrc/band_scope.cpp).  TRS4 rows: the one-rank "
                 "loop at N / P (slab session) + per product the halo of the left operand, the extent all-gather, eight small launches "
                 "and a 4-double reduction (sessions of column panels, option panel_sessions; tests/test_gpu_panel_sessions.py measures two "
-                "host round trips per product, as on one rank)",
+                "host round trips per product, as on one rank).  estimate_with_measured_machinery_*: the panel step itself timed in a child "
+                "process with a 1-rank RCCL communicator (its preparation kernels, uploads and reduction record included, RCCL's own kernels and "
+                "the transfer not) + the modelled halo and all-gather times -- the more realistic of the two TRS2 estimates",
         "n": args.n, "halfband": h, "threshold": thr, "arithmetic": args.arithmetic,
         "host_round_trip_us": sync_us, "xgmi_link_GBps": XGMI_LINK_GBS, "table": rows}, indent=1))
 
