@@ -4,19 +4,29 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                 (no launcher: starts its own N rank processes)
 
 A "step" is one TRS2 iteration, driven through the engine's C ABI exactly as
 DensityMatrixSolversModule.F90:380-413 does it: trace(X) -> sigma, X2 = X*X (SpGEMM with threshold),
 X <- 2X - X2 or X2, energy = dot(X, H).  All matrices stay in HBM; only scalars return to the host.
 W warm-up iterations are followed by exactly K timed ones (barrier + device synchronise on both
-sides, max over ranks).  Rank 0 prints ONE JSON line.
+sides, max over ranks); the region is repeated --blocks times from X0 and the MEDIAN block is reported.
+Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant kernel (SpGEMM numeric, k_spgemm_slab): algorithmic bytes
-                  12*(nnzA+nnzB+nnzC)+4*(cols...) per launch / its HIP-event time, vs 8 TB/s HBM
-  cpu_baseline -- the oracle (C restatement, kind "port") timed on all host cores at the FULL size, three
-                  iterations of the same region (two runs differenced) -- reported, not the target
+  roofline     -- the dominant kernel (SpGEMM numeric phase with the TRS2 update in its epilogue: k_spgemm_tile on the FP64
+                  matrix cores in the default FMA arithmetic, k_spgemm_slab in unfused arithmetic, k_bs_numeric / k_spgemm_ghash
+                  for operands without runs): algorithmic bytes 12*(nnzA+nnzB+nnzC)+4*(cols...) per launch / its HIP-event
+                  time on the engine's stream, vs 8 TB/s HBM; traffic = the committed PMC passes of the same command
+  roofline_compute -- the same launches against the FP64 peak of the arithmetic mode
+  cpu_baseline -- the oracle (C restatement with OpenMP, kind "port") on all host cores at the FULL size: ONE solve of
+                  warmup + 5 iterations, the last five timed one by one, median -- reported, not the target
   trs2_wrp_check -- the same rate measured through the reference's entry point TRS2_wrp ((t(25) - t(5)) / 20)
+
+Other workloads: --permute SEED (the operand under the load balancer's random relabelling), --random SEED (the same
+operand left AS IT STANDS -- no band recovery, no block order: the north star's LDS-hash SpGEMM, the shape of the
+reference's own UnitTests/bench.f90:58-76), --lattice L (3-D Hamiltonian), --config 3 (BASELINE configs[3]: one A*A at
+N = 1 048 576), --arithmetic fma|unfused, --set OPTION=VALUE.
 """
 import argparse
 import json
@@ -208,7 +218,8 @@ def run_config3(nt, args, rank, world):
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "one distributed product A*A (BASELINE configs[3]): banded A N=%d halfband=%d%s, threshold=%g, 1-D column panels on %d rank(s)" % (
-                       n, h, "" if args.permute is None else " under a random symmetric relabelling (seed %d)" % args.permute, thr, world),
+                       n, h, "" if args.permute is None else " under a random symmetric relabelling (seed %d)%s" % (
+                           args.permute, ", taken as it stands (no band recovery, no block order: the LDS-hash SpGEMM)" if args.random is not None else ""), thr, world),
                    "arithmetic": arithmetic, "arithmetic_default": lib_default, "blocks_ms": [1e3 * b["elapsed"] for b in blocks],
                    "n": n, "halfband": h, "threshold": thr, "permute_seed": args.permute, "nnz_A": int(nnz_a), "nnz_C": int(nnz_c),
                    "host_syncs_per_step": med["syncs"] / float(args.steps),
@@ -326,6 +337,11 @@ def main():
     ap.add_argument("--permute", type=int, default=None, metavar="SEED",
                     help="run on P^T H P under a seeded random relabelling (SURVEY 8(d): the load-balanced / "
                          "unstructured operand; the SpGEMM leaves the run-based kernels for the LDS hash path)")
+    ap.add_argument("--random", type=int, default=None, metavar="SEED",
+                    help="the unstructured workload: P^T H P under a seeded random relabelling taken AS IT STANDS (options label_order = 0, "
+                         "block_path = 0, band_scope = 0: no band recovery, no block order) -- the shape of the reference's own harness "
+                         "(UnitTests/bench.f90:58-76: a decaying band, randomly permuted, multiplied) on the north star's named kernel, "
+                         "the grouped LDS-hash SpGEMM k_spgemm_ghash; with --config 3 one product, otherwise TRS2 iterations")
     ap.add_argument("--lattice", type=int, default=None, metavar="L",
                     help="run on the Hamiltonian of an L x L x L lattice (tests/gen.py lattice_triplets: 203 entries per row, "
                          "no band any relabelling could recover; N = L^3, e.g. 64 -> 262 144): the operand the north star's "
@@ -360,6 +376,23 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
 
+    # experiment switches first: they apply to every workload (--config 3 included)
+    if args.random is not None:
+        if args.permute is not None or args.lattice is not None:
+            raise SystemExit("--random SEED is a workload of its own (not with --permute / --lattice)")
+        args.permute = args.random
+        for k in ("label_order", "block_path", "band_scope"):
+            nt.set_option(k, 0)
+    if args.tile_rows is not None:
+        nt.set_option("tile_rows", args.tile_rows)
+    if args.tile_waves is not None:
+        nt.set_option("tile_waves", args.tile_waves)
+    if args.no_label_order:
+        nt.set_option("label_order", 0)
+    for kv in args.set:
+        k, v = kv.split("=")
+        nt.set_option(k, int(v))
+
     if args.config == 3:
         line = run_config3(nt, args, rank, world)
         if rank == 0:
@@ -380,16 +413,6 @@ def main():
     if args.arithmetic is None:
         args.arithmetic = lib_default
     nt.set_option("spgemm_fma", 1 if args.arithmetic == "fma" else 0)
-    if args.tile_rows is not None:
-        nt.set_option("tile_rows", args.tile_rows)
-    if args.tile_waves is not None:
-        nt.set_option("tile_waves", args.tile_waves)
-    if args.no_label_order:
-        nt.set_option("label_order", 0)
-    for kv in args.set:
-        k, v = kv.split("=")
-        nt.set_option(k, int(v))
-
     # ---- setup (untimed): Hamiltonian panel, X0 = (e_max*I - H)/(e_max - e_min)  (:344-371)
     H = nt.Matrix_ps(n)
     c0, c1 = H.local_columns()
@@ -461,8 +484,8 @@ def main():
         # the corrected bytes per launch together with a fingerprint of the kernel sources it was measured on -- a
         # figure measured on other sources is not reported (null)
         traffic, traffic_src = None, None
-        tname = ("r05_pmc_traffic%s.json" if args.arithmetic == "fma" else "r05_pmc_traffic_unfused%s.json") % (
-            "_lattice" if args.lattice is not None else "" if args.permute is None else "_permute")
+        tname = ("r06_pmc_traffic%s.json" if args.arithmetic == "fma" else "r06_pmc_traffic_unfused%s.json") % (
+            "_lattice" if args.lattice is not None else "" if args.permute is None else "_random" if args.random is not None else "_permute")
         try:
             with open(os.path.join(ROOT, "profiles", tname)) as f:
                 tj = json.load(f)
@@ -498,7 +521,8 @@ def main():
                        "TRS2 purification (BASELINE configs[2]): banded H N=%d halfband=%d (%d nnz/row)%s, "
                        "threshold=%g, ISQ=I, trace=N/2; timed iterations %d..%d" % (
                            n, h, 2 * h + 1,
-                           "" if args.permute is None else " under a random symmetric relabelling (seed %d)" % args.permute,
+                           "" if args.permute is None else " under a random symmetric relabelling (seed %d)%s" % (
+                               args.permute, ", taken as it stands (no band recovery, no block order: the LDS-hash SpGEMM)" if args.random is not None else ""),
                            thr, args.warmup + 1, args.warmup + args.steps),
                        "lattice": args.lattice,
                        "arithmetic": ("fma: every product entry is the chain of fma() over ascending k (one rounding per product), "
@@ -511,7 +535,7 @@ def main():
                        "blocks_ms": block_ms,               # every repetition of the timed region; `value` is the median block
                        "n": n, "halfband": h, "threshold": thr, "nnz_H": int(nnz_h), "nnz_X_end": int(nnz_x),
                        "nnz_product_last": int(st.get("nnz_c", -1)), "energy_end": energy,
-                       "permute_seed": args.permute,
+                       "permute_seed": args.permute, "random": args.random is not None,
                        "decomposition": "1-D column panels, %d rank(s)" % world,
                        "transport": transport_note(world),
                        "hipMalloc_in_timed_region": {"calls": m1[0] - m0[0], "ms": m1[1] - m0[1]}},
@@ -559,12 +583,11 @@ def main():
         check = trs2_wrp_check(nt, H, n, thr)       # (collective: every rank takes part)
     if rank == 0 and world > 1 and reordered and check:
         # A relabelled or 3-D operand on several ranks: the SOLVER recovers the band (or takes the pattern's block order) once per
-        # solve and redistributes the operands (csrc/band_scope.cpp); the step API above works on the caller's distribution and cannot.  The line's value is
-        # therefore the rate of the reference's own entry point, TRS2_wrp, differenced over two iteration counts.
-        line["value_of_the_step_api"] = line["value"]
-        line["value"] = check["iters_per_s"]
-        line["ms_per_step"] = check["ms_per_iter"]
-        line["config"]["value_measured_through"] = check["method"]
+        # solve and redistributes the operands (csrc/band_scope.cpp); the step API above works on the caller's distribution and
+        # cannot.  `value` stays what it is on every other line -- the rate of the step API -- and the rate of the reference's
+        # own entry point, TRS2_wrp differenced over two iteration counts, is reported beside it.
+        line["solver_path_iters_per_s"] = check["iters_per_s"]
+        line["config"]["solver_path_measured_through"] = check["method"]
     if rank == 0:
         if check:
             line["trs2_wrp_check"] = check

@@ -13,9 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libntpoly_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["kernels.hip", "spgemm_tile.hip", "spgemm_tile2.hip", "spgemm_tile_c.hip", "spgemm_thin.hip", "column_fused.hip", "spgemm_grouped.hip", "spgemm_block.hip", "relabel.hip", "slab_extra.hip", "dense.hip", "common.cpp", "comm.cpp", "psmatrix.cpp", "band_scope.cpp", "solvers.cpp", "solvers_poly.cpp", "solvers_func.cpp", "solvers_extra.cpp", "io.cpp", "wrp.cpp"]
+SOURCES = ["kernels.hip", "spgemm_tile.hip", "spgemm_tile_c.hip", "spgemm_thin.hip", "column_fused.hip", "spgemm_grouped.hip", "spgemm_block.hip", "relabel.hip", "slab_extra.hip", "dense.hip", "common.cpp", "comm.cpp", "psmatrix.cpp", "band_scope.cpp", "solvers.cpp", "solvers_poly.cpp", "solvers_func.cpp", "solvers_extra.cpp", "io.cpp", "wrp.cpp"]
+# experiments kept out of the product build (csrc/experiments/): NTPOLY_AMD_WITH_TILE2=1 adds the two-block geometry of the
+# MFMA kernel (measured slower than k_spgemm_tile in round 5, profiles/README.md 83; option tile2 is a no-op without it)
+WITH_TILE2 = os.environ.get("NTPOLY_AMD_WITH_TILE2", "0") == "1"
+if WITH_TILE2:
+    SOURCES.insert(2, "experiments/spgemm_tile2.hip")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("NTPOLY_AMD_EXTRA_FLAGS", "").split()
+         "-Wno-unused-function", "-Wno-unused-result"] + (["-DNTP_WITH_TILE2"] if WITH_TILE2 else []) + os.environ.get("NTPOLY_AMD_EXTRA_FLAGS", "").split()
 
 
 # per-file flags.  spgemm_block.hip: its matrix instructions sit behind wave-uniform branches; with the accumulators in
@@ -84,7 +89,7 @@ def build(force=False, verbose=False, lib=None, objdir=None, flags=None, link_ex
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(objdir, os.path.basename(s).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if not force and not object_is_stale(obj, src):
             continue

@@ -67,6 +67,10 @@ bool block_scope_active() { return g_block_scope; }
 bool band_scope_try(const std::vector<const PSMatrix*>& ins, const std::vector<PSMatrix*>& outs,
                     const std::function<void(const std::vector<const PSMatrix*>&, const std::vector<PSMatrix*>&)>& run) {
   if (g_scope_depth > 0 || ins.empty() || !world().active() || options().label_order == 0 || options().band_scope == 0) return false;
+  // Unfused arithmetic is the mode whose point is the BITS of the reference's default build on the caller's labels, on any
+  // number of ranks: a solve in a permuted index space keeps other entries below the threshold alive (section 4 of
+  // DESIGN.md), so the scope is taken there only on request (band_scope = 2); the label-ordered kernels run instead.
+  if (options().spgemm_fma == 0 && options().band_scope != 2) return false;
   const PSMatrix& H = *ins[0];
   const int32_t n = H.dim;
   if (n < 1024 || (H.grid && H.grid->num_slices > 1)) return false;
@@ -159,11 +163,13 @@ bool band_scope_try(const std::vector<const PSMatrix*>& ins, const std::vector<P
     ps_construct_empty(out_b[i], n, H.grid, outs[i]->cplx);
     out_p.push_back(&out_b[i]);
   }
-  g_scope_depth += 1;
-  g_block_scope = block_mode;
-  run(in_p, out_p);
-  g_block_scope = false;
-  g_scope_depth -= 1;
+  {
+    struct ScopeGuard {   // (restored on every way out of run(), an exception included)
+      explicit ScopeGuard(bool block) { g_scope_depth += 1; g_block_scope = block; }
+      ~ScopeGuard() { g_block_scope = false; g_scope_depth -= 1; }
+    } guard(block_mode);
+    run(in_p, out_p);
+  }
   for (size_t i = 0; i < outs.size(); ++i) relabel_ps(out_b[i], *outs[i], d_inv.p);
   g_scope_counts[block_mode ? 2 : 0] += 1;
   return true;

@@ -21,7 +21,7 @@
 //
 // Arithmetic: as k_spgemm_tile -- v_mfma_f64_16x16x4_f64 is a chain of fma() over ascending k, the groups follow in
 // ascending k, zero padding is exact -- so every C(i, j) is the FMA chain of the reference's FP-contracted build.
-#include "spgemm_tile.hpp"
+#include "../spgemm_tile.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -29,8 +29,8 @@
 #include <cstdlib>
 #include <vector>
 
-#include "device_util.hpp"
-#include "kernels.hpp"
+#include "../device_util.hpp"
+#include "../kernels.hpp"
 
 namespace ntp {
 namespace {

@@ -5722,6 +5722,7 @@ void drop_operand_caches() {   // the device memory kept between solves (expande
   c.serial = 0;
   c.usable = false;
   drop_dot_operand();
+  drop_pending_exchange();
 }
 long long& band_searches() {
   static long long n = 0;

@@ -86,7 +86,7 @@ struct EngineOptions {
   int panel_sessions = 1;      // slab sessions (TRS4, sign, inverse, square roots, polynomials ...) on more than one rank: the loops' matrices stay in slab form as column panels, a product exchanges the runs of the left operand's halo (psmatrix.cpp panel_slab_multiply); 0: compressed columns across ranks
   int plan_fused = 1;          // the maxima and prefix sums of a slab step's plan in ONE launch (k_slab_offsets: every workgroup sums what lies before its part itself) instead of four to seven; 0: separate launches
   int exchange_ahead = 1;      // panel steps across ranks: a step prepares the NEXT step's exchange (extents all-gathered, counts, plan) from its result and reads it back with its own totals -- one host round trip per panel step (psmatrix.cpp PanelExchange); 0: two
-  int band_scope = 1;          // solvers on SEVERAL ranks: an operand without run structure is searched for a hidden band once per solve, the operands are redistributed in the recovered order, the results carried back (band_scope.cpp)
+  int band_scope = 1;          // solvers on SEVERAL ranks, FMA arithmetic: an operand without run structure is searched for a hidden band once per solve, the operands are redistributed in the recovered order, the results carried back (band_scope.cpp).  2: in unfused arithmetic too (the results are then the reference's under its load balancer with that permutation, not its bits on the caller's labels); 0: never
   int label_order = 1;         // TRS2 on one rank: an operand without run structure is searched for a hidden band (relabel.hip)
                                // and, if there is one, the loop runs in that order with label-ordered arithmetic; 0: never
   int label_rowoff = 1;        // label-ordered steps: the loop takes a step's multiplier row from its run record (no copy of
@@ -272,6 +272,7 @@ bool relabel_enter(DevMat& X, const DevMat& D);
 const DevMat* relabelled_operand(const DevMat& D);
 void relabel_giveup(const DevMat& D);
 void drop_operand_caches();   // frees what the fused / relabelled TRS2 paths keep between solves
+void drop_pending_exchange(); // psmatrix.cpp: the exchange layout a panel step prepared for a successor that never came
 // relabel.hip: a bandwidth-reducing order of a symmetric pattern (Cuthill-McKee, breadth-first levels on the device):
 // newpos[old index] = new index, *bandwidth = max |new row - new column|.  false: not a square packed matrix, or
 // more components than the search is willing to chain

@@ -182,6 +182,7 @@ void SlabSession::close() {
 }
 void ps_slab_leave(PSMatrix& m) {
   if (m.loc.expanded() || m.loc.blocked()) pack(m.loc);
+  drop_pending_exchange();   // (the iterate leaves slab form: no step follows the last one)
 }
 
 void ps_copy(const PSMatrix& a, PSMatrix& b) {
@@ -1076,13 +1077,19 @@ struct PanelExchange {
   DevBuf<int32_t> gfirst, glast;
   std::vector<int64_t> req, bound, cnt;
   unsigned long long plan_hs[2] = {0, 0};
-  const void* owner = nullptr;   // the value buffer of the iterate (in slab form) it was prepared for
+  const void* owner = nullptr;   // the value buffer of the iterate (in slab form) it was prepared for ...
+  unsigned long long owner_serial = 0;   // ... and that buffer's allocation serial: an address alone comes back from the caching allocator
   const int64_t* d_ext_all() const { return d_all.p + 4; }
   const int64_t* d_pre_all() const { return d_all.p + 4 + wcols; }
   const int64_t* d_cnt_all() const { return with_counts ? d_all.p + 4 + 2 * (size_t)wcols : nullptr; }
 };
 std::unique_ptr<PanelExchange> g_pending_exchange;
 long long g_exchange_prefetched = 0;   // panel steps whose exchange layout came with the step before
+}  // namespace
+// the preparation a step left for a successor that never came (the last step of a solve or of a bench block): P * pitch * 8
+// bytes of device memory and a stale layout -- dropped where a solve begins and ends and with the operand caches
+void drop_pending_exchange() { g_pending_exchange.reset(); }
+namespace {
 
 int panel_pitch(int32_t dim, int P, bool with_counts, int* wcols_out) {
   int32_t maxw = 0;
@@ -1132,6 +1139,7 @@ void exchange_prepare(const DevMat& Xl, int32_t dim, const long long* d_nnz, Pan
   f.add(pe.plan.blk_toff.p + pe.snb, 1, &pe.plan.total);
   f.add(pe.plan_stats.p + 16, 2, pe.plan_hs);
   pe.owner = Xl.slab->val.p;
+  pe.owner_serial = dev_alloc_serial(Xl.slab->val.p);
 }
 bool exchange_fits_fetch(int P) { return (size_t)4 * P + (size_t)P * P + 2 * P <= 400; }
 
@@ -1145,7 +1153,12 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   const bool ahead = options().exchange_ahead != 0 && exchange_fits_fetch(P);
   // the preparation: left behind by the step that produced this iterate, or made (and read back) here
   std::unique_ptr<PanelExchange> pe;
-  if (g_pending_exchange && g_pending_exchange->owner == B.loc.slab->val.p && g_pending_exchange->dim == dim && g_pending_exchange->P == P &&
+  // (matched by ALLOCATION, not by address: the allocator hands a freed address to the next matrix of the size, and a hit
+  // decided from an address could differ between ranks -- one rank skipping an all-gather the others enter.  An allocation
+  // serial names one buffer of one step's result; the steps are collective, so either every rank holds the preparation
+  // of this iterate or none does)
+  if (g_pending_exchange && g_pending_exchange->owner == B.loc.slab->val.p && g_pending_exchange->owner_serial != 0 &&
+      g_pending_exchange->owner_serial == dev_alloc_serial(B.loc.slab->val.p) && g_pending_exchange->dim == dim && g_pending_exchange->P == P &&
       g_pending_exchange->with_counts == with_counts) {
     pe = std::move(g_pending_exchange);
     g_exchange_prefetched += 1;

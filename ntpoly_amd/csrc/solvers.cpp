@@ -182,7 +182,10 @@ double ms_since(Clock::time_point t0) {
   sync_stream();
   return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
 }
-void trace_reset() { last_trace() = SolverTrace(); }
+void trace_reset() {   // (every solver's first statement: whatever a panel step of an earlier solve prepared for a successor goes here)
+  last_trace() = SolverTrace();
+  drop_pending_exchange();
+}
 void trace_rec(double value, double energy, double sigma, const PSMatrix& X) {
   SolverTrace& t = last_trace();
   t.value.push_back(value);

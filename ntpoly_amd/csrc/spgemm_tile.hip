@@ -687,6 +687,11 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
 
 }  // namespace
 
+#ifndef NTP_WITH_TILE2
+// (the two-block geometry is an experiment outside the product build, csrc/experiments/spgemm_tile2.hip: declined here)
+bool launch_spgemm_tile2(const TileLaunch&, int*) { return false; }
+#endif
+
 int tile_rows() {
   const int r = options().tile_rows;
   return r == 4 ? 4 : r == 1 ? 1 : 2;

@@ -96,8 +96,9 @@ def test_big_multirank_equals_single_rank(world, arith, references, tmp_path):
             assert np.all(np.abs(nnz_all - ref[tag + "_trs2_nnz"]) <= 1e-4 * ref[tag + "_trs2_nnz"] + 8), (nnz_all, ref[tag + "_trs2_nnz"])
             assert abs(int(got[0]) - int(want[0])) <= 1e-4 * int(want[0]) + 8
             assert np.allclose(sums, ref[tag + "_K_sums"], rtol=1e-8, atol=1e-7), (tag, sums, ref[tag + "_K_sums"])
-        elif tag == "perm":
-            # several ranks solve a relabelled band in its RECOVERED order (csrc/band_scope.cpp: the reference's load-balancer
+        elif tag == "perm" and arith == "fma":
+            # (unfused arithmetic takes no scope: the bits of the reference's default build on the caller's labels on any number of
+            # ranks -- the exact branch below.)  FMA arithmetic: several ranks solve a relabelled band in its RECOVERED order (csrc/band_scope.cpp: the reference's load-balancer
             # semantics -- the arithmetic of the solve, including "beyond the other column's last row" of every merge, in the
             # permuted index space), one rank in the caller's labels: entries below the threshold survive a merge in different
             # places, everything else agrees -- entry counts to 1e-4, energies and the density's sums to 1e-8

@@ -1,4 +1,6 @@
-"""GPU: the two-block geometry of the MFMA kernel (csrc/spgemm_tile2.hip: pairs of 16-column blocks share every fragment
+"""GPU, EXPERIMENT BUILD ONLY (NTPOLY_AMD_WITH_TILE2=1 python -m ntpoly_amd._build; skipped on the product build, which does not
+carry the kernel: measured slower than k_spgemm_tile in round 5, profiles/README.md 83).
+The two-block geometry of the MFMA kernel (csrc/experiments/spgemm_tile2.hip: pairs of 16-column blocks share every fragment
 of A, the multiplier rows stream through LDS in chunks of 32 k) against k_spgemm_tile (option tile2 = 0) and the
 oracle's FMA mode.  Same FMA chain over ascending k (MultiplyBlock.f90:9-36 in the reference's FP-contracted build), same
 prune (PruneList.f90:8-38), same fused TRS2 update (AddSparseVectors.f90:21-70): results must agree BIT FOR BIT; where a
@@ -17,6 +19,20 @@ def nt():
     import ntpoly_amd as nt
     nt.init_comm()
     nt.ConstructGlobalProcessGrid(1, 1, 1)
+    # is the experiment kernel in this build?  One small product with the option on: the product build's stub declines
+    nt.set_option("spgemm_fma", 1)
+    nt.set_option("tile2", 1)
+    try:
+        c0 = nt.tile2_counts()
+        A = nt.Matrix_ps.from_triplets(4096, *banded_triplets(4096, 60))
+        C = nt.Matrix_ps(4096)
+        C.Gemm(A, A, None, 1.0, 0.0, 1e-8)
+        c1 = nt.tile2_counts()
+    finally:
+        nt.set_option("tile2", 0)
+        nt.set_option("spgemm_fma", 0)
+    if c1[0] + c1[1] == c0[0] + c0[1]:
+        pytest.skip("spgemm_tile2.hip is not part of this build (experiment: NTPOLY_AMD_WITH_TILE2=1)")
     return nt
 
 
@@ -28,7 +44,7 @@ def fma(nt):
     yield O
     O.set_fma(False)
     nt.set_option("spgemm_fma", 0)
-    nt.set_option("tile2", 1)
+    nt.set_option("tile2", 0)
     nt.set_option("slab_algebra", 1)
 
 
