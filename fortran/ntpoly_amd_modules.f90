@@ -989,8 +989,9 @@ CONTAINS
     CALL GatherMatrixToProcess_psc_id(this, local_mat, -1)
   END SUBROUTINE GatherMatrixToProcess_psc_all
   !> CommSplitMatrix (PSMatrixModule.F90:1489-1541): a copy of the matrix hosted on one half of the process grid.  One
-  !> process: the copy, colour 0, split along the slices (distributed_includes/CommSplitMatrix.f90:11-14); more: fatal -- the
-  !> engine has one communicator (csrc/wrp.cpp ntpoly_amd_comm_split_matrix)
+  !> process: the copy, colour 0, split along the slices (distributed_includes/CommSplitMatrix.f90:11-14); more: the grid is
+  !> split as SplitProcessGrid does (ProcessGridModule.F90:430-515) and the copy lives on the sub-communicator of this
+  !> process's half (csrc/psmatrix.cpp ps_comm_split, ncclCommSplit)
   SUBROUTINE CommSplitMatrix(this, split_mat, my_color, split_slice)
     TYPE(Matrix_ps), INTENT(INOUT) :: this
     TYPE(Matrix_ps), INTENT(INOUT) :: split_mat

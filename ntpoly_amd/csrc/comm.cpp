@@ -28,10 +28,19 @@ namespace ntp {
       ::ntp::fatal(__FILE__, __LINE__, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
   } while (0)
 
-Comm& world() {
+Comm& base_world() {
   static Comm* c = new Comm();
   return *c;
 }
+namespace {
+Comm* g_current_comm = nullptr;                  // nullptr: the communicator over all processes
+std::vector<Comm*>& split_comms() {              // sub-communicators made by comm_split (kept until comm_finalize)
+  static std::vector<Comm*>* v = new std::vector<Comm*>();
+  return *v;
+}
+}  // namespace
+Comm& world() { return g_current_comm ? *g_current_comm : base_world(); }
+void use_comm(Comm* c) { g_current_comm = (c == &base_world()) ? nullptr : c; }
 ExchangeStats& exchange_stats() {
   static ExchangeStats* e = new ExchangeStats();
   return *e;
@@ -63,6 +72,11 @@ struct RcclTransport : Transport {
   void send(const void* p, size_t bytes, int peer) override { NCCL_CHECK(ncclSend(p, bytes, ncclInt8, peer, comm, p2p_stream())); }
   void recv(void* p, size_t bytes, int peer) override { NCCL_CHECK(ncclRecv(p, bytes, ncclInt8, peer, comm, p2p_stream())); }
   void group_end() override { NCCL_CHECK(ncclGroupEnd()); }
+  Transport* split(int color, int key, int, const std::vector<int>&) override {
+    auto* t = new RcclTransport();
+    NCCL_CHECK(ncclCommSplit(comm, color, key, &t->comm, nullptr));
+    return t;
+  }
 };
 
 // ------------------------------------------------------------------ transport 2: shared memory (tests only)
@@ -81,6 +95,12 @@ struct ShmTransport : Transport {
   char* base = nullptr;
   size_t total = 0;
   int local_sense = 0;
+  // a sub-group (split): ranks of the segment's owner in new-rank order, a barrier slot of its own in the header page, the
+  // owner's mailboxes addressed with the owner's rank numbers (the halves of a split work on disjoint pairs)
+  std::vector<int> members;     // empty: all ranks of the segment
+  int seg_P = 1;                // ranks of the segment (mailbox pitch)
+  int slot = 0;                 // barrier slot (0: the segment's own)
+  bool owner = true;
   struct Pending { const void* s; void* r; size_t bytes; int peer; };
   std::vector<Pending> sends, recvs;
   std::vector<char> host;
@@ -98,8 +118,27 @@ struct ShmTransport : Transport {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     wait_ms += ms; waits += 1; slow_waits += ms > 10.0 ? 1 : 0;
   }
-  ShmHeader* hdr() { return reinterpret_cast<ShmHeader*>(base); }
-  char* mailbox(int s, int q) { return base + 4096 + ((size_t)s * P + q) * box; }
+  ShmHeader* hdr() { return reinterpret_cast<ShmHeader*>(base + 64 * slot); }
+  int seg_rank(int r) const { return members.empty() ? r : members[(size_t)r]; }
+  char* mailbox(int s, int q) { return base + 4096 + ((size_t)seg_rank(s) * seg_P + seg_rank(q)) * box; }
+  Transport* split(int color, int, int new_rank, const std::vector<int>& mem) override {
+    // barrier slots of the header page, numbered like the nodes of a binary tree: the two halves of the group on slot s get
+    // the slots 2 s + 1 and 2 s + 2 (two colours: what SplitProcessGrid makes), so no two groups alive at the same time share
+    // one; a later split of the same group reuses its children's slots and picks up the sense they were left in
+    auto* t = new ShmTransport();
+    t->rank = new_rank;
+    t->P = (int)mem.size();
+    t->box = box;
+    t->base = base;
+    t->total = total;
+    t->seg_P = seg_P;
+    t->owner = false;
+    for (int m : mem) t->members.push_back(seg_rank(m));
+    t->slot = 2 * slot + 1 + (color & 1);
+    if (t->slot >= 64) NTP_FATAL("shm transport: communicators split more than five levels deep");
+    t->local_sense = t->hdr()->sense;
+    return t;
+  }
   void barrier() {
     const auto tb0 = std::chrono::steady_clock::now();
     barrier_impl();
@@ -195,7 +234,7 @@ struct ShmTransport : Transport {
     if (dbg_sync)
       std::fprintf(stderr, "[shm transport] rank %d: %lld stream waits %.1f ms (%lld longer than 10 ms), barriers %.1f ms, staging copies %.1f ms\n",
                    rank, waits, wait_ms, slow_waits, barrier_ms, copy_ms);
-    if (base) munmap(base, total);
+    if (base && owner) munmap(base, total);
   }
 };
 
@@ -203,6 +242,7 @@ Transport* open_shm(const std::string& name, int rank, int nranks) {
   auto* t = new ShmTransport();
   t->rank = rank;
   t->P = nranks;
+  t->seg_P = nranks;
   const char* mb = std::getenv("NTPOLY_AMD_SHM_MB");
   t->box = (size_t)(mb ? std::atoi(mb) : 16) << 20;
   t->total = 4096 + (size_t)nranks * nranks * t->box;
@@ -231,7 +271,7 @@ void comm_get_unique_id(char out[128]) {
 }
 
 void comm_init(const char idbytes[128], int rank, int nranks) {
-  Comm& c = world();
+  Comm& c = base_world();
   if (c.tr) comm_finalize();
   c.user_init = true;
   c.rank = rank;
@@ -386,7 +426,7 @@ bool mpi_rank_size(const MpiLib& m, int fcomm, int* rank, int* size) {
 }  // namespace
 
 bool comm_bind_mpi(int fcomm) {
-  Comm& c = world();
+  Comm& c = base_world();
   const bool bound = c.tr || c.nranks > 1;       // the engine already has its communicator
   if (!bound && c.user_init) return false;       // an explicit single-rank bootstrap
   const MpiLib& m = mpi_lib();
@@ -429,7 +469,16 @@ bool comm_bind_mpi(int fcomm) {
 }
 
 void comm_finalize() {
-  Comm& c = world();
+  use_comm(nullptr);
+  for (Comm* sc : split_comms()) {   // (sub-communicators first: they lean on the transport of all processes)
+    if (sc->tr) {
+      sync_stream();
+      delete sc->tr;
+    }
+    delete sc;
+  }
+  split_comms().clear();
+  Comm& c = base_world();
   if (c.tr) {
     sync_stream();
     delete c.tr;
@@ -481,6 +530,39 @@ void comm_allgather_i64(const int64_t* mine, int n, int64_t* all) {
 void comm_barrier() {
   double x = 0;
   comm_allreduce_sum(&x, 1);
+}
+
+Comm* comm_split(int color, int key) {
+  Comm& c = world();
+  auto* n = new Comm();
+  n->force = c.force;
+  n->user_init = c.user_init;
+  split_comms().push_back(n);
+  if (!c.active()) {   // one process: the communicator of that process
+    n->rank = 0;
+    n->nranks = 1;
+    return n;
+  }
+  // who has my colour, in (key, rank) order -- one all-gather of (colour, key) over the communicator being split
+  std::vector<int64_t> mine = {(int64_t)color, (int64_t)key}, all((size_t)2 * c.nranks);
+  comm_allgather_i64(mine.data(), 2, all.data());
+  std::vector<int> members;
+  for (int r = 0; r < c.nranks; ++r)
+    if (all[(size_t)2 * r] == (int64_t)color) members.push_back(r);
+  std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return all[(size_t)2 * x + 1] < all[(size_t)2 * y + 1]; });
+  int new_rank = -1;
+  for (size_t i = 0; i < members.size(); ++i)
+    if (members[i] == c.rank) new_rank = (int)i;
+  if (new_rank < 0) NTP_FATAL("comm_split: this rank is not in its own colour");
+  n->rank = new_rank;
+  n->nranks = (int)members.size();
+  n->tr = c.tr->split(color, key, new_rank, members);   // (collective: RCCL builds both halves in one call)
+  if (n->nranks <= 1 && !n->force) {   // a half of one process needs no transport
+    sync_stream();
+    delete n->tr;
+    n->tr = nullptr;
+  }
+  return n;
 }
 
 // Panel all-gather (the reference's ReduceAndComposeMatrix{Sizes,Data,Cleanup}: M1-M3 of SURVEY 2c):
@@ -735,6 +817,7 @@ DevMat gather_needed(const PSMatrix& m, const DevMat& Bloc, int64_t nnz_global[2
 }
 
 DevMat ps_gather_full(const PSMatrix& m) {
+  use_grid_comm(m.grid);
   if (!world().active()) return m.loc.clone();
   const int P = world().nranks;
   std::vector<int32_t> widths((size_t)P);

@@ -30,6 +30,9 @@ struct Transport {
   virtual void group_end() = 0;
   // stream the following point-to-point group is enqueued on (RCCL); the shared-memory test transport is synchronous
   virtual void set_stream(hipStream_t) {}
+  // a transport over the sub-group `members` (ranks of THIS transport, ascending new rank; this rank is members[new_rank]);
+  // collective over this transport's ranks: every rank calls it with its own colour (RCCL: ncclCommSplit)
+  virtual Transport* split(int color, int key, int new_rank, const std::vector<int>& members) = 0;
 };
 struct Comm {
   int rank = 0, nranks = 1;
@@ -38,7 +41,16 @@ struct Comm {
   bool user_init = false;  // ntpoly_amd_init_comm was called (also with one rank): the caller's MPI communicator is not consulted
   bool active() const { return tr != nullptr && (nranks > 1 || force); }
 };
+// The communicator the engine's collectives run on.  Normally the one over all processes; while matrices hosted on a
+// SUB-grid are worked on (SplitProcessGrid / CommSplitMatrix, ProcessGridModule.F90:430-515) that grid's communicator: the C
+// ABI selects it from the grid of the matrices it is handed (use_grid_comm), so the multiply, the reductions and the solvers
+// of a half of the processes stay inside that half.
 Comm& world();
+Comm& base_world();                 // the communicator over all processes, whatever is selected
+void use_comm(Comm* c);             // nullptr: the communicator over all processes
+// MPI_Comm_split on the current communicator (collective): the ranks of one colour, ordered by (key, rank); the result is
+// owned by the engine (kept until comm_finalize)
+Comm* comm_split(int color, int key);
 // halo exchanges of the distributed multiply since the start, and the host synchronisations they needed
 struct ExchangeStats { long long exchanges = 0, host_syncs = 0; };
 ExchangeStats& exchange_stats();
@@ -63,8 +75,18 @@ struct ProcessGrid {
   int num_rows = 1, num_cols = 1, num_slices = 1;
   int my_row = 0, my_col = 0, my_slice = 0;
   int global_rank = 0, total = 1;
+  Comm* comm = nullptr;   // the communicator the grid lives on (nullptr: all processes); set by split_process_grid
   bool is_root() const { return global_rank == 0; }
 };
+void use_grid_comm(const ProcessGrid* g);   // selects the communicator of g (collectives that follow run on it)
+// SplitProcessGrid (ProcessGridModule.F90:430-515): two grids of about half the size, preferably along the slices, else along
+// the longer of rows / columns; collective over the old grid.  The new grid (owned by the engine) lives on a sub-communicator
+// made of the processes of this process's colour in the order of their old ranks.
+ProcessGrid* split_process_grid(const ProcessGrid& old_grid, int* my_color, bool* split_slice);
+// CommSplitMatrix (PSMatrixModule.F90:1489-1541, distributed_includes/CommSplitMatrix.f90): a copy of the WHOLE matrix on each
+// of the two halves of its grid (column panels over the half's processes)
+struct PSMatrix;
+void ps_comm_split(const PSMatrix& m, PSMatrix& split, int* my_color, bool* split_slice);
 ProcessGrid& global_grid();
 bool global_grid_constructed();
 void construct_grid(ProcessGrid& g, int rows, int cols, int slices);

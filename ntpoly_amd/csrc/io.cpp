@@ -76,6 +76,7 @@ void ps_read_matrix_market(PSMatrix& m, const std::string& path, const ProcessGr
 }
 
 void ps_write_matrix_market(const PSMatrix& m, const std::string& path) {
+  use_grid_comm(m.grid);
   const int64_t total = ps_size(m);
   HostTriplets t;
   if (world().active()) {
@@ -102,6 +103,7 @@ void ps_write_matrix_market(const PSMatrix& m, const std::string& path) {
 // header int32[3] {rows, cols, is_complex}, int64 total, then {int32 col, int32 row, f64 val
 // (| f64 re, f64 im)} in native endianness (WriteMatrixToBinary.f90:43-65)
 void ps_write_binary(const PSMatrix& m, const std::string& path) {
+  use_grid_comm(m.grid);
   const int64_t total = ps_size(m);
   HostTriplets t;
   if (world().active()) {

@@ -3824,6 +3824,8 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
         tl.ofirst = fz_first.p; tl.olast = fz_last.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
         tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
         tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = fuse->mode; tl.fz = &fz; tl.rows = tile_rows();
+        tl.abase = aexp.p; tl.abytes = aexp.n * sizeof(double);
+        tl.dbase = dop.dexp.p; tl.dbytes = dop.dexp.n * sizeof(double);
         launch_spgemm_tile(tl);   // (writes the end markers of tile_ooff / tile_otoff as well)
       } else if (max_w_now > 6 * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
       else if (max_w_now > SLAB_NW * SLAB_SL * WAVE) by_mode(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
@@ -3838,6 +3840,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       tl.ofirst = fz_first.p; tl.olast = fz_last.p; tl.ooff = tile_ooff.p;
       tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
       tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = 0; tl.rows = tile_rows();
+      tl.abase = aexp.p; tl.abytes = aexp.n * sizeof(double);
       launch_spgemm_tile(tl);
     } else if (max_w_now > 6 * SLAB_SL * WAVE)         // 1153 .. 1536 rows: eight waves per workgroup
       hipLaunchKernelGGL((k_spgemm_slab<SLAB_J, SLAB_SL, 8, 0>), dim3(xcd_grid(snb)), dim3(8 * WAVE), 0, stream(),
@@ -4490,6 +4493,10 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     tl.ofirst = ofirst.p; tl.olast = olast.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
     tl.alpha = 1.0; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
     tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = &fz; tl.rows = trows; tl.labelled = tile_labelled;
+    if (!halo) {   // (every run of A -- and X itself -- in the iterate's own value buffer, D in its expansion: 32-bit offsets)
+      tl.abase = in.val.p; tl.abytes = in.val.n * sizeof(double);
+      tl.dbase = dop.dexp.p; tl.dbytes = dop.dexp.n * sizeof(double);
+    }
     // (the fused epilogue's arguments travel by value; the kernel writes the end markers of the offsets.)  The two-block
     // geometry first where it can apply: one rank, runs only, two rows per lane; a pair that does not fit after all leaves a
     // mark that comes back with the totals -- the step is then repeated on k_spgemm_tile
@@ -6626,6 +6633,7 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
   tl.ofirst = fo->first.p; tl.olast = fo->last.p; tl.ooff = fo->off.p; tl.otoff = nullptr;
   tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = (dense_rule ? 1 : 0) | 2; tl.ncols = n; tl.nblocks = snb;
   tl.max_kn = P.max_kn; tl.max_w = P.max_w; tl.epi = 0; tl.fz = nullptr; tl.rows = trows; tl.labelled = false;
+  if (!left) { tl.abase = fa.val.p; tl.abytes = fa.val.n * sizeof(double); }   // (the runs of A in one buffer: 32-bit offsets)
   // the two-block geometry first (right operand by its runs); a pair of blocks that does not fit after all leaves a mark
   // that comes back with the entry count, and the product is repeated on k_spgemm_tile
   DevBuf<int> t2fail(2);

@@ -78,6 +78,66 @@ void construct_grid_default(ProcessGrid& g, int slices) {
   construct_grid(g, rows, cols, slices);
 }
 
+void use_grid_comm(const ProcessGrid* g) { use_comm(g ? g->comm : nullptr); }
+
+ProcessGrid* split_process_grid(const ProcessGrid& old_grid, int* my_color, bool* split_slice) {
+  static std::vector<ProcessGrid*>* kept = new std::vector<ProcessGrid*>();   // (grids made here live as long as the library)
+  use_grid_comm(&old_grid);
+  int rows = 1, cols = 1, slices = 1, color = 0;
+  *split_slice = false;
+  if (old_grid.total == 1) {
+    // base case (:447-453)
+  } else if (old_grid.num_slices > 1) {          // preferably along the slices (:455-468)
+    const int mid = old_grid.num_slices / 2;
+    rows = old_grid.num_rows;
+    cols = old_grid.num_cols;
+    color = old_grid.my_slice < mid ? 0 : 1;
+    slices = color == 0 ? mid : old_grid.num_slices - mid;
+    *split_slice = true;
+  } else if (old_grid.num_rows > old_grid.num_cols) {   // else the longer direction (:470-482)
+    const int mid = old_grid.num_rows / 2;
+    cols = old_grid.num_cols;
+    color = old_grid.my_row < mid ? 0 : 1;
+    rows = color == 0 ? mid : old_grid.num_rows - mid;
+  } else {                                       // default: the columns (:484-496)
+    const int mid = old_grid.num_cols / 2;
+    rows = old_grid.num_rows;
+    color = old_grid.my_col < mid ? 0 : 1;
+    cols = color == 0 ? mid : old_grid.num_cols - mid;
+  }
+  *my_color = color;
+  // MPI_COMM_SPLIT(global_comm, my_color, global_rank) (:499-501): the processes of a colour in the order of their old ranks
+  Comm* nc = comm_split(color, old_grid.global_rank);
+  auto* g = new ProcessGrid();
+  kept->push_back(g);
+  use_comm(nc);
+  construct_grid(*g, rows, cols, slices);
+  g->comm = nc;
+  use_grid_comm(&old_grid);
+  return g;
+}
+
+void ps_comm_split(const PSMatrix& m, PSMatrix& split, int* my_color, bool* split_slice) {
+  const ProcessGrid& g = *m.grid;
+  use_grid_comm(&g);
+  if (g.total == 1) {   // (distributed_includes/CommSplitMatrix.f90:11-14)
+    ps_copy(m, split);
+    *my_color = 0;
+    *split_slice = true;
+    return;
+  }
+  // every process of either half ends up with a share of the WHOLE matrix (:20-60: the triplets of the other half travel over
+  // the between-grid communicator); here: the panels gathered once over the old grid, each process cuts the column panel it
+  // owns on its half
+  DevMat full = ps_gather_full(m);
+  ProcessGrid* ng = split_process_grid(g, my_color, split_slice);
+  use_grid_comm(ng);
+  ps_construct_empty(split, m.dim, ng, m.cplx);
+  split.loc = column_slice(full, split.c0, split.c1);
+  sync_stream();
+  use_grid_comm(&g);
+}
+
 void write_grid_info(const ProcessGrid& g) {
   log_header("Process Grid");
   log_enter();
@@ -97,6 +157,7 @@ void panel_range(int32_t dim, int nranks, int rank, int32_t* c0, int32_t* c1) {
 void ps_construct_empty(PSMatrix& m, int32_t dim, const ProcessGrid* g, bool cplx) {
   if (!g) NTP_FATAL("matrix constructed without a process grid (construct the global grid first)");
   ensure_init();
+  use_grid_comm(g);   // (the matrix lives on its grid's communicator: what follows on it runs there)
   m.grid = g;
   m.dim = dim;
   m.cplx = cplx;
@@ -104,7 +165,8 @@ void ps_construct_empty(PSMatrix& m, int32_t dim, const ProcessGrid* g, bool cpl
   m.loc.reset_empty(dim, m.c1 - m.c0, cplx);
 }
 
-void ps_construct_like(PSMatrix& m, const PSMatrix& ref) { ps_construct_empty(m, ref.dim, ref.grid, ref.cplx); }
+void ps_construct_like(PSMatrix& m, const PSMatrix& ref) {
+  use_grid_comm(ref.grid); ps_construct_empty(m, ref.dim, ref.grid, ref.cplx); }
 
 namespace {
 int g_slab_depth = 0;
@@ -186,6 +248,7 @@ void ps_slab_leave(PSMatrix& m) {
 }
 
 void ps_copy(const PSMatrix& a, PSMatrix& b) {
+  use_grid_comm(a.grid);
   if (&a == &b) return;
   if (blk_any({&a})) {
     DevMat t;
@@ -226,11 +289,13 @@ void ps_copy(const PSMatrix& a, PSMatrix& b) {
   b.loc = std::move(t);
 }
 
-void ps_fill_identity(PSMatrix& m) {  // FillMatrixIdentity (O(N) here, O(N^2/P) in the reference)
+void ps_fill_identity(PSMatrix& m) {
+  use_grid_comm(m.grid);  // FillMatrixIdentity (O(N) here, O(N^2/P) in the reference)
   m.loc = identity(m.dim, m.c0, m.c1 - m.c0, m.cplx);
 }
 
 void ps_fill_permutation(PSMatrix& m, const std::vector<int32_t>& lookup, bool rows) {
+  use_grid_comm(m.grid);
   // distributed_includes/FillMatrixPermutation.f90:1-35
   HostTriplets t;
   t.cplx = m.cplx;
@@ -249,6 +314,7 @@ void ps_fill_permutation(PSMatrix& m, const std::vector<int32_t>& lookup, bool r
 }
 
 void ps_fill_from_triplets(PSMatrix& m, const HostTriplets& t) {
+  use_grid_comm(m.grid);
   // FillMatrixFromTripletList (distributed_includes/FillMatrixFromTripletList.f90:14-47): any rank
   // may hold any triplet.  Ranks exchange what they hold (setup path, host triplets travel through
   // device buffers because RCCL moves device memory) and keep their own columns.
@@ -294,11 +360,13 @@ void ps_fill_from_triplets(PSMatrix& m, const HostTriplets& t) {
   m.loc = std::move(acc);
 }
 
-void ps_get_triplets(const PSMatrix& m, HostTriplets& t) { to_triplets(m.loc, m.c0, t); }
+void ps_get_triplets(const PSMatrix& m, HostTriplets& t) {
+  use_grid_comm(m.grid); to_triplets(m.loc, m.c0, t); }
 
 // FillMatrixDense (PSMatrixModule.F90:958-990, distributed_includes/FillMatrixDense.f90): every element of the
 // local panel is 1; dense by definition, so the O(dim * width) host triplets are what the caller asked for
 void ps_fill_dense(PSMatrix& m) {
+  use_grid_comm(m.grid);
   HostTriplets t;
   t.cplx = m.cplx;
   const size_t w = m.cplx ? 2 : 1;
@@ -317,6 +385,7 @@ void ps_fill_dense(PSMatrix& m) {
 // MatrixDiagonalScale (PSMatrixAlgebraModule.F90:507-532, ScaleDiagonal.f90, sparse_includes/DiagonalScale.f90):
 // for every triplet whose column is stored here, the values of that column are multiplied by its value
 void ps_diagonal_scale(PSMatrix& m, const HostTriplets& t) {
+  use_grid_comm(m.grid);
   const int32_t width = m.c1 - m.c0;
   if (width == 0) return;
   const size_t w = m.cplx ? 2 : 1;
@@ -347,6 +416,7 @@ void ps_diagonal_scale(PSMatrix& m, const HostTriplets& t) {
 // [start_row, end_row) x [start_column, end_column) (1-based) and receives its entries with absolute coordinates;
 // an entry goes to the FIRST rank whose block contains it (the EXIT in the reference's routing loop)
 void ps_get_block(const PSMatrix& m, int sr, int er, int sc, int ec, HostTriplets& out) {
+  use_grid_comm(m.grid);
   const int P = world().active() ? world().nranks : 1, me = world().active() ? world().rank : 0;
   std::vector<int64_t> box((size_t)4 * P);
   const int64_t mine[4] = {sr, er, sc, ec};
@@ -375,6 +445,7 @@ void ps_get_block(const PSMatrix& m, int sr, int er, int sc, int ec, HostTriplet
 // GetMatrixSlice (PSMatrixModule.F90:1153-1225, distributed_includes/SliceMatrix.f90): inclusive bounds, result of
 // dimension max(rows, columns) of the slice on the same grid
 void ps_get_slice(const PSMatrix& m, PSMatrix& sub, int sr, int er, int sc, int ec) {
+  use_grid_comm(m.grid);
   HostTriplets t, s;
   ps_get_triplets(m, t);
   s.cplx = m.cplx;
@@ -396,6 +467,7 @@ void ps_get_slice(const PSMatrix& m, PSMatrix& sub, int sr, int er, int sc, int 
 // ResizeMatrix (PSMatrixModule.F90:1704-1741, distributed_includes/ResizeMatrix.f90): entries beyond the new size
 // are dropped
 void ps_resize(PSMatrix& m, int new_size) {
+  use_grid_comm(m.grid);
   HostTriplets t, s;
   ps_get_triplets(m, t);
   s.cplx = m.cplx;
@@ -413,19 +485,22 @@ void ps_resize(PSMatrix& m, int new_size) {
   ps_fill_from_triplets(m, s);
 }
 
-int64_t ps_size(const PSMatrix& m) {  // GetMatrixSize (PSMatrixModule.F90:1360-1389)
+int64_t ps_size(const PSMatrix& m) {
+  use_grid_comm(m.grid);  // GetMatrixSize (PSMatrixModule.F90:1360-1389)
   int64_t n = m.loc.nnz;
   comm_allreduce_sum_i64(&n, 1);
   return n;
 }
 
 void ps_to_complex(const PSMatrix& a, PSMatrix& out) {
+  use_grid_comm(a.grid);
   DevMat t = to_complex(a.loc);
   out.grid = a.grid; out.dim = a.dim; out.c0 = a.c0; out.c1 = a.c1;
   out.cplx = true;
   out.loc = std::move(t);
 }
 void ps_to_real(const PSMatrix& a, PSMatrix& out) {
+  use_grid_comm(a.grid);
   DevMat t = to_real(a.loc);
   out.grid = a.grid; out.dim = a.dim; out.c0 = a.c0; out.c1 = a.c1;
   out.cplx = false;
@@ -704,6 +779,7 @@ DevMat multiply_panel(const PSMatrix& A, const PSMatrix& B, double alpha, double
 }  // namespace
 
 void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha, double beta, double threshold) {
+  use_grid_comm(A.grid);
   if (A.dim != B.dim) NTP_FATAL("MatrixMultiply: dimension mismatch");
   // up-casting of mixed real/complex operands (PSMatrixAlgebraModule.F90:171-188)
   if (A.cplx != B.cplx) {
@@ -846,6 +922,7 @@ void ps_multiply(const PSMatrix& A, const PSMatrix& B, PSMatrix& C, double alpha
 
 // IncrementMatrix_ps (PSMatrixAlgebraModule.F90:414-460)
 void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold) {
+  use_grid_comm(A.grid);
   if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
   if (blk_any({&A, &B}) && &A != &B && !A.cplx && !B.cplx) {
     ps_axpby(A, B, alpha, 1.0, threshold);
@@ -874,6 +951,7 @@ void ps_increment(const PSMatrix& A, PSMatrix& B, double alpha, double threshold
 }
 
 void ps_scale(PSMatrix& A, double c) {
+  use_grid_comm(A.grid);
   if (blk_any({&A})) {
     if (block_scale(A.loc, c)) { g_block_counts[0] += 1; return; }
     g_block_counts[1] += 1;
@@ -890,6 +968,7 @@ void ps_scale(PSMatrix& A, double c) {
 // B <- alpha*A + beta*B: ScaleMatrix(B, beta) followed by IncrementMatrix(A, B, alpha, threshold) in one pass (the
 // merge kernels scale B's values as they read them: the same products, the same rules, bit for bit)
 void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold) {
+  use_grid_comm(A.grid);
   if (A.dim != B.dim) NTP_FATAL("IncrementMatrix: dimension mismatch");
   if (blk_any({&A, &B}) && !A.cplx && !B.cplx && &A != &B && !A.loc.expanded() && !B.loc.expanded() && !A.loc.loose() && !B.loc.loose()) {
     if (block_axpby(A.loc, B.loc, alpha, beta, threshold)) { g_block_counts[0] += 1; return; }
@@ -916,6 +995,7 @@ void ps_axpby(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double 
 }
 
 void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) {
+  use_grid_comm(Identity.grid);
   if (slab_on() && B.loc.expanded() && !B.cplx && !Identity.cplx && Identity.dim == B.dim && slab_add_diagonal(B.loc, alpha, B.c0)) {
     g_slab_counts[1] += 1;
     return;
@@ -934,6 +1014,7 @@ void ps_increment_identity(const PSMatrix& Identity, PSMatrix& B, double alpha) 
 }
 
 bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double beta, double* norm) {
+  use_grid_comm(A.grid);
   if (blk_any({&A, &B})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
   if (world().active() && g_slab_depth > 0 && !A.cplx && !B.cplx && A.dim == B.dim && &A != &B) {
     // (a session across ranks: the decision is collective -- one reduction carries the norm and "some rank declined")
@@ -976,6 +1057,7 @@ bool ps_norm_axpby(const PSMatrix& A, const PSMatrix& B, double alpha, double be
 }
 
 bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, double* trace_gx) {
+  use_grid_comm(X.grid);
   if (blk_any({&X, &X2})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
   if (world().active()) {
     // (a session across ranks: the decision is collective -- the sums and "some rank declined" in one reduction)
@@ -996,6 +1078,7 @@ bool ps_trs4_traces(const PSMatrix& X, const PSMatrix& X2, double* trace_fx, dou
   return true;
 }
 bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatrix& P) {
+  use_grid_comm(X.grid);
   if (blk_any({&X, &X2})) return false;   // (the caller spells it with the vocabulary, which knows the block form)
   if (!slab_on() || !X.loc.expanded() || !X2.loc.expanded() || X.cplx || X2.cplx || sigma == 0.0) return false;
   DevMat R;
@@ -1007,6 +1090,7 @@ bool ps_trs4_operand(const PSMatrix& X, const PSMatrix& X2, double sigma, PSMatr
 }
 
 void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double alpha, double beta, double threshold) {
+  use_grid_comm(B.grid);
   if (blk_any({&A, &B}) && !A.cplx && !B.cplx && &A != &B && &Out != &A && &Out != &B) {
     ps_copy(B, Out);
     ps_axpby(A, Out, alpha, beta, threshold);
@@ -1040,6 +1124,7 @@ void ps_copy_axpby(const PSMatrix& B, const PSMatrix& A, PSMatrix& Out, double a
 
 void ps_axpby_dot(const PSMatrix& A, PSMatrix& B, double alpha, double beta, double threshold, const PSMatrix& D, double out[4],
                   bool want_trace) {
+  use_grid_comm(A.grid);
   out[2] = out[3] = 0.0;
   if (A.cplx != B.cplx || A.cplx != D.cplx || &A == &B) {  // mixed types: unfused sequence
     ps_scale(B, beta);
@@ -1347,6 +1432,7 @@ bool trs2_block(PSMatrix& B, int mode, double threshold, const PSMatrix& D, doub
 }  // namespace
 
 void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
+  use_grid_comm(D.grid);
   out[2] = out[3] = 0.0;
   if (trs2_block(B, 2, threshold, D, out)) return;
   trs2_iterate_form(B);
@@ -1458,6 +1544,7 @@ void ps_square_update_dot(PSMatrix& B, PSMatrix& scratch, double threshold, cons
 // B <- B * B, out = dot(B_new, D) (+ trace(B_new)): the sigma < 0 step of TRS2.  On one rank with real operands the
 // product stays loose (no compaction pass); otherwise multiply, swap and reduce as before.
 void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMatrix& D, double out[4], bool want_trace) {
+  use_grid_comm(D.grid);
   out[2] = out[3] = 0.0;
   if (trs2_block(B, 1, threshold, D, out)) return;
   trs2_iterate_form(B);
@@ -1514,6 +1601,7 @@ void ps_square_dot(PSMatrix& B, PSMatrix& scratch, double threshold, const PSMat
 
 // dot(A, B) and trace(A) from one pass
 void ps_dot_trace(const PSMatrix& A, const PSMatrix& B, double out[4], bool want_trace) {
+  use_grid_comm(A.grid);
   unblock({&A, &B});
   out[2] = out[3] = 0.0;
   if (A.cplx != B.cplx) {
@@ -1526,6 +1614,7 @@ void ps_dot_trace(const PSMatrix& A, const PSMatrix& B, double out[4], bool want
 }
 
 void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {
+  use_grid_comm(A.grid);
   unblock({&A, &B});
   if (A.cplx != B.cplx) {
     PSMatrix Ac, Bc;
@@ -1544,6 +1633,7 @@ void ps_pairwise(const PSMatrix& A, const PSMatrix& B, PSMatrix& C) {
 // DotMatrix_psr/psc (PSMatrixAlgebraModule.F90:387-410, distributed_algebra_includes/DotMatrix.f90):
 // sum conj(A).B; fused, no Hadamard temporary.
 void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
+  use_grid_comm(A.grid);
   if (blk_any({&A, &B}) && !A.cplx && !B.cplx) {
     double d = 0.0;
     // (the sum runs over the super-tiles of its first operand: the one in block form)
@@ -1574,7 +1664,8 @@ void ps_dot(const PSMatrix& A, const PSMatrix& B, double out[2]) {
   comm_allreduce_sum(out, 2);
 }
 
-double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includes/MatrixTrace.f90)
+double ps_trace(const PSMatrix& A) {
+  use_grid_comm(A.grid);  // MatrixTrace (distributed_algebra_includes/MatrixTrace.f90)
   if (blk_any({&A}) && !A.cplx) {
     double t = 0.0;
     if (block_dot_trace(A.loc, A.loc, nullptr, &t)) { g_block_counts[0] += 1; return t; }
@@ -1597,7 +1688,8 @@ double ps_trace(const PSMatrix& A) {  // MatrixTrace (distributed_algebra_includ
   return t;
 }
 
-double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns are local
+double ps_norm(const PSMatrix& A) {
+  use_grid_comm(A.grid);  // MatrixNorm: max column abs-sum; columns are local
   if (blk_any({&A}) && !A.cplx) {
     double v = 0.0;
     if (block_norm(A.loc, &v)) { g_block_counts[0] += 1; return v; }
@@ -1626,12 +1718,14 @@ double ps_norm(const PSMatrix& A) {  // MatrixNorm: max column abs-sum; columns 
   return n;
 }
 
-double ps_sigma(const PSMatrix& A) {  // MatrixSigma (distributed_algebra_includes/MatrixSigma.f90)
+double ps_sigma(const PSMatrix& A) {
+  use_grid_comm(A.grid);  // MatrixSigma (distributed_algebra_includes/MatrixSigma.f90)
   const double n = ps_norm(A);
   return 1.0 / (n * n);
 }
 
-void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {  // GershgorinBounds.f90:1-41
+void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {
+  use_grid_comm(A.grid);  // GershgorinBounds.f90:1-41
   unblock({&A});
   double mn, mx;
   if (slab_on() && A.loc.expanded()) {
@@ -1654,7 +1748,8 @@ void ps_gershgorin(const PSMatrix& A, double* e_min, double* e_max) {  // Gershg
   *e_max = mx;
 }
 
-void ps_transpose(const PSMatrix& A, PSMatrix& AT) {  // TransposeMatrix_ps
+void ps_transpose(const PSMatrix& A, PSMatrix& AT) {
+  use_grid_comm(A.grid);  // TransposeMatrix_ps
   unblock({&A});
   DevMat R;
   if (world().active()) {
@@ -1668,16 +1763,19 @@ void ps_transpose(const PSMatrix& A, PSMatrix& AT) {  // TransposeMatrix_ps
   AT.loc = std::move(R);
 }
 
-void ps_conjugate(PSMatrix& A) { conjugate(A.loc); }
+void ps_conjugate(PSMatrix& A) {
+  use_grid_comm(A.grid); conjugate(A.loc); }
 
-bool ps_is_identity(const PSMatrix& A) {  // distributed_includes/IsIdentity.f90:7-38
+bool ps_is_identity(const PSMatrix& A) {
+  use_grid_comm(A.grid);  // distributed_includes/IsIdentity.f90:7-38
   int64_t d = identity_check(A.loc, A.c0);
   int64_t v[2] = {d < 0 ? 1 : 0, d < 0 ? 0 : d};
   comm_allreduce_sum_i64(v, 2);
   return v[0] == 0 && v[1] == A.dim;
 }
 
-double ps_measure_asymmetry(const PSMatrix& A) {  // MeasureAsymmetry: norm(A - A^H)
+double ps_measure_asymmetry(const PSMatrix& A) {
+  use_grid_comm(A.grid);  // MeasureAsymmetry: norm(A - A^H)
   PSMatrix T;
   ps_transpose(A, T);
   ps_conjugate(T);
@@ -1685,7 +1783,8 @@ double ps_measure_asymmetry(const PSMatrix& A) {  // MeasureAsymmetry: norm(A - 
   return ps_norm(T);
 }
 
-void ps_symmetrize(PSMatrix& A) {  // SymmetrizeMatrix: A <- (A + A^H)/2
+void ps_symmetrize(PSMatrix& A) {
+  use_grid_comm(A.grid);  // SymmetrizeMatrix: A <- (A + A^H)/2
   PSMatrix T;
   ps_transpose(A, T);
   ps_conjugate(T);
@@ -1694,6 +1793,7 @@ void ps_symmetrize(PSMatrix& A) {  // SymmetrizeMatrix: A <- (A + A^H)/2
 }
 
 void ps_similarity(const PSMatrix& A, const PSMatrix& P, const PSMatrix& PInv, PSMatrix& Res, double threshold) {
+  use_grid_comm(A.grid);
   // SimilarityTransform (PSMatrixAlgebraModule.F90:603-654)
   if (ps_is_identity(P)) {
     ps_copy(A, Res);
@@ -1737,6 +1837,7 @@ void permutation_random(Permutation& p, int n) {
 // permutation matrices; out(i,j) = in(perm(i), perm(j)) is computed here by re-indexing and a device
 // sort, with the same result (including the pruning of stored zeros by the threshold-0 products).
 void ps_permute(const PSMatrix& in, PSMatrix& out, const Permutation& perm, bool undo) {
+  use_grid_comm(in.grid);
   const int n = in.dim;
   if ((int)perm.index_lookup.size() != n) NTP_FATAL("permutation size does not match the matrix");
   std::vector<int32_t> map((size_t)n);

@@ -157,7 +157,8 @@ void print_parameters(const SolverParameters& p) {  // SolverParametersModule.F9
   log_exit();
 }
 
-void print_matrix_information(const PSMatrix& m) {  // PSMatrixModule.F90:1248-1266
+void print_matrix_information(const PSMatrix& m) {
+  use_grid_comm(m.grid);  // PSMatrixModule.F90:1248-1266
   double mn = (double)m.loc.nnz, mx = (double)m.loc.nnz;
   comm_allreduce_min(&mn, 1);
   comm_allreduce_max(&mx, 1);
@@ -238,6 +239,7 @@ void density_finish(PSMatrix& X, const PSMatrix& ISQT, const PSMatrix& ISQ, PSMa
 // and WH (same arithmetic: 2*x is exact, then the AddSparseVectors rules, then the energy).
 double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_target, double threshold, double* sigma,
                  double* trace_io) {
+  use_grid_comm(WH.grid);
   // trace_io (optional): in = trace(X) if the caller already has it (NaN: compute it), out = trace of the new X,
   // accumulated in the pass that produces the energy -> one reduction + read-back less per iteration
   const double trace_value = (trace_io && *trace_io == *trace_io) ? *trace_io : ps_trace(X);
@@ -254,6 +256,7 @@ double trs2_step(PSMatrix& X, PSMatrix& X2, const PSMatrix& WH, double trace_tar
 
 void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                  const SolverParameters& p) {
+  use_grid_comm(H.grid);
   // (several ranks, an operand without runs: the whole solve in a recovered band order -- band_scope.cpp)
   if (band_scope_try({&H, &ISQ}, {&K}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) {
         solver_trs2(*in[0], *in[1], trace, *out[0], energy_out, mu_out, p);
@@ -327,6 +330,7 @@ void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
 // running estimates Beta / BetaBar of where lumo and homo have moved to
 void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double homo, double lumo,
                            double* energy_out, const SolverParameters& p) {
+  use_grid_comm(H.grid);
   trace_reset();
   auto t0 = Clock::now();
   Monitor mon;
@@ -393,11 +397,13 @@ void solver_scale_and_fold(const PSMatrix& H, const PSMatrix& ISQ, double trace,
 
 // EnergyDensityMatrix (:1165-1187): ED = D H D
 void energy_density_matrix(const PSMatrix& H, const PSMatrix& D, PSMatrix& ED, double threshold) {
+  use_grid_comm(H.grid);
   ps_similarity(H, D, D, ED, threshold);
 }
 
 // McWeenyStep (:1190-1231): DOut = 3 DSD - 2 DSDSD
 void mcweeny_step(const PSMatrix& D, PSMatrix& DOut, const PSMatrix* S, double threshold) {
+  use_grid_comm(D.grid);
   PSMatrix DS, DSD;
   if (S) ps_multiply(D, *S, DS, 1.0, 0.0, threshold);
   else ps_copy(D, DS);
@@ -411,6 +417,7 @@ void mcweeny_step(const PSMatrix& D, PSMatrix& DOut, const PSMatrix* S, double t
 
 void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                  const SolverParameters& p) {
+  use_grid_comm(H.grid);
   // (several ranks, an operand without runs: the whole solve in a recovered band order -- band_scope.cpp)
   if (band_scope_try({&H, &ISQ}, {&K}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) {
         solver_trs4(*in[0], *in[1], trace, *out[0], energy_out, mu_out, p);
@@ -521,6 +528,7 @@ void solver_trs4(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
 // ------------------------------------------------------------------ PM
 void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                const SolverParameters& p) {
+  use_grid_comm(H.grid);
   // (several ranks, an operand without runs: the whole solve in a recovered band order -- band_scope.cpp)
   if (band_scope_try({&H, &ISQ}, {&K}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) {
         solver_pm(*in[0], *in[1], trace, *out[0], energy_out, mu_out, p);
@@ -625,6 +633,7 @@ void solver_pm(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K
 // ------------------------------------------------------------------ HPCP
 void solver_hpcp(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, double* energy_out, double* mu_out,
                  const SolverParameters& p) {
+  use_grid_comm(H.grid);
   // (several ranks, an operand without runs: the whole solve in a recovered band order -- band_scope.cpp)
   if (band_scope_try({&H, &ISQ}, {&K}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) {
         solver_hpcp(*in[0], *in[1], trace, *out[0], energy_out, mu_out, p);
@@ -774,6 +783,7 @@ void sign_core(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters& 
 }  // namespace
 
 void solver_sign(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p) {
+  use_grid_comm(A.grid);
   if (band_scope_try({&A}, {&Out}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) { solver_sign(*in[0], *out[0], p); }))
     return;
   trace_reset();
@@ -791,6 +801,7 @@ void solver_sign(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p) {
 }
 
 void solver_polar(const PSMatrix& A, PSMatrix& U, PSMatrix* Hm, const SolverParameters& p) {
+  use_grid_comm(A.grid);
   trace_reset();
   if (p.be_verbose) {
     log_header("Polar Decomposition Solver");
@@ -874,12 +885,14 @@ void invert_core(const PSMatrix& InputMat, PSMatrix& OutputMat, const SolverPara
 }  // namespace
 
 void solver_invert(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p) {
+  use_grid_comm(A.grid);
   if (band_scope_try({&A}, {&Out}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) { solver_invert(*in[0], *out[0], p); }))
     return;
   trace_reset();
   invert_core(A, Out, p, true);
 }
 void solver_pseudoinverse(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p) {
+  use_grid_comm(A.grid);
   if (band_scope_try({&A}, {&Out}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) { solver_pseudoinverse(*in[0], *out[0], p); }))
     return;
   trace_reset();
@@ -1046,6 +1059,7 @@ void isr_taylor(const PSMatrix& InMat, PSMatrix& OutMat, const SolverParameters&
 }  // namespace
 
 void solver_square_root(const PSMatrix& A, PSMatrix& Out, const SolverParameters& p, bool inverse, int order) {
+  use_grid_comm(A.grid);
   if (band_scope_try({&A}, {&Out}, [&](const std::vector<const PSMatrix*>& in, const std::vector<PSMatrix*>& out) { solver_square_root(*in[0], *out[0], p, inverse, order); }))
     return;
   trace_reset();

@@ -26,17 +26,20 @@ void conj_transpose(const PSMatrix& A, PSMatrix& AT) {
 
 // FilterMatrix (PSMatrixModule.F90:1318-1357): entries with |v| > threshold stay
 void ps_filter(PSMatrix& m, double threshold) {
+  use_grid_comm(m.grid);
   m.loc = filter(m.loc, threshold);
 }
 
 // GatherMatrixTripletList: every rank receives every entry (ordered by column, then row)
 void ps_gather_triplets(const PSMatrix& m, HostTriplets& t) {
+  use_grid_comm(m.grid);
   DevMat full = ps_gather_full(m);
   to_triplets(full, 0, t);
 }
 
 // ------------------------------------------------------------------ CG (LinearSolversModule.F90:31-171)
 void solver_cg(const PSMatrix& AMat, PSMatrix& XMat, const PSMatrix& BMat, const SolverParameters& p_in) {
+  use_grid_comm(AMat.grid);
   Monitor mon;
   const SolverParameters p = with_monitor(p_in, mon);
   if (p.be_verbose) {
@@ -99,6 +102,7 @@ void solver_cg(const PSMatrix& AMat, PSMatrix& XMat, const PSMatrix& BMat, const
 
 // ------------------------------------------------------------------ Pade exponential (ExponentialSolversModule.F90:152-271)
 void compute_exponential_pade(const PSMatrix& In, PSMatrix& OutMat, const SolverParameters& p) {
+  use_grid_comm(In.grid);
   if (p.be_verbose) {
     log_header("Exponential Solver");
     log_enter();
@@ -156,7 +160,8 @@ void compute_exponential_pade(const PSMatrix& In, PSMatrix& OutMat, const Solver
 
 // ------------------------------------------------------------------ GeometryOptimizationModule.F90
 void purification_extrapolate(const PSMatrix& PreviousDensity, const PSMatrix& Overlap, double trace, PSMatrix& NewDensityOut,
-                              const SolverParameters& p_in) {                  // :24-136
+                              const SolverParameters& p_in) {
+  use_grid_comm(PreviousDensity.grid);                  // :24-136
   Monitor mon;
   const SolverParameters p = with_monitor(p_in, mon);
   if (p.be_verbose) {
@@ -214,7 +219,8 @@ void purification_extrapolate(const PSMatrix& PreviousDensity, const PSMatrix& O
 }
 
 void lowdin_extrapolate(const PSMatrix& PreviousDensity, const PSMatrix& OldOverlap, const PSMatrix& NewOverlap,
-                        PSMatrix& NewDensity, const SolverParameters& p) {     // :137-214
+                        PSMatrix& NewDensity, const SolverParameters& p) {
+  use_grid_comm(PreviousDensity.grid);     // :137-214
   if (p.be_verbose) {
     log_header("Density Matrix Extrapolator");
     log_enter();
@@ -236,6 +242,7 @@ void lowdin_extrapolate(const PSMatrix& PreviousDensity, const PSMatrix& OldOver
 
 // ------------------------------------------------------------------ MatrixConversionModule.F90:12-43
 void snap_to_sparsity_pattern(PSMatrix& mat, const PSMatrix& pattern) {
+  use_grid_comm(pattern.grid);
   PSMatrix ones, zeros, filtered;
   if (pattern.cplx) ps_to_real(pattern, ones);
   else ps_copy(pattern, ones);
@@ -269,6 +276,7 @@ void snap_to_sparsity_pattern(PSMatrix& mat, const PSMatrix& pattern) {
 // code, same device type), so no broadcast of the vectors is needed.
 void ps_eigendecomposition(const PSMatrix& A, PSMatrix& eigenvalues, PSMatrix* eigenvectors, int nvals,
                            const SolverParameters& p) {
+  use_grid_comm(A.grid);
   if (p.be_verbose) {
     log_header("Eigen Solver");
     log_enter();
@@ -313,6 +321,7 @@ void ps_eigendecomposition(const PSMatrix& A, PSMatrix& eigenvalues, PSMatrix* e
 // DenseMatrixFunction (EigenSolversModule.F90:74-131): f(A) = V f(L) V^H
 void dense_matrix_function(const PSMatrix& A, PSMatrix& Result, const std::function<double(double)>& func,
                            const SolverParameters& p) {
+  use_grid_comm(A.grid);
   PSMatrix vecs, vecsT, vals, Out;
   ps_eigendecomposition(A, vals, &vecs, A.dim, p);
   HostTriplets t;
@@ -336,6 +345,7 @@ void dense_matrix_function(const PSMatrix& A, PSMatrix& Result, const std::funct
 
 // SingularValueDecomposition (SingularValueSolversModule.F90:14-52): polar decomposition, then the eigenpairs of H
 void ps_svd(const PSMatrix& A, PSMatrix& left, PSMatrix& right, PSMatrix& singular, const SolverParameters& p) {
+  use_grid_comm(A.grid);
   if (p.be_verbose) {
     log_header("Singular Value Solver");
     log_enter();
@@ -354,6 +364,7 @@ void ps_svd(const PSMatrix& A, PSMatrix& left, PSMatrix& right, PSMatrix& singul
 
 // EstimateGap (EigenSolversModule.F90:153-226)
 void estimate_gap(const PSMatrix& H, const PSMatrix& K, double chemical_potential, double* gap, const SolverParameters& p) {
+  use_grid_comm(H.grid);
   if (p.be_verbose) {
     log_header("Estimate Gap");
     log_enter();
@@ -397,7 +408,8 @@ double foe_erf(double x) {  // :531-546 (its own rational approximation, kept fo
 }  // namespace
 
 void compute_dense_foe(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix& K, const double* inv_temp_in,
-                       double* energy_out, double* mu_out, const SolverParameters& p) {  // :31-248
+                       double* energy_out, double* mu_out, const SolverParameters& p) {
+  use_grid_comm(H.grid);  // :31-248
   const bool do_smearing = inv_temp_in != nullptr;
   const double inv_temp = do_smearing ? *inv_temp_in : 0.0;
   if (p.be_verbose) {
@@ -528,6 +540,7 @@ void wom_c_step(const PSMatrix& X, const PSMatrix& A, const PSMatrix& W, double 
 // WOM_Implementation (:317-447): adaptive Heun integration of the wave-operator flow up to inv_temp
 void solver_wom(const PSMatrix& H, const PSMatrix& ISQ, PSMatrix& K, double inv_temp, const double* trace_in,
                 const double* mu_in, double* energy_out, const SolverParameters& p) {
+  use_grid_comm(H.grid);
   const bool GC = mu_in != nullptr;
   if (p.be_verbose) {
     log_header("Density Matrix Solver");
@@ -631,6 +644,7 @@ void solver_wom(const PSMatrix& H, const PSMatrix& ISQ, PSMatrix& K, double inv_
 // at a time with a broadcast per column; here every rank factors the gathered dense matrix on its GPU and keeps
 // its own column panel of L.  rank < 0: plain Cholesky.
 void ps_cholesky(const PSMatrix& A, PSMatrix& L, int rank, const SolverParameters& p) {
+  use_grid_comm(A.grid);
   if (A.cplx) NTP_FATAL("CholeskyDecomposition: real matrices only (as the reference, LinearSolversModule.F90:186-187)");
   if (p.be_verbose) {
     log_header("Linear Solver");
@@ -667,6 +681,7 @@ void ps_cholesky(const PSMatrix& A, PSMatrix& L, int rank, const SolverParameter
 
 // ReduceDimension (AnalysisModule.F90:199-245)
 void reduce_dimension(const PSMatrix& A, int dim, PSMatrix& Reduced, const SolverParameters& p) {
+  use_grid_comm(A.grid);
   PSMatrix Identity, PMat, PVec, PVecT, VAV;
   ps_construct_like(Identity, A);
   ps_fill_identity(Identity);

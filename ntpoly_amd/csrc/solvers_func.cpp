@@ -14,6 +14,7 @@ namespace ntp {
 
 // ------------------------------------------------------------------ PowerBounds
 void power_bounds(const PSMatrix& A, double* max_value_out, const SolverParameters& p_in, bool defaults) {
+  use_grid_comm(A.grid);
   SolverParameters p = p_in;
   if (defaults) p.max_iterations = 10;  // :81-86
   Monitor mon;
@@ -87,6 +88,7 @@ void power_bounds(const PSMatrix& A, double* max_value_out, const SolverParamete
 
 // ------------------------------------------------------------------ exponential
 void compute_exponential(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p) {
+  use_grid_comm(In.grid);
   SolverParameters sub = p, psub = p;
   psub.max_iterations = 10;
   if (p.be_verbose) {
@@ -217,9 +219,11 @@ void scale_square_trig(const PSMatrix& In, PSMatrix& Out, const SolverParameters
 }
 }  // namespace
 
-void compute_cosine(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p) { scale_square_trig(In, Out, p); }
+void compute_cosine(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p) {
+  use_grid_comm(In.grid); scale_square_trig(In, Out, p); }
 
-void compute_sine(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p) {  // sin(x) = cos(x - pi/2), :30-64
+void compute_sine(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p) {
+  use_grid_comm(In.grid);  // sin(x) = cos(x - pi/2), :30-64
   const double PI = 4 * std::atan(1.0);
   PSMatrix Shifted, Ident;
   ps_copy(In, Shifted);
@@ -333,7 +337,8 @@ void root_impl(const PSMatrix& In, PSMatrix& Out, int root, const SolverParamete
 }
 }  // namespace
 
-void compute_root(const PSMatrix& In, PSMatrix& Out, int root, const SolverParameters& p) {  // :31-83
+void compute_root(const PSMatrix& In, PSMatrix& Out, int root, const SolverParameters& p) {
+  use_grid_comm(In.grid);  // :31-83
   if (p.be_verbose) {
     log_header("Root Solver");
     log_enter();
@@ -363,7 +368,8 @@ void compute_root(const PSMatrix& In, PSMatrix& Out, int root, const SolverParam
   if (p.be_verbose) log_exit();
 }
 
-void compute_inverse_root(const PSMatrix& In, PSMatrix& Out, int root, const SolverParameters& p) {  // :124-174
+void compute_inverse_root(const PSMatrix& In, PSMatrix& Out, int root, const SolverParameters& p) {
+  use_grid_comm(In.grid);  // :124-174
   if (p.be_verbose) {
     log_header("Inverse Root Solver");
     log_enter();
@@ -396,6 +402,7 @@ void compute_inverse_root(const PSMatrix& In, PSMatrix& Out, int root, const Sol
 
 // ------------------------------------------------------------------ logarithm
 void compute_logarithm(const PSMatrix& In, PSMatrix& Out, const SolverParameters& p) {
+  use_grid_comm(In.grid);
   SolverParameters isub = p, psub = p, fsub = p;
   psub.max_iterations = 16;
   if (p.be_verbose) {

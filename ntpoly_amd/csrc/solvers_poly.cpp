@@ -55,6 +55,7 @@ void poly_header(const char* solver, const char* method, const char* citation, i
 
 // ------------------------------------------------------------------ Horner
 void polynomial_horner(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p) {
+  use_grid_comm(In.grid);
   const int degree = (int)c.size();
   if (degree < 1) NTP_FATAL("polynomial without coefficients");
   poly_header("Polynomial Solver", "Horner", nullptr, degree, p, false);
@@ -84,6 +85,7 @@ void polynomial_horner(const PSMatrix& In, PSMatrix& Out, const std::vector<doub
 // ------------------------------------------------------------------ Paterson-Stockmeyer
 void polynomial_paterson_stockmeyer(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c,
                                     const SolverParameters& p) {
+  use_grid_comm(In.grid);
   const int degree = (int)c.size();
   if (degree < 2) NTP_FATAL("Paterson-Stockmeyer needs a polynomial of degree >= 1");
   const int m_value = degree - 1;
@@ -140,6 +142,7 @@ void polynomial_paterson_stockmeyer(const PSMatrix& In, PSMatrix& Out, const std
 
 // ------------------------------------------------------------------ Chebyshev, three-term recurrence
 void chebyshev_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p) {
+  use_grid_comm(In.grid);
   const int degree = (int)c.size();
   if (degree < 1) NTP_FATAL("polynomial without coefficients");
   poly_header("Chebyshev Solver", "Standard", nullptr, degree, p, true);
@@ -206,6 +209,7 @@ void cheby_recursive(const std::vector<PSMatrix>& T, const std::vector<double>& 
 }  // namespace
 
 void chebyshev_factorized(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p) {
+  use_grid_comm(In.grid);
   const int degree = (int)c.size();
   if (degree < 1) NTP_FATAL("polynomial without coefficients");
   poly_header("Chebyshev Solver", "Recursive", nullptr, degree, p, true);
@@ -237,6 +241,7 @@ void chebyshev_factorized(const PSMatrix& In, PSMatrix& Out, const std::vector<d
 
 // ------------------------------------------------------------------ Hermite
 void hermite_compute(const PSMatrix& In, PSMatrix& Out, const std::vector<double>& c, const SolverParameters& p) {
+  use_grid_comm(In.grid);
   const int degree = (int)c.size();
   if (degree < 1) NTP_FATAL("polynomial without coefficients");
   poly_header("Hermite Solver", "Standard", nullptr, degree, p, true);

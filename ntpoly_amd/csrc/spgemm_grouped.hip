@@ -451,7 +451,15 @@ struct GhTable {
   static constexpr int SHIFT = TH == 2048 ? 22 : TH == 4096 ? 21 : 20;   // top bits of the multiplicative hash -> bucket (TH / 2 of them)
 };
 
-template <typename T, int NW, int SL, int WPC>
+// MF (real operands, FMA arithmetic): the products of a phase on the FP64 matrix cores.  The four steps of a phase are the k
+// dimension of ONE v_mfma_f64_16x16x4_f64 per tile of 16 slots: A operand = x[step][slot] straight from the slot-indexed LDS
+// copies (lane l: slot 16 tile + l % 16 of step l / 16), B operand = the phase's four multiplier rows (lane l: row l / 16,
+// column l % 16 of the group's tile, one coalesced load per phase), accumulator = the sums of 16 slots x 16 columns.  The matrix
+// instruction adds its four products in ascending k with one rounding each -- the chain of fma() the vector path computes
+// (tools/micro/mfma_f64_probe.hip), so the results are bit for bit the same; a slot a column does not touch contributes
+// fma(0, b, acc) = acc.  A lane then owns (4 slots x 1 column) per tile instead of (1 slot x 16 columns) per chunk; the
+// epilogue is the same prune / rank-bitmap / compaction re-indexed.
+template <typename T, int NW, int SL, int WPC, bool MF = false>
 __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL == 1 && !Sc<T>::cplx) ? 6 : 2))) void k_spgemm_ghash(
     Csc A, const int32_t* __restrict__ cols, const int32_t* __restrict__ grp_kn, const int32_t* __restrict__ grp_maxlen,
     const int64_t* __restrict__ grp_off, const GhRec* __restrict__ recs, const T* __restrict__ tiles,
@@ -465,7 +473,10 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
   constexpr unsigned long long EMPTY = ~0ull;
   static_assert(NW % WPC == 0 && KB >= 1 && 2 * KB * CAP >= 2 * CAP, "geometry");
   __shared__ unsigned long long htab[TH];   // (row << 32 | slot); the epilogue sorts (row, slot) pairs in the same memory
-  __shared__ T xbuf[2][KB][CAP];            // slot-indexed copies of the A columns of two consecutive phases
+  static_assert(!MF || (!Sc<T>::cplx && KB == 4 && CAP % (16 * NW) == 0), "matrix-core products: real operands, four steps per phase");
+  constexpr int XP = MF ? CAP + 16 : CAP;   // (MF: rows 16 slots apart in the banks -- the four steps a lane group reads do not collide)
+  constexpr int NTILE = CAP / (16 * NW);    // MF: tiles of 16 slots per wave (tile u of wave w = slots 16 (u NW + w) ..)
+  __shared__ T xbuf[2][KB][XP];             // slot-indexed copies of the A columns of two consecutive phases
   __shared__ int slot_row[CAP];
   __shared__ int ctl[4];                    // [0] slots handed out, [1], [2] overflow seen while scattering an even / odd
                                             // phase (read after the barrier that ends that scatter, rewritten two
@@ -482,7 +493,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
   }
   const int nph = (kn + KB - 1) / KB;
   for (int s = tid; s < TH; s += NT) htab[s] = EMPTY;
-  for (int s = tid; s < 2 * KB * CAP; s += NT) (&xbuf[0][0][0])[s] = Sc<T>::zero();
+  for (int s = tid; s < 2 * KB * XP; s += NT) (&xbuf[0][0][0])[s] = Sc<T>::zero();
   for (int s = tid; s < CAP; s += NT) slot_row[s] = -1;
   if (tid < 4) ctl[tid] = 0;
   __syncthreads();
@@ -494,11 +505,18 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
   const T* __restrict__ tile = tiles + off * G;
   const int my_kb = wave / WPC, my_part = wave % WPC;   // this wave's column of a phase and its share of it
 
-  T acc[SL][G];
+  T acc[MF ? 1 : SL][MF ? 1 : G];
+  typedef double mf_v4d __attribute__((ext_vector_type(4)));
+  [[maybe_unused]] mf_v4d macc[MF ? NTILE : 1];   // MF: element v of tile u = slot 16 (u NW + wave) + 4 v + lane / 16, column lane % 16
+  if constexpr (MF) {
 #pragma unroll
-  for (int s = 0; s < SL; ++s)
+    for (int u = 0; u < NTILE; ++u) macc[u] = mf_v4d{0.0, 0.0, 0.0, 0.0};
+  } else {
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[s][g] = Sc<T>::zero();
+    for (int s = 0; s < SL; ++s)
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[s][g] = Sc<T>::zero();
+  }
 
   struct Fetch {
     int idx[PF];
@@ -624,6 +642,26 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
     const int nsl = uni_i32(min(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), CAP));
     const int t0 = ph * KB;
     const int nstep = min(KB, kn - t0);
+    if constexpr (MF) {
+      // this lane's multiplier: row t0 + lane / 16, column lane % 16 of the tile (rows beyond the union: zero, whatever the
+      // padding of the tile holds)
+      const int q = lane >> 4, jj = lane & 15;
+      double bv = 0.0;
+      if constexpr (!Sc<T>::cplx) bv = (q < nstep) ? tile[(int64_t)(t0 + q) * G + jj] : 0.0;
+#pragma unroll
+      for (int u = 0; u < NTILE; ++u) {
+        const int s0 = 16 * (u * NW + wave);
+        if (s0 < nsl) {
+          if constexpr (!Sc<T>::cplx) {
+            const double xv = xbuf[set][q][s0 + jj];
+            if (__ballot(xv != 0.0) != 0ull) {
+              xbuf[set][q][s0 + jj] = 0.0;
+              macc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, bv, macc[u], 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else {
     // the multipliers (wave-uniform: scalar registers) are fetched two rows per round trip of the scalar cache
     for (int kb = 0; kb < nstep; kb += 2) {
       const T* __restrict__ brow = tile + (int64_t)(t0 + kb) * G;
@@ -650,6 +688,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
           }
         }
       }
+    }
     }
     if (ablate & 8) c3s = __builtin_amdgcn_s_memtime();
     __syncthreads();
@@ -731,8 +770,28 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
   }
   if (tid == 0) atomicMax(&stats[1], (unsigned long long)nsl);
   __syncthreads();
-  unsigned long long keepbits = 0;   // bit s * G + g
+  unsigned long long keepbits = 0;   // bit s * G + g (MF: bit 4 u + v)
   int myrank[SL], myrow[SL];
+  if constexpr (MF) {
+    // (a lane's sums: slots 16 (u NW + wave) + 4 v + lane / 16 of column lane % 16)
+    const int q = lane >> 4, g = lane & 15;
+#pragma unroll
+    for (int u = 0; u < NTILE; ++u) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int slot = 16 * (u * NW + wave) + 4 * v + q;
+        const int row = slot < nsl ? slot_row[slot] : -1;
+        if (row >= 0) {
+          const double val = macc[u][v];
+          if (fabs((dense_rule & 1) ? val : __dmul_rn(alpha, val)) > threshold) {
+            const int rk = rank_s[slot];
+            keepbits |= 1ull << (4 * u + v);
+            atomicOr(&bm[g * NWORD + (rk >> 6)], 1ull << (rk & 63));
+          }
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < SL; ++s) {
     const int slot = (wave + NW * s) * WAVE + lane;
@@ -749,6 +808,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
       }
     }
   }
+  }
   __syncthreads();
   for (int i = tid; i < G * NWORD; i += NT) {
     const int g = i / NWORD, w = i % NWORD;
@@ -761,6 +821,23 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
     }
   }
   __syncthreads();
+  if constexpr (MF) {
+    const int q = lane >> 4, g = lane & 15;
+#pragma unroll
+    for (int u = 0; u < NTILE; ++u) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if ((keepbits >> (4 * u + v)) & 1ull) {
+          const int slot = 16 * (u * NW + wave) + 4 * v + q;
+          const int rk = rank_s[slot];
+          const int w = rk >> 6, bit = rk & 63;
+          const int64_t pos = colbase[g] + pre[g * NWORD + w] + __popcll(bm[g * NWORD + w] & ((1ull << bit) - 1ull));
+          out_inner[pos] = slot_row[slot];
+          if constexpr (!Sc<T>::cplx) out_val[pos] = __dmul_rn(alpha, macc[u][v]);
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < SL; ++s) {
 #pragma unroll
@@ -772,6 +849,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
         out_val[pos] = Sc<T>::scale(alpha, acc[s][g]);
       }
     }
+  }
   }
   if ((ablate & 8) && tid == 0) {
     atomicAdd(&stats[13], __builtin_amdgcn_s_memtime() - epi0);
@@ -798,7 +876,7 @@ __global__ void k_gh_finish(const int32_t* __restrict__ cols, const uint8_t* __r
   }
 }
 
-template <typename T, int NW, int SL, int WPC>
+template <typename T, int NW, int SL, int WPC, bool MF = false>
 void launch_ghash(const DevMat& A, int ngroups, const int32_t* cols, const int32_t* grp_kn, const int32_t* grp_maxlen,
                   const int64_t* grp_off, const GhRec* recs, const double* tiles, const int64_t* tmpoff, int32_t* tmp_inner,
                   double* tmp_val, int32_t* count, uint8_t* state, unsigned long long* stats, double alpha, double thr, int dr) {
@@ -809,7 +887,7 @@ void launch_ghash(const DevMat& A, int ngroups, const int32_t* cols, const int32
   // (the wrong-result experiment bits exist only in the experiment build, -DNTP_ABLATIONS; 518 = in-kernel stamps stays)
   const int ablate = (sv == 518) ? 8 : 0;
 #endif
-  hipLaunchKernelGGL((k_spgemm_ghash<T, NW, SL, WPC>), dim3(xcd_grid(ngroups)), dim3(NW * WAVE), 0, stream(), view(A), cols, grp_kn,
+  hipLaunchKernelGGL((k_spgemm_ghash<T, NW, SL, WPC, MF>), dim3(xcd_grid(ngroups)), dim3(NW * WAVE), 0, stream(), view(A), cols, grp_kn,
                      grp_maxlen, grp_off, recs, reinterpret_cast<const T*>(tiles), tmpoff, tmp_inner,
                      reinterpret_cast<T*>(tmp_val), count, state, stats, alpha, thr, dr, ngroups, ablate);
 }
@@ -994,6 +1072,19 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
   const int first = start;
   for (int level = first; level < 3; ++level) {
     stats.zero();
+    // (real operands in FMA arithmetic: the products on the matrix cores, four steps per phase -- option ghash_mfma)
+    const bool mf = !A.cplx && (dense_rule & 2) != 0 && options().ghash_mfma != 0;
+    if (mf) {
+      if (level == 0)
+        launch_ghash<double, 8, 1, 2, true>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
+                                            count, state.p, stats.p, alpha, threshold, dense_rule);
+      else if (level == 1)
+        launch_ghash<double, 8, 2, 2, true>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
+                                            count, state.p, stats.p, alpha, threshold, dense_rule);
+      else   // (the largest class: four slot-indexed columns of 1536 per set and the table do not fit the LDS together -- vector units)
+        launch_ghash<double, 8, 3, 4>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
+                                      count, state.p, stats.p, alpha, threshold, dense_rule);
+    } else
     dispatch_type(A.cplx, [&](auto tag) {
       using T = decltype(tag);
       if (level == 0)

@@ -56,6 +56,24 @@ template <int R> __device__ inline void rv_store(double* p, const typename RowVe
   *reinterpret_cast<typename RowVec<R>::type __attribute__((address_space(1)))*>(reinterpret_cast<unsigned long long>(p)) = v;
 }
 
+// buffer loads (raw, offen): out-of-range offsets read as zero -- the "outside the run" case of the A operand costs no select
+// of a 64-bit address and no load from a page of zeros
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr unsigned TILE_OOB = 0xffffff00u;   // (beyond every buffer: abytes < 4 GB - 4 KB)
+template <int R> __device__ inline typename RowVec<R>::type rv_buffer_load(__amdgpu_buffer_rsrc_t rsrc, unsigned off);
+template <> __device__ inline double rv_buffer_load<1>(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+}
+template <> __device__ inline v2d rv_buffer_load<2>(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+  return __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+}
+template <> __device__ inline v4d rv_buffer_load<4>(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+  const v2d lo = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+  const v2d hi = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0));
+  return v4d{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // run of column k as the tile loop wants it: rz = address of (hypothetical) row 0, valid rows first .. last
 struct alignas(16) TileRec {
   unsigned long long rz;
@@ -63,7 +81,7 @@ struct alignas(16) TileRec {
   uint32_t span;     // last - first; an empty run: first = INT_MAX, span = 0 (no row passes (unsigned)(r - first) <= span)
 };
 constexpr int TILE_PF = 6;           // run loads (k groups) in flight per wave; a multiple of 3
-constexpr int TILE_RPAD = 4, TILE_BPAD = 0;   // one group of empty records behind the last (the pipeline's look-ahead is clamped to it)
+constexpr int TILE_RPAD = 4, TILE_BPAD = 0;   // one group of empty records behind the last (the pipeline's look-ahead is clamped to it; OFF32: see the loop)
 // an element of X whose fate depends on the last kept row of the product column (decided when the block is done)
 struct alignas(16) TileDefer {
   int32_t r, jj, prow, pad;
@@ -93,6 +111,14 @@ struct TileArgs {
   const int64_t* brun_off;
   const double* brun_val;
   const double* zero;   // 16 bytes of zeros: where the lanes outside a run load from
+  // OFF32 instantiations: every run of A lies in [abase, abase + abytes), abytes < 4 GB -- the runs are read through a buffer
+  // resource with 32-bit offsets, lanes outside a run get an offset beyond the buffer (the bounds check returns 0.0)
+  const void* abase;
+  uint32_t abytes;
+  // OFF32 instantiations with a fused epilogue: X lies in the same allocation as the runs of A (it IS the left operand of a
+  // TRS2 step), the expanded D operand in [dbase, dbase + dbytes) -- the epilogue's reads go through buffer resources too
+  const void* dbase;
+  uint32_t dbytes;
   int ablate;           // experiment build (-DNTP_ABLATIONS) only
 #ifdef NTP_TILE_STAMPS
   long long* stamps;    // diagnostic build: [block][wave][64] s_memtime stamps
@@ -112,7 +138,7 @@ __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax, int lab_ro
 #define STAMP(i) do { } while (0)
 #endif
 
-template <int EPI, int TILE_NW, int R, bool LAB>
+template <int EPI, int TILE_NW, int R, bool LAB, bool OFF32>
 __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(((EPI == 0 || !LAB) && R <= 2) ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = xcd_block(a.nblocks);
@@ -227,6 +253,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       if (rows > 0) {
         const unsigned long long addr = (unsigned long long)r0.x | ((unsigned long long)r0.y << 32);
         rec.rz = addr - (unsigned long long)((long long)first * 8);
+        if constexpr (OFF32) rec.rz -= reinterpret_cast<unsigned long long>(a.abase);   // (the low word is the offset, modulo 2^32)
         rec.first = first - (R - 1);               // a lane's rows ra .. ra + R - 1 touch the run iff (unsigned)(ra - rec.first) <= rec.span
         rec.span = (uint32_t)(rows - 1 + (R - 1));
         rmin = first;
@@ -275,15 +302,18 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   STAMP(63);
   if constexpr (EPI != 0) {
     if (a.fzv.prod) {   // products of this block = sum over the tile rows k of (non-zero multipliers) * (entries of A(:, k))
+      // (wave-uniform work: a wave reads four tile rows at once, the ballot of their non-zeros gives the four counts, the
+      // entry counts of the columns of A are scalar loads -- almost nothing of it issues on the vector unit)
       const int32_t* __restrict__ in_count = a.fzv.in_count;
       long long p = 0;
-      for (int k = tid; k < kn; k += TILE_NW * WAVE) {
-        int c = 0;
+      for (int k4 = 4 * wave; k4 < kn; k4 += 4 * TILE_NW) {
+        const unsigned long long m = __ballot(Bs[(size_t)k4 * SLAB_J + lane] != 0.0);   // (rows kn .. K4 are zero)
 #pragma unroll
-        for (int qq = 0; qq < SLAB_J; ++qq) c += Bs[(size_t)k * SLAB_J + ((qq + tid) & 15)] != 0.0 ? 1 : 0;
-        p += (long long)c * (in_count ? in_count[kmin + k] : 1);
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int c = __builtin_popcount((unsigned)(m >> (16 * s4)) & 0xffffu);
+          p += (long long)c * (in_count ? in_count[kmin + min(k4 + s4, kn - 1)] : 1);
+        }
       }
-      p = wave_sum_i64(p);
       if (lane == 0 && p) atomicAdd(reinterpret_cast<unsigned long long*>(misc + 2), (unsigned long long)p);
     }
   }
@@ -329,6 +359,27 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       }
     }
   }
+  // (OFF32: the same columns as offsets into the two buffers; a lane's rows rb .. rb + R - 1 touch the run iff
+  // (unsigned)(rb - first') <= span', as for the runs of A)
+  [[maybe_unused]] unsigned xo0 = 0, xsp = 0, do0 = 0, dsp = 0;
+  [[maybe_unused]] int xf1 = INT_MAX, df1 = INT_MAX;
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t xrsrc, drsrc;
+  if constexpr (OFF32 && EPI != 0) {
+    drsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dbase), 0, a.dbytes, 0x00020000);
+    if (dl >= df) {
+      df1 = df - (R - 1);
+      dsp = (unsigned)(dl - df + (R - 1));
+      do0 = (unsigned)(reinterpret_cast<unsigned long long>(drz) - reinterpret_cast<unsigned long long>(a.dbase));
+    }
+    if constexpr (EPI == 2) {
+      xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.abase), 0, a.abytes, 0x00020000);
+      if (xlrow >= xf) {
+        xf1 = xf - (R - 1);
+        xsp = (unsigned)(xlrow - xf + (R - 1));
+        xo0 = (unsigned)(reinterpret_cast<unsigned long long>(xrz) - reinterpret_cast<unsigned long long>(a.abase));
+      }
+    }
+  }
   const double alpha = a.alpha, thr = a.threshold;
   const bool dense_rule = (a.dense_rule & 1) != 0;
   double dsum = 0.0, tsum = 0.0;
@@ -361,9 +412,14 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int rb = r0 + R * (4 * v + q);
-        if constexpr (EPI == 2) xv[v] = rv_load<R>(((rb + R - 1 >= xf) & (rb <= xlrow)) ? xrz + rb : zp);
-        if constexpr (EPI != 0) {
-          dv[v] = rv_load<R>(((rb + R - 1 >= df) & (rb <= dl)) ? drz + rb : zp);
+        if constexpr (OFF32) {
+          if constexpr (EPI == 2) xv[v] = rv_buffer_load<R>(xrsrc, (unsigned)(rb - xf1) <= xsp ? xo0 + (unsigned)rb * 8u : TILE_OOB);
+          if constexpr (EPI != 0) dv[v] = rv_buffer_load<R>(drsrc, (unsigned)(rb - df1) <= dsp ? do0 + (unsigned)rb * 8u : TILE_OOB);
+        } else {
+          if constexpr (EPI == 2) xv[v] = rv_load<R>(((rb + R - 1 >= xf) & (rb <= xlrow)) ? xrz + rb : zp);
+          if constexpr (EPI != 0) {
+            dv[v] = rv_load<R>(((rb + R - 1 >= df) & (rb <= dl)) ? drz + rb : zp);
+          }
         }
       }
     };
@@ -376,7 +432,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       // is read from LDS while the run load of group g + PF is issued from the record read one step earlier, the
       // multiplier row of g + 1 is read, and group g -- operands landed PF steps / one step ago -- is multiplied.
       const int rl = r0 + R * jj;                  // A operand: rows rl .. rl + R - 1, column 4 g + q
-      const unsigned long long r8 = (unsigned long long)((long long)rl * 8);
+      [[maybe_unused]] const unsigned long long r8 = (unsigned long long)((long long)rl * 8);
       const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(recs) + q;     // record of group g: rq[4 g]
       const double* __restrict__ bq = Bs + lane;                                   // multiplier of group g: bq[64 g]
 #ifdef NTP_TILE_ABL_NOLOAD
@@ -385,42 +441,57 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
 #ifdef NTP_ABLATIONS
       const unsigned long long abl_base = reinterpret_cast<unsigned long long>(a.out_val) & ~0x3fffull;   // (any mapped memory)
 #endif
+      [[maybe_unused]] const unsigned r8lo = (unsigned)rl * 8u;
+      [[maybe_unused]] __amdgpu_buffer_rsrc_t arsrc;
+      if constexpr (OFF32) arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.abase), 0, a.abytes, 0x00020000);
       auto run_load = [&](const uint4 raw) -> VR {
-        const unsigned long long rz = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
         const bool ok = (unsigned)(rl - (int)raw.z) <= raw.w;
+        if constexpr (OFF32) {
+          // (four vector instructions per load: row - first, compare, offset, select of the out-of-range offset)
+          return rv_buffer_load<R>(arsrc, ok ? raw.x + r8lo : TILE_OOB);
+        } else {
+          const unsigned long long rz = (unsigned long long)raw.x | ((unsigned long long)raw.y << 32);
 #ifdef NTP_ABLATIONS
-        // (experiment build, WRONG results: option spgemm_variant 601 makes every run load hit a 16 KB window -- what the
-        // loop costs when the operand comes from L1)
-        if (a.ablate == 1) return rv_load<R>(ok ? abl_base + ((rz + r8 - abl_base) & 0x3fe0ull) : zaddr);
+          // (experiment build, WRONG results: option spgemm_variant 601 makes every run load hit a 16 KB window -- what the
+          // loop costs when the operand comes from L1)
+          if (a.ablate == 1) return rv_load<R>(ok ? abl_base + ((rz + r8 - abl_base) & 0x3fe0ull) : zaddr);
 #endif
-        return rv_load<R>(ok ? rz + r8 : zaddr);
+          return rv_load<R>(ok ? rz + r8 : zaddr);
+        }
       };
       // slot u of the ring holds the A operand of group g + u; it is refilled (group g + u + PF) right after the matrix
       // instruction that read it has been issued, so no value is ever copied from one register to another.  PF run
       // loads per wave stay in flight: they return in order, so one HBM miss holds back everything behind it and the
       // depth has to cover a miss, not a hit.  The multiplier rows come from LDS two slots ahead (three registers).
+      // The look-ahead reads records up to PF + 1 groups and multiplier rows up to two groups beyond g1; what it finds there
+      // is never multiplied (a ring slot is consumed only for groups <= g1).  With 64-bit addresses every such index is
+      // clamped to the empty group KG behind the last record (a record must never be garbage: it becomes an address).
+      // OFF32: NOT clamped -- behind the records lie other arrays of this block's LDS, and a "record" read from them can only
+      // produce a buffer offset, whose load is bounds-checked; inside the unrolled body every LDS address is then the body's
+      // base plus a constant (one address computation per six groups instead of two per group).
+      auto gi = [&](int x) { return OFF32 ? x : min(x, KG); };
+      auto bi = [&](int x) { return OFF32 ? x : min(x, KG - 1); };
       VR ring[TILE_PF];
       double bb[3];
-      const int KGm1 = KG - 1;
 #pragma unroll
-      for (int u = 0; u < TILE_PF; ++u) ring[u] = run_load(rq[4 * min(g0 + u, KG)]);
+      for (int u = 0; u < TILE_PF; ++u) ring[u] = run_load(rq[4 * gi(g0 + u)]);
       bb[0] = bq[64 * g0];
-      bb[1] = bq[64 * min(g0 + 1, KGm1)];
+      bb[1] = bq[64 * bi(g0 + 1)];
       bb[2] = 0.0;
-      uint4 raw = rq[4 * min(g0 + TILE_PF, KG)];
+      uint4 raw = rq[4 * gi(g0 + TILE_PF)];
       int g = g0;
       STAMP(sidx);
       for (; g + TILE_PF - 1 <= g1; g += TILE_PF) {
 #pragma unroll
         for (int u = 0; u < TILE_PF; ++u) {
           // (the order is pinned: record read one slot ahead | matrix instruction | refill of the slot it has read)
-          const uint4 raw_n = rq[4 * min(g + u + TILE_PF + 1, KG)];
+          const uint4 raw_n = rq[4 * gi(g + u + TILE_PF + 1)];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int m = 0; m < R; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(rv_get<R>(ring[u], m), bb[u % 3], acc[m], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           ring[u] = run_load(raw);
-          bb[(u + 2) % 3] = bq[64 * min(g + u + 2, KGm1)];
+          bb[(u + 2) % 3] = bq[64 * bi(g + u + 2)];
           raw = raw_n;
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -462,6 +533,60 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
         continue;
       }
     }
+#ifndef NTP_TILE_NO_FULL_TILES
+    if constexpr (EPI == 2 && !LAB) {
+      // FULL tiles -- every element has a product entry above the threshold AND an entry of X AND a sum above the update's
+      // threshold (the interior of the band: most of the live tiles of a purification step) -- keep everything: no
+      // AddSparseVectors case analysis, no selects, no deferred elements; the values, the order of the sums and the column
+      // statistics are those of the general path below (adding +0.0 to the trace sum, which it does for every off-diagonal
+      // element, changes no bit)
+      bool full = true;
+      VR both[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+          const double vv = acc[m][v];
+          const double sv = __dmul_rn(alpha, vv);
+          const double bv = rv_get<R>(xv[v], m);
+          const double bo = __dadd_rn(__dmul_rn(am, sv), __dmul_rn(bm, bv));
+          full &= (dense_rule ? (fabs(vv) > thr) : (fabs(sv) > thr)) & (bv != 0.0) & (fabs(bo) > thr_m);
+          rv_set<R>(both[v], m, bo);
+        }
+      }
+      if (__ballot(!full) == 0ull) {
+        pn += 64 * 4 * R;
+        const bool has_diag = r0 <= b * SLAB_J + SLAB_J - 1 + a.fzv.col_offset && r0 + TROWS - 1 >= b * SLAB_J + a.fzv.col_offset;   // (wave-uniform)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+          for (int m = 0; m < R; ++m) {
+            const double o = rv_get<R>(both[v], m);
+            dsum = __dadd_rn(dsum, __dmul_rn(o, rv_get<R>(dv[v], m)));
+            if (has_diag) tsum = __dadd_rn(tsum, (r0 + R * (4 * v + q) + m == diag) ? o : 0.0);
+          }
+        }
+        if (q == 0) {   // (one lane per column leaves the column's statistics: 16 R rows kept, first r0, last r0 + 16 R - 1)
+          atomicAdd(&col_cnt[jj], TROWS);
+          atomicMin(&col_first[jj], r0);
+          atomicMax(&col_last[jj], r0 + TROWS - 1);
+          atomicMax(&col_pmax[jj], r0 + TROWS - 1);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) rv_store<R>(orun + (r0 + R * (4 * v + q)), both[v]);
+        if (otile) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int m = 0; m < R; ++m) otile[(int64_t)(r0 + R * (4 * v + q) + m) * SLAB_J] = rv_get<R>(both[v], m);
+          }
+        }
+        if (lane == 0) colmask[t] = 0xffffu;
+        STAMP(sidx); ++sidx;
+        continue;
+      }
+    }
+#endif
     VR res[4];
     unsigned long long anykeep = 0;
     int c_l = 0, f_l = INT_MAX, l_l = -1, pm_l = -1, pl_l = -1;
@@ -720,6 +845,18 @@ void launch_spgemm_tile(const TileLaunch& L) {
     zeros->zero();
   }
   a.zero = zeros->p;
+  // 32-bit offsets: every run of A in one allocation below 4 GB; with a fused epilogue also X inside that allocation and the
+  // expanded D operand in one of its own
+  bool off32 = options().tile_off32 != 0 && L.abase != nullptr && L.abytes > 0 && L.abytes < 0xfffff000ull;
+  if (off32 && L.epi != 0) {
+    const SlabFuseArgs& fzh = *static_cast<const SlabFuseArgs*>(L.fz);
+    const char *a0 = static_cast<const char*>(L.abase), *x0 = reinterpret_cast<const char*>(fzh.xexp);
+    off32 = L.dbase != nullptr && L.dbytes > 0 && L.dbytes < 0xfffff000ull && (L.epi != 2 || (x0 >= a0 && x0 < a0 + L.abytes));
+  }
+  a.abase = off32 ? L.abase : nullptr;
+  a.abytes = off32 ? (uint32_t)L.abytes : 0u;
+  a.dbase = off32 ? L.dbase : nullptr;
+  a.dbytes = off32 ? (uint32_t)L.dbytes : 0u;
   a.ablate = options().spgemm_variant == 601 ? 1 : options().spgemm_variant == 602 ? 2 : 0;
 #ifdef NTP_TILE_STAMPS
   static DevBuf<long long>* stamps = nullptr;
@@ -739,22 +876,30 @@ void launch_spgemm_tile(const TileLaunch& L) {
   const bool wide = 3 * lds > 160 * 1024;
   const int tw = options().tile_waves;
   const int nw = (tw == 4 || tw == 5 || tw == 6 || tw == 8) ? tw : (wide ? 8 : 4);
-  auto go = [&](auto epi_tag, auto nw_tag, auto r_tag, auto lab_tag) {
+  auto go = [&](auto epi_tag, auto nw_tag, auto r_tag, auto lab_tag, auto off_tag) {
     constexpr int E = decltype(epi_tag)::value, NW = decltype(nw_tag)::value, RR = decltype(r_tag)::value;
-    constexpr bool LB = decltype(lab_tag)::value;
+    constexpr bool LB = decltype(lab_tag)::value, OF = decltype(off_tag)::value;
     static size_t raised = 0;   // (one per instantiation)
     if (lds > 64 * 1024 && lds > raised) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile<E, NW, RR, LB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spgemm_tile<E, NW, RR, LB, OF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     150 * 1024));
       raised = 150 * 1024;
     }
-    hipLaunchKernelGGL((k_spgemm_tile<E, NW, RR, LB>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
+    hipLaunchKernelGGL((k_spgemm_tile<E, NW, RR, LB, OF>), dim3(xcd_grid(L.nblocks)), dim3(NW * WAVE), lds, stream(), a);
+  };
+  auto by_off = [&](auto epi_tag, auto nw_tag, auto r_tag, auto lab_tag) {
+    // (32-bit offsets: the default geometries only -- four or eight waves, one or two rows per lane)
+    constexpr int NW = decltype(nw_tag)::value, RR = decltype(r_tag)::value;
+    if constexpr ((NW == 4 || NW == 8) && RR <= 2) {
+      if (off32) return go(epi_tag, nw_tag, r_tag, lab_tag, std::true_type{});
+    }
+    go(epi_tag, nw_tag, r_tag, lab_tag, std::false_type{});
   };
   auto by_nw = [&](auto epi_tag, auto r_tag, auto lab_tag) {
-    if (nw == 4) go(epi_tag, std::integral_constant<int, 4>{}, r_tag, lab_tag);
-    else if (nw == 5) go(epi_tag, std::integral_constant<int, 5>{}, r_tag, lab_tag);
-    else if (nw == 6) go(epi_tag, std::integral_constant<int, 6>{}, r_tag, lab_tag);
-    else go(epi_tag, std::integral_constant<int, 8>{}, r_tag, lab_tag);
+    if (nw == 4) by_off(epi_tag, std::integral_constant<int, 4>{}, r_tag, lab_tag);
+    else if (nw == 5) by_off(epi_tag, std::integral_constant<int, 5>{}, r_tag, lab_tag);
+    else if (nw == 6) by_off(epi_tag, std::integral_constant<int, 6>{}, r_tag, lab_tag);
+    else by_off(epi_tag, std::integral_constant<int, 8>{}, r_tag, lab_tag);
   };
   auto by_r = [&](auto epi_tag) {
     constexpr int E = decltype(epi_tag)::value;

@@ -36,6 +36,12 @@ struct TileLaunch {
   const int32_t *brun_first = nullptr, *brun_last = nullptr;
   const int64_t* brun_off = nullptr;
   const double* brun_val = nullptr;
+  // optional: ONE allocation [abase, abase + abytes) that holds every run `runs` points into (no halo): below 4 GB the kernel
+  // reads the runs through a buffer resource with 32-bit offsets (option tile_off32)
+  const void* abase = nullptr;
+  size_t abytes = 0;
+  const void* dbase = nullptr;       // epi != 0: the allocation that holds the expanded D operand (fz.dexp), for the same purpose
+  size_t dbytes = 0;
   bool labelled = false;             // fz carries labels (SlabFuseArgs::lab, xplast, oplast): the epilogue's "beyond the last entry"
                                      // tests compare the caller's labels.  The k steps are walked in POSITION order (the rounding
                                      // of a product entry then differs from the label-ordered chain in its last bits: tolerance mode)

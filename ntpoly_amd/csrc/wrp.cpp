@@ -30,12 +30,14 @@ PSMatrix* get<PSMatrix>(const int* ih) {
   std::memcpy(&p, ih, sizeof(p));
   if (!p) NTP_FATAL("null handle passed to the C ABI");
   if (p->loc.loose() || p->loc.expanded() || p->loc.blocked()) pack(p->loc);
+  if (p->grid) use_grid_comm(p->grid);   // (a matrix on a sub-grid: the call's collectives run on that grid's communicator)
   return p;
 }
 PSMatrix* get_unpacked(const int* ih) {
   PSMatrix* p;
   std::memcpy(&p, ih, sizeof(p));
   if (!p) NTP_FATAL("null handle passed to the C ABI");
+  if (p->grid) use_grid_comm(p->grid);
   return p;
 }
 // The vocabulary entry points (MatrixMultiply, IncrementMatrix, ScaleMatrix, CopyMatrix, DotMatrix, MatrixNorm) run
@@ -120,9 +122,9 @@ void ntpoly_amd_init_comm(const char* id128, const int* rank, const int* nranks)
 void ntpoly_amd_finalize_comm() { comm_finalize(); }
 int ntpoly_amd_comm_rank() { return world().rank; }
 int ntpoly_amd_comm_size() { return world().nranks; }
-void ntpoly_amd_barrier() { comm_barrier(); }
+void ntpoly_amd_barrier() { use_comm(nullptr); comm_barrier(); }   // (all processes, whatever grid was worked on last)
 // max over all ranks of n host doubles, in place (timing of a distributed region: the slowest rank counts)
-void ntpoly_amd_allreduce_max(double* values, const int* n) { comm_allreduce_max(values, *n); }
+void ntpoly_amd_allreduce_max(double* values, const int* n) { use_comm(nullptr); comm_allreduce_max(values, *n); }
 void ntpoly_amd_synchronize() {
   ensure_init();
   sync_stream();
@@ -163,6 +165,8 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "band_scope") options().band_scope = *value;
   else if (n == "exchange_ahead") options().exchange_ahead = *value;
   else if (n == "plan_fused") options().plan_fused = *value;
+  else if (n == "tile_off32") options().tile_off32 = *value;
+  else if (n == "ghash_mfma") options().ghash_mfma = *value;
   else if (n == "block_unfused") options().block_unfused = *value;
   else if (n == "block_match") options().block_match = *value;
   else if (n == "block_scope") options().block_scope = *value;
@@ -190,6 +194,8 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "band_scope") return options().band_scope;
   if (n == "exchange_ahead") return options().exchange_ahead;
   if (n == "plan_fused") return options().plan_fused;
+  if (n == "tile_off32") return options().tile_off32;
+  if (n == "ghash_mfma") return options().ghash_mfma;
   if (n == "block_unfused") return options().block_unfused;
   if (n == "block_match") return options().block_match;
   if (n == "block_scope") return options().block_scope;
@@ -285,20 +291,31 @@ void ntpoly_amd_gather_matrix_to_process(const int* ih_this, int* ih_local, cons
   L->m = std::move(full);
   put(ih_local, L);
 }
-// CommSplitMatrix (PSMatrixModule.F90:1489-1541, distributed_includes/CommSplitMatrix.f90): a copy of the matrix on one half
-// of the process grid.  On one process -- the reference's base case (:11-14) -- the copy itself, colour 0, "split along the
-// slices".  More processes need a grid on a sub-communicator; this engine has ONE RCCL communicator (its grids are shapes
-// over it), so the call is fatal there, as the reference is for grids it cannot build (ErrorModule.F90:193-205).  Only the
-// divide-and-conquer eigensolver of the reference, outside this engine's scope, calls it.
+// CommSplitMatrix (PSMatrixModule.F90:1489-1541, distributed_includes/CommSplitMatrix.f90): a copy of the WHOLE matrix on each
+// half of its process grid (SplitProcessGrid, ProcessGridModule.F90:430-515: along the slices where there are several, else
+// along the longer of rows / columns).  The half lives on a sub-communicator (ncclCommSplit); every later call on the copy --
+// products, reductions, solvers -- runs inside that half (engine.hpp use_grid_comm).  One process: the copy itself, colour 0,
+// "split along the slices" (the reference's base case, :11-14).
 void ntpoly_amd_comm_split_matrix(const int* ih_this, int* ih_split, int* my_color, bool* split_slice) {
   const PSMatrix& m = *get<PSMatrix>(ih_this);
-  const ProcessGrid& g = m.grid ? *m.grid : global_grid();
-  if (g.total != 1) NTP_FATAL("CommSplitMatrix on " + std::to_string(g.total) + " processes needs a process grid on a sub-communicator, which this engine does not have");
+  if (!m.grid) NTP_FATAL("CommSplitMatrix of a matrix that was never constructed");
   auto* out = new PSMatrix();
-  ps_copy(m, *out);
+  ps_comm_split(m, *out, my_color, split_slice);
   put(ih_split, out);
-  *my_color = 0;
-  *split_slice = true;
+}
+// SplitProcessGrid (ProcessGridModule.F90:430-515): the grid of this process's half (colour 0 / 1); collective over the old grid.
+// The handle is owned by the engine (not to be handed to DestructProcessGrid_wrp); matrices constructed on it live on the
+// half's communicator.  The reference's fifth result, the between-grid communicator, has no counterpart: what CommSplitMatrix
+// uses it for is done by ntpoly_amd_comm_split_matrix.
+void ntpoly_amd_split_process_grid(const int* ih_old_grid, int* ih_new_grid, int* my_color, bool* split_slice) {
+  put(ih_new_grid, split_process_grid(*get<ProcessGrid>(ih_old_grid), my_color, split_slice));
+}
+// out[0] = rank of this process on the grid's communicator, out[1] = its size, out[2] = 1 when that is a sub-communicator
+void ntpoly_amd_grid_comm_info(const int* ih_grid, int* out) {
+  const ProcessGrid* g = get<ProcessGrid>(ih_grid);
+  out[0] = g->global_rank;
+  out[1] = g->total;
+  out[2] = g->comm != nullptr ? 1 : 0;
 }
 // out[0] = solves that ran in a recovered band order across ranks (band_scope.cpp), out[1] = operands searched for one
 void ntpoly_amd_band_scope_counts(long long* out) {

@@ -492,6 +492,25 @@ class Matrix_ps:
     def Symmetrize(self):
         lib.SymmetrizeMatrix_ps_wrp(self.ih)
 
+    def CommSplit(self):
+        """(copy of the WHOLE matrix on this process's half of the grid, colour 0 / 1, True when the grid was split along its
+        slices) -- CommSplitMatrix, PSMatrixModule.F90:1489-1541; the copy lives on a sub-communicator: everything done with
+        it afterwards (products, reductions, solvers) stays inside the half"""
+        out = Matrix_ps.__new__(Matrix_ps)
+        out.ih = handle()
+        color = C.c_int(0)
+        split_slice = C.c_bool(False)
+        lib.ntpoly_amd_comm_split_matrix(self.ih, out.ih, C.byref(color), C.byref(split_slice))
+        return out, int(color.value), bool(split_slice.value)
+
+    def grid_comm_info(self):
+        """(rank on the communicator of this matrix's grid, its size, True when that is a sub-communicator)"""
+        g = handle()
+        lib.GetMatrixProcessGrid_ps_wrp(self.ih, g)
+        out = (C.c_int * 3)()
+        lib.ntpoly_amd_grid_comm_info(g, out)
+        return int(out[0]), int(out[1]), bool(out[2])
+
     def GatherMatrixToProcess(self, within_slice_id=None):
         """the whole matrix as a LOCAL matrix on every process (None) or on the process with this rank inside its slice (the
         others get None) -- PSMatrixModule.F90:1704-1808"""

@@ -21,7 +21,9 @@ def main():
     import ntpoly_amd as nt
     from gen import banded_triplets
     nt.init_comm(nt.get_unique_id(), rank, world)
-    nt.ConstructGlobalProcessGrid(1, world, 1)
+    # (NTPOLY_AMD_TEST_GRID=rows,columns,slices: another shape over the same ranks -- the CommSplitMatrix test splits along slices)
+    shape = tuple(int(x) for x in os.environ.get("NTPOLY_AMD_TEST_GRID", "1,%d,1" % world).split(","))
+    nt.ConstructGlobalProcessGrid(*shape)
     res = {}
 
     def keep(tag, M):
@@ -153,6 +155,31 @@ def main():
     Sn = nt.Matrix_ps(F)
     nt.MatrixConversion.SnapMatrixToSparsityPattern(Sn, S)
     keep("snap", Sn)
+
+    # ---- CommSplitMatrix (PSMatrixModule.F90:1489-1541; SplitProcessGrid, ProcessGridModule.F90:430-515): a copy of the WHOLE
+    # matrix on each half of the grid, on a sub-communicator; a product, reductions and a TRS2 solve INSIDE the half
+    # (the halves work at the same time and must not wait for each other), then the grid of all processes again
+    Sp, color, split_slice = A.CommSplit()
+    sub_rank, sub_size, is_sub = Sp.grid_comm_info()
+    res["split_info"] = np.array([color, int(split_slice), sub_rank, sub_size, int(is_sub)])
+    keep("split", Sp)
+    SS = nt.Matrix_ps(n)      # (a matrix of the default grid; the result of a product takes the grid of its operands)
+    SS.Gemm(Sp, Sp, None, 1.0, 0.0, 1e-7)
+    keep("split_SS", SS)
+    res["split_scal"] = np.array([Sp.Trace(), Sp.Norm(), float(np.real(SS.Dot(Sp)))])
+    Isub = nt.Matrix_ps(Sp)
+    Isub.FillIdentity()
+    ps = nt.SolverParameters()
+    ps.SetThreshold(1e-7)
+    ps.SetConvergeDiff(1e-30)
+    ps.SetMaxIterations(4 + color)      # (the halves do different amounts of work: no hidden coupling between them)
+    ps.SetMonitorConvergence(False)
+    Ksub = nt.Matrix_ps(Sp)
+    e_sub, mu_sub = nt.DensityMatrixSolvers.TRS2(Sp, Isub, n / 2.0, Ksub, ps)
+    res["split_trs2"] = np.array([e_sub, mu_sub])
+    keep("split_K", Ksub)
+    res["after_split"] = np.array([A.Trace(), A.Norm()])      # (the grid of all processes again)
+    nt.barrier()
 
     np.savez(out + ".%d.npz" % rank, **res)
     nt.DestructGlobalProcessGrid()

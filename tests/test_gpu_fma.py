@@ -185,3 +185,43 @@ def test_fma_and_unfused_modes_agree_to_roundoff(nt, fma):
     assert np.array_equal(g1[0], g0[0]) and np.array_equal(g1[1], g0[1])
     assert not np.array_equal(g1[2], g0[2])
     assert np.abs(g1[2] - g0[2]).max() <= 1e-13 * np.abs(g0[2]).max()
+
+
+@pytest.mark.parametrize("n,h,holes,thr,same", [(8192, 50, 0.0, 1e-8, True), (6000, 100, 0.15, 1e-7, False), (7000, 160, 0.0, 1e-8, True),
+                                                 (5000, 30, 0.3, 0.0, False), (4097, 300, 0.0, 1e-6, True)])
+def test_grouped_hash_products_on_the_matrix_cores(nt, fma, n, h, holes, thr, same):
+    """the grouped LDS-hash SpGEMM (csrc/spgemm_grouped.hip: operands WITHOUT runs as they stand -- `bench.py --random`) in FMA
+    arithmetic with the products of a phase on the FP64 matrix cores (option ghash_mfma: four steps = the k dimension of one
+    v_mfma_f64_16x16x4_f64 per 16 slots x 16 columns): bit for bit the oracle's FMA mode and the vector-unit path, every group
+    computed by the kernel (no fallback beyond what the vector path hands back)."""
+    import scipy.sparse as sp
+    O = fma
+    rng = np.random.default_rng(n + h)
+    mats = []
+    for t in range(1 if same else 2):
+        col, row, val = permuted_banded_triplets(n, h, 42, shift=0.1 * t)
+        keep = (rng.random(len(val)) >= holes) | (col == row)
+        mats.append((col[keep], row[keep], val[keep]))
+    A = nt.Matrix_ps.from_triplets(n, *mats[0])
+    B = A if same else nt.Matrix_ps.from_triplets(n, *mats[1])
+    alpha = 1.0 if same else -0.5
+    nt.set_option("block_path", 0)
+    res = []
+    for mf in (1, 0):
+        nt.set_option("ghash_mfma", mf)
+        nt.set_option("spgemm_variant", 500)     # (the grouped kernel, forced)
+        try:
+            C = nt.Matrix_ps(n)
+            C.Gemm(A, B, None, alpha, 0.0, thr)
+            st, gs = nt.last_spgemm_stats(), nt.last_grouped_stats()
+        finally:
+            nt.set_option("spgemm_variant", -1)
+            nt.set_option("ghash_mfma", 1)
+        assert st["slab"] == 0 and gs["used"] == 1 and gs["minhash"] == 1, (mf, st, gs)
+        res.append((srt(C.triplets()), gs))
+    Ao = O.Mat.from_triplets(n, n, *mats[0])
+    Bo = Ao if same else O.Mat.from_triplets(n, n, *mats[1])
+    want = O.ps_multiply(Ao, Bo, None, alpha, 0.0, thr).triplets()
+    exact(res[0][0], want, "grouped hash, matrix cores")
+    exact(res[1][0], want, "grouped hash, vector units")
+    assert res[0][1]["failed_cols"] <= res[1][1]["failed_cols"] + n // 50, (res[0][1], res[1][1])

@@ -16,13 +16,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(world, tmp_path, arith="unfused"):
-    out = str(tmp_path / ("w%d%s" % (world, arith)))
+def run_world(world, tmp_path, arith="unfused", grid=None):
+    out = str(tmp_path / ("w%d%s%s" % (world, arith, "" if grid is None else grid.replace(",", "x"))))
     name = "t%s" % uuid.uuid4().hex[:12]
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", NTPOLY_AMD_COMM="shm:" + name,
                    NTPOLY_AMD_SHM_MB="8", NTPOLY_AMD_SPGEMM_FMA="1" if arith == "fma" else "0")
+        if grid is not None:
+            env["NTPOLY_AMD_TEST_GRID"] = grid
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -125,3 +127,54 @@ def test_multirank_equals_single_rank(world, arith, references, tmp_path):
             assert parts[r][s] == pytest.approx(float(reference[s]), rel=1e-12, abs=1e-12), (s, r)
         assert parts[r]["trs2_iters"] == reference["trs2_iters"]
         assert np.allclose(parts[r]["trs2_log"], reference["trs2_log"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("world,grid", [(2, None), (3, None), (4, None), (4, "1,2,2"), (4, "4,1,1")])
+def test_comm_split_matrix_on_several_ranks(world, grid, references, tmp_path):
+    """CommSplitMatrix (PSMatrixModule.F90:1489-1541) on more than one process: the grid is split as SplitProcessGrid does
+    (ProcessGridModule.F90:430-515: along the slices where there are several, else along the longer of rows / columns; the
+    processes of a half keep the order of their old ranks), every half holds a copy of the WHOLE matrix on a sub-communicator,
+    and what is done with the copy -- a product, reductions, a TRS2 solve of its own length -- happens inside the half and
+    equals the one-rank results."""
+    reference = references("unfused")
+    parts = run_world(world, tmp_path, "unfused", grid)
+    rows, cols, slices = (1, world, 1) if grid is None else tuple(int(x) for x in grid.split(","))
+    # what SplitProcessGrid decides for every old rank (rank -> slice, row, column as ProcessGridModule.F90:180-183)
+    want_color, want_slice = [], slices > 1
+    for r in range(world):
+        sl, rem = divmod(r, rows * cols)
+        row, col = divmod(rem, cols)
+        if slices > 1:
+            want_color.append(0 if sl < slices // 2 else 1)
+        elif rows > cols:
+            want_color.append(0 if row < rows // 2 else 1)
+        else:
+            want_color.append(0 if col < cols // 2 else 1)
+    for color in (0, 1):
+        members = [r for r in range(world) if want_color[r] == color]
+        assert members, (world, grid, color)
+        for i, r in enumerate(members):
+            c, ss, sub_rank, sub_size, is_sub = (int(x) for x in parts[r]["split_info"])
+            assert (c, bool(ss), sub_rank, sub_size, bool(is_sub)) == (color, want_slice, i, len(members), True), (r, parts[r]["split_info"])
+        half = [parts[r] for r in members]
+        # the copy: the whole matrix, panels in the order of the half's ranks
+        got = cat(half, "split")
+        one = tuple(reference["split" + s] for s in ("_col", "_row", "_val"))
+        assert all(np.array_equal(g, w) for g, w in zip(got, one)), ("copy", color)
+        # the product on the half: bit for bit the one-rank product
+        got = cat(half, "split_SS")
+        assert all(np.array_equal(g, reference["split_SS" + s]) for g, s in zip(got, ("_col", "_row", "_val"))), ("product", color)
+        for p in half:
+            assert np.allclose(p["split_scal"], reference["split_scal"], rtol=1e-12, atol=1e-12)
+            assert np.allclose(p["after_split"], reference["after_split"], rtol=1e-12, atol=1e-12)
+        # the solve on the half (4 + colour iterations): the one-rank solve of the same length
+        if color == 0:
+            for p in half:
+                assert np.allclose(p["split_trs2"], reference["split_trs2"], rtol=1e-11, atol=1e-11), (p["split_trs2"], reference["split_trs2"])
+            got = cat(half, "split_K")
+            want = tuple(reference["split_K" + s] for s in ("_col", "_row", "_val"))
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+            assert np.allclose(got[2], want[2], rtol=0, atol=1e-10)
+        else:
+            e = [float(p["split_trs2"][0]) for p in half]
+            assert max(e) - min(e) <= 1e-11 * abs(e[0])      # (one value inside the half; five iterations, no one-rank twin)
