@@ -165,9 +165,11 @@ bool band_scope_try(const std::vector<const PSMatrix*>& ins, const std::vector<P
   }
   {
     struct ScopeGuard {   // (restored on every way out of run(), an exception included)
-      explicit ScopeGuard(bool block) { g_scope_depth += 1; g_block_scope = block; }
-      ~ScopeGuard() { g_block_scope = false; g_scope_depth -= 1; }
-    } guard(block_mode);
+      ScopeGuard(bool block, const int32_t* labels) { g_scope_depth += 1; g_block_scope = block; set_scope_labels(labels); }
+      ~ScopeGuard() { set_scope_labels(nullptr); g_block_scope = false; g_scope_depth -= 1; }
+    // band order: the fused TRS2 panel steps merge on the CALLER'S labels (d_inv[position] = label), as the one-rank steps on a
+    // relabelled operand do -- the solve keeps the entries the one-rank solve keeps (kernels.hpp scope_labels)
+    } guard(block_mode, block_mode ? nullptr : d_inv.p);
     run(in_p, out_p);
   }
   for (size_t i = 0; i < outs.size(); ++i) relabel_ps(out_b[i], *outs[i], d_inv.p);

@@ -158,6 +158,8 @@ void ps_get_slice(const PSMatrix& m, PSMatrix& sub, int sr, int er, int sc, int 
 void ps_resize(PSMatrix& m, int new_size);
 void ps_to_complex(const PSMatrix& a, PSMatrix& out);
 void ps_to_real(const PSMatrix& a, PSMatrix& out);
+void panel_exchange_layout(int32_t dim, int P, int me, const int64_t* req, const int64_t* cnt, int32_t* sa, int32_t* sb, int64_t* soff,
+                           int32_t* ra, int32_t* rb, int64_t* zoff);   // psmatrix.cpp: who sends which columns where in a panel exchange (host)
 DevMat ps_gather_full(const PSMatrix& m);  // every rank gets the whole matrix (dim x dim)
 // range-restricted exchange: a dim x dim matrix holding only the columns [kmin, kmax] of the distributed matrix
 // halo exchange for C = A*B: the columns of A named by the rows of the local B panel; also returns the global

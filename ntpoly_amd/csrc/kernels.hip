@@ -986,6 +986,17 @@ __global__ void k_slab_runs(const int32_t* __restrict__ cmin, const int32_t* __r
   runs[k] = r;
 }
 
+// plast[j] = largest label among the rows of column j (lab[row]): label-ordered steps (SlabForm::plast)
+__global__ __launch_bounds__(256) void k_col_plast(Csc A, const int32_t* __restrict__ lab, int32_t* __restrict__ plast) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  if (j >= A.cols) return;
+  const int lane = lane_id();
+  int mx = -1;
+  for (int64_t p = A.outer[j] + lane, e = A.outer[j + 1]; p < e; p += WAVE) mx = max(mx, lab[A.inner[p]]);
+  mx = wave_max_i32(mx);
+  if (lane == 0) plast[j] = mx;
+}
+
 constexpr int SLAB_DTILE = 4096;   // doubles of LDS for the D columns of a block (fused epilogues): 32 KB, four workgroups per CU
 typedef double v8d __attribute__((ext_vector_type(8)));
 #include "slab_loop.inc"
@@ -2507,16 +2518,40 @@ __global__ __launch_bounds__(256) void k_colstat(Csc A, int col_offset, int mode
   const int lane = lane_id();
   const T* __restrict__ Av = static_cast<const T*>(A.val);
   double r = 0, d = 0;
-  for (int64_t p = A.outer[j] + lane; p < A.outer[j + 1]; p += WAVE) {
-    if (mode == 1 && A.inner[p] == j + col_offset) d = __dadd_rn(d, Sc<T>::re(Av[p]));
-    else r = __dadd_rn(r, Sc<T>::mag(Av[p]));
+  if (mode == 1) {
+    // Gershgorin radius: the sum of the column's moduli must not depend on the ORDER the entries are stored in -- a solve
+    // that runs on a relabelled copy of the matrix (band scope across ranks, the load balancer) has to start from the same
+    // spectral bounds as the solve on the caller's labels, or the two differ in the last bits of every entry from the first
+    // iterate on.  Accumulated in double-double (error-free two-sums), rounded once at the end: the correctly rounded sum for
+    // any order, up to an error of ~1e-32 relative before that rounding.
+    double rl = 0.0;
+    auto two_sum = [](double a, double b, double& s, double& e) {
+      s = __dadd_rn(a, b);
+      const double bb = __dsub_rn(s, a);
+      e = __dadd_rn(__dsub_rn(a, __dsub_rn(s, bb)), __dsub_rn(b, bb));
+    };
+    auto dd_add = [&](double& hi, double& lo, double xh, double xl) {
+      double s, e;
+      two_sum(hi, xh, s, e);
+      e = __dadd_rn(e, __dadd_rn(lo, xl));
+      hi = __dadd_rn(s, e);
+      lo = __dsub_rn(e, __dsub_rn(hi, s));
+    };
+    for (int64_t p = A.outer[j] + lane; p < A.outer[j + 1]; p += WAVE) {
+      if (A.inner[p] == j + col_offset) d = __dadd_rn(d, Sc<T>::re(Av[p]));
+      else dd_add(r, rl, Sc<T>::mag(Av[p]), 0.0);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double oh = __shfl_xor(r, o, WAVE), ol = __shfl_xor(rl, o, WAVE);
+      dd_add(r, rl, oh, ol);
+    }
+    d = wave_sum_f64(d);
+    if (lane == 0) { out0[j] = d - r; out1[j] = d + r; }
+    return;
   }
+  for (int64_t p = A.outer[j] + lane; p < A.outer[j + 1]; p += WAVE) r = __dadd_rn(r, Sc<T>::mag(Av[p]));
   r = wave_sum_f64(r);
-  d = wave_sum_f64(d);
-  if (lane == 0) {
-    if (mode == 0) out0[j] = r;
-    else { out0[j] = d - r; out1[j] = d + r; }
-  }
+  if (lane == 0) out0[j] = r;
 }
 
 __global__ void k_scale(double* __restrict__ v, int64_t n, double c) {
@@ -3672,6 +3707,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
   DevBuf<double> fz_tiles;
   DevBuf<int64_t> tile_ooff, tile_otoff;   // (tile kernel: where every column's run / every block's tile rows start)
   bool fuse_now = false;
+  DevBuf<int32_t> sc_xplast, sc_oplast;   // (label-aware panel step inside a band scope: largest label per column of X / of the result)
   if (use_slab) {
     zwords.alloc((size_t)4 * snb + 4);
     zwords.zero();
@@ -3798,6 +3834,13 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
       fz.dexp = dop.dexp.p; fz.doff = dop.doff.p; fz.dmin = dop.dmin.p; fz.dmax = dop.dmax.p;
       fz.part = fz_part; fz.pnnz = reinterpret_cast<long long*>(fz_pnnz); fz.flag = reinterpret_cast<int*>(fz_flag);
       fz.col_offset = fuse->col_offset;
+      // (a panel step of a solve in a recovered band order across ranks: the merge's "beyond the last entry" tests on the caller's
+      // labels -- scope_labels(), kernels.hpp; the largest label of every column of X from its compressed columns)
+      if (panel && use_tile && scope_labels() != nullptr) {
+        sc_xplast.alloc((size_t)n); sc_oplast.alloc((size_t)n);
+        hipLaunchKernelGGL(k_col_plast, dim3(cdiv((int64_t)n * WAVE, 256)), dim3(256), 0, stream(), lview(B), scope_labels(), sc_xplast.p);
+        fz.lab = scope_labels(); fz.xplast = sc_xplast.p; fz.oplast = sc_oplast.p;
+      }
       fz_first.alloc((size_t)n); fz_last.alloc((size_t)n);
       fz_tiles.alloc((size_t)tmp_total + kIndexSlack);
       fz.ofirst = fz_first.p; fz.olast = fz_last.p; fz.tiles = fz_tiles.p;
@@ -3824,6 +3867,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
         tl.ofirst = fz_first.p; tl.olast = fz_last.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
         tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
         tl.max_kn = (int)hstats[17]; tl.max_w = (int)hstats[16]; tl.epi = fuse->mode; tl.fz = &fz; tl.rows = tile_rows();
+        tl.labelled = fz.lab != nullptr; tl.nrows = m;
         tl.abase = aexp.p; tl.abytes = aexp.n * sizeof(double);
         tl.dbase = dop.dexp.p; tl.dbytes = dop.dexp.n * sizeof(double);
         launch_spgemm_tile(tl);   // (writes the end markers of tile_ooff / tile_otoff as well)
@@ -4096,6 +4140,7 @@ void spgemm(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double th
     R.slab->val = std::move(tmp_val);
     R.slab->tiles = std::move(fz_tiles);
     R.slab->slots = tmp_total;
+    if (sc_oplast.p) R.slab->plast = std::move(sc_oplast);
     fuse->result = std::move(R);
     fuse->done = true;
     fusion_counts()[fuse->mode == 1 ? 0 : 1] += 1;
@@ -4281,15 +4326,6 @@ __global__ __launch_bounds__(256) void k_slab_order_steps(const int32_t* __restr
   }
 }
 // largest label among the entries of every column
-__global__ __launch_bounds__(256) void k_col_plast(Csc A, const int32_t* __restrict__ lab, int32_t* __restrict__ plast) {
-  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  if (j >= A.cols) return;
-  const int lane = lane_id();
-  int mx = -1;
-  for (int64_t p = A.outer[j] + lane, e = A.outer[j + 1]; p < e; p += WAVE) mx = max(mx, lab[A.inner[p]]);
-  mx = wave_max_i32(mx);
-  if (lane == 0) plast[j] = mx;
-}
 }  // namespace
 
 namespace {
@@ -4447,10 +4483,14 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     fz.xplast = in.plast.p;
     fz.oplast = oplast.p;
   }
-  const bool tile_labelled = tile && in.labelled() && !halo;   // (labels only steer the epilogue's "beyond the last entry" tests)
+  // (labels only steer the epilogue's "beyond the last entry" tests.  A panel step of a solve that runs in a recovered band
+  // order across ranks takes them from the scope -- one array for all rows -- and the largest label of every column of the
+  // iterate from the step before, SlabForm::plast)
+  const bool scope_lab = tile && halo && !in.labelled() && scope_labels() != nullptr && in.plast.p != nullptr && fu.mode != 0;
+  const bool tile_labelled = tile && ((in.labelled() && !halo) || scope_lab);
   if (tile_labelled) {
     oplast.alloc((size_t)n);
-    fz.lab = in.lab.p;
+    fz.lab = scope_lab ? scope_labels() : in.lab.p;
     fz.xplast = in.plast.p;
     fz.oplast = oplast.p;
   }
@@ -4493,6 +4533,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     tl.ofirst = ofirst.p; tl.olast = olast.p; tl.ooff = tile_ooff.p; tl.otoff = tile_otoff.p;
     tl.alpha = 1.0; tl.threshold = threshold; tl.dense_rule = dr; tl.ncols = n; tl.nblocks = snb;
     tl.max_kn = (int)hst[1]; tl.max_w = (int)max_w; tl.epi = fu.mode; tl.fz = &fz; tl.rows = trows; tl.labelled = tile_labelled;
+    tl.nrows = X.rows;
     if (!halo) {   // (every run of A -- and X itself -- in the iterate's own value buffer, D in its expansion: 32-bit offsets)
       tl.abase = in.val.p; tl.abytes = in.val.n * sizeof(double);
       tl.dbase = dop.dexp.p; tl.dbytes = dop.dexp.n * sizeof(double);
@@ -5721,6 +5762,12 @@ void relabel_giveup(const DevMat& D) {   // a step on the relabelled form was re
   RelabelCache& c = relabel_cache();
   if (relabel_key_matches(c, D)) c.usable = false;
 }
+
+namespace {
+const int32_t* g_scope_labels = nullptr;
+}
+void set_scope_labels(const int32_t* lab) { g_scope_labels = lab; }
+const int32_t* scope_labels() { return g_scope_labels; }
 
 void drop_operand_caches() {   // the device memory kept between solves (expanded D, D in the recovered order)
   RelabelCache& c = relabel_cache();   // (the order itself -- 8 bytes per column -- and its pattern fingerprint stay)

@@ -274,6 +274,12 @@ bool relabel_enter(DevMat& X, const DevMat& D);
 const DevMat* relabelled_operand(const DevMat& D);
 void relabel_giveup(const DevMat& D);
 void drop_operand_caches();   // frees what the fused / relabelled TRS2 paths keep between solves
+// band_scope.cpp: while a solve runs on operands redistributed in a recovered band order across ranks, the caller's label of every
+// position (device, one per row of the matrices; nullptr outside such a solve).  The fused TRS2 panel steps then decide the
+// "beyond the other column's last entry" cases of their merges on these labels, as the one-rank steps on a relabelled operand
+// do (SlabForm::lab): the several-rank solve keeps the entries the one-rank solve keeps.
+void set_scope_labels(const int32_t* lab);
+const int32_t* scope_labels();
 void drop_pending_exchange(); // psmatrix.cpp: the exchange layout a panel step prepared for a successor that never came
 // relabel.hip: a bandwidth-reducing order of a symmetric pattern (Cuthill-McKee, breadth-first levels on the device):
 // newpos[old index] = new index, *bandwidth = max |new row - new column|.  false: not a square packed matrix, or

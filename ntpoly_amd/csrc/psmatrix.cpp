@@ -154,6 +154,26 @@ void panel_range(int32_t dim, int nranks, int rank, int32_t* c0, int32_t* c1) {
   *c1 = (int32_t)(((int64_t)dim * (rank + 1)) / nranks);
 }
 
+// The layout of one panel exchange on rank `me`, from what every rank knows after the step's all-gather: req[4 q ..] = (first,
+// last row of rank q's panel of B, ...), cnt[s P + q] = doubles rank s sends to rank q.  sa / sb [q]: my columns [sa, sb) go to
+// rank q, packed from soff[q] in my send buffer; ra / rb [s]: the columns [ra, rb) of rank s arrive at zoff[s] of my receive
+// buffer (nothing travels from a rank to itself).  Pure host arithmetic (tests/test_distributed_cpu.py drives it over gloo).
+void panel_exchange_layout(int32_t dim, int P, int me, const int64_t* req, const int64_t* cnt, int32_t* sa, int32_t* sb, int64_t* soff,
+                           int32_t* ra, int32_t* rb, int64_t* zoff) {
+  auto kmin_of = [&](int q) { const int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? 0 : (int32_t)lo; };
+  auto kmax_of = [&](int q) { const int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? -1 : (int32_t)hi; };
+  soff[0] = 0;
+  zoff[0] = 0;
+  for (int q = 0; q < P; ++q) {
+    halo_segment(dim, P, me, kmin_of(q), kmax_of(q), &sa[q], &sb[q]);
+    soff[q + 1] = soff[q] + (q == me ? 0 : cnt[(size_t)me * P + q]);
+  }
+  for (int s = 0; s < P; ++s) {
+    halo_segment(dim, P, s, kmin_of(me), kmax_of(me), &ra[s], &rb[s]);
+    zoff[s + 1] = zoff[s] + (s == me ? 0 : cnt[(size_t)s * P + me]);
+  }
+}
+
 void ps_construct_empty(PSMatrix& m, int32_t dim, const ProcessGrid* g, bool cplx) {
   if (!g) NTP_FATAL("matrix constructed without a process grid (construct the global grid first)");
   ensure_init();
@@ -604,24 +624,15 @@ bool panel_slab_multiply(const PSMatrix& A, const PSMatrix& B, DevMat& AB, doubl
   auto kmin_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? 0 : (int32_t)lo; };
   auto kmax_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? -1 : (int32_t)hi; };
   const int32_t kmin = kmin_of(me), kmax = kmax_of(me);
-  // what I send: my columns of A inside every requester's range, packed per requester
-  std::vector<int32_t> sa((size_t)P), sb((size_t)P);
-  std::vector<int64_t> soff((size_t)P + 1, 0);
-  for (int q = 0; q < P; ++q) {
-    halo_segment(dim, P, me, kmin_of(q), kmax_of(q), &sa[(size_t)q], &sb[(size_t)q]);
-    soff[(size_t)q + 1] = soff[(size_t)q] + (q == me ? 0 : cnt[(size_t)me * P + q]);
-  }
+  // what I send (my columns inside every requester's range, packed per requester) and what I receive (the segments of the
+  // other owners tile [kmin, kmax] in rank order): panel_exchange_layout, host arithmetic on the gathered requests and counts
+  std::vector<int32_t> sa((size_t)P), sb((size_t)P), ra((size_t)P), rb((size_t)P);
+  std::vector<int64_t> soff((size_t)P + 1, 0), zoff((size_t)P + 1, 0);
+  panel_exchange_layout(dim, P, me, req.data(), cnt.data(), sa.data(), sb.data(), soff.data(), ra.data(), rb.data(), zoff.data());
   DevBuf<double> sendbuf((size_t)soff[(size_t)P] + 1);
   for (int q = 0; q < P; ++q)
     if (q != me && cnt[(size_t)me * P + q] > 0)
       slab_pack_runs_async(A.loc, d_pre_all + (size_t)me * pitch, sa[(size_t)q] - A.c0, sb[(size_t)q] - A.c0, sendbuf.p + soff[(size_t)q]);
-  // what I receive: the segments of the other owners tile [kmin, kmax] in rank order
-  std::vector<int32_t> ra((size_t)P), rb((size_t)P);
-  std::vector<int64_t> zoff((size_t)P + 1, 0);
-  for (int s = 0; s < P; ++s) {
-    halo_segment(dim, P, s, kmin, kmax, &ra[(size_t)s], &rb[(size_t)s]);
-    zoff[(size_t)s + 1] = zoff[(size_t)s] + (s == me ? 0 : cnt[(size_t)s * P + me]);
-  }
   DevBuf<double> recvbuf((size_t)zoff[(size_t)P] + kIndexSlack);
   tr.group_begin();
   for (int q = 0; q < P; ++q) {
@@ -1279,25 +1290,16 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   auto kmin_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? 0 : (int32_t)lo; };
   auto kmax_of = [&](int q) { int64_t lo = req[(size_t)4 * q], hi = req[(size_t)4 * q + 1]; return hi < lo ? -1 : (int32_t)hi; };
   const int32_t kmin = kmin_of(me), kmax = kmax_of(me);
-  // what I send: my columns inside every requester's range, packed per requester
-  std::vector<int32_t> sa((size_t)P), sb((size_t)P);
-  std::vector<int64_t> soff((size_t)P + 1, 0);
-  for (int q = 0; q < P; ++q) {
-    halo_segment(dim, P, me, kmin_of(q), kmax_of(q), &sa[(size_t)q], &sb[(size_t)q]);
-    soff[(size_t)q + 1] = soff[(size_t)q] + (q == me ? 0 : cnt[(size_t)me * P + q]);
-  }
+  // what I send (my columns inside every requester's range, packed per requester) and what I receive (the segments of the
+  // other owners tile [kmin, kmax] in rank order): panel_exchange_layout, host arithmetic on the gathered requests and counts
+  std::vector<int32_t> sa((size_t)P), sb((size_t)P), ra((size_t)P), rb((size_t)P);
+  std::vector<int64_t> soff((size_t)P + 1, 0), zoff((size_t)P + 1, 0);
+  panel_exchange_layout(dim, P, me, req.data(), cnt.data(), sa.data(), sb.data(), soff.data(), ra.data(), rb.data(), zoff.data());
   DevBuf<double> sendbuf((size_t)soff[(size_t)P] + 1);
   for (int q = 0; q < P; ++q)
     if (q != me && cnt[(size_t)me * P + q] > 0)
       slab_pack_runs_async(B.loc, d_pre_all + (size_t)me * pitch, sa[(size_t)q] - B.c0, sb[(size_t)q] - B.c0,
                            sendbuf.p + soff[(size_t)q]);
-  // what I receive: the segments of the other owners tile [kmin, kmax] in rank order
-  std::vector<int32_t> ra((size_t)P), rb((size_t)P);
-  std::vector<int64_t> zoff((size_t)P + 1, 0);
-  for (int s = 0; s < P; ++s) {
-    halo_segment(dim, P, s, kmin, kmax, &ra[(size_t)s], &rb[(size_t)s]);
-    zoff[(size_t)s + 1] = zoff[(size_t)s] + (s == me ? 0 : cnt[(size_t)s * P + me]);
-  }
   DevBuf<double> recvbuf((size_t)zoff[(size_t)P] + kIndexSlack);
   tr.group_begin();
   for (int q = 0; q < P; ++q) {

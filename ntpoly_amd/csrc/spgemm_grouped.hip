@@ -469,10 +469,10 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
   constexpr int G = GhG<T>::value;
   constexpr int NT = NW * WAVE, CAP = NT * SL, TH = GhTable<CAP, (int)sizeof(T)>::TH, SHIFT = GhTable<CAP, (int)sizeof(T)>::SHIFT;
   constexpr int KB = NW / WPC;   // steps per phase
-  constexpr int PF = 2;          // chunks of a wave's share requested a phase ahead
+  constexpr int PF = (MF && WPC == 2) ? 3 : 2;   // chunks of a wave's share requested a phase ahead (two waves per column: 3 x 128 entries)
   constexpr unsigned long long EMPTY = ~0ull;
   static_assert(NW % WPC == 0 && KB >= 1 && 2 * KB * CAP >= 2 * CAP, "geometry");
-  __shared__ unsigned long long htab[TH];   // (row << 32 | slot); the epilogue sorts (row, slot) pairs in the same memory
+  __shared__ __attribute__((aligned(16))) unsigned long long htab[TH];   // (row << 32 | slot); the epilogue sorts (row, slot) pairs in the same memory
   static_assert(!MF || (!Sc<T>::cplx && KB == 4 && CAP % (16 * NW) == 0), "matrix-core products: real operands, four steps per phase");
   constexpr int XP = MF ? CAP + 16 : CAP;   // (MF: rows 16 slots apart in the banks -- the four steps a lane group reads do not collide)
   constexpr int NTILE = CAP / (16 * NW);    // MF: tiles of 16 slots per wave (tile u of wave w = slots 16 (u NW + w) ..)
@@ -648,6 +648,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu((SL ==
       const int q = lane >> 4, jj = lane & 15;
       double bv = 0.0;
       if constexpr (!Sc<T>::cplx) bv = (q < nstep) ? tile[(int64_t)(t0 + q) * G + jj] : 0.0;
+      // (tried and measured slower by 8 %: all of the wave's tiles read up front, the two entries of a bucket in one 16-byte read)
 #pragma unroll
       for (int u = 0; u < NTILE; ++u) {
         const int s0 = 16 * (u * NW + wave);
@@ -1078,9 +1079,10 @@ bool spgemm_grouped(const DevMat& A, const DevMat& B, const int64_t* tmpoff, int
       if (level == 0)
         launch_ghash<double, 8, 1, 2, true>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
                                             count, state.p, stats.p, alpha, threshold, dense_rule);
-      else if (level == 1)
-        launch_ghash<double, 8, 2, 2, true>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
-                                            count, state.p, stats.p, alpha, threshold, dense_rule);
+      else if (level == 1)   // (1024 slots: SIXTEEN waves -- four per column of a phase, four tiles of 16 slots each; the two sets of four
+                             // slot-indexed columns and the table fill the LDS of a CU, so the waves of one workgroup are its occupancy)
+        launch_ghash<double, 16, 1, 4, true>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
+                                             count, state.p, stats.p, alpha, threshold, dense_rule);
       else   // (the largest class: four slot-indexed columns of 1536 per set and the table do not fit the LDS together -- vector units)
         launch_ghash<double, 8, 3, 4>(A, ngroups, colp, grp_kn.p, grp_maxlen.p, grp_off.p, recs.p, tiles.p, tmpoff, tmp_inner, tmp_val,
                                       count, state.p, stats.p, alpha, threshold, dense_rule);

@@ -103,6 +103,7 @@ struct TileArgs {
   int64_t* otoff;
   double alpha, threshold;
   int dense_rule, ncols, nblocks;
+  int nrows;            // rows of the operands (labels are per row: panels have more rows than columns)
   int k4max, tmax;
   SlabFuseArgs fzv;     // EPI != 0: the fused epilogue's arguments, by value (kernel arguments: scalar loads, no upload before the launch)
   // EPI 0 only, optional: the right operand as the runs of its columns (slab algebra: no multiplier tiles were built) --
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   if constexpr (LAB) {
     const int32_t* __restrict__ lab_g = a.fzv.lab;
 #pragma unroll
-    for (int u = 0; u < LABCH; ++u) labtmp[u] = lab_g[min(lo + tid + u * NT, a.ncols - 1)];
+    for (int u = 0; u < LABCH; ++u) labtmp[u] = lab_g[min(lo + tid + u * NT, a.nrows - 1)];
   }
   {
     // one thread per record (all loads independent and in flight together with the tile's), the row range of a k
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   }
   if constexpr (LAB) {   // (the labels beyond the first LABCH per thread, requested above)
     const int32_t* __restrict__ lab_g = a.fzv.lab;
-    for (int i = tid + LABCH * NT; i < T * TROWS; i += NT) labs[i] = lab_g[min(lo + i, a.ncols - 1)];
+    for (int i = tid + LABCH * NT; i < T * TROWS; i += NT) labs[i] = lab_g[min(lo + i, a.nrows - 1)];
     __syncthreads();
   }
   STAMP(1);
@@ -481,6 +482,9 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       uint4 raw = rq[4 * gi(g0 + TILE_PF)];
       int g = g0;
       STAMP(sidx);
+#ifdef NTP_TILE_SETPRIO
+      __builtin_amdgcn_s_setprio(NTP_TILE_SETPRIO);   // (experiment: waves inside the matrix loop ahead of the waves in prologues / epilogues)
+#endif
       for (; g + TILE_PF - 1 <= g1; g += TILE_PF) {
 #pragma unroll
         for (int u = 0; u < TILE_PF; ++u) {
@@ -496,6 +500,9 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#ifdef NTP_TILE_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       epilogue_loads();
 #pragma unroll
       for (int u = 0; u < TILE_PF - 1; ++u) {
@@ -834,6 +841,7 @@ void launch_spgemm_tile(const TileLaunch& L) {
   a.blk_toff = L.blk_toff; a.out_val = L.out_val; a.count = L.count; a.ofirst = L.ofirst; a.olast = L.olast; a.ooff = L.ooff;
   a.otoff = L.otoff; a.alpha = L.alpha; a.threshold = L.threshold; a.dense_rule = L.dense_rule; a.ncols = L.ncols;
   a.nblocks = L.nblocks;
+  a.nrows = L.nrows > 0 ? L.nrows : L.ncols;
   a.k4max = std::max(8, (L.max_kn + 3) & ~3);   // (>= 8: the multiplier tile doubles as scratch for 2 x TILE_DEFER sums)
   const int trows = 16 * (L.rows == 4 ? 4 : L.rows == 2 ? 2 : 1);
   a.tmax = (L.max_w + trows - 1) / trows;

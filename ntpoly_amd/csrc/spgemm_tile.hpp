@@ -42,6 +42,7 @@ struct TileLaunch {
   size_t abytes = 0;
   const void* dbase = nullptr;       // epi != 0: the allocation that holds the expanded D operand (fz.dexp), for the same purpose
   size_t dbytes = 0;
+  int nrows = 0;                     // rows of the operands (0: ncols -- square); label-aware epilogues index fz.lab by row
   bool labelled = false;             // fz carries labels (SlabFuseArgs::lab, xplast, oplast): the epilogue's "beyond the last entry"
                                      // tests compare the caller's labels.  The k steps are walked in POSITION order (the rounding
                                      // of a product entry then differs from the label-ordered chain in its last bits: tolerance mode)

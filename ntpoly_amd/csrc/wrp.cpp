@@ -144,6 +144,14 @@ void ntpoly_amd_halo_segment(const int* dim, const int* nranks, const int* s, co
                              int* b) {
   halo_segment(*dim, *nranks, *s, *kmin, *kmax, a, b);
 }
+// the layout of one panel exchange on rank `me` (psmatrix.cpp panel_exchange_layout: the host arithmetic of the halo exchange of
+// the fused panel steps): req = 4 words per rank (first, last row of its panel of B, two unused here), cnt[s P + q] = doubles
+// rank s sends to rank q
+void ntpoly_amd_panel_exchange_layout(const int* dim, const int* nranks, const int* me, const long long* req, const long long* cnt,
+                                      int* sa, int* sb, long long* soff, int* ra, int* rb, long long* zoff) {
+  panel_exchange_layout(*dim, *nranks, *me, reinterpret_cast<const int64_t*>(req), reinterpret_cast<const int64_t*>(cnt), sa, sb,
+                        reinterpret_cast<int64_t*>(soff), ra, rb, reinterpret_cast<int64_t*>(zoff));
+}
 void ntpoly_amd_set_option(const char* name, const int* value) {
   const std::string n(name);
   if (n == "spgemm_force_bin") options().spgemm_force_bin = *value;

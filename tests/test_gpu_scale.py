@@ -250,10 +250,18 @@ def test_config4_product_and_sign_iterations_vs_oracle_at_the_benched_size(nt, a
     compare(S.triplets(), So.triplets(), "three SignFunction iterations", exact_in_unfused=False)
 
 
-def test_headline_config2_vs_oracle_full_size(nt, arith):
-    if arith == "fma":
-        pytest.skip("FMA arithmetic at the full size: all 25 timed iterations in test_headline_fma_all_timed_iterations_vs_oracle")
-    _headline_config2_vs_oracle_full_size(nt, arith)
+@pytest.fixture()
+def unfused(nt):
+    from oracle import oracle_py as O
+    nt.set_option("spgemm_fma", 0)
+    O.set_fma(False)
+    yield "unfused"
+
+
+def test_headline_config2_vs_oracle_full_size(nt, unfused):
+    """(unfused arithmetic; the FMA mode at the full size is test_headline_fma_all_timed_iterations_vs_oracle: all 25 iterations
+    the bench touches, the first eight among them)"""
+    _headline_config2_vs_oracle_full_size(nt, unfused)
 
 
 def _headline_config2_vs_oracle_full_size(nt, arith):
@@ -290,8 +298,6 @@ def _headline_config2_vs_oracle_full_size(nt, arith):
 
 @pytest.mark.parametrize("label_order", [1, 0])
 def test_relabelled_trs2_vs_oracle(nt, arith, label_order):
-    if label_order == 0 and arith == "unfused":
-        pytest.skip("the grouped LDS hash in unfused arithmetic: tests/test_gpu_parity.py (suite budget)")
     _relabelled_trs2_vs_oracle(nt, arith, label_order)
 
 
