@@ -482,9 +482,6 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       uint4 raw = rq[4 * gi(g0 + TILE_PF)];
       int g = g0;
       STAMP(sidx);
-#ifdef NTP_TILE_SETPRIO
-      __builtin_amdgcn_s_setprio(NTP_TILE_SETPRIO);   // (experiment: waves inside the matrix loop ahead of the waves in prologues / epilogues)
-#endif
       for (; g + TILE_PF - 1 <= g1; g += TILE_PF) {
 #pragma unroll
         for (int u = 0; u < TILE_PF; ++u) {
@@ -500,9 +497,6 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-#ifdef NTP_TILE_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
       epilogue_loads();
 #pragma unroll
       for (int u = 0; u < TILE_PF - 1; ++u) {
