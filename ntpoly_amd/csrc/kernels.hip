@@ -6535,10 +6535,22 @@ bool slab_multiply_loop(const DevMat& A, const DevMat& B, DevMat& C, double alph
 
 // C = alpha A B with the threshold rule of the SpGEMM, operands and result in slab form: on the MFMA tile kernel in FMA
 // arithmetic, on the register-slab kernel in unfused arithmetic
+// Every reason slab_multiply has to decline a PANEL product (left halo, FMA arithmetic) once its plan is known -- ONE predicate,
+// used by slab_multiply itself and by the caller before the ranks agree on the product's path (psmatrix.cpp panel_slab_multiply):
+// a rank that says yes there cannot say no later, when the others are already inside the collectives that follow.
+bool slab_multiply_takes_panel(const DevMat& A, const DevMat& B, int left_row_pad, int32_t ka, int32_t kb, const SlabPlan* plan) {
+  if (options().spgemm_fma != 1 || kb <= ka) return false;
+  if (!sa_operand(A) || !sa_operand(B) || options().spgemm_variant >= 0 || options().spgemm_force_bin > 0) return false;
+  if (left_row_pad % 16 != 0) return false;
+  const int snb = cdiv(B.cols, SLAB_J);
+  if (!plan || plan->align != 16 * tile_rows() || (int64_t)plan->blk_lo.n != snb) return false;   // (a plan of its own would be a late decision)
+  return plan->max_w > 0 && spgemm_tile_fits(plan->max_kn, plan->max_w);
+}
+
 bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, double threshold, bool dense_rule, const SlabHalo* left) {
   // left (a panel product, psmatrix.cpp): A and B are column panels of the distributed operands; the columns of the left
   // operand named by the rows of B's panel -- this rank's own and the halo -- are described by `left` (global column numbers)
-  if (left && (options().spgemm_fma != 1 || left->kb <= left->ka)) return false;
+  if (left && !slab_multiply_takes_panel(A, B, left->row_pad, left->ka, left->kb, left->plan)) return false;
   if (options().spgemm_fma == 0) {
     if (!sa_operand(A) || !sa_operand(B) || A.cols != B.rows || options().spgemm_variant >= 0 || options().spgemm_force_bin > 0 ||
         A.slab->row_pad != 1)

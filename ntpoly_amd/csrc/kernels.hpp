@@ -203,6 +203,9 @@ struct SlabHalo {   // A side of a panel step: the columns ka .. kb (global numb
 };
 // (could the tile kernel take a plan with these maxima: psmatrix.cpp decides a panel product before its exchange is over)
 bool slab_plan_fits_tile(int max_kn, int max_w);
+struct SlabPlan;
+// true: slab_multiply with a left halo of these columns, this alignment and this plan will NOT decline (the one predicate it uses itself)
+bool slab_multiply_takes_panel(const DevMat& A, const DevMat& B, int left_row_pad, int32_t ka, int32_t kb, const SlabPlan* plan);
 // the plan of a panel step from the all-gathered packed extents (record stride `pitch`, extents at d_ext_all): flat
 // extent arrays of all `dim` columns are left in gfirst / glast, the plan's sizes on the device in plan.blk_toff[blocks]
 // and stats24[16..17] (stats24: 24 zeroed words)

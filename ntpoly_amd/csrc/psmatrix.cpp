@@ -646,7 +646,10 @@ bool panel_slab_multiply(const PSMatrix& A, const PSMatrix& B, DevMat& AB, doubl
   tr.group_end();
   // "did every rank's kernel take its panel": known to a rank once its plan is back; the sum over the ranks is enqueued
   // here and read back with the product's entry count
-  bool ok = kmax >= kmin && slab_plan_fits_tile(plan.max_kn, plan.max_w);
+  // (plan.max_w / max_kn are back: the SAME predicate slab_multiply applies -- a rank that agrees here cannot decline later)
+  plan.max_w = (int)plan_hs[0];
+  plan.max_kn = (int)plan_hs[1];
+  bool ok = mine_ok && kmax >= kmin && slab_multiply_takes_panel(A.loc, B.loc, row_pad, kmin, kmax + 1, &plan);
   DevBuf<double> d_declined(4);
   double declined[4] = {ok ? 0.0 : 1.0, 0.0, 0.0, 0.0};
   d_declined.upload(declined, 4);

@@ -77,7 +77,7 @@ def run(nt, solver, H, n, thr, conv, iters=None):
     return srt(Out.triplets()), tr, extra
 
 
-ORDER2 = [("inverse_square_root", 2560, 20, 1e-8, 2.0)]
+ORDER2 = [("inverse_square_root", 4096, 20, 1e-8, 2.0)]
 # (sizes: what these cases cost is the ORACLE's solve on the host cores -- the iterates of the sign and root loops fill in -- so the
 # loops run at N = 2048 .. 2560, every case in both arithmetic modes, instead of at N = 4096 with most unfused cases left out)
 CASES = [("trs4", 4096, 20, 1e-8, 0.0), ("trs4", 3000, 12, 1e-6, 0.0), ("sign", 2560, 20, 1e-8, 0.0), ("sign", 2048, 8, 1e-7, 0.3),
