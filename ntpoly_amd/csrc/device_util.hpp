@@ -56,6 +56,26 @@ struct Sc<double2> {
   __device__ static inline bool is_zero(double2 v) { return v.x == 0.0 && v.y == 0.0; }
 };
 
+// double-double accumulation (error-free two-sums): (hi, lo) += (xh, xl).  A sum accumulated this way and rounded once at the end
+// is the correctly rounded sum for ANY order of its terms, up to an error of ~1e-32 relative before that rounding -- used where a
+// result must not depend on the order entries are stored in (the Gershgorin radius that starts a solve: a solve on a relabelled
+// copy of a matrix, or on its slab form, has to start from the same spectral bounds as the solve on the caller's columns)
+__device__ inline void dd_add(double& hi, double& lo, double xh, double xl) {
+  const double s = __dadd_rn(hi, xh);
+  const double bb = __dsub_rn(s, hi);
+  double e = __dadd_rn(__dsub_rn(hi, __dsub_rn(s, bb)), __dsub_rn(xh, bb));
+  e = __dadd_rn(e, __dadd_rn(lo, xl));
+  hi = __dadd_rn(s, e);
+  lo = __dsub_rn(e, __dsub_rn(hi, s));
+}
+// the sum of (hi, lo) over the lanes of a wave, every lane gets it
+__device__ inline void dd_wave_sum(double& hi, double& lo) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const double oh = __shfl_xor(hi, o, 64), ol = __shfl_xor(lo, o, 64);
+    dd_add(hi, lo, oh, ol);
+  }
+}
+
 // ------------------------------------------------------------------ wave helpers
 __device__ inline int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ inline int readlane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }

@@ -2522,29 +2522,14 @@ __global__ __launch_bounds__(256) void k_colstat(Csc A, int col_offset, int mode
     // Gershgorin radius: the sum of the column's moduli must not depend on the ORDER the entries are stored in -- a solve
     // that runs on a relabelled copy of the matrix (band scope across ranks, the load balancer) has to start from the same
     // spectral bounds as the solve on the caller's labels, or the two differ in the last bits of every entry from the first
-    // iterate on.  Accumulated in double-double (error-free two-sums), rounded once at the end: the correctly rounded sum for
-    // any order, up to an error of ~1e-32 relative before that rounding.
+    // iterate on.  Accumulated in double-double (device_util.hpp dd_add), rounded once at the end; k_sa_colstat sums the runs
+    // of a slab form the same way, so a session's bounds are these bits too.
     double rl = 0.0;
-    auto two_sum = [](double a, double b, double& s, double& e) {
-      s = __dadd_rn(a, b);
-      const double bb = __dsub_rn(s, a);
-      e = __dadd_rn(__dsub_rn(a, __dsub_rn(s, bb)), __dsub_rn(b, bb));
-    };
-    auto dd_add = [&](double& hi, double& lo, double xh, double xl) {
-      double s, e;
-      two_sum(hi, xh, s, e);
-      e = __dadd_rn(e, __dadd_rn(lo, xl));
-      hi = __dadd_rn(s, e);
-      lo = __dsub_rn(e, __dsub_rn(hi, s));
-    };
     for (int64_t p = A.outer[j] + lane; p < A.outer[j + 1]; p += WAVE) {
       if (A.inner[p] == j + col_offset) d = __dadd_rn(d, Sc<T>::re(Av[p]));
       else dd_add(r, rl, Sc<T>::mag(Av[p]), 0.0);
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      const double oh = __shfl_xor(r, o, WAVE), ol = __shfl_xor(rl, o, WAVE);
-      dd_add(r, rl, oh, ol);
-    }
+    dd_wave_sum(r, rl);
     d = wave_sum_f64(d);
     if (lane == 0) { out0[j] = d - r; out1[j] = d + r; }
     return;
@@ -6136,13 +6121,24 @@ __global__ __launch_bounds__(256) void k_sa_colstat(int n, const int32_t* __rest
   const int lane = lane_id();
   const int f = first[j], l = last[j];
   double r = 0.0, d = 0.0;
+  if (mode == 1) {   // (Gershgorin: the order-independent sum of k_colstat -- the zeros of a run add nothing)
+    double rl = 0.0;
+    if (l >= f) {
+      const T* __restrict__ p = val + (off[j] - f);
+      for (int i = f + lane; i <= l; i += WAVE) {
+        const T v = p[i];
+        if (i == j + col_offset) d = __dadd_rn(d, Sc<T>::re(v));   // (GershgorinBounds.f90: the real part of the diagonal)
+        else dd_add(r, rl, Sc<T>::mag(v), 0.0);
+      }
+    }
+    dd_wave_sum(r, rl);
+    d = wave_sum_f64(d);
+    if (lane == 0) { out0[j] = d - r; out1[j] = d + r; }
+    return;
+  }
   if (l >= f) {
     const T* __restrict__ p = val + (off[j] - f);
-    for (int i = f + lane; i <= l; i += WAVE) {
-      const T v = p[i];
-      if (mode == 1 && i == j + col_offset) d = __dadd_rn(d, Sc<T>::re(v));   // (GershgorinBounds.f90: the real part of the diagonal)
-      else r = __dadd_rn(r, Sc<T>::mag(v));
-    }
+    for (int i = f + lane; i <= l; i += WAVE) r = __dadd_rn(r, Sc<T>::mag(p[i]));
   }
   r = wave_sum_f64(r);
   d = wave_sum_f64(d);

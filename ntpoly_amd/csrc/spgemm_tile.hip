@@ -80,7 +80,10 @@ struct alignas(16) TileRec {
   int32_t first;
   uint32_t span;     // last - first; an empty run: first = INT_MAX, span = 0 (no row passes (unsigned)(r - first) <= span)
 };
-constexpr int TILE_PF = 6;           // run loads (k groups) in flight per wave; a multiple of 3
+#ifndef NTP_TILE_PF
+#define NTP_TILE_PF 6
+#endif
+constexpr int TILE_PF = NTP_TILE_PF;           // run loads (k groups) in flight per wave; a multiple of 3
 constexpr int TILE_RPAD = 4, TILE_BPAD = 0;   // one group of empty records behind the last (the pipeline's look-ahead is clamped to it; OFF32: see the loop)
 // an element of X whose fate depends on the last kept row of the product column (decided when the block is done)
 struct alignas(16) TileDefer {
@@ -140,7 +143,11 @@ __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax, int lab_ro
 #endif
 
 template <int EPI, int TILE_NW, int R, bool LAB, bool OFF32>
+#ifdef NTP_TILE_WPE3
+__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((((EPI == 0 || !LAB) && R <= 2) && TILE_NW != 4) ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
+#else
 __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(((EPI == 0 || !LAB) && R <= 2) ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = xcd_block(a.nblocks);
   if (b < 0) return;
@@ -218,11 +225,22 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     v.y = (i < kn * 8 && r >= bf1 && r <= bl1) ? bp1[r] : 0.0;
     return v;
   };
+  // (the block's product count = sum over the tile's non-zeros B(k, j) of the entries of A(:, k): the entry counts of the rows a
+  // thread holds are requested WITH the tile's values and multiplied while the values sit in registers -- the count used to
+  // be a pass of its own over the LDS tile behind the barrier, 7 % of the kernel for a statistic, profiles/README.md round 6)
+  [[maybe_unused]] int bcnt[BCH];
+  [[maybe_unused]] const int32_t* __restrict__ prod_count = nullptr;
+  [[maybe_unused]] bool want_prod = false;
+  if constexpr (EPI != 0) {
+    want_prod = a.fzv.prod != nullptr;
+    prod_count = a.fzv.in_count;
+  }
 #pragma unroll
   for (int u = 0; u < BCH; ++u) {
     const int i = tid + u * NT;
     if (brun) btmp[u] = brun_load(i);
     else btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+    if constexpr (EPI != 0) bcnt[u] = (want_prod && i < kn * 8) ? (prod_count ? prod_count[kmin + (i >> 3)] : 1) : 0;
   }
   // (label-aware kernels: the caller's labels of the window's rows are requested with the tile and the records -- not in a
   // round trip of their own behind the barrier -- and stored with them)
@@ -274,14 +292,20 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     }
   }
   STAMP(60);
+  [[maybe_unused]] long long prod_p = 0;
 #pragma unroll
   for (int u = 0; u < BCH; ++u) {
     const int i = tid + u * NT;
     if (i < K4 * 8) bdst[i] = btmp[u];
+    if constexpr (EPI != 0) prod_p += (long long)(((btmp[u].x != 0.0) ? 1 : 0) + ((btmp[u].y != 0.0) ? 1 : 0)) * bcnt[u];
   }
   for (int i = tid + BCH * NT; i < K4 * 8; i += NT) {
-    if (brun) bdst[i] = brun_load(i);
-    else bdst[i] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+    const double2 v = brun ? brun_load(i) : (i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0));
+    bdst[i] = v;
+    if constexpr (EPI != 0) {
+      if (want_prod && i < kn * 8)
+        prod_p += (long long)(((v.x != 0.0) ? 1 : 0) + ((v.y != 0.0) ? 1 : 0)) * (prod_count ? prod_count[kmin + (i >> 3)] : 1);
+    }
   }
   STAMP(61);
   if constexpr (LAB) {
@@ -302,20 +326,9 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   STAMP(62);
   STAMP(63);
   if constexpr (EPI != 0) {
-    if (a.fzv.prod) {   // products of this block = sum over the tile rows k of (non-zero multipliers) * (entries of A(:, k))
-      // (wave-uniform work: a wave reads four tile rows at once, the ballot of their non-zeros gives the four counts, the
-      // entry counts of the columns of A are scalar loads -- almost nothing of it issues on the vector unit)
-      const int32_t* __restrict__ in_count = a.fzv.in_count;
-      long long p = 0;
-      for (int k4 = 4 * wave; k4 < kn; k4 += 4 * TILE_NW) {
-        const unsigned long long m = __ballot(Bs[(size_t)k4 * SLAB_J + lane] != 0.0);   // (rows kn .. K4 are zero)
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int c = __builtin_popcount((unsigned)(m >> (16 * s4)) & 0xffffu);
-          p += (long long)c * (in_count ? in_count[kmin + min(k4 + s4, kn - 1)] : 1);
-        }
-      }
-      if (lane == 0 && p) atomicAdd(reinterpret_cast<unsigned long long*>(misc + 2), (unsigned long long)p);
+    if (want_prod) {
+      prod_p = wave_sum_i64(prod_p);
+      if (lane == 0 && prod_p) atomicAdd(reinterpret_cast<unsigned long long*>(misc + 2), (unsigned long long)prod_p);
     }
   }
   if constexpr (LAB) {   // (the labels beyond the first LABCH per thread, requested above)
