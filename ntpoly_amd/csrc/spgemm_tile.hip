@@ -164,6 +164,19 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     if (c0 < a.ncols) { bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0]; bp0 = a.brun_val + (a.brun_off[c0] - bf0); }
     if (c0 + 1 < a.ncols) { bf1 = a.brun_first[c0 + 1]; bl1 = a.brun_last[c0 + 1]; bp1 = a.brun_val + (a.brun_off[c0 + 1] - bf1); }
   }
+  // (what the fused epilogue needs of this lane's column -- extents and offsets of D and X -- depends on the block's number only:
+  // requested here with the plan's scalars, used behind the barrier.  Loaded there, the test "does X fit the window" made every
+  // wave wait for a memory round trip between the barrier and its first tile)
+  [[maybe_unused]] int e_d0 = 0, e_d1 = -1, e_x0 = 0, e_x1 = -1, e_xpl = -1;
+  [[maybe_unused]] int64_t e_doff = 0, e_xoff = 0;
+  if constexpr (EPI != 0) {
+    const int jc0 = min(b * SLAB_J + (tid & 15), a.ncols - 1);
+    e_d0 = a.fzv.dmin[jc0]; e_d1 = a.fzv.dmax[jc0]; e_doff = a.fzv.doff[jc0];
+    if constexpr (EPI == 2) {
+      e_x0 = a.fzv.xmin[jc0]; e_x1 = a.fzv.xmax[jc0]; e_xoff = a.fzv.xoff[jc0];
+      if constexpr (LAB) e_xpl = a.fzv.xplast[jc0];
+    }
+  }
   if (b == 0 && tid == 0) {   // (the end markers of the result's offset arrays)
     a.ooff[a.ncols] = a.blk_toff[a.nblocks];
     if (EPI != 0 && a.otoff) a.otoff[a.nblocks] = a.blk_toff[a.nblocks];
@@ -354,21 +367,21 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   if constexpr (EPI != 0) {
     // (fzv.tiles == nullptr: the result carries runs only -- the next step builds its multiplier tile from them)
     if (a.fzv.tiles) otile = a.fzv.tiles + (tbase - (int64_t)lo * SLAB_J + jj);   // otile[r * 16] = row r, column jj of the tile
-    const int d0 = a.fzv.dmin[jc], d1 = a.fzv.dmax[jc];
+    const int d0 = e_d0, d1 = e_d1;
     if (colv && d1 >= d0) {
       df = d0;
       dl = d1;
-      drz = a.fzv.dexp + (a.fzv.doff[jc] - d0);
+      drz = a.fzv.dexp + (e_doff - d0);
     }
     diag = j + a.fzv.col_offset;
     if constexpr (EPI == 2) {
       am = a.fzv.am; bm = a.fzv.bm; thr_m = a.fzv.thr_m;
-      const int x0 = a.fzv.xmin[jc], x1 = a.fzv.xmax[jc];
+      const int x0 = e_x0, x1 = e_x1;
       if (colv && x1 >= x0) {
         xf = x0;
         xlrow = x1;
-        xrz = a.fzv.xexp + (a.fzv.xoff[jc] - x0);
-        xpl = LAB ? a.fzv.xplast[jc] : x1;
+        xrz = a.fzv.xexp + (e_xoff - x0);
+        xpl = LAB ? e_xpl : x1;
         if (x0 < lo || x1 >= lo + w) atomicOr(a.fzv.flag, 1);   // every stored row of X(:, j) must be a row of this block's window
       }
     }
