@@ -566,19 +566,6 @@ def main():
         else:
             line["roofline_compute"] = {"bound": "fp64 vector ALU (unfused mul+add)", "achieved": tfl, "peak": 39.3,
                                         "unit": "TFLOP/s", "frac": tfl / 39.3}
-        if args.arithmetic == "fma" and st.get("slab"):
-            # what the tile kernel's loop is bound by (profiles/README.md items 99, 106): every matrix instruction consumes 512 bytes
-            # of A fragments (a 16-byte load per lane feeds two instructions) that come through the L2 -- >= products / 1024
-            # instructions per launch -- against what the L2 delivers to a CU for that access pattern, measured without any
-            # arithmetic by tools/micro/l2_fragment_bw.hip (profiles/r06_micro_l2_fragment_bw.txt: 41.1 B/clk/CU at the kernel's
-            # 12 waves x 6 loads in flight; it FALLS with more waves or deeper rings).  An average over the whole kernel: the
-            # loops are 56 % of a wave's time, so inside them the kernel runs at that ceiling.
-            frag_bytes = acc["products"] / 1024.0 * 512.0 / calls
-            rate = frag_bytes / (ms_numeric / calls * 1e-3) / 2.4e9 / 256.0
-            line["roofline_l2_fragments"] = {"bound": "L2 -> CU delivery of 4 x 256-byte fragment loads", "achieved": rate, "peak": 41.1,
-                                             "unit": "B/clk/CU (2.4 GHz, 256 CUs)", "frac": rate / 41.1,
-                                             "fragment_bytes_per_launch_lower_bound": frag_bytes,
-                                             "note": "whole-kernel average of a quantity that flows only while the loops run; informational, beside the two rooflines the contract names"}
         # timed steps computed inside the SpGEMM kernel (X*X; 2X - X*X) and fused steps that had to be repeated unfused
         line["fused_steps"] = fused
         if gs.get("used"):
