@@ -114,6 +114,7 @@ struct TileArgs {
   const int32_t *brun_first, *brun_last;
   const int64_t* brun_off;
   const double* brun_val;
+  uint32_t bbytes;      // > 0: the runs brun_* lie in [brun_val, brun_val + bbytes), below 4 GB - 8 KB: the multiplier tile is read through a buffer resource
   const double* zero;   // 16 bytes of zeros: where the lanes outside a run load from
   // OFF32 instantiations: every run of A lies in [abase, abase + abytes), abytes < 4 GB -- the runs are read through a buffer
   // resource with 32-bit offsets, lanes outside a run get an offset beyond the buffer (the bounds check returns 0.0)
@@ -159,10 +160,21 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   const bool brun = a.brun_val != nullptr;
   int bf0 = INT_MAX, bl0 = -1, bf1 = INT_MAX, bl1 = -1;
   const double *bp0 = nullptr, *bp1 = nullptr;
+  unsigned bo0 = 0u, bo1 = 0u;   // (bbytes: byte offset of the hypothetical row 0 of the column's run in the buffer, modulo 2^32)
   if (brun) {   // (EPI 0: the slab algebra's right operand; EPI 1 / 2: the iterate itself -- its runs are the kernel's left operand already)
     const int c0 = b * SLAB_J + 2 * (tid & 7);
-    if (c0 < a.ncols) { bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0]; bp0 = a.brun_val + (a.brun_off[c0] - bf0); }
-    if (c0 + 1 < a.ncols) { bf1 = a.brun_first[c0 + 1]; bl1 = a.brun_last[c0 + 1]; bp1 = a.brun_val + (a.brun_off[c0 + 1] - bf1); }
+    if (c0 < a.ncols) {
+      bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0];
+      const int64_t o = a.brun_off[c0];
+      bp0 = a.brun_val + (o - bf0);
+      bo0 = ((unsigned)o - (unsigned)bf0) * 8u;
+    }
+    if (c0 + 1 < a.ncols) {
+      bf1 = a.brun_first[c0 + 1]; bl1 = a.brun_last[c0 + 1];
+      const int64_t o = a.brun_off[c0 + 1];
+      bp1 = a.brun_val + (o - bf1);
+      bo1 = ((unsigned)o - (unsigned)bf1) * 8u;
+    }
   }
   // (what the fused epilogue needs of this lane's column -- extents and offsets of D and X -- depends on the block's number only:
   // requested here with the plan's scalars, used behind the barrier.  Loaded there, the test "does X fit the window" made every
@@ -234,6 +246,11 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   auto brun_load = [&](int i) {
     const int r = kmin + (i >> 3);
     double2 v;
+#ifdef NTP_ABL_NOBLOAD   // (ablation, wrong results: what the multiplier tile's loads cost)
+    v.x = (i < kn * 8 && r >= bf0 && r <= bl0) ? 1.0 : 0.0;
+    v.y = (i < kn * 8 && r >= bf1 && r <= bl1) ? 1.0 : 0.0;
+    return v;
+#endif
     v.x = (i < kn * 8 && r >= bf0 && r <= bl0) ? bp0[r] : 0.0;
     v.y = (i < kn * 8 && r >= bf1 && r <= bl1) ? bp1[r] : 0.0;
     return v;
@@ -248,13 +265,69 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     want_prod = a.fzv.prod != nullptr;
     prod_count = a.fzv.in_count;
   }
+#ifndef NTP_TILE_NO_RECFIRST
+  // (the run records requested BEFORE the tile's values: loads return in order, so records requested behind the tile's 36
+  // loads per thread could not be worked on before the last of those had arrived)
+  constexpr int RCH = (384 + 4 + NT - 1) / NT;
+  uint4 rh0[RCH], rh1[RCH];
+  {
+    const uint4* __restrict__ rp_h = reinterpret_cast<const uint4*>(a.runs + kmin);
 #pragma unroll
-  for (int u = 0; u < BCH; ++u) {
-    const int i = tid + u * NT;
-    if (brun) btmp[u] = brun_load(i);
-    else btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
-    if constexpr (EPI != 0) bcnt[u] = (want_prod && i < kn * 8) ? (prod_count ? prod_count[kmin + (i >> 3)] : 1) : 0;
+    for (int u = 0; u < RCH; ++u) {
+      const int ic = min(tid + u * NT, kn - 1);
+      rh0[u] = rp_h[2 * ic];
+      rh1[u] = rp_h[2 * ic + 1];
+    }
   }
+  STAMP(50);
+#ifdef NTP_TILE_STAMPS
+  if (brun && bf0 + bl0 + bf1 + bl1 == 0x7ffffff1) STAMP(59);   // (forces the wait for the column extents between stamps 50 and 52)
+  STAMP(52);
+#endif
+#endif
+  const bool bbuf = brun && a.bbytes != 0u;
+  if (bbuf) {
+    // The tile through ONE buffer resource over the operand's values: a thread's two columns are 32-bit offsets, a row outside a
+    // column's run gets an offset beyond the buffer and reads as 0.0 -- three vector instructions and the load per element,
+    // no branch, no 64-bit address (the prologue is bound by the instructions it issues, profiles/README.md round 6)
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.brun_val), 0, a.bbytes, 0x00020000);
+    constexpr unsigned BOOB = 0xffffe000u;            // (+ 256 (BCH - 1) stays below 2^32 and beyond bbytes)
+    const int rr = kmin + (tid >> 3);                 // chunk u: row rr + (NT / 8) u
+    const bool v0 = bl0 >= bf0, v1 = bl1 >= bf1;
+    const unsigned t0 = v0 ? (unsigned)(rr - bf0) : 0x40000000u, s0 = v0 ? (unsigned)(bl0 - bf0) : 0u;
+    const unsigned t1 = v1 ? (unsigned)(rr - bf1) : 0x40000000u, s1 = v1 ? (unsigned)(bl1 - bf1) : 0u;
+    const unsigned o0 = bo0 + (unsigned)rr * 8u, o1 = bo1 + (unsigned)rr * 8u;
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) {
+      const unsigned du = (unsigned)(u * (NT / 8));
+      btmp[u].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(brsrc, (t0 + du <= s0 ? o0 : BOOB) + 8u * du, 0, 0));
+      btmp[u].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(brsrc, (t1 + du <= s1 ? o1 : BOOB) + 8u * du, 0, 0));
+    }
+    if constexpr (EPI != 0) {
+      if (want_prod) {   // (rows beyond the k range hold no value of the tile: any count will do there)
+        const int32_t* __restrict__ pc = prod_count;
+        const int rmax = kmin + kn - 1;
+#pragma unroll
+        for (int u = 0; u < BCH; ++u) bcnt[u] = pc ? pc[min(rr + u * (NT / 8), rmax)] : 1;
+      } else {
+#pragma unroll
+        for (int u = 0; u < BCH; ++u) bcnt[u] = 0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) {
+      const int i = tid + u * NT;
+      if (brun) btmp[u] = brun_load(i);
+      else btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
+#ifdef NTP_ABL_NOBLOAD
+      if constexpr (EPI != 0) bcnt[u] = (want_prod && i < kn * 8) ? 1 : 0;
+#else
+      if constexpr (EPI != 0) bcnt[u] = (want_prod && i < kn * 8) ? (prod_count ? prod_count[kmin + (i >> 3)] : 1) : 0;
+#endif
+    }
+  }
+  STAMP(51);
   // (label-aware kernels: the caller's labels of the window's rows are requested with the tile and the records -- not in a
   // round trip of their own behind the barrier -- and stored with them)
   constexpr int LABCH = LAB ? 4 : 0;
@@ -268,10 +341,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
     // one thread per record (all loads independent and in flight together with the tile's), the row range of a k
     // group = min / max over its four records: two quad-permute steps
     const uint4* __restrict__ rp = reinterpret_cast<const uint4*>(a.runs + kmin);
-    for (int i0 = 0; i0 < K4 + 4; i0 += NT) {
-      const int i = i0 + tid;
-      const int ic = min(i, kn - 1);
-      const uint4 r0 = rp[2 * ic], r1 = rp[2 * ic + 1];      // (addr_lo, addr_hi, nbytes, flags), (first8, first, span62, pad)
+    auto build_rec = [&](int i, const uint4 r0, const uint4 r1) {   // r0 = (addr_lo, addr_hi, nbytes, flags), r1 = (first8, first, span62, pad)
       STAMP(57);
       if (r0.z + r1.y == 0x7fffffffu) STAMP(59);
       STAMP(58);
@@ -302,6 +372,17 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
           grmax[i >> 2] = rmax;
         }
       }
+    };
+#ifndef NTP_TILE_NO_RECFIRST
+#pragma unroll
+    for (int u = 0; u < RCH; ++u)
+      if (u * NT < K4 + 4) build_rec(u * NT + tid, rh0[u], rh1[u]);
+    for (int i0 = RCH * NT; i0 < K4 + 4; i0 += NT) {
+#else
+    for (int i0 = 0; i0 < K4 + 4; i0 += NT) {
+#endif
+      const int ic = min(i0 + tid, kn - 1);
+      build_rec(i0 + tid, rp[2 * ic], rp[2 * ic + 1]);
     }
   }
   STAMP(60);
@@ -867,6 +948,7 @@ void launch_spgemm_tile(const TileLaunch& L) {
   a.tmax = (L.max_w + trows - 1) / trows;
   if (L.fz) a.fzv = *static_cast<const SlabFuseArgs*>(L.fz);   // (a HOST copy: it travels with the kernel arguments)
   a.brun_first = L.brun_first; a.brun_last = L.brun_last; a.brun_off = L.brun_off; a.brun_val = L.brun_val;
+  a.bbytes = (options().tile_bbuf != 0 && L.brun_val && L.bbytes > 0 && L.bbytes < 0xffffe000ull) ? (uint32_t)L.bbytes : 0u;
   static DevBuf<double>* zeros = nullptr;   // (never freed: lives as long as the library)
   if (!zeros) {
     zeros = new DevBuf<double>(8);

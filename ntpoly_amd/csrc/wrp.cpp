@@ -174,6 +174,7 @@ void ntpoly_amd_set_option(const char* name, const int* value) {
   else if (n == "exchange_ahead") options().exchange_ahead = *value;
   else if (n == "plan_fused") options().plan_fused = *value;
   else if (n == "tile_off32") options().tile_off32 = *value;
+  else if (n == "tile_bbuf") options().tile_bbuf = *value;
   else if (n == "ghash_mfma") options().ghash_mfma = *value;
   else if (n == "block_unfused") options().block_unfused = *value;
   else if (n == "block_match") options().block_match = *value;
@@ -203,6 +204,7 @@ int ntpoly_amd_get_option(const char* name) {
   if (n == "exchange_ahead") return options().exchange_ahead;
   if (n == "plan_fused") return options().plan_fused;
   if (n == "tile_off32") return options().tile_off32;
+  if (n == "tile_bbuf") return options().tile_bbuf;
   if (n == "ghash_mfma") return options().ghash_mfma;
   if (n == "block_unfused") return options().block_unfused;
   if (n == "block_match") return options().block_match;

@@ -24,6 +24,7 @@ for blk, w, pro, loopend, bar, tiles in rows[: 4 * nw]:
 pro = np.array([r[2] for r in rows]); le = np.array([r[3] for r in rows]); bar = np.array([r[4] for r in rows])
 fill = np.array([t[1] for r in rows for t in r[5]]); loop = np.array([t[2] for r in rows for t in r[5]]); epi = np.array([t[3] for r in rows for t in r[5]])
 print("prologue phases (B copy issued, records, group ranges, tile ranges):", [float((a[:, :nw, i] - a[:, :nw, 0])[a[:, :nw, 0] > 0].mean()) for i in (56, 57, 58, 60, 61, 62, 63)])
+print("records requested / tile requested (stamps 50, 52 = the block's column extents have arrived, 51):", [float((a[:, :nw, i] - a[:, :nw, 0])[(a[:, :nw, 0] > 0) & (a[:, :nw, i] > 0)].mean()) if ((a[:, :nw, 0] > 0) & (a[:, :nw, i] > 0)).any() else None for i in (50, 52, 51)])
 end = a[:, :nw, 55]; b3 = a[:, :nw, 3]
 print("end-of-block phase (after the barrier): %.0f" % float((end - b3)[(end > 0) & (b3 > 0)].mean()))
 print("mean: prologue %.0f, tiles done %.0f, barrier %.0f | per tile fill %.0f loop %.0f epilogue %.0f (n=%d)" % (
