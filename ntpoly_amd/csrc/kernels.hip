@@ -4511,7 +4511,7 @@ bool slab_step(DevMat& X, SlabFusion& fu, double threshold, bool dense_rule, con
     tl.bblk = in.tiles.p; tl.blk_boff = in.tile_off.p;
     if (in.tiles.p == nullptr || in.tile_off.p == nullptr) {   // (the iterate carries runs only: the right operand from its runs)
       tl.bblk = nullptr; tl.blk_boff = nullptr;
-      tl.brun_first = in.first.p; tl.brun_last = in.last.p; tl.brun_off = in.off.p; tl.brun_val = in.val.p; tl.bbytes = in.val.n * sizeof(double);
+      tl.brun_first = in.first.p; tl.brun_last = in.last.p; tl.brun_off = in.off.p; tl.brun_val = in.val.p; tl.bbytes = in.val.n * sizeof(double); tl.brun_pad = in.row_pad;
     }
     tl.blk_kmin = blk_kmin.p; tl.blk_kn = blk_kn.p; tl.blk_lo = blk_lo.p;
     tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p; tl.out_val = oval.p; tl.count = count.p;
@@ -6681,7 +6681,7 @@ bool slab_multiply(const DevMat& A, const DevMat& B, DevMat& C, double alpha, do
     tl.bblk = fb.tiles.p; tl.blk_boff = fb.tile_off.p;
   } else {
     tl.bblk = fb.val.p; tl.blk_boff = nullptr;
-    tl.brun_first = fb.first.p; tl.brun_last = fb.last.p; tl.brun_off = fb.off.p; tl.brun_val = fb.val.p; tl.bbytes = fb.val.n * sizeof(double);
+    tl.brun_first = fb.first.p; tl.brun_last = fb.last.p; tl.brun_off = fb.off.p; tl.brun_val = fb.val.p; tl.bbytes = fb.val.n * sizeof(double); tl.brun_pad = fb.row_pad;
   }
   tl.blk_kmin = P.blk_kmin.p; tl.blk_kn = P.blk_kn.p; tl.blk_lo = P.blk_lo.p;
   tl.blk_w = P.blk_w.p; tl.blk_toff = P.blk_toff.p; tl.out_val = fo->val.p; tl.count = fo->count.p;
@@ -6856,7 +6856,7 @@ bool slab_multiply_c(const DevMat& A, const DevMat& B, DevMat& C, double alpha, 
   TileLaunch tl;
   tl.runs = reinterpret_cast<const SlabRun*>(runs.p);
   tl.bblk = fb.val.p; tl.blk_boff = nullptr;
-  tl.brun_first = fb.first.p; tl.brun_last = fb.last.p; tl.brun_off = fb.off.p; tl.brun_val = fb.val.p; tl.bbytes = fb.val.n * sizeof(double);
+  tl.brun_first = fb.first.p; tl.brun_last = fb.last.p; tl.brun_off = fb.off.p; tl.brun_val = fb.val.p; tl.bbytes = fb.val.n * sizeof(double); tl.brun_pad = fb.row_pad;
   tl.blk_kmin = blk_kmin.p; tl.blk_kn = blk_kn.p; tl.blk_lo = blk_lo.p; tl.blk_w = blk_w.p; tl.blk_toff = blk_toff.p;
   tl.out_val = fo->val.p; tl.count = fo->count.p; tl.ofirst = fo->first.p; tl.olast = fo->last.p; tl.ooff = fo->off.p;
   tl.alpha = alpha; tl.threshold = threshold; tl.dense_rule = dense_rule ? 1 : 0; tl.ncols = n; tl.nblocks = snb;

@@ -86,7 +86,7 @@ struct EngineOptions {
   int panel_sessions = 1;      // slab sessions (TRS4, sign, inverse, square roots, polynomials ...) on more than one rank: the loops' matrices stay in slab form as column panels, a product exchanges the runs of the left operand's halo (psmatrix.cpp panel_slab_multiply); 0: compressed columns across ranks
   int ghash_mfma = 1;          // grouped LDS-hash SpGEMM, real operands, FMA arithmetic: the products of a phase (four steps) as ONE v_mfma_f64_16x16x4_f64 per tile of 16 slots x 16 columns instead of 64 vector FMAs -- the same chain of fma() over ascending k, bit for bit; 0: vector units
   int tile_off32 = 1;          // MFMA tile kernel: the runs of the left operand read through a buffer resource with 32-bit offsets where they lie in ONE allocation below 4 GB (no halo): lanes outside a run get an out-of-range offset and the bounds check returns 0.0 -- four vector instructions per run load instead of seven; 0: 64-bit addresses everywhere
-  int tile_bbuf = 1;           // MFMA tile kernel: the multiplier tile of a block read from the runs of its columns through a buffer resource (operand below 4 GB): a row outside a run reads as 0.0 by the bounds check -- no branch and no 64-bit address per element (the block prologue is bound by the instructions it issues); 0: per-element address selection
+  int tile_bbuf = 2;           // MFMA tile kernel: the multiplier tile of a block read from the runs of its columns through a buffer resource (operand below 4 GB): a row outside a run reads as 0.0 by the bounds check -- no branch and no 64-bit address per element (1); 2 (default): as PAIRS of rows, a wave per group of columns, where the operand's slots are padded to even rows -- a third of the requests; 0: per-element address selection
   int plan_fused = 1;          // the maxima and prefix sums of a slab step's plan in ONE launch (k_slab_offsets: every workgroup sums what lies before its part itself) instead of four to seven; 0: separate launches
   int exchange_ahead = 1;      // panel steps across ranks: a step prepares the NEXT step's exchange (extents all-gathered, counts, plan) from its result and reads it back with its own totals -- one host round trip per panel step (psmatrix.cpp PanelExchange); 0: two
   int band_scope = 1;          // solvers on SEVERAL ranks, FMA arithmetic: an operand without run structure is searched for a hidden band once per solve, the operands are redistributed in the recovered order, the results carried back (band_scope.cpp).  2: in unfused arithmetic too (the results are then the reference's under its load balancer with that permutation, not its bits on the caller's labels); 0: never

@@ -84,7 +84,13 @@ struct alignas(16) TileRec {
 #define NTP_TILE_PF 6
 #endif
 constexpr int TILE_PF = NTP_TILE_PF;           // run loads (k groups) in flight per wave; a multiple of 3
-constexpr int TILE_RPAD = 4, TILE_BPAD = 0;   // one group of empty records behind the last (the pipeline's look-ahead is clamped to it; OFF32: see the loop)
+constexpr int TILE_RPAD = 4;   // one group of empty records behind the last (the pipeline's look-ahead is clamped to it; OFF32: see the loop)
+// The multiplier tile in LDS: row pitch 17 with one spare row in front and one behind where the tile is read as pairs of rows (a
+// wave then writes consecutive rows of ONE column: at pitch 16 they would all fall on two banks; the pairs start at an even row).
+// Label-aware instantiations keep pitch 16 and the element-wise paths: with the labels of the window's rows in LDS as well, the
+// wider tile would cost them the third resident workgroup at the headline's geometry.
+__host__ __device__ constexpr int tile_bp(bool lab) { return lab ? 16 : 17; }
+__host__ __device__ constexpr int tile_bpad(bool lab) { return lab ? 0 : 2; }
 // an element of X whose fate depends on the last kept row of the product column (decided when the block is done)
 struct alignas(16) TileDefer {
   int32_t r, jj, prow, pad;
@@ -114,6 +120,7 @@ struct TileArgs {
   const int32_t *brun_first, *brun_last;
   const int64_t* brun_off;
   const double* brun_val;
+  int bpair;            // (with bbytes) the runs sit in zero-padded slots aligned to an even number of rows: the tile is read as pairs of rows, a wave per group of columns
   uint32_t bbytes;      // > 0: the runs brun_* lie in [brun_val, brun_val + bbytes), below 4 GB - 8 KB: the multiplier tile is read through a buffer resource
   const double* zero;   // 16 bytes of zeros: where the lanes outside a run load from
   // OFF32 instantiations: every run of A lies in [abase, abase + abytes), abytes < 4 GB -- the runs are read through a buffer
@@ -133,7 +140,7 @@ struct TileArgs {
 
 // (lab_rows: label-aware instantiations keep the caller's labels of the window's rows in LDS)
 __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax, int lab_rows = 0) {
-  return (size_t)lab_rows * 4 + (size_t)(k4max + TILE_BPAD) * 16 * 8 + (size_t)(k4max + TILE_RPAD) * sizeof(TileRec) + (size_t)tmax * 4 + (size_t)(k4max / 4 + 1) * 8 + 16 + TILE_DEFER * sizeof(TileDefer) + 16 * 5 * 4 +
+  return (size_t)lab_rows * 4 + (size_t)(k4max + tile_bpad(lab_rows > 0)) * tile_bp(lab_rows > 0) * 8 + (size_t)(k4max + TILE_RPAD) * sizeof(TileRec) + (size_t)tmax * 4 + (size_t)(k4max / 4 + 1) * 8 + 16 + TILE_DEFER * sizeof(TileDefer) + 16 * 5 * 4 +
          2 * 8 * 8 + 64;
 }
 
@@ -147,9 +154,11 @@ template <int EPI, int TILE_NW, int R, bool LAB, bool OFF32>
 #ifdef NTP_TILE_WPE3
 __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((((EPI == 0 || !LAB) && R <= 2) && TILE_NW != 4) ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
 #else
-__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(((EPI == 0 || !LAB) && R <= 2) ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
+__global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R <= 2 ? 4 : 3, 8))) void k_spgemm_tile(const TileArgs a) {
 #endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool LABK = LAB && EPI != 0;   // (what the launcher sizes the LDS by: labels of the window's rows)
+  constexpr int BP = tile_bp(LABK), BPAD = tile_bpad(LABK);
   const int b = xcd_block(a.nblocks);
   if (b < 0) return;
   const int tid = threadIdx.x, wave = uni_i32(tid / WAVE), lane = lane_id();
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   int bf0 = INT_MAX, bl0 = -1, bf1 = INT_MAX, bl1 = -1;
   const double *bp0 = nullptr, *bp1 = nullptr;
   unsigned bo0 = 0u, bo1 = 0u;   // (bbytes: byte offset of the hypothetical row 0 of the column's run in the buffer, modulo 2^32)
-  if (brun) {   // (EPI 0: the slab algebra's right operand; EPI 1 / 2: the iterate itself -- its runs are the kernel's left operand already)
+  auto thread_extents = [&]() {   // (a thread's column pair: the paths that read the tile element by element)
     const int c0 = b * SLAB_J + 2 * (tid & 7);
     if (c0 < a.ncols) {
       bf0 = a.brun_first[c0]; bl0 = a.brun_last[c0];
@@ -175,7 +184,24 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       bp1 = a.brun_val + (o - bf1);
       bo1 = ((unsigned)o - (unsigned)bf1) * 8u;
     }
-  }
+  };
+  // (pairs of rows: a wave reads CPW whole columns -- their extents are wave-uniform: scalar loads)
+  constexpr bool PAIR_OK = (TILE_NW == 4 || TILE_NW == 8) && BPAD == 2;
+  constexpr int CPW = PAIR_OK ? SLAB_J / TILE_NW : 1;
+  [[maybe_unused]] int cbf[CPW], cbl[CPW];
+  [[maybe_unused]] unsigned cbo[CPW];
+  const bool bpair = PAIR_OK && brun && a.bbytes != 0u && a.bpair != 0;
+  if (bpair) {
+#pragma unroll
+    for (int m = 0; m < CPW; ++m) {
+      const int c = b * SLAB_J + CPW * wave + m;
+      cbf[m] = INT_MAX; cbl[m] = -1; cbo[m] = 0u;
+      if (c < a.ncols) {
+        cbf[m] = a.brun_first[c]; cbl[m] = a.brun_last[c];
+        cbo[m] = ((unsigned)a.brun_off[c] - (unsigned)cbf[m]) * 8u;
+      }
+    }
+  } else if (brun) thread_extents();   // (EPI 0: the slab algebra's right operand; EPI 1 / 2: the iterate itself -- its runs are the kernel's left operand already)
   // (what the fused epilogue needs of this lane's column -- extents and offsets of D and X -- depends on the block's number only:
   // requested here with the plan's scalars, used behind the barrier.  Loaded there, the test "does X fit the window" made every
   // wave wait for a memory round trip between the barrier and its first tile)
@@ -214,8 +240,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   if (tid == 0 && a.blkdur) a.blkdur[4 * b] = __builtin_amdgcn_s_memtime();
 #endif
   // ---- LDS
-  double* Bs = reinterpret_cast<double*>(smem);                                    // [k4max][16]
-  TileRec* recs = reinterpret_cast<TileRec*>(Bs + (size_t)(a.k4max + TILE_BPAD) * 16);   // [k4max + TILE_RPAD]
+  double* Bs = reinterpret_cast<double*>(smem) + (BPAD / 2) * BP;                  // [-1 .. k4max][BP] (BPAD 2): row k - kmin, column j at Bs[(k - kmin) BP + j]
+  TileRec* recs = reinterpret_cast<TileRec*>(reinterpret_cast<double*>(smem) + (size_t)(a.k4max + BPAD) * BP);   // [k4max + TILE_RPAD]
   int* grmin = reinterpret_cast<int*>(recs + a.k4max + TILE_RPAD);                 // [k4max / 4 + 1]: first / last row any
   int* grmax = grmin + (a.k4max / 4 + 1);                                          // column of a k group reaches
   unsigned* colmask = reinterpret_cast<unsigned*>(grmax + (a.k4max / 4 + 1));      // [tmax]
@@ -239,7 +265,6 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   if (kn > 0 && w > 0 && tbase >= 0) STAMP(56);
   constexpr int NT = TILE_NW * WAVE, BCH = 3072 / NT;   // (in flight together: the tile of a k range of 384, 48 KB)
   const double2* __restrict__ bsrc = reinterpret_cast<const double2*>(a.bblk + (a.blk_boff ? a.blk_boff[b] : 0));
-  double2* bdst = reinterpret_cast<double2*>(Bs);
   double2 btmp[BCH];
   // (the multiplier tile from the runs of the block's columns: a thread always serves the same column pair -- NT is a
   // multiple of 8 -- and consecutive rows of a column go to threads 8 apart)
@@ -285,8 +310,43 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   STAMP(52);
 #endif
 #endif
-  const bool bbuf = brun && a.bbytes != 0u;
-  if (bbuf) {
+  const int bpath = (brun && a.bbytes != 0u) ? ((bpair && K4 + 2 <= 384) ? 2 : 1) : 0;
+  if (bpath != 2 && bpair) thread_extents();   // (a k range beyond three requests of 128 rows: element by element after all)
+  [[maybe_unused]] int pcnt0[3] = {0, 0, 0}, pcnt1[3] = {0, 0, 0};
+  const int ke = kmin & ~1, pr = ke + 2 * lane;   // pairs: request u of a column holds rows pr + 128 u, + 1
+  if (bpath == 2) {
+    // Pairs of rows, a wave per CPW columns: 64 lanes x 16 bytes = 128 consecutive rows of ONE column per request -- twelve
+    // requests per wave for the tile and six for the counts, where the element-wise paths issue 24 + 12 per THREAD (a CU's
+    // request pipeline is what a block's prologue waits for, profiles/README.md round 6).  The slots are zero-padded to even
+    // rows on both sides (bpair), so a pair that straddles an end of its run reads a stored zero.
+    if constexpr (PAIR_OK) {
+      const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.brun_val), 0, a.bbytes, 0x00020000);
+      constexpr unsigned BOOB = 0xffffe000u;
+#pragma unroll
+      for (int m = 0; m < CPW; ++m) {
+        const bool cv = cbl[m] >= cbf[m];
+        const unsigned tb = cv ? (unsigned)(pr + 1 - cbf[m]) : 0x40000000u, sp = cv ? (unsigned)(cbl[m] - cbf[m] + 1) : 0u;
+        const unsigned ob = cbo[m] + (unsigned)pr * 8u;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const v2d v = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (tb + 128u * u <= sp ? ob : BOOB) + 1024u * u, 0, 0));
+          btmp[m * 3 + u].x = v[0];
+          btmp[m * 3 + u].y = v[1];
+        }
+      }
+      if constexpr (EPI != 0) {
+        if (want_prod) {   // (rows outside the k range hold no value of the tile: any count will do there)
+          const int32_t* __restrict__ pc = prod_count;
+          const int rmax = kmin + kn - 1;
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            pcnt0[u] = pc ? pc[min(max(pr + 128 * u, kmin), rmax)] : 1;
+            pcnt1[u] = pc ? pc[min(pr + 128 * u + 1, rmax)] : 1;
+          }
+        }
+      }
+    }
+  } else if (bpath == 1) {
     // The tile through ONE buffer resource over the operand's values: a thread's two columns are 32-bit offsets, a row outside a
     // column's run gets an offset beyond the buffer and reads as 0.0 -- three vector instructions and the load per element,
     // no branch, no 64-bit address (the prologue is bound by the instructions it issues, profiles/README.md round 6)
@@ -387,15 +447,35 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
   }
   STAMP(60);
   [[maybe_unused]] long long prod_p = 0;
+  if (bpath == 2) {
+    if constexpr (PAIR_OK) {
 #pragma unroll
-  for (int u = 0; u < BCH; ++u) {
-    const int i = tid + u * NT;
-    if (i < K4 * 8) bdst[i] = btmp[u];
-    if constexpr (EPI != 0) prod_p += (long long)(((btmp[u].x != 0.0) ? 1 : 0) + ((btmp[u].y != 0.0) ? 1 : 0)) * bcnt[u];
+      for (int m = 0; m < CPW; ++m) {
+        double* const bcol = Bs + (pr - kmin) * BP + CPW * wave + m;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (pr - kmin + 128 * u < K4) {   // (rows -1 and K4: the spare rows)
+            bcol[128 * u * BP] = btmp[m * 3 + u].x;
+            bcol[(128 * u + 1) * BP] = btmp[m * 3 + u].y;
+          }
+          if constexpr (EPI != 0)
+            prod_p += (long long)((btmp[m * 3 + u].x != 0.0) ? pcnt0[u] : 0) + (long long)((btmp[m * 3 + u].y != 0.0) ? pcnt1[u] : 0);
+        }
+      }
+    }
+  }
+  else {
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) {
+      const int i = tid + u * NT;
+      if (i < K4 * 8) { Bs[(i >> 3) * BP + 2 * (i & 7)] = btmp[u].x; Bs[(i >> 3) * BP + 2 * (i & 7) + 1] = btmp[u].y; }
+      if constexpr (EPI != 0) prod_p += (long long)(((btmp[u].x != 0.0) ? 1 : 0) + ((btmp[u].y != 0.0) ? 1 : 0)) * bcnt[u];
+    }
   }
   for (int i = tid + BCH * NT; i < K4 * 8; i += NT) {
     const double2 v = brun ? brun_load(i) : (i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0));
-    bdst[i] = v;
+    Bs[(i >> 3) * BP + 2 * (i & 7)] = v.x;
+    Bs[(i >> 3) * BP + 2 * (i & 7) + 1] = v.y;
     if constexpr (EPI != 0) {
       if (want_prod && i < kn * 8)
         prod_p += (long long)(((v.x != 0.0) ? 1 : 0) + ((v.y != 0.0) ? 1 : 0)) * (prod_count ? prod_count[kmin + (i >> 3)] : 1);
@@ -542,7 +622,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       const int rl = r0 + R * jj;                  // A operand: rows rl .. rl + R - 1, column 4 g + q
       [[maybe_unused]] const unsigned long long r8 = (unsigned long long)((long long)rl * 8);
       const uint4* __restrict__ rq = reinterpret_cast<const uint4*>(recs) + q;     // record of group g: rq[4 g]
-      const double* __restrict__ bq = Bs + lane;                                   // multiplier of group g: bq[64 g]
+      const double* __restrict__ bq = Bs + q * BP + jj;                            // multiplier of group g: bq[4 BP g]
 #ifdef NTP_TILE_ABL_NOLOAD
       const unsigned long long abl_base = reinterpret_cast<unsigned long long>(a.out_val) & ~0x3fffull;   // (any mapped memory)
 #endif
@@ -583,8 +663,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
       double bb[3];
 #pragma unroll
       for (int u = 0; u < TILE_PF; ++u) ring[u] = run_load(rq[4 * gi(g0 + u)]);
-      bb[0] = bq[64 * g0];
-      bb[1] = bq[64 * bi(g0 + 1)];
+      bb[0] = bq[4 * BP * g0];
+      bb[1] = bq[4 * BP * bi(g0 + 1)];
       bb[2] = 0.0;
       uint4 raw = rq[4 * gi(g0 + TILE_PF)];
       int g = g0;
@@ -599,7 +679,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
           for (int m = 0; m < R; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(rv_get<R>(ring[u], m), bb[u % 3], acc[m], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           ring[u] = run_load(raw);
-          bb[(u + 2) % 3] = bq[64 * bi(g + u + 2)];
+          bb[(u + 2) % 3] = bq[4 * BP * bi(g + u + 2)];
           raw = raw_n;
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -608,7 +688,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu((
 #pragma unroll
       for (int u = 0; u < TILE_PF - 1; ++u) {
         if (g + u <= g1) {
-          const double bt = bq[64 * (g + u)];
+          const double bt = bq[4 * BP * (g + u)];
 #pragma unroll
           for (int m = 0; m < R; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(rv_get<R>(ring[u], m), bt, acc[m], 0, 0, 0);
         }
@@ -932,7 +1012,7 @@ int tile_rows() {
 
 bool spgemm_tile_fits(int max_kn, int max_w) {
   const int k4 = std::max(8, (max_kn + 3) & ~3), tm = (max_w + 15) >> 4;
-  return max_kn > 0 && max_w > 0 && tile_lds_bytes(k4, tm, 16 * tm + 64) <= 150 * 1024;   // (with the labels of a label-aware step)
+  return max_kn > 0 && max_w > 0 && std::max(tile_lds_bytes(k4, tm, 16 * tm + 64), tile_lds_bytes(k4, tm, 0)) <= 150 * 1024;   // (with the labels of a label-aware step)
 }
 
 void launch_spgemm_tile(const TileLaunch& L) {
@@ -949,6 +1029,7 @@ void launch_spgemm_tile(const TileLaunch& L) {
   if (L.fz) a.fzv = *static_cast<const SlabFuseArgs*>(L.fz);   // (a HOST copy: it travels with the kernel arguments)
   a.brun_first = L.brun_first; a.brun_last = L.brun_last; a.brun_off = L.brun_off; a.brun_val = L.brun_val;
   a.bbytes = (options().tile_bbuf != 0 && L.brun_val && L.bbytes > 0 && L.bbytes < 0xffffe000ull) ? (uint32_t)L.bbytes : 0u;
+  a.bpair = (a.bbytes != 0u && options().tile_bbuf >= 2 && L.brun_pad >= 2 && L.brun_pad % 2 == 0) ? 1 : 0;
   static DevBuf<double>* zeros = nullptr;   // (never freed: lives as long as the library)
   if (!zeros) {
     zeros = new DevBuf<double>(8);

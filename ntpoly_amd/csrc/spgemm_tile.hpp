@@ -37,6 +37,7 @@ struct TileLaunch {
   const int64_t* brun_off = nullptr;
   const double* brun_val = nullptr;
   size_t bbytes = 0;                 // optional: the allocation behind brun_val -- below 4 GB the multiplier tile is read through a buffer resource (option tile_bbuf)
+  int brun_pad = 1;                  // SlabForm::row_pad of the operand behind brun_*: even -- the tile is read as pairs of rows (16-byte requests, a wave per group of columns)
   // optional: ONE allocation [abase, abase + abytes) that holds every run `runs` points into (no halo): below 4 GB the kernel
   // reads the runs through a buffer resource with 32-bit offsets (option tile_off32)
   const void* abase = nullptr;
