@@ -96,7 +96,7 @@ struct alignas(16) TileDefer {
   int32_t r, jj, prow, pad;
   double o, d;
 };
-constexpr int TILE_DEFER = 64;       // deferred elements per block (more: the step is refused)
+constexpr int TILE_DEFER = 48;       // deferred elements per block (more: the step is refused)
 
 
 struct TileArgs {
@@ -141,7 +141,7 @@ struct TileArgs {
 // (lab_rows: label-aware instantiations keep the caller's labels of the window's rows in LDS)
 __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax, int lab_rows = 0) {
   return (size_t)lab_rows * 4 + (size_t)(k4max + tile_bpad(lab_rows > 0)) * tile_bp(lab_rows > 0) * 8 + (size_t)(k4max + TILE_RPAD) * sizeof(TileRec) + (size_t)tmax * 4 + (size_t)(k4max / 4 + 1) * 8 + 16 + TILE_DEFER * sizeof(TileDefer) + 16 * 5 * 4 +
-         2 * 8 * 8 + 64;
+         2 * 8 * 8 + (size_t)tmax * 16 + 8 + 64;
 }
 
 #ifdef NTP_TILE_STAMPS
@@ -252,8 +252,9 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
   int* col_pmax = col_last + 16;
   int* col_plast = col_pmax + 16;
   double* red = reinterpret_cast<double*>(col_plast + 16);                         // [2 * 8]
-  int* misc = reinterpret_cast<int*>(red + 2 * 8);                           // [0] deferred, [1] product entries, [2..3] products
-  [[maybe_unused]] int* labs = misc + 4;                                     // LAB: [tmax * 16 R] the caller's label of every row of the window
+  double* tred = red + 2 * 8;                                                // [2 * tmax]: every tile's share of the two sums (EPI != 0)
+  int* misc = reinterpret_cast<int*>(tred + 2 * a.tmax);                     // [0] deferred, [1] product entries, [2..3] products, [4] tiles taken
+  [[maybe_unused]] int* labs = misc + 6;                                     // LAB: [tmax * 16 R] the caller's label of every row of the window
 
   const int KG = (kn + 3) >> 2, K4 = KG * 4;
   constexpr int TROWS = 16 * R;   // rows of a tile: R matrix instructions per k group (the window is a multiple, the host sees to it)
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
   const int bpath = (brun && a.bbytes != 0u) ? ((bpair && K4 + 2 <= 384) ? 2 : 1) : 0;
   if (bpath != 2 && bpair) thread_extents();   // (a k range beyond three requests of 128 rows: element by element after all)
   [[maybe_unused]] int pcnt0[3] = {0, 0, 0}, pcnt1[3] = {0, 0, 0};
-  const int ke = kmin & ~1, pr = ke + 2 * lane;   // pairs: request u of a column holds rows pr + 128 u, + 1
+  const int ke = kmin & ~1, pair_r = ke + 2 * lane;   // pairs: request u of a column holds rows pair_r + 128 u, + 1
   if (bpath == 2) {
     // Pairs of rows, a wave per CPW columns: 64 lanes x 16 bytes = 128 consecutive rows of ONE column per request -- twelve
     // requests per wave for the tile and six for the counts, where the element-wise paths issue 24 + 12 per THREAD (a CU's
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
 #pragma unroll
       for (int m = 0; m < CPW; ++m) {
         const bool cv = cbl[m] >= cbf[m];
-        const unsigned tb = cv ? (unsigned)(pr + 1 - cbf[m]) : 0x40000000u, sp = cv ? (unsigned)(cbl[m] - cbf[m] + 1) : 0u;
-        const unsigned ob = cbo[m] + (unsigned)pr * 8u;
+        const unsigned tb = cv ? (unsigned)(pair_r + 1 - cbf[m]) : 0x40000000u, sp = cv ? (unsigned)(cbl[m] - cbf[m] + 1) : 0u;
+        const unsigned ob = cbo[m] + (unsigned)pair_r * 8u;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const v2d v = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (tb + 128u * u <= sp ? ob : BOOB) + 1024u * u, 0, 0));
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
           const int rmax = kmin + kn - 1;
 #pragma unroll
           for (int u = 0; u < 3; ++u) {
-            pcnt0[u] = pc ? pc[min(max(pr + 128 * u, kmin), rmax)] : 1;
-            pcnt1[u] = pc ? pc[min(pr + 128 * u + 1, rmax)] : 1;
+            pcnt0[u] = pc ? pc[min(max(pair_r + 128 * u, kmin), rmax)] : 1;
+            pcnt1[u] = pc ? pc[min(pair_r + 128 * u + 1, rmax)] : 1;
           }
         }
       }
@@ -451,10 +452,10 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
     if constexpr (PAIR_OK) {
 #pragma unroll
       for (int m = 0; m < CPW; ++m) {
-        double* const bcol = Bs + (pr - kmin) * BP + CPW * wave + m;
+        double* const bcol = Bs + (pair_r - kmin) * BP + CPW * wave + m;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-          if (pr - kmin + 128 * u < K4) {   // (rows -1 and K4: the spare rows)
+          if (pair_r - kmin + 128 * u < K4) {   // (rows -1 and K4: the spare rows)
             bcol[128 * u * BP] = btmp[m * 3 + u].x;
             bcol[(128 * u + 1) * BP] = btmp[m * 3 + u].y;
           }
@@ -487,7 +488,10 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
     for (int u = 0; u < LABCH; ++u)
       if (tid + u * NT < T * TROWS) labs[tid + u * NT] = labtmp[u];
   }
-  for (int t = tid; t < T; t += NT) colmask[t] = 0u;
+  for (int t = tid; t < T; t += NT) {
+    colmask[t] = 0u;
+    if constexpr (EPI != 0) { tred[2 * t] = 0.0; tred[2 * t + 1] = 0.0; }
+  }
   if (tid < 16) {
     col_cnt[tid] = 0;
     col_first[tid] = INT_MAX;
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
     col_pmax[tid] = -1;
     col_plast[tid] = -1;
   }
-  if (tid < 4) misc[tid] = 0;
+  if (tid < 6) misc[tid] = 0;
   __syncthreads();
   STAMP(62);
   STAMP(63);
@@ -576,10 +580,22 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
   const int mid = (T - 1) >> 1;
 
   [[maybe_unused]] int sidx = 4;
+#ifdef NTP_TILE_STATIC
   for (int ti = 0;; ++ti) {   // (snake order over the waves: every wave gets tiles from both ends of each round)
     const int ts = ti * TILE_NW + ((ti & 1) ? TILE_NW - 1 - wave : wave);
     if (ti * TILE_NW >= T) break;
     if (ts >= T) continue;
+#else
+  // A wave takes the next tile when it is through with its last (a counter in LDS): the tiles of a window cost between a few
+  // and ~40 slots of the loop, and with a fixed deal the waves reached the block's closing barrier 6 k cycles apart on average.
+  // The two sums stay reproducible: every tile leaves its share in LDS, the block adds them in tile order.
+  for (;;) {
+    int ts = 0;
+    if (lane == 0) ts = atomicAdd(&misc[4], 1);
+    ts = __builtin_amdgcn_readfirstlane(ts);
+    if (ts >= T) break;
+    if constexpr (EPI != 0) { dsum = 0.0; tsum = 0.0; }
+#endif
     STAMP(sidx); ++sidx;   // centre first: the tiles in the middle of the window have the longest k ranges
     const int t = (ts & 1) ? mid + ((ts + 1) >> 1) : mid - (ts >> 1);
     const int r0 = lo + TROWS * t;
@@ -770,6 +786,15 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
           }
         }
         if (lane == 0) colmask[t] = 0xffffu;
+#ifndef NTP_TILE_STATIC
+        {
+          const double td = wave_sum_f64(dsum), tt = wave_sum_f64(tsum);
+          if (lane == 0) {
+            tred[2 * t] = td;
+            tred[2 * t + 1] = tt;
+          }
+        }
+#endif
         STAMP(sidx); ++sidx;
         continue;
       }
@@ -862,10 +887,20 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
       }
     }
     if (lane == 0) colmask[t] = cm;
+#ifndef NTP_TILE_STATIC
+    if constexpr (EPI != 0) {
+      const double td = wave_sum_f64(dsum), tt = wave_sum_f64(tsum);
+      if (lane == 0) {
+        tred[2 * t] = td;
+        tred[2 * t + 1] = tt;
+      }
+    }
+#endif
     STAMP(sidx); ++sidx;
   }
   STAMP(2);
   // ---- the block
+#ifdef NTP_TILE_STATIC
   if constexpr (EPI != 0) {
     dsum = wave_sum_f64(dsum);
     tsum = wave_sum_f64(tsum);
@@ -874,6 +909,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
       red[2 * wave + 1] = tsum;
     }
   }
+#endif
   if (lane == 0 && pn) atomicAdd(&misc[1], pn);
   __syncthreads();
   STAMP(3);
@@ -942,10 +978,17 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
     }
     if (tid == 64) {
       double x = 0.0, y = 0.0;
+#ifdef NTP_TILE_STATIC
       for (int qq = 0; qq < TILE_NW; ++qq) {
         x = __dadd_rn(x, red[2 * qq]);
         y = __dadd_rn(y, red[2 * qq + 1]);
       }
+#else
+      for (int t2 = 0; t2 < T; ++t2) {
+        x = __dadd_rn(x, tred[2 * t2]);
+        y = __dadd_rn(y, tred[2 * t2 + 1]);
+      }
+#endif
       if constexpr (EPI == 2) {   // kept deferred elements, in (row, column) order (ranked above)
         const int nd = min(misc[0], TILE_DEFER);
         int nk = 0;
@@ -1064,7 +1107,7 @@ void launch_spgemm_tile(const TileLaunch& L) {
   // independent blocks: the prologue of one runs under the main loop of the others), eight when only two fit.  (Every
   // default instantiation -- one or two rows per lane -- stays within 128 registers per lane, four waves per SIMD, so two
   // workgroups of eight are resident together; six waves, tried where only three waves fit a SIMD, were slower.)
-  const bool wide = 3 * lds > 160 * 1024;
+  const bool wide = 3 * ((lds + 511) & ~(size_t)511) > 160 * 1024;   // (LDS is granted in units of 512 bytes)
   const int tw = options().tile_waves;
   const int nw = (tw == 4 || tw == 5 || tw == 6 || tw == 8) ? tw : (wide ? 8 : 4);
   auto go = [&](auto epi_tag, auto nw_tag, auto r_tag, auto lab_tag, auto off_tag) {
