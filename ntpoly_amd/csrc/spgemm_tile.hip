@@ -917,6 +917,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
     // the deferred elements: kept (unfiltered) where they lie beyond the last kept entry of the product column.  Only
     // the decision and the column statistics here; the values are stored after the holes have been zeroed (below)
     const int nd = misc[0];
+    if (nd != 0) {   // (block-uniform; no deferred element -- the rule -- and the two barriers below are not entered)
     if (nd > TILE_DEFER) {
       if (tid == 0) atomicOr(a.fzv.flag, 1);
     } else {
@@ -949,6 +950,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
       }
     }
     __syncthreads();
+    }
   }
   // entries, first and last row of every column; where its run and the block's tile rows start
   if (tid < SLAB_J) {
