@@ -244,7 +244,8 @@ def test_round5_options_defaults_and_round_trip():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     defaults = {"plan_fused": 1, "panel_sessions": 1, "block_scope": 1, "band_scope": 1, "exchange_ahead": 1, "block_unfused": 0,
-                "block_match": 0, "tile2": 0}
+                "block_match": 0, "tile2": 0,
+                "tile_off32": 1, "tile_bbuf": 2, "ghash_mfma": 1}   # (round 6)
     code = ("import ntpoly_amd as nt\n"
             "names = %r\n"
             "print(' '.join(str(nt.get_option(k)) for k in names))\n"
