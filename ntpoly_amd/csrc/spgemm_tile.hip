@@ -85,12 +85,12 @@ struct alignas(16) TileRec {
 #endif
 constexpr int TILE_PF = NTP_TILE_PF;           // run loads (k groups) in flight per wave; a multiple of 3
 constexpr int TILE_RPAD = 4;   // one group of empty records behind the last (the pipeline's look-ahead is clamped to it; OFF32: see the loop)
-// The multiplier tile in LDS: row pitch 17 with one spare row in front and one behind where the tile is read as pairs of rows (a
-// wave then writes consecutive rows of ONE column: at pitch 16 they would all fall on two banks; the pairs start at an even row).
-// Label-aware instantiations keep pitch 16 and the element-wise paths: with the labels of the window's rows in LDS as well, the
-// wider tile would cost them the third resident workgroup at the headline's geometry.
-__host__ __device__ constexpr int tile_bp(bool lab) { return lab ? 16 : 17; }
-__host__ __device__ constexpr int tile_bpad(bool lab) { return lab ? 0 : 2; }
+// The multiplier tile in LDS: row pitch 17 with one spare row in front and one behind: the tile is read as pairs of rows, a wave
+// then writes consecutive rows of ONE column (at pitch 16 they would all fall on two banks), and the pairs start at an even row.
+// (Label-aware instantiations kept pitch 16 and the element-wise path while three workgroups of four waves were preferred to two
+// of eight -- with the labels of the window's rows in LDS as well the wider tile cost them the third workgroup.)
+__host__ __device__ constexpr int tile_bp(bool) { return 17; }
+__host__ __device__ constexpr int tile_bpad(bool) { return 2; }
 // an element of X whose fate depends on the last kept row of the product column (decided when the block is done)
 struct alignas(16) TileDefer {
   int32_t r, jj, prow, pad;
@@ -1105,11 +1105,17 @@ void launch_spgemm_tile(const TileLaunch& L) {
   a.blkdur = blkdur->p;
 #endif
   const size_t lds = tile_lds_bytes(a.k4max, a.tmax, (L.labelled && L.epi != 0) ? a.tmax * trows : 0);
-  // waves per workgroup (option tile_waves overrides): four when three or more workgroups fit a CU's LDS (more
-  // independent blocks: the prologue of one runs under the main loop of the others), eight when only two fit.  (Every
-  // default instantiation -- one or two rows per lane -- stays within 128 registers per lane, four waves per SIMD, so two
-  // workgroups of eight are resident together; six waves, tried where only three waves fit a SIMD, were slower.)
-  const bool wide = 3 * ((lds + 511) & ~(size_t)511) > 160 * 1024;   // (LDS is granted in units of 512 bytes)
+  // waves per workgroup (option tile_waves overrides): four when FOUR workgroups fit a CU's LDS (sixteen waves, four per SIMD --
+  // what 128 registers per lane admit -- in four independent blocks: the prologue of one runs under the main loop of the
+  // others), eight when fewer do: two workgroups of eight are again sixteen waves where three of four would be twelve.  (Up to
+  // round 5 three workgroups of four were preferred to two of eight; since a wave takes its tiles from a counter, eight waves
+  // share a window without waiting for one another at its end, and the fourth wave per SIMD pays: headline 683 -> 696
+  // iterations/s, profiles/README.md round 6.  LDS is granted in units of 512 bytes.)
+#ifdef NTP_TILE_WIDE3   // (A/B builds: the rule up to round 5 -- eight waves only where fewer than THREE workgroups of four fit)
+  const bool wide = 3 * ((lds + 511) & ~(size_t)511) > 160 * 1024;
+#else
+  const bool wide = 4 * ((lds + 511) & ~(size_t)511) > 160 * 1024;
+#endif
   const int tw = options().tile_waves;
   const int nw = (tw == 4 || tw == 5 || tw == 6 || tw == 8) ? tw : (wide ? 8 : 4);
   auto go = [&](auto epi_tag, auto nw_tag, auto r_tag, auto lab_tag, auto off_tag) {
