@@ -141,7 +141,7 @@ struct TileArgs {
 // (lab_rows: label-aware instantiations keep the caller's labels of the window's rows in LDS)
 __host__ __device__ inline size_t tile_lds_bytes(int k4max, int tmax, int lab_rows = 0) {
   return (size_t)lab_rows * 4 + (size_t)(k4max + tile_bpad(lab_rows > 0)) * tile_bp(lab_rows > 0) * 8 + (size_t)(k4max + TILE_RPAD) * sizeof(TileRec) + (size_t)tmax * 4 + (size_t)(k4max / 4 + 1) * 8 + 16 + TILE_DEFER * sizeof(TileDefer) + 16 * 5 * 4 +
-         2 * 8 * 8 + (size_t)tmax * 16 + 8 + 64;
+         2 * 8 * 8 + (size_t)tmax * 16 + 8 + (size_t)(k4max + 8) * 4 + 64;
 }
 
 #ifdef NTP_TILE_STAMPS
@@ -205,14 +205,24 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
   // (what the fused epilogue needs of this lane's column -- extents and offsets of D and X -- depends on the block's number only:
   // requested here with the plan's scalars, used behind the barrier.  Loaded there, the test "does X fit the window" made every
   // wave wait for a memory round trip between the barrier and its first tile)
-  [[maybe_unused]] int e_d0 = 0, e_d1 = -1, e_x0 = 0, e_x1 = -1, e_xpl = -1;
-  [[maybe_unused]] int64_t e_doff = 0, e_xoff = 0;
+  // In TWO requests per wave (six before: a request costs a block in its prologue ~400 cycles whatever it carries): lane 16 s + jj
+  // asks for value s of column jj -- dmin, dmax, xmin, xmax in one request, doff / xoff in the other -- and the lanes of a column
+  // exchange them behind the barrier (ds_bpermute).
+  [[maybe_unused]] int e_raw = 0, e_xpl = -1;
+  [[maybe_unused]] int64_t e_raw8 = 0;
   if constexpr (EPI != 0) {
     const int jc0 = min(b * SLAB_J + (tid & 15), a.ncols - 1);
-    e_d0 = a.fzv.dmin[jc0]; e_d1 = a.fzv.dmax[jc0]; e_doff = a.fzv.doff[jc0];
+    const int sel = (tid >> 4) & 3;
     if constexpr (EPI == 2) {
-      e_x0 = a.fzv.xmin[jc0]; e_x1 = a.fzv.xmax[jc0]; e_xoff = a.fzv.xoff[jc0];
+      const int32_t* p4 = sel == 0 ? a.fzv.dmin : sel == 1 ? a.fzv.dmax : sel == 2 ? a.fzv.xmin : a.fzv.xmax;
+      const int64_t* p8 = (sel & 1) ? a.fzv.xoff : a.fzv.doff;
+      e_raw = p4[jc0];
+      e_raw8 = p8[jc0];
       if constexpr (LAB) e_xpl = a.fzv.xplast[jc0];
+    } else {
+      const int32_t* p4 = (sel & 1) ? a.fzv.dmax : a.fzv.dmin;
+      e_raw = p4[jc0];
+      e_raw8 = a.fzv.doff[jc0];
     }
   }
   if (b == 0 && tid == 0) {   // (the end markers of the result's offset arrays)
@@ -254,7 +264,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
   double* red = reinterpret_cast<double*>(col_plast + 16);                         // [2 * 8]
   double* tred = red + 2 * 8;                                                // [2 * tmax]: every tile's share of the two sums (EPI != 0)
   int* misc = reinterpret_cast<int*>(tred + 2 * a.tmax);                     // [0] deferred, [1] product entries, [2..3] products, [4] tiles taken
-  [[maybe_unused]] int* labs = misc + 6;                                     // LAB: [tmax * 16 R] the caller's label of every row of the window
+  [[maybe_unused]] int* cntl = misc + 6 + 1;                                  // [-1 .. k4max + 2]: entries of column kmin + i of the left operand (pair path: the product count)
+  [[maybe_unused]] int* labs = misc + 6 + (a.k4max + 8);                                     // LAB: [tmax * 16 R] the caller's label of every row of the window
 
   const int KG = (kn + 3) >> 2, K4 = KG * 4;
   constexpr int TROWS = 16 * R;   // rows of a tile: R matrix instructions per k group (the window is a multiple, the host sees to it)
@@ -313,7 +324,19 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
 #endif
   const int bpath = (brun && a.bbytes != 0u) ? ((bpair && K4 + 2 <= 384) ? 2 : 1) : 0;
   if (bpath != 2 && bpair) thread_extents();   // (a k range beyond three requests of 128 rows: element by element after all)
-  [[maybe_unused]] int pcnt0[3] = {0, 0, 0}, pcnt1[3] = {0, 0, 0};
+  // (pair path: the entry counts behind the block's product count, ONE request per 64 rows and block -- a thread per row, to LDS
+  // with the records; every wave reads the rows of its pairs behind the barrier.  Requested per wave they were as many requests
+  // as the tile itself)
+  constexpr int CCH = (384 + NT - 1) / NT;
+  [[maybe_unused]] int ctmp[CCH];
+  if constexpr (EPI != 0) {
+    if (bpath == 2 && want_prod) {
+      const int32_t* __restrict__ pc = prod_count;
+      const int rmax = kmin + kn - 1;
+#pragma unroll
+      for (int u = 0; u < CCH; ++u) ctmp[u] = pc ? pc[min(kmin + tid + u * NT, rmax)] : 1;
+    }
+  }
   const int ke = kmin & ~1, pair_r = ke + 2 * lane;   // pairs: request u of a column holds rows pair_r + 128 u, + 1
   if (bpath == 2) {
     // Pairs of rows, a wave per CPW columns: 64 lanes x 16 bytes = 128 consecutive rows of ONE column per request -- twelve
@@ -333,17 +356,6 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
           const v2d v = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (tb + 128u * u <= sp ? ob : BOOB) + 1024u * u, 0, 0));
           btmp[m * 3 + u].x = v[0];
           btmp[m * 3 + u].y = v[1];
-        }
-      }
-      if constexpr (EPI != 0) {
-        if (want_prod) {   // (rows outside the k range hold no value of the tile: any count will do there)
-          const int32_t* __restrict__ pc = prod_count;
-          const int rmax = kmin + kn - 1;
-#pragma unroll
-          for (int u = 0; u < 3; ++u) {
-            pcnt0[u] = pc ? pc[min(max(pair_r + 128 * u, kmin), rmax)] : 1;
-            pcnt1[u] = pc ? pc[min(pair_r + 128 * u + 1, rmax)] : 1;
-          }
         }
       }
     }
@@ -448,8 +460,17 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
   }
   STAMP(60);
   [[maybe_unused]] long long prod_p = 0;
+  [[maybe_unused]] unsigned nzm = 0u;   // pair path: bit 2 (3 m + u) + e: element e of the pair of request u of column m is not zero
   if (bpath == 2) {
     if constexpr (PAIR_OK) {
+      if constexpr (EPI != 0) {
+        if (want_prod) {
+#pragma unroll
+          for (int u = 0; u < CCH; ++u)
+            if (tid + u * NT <= K4) cntl[tid + u * NT] = tid + u * NT < K4 ? ctmp[u] : 0;
+          if (tid == 0) cntl[-1] = 0;
+        }
+      }
 #pragma unroll
       for (int m = 0; m < CPW; ++m) {
         double* const bcol = Bs + (pair_r - kmin) * BP + CPW * wave + m;
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
             bcol[(128 * u + 1) * BP] = btmp[m * 3 + u].y;
           }
           if constexpr (EPI != 0)
-            prod_p += (long long)((btmp[m * 3 + u].x != 0.0) ? pcnt0[u] : 0) + (long long)((btmp[m * 3 + u].y != 0.0) ? pcnt1[u] : 0);
+            nzm |= ((btmp[m * 3 + u].x != 0.0) ? 1u : 0u) << (2 * (m * 3 + u)) | ((btmp[m * 3 + u].y != 0.0) ? 2u : 0u) << (2 * (m * 3 + u));
         }
       }
     }
@@ -505,6 +526,18 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
   STAMP(63);
   if constexpr (EPI != 0) {
     if (want_prod) {
+      if constexpr (PAIR_OK) {
+        if (bpath == 2) {   // (a pair's rows beyond the k range hold zeros: their count is not read -- index K4 is a zero)
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int rho = pair_r - kmin + 128 * u;
+            const int c0 = cntl[min(rho, K4)], c1 = cntl[min(rho + 1, K4)];
+#pragma unroll
+            for (int m = 0; m < CPW; ++m)
+              prod_p += (long long)(((nzm >> (2 * (m * 3 + u))) & 1u) ? c0 : 0) + (long long)(((nzm >> (2 * (m * 3 + u) + 1)) & 1u) ? c1 : 0);
+          }
+        }
+      }
       prod_p = wave_sum_i64(prod_p);
       if (lane == 0 && prod_p) atomicAdd(reinterpret_cast<unsigned long long*>(misc + 2), (unsigned long long)prod_p);
     }
@@ -532,6 +565,15 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
   if constexpr (EPI != 0) {
     // (fzv.tiles == nullptr: the result carries runs only -- the next step builds its multiplier tile from them)
     if (a.fzv.tiles) otile = a.fzv.tiles + (tbase - (int64_t)lo * SLAB_J + jj);   // otile[r * 16] = row r, column jj of the tile
+    // (the values requested at the kernel's top, lane 16 s + jj: see there)
+    const int pj = 4 * jj;
+    auto pull64 = [&](int from, int64_t v) {
+      const int lo32 = __builtin_amdgcn_ds_bpermute(from, (int)(unsigned)(unsigned long long)v);
+      const int hi32 = __builtin_amdgcn_ds_bpermute(from, (int)(unsigned)((unsigned long long)v >> 32));
+      return (int64_t)(((unsigned long long)(unsigned)hi32 << 32) | (unsigned long long)(unsigned)lo32);
+    };
+    const int e_d0 = __builtin_amdgcn_ds_bpermute(pj, e_raw), e_d1 = __builtin_amdgcn_ds_bpermute(pj + 64, e_raw);
+    const int64_t e_doff = EPI == 2 ? pull64(pj, e_raw8) : e_raw8;
     const int d0 = e_d0, d1 = e_d1;
     if (colv && d1 >= d0) {
       df = d0;
@@ -541,6 +583,8 @@ __global__ __launch_bounds__(TILE_NW* WAVE) __attribute__((amdgpu_waves_per_eu(R
     diag = j + a.fzv.col_offset;
     if constexpr (EPI == 2) {
       am = a.fzv.am; bm = a.fzv.bm; thr_m = a.fzv.thr_m;
+      const int e_x0 = __builtin_amdgcn_ds_bpermute(pj + 128, e_raw), e_x1 = __builtin_amdgcn_ds_bpermute(pj + 192, e_raw);
+      const int64_t e_xoff = pull64(pj + 64, e_raw8);
       const int x0 = e_x0, x1 = e_x1;
       if (colv && x1 >= x0) {
         xf = x0;
