@@ -5755,6 +5755,7 @@ void set_scope_labels(const int32_t* lab) { g_scope_labels = lab; }
 const int32_t* scope_labels() { return g_scope_labels; }
 
 void drop_operand_caches() {   // the device memory kept between solves (expanded D, D in the recovered order)
+  drop_thin_transposes();
   RelabelCache& c = relabel_cache();   // (the order itself -- 8 bytes per column -- and its pattern fingerprint stay)
   c.Dr = DevMat();
   c.val = nullptr;

@@ -277,6 +277,7 @@ bool slab_from_csc(DevMat& Xs, DevBuf<int32_t>& lab);
 bool relabel_enter(DevMat& X, const DevMat& D);
 const DevMat* relabelled_operand(const DevMat& D);
 void relabel_giveup(const DevMat& D);
+void drop_thin_transposes();   // (spgemm_thin.hip: the transposes kept per thin left operand)
 void drop_operand_caches();   // frees what the fused / relabelled TRS2 paths keep between solves
 // band_scope.cpp: while a solve runs on operands redistributed in a recovered band order across ranks, the caller's label of every
 // position (device, one per row of the matrices; nullptr outside such a solve).  The fused TRS2 panel steps then decide the

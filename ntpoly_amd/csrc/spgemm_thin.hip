@@ -380,7 +380,23 @@ __global__ __launch_bounds__(THIN_NW* WAVE) void k_thin_slab_right(const ThinSla
   if (lane == 0) thin_finish(a, j, slot, lo, cnt, f, l);
 }
 
+// rows of a thin left operand as columns, kept per matrix (spgemm_thin_left); released with the other operand caches
+struct KeptTranspose {
+  const void* val = nullptr;
+  unsigned long long serial = 0, epoch = 0, used = 0;
+  int64_t nnz = -1;
+  std::shared_ptr<DevMat> at;
+};
+KeptTranspose* kept_transposes() {
+  static KeptTranspose kept[2];
+  return kept;
+}
 }  // namespace
+
+void drop_thin_transposes() {
+  KeptTranspose* const kept = kept_transposes();
+  for (int ki = 0; ki < 2; ++ki) kept[ki] = KeptTranspose();
+}
 
 void launch_thin_slab(const ThinSlabArgs& a, bool left) {
   const int nb4 = cdiv(a.ncols, THIN_NW);
@@ -414,21 +430,17 @@ bool spgemm_thin_left(const DevMat& A, const DevMat& B, DevMat& C, double alpha,
   if ((double)(up + dn) > 2.0 * (double)wmax + 64.0) return false;
   // rows of A as columns, ascending k inside each.  A solver loop multiplies by the same thin factor again and again (an
   // identity, a preconditioner): its transpose is kept per matrix (value buffer, allocation serial, value epoch), two slots
-  struct KeptTranspose {
-    const void* val = nullptr;
-    unsigned long long serial = 0, epoch = 0, used = 0;
-    int64_t nnz = -1;
-    std::shared_ptr<DevMat> at;
-  };
-  static KeptTranspose kept[2];
+  KeptTranspose* const kept = kept_transposes();
   static unsigned long long clock = 0;
   const unsigned long long ser = dev_alloc_serial(A.val.p), ep = matrix_value_epoch();
   std::shared_ptr<DevMat> pAT;
-  for (KeptTranspose& k : kept)
+  for (int ki = 0; ki < 2; ++ki) {
+    KeptTranspose& k = kept[ki];
     if (k.at && k.val == A.val.p && k.serial == ser && ser != 0 && k.epoch == ep && k.nnz == A.nnz && k.at->rows == A.cols && k.at->cols == A.rows) {
       pAT = k.at;
       k.used = ++clock;
     }
+  }
   if (!pAT) {
     pAT.reset(new DevMat(transpose(A)));
     KeptTranspose* slot = kept[0].used <= kept[1].used ? &kept[0] : &kept[1];

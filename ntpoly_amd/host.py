@@ -1063,6 +1063,11 @@ def malloc_stats():
     return n.value, ms.value
 
 
+def release_cache():
+    """frees what the engine keeps on the device between solves (operand caches, kept transposes) -- ntpoly_amd_release_cache"""
+    lib.ntpoly_amd_release_cache()
+
+
 def memory():
     a, c = C.c_longlong(), C.c_longlong()
     lib.ntpoly_amd_memory(C.byref(a), C.byref(c))

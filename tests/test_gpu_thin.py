@@ -127,3 +127,27 @@ def test_thin_left_declines_far_entries(nt):
     assert nt.last_spgemm_thin() == 0
     want = O.ps_multiply(O.Mat.from_triplets(n, n, *At), O.Mat.from_triplets(n, n, col, row, val), None, 1.0, 0.0, 1e-9).triplets()
     exact(C.triplets(), want, "permutation * B")
+
+
+def test_kept_transposes_are_released_with_the_operand_caches(nt):
+    """the transposes the thin-left path keeps per left operand (two slots) are device memory held between calls:
+    ntpoly_amd_release_cache() returns it with the other operand caches (the engine's in-use figure goes back)"""
+    n = 4096
+    At = thin_triplets(n, 2, 3, True, seed=5, drop_diag=0.0)
+    col, row, val = banded_triplets(n, 40, complex_=True)
+    nt.set_option("spgemm_fma", 0)
+    nt.release_cache()
+    A = nt.Matrix_ps.from_triplets(n, *At)
+    B = nt.Matrix_ps.from_triplets(n, col, row, val)
+    C = nt.Matrix_ps(n)
+    nt.synchronize()
+    before = nt.memory()[0]
+    C.Gemm(A, B, None, 1.0, 0.0, 1e-9)
+    assert nt.last_spgemm_thin() == 1
+    del C
+    nt.synchronize()
+    held = nt.memory()[0]
+    assert held > before, "the product left nothing behind: the kept transpose is gone, update this test"
+    nt.release_cache()
+    nt.synchronize()
+    assert nt.memory()[0] <= before, (before, held, nt.memory()[0])
