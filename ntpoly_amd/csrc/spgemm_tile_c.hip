@@ -72,7 +72,7 @@ struct TileCArgs {
 };
 
 __host__ __device__ inline size_t tile_c_lds_bytes(int k4max, int tmax) {
-  return (size_t)k4max * 16 * 8 + (size_t)(k4max + CRPAD) * sizeof(CRec) + (size_t)(k4max / 4 + 1) * 8 + (size_t)((tmax + 3) & ~3) * 4 + 3 * CJ * 4 + 64;
+  return (size_t)k4max * 16 * 8 + (size_t)(k4max + CRPAD) * sizeof(CRec) + (size_t)(k4max / 4 + 1) * 8 + (size_t)((tmax + 3) & ~3) * 4 + 3 * CJ * 4 + 16 + 64;
 }
 
 // R: tiles of 16 rows a wave multiplies together (they share the multiplier rows read from LDS and the run records: 2 R
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(R == 1
   int* col_cnt = reinterpret_cast<int*>(colmask + ((a.tmax + 3) & ~3));            // [CJ] each
   int* col_first = col_cnt + CJ;
   int* col_last = col_first + CJ;
+  int* tnext = col_last + CJ;                                                      // [1]: groups of tiles taken
 
   const int KG = (kn + 3) >> 2, K4 = KG * 4;
   const int T = (w + 15) >> 4;
@@ -127,6 +128,15 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(R == 1
     const int r = kmin + (i >> 3);
     return (i < kn * 8 && r >= bf0 && r <= bl0) ? bp0[r] : make_double2(0.0, 0.0);
   };
+  // (the run records requested BEFORE the tile's values: loads return in order, records requested behind the tile's could not
+  // be worked on before the last of those had arrived)
+  const uint4* __restrict__ rp = reinterpret_cast<const uint4*>(a.runs + kmin);
+  uint4 rh0, rh1;
+  {
+    const int ic = min(tid, kn - 1);
+    rh0 = rp[2 * ic];
+    rh1 = rp[2 * ic + 1];
+  }
 #pragma unroll
   for (int u = 0; u < BCH; ++u) {
     const int i = tid + u * NT;
@@ -134,11 +144,11 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(R == 1
     else btmp[u] = i < kn * 8 ? bsrc[i] : make_double2(0.0, 0.0);
   }
   {
-    const uint4* __restrict__ rp = reinterpret_cast<const uint4*>(a.runs + kmin);
     for (int i0 = 0; i0 < K4 + 4; i0 += NT) {
       const int i = i0 + tid;
       const int ic = min(i, kn - 1);
-      const uint4 r0 = rp[2 * ic], r1 = rp[2 * ic + 1];      // (addr_lo, addr_hi, nbytes, flags), (first16, first, span62, pad)
+      uint4 r0 = rh0, r1 = rh1;                              // (addr_lo, addr_hi, nbytes, flags), (first16, first, span62, pad)
+      if (i0 != 0) { r0 = rp[2 * ic]; r1 = rp[2 * ic + 1]; }
       const int rows = i < kn ? (int)(r0.z >> 4) : 0;
       const int first = (int)r1.y;
       CRec rec;
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(R == 1
     col_first[tid] = INT_MAX;
     col_last[tid] = -1;
   }
+  if (tid == 0) *tnext = 0;
   __syncthreads();
 
   // ---- per-lane constants: real column jj of the matrix instruction = part (jj & 1) of complex column jj >> 1
@@ -252,10 +263,15 @@ __global__ __launch_bounds__(NW* WAVE) __attribute__((amdgpu_waves_per_eu(R == 1
     if (lane == 0) colmask[t16] = cm;
   };
 
-  for (int ti = 0;; ++ti) {   // (snake order over the waves; centre first: the tiles in the middle of the window have the longest k ranges)
-    const int ts = ti * NW + ((ti & 1) ? NW - 1 - wave : wave);
-    if (ti * NW >= TS) break;
-    if (ts >= TS) continue;
+  // A wave takes its next group of tiles from a counter in LDS when it is through with its last (as k_spgemm_tile does: the
+  // tiles of a window cost between a few and all of the k groups, a fixed deal left the waves apart at the block's end); centre
+  // first: the tiles in the middle of the window have the longest k ranges.  (The loop is counted: written as for (;;) the
+  // kernel did not come back -- profiles/README.md round 6 -- and a wave takes at most TS groups anyway.)
+  for (int taken = 0; taken <= TS; ++taken) {
+    int ts = 0;
+    if (lane == 0) ts = atomicAdd(tnext, 1);
+    ts = __builtin_amdgcn_readfirstlane(ts);
+    if (ts >= TS) break;
     const int t = (ts & 1) ? mid + ((ts + 1) >> 1) : mid - (ts >> 1);
     const int r0 = lo + 16 * R * t;
     int g0 = INT_MAX, g1 = -1;   // the k groups that can reach the tiles: a ballot over the groups' row ranges
@@ -391,8 +407,7 @@ void launch_spgemm_tile_c(const TileLaunch& L) {
   }
   a.zero = zeros->p;
   const size_t lds = tile_c_lds_bytes(a.k4max, a.tmax);
-  // four waves when three or more workgroups fit a CU's LDS, eight when fewer do (as launch_spgemm_tile)
-  const bool wide = 3 * lds > 160 * 1024;
+  const bool wide = 4 * ((lds + 511) & ~(size_t)511) > 160 * 1024;   // (as launch_spgemm_tile: eight waves where fewer than FOUR workgroups of four fit; LDS is granted in units of 512 bytes)
   const int tw = options().tile_waves;
   const int nw = (tw == 4 || tw == 8) ? tw : (wide ? 8 : 4);
   // R = 2 (two tiles per wave step) where the windows hold enough tiles for every wave to get a pair (option tile_rows = 1: one)
