@@ -1,6 +1,7 @@
 // Distributed matrix (Matrix_ps) and distributed algebra on column panels.
 // Reference: PSMatrixModule.F90, PSMatrixAlgebraModule.F90, ProcessGridModule.F90,
 // LoadBalancerModule.F90, PermutationModule.F90.
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -1243,6 +1244,10 @@ void exchange_prepare(const DevMat& Xl, int32_t dim, const long long* d_nnz, Pan
 bool exchange_fits_fetch(int P) { return (size_t)4 * P + (size_t)P * P + 2 * P <= 400; }
 
 bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabReduce& red, bool* owed_prefetch) {
+  static const bool step_times = std::getenv("NTPOLY_AMD_DEBUG_STEPTIME") != nullptr;   // (host clock of a panel step's phases, rank 0)
+  const auto st0 = std::chrono::steady_clock::now();
+  auto st_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st0).count(); };
+  double st_prep = 0, st_xchg = 0;
   const long long syncs_before = host_sync_count();
   Comm& c = world();
   Transport& tr = *c.tr;
@@ -1280,6 +1285,7 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
       sync_stream();
     }
   }
+  st_prep = st_ms();
   const int pitch = pe->pitch;
   std::vector<int64_t>&req = pe->req, &cnt = pe->cnt;
   const int64_t *d_ext_all = pe->d_ext_all(), *d_pre_all = pe->d_pre_all(), *d_cnt_all = pe->d_cnt_all();
@@ -1314,6 +1320,7 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
     if (s != me && m > 0) tr.recv(recvbuf.p + zoff[(size_t)s], (size_t)m * sizeof(double), s);
   }
   tr.group_end();
+  st_xchg = st_ms();
   if (kmax < kmin) {   // (an empty panel: nothing to multiply; the caller's consensus takes the other path)
     if (ahead) *owed_prefetch = true;
     return false;
@@ -1354,6 +1361,10 @@ bool slab_exchange_and_step(PSMatrix& B, SlabFusion& fu, double threshold, SlabR
   }
   // (the buffers above are released on return: the allocator is stream ordered, and slab_step ends with a read-back)
   const bool ok = slab_step(B.loc, fu, threshold, dense_rule, &halo);
+  if (step_times && me == 0)
+    std::fprintf(stderr, "[panel step] preparation %.3f ms (%s), halo exchange %.3f ms (%lld doubles out, %lld in), step %.3f ms\n", st_prep,
+                 g_exchange_prefetched ? "left by the step before or made" : "made", st_xchg - st_prep, (long long)soff[(size_t)P],
+                 (long long)zoff[(size_t)P], st_ms() - st_xchg);
   if (ahead && !next) *owed_prefetch = true;   // (this rank gave up before its kernel: it owes the others the all-gather)
   if (ok && next) g_pending_exchange = std::move(next);
   return ok;

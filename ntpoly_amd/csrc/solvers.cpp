@@ -286,9 +286,14 @@ void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
   int II;
   for (II = 1; II <= p.max_iterations; ++II) {                     // :380-413
     energy_old = energy_value;
+    static const bool step_times = std::getenv("NTPOLY_AMD_DEBUG_STEPTIME") != nullptr;   // (host clock per iteration, rank 0)
+    const auto ts0 = Clock::now();
     energy_value = trs2_step(X, X2, WH, trace, p.threshold, &sigma_array[(size_t)II], &trace_x);
+    const double ts_step = ms_since(ts0);
     monitor_append(mon, energy_value - energy_old);
     trace_rec(energy_value - energy_old, energy_value, sigma_array[(size_t)II], X);
+    if (step_times && world().rank == 0)
+      std::fprintf(stderr, "[trs2] iteration %d: step %.3f ms, with the trace record %.3f ms\n", II, ts_step, ms_since(ts0));
     if (monitor_converged(mon, p.be_verbose)) break;
     if (p.be_verbose) {
       log_enter();
