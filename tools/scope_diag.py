@@ -61,6 +61,16 @@ if len(sys.argv) > 3 and sys.argv[3] == "gather":
     G = H0.GatherMatrixToProcess()
     del G
     solve("natural operand after one gather of the whole matrix through the transport")
+    if os.environ.get("SCOPE_DIAG_LONG_KERNEL"):
+        import torch
+        a = torch.randn(24576, 24576, device="cuda")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        b = a @ a
+        torch.cuda.synchronize()
+        if rank == 0:
+            print("one long kernel in each process (a dense product through torch): %.3f s" % (time.perf_counter() - t0), flush=True)
+        del a, b
+        solve("natural operand after one long-running kernel in each process")
     perm = nt.Permutation(n)
     perm.SetRandomPermutation()
     Hp = nt.Matrix_ps(n)
