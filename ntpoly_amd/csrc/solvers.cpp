@@ -289,7 +289,7 @@ void solver_trs2(const PSMatrix& H, const PSMatrix& ISQ, double trace, PSMatrix&
     static const bool step_times = std::getenv("NTPOLY_AMD_DEBUG_STEPTIME") != nullptr;   // (host clock per iteration, rank 0)
     const auto ts0 = Clock::now();
     energy_value = trs2_step(X, X2, WH, trace, p.threshold, &sigma_array[(size_t)II], &trace_x);
-    const double ts_step = ms_since(ts0);
+    const double ts_step = step_times ? ms_since(ts0) : 0.0;   // (ms_since waits for the stream: only when asked for)
     monitor_append(mon, energy_value - energy_old);
     trace_rec(energy_value - energy_old, energy_value, sigma_array[(size_t)II], X);
     if (step_times && world().rank == 0)
