@@ -203,16 +203,18 @@ int bfs_from(const DevMat& A, int start, int base, DevBuf<int32_t>& dist, DevBuf
   const unsigned long long init = ~0ull;
   best.upload(&init, 1);
   {
-    // the grid barrier needs all workgroups resident at once: a cooperative launch makes the runtime CHECK that (a
-    // CU-masked or partitioned device that cannot hold them refuses the launch instead of hanging in the barrier)
+    // The grid barrier needs all workgroups resident at once: eight workgroups of 1024 threads, which any partition of the
+    // device holds.  A PLAIN launch: hipLaunchCooperativeKernel would make the runtime check the residency, but one
+    // cooperative launch puts the process under exclusive, time-sliced scheduling for the rest of its life -- two ranks
+    // sharing a GPU then waited ~21 ms at every transport operation (a relabelled solve on two ranks 63.8 -> 2.5 ms per
+    // iteration, profiles/README.md 116)
     const int64_t* a_outer = A.outer.p;
     const int32_t* a_inner = A.inner.p;
     int32_t *p_dist = dist.p, *p_pos = pos.p, *p_cur = cur.p, *p_nxt = nxt.p, *p_key = key.p;
     unsigned* p_ctl = ctl.p;
     unsigned long long* p_best = best.p;
     long long* p_out = out.p;
-    void* args[] = {&a_outer, &a_inner, &start, &base, &p_dist, &p_pos, &p_cur, &p_nxt, &p_key, &p_ctl, &p_best, &p_out};
-    HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_bfs_multi), dim3(kBfsBlocks), dim3(1024), args, 0, stream()));
+    hipLaunchKernelGGL(k_bfs_multi, dim3(kBfsBlocks), dim3(1024), 0, stream(), a_outer, a_inner, start, base, p_dist, p_pos, p_cur, p_nxt, p_key, p_ctl, p_best, p_out);
   }
   long long h[3] = {0, 0, 0};
   ScalarFetch f;
